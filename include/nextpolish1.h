@@ -1,0 +1,191 @@
+/* include/nextpolish1.h -- C ABI of the MI355X-native short-read polishing core.
+ *
+ * Part 1 is the DROP-IN surface: the exact symbols, struct layouts and ownership rules
+ * the reference's ctypes caller binds in nextpolish1.so
+ *   (reference: source/lib/nextpolish1.py:27-100  -- ctypes structs and prototypes,
+ *               source/lib/config.h:25-70, source/lib/contig.h:10-25,
+ *               source/lib/scorechain.h, source/lib/kmercount.h).
+ * Part 2 is this library's own batch interface (np1_ prefix): decoded record streams
+ * resident in HBM, one launch sequence for many contigs, used by the CLI, bench.py and
+ * the multi-GPU driver.  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * All compute entry points run on the GPU and fail loudly (message on stderr, exit(1)
+ * for Part 1 like the reference; negative return + np1_last_error() for Part 2) when no
+ * HIP device is usable.  There is no CPU fallback in this library.
+ */
+#ifndef NEXTPOLISH1_H
+#define NEXTPOLISH1_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ Part 1: drop-in */
+
+/* reference: source/lib/config.h:25-67 (field order and natural alignment are ABI;
+ * the Python caller mutates the struct in place after config_init, nextpolish1.py:102-133) */
+typedef struct {
+    uint8_t trim_len_edge;
+    uint8_t ext_len_edge;
+    uint8_t min_map_quality;
+    double indel_balance_factor_sgs;
+    double min_count_ratio_skip;
+    uint8_t min_len_ldr;
+    uint8_t min_len_inter_kmer;
+    uint8_t max_len_kmer;
+    uint8_t max_count_kmer;
+    uint8_t min_depth_snp;
+    uint8_t min_count_snp;
+    int8_t min_count_snp_link;
+    double ploidy;
+    double indel_balance_factor_lgs;
+    double max_indel_factor_lgs;
+    double max_snp_factor_lgs;
+    double min_snp_factor_sgs;
+    int32_t region_count;
+    uint32_t count_read_ins_sgs;
+    uint32_t max_ins_len_sgs;
+    int32_t max_ins_fold_sgs;
+    int32_t max_variant_count_lgs;
+    double max_clip_ratio_sgs;
+    double max_clip_ratio_lgs;
+    int32_t trace_polish_open;
+    int32_t read_tlen;
+    int32_t read_len;
+    char* fastafn;
+    char* bamfn;
+    char* thirdbamfn;
+} Configure;
+
+/* reference: source/lib/contig.h:10-22 */
+typedef struct {
+    int32_t pos;
+    int16_t index;
+    char curbase;
+    char base;
+} PolishPoint;
+
+typedef struct {
+    char* contig;          /* calloc'd, NUL terminated; caller copies then calls polishresult_destory */
+    PolishPoint* data;     /* non-NULL only when trace_polish_open */
+    int32_t length;
+    int32_t datalength;
+} PolishResult;
+
+/* reference: source/lib/config.c:8-56 (defaults, insert-size probe of the first 10000 records,
+ * bamfn/thirdbamfn become NULL when the file is not accessible) */
+Configure* config_init(const char* fastafn, const char* bamfn, const char* thirdbamfn);
+/* reference: source/lib/config.c:58-68 (sic: "destory") */
+void config_destory(Configure* config);
+
+/* reference: source/lib/scorechain.c:3-15 -- polishes one contig with the score-chain pass */
+PolishResult* score_chain(const char* tigname, Configure* configure);
+/* reference: source/lib/kmercount.c:93-126 -- re-votes lowercase regions by spanning-read haplotypes */
+PolishResult* kmer_count(const char* tigname, Configure* configure);
+/* reference: source/lib/snpphase.c / snpvalid.c / lgspolish.c -- symbols the ctypes caller resolves at
+ * import time (nextpolish1.py:95-100).  Outside the accelerated hot path (task 5 is
+ * refused by the caller itself, nextpolish1.py:338-340): they report that and exit(1). */
+PolishResult* snp_phase(const char* tigname, Configure* configure);
+PolishResult* snp_valid(const char* tigname, Configure* configure);
+PolishResult* lgspolish(const char* tigname, Configure* configure);
+/* reference: source/lib/contig.c:25-30 */
+void polishresult_destory(PolishResult* polishresult);
+
+/* ------------------------------------------------------------------ Part 2: batch interface */
+
+const char* np1_last_error(void);
+
+/* Host-side decoded record stream = whole contigs + their BAM records (see DESIGN.md "data layout"). */
+typedef struct np1_stream np1_stream;
+
+typedef struct {
+    int64_t n_contigs, n_reads;
+    const int32_t* ctg_len;       /* [n_contigs] */
+    const uint32_t* ctg_off;      /* [n_contigs+1] offsets into draft */
+    const uint64_t* read_begin;   /* [n_contigs+1] */
+    const char* draft;            /* concatenated FASTA characters */
+    int64_t draft_len;
+    const int32_t* pos;
+    const uint32_t* ctg;
+    const uint16_t* flag;
+    const uint16_t* n_cigar;
+    const int32_t* l_qseq;
+    const uint64_t* cigar_off;
+    const uint64_t* seq_off;
+    const uint8_t* mapq;
+    const int32_t* isize;
+    const uint64_t* qual_off;
+    const uint32_t* cigar;
+    int64_t cigar_len;
+    const uint8_t* seq;
+    int64_t seq_len;
+    const uint8_t* qual;
+    int64_t qual_len;             /* 0 when qualities were not loaded */
+} np1_stream_view;
+
+/* names == NULL / n_names == 0: every contig of the FASTA index, in index order. */
+np1_stream* np1_stream_load(const char* fasta, const char* bam, const char* const* names, int n_names, int with_qual);
+void np1_stream_get_view(const np1_stream* s, np1_stream_view* out);
+const char* np1_stream_contig_name(const np1_stream* s, int64_t i);
+uint64_t np1_stream_algorithmic_bytes(const np1_stream* s, int with_qual);
+int np1_stream_write_files(const np1_stream* s, const char* fasta, const char* bam, int bgzf_level);
+void np1_stream_free(np1_stream* s);
+
+/* Synthetic workload.  Field meanings: nextpolish_amd/csrc/np_synth.h */
+typedef struct {
+    uint64_t seed;
+    int32_t n_contigs;
+    const int32_t* contig_len;
+    double depth;
+    int32_t read_len;
+    double frag_mean, frag_sd;
+    double draft_sub, draft_indel;
+    double draft_lower;
+    double read_sub, read_indel;
+    double softclip_rate;
+    double dup_rate, supp_rate, sec_rate, unmapped_rate;
+    double lowmapq_rate;
+    double weird_rate;
+    int32_t with_qual;
+} np1_synth_params;
+void np1_synth_defaults(np1_synth_params* p);
+np1_stream* np1_stream_synth(const np1_synth_params* p, const char* contig_name_prefix);
+
+/* Device context: one per process per GPU; created lazily AFTER any fork (the reference's callers
+ * fork worker pools after config_init, nextpolish1.py:219-223). */
+typedef struct np1_ctx np1_ctx;
+int np1_device_count(void);
+np1_ctx* np1_ctx_create(int device);
+void np1_ctx_destroy(np1_ctx* ctx);
+
+/* A batch resident in HBM. */
+typedef struct np1_batch np1_batch;
+np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* s);
+void np1_batch_free(np1_batch* b);
+
+/* Names of the timed stages of one score_chain pass, in launch order (for profiles / roofline). */
+#define NP1_MAX_STAGES 16
+int np1_stage_count(void);
+const char* np1_stage_name(int i);
+
+/* Runs score_chain over every contig of the batch on the context's stream; outputs stay on the device.
+ * stage_ms: NULL, or float[NP1_MAX_STAGES] receiving per-stage HIP-event milliseconds (forces a sync).
+ * Returns 0 on success. */
+int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms);
+/* Blocks until the batch's work is complete. */
+int np1_batch_sync(np1_batch* b);
+/* Polished length of contig i (valid after a completed run), and copy-out of its NUL-terminated string. */
+int64_t np1_batch_result_len(np1_batch* b, int64_t contig);
+int np1_batch_result_copy(np1_batch* b, int64_t contig, char* dst, int64_t cap);
+/* total slot votes ("updates") of the last run and HBM bytes held by the batch */
+int64_t np1_batch_update_count(np1_batch* b);
+int64_t np1_batch_device_bytes(np1_batch* b);
+
+/* calgs (reference: source/lib/calgs.c:8-24): sum of sequence lengths of a FASTA/FASTQ (gz aware) */
+uint64_t calgs(const char* file);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

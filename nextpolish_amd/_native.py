@@ -1,0 +1,233 @@
+"""ctypes binding of the in-tree shared library (include/nextpolish1.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C nextpolish_amd/csrc``
+as ``nextpolish_amd/lib/nextpolish1.so`` -- the same file name the reference's caller loads
+(reference: source/lib/nextpolish1.py:84).  Importing this module never touches a GPU; device
+work starts at ``np1_ctx_create``.  A missing library is a hard error (no fallback path).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.realpath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "nextpolish1.so")
+
+
+class Configure(C.Structure):
+    """reference: source/lib/config.h:25-67, source/lib/nextpolish1.py:27-65"""
+    _fields_ = [
+        ("trim_len_edge", C.c_uint8), ("ext_len_edge", C.c_uint8), ("min_map_quality", C.c_uint8),
+        ("indel_balance_factor_sgs", C.c_double), ("min_count_ratio_skip", C.c_double),
+        ("min_len_ldr", C.c_uint8), ("min_len_inter_kmer", C.c_uint8), ("max_len_kmer", C.c_uint8),
+        ("max_count_kmer", C.c_uint8),
+        ("min_depth_snp", C.c_uint8), ("min_count_snp", C.c_uint8), ("min_count_snp_link", C.c_int8),
+        ("ploidy", C.c_double), ("indel_balance_factor_lgs", C.c_double), ("max_indel_factor_lgs", C.c_double),
+        ("max_snp_factor_lgs", C.c_double), ("min_snp_factor_sgs", C.c_double),
+        ("region_count", C.c_int32), ("count_read_ins_sgs", C.c_uint32), ("max_ins_len_sgs", C.c_uint32),
+        ("max_ins_fold_sgs", C.c_int32), ("max_variant_count_lgs", C.c_int32),
+        ("max_clip_ratio_sgs", C.c_double), ("max_clip_ratio_lgs", C.c_double),
+        ("trace_polish_open", C.c_int32), ("read_tlen", C.c_int32), ("read_len", C.c_int32),
+        ("fastafn", C.c_char_p), ("bamfn", C.c_char_p), ("thirdbamfn", C.c_char_p),
+    ]
+
+
+class PolishPoint(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("index", C.c_int16), ("curbase", C.c_char), ("base", C.c_char)]
+
+
+class PolishResult(C.Structure):
+    _fields_ = [("contig", C.c_void_p), ("data", C.POINTER(PolishPoint)), ("length", C.c_int32),
+                ("datalength", C.c_int32)]
+
+
+class StreamView(C.Structure):
+    _fields_ = [
+        ("n_contigs", C.c_int64), ("n_reads", C.c_int64),
+        ("ctg_len", C.c_void_p), ("ctg_off", C.c_void_p), ("read_begin", C.c_void_p),
+        ("draft", C.c_void_p), ("draft_len", C.c_int64),
+        ("pos", C.c_void_p), ("ctg", C.c_void_p), ("flag", C.c_void_p), ("n_cigar", C.c_void_p),
+        ("l_qseq", C.c_void_p), ("cigar_off", C.c_void_p), ("seq_off", C.c_void_p),
+        ("mapq", C.c_void_p), ("isize", C.c_void_p), ("qual_off", C.c_void_p),
+        ("cigar", C.c_void_p), ("cigar_len", C.c_int64),
+        ("seq", C.c_void_p), ("seq_len", C.c_int64),
+        ("qual", C.c_void_p), ("qual_len", C.c_int64),
+    ]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64), ("n_contigs", C.c_int32), ("contig_len", C.POINTER(C.c_int32)),
+        ("depth", C.c_double), ("read_len", C.c_int32), ("frag_mean", C.c_double), ("frag_sd", C.c_double),
+        ("draft_sub", C.c_double), ("draft_indel", C.c_double), ("draft_lower", C.c_double),
+        ("read_sub", C.c_double), ("read_indel", C.c_double), ("softclip_rate", C.c_double),
+        ("dup_rate", C.c_double), ("supp_rate", C.c_double), ("sec_rate", C.c_double),
+        ("unmapped_rate", C.c_double), ("lowmapq_rate", C.c_double), ("weird_rate", C.c_double),
+        ("with_qual", C.c_int32),
+    ]
+
+
+NP1_MAX_STAGES = 16
+_lib = None
+
+
+def lib():
+    """Loads nextpolish1.so once; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no non-HIP fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.config_init.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.config_init.restype = C.POINTER(Configure)
+    L.config_destory.argtypes = [C.POINTER(Configure)]
+    L.config_destory.restype = None
+    for fn in ("score_chain", "kmer_count", "snp_phase", "snp_valid", "lgspolish"):
+        getattr(L, fn).argtypes = [C.c_char_p, C.POINTER(Configure)]
+        getattr(L, fn).restype = C.POINTER(PolishResult)
+    L.polishresult_destory.argtypes = [C.POINTER(PolishResult)]
+    L.polishresult_destory.restype = None
+    L.np1_last_error.restype = C.c_char_p
+    L.np1_stream_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int]
+    L.np1_stream_load.restype = C.c_void_p
+    L.np1_stream_get_view.argtypes = [C.c_void_p, C.POINTER(StreamView)]
+    L.np1_stream_get_view.restype = None
+    L.np1_stream_contig_name.argtypes = [C.c_void_p, C.c_int64]
+    L.np1_stream_contig_name.restype = C.c_char_p
+    L.np1_stream_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int]
+    L.np1_stream_algorithmic_bytes.restype = C.c_uint64
+    L.np1_stream_write_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+    L.np1_stream_write_files.restype = C.c_int
+    L.np1_stream_free.argtypes = [C.c_void_p]
+    L.np1_stream_free.restype = None
+    L.np1_synth_defaults.argtypes = [C.POINTER(SynthParams)]
+    L.np1_synth_defaults.restype = None
+    L.np1_stream_synth.argtypes = [C.POINTER(SynthParams), C.c_char_p]
+    L.np1_stream_synth.restype = C.c_void_p
+    L.np1_device_count.restype = C.c_int
+    L.np1_ctx_create.argtypes = [C.c_int]
+    L.np1_ctx_create.restype = C.c_void_p
+    L.np1_ctx_destroy.argtypes = [C.c_void_p]
+    L.np1_ctx_destroy.restype = None
+    L.np1_batch_upload.argtypes = [C.c_void_p, C.c_void_p]
+    L.np1_batch_upload.restype = C.c_void_p
+    L.np1_batch_free.argtypes = [C.c_void_p]
+    L.np1_batch_free.restype = None
+    L.np1_stage_count.restype = C.c_int
+    L.np1_stage_name.argtypes = [C.c_int]
+    L.np1_stage_name.restype = C.c_char_p
+    L.np1_batch_score_chain.argtypes = [C.c_void_p, C.POINTER(Configure), C.POINTER(C.c_float)]
+    L.np1_batch_score_chain.restype = C.c_int
+    L.np1_batch_sync.argtypes = [C.c_void_p]
+    L.np1_batch_sync.restype = C.c_int
+    L.np1_batch_result_len.argtypes = [C.c_void_p, C.c_int64]
+    L.np1_batch_result_len.restype = C.c_int64
+    L.np1_batch_result_copy.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]
+    L.np1_batch_result_copy.restype = C.c_int
+    L.np1_batch_update_count.argtypes = [C.c_void_p]
+    L.np1_batch_update_count.restype = C.c_int64
+    L.np1_batch_device_bytes.argtypes = [C.c_void_p]
+    L.np1_batch_device_bytes.restype = C.c_int64
+    L.calgs.argtypes = [C.c_char_p]
+    L.calgs.restype = C.c_uint64
+    _lib = L
+    return L
+
+
+def last_error():
+    return (lib().np1_last_error() or b"").decode()
+
+
+def default_config():
+    """A Configure carrying config_init's defaults (reference: source/lib/config.c:11-38), no files."""
+    cfg = Configure()
+    cfg.trim_len_edge, cfg.ext_len_edge, cfg.min_map_quality = 2, 2, 0
+    cfg.indel_balance_factor_sgs, cfg.min_count_ratio_skip = 0.5, 0.8
+    cfg.min_len_ldr, cfg.min_len_inter_kmer, cfg.max_len_kmer, cfg.max_count_kmer = 3, 5, 50, 50
+    cfg.min_depth_snp, cfg.min_count_snp, cfg.min_count_snp_link = 3, 5, 5
+    cfg.ploidy, cfg.indel_balance_factor_lgs, cfg.max_indel_factor_lgs = 2, 0.33, 0.21
+    cfg.max_snp_factor_lgs, cfg.min_snp_factor_sgs = 0.53, 0.34
+    cfg.region_count, cfg.count_read_ins_sgs, cfg.max_ins_len_sgs = 10000, 10000, 10000
+    cfg.max_ins_fold_sgs, cfg.max_variant_count_lgs = 5, 150000
+    cfg.max_clip_ratio_sgs, cfg.max_clip_ratio_lgs = 0.15, 0.4
+    return cfg
+
+
+def _arr(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=int(n))
+
+
+class Stream(object):
+    """Owning wrapper of a host decoded record stream (np1_stream)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("stream creation failed: " + last_error())
+        self.handle = handle
+        v = StreamView()
+        lib().np1_stream_get_view(handle, C.byref(v))
+        self.view = v
+        nc, nr = v.n_contigs, v.n_reads
+        self.n_contigs, self.n_reads = int(nc), int(nr)
+        self.ctg_len = _arr(v.ctg_len, nc, np.int32)
+        self.ctg_off = _arr(v.ctg_off, nc + 1, np.uint32)
+        self.read_begin = _arr(v.read_begin, nc + 1, np.uint64)
+        self.draft = _arr(v.draft, v.draft_len, np.uint8)
+        self.pos = _arr(v.pos, nr, np.int32)
+        self.ctg = _arr(v.ctg, nr, np.uint32)
+        self.flag = _arr(v.flag, nr, np.uint16)
+        self.n_cigar = _arr(v.n_cigar, nr, np.uint16)
+        self.l_qseq = _arr(v.l_qseq, nr, np.int32)
+        self.cigar_off = _arr(v.cigar_off, nr, np.uint64)
+        self.seq_off = _arr(v.seq_off, nr, np.uint64)
+        self.mapq = _arr(v.mapq, nr, np.uint8)
+        self.isize = _arr(v.isize, nr, np.int32)
+        self.qual_off = _arr(v.qual_off, nr, np.uint64)
+        self.cigar = _arr(v.cigar, v.cigar_len, np.uint32)
+        self.seq = _arr(v.seq, v.seq_len, np.uint8)
+        self.qual = _arr(v.qual, v.qual_len, np.uint8)
+        self.names = [lib().np1_stream_contig_name(handle, i).decode() for i in range(self.n_contigs)]
+
+    @classmethod
+    def load(cls, fasta, bam, names=None, with_qual=False):
+        names = list(names or [])
+        arr = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        return cls(lib().np1_stream_load(fasta.encode(), bam.encode(), arr, len(names), 1 if with_qual else 0))
+
+    @classmethod
+    def synth(cls, contig_len, depth=30.0, seed=20250117, prefix="ctg", **kw):
+        p = SynthParams()
+        lib().np1_synth_defaults(C.byref(p))
+        lens = (C.c_int32 * len(contig_len))(*contig_len)
+        p.seed, p.n_contigs, p.contig_len, p.depth = seed, len(contig_len), lens, depth
+        for k, val in kw.items():
+            if not hasattr(p, k):
+                raise TypeError("unknown synth parameter " + k)
+            setattr(p, k, val)
+        return cls(lib().np1_stream_synth(C.byref(p), prefix.encode()))
+
+    def algorithmic_bytes(self, with_qual=False):
+        return int(lib().np1_stream_algorithmic_bytes(self.handle, 1 if with_qual else 0))
+
+    def write_files(self, fasta, bam, level=1):
+        if lib().np1_stream_write_files(self.handle, fasta.encode(), bam.encode(), level) != 0:
+            raise RuntimeError("write_files: " + last_error())
+
+    def contig_draft(self, i):
+        return self.draft[int(self.ctg_off[i]):int(self.ctg_off[i + 1])].tobytes()
+
+    def close(self):
+        if self.handle:
+            lib().np1_stream_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,86 @@
+// CLI of the short-read core: same surface as the reference binary
+// (reference: source/lib/main.c:12-75, contig_total source/lib/contig.c:1056-1110):
+//   nextpolish1 <scorechain|kmercount|snpphase|snpvalid|lgspolish> fasta bam [bam3]
+// prints ">name_<step>\nseq" per contig in FASTA-index order.  Unlike the reference, which loops
+// score_chain contig by contig, all contigs travel to the GPU as ONE batch (the records are read in a
+// single sequential pass over the BAM).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "../../include/nextpolish1.h"
+
+static const char* kCmds[] = {"scorechain", "kmercount", "snpphase", "snpvalid", "lgspolish"};
+
+static void stamp(FILE* f) {
+    time_t t = time(nullptr);
+    struct tm* lt = localtime(&t);
+    fprintf(f, "[ %02d-%02d-%02d %02d:%02d:%02d ] ", lt->tm_year + 1900, lt->tm_mon + 1, lt->tm_mday, lt->tm_hour,
+            lt->tm_min, lt->tm_sec);
+}
+
+int main(int argc, char* argv[]) {
+    int step = 0;
+    if (argc > 1)
+        for (int i = 0; i < 5; ++i)
+            if (strcmp(kCmds[i], argv[1]) == 0) step = i + 1;
+    if (step == 0) {
+        printf("Usage: %s <command> [options]\n\nCommands:\n"
+               "\tscorechain\t\tscore chain run\n\t\t\t\teg. scorechain fastafn sgsbamf > output.fa\n"
+               "\tkmercount\t\tkmer count run\n\t\t\t\teg. kmercount fastafn sgsbamf > output.fa\n"
+               "\tsnpphase\t\tsnp phase run\n\t\t\t\teg. snpphase fastafn sgsbamf lgsbamf > output.fa\n"
+               "\tsnpvalid\t\tsnp valid run\n\t\t\t\teg. snpvalid fastafn sgsbamf > output.fa\n"
+               "\tlgspolish \t\tlgs polish run\n\t\t\t\teg. lgspolish fasta_file lgsbamf > output.fa\n\n",
+               argv[0]);
+        return 0;
+    }
+    if ((step == 3 && argc != 5) || (step != 3 && argc != 4)) {
+        if (step == 3) printf("%s %s fastafn bamfn thirdbamfn\n", argv[0], argv[1]);
+        else printf("%s %s fastafn lgsbam\n", argv[0], argv[1]);
+        return 0;
+    }
+    time_t t_start = time(nullptr);
+    Configure* cfg = (step == 5) ? config_init(argv[2], nullptr, argv[3]) : config_init(argv[2], argv[3], argc > 4 ? argv[4] : nullptr);
+    if (step == 1) {
+        if (!cfg->bamfn) { fprintf(stderr, "cannot access BAM %s\n", argv[3]); return 1; }
+        np1_stream* st = np1_stream_load(cfg->fastafn, cfg->bamfn, nullptr, 0, 0);
+        if (!st) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+        int dev = 0;
+        if (const char* e = getenv("NP1_DEVICE")) dev = atoi(e);
+        np1_ctx* ctx = np1_ctx_create(dev);
+        if (!ctx) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+        np1_batch* b = np1_batch_upload(ctx, st);
+        if (!b || np1_batch_score_chain(b, cfg, nullptr) != 0) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+        np1_stream_view v;
+        np1_stream_get_view(st, &v);
+        std::vector<char> buf;
+        for (int64_t c = 0; c < v.n_contigs; ++c) {
+            int64_t len = np1_batch_result_len(b, c);
+            buf.resize((size_t)len + 1);
+            if (np1_batch_result_copy(b, c, buf.data(), len + 1) != 0) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+            printf(">%s_%d\n%s\n", np1_stream_contig_name(st, c), step, buf.data());
+        }
+        np1_batch_free(b);
+        np1_ctx_destroy(ctx);
+        np1_stream_free(st);
+    } else {
+        PolishResult* (*fn)(const char*, Configure*) = step == 2 ? kmer_count : step == 3 ? snp_phase : step == 4 ? snp_valid : lgspolish;
+        np1_stream* st = np1_stream_load(cfg->fastafn, cfg->bamfn ? cfg->bamfn : argv[3], nullptr, 0, 0);
+        if (!st) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+        np1_stream_view v;
+        np1_stream_get_view(st, &v);
+        for (int64_t c = 0; c < v.n_contigs; ++c) {
+            PolishResult* r = fn(np1_stream_contig_name(st, c), cfg);
+            printf(">%s_%d\n%s\n", np1_stream_contig_name(st, c), step, r->contig);
+            polishresult_destory(r);
+        }
+        np1_stream_free(st);
+    }
+    config_destory(cfg);
+    stamp(stderr);
+    fprintf(stderr, "total time:%ds\n", (int)(time(nullptr) - t_start));
+    return 0;
+}

@@ -1,0 +1,389 @@
+// Device context, HBM-resident batches and the score_chain launch sequence
+// (include/nextpolish1.h, Part 2: np1_ctx_*, np1_batch_*).  Kernels: np1_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nextpolish1.h"
+#include "np1_kernels.h"
+#include "np_stream.h"
+
+void np1_set_error(const std::string& e);   // np_host_abi.cpp
+struct np1_stream { np::ReadStream s; };
+
+using namespace np1k;
+
+namespace {
+
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    np1_set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+#define HIPCHK(x) do { if (!hip_ok((x), #x)) return -1; } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes, double slack = 1.0) {
+        if (bytes <= cap && p) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = (size_t)((double)bytes * slack) + 256;
+        if (!hip_ok(hipMalloc(&p, want), "hipMalloc")) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+const char* kStageNames[] = {"prep", "scan_slots", "slotinfo", "rowcap_scan", "rows", "vote", "dp", "emit"};
+constexpr int kStages = 8;
+
+}  // namespace
+
+struct np1_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0[kStages], ev1[kStages];
+};
+
+struct np1_batch {
+    np1_ctx* ctx = nullptr;
+    uint32_t nc = 0;
+    uint64_t G = 0;
+    int64_t n_reads = 0;
+    // inputs
+    DevBuf draft, ctg_off, pos, ctg, flag, ncig, lq, cigoff, seqoff, cigar, seq;
+    // work
+    DevBuf qs, qe, span, ins, soff, slot_info, rbase, capb, rowoff, rows, meta, chunk_first, chunk_last, slot_res,
+        slot_rec, pool, heads, redo, redo2, counters, opos, out, bounds, scan_tmp, totals;
+    size_t input_bytes = 0;
+    // results of the last run
+    uint32_t S = 0;
+    uint64_t votes = 0;
+    bool ran = false, out_cached = false;
+    std::vector<uint32_t> h_bounds;
+    std::vector<uint8_t> h_out;
+    std::vector<uint32_t> h_ctg_off;
+
+    size_t device_bytes() const {
+        const DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
+                               &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
+                               &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out,
+                               &bounds, &scan_tmp, &totals};
+        size_t t = 0;
+        for (const DevBuf* b : all) t += b->cap;
+        return t;
+    }
+    void release_all() {
+        DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
+                         &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
+                         &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out,
+                         &bounds, &scan_tmp, &totals};
+        for (DevBuf* b : all) b->release();
+    }
+};
+
+extern "C" {
+
+int np1_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+np1_ctx* np1_ctx_create(int device) {
+    int n = np1_device_count();
+    if (n <= 0) { np1_set_error("no HIP device available (this library has no CPU path)"); return nullptr; }
+    if (device < 0 || device >= n) { np1_set_error("invalid HIP device index"); return nullptr; }
+    if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
+    np1_ctx* c = new np1_ctx();
+    c->device = device;
+    if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
+    for (int i = 0; i < kStages; ++i) {
+        (void)hipEventCreate(&c->ev0[i]);
+        (void)hipEventCreate(&c->ev1[i]);
+    }
+    return c;
+}
+
+void np1_ctx_destroy(np1_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (int i = 0; i < kStages; ++i) { (void)hipEventDestroy(c->ev0[i]); (void)hipEventDestroy(c->ev1[i]); }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int np1_stage_count(void) { return kStages; }
+const char* np1_stage_name(int i) { return (i >= 0 && i < kStages) ? kStageNames[i] : ""; }
+
+static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t st) {
+    if (b.ensure(bytes ? bytes : 4) != 0) return -1;
+    if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* st) {
+    if (!ctx || !st) { np1_set_error("np1_batch_upload: null argument"); return nullptr; }
+    const np::ReadStream& s = st->s;
+    if (s.draft.size() >= 0xfff00000ull) { np1_set_error("batch too large: draft must stay below 2^32 slots"); return nullptr; }
+    (void)hipSetDevice(ctx->device);
+    np1_batch* b = new np1_batch();
+    b->ctx = ctx;
+    b->nc = (uint32_t)s.n_contigs();
+    b->G = s.draft.size();
+    b->n_reads = (int64_t)s.n_reads();
+    b->h_ctg_off = s.ctg_off;
+    hipStream_t q = ctx->stream;
+    size_t n = s.n_reads();
+    int rc = 0;
+    rc |= upload(b->draft, s.draft.data(), s.draft.size(), q);
+    rc |= upload(b->ctg_off, s.ctg_off.data(), 4 * s.ctg_off.size(), q);
+    rc |= upload(b->pos, s.pos.data(), 4 * n, q);
+    rc |= upload(b->ctg, s.ctg.data(), 4 * n, q);
+    rc |= upload(b->flag, s.flag.data(), 2 * n, q);
+    rc |= upload(b->ncig, s.n_cigar.data(), 2 * n, q);
+    rc |= upload(b->lq, s.l_qseq.data(), 4 * n, q);
+    rc |= upload(b->cigoff, s.cigar_off.data(), 8 * n, q);
+    rc |= upload(b->seqoff, s.seq_off.data(), 8 * n, q);
+    rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);
+    // +8 bytes of slack: the trim loops never read past l_qseq, but keep loads inside the allocation anyway
+    rc |= upload(b->seq, s.seq.data(), s.seq.size(), q);
+    if (rc == 0 && hipStreamSynchronize(q) != hipSuccess) { np1_set_error("upload failed"); rc = -1; }
+    if (rc != 0) { b->release_all(); delete b; return nullptr; }
+    b->input_bytes = s.draft.size() + 32 * n + 4 * s.cigar.size() + s.seq.size();
+    return b;
+}
+
+void np1_batch_free(np1_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    b->release_all();
+    delete b;
+}
+
+// rate = R / 2^K exactly?  (scores are then exact integers, see k_dp)
+static bool rate_fixed_point(double rate, int* K, long long* R) {
+    if (!std::isfinite(rate)) return false;
+    for (int k = 0; k <= 10; ++k) {
+        double x = std::ldexp(rate, k);
+        if (x == std::floor(x) && std::fabs(x) < 1e12) { *K = k; *R = (long long)x; return true; }
+    }
+    return false;
+}
+
+int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
+    if (!b || !cfg) { np1_set_error("np1_batch_score_chain: null argument"); return -1; }
+    np1_ctx* ctx = b->ctx;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t q = ctx->stream;
+    b->ran = false;
+    b->out_cached = false;
+    int K = 0;
+    long long Rfix = 0;
+    if (!rate_fixed_point(cfg->indel_balance_factor_sgs, &K, &Rfix)) {
+        np1_set_error("indel_balance_factor_sgs must be a multiple of 2^-10 on the GPU path (default 0.5)");
+        return -1;
+    }
+    const uint32_t flag_single = (1.0 < cfg->min_count_ratio_skip) ? 2u : 0u;
+    const uint64_t G = b->G;
+    const int64_t n = b->n_reads;
+    const uint32_t nc = b->nc;
+    if (nc == 0) { b->h_bounds.assign(1, 0); b->S = 0; b->ran = true; return 0; }
+
+    ReadsDev R{b->pos.as<int32_t>(), b->ctg.as<uint32_t>(), b->flag.as<uint16_t>(), b->ncig.as<uint16_t>(),
+               b->lq.as<int32_t>(), b->cigoff.as<uint64_t>(), b->seqoff.as<uint64_t>(), b->cigar.as<uint32_t>(),
+               b->seq.as<uint8_t>()};
+    const uint32_t* ctg_off = b->ctg_off.as<uint32_t>();
+    bool timing = stage_ms != nullptr;
+    auto t0 = [&](int i) { if (timing) (void)hipEventRecord(ctx->ev0[i], q); };
+    auto t1 = [&](int i) { if (timing) (void)hipEventRecord(ctx->ev1[i], q); };
+
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    if (b->qs.ensure(4 * nn) || b->qe.ensure(4 * nn) || b->span.ensure(4 * nn) || b->rbase.ensure(4 * nn) ||
+        b->capb.ensure(4 * nn) || b->rowoff.ensure(8 * (nn + 1)) || b->meta.ensure(16 * nn) ||
+        b->ins.ensure(4 * (G + 1)) || b->soff.ensure(4 * (G + 2)) || b->counters.ensure(4 * CNT_WORDS) ||
+        b->totals.ensure(8 * 8) || b->bounds.ensure(4 * ((size_t)nc + 1)) ||
+        b->scan_tmp.ensure(8 * (scan_tmp_words(G + G / 8 + 1024) + scan_tmp_words(nn))))
+        return -1;
+    uint64_t* totals = b->totals.as<uint64_t>();   // [0] slots, [1] row bytes, [2] out chars, [3] votes
+    uint32_t* counters = b->counters.as<uint32_t>();
+    uint64_t* scan_tmp = b->scan_tmp.as<uint64_t>();
+
+    // ---- stage 0: prep
+    HIPCHK(hipMemsetAsync(b->ins.p, 0, 4 * (G + 1), q));
+    HIPCHK(hipMemsetAsync(b->counters.p, 0, 4 * CNT_WORDS, q));
+    HIPCHK(hipMemsetAsync(b->totals.p, 0, 64, q));
+    t0(0);
+    launch_prep(q, R, n, ctg_off, cfg->trim_len_edge, b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->span.as<int32_t>(),
+                b->ins.as<uint32_t>(), counters);
+    t1(0);
+    // ---- stage 1: slot offsets
+    t0(1);
+    launch_scan_slots(q, b->ins.as<uint32_t>(), G, b->soff.as<uint32_t>(), scan_tmp, &totals[0]);
+    t1(1);
+    uint64_t S64 = 0;
+    HIPCHK(hipMemcpyAsync(&S64, &totals[0], 8, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipStreamSynchronize(q));
+    if (S64 >= 0xfffffff0ull) { np1_set_error("batch too large: more than 2^32 slots"); return -1; }
+    const uint32_t S = (uint32_t)S64;
+    b->S = S;
+    const uint32_t n_chunks = (S + VOTE_CH - 1) / VOTE_CH + 1;
+    if (b->slot_info.ensure(S + 64) || b->slot_res.ensure(2 * ((size_t)S + 64)) || b->slot_rec.ensure(4 * ((size_t)S + 64)) ||
+        b->opos.ensure(4 * ((size_t)S + 2)) || b->out.ensure((size_t)S + 64) || b->chunk_first.ensure(4 * (size_t)n_chunks) ||
+        b->chunk_last.ensure(4 * (size_t)n_chunks) || b->heads.ensure(4 * ((size_t)S / 2 + 64)) ||
+        b->redo.ensure(4 * (size_t)n_chunks) || b->redo2.ensure(4 * (size_t)n_chunks))
+        return -1;
+    if (scan_tmp_words((uint64_t)S + 1) * 8 > b->scan_tmp.cap && b->scan_tmp.ensure(8 * (scan_tmp_words((uint64_t)S + 1) + scan_tmp_words(nn)))) return -1;
+    scan_tmp = b->scan_tmp.as<uint64_t>();
+    if (b->pool.cap == 0 && b->pool.ensure(4 * (3 * (size_t)S + (1u << 20)))) return -1;
+    // ---- stage 2: per-slot draft symbols
+    t0(2);
+    launch_slotinfo(q, b->draft.as<uint8_t>(), (uint32_t)G, ctg_off, nc, b->soff.as<uint32_t>(), b->slot_info.as<uint8_t>());
+    t1(2);
+    // ---- stage 3: row placement
+    t0(3);
+    launch_rowcap(q, R, n, ctg_off, b->soff.as<uint32_t>(), b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->span.as<int32_t>(),
+                  b->rbase.as<uint32_t>(), b->capb.as<uint32_t>());
+    launch_scan_rows(q, b->capb.as<uint32_t>(), (uint64_t)(n > 0 ? n : 0), b->rowoff.as<uint64_t>(), scan_tmp, &totals[1]);
+    t1(3);
+    uint64_t row_bytes = 0;
+    HIPCHK(hipMemcpyAsync(&row_bytes, &totals[1], 8, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipStreamSynchronize(q));
+    if ((row_bytes >> 2) >= 0xffffffffull) { np1_set_error("batch too large: symbol rows exceed 16 GiB"); return -1; }
+    if (b->rows.ensure(row_bytes + 64, 1.02)) return -1;
+    // ---- stage 4: rows
+    HIPCHK(hipMemsetAsync(b->chunk_first.p, 0xff, 4 * (size_t)n_chunks, q));
+    HIPCHK(hipMemsetAsync(b->chunk_last.p, 0, 4 * (size_t)n_chunks, q));
+    t0(4);
+    launch_rows(q, R, n, ctg_off, b->soff.as<uint32_t>(), b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->rbase.as<uint32_t>(),
+                b->rowoff.as<uint64_t>(), b->rows.as<uint8_t>(), b->meta.as<uint4>(), b->chunk_first.as<uint32_t>(),
+                b->chunk_last.as<uint32_t>(), reinterpret_cast<unsigned long long*>(&totals[3]));
+    t1(4);
+    // ---- stage 5: vote (+ escalation for crowded slots, + pool growth)
+    uint32_t hc[CNT_WORDS];
+    for (int attempt = 0;; ++attempt) {
+        uint32_t pool_cap = (uint32_t)std::min<size_t>(b->pool.cap / 4, 0xfffffff0u);
+        t0(5);
+        launch_vote(q, 16, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
+                    b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, nullptr, 0,
+                    b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
+                    b->heads.as<uint32_t>(), b->redo.as<uint32_t>(), CNT_REDO, flag_single);
+        t1(5);
+        HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+        HIPCHK(hipStreamSynchronize(q));
+        if (hc[CNT_REDO]) {
+            launch_vote(q, 64, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
+                        b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->redo.as<uint32_t>(),
+                        hc[CNT_REDO], b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(),
+                        pool_cap, counters, b->heads.as<uint32_t>(), b->redo2.as<uint32_t>(), CNT_REDO2, flag_single);
+            HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+            HIPCHK(hipStreamSynchronize(q));
+            if (hc[CNT_REDO2]) {
+                launch_vote(q, 160, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
+                            b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->redo2.as<uint32_t>(),
+                            hc[CNT_REDO2], b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(),
+                            pool_cap, counters, b->heads.as<uint32_t>(), nullptr, CNT_REDO2, flag_single);
+                HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+                HIPCHK(hipStreamSynchronize(q));
+            }
+        }
+        if (hc[CNT_ERR] & ERR_POOL_OVERFLOW) {
+            if (attempt >= 3) { np1_set_error("DP record pool keeps overflowing"); return -1; }
+            size_t need = (size_t)hc[CNT_POOL] * 4;
+            if (b->pool.ensure(need + need / 4 + (1u << 20))) return -1;
+            uint32_t zero[CNT_WORDS] = {0};
+            zero[CNT_ERR] = hc[CNT_ERR] & ~ERR_POOL_OVERFLOW;
+            HIPCHK(hipMemcpyAsync(counters, zero, sizeof(zero), hipMemcpyHostToDevice, q));
+            HIPCHK(hipStreamSynchronize(q));
+            continue;
+        }
+        break;
+    }
+    if (hc[CNT_ERR] & ERR_DOUBLE_INS) { np1_set_error("unsupported CIGAR: two insertion ops at one reference position"); return -1; }
+    if (hc[CNT_ERR] & ERR_BAD_RECORD) { np1_set_error("alignment record extends beyond its contig"); return -1; }
+    if (hc[CNT_ERR] & ERR_CTX_OVERFLOW) { np1_set_error("a slot holds more than 160 distinct 3-base contexts"); return -1; }
+    // ---- stage 6: chain DP over multi-state runs
+    t0(6);
+    {
+        uint32_t heads = hc[CNT_HEADS];
+        uint32_t grid = (heads + 63) / 64;
+        if (grid == 0) grid = 1;
+        launch_dp(q, b->heads.as<uint32_t>(), counters, b->pool.as<uint32_t>(), b->slot_rec.as<uint32_t>(),
+                  b->slot_res.as<uint16_t>(), K, Rfix, cfg->min_count_ratio_skip, grid);
+    }
+    t1(6);
+    // ---- stage 7: emit
+    t0(7);
+    launch_fixfirst(q, ctg_off, nc, b->soff.as<uint32_t>(), b->slot_info.as<uint8_t>(), b->slot_res.as<uint16_t>());
+    launch_scan_keep(q, b->slot_res.as<uint16_t>(), S, b->opos.as<uint32_t>(), scan_tmp, &totals[2]);
+    launch_emit(q, b->slot_res.as<uint16_t>(), b->slot_info.as<uint8_t>(), b->opos.as<uint32_t>(), S, 1u | 2u, b->out.as<uint8_t>());
+    launch_contig_bounds(q, ctg_off, nc, b->soff.as<uint32_t>(), b->opos.as<uint32_t>(), b->bounds.as<uint32_t>());
+    t1(7);
+    b->h_bounds.resize((size_t)nc + 1);
+    HIPCHK(hipMemcpyAsync(b->h_bounds.data(), b->bounds.p, 4 * ((size_t)nc + 1), hipMemcpyDeviceToHost, q));
+    HIPCHK(hipMemcpyAsync(&b->votes, &totals[3], 8, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+    HIPCHK(hipStreamSynchronize(q));
+    if (hc[CNT_ERR] & ERR_DP_INCONSISTENT) { np1_set_error("inconsistent pileup state in the chain DP"); return -1; }
+    b->votes += S;   // the draft votes once per slot
+    if (timing) {
+        for (int i = 0; i < NP1_MAX_STAGES; ++i) stage_ms[i] = 0.f;
+        for (int i = 0; i < kStages; ++i) (void)hipEventElapsedTime(&stage_ms[i], ctx->ev0[i], ctx->ev1[i]);
+    }
+    b->ran = true;
+    return 0;
+}
+
+int np1_batch_sync(np1_batch* b) {
+    if (!b) return -1;
+    (void)hipSetDevice(b->ctx->device);
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+int64_t np1_batch_result_len(np1_batch* b, int64_t c) {
+    if (!b || !b->ran || c < 0 || c >= (int64_t)b->nc) return -1;
+    return (int64_t)b->h_bounds[(size_t)c + 1] - (int64_t)b->h_bounds[(size_t)c];
+}
+
+int np1_batch_result_copy(np1_batch* b, int64_t c, char* dst, int64_t cap) {
+    int64_t len = np1_batch_result_len(b, c);
+    if (len < 0 || cap < len + 1) { np1_set_error("np1_batch_result_copy: no result or buffer too small"); return -1; }
+    (void)hipSetDevice(b->ctx->device);
+    if (!b->out_cached) {
+        size_t total = b->h_bounds[b->nc];
+        b->h_out.resize(total + 1);
+        if (total) HIPCHK(hipMemcpy(b->h_out.data(), b->out.p, total, hipMemcpyDeviceToHost));
+        b->out_cached = true;
+    }
+    memcpy(dst, b->h_out.data() + b->h_bounds[(size_t)c], (size_t)len);
+    dst[len] = '\0';
+    return 0;
+}
+
+int64_t np1_batch_update_count(np1_batch* b) { return b && b->ran ? (int64_t)b->votes : -1; }
+int64_t np1_batch_device_bytes(np1_batch* b) { return b ? (int64_t)b->device_bytes() : -1; }
+
+}  // extern "C"
+
+// ---- internal accessors used by the drop-in entry points (np1_abi.cpp) for the -debug trace list
+int np1_batch_download_slots(np1_batch* b, int64_t c, std::vector<uint32_t>* soff, std::vector<uint16_t>* res) {
+    if (!b || !b->ran || c < 0 || c >= (int64_t)b->nc) return -1;
+    (void)hipSetDevice(b->ctx->device);
+    uint32_t g0 = b->h_ctg_off[(size_t)c], g1 = b->h_ctg_off[(size_t)c + 1];
+    soff->resize((size_t)(g1 - g0) + 1);
+    HIPCHK(hipMemcpy(soff->data(), b->soff.as<uint32_t>() + g0, 4 * soff->size(), hipMemcpyDeviceToHost));
+    uint32_t s0 = (*soff)[0], s1 = soff->back();
+    res->resize(s1 - s0);
+    if (s1 > s0) HIPCHK(hipMemcpy(res->data(), b->slot_res.as<uint16_t>() + s0, 2 * (size_t)(s1 - s0), hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,434 @@
+// HIP kernels of the short-read score_chain pass for gfx950 (CDNA4, wave64).
+//
+// The reference walks every read twice through htslib and keeps, per draft base, malloc'd lists of
+// (3-base context, count) pairs, then runs a sequential fp64 chain DP over the whole contig
+// (reference: source/lib/contig.c:170-496).  Here the same result is produced by
+// data-parallel stages over a decoded record stream resident in HBM:
+//
+//   k_prep      1 lane / record : filter, trimmed query window, insertion-column max-reduce   (contig.c:202-245,333-358,667-677)
+//   scan        draft -> slot offsets (a "slot" = a draft base or one insertion column after it)
+//   k_slotinfo  1 lane / draft base : per-slot draft symbol + contig-boundary / lowercase bits    (contig.c:81-102,373-383)
+//   k_rowcap    1 lane / record : row placement in slot space; scan -> row offsets
+//   k_rows      1 lane / record : CIGAR walk -> the record's gapped row of 4-bit symbols          (contig.c:247-331)
+//   k_vote      1 wave / 62 slots: per-slot context histogram in first-seen order, single-state
+//               slots resolved at once, multi-state runs spilled as compact records               (base.c:60-71, contig.c:424-454)
+//   k_dp        1 lane / multi-state run : exact fixed-point chain DP + backtrace                  (contig.c:424-496)
+//   k_fixfirst  reference quirk: base 0 of a contig keeps its input state when it owns insertion columns
+//   scan+k_emit polished characters, lowercase mask with the carried "sign"                       (contig.c:736-786)
+//
+// Integer / byte work throughout: no MFMA.  Bound: HBM bytes of the record stream.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "np1_core.h"
+#include "np1_kernels.h"
+
+namespace np1k {
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep(ReadsDev R, int64_t n_reads, const uint32_t* __restrict__ ctg_off,
+                                              int trim, int32_t* __restrict__ qs_out, int32_t* __restrict__ qe_out,
+                                              int32_t* __restrict__ span_out, uint32_t* __restrict__ ins,
+                                              uint32_t* __restrict__ counters) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    prep_record(R, r, ctg_off, trim, qs_out, qe_out, span_out, ins, counters);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scans (3 launches: tile reduce, tile-sum scan, tile scan + offset)
+struct LoadInsPlus1 {
+    const uint32_t* p;
+    __device__ uint64_t operator()(uint64_t i) const { return 1ull + p[i]; }
+};
+struct LoadU32 {
+    const uint32_t* p;
+    __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
+};
+struct LoadKeep {
+    const uint16_t* p;
+    __device__ uint64_t operator()(uint64_t i) const { return (p[i] & 0xff) != 3 ? 1ull : 0ull; }
+};
+
+constexpr int SCAN_T = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_T * SCAN_ITEMS;
+
+__device__ __forceinline__ uint64_t block_reduce_sum(uint64_t v, uint64_t* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    uint64_t t = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < SCAN_T / 64; ++i) t += sh[i];
+    return t;   // valid in thread 0
+}
+
+template <class F>
+__global__ __launch_bounds__(SCAN_T) void k_scan_reduce(F f, uint64_t n, uint64_t* __restrict__ tile_sums) {
+    __shared__ uint64_t sh[SCAN_T / 64];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    uint64_t acc = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = base + (uint64_t)k * SCAN_T + threadIdx.x;
+        if (i < n) acc += f(i);
+    }
+    uint64_t t = block_reduce_sum(acc, sh);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = t;
+}
+
+// single block: in-place exclusive scan of the tile sums; total -> *total_out
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint64_t* __restrict__ tile_sums, uint64_t n_tiles,
+                                                     uint64_t* __restrict__ total_out) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t b = 0; b < n_tiles; b += 1024) {
+        uint64_t i = b + threadIdx.x;
+        uint64_t v = i < n_tiles ? tile_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            uint64_t add = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        uint64_t incl = sh[threadIdx.x];
+        uint64_t c = carry;
+        if (i < n_tiles) tile_sums[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+template <class F, class OutT>
+__global__ __launch_bounds__(SCAN_T) void k_scan_final(F f, uint64_t n, const uint64_t* __restrict__ tile_offs,
+                                                       OutT* __restrict__ out, const uint64_t* __restrict__ total) {
+    __shared__ uint64_t sh[SCAN_T];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    // thread t owns SCAN_ITEMS consecutive elements
+    uint64_t first = base + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = first + k;
+        v[k] = i < n ? f(i) : 0;
+        acc += v[k];
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 1; o < SCAN_T; o <<= 1) {
+        uint64_t add = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint64_t run = tile_offs[blockIdx.x] + sh[threadIdx.x] - acc;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        uint64_t i = first + k;
+        if (i < n) out[i] = (OutT)run;
+        run += v[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (OutT)*total;
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t contig_of(const uint32_t* __restrict__ ctg_off, uint32_t nc, uint32_t g) {
+    uint32_t lo = 0, hi = nc;   // largest c with ctg_off[c] <= g
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (ctg_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_slotinfo(const uint8_t* __restrict__ draft, uint32_t G,
+                                                  const uint32_t* __restrict__ ctg_off, uint32_t nc,
+                                                  const uint32_t* __restrict__ soff, uint8_t* __restrict__ slot_info) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    uint32_t c = contig_of(ctg_off, nc, g);
+    slotinfo_base(draft, g, ctg_off[c], ctg_off[c + 1], soff, slot_info);
+}
+
+__global__ __launch_bounds__(256) void k_rowcap(ReadsDev R, int64_t n_reads, const uint32_t* __restrict__ ctg_off,
+                                                const uint32_t* __restrict__ soff, const int32_t* __restrict__ qs,
+                                                const int32_t* __restrict__ qe, const int32_t* __restrict__ span,
+                                                uint32_t* __restrict__ rbase, uint32_t* __restrict__ cap_bytes) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    rowcap_record(R, r, ctg_off, soff, qs, qe, span, rbase, cap_bytes);
+}
+
+__global__ __launch_bounds__(256) void k_rows(ReadsDev R, int64_t n_reads, const uint32_t* __restrict__ ctg_off,
+                                              const uint32_t* __restrict__ soff, const int32_t* __restrict__ qs_in,
+                                              const int32_t* __restrict__ qe_in, const uint32_t* __restrict__ rbase,
+                                              const uint64_t* __restrict__ rowoff, uint8_t* __restrict__ rows,
+                                              uint4* __restrict__ meta, uint32_t* __restrict__ chunk_first,
+                                              uint32_t* __restrict__ chunk_last,
+                                              unsigned long long* __restrict__ votes) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long myvotes = 0;
+    if (r < n_reads) myvotes = rows_record(R, r, ctg_off, soff, qs_in, qe_in, rbase, rowoff, rows, meta, chunk_first, chunk_last);
+    for (int o = 32; o > 0; o >>= 1) myvotes += __shfl_down(myvotes, o);
+    if ((threadIdx.x & 63) == 0 && myvotes) atomicAdd(votes, myvotes);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_vote: one wave per 62 consecutive slots (+2 halo lanes that only provide left context).
+// Lanes are slots, the loop runs over the records overlapping the chunk in file order (wave-uniform),
+// so every lane sees its votes in first-seen order without atomics; left context comes from the two
+// neighbouring lanes.  Single-state slots (one distinct base voted) are final here: the chain DP can
+// neither change them nor couple across them (scores are exact integers), so only multi-state runs
+// (plus their terminating single-state slot) are spilled as compact records for k_dp.
+template <int E>
+__global__ __launch_bounds__(256) void k_vote(const uint4* __restrict__ meta, const uint8_t* __restrict__ rows,
+                                              const uint8_t* __restrict__ slot_info, uint32_t S,
+                                              const uint32_t* __restrict__ chunk_first,
+                                              const uint32_t* __restrict__ chunk_last, uint32_t n_chunks,
+                                              const uint32_t* __restrict__ redo_in, uint32_t n_redo_in,
+                                              uint16_t* __restrict__ slot_res, uint32_t* __restrict__ slot_rec,
+                                              uint32_t* __restrict__ pool, uint32_t pool_cap,
+                                              uint32_t* __restrict__ counters, uint32_t* __restrict__ heads,
+                                              uint32_t* __restrict__ redo_out, uint32_t redo_ci, uint32_t flag_single) {
+    extern __shared__ uint32_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t ci = blockIdx.x * 4 + wave;
+    uint32_t c;
+    if (redo_in) {
+        if (ci >= n_redo_in) return;
+        c = redo_in[ci];
+    } else {
+        c = ci;
+        if (c >= n_chunks) return;
+    }
+    uint32_t* L = lds + wave * (E - 2) * 64;
+    const int64_t s64 = (int64_t)c * VOTE_CH - 2 + lane;
+    const bool valid = s64 >= 0 && s64 < (int64_t)S;
+    const uint32_t s = (uint32_t)s64;
+    const uint32_t info = valid ? slot_info[s] : 0u;
+    const uint32_t dsym = info & 0xf;
+    const bool first = (info & SI_FIRST) != 0;
+    // the draft votes once per slot with its own rolling context (contig.c:373-383)
+    uint32_t d1 = __shfl_up(dsym, 1), d2 = __shfl_up(dsym, 2);
+    const uint32_t f1 = __shfl_up((uint32_t)first, 1);
+    const uint32_t prev_dsym = d1;
+    if (first) { d1 = 0; d2 = 0; }
+    else if (f1) d2 = 0;
+    VoteLane<E> vl;
+    vl.init(d2 << 8 | d1 << 4 | dsym);
+    uint32_t basemask = 1u << dsym;
+    const uint32_t r0 = chunk_first[c], r1 = chunk_last[c];
+    if (r0 != 0xffffffffu) {
+        for (uint32_t r = r0; r <= r1; ++r) {
+            const uint4 m = meta[r];
+            const bool cov = valid && s >= m.x && s <= m.y;
+            uint32_t sym = 0;
+            if (cov) {
+                uint32_t nn = s - m.z;
+                uint32_t byte = rows[(uint64_t)m.w * 4 + (nn >> 1)];
+                sym = (byte >> ((nn & 1) * 4)) & 0xf;
+            }
+            uint32_t p1 = __shfl_up(sym, 1), p2 = __shfl_up(sym, 2);
+            if (lane < 1) p1 = 0;
+            if (lane < 2) p2 = 0;
+            if (cov) {
+                basemask |= 1u << sym;
+                if (lane >= 2) vl.tally(p2 << 8 | p1 << 4 | sym, L, lane);
+            }
+        }
+    }
+    if (__ballot(vl.ovf) != 0ull) {   // more distinct contexts in a slot than this instantiation keeps: redo with a larger E
+        if (lane == 0) {
+            if (redo_out) redo_out[atomicAdd(&counters[redo_ci], 1u)] = c;
+            else atomicOr(&counters[CNT_ERR], ERR_CTX_OVERFLOW);
+        }
+        return;
+    }
+    const bool own = lane >= 2 && valid;
+    const uint32_t total = vl.total(L, lane);
+    const bool single = __popc(basemask) == 1;
+    uint32_t psingle = __shfl_up((uint32_t)single, 1);
+    const bool prev_is_single = first || psingle != 0;
+    const bool is_head = own && !single && prev_is_single;
+    const bool need_rec = own && (!single || !prev_is_single);
+    if (own) {
+        uint32_t res = 0xffu;
+        if (single) res = dsym | (((total == 1 ? 1u : 0u) | flag_single) << 8);
+        slot_res[s] = (uint16_t)res;
+    }
+    const uint32_t words = need_rec ? vl.n + REC_FIXED_WORDS : 0u;
+    uint32_t incl = words;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const uint32_t wave_total = __shfl(incl, 63);
+    uint32_t base = 0;
+    if (wave_total) {
+        if (lane == 63) base = atomicAdd(&counters[CNT_POOL], wave_total);
+        base = __shfl(base, 63);
+    }
+    const bool fits = (uint64_t)base + wave_total <= (uint64_t)pool_cap;
+    if (!fits && lane == 0) atomicOr(&counters[CNT_ERR], ERR_POOL_OVERFLOW);
+    uint32_t my_off = 0xffffffffu;
+    if (need_rec && fits) {
+        my_off = base + incl - words;
+        uint32_t hdr = (single ? REC_SINGLE : 0u) | ((info & SI_LAST) ? REC_CTG_LAST : 0u) |
+                       (first ? REC_CTG_FIRST : 0u) | (prev_dsym << 4);
+        vl.write_record(pool + my_off, s, total, hdr, L, lane);
+    }
+    if (own) slot_rec[s] = my_off;
+    const unsigned long long hb = __ballot(is_head && fits);
+    if (hb) {
+        uint32_t hbase = 0;
+        if (lane == 0) hbase = atomicAdd(&counters[CNT_HEADS], (uint32_t)__popcll(hb));
+        hbase = __shfl(hbase, 0);
+        if (is_head && fits) heads[hbase + __popcll(hb & ((1ull << lane) - 1ull))] = my_off;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dp: one lane per multi-state run
+constexpr int DP_T = 64;
+struct DpLds {
+    long long (*sc_)[16][DP_T];
+    uint16_t (*km_)[16][DP_T];
+    uint8_t (*rk_)[16][DP_T];
+    int t;
+    __device__ __forceinline__ long long& sc(int buf, uint32_t b) { return sc_[buf][b][t]; }
+    __device__ __forceinline__ uint16_t& km(int buf, uint32_t b) { return km_[buf][b][t]; }
+    __device__ __forceinline__ uint8_t& rk(int buf, uint32_t b) { return rk_[buf][b][t]; }
+};
+
+__global__ __launch_bounds__(DP_T) void k_dp(const uint32_t* __restrict__ heads, const uint32_t* __restrict__ counters,
+                                             uint32_t* __restrict__ pool, const uint32_t* __restrict__ slot_rec,
+                                             uint16_t* __restrict__ slot_res, int K, long long Rfix, double min_ratio,
+                                             uint32_t* __restrict__ err) {
+    __shared__ long long sc[2][16][DP_T];
+    __shared__ uint16_t km[2][16][DP_T];
+    __shared__ uint8_t rk[2][16][DP_T];
+    DpLds st{sc, km, rk, (int)threadIdx.x};
+    const uint32_t n_heads = counters[CNT_HEADS];
+    for (uint32_t hi = blockIdx.x * DP_T + threadIdx.x; hi < n_heads; hi += gridDim.x * DP_T)
+        if (!dp_run(heads[hi], pool, slot_rec, slot_res, K, Rfix, min_ratio, st)) atomicOr(err, ERR_DP_INCONSISTENT);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fixfirst(const uint32_t* __restrict__ ctg_off, uint32_t nc, const uint32_t* __restrict__ soff,
+                           const uint8_t* __restrict__ slot_info, uint16_t* __restrict__ slot_res) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc) return;
+    fixfirst_contig(ctg_off[c], ctg_off[c + 1], soff, slot_info, slot_res);
+}
+
+__global__ __launch_bounds__(256) void k_emit(const uint16_t* __restrict__ slot_res, const uint8_t* __restrict__ slot_info,
+                                              const uint32_t* __restrict__ opos, uint32_t S, uint32_t mask,
+                                              uint8_t* __restrict__ out) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    emit_slot(s, slot_res, slot_info, opos, mask, out);
+}
+
+__global__ void k_contig_bounds(const uint32_t* __restrict__ ctg_off, uint32_t nc, const uint32_t* __restrict__ soff,
+                                const uint32_t* __restrict__ opos, uint32_t* __restrict__ out_bounds) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > nc) return;
+    out_bounds[c] = opos[soff[ctg_off[c]]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (host)
+static inline unsigned nblk(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+void launch_prep(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, int trim, int32_t* qs,
+                 int32_t* qe, int32_t* span, uint32_t* ins, uint32_t* counters) {
+    if (n_reads == 0) return;
+    k_prep<<<nblk(n_reads, 256), 256, 0, st>>>(R, n_reads, ctg_off, trim, qs, qe, span, ins, counters);
+}
+
+template <class F, class OutT>
+static void scan_impl(hipStream_t st, F f, uint64_t n, OutT* out, uint64_t* tile_tmp, uint64_t* total_dev) {
+    unsigned tiles = nblk(n, SCAN_TILE);
+    if (tiles == 0) tiles = 1;
+    k_scan_reduce<F><<<tiles, SCAN_T, 0, st>>>(f, n, tile_tmp);
+    k_scan_tiles<<<1, 1024, 0, st>>>(tile_tmp, tiles, total_dev);
+    k_scan_final<F, OutT><<<tiles, SCAN_T, 0, st>>>(f, n, tile_tmp, out, total_dev);
+}
+uint64_t scan_tmp_words(uint64_t n) { return nblk(n, SCAN_TILE) + 2; }
+
+void launch_scan_slots(hipStream_t st, const uint32_t* ins, uint64_t G, uint32_t* soff, uint64_t* tmp, uint64_t* total) {
+    scan_impl<LoadInsPlus1, uint32_t>(st, LoadInsPlus1{ins}, G, soff, tmp, total);
+}
+void launch_scan_rows(hipStream_t st, const uint32_t* cap_bytes, uint64_t n, uint64_t* rowoff, uint64_t* tmp, uint64_t* total) {
+    scan_impl<LoadU32, uint64_t>(st, LoadU32{cap_bytes}, n, rowoff, tmp, total);
+}
+void launch_scan_keep(hipStream_t st, const uint16_t* slot_res, uint64_t S, uint32_t* opos, uint64_t* tmp, uint64_t* total) {
+    scan_impl<LoadKeep, uint32_t>(st, LoadKeep{slot_res}, S, opos, tmp, total);
+}
+
+void launch_slotinfo(hipStream_t st, const uint8_t* draft, uint32_t G, const uint32_t* ctg_off, uint32_t nc,
+                     const uint32_t* soff, uint8_t* slot_info) {
+    if (G == 0) return;
+    k_slotinfo<<<nblk(G, 256), 256, 0, st>>>(draft, G, ctg_off, nc, soff, slot_info);
+}
+
+void launch_rowcap(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
+                   const int32_t* qs, const int32_t* qe, const int32_t* span, uint32_t* rbase, uint32_t* cap_bytes) {
+    if (n_reads == 0) return;
+    k_rowcap<<<nblk(n_reads, 256), 256, 0, st>>>(R, n_reads, ctg_off, soff, qs, qe, span, rbase, cap_bytes);
+}
+
+void launch_rows(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
+                 const int32_t* qs, const int32_t* qe, const uint32_t* rbase, const uint64_t* rowoff, uint8_t* rows,
+                 uint4* meta, uint32_t* chunk_first, uint32_t* chunk_last, unsigned long long* votes) {
+    if (n_reads == 0) return;
+    k_rows<<<nblk(n_reads, 256), 256, 0, st>>>(R, n_reads, ctg_off, soff, qs, qe, rbase, rowoff, rows, meta,
+                                               chunk_first, chunk_last, votes);
+}
+
+void launch_vote(hipStream_t st, int E, const uint4* meta, const uint8_t* rows, const uint8_t* slot_info, uint32_t S,
+                 const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint32_t* redo_in,
+                 uint32_t n_redo_in, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap,
+                 uint32_t* counters, uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single) {
+    uint32_t work = redo_in ? n_redo_in : n_chunks;
+    if (work == 0) return;
+    unsigned blocks = nblk(work, 4);
+#define NP1_VOTE(EE)                                                                                              \
+    k_vote<EE><<<blocks, 256, 4 * ((EE)-2) * 64 * sizeof(uint32_t), st>>>(                                        \
+        meta, rows, slot_info, S, chunk_first, chunk_last, n_chunks, redo_in, n_redo_in, slot_res, slot_rec, pool, \
+        pool_cap, counters, heads, redo_out, redo_ci, flag_single)
+    if (E <= 16) NP1_VOTE(16);
+    else if (E <= 64) NP1_VOTE(64);
+    else NP1_VOTE(160);
+#undef NP1_VOTE
+}
+
+void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t* pool, const uint32_t* slot_rec,
+               uint16_t* slot_res, int K, long long Rfix, double min_ratio, uint32_t grid) {
+    k_dp<<<grid, DP_T, 0, st>>>(heads, counters, pool, slot_rec, slot_res, K, Rfix, min_ratio, &counters[CNT_ERR]);
+}
+
+void launch_fixfirst(hipStream_t st, const uint32_t* ctg_off, uint32_t nc, const uint32_t* soff, const uint8_t* slot_info,
+                     uint16_t* slot_res) {
+    if (nc == 0) return;
+    k_fixfirst<<<nblk(nc, 64), 64, 0, st>>>(ctg_off, nc, soff, slot_info, slot_res);
+}
+
+void launch_emit(hipStream_t st, const uint16_t* slot_res, const uint8_t* slot_info, const uint32_t* opos, uint32_t S,
+                 uint32_t mask, uint8_t* out) {
+    if (S == 0) return;
+    k_emit<<<nblk(S, 256), 256, 0, st>>>(slot_res, slot_info, opos, S, mask, out);
+}
+
+void launch_contig_bounds(hipStream_t st, const uint32_t* ctg_off, uint32_t nc, const uint32_t* soff, const uint32_t* opos,
+                          uint32_t* out_bounds) {
+    k_contig_bounds<<<nblk(nc + 1, 64), 64, 0, st>>>(ctg_off, nc, soff, opos, out_bounds);
+}
+
+}  // namespace np1k

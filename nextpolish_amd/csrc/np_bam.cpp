@@ -1,0 +1,426 @@
+// BAM / BAI / FAI reader + writer (SAMv1 §4.2, §5.2, §5.3).  See np_bam.h.
+#include "np_bam.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+
+namespace np {
+
+int BamHeader::name2id(const std::string& n) const {
+    for (size_t i = 0; i < names.size(); ++i)
+        if (names[i] == n) return (int)i;
+    return -1;
+}
+
+int32_t BamRec::rlen() const {
+    int32_t l = 0;
+    const uint32_t* c = cigar();
+    for (uint32_t i = 0; i < n_cigar; ++i) {
+        uint32_t op = c[i] & 0xf;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += (int32_t)(c[i] >> 4);
+    }
+    return l;
+}
+
+int32_t BamRec::endpos() const {
+    if (!(flag & 4) && n_cigar > 0) {
+        int32_t l = rlen();
+        return pos + (l > 0 ? l : 1);   // htslib: a zero-length alignment still occupies one base
+    }
+    return pos + 1;
+}
+
+bool BamReader::open(const std::string& path) {
+    if (!bg_.open(path)) return false;
+    char magic[4];
+    if (bg_.read(magic, 4) != 4 || memcmp(magic, "BAM\1", 4) != 0) return false;
+    int32_t l_text;
+    if (bg_.read(&l_text, 4) != 4 || l_text < 0) return false;
+    hdr_.text.resize(l_text);
+    if (l_text && bg_.read(&hdr_.text[0], l_text) != l_text) return false;
+    int32_t n_ref;
+    if (bg_.read(&n_ref, 4) != 4 || n_ref < 0) return false;
+    hdr_.names.clear();
+    hdr_.lens.clear();
+    for (int i = 0; i < n_ref; ++i) {
+        int32_t l_name;
+        if (bg_.read(&l_name, 4) != 4 || l_name <= 0) return false;
+        std::string nm(l_name, '\0');
+        if (bg_.read(&nm[0], l_name) != l_name) return false;
+        nm.resize(strlen(nm.c_str()));
+        uint32_t l_ref;
+        if (bg_.read(&l_ref, 4) != 4) return false;
+        hdr_.names.push_back(nm);
+        hdr_.lens.push_back(l_ref);
+    }
+    first_rec_ = bg_.tell();
+    return true;
+}
+
+int BamReader::next(BamRec& r) {
+    int32_t block_len;
+    int64_t got = bg_.read(&block_len, 4);
+    if (got == 0) return 0;
+    if (got != 4 || block_len < 32) return -1;
+    uint32_t x[8];
+    if (bg_.read(x, 32) != 32) return -1;
+    r.tid = (int32_t)x[0];
+    r.pos = (int32_t)x[1];
+    r.l_qname = (uint8_t)(x[2] & 0xff);
+    r.mapq = (uint8_t)((x[2] >> 8) & 0xff);
+    r.bin = (uint16_t)(x[2] >> 16);
+    r.n_cigar = x[3] & 0xffff;
+    r.flag = (uint16_t)(x[3] >> 16);
+    r.l_qseq = (int32_t)x[4];
+    r.mtid = (int32_t)x[5];
+    r.mpos = (int32_t)x[6];
+    r.isize = (int32_t)x[7];
+    size_t rest = (size_t)block_len - 32;
+    if (r.l_qseq < 0 || (size_t)r.l_qname + 4 * (size_t)r.n_cigar + ((size_t)r.l_qseq + 1) / 2 + (size_t)r.l_qseq > rest)
+        return -1;
+    r.data.resize(rest + 8);   // small tail pad: the trim loops may peek one nibble past the sequence
+    if (rest && bg_.read(r.data.data(), rest) != (int64_t)rest) return -1;
+    memset(r.data.data() + rest, 0, 8);
+    return 1;
+}
+
+int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+static void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>* out) {
+    out->clear();
+    if (beg >= end) return;
+    --end;
+    out->push_back(0);
+    for (int64_t k = 1 + (beg >> 26); k <= 1 + (end >> 26); ++k) out->push_back((uint32_t)k);
+    for (int64_t k = 9 + (beg >> 23); k <= 9 + (end >> 23); ++k) out->push_back((uint32_t)k);
+    for (int64_t k = 73 + (beg >> 20); k <= 73 + (end >> 20); ++k) out->push_back((uint32_t)k);
+    for (int64_t k = 585 + (beg >> 17); k <= 585 + (end >> 17); ++k) out->push_back((uint32_t)k);
+    for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (end >> 14); ++k) out->push_back((uint32_t)k);
+}
+
+static const uint32_t kMetaBin = 37450;
+
+bool BaiIndex::load(const std::string& path) {
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) return false;
+    auto rd = [&](void* p, size_t n) { return fread(p, 1, n, fp) == n; };
+    char magic[4];
+    int32_t n_ref;
+    bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0;
+    if (ok) {
+        refs.assign(n_ref, BaiRef());
+        for (int i = 0; ok && i < n_ref; ++i) {
+            int32_t n_bin;
+            ok = rd(&n_bin, 4);
+            for (int b = 0; ok && b < n_bin; ++b) {
+                uint32_t bin;
+                int32_t n_chunk;
+                ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0;
+                if (!ok) break;
+                std::vector<BaiChunk> ch(n_chunk);
+                if (n_chunk) ok = rd(ch.data(), sizeof(BaiChunk) * (size_t)n_chunk);
+                refs[i].bins[bin] = std::move(ch);
+            }
+            int32_t n_intv;
+            ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+            if (ok) {
+                refs[i].linear.resize(n_intv);
+                if (n_intv) ok = rd(refs[i].linear.data(), 8 * (size_t)n_intv);
+            }
+        }
+    }
+    fclose(fp);
+    return ok;
+}
+
+bool BaiIndex::region_start(int tid, int32_t beg, int32_t end, voff_t* out) const {
+    if (tid < 0 || tid >= (int)refs.size()) return false;
+    const BaiRef& r = refs[tid];
+    if (beg < 0) beg = 0;
+    voff_t min_off = 0;
+    size_t w = (size_t)(beg >> 14);
+    if (!r.linear.empty()) min_off = r.linear[w < r.linear.size() ? w : r.linear.size() - 1];
+    std::vector<uint32_t> bins;
+    reg2bins(beg, end, &bins);
+    bool found = false;
+    voff_t best = 0;
+    for (uint32_t b : bins) {
+        auto it = r.bins.find(b);
+        if (it == r.bins.end()) continue;
+        for (const BaiChunk& c : it->second) {
+            if (c.end <= min_off) continue;
+            if (!found || c.beg < best) { best = c.beg; found = true; }
+        }
+    }
+    if (found) *out = best;
+    return found;
+}
+
+bool BamWriter::open(const std::string& path, const BamHeader& hdr, int level) {
+    path_ = path;
+    if (!bg_.open(path, level)) return false;
+    std::vector<uint8_t> h;
+    auto put32 = [&](int32_t v) { uint8_t b[4]; memcpy(b, &v, 4); h.insert(h.end(), b, b + 4); };
+    h.insert(h.end(), {'B', 'A', 'M', 1});
+    put32((int32_t)hdr.text.size());
+    h.insert(h.end(), hdr.text.begin(), hdr.text.end());
+    put32((int32_t)hdr.names.size());
+    for (size_t i = 0; i < hdr.names.size(); ++i) {
+        put32((int32_t)hdr.names[i].size() + 1);
+        h.insert(h.end(), hdr.names[i].begin(), hdr.names[i].end());
+        h.push_back(0);
+        put32((int32_t)hdr.lens[i]);
+    }
+    if (!bg_.write(h.data(), h.size())) return false;
+    if (!bg_.flush_block()) return false;   // records start on a fresh block, as samtools does
+    size_t n = hdr.names.size();
+    refs_.assign(n, BaiRef());
+    n_mapped_.assign(n, 0);
+    n_unmapped_.assign(n, 0);
+    ref_beg_.assign(n, 0);
+    ref_end_.assign(n, 0);
+    return true;
+}
+
+void BamWriter::index_record(int32_t tid, int32_t beg, int32_t end, voff_t v0, voff_t v1, bool mapped) {
+    if (tid < 0) { ++n_no_coor_; return; }
+    BaiRef& r = refs_[tid];
+    if (n_mapped_[tid] + n_unmapped_[tid] == 0) ref_beg_[tid] = v0;
+    ref_end_[tid] = v1;
+    if (mapped) ++n_mapped_[tid]; else ++n_unmapped_[tid];
+    uint32_t bin = (uint32_t)reg2bin(beg, end);
+    std::vector<BaiChunk>& ch = r.bins[bin];
+    if (!ch.empty() && ch.back().end == v0) ch.back().end = v1;
+    else ch.push_back(BaiChunk{v0, v1});
+    size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+    if (r.linear.size() <= w1) r.linear.resize(w1 + 1, (voff_t)-1);
+    for (size_t w = w0; w <= w1; ++w)
+        if (r.linear[w] == (voff_t)-1) r.linear[w] = v0;
+}
+
+bool BamWriter::write(int32_t tid, int32_t pos, uint8_t mapq, uint16_t flag, int32_t mtid, int32_t mpos,
+                      int32_t isize, const std::string& qname, const uint32_t* cigar, uint32_t n_cigar,
+                      const uint8_t* seq4, const uint8_t* qual, int32_t l_qseq) {
+    int32_t rl = 0;
+    for (uint32_t i = 0; i < n_cigar; ++i) {
+        uint32_t op = cigar[i] & 0xf;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += (int32_t)(cigar[i] >> 4);
+    }
+    bool mapped = !(flag & 4);
+    int32_t end = pos + ((mapped && rl > 0) ? rl : 1);
+    uint32_t bin = (uint32_t)reg2bin(pos < 0 ? 0 : pos, end < 1 ? 1 : end);
+    uint32_t l_qname = (uint32_t)qname.size() + 1;
+    size_t body = 32 + l_qname + 4 * (size_t)n_cigar + ((size_t)l_qseq + 1) / 2 + (size_t)l_qseq;
+    buf_.resize(4 + body);
+    uint8_t* p = buf_.data();
+    int32_t block_len = (int32_t)body;
+    uint32_t x[8];
+    x[0] = (uint32_t)tid;
+    x[1] = (uint32_t)pos;
+    x[2] = (bin << 16) | ((uint32_t)mapq << 8) | l_qname;
+    x[3] = ((uint32_t)flag << 16) | (n_cigar & 0xffff);
+    x[4] = (uint32_t)l_qseq;
+    x[5] = (uint32_t)mtid;
+    x[6] = (uint32_t)mpos;
+    x[7] = (uint32_t)isize;
+    memcpy(p, &block_len, 4); p += 4;
+    memcpy(p, x, 32); p += 32;
+    memcpy(p, qname.c_str(), l_qname); p += l_qname;
+    if (n_cigar) memcpy(p, cigar, 4 * (size_t)n_cigar);
+    p += 4 * (size_t)n_cigar;
+    size_t sb = ((size_t)l_qseq + 1) / 2;
+    if (sb) memcpy(p, seq4, sb);
+    p += sb;
+    if (l_qseq) {
+        if (qual) memcpy(p, qual, l_qseq); else memset(p, 0xff, l_qseq);
+    }
+    voff_t v0 = bg_.tell();
+    if (!bg_.write(buf_.data(), buf_.size())) return false;
+    voff_t v1 = bg_.tell();
+    index_record(tid, pos < 0 ? 0 : pos, end < 1 ? 1 : end, v0, v1, mapped);
+    return true;
+}
+
+bool BamWriter::close() {
+    // tell() of the last record may point inside an unflushed block; offsets stay valid after flush
+    if (!bg_.close()) return false;
+    FILE* fp = fopen((path_ + ".bai").c_str(), "wb");
+    if (!fp) return false;
+    auto wr = [&](const void* p, size_t n) { return fwrite(p, 1, n, fp) == n; };
+    bool ok = wr("BAI\1", 4);
+    int32_t n_ref = (int32_t)refs_.size();
+    ok = ok && wr(&n_ref, 4);
+    for (int i = 0; ok && i < n_ref; ++i) {
+        BaiRef& r = refs_[i];
+        bool has = (n_mapped_[i] + n_unmapped_[i]) > 0;
+        int32_t n_bin = (int32_t)r.bins.size() + (has ? 1 : 0);
+        ok = wr(&n_bin, 4);
+        for (auto& kv : r.bins) {
+            uint32_t bin = kv.first;
+            int32_t n_chunk = (int32_t)kv.second.size();
+            ok = ok && wr(&bin, 4) && wr(&n_chunk, 4) && wr(kv.second.data(), sizeof(BaiChunk) * kv.second.size());
+        }
+        if (has) {
+            uint32_t bin = kMetaBin;
+            int32_t n_chunk = 2;
+            uint64_t meta[4] = {ref_beg_[i], ref_end_[i], n_mapped_[i], n_unmapped_[i]};
+            ok = ok && wr(&bin, 4) && wr(&n_chunk, 4) && wr(meta, 32);
+        }
+        // back-fill unset linear slots from the next set one (hts_idx_finish behaviour)
+        for (size_t w = r.linear.size(); w-- > 0;)
+            if (r.linear[w] == (voff_t)-1) r.linear[w] = (w + 1 < r.linear.size()) ? r.linear[w + 1] : 0;
+        int32_t n_intv = (int32_t)r.linear.size();
+        ok = ok && wr(&n_intv, 4);
+        if (n_intv) ok = ok && wr(r.linear.data(), 8 * (size_t)n_intv);
+    }
+    ok = ok && wr(&n_no_coor_, 8);
+    ok = (fclose(fp) == 0) && ok;
+    return ok;
+}
+
+bool Fai::build(const std::string& fasta, std::vector<FaiEntry>* out) {
+    FILE* fp = fopen(fasta.c_str(), "rb");
+    if (!fp) return false;
+    out->clear();
+    std::vector<char> buf(1 << 20);
+    int64_t off = 0;          // file offset of buf[0]
+    FaiEntry cur;
+    bool in_seq = false;
+    int64_t line_start = 0;   // file offset where the current line began
+    int32_t line_bases_cur = 0;
+    enum { HDR, SEQ } st = SEQ;
+    bool at_line_start = true;
+    std::string name;
+    bool name_done = false;
+    size_t n;
+    auto finish_line = [&](int64_t line_end_excl /* offset after '\n' or EOF */, bool had_nl) {
+        if (!in_seq) return;
+        int32_t width = (int32_t)(line_end_excl - line_start);
+        if (line_bases_cur == 0 && width == 0) return;
+        if (cur.line_bases == 0 && line_bases_cur > 0) {
+            cur.line_bases = line_bases_cur;
+            cur.line_width = had_nl ? width : line_bases_cur + 1;
+        }
+        cur.len += line_bases_cur;
+    };
+    while ((n = fread(buf.data(), 1, buf.size(), fp)) > 0) {
+        for (size_t i = 0; i < n; ++i) {
+            char c = buf[i];
+            int64_t here = off + (int64_t)i;
+            if (at_line_start) {
+                line_start = here;
+                line_bases_cur = 0;
+                at_line_start = false;
+                if (c == '>') {
+                    if (in_seq) out->push_back(cur);
+                    st = HDR;
+                    name.clear();
+                    name_done = false;
+                    in_seq = false;
+                    continue;
+                }
+                st = SEQ;
+            }
+            if (c == '\n') {
+                if (st == HDR) {
+                    cur = FaiEntry();
+                    cur.name = name;
+                    cur.len = 0;
+                    cur.offset = here + 1;
+                    cur.line_bases = 0;
+                    cur.line_width = 0;
+                    in_seq = true;
+                } else {
+                    finish_line(here + 1, true);
+                }
+                at_line_start = true;
+                continue;
+            }
+            if (st == HDR) {
+                if (!name_done) {
+                    if (isspace((unsigned char)c)) name_done = true; else name.push_back(c);
+                }
+            } else if (isgraph((unsigned char)c)) {
+                ++line_bases_cur;
+            }
+        }
+        off += (int64_t)n;
+    }
+    if (!at_line_start && st == SEQ) finish_line(off, false);
+    if (in_seq) out->push_back(cur);
+    fclose(fp);
+    for (FaiEntry& e : *out)
+        if (e.line_bases == 0) { e.line_bases = 1; e.line_width = 2; }   // empty sequence
+    return true;
+}
+
+bool Fai::load(const std::string& fasta) {
+    fasta_ = fasta;
+    entries_.clear();
+    by_name_.clear();
+    std::string fai = fasta + ".fai";
+    FILE* fp = fopen(fai.c_str(), "r");
+    if (fp) {
+        char line[65536];
+        while (fgets(line, sizeof(line), fp)) {
+            FaiEntry e;
+            char* tab = strchr(line, '\t');
+            if (!tab) continue;
+            e.name.assign(line, tab - line);
+            long long len, offset;
+            int lb, lw;
+            if (sscanf(tab + 1, "%lld\t%lld\t%d\t%d", &len, &offset, &lb, &lw) != 4) continue;
+            e.len = len; e.offset = offset; e.line_bases = lb; e.line_width = lw;
+            entries_.push_back(e);
+        }
+        fclose(fp);
+    } else {
+        if (!build(fasta, &entries_)) return false;
+        FILE* out = fopen(fai.c_str(), "w");   // fai_load writes the index next to the FASTA
+        if (out) {
+            for (const FaiEntry& e : entries_)
+                fprintf(out, "%s\t%lld\t%lld\t%d\t%d\n", e.name.c_str(), (long long)e.len, (long long)e.offset,
+                        e.line_bases, e.line_width);
+            fclose(out);
+        }
+    }
+    for (size_t i = 0; i < entries_.size(); ++i)
+        if (!by_name_.count(entries_[i].name)) by_name_[entries_[i].name] = (int)i;
+    return true;
+}
+
+int Fai::find(const std::string& name) const {
+    auto it = by_name_.find(name);
+    return it == by_name_.end() ? -1 : it->second;
+}
+
+bool Fai::fetch(int i, std::string* out) const {
+    if (i < 0 || i >= (int)entries_.size()) return false;
+    const FaiEntry& e = entries_[i];
+    out->clear();
+    out->reserve((size_t)e.len);
+    FILE* fp = fopen(fasta_.c_str(), "rb");
+    if (!fp) return false;
+    if (fseeko(fp, (off_t)e.offset, SEEK_SET) != 0) { fclose(fp); return false; }
+    std::vector<char> buf(1 << 20);
+    while ((int64_t)out->size() < e.len) {
+        size_t n = fread(buf.data(), 1, buf.size(), fp);
+        if (n == 0) break;
+        for (size_t k = 0; k < n && (int64_t)out->size() < e.len; ++k)
+            if (isgraph((unsigned char)buf[k])) out->push_back(buf[k]);
+    }
+    fclose(fp);
+    return (int64_t)out->size() == e.len;
+}
+
+}  // namespace np

@@ -1,0 +1,63 @@
+// BGZF (blocked gzip) reader/writer, written from the SAM/BAM specification (SAMv1 §4.1).
+// Replaces, for the polishing hot path only, the slice of the reference's vendored
+// htslib that it uses for BAM access (reference: source/lib/contig.c:35-52,172-174,692-694
+// call hts_open/bgzf_* / sam_itr_next; source/lib/config.c:80-101 calls bgzf_open/bam_read1).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace np {
+
+// Virtual file offset: (compressed block start << 16) | offset inside the inflated block.
+typedef uint64_t voff_t;
+
+class BgzfReader {
+public:
+    BgzfReader() = default;
+    ~BgzfReader();
+    BgzfReader(const BgzfReader&) = delete;
+    BgzfReader& operator=(const BgzfReader&) = delete;
+
+    bool open(const std::string& path);
+    void close();
+    // Reads exactly n bytes unless EOF; returns bytes read, or -1 on a corrupt block.
+    int64_t read(void* dst, size_t n);
+    bool seek(voff_t v);
+    voff_t tell() const;
+    bool is_open() const { return fp_ != nullptr; }
+
+private:
+    bool load_block();   // inflate the block at file offset next_coff_
+    FILE* fp_ = nullptr;
+    std::vector<uint8_t> cbuf_;   // compressed block
+    std::vector<uint8_t> ubuf_;   // inflated block (<= 64 KiB)
+    uint64_t block_coff_ = 0;     // file offset of the block in ubuf_
+    uint64_t next_coff_ = 0;      // file offset of the next block
+    uint32_t ulen_ = 0, upos_ = 0;
+    bool eof_ = false;
+};
+
+class BgzfWriter {
+public:
+    BgzfWriter() = default;
+    ~BgzfWriter();
+    bool open(const std::string& path, int level = 1);
+    bool write(const void* src, size_t n);
+    voff_t tell() const { return (coff_ << 16) | (uint64_t)fill_; }
+    bool flush_block();
+    bool close();   // flushes and appends the 28-byte EOF marker block
+
+private:
+    FILE* fp_ = nullptr;
+    int level_ = 1;
+    std::vector<uint8_t> ubuf_, cbuf_;
+    uint32_t fill_ = 0;
+    uint64_t coff_ = 0;
+};
+
+// Inflate one raw-deflate payload (used by the threaded whole-file loader).
+bool bgzf_inflate_block(const uint8_t* cdata, size_t clen, uint8_t* out, size_t out_len);
+
+}  // namespace np

@@ -1,0 +1,88 @@
+// C ABI for the host-side stream objects (include/nextpolish1.h, Part 2: np1_stream_*).
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nextpolish1.h"
+#include "np_stream.h"
+#include "np_synth.h"
+
+struct np1_stream { np::ReadStream s; };
+
+static thread_local std::string g_err;
+extern "C" const char* np1_last_error(void) { return g_err.c_str(); }
+void np1_set_error(const std::string& e) { g_err = e; }
+
+extern "C" {
+
+np1_stream* np1_stream_load(const char* fasta, const char* bam, const char* const* names, int n_names, int with_qual) {
+    std::vector<std::string> nm;
+    for (int i = 0; i < n_names; ++i) nm.push_back(names[i]);
+    np1_stream* st = new np1_stream();
+    std::string err;
+    if (!np::load_stream(fasta, bam, nm, with_qual != 0, &st->s, &err)) {
+        g_err = err;
+        delete st;
+        return nullptr;
+    }
+    return st;
+}
+
+void np1_stream_get_view(const np1_stream* st, np1_stream_view* v) {
+    const np::ReadStream& s = st->s;
+    memset(v, 0, sizeof(*v));
+    v->n_contigs = (int64_t)s.n_contigs();
+    v->n_reads = (int64_t)s.n_reads();
+    v->ctg_len = s.ctg_len.data();
+    v->ctg_off = s.ctg_off.data();
+    v->read_begin = s.read_begin.data();
+    v->draft = s.draft.data();
+    v->draft_len = (int64_t)s.draft.size();
+    v->pos = s.pos.data();
+    v->ctg = s.ctg.data();
+    v->flag = s.flag.data();
+    v->n_cigar = s.n_cigar.data();
+    v->l_qseq = s.l_qseq.data();
+    v->cigar_off = s.cigar_off.data();
+    v->seq_off = s.seq_off.data();
+    v->mapq = s.mapq.data();
+    v->isize = s.isize.data();
+    v->qual_off = s.qual_off.data();
+    v->cigar = s.cigar.data();
+    v->cigar_len = (int64_t)s.cigar.size();
+    v->seq = s.seq.data();
+    v->seq_len = (int64_t)s.seq.size();
+    v->qual = s.qual.data();
+    v->qual_len = (int64_t)s.qual.size();
+}
+
+const char* np1_stream_contig_name(const np1_stream* st, int64_t i) {
+    if (i < 0 || i >= (int64_t)st->s.n_contigs()) return nullptr;
+    return st->s.names[(size_t)i].c_str();
+}
+
+uint64_t np1_stream_algorithmic_bytes(const np1_stream* st, int with_qual) {
+    return st->s.algorithmic_input_bytes(with_qual != 0);
+}
+
+int np1_stream_write_files(const np1_stream* st, const char* fasta, const char* bam, int level) {
+    std::string err;
+    if (!np::write_stream_files(st->s, fasta, bam, level, &err)) { g_err = err; return -1; }
+    return 0;
+}
+
+void np1_stream_free(np1_stream* st) { delete st; }
+
+void np1_synth_defaults(np1_synth_params* p) { np::synth_default_params(p); }
+
+np1_stream* np1_stream_synth(const np1_synth_params* p, const char* prefix) {
+    np1_stream* st = new np1_stream();
+    if (!np::synth_stream(*p, prefix ? prefix : "ctg", &st->s)) {
+        g_err = "synthetic generation failed";
+        delete st;
+        return nullptr;
+    }
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Decoded record stream: the host-side (and, mirrored, HBM-side) layout of "draft contigs +
+// their position-sorted alignment records" that every kernel of the short-read polishing
+// path consumes.  One ReadStream = one batch of whole contigs.
+//
+// It carries exactly the BAM core fields the reference's per-read code touches
+// (reference: source/lib/contig.c:202-358,632-686 read core.pos/flag/n_cigar/l_qseq/isize/qual,
+// the CIGAR array, the 4-bit sequence and, for kmer_count, the base qualities
+// source/lib/kmercount.c:365-465).  Algorithmic bytes per record = 32 (fixed fields below)
+// + 4*n_cigar + ceil(l_qseq/2) [+ l_qseq with qualities]  (SURVEY.md §8d).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace np {
+
+struct ReadStream {
+    // ---- contigs of this batch, in request order
+    std::vector<std::string> names;
+    std::vector<int32_t> ctg_len;       // draft length of each contig
+    std::vector<uint32_t> ctg_off;      // size n+1: offset of contig c in `draft` (global draft coordinate)
+    std::string draft;                  // concatenated raw FASTA characters (case preserved)
+    std::vector<uint64_t> read_begin;   // size n+1: reads [read_begin[c], read_begin[c+1]) belong to contig c
+
+    // ---- records, BAM file order inside each contig (fixed part: 32 B / record)
+    std::vector<int32_t> pos;           // 0-based leftmost draft coordinate inside the contig
+    std::vector<uint32_t> ctg;          // contig index inside this batch
+    std::vector<uint16_t> flag;
+    std::vector<uint16_t> n_cigar;
+    std::vector<int32_t> l_qseq;
+    std::vector<uint64_t> cigar_off;    // index of the first op in `cigar`
+    std::vector<uint64_t> seq_off;      // byte offset of the first base pair in `seq`
+    // ---- only needed by kmer_count (filters + haplotype scoring)
+    std::vector<uint8_t> mapq;
+    std::vector<int32_t> isize;
+    std::vector<uint64_t> qual_off;     // byte offset into `qual` (when loaded)
+
+    // ---- pools
+    std::vector<uint32_t> cigar;        // BAM-encoded ops: len<<4 | op
+    std::vector<uint8_t> seq;           // 4-bit bases, two per byte, high nibble first; each record byte aligned
+    std::vector<uint8_t> qual;          // phred bytes; empty unless requested
+
+    size_t n_reads() const { return pos.size(); }
+    size_t n_contigs() const { return names.size(); }
+    void clear();
+    // bytes the roofline accounting uses: records + draft (+ quals)
+    uint64_t algorithmic_input_bytes(bool with_qual) const;
+};
+
+// Loads the given contigs (all contigs of the FASTA index, in index order, when `names` is empty)
+// and every BAM record placed on them.  Uses <bam>.bai to seek when a subset is requested and a
+// single sequential pass otherwise.  Returns false and fills *err on any I/O / format problem.
+bool load_stream(const std::string& fasta, const std::string& bam, const std::vector<std::string>& names,
+                 bool with_qual, ReadStream* out, std::string* err);
+
+// Mean-insert-size probe of config_init (reference: source/lib/config.c:80-101): scans the first
+// records of the BAM; returns sum/count with count starting at 1, and the first qualifying l_qseq.
+bool bam_insert_probe(const std::string& bam, uint32_t count_read_ins, uint32_t max_ins_len, uint32_t* mean_out,
+                      int32_t* read_len_out);
+
+}  // namespace np

@@ -1,0 +1,348 @@
+// Synthetic draft + short-read workload generator.  See np_synth.h.
+#include "np_synth.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "np_bam.h"
+
+namespace np {
+
+namespace {
+
+struct Rng {
+    uint64_t s[4];
+    explicit Rng(uint64_t seed) {
+        uint64_t z = seed;
+        for (int i = 0; i < 4; ++i) {   // splitmix64 seeding
+            z += 0x9e3779b97f4a7c15ULL;
+            uint64_t x = z;
+            x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+            x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+            s[i] = x ^ (x >> 31);
+        }
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {   // xoshiro256**
+        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
+    bool chance(double p) { return p > 0 && uni() < p; }
+    double normal() {
+        double u1 = uni(), u2 = uni();
+        if (u1 < 1e-300) u1 = 1e-300;
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    }
+};
+
+const char kBases[4] = {'A', 'C', 'G', 'T'};
+inline uint8_t nt16(char c) {
+    switch (c) {
+        case 'A': case 'a': return 1;
+        case 'C': case 'c': return 2;
+        case 'G': case 'g': return 4;
+        case 'T': case 't': return 8;
+        default: return 15;
+    }
+}
+
+struct TmpRead {
+    int32_t pos;
+    uint16_t flag;
+    uint8_t mapq;
+    int32_t isize;
+    uint32_t cig_beg, cig_n;
+    uint32_t seq_beg, l_qseq;   // into the unpacked base / qual pools
+};
+
+struct Col { char op; int32_t dcoord; char base; };   // one alignment column of a read against the draft
+
+}  // namespace
+
+void synth_default_params(np_synth_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->seed = 20250117;
+    p->depth = 30;
+    p->read_len = 150;
+    p->frag_mean = 300;
+    p->frag_sd = 30;
+    p->draft_sub = 0.001;
+    p->draft_indel = 0.005;
+    p->draft_lower = 0.0;
+    p->read_sub = 0.001;
+    p->read_indel = 0.0001;
+    p->softclip_rate = 0.005;
+    p->dup_rate = 0.002;
+    p->supp_rate = 0.001;
+    p->sec_rate = 0.001;
+    p->unmapped_rate = 0.001;
+    p->lowmapq_rate = 0.01;
+    p->weird_rate = 0.0;
+    p->with_qual = 0;
+}
+
+bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStream* out) {
+    out->clear();
+    out->ctg_off.push_back(0);
+    Rng rng(p.seed);
+    std::vector<TmpRead> reads;
+    std::vector<uint32_t> cig_pool;
+    std::vector<char> base_pool;
+    std::vector<uint8_t> qual_pool;
+    std::vector<Col> cols;
+    for (int c = 0; c < p.n_contigs; ++c) {
+        const int32_t Lt = p.contig_len[c];
+        reads.clear(); cig_pool.clear(); base_pool.clear(); qual_pool.clear();
+        // ---- truth
+        std::string T(Lt, 'A');
+        for (int32_t i = 0; i < Lt; ++i) T[i] = kBases[rng.below(4)];
+        // ---- draft = truth + edits.  dpos[t]: draft coordinate of truth base t (or -1 when the draft
+        // lacks it); dins[t]: number of extra draft bases inserted right before truth base t.
+        std::vector<int32_t> dpos(Lt + 1, -1);
+        std::vector<uint8_t> dins(Lt + 1, 0);
+        std::string D;
+        D.reserve((size_t)Lt + Lt / 100);
+        for (int32_t t = 0; t < Lt;) {
+            if (t > 0 && rng.chance(p.draft_indel * 0.5)) {   // draft insertion, 1-3 bp, sometimes homopolymer
+                int n = 1 + (int)rng.below(3);
+                bool hp = rng.chance(0.5);
+                for (int k = 0; k < n; ++k) D.push_back(hp ? T[t - 1] : kBases[rng.below(4)]);
+                dins[t] = (uint8_t)n;
+            }
+            if (t > 0 && rng.chance(p.draft_indel * 0.5)) {   // draft deletion, 1-3 bp
+                int n = 1 + (int)rng.below(3);
+                for (int k = 0; k < n && t < Lt - 1; ++k) dpos[t++] = -1;
+                continue;
+            }
+            char b = T[t];
+            if (rng.chance(p.draft_sub)) b = kBases[(std::find(kBases, kBases + 4, b) - kBases + 1 + rng.below(3)) & 3];
+            dpos[t] = (int32_t)D.size();
+            D.push_back(b);
+            ++t;
+        }
+        const int32_t Ld = (int32_t)D.size();
+        if (p.draft_lower > 0)
+            for (int32_t i = 0; i < Ld; ++i)
+                if (rng.chance(p.draft_lower)) {   // short lowercase runs, like a previous round's output
+                    int n = 1 + (int)rng.below(4);
+                    for (int k = 0; k < n && i + k < Ld; ++k) D[i + k] = (char)(D[i + k] + 32);
+                    i += n;
+                }
+        // ---- reads
+        const int RL = p.read_len;
+        uint64_t n_pairs = (uint64_t)((double)Lt * p.depth / (2.0 * RL) + 0.5);
+        if (Lt < RL + 2) n_pairs = 0;
+        for (uint64_t pi = 0; pi < n_pairs; ++pi) {
+            int32_t frag = (int32_t)std::lround(p.frag_mean + p.frag_sd * rng.normal());
+            if (frag < RL) frag = RL;
+            if (frag > Lt) frag = Lt;
+            int32_t f = (int32_t)rng.below((uint32_t)(Lt - frag + 1));
+            bool swap = rng.chance(0.5);   // which mate is on the forward strand
+            int32_t starts[2] = {f, f + frag - RL};
+            int32_t mate_pos[2] = {-1, -1};
+            size_t first_idx = reads.size();
+            for (int m = 0; m < 2; ++m) {
+                // alignment columns of truth[a..) against the draft, plus read errors
+                cols.clear();
+                int32_t t = starts[m], q = 0;
+                while (q < RL && t < Lt) {
+                    if (!cols.empty() && dins[t]) {
+                        int32_t d0 = (dpos[t] >= 0 ? dpos[t] : -1);
+                        // extra draft bases sit right before dpos of the next kept truth base
+                        int32_t tt = t;
+                        while (tt < Lt && dpos[tt] < 0) ++tt;
+                        d0 = (tt < Lt ? dpos[tt] : Ld) - dins[t];
+                        for (int k = 0; k < dins[t]; ++k) cols.push_back(Col{'D', d0 + k, 0});
+                    }
+                    if (!cols.empty() && rng.chance(p.read_indel * 0.5)) {   // read deletion
+                        if (dpos[t] >= 0) cols.push_back(Col{'D', dpos[t], 0});
+                        ++t;
+                        continue;
+                    }
+                    if (!cols.empty() && rng.chance(p.read_indel * 0.5)) {   // read insertion
+                        cols.push_back(Col{'I', -1, kBases[rng.below(4)]});
+                        ++q;
+                        continue;
+                    }
+                    char b = T[t];
+                    if (rng.chance(p.read_sub)) b = kBases[(std::find(kBases, kBases + 4, b) - kBases + 1 + rng.below(3)) & 3];
+                    if (dpos[t] >= 0) cols.push_back(Col{'M', dpos[t], b});
+                    else cols.push_back(Col{'I', -1, b});
+                    ++q; ++t;
+                }
+                // optional soft clips
+                int clipL = 0, clipR = 0;
+                if (rng.chance(p.softclip_rate)) {
+                    int k = 3 + (int)rng.below(40);
+                    if (rng.chance(0.5)) clipL = k; else clipR = k;
+                }
+                // left end: turn the first clipL query bases into S, then make the alignment start with M
+                size_t lo = 0, hi = cols.size();
+                int sL = 0, sR = 0;
+                while (lo < hi && (sL < clipL || cols[lo].op != 'M')) {
+                    if (cols[lo].op != 'D') ++sL;
+                    ++lo;
+                }
+                while (hi > lo && (sR < clipR || cols[hi - 1].op != 'M')) {
+                    if (cols[hi - 1].op != 'D') ++sR;
+                    --hi;
+                }
+                if (lo >= hi) continue;   // nothing aligned (can only happen for absurd parameters)
+                TmpRead r;
+                r.pos = cols[lo].dcoord;
+                r.cig_beg = (uint32_t)cig_pool.size();
+                r.seq_beg = (uint32_t)base_pool.size();
+                // sequence = every non-D column in order (clipped bases stay in SEQ)
+                for (const Col& cl : cols)
+                    if (cl.op != 'D') base_pool.push_back(cl.base);
+                r.l_qseq = (uint32_t)(base_pool.size() - r.seq_beg);
+                if (p.with_qual)
+                    for (uint32_t k = 0; k < r.l_qseq; ++k) qual_pool.push_back((uint8_t)(25 + rng.below(16)));
+                auto push_op = [&](uint32_t op, uint32_t len) {
+                    if (!len) return;
+                    if (cig_pool.size() > r.cig_beg && (cig_pool.back() & 0xf) == op) cig_pool.back() += len << 4;
+                    else cig_pool.push_back(len << 4 | op);
+                };
+                bool weird = rng.chance(p.weird_rate);
+                int wkind = weird ? (int)rng.below(5) : -1;
+                if (wkind == 0 && sL == 0) {
+                    // hard clip on a primary record: SEQ does not hold the clipped bases, the walk still
+                    // advances the query cursor (reference: source/lib/contig.c:321-324)
+                    push_op(5, 5 + rng.below(20));
+                }
+                push_op(4, (uint32_t)sL);
+                bool used_eqx = false;
+                for (size_t k = lo; k < hi; ++k) {
+                    uint32_t op = cols[k].op == 'M' ? 0u : (cols[k].op == 'I' ? 1u : 2u);
+                    if (wkind == 1 && op == 0 && !used_eqx && k > lo + 20 && k + 20 < hi) {
+                        // a short '='/'X' stretch (ops the reference walk ignores entirely)
+                        uint32_t n = 0;
+                        while (n < 6 && k + n < hi && cols[k + n].op == 'M') ++n;
+                        push_op(rng.chance(0.5) ? 7u : 8u, n);
+                        k += n - 1;
+                        used_eqx = true;
+                        continue;
+                    }
+                    if (wkind == 2 && op == 2 && !used_eqx) { push_op(3, 1); used_eqx = true; continue; }   // N
+                    push_op(op, 1);
+                }
+                push_op(4, (uint32_t)sR);
+                if (wkind == 3) push_op(5, 3 + rng.below(9));   // trailing hard clip
+                r.cig_n = (uint32_t)(cig_pool.size() - r.cig_beg);
+                if (wkind == 4 && r.pos == 0 && r.cig_n >= 1 && sL >= 2) {
+                    // leading insertion at contig position 0 (reference: source/lib/contig.c:315-319)
+                    cig_pool[r.cig_beg] = (uint32_t)sL << 4 | 1u;
+                }
+                bool fwd = (m == 0) != swap;
+                uint16_t flag = (uint16_t)(0x1 | 0x2 | (fwd ? 0x20 : 0x10) | (m == 0 ? 0x40 : 0x80));
+                if (rng.chance(p.dup_rate)) flag |= 0x400;
+                if (rng.chance(p.supp_rate)) flag |= 0x800;
+                if (rng.chance(p.sec_rate)) flag |= 0x100;
+                r.flag = flag;
+                r.mapq = rng.chance(p.lowmapq_rate) ? (uint8_t)rng.below(31) : 60;
+                r.isize = (m == 0) ? frag : -frag;
+                if (rng.chance(0.002)) r.isize = (m == 0 ? 1 : -1) * (int32_t)(20000 + rng.below(100000));   // chimeric pair
+                mate_pos[m] = r.pos;
+                reads.push_back(r);
+                if (rng.chance(p.unmapped_rate)) {   // an unmapped mate placed at this position, no CIGAR
+                    TmpRead u = r;
+                    u.flag = (uint16_t)(0x1 | 0x4 | (m == 0 ? 0x80 : 0x40));
+                    u.cig_beg = (uint32_t)cig_pool.size();
+                    u.cig_n = 0;
+                    u.mapq = 0;
+                    u.isize = 0;
+                    reads.push_back(u);
+                }
+            }
+            (void)first_idx; (void)mate_pos;
+        }
+        // ---- coordinate sort (stable) and append to the stream
+        std::vector<uint32_t> order(reads.size());
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return reads[a].pos < reads[b].pos; });
+        char nm[64];
+        snprintf(nm, sizeof(nm), "%s%04d", prefix.c_str(), c + 1);
+        out->names.push_back(nm);
+        out->ctg_len.push_back(Ld);
+        out->draft += D;
+        out->ctg_off.push_back((uint32_t)out->draft.size());
+        out->read_begin.push_back(out->n_reads());
+        for (uint32_t oi : order) {
+            const TmpRead& r = reads[oi];
+            out->pos.push_back(r.pos);
+            out->ctg.push_back((uint32_t)c);
+            out->flag.push_back(r.flag);
+            out->n_cigar.push_back((uint16_t)r.cig_n);
+            out->l_qseq.push_back((int32_t)r.l_qseq);
+            out->mapq.push_back(r.mapq);
+            out->isize.push_back(r.isize);
+            out->cigar_off.push_back(out->cigar.size());
+            out->seq_off.push_back(out->seq.size());
+            out->cigar.insert(out->cigar.end(), cig_pool.begin() + r.cig_beg, cig_pool.begin() + r.cig_beg + r.cig_n);
+            for (uint32_t k = 0; k < r.l_qseq; k += 2) {
+                uint8_t hi4 = nt16(base_pool[r.seq_beg + k]);
+                uint8_t lo4 = (k + 1 < r.l_qseq) ? nt16(base_pool[r.seq_beg + k + 1]) : 0;
+                out->seq.push_back((uint8_t)(hi4 << 4 | lo4));
+            }
+            out->qual_off.push_back(out->qual.size());
+            if (p.with_qual)
+                out->qual.insert(out->qual.end(), qual_pool.begin() + r.seq_beg, qual_pool.begin() + r.seq_beg + r.l_qseq);
+        }
+    }
+    out->read_begin.push_back(out->n_reads());
+    return true;
+}
+
+bool write_stream_files(const ReadStream& s, const std::string& fasta, const std::string& bam, int level,
+                        std::string* err) {
+    FILE* fp = fopen(fasta.c_str(), "w");
+    if (!fp) { *err = "cannot write " + fasta; return false; }
+    FILE* fi = fopen((fasta + ".fai").c_str(), "w");
+    if (!fi) { fclose(fp); *err = "cannot write " + fasta + ".fai"; return false; }
+    const int W = 60;
+    int64_t off = 0;
+    for (size_t c = 0; c < s.n_contigs(); ++c) {
+        off += fprintf(fp, ">%s\n", s.names[c].c_str());
+        int64_t L = s.ctg_len[c];
+        fprintf(fi, "%s\t%lld\t%lld\t%d\t%d\n", s.names[c].c_str(), (long long)L, (long long)off, W, W + 1);
+        const char* d = s.draft.data() + s.ctg_off[c];
+        for (int64_t i = 0; i < L; i += W) {
+            int n = (int)std::min<int64_t>(W, L - i);
+            fwrite(d + i, 1, n, fp);
+            fputc('\n', fp);
+            off += n + 1;
+        }
+    }
+    fclose(fp);
+    fclose(fi);
+    BamHeader h;
+    h.text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (size_t c = 0; c < s.n_contigs(); ++c) {
+        h.names.push_back(s.names[c]);
+        h.lens.push_back((uint32_t)s.ctg_len[c]);
+        h.text += "@SQ\tSN:" + s.names[c] + "\tLN:" + std::to_string(s.ctg_len[c]) + "\n";
+    }
+    BamWriter w;
+    if (!w.open(bam, h, level)) { *err = "cannot write " + bam; return false; }
+    bool have_q = !s.qual.empty();
+    char qn[32];
+    for (size_t i = 0; i < s.n_reads(); ++i) {
+        snprintf(qn, sizeof(qn), "r%zu", i);
+        const uint8_t* q = have_q ? s.qual.data() + s.qual_off[i] : nullptr;
+        if (!w.write((int32_t)s.ctg[i], s.pos[i], s.mapq[i], s.flag[i], (int32_t)s.ctg[i], s.pos[i], s.isize[i], qn,
+                     s.cigar.data() + s.cigar_off[i], s.n_cigar[i], s.seq.data() + s.seq_off[i], q, s.l_qseq[i])) {
+            *err = "BAM write failed";
+            return false;
+        }
+    }
+    if (!w.close()) { *err = "BAM/BAI close failed"; return false; }
+    return true;
+}
+
+}  // namespace np

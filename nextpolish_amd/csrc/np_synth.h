@@ -1,0 +1,29 @@
+// Synthetic polishing workload generator (SURVEY.md §8d "synthetic inputs"): a truth genome, a
+// draft assembly derived from it by long-read-assembly-like edits, and paired-end short reads
+// sampled from the truth whose CIGARs against the *draft* follow from the known edit script.
+// Output is a decoded ReadStream (for the HBM-resident benchmark) that can also be serialised as
+// FASTA(+.fai) and coordinate-sorted BAM(+.bai) so the CPU reference binary reads the same data.
+// Deterministic for a given parameter block (own xoshiro256** stream, no libc rand).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "np_stream.h"
+
+#include "../../include/nextpolish1.h"
+typedef np1_synth_params np_synth_params;   // field documentation: see the comments below
+// seed; n_contigs + contig_len[] (truth lengths); depth (mean short-read depth); read_len (150);
+// frag_mean/frag_sd (300/30); draft_sub/draft_indel (per-base draft error rates 0.001/0.005);
+// draft_lower (fraction of draft bases written lowercase); read_sub/read_indel (0.001/0.0001);
+// softclip_rate (0.005); dup/supp/sec/unmapped_rate (flag mix); lowmapq_rate (mapq in [0,30]);
+// weird_rate (rare CIGAR shapes: H on a primary record, N, =/X ...; 0 for benchmarks); with_qual.
+
+namespace np {
+void synth_default_params(np_synth_params* p);
+// Generates the batch.  `contig_name_prefix` + index names the contigs.
+bool synth_stream(const np_synth_params& p, const std::string& contig_name_prefix, ReadStream* out);
+// Serialises a stream (needs qualities loaded unless write_qual_ff) to fasta(+.fai) and bam(+.bai).
+bool write_stream_files(const ReadStream& s, const std::string& fasta, const std::string& bam, int bgzf_level,
+                        std::string* err);
+}  // namespace np

@@ -1,0 +1,843 @@
+/* oracle/np1_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see np1_oracle.h).
+ *
+ * CPU restatement of nextpolish1.so's score_chain and kmer_count on a decoded record
+ * stream.  Every routine cites the reference lines it restates; data structures mirror
+ * the reference's per-base lists so that first-seen ordering, uint16 counters and the
+ * traversal quirks fall out naturally.  Written from the behaviour described in
+ * SURVEY.md appendix A/A2 and checked against the compiled reference (oracle/_ref).
+ */
+#include "np1_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define BASE_DEL 3
+#define FLAG_ZERO 1
+#define FLAG_COVERAGE 2
+#define MAX_MAPQ 60
+
+static int64_t g_updates;
+int64_t np1o_last_update_count(void) { return g_updates; }
+void np1o_free(void* p) { free(p); }
+
+/* ---- nt16 <-> char tables (reference: source/lib/base.c:5-15) */
+static const char basetostr[] = "=ACMGRSVTWYHKDBN";
+static uint8_t strtobase(uint8_t c) {
+    /* the reference table has 100 entries indexed by the upper-cased character */
+    switch (c) {
+        case '=': return 0;  case 'A': return 1;  case 'C': return 2;  case 'M': return 3;
+        case 'G': return 4;  case 'R': return 5;  case 'S': return 6;  case 'V': return 7;
+        case 'T': return 8;  case 'W': return 9;  case 'Y': return 10; case 'H': return 11;
+        case 'K': return 12; case 'D': return 13; case 'B': return 14;
+        default: return 15;
+    }
+}
+
+/* ---- per-slot state (reference: source/lib/base.h:28-48) */
+typedef struct { uint16_t kmer, count; } okmer;
+typedef struct { uint8_t base; uint16_t kmer; double score; } oscore;
+typedef struct {
+    uint8_t base, flag;
+    uint16_t refkmer, count;
+    uint32_t nk, capk;
+    okmer* k;
+    uint32_t ns;
+    oscore s[16];   /* states are keyed by the 4-bit base => at most 16 */
+} oslot;
+typedef struct { oslot m; oslot* ins; int32_t nins; } obase;
+
+typedef struct {
+    const np1o_contig* in;
+    const np1o_configure* cfg;
+    obase* b;
+    int32_t L;
+    int32_t inslength;
+    int filter_kind;   /* 1: contig_read_fliter1 (score_chain); 0: contig_read_fliter (kmer_count) */
+} octg;
+
+static void slot_init(oslot* s) {   /* base.c:17-32 */
+    memset(s, 0, sizeof(*s));
+    s->base = 3;
+}
+static void slot_free(oslot* s) { free(s->k); }
+
+static void slot_add_data(oslot* s, uint16_t kmer) {   /* base.c:60-71, seqlist.c:84-101 (uint16 scan index) */
+    okmer* hit = NULL;
+    for (uint16_t i = 0; i < s->nk; i++)
+        if (s->k[i].kmer == kmer) { hit = &s->k[i]; break; }
+    if (!hit) {
+        if (s->nk == s->capk) {
+            s->capk += s->capk / 2 + 1;
+            s->k = (okmer*)realloc(s->k, s->capk * sizeof(okmer));
+        }
+        s->k[s->nk].kmer = kmer;
+        s->k[s->nk].count = 1;
+        s->nk++;
+    } else {
+        hit->count++;
+    }
+    s->count++;
+    g_updates++;
+}
+
+static oscore* slot_max_score(oslot* s) {   /* base.c:185-197: first strictly greatest */
+    oscore* q = NULL;
+    if (s->ns) {
+        q = &s->s[0];
+        for (uint32_t i = 0; i < s->ns; i++)
+            if (s->s[i].score > q->score) q = &s->s[i];
+    }
+    return q;
+}
+static oscore* slot_find_score(oslot* s, uint8_t base) {
+    for (uint32_t i = 0; i < s->ns; i++)
+        if (s->s[i].base == base) return &s->s[i];
+    return NULL;
+}
+static oscore* slot_get_score(oslot* s, uint16_t kmer) {   /* base.c:171-178 */
+    if (kmer) return slot_find_score(s, kmer & 0xf);
+    return slot_max_score(s);
+}
+static void slot_add_score(oslot* s, uint16_t kmer, double score) {   /* base.c:159-169 */
+    oscore* r = slot_find_score(s, kmer & 0xf);
+    if (!r) r = &s->s[s->ns++];
+    r->base = kmer & 0xf;
+    r->kmer = kmer;
+    r->score = score;
+}
+static double slot_coverage(oslot* s, uint16_t base) {   /* base.c:79-89 */
+    uint32_t count = 0;
+    for (uint32_t i = 0; i < s->nk; i++)
+        if ((s->k[i].kmer & 0xf) == base) count += s->k[i].count;
+    return count / (double)s->count;
+}
+
+/* ---- traversal in (base, insert-column) order (reference: source/lib/contig.c:385-422) */
+static oslot* ctg_next(octg* c, int32_t* i, int32_t* j) {
+    if (*i + 1 >= c->L) { *i = c->L; return &c->b[c->L - 1].m; }
+    obase* p = &c->b[*i];
+    if (p->ins == NULL || p->nins == *j) { (*i)++; *j = 0; return &c->b[*i].m; }
+    (*j)++;
+    return &p->ins[*j - 1];
+}
+static oslot* ctg_prev(octg* c, int32_t* i, int32_t* j) {
+    if (*i - 1 < 0) { *i = -1; return &c->b[0].m; }
+    obase* p = &c->b[*i];
+    if (*j == 0) {
+        (*i)--;
+        p = &c->b[*i];
+        if (p->ins != NULL) *j = p->nins;
+    } else {
+        (*j)--;
+    }
+    if (*j == 0) return &p->m;
+    return &p->ins[*j - 1];
+}
+#define IN_RANGE(i, j, end) ((i) < (end) || ((i) == (end) && (j) == 0))
+
+/* ---- record helpers */
+static inline uint8_t seqi(const uint8_t* s, int32_t i) { return s[i >> 1] >> ((~i & 1) << 2) & 0xf; }
+#define OP(c) ((c) & 0xf)
+#define OPLEN(c) ((int32_t)((c) >> 4))
+enum { CMATCH = 0, CINS = 1, CDEL = 2, CREF_SKIP = 3, CSOFT = 4, CHARD = 5, CPAD = 6, CEQUAL = 7, CDIFF = 8 };
+
+static int32_t read_endpos(const np1o_contig* in, int64_t r) {   /* htslib bam_endpos */
+    if (!(in->flag[r] & 4) && in->n_cigar[r] > 0) {
+        const uint32_t* cg = in->cigar + in->cigar_off[r];
+        int32_t l = 0;
+        for (int k = 0; k < in->n_cigar[r]; k++) {
+            uint32_t op = OP(cg[k]);
+            if (op == CMATCH || op == CDEL || op == CREF_SKIP || op == CEQUAL || op == CDIFF) l += OPLEN(cg[k]);
+        }
+        return in->pos[r] + (l > 0 ? l : 1);
+    }
+    return in->pos[r] + 1;
+}
+
+static double read_cliprate(const np1o_contig* in, int64_t r) {   /* contig.c:632-646 */
+    if (in->n_cigar[r] == 0) return 0;   /* the reference reads out of bounds here; such reads never vote */
+    const uint32_t* cg = in->cigar + in->cigar_off[r];
+    int32_t addlen = 0;
+    if (OP(cg[0]) == CSOFT) addlen += OPLEN(cg[0]);
+    uint32_t last = cg[in->n_cigar[r] - 1];
+    if (OP(last) == CSOFT) addlen += OPLEN(last);
+    return in->l_qseq[r] > 0 ? addlen / (double)in->l_qseq[r] : 0;
+}
+
+static uint8_t read_filter(octg* c, int64_t r) {
+    const np1o_contig* in = c->in;
+    uint8_t result = 0;
+    if (c->filter_kind == 1) {   /* contig_read_fliter1, contig.c:667-677 */
+        if ((in->flag[r] & 0xC04) == 0) result = 1;
+        return result;
+    }
+    if ((in->flag[r] & 0xC04) == 0) {   /* contig_read_fliter, contig.c:648-665 */
+        int32_t length = in->isize[r] >= 0 ? in->isize[r] : -in->isize[r];
+        double cliprate = read_cliprate(in, r);
+        if ((length > 0 && length < c->cfg->read_tlen) || cliprate < c->cfg->max_clip_ratio_sgs) {
+            result = 1;
+            if (in->mapq[r] >= c->cfg->min_map_quality && (cliprate < c->cfg->max_clip_ratio_sgs + 0.05)) result = 2;
+        }
+    }
+    return result;
+}
+
+/* usable query window (reference: source/lib/contig.c:333-358).  The reference's two
+ * homopolymer loops have no bounds checks; running off either end can only produce
+ * qstart > qend (the record then contributes nothing), which is what we return. */
+static void cut_read(octg* c, int64_t r, int32_t* qstart, int32_t* qend) {
+    const np1o_contig* in = c->in;
+    const uint32_t* cg = in->cigar + in->cigar_off[r];
+    const uint8_t* seq = in->seq + in->seq_off[r];
+    int32_t lq = in->l_qseq[r], trim = c->cfg->trim_len_edge, addlen = 0;
+    if (OP(cg[0]) == CSOFT) addlen = OPLEN(cg[0]);
+    int32_t qs = trim + addlen;
+    uint32_t last = cg[in->n_cigar[r] - 1];
+    addlen = 0;
+    if (OP(last) == CSOFT) addlen = OPLEN(last);
+    int32_t qe = lq - trim - addlen - 1;
+    if (trim > 0) {
+        int dead = 0;
+        for (;;) {   /* while (seqi(qs) == seqi(qs-1)) qs++ */
+            if (qs >= lq) { dead = 1; break; }
+            if (seqi(seq, qs) != seqi(seq, qs - 1)) break;
+            qs++;
+        }
+        while (!dead) {   /* while (seqi(qe) == seqi(qe+1)) qe-- */
+            if (qe < 0 || qe + 1 >= lq) { dead = (qe < qs); break; }
+            if (seqi(seq, qe) != seqi(seq, qe + 1)) break;
+            qe--;
+        }
+        if (dead || qs > qe) { qs = 1; qe = 0; }
+    }
+    *qstart = qs;
+    *qend = qe;
+}
+
+static inline uint16_t left_kmer(uint16_t kmer, uint8_t base) { return (uint16_t)((kmer & 0xff) << 4 | base); }
+
+/* PASS 1: insertion columns (reference: source/lib/contig.c:202-245, flag argument 0) */
+static void parse_read_insert(octg* c, int64_t r, int32_t start, int32_t end) {
+    const np1o_contig* in = c->in;
+    if (!in->n_cigar[r]) return;
+    const uint32_t* cg = in->cigar + in->cigar_off[r];
+    int32_t pos = in->pos[r];
+    for (int i = 0; i < in->n_cigar[r]; ++i) {
+        switch (OP(cg[i])) {
+            case CMATCH: case CDEL: pos += OPLEN(cg[i]); break;
+            case CINS:
+                if (pos > start && pos <= end) {
+                    int32_t len = OPLEN(cg[i]);
+                    obase* b = &c->b[pos - 1];
+                    if (b->nins < len) {
+                        b->ins = (oslot*)realloc(b->ins, (size_t)len * sizeof(oslot));
+                        for (int32_t j = b->nins; j < len; j++, c->inslength++) {
+                            slot_init(&b->ins[j]);
+                            b->ins[j].flag = b->m.flag;
+                        }
+                        b->nins = len;
+                    }
+                }
+                break;
+        }
+    }
+}
+
+/* PASS 2: per-read pileup of 3-base contexts (reference: source/lib/contig.c:247-331) */
+static void parse_read(octg* c, int64_t r, int32_t start, int32_t end) {
+    const np1o_contig* in = c->in;
+    if (!in->n_cigar[r]) return;
+    uint16_t kmer = 0;
+    int32_t pos = in->pos[r], qpos = 0, qstart, qend, i, j, k, len;
+    uint8_t curcigar, lastcigar = CINS;
+    const uint32_t* cg = in->cigar + in->cigar_off[r];
+    const uint8_t* seq = in->seq + in->seq_off[r];
+    cut_read(c, r, &qstart, &qend);
+    for (i = 0; i < in->n_cigar[r]; ++i) {
+        len = OPLEN(cg[i]);
+        curcigar = OP(cg[i]);
+        switch (curcigar) {
+            case CMATCH: case CDEL:
+                for (j = 0; j < len; j++, pos++) {
+                    if (pos >= start && pos <= end && qpos >= qstart && qpos <= qend) {
+                        if (lastcigar != CINS && pos > start && (qpos > qstart || (qpos == qstart && lastcigar == CDEL))) {
+                            obase* pb = &c->b[pos - 1];
+                            for (k = 0; k < pb->nins; k++) {
+                                kmer = left_kmer(kmer, BASE_DEL);
+                                slot_add_data(&pb->ins[k], kmer);
+                            }
+                        }
+                        if (curcigar == CDEL) kmer = left_kmer(kmer, BASE_DEL);
+                        else kmer = left_kmer(kmer, seqi(seq, qpos));
+                        slot_add_data(&c->b[pos].m, kmer);
+                    }
+                    if (curcigar != CDEL) qpos++;
+                    lastcigar = curcigar;
+                }
+                break;
+            case CINS:
+                if (pos) {
+                    obase* pb = (pos - 1 < c->L) ? &c->b[pos - 1] : NULL;
+                    for (j = 0; j < len; j++, qpos++) {
+                        if (pos > start && pos <= end && qpos >= qstart && qpos <= qend) {
+                            kmer = left_kmer(kmer, seqi(seq, qpos));
+                            slot_add_data(&pb->ins[j], kmer);
+                        }
+                    }
+                    if (pos > start && pos <= end && qpos > qstart && qpos <= qend + 1) {
+                        for (; j < pb->nins; j++) {
+                            kmer = left_kmer(kmer, BASE_DEL);
+                            slot_add_data(&pb->ins[j], kmer);
+                        }
+                    }
+                    lastcigar = curcigar;
+                } else {
+                    qpos += len;
+                    qstart += len;
+                    lastcigar = curcigar;
+                }
+                break;
+            case CHARD: case CSOFT:
+                qpos += len;
+                break;
+        }
+        if (pos > end) break;
+    }
+}
+
+/* region iteration = htslib overlap query in file order (hts.c hts_itr_next):
+ * records with pos < end+1 and endpos > start; stop at the first record with pos >= end+1.
+ * first_candidate(): records are position sorted, so nothing before the first record whose
+ * pos could reach `start` matters; we simply scan from a lower bound computed with max_span. */
+typedef struct { int64_t lo; int32_t max_span; } oscan;
+static int32_t stream_max_span(const np1o_contig* in) {
+    int32_t m = 1;
+    for (int64_t r = 0; r < in->n_reads; r++) {
+        int32_t s = read_endpos(in, r) - in->pos[r];
+        if (s > m) m = s;
+    }
+    return m;
+}
+static int64_t lower_bound_pos(const np1o_contig* in, int32_t p) {   /* first r with pos[r] >= p */
+    int64_t lo = 0, hi = in->n_reads;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (in->pos[mid] < p) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+static void create_insert(octg* c, int32_t start, int32_t end, int32_t max_span) {   /* contig.c:170-180 */
+    const np1o_contig* in = c->in;
+    for (int64_t r = lower_bound_pos(in, start - max_span); r < in->n_reads; r++) {
+        if (in->pos[r] >= end + 1) break;
+        if (read_endpos(in, r) <= start) continue;
+        if (read_filter(c, r) >= 1) parse_read_insert(c, r, start, end);
+    }
+}
+
+static void parse_region(octg* c, int32_t start, int32_t end, uint8_t level, int32_t max_span) {   /* contig.c:688-704 */
+    const np1o_contig* in = c->in;
+    for (int64_t r = lower_bound_pos(in, start - max_span); r < in->n_reads; r++) {
+        if (in->pos[r] >= end + 1) break;
+        if (read_endpos(in, r) <= start) continue;
+        if (read_filter(c, r) == level) parse_read(c, r, start, end);
+    }
+}
+
+static void as_read(octg* c, int32_t start, int32_t end) {   /* contig.c:373-383 */
+    uint16_t kmer = 0;
+    int32_t i = start, j = 0;
+    oslot* p = &c->b[start].m;
+    while (IN_RANGE(i, j, end)) {
+        p->refkmer = kmer = left_kmer(kmer, p->base);
+        slot_add_data(p, kmer);
+        p = ctg_next(c, &i, &j);
+    }
+}
+
+static void calculate_score(oslot* cur, oslot* last, double rate) {   /* contig.c:424-454 */
+    cur->ns = 0;
+    double score = 0;
+    uint16_t temp, count, total = cur->count;
+    if (total > 1) total--;
+    for (uint32_t i = 0; i < cur->nk; i++) {
+        okmer* p = &cur->k[i];
+        temp = p->kmer >> 4;
+        if ((temp & 0xf) == 0) score = slot_max_score(last)->score;
+        else score = slot_get_score(last, temp)->score;
+        count = p->count;
+        if (p->kmer == cur->refkmer && cur->count > 1) count--;
+        score += count - total * rate;
+        oscore* q = slot_get_score(cur, p->kmer);
+        if (q == NULL || q->score < score) slot_add_score(cur, p->kmer, score);
+    }
+}
+
+static void region_score(octg* c, int32_t start, int32_t end, double rate) {   /* contig.c:456-471 */
+    int32_t i = start, j = 0;
+    oslot temp;
+    slot_init(&temp);
+    oslot *p = &temp, *q = &c->b[start].m;
+    for (uint32_t t = 0; t < q->nk; t++) slot_add_score(&temp, q->k[t].kmer >> 4, 0);
+    while (IN_RANGE(i, j, end)) {
+        calculate_score(q, p, rate);
+        p = q;
+        q = ctg_next(c, &i, &j);
+    }
+}
+
+static void region_correct(octg* c, int32_t start, int32_t end) {   /* contig.c:473-496 */
+    oslot* base = &c->b[end].m;
+    oscore* score = slot_max_score(base);
+    int32_t i = end, j = 0;
+    while (i > start || (i == start && j == 0)) {
+        base->base = score->base;
+        if (base->count == 1) base->flag |= FLAG_ZERO; else base->flag &= (uint8_t)~FLAG_ZERO;
+        if (slot_coverage(base, base->base) < c->cfg->min_count_ratio_skip) base->flag |= FLAG_COVERAGE;
+        else base->flag &= (uint8_t)~FLAG_COVERAGE;
+        base = ctg_prev(c, &i, &j);
+        score = slot_get_score(base, score->kmer >> 4);
+    }
+}
+
+/* ---- low-quality regions (reference: source/lib/contig.c:498-620) */
+typedef struct { int32_t* v; int32_t n, cap; } ilist;
+static void il_push(ilist* l, int32_t x) {
+    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 64; l->v = (int32_t*)realloc(l->v, l->cap * sizeof(int32_t)); }
+    l->v[l->n++] = x;
+}
+static void brim_no_ext(octg* c, uint8_t flag, int32_t bstart, int32_t bend, int32_t* start, int32_t* end) {
+    (void)flag;
+    int32_t e = c->cfg->ext_len_edge;
+    *start = *start >= bstart + e ? *start - e : bstart;
+    *end = *end <= bend - e ? *end + e : bend;
+}
+static void brim_with_ext(octg* c, uint8_t flag, int32_t bstart, int32_t bend, int32_t* start, int32_t* end) {
+    brim_no_ext(c, flag, bstart, bend, start, end);
+    int32_t p = *start + 1;
+    while (*start > bstart && (c->b[p].m.base == c->b[p - 1].m.base || (c->b[p - 1].m.flag & flag) != 0)) {
+        (*start)--;
+        p--;
+    }
+    p = *end - 1;
+    while (*end < bend && (c->b[p].m.base == c->b[p + 1].m.base || (c->b[p + 1].m.flag & flag) != 0)) {
+        (*end)++;
+        p++;
+    }
+}
+typedef void (*brimfn)(octg*, uint8_t, int32_t, int32_t, int32_t*, int32_t*);
+
+static ilist get_region(octg* c, int32_t start, int32_t end, uint16_t gap, uint16_t con, uint8_t flag, brimfn brim) {
+    ilist result = {0, 0, 0};
+    int32_t i = start, j = 0, qstart = -1, qend = -1;
+    uint16_t pgap = 0, pcon = 0;
+    oslot* p = &c->b[start].m;
+    while (IN_RANGE(i, j, end)) {
+        if ((p->flag & flag) != 0) {
+            if (qstart == -1) { qstart = i; pcon = 1; }
+            else if (pgap == 0) pcon++;
+            else pcon = 1;
+            pgap = 0;
+            qend = i;
+        } else if (qstart != -1) {
+            pgap++;
+            if (pgap > gap) {
+                if (pcon > con) {
+                    brim(c, flag, start, end, &qstart, &qend);
+                    il_push(&result, qstart);
+                    il_push(&result, qend);
+                    if (qend > i) { i = qend; j = 0; }
+                }
+                qstart = qend = -1;
+            }
+        }
+        p = ctg_next(c, &i, &j);
+    }
+    if (qstart != -1) {
+        brim(c, flag, start, end, &qstart, &qend);
+        il_push(&result, qstart);
+        il_push(&result, qend);
+    }
+    return result;
+}
+
+static void merge_region(ilist* l) {   /* contig.c:595-620, literal */
+    if (l->n == 0) return;
+    int32_t *pstart = l->v, *pend = pstart + 1, *qstart = pstart, *qend = pend, length = 2;
+    for (int i = 0; i < l->n; i += 2) {
+        if (*pstart >= *qend) {
+            qstart += 2;
+            qend = qstart + 1;
+            if (qstart != pstart) *qstart = *pstart;
+            if (qend != pend) *qend = *pend;
+            length += 2;
+        } else {
+            while (*pstart < *qstart) qstart -= 2;
+            qend = qstart + 1;
+            *qend = *pend;
+        }
+        pstart += 2;
+        pend = pstart + 1;
+    }
+    l->n = length;
+}
+
+/* contig_score_correct (reference: source/lib/contig.c:706-734) */
+static void score_correct(octg* c, int32_t start, int32_t end, int32_t flag, double rate, int32_t max_span) {
+    int32_t level = flag & 0xf, insert = (flag >> 4) & 0xf;
+    if ((insert & 0x1) == 0) create_insert(c, start, end, max_span);
+    as_read(c, start, end);
+    parse_region(c, start, end, (uint8_t)level, max_span);
+    region_score(c, start, end, rate);
+    region_correct(c, start, end);
+    if (level == 2) {
+        ilist nd = get_region(c, start, end, 0, 0, 1, brim_no_ext);
+        if (nd.n != 0) {
+            merge_region(&nd);
+            for (int i = 0; i < nd.n; i += 2) {
+                parse_region(c, nd.v[i], nd.v[i + 1], 1, max_span);
+                region_score(c, nd.v[i], nd.v[i + 1], c->cfg->indel_balance_factor_sgs);
+                region_correct(c, nd.v[i], nd.v[i + 1]);
+            }
+        }
+        free(nd.v);
+    }
+}
+
+/* contig_get_contig without the trace list (reference: source/lib/contig.c:736-799) */
+static char* get_contig(octg* c, int32_t start, int32_t end, uint8_t flag, int32_t* out_len) {
+    int32_t i = start, j = 0, length = 0;
+    char* result = (char*)calloc(1, (size_t)c->L + (size_t)c->inslength + 1), *q = result;
+    oslot* p = &c->b[start].m;
+    uint8_t sign = 0;
+    while (IN_RANGE(i, j, end)) {
+        if (p->base == 3) {
+            if ((p->flag & flag) != 0) sign = 1;
+        } else {
+            *q = basetostr[p->base];
+            if (sign || (p->flag & flag) != 0) { *q += 32; sign = 0; }
+            q++;
+            length++;
+        }
+        p = ctg_next(c, &i, &j);
+    }
+    result[length] = '\0';
+    *out_len = length;
+    return result;
+}
+
+static octg* ctg_init(const np1o_contig* in, const np1o_configure* cfg) {   /* contig.c:81-102 */
+    octg* c = (octg*)calloc(1, sizeof(octg));
+    c->in = in;
+    c->cfg = cfg;
+    c->L = in->length;
+    c->b = (obase*)calloc((size_t)(in->length > 0 ? in->length : 1), sizeof(obase));
+    for (int32_t i = 0; i < in->length; i++) {
+        slot_init(&c->b[i].m);
+        uint8_t ch = (uint8_t)in->draft[i];
+        if (ch >= 97 && ch <= 122) { ch -= 32; c->b[i].m.flag |= FLAG_ZERO; }
+        c->b[i].m.base = strtobase(ch);
+    }
+    return c;
+}
+static void ctg_free(octg* c) {
+    for (int32_t i = 0; i < c->L; i++) {
+        for (int32_t j = 0; j < c->b[i].nins; j++) slot_free(&c->b[i].ins[j]);
+        free(c->b[i].ins);
+        slot_free(&c->b[i].m);
+    }
+    free(c->b);
+    free(c);
+}
+
+void np1o_default_config(np1o_configure* r) {   /* config.c:8-38 */
+    memset(r, 0, sizeof(*r));
+    r->trim_len_edge = 2; r->ext_len_edge = 2; r->min_map_quality = 0;
+    r->indel_balance_factor_sgs = 0.5; r->min_count_ratio_skip = 0.8;
+    r->min_len_ldr = 3; r->min_len_inter_kmer = 5; r->max_len_kmer = 50; r->max_count_kmer = 50;
+    r->min_depth_snp = 3; r->min_count_snp = 5; r->min_count_snp_link = 5;
+    r->ploidy = 2; r->indel_balance_factor_lgs = 0.33; r->max_indel_factor_lgs = 0.21;
+    r->max_snp_factor_lgs = 0.53; r->min_snp_factor_sgs = 0.34;
+    r->region_count = 10000; r->count_read_ins_sgs = 10000; r->max_ins_len_sgs = 10000;
+    r->max_ins_fold_sgs = 5; r->max_variant_count_lgs = 150000;
+    r->max_clip_ratio_sgs = 0.15; r->max_clip_ratio_lgs = 0.4;
+}
+
+/* score_chain (reference: source/lib/scorechain.c:3-15) */
+char* np1o_score_chain(const np1o_contig* in, const np1o_configure* cfg, int32_t* out_len) {
+    g_updates = 0;
+    if (in->length <= 0) { *out_len = 0; return (char*)calloc(1, 1); }
+    octg* c = ctg_init(in, cfg);
+    c->filter_kind = 1;
+    int32_t max_span = stream_max_span(in);
+    score_correct(c, 0, c->L - 1, 0x1, cfg->indel_balance_factor_sgs, max_span);
+    char* out = get_contig(c, 0, c->L - 1, FLAG_ZERO | FLAG_COVERAGE, out_len);
+    ctg_free(c);
+    return out;
+}
+
+/* ================= kmer_count (reference: source/lib/kmercount.c) ================= */
+
+static void create_insert_region(octg* c, ilist* regs, int32_t max_span) {   /* contig.c:182-200 */
+    c->filter_kind = 0;
+    for (int i = 0; i < regs->n; i += 2) create_insert(c, regs->v[i], regs->v[i + 1], max_span);
+}
+
+static int32_t get_length(octg* c, int32_t start, int32_t end) {   /* contig.c:801-809 */
+    int32_t i = start, j = 0, length = 0;
+    while (IN_RANGE(i, j, end)) { length++; ctg_next(c, &i, &j); }
+    return length;
+}
+
+static ilist split_region(octg* c, ilist* regs, uint8_t flag, uint8_t max) {   /* kmercount.c:128-173 */
+    ilist result = {0, 0, 0}, temp = {0, 0, 0};
+    for (int i = 0; i < regs->n; i += 2) {
+        int32_t* p = &regs->v[i];
+        il_push(&result, p[0]);
+        if (p[1] - p[0] > max) {
+            int32_t j = p[0], k = 0, qstart = -1, qend = -1;
+            oslot* q = &c->b[j].m;
+            temp.n = 0;
+            while (IN_RANGE(j, k, p[1])) {
+                if ((q->flag & flag) != 0) break;
+                q = ctg_next(c, &j, &k);
+            }
+            while (IN_RANGE(j, k, p[1])) {
+                if ((q->flag & flag) == 0) {
+                    if (qstart == -1) qstart = j;
+                    qend = j;
+                } else if (qstart != -1) {
+                    il_push(&temp, qstart);
+                    il_push(&temp, qend);
+                    qstart = qend = -1;
+                }
+                q = ctg_next(c, &j, &k);
+            }
+            for (j = 0; j < temp.n; j += 2) {
+                k = (temp.v[j] + temp.v[j + 1]) >> 1;
+                il_push(&result, k);
+                il_push(&result, k);
+            }
+        }
+        il_push(&result, p[1]);
+    }
+    free(temp.v);
+    return result;
+}
+
+typedef struct { uint8_t* region; int32_t length, qual, mapqual, num; } okscore;
+
+/* ss_parse_read_kmer with left = right = -1, flagzero = 0 (reference: source/lib/kmercount.c:365-465) */
+static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, okscore* ks) {
+    const np1o_contig* in = c->in;
+    if (!in->n_cigar[r]) return;
+    int32_t pos = in->pos[r], qpos = 0, qstart, qend, i, j, k, len, del = 0;
+    uint8_t curcigar, lastcigar = CINS;
+    const uint32_t* cg = in->cigar + in->cigar_off[r];
+    const uint8_t* seq = in->seq + in->seq_off[r];
+    const uint8_t* qual = in->qual + in->qual_off[r];
+    cut_read(c, r, &qstart, &qend);
+    ks->mapqual = in->mapq[r];
+    for (i = 0; i < in->n_cigar[r]; ++i) {
+        len = OPLEN(cg[i]);
+        curcigar = OP(cg[i]);
+        switch (curcigar) {
+            case CMATCH: case CDEL:
+                for (j = 0; j < len; j++, pos++) {
+                    if (pos >= start && pos <= end && qpos >= qstart && qpos <= qend) {
+                        if (lastcigar != CINS && pos > start && (qpos > qstart || (qpos == qstart && lastcigar == CDEL))) {
+                            obase* pb = &c->b[pos - 1];
+                            for (k = 0; k < pb->nins; k++) {
+                                ks->region[ks->length++] = BASE_DEL;
+                                pb->ins[k].flag &= (uint8_t)~FLAG_ZERO;
+                                del++;
+                            }
+                        }
+                        if (curcigar == CDEL) {
+                            ks->region[ks->length++] = BASE_DEL;
+                        } else {
+                            ks->region[ks->length++] = seqi(seq, qpos);
+                            ks->qual += qual[qpos];
+                        }
+                        c->b[pos].m.flag &= (uint8_t)~FLAG_ZERO;
+                    }
+                    if (curcigar != CDEL) qpos++;
+                    lastcigar = curcigar;
+                }
+                break;
+            case CINS:
+                if (pos) {
+                    obase* pb = (pos - 1 < c->L) ? &c->b[pos - 1] : NULL;
+                    for (j = 0; j < len; j++, qpos++) {
+                        if (pos > start && pos <= end && qpos >= qstart && qpos <= qend) {
+                            ks->region[ks->length++] = seqi(seq, qpos);
+                            ks->qual += qual[qpos];
+                            pb->ins[j].flag &= (uint8_t)~FLAG_ZERO;
+                        }
+                    }
+                    if (pos > start && pos <= end && qpos > qstart && qpos <= qend + 1) {
+                        for (; j < pb->nins; j++) {
+                            ks->region[ks->length++] = BASE_DEL;
+                            pb->ins[j].flag &= (uint8_t)~FLAG_ZERO;
+                            del++;
+                        }
+                    }
+                    lastcigar = curcigar;
+                } else {
+                    qpos += len;
+                    qstart += len;
+                    lastcigar = curcigar;
+                }
+                break;
+            case CHARD: case CSOFT:
+                qpos += len;
+                break;
+        }
+        if (pos > end) break;
+    }
+    if (ks->length > 0 && ks->length != del) ks->qual /= ks->length - del;
+    else ks->qual = 0;
+}
+
+typedef struct { okscore* v; int32_t n, cap; } kslist;
+
+/* ss_kmer_get_region (reference: source/lib/kmercount.c:332-363); returns nothing, mutates ks */
+static void kmer_get_region(octg* c, int64_t r, int32_t start, int32_t end, int32_t length, kslist* rd, okscore* ks) {
+    if (ks->region == NULL) ks->region = (uint8_t*)calloc(1, (size_t)length + 8);
+    parse_read_kmer(c, r, start, end, ks);
+    if (ks->length == length) {
+        okscore* hit = NULL;
+        for (int32_t i = 0; i < rd->n; i++)
+            if (memcmp(rd->v[i].region, ks->region, (size_t)rd->v[i].length) == 0) { hit = &rd->v[i]; break; }
+        if (!hit) {
+            ks->num = 1;
+            if (rd->n == rd->cap) { rd->cap = rd->cap ? rd->cap * 2 : 16; rd->v = (okscore*)realloc(rd->v, rd->cap * sizeof(okscore)); }
+            rd->v[rd->n++] = *ks;
+            ks->region = NULL;
+        } else {
+            hit->num++;
+            hit->mapqual += ks->mapqual;
+            hit->qual += ks->qual;
+        }
+    } else {
+        ks->mapqual = 0;
+    }
+}
+static void ks_clean(okscore* ks, int32_t length) {   /* kmercount.c:24-33 */
+    if (ks->region == NULL) ks->region = (uint8_t*)calloc(1, (size_t)length + 8);
+    ks->length = 0; ks->qual = 0; ks->mapqual = 0; ks->num = 0;
+}
+static int ks_compare(const okscore* a, const okscore* b) {   /* kmercount.c:63-88 */
+    if (a == b) return 0;
+    if (a->num != b->num) return a->num > b->num ? 1 : -1;
+    if (a->mapqual != b->mapqual) return a->mapqual > b->mapqual ? 1 : -1;
+    if (a->qual != b->qual) return a->qual > b->qual ? 1 : -1;
+    return 0;
+}
+
+/* ss_kmer_correct with nodepth = NULL, flagzero = 0 (reference: source/lib/kmercount.c:175-261).
+ * Spanning query = swapped-interval iterator (contig.c:1130-1135): records with pos < start and
+ * endpos > end+1 in file order, iteration ends at the first record with pos >= start; that
+ * terminating record is the "stale read" the reference's fallback loop keeps re-parsing. */
+static void kmer_correct(octg* c, ilist* regs, int32_t max_span) {
+    const np1o_contig* in = c->in;
+    kslist rd = {0, 0, 0};
+    c->filter_kind = 0;
+    for (int ri = 0; ri < regs->n; ri += 2) {
+        int32_t start = regs->v[ri], end = regs->v[ri + 1];
+        int32_t length = get_length(c, start, end), count = 0;
+        okscore ks;
+        memset(&ks, 0, sizeof(ks));
+        int have_ks = 0;
+        int64_t r0 = lower_bound_pos(in, start - max_span);
+        int64_t rstop = lower_bound_pos(in, start);   /* first record with pos >= start */
+        int64_t n_span = 0;
+        for (int64_t r = r0; r < rstop; r++) {
+            if (!(read_endpos(in, r) > end + 1)) continue;
+            n_span++;
+            if (read_filter(c, r) == 2) {
+                kmer_get_region(c, r, start, end, length, &rd, &ks);
+                have_ks = 1;
+                if (ks.mapqual == MAX_MAPQ) {
+                    count++;
+                    if (count >= c->cfg->max_count_kmer) break;
+                }
+                ks_clean(&ks, length);
+            }
+        }
+        /* the record the first loop stopped on: first record with pos >= start; when the contig has
+         * none, the next record in file order (another contig's) or, at EOF, the last record read */
+        int64_t stale = -1;
+        if (rstop < in->n_reads) stale = rstop;
+        else if (in->has_next) stale = in->n_reads;
+        else if (in->n_reads > 0) stale = in->n_reads - 1;
+        if (rd.n == 0 && stale >= 0) {
+            /* bug-compatible fallback (kmercount.c:212-217): one pass per spanning record, always
+             * testing and parsing the stale record */
+            for (int64_t t = 0; t < n_span; t++) {
+                if (read_filter(c, stale) == 1) {
+                    kmer_get_region(c, stale, start, end, length, &rd, &ks);
+                    have_ks = 1;
+                    ks_clean(&ks, length);
+                }
+            }
+        }
+        if (rd.n > 0) {
+            okscore* best = NULL;
+            if (count == c->cfg->max_count_kmer) {
+                int32_t want = MAX_MAPQ * count;
+                for (int32_t i = 0; i < rd.n; i++)
+                    if (rd.v[i].mapqual == want) { best = &rd.v[i]; break; }
+            }
+            if (best == NULL) {
+                best = &rd.v[0];
+                for (int32_t i = 0; i < rd.n; i++)
+                    if (ks_compare(best, &rd.v[i]) < 0) best = &rd.v[i];
+            }
+            /* contig_update_contig, contig.c:811-821 */
+            int32_t i = start, j = 0;
+            oslot* p = &c->b[start].m;
+            uint8_t* q = best->region;
+            while (IN_RANGE(i, j, end)) {
+                p->base = *q;
+                p = ctg_next(c, &i, &j);
+                q++;
+            }
+        }
+        if (have_ks) free(ks.region);
+        for (int32_t i = 0; i < rd.n; i++) free(rd.v[i].region);
+        rd.n = 0;
+    }
+    free(rd.v);
+}
+
+char* np1o_kmer_count(const np1o_contig* in, const np1o_configure* cfg, int32_t* out_len) {   /* kmercount.c:93-126 */
+    g_updates = 0;
+    if (in->length <= 0) { *out_len = 0; return (char*)calloc(1, 1); }
+    octg* c = ctg_init(in, cfg);
+    c->filter_kind = 0;
+    int32_t max_span = stream_max_span(in);
+    ilist nodepth = get_region(c, 0, c->L - 1, 0, cfg->min_len_ldr, 0x1, brim_no_ext);
+    ilist kreg = get_region(c, 0, c->L - 1, cfg->min_len_inter_kmer, 0, 0x1, brim_with_ext);
+    if (kreg.n > 0) {
+        merge_region(&kreg);
+        create_insert_region(c, &kreg, max_span);
+    }
+    if (nodepth.n > 0) {
+        merge_region(&nodepth);
+        create_insert_region(c, &nodepth, max_span);
+        for (int i = 0; i < nodepth.n; i += 2)
+            score_correct(c, nodepth.v[i], nodepth.v[i + 1], 0x12, cfg->indel_balance_factor_sgs, max_span);
+    }
+    free(nodepth.v);
+    if (kreg.n > 0) {
+        ilist parts = split_region(c, &kreg, 0x1, cfg->max_len_kmer);
+        kmer_correct(c, &parts, max_span);
+        free(parts.v);
+    }
+    free(kreg.v);
+    char* out = get_contig(c, 0, c->L - 1, FLAG_ZERO, out_len);
+    ctg_free(c);
+    return out;
+}

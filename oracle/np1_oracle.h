@@ -1,0 +1,69 @@
+/* oracle/np1_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the reference's short-read polishing hot path
+ * (nextpolish1.so: score_chain and kmer_count), operating on an already decoded
+ * record stream instead of htslib iterators.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library -- as the checker, never
+ * as the thing measured or shipped.
+ *
+ * Parity status: PINNED.  The restatement is checked record-for-record against the
+ * real reference compiled from /root/reference by oracle/Makefile (`make ref` ->
+ * oracle/_ref/nextpolish1) on fuzzed and synthetic BAM+FASTA inputs
+ * (tests/test_oracle_vs_ref.py) and against golden vectors generated from that
+ * binary (tests/golden/, generator: tests/golden/make_golden.py).
+ */
+#ifndef NP1_ORACLE_H
+#define NP1_ORACLE_H
+#include <stdint.h>
+
+/* Same field order / natural alignment as the reference `Configure`
+ * (reference: source/lib/config.h:25-67). */
+typedef struct {
+    uint8_t trim_len_edge, ext_len_edge, min_map_quality;
+    double indel_balance_factor_sgs, min_count_ratio_skip;
+    uint8_t min_len_ldr, min_len_inter_kmer, max_len_kmer, max_count_kmer;
+    uint8_t min_depth_snp, min_count_snp;
+    int8_t min_count_snp_link;
+    double ploidy, indel_balance_factor_lgs, max_indel_factor_lgs, max_snp_factor_lgs, min_snp_factor_sgs;
+    int32_t region_count;
+    uint32_t count_read_ins_sgs, max_ins_len_sgs;
+    int32_t max_ins_fold_sgs, max_variant_count_lgs;
+    double max_clip_ratio_sgs, max_clip_ratio_lgs;
+    int32_t trace_polish_open, read_tlen, read_len;
+    char *fastafn, *bamfn, *thirdbamfn;
+} np1o_configure;
+
+/* One contig + its records in BAM file order (a slice of a decoded stream). */
+typedef struct {
+    const char* draft;      /* raw FASTA characters, case preserved */
+    int32_t length;
+    int64_t n_reads;
+    const int32_t* pos;
+    const uint16_t* flag;
+    const uint16_t* n_cigar;
+    const int32_t* l_qseq;
+    const uint8_t* mapq;
+    const int32_t* isize;
+    const uint64_t* cigar_off;   /* absolute index into cigar[] */
+    const uint64_t* seq_off;     /* absolute byte offset into seq[] */
+    const uint64_t* qual_off;    /* absolute byte offset into qual[] (kmer_count only) */
+    const uint32_t* cigar;
+    const uint8_t* seq;
+    const uint8_t* qual;
+    int32_t has_next;            /* 1: arrays hold one more record (index n_reads) = the next record in BAM
+                                    file order after this contig's (kmer_count's stale-read quirk) */
+} np1o_contig;
+
+/* Fills *cfg with the defaults of config_init (reference: source/lib/config.c:8-38). */
+void np1o_default_config(np1o_configure* cfg);
+
+/* score_chain / kmer_count for one contig.  Returns a malloc'd NUL-terminated polished
+ * string (caller frees with np1o_free) and its length in *out_len. */
+char* np1o_score_chain(const np1o_contig* c, const np1o_configure* cfg, int32_t* out_len);
+char* np1o_kmer_count(const np1o_contig* c, const np1o_configure* cfg, int32_t* out_len);
+void np1o_free(void* p);
+
+/* Algorithmic update count of score_chain's pileup (one per slot vote), for throughput reports. */
+int64_t np1o_last_update_count(void);
+
+#endif
