@@ -126,6 +126,8 @@ typedef struct {
 
 /* names == NULL / n_names == 0: every contig of the FASTA index, in index order. */
 np1_stream* np1_stream_load(const char* fasta, const char* bam, const char* const* names, int n_names, int with_qual);
+/* Deep copy of caller-owned arrays into a new stream (tests, adapters from other decoders). */
+np1_stream* np1_stream_build(const np1_stream_view* v, const char* const* contig_names);
 void np1_stream_get_view(const np1_stream* s, np1_stream_view* out);
 const char* np1_stream_contig_name(const np1_stream* s, int64_t i);
 uint64_t np1_stream_algorithmic_bytes(const np1_stream* s, int with_qual);

@@ -92,6 +92,8 @@ def lib():
     L.np1_last_error.restype = C.c_char_p
     L.np1_stream_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int]
     L.np1_stream_load.restype = C.c_void_p
+    L.np1_stream_build.argtypes = [C.POINTER(StreamView), C.POINTER(C.c_char_p)]
+    L.np1_stream_build.restype = C.c_void_p
     L.np1_stream_get_view.argtypes = [C.c_void_p, C.POINTER(StreamView)]
     L.np1_stream_get_view.restype = None
     L.np1_stream_contig_name.argtypes = [C.c_void_p, C.c_int64]
@@ -210,6 +212,49 @@ class Stream(object):
                 raise TypeError("unknown synth parameter " + k)
             setattr(p, k, val)
         return cls(lib().np1_stream_synth(C.byref(p), prefix.encode()))
+
+    @classmethod
+    def from_reads(cls, contigs, reads):
+        """contigs: [(name, draft_str)]; reads: [dict(ctg=int, pos=int, flag=int, mapq=int, isize=int,
+        cigar=[(op_char, len)], seq=str, qual=bytes|None)] already sorted by (ctg, pos).  Test helper."""
+        OPS = "MIDNSHP=X"
+        NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+        nc, nr = len(contigs), len(reads)
+        draft = "".join(d for _, d in contigs).encode()
+        ctg_len = np.array([len(d) for _, d in contigs], dtype=np.int32)
+        ctg_off = np.zeros(nc + 1, dtype=np.uint32)
+        ctg_off[1:] = np.cumsum(ctg_len)
+        read_begin = np.zeros(nc + 1, dtype=np.uint64)
+        for r in reads:
+            read_begin[r["ctg"] + 1:] += 1
+        cig, seq, qual = [], bytearray(), bytearray()
+        cigar_off, seq_off, qual_off = [], [], []
+        for r in reads:
+            cigar_off.append(len(cig)); seq_off.append(len(seq)); qual_off.append(len(qual))
+            cig += [(n << 4) | OPS.index(o) for o, n in r["cigar"]]
+            s = r["seq"]
+            for k in range(0, len(s), 2):
+                seq.append(NT16.get(s[k], 15) << 4 | (NT16.get(s[k + 1], 15) if k + 1 < len(s) else 0))
+            q = r.get("qual")
+            qual += bytes(q) if q is not None else bytes([30] * len(s))
+        arrs = dict(
+            ctg_len=ctg_len, ctg_off=ctg_off, read_begin=read_begin, draft=np.frombuffer(draft, dtype=np.uint8),
+            pos=np.array([r["pos"] for r in reads], dtype=np.int32), ctg=np.array([r["ctg"] for r in reads], dtype=np.uint32),
+            flag=np.array([r.get("flag", 0) for r in reads], dtype=np.uint16),
+            n_cigar=np.array([len(r["cigar"]) for r in reads], dtype=np.uint16),
+            l_qseq=np.array([len(r["seq"]) for r in reads], dtype=np.int32),
+            cigar_off=np.array(cigar_off, dtype=np.uint64), seq_off=np.array(seq_off, dtype=np.uint64),
+            mapq=np.array([r.get("mapq", 60) for r in reads], dtype=np.uint8),
+            isize=np.array([r.get("isize", 0) for r in reads], dtype=np.int32),
+            qual_off=np.array(qual_off, dtype=np.uint64), cigar=np.array(cig, dtype=np.uint32),
+            seq=np.frombuffer(bytes(seq), dtype=np.uint8), qual=np.frombuffer(bytes(qual), dtype=np.uint8))
+        v = StreamView()
+        v.n_contigs, v.n_reads = nc, nr
+        for k, a in arrs.items():
+            setattr(v, k, a.ctypes.data if a.size else 0)
+        v.draft_len, v.cigar_len, v.seq_len, v.qual_len = len(draft), len(cig), len(seq), len(qual)
+        names = (C.c_char_p * max(1, nc))(*[n.encode() for n, _ in contigs])
+        return cls(lib().np1_stream_build(C.byref(v), names))
 
     def algorithmic_bytes(self, with_qual=False):
         return int(lib().np1_stream_algorithmic_bytes(self.handle, 1 if with_qual else 0))

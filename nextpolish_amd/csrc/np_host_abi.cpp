@@ -73,6 +73,31 @@ int np1_stream_write_files(const np1_stream* st, const char* fasta, const char* 
 
 void np1_stream_free(np1_stream* st) { delete st; }
 
+np1_stream* np1_stream_build(const np1_stream_view* v, const char* const* names) {
+    np1_stream* st = new np1_stream();
+    np::ReadStream& s = st->s;
+    size_t nc = (size_t)v->n_contigs, nr = (size_t)v->n_reads;
+    for (size_t c = 0; c < nc; ++c) s.names.push_back(names[c]);
+    s.ctg_len.assign(v->ctg_len, v->ctg_len + nc);
+    s.ctg_off.assign(v->ctg_off, v->ctg_off + nc + 1);
+    s.read_begin.assign(v->read_begin, v->read_begin + nc + 1);
+    s.draft.assign(v->draft, (size_t)v->draft_len);
+    s.pos.assign(v->pos, v->pos + nr);
+    s.ctg.assign(v->ctg, v->ctg + nr);
+    s.flag.assign(v->flag, v->flag + nr);
+    s.n_cigar.assign(v->n_cigar, v->n_cigar + nr);
+    s.l_qseq.assign(v->l_qseq, v->l_qseq + nr);
+    s.cigar_off.assign(v->cigar_off, v->cigar_off + nr);
+    s.seq_off.assign(v->seq_off, v->seq_off + nr);
+    s.mapq.assign(v->mapq, v->mapq + nr);
+    s.isize.assign(v->isize, v->isize + nr);
+    s.qual_off.assign(v->qual_off, v->qual_off + nr);
+    s.cigar.assign(v->cigar, v->cigar + v->cigar_len);
+    s.seq.assign(v->seq, v->seq + v->seq_len);
+    s.qual.assign(v->qual, v->qual + v->qual_len);
+    return st;
+}
+
 void np1_synth_defaults(np1_synth_params* p) { np::synth_default_params(p); }
 
 np1_stream* np1_stream_synth(const np1_synth_params* p, const char* prefix) {

@@ -151,15 +151,11 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
                 // alignment columns of truth[a..) against the draft, plus read errors
                 cols.clear();
                 int32_t t = starts[m], q = 0;
+                int32_t dins_done = -1;   // truth position whose preceding draft-only bases were already emitted
                 while (q < RL && t < Lt) {
-                    if (!cols.empty() && dins[t]) {
-                        int32_t d0 = (dpos[t] >= 0 ? dpos[t] : -1);
-                        // extra draft bases sit right before dpos of the next kept truth base
-                        int32_t tt = t;
-                        while (tt < Lt && dpos[tt] < 0) ++tt;
-                        d0 = (tt < Lt ? dpos[tt] : Ld) - dins[t];
-                        for (int k = 0; k < dins[t]; ++k) cols.push_back(Col{'D', d0 + k, 0});
-                    }
+                    if (!cols.empty() && dins[t] && dins_done != t)
+                        for (int k = 0; k < dins[t]; ++k) cols.push_back(Col{'D', -1, 0});   // bases only the draft has
+                    dins_done = t;
                     if (!cols.empty() && rng.chance(p.read_indel * 0.5)) {   // read deletion
                         if (dpos[t] >= 0) cols.push_back(Col{'D', dpos[t], 0});
                         ++t;

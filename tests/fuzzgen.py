@@ -1,0 +1,98 @@
+"""Random micro-workloads with deliberately odd CIGAR shapes, contig edges and draft letters
+(SURVEY.md §8c "hand-made micro-BAMs hitting each quirk").  Deterministic per seed."""
+import random
+
+
+def random_case(seed, n_contigs=2, max_len=160, max_reads=40, letters="ACGT", odd_letters=True, odd_cigars=True):
+    rng = random.Random(seed)
+    contigs, reads = [], []
+    for c in range(n_contigs):
+        L = rng.randint(12, max_len)
+        alpha = letters
+        d = [rng.choice(alpha) for _ in range(L)]
+        if odd_letters:
+            for _ in range(rng.randint(0, 4)):
+                i = rng.randrange(L)
+                d[i] = rng.choice("acgtNnMRYKm")
+        draft = "".join(d)
+        contigs.append(("tig%d" % c, draft))
+        rs = []
+        for _ in range(rng.randint(0, max_reads)):
+            ref_len = rng.randint(6, min(L, 60))
+            pos = rng.randint(0, L - ref_len)
+            if rng.random() < 0.25:
+                pos = 0 if rng.random() < 0.5 else L - ref_len
+            # alignment ops over the reference span
+            cig, seq = [], []
+            def add(op, n):
+                if n <= 0:
+                    return
+                if cig and cig[-1][0] == op:
+                    cig[-1] = (op, cig[-1][1] + n)
+                else:
+                    cig.append((op, n))
+            if odd_cigars and rng.random() < 0.1:
+                add("H", rng.randint(1, 6))
+            if rng.random() < 0.3:
+                n = rng.randint(1, 8)
+                add("S", n)
+                seq += [rng.choice("ACGT") for _ in range(n)]
+            if odd_cigars and rng.random() < 0.15:
+                n = rng.randint(1, 4)          # leading insertion (also at pos 0)
+                add("I", n)
+                seq += [rng.choice("ACGT") for _ in range(n)]
+                last_was_ins = True
+            else:
+                last_was_ins = False
+            p = pos
+            end = pos + ref_len
+            while p < end:
+                x = rng.random()
+                n = min(end - p, rng.randint(1, 12))
+                if x < 0.62:
+                    for k in range(n):
+                        b = draft[p + k].upper()
+                        if b not in "ACGT" or rng.random() < 0.08:
+                            b = rng.choice("ACGT")
+                        seq.append(b)
+                    if rng.random() < 0.06:
+                        seq[-1] = "N"
+                    add("M", n); p += n; last_was_ins = False
+                elif x < 0.74:
+                    n = min(n, 3)
+                    add("D", n); p += n; last_was_ins = False
+                elif x < 0.88:
+                    if last_was_ins:
+                        continue
+                    n = rng.randint(1, 4)
+                    add("I", n); seq += [rng.choice("ACGT") for _ in range(n)]; last_was_ins = True
+                elif odd_cigars and x < 0.92:
+                    add("N", min(n, 3)); p += min(n, 3)   # the walk ignores N entirely (no pos advance)
+                elif odd_cigars and x < 0.97:
+                    op = rng.choice("=X")
+                    add(op, n); p += n
+                    seq += [rng.choice("ACGT") for _ in range(n)]
+                elif odd_cigars:
+                    add("P", 1)
+            if rng.random() < 0.3:
+                n = rng.randint(1, 8)
+                add("S", n)
+                seq += [rng.choice("ACGT") for _ in range(n)]
+            if odd_cigars and rng.random() < 0.1:
+                add("H", rng.randint(1, 6))
+            if len(seq) >= 2 and rng.random() < 0.1:   # homopolymer-rich read ends / whole read
+                b = rng.choice("ACGT")
+                k = rng.randint(2, len(seq))
+                if rng.random() < 0.5:
+                    seq[:k] = [b] * k
+                else:
+                    seq[-k:] = [b] * k
+            flag = rng.choice([0, 16, 99, 147, 83, 163])
+            if rng.random() < 0.05:
+                flag |= rng.choice([0x400, 0x800, 0x100, 0x4])
+            rs.append(dict(ctg=c, pos=pos, flag=flag, mapq=rng.choice([60, 60, 60, 0, 13, 30]),
+                           isize=rng.choice([0, 300, -300, 250, 20000, -7]), cigar=cig, seq="".join(seq),
+                           qual=[rng.randint(2, 41) for _ in seq]))
+        rs.sort(key=lambda r: r["pos"])
+        reads += rs
+    return contigs, reads

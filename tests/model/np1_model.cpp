@@ -1,0 +1,180 @@
+// tests/model/np1_model.cpp -- TEST INFRASTRUCTURE, never loaded by the product.
+//
+// Host-side lockstep model of the HIP launch sequence in nextpolish_amd/csrc/np1_device.hip:
+// the same per-lane bodies (np1_core.h, compiled for the host) driven by plain loops, with the
+// wave-cooperative k_vote re-stated over 64-entry lane arrays.  It lets the CPU test-suite check
+// the *staged algorithm* (slot space, symbol rows, single-state shortcut, run-wise exact DP,
+// emission) against the oracle without a GPU; the real kernels are checked on the GPU (-m gpu).
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/nextpolish1.h"
+#include "../../nextpolish_amd/csrc/np1_core.h"
+
+using namespace np1k;
+
+namespace {
+struct HostState {
+    long long sc_[2][16];
+    uint16_t km_[2][16];
+    uint8_t rk_[2][16];
+    long long& sc(int b, uint32_t i) { return sc_[b][i]; }
+    uint16_t& km(int b, uint32_t i) { return km_[b][i]; }
+    uint8_t& rk(int b, uint32_t i) { return rk_[b][i]; }
+};
+
+template <int E>
+bool vote_chunk(uint32_t c, const std::vector<uint4>& meta, const std::vector<uint8_t>& rows,
+                const std::vector<uint8_t>& slot_info, uint32_t S, const std::vector<uint32_t>& chunk_first,
+                const std::vector<uint32_t>& chunk_last, std::vector<uint16_t>& slot_res, std::vector<uint32_t>& slot_rec,
+                std::vector<uint32_t>& pool, std::vector<uint32_t>& heads, uint32_t flag_single) {
+    std::vector<uint32_t> L((E - 2) * 64);
+    VoteLane<E> vl[64];
+    uint32_t info[64], dsym[64], basemask[64], sym[64];
+    bool valid[64], first[64];
+    uint32_t s[64];
+    for (int l = 0; l < 64; ++l) {
+        int64_t s64 = (int64_t)c * VOTE_CH - 2 + l;
+        valid[l] = s64 >= 0 && s64 < (int64_t)S;
+        s[l] = (uint32_t)s64;
+        info[l] = valid[l] ? slot_info[s[l]] : 0u;
+        dsym[l] = info[l] & 0xf;
+        first[l] = (info[l] & SI_FIRST) != 0;
+    }
+    uint32_t prev_dsym[64];
+    for (int l = 0; l < 64; ++l) {
+        // __shfl_up returns the lane's own value when there is no source lane
+        uint32_t d1 = l >= 1 ? dsym[l - 1] : dsym[l], d2 = l >= 2 ? dsym[l - 2] : dsym[l];
+        uint32_t f1 = l >= 1 ? (uint32_t)first[l - 1] : (uint32_t)first[l];
+        prev_dsym[l] = d1;
+        if (first[l]) { d1 = 0; d2 = 0; }
+        else if (f1) d2 = 0;
+        vl[l].init(d2 << 8 | d1 << 4 | dsym[l]);
+        basemask[l] = 1u << dsym[l];
+    }
+    uint32_t r0 = chunk_first[c], r1 = chunk_last[c];
+    if (r0 != 0xffffffffu)
+        for (uint32_t r = r0; r <= r1; ++r) {
+            const uint4 m = meta[r];
+            bool cov[64];
+            for (int l = 0; l < 64; ++l) {
+                cov[l] = valid[l] && s[l] >= m.x && s[l] <= m.y;
+                sym[l] = 0;
+                if (cov[l]) {
+                    uint32_t nn = s[l] - m.z;
+                    uint32_t byte = rows[(uint64_t)m.w * 4 + (nn >> 1)];
+                    sym[l] = (byte >> ((nn & 1) * 4)) & 0xf;
+                }
+            }
+            for (int l = 0; l < 64; ++l) {
+                uint32_t p1 = l >= 1 ? sym[l - 1] : 0, p2 = l >= 2 ? sym[l - 2] : 0;
+                if (cov[l]) {
+                    basemask[l] |= 1u << sym[l];
+                    if (l >= 2) vl[l].tally(p2 << 8 | p1 << 4 | sym[l], L.data(), l);
+                }
+            }
+        }
+    for (int l = 0; l < 64; ++l)
+        if (vl[l].ovf) return false;
+    bool single[64];
+    for (int l = 0; l < 64; ++l) single[l] = __builtin_popcount(basemask[l]) == 1;
+    for (int l = 2; l < 64; ++l) {
+        if (!valid[l]) continue;
+        uint32_t total = vl[l].total(L.data(), l);
+        bool prev_is_single = first[l] || single[l - 1];
+        bool is_head = !single[l] && prev_is_single;
+        bool need_rec = !single[l] || !prev_is_single;
+        uint32_t res = 0xffu;
+        if (single[l]) res = dsym[l] | (((total == 1 ? 1u : 0u) | flag_single) << 8);
+        slot_res[s[l]] = (uint16_t)res;
+        uint32_t my_off = 0xffffffffu;
+        if (need_rec) {
+            my_off = (uint32_t)pool.size();
+            pool.resize(pool.size() + vl[l].n + REC_FIXED_WORDS, 0xdeadbeefu);
+            uint32_t hdr = (single[l] ? REC_SINGLE : 0u) | ((info[l] & SI_LAST) ? REC_CTG_LAST : 0u) |
+                           (first[l] ? REC_CTG_FIRST : 0u) | (prev_dsym[l] << 4);
+            vl[l].write_record(pool.data() + my_off, s[l], total, hdr, L.data(), l);
+        }
+        slot_rec[s[l]] = my_off;
+        if (is_head) heads.push_back(my_off);
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+// Returns 0 on success; *out is malloc'd concatenation of the polished contigs, bounds[n_contigs+1].
+// stats (optional, 4 words): slots, dp heads, pool words, max context list length escalations
+int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds, uint64_t* stats) {
+    const uint32_t nc = (uint32_t)v->n_contigs;
+    const int64_t n = v->n_reads;
+    const uint64_t G = (uint64_t)v->draft_len;
+    ReadsDev R{v->pos, v->ctg, v->flag, v->n_cigar, v->l_qseq, v->cigar_off, v->seq_off, v->cigar, v->seq};
+    int K = -1;
+    long long Rfix = 0;
+    for (int k = 0; k <= 10; ++k) {
+        double x = cfg->indel_balance_factor_sgs * (double)(1 << k);
+        if (x == (double)(long long)x) { K = k; Rfix = (long long)x; break; }
+    }
+    if (K < 0) return -2;
+    uint32_t flag_single = (1.0 < cfg->min_count_ratio_skip) ? 2u : 0u;
+    std::vector<int32_t> qs(n), qe(n), span(n);
+    std::vector<uint32_t> ins(G + 1, 0), counters(CNT_WORDS, 0);
+    for (int64_t r = 0; r < n; ++r)
+        prep_record(R, r, v->ctg_off, cfg->trim_len_edge, qs.data(), qe.data(), span.data(), ins.data(), counters.data());
+    if (counters[CNT_ERR]) return (int)counters[CNT_ERR];
+    std::vector<uint32_t> soff(G + 2);
+    uint64_t acc = 0;
+    for (uint64_t g = 0; g < G; ++g) { soff[g] = (uint32_t)acc; acc += 1 + ins[g]; }
+    soff[G] = (uint32_t)acc;
+    const uint32_t S = (uint32_t)acc;
+    std::vector<uint8_t> slot_info(S + 64, 0);
+    for (uint32_t c = 0; c < nc; ++c)
+        for (uint32_t g = v->ctg_off[c]; g < v->ctg_off[c + 1]; ++g)
+            slotinfo_base((const uint8_t*)v->draft, g, v->ctg_off[c], v->ctg_off[c + 1], soff.data(), slot_info.data());
+    std::vector<uint32_t> rbase(n), capb(n);
+    std::vector<uint64_t> rowoff(n + 1);
+    uint64_t rb = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        rowcap_record(R, r, v->ctg_off, soff.data(), qs.data(), qe.data(), span.data(), rbase.data(), capb.data());
+        rowoff[r] = rb;
+        rb += capb[r];
+    }
+    rowoff[n] = rb;
+    std::vector<uint8_t> rows(rb + 64, 0xEE);
+    std::vector<uint4> meta(n ? n : 1);
+    const uint32_t n_chunks = (S + VOTE_CH - 1) / VOTE_CH + 1;
+    std::vector<uint32_t> chunk_first(n_chunks, 0xffffffffu), chunk_last(n_chunks, 0);
+    for (int64_t r = 0; r < n; ++r)
+        rows_record(R, r, v->ctg_off, soff.data(), qs.data(), qe.data(), rbase.data(), rowoff.data(), rows.data(), meta.data(),
+                    chunk_first.data(), chunk_last.data());
+    std::vector<uint16_t> slot_res(S + 64, 0xffff);
+    std::vector<uint32_t> slot_rec(S + 64, 0xffffffffu), pool, heads;
+    uint64_t escal = 0;
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        if (vote_chunk<16>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
+        ++escal;
+        if (vote_chunk<64>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
+        if (!vote_chunk<160>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) return -3;
+    }
+    HostState st;
+    for (uint32_t h : heads)
+        if (!dp_run(h, pool.data(), slot_rec.data(), slot_res.data(), K, Rfix, cfg->min_count_ratio_skip, st)) return -4;
+    for (uint32_t c = 0; c < nc; ++c) fixfirst_contig(v->ctg_off[c], v->ctg_off[c + 1], soff.data(), slot_info.data(), slot_res.data());
+    std::vector<uint32_t> opos(S + 1);
+    uint32_t o = 0;
+    for (uint32_t s = 0; s < S; ++s) { opos[s] = o; o += (slot_res[s] & 0xff) != 3; }
+    opos[S] = o;
+    char* buf = (char*)calloc(1, (size_t)o + 1);
+    for (uint32_t s = 0; s < S; ++s) emit_slot(s, slot_res.data(), slot_info.data(), opos.data(), 3u, (uint8_t*)buf);
+    for (uint32_t c = 0; c <= nc; ++c) bounds[c] = opos[soff[v->ctg_off[c]]];
+    *out = buf;
+    if (stats) { stats[0] = S; stats[1] = heads.size(); stats[2] = pool.size(); stats[3] = escal; }
+    return 0;
+}
+
+void np1m_free(void* p) { free(p); }
+}

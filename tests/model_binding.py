@@ -1,0 +1,35 @@
+"""ctypes binding of tests/model/libnp1_model.so (host lockstep model of the HIP launch sequence)."""
+import ctypes as C
+import os
+
+from nextpolish_amd import _native as nat
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "model", "libnp1_model.so"))
+        L.np1m_score_chain.argtypes = [C.POINTER(nat.StreamView), C.POINTER(nat.Configure), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.np1m_score_chain.restype = C.c_int
+        L.np1m_free.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def score_chain(stream, cfg=None, want_stats=False):
+    cfg = cfg or nat.default_config()
+    out = C.c_void_p()
+    bounds = (C.c_uint32 * (stream.n_contigs + 1))()
+    stats = (C.c_uint64 * 4)()
+    rc = lib().np1m_score_chain(C.byref(stream.view), C.byref(cfg), C.byref(out), bounds, stats)
+    if rc != 0:
+        raise RuntimeError("model failed rc=%d" % rc)
+    blob = C.string_at(out, bounds[stream.n_contigs])
+    lib().np1m_free(out)
+    res = [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)]
+    if want_stats:
+        return res, dict(slots=stats[0], heads=stats[1], pool_words=stats[2], escalations=stats[3])
+    return res
