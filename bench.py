@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""Headline benchmark: short-read score_chain polishing throughput (BASELINE.json metric).
+
+One "step" = one full score_chain pass (every kernel of nextpolish_amd/csrc/np1_device.hip's launch
+sequence) over one batch of synthetic draft contigs + position-sorted short reads that is already
+resident in HBM.  Default workload = BASELINE.json configs[1]: 5 Mb draft, 50x PE150.
+With --gpus N every rank polishes its own 5 Mb shard (contigs are independent units: weak scaling,
+no data-path collective; reference: source/lib/nextpolish1.py:181-189,223-224).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description), including
+  roofline     : achieved algorithmic HBM bytes/s of the dominant kernel (k_vote) vs the 8 TB/s peak
+  cpu_baseline : the reference CPU path (oracle/_ref/nextpolish1, or the oracle port) timed on a
+                 bounded sample of the same workload on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+WORKLOADS = {
+    # name: (contig truth lengths, depth)            -- SURVEY.md §8d synthetic shapes
+    "c2_5mb_50x": ([2500000, 1500000, 1000000], 50.0),
+    "small_1mb_50x": ([600000, 400000], 50.0),
+    "c3shard_12mb_30x": ([3000000, 2500000, 2000000, 1500000, 1200000, 1000000, 800000], 30.0),
+}
+
+
+def cpu_baseline(stream_factory, sample_len, depth, seed):
+    """Times the reference C path on a bounded sample (own process, 1 thread)."""
+    from nextpolish_amd import _native as nat
+    st = stream_factory([sample_len], depth, seed)
+    bp = int(st.ctg_len.sum())
+    ref = os.path.join(ROOT, "oracle", "_ref", "nextpolish1")
+    if os.path.exists(ref):
+        with tempfile.TemporaryDirectory() as td:
+            fa, bam = os.path.join(td, "s.fa"), os.path.join(td, "s.bam")
+            st.write_files(fa, bam, 1)
+            t0 = time.time()
+            subprocess.run([ref, "scorechain", fa, bam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            dt = time.time() - t0
+        kind = "reference"
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding as ob
+        t0 = time.time()
+        for i in range(st.n_contigs):
+            ob.score_chain(st, i)
+        dt = time.time() - t0
+        kind = "port"
+    return {"value": round(bp / 1e6 / dt, 4), "unit": "Mbp/s", "cores": 1, "kind": kind,
+            "sample": "%.1f Mb synthetic draft, %.0fx PE150, score_chain, BAM(+BGZF inflate) -> FASTA, %.1f s"
+                      % (bp / 1e6, depth, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2_5mb_50x", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mb", type=float, default=3.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from nextpolish_amd import _native as nat
+    from nextpolish_amd.device import Context
+
+    lens, depth = WORKLOADS[args.workload]
+
+    def make_stream(contig_lens, d, seed):
+        return nat.Stream.synth(contig_lens, depth=d, seed=seed, prefix="r%dctg" % rank)
+
+    # per-rank shard: same shape, different seed (weak scaling)
+    st = make_stream(lens, depth, 20250117 + 2 + 1000 * rank)
+    draft_bp = int(st.ctg_len.sum())
+    alg_bytes = st.algorithmic_bytes(False)   # records (32 + 4 n_cigar + ceil(l/2)) + draft
+    ctx = Context(local_rank)
+    batch = ctx.upload(st)
+    cfg = nat.default_config()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.score_chain(cfg)
+    batch.ctx and nat.lib().np1_batch_sync(batch.handle)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.score_chain(cfg)
+    nat.lib().np1_batch_sync(batch.handle)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    polished_len = sum(len(s) for s in batch.results())
+    alg_bytes_total = alg_bytes + polished_len
+    updates = batch.update_count()
+
+    # per-stage HIP-event timing on the pipeline's own stream (separate instrumented passes)
+    stage_acc = {}
+    n_inst = 5
+    for _ in range(n_inst):
+        ms = batch.score_chain(cfg, timed=True)
+        for k, v in ms.items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v / n_inst
+    dom = max(stage_acc, key=lambda k: stage_acc[k])
+    dom_ms = stage_acc[dom]
+    achieved = alg_bytes_total / (dom_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * draft_bp / 1e6 / (dt / args.steps)
+        out = {
+            "metric": "polished Mbp/s (score_chain, short reads, inputs resident in HBM)",
+            "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int64", "data": "synthetic",
+            "config": {"workload": "%s: %.2f Mb synthetic draft (%d contigs) + %.0fx simulated 2x150 bp PE reads per GPU, "
+                                   "one score_chain pass" % (args.workload, draft_bp / 1e6, st.n_contigs, depth),
+                       "reads_per_gpu": st.n_reads, "slot_votes_per_step": updates,
+                       "parallelism": "contig-sharded x%d (no collective)" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes_total, "kernel_ms": round(dom_ms, 4),
+                         "stage_ms": {k: round(v, 4) for k, v in stage_acc.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(make_stream, int(args.cpu_sample_mb * 1e6), depth, 424242)
+        print(json.dumps(out))
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -326,7 +326,8 @@ NP1_HD bool dp_run(uint32_t head_off, uint32_t* pool, const uint32_t* slot_rec, 
     }
     uint32_t s = s_head;
     bool ok = true;
-    for (;;) {   // ---- forward
+    for (uint32_t guard = 0;; ++guard) {   // ---- forward
+        if (guard > (1u << 26)) { ok = false; break; }
         const uint32_t n = rec[1] >> 16, total = rec[1] & 0xffffu, refk = rec[2] & 0xffffu;
         hdr = rec[2] >> 16;
         const uint32_t tot = total > 1 ? total - 1 : total;
@@ -444,7 +445,7 @@ NP1_HD void emit_slot(uint32_t s, const uint16_t* slot_res, const uint8_t* slot_
     bool lower = ((r >> 8) & mask) != 0;
     if (!lower) {
         uint32_t t = s;
-        while (!(slot_info[t] & SI_FIRST)) {
+        while (t > 0 && !(slot_info[t] & SI_FIRST)) {
             --t;
             uint32_t rr = slot_res[t];
             if ((rr & 0xff) != 3) break;
