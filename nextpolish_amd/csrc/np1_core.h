@@ -36,9 +36,9 @@ constexpr uint32_t VOTE_CH = 62;
 // DP record: [slot][n<<16|total][refk | hdr<<16][n x (kmer<<16|count)][8 words state kmers][fmax base | mask<<8]
 constexpr uint32_t REC_SINGLE = 1, REC_CTG_LAST = 2, REC_CTG_FIRST = 4;   // hdr bits; hdr bits 4..7 = previous slot's draft symbol
 constexpr uint32_t REC_FIXED_WORDS = 12;
-enum { CNT_POOL = 0, CNT_HEADS = 1, CNT_REDO = 2, CNT_ERR = 3, CNT_REDO2 = 4, CNT_WORDS = 8 };
+enum { CNT_POOL = 0, CNT_HEADS = 1, CNT_REDO = 2, CNT_ERR = 3, CNT_REDO2 = 4, CNT_OVFDESC = 5, CNT_WORDS = 8 };
 constexpr uint32_t ERR_DOUBLE_INS = 1, ERR_BAD_RECORD = 2, ERR_CTX_OVERFLOW = 4, ERR_POOL_OVERFLOW = 8,
-                   ERR_DP_INCONSISTENT = 16;
+                   ERR_DP_INCONSISTENT = 16, ERR_DESC_OVERFLOW = 32;
 
 NP1_HD uint32_t cig_op(uint32_t c) { return c & 0xf; }
 NP1_HD int32_t cig_len(uint32_t c) { return (int32_t)(c >> 4); }
@@ -132,7 +132,7 @@ NP1_HD void prep_record(const ReadsDev& R, int64_t r, const uint32_t* ctg_off, i
 // per draft base: slot_info for the base and its insertion columns (contig.c:81-102: lowercase input
 // sets FLAG_ZERO; contig.c:230-234: new insertion columns copy the flag of their base)
 NP1_HD void slotinfo_base(const uint8_t* draft, uint32_t g, uint32_t g_first, uint32_t g_end, const uint32_t* soff,
-                          uint8_t* slot_info) {
+                          uint8_t* slot_info, uint32_t* slot_g = nullptr) {
     uint32_t ch = draft[g];
     uint32_t lower = 0;
     if (ch >= 97 && ch <= 122) { ch -= 32; lower = SI_LOWER; }
@@ -142,6 +142,8 @@ NP1_HD void slotinfo_base(const uint8_t* draft, uint32_t g, uint32_t g_first, ui
     if (g + 1 == g_end) info |= SI_LAST;
     slot_info[s0] = (uint8_t)info;
     for (uint32_t s = s0 + 1; s < s1; ++s) slot_info[s] = (uint8_t)(3u | SI_INSERT | lower);
+    if (slot_g)
+        for (uint32_t s = s0; s < s1; ++s) slot_g[s] = g;   // draft index of every slot (fused pipeline)
 }
 
 // where a record's symbol row starts in slot space, and its byte capacity
@@ -164,15 +166,18 @@ NP1_HD void rowcap_record(const ReadsDev& R, int64_t r, const uint32_t* ctg_off,
 }
 
 struct RowWriter {
-    uint8_t* row;   // 4-byte aligned
+    uint32_t* roww;   // the record's row, 4-byte words (global memory in the staged pipeline, LDS in the fused one)
     uint32_t rbase, cur_word, w, sfirst, slast;
     bool any;
+    NP1_HD void init(uint32_t* row_words, uint32_t row_base_slot) {
+        roww = row_words; rbase = row_base_slot; any = false; sfirst = 1; slast = 0; cur_word = 0; w = 0;
+    }
     NP1_HD void emit(uint32_t slot, uint32_t sym) {
         uint32_t n = slot - rbase;
         uint32_t wi = n >> 3;
         if (!any) { any = true; sfirst = slot; cur_word = wi; w = 0; }
         else if (wi != cur_word) {
-            *reinterpret_cast<uint32_t*>(row + 4ull * cur_word) = w;
+            roww[cur_word] = w;
             cur_word = wi;
             w = 0;
         }
@@ -180,12 +185,92 @@ struct RowWriter {
         slast = slot;
     }
     NP1_HD void flush() {
-        if (any) *reinterpret_cast<uint32_t*>(row + 4ull * cur_word) = w;
+        if (any) roww[cur_word] = w;
     }
 };
 
-// pass 2 (contig.c:247-331 with start = 0, end = L-1): writes the record's symbol for every slot it
-// votes on (a contiguous slot run), returns the number of votes
+// plain accessors used by the staged pipeline and the host model
+struct SoGlobal {
+    const uint32_t* soff;
+    NP1_HD uint32_t operator()(uint32_t gi) const { return soff[gi]; }
+};
+struct SeqBytes {
+    const uint8_t* seq;
+    NP1_HD uint32_t operator()(int32_t q) { return seq_nib(seq, q); }
+};
+
+// pass 2 (contig.c:247-331 with start = 0, end = L-1): emits the record's symbol for every slot it votes on
+// (always a contiguous slot run).  So(gi) = slot offset of global draft index gi; Sq(q) = 4-bit base q of the record.
+template <class So, class Sq>
+NP1_HD void walk_record(const uint32_t* cg, uint32_t ncig, int32_t pos0, uint32_t g0, int32_t L, int32_t qs, int32_t qe,
+                        So so, Sq sq, RowWriter& wr) {
+    int32_t pos = pos0, qpos = 0;
+    uint32_t last = 1;   // BAM_CINS
+    for (uint32_t i = 0; i < ncig; ++i) {
+        const uint32_t op = cig_op(cg[i]);
+        const int32_t len = cig_len(cg[i]);
+        if (op == 0 || op == 2) {
+            // columns j of this op that lie inside the contig and inside the trimmed query window
+            int32_t jlo = 0, jhi = len - 1;
+            if (-pos > jlo) jlo = -pos;
+            if (L - 1 - pos < jhi) jhi = L - 1 - pos;
+            if (op == 0) {
+                if (qs - qpos > jlo) jlo = qs - qpos;
+                if (qe - qpos < jhi) jhi = qe - qpos;
+            } else if (qpos < qs || qpos > qe) {
+                jhi = -1;
+            }
+            if (jlo <= jhi) {
+                uint32_t sprev = 0;
+                for (int32_t j = jlo; j <= jhi; ++j) {
+                    const int32_t p = pos + j, q = op == 0 ? qpos + j : qpos;
+                    const uint32_t scur = so(g0 + (uint32_t)p);
+                    bool pad;
+                    if (j > jlo) {
+                        pad = true;   // inside a run the previous column was emitted by this very op
+                    } else {
+                        const uint32_t lastj = j > 0 ? op : last;
+                        pad = lastj != 1 && p > 0 && (q > qs || (q == qs && lastj == 2));
+                        if (pad) sprev = so(g0 + (uint32_t)p - 1);
+                    }
+                    if (pad)
+                        for (uint32_t s = sprev + 1; s < scur; ++s) wr.emit(s, 3u);   // unused insertion columns vote DEL
+                    wr.emit(scur, op == 2 ? 3u : sq(q));
+                    sprev = scur;
+                }
+            }
+            if (len > 0) last = op;
+            pos += len;
+            if (op == 0) qpos += len;
+        } else if (op == 1) {
+            if (pos != 0) {
+                const bool inr = pos > 0 && pos <= L - 1;
+                if (inr) {
+                    const uint32_t sprev = so(g0 + (uint32_t)pos - 1), scur = so(g0 + (uint32_t)pos);
+                    int32_t jlo = 0, jhi = len - 1;
+                    if (qs - qpos > jlo) jlo = qs - qpos;
+                    if (qe - qpos < jhi) jhi = qe - qpos;
+                    for (int32_t j = jlo; j <= jhi; ++j) wr.emit(sprev + 1 + (uint32_t)j, sq(qpos + j));
+                    const int32_t qafter = qpos + len;
+                    if (qafter > qs && qafter <= qe + 1)
+                        for (uint32_t s = sprev + 1 + (uint32_t)len; s < scur; ++s) wr.emit(s, 3u);
+                }
+                qpos += len;
+                last = 1;
+            } else {   // insertion before the first base of the contig: skipped, the window shifts (contig.c:315-319)
+                qpos += len;
+                qs += len;
+                last = 1;
+            }
+        } else if (op == 4 || op == 5) {
+            qpos += len;   // hard clips advance the query cursor too (contig.c:321-324)
+        }
+        if (pos > L - 1) break;
+    }
+    wr.flush();
+}
+
+// staged pipeline: one record -> its row in the global row pool + vote-chunk bounds; returns the number of votes
 NP1_HD uint32_t rows_record(const ReadsDev& R, int64_t r, const uint32_t* ctg_off, const uint32_t* soff,
                             const int32_t* qs_in, const int32_t* qe_in, const uint32_t* rbase, const uint64_t* rowoff,
                             uint8_t* rows, uint4* meta, uint32_t* chunk_first, uint32_t* chunk_last) {
@@ -194,56 +279,12 @@ NP1_HD uint32_t rows_record(const ReadsDev& R, int64_t r, const uint32_t* ctg_of
     m.x = 1; m.y = 0; m.z = 0; m.w = 0;
     uint32_t votes = 0;
     if (qs <= qe) {
-        uint32_t ncig = R.n_cigar[r];
-        const uint32_t* cg = R.cigar + R.cigar_off[r];
-        const uint8_t* seq = R.seq + R.seq_off[r];
         uint32_t c = R.ctg[r];
         uint32_t g0 = ctg_off[c];
-        int32_t L = (int32_t)(ctg_off[c + 1] - g0);
-        const uint32_t* so = soff + g0;
         RowWriter wr;
-        wr.row = rows + rowoff[r];
-        wr.rbase = rbase[r];
-        wr.any = false;
-        wr.sfirst = 1; wr.slast = 0; wr.cur_word = 0; wr.w = 0;
-        int32_t pos = R.pos[r], qpos = 0;
-        uint32_t last = 1;   // BAM_CINS
-        for (uint32_t i = 0; i < ncig; ++i) {
-            uint32_t op = cig_op(cg[i]);
-            int32_t len = cig_len(cg[i]);
-            if (op == 0 || op == 2) {
-                for (int32_t j = 0; j < len; ++j, ++pos) {
-                    if (pos >= 0 && pos <= L - 1 && qpos >= qs && qpos <= qe) {
-                        uint32_t scur = so[pos];
-                        if (last != 1 && pos > 0 && (qpos > qs || (qpos == qs && last == 2))) {
-                            uint32_t sprev = so[pos - 1];
-                            for (uint32_t s = sprev + 1; s < scur; ++s) wr.emit(s, 3u);   // unused insertion columns vote DEL
-                        }
-                        wr.emit(scur, op == 2 ? 3u : seq_nib(seq, qpos));
-                    }
-                    if (op != 2) ++qpos;
-                    last = op;
-                }
-            } else if (op == 1) {
-                if (pos != 0) {
-                    bool inr = pos > 0 && pos <= L - 1;
-                    uint32_t sprev = inr ? so[pos - 1] : 0, scur = inr ? so[pos] : 0;
-                    for (int32_t j = 0; j < len; ++j, ++qpos)
-                        if (inr && qpos >= qs && qpos <= qe) wr.emit(sprev + 1 + (uint32_t)j, seq_nib(seq, qpos));
-                    if (inr && qpos > qs && qpos <= qe + 1)
-                        for (uint32_t s = sprev + 1 + (uint32_t)len; s < scur; ++s) wr.emit(s, 3u);
-                    last = 1;
-                } else {   // insertion before the first base of the contig: skipped, the window shifts (contig.c:315-319)
-                    qpos += len;
-                    qs += len;
-                    last = 1;
-                }
-            } else if (op == 4 || op == 5) {
-                qpos += len;   // hard clips advance the query cursor too (contig.c:321-324)
-            }
-            if (pos > L - 1) break;
-        }
-        wr.flush();
+        wr.init(reinterpret_cast<uint32_t*>(rows + rowoff[r]), rbase[r]);
+        walk_record(R.cigar + R.cigar_off[r], R.n_cigar[r], R.pos[r], g0, (int32_t)(ctg_off[c + 1] - g0), qs, qe,
+                    SoGlobal{soff}, SeqBytes{R.seq + R.seq_off[r]}, wr);
         if (wr.any) {
             m.x = wr.sfirst;
             m.y = wr.slast;

@@ -42,8 +42,20 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-const char* kStageNames[] = {"prep", "scan_slots", "slotinfo", "rowcap_scan", "rows", "vote", "dp", "emit"};
+// Two launch sequences share everything but the middle: the default FUSED one stages pileup columns through
+// LDS (k_place + k_tile); the STAGED one (NP1_PIPELINE=staged, kept for A/B measurements and mirrored by the
+// host model in tests/model) materialises symbol rows in HBM (k_rowcap + scan + k_rows + k_vote).
+const char* kStageNamesStaged[] = {"prep", "scan_slots", "slotinfo", "rowcap_scan", "rows", "vote", "dp", "emit"};
+const char* kStageNamesFused[] = {"prep", "scan_slots", "slotinfo", "place", "-", "tile", "dp", "emit"};
 constexpr int kStages = 8;
+bool use_staged() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("NP1_PIPELINE");
+        v = (e && strcmp(e, "staged") == 0) ? 1 : 0;
+    }
+    return v == 1;
+}
 
 }  // namespace
 
@@ -61,9 +73,12 @@ struct np1_batch {
     // inputs
     DevBuf draft, ctg_off, pos, ctg, flag, ncig, lq, cigoff, seqoff, cigar, seq;
     // work
+    DevBuf desc, ovf_desc, slot_g;
     DevBuf qs, qe, span, ins, soff, slot_info, rbase, capb, rowoff, rows, meta, chunk_first, chunk_last, slot_res,
         slot_rec, pool, heads, redo, redo2, counters, opos, out, bounds, scan_tmp, totals;
     size_t input_bytes = 0;
+    uint32_t max_lq = 0;   // longest record of the batch (bases)
+    bool force_staged = false;   // a record exceeded the descriptor capacity once: this batch uses the staged sequence
     // results of the last run
     uint32_t S = 0;
     uint64_t votes = 0;
@@ -76,7 +91,7 @@ struct np1_batch {
         const DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
                                &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
                                &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out,
-                               &bounds, &scan_tmp, &totals};
+                               &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g};
         size_t t = 0;
         for (const DevBuf* b : all) t += b->cap;
         return t;
@@ -85,7 +100,7 @@ struct np1_batch {
         DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
                          &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
                          &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out,
-                         &bounds, &scan_tmp, &totals};
+                         &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -122,7 +137,10 @@ void np1_ctx_destroy(np1_ctx* c) {
 }
 
 int np1_stage_count(void) { return kStages; }
-const char* np1_stage_name(int i) { return (i >= 0 && i < kStages) ? kStageNames[i] : ""; }
+const char* np1_stage_name(int i) {
+    if (i < 0 || i >= kStages) return "";
+    return use_staged() ? kStageNamesStaged[i] : kStageNamesFused[i];
+}
 
 static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t st) {
     if (b.ensure(bytes ? bytes : 4) != 0) return -1;
@@ -141,6 +159,8 @@ np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* st) {
     b->G = s.draft.size();
     b->n_reads = (int64_t)s.n_reads();
     b->h_ctg_off = s.ctg_off;
+    for (int32_t l : s.l_qseq)
+        if (l > 0 && (uint32_t)l > b->max_lq) b->max_lq = (uint32_t)l;
     hipStream_t q = ctx->stream;
     size_t n = s.n_reads();
     int rc = 0;
@@ -247,66 +267,139 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     if (b->pool.cap == 0 && b->pool.ensure(4 * (3 * (size_t)S + (1u << 20)))) return -1;
     // ---- stage 2: per-slot draft symbols
     t0(2);
-    launch_slotinfo(q, b->draft.as<uint8_t>(), (uint32_t)G, ctg_off, nc, b->soff.as<uint32_t>(), b->slot_info.as<uint8_t>());
+    if (!(use_staged() || b->force_staged) && b->slot_g.ensure(4 * ((size_t)S + 64))) return -1;
+    launch_slotinfo(q, b->draft.as<uint8_t>(), (uint32_t)G, ctg_off, nc, b->soff.as<uint32_t>(), b->slot_info.as<uint8_t>(),
+                    (use_staged() || b->force_staged) ? nullptr : b->slot_g.as<uint32_t>());
     t1(2);
-    // ---- stage 3: row placement
-    t0(3);
-    launch_rowcap(q, R, n, ctg_off, b->soff.as<uint32_t>(), b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->span.as<int32_t>(),
-                  b->rbase.as<uint32_t>(), b->capb.as<uint32_t>());
-    launch_scan_rows(q, b->capb.as<uint32_t>(), (uint64_t)(n > 0 ? n : 0), b->rowoff.as<uint64_t>(), scan_tmp, &totals[1]);
-    t1(3);
-    uint64_t row_bytes = 0;
-    HIPCHK(hipMemcpyAsync(&row_bytes, &totals[1], 8, hipMemcpyDeviceToHost, q));
-    HIPCHK(hipStreamSynchronize(q));
-    if ((row_bytes >> 2) >= 0xffffffffull) { np1_set_error("batch too large: symbol rows exceed 16 GiB"); return -1; }
-    if (b->rows.ensure(row_bytes + 64, 1.02)) return -1;
-    // ---- stage 4: rows
-    HIPCHK(hipMemsetAsync(b->chunk_first.p, 0xff, 4 * (size_t)n_chunks, q));
-    HIPCHK(hipMemsetAsync(b->chunk_last.p, 0, 4 * (size_t)n_chunks, q));
-    t0(4);
-    launch_rows(q, R, n, ctg_off, b->soff.as<uint32_t>(), b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->rbase.as<uint32_t>(),
-                b->rowoff.as<uint64_t>(), b->rows.as<uint8_t>(), b->meta.as<uint4>(), b->chunk_first.as<uint32_t>(),
-                b->chunk_last.as<uint32_t>(), reinterpret_cast<unsigned long long*>(&totals[3]));
-    t1(4);
-    // ---- stage 5: vote (+ escalation for crowded slots, + pool growth)
+    const bool staged = use_staged() || b->force_staged;
     uint32_t hc[CNT_WORDS];
-    for (int attempt = 0;; ++attempt) {
-        uint32_t pool_cap = (uint32_t)std::min<size_t>(b->pool.cap / 4, 0xfffffff0u);
-        t0(5);
-        launch_vote(q, 16, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
-                    b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, nullptr, 0,
-                    b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
-                    b->heads.as<uint32_t>(), b->redo.as<uint32_t>(), CNT_REDO, flag_single);
-        t1(5);
-        HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+    if (staged) {
+        // ---- stage 3: row placement
+        t0(3);
+        launch_rowcap(q, R, n, ctg_off, b->soff.as<uint32_t>(), b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->span.as<int32_t>(),
+                      b->rbase.as<uint32_t>(), b->capb.as<uint32_t>());
+        launch_scan_rows(q, b->capb.as<uint32_t>(), (uint64_t)(n > 0 ? n : 0), b->rowoff.as<uint64_t>(), scan_tmp, &totals[1]);
+        t1(3);
+        uint64_t row_bytes = 0;
+        HIPCHK(hipMemcpyAsync(&row_bytes, &totals[1], 8, hipMemcpyDeviceToHost, q));
         HIPCHK(hipStreamSynchronize(q));
-        if (hc[CNT_REDO]) {
-            launch_vote(q, 64, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
-                        b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->redo.as<uint32_t>(),
-                        hc[CNT_REDO], b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(),
-                        pool_cap, counters, b->heads.as<uint32_t>(), b->redo2.as<uint32_t>(), CNT_REDO2, flag_single);
+        if ((row_bytes >> 2) >= 0xffffffffull) { np1_set_error("batch too large: symbol rows exceed 16 GiB"); return -1; }
+        if (b->rows.ensure(row_bytes + 64, 1.02)) return -1;
+        // ---- stage 4: rows
+        HIPCHK(hipMemsetAsync(b->chunk_first.p, 0xff, 4 * (size_t)n_chunks, q));
+        HIPCHK(hipMemsetAsync(b->chunk_last.p, 0, 4 * (size_t)n_chunks, q));
+        t0(4);
+        launch_rows(q, R, n, ctg_off, b->soff.as<uint32_t>(), b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->rbase.as<uint32_t>(),
+                    b->rowoff.as<uint64_t>(), b->rows.as<uint8_t>(), b->meta.as<uint4>(), b->chunk_first.as<uint32_t>(),
+                    b->chunk_last.as<uint32_t>(), reinterpret_cast<unsigned long long*>(&totals[3]));
+        t1(4);
+        // ---- stage 5: vote (+ escalation for crowded slots, + pool growth)
+        for (int attempt = 0;; ++attempt) {
+            uint32_t pool_cap = (uint32_t)std::min<size_t>(b->pool.cap / 4, 0xfffffff0u);
+            t0(5);
+            launch_vote(q, 16, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
+                        b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, nullptr, 0,
+                        b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
+                        b->heads.as<uint32_t>(), b->redo.as<uint32_t>(), CNT_REDO, flag_single);
+            t1(5);
             HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
             HIPCHK(hipStreamSynchronize(q));
-            if (hc[CNT_REDO2]) {
-                launch_vote(q, 160, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
-                            b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->redo2.as<uint32_t>(),
-                            hc[CNT_REDO2], b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(),
-                            pool_cap, counters, b->heads.as<uint32_t>(), nullptr, CNT_REDO2, flag_single);
+            if (hc[CNT_REDO]) {
+                launch_vote(q, 64, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
+                            b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->redo.as<uint32_t>(),
+                            hc[CNT_REDO], b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(),
+                            pool_cap, counters, b->heads.as<uint32_t>(), b->redo2.as<uint32_t>(), CNT_REDO2, flag_single);
                 HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
                 HIPCHK(hipStreamSynchronize(q));
+                if (hc[CNT_REDO2]) {
+                    launch_vote(q, 160, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
+                                b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->redo2.as<uint32_t>(),
+                                hc[CNT_REDO2], b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(),
+                                pool_cap, counters, b->heads.as<uint32_t>(), nullptr, CNT_REDO2, flag_single);
+                    HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+                    HIPCHK(hipStreamSynchronize(q));
+                }
             }
+            if (hc[CNT_ERR] & ERR_POOL_OVERFLOW) {
+                if (attempt >= 3) { np1_set_error("DP record pool keeps overflowing"); return -1; }
+                size_t need = (size_t)hc[CNT_POOL] * 4;
+                if (b->pool.ensure(need + need / 4 + (1u << 20))) return -1;
+                uint32_t zero[CNT_WORDS] = {0};
+                zero[CNT_ERR] = hc[CNT_ERR] & ~ERR_POOL_OVERFLOW;
+                HIPCHK(hipMemcpyAsync(counters, zero, sizeof(zero), hipMemcpyHostToDevice, q));
+                HIPCHK(hipStreamSynchronize(q));
+                continue;
+            }
+            break;
         }
-        if (hc[CNT_ERR] & ERR_POOL_OVERFLOW) {
-            if (attempt >= 3) { np1_set_error("DP record pool keeps overflowing"); return -1; }
-            size_t need = (size_t)hc[CNT_POOL] * 4;
-            if (b->pool.ensure(need + need / 4 + (1u << 20))) return -1;
-            uint32_t zero[CNT_WORDS] = {0};
-            zero[CNT_ERR] = hc[CNT_ERR] & ~ERR_POOL_OVERFLOW;
-            HIPCHK(hipMemcpyAsync(counters, zero, sizeof(zero), hipMemcpyHostToDevice, q));
+
+    } else {
+        // ---- stage 3 (fused): record descriptors (+ overflow parts) and the candidate record range of every vote chunk
+        if (b->desc.ensure(4 * (size_t)DESC_WORDS * nn)) return -1;
+        if (b->ovf_desc.cap == 0 && b->ovf_desc.ensure(4 * (size_t)DESC_WORDS * (nn / 64 + 4096))) return -1;
+        for (int attempt = 0;; ++attempt) {
+            const uint32_t ovf_cap = (uint32_t)std::min<size_t>(b->ovf_desc.cap / (4 * DESC_WORDS), 0x7fffffffu);
+            HIPCHK(hipMemsetAsync(b->chunk_first.p, 0xff, 4 * (size_t)n_chunks, q));
+            HIPCHK(hipMemsetAsync(b->chunk_last.p, 0, 4 * (size_t)n_chunks, q));
+            HIPCHK(hipMemsetAsync(&counters[CNT_OVFDESC], 0, 4, q));
+            t0(3);
+            launch_desc(q, R, n, ctg_off, b->soff.as<uint32_t>(), b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->desc.as<uint32_t>(),
+                        b->ovf_desc.as<uint32_t>(), ovf_cap, b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), counters);
+            t1(3);
+            HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
             HIPCHK(hipStreamSynchronize(q));
-            continue;
+            if (!(hc[CNT_ERR] & ERR_DESC_OVERFLOW)) break;
+            if (hc[CNT_OVFDESC] <= ovf_cap || attempt >= 2) {   // not a capacity problem: a record is too long for 16-bit query indices
+                np1_set_error("record too long for the short-read descriptors (long reads belong to nextpolish2)");
+                return -1;
+            }
+            if (b->ovf_desc.ensure(4 * (size_t)DESC_WORDS * ((size_t)hc[CNT_OVFDESC] + 1024))) return -1;
+            uint32_t zero = hc[CNT_ERR] & ~ERR_DESC_OVERFLOW;
+            HIPCHK(hipMemcpyAsync(&counters[CNT_ERR], &zero, 4, hipMemcpyHostToDevice, q));
         }
-        break;
+        // ---- stage 5 (fused): votes through LDS (+ escalation for crowded slots, + pool growth)
+        for (int attempt = 0;; ++attempt) {
+            uint32_t pool_cap = (uint32_t)std::min<size_t>(b->pool.cap / 4, 0xfffffff0u);
+            unsigned long long* votes = reinterpret_cast<unsigned long long*>(&totals[3]);
+            auto tile = [&](int level, const uint32_t* redo_in, uint32_t n_redo, uint32_t* redo_out, uint32_t redo_ci) {
+                return launch_tile3(q, level, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
+                                    b->chunk_first.as<uint32_t>(),
+                                    b->chunk_last.as<uint32_t>(), n_chunks, redo_in, n_redo, b->slot_info.as<uint8_t>(),
+                                    b->slot_g.as<uint32_t>(), S, b->max_lq, b->slot_res.as<uint16_t>(),
+                                    b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
+                                    b->heads.as<uint32_t>(), redo_out, redo_ci, flag_single, votes);
+            };
+            HIPCHK(hipMemsetAsync(&totals[3], 0, 8, q));
+            t0(5);
+            if (tile(0, nullptr, 0, b->redo.as<uint32_t>(), CNT_REDO) != 0) {
+                np1_set_error("records are too long for the LDS-staged path (long reads belong to nextpolish2)");
+                return -1;
+            }
+            t1(5);
+            HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+            HIPCHK(hipStreamSynchronize(q));
+            if (hc[CNT_REDO]) {
+                if (tile(1, b->redo.as<uint32_t>(), hc[CNT_REDO], b->redo2.as<uint32_t>(), CNT_REDO2) != 0) { np1_set_error("LDS plan failed (level 1)"); return -1; }
+                HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+                HIPCHK(hipStreamSynchronize(q));
+                if (hc[CNT_REDO2]) {
+                    if (tile(2, b->redo2.as<uint32_t>(), hc[CNT_REDO2], nullptr, CNT_REDO2) != 0) { np1_set_error("LDS plan failed (level 2)"); return -1; }
+                    HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+                    HIPCHK(hipStreamSynchronize(q));
+                }
+            }
+            if (hc[CNT_ERR] & ERR_POOL_OVERFLOW) {
+                if (attempt >= 3) { np1_set_error("DP record pool keeps overflowing"); return -1; }
+                size_t need = (size_t)hc[CNT_POOL] * 4;
+                if (b->pool.ensure(need + need / 4 + (1u << 20))) return -1;
+                uint32_t zero[CNT_WORDS] = {0};
+                zero[CNT_ERR] = hc[CNT_ERR] & ~ERR_POOL_OVERFLOW;
+                HIPCHK(hipMemcpyAsync(counters, zero, sizeof(zero), hipMemcpyHostToDevice, q));
+                HIPCHK(hipStreamSynchronize(q));
+                continue;
+            }
+            break;
+        }
     }
     if (hc[CNT_ERR] & ERR_DOUBLE_INS) { np1_set_error("unsupported CIGAR: two insertion ops at one reference position"); return -1; }
     if (hc[CNT_ERR] & ERR_BAD_RECORD) { np1_set_error("alignment record extends beyond its contig"); return -1; }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "np1_core.h"
+#include "np1_desc.h"
 
 namespace np1k {
 
@@ -15,7 +16,7 @@ void launch_scan_slots(hipStream_t st, const uint32_t* ins, uint64_t G, uint32_t
 void launch_scan_rows(hipStream_t st, const uint32_t* cap_bytes, uint64_t n, uint64_t* rowoff, uint64_t* tmp, uint64_t* total);
 void launch_scan_keep(hipStream_t st, const uint16_t* slot_res, uint64_t S, uint32_t* opos, uint64_t* tmp, uint64_t* total);
 void launch_slotinfo(hipStream_t st, const uint8_t* draft, uint32_t G, const uint32_t* ctg_off, uint32_t nc,
-                     const uint32_t* soff, uint8_t* slot_info);
+                     const uint32_t* soff, uint8_t* slot_info, uint32_t* slot_g);
 void launch_rowcap(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
                    const int32_t* qs, const int32_t* qe, const int32_t* span, uint32_t* rbase, uint32_t* cap_bytes);
 void launch_rows(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
@@ -25,6 +26,15 @@ void launch_vote(hipStream_t st, int E, const uint4* meta, const uint8_t* rows, 
                  const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint32_t* redo_in,
                  uint32_t n_redo_in, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap,
                  uint32_t* counters, uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single);
+void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
+                 const int32_t* qs, const int32_t* qe, uint32_t* desc, uint32_t* ovf_pool, uint32_t ovf_cap,
+                 uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters);
+// default fused kernel (descriptors + packed bases staged through LDS); levels as launch_tile
+int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc,
+                 const uint32_t* ovf_pool, const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint32_t* redo_in,
+                 uint32_t n_redo_in, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S, uint32_t max_lq,
+                 uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters,
+                 uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes);
 void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t* pool, const uint32_t* slot_rec,
                uint16_t* slot_res, int K, long long Rfix, double min_ratio, uint32_t grid);
 void launch_fixfirst(hipStream_t st, const uint32_t* ctg_off, uint32_t nc, const uint32_t* soff, const uint8_t* slot_info,

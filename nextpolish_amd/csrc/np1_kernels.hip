@@ -19,8 +19,10 @@
 // Integer / byte work throughout: no MFMA.  Bound: HBM bytes of the record stream.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "np1_core.h"
+#include "np1_desc.h"
 #include "np1_kernels.h"
 
 namespace np1k {
@@ -149,11 +151,12 @@ __device__ __forceinline__ uint32_t contig_of(const uint32_t* __restrict__ ctg_o
 
 __global__ __launch_bounds__(256) void k_slotinfo(const uint8_t* __restrict__ draft, uint32_t G,
                                                   const uint32_t* __restrict__ ctg_off, uint32_t nc,
-                                                  const uint32_t* __restrict__ soff, uint8_t* __restrict__ slot_info) {
+                                                  const uint32_t* __restrict__ soff, uint8_t* __restrict__ slot_info,
+                                                  uint32_t* __restrict__ slot_g) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     uint32_t c = contig_of(ctg_off, nc, g);
-    slotinfo_base(draft, g, ctg_off[c], ctg_off[c + 1], soff, slot_info);
+    slotinfo_base(draft, g, ctg_off[c], ctg_off[c + 1], soff, slot_info, slot_g);
 }
 
 __global__ __launch_bounds__(256) void k_rowcap(ReadsDev R, int64_t n_reads, const uint32_t* __restrict__ ctg_off,
@@ -177,6 +180,250 @@ __global__ __launch_bounds__(256) void k_rows(ReadsDev R, int64_t n_reads, const
     if (r < n_reads) myvotes = rows_record(R, r, ctg_off, soff, qs_in, qe_in, rbase, rowoff, rows, meta, chunk_first, chunk_last);
     for (int o = 32; o > 0; o >>= 1) myvotes += __shfl_down(myvotes, o);
     if ((threadIdx.x & 63) == 0 && myvotes) atomicAdd(votes, myvotes);
+}
+
+// Shared tail of k_vote / k_tile: resolve single-state slots, spill DP records, list run heads.
+template <int E>
+__device__ __forceinline__ void vote_epilogue(const VoteLane<E>& vl, const uint32_t* L, int lane, uint32_t c, bool valid,
+                                              uint32_t s, uint32_t info, uint32_t dsym, bool first, uint32_t prev_dsym,
+                                              uint32_t basemask, uint32_t S, uint16_t* __restrict__ slot_res,
+                                              uint32_t* __restrict__ slot_rec, uint32_t* __restrict__ pool,
+                                              uint32_t pool_cap, uint32_t* __restrict__ counters,
+                                              uint32_t* __restrict__ heads, uint32_t* __restrict__ redo_out,
+                                              uint32_t redo_ci, uint32_t flag_single) {
+    (void)S;
+    if (__ballot(vl.ovf) != 0ull) {   // more distinct contexts in a slot than this instantiation keeps: redo with a larger E
+        if (lane == 0) {
+            if (redo_out) redo_out[atomicAdd(&counters[redo_ci], 1u)] = c;
+            else atomicOr(&counters[CNT_ERR], ERR_CTX_OVERFLOW);
+        }
+        return;
+    }
+    const bool own = lane >= 2 && valid;
+    const uint32_t total = vl.total(L, lane);
+    const bool single = __popc(basemask) == 1;
+    uint32_t psingle = __shfl_up((uint32_t)single, 1);
+    const bool prev_is_single = first || psingle != 0;
+    const bool is_head = own && !single && prev_is_single;
+    const bool need_rec = own && (!single || !prev_is_single);
+    if (own) {
+        uint32_t res = 0xffu;
+        if (single) res = dsym | (((total == 1 ? 1u : 0u) | flag_single) << 8);
+        slot_res[s] = (uint16_t)res;
+    }
+    const uint32_t words = need_rec ? vl.n + REC_FIXED_WORDS : 0u;
+    uint32_t incl = words;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const uint32_t wave_total = __shfl(incl, 63);
+    uint32_t base = 0;
+    if (wave_total) {
+        if (lane == 63) base = atomicAdd(&counters[CNT_POOL], wave_total);
+        base = __shfl(base, 63);
+    }
+    const bool fits = (uint64_t)base + wave_total <= (uint64_t)pool_cap;
+    if (!fits && lane == 0) atomicOr(&counters[CNT_ERR], ERR_POOL_OVERFLOW);
+    uint32_t my_off = 0xffffffffu;
+    if (need_rec && fits) {
+        my_off = base + incl - words;
+        uint32_t hdr = (single ? REC_SINGLE : 0u) | ((info & SI_LAST) ? REC_CTG_LAST : 0u) |
+                       (first ? REC_CTG_FIRST : 0u) | (prev_dsym << 4);
+        vl.write_record(pool + my_off, s, total, hdr, L, lane);
+    }
+    if (own) slot_rec[s] = my_off;
+    const unsigned long long hb = __ballot(is_head && fits);
+    if (hb) {
+        uint32_t hbase = 0;
+        if (lane == 0) hbase = atomicAdd(&counters[CNT_HEADS], (uint32_t)__popcll(hb));
+        hbase = __shfl(hbase, 0);
+        if (is_head && fits) heads[hbase + __popcll(hb & ((1ull << lane) - 1ull))] = my_off;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SeqLds {   // the record's packed bases, staged in LDS with the rest of its batch
+    const uint8_t* b;
+    __device__ __forceinline__ uint32_t operator()(int32_t q) const { return (b[q >> 1] >> ((~q & 1) << 2)) & 0xf; }
+};
+
+// whole-wave shift right by one lane (lane i receives lane i-1, lane 0 receives 0): one DPP move, no LDS traffic
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_desc (fused pipeline, default): one lane per record -> its descriptor (np1_core.h build_desc) and the
+// candidate record range of every vote chunk (wave-aggregated min/max instead of per-record atomics)
+__global__ __launch_bounds__(256) void k_desc(ReadsDev R, int64_t n_reads, const uint32_t* __restrict__ ctg_off,
+                                              const uint32_t* __restrict__ soff, const int32_t* __restrict__ qs,
+                                              const int32_t* __restrict__ qe, uint32_t* __restrict__ desc,
+                                              uint32_t* __restrict__ ovf_pool, uint32_t ovf_cap,
+                                              uint32_t* __restrict__ chunk_first, uint32_t* __restrict__ chunk_last,
+                                              uint32_t* __restrict__ counters) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t c0 = 1, c1 = 0;
+    if (r < n_reads) desc_record(R, r, ctg_off, soff, qs, qe, desc, ovf_pool, ovf_cap, counters, &c0, &c1);
+    const bool has = c0 <= c1;
+    if (__ballot(has) == 0ull) return;
+    uint32_t lo = has ? c0 : 0xffffffffu, hi = has ? c1 : 0u;
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+        if (a < lo) lo = a;
+        if (b > hi) hi = b;
+    }
+    const uint32_t r_wave = (uint32_t)(r - lane);
+    if (hi - lo <= 48) {
+        for (uint32_t cc = lo; cc <= hi; ++cc) {
+            const unsigned long long mk = __ballot(has && c0 <= cc && cc <= c1);
+            if (mk && lane == 0) {
+                atomicMin(&chunk_first[cc], r_wave + (uint32_t)__builtin_ctzll(mk));
+                atomicMax(&chunk_last[cc], r_wave + 63u - (uint32_t)__builtin_clzll(mk));
+            }
+        }
+    } else if (has) {   // records of one wave far apart (sparse coverage, contig boundaries): plain per-record updates
+        for (uint32_t cc = c0; cc <= c1; ++cc) {
+            atomicMin(&chunk_first[cc], (uint32_t)r);
+            atomicMax(&chunk_last[cc], (uint32_t)r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tile3 (fused pipeline, default): pileup columns through LDS without symbol rows.
+// A workgroup owns NW consecutive vote chunks.  Per batch of candidate records it stages, fully coalesced,
+// the records' descriptors (88 B) and packed bases (~75 B) into LDS; then every wave walks the batch in
+// record order (wave-uniform loop, descriptor reads are LDS broadcasts) and each lane (= slot) evaluates
+// the record's symbol at its own (draft index, insertion column) straight from the staged bases, takes
+// its two left neighbours' symbols with DPP shifts and tallies the 3-base context.  HBM traffic: the
+// record stream once per overlapped tile (x1.3), slot_info/slot_g, per-slot results, DP records.
+template <int E, int NW>
+__global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* __restrict__ soff,
+                                                   const uint32_t* __restrict__ desc,
+                                                   const uint32_t* __restrict__ ovf_pool,
+                                                   const uint32_t* __restrict__ chunk_first,
+                                                   const uint32_t* __restrict__ chunk_last, uint32_t n_chunks,
+                                                   const uint32_t* __restrict__ redo_in, uint32_t n_items,
+                                                   const uint8_t* __restrict__ slot_info,
+                                                   const uint32_t* __restrict__ slot_g, uint32_t S, uint32_t seq_w,
+                                                   uint32_t nb_max, uint16_t* __restrict__ slot_res,
+                                                   uint32_t* __restrict__ slot_rec, uint32_t* __restrict__ pool,
+                                                   uint32_t pool_cap, uint32_t* __restrict__ counters,
+                                                   uint32_t* __restrict__ heads, uint32_t* __restrict__ redo_out,
+                                                   uint32_t redo_ci, uint32_t flag_single,
+                                                   unsigned long long* __restrict__ votes) {
+    extern __shared__ uint32_t lds[];
+    __shared__ uint32_t sh_r[2];
+    uint32_t* lists = lds;                             // NW * (E-2) * 64
+    uint32_t* dsc = lists + NW * (E - 2) * 64;         // nb_max * DESC_WORDS
+    uint32_t* seqst = dsc + nb_max * DESC_WORDS;       // nb_max * seq_w + 2
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    const uint32_t cbase = redo_in ? redo_in[item] : item * NW;
+    const uint32_t c = cbase + wave;
+    const bool chunk_ok = c < n_chunks;
+    if (tid == 0) {
+        uint32_t r0 = 0xffffffffu, r1 = 0;
+        for (int w = 0; w < NW; ++w) {
+            uint32_t cc = cbase + w;
+            if (cc < n_chunks) {
+                uint32_t f = chunk_first[cc];
+                if (f != 0xffffffffu) {
+                    if (f < r0) r0 = f;
+                    uint32_t l = chunk_last[cc];
+                    if (l > r1) r1 = l;
+                }
+            }
+        }
+        sh_r[0] = r0;
+        sh_r[1] = r1;
+    }
+    uint32_t* L = lists + wave * (E - 2) * 64;
+    const int64_t s64 = (int64_t)c * VOTE_CH - 2 + lane;
+    const bool valid = chunk_ok && s64 >= 0 && s64 < (int64_t)S;
+    const uint32_t s = (uint32_t)s64;
+    const uint32_t info = valid ? slot_info[s] : 0u;
+    const uint32_t g = valid ? slot_g[s] : 0u;
+    const int32_t jj = (valid && (info & SI_INSERT)) ? (int32_t)(s - soff[g]) - 1 : -1;   // insertion column, -1 = base slot
+    const uint32_t dsym = info & 0xf;
+    const bool first = (info & SI_FIRST) != 0;
+    // the draft votes once per slot with its own rolling context (contig.c:373-383)
+    uint32_t d1 = wave_shr1(dsym), d2 = wave_shr1(d1);
+    const uint32_t f1 = wave_shr1((uint32_t)first);
+    const uint32_t prev_dsym = d1;
+    if (first) { d1 = 0; d2 = 0; }
+    else if (f1) d2 = 0;
+    VoteLane<E> vl;
+    vl.init(d2 << 8 | d1 << 4 | dsym);
+    uint32_t basemask = 1u << dsym;
+    uint32_t nvotes = 0;
+    const int64_t cs = (int64_t)c * VOTE_CH - 2, ce = (int64_t)c * VOTE_CH + VOTE_CH - 1;
+    __syncthreads();
+    const uint32_t r0 = sh_r[0], r1 = sh_r[1];
+    if (r0 != 0xffffffffu) {
+        for (uint64_t rb = r0; rb <= r1; rb += nb_max) {
+            const uint32_t nb = (uint32_t)((r1 - rb + 1 < nb_max) ? (r1 - rb + 1) : nb_max);
+            // ---- stage descriptors and packed bases of the batch (both contiguous in HBM)
+            const uint32_t* dsrc = desc + rb * DESC_WORDS;
+            for (uint32_t i = tid; i < nb * DESC_WORDS; i += NW * 64) dsc[i] = dsrc[i];
+            const uint64_t sq0 = R.seq_off[rb] & ~3ull;
+            const uint64_t sq1 = R.seq_off[rb + nb - 1] + (((uint64_t)R.l_qseq[rb + nb - 1] + 1) >> 1);
+            const uint32_t sq_words = (uint32_t)((sq1 - sq0 + 3) >> 2);
+            const bool seq_staged = sq_words <= nb_max * seq_w + 2;   // always true for a well-formed stream
+            if (seq_staged) {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(R.seq + sq0);
+                for (uint32_t i = tid; i < sq_words; i += NW * 64) seqst[i] = src[i];
+            }
+            __syncthreads();
+            for (uint32_t k = tid; k < nb; k += NW * 64) dsc[k * DESC_WORDS + 3] = (uint32_t)(R.seq_off[rb + k] - sq0);
+            __syncthreads();
+            // ---- this wave's chunk votes over the batch, in record order
+            if (chunk_ok) {
+                uint32_t a = nb, b = 0;
+                for (uint32_t base = 0; base < nb; base += 64) {
+                    const uint32_t i = base + lane;
+                    bool hit = false;
+                    if (i < nb) {
+                        const uint32_t sf = dsc[i * DESC_WORDS], sl = dsc[i * DESC_WORDS + DESC_NEXT + 1];   // whole record
+                        hit = sf <= sl && dsc[i * DESC_WORDS + 1] >= sf && (int64_t)sl + 2 >= cs && (int64_t)sf <= ce;
+                    }
+                    const unsigned long long mk = __ballot(hit);
+                    if (mk) {
+                        const uint32_t lo = base + (uint32_t)__builtin_ctzll(mk), hi = base + 63u - (uint32_t)__builtin_clzll(mk);
+                        if (lo < a) a = lo;
+                        if (hi > b) b = hi;
+                    }
+                }
+                for (uint32_t i = a; i <= b && a < nb; ++i) {
+                    const uint32_t* d = dsc + i * DESC_WORDS;
+                    const uint8_t* sb = seq_staged ? reinterpret_cast<const uint8_t*>(seqst) + d[3] : R.seq + R.seq_off[rb + i];
+                    uint32_t rsym = 0;   // this record's symbol at my slot (kept across the parts of a chained record)
+                    for (;;) {
+                        const bool cov = valid && s >= d[0] && s <= d[1];
+                        if (cov) rsym = desc_symbol(d, g, jj, SeqLds{sb});
+                        const uint32_t p1 = wave_shr1(rsym), p2 = wave_shr1(p1);
+                        if (cov) {
+                            basemask |= 1u << rsym;
+                            if (lane >= 2) { vl.tally(p2 << 8 | p1 << 4 | rsym, L, lane); ++nvotes; }
+                        }
+                        const uint32_t nx = d[DESC_NEXT];
+                        if (nx == 0) break;
+                        d = ovf_pool + (uint64_t)(nx - 1) * DESC_WORDS;   // rare: record with many indel operations
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!chunk_ok) return;
+    for (int o = 32; o > 0; o >>= 1) nvotes += __shfl_down(nvotes, o);
+    const bool ovf_any = __ballot(vl.ovf) != 0ull;
+    if (lane == 0 && nvotes && !ovf_any) atomicAdd(votes, (unsigned long long)nvotes);
+    vote_epilogue<E>(vl, L, lane, c, valid, s, info, dsym, first, prev_dsym, basemask, S, slot_res, slot_rec, pool, pool_cap,
+                     counters, heads, redo_out, redo_ci, flag_single);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -243,54 +490,8 @@ __global__ __launch_bounds__(256) void k_vote(const uint4* __restrict__ meta, co
             }
         }
     }
-    if (__ballot(vl.ovf) != 0ull) {   // more distinct contexts in a slot than this instantiation keeps: redo with a larger E
-        if (lane == 0) {
-            if (redo_out) redo_out[atomicAdd(&counters[redo_ci], 1u)] = c;
-            else atomicOr(&counters[CNT_ERR], ERR_CTX_OVERFLOW);
-        }
-        return;
-    }
-    const bool own = lane >= 2 && valid;
-    const uint32_t total = vl.total(L, lane);
-    const bool single = __popc(basemask) == 1;
-    uint32_t psingle = __shfl_up((uint32_t)single, 1);
-    const bool prev_is_single = first || psingle != 0;
-    const bool is_head = own && !single && prev_is_single;
-    const bool need_rec = own && (!single || !prev_is_single);
-    if (own) {
-        uint32_t res = 0xffu;
-        if (single) res = dsym | (((total == 1 ? 1u : 0u) | flag_single) << 8);
-        slot_res[s] = (uint16_t)res;
-    }
-    const uint32_t words = need_rec ? vl.n + REC_FIXED_WORDS : 0u;
-    uint32_t incl = words;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    const uint32_t wave_total = __shfl(incl, 63);
-    uint32_t base = 0;
-    if (wave_total) {
-        if (lane == 63) base = atomicAdd(&counters[CNT_POOL], wave_total);
-        base = __shfl(base, 63);
-    }
-    const bool fits = (uint64_t)base + wave_total <= (uint64_t)pool_cap;
-    if (!fits && lane == 0) atomicOr(&counters[CNT_ERR], ERR_POOL_OVERFLOW);
-    uint32_t my_off = 0xffffffffu;
-    if (need_rec && fits) {
-        my_off = base + incl - words;
-        uint32_t hdr = (single ? REC_SINGLE : 0u) | ((info & SI_LAST) ? REC_CTG_LAST : 0u) |
-                       (first ? REC_CTG_FIRST : 0u) | (prev_dsym << 4);
-        vl.write_record(pool + my_off, s, total, hdr, L, lane);
-    }
-    if (own) slot_rec[s] = my_off;
-    const unsigned long long hb = __ballot(is_head && fits);
-    if (hb) {
-        uint32_t hbase = 0;
-        if (lane == 0) hbase = atomicAdd(&counters[CNT_HEADS], (uint32_t)__popcll(hb));
-        hbase = __shfl(hbase, 0);
-        if (is_head && fits) heads[hbase + __popcll(hb & ((1ull << lane) - 1ull))] = my_off;
-    }
+    vote_epilogue<E>(vl, L, lane, c, valid, s, info, dsym, first, prev_dsym, basemask, S, slot_res, slot_rec, pool, pool_cap,
+                     counters, heads, redo_out, redo_ci, flag_single);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -373,9 +574,9 @@ void launch_scan_keep(hipStream_t st, const uint16_t* slot_res, uint64_t S, uint
 }
 
 void launch_slotinfo(hipStream_t st, const uint8_t* draft, uint32_t G, const uint32_t* ctg_off, uint32_t nc,
-                     const uint32_t* soff, uint8_t* slot_info) {
+                     const uint32_t* soff, uint8_t* slot_info, uint32_t* slot_g) {
     if (G == 0) return;
-    k_slotinfo<<<nblk(G, 256), 256, 0, st>>>(draft, G, ctg_off, nc, soff, slot_info);
+    k_slotinfo<<<nblk(G, 256), 256, 0, st>>>(draft, G, ctg_off, nc, soff, slot_info, slot_g);
 }
 
 void launch_rowcap(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
@@ -407,6 +608,51 @@ void launch_vote(hipStream_t st, int E, const uint4* meta, const uint8_t* rows, 
     else if (E <= 64) NP1_VOTE(64);
     else NP1_VOTE(160);
 #undef NP1_VOTE
+}
+
+void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
+                 const int32_t* qs, const int32_t* qe, uint32_t* desc, uint32_t* ovf_pool, uint32_t ovf_cap,
+                 uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters) {
+    if (n_reads == 0) return;
+    k_desc<<<nblk(n_reads, 256), 256, 0, st>>>(R, n_reads, ctg_off, soff, qs, qe, desc, ovf_pool, ovf_cap, chunk_first,
+                                               chunk_last, counters);
+}
+
+int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc,
+                 const uint32_t* ovf_pool, const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint32_t* redo_in,
+                 uint32_t n_redo_in, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S, uint32_t max_lq,
+                 uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters,
+                 uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes) {
+    const uint32_t seq_w = (((max_lq + 1) >> 1) + 3) / 4 + 1;   // packed bases per record, in words (upper bound)
+    const uint32_t per = (uint32_t)DESC_WORDS + seq_w;
+#define NP1_TILE3(EE, NWW, BUDGET)                                                                                   \
+    do {                                                                                                             \
+        const uint32_t fixed = (uint32_t)(NWW) * (uint32_t)((EE)-2) * 64u + 2u;                                      \
+        uint32_t budget = (BUDGET);                                                                                  \
+        if (budget < fixed + per) budget = fixed + per;                                                              \
+        if (budget > 40960u - 64u) return -1;                                                                        \
+        uint32_t nb_max = (budget - fixed) / per;                                                                    \
+        if (nb_max > 512u) nb_max = 512u;                                                                            \
+        const uint32_t bytes = (fixed + nb_max * per) * 4u;                                                          \
+        uint32_t items = redo_in ? n_redo_in : (n_chunks + (NWW)-1) / (NWW);                                          \
+        if (items == 0) return 0;                                                                                    \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile3<EE, NWW>),                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);                 \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        k_tile3<EE, NWW><<<items, (NWW)*64, bytes, st>>>(R, soff, desc, ovf_pool, chunk_first, chunk_last, n_chunks,    \
+                                                          redo_in,                                                   \
+                                                          items, slot_info, slot_g, S, seq_w, nb_max, slot_res,      \
+                                                          slot_rec, pool, pool_cap, counters, heads, redo_out,       \
+                                                          redo_ci, flag_single, votes);                              \
+    } while (0)
+    if (level == 0) NP1_TILE3(8, 8, 13312u);        // 52 KiB: three workgroups per CU
+    else if (level == 1) NP1_TILE3(64, 1, 13312u);
+    else NP1_TILE3(160, 1, 24576u);
+#undef NP1_TILE3
+    return 0;
 }
 
 void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t* pool, const uint32_t* slot_rec,

@@ -220,12 +220,17 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
                         // a short '='/'X' stretch (ops the reference walk ignores entirely)
                         uint32_t n = 0;
                         while (n < 6 && k + n < hi && cols[k + n].op == 'M') ++n;
+                        // keep an M on both sides: two insertions with nothing but ignored ops between them would sit
+                        // at one reference position, a CIGAR shape no aligner emits and the GPU path rejects
+                        if (cols[k - 1].op != 'M' || k + n >= hi || cols[k + n].op != 'M') { push_op(op, 1); continue; }
                         push_op(rng.chance(0.5) ? 7u : 8u, n);
                         k += n - 1;
                         used_eqx = true;
                         continue;
                     }
-                    if (wkind == 2 && op == 2 && !used_eqx) { push_op(3, 1); used_eqx = true; continue; }   // N
+                    if (wkind == 2 && op == 2 && !used_eqx && k > lo && k + 1 < hi && cols[k - 1].op == 'M' && cols[k + 1].op == 'M') {
+                        push_op(3, 1); used_eqx = true; continue;   // N (ignored by the reference walk: no pos advance)
+                    }
                     push_op(op, 1);
                 }
                 push_op(4, (uint32_t)sR);

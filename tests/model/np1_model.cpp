@@ -12,6 +12,7 @@
 
 #include "../../include/nextpolish1.h"
 #include "../../nextpolish_amd/csrc/np1_core.h"
+#include "../../nextpolish_amd/csrc/np1_desc.h"
 
 using namespace np1k;
 
@@ -102,9 +103,90 @@ bool vote_chunk(uint32_t c, const std::vector<uint4>& meta, const std::vector<ui
     }
     return true;
 }
+// fused sequence (k_desc + k_tile3): lanes evaluate record descriptors instead of reading symbol rows
+template <int E>
+bool vote_chunk_desc(uint32_t c, const std::vector<uint32_t>& desc, const std::vector<uint32_t>& ovf, const ReadsDev& R, const std::vector<uint32_t>& soff,
+                     const std::vector<uint8_t>& slot_info, const std::vector<uint32_t>& slot_g, uint32_t S,
+                     const std::vector<uint32_t>& chunk_first, const std::vector<uint32_t>& chunk_last,
+                     std::vector<uint16_t>& slot_res, std::vector<uint32_t>& slot_rec, std::vector<uint32_t>& pool,
+                     std::vector<uint32_t>& heads, uint32_t flag_single) {
+    std::vector<uint32_t> L((E - 2) * 64);
+    VoteLane<E> vl[64];
+    uint32_t info[64], dsym[64], basemask[64], sym[64], g[64], s[64], prev_dsym[64];
+    int32_t jj[64];
+    bool valid[64], first[64];
+    for (int l = 0; l < 64; ++l) {
+        int64_t s64 = (int64_t)c * VOTE_CH - 2 + l;
+        valid[l] = s64 >= 0 && s64 < (int64_t)S;
+        s[l] = (uint32_t)s64;
+        info[l] = valid[l] ? slot_info[s[l]] : 0u;
+        g[l] = valid[l] ? slot_g[s[l]] : 0u;
+        jj[l] = (valid[l] && (info[l] & SI_INSERT)) ? (int32_t)(s[l] - soff[g[l]]) - 1 : -1;
+        dsym[l] = info[l] & 0xf;
+        first[l] = (info[l] & SI_FIRST) != 0;
+    }
+    for (int l = 0; l < 64; ++l) {   // wave_shr1: lane 0 receives 0
+        uint32_t d1 = l >= 1 ? dsym[l - 1] : 0, d2 = l >= 2 ? dsym[l - 2] : 0;
+        uint32_t f1 = l >= 1 ? (uint32_t)first[l - 1] : 0;
+        prev_dsym[l] = d1;
+        if (first[l]) { d1 = 0; d2 = 0; }
+        else if (f1) d2 = 0;
+        vl[l].init(d2 << 8 | d1 << 4 | dsym[l]);
+        basemask[l] = 1u << dsym[l];
+    }
+    uint32_t r0 = chunk_first[c], r1 = chunk_last[c];
+    if (r0 != 0xffffffffu)
+        for (uint32_t r = r0; r <= r1; ++r) {
+            const uint32_t* d = desc.data() + (uint64_t)r * DESC_WORDS;
+            for (int l = 0; l < 64; ++l) sym[l] = 0;   // rsym: kept across the parts of a chained record
+            for (;;) {
+                bool cov[64];
+                for (int l = 0; l < 64; ++l) {
+                    cov[l] = valid[l] && s[l] >= d[0] && s[l] <= d[1];
+                    if (cov[l]) sym[l] = desc_symbol(d, g[l], jj[l], SeqBytes{R.seq + R.seq_off[r]});
+                }
+                for (int l = 0; l < 64; ++l) {
+                    uint32_t p1 = l >= 1 ? sym[l - 1] : 0, p2 = l >= 2 ? sym[l - 2] : 0;
+                    if (cov[l]) {
+                        basemask[l] |= 1u << sym[l];
+                        if (l >= 2) vl[l].tally(p2 << 8 | p1 << 4 | sym[l], L.data(), l);
+                    }
+                }
+                if (d[DESC_NEXT] == 0) break;
+                d = ovf.data() + (uint64_t)(d[DESC_NEXT] - 1) * DESC_WORDS;
+            }
+        }
+    for (int l = 0; l < 64; ++l)
+        if (vl[l].ovf) return false;
+    bool single[64];
+    for (int l = 0; l < 64; ++l) single[l] = __builtin_popcount(basemask[l]) == 1;
+    for (int l = 2; l < 64; ++l) {
+        if (!valid[l]) continue;
+        uint32_t total = vl[l].total(L.data(), l);
+        bool prev_is_single = first[l] || single[l - 1];
+        bool is_head = !single[l] && prev_is_single;
+        bool need_rec = !single[l] || !prev_is_single;
+        uint32_t res = 0xffu;
+        if (single[l]) res = dsym[l] | (((total == 1 ? 1u : 0u) | flag_single) << 8);
+        slot_res[s[l]] = (uint16_t)res;
+        uint32_t my_off = 0xffffffffu;
+        if (need_rec) {
+            my_off = (uint32_t)pool.size();
+            pool.resize(pool.size() + vl[l].n + REC_FIXED_WORDS, 0xdeadbeefu);
+            uint32_t hdr = (single[l] ? REC_SINGLE : 0u) | ((info[l] & SI_LAST) ? REC_CTG_LAST : 0u) |
+                           (first[l] ? REC_CTG_FIRST : 0u) | (prev_dsym[l] << 4);
+            vl[l].write_record(pool.data() + my_off, s[l], total, hdr, L.data(), l);
+        }
+        slot_rec[s[l]] = my_off;
+        if (is_head) heads.push_back(my_off);
+    }
+    return true;
+}
 }  // namespace
 
 extern "C" {
+int np1m_fused = 0;   // 0: staged sequence (rows in memory), 1: fused sequence (descriptors)
+
 
 // Returns 0 on success; *out is malloc'd concatenation of the polished contigs, bounds[n_contigs+1].
 // stats (optional, 4 words): slots, dp heads, pool words, max context list length escalations
@@ -132,33 +214,57 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
     soff[G] = (uint32_t)acc;
     const uint32_t S = (uint32_t)acc;
     std::vector<uint8_t> slot_info(S + 64, 0);
+    std::vector<uint32_t> slot_g(S + 64, 0);
     for (uint32_t c = 0; c < nc; ++c)
         for (uint32_t g = v->ctg_off[c]; g < v->ctg_off[c + 1]; ++g)
-            slotinfo_base((const uint8_t*)v->draft, g, v->ctg_off[c], v->ctg_off[c + 1], soff.data(), slot_info.data());
-    std::vector<uint32_t> rbase(n), capb(n);
-    std::vector<uint64_t> rowoff(n + 1);
-    uint64_t rb = 0;
-    for (int64_t r = 0; r < n; ++r) {
-        rowcap_record(R, r, v->ctg_off, soff.data(), qs.data(), qe.data(), span.data(), rbase.data(), capb.data());
-        rowoff[r] = rb;
-        rb += capb[r];
-    }
-    rowoff[n] = rb;
-    std::vector<uint8_t> rows(rb + 64, 0xEE);
-    std::vector<uint4> meta(n ? n : 1);
+            slotinfo_base((const uint8_t*)v->draft, g, v->ctg_off[c], v->ctg_off[c + 1], soff.data(), slot_info.data(), slot_g.data());
     const uint32_t n_chunks = (S + VOTE_CH - 1) / VOTE_CH + 1;
     std::vector<uint32_t> chunk_first(n_chunks, 0xffffffffu), chunk_last(n_chunks, 0);
-    for (int64_t r = 0; r < n; ++r)
-        rows_record(R, r, v->ctg_off, soff.data(), qs.data(), qe.data(), rbase.data(), rowoff.data(), rows.data(), meta.data(),
-                    chunk_first.data(), chunk_last.data());
     std::vector<uint16_t> slot_res(S + 64, 0xffff);
     std::vector<uint32_t> slot_rec(S + 64, 0xffffffffu), pool, heads;
     uint64_t escal = 0;
-    for (uint32_t c = 0; c < n_chunks; ++c) {
-        if (vote_chunk<16>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
-        ++escal;
-        if (vote_chunk<64>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
-        if (!vote_chunk<160>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) return -3;
+    if (np1m_fused) {
+        std::vector<uint32_t> desc((size_t)(n ? n : 1) * DESC_WORDS, 0xdeadbeefu);
+        const uint32_t ovf_cap = (uint32_t)(v->cigar_len + 16);
+        std::vector<uint32_t> ovf((size_t)ovf_cap * DESC_WORDS, 0xdeadbeefu);
+        for (int64_t r = 0; r < n; ++r) {
+            uint32_t c0, c1;
+            desc_record(R, r, v->ctg_off, soff.data(), qs.data(), qe.data(), desc.data(), ovf.data(), ovf_cap, counters.data(), &c0, &c1);
+            if (counters[CNT_ERR] & ERR_DESC_OVERFLOW) return -5;
+            for (uint32_t cc = c0; cc <= c1 && c0 <= c1; ++cc) {
+                if ((uint32_t)r < chunk_first[cc]) chunk_first[cc] = (uint32_t)r;
+                if ((uint32_t)r > chunk_last[cc]) chunk_last[cc] = (uint32_t)r;
+            }
+        }
+        if (stats) stats[3] = counters[CNT_OVFDESC];
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            if (vote_chunk_desc<8>(c, desc, ovf, R, soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
+            ++escal;
+            if (vote_chunk_desc<64>(c, desc, ovf, R, soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
+            if (!vote_chunk_desc<160>(c, desc, ovf, R, soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) return -3;
+        }
+    } else {
+        std::vector<uint32_t> rbase(n), capb(n);
+        std::vector<uint64_t> rowoff(n + 1);
+        uint64_t rb = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            rowcap_record(R, r, v->ctg_off, soff.data(), qs.data(), qe.data(), span.data(), rbase.data(), capb.data());
+            rowoff[r] = rb;
+            rb += capb[r];
+        }
+        rowoff[n] = rb;
+        std::vector<uint8_t> rows(rb + 64, 0xEE);
+        std::vector<uint4> meta(n ? n : 1);
+        for (int64_t r = 0; r < n; ++r)
+            rows_record(R, r, v->ctg_off, soff.data(), qs.data(), qe.data(), rbase.data(), rowoff.data(), rows.data(), meta.data(),
+                        chunk_first.data(), chunk_last.data());
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            if (vote_chunk<16>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
+            ++escal;
+            if (vote_chunk<64>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
+            if (!vote_chunk<160>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) return -3;
+        }
+
     }
     HostState st;
     for (uint32_t h : heads)
@@ -172,7 +278,7 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
     for (uint32_t s = 0; s < S; ++s) emit_slot(s, slot_res.data(), slot_info.data(), opos.data(), 3u, (uint8_t*)buf);
     for (uint32_t c = 0; c <= nc; ++c) bounds[c] = opos[soff[v->ctg_off[c]]];
     *out = buf;
-    if (stats) { stats[0] = S; stats[1] = heads.size(); stats[2] = pool.size(); stats[3] = escal; }
+    if (stats) { stats[0] = S; stats[1] = heads.size(); stats[2] = pool.size(); if (!np1m_fused) stats[3] = escal; }
     return 0;
 }
 
