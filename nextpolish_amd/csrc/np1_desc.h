@@ -16,6 +16,7 @@ namespace np1k {
 constexpr int DESC_NSEG = 5, DESC_NINS = 2;
 constexpr int DESC_SEG0 = 4, DESC_INS0 = DESC_SEG0 + 2 * DESC_NSEG, DESC_NEXT = DESC_INS0 + 2 * DESC_NINS;
 constexpr int DESC_WORDS = DESC_NEXT + 2;   // 20 words = 80 B per record
+constexpr uint32_t DESC_CHAIN = 1u << 16;   // d[2] flag of a head part that continues in the overflow pool
 // d[0]=sfirst d[1]=slast (this part)  d[2]=nseg | nins<<8  d[3]=(k_tile3: byte offset of the packed bases in LDS)
 // seg k: d[SEG0+2k]=g_lo, +1: len | qcode<<16 (qcode = q_lo, or 0xffff for DEL)
 // ins k: d[INS0+2k]=p,    +1: len | q0<<16
@@ -51,7 +52,7 @@ struct DescBuilder {
         if (failed) return;
         uint32_t idx = desc_alloc_part(sink);
         if (idx >= sink.ovf_cap) { failed = true; np1_atomic_or(sink.err, ERR_DESC_OVERFLOW); return; }
-        d[0] = sfirst; d[1] = slast; d[2] = nseg | nins << 8;
+        d[0] = sfirst; d[1] = slast; d[2] = nseg | nins << 8 | DESC_CHAIN;
         d[DESC_NEXT] = idx + 1;
         d = sink.ovf_pool + (uint64_t)idx * DESC_WORDS;
         d[DESC_NEXT] = 0; d[DESC_NEXT + 1] = 0; d[3] = 0;

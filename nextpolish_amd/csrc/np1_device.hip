@@ -367,7 +367,8 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                                     b->chunk_last.as<uint32_t>(), n_chunks, redo_in, n_redo, b->slot_info.as<uint8_t>(),
                                     b->slot_g.as<uint32_t>(), S, b->max_lq, b->slot_res.as<uint16_t>(),
                                     b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
-                                    b->heads.as<uint32_t>(), redo_out, redo_ci, flag_single, votes);
+                                    b->heads.as<uint32_t>(), (uint32_t)std::min<size_t>(b->heads.cap / 4, 0xfffffff0u), redo_out,
+                                    redo_ci, flag_single, votes);
             };
             HIPCHK(hipMemsetAsync(&totals[3], 0, 8, q));
             t0(5);
@@ -390,7 +391,8 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
             }
             if (hc[CNT_ERR] & ERR_POOL_OVERFLOW) {
                 if (attempt >= 3) { np1_set_error("DP record pool keeps overflowing"); return -1; }
-                size_t need = (size_t)hc[CNT_POOL] * 4;
+                size_t need = 2 * b->pool.cap;   // a shard ran out: double the pool (and the run-head list with it)
+                if (b->heads.ensure(2 * b->heads.cap)) return -1;
                 if (b->pool.ensure(need + need / 4 + (1u << 20))) return -1;
                 uint32_t zero[CNT_WORDS] = {0};
                 zero[CNT_ERR] = hc[CNT_ERR] & ~ERR_POOL_OVERFLOW;
@@ -408,10 +410,16 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     t0(6);
     {
         uint32_t heads = hc[CNT_HEADS];
+        if (!staged) {
+            heads = 0;
+            for (uint32_t sh = 0; sh < POOL_SHARDS; ++sh) heads += hc[CNT_HEADS_S0 + sh];
+        }
         uint32_t grid = (heads + 63) / 64;
         if (grid == 0) grid = 1;
-        launch_dp(q, b->heads.as<uint32_t>(), counters, b->pool.as<uint32_t>(), b->slot_rec.as<uint32_t>(),
-                  b->slot_res.as<uint16_t>(), K, Rfix, cfg->min_count_ratio_skip, grid);
+        const uint32_t heads_cap = (uint32_t)std::min<size_t>(b->heads.cap / 4, 0xfffffff0u);
+        launch_dp(q, b->heads.as<uint32_t>(), counters, staged ? (uint32_t)CNT_HEADS : (uint32_t)CNT_HEADS_S0,
+                  staged ? 1u : POOL_SHARDS, staged ? 0u : heads_cap / POOL_SHARDS, b->pool.as<uint32_t>(),
+                  b->slot_rec.as<uint32_t>(), b->slot_res.as<uint16_t>(), K, Rfix, cfg->min_count_ratio_skip, grid);
     }
     t1(6);
     // ---- stage 7: emit

@@ -299,6 +299,21 @@ __global__ __launch_bounds__(256) void k_desc(ReadsDev R, int64_t n_reads, const
 // the record's symbol at its own (draft index, insertion column) straight from the staged bases, takes
 // its two left neighbours' symbols with DPP shifts and tallies the 3-base context.  HBM traffic: the
 // record stream once per overlapped tile (x1.3), slot_info/slot_g, per-slot results, DP records.
+// one part of one record against this wave's 64 slots (d may live in LDS or, for overflow parts, in HBM: the two
+// call sites keep the address spaces apart so the common path compiles to ds_read)
+template <int E>
+__device__ __forceinline__ void vote_part(const uint32_t* d, const SeqLds& sq, bool valid, uint32_t s, uint32_t g,
+                                          int32_t jj, int lane, uint32_t& rsym, uint32_t& basemask, VoteLane<E>& vl,
+                                          uint32_t* L, uint32_t& nvotes, uint32_t ablate = 0) {
+    const bool cov = valid && s >= d[0] && s <= d[1];
+    if (cov) rsym = (ablate & 8u) ? (g & 0xfu) : desc_symbol(d, g, jj, sq);
+    const uint32_t p1 = wave_shr1(rsym), p2 = wave_shr1(p1);
+    if (cov) {
+        basemask |= 1u << rsym;
+        if (lane >= 2 && !(ablate & 4u)) { vl.tally(p2 << 8 | p1 << 4 | rsym, L, lane); ++nvotes; }
+    }
+}
+
 template <int E, int NW>
 __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* __restrict__ soff,
                                                    const uint32_t* __restrict__ desc,
@@ -311,14 +326,15 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
                                                    uint32_t nb_max, uint16_t* __restrict__ slot_res,
                                                    uint32_t* __restrict__ slot_rec, uint32_t* __restrict__ pool,
                                                    uint32_t pool_cap, uint32_t* __restrict__ counters,
-                                                   uint32_t* __restrict__ heads, uint32_t* __restrict__ redo_out,
+                                                   uint32_t* __restrict__ heads, uint32_t heads_cap,
+                                                   uint32_t* __restrict__ redo_out,
                                                    uint32_t redo_ci, uint32_t flag_single,
-                                                   unsigned long long* __restrict__ votes) {
-    extern __shared__ uint32_t lds[];
-    __shared__ uint32_t sh_r[2];
+                                                   unsigned long long* __restrict__ votes, uint32_t ablate) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ __attribute__((aligned(16))) uint32_t sh_r[4];
     uint32_t* lists = lds;                             // NW * (E-2) * 64
     uint32_t* dsc = lists + NW * (E - 2) * 64;         // nb_max * DESC_WORDS
-    uint32_t* seqst = dsc + nb_max * DESC_WORDS;       // nb_max * seq_w + 2
+    uint32_t* seqst = dsc + (nb_max + 1) * DESC_WORDS; // nb_max * seq_w + 2 (one spare descriptor slot before it)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t item = blockIdx.x;
     if (item >= n_items) return;
@@ -360,6 +376,7 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
     vl.init(d2 << 8 | d1 << 4 | dsym);
     uint32_t basemask = 1u << dsym;
     uint32_t nvotes = 0;
+    const uint32_t sv = valid ? s : 0xffffffffu;   // slot for coverage tests (never covered when invalid)
     const int64_t cs = (int64_t)c * VOTE_CH - 2, ce = (int64_t)c * VOTE_CH + VOTE_CH - 1;
     __syncthreads();
     const uint32_t r0 = sh_r[0], r1 = sh_r[1];
@@ -372,16 +389,16 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
             const uint64_t sq0 = R.seq_off[rb] & ~3ull;
             const uint64_t sq1 = R.seq_off[rb + nb - 1] + (((uint64_t)R.l_qseq[rb + nb - 1] + 1) >> 1);
             const uint32_t sq_words = (uint32_t)((sq1 - sq0 + 3) >> 2);
-            const bool seq_staged = sq_words <= nb_max * seq_w + 2;   // always true for a well-formed stream
-            if (seq_staged) {
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(R.seq + sq0);
-                for (uint32_t i = tid; i < sq_words; i += NW * 64) seqst[i] = src[i];
-            }
+            // the pool holds the records back to back, so nb records never need more than nb * seq_w (+2) words
+            const uint32_t sq_fit = sq_words <= nb_max * seq_w + 2 ? sq_words : nb_max * seq_w + 2;
+            if (sq_fit != sq_words && tid == 0) atomicOr(&counters[CNT_ERR], ERR_BAD_RECORD);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(R.seq + sq0);
+            for (uint32_t i = tid; i < sq_fit; i += NW * 64) seqst[i] = src[i];
             __syncthreads();
             for (uint32_t k = tid; k < nb; k += NW * 64) dsc[k * DESC_WORDS + 3] = (uint32_t)(R.seq_off[rb + k] - sq0);
             __syncthreads();
             // ---- this wave's chunk votes over the batch, in record order
-            if (chunk_ok) {
+            if (chunk_ok && !(ablate & 2u)) {
                 uint32_t a = nb, b = 0;
                 for (uint32_t base = 0; base < nb; base += 64) {
                     const uint32_t i = base + lane;
@@ -397,33 +414,142 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
                         if (hi > b) b = hi;
                     }
                 }
-                for (uint32_t i = a; i <= b && a < nb; ++i) {
-                    const uint32_t* d = dsc + i * DESC_WORDS;
-                    const uint8_t* sb = seq_staged ? reinterpret_cast<const uint8_t*>(seqst) + d[3] : R.seq + R.seq_off[rb + i];
-                    uint32_t rsym = 0;   // this record's symbol at my slot (kept across the parts of a chained record)
-                    for (;;) {
-                        const bool cov = valid && s >= d[0] && s <= d[1];
-                        if (cov) rsym = desc_symbol(d, g, jj, SeqLds{sb});
-                        const uint32_t p1 = wave_shr1(rsym), p2 = wave_shr1(p1);
-                        if (cov) {
-                            basemask |= 1u << rsym;
-                            if (lane >= 2) { vl.tally(p2 << 8 | p1 << 4 | rsym, L, lane); ++nvotes; }
+                if (a < nb && !(ablate & 16u)) {
+                    const uint8_t* seqb = reinterpret_cast<const uint8_t*>(seqst);
+                    // descriptor head (sfirst, slast, counts, base offset) and first segment of record a; the loop
+                    // fetches record i+1's while it votes record i (one spare descriptor slot keeps the loads in range)
+                    uint4 h = *reinterpret_cast<const uint4*>(dsc + a * DESC_WORDS);
+                    uint2 sg = *reinterpret_cast<const uint2*>(dsc + a * DESC_WORDS + DESC_SEG0);
+                    for (uint32_t i = a; i <= b; ++i) {
+                        const uint4 hn = *reinterpret_cast<const uint4*>(dsc + (i + 1) * DESC_WORDS);
+                        const uint2 sgn = *reinterpret_cast<const uint2*>(dsc + (i + 1) * DESC_WORDS + DESC_SEG0);
+                        if (!(h.z & DESC_CHAIN)) {
+                            // wave-uniform shape test; the body is branch-free apart from uniform trip counts
+                            const uint32_t nseg = h.z & 0xffu, nins = (h.z >> 8) & 0xffu;
+                            const bool cov = sv >= h.x && sv <= h.y;
+                            uint32_t q = 0;
+                            bool isdel = true;   // covered insertion column the record merely passes (or pads): DEL
+                            {
+                                const uint32_t off = g - sg.x;
+                                const bool in = jj < 0 && off < (sg.y & 0xffffu);
+                                isdel = in ? (sg.y >> 16) == 0xffffu : isdel;
+                                q = in ? (sg.y >> 16) + off : q;
+                            }
+                            for (uint32_t k2 = 1; k2 < nseg; ++k2) {
+                                const uint2 sk = *reinterpret_cast<const uint2*>(dsc + i * DESC_WORDS + DESC_SEG0 + 2 * k2);
+                                const uint32_t off = g - sk.x;
+                                const bool in = jj < 0 && off < (sk.y & 0xffffu);
+                                isdel = in ? (sk.y >> 16) == 0xffffu : isdel;
+                                q = in ? (sk.y >> 16) + off : q;
+                            }
+                            for (uint32_t k2 = 0; k2 < nins; ++k2) {
+                                const uint2 ik = *reinterpret_cast<const uint2*>(dsc + i * DESC_WORDS + DESC_INS0 + 2 * k2);
+                                const bool in = jj >= 0 && ik.x == g && (uint32_t)jj < (ik.y & 0xffffu);
+                                isdel = in ? false : isdel;
+                                q = in ? (ik.y >> 16) + (uint32_t)jj : q;
+                            }
+                            q = (cov && !isdel) ? q : 0u;
+                            const uint32_t byte = seqb[h.w + (q >> 1)];
+                            uint32_t sym = (byte >> ((~q & 1u) << 2)) & 0xfu;
+                            sym = cov ? (isdel ? 3u : sym) : 0u;
+                            const uint32_t p1 = wave_shr1(sym), p2 = wave_shr1(p1);
+                            const uint32_t k = p2 << 8 | p1 << 4 | sym;
+                            basemask |= cov ? 1u << sym : 0u;
+                            const bool vote = cov && lane >= 2;
+                            const bool m0 = vote && k == vl.k0, m1 = vote && k == vl.k1;
+                            vl.c0 += m0 ? 1u : 0u;
+                            vl.c1 += m1 ? 1u : 0u;
+                            nvotes += vote ? 1u : 0u;
+                            const bool rest = vote && !m0 && !m1;
+                            if (__ballot(rest) != 0ull) {
+                                if (rest) vl.tally(k, L, lane);   // a context seen for the first time, or one kept in the LDS list
+                            }
+                        } else {
+                            const uint32_t* d = dsc + i * DESC_WORDS;   // LDS: every access below is a ds_read broadcast
+                            const SeqLds sq{seqb + h.w};
+                            uint32_t rsym = 0;   // this record's symbol at my slot (kept across the parts of a chained record)
+                            vote_part<E>(d, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nvotes);
+                            uint32_t nx = d[DESC_NEXT];
+                            while (nx) {   // rare: record with more indel operations than one descriptor holds; parts live in HBM
+                                const uint32_t* dg = ovf_pool + (uint64_t)(nx - 1) * DESC_WORDS;
+                                vote_part<E>(dg, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nvotes);
+                                nx = dg[DESC_NEXT];
+                            }
                         }
-                        const uint32_t nx = d[DESC_NEXT];
-                        if (nx == 0) break;
-                        d = ovf_pool + (uint64_t)(nx - 1) * DESC_WORDS;   // rare: record with many indel operations
+                        h = hn;
+                        sg = sgn;
                     }
                 }
             }
             __syncthreads();
         }
     }
-    if (!chunk_ok) return;
+    // ---- epilogue: single-state slots are final; multi-state runs spill DP records.  Pool space and run-head
+    // slots are claimed ONCE PER WORKGROUP on a counter sharded 8 ways (a single device-scope counter bumped by
+    // every wave saturates at ~90 atomics/us and used to cost as much as the voting itself).
+    __shared__ uint32_t sh_e[2 * NW + 4];
     for (int o = 32; o > 0; o >>= 1) nvotes += __shfl_down(nvotes, o);
-    const bool ovf_any = __ballot(vl.ovf) != 0ull;
-    if (lane == 0 && nvotes && !ovf_any) atomicAdd(votes, (unsigned long long)nvotes);
-    vote_epilogue<E>(vl, L, lane, c, valid, s, info, dsym, first, prev_dsym, basemask, S, slot_res, slot_rec, pool, pool_cap,
-                     counters, heads, redo_out, redo_ci, flag_single);
+    const bool ovf_any = chunk_ok && __ballot(vl.ovf) != 0ull;
+    if (lane == 0 && nvotes && !ovf_any && chunk_ok) atomicAdd(votes, (unsigned long long)nvotes);
+    if (ovf_any && lane == 0) {   // a slot holds more distinct contexts than this instantiation keeps: redo the chunk with a larger E
+        if (redo_out) redo_out[atomicAdd(&counters[redo_ci], 1u)] = c;
+        else atomicOr(&counters[CNT_ERR], ERR_CTX_OVERFLOW);
+    }
+    const bool live = chunk_ok && !ovf_any;
+    const bool own = live && lane >= 2 && valid;
+    const uint32_t total = vl.total(L, lane);
+    const bool single = __popc(basemask) == 1;
+    const uint32_t psingle = wave_shr1((uint32_t)single);
+    const bool prev_is_single = first || psingle != 0;
+    const bool is_head = own && !single && prev_is_single;
+    const bool need_rec = own && (!single || !prev_is_single);
+    if (own) {
+        uint32_t res = 0xffu;
+        if (single) res = dsym | (((total == 1 ? 1u : 0u) | flag_single) << 8);
+        slot_res[s] = (uint16_t)res;
+    }
+    const uint32_t words = need_rec ? vl.n + REC_FIXED_WORDS : 0u;
+    uint32_t incl = words;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const unsigned long long hb = __ballot(is_head);
+    if (lane == 63) sh_e[wave] = incl;
+    if (lane == 0) sh_e[NW + wave] = (uint32_t)__popcll(hb);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t wsum = 0, hsum = 0;
+        for (int w = 0; w < NW; ++w) { wsum += sh_e[w]; hsum += sh_e[NW + w]; }
+        const uint32_t shard = blockIdx.x & (POOL_SHARDS - 1);
+        const uint32_t pregion = pool_cap / POOL_SHARDS, hregion = heads_cap / POOL_SHARDS;
+        uint32_t pbase = 0xffffffffu, hbase = 0;
+        if (wsum) {
+            const uint32_t o = atomicAdd(&counters[CNT_POOL_S0 + shard], wsum);
+            if ((uint64_t)o + wsum <= pregion) pbase = shard * pregion + o;
+            else atomicOr(&counters[CNT_ERR], ERR_POOL_OVERFLOW);
+        }
+        if (hsum) {
+            const uint32_t o = atomicAdd(&counters[CNT_HEADS_S0 + shard], hsum);
+            if ((uint64_t)o + hsum <= hregion) hbase = shard * hregion + o;
+            else { atomicOr(&counters[CNT_ERR], ERR_POOL_OVERFLOW); pbase = 0xffffffffu; }
+        }
+        sh_e[2 * NW] = pbase;
+        sh_e[2 * NW + 1] = hbase;
+    }
+    __syncthreads();
+    uint32_t pbase = sh_e[2 * NW], hbase = sh_e[2 * NW + 1];
+    const bool fits = pbase != 0xffffffffu;
+    for (int w = 0; w < wave; ++w) { pbase += sh_e[w]; hbase += sh_e[NW + w]; }
+    uint32_t my_off = 0xffffffffu;
+    if (need_rec && fits) {
+        my_off = pbase + incl - words;
+        const uint32_t hdr = (single ? REC_SINGLE : 0u) | ((info & SI_LAST) ? REC_CTG_LAST : 0u) |
+                             (first ? REC_CTG_FIRST : 0u) | (prev_dsym << 4);
+        vl.write_record(pool + my_off, s, total, hdr, L, lane);
+    }
+    if (own) slot_rec[s] = my_off;
+    if (is_head && fits) heads[hbase + __popcll(hb & ((1ull << lane) - 1ull))] = my_off;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,6 +634,7 @@ struct DpLds {
 };
 
 __global__ __launch_bounds__(DP_T) void k_dp(const uint32_t* __restrict__ heads, const uint32_t* __restrict__ counters,
+                                             uint32_t cnt0, uint32_t n_shards, uint32_t heads_region,
                                              uint32_t* __restrict__ pool, const uint32_t* __restrict__ slot_rec,
                                              uint16_t* __restrict__ slot_res, int K, long long Rfix, double min_ratio,
                                              uint32_t* __restrict__ err) {
@@ -515,9 +642,14 @@ __global__ __launch_bounds__(DP_T) void k_dp(const uint32_t* __restrict__ heads,
     __shared__ uint16_t km[2][16][DP_T];
     __shared__ uint8_t rk[2][16][DP_T];
     DpLds st{sc, km, rk, (int)threadIdx.x};
-    const uint32_t n_heads = counters[CNT_HEADS];
-    for (uint32_t hi = blockIdx.x * DP_T + threadIdx.x; hi < n_heads; hi += gridDim.x * DP_T)
-        if (!dp_run(heads[hi], pool, slot_rec, slot_res, K, Rfix, min_ratio, st)) atomicOr(err, ERR_DP_INCONSISTENT);
+    uint32_t n_heads = 0;
+    for (uint32_t sh = 0; sh < n_shards; ++sh) n_heads += counters[cnt0 + sh];
+    for (uint32_t hi = blockIdx.x * DP_T + threadIdx.x; hi < n_heads; hi += gridDim.x * DP_T) {
+        uint32_t k = hi, sh = 0;   // run-head lists are sharded like the record pool
+        while (sh + 1 < n_shards && k >= counters[cnt0 + sh]) { k -= counters[cnt0 + sh]; ++sh; }
+        if (!dp_run(heads[sh * heads_region + k], pool, slot_rec, slot_res, K, Rfix, min_ratio, st))
+            atomicOr(err, ERR_DP_INCONSISTENT);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -622,12 +754,14 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
                  const uint32_t* ovf_pool, const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint32_t* redo_in,
                  uint32_t n_redo_in, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S, uint32_t max_lq,
                  uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters,
-                 uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes) {
+                 uint32_t* heads, uint32_t heads_cap, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single,
+                 unsigned long long* votes) {
     const uint32_t seq_w = (((max_lq + 1) >> 1) + 3) / 4 + 1;   // packed bases per record, in words (upper bound)
     const uint32_t per = (uint32_t)DESC_WORDS + seq_w;
+    static const uint32_t ablate = getenv("NP1_ABLATE") ? (uint32_t)atoi(getenv("NP1_ABLATE")) : 0u;   // timing experiments only
 #define NP1_TILE3(EE, NWW, BUDGET)                                                                                   \
     do {                                                                                                             \
-        const uint32_t fixed = (uint32_t)(NWW) * (uint32_t)((EE)-2) * 64u + 2u;                                      \
+        const uint32_t fixed = (uint32_t)(NWW) * (uint32_t)((EE)-2) * 64u + 2u + (uint32_t)DESC_WORDS;               \
         uint32_t budget = (BUDGET);                                                                                  \
         if (budget < fixed + per) budget = fixed + per;                                                              \
         if (budget > 40960u - 64u) return -1;                                                                        \
@@ -645,8 +779,8 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
         k_tile3<EE, NWW><<<items, (NWW)*64, bytes, st>>>(R, soff, desc, ovf_pool, chunk_first, chunk_last, n_chunks,    \
                                                           redo_in,                                                   \
                                                           items, slot_info, slot_g, S, seq_w, nb_max, slot_res,      \
-                                                          slot_rec, pool, pool_cap, counters, heads, redo_out,       \
-                                                          redo_ci, flag_single, votes);                              \
+                                                          slot_rec, pool, pool_cap, counters, heads, heads_cap,      \
+                                                          redo_out, redo_ci, flag_single, votes, ablate);            \
     } while (0)
     if (level == 0) NP1_TILE3(8, 8, 13312u);        // 52 KiB: three workgroups per CU
     else if (level == 1) NP1_TILE3(64, 1, 13312u);
@@ -655,9 +789,11 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
     return 0;
 }
 
-void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t* pool, const uint32_t* slot_rec,
-               uint16_t* slot_res, int K, long long Rfix, double min_ratio, uint32_t grid) {
-    k_dp<<<grid, DP_T, 0, st>>>(heads, counters, pool, slot_rec, slot_res, K, Rfix, min_ratio, &counters[CNT_ERR]);
+void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t cnt0, uint32_t n_shards,
+               uint32_t heads_region, uint32_t* pool, const uint32_t* slot_rec, uint16_t* slot_res, int K, long long Rfix,
+               double min_ratio, uint32_t grid) {
+    k_dp<<<grid, DP_T, 0, st>>>(heads, counters, cnt0, n_shards, heads_region, pool, slot_rec, slot_res, K, Rfix, min_ratio,
+                                &counters[CNT_ERR]);
 }
 
 void launch_fixfirst(hipStream_t st, const uint32_t* ctg_off, uint32_t nc, const uint32_t* soff, const uint8_t* slot_info,
