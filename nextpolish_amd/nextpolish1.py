@@ -1,0 +1,288 @@
+#!/usr/bin/env python
+"""Host-side mirror of the reference's per-block polish driver (reference: source/lib/nextpolish1.py).
+
+Same command line, same block-file / resume / naming behaviour, same output records
+(``>name_np1 length`` + sequence); the compute goes through the in-tree HIP library instead of a
+``multiprocessing.Pool`` of CPU workers:
+
+* task 1 (score_chain): the still-unpolished contigs of this block are decoded once, sequentially,
+  into a record stream, split into batches that fit the HBM budget, and each batch is polished by the
+  fused launch sequence (include/nextpolish1.h, np1_batch_*).  ``--gpus N`` shards the batches over N
+  GPUs of the node, one process per GPU (contigs are independent: no collective on the data path;
+  reference: nextpolish1.py:181-189,223-224 and source/nextPolish:93-117 for the block split).
+* ``-debug`` needs the per-base change list of the drop-in ABI and therefore goes contig by contig through
+  ``score_chain(tigname, cfg)`` exactly like the reference worker (nextpolish1.py:181-189).
+* tasks 2-5 call the library's drop-in symbols, which report what is (not) available on the GPU path.
+
+Record order is the order of the block file / FASTA (the reference's order is nondeterministic: it
+iterates a Python set through imap_unordered, nextpolish1.py:148-161,224).
+"""
+from __future__ import print_function
+
+import argparse
+import ctypes as C
+import os
+import sys
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.realpath(__file__))))
+from nextpolish_amd import _native as nat  # noqa: E402
+
+
+def parse_num_unit(s):
+    """reference: source/lib/kit.py parse_num_unit ('150k' -> 150000)."""
+    s = str(s).strip().lower()
+    mult = {"k": 1000, "m": 1000000, "g": 1000000000}
+    if s and s[-1] in mult:
+        return int(float(s[:-1]) * mult[s[-1]])
+    return int(float(s))
+
+
+def read_polished_seqs(infile, polished_seqs):
+    """Resume support (reference: nextpolish1.py:163-179): names already written to the output; the last
+    record may be truncated, so it is dropped and its file offset returned for the rewrite."""
+    last_seq = ""
+    cur_seq_offset = last_seq_position = 0
+    with open(infile) as IN:
+        for line in IN:
+            if line.startswith(">"):
+                last_seq_position += cur_seq_offset
+                cur_seq_offset = len(line)
+                last_seq = seq_name = line.split()[0].split("_np")[0][1:]
+                polished_seqs.add(seq_name)
+            else:
+                cur_seq_offset += len(line)
+    if last_seq:
+        polished_seqs.remove(last_seq)
+    return last_seq_position
+
+
+def read_unpolished_seqs(infile, index, polished_seqs):
+    """reference: nextpolish1.py:148-161, but order preserving."""
+    names = []
+    if index != "all":
+        with open(infile) as IN:
+            for line in IN:
+                lines = line.strip().split()
+                if lines and lines[0].split("_np")[0] not in polished_seqs and lines[1] == index:
+                    names.append(lines[0])
+    else:
+        with open(infile) as IN:
+            for line in IN:
+                if line.startswith(">"):
+                    names.append(line.strip().split()[0][1:])
+    seen, out = set(), []
+    for n in names:
+        if n not in seen:
+            seen.add(n)
+            out.append(n)
+    return out
+
+
+def output_name(seq_pname, task):
+    """reference: nextpolish1.py:228 -- 'x' -> 'x_np1'; 'x_np1' -> 'x_np12'."""
+    return seq_pname + (str(task) if seq_pname.split("_")[-1].startswith("np") else ("_np" + str(task)))
+
+
+def update_cfg(cfg, args):
+    """reference: nextpolish1.py:102-133 (the struct is mutated in place after config_init)."""
+    c = cfg.contents
+    c.trim_len_edge = args.trim_len_edge
+    c.ext_len_edge = args.ext_len_edge
+    c.min_map_quality = args.min_map_quality
+    c.indel_balance_factor_sgs = args.indel_balance_factor_sgs
+    c.min_count_ratio_skip = args.min_count_ratio_skip
+    c.min_len_ldr = args.min_len_ldr
+    c.min_len_inter_kmer = args.min_len_inter_kmer
+    c.max_len_kmer = args.max_len_kmer
+    c.max_count_kmer = args.max_count_kmer
+    c.min_depth_snp = args.min_depth_snp
+    c.min_count_snp = args.min_count_snp
+    c.min_count_snp_link = args.min_count_snp_link
+    c.ploidy = args.ploidy
+    c.indel_balance_factor_lgs = args.indel_balance_factor_lgs
+    c.max_indel_factor_lgs = args.max_indel_factor_lgs
+    c.max_snp_factor_lgs = args.max_snp_factor_lgs
+    c.min_snp_factor_sgs = args.min_snp_factor_sgs
+    c.region_count = 10000
+    c.count_read_ins_sgs = args.count_read_ins_sgs
+    c.max_ins_len_sgs = args.max_ins_len_sgs
+    c.max_ins_fold_sgs = args.max_ins_fold_sgs
+    c.max_variant_count_lgs = args.max_variant_count_lgs
+    c.max_clip_ratio_sgs = args.max_clip_ratio_sgs
+    c.max_clip_ratio_lgs = args.max_clip_ratio_lgs
+    c.trace_polish_open = 1 if args.debug else 0
+
+
+def plan_batches(names, lengths, max_bp):
+    """Greedy in-order packing of contigs into batches of at most max_bp draft bases (a contig longer
+    than that gets a batch of its own)."""
+    batches, cur, cur_bp = [], [], 0
+    for n in names:
+        L = lengths[n]
+        if cur and cur_bp + L > max_bp:
+            batches.append(cur)
+            cur, cur_bp = [], 0
+        cur.append(n)
+        cur_bp += L
+    if cur:
+        batches.append(cur)
+    return batches
+
+
+def shard_batches(batches, world, rank):
+    """Batch k goes to GPU k mod world (the reference's own unit of distribution is the contig block)."""
+    return [b for k, b in enumerate(batches) if k % world == rank]
+
+
+def fasta_lengths(genome):
+    """Contig lengths from <genome>.fai, or from the FASTA itself when the index does not exist yet."""
+    lens = {}
+    fai = genome + ".fai"
+    if os.path.exists(fai):
+        with open(fai) as IN:
+            for line in IN:
+                f = line.rstrip("\n").split("\t")
+                lens[f[0]] = int(f[1])
+        return lens
+    name = None
+    with open(genome) as IN:
+        for line in IN:
+            if line.startswith(">"):
+                name = line[1:].split()[0]
+                lens[name] = 0
+            elif name is not None:
+                lens[name] += len("".join(line.split()))
+    return lens
+
+
+def polish_score_chain_batched(args, cfg, names, device, emit):
+    from nextpolish_amd.device import Context
+    lengths = fasta_lengths(args.genome)
+    names = [n for n in names if n in lengths]
+    batches = plan_batches(names, lengths, args.batch_bp)
+    ctx = Context(device)
+    try:
+        for b in shard_batches(batches, args.world, args.rank):
+            st = nat.Stream.load(args.genome, args.bam_sgs, names=b)
+            batch = ctx.upload(st)
+            batch.score_chain(cfg.contents)
+            for name, seq in zip(st.names, batch.results()):
+                emit(name, seq, [])
+            batch.close()
+            st.close()
+    finally:
+        ctx.close()
+
+
+def polish_per_contig(args, cfg, names, fun, emit):
+    L = nat.lib()
+    for k, name in enumerate(names):
+        if k % args.world != args.rank:
+            continue
+        r = fun(name.encode(), cfg)
+        seq = C.string_at(r.contents.contig).decode()
+        pts = [(r.contents.data[p].pos, r.contents.data[p].index, r.contents.data[p].curbase.decode(),
+                r.contents.data[p].base.decode()) for p in range(r.contents.datalength)]
+        L.polishresult_destory(r)
+        emit(name, seq, pts)
+
+
+def main(args):
+    OUT = sys.stdout
+    polished_seqs = set()
+    if args.out != "stdout":
+        if os.path.exists(args.out):
+            last_seq_position = read_polished_seqs(args.out, polished_seqs)
+            OUT = open(args.out, "r+")
+            OUT.seek(last_seq_position, os.SEEK_SET)
+            OUT.truncate()
+        else:
+            OUT = open(args.out, "w")
+    blockfile = args.block
+    if args.block_index == "all" or not args.block:
+        args.block_index = "all"
+        blockfile = args.genome
+    names = read_unpolished_seqs(blockfile, args.block_index, polished_seqs)
+
+    L = nat.lib()
+    cfg = L.config_init(args.genome.encode(), (args.bam_sgs or "").encode() or None,
+                        (args.bam_lgs or "").encode() or None)
+    update_cfg(cfg, args)
+
+    def emit(name, seq, pts):
+        if args.uppercase:
+            seq = seq.upper()
+        print(">%s %d\n%s" % (output_name(name, args.task), len(seq), seq), file=OUT)
+        for p in pts:
+            print(name + " %d %d %c %c" % p, file=sys.stderr)
+
+    fun = {1: L.score_chain, 2: L.kmer_count, 3: L.snp_phase, 4: L.snp_valid, 5: L.lgspolish}[args.task]
+    if args.task == 1 and not args.debug:
+        device = args.device if args.device >= 0 else args.rank
+        polish_score_chain_batched(args, cfg, names, device, emit)
+    else:
+        polish_per_contig(args, cfg, names, fun, emit)
+    if args.out != "stdout":
+        OUT.close()
+    L.config_destory(cfg)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Polish the genome on MI355X GPUs (drop-in for lib/nextpolish1.py).")
+    io = p.add_argument_group("Input/Output arguments")
+    io.add_argument("-g", "--genome", metavar="FILE", required=True, type=str)
+    io.add_argument("-s", "--bam_sgs", metavar="FILE", type=str)
+    io.add_argument("-l", "--bam_lgs", metavar="FILE", type=str)
+    io.add_argument("-b", "--block", metavar="FILE", type=str)
+    io.add_argument("-i", "--block_index", type=str, default="all")
+    io.add_argument("-u", "--uppercase", action="store_true", default=False)
+    io.add_argument("-debug", action="store_true", default=False)
+    io.add_argument("-o", "--out", metavar="FILE", default="stdout")
+    alg = p.add_argument_group("Algorithm arguments")
+    alg.add_argument("-t", "--task", metavar="N", type=int, required=True, choices=[1, 2, 3, 4, 5])
+    alg.add_argument("-p", "--process", metavar="N", type=int, default=10,
+                     help="accepted for compatibility; contig-level parallelism lives on the GPU")
+    alg.add_argument("-count_read_ins_sgs", metavar="N", type=int, default=10000)
+    alg.add_argument("-min_map_quality", metavar="N", type=int, default=0)
+    alg.add_argument("-max_ins_len_sgs", metavar="N", type=int, default=10000)
+    alg.add_argument("-max_ins_fold_sgs", metavar="N", type=int, default=5)
+    alg.add_argument("-max_clip_ratio_sgs", metavar="F", type=float, default=0.15)
+    alg.add_argument("-max_clip_ratio_lgs", metavar="F", type=float, default=0.4)
+    alg.add_argument("-trim_len_edge", metavar="N", type=int, default=2)
+    alg.add_argument("-ext_len_edge", metavar="N", type=int, default=2)
+    sc = p.add_argument_group("score_chain")
+    sc.add_argument("-indel_balance_factor_sgs", metavar="F", type=float, default=0.5)
+    sc.add_argument("-min_count_ratio_skip", metavar="F", type=float, default=0.8)
+    kc = p.add_argument_group("kmer_count")
+    kc.add_argument("-min_len_ldr", metavar="N", type=int, default=3)
+    kc.add_argument("-max_len_kmer", metavar="N", type=int, default=50)
+    kc.add_argument("-min_len_inter_kmer", metavar="N", type=int, default=5)
+    kc.add_argument("-max_count_kmer", metavar="N", type=int, default=50)
+    sp = p.add_argument_group("snp_phase")
+    sp.add_argument("-ploidy", metavar="N", type=int, default=2)
+    sp.add_argument("-max_variant_count_lgs", metavar="N", type=str, default="150k")
+    sp.add_argument("-indel_balance_factor_lgs", metavar="F", type=float, default=0.33)
+    sp.add_argument("-min_depth_snp", metavar="N", type=int, default=3)
+    sp.add_argument("-min_count_snp", metavar="N", type=int, default=5)
+    sp.add_argument("-min_count_snp_link", metavar="N", type=int, default=5)
+    sp.add_argument("-max_indel_factor_lgs", metavar="F", type=float, default=0.21)
+    sp.add_argument("-max_snp_factor_lgs", metavar="F", type=float, default=0.53)
+    sp.add_argument("-min_snp_factor_sgs", metavar="F", type=float, default=0.34)
+    gpu = p.add_argument_group("GPU placement (this implementation)")
+    gpu.add_argument("--device", type=int, default=-1, help="HIP device of this process (default: its rank)")
+    gpu.add_argument("--rank", type=int, default=int(os.environ.get("LOCAL_RANK", "0")))
+    gpu.add_argument("--world", type=int, default=int(os.environ.get("WORLD_SIZE", "1")),
+                     help="number of processes sharing this block (one per GPU); each writes its own -o part")
+    gpu.add_argument("--batch_bp", type=parse_num_unit, default=parse_num_unit("500m"),
+                     help="draft bases per HBM-resident batch")
+    return p
+
+
+if __name__ == "__main__":
+    a, _unknown = build_parser().parse_known_args()
+    a.max_variant_count_lgs = parse_num_unit(a.max_variant_count_lgs)
+    if a.task == 5:
+        sys.stderr.write("Please use nextpolish2 to polish the genome with long reads.\n")
+        sys.exit(1)
+    main(a)

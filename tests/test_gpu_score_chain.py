@@ -121,3 +121,61 @@ def test_dropin_abi_and_cli(tmp_path):
     if ref_binary():
         ref = run_ref("scorechain", fa, bam)
         assert [ref[n] for n in st.names] == want
+
+
+def test_python_harness_end_to_end(tmp_path):
+    """nextpolish_amd/nextpolish1.py (mirror of the reference's lib/nextpolish1.py): batched GPU path, block
+    file selection, resume after a truncated output, -u, and the -debug per-contig path with its trace lines."""
+    import sys
+    st = nat.Stream.synth([12000, 5000, 3000, 800], depth=30, seed=31, with_qual=1)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "g.bam")
+    st.write_files(fa, bam)
+    want = {n: ob.score_chain(st, i) for i, n in enumerate(st.names)}
+    exe = [sys.executable, os.path.join(ROOT, "nextpolish_amd", "nextpolish1.py")]
+
+    def parse(text):
+        recs, name = {}, None
+        for line in text.splitlines():
+            if line.startswith(">"):
+                name, ln = line[1:].split()
+                recs[name] = [int(ln), ""]
+            else:
+                recs[name][1] += line
+        return recs
+
+    out = subprocess.run(exe + ["-g", fa, "-s", bam, "-t", "1", "--batch_bp", "9000"], stdout=subprocess.PIPE, check=True).stdout.decode()
+    recs = parse(out)
+    assert list(recs) == [n + "_np1" for n in st.names]
+    for n in st.names:
+        assert recs[n + "_np1"] == [len(want[n]), want[n]]
+    # block file + resume: contig 0 finished, contig 2 cut off mid-record, contig 1 belongs to another block
+    blc = tmp_path / "g.blc"
+    blc.write_text("".join("%s %d\n" % (n, 1 if k == 1 else 0) for k, n in enumerate(st.names)))
+    part = tmp_path / "part0.fa"
+    part.write_text(">%s_np1 %d\n%s\n>%s_np1 %d\n%s" % (st.names[0], len(want[st.names[0]]), want[st.names[0]],
+                                                       st.names[2], len(want[st.names[2]]), want[st.names[2]][:100]))
+    subprocess.run(exe + ["-g", fa, "-s", bam, "-t", "1", "-b", str(blc), "-i", "0", "-u", "-o", str(part)], check=True)
+    recs = parse(part.read_text())
+    assert list(recs) == [st.names[k] + "_np1" for k in (0, 2, 3)]
+    assert recs[st.names[2] + "_np1"][1] == want[st.names[2]].upper()
+    # -debug: per-contig drop-in path, trace lines "name pos index curbase base" on stderr
+    r = subprocess.run(exe + ["-g", fa, "-s", bam, "-t", "1", "-debug", "-b", str(blc), "-i", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, check=True)
+    recs = parse(r.stdout.decode())
+    assert recs == {st.names[1] + "_np1": [len(want[st.names[1]]), want[st.names[1]]]}
+    trace = [l.split() for l in r.stderr.decode().splitlines() if l.startswith(st.names[1] + " ")]
+    assert trace and all(len(t) == 5 for t in trace)
+    # replaying the trace over the draft reproduces the polished sequence (uppercased)
+    draft = st.contig_draft(1).decode().upper()
+    cols = {}
+    for _, pos, idx, cur, _ in trace:
+        cols.setdefault(int(pos), {})[int(idx)] = cur
+    rebuilt = []
+    for i, ch in enumerate(draft):
+        c = cols.get(i, {})
+        b = c.get(0, ch)
+        if b != ".":
+            rebuilt.append(b)
+        for j in sorted(k for k in c if k > 0):
+            rebuilt.append(c[j])
+    assert "".join(rebuilt) == want[st.names[1]].upper()

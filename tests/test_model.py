@@ -1,0 +1,51 @@
+"""Host lockstep model of the two HIP launch sequences (tests/model) against the oracle: checks the staged
+algorithm itself -- slot space, symbol rows / record descriptors incl. chained parts, single-state shortcut,
+run-wise exact integer DP, emission -- on the CPU, with the same per-lane bodies the kernels compile."""
+import pytest
+
+from nextpolish_amd import _native as nat
+import oracle_binding as ob
+import model_binding as mb
+from fuzzgen import random_case
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_model_micro_cases(fused):
+    parts = 0
+    for seed in range(250):
+        contigs, reads = random_case(seed)
+        st = nat.Stream.from_reads(contigs, reads)
+        got, stats = mb.score_chain(st, fused=fused, want_stats=True)
+        parts += stats["escalations"] if fused else 0
+        for i in range(st.n_contigs):
+            assert got[i] == ob.score_chain(st, i), "seed %d contig %d fused=%s" % (seed, i, fused)
+    if fused:
+        assert parts > 100   # the chained-descriptor path is really exercised
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("seed", range(5))
+def test_model_synth(fused, seed):
+    st = nat.Stream.synth([3000 + seed * 137, 900 + seed * 11, 200], depth=[5, 15, 30, 60, 120][seed % 5], seed=1000 + seed,
+                          weird_rate=0.02 if seed % 2 else 0.0, draft_lower=0.01 if seed % 3 == 0 else 0.0,
+                          read_indel=0.002 if seed % 4 == 0 else 0.0001, softclip_rate=0.05)
+    got = mb.score_chain(st, fused=fused)
+    for i in range(st.n_contigs):
+        assert got[i] == ob.score_chain(st, i)
+
+
+def test_model_parameters():
+    st = nat.Stream.synth([6000], depth=40, seed=77, softclip_rate=0.05)
+    for rate, ratio, trim in [(0.25, 0.8, 2), (1.0, 0.5, 0), (0.75, 1.2, 5), (0.0, 0.95, 1)]:
+        cfg = nat.default_config()
+        cfg.indel_balance_factor_sgs, cfg.min_count_ratio_skip, cfg.trim_len_edge = rate, ratio, trim
+        ocfg = ob.default_config(indel_balance_factor_sgs=rate, min_count_ratio_skip=ratio, trim_len_edge=trim)
+        for fused in (False, True):
+            assert mb.score_chain(st, cfg, fused=fused)[0] == ob.score_chain(st, 0, ocfg)
+
+
+def test_model_crowded_slots_escalate():
+    st = nat.Stream.synth([1500], depth=250, seed=5, read_sub=0.08, read_indel=0.01)
+    got, stats = mb.score_chain(st, want_stats=True)
+    assert stats["escalations"] > 0
+    assert got[0] == ob.score_chain(st, 0)

@@ -1,0 +1,85 @@
+"""The CPU oracle (oracle/np1_oracle.c) against (a) the committed golden vectors that were generated from
+the real reference binary (tests/golden/make_golden.py) and (b), when oracle/_ref/nextpolish1 is present,
+the reference binary itself on fresh fuzzed inputs.  This is what pins the oracle."""
+import hashlib
+import json
+import os
+
+import pytest
+
+from nextpolish_amd import _native as nat
+import oracle_binding as ob
+from conftest import ROOT, ref_binary, run_ref
+from fuzzgen import random_case
+
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "np1_golden.json")))
+
+
+def md5(s):
+    return hashlib.md5(s.encode()).hexdigest()
+
+
+@pytest.mark.parametrize("k", range(len(GOLD["synth"])))
+def test_golden_synth_score_chain_and_kmer_count(k):
+    g = GOLD["synth"][k]
+    kw = dict(g["params"])
+    lens = kw.pop("contig_len")
+    st = nat.Stream.synth(lens, with_qual=1, **kw)
+    assert st.n_reads == g["n_reads"]          # the generator itself is part of the fixture
+    cfg = ob.default_config(read_tlen=g["read_tlen"], read_len=g["read_len"])
+    for i, exp in enumerate(g["score_chain"]):
+        got = ob.score_chain(st, i)
+        assert (len(got), md5(got)) == (exp["len"], exp["md5"]), "score_chain %s" % exp["name"]
+    for i, exp in enumerate(g["kmer_count"]):
+        got = ob.kmer_count(st, i, cfg)
+        assert (len(got), md5(got)) == (exp["len"], exp["md5"]), "kmer_count %s" % exp["name"]
+
+
+def test_golden_micro_cases():
+    for g in GOLD["micro"]:
+        contigs = [tuple(c) for c in g["contigs"]]
+        for r in g["reads"]:
+            r["cigar"] = [tuple(x) for x in r["cigar"]]
+        st = nat.Stream.from_reads(contigs, g["reads"])
+        for i, exp in enumerate(g["score_chain"]):
+            assert ob.score_chain(st, i) == exp, "micro seed %d contig %d" % (g["seed"], i)
+
+
+def test_fuzzgen_is_stable():
+    """The committed micro fixtures were produced by tests/fuzzgen.py; a silent change of the generator would
+    make the GPU fuzz tests wander away from what the goldens pinned."""
+    for g in GOLD["micro"][:10]:
+        contigs, reads = random_case(g["seed"])
+        assert [list(c) for c in contigs] == [list(c) for c in g["contigs"]]
+        assert len(reads) == len(g["reads"])
+
+
+needs_ref = pytest.mark.skipif(ref_binary() is None, reason="oracle/_ref/nextpolish1 not built (needs /root/reference)")
+
+
+@needs_ref
+def test_oracle_vs_reference_micro_fuzz(tmp_path):
+    fa, bam = str(tmp_path / "z.fa"), str(tmp_path / "z.bam")
+    for seed in range(1000, 1150):
+        contigs, reads = random_case(seed)
+        st = nat.Stream.from_reads(contigs, reads)
+        st.write_files(fa, bam)
+        ref = run_ref("scorechain", fa, bam)
+        for i, (n, _) in enumerate(contigs):
+            assert ob.score_chain(st, i) == ref[n], "seed %d contig %s" % (seed, n)
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_vs_reference_synth(tmp_path, seed):
+    fa, bam = str(tmp_path / "s.fa"), str(tmp_path / "s.bam")
+    st = nat.Stream.synth([4000 + 911 * seed, 700], depth=[6, 25, 90][seed % 3], seed=500 + seed, with_qual=1,
+                          weird_rate=0.03, softclip_rate=0.06, draft_lower=0.02, read_indel=0.001)
+    st.write_files(fa, bam)
+    sc, kc = run_ref("scorechain", fa, bam), run_ref("kmercount", fa, bam)
+    cfgp = nat.lib().config_init(fa.encode(), bam.encode(), None)
+    cfg = ob.default_config(read_tlen=cfgp.contents.read_tlen, read_len=cfgp.contents.read_len)
+    nat.lib().config_destory(cfgp)
+    for i, n in enumerate(st.names):
+        assert ob.score_chain(st, i) == sc[n]
+        assert ob.kmer_count(st, i, cfg) == kc[n]
