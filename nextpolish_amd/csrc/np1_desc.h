@@ -17,7 +17,7 @@ constexpr int DESC_NSEG = 5, DESC_NINS = 2;
 constexpr int DESC_SEG0 = 4, DESC_INS0 = DESC_SEG0 + 2 * DESC_NSEG, DESC_NEXT = DESC_INS0 + 2 * DESC_NINS;
 constexpr int DESC_WORDS = DESC_NEXT + 2;   // 20 words = 80 B per record
 constexpr uint32_t DESC_CHAIN = 1u << 16;   // d[2] flag of a head part that continues in the overflow pool
-// d[0]=sfirst d[1]=slast (this part)  d[2]=nseg | nins<<8  d[3]=(k_tile3: byte offset of the packed bases in LDS)
+// d[0]=sfirst d[1]=slast (this part)  d[2]=nseg | nins<<8 | flags  d[3]=low word of the record's offset in the base pool
 // seg k: d[SEG0+2k]=g_lo, +1: len | qcode<<16 (qcode = q_lo, or 0xffff for DEL)
 // ins k: d[INS0+2k]=p,    +1: len | q0<<16
 // d[NEXT]=index+1 of the next part in the overflow pool (0 = none)   d[NEXT+1]=slast of the whole record (head part only)
@@ -192,6 +192,7 @@ NP1_HD void desc_record(const ReadsDev& R, int64_t r, const uint32_t* ctg_off, c
         DescSink sink{d, ovf_pool, ovf_cap, &counters[CNT_OVFDESC], &counters[CNT_ERR]};
         build_desc(R.cigar + R.cigar_off[r], R.n_cigar[r], R.pos[r], g0, (int32_t)(ctg_off[c + 1] - g0), qs[r], qe[r],
                    R.l_qseq[r], SoGlobal{soff}, sink);
+        d[3] = (uint32_t)R.seq_off[r];
         if (d[0] <= d[DESC_NEXT + 1] && d[0] <= d[1]) {
             *c0_out = d[0] / VOTE_CH;
             *c1_out = (d[DESC_NEXT + 1] + 2) / VOTE_CH;

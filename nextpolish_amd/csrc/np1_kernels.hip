@@ -334,7 +334,7 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
     __shared__ __attribute__((aligned(16))) uint32_t sh_r[4];
     uint32_t* lists = lds;                             // NW * (E-2) * 64
     uint32_t* dsc = lists + NW * (E - 2) * 64;         // nb_max * DESC_WORDS
-    uint32_t* seqst = dsc + (nb_max + 1) * DESC_WORDS; // nb_max * seq_w + 2 (one spare descriptor slot before it)
+    uint32_t* seqst = dsc + (nb_max + 1) * DESC_WORDS; // nb_max * seq_w + 8 (one spare descriptor slot before it)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t item = blockIdx.x;
     if (item >= n_items) return;
@@ -383,19 +383,24 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
     if (r0 != 0xffffffffu) {
         for (uint64_t rb = r0; rb <= r1; rb += nb_max) {
             const uint32_t nb = (uint32_t)((r1 - rb + 1 < nb_max) ? (r1 - rb + 1) : nb_max);
-            // ---- stage descriptors and packed bases of the batch (both contiguous in HBM)
-            const uint32_t* dsrc = desc + rb * DESC_WORDS;
-            for (uint32_t i = tid; i < nb * DESC_WORDS; i += NW * 64) dsc[i] = dsrc[i];
-            const uint64_t sq0 = R.seq_off[rb] & ~3ull;
+            // ---- stage descriptors and packed bases of the batch (both contiguous in HBM): 16-byte lanes, coalesced
+            {
+                const uint4* dsrc = reinterpret_cast<const uint4*>(desc + rb * DESC_WORDS);
+                uint4* ddst = reinterpret_cast<uint4*>(dsc);
+                for (uint32_t i = tid; i < nb * (DESC_WORDS / 4); i += NW * 64) ddst[i] = dsrc[i];
+            }
+            const uint64_t sq0 = R.seq_off[rb] & ~15ull;
             const uint64_t sq1 = R.seq_off[rb + nb - 1] + (((uint64_t)R.l_qseq[rb + nb - 1] + 1) >> 1);
-            const uint32_t sq_words = (uint32_t)((sq1 - sq0 + 3) >> 2);
-            // the pool holds the records back to back, so nb records never need more than nb * seq_w (+2) words
-            const uint32_t sq_fit = sq_words <= nb_max * seq_w + 2 ? sq_words : nb_max * seq_w + 2;
-            if (sq_fit != sq_words && tid == 0) atomicOr(&counters[CNT_ERR], ERR_BAD_RECORD);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(R.seq + sq0);
-            for (uint32_t i = tid; i < sq_fit; i += NW * 64) seqst[i] = src[i];
-            __syncthreads();
-            for (uint32_t k = tid; k < nb; k += NW * 64) dsc[k * DESC_WORDS + 3] = (uint32_t)(R.seq_off[rb + k] - sq0);
+            const uint32_t sq_quads = (uint32_t)((sq1 - sq0 + 15) >> 4);
+            // the pool holds the records back to back, so nb records never need more than nb * seq_w words (+ alignment)
+            const uint32_t sq_fit = sq_quads * 4 <= nb_max * seq_w + 8 ? sq_quads : (nb_max * seq_w + 8) / 4;
+            if (sq_fit != sq_quads && tid == 0) atomicOr(&counters[CNT_ERR], ERR_BAD_RECORD);
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(R.seq + sq0);
+                uint4* dst = reinterpret_cast<uint4*>(seqst);
+                for (uint32_t i = tid; i < sq_fit; i += NW * 64) dst[i] = src[i];
+            }
+            const uint32_t sq0_lo = (uint32_t)sq0;   // descriptors carry the low word of their record's pool offset
             __syncthreads();
             // ---- this wave's chunk votes over the batch, in record order
             if (chunk_ok && !(ablate & 2u)) {
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
                                 q = in ? (ik.y >> 16) + (uint32_t)jj : q;
                             }
                             q = (cov && !isdel) ? q : 0u;
-                            const uint32_t byte = seqb[h.w + (q >> 1)];
+                            const uint32_t byte = seqb[(h.w - sq0_lo) + (q >> 1)];
                             uint32_t sym = (byte >> ((~q & 1u) << 2)) & 0xfu;
                             sym = cov ? (isdel ? 3u : sym) : 0u;
                             const uint32_t p1 = wave_shr1(sym), p2 = wave_shr1(p1);
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
                             }
                         } else {
                             const uint32_t* d = dsc + i * DESC_WORDS;   // LDS: every access below is a ds_read broadcast
-                            const SeqLds sq{seqb + h.w};
+                            const SeqLds sq{seqb + (h.w - sq0_lo)};
                             uint32_t rsym = 0;   // this record's symbol at my slot (kept across the parts of a chained record)
                             vote_part<E>(d, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nvotes);
                             uint32_t nx = d[DESC_NEXT];
@@ -761,7 +766,7 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
     static const uint32_t ablate = getenv("NP1_ABLATE") ? (uint32_t)atoi(getenv("NP1_ABLATE")) : 0u;   // timing experiments only
 #define NP1_TILE3(EE, NWW, BUDGET)                                                                                   \
     do {                                                                                                             \
-        const uint32_t fixed = (uint32_t)(NWW) * (uint32_t)((EE)-2) * 64u + 2u + (uint32_t)DESC_WORDS;               \
+        const uint32_t fixed = (uint32_t)(NWW) * (uint32_t)((EE)-2) * 64u + 8u + (uint32_t)DESC_WORDS;               \
         uint32_t budget = (BUDGET);                                                                                  \
         if (budget < fixed + per) budget = fixed + per;                                                              \
         if (budget > 40960u - 64u) return -1;                                                                        \
