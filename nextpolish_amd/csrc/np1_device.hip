@@ -46,7 +46,7 @@ struct DevBuf {
 // LDS (k_place + k_tile); the STAGED one (NP1_PIPELINE=staged, kept for A/B measurements and mirrored by the
 // host model in tests/model) materialises symbol rows in HBM (k_rowcap + scan + k_rows + k_vote).
 const char* kStageNamesStaged[] = {"prep", "scan_slots", "slotinfo", "rowcap_scan", "rows", "vote", "dp", "emit"};
-const char* kStageNamesFused[] = {"prep", "scan_slots", "slotinfo", "place", "-", "tile", "dp", "emit"};
+const char* kStageNamesFused[] = {"prep", "scan_slots", "slotinfo", "desc", "-", "tile", "dp", "emit"};
 constexpr int kStages = 8;
 bool use_staged() {
     static int v = -1;
