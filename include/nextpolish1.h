@@ -175,6 +175,10 @@ const char* np1_stage_name(int i);
  * stage_ms: NULL, or float[NP1_MAX_STAGES] receiving per-stage HIP-event milliseconds (forces a sync).
  * Returns 0 on success. */
 int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms);
+/* kmer_count (task 2) over the same batch; the stream must have been loaded with base qualities
+ * (np1_stream_load(..., with_qual = 1)) and cfg->read_tlen must be set (config_init does).  Returns 0 on success;
+ * results are fetched with np1_batch_result_len / np1_batch_result_copy like for score_chain. */
+int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms);
 /* Blocks until the batch's work is complete. */
 int np1_batch_sync(np1_batch* b);
 /* Polished length of contig i (valid after a completed run), and copy-out of its NUL-terminated string. */

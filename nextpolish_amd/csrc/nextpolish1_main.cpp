@@ -44,16 +44,16 @@ int main(int argc, char* argv[]) {
     }
     time_t t_start = time(nullptr);
     Configure* cfg = (step == 5) ? config_init(argv[2], nullptr, argv[3]) : config_init(argv[2], argv[3], argc > 4 ? argv[4] : nullptr);
-    if (step == 1) {
+    if (step == 1 || step == 2) {
         if (!cfg->bamfn) { fprintf(stderr, "cannot access BAM %s\n", argv[3]); return 1; }
-        np1_stream* st = np1_stream_load(cfg->fastafn, cfg->bamfn, nullptr, 0, 0);
+        np1_stream* st = np1_stream_load(cfg->fastafn, cfg->bamfn, nullptr, 0, step == 2 ? 1 : 0);
         if (!st) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
         int dev = 0;
         if (const char* e = getenv("NP1_DEVICE")) dev = atoi(e);
         np1_ctx* ctx = np1_ctx_create(dev);
         if (!ctx) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
         np1_batch* b = np1_batch_upload(ctx, st);
-        if (!b || np1_batch_score_chain(b, cfg, nullptr) != 0) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+        if (!b || (step == 1 ? np1_batch_score_chain(b, cfg, nullptr) : np1_batch_kmer_count(b, cfg, nullptr)) != 0) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
         np1_stream_view v;
         np1_stream_get_view(st, &v);
         std::vector<char> buf;

@@ -11,6 +11,7 @@
 
 #include "../../include/nextpolish1.h"
 #include "np1_kernels.h"
+#include "np1_kmer_kernels.h"
 #include "np_stream.h"
 
 void np1_set_error(const std::string& e);   // np_host_abi.cpp
@@ -74,6 +75,13 @@ struct np1_batch {
     DevBuf draft, ctg_off, pos, ctg, flag, ncig, lq, cigoff, seqoff, cigar, seq;
     // work
     DevBuf desc, ovf_desc, slot_g;
+    // kmer_count inputs (uploaded only when the stream carries qualities) and work buffers
+    DevBuf mapq, isize, qualoff, qual, read_begin;
+    DevBuf kc_level, kc_endpos, kc_code, kc_flag, kc_fpos, kc_flagged, kc_work, kc_nd_ctg, kc_nd_se, kc_kr_ctg, kc_kr_se, kc_cnt,
+        kc_sbase, kc_sflag, kc_srefk, kc_scount, kc_lhead, kc_lpool, kc_stsc, kc_stkm, kc_strk, kc_hpool, kc_workoff, kc_nparts,
+        kc_partoff, kc_pt_ctg, kc_pt_se, kc_pt_len, kc_woff, kc_wpool, kc_haswin;
+    bool has_qual = false;
+    std::vector<uint64_t> h_read_begin;
     DevBuf qs, qe, span, ins, soff, slot_info, rbase, capb, rowoff, rows, meta, chunk_first, chunk_last, slot_res,
         slot_rec, pool, heads, redo, redo2, counters, opos, out, bounds, scan_tmp, totals;
     size_t input_bytes = 0;
@@ -91,7 +99,11 @@ struct np1_batch {
         const DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
                                &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
                                &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out,
-                               &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g};
+                               &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &mapq, &isize, &qualoff, &qual, &read_begin,
+                               &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg, &kc_nd_se,
+                               &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool,
+                               &kc_stsc, &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg,
+                               &kc_pt_se, &kc_pt_len, &kc_woff, &kc_wpool, &kc_haswin};
         size_t t = 0;
         for (const DevBuf* b : all) t += b->cap;
         return t;
@@ -100,7 +112,11 @@ struct np1_batch {
         DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
                          &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
                          &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out,
-                         &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g};
+                         &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &mapq, &isize, &qualoff, &qual, &read_begin,
+                         &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg, &kc_nd_se,
+                         &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool,
+                         &kc_stsc, &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg, &kc_pt_se,
+                         &kc_pt_len, &kc_woff, &kc_wpool, &kc_haswin};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -176,6 +192,15 @@ np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* st) {
     rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);
     // +8 bytes of slack: the trim loops never read past l_qseq, but keep loads inside the allocation anyway
     rc |= upload(b->seq, s.seq.data(), s.seq.size(), q);
+    b->h_read_begin = s.read_begin;
+    rc |= upload(b->read_begin, s.read_begin.data(), 8 * s.read_begin.size(), q);
+    b->has_qual = !s.qual.empty() || n == 0;
+    if (b->has_qual) {   // kmer_count needs mapq / isize / base qualities too (kmercount.c:365-465, contig.c:648-665)
+        rc |= upload(b->mapq, s.mapq.data(), n, q);
+        rc |= upload(b->isize, s.isize.data(), 4 * n, q);
+        rc |= upload(b->qualoff, s.qual_off.data(), 8 * n, q);
+        rc |= upload(b->qual, s.qual.data(), s.qual.size(), q);
+    }
     if (rc == 0 && hipStreamSynchronize(q) != hipSuccess) { np1_set_error("upload failed"); rc = -1; }
     if (rc != 0) { b->release_all(); delete b; return nullptr; }
     b->input_bytes = s.draft.size() + 32 * n + 4 * s.cigar.size() + s.seq.size();
@@ -442,6 +467,167 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     }
     b->ran = true;
     return 0;
+}
+
+
+// ---- kmer_count (task 2): launch sequence over the same HBM-resident batch (needs qualities) -------------------
+int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
+    (void)stage_ms;
+    if (!b || !cfg) { np1_set_error("np1_batch_kmer_count: null argument"); return -1; }
+    if (!b->has_qual) { np1_set_error("kmer_count needs a stream loaded with base qualities"); return -1; }
+    np1_ctx* ctx = b->ctx;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t q = ctx->stream;
+    b->ran = false;
+    b->out_cached = false;
+    int K = 0;
+    long long Rfix = 0;
+    if (!rate_fixed_point(cfg->indel_balance_factor_sgs, &K, &Rfix)) {
+        np1_set_error("indel_balance_factor_sgs must be a multiple of 2^-10 on the GPU path (default 0.5)");
+        return -1;
+    }
+    const uint64_t G = b->G;
+    const int64_t n = b->n_reads;
+    const uint32_t nc = b->nc;
+    if (nc == 0) { b->h_bounds.assign(1, 0); b->S = 0; b->ran = true; return 0; }
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    if (b->kc_level.ensure(nn) || b->kc_endpos.ensure(4 * nn) || b->kc_code.ensure(G + 1) || b->kc_flag.ensure(G + 1) ||
+        b->kc_fpos.ensure(4 * (G + 2)) || b->kc_cnt.ensure(4 * KCC_WORDS) || b->ins.ensure(4 * (G + 1)) || b->soff.ensure(4 * (G + 2)) ||
+        b->totals.ensure(64) || b->counters.ensure(4 * CNT_WORDS) || b->bounds.ensure(4 * ((size_t)nc + 1)) ||
+        b->scan_tmp.ensure(8 * (scan_tmp_words(G + G / 8 + 1024) + scan_tmp_words(nn))))
+        return -1;
+    uint64_t* totals = b->totals.as<uint64_t>();
+    uint64_t* scan_tmp = b->scan_tmp.as<uint64_t>();
+    uint32_t* kcnt = b->kc_cnt.as<uint32_t>();
+    const uint32_t* ctg_off = b->ctg_off.as<uint32_t>();
+
+    KcCtx c;
+    memset(&c, 0, sizeof(c));
+    c.R = ReadsDev{b->pos.as<int32_t>(), b->ctg.as<uint32_t>(), b->flag.as<uint16_t>(), b->ncig.as<uint16_t>(), b->lq.as<int32_t>(),
+                   b->cigoff.as<uint64_t>(), b->seqoff.as<uint64_t>(), b->cigar.as<uint32_t>(), b->seq.as<uint8_t>()};
+    c.mapq = b->mapq.as<uint8_t>(); c.isize = b->isize.as<int32_t>(); c.qual_off = b->qualoff.as<uint64_t>(); c.qual = b->qual.as<uint8_t>();
+    c.level = b->kc_level.as<uint8_t>(); c.endpos = b->kc_endpos.as<int32_t>();
+    c.ctg_off = ctg_off; c.read_begin = b->read_begin.as<uint64_t>();
+    c.draft_code = b->kc_code.as<uint8_t>(); c.draft_flag = b->kc_flag.as<uint8_t>();
+    c.trim = cfg->trim_len_edge; c.ext_len_edge = cfg->ext_len_edge; c.min_len_ldr = cfg->min_len_ldr;
+    c.min_len_inter_kmer = cfg->min_len_inter_kmer; c.max_len_kmer = cfg->max_len_kmer; c.max_count_kmer = cfg->max_count_kmer;
+    c.min_map_quality = cfg->min_map_quality; c.read_tlen = cfg->read_tlen;
+    c.max_clip_ratio_sgs = cfg->max_clip_ratio_sgs; c.min_count_ratio_skip = cfg->min_count_ratio_skip;
+    c.K = K; c.Rfix = Rfix;
+    c.err = &kcnt[KCC_ERR];
+
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        const size_t scale = (size_t)1 << (2 * attempt);   // pool growth on overflow: x1, x4, x16 ...
+        uint32_t hk[KCC_WORDS];
+        HIPCHK(hipMemsetAsync(kcnt, 0, 4 * KCC_WORDS, q));
+        HIPCHK(hipMemsetAsync(b->totals.p, 0, 64, q));
+        // ---- records, draft flags, compacted lowercase positions
+        kc_launch_records(q, c, n, b->kc_level.as<uint8_t>(), b->kc_endpos.as<int32_t>(), &kcnt[KCC_MAXSPAN]);
+        kc_launch_draft(q, b->draft.as<uint8_t>(), (uint32_t)G, b->kc_code.as<uint8_t>(), b->kc_flag.as<uint8_t>());
+        launch_scan_u8(q, b->kc_flag.as<uint8_t>(), G, b->kc_fpos.as<uint32_t>(), scan_tmp, &totals[0]);
+        uint64_t M = 0;
+        HIPCHK(hipMemcpyAsync(&M, &totals[0], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(hipStreamSynchronize(q));
+        const uint32_t reg_cap = (uint32_t)(M + nc + 16);
+        if (b->kc_flagged.ensure(4 * (M + 4)) || b->kc_work.ensure(4 * (2 * M + 4ull * nc + 16)) || b->kc_nd_ctg.ensure(4ull * reg_cap) ||
+            b->kc_nd_se.ensure(8ull * reg_cap) || b->kc_kr_ctg.ensure(4ull * reg_cap) || b->kc_kr_se.ensure(8ull * reg_cap))
+            return -1;
+        kc_launch_compact(q, b->kc_flag.as<uint8_t>(), b->kc_fpos.as<uint32_t>(), (uint32_t)G, b->kc_flagged.as<uint32_t>());
+        kc_launch_regions(q, c, nc, b->kc_fpos.as<uint32_t>(), b->kc_flagged.as<uint32_t>(), b->kc_work.as<int32_t>(),
+                          b->kc_nd_ctg.as<uint32_t>(), b->kc_nd_se.as<int32_t>(), b->kc_kr_ctg.as<uint32_t>(), b->kc_kr_se.as<int32_t>(),
+                          reg_cap, kcnt);
+        HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
+        HIPCHK(hipStreamSynchronize(q));
+        if (hk[KCC_ERR]) { np1_set_error("kmer_count: region discovery failed"); return -1; }
+        const uint32_t n_nd = hk[KCC_NODEPTH], n_kr = hk[KCC_KREG];
+        const uint64_t nd_len = (uint64_t)hk[KCC_ND_LEN] | (uint64_t)hk[KCC_ND_LEN + 1] << 32;
+        c.max_span = (int32_t)(hk[KCC_MAXSPAN] ? hk[KCC_MAXSPAN] : 1);
+        // ---- insertion columns of the regions, slot space
+        HIPCHK(hipMemsetAsync(b->ins.p, 0, 4 * (G + 1), q));
+        kc_launch_inserts(q, c, b->kc_kr_ctg.as<uint32_t>(), b->kc_kr_se.as<int32_t>(), n_kr, b->kc_nd_ctg.as<uint32_t>(),
+                          b->kc_nd_se.as<int32_t>(), n_nd, b->ins.as<uint32_t>());
+        launch_scan_slots(q, b->ins.as<uint32_t>(), G, b->soff.as<uint32_t>(), scan_tmp, &totals[1]);
+        uint64_t S64 = 0;
+        HIPCHK(hipMemcpyAsync(&S64, &totals[1], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(hipStreamSynchronize(q));
+        if (S64 >= 0xfffffff0ull) { np1_set_error("batch too large: more than 2^32 slots"); return -1; }
+        const uint32_t S = (uint32_t)S64;
+        b->S = S;
+        const size_t lcap = std::min<size_t>(((size_t)64 * (nd_len + (S - G)) + ((size_t)1 << 20)) * scale, (size_t)0x7ffffff0u);
+        const size_t stcap = std::min<size_t>((4 * nd_len + 64ull * n_nd + 4ull * (S - G) + 4096) * scale, (size_t)0x0ffffff0u);
+        if (b->slot_info.ensure(S + 64) || b->slot_res.ensure(2 * ((size_t)S + 64)) || b->opos.ensure(4 * ((size_t)S + 2)) ||
+            b->out.ensure((size_t)S + 64) || b->kc_sbase.ensure(S + 64) || b->kc_sflag.ensure(S + 64) ||
+            b->kc_srefk.ensure(2 * ((size_t)S + 64)) || b->kc_scount.ensure(2 * ((size_t)S + 64)) || b->kc_lhead.ensure(4 * ((size_t)S + 64)) ||
+            b->kc_lpool.ensure(8 * lcap) || b->kc_stsc.ensure(8 * 16 * stcap) || b->kc_stkm.ensure(2 * 16 * stcap) || b->kc_strk.ensure(16 * stcap))
+            return -1;
+        if (scan_tmp_words((uint64_t)S + 1) * 8 > b->scan_tmp.cap && b->scan_tmp.ensure(8 * (scan_tmp_words((uint64_t)S + 1) + scan_tmp_words(nn)))) return -1;
+        scan_tmp = b->scan_tmp.as<uint64_t>();
+        launch_slotinfo(q, b->draft.as<uint8_t>(), (uint32_t)G, ctg_off, nc, b->soff.as<uint32_t>(), b->slot_info.as<uint8_t>(), nullptr);
+        kc_launch_slots(q, b->slot_info.as<uint8_t>(), S, b->kc_sbase.as<uint8_t>(), b->kc_sflag.as<uint8_t>(), b->kc_scount.as<uint16_t>(),
+                        b->kc_lhead.as<uint32_t>());
+        c.soff = b->soff.as<uint32_t>(); c.sbase = b->kc_sbase.as<uint8_t>(); c.sflag = b->kc_sflag.as<uint8_t>();
+        c.srefk = b->kc_srefk.as<uint16_t>(); c.scount = b->kc_scount.as<uint16_t>(); c.lhead = b->kc_lhead.as<uint32_t>();
+        c.lpool = b->kc_lpool.as<uint32_t>(); c.lcap = (uint32_t)lcap; c.lcount = &kcnt[KCC_LCOUNT];
+        c.st_score = b->kc_stsc.as<long long>(); c.st_kmer = b->kc_stkm.as<uint16_t>(); c.st_rank = b->kc_strk.as<uint8_t>();
+        c.st_cap = (uint32_t)stcap; c.st_count = &kcnt[KCC_STCOUNT];
+        // ---- no-depth regions: level-2 / level-1 score chain
+        kc_launch_nodepth(q, c, b->kc_nd_ctg.as<uint32_t>(), b->kc_nd_se.as<int32_t>(), n_nd);
+        // ---- split the k-mer regions into parts (host only lays out the per-region scratch rows)
+        uint32_t n_parts = 0;
+        uint64_t W = 0;
+        if (n_kr) {
+            std::vector<int32_t> se(2 * (size_t)n_kr);
+            HIPCHK(hipMemcpyAsync(se.data(), b->kc_kr_se.p, 8 * (size_t)n_kr, hipMemcpyDeviceToHost, q));
+            HIPCHK(hipStreamSynchronize(q));
+            std::vector<uint32_t> woff((size_t)n_kr + 1, 0);
+            for (uint32_t i = 0; i < n_kr; ++i) woff[i + 1] = woff[i] + (uint32_t)(se[2 * i + 1] - se[2 * i]) + 8u;
+            if (b->kc_workoff.ensure(4 * ((size_t)n_kr + 1)) || b->kc_work.ensure(4 * ((size_t)woff[n_kr] + 16)) ||
+                b->kc_nparts.ensure(4 * ((size_t)n_kr + 2)) || b->kc_partoff.ensure(4 * ((size_t)n_kr + 2)))
+                return -1;
+            HIPCHK(hipMemcpyAsync(b->kc_workoff.p, woff.data(), 4 * ((size_t)n_kr + 1), hipMemcpyHostToDevice, q));
+            kc_launch_split(q, c, b->kc_kr_ctg.as<uint32_t>(), b->kc_kr_se.as<int32_t>(), n_kr, b->kc_work.as<int32_t>(),
+                            b->kc_workoff.as<uint32_t>(), b->kc_nparts.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
+            launch_scan_u32(q, b->kc_nparts.as<uint32_t>(), n_kr, b->kc_partoff.as<uint32_t>(), scan_tmp, &totals[2]);
+            uint64_t np64 = 0;
+            HIPCHK(hipMemcpyAsync(&np64, &totals[2], 8, hipMemcpyDeviceToHost, q));
+            HIPCHK(hipStreamSynchronize(q));   // also keeps woff alive until the copy above is done
+            n_parts = (uint32_t)np64;
+            if (b->kc_pt_ctg.ensure(4 * ((size_t)n_parts + 1)) || b->kc_pt_se.ensure(8 * ((size_t)n_parts + 1)) ||
+                b->kc_pt_len.ensure(4 * ((size_t)n_parts + 2)) || b->kc_woff.ensure(4 * ((size_t)n_parts + 2)) ||
+                b->kc_haswin.ensure((size_t)n_parts + 1))
+                return -1;
+            kc_launch_split(q, c, b->kc_kr_ctg.as<uint32_t>(), b->kc_kr_se.as<int32_t>(), n_kr, b->kc_work.as<int32_t>(),
+                            b->kc_workoff.as<uint32_t>(), b->kc_nparts.as<uint32_t>(), b->kc_partoff.as<uint32_t>(),
+                            b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>());
+            launch_scan_u32(q, b->kc_pt_len.as<uint32_t>(), n_parts, b->kc_woff.as<uint32_t>(), scan_tmp, &totals[3]);
+            HIPCHK(hipMemcpyAsync(&W, &totals[3], 8, hipMemcpyDeviceToHost, q));
+            HIPCHK(hipStreamSynchronize(q));
+            const size_t hcap = std::min<size_t>(((size_t)8192 * n_parts + ((size_t)64 << 20)) * scale, (size_t)0xfffffff0u);
+            if (b->kc_wpool.ensure(W + 64) || b->kc_hpool.ensure(hcap)) return -1;
+            c.hpool = b->kc_hpool.as<uint8_t>(); c.hcap = (uint32_t)hcap; c.hcount = &kcnt[KCC_HCOUNT];
+            // ---- spanning-read haplotype vote, then the writes in part order
+            kc_launch_winner(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(),
+                             b->kc_woff.as<uint32_t>(), n_parts, n, b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>());
+            kc_launch_apply(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(),
+                            b->kc_woff.as<uint32_t>(), n_parts, b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>());
+        }
+        // ---- emit with mask FLAG_ZERO (kmercount.c:121)
+        kc_launch_result(q, b->kc_sbase.as<uint8_t>(), b->kc_sflag.as<uint8_t>(), S, b->slot_res.as<uint16_t>());
+        launch_scan_keep(q, b->slot_res.as<uint16_t>(), S, b->opos.as<uint32_t>(), scan_tmp, &totals[4]);
+        launch_emit(q, b->slot_res.as<uint16_t>(), b->slot_info.as<uint8_t>(), b->opos.as<uint32_t>(), S, 1u, b->out.as<uint8_t>());
+        launch_contig_bounds(q, ctg_off, nc, b->soff.as<uint32_t>(), b->opos.as<uint32_t>(), b->bounds.as<uint32_t>());
+        b->h_bounds.resize((size_t)nc + 1);
+        HIPCHK(hipMemcpyAsync(b->h_bounds.data(), b->bounds.p, 4 * ((size_t)nc + 1), hipMemcpyDeviceToHost, q));
+        HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
+        HIPCHK(hipStreamSynchronize(q));
+        if (hk[KCC_ERR] & ERR_KC_POOL) continue;   // a scratch pool ran out: rerun with larger pools
+        if (hk[KCC_ERR]) { np1_set_error("kmer_count: inconsistent pileup or region overflow on the device"); return -1; }
+        b->votes = 0;
+        b->ran = true;
+        return 0;
+    }
+    np1_set_error("kmer_count: scratch pools keep overflowing");
+    return -1;
 }
 
 int np1_batch_sync(np1_batch* b) {

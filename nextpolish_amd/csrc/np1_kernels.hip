@@ -709,6 +709,16 @@ void launch_scan_rows(hipStream_t st, const uint32_t* cap_bytes, uint64_t n, uin
 void launch_scan_keep(hipStream_t st, const uint16_t* slot_res, uint64_t S, uint32_t* opos, uint64_t* tmp, uint64_t* total) {
     scan_impl<LoadKeep, uint32_t>(st, LoadKeep{slot_res}, S, opos, tmp, total);
 }
+struct LoadU8 {
+    const uint8_t* p;
+    __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
+};
+void launch_scan_u8(hipStream_t st, const uint8_t* v, uint64_t n, uint32_t* out, uint64_t* tmp, uint64_t* total) {
+    scan_impl<LoadU8, uint32_t>(st, LoadU8{v}, n, out, tmp, total);
+}
+void launch_scan_u32(hipStream_t st, const uint32_t* v, uint64_t n, uint32_t* out, uint64_t* tmp, uint64_t* total) {
+    scan_impl<LoadU32, uint32_t>(st, LoadU32{v}, n, out, tmp, total);
+}
 
 void launch_slotinfo(hipStream_t st, const uint8_t* draft, uint32_t G, const uint32_t* ctg_off, uint32_t nc,
                      const uint32_t* soff, uint8_t* slot_info, uint32_t* slot_g) {

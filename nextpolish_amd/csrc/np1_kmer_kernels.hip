@@ -1,0 +1,244 @@
+// HIP kernels of kmer_count (task 2) for gfx950.  Bodies: np1_kmer.h (shared with the host model).
+//
+// kmer_count re-votes only the lowercase neighbourhoods that score_chain left behind (reference:
+// source/lib/kmercount.c:93-126) -- a fraction of a percent of the draft -- so unlike score_chain this is a
+// sparse, irregular job.  Mapping: dense per-base / per-record / per-slot preparation kernels, then ONE LANE PER
+// REGION for the reference's per-region logic (region discovery per contig on the compacted list of lowercase
+// positions, insertion columns, level-2/level-1 score chain on the no-depth regions, region splitting,
+// spanning-read haplotype vote), and the shared scan + k_emit for the output.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "np1_core.h"
+#include "np1_kmer.h"
+#include "np1_kmer_kernels.h"
+
+namespace np1k {
+
+static inline unsigned kblk(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+// per record: filter level, end position, longest reference span
+__global__ __launch_bounds__(256) void k_kc_records(KcCtx c, int64_t n_all, uint8_t* __restrict__ level,
+                                                    int32_t* __restrict__ endpos, uint32_t* __restrict__ max_span) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t span = 0;
+    if (r < n_all) {
+        level[r] = (uint8_t)kc_filter_level(c.R, r, c.mapq, c.isize, c.read_tlen, c.max_clip_ratio_sgs, c.min_map_quality);
+        const int32_t e = kc_endpos(c.R, r);
+        endpos[r] = e;
+        span = (uint32_t)(e - c.R.pos[r]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = __shfl_down(span, o);
+        if (t > span) span = t;
+    }
+    if ((threadIdx.x & 63) == 0 && span) atomicMax(max_span, span);
+}
+
+// per draft base: nt16 code + FLAG_ZERO of the input draft (contig.c:92-99)
+__global__ __launch_bounds__(256) void k_kc_draft(const uint8_t* __restrict__ draft, uint32_t G, uint8_t* __restrict__ code,
+                                                  uint8_t* __restrict__ flag) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    uint32_t ch = draft[g], f = 0;
+    if (ch >= 97 && ch <= 122) { ch -= 32; f = KC_FLAG_ZERO; }
+    code[g] = (uint8_t)draft_code(ch);
+    flag[g] = (uint8_t)f;
+}
+
+// compaction of the lowercase positions (fpos = exclusive scan of flag): flagged[fpos[g]] = g
+__global__ __launch_bounds__(256) void k_kc_compact(const uint8_t* __restrict__ flag, const uint32_t* __restrict__ fpos, uint32_t G,
+                                                    uint32_t* __restrict__ flagged) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G && flag[g]) flagged[fpos[g]] = g;
+}
+
+// one lane per contig: no-depth and k-mer regions on the compacted list, merged (kmercount.c:97-106).
+// Regions of a contig land contiguously and in order in the flat arrays (block allocated per contig).
+__global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const uint32_t* __restrict__ fpos,
+                                                   uint32_t* __restrict__ flagged_local, int32_t* __restrict__ work,
+                                                   uint32_t* __restrict__ nd_ctg, int32_t* __restrict__ nd_se,
+                                                   uint32_t* __restrict__ kr_ctg, int32_t* __restrict__ kr_se,
+                                                   uint32_t reg_cap, uint32_t* __restrict__ counters) {
+    const uint32_t ct = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ct >= nc) return;
+    const uint32_t g0 = c.ctg_off[ct], g1 = c.ctg_off[ct + 1];
+    const int32_t L = (int32_t)(g1 - g0);
+    if (L <= 0) return;
+    const uint32_t f0 = fpos[g0], f1 = fpos[g1];
+    const uint32_t m = f1 - f0;
+    if (m == 0) return;
+    uint32_t* fl = flagged_local + f0;
+    for (uint32_t k = 0; k < m; ++k) fl[k] -= g0;   // global draft index -> position inside the contig
+    int32_t* buf = work + 2ull * f0 + 4ull * ct;   // room for 2*m + 4 values
+    const int32_t cap = (int32_t)(2 * m + 4);
+    for (int pass = 0; pass < 2; ++pass) {
+        int32_t k = pass == 0 ? kc_find_regions(c.draft_code + g0, c.draft_flag + g0, L, fl, m, 0, (uint32_t)c.min_len_ldr,
+                                                c.ext_len_edge, false, buf, cap)
+                              : kc_find_regions(c.draft_code + g0, c.draft_flag + g0, L, fl, m, (uint32_t)c.min_len_inter_kmer, 0,
+                                                c.ext_len_edge, true, buf, cap);
+        if (k < 0) { atomicOr(c.err, ERR_KC_REGIONS); return; }
+        k = kc_merge_regions(buf, k);
+        const uint32_t nr = (uint32_t)k / 2;
+        if (nr == 0) continue;
+        const uint32_t o = atomicAdd(&counters[pass == 0 ? KCC_NODEPTH : KCC_KREG], nr);
+        if (o + nr > reg_cap) { atomicOr(c.err, ERR_KC_REGIONS); return; }
+        uint32_t* dc = pass == 0 ? nd_ctg : kr_ctg;
+        int32_t* ds = pass == 0 ? nd_se : kr_se;
+        unsigned long long len_sum = 0;
+        for (uint32_t i = 0; i < nr; ++i) {
+            dc[o + i] = ct;
+            ds[2 * (o + i)] = buf[2 * i];
+            ds[2 * (o + i) + 1] = buf[2 * i + 1];
+            len_sum += (unsigned long long)(buf[2 * i + 1] - buf[2 * i] + 1);
+        }
+        if (pass == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[KCC_ND_LEN]), len_sum);
+    }
+}
+
+// one lane per region (k-mer regions first, then no-depth regions): insertion columns (contig.c:182-245)
+__global__ __launch_bounds__(64) void k_kc_inserts(KcCtx c, const uint32_t* __restrict__ kr_ctg, const int32_t* __restrict__ kr_se,
+                                                   uint32_t n_kr, const uint32_t* __restrict__ nd_ctg,
+                                                   const int32_t* __restrict__ nd_se, uint32_t n_nd, uint32_t* __restrict__ ins) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_kr) kc_insert_region(c, kr_ctg[i], kr_se[2 * i], kr_se[2 * i + 1], ins);
+    else if (i < n_kr + n_nd) kc_insert_region(c, nd_ctg[i - n_kr], nd_se[2 * (i - n_kr)], nd_se[2 * (i - n_kr) + 1], ins);
+}
+
+// per slot: working base / flag from slot_info; empty context lists
+__global__ __launch_bounds__(256) void k_kc_slots(const uint8_t* __restrict__ slot_info, uint32_t S, uint8_t* __restrict__ sbase,
+                                                  uint8_t* __restrict__ sflag, uint16_t* __restrict__ scount,
+                                                  uint32_t* __restrict__ lhead) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const uint32_t info = slot_info[s];
+    sbase[s] = (uint8_t)(info & 0xf);
+    sflag[s] = (uint8_t)((info & SI_LOWER) ? KC_FLAG_ZERO : 0);
+    scount[s] = 0;
+    lhead[s] = 0;
+}
+
+// one lane per chain of no-depth regions (regions sharing an end point are solved in order by the same lane,
+// like the reference's sequential loop, kmercount.c:107-114)
+__global__ __launch_bounds__(64) void k_kc_nodepth(KcCtx c, const uint32_t* __restrict__ nd_ctg, const int32_t* __restrict__ nd_se,
+                                                   uint32_t n_nd) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nd) return;
+    const uint32_t ct = nd_ctg[i];
+    if (i > 0 && nd_ctg[i - 1] == ct && nd_se[2 * (i - 1) + 1] == nd_se[2 * i]) return;   // not a chain head
+    for (uint32_t k = i;; ++k) {
+        kc_score_correct_level2(c, ct, nd_se[2 * k], nd_se[2 * k + 1]);
+        if (k + 1 >= n_nd || nd_ctg[k + 1] != ct || nd_se[2 * (k + 1)] != nd_se[2 * k + 1]) break;
+    }
+}
+
+// split pass 1/2: parts per k-mer region (count), then fill at scanned offsets
+__global__ __launch_bounds__(64) void k_kc_split(KcCtx c, const uint32_t* __restrict__ kr_ctg, const int32_t* __restrict__ kr_se,
+                                                 uint32_t n_kr, int32_t* __restrict__ work, const uint32_t* __restrict__ work_off,
+                                                 uint32_t* __restrict__ n_parts, const uint32_t* __restrict__ part_off,
+                                                 uint32_t* __restrict__ pt_ctg, int32_t* __restrict__ pt_se,
+                                                 uint32_t* __restrict__ pt_len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_kr) return;
+    const uint32_t ct = kr_ctg[i];
+    const int32_t rs = kr_se[2 * i], re = kr_se[2 * i + 1];
+    if (part_off == nullptr) {   // count: an upper bound without walking (one cut per 2 positions) is too loose; walk
+        int32_t* buf = work + work_off[i];
+        int32_t np = kc_split_region(c, ct, rs, re, buf, (int32_t)(work_off[i + 1] - work_off[i]));
+        if (np < 0) { atomicOr(c.err, ERR_KC_REGIONS); np = 0; }
+        n_parts[i] = (uint32_t)np / 2;
+        return;
+    }
+    const int32_t* buf = work + work_off[i];
+    const uint32_t o = part_off[i], np = n_parts[i];
+    const uint32_t g0 = c.ctg_off[ct];
+    for (uint32_t k = 0; k < np; ++k) {
+        pt_ctg[o + k] = ct;
+        pt_se[2 * (o + k)] = buf[2 * k];
+        pt_se[2 * (o + k) + 1] = buf[2 * k + 1];
+        pt_len[o + k] = c.soff[g0 + (uint32_t)buf[2 * k + 1]] - c.soff[g0 + (uint32_t)buf[2 * k]] + 1;
+    }
+}
+
+// one lane per part: winner haplotype into wpool[woff[p] ..) (kmercount.c:175-261)
+__global__ __launch_bounds__(64) void k_kc_winner(KcCtx c, const uint32_t* __restrict__ pt_ctg, const int32_t* __restrict__ pt_se,
+                                                  const uint32_t* __restrict__ pt_len, const uint32_t* __restrict__ woff,
+                                                  uint32_t n_parts, int64_t n_all, uint8_t* __restrict__ wpool,
+                                                  uint8_t* __restrict__ has_winner) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parts) return;
+    const uint32_t ct = pt_ctg[p];
+    const bool has_next = (int64_t)c.read_begin[ct + 1] < n_all;
+    has_winner[p] = (uint8_t)kc_part_winner(c, ct, pt_se[2 * p], pt_se[2 * p + 1], has_next, wpool + woff[p], (int32_t)pt_len[p]);
+}
+
+// one lane per part: contig_update_contig (contig.c:811-821).  Parts are processed in order by the reference and
+// consecutive parts share their boundary position: the later part's value stays, so a part leaves its last slot to
+// its successor when that one has a winner.
+__global__ __launch_bounds__(64) void k_kc_apply(KcCtx c, const uint32_t* __restrict__ pt_ctg, const int32_t* __restrict__ pt_se,
+                                                 const uint32_t* __restrict__ pt_len, const uint32_t* __restrict__ woff,
+                                                 uint32_t n_parts, const uint8_t* __restrict__ wpool,
+                                                 const uint8_t* __restrict__ has_winner) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parts || !has_winner[p]) return;
+    const uint32_t ct = pt_ctg[p];
+    uint32_t n = pt_len[p];
+    // successors starting exactly at my end (a chain of zero-length... parts [k,k] can repeat): any winner among them wins
+    for (uint32_t q = p + 1; q < n_parts && pt_ctg[q] == ct && pt_se[2 * q] == pt_se[2 * p + 1]; ++q) {
+        if (has_winner[q]) { --n; break; }
+        if (pt_se[2 * q + 1] != pt_se[2 * q]) break;   // only single-position parts keep sharing the same start
+    }
+    const uint32_t s0 = c.soff[c.ctg_off[ct] + (uint32_t)pt_se[2 * p]];
+    const uint8_t* w = wpool + woff[p];
+    for (uint32_t t = 0; t < n; ++t) c.sbase[s0 + t] = w[t];
+}
+
+__global__ __launch_bounds__(256) void k_kc_result(const uint8_t* __restrict__ sbase, const uint8_t* __restrict__ sflag, uint32_t S,
+                                                   uint16_t* __restrict__ slot_res) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) slot_res[s] = (uint16_t)(sbase[s] | (uint32_t)sflag[s] << 8);
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+void kc_launch_records(hipStream_t st, const KcCtx& c, int64_t n_all, uint8_t* level, int32_t* endpos, uint32_t* max_span) {
+    if (n_all > 0) k_kc_records<<<kblk(n_all, 256), 256, 0, st>>>(c, n_all, level, endpos, max_span);
+}
+void kc_launch_draft(hipStream_t st, const uint8_t* draft, uint32_t G, uint8_t* code, uint8_t* flag) {
+    if (G) k_kc_draft<<<kblk(G, 256), 256, 0, st>>>(draft, G, code, flag);
+}
+void kc_launch_compact(hipStream_t st, const uint8_t* flag, const uint32_t* fpos, uint32_t G, uint32_t* flagged) {
+    if (G) k_kc_compact<<<kblk(G, 256), 256, 0, st>>>(flag, fpos, G, flagged);
+}
+void kc_launch_regions(hipStream_t st, const KcCtx& c, uint32_t nc, const uint32_t* fpos, uint32_t* flagged, int32_t* work,
+                       uint32_t* nd_ctg, int32_t* nd_se, uint32_t* kr_ctg, int32_t* kr_se, uint32_t reg_cap, uint32_t* counters) {
+    if (nc) k_kc_regions<<<kblk(nc, 64), 64, 0, st>>>(c, nc, fpos, flagged, work, nd_ctg, nd_se, kr_ctg, kr_se, reg_cap, counters);
+}
+void kc_launch_inserts(hipStream_t st, const KcCtx& c, const uint32_t* kr_ctg, const int32_t* kr_se, uint32_t n_kr,
+                       const uint32_t* nd_ctg, const int32_t* nd_se, uint32_t n_nd, uint32_t* ins) {
+    if (n_kr + n_nd) k_kc_inserts<<<kblk(n_kr + n_nd, 64), 64, 0, st>>>(c, kr_ctg, kr_se, n_kr, nd_ctg, nd_se, n_nd, ins);
+}
+void kc_launch_slots(hipStream_t st, const uint8_t* slot_info, uint32_t S, uint8_t* sbase, uint8_t* sflag, uint16_t* scount,
+                     uint32_t* lhead) {
+    if (S) k_kc_slots<<<kblk(S, 256), 256, 0, st>>>(slot_info, S, sbase, sflag, scount, lhead);
+}
+void kc_launch_nodepth(hipStream_t st, const KcCtx& c, const uint32_t* nd_ctg, const int32_t* nd_se, uint32_t n_nd) {
+    if (n_nd) k_kc_nodepth<<<kblk(n_nd, 64), 64, 0, st>>>(c, nd_ctg, nd_se, n_nd);
+}
+void kc_launch_split(hipStream_t st, const KcCtx& c, const uint32_t* kr_ctg, const int32_t* kr_se, uint32_t n_kr, int32_t* work,
+                     const uint32_t* work_off, uint32_t* n_parts, const uint32_t* part_off, uint32_t* pt_ctg, int32_t* pt_se,
+                     uint32_t* pt_len) {
+    if (n_kr) k_kc_split<<<kblk(n_kr, 64), 64, 0, st>>>(c, kr_ctg, kr_se, n_kr, work, work_off, n_parts, part_off, pt_ctg, pt_se, pt_len);
+}
+void kc_launch_winner(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len,
+                      const uint32_t* woff, uint32_t n_parts, int64_t n_all, uint8_t* wpool, uint8_t* has_winner) {
+    if (n_parts) k_kc_winner<<<kblk(n_parts, 64), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, n_all, wpool, has_winner);
+}
+void kc_launch_apply(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len,
+                     const uint32_t* woff, uint32_t n_parts, const uint8_t* wpool, const uint8_t* has_winner) {
+    if (n_parts) k_kc_apply<<<kblk(n_parts, 64), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, wpool, has_winner);
+}
+void kc_launch_result(hipStream_t st, const uint8_t* sbase, const uint8_t* sflag, uint32_t S, uint16_t* slot_res) {
+    if (S) k_kc_result<<<kblk(S, 256), 256, 0, st>>>(sbase, sflag, S, slot_res);
+}
+
+}  // namespace np1k

@@ -24,6 +24,11 @@ class Batch(object):
             return {nat.lib().np1_stage_name(i).decode(): float(ms[i]) for i in range(n)}
         return None
 
+    def kmer_count(self, cfg):
+        """Task 2 over the resident batch (stream loaded with qualities; cfg.read_tlen set, e.g. by config_init)."""
+        if nat.lib().np1_batch_kmer_count(self.handle, C.byref(cfg), None) != 0:
+            raise RuntimeError("np1_batch_kmer_count: " + nat.last_error())
+
     def results(self):
         L = nat.lib()
         out = []

@@ -13,6 +13,7 @@
 #include "../../include/nextpolish1.h"
 #include "../../nextpolish_amd/csrc/np1_core.h"
 #include "../../nextpolish_amd/csrc/np1_desc.h"
+#include "../../nextpolish_amd/csrc/np1_kmer.h"
 
 using namespace np1k;
 
@@ -279,6 +280,130 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
     for (uint32_t c = 0; c <= nc; ++c) bounds[c] = opos[soff[v->ctg_off[c]]];
     *out = buf;
     if (stats) { stats[0] = S; stats[1] = heads.size(); stats[2] = pool.size(); if (!np1m_fused) stats[3] = escal; }
+    return 0;
+}
+
+// kmer_count through the per-region bodies of np1_kmer.h, driven sequentially (the GPU runs one lane per region)
+int np1m_kmer_count(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds) {
+    const uint32_t nc = (uint32_t)v->n_contigs;
+    const int64_t n = v->n_reads;
+    const uint64_t G = (uint64_t)v->draft_len;
+    if (v->qual_len == 0 && n > 0) return -10;
+    KcCtx c;
+    memset(&c, 0, sizeof(c));
+    c.R = ReadsDev{v->pos, v->ctg, v->flag, v->n_cigar, v->l_qseq, v->cigar_off, v->seq_off, v->cigar, v->seq};
+    c.mapq = v->mapq; c.isize = v->isize; c.qual_off = v->qual_off; c.qual = v->qual;
+    c.ctg_off = v->ctg_off; c.read_begin = v->read_begin;
+    c.trim = cfg->trim_len_edge; c.ext_len_edge = cfg->ext_len_edge; c.min_len_ldr = cfg->min_len_ldr;
+    c.min_len_inter_kmer = cfg->min_len_inter_kmer; c.max_len_kmer = cfg->max_len_kmer; c.max_count_kmer = cfg->max_count_kmer;
+    c.min_map_quality = cfg->min_map_quality; c.read_tlen = cfg->read_tlen;
+    c.max_clip_ratio_sgs = cfg->max_clip_ratio_sgs; c.min_count_ratio_skip = cfg->min_count_ratio_skip;
+    c.K = -1;
+    for (int k = 0; k <= 10; ++k) {
+        double x = cfg->indel_balance_factor_sgs * (double)(1 << k);
+        if (x == (double)(long long)x) { c.K = k; c.Rfix = (long long)x; break; }
+    }
+    if (c.K < 0) return -2;
+    uint32_t err = 0;
+    c.err = &err;
+    std::vector<uint8_t> level(n ? n : 1);
+    std::vector<int32_t> endpos(n ? n : 1);
+    int32_t max_span = 1;
+    for (int64_t r = 0; r < n; ++r) {
+        level[r] = (uint8_t)kc_filter_level(c.R, r, c.mapq, c.isize, c.read_tlen, c.max_clip_ratio_sgs, c.min_map_quality);
+        endpos[r] = kc_endpos(c.R, r);
+        if (endpos[r] - v->pos[r] > max_span) max_span = endpos[r] - v->pos[r];
+    }
+    c.level = level.data(); c.endpos = endpos.data(); c.max_span = max_span;
+    std::vector<uint8_t> dcode(G + 1), dflag(G + 1);
+    for (uint64_t g = 0; g < G; ++g) {
+        uint32_t ch = (uint8_t)v->draft[g];
+        dflag[g] = 0;
+        if (ch >= 97 && ch <= 122) { ch -= 32; dflag[g] = KC_FLAG_ZERO; }
+        dcode[g] = (uint8_t)draft_code(ch);
+    }
+    c.draft_code = dcode.data(); c.draft_flag = dflag.data();
+    // regions per contig
+    std::vector<std::vector<int32_t>> nodepth(nc), kreg(nc);
+    std::vector<uint32_t> ins(G + 1, 0);
+    for (uint32_t ct = 0; ct < nc; ++ct) {
+        const uint32_t g0 = v->ctg_off[ct];
+        const int32_t L = (int32_t)(v->ctg_off[ct + 1] - g0);
+        if (L <= 0) continue;
+        std::vector<uint32_t> fl;
+        for (int32_t i = 0; i < L; ++i) if (dflag[g0 + i]) fl.push_back((uint32_t)i);
+        std::vector<int32_t> buf(2 * fl.size() + 4);
+        int32_t k = kc_find_regions(dcode.data() + g0, dflag.data() + g0, L, fl.data(), (uint32_t)fl.size(), 0,
+                                    (uint32_t)c.min_len_ldr, c.ext_len_edge, false, buf.data(), (int32_t)buf.size());
+        if (k < 0) return -11;
+        k = kc_merge_regions(buf.data(), k);
+        nodepth[ct].assign(buf.begin(), buf.begin() + k);
+        k = kc_find_regions(dcode.data() + g0, dflag.data() + g0, L, fl.data(), (uint32_t)fl.size(), (uint32_t)c.min_len_inter_kmer, 0,
+                            c.ext_len_edge, true, buf.data(), (int32_t)buf.size());
+        if (k < 0) return -11;
+        k = kc_merge_regions(buf.data(), k);
+        kreg[ct].assign(buf.begin(), buf.begin() + k);
+        for (size_t i = 0; i + 1 < kreg[ct].size(); i += 2) kc_insert_region(c, ct, kreg[ct][i], kreg[ct][i + 1], ins.data());
+        for (size_t i = 0; i + 1 < nodepth[ct].size(); i += 2) kc_insert_region(c, ct, nodepth[ct][i], nodepth[ct][i + 1], ins.data());
+    }
+    std::vector<uint32_t> soff(G + 2);
+    uint64_t acc = 0;
+    for (uint64_t g = 0; g < G; ++g) { soff[g] = (uint32_t)acc; acc += 1 + ins[g]; }
+    soff[G] = (uint32_t)acc;
+    const uint32_t S = (uint32_t)acc;
+    std::vector<uint8_t> slot_info(S + 64, 0), sbase(S + 64), sflag(S + 64);
+    for (uint32_t ct = 0; ct < nc; ++ct)
+        for (uint32_t g = v->ctg_off[ct]; g < v->ctg_off[ct + 1]; ++g)
+            slotinfo_base((const uint8_t*)v->draft, g, v->ctg_off[ct], v->ctg_off[ct + 1], soff.data(), slot_info.data());
+    for (uint32_t s = 0; s < S; ++s) { sbase[s] = slot_info[s] & 0xf; sflag[s] = (slot_info[s] & SI_LOWER) ? 1 : 0; }
+    std::vector<uint16_t> srefk(S + 64, 0), scount(S + 64, 0);
+    std::vector<uint32_t> lhead(S + 64, 0), lpool(2ull * (1u << 22));
+    uint32_t lcount = 0, stcount = 0, hcount = 0;
+    const uint32_t stcap = 1u << 20;
+    std::vector<long long> stsc(16ull * stcap);
+    std::vector<uint16_t> stkm(16ull * stcap);
+    std::vector<uint8_t> strk(16ull * stcap);
+    std::vector<uint8_t> hpool(64u << 20);
+    c.soff = soff.data(); c.sbase = sbase.data(); c.sflag = sflag.data(); c.srefk = srefk.data(); c.scount = scount.data();
+    c.lhead = lhead.data(); c.lpool = lpool.data(); c.lcap = 1u << 22; c.lcount = &lcount;
+    c.st_score = stsc.data(); c.st_kmer = stkm.data(); c.st_rank = strk.data(); c.st_cap = stcap; c.st_count = &stcount;
+    c.hpool = hpool.data(); c.hcap = (uint32_t)hpool.size(); c.hcount = &hcount;
+    for (uint32_t ct = 0; ct < nc; ++ct)
+        for (size_t i = 0; i + 1 < nodepth[ct].size(); i += 2) {
+            stcount = 0;
+            kc_score_correct_level2(c, ct, nodepth[ct][i], nodepth[ct][i + 1]);
+        }
+    if (err) return (int)err;
+    for (uint32_t ct = 0; ct < nc; ++ct) {
+        const uint32_t g0 = v->ctg_off[ct];
+        const bool has_next = (int64_t)v->read_begin[ct + 1] < n;
+        for (size_t i = 0; i + 1 < kreg[ct].size(); i += 2) {
+            std::vector<int32_t> parts(2 * (size_t)(kreg[ct][i + 1] - kreg[ct][i] + 4));
+            int32_t np = kc_split_region(c, ct, kreg[ct][i], kreg[ct][i + 1], parts.data(), (int32_t)parts.size());
+            if (np < 0) return -12;
+            for (int32_t k = 0; k + 1 < np; k += 2) {
+                const int32_t ps = parts[k], pe = parts[k + 1];
+                const int32_t length = (int32_t)(soff[g0 + pe] - soff[g0 + ps] + 1);
+                std::vector<uint8_t> win(length);
+                hcount = 0;
+                if (kc_part_winner(c, ct, ps, pe, has_next, win.data(), length)) {
+                    const uint32_t s0 = soff[g0 + ps];
+                    for (int32_t t = 0; t < length; ++t) sbase[s0 + t] = win[t];   // contig_update_contig (contig.c:811-821)
+                }
+            }
+        }
+    }
+    if (err) return (int)err;
+    std::vector<uint16_t> slot_res(S + 64);
+    for (uint32_t s = 0; s < S; ++s) slot_res[s] = (uint16_t)(sbase[s] | sflag[s] << 8);
+    std::vector<uint32_t> opos(S + 1);
+    uint32_t o = 0;
+    for (uint32_t s = 0; s < S; ++s) { opos[s] = o; o += (slot_res[s] & 0xff) != 3; }
+    opos[S] = o;
+    char* buf = (char*)calloc(1, (size_t)o + 1);
+    for (uint32_t s = 0; s < S; ++s) emit_slot(s, slot_res.data(), slot_info.data(), opos.data(), 1u, (uint8_t*)buf);
+    for (uint32_t ct = 0; ct <= nc; ++ct) bounds[ct] = opos[soff[v->ctg_off[ct]]];
+    *out = buf;
     return 0;
 }
 

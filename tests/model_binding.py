@@ -15,6 +15,9 @@ def lib():
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         L.np1m_score_chain.restype = C.c_int
         L.np1m_free.argtypes = [C.c_void_p]
+        L.np1m_kmer_count.argtypes = [C.POINTER(nat.StreamView), C.POINTER(nat.Configure), C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_uint32)]
+        L.np1m_kmer_count.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -35,3 +38,15 @@ def score_chain(stream, cfg=None, want_stats=False, fused=False):
     if want_stats:
         return res, dict(slots=stats[0], heads=stats[1], pool_words=stats[2], escalations=stats[3])
     return res
+
+
+def kmer_count(stream, cfg):
+    """kmer_count through the per-region bodies of np1_kmer.h (stream must carry qualities; cfg.read_tlen set)."""
+    out = C.c_void_p()
+    bounds = (C.c_uint32 * (stream.n_contigs + 1))()
+    rc = lib().np1m_kmer_count(C.byref(stream.view), C.byref(cfg), C.byref(out), bounds)
+    if rc != 0:
+        raise RuntimeError("kmer_count model failed rc=%d" % rc)
+    blob = C.string_at(out, bounds[stream.n_contigs])
+    lib().np1m_free(out)
+    return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)]

@@ -179,3 +179,73 @@ def test_python_harness_end_to_end(tmp_path):
         for j in sorted(k for k in c if k > 0):
             rebuilt.append(c[j])
     assert "".join(rebuilt) == want[st.names[1]].upper()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# kmer_count (task 2) on the GPU against the oracle
+
+def _check_kmer(ctx, st, read_tlen=1500):
+    cfg = nat.default_config()
+    cfg.read_tlen = read_tlen
+    ocfg = ob.default_config(read_tlen=read_tlen)
+    b = ctx.upload(st)
+    b.kmer_count(cfg)
+    got = b.results()
+    b.close()
+    for i in range(st.n_contigs):
+        want = ob.kmer_count(st, i, ocfg)
+        assert len(got[i]) == len(want), "contig %d: length %d != %d" % (i, len(got[i]), len(want))
+        if got[i] != want:
+            k = next(j for j in range(len(want)) if got[i][j] != want[j])
+            raise AssertionError("kmer_count contig %d differs at %d: %r vs %r" % (i, k, got[i][max(0, k - 8):k + 8], want[max(0, k - 8):k + 8]))
+    return got
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_kmer_count_synth_matches_oracle(ctx, seed):
+    kw = dict(depth=[5, 15, 30, 60, 120][seed % 5], seed=2000 + seed, with_qual=1, weird_rate=0.02 if seed % 2 else 0.0,
+              draft_lower=[0.01, 0.03, 0.002][seed % 3], read_indel=0.002 if seed % 4 == 0 else 0.0001, softclip_rate=0.05,
+              draft_indel=0.02 if seed % 7 == 0 else 0.005)
+    st = nat.Stream.synth([3000 + seed * 137, 900 + seed * 11, 200], **kw)
+    _check_kmer(ctx, st)
+
+
+def test_kmer_count_micro_cases_match_oracle(ctx):
+    import random
+    for seed in range(300):
+        contigs, reads = random_case(seed + 5000, max_len=300, max_reads=80)
+        rng = random.Random(seed)
+        c2 = []
+        for n, d in contigs:
+            d = list(d)
+            for _ in range(rng.randint(0, 6)):
+                i = rng.randrange(len(d))
+                for j in range(i, min(len(d), i + rng.randint(1, 6))):
+                    d[j] = d[j].lower()
+            c2.append((n, "".join(d)))
+        st = nat.Stream.from_reads(c2, reads)
+        _check_kmer(ctx, st, read_tlen=1000)
+
+
+def test_one_round_score_chain_then_kmer_count(ctx, tmp_path):
+    """Task 1 then task 2 on its output, as the workflow chains them (reads re-placed on the new draft by shifting
+    nothing: the second task simply runs on a draft with score_chain's lowercase marks).  Drop-in ABI + CLI."""
+    st = nat.Stream.synth([40000, 9000], depth=40, seed=91, with_qual=1, draft_lower=0.004)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "g.bam")
+    st.write_files(fa, bam)
+    L = nat.lib()
+    cfg = L.config_init(fa.encode(), bam.encode(), None)
+    ocfg = ob.default_config(read_tlen=cfg.contents.read_tlen, read_len=cfg.contents.read_len)
+    want = [ob.kmer_count(st, i, ocfg) for i in range(st.n_contigs)]
+    for i, name in enumerate(st.names):
+        r = L.kmer_count(name.encode(), cfg)
+        assert C.string_at(r.contents.contig).decode() == want[i]
+        L.polishresult_destory(r)
+    L.config_destory(cfg)
+    out = subprocess.run([os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1"), "kmercount", fa, bam],
+                         stdout=subprocess.PIPE, check=True).stdout.decode()
+    cli = parse_cli_fasta(out)
+    assert [cli[n] for n in st.names] == want
+    if ref_binary():
+        ref = run_ref("kmercount", fa, bam)
+        assert [ref[n] for n in st.names] == want

@@ -49,3 +49,41 @@ def test_model_crowded_slots_escalate():
     got, stats = mb.score_chain(st, want_stats=True)
     assert stats["escalations"] > 0
     assert got[0] == ob.score_chain(st, 0)
+
+
+# ---- kmer_count bodies (np1_kmer.h) against the oracle ----------------------------------------------------------
+def _lowercase_some(contigs, seed):
+    import random
+    rng = random.Random(seed)
+    out = []
+    for n, d in contigs:
+        d = list(d)
+        for _ in range(rng.randint(0, 6)):
+            i = rng.randrange(len(d))
+            for j in range(i, min(len(d), i + rng.randint(1, 6))):
+                d[j] = d[j].lower()
+        out.append((n, "".join(d)))
+    return out
+
+
+def test_model_kmer_count_micro_cases():
+    for seed in range(200):
+        contigs, reads = random_case(seed + 5000, max_len=300, max_reads=80)
+        st = nat.Stream.from_reads(_lowercase_some(contigs, seed), reads)
+        cfg = nat.default_config()
+        cfg.read_tlen = 1000
+        got = mb.kmer_count(st, cfg)
+        for i in range(st.n_contigs):
+            assert got[i] == ob.kmer_count(st, i, ob.default_config(read_tlen=1000)), "seed %d contig %d" % (seed, i)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_model_kmer_count_synth(seed):
+    st = nat.Stream.synth([3000 + seed * 137, 900 + seed * 11, 200], depth=[5, 15, 30, 60, 120][seed % 5], seed=2000 + seed,
+                          with_qual=1, weird_rate=0.02 if seed % 2 else 0.0, draft_lower=[0.01, 0.03, 0.002][seed % 3],
+                          read_indel=0.002 if seed % 4 == 0 else 0.0001, softclip_rate=0.05)
+    cfg = nat.default_config()
+    cfg.read_tlen = 1500
+    got = mb.kmer_count(st, cfg)
+    for i in range(st.n_contigs):
+        assert got[i] == ob.kmer_count(st, i, ob.default_config(read_tlen=1500))
