@@ -187,6 +187,11 @@ int np1_batch_result_copy(np1_batch* b, int64_t contig, char* dst, int64_t cap);
 /* total slot votes ("updates") of the last run and HBM bytes held by the batch */
 int64_t np1_batch_update_count(np1_batch* b);
 int64_t np1_batch_device_bytes(np1_batch* b);
+/* device work counters of the last score_chain run (diagnostics; layout = np1_core.h CNT_*), up to n words */
+int np1_batch_debug_counters(np1_batch* b, uint32_t* out, int n);
+/* raw per-slot arrays of the last run (diagnostics): kind 0 = slot_info u8, 1 = slot_res u16, 2 = slot_rec u32;
+ * copies min(n, slots) elements and returns the slot count */
+int64_t np1_batch_debug_slots(np1_batch* b, int kind, void* out, int64_t n);
 
 /* calgs (reference: source/lib/calgs.c:8-24): sum of sequence lengths of a FASTA/FASTQ (gz aware) */
 uint64_t calgs(const char* file);

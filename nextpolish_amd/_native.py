@@ -130,6 +130,10 @@ def lib():
     L.np1_batch_result_len.restype = C.c_int64
     L.np1_batch_result_copy.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]
     L.np1_batch_result_copy.restype = C.c_int
+    L.np1_batch_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
+    L.np1_batch_debug_counters.restype = C.c_int
+    L.np1_batch_debug_slots.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    L.np1_batch_debug_slots.restype = C.c_int64
     L.np1_batch_update_count.argtypes = [C.c_void_p]
     L.np1_batch_update_count.restype = C.c_int64
     L.np1_batch_device_bytes.argtypes = [C.c_void_p]

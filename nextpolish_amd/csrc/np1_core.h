@@ -37,6 +37,7 @@ constexpr uint32_t VOTE_CH = 62;
 constexpr uint32_t REC_SINGLE = 1, REC_CTG_LAST = 2, REC_CTG_FIRST = 4;   // hdr bits; hdr bits 4..7 = previous slot's draft symbol
 constexpr uint32_t REC_FIXED_WORDS = 12;
 enum { CNT_POOL = 0, CNT_HEADS = 1, CNT_REDO = 2, CNT_ERR = 3, CNT_REDO2 = 4, CNT_OVFDESC = 5,
+       CNT_STAT_EVENTS = 6, CNT_STAT_FALLBACK = 7,   // statistics of the event kernels
        CNT_POOL_S0 = 8, CNT_HEADS_S0 = 16, CNT_WORDS = 24 };   // fused pipeline: pool / run-head counters sharded 8 ways
 constexpr uint32_t POOL_SHARDS = 8;
 constexpr uint32_t ERR_DOUBLE_INS = 1, ERR_BAD_RECORD = 2, ERR_CTX_OVERFLOW = 4, ERR_POOL_OVERFLOW = 8,

@@ -86,6 +86,7 @@ struct np1_batch {
         slot_rec, pool, heads, redo, redo2, counters, opos, out, bounds, scan_tmp, totals;
     size_t input_bytes = 0;
     uint32_t max_lq = 0;   // longest record of the batch (bases)
+    uint32_t last_counters[CNT_WORDS] = {0};
     bool force_staged = false;   // a record exceeded the descriptor capacity once: this batch uses the staged sequence
     // results of the last run
     uint32_t S = 0;
@@ -397,7 +398,16 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
             };
             HIPCHK(hipMemsetAsync(&totals[3], 0, 8, q));
             t0(5);
-            if (tile(0, nullptr, 0, b->redo.as<uint32_t>(), CNT_REDO) != 0) {
+            static const bool use_tile3 = !(getenv("NP1_TILE") && atoi(getenv("NP1_TILE")) == 5);   // NP1_TILE=5: event kernel (exact, slower so far)
+            const int rc5 = use_tile3
+                ? tile(0, nullptr, 0, b->redo.as<uint32_t>(), CNT_REDO)
+                : launch_tile5(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
+                               b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(),
+                               b->slot_g.as<uint32_t>(), S, b->max_lq, b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(),
+                               b->pool.as<uint32_t>(), pool_cap, counters, b->heads.as<uint32_t>(),
+                               (uint32_t)std::min<size_t>(b->heads.cap / 4, 0xfffffff0u), b->redo.as<uint32_t>(), CNT_REDO,
+                               flag_single, votes);
+            if (rc5 != 0) {
                 np1_set_error("records are too long for the LDS-staged path (long reads belong to nextpolish2)");
                 return -1;
             }
@@ -460,6 +470,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
     HIPCHK(hipStreamSynchronize(q));
     if (hc[CNT_ERR] & ERR_DP_INCONSISTENT) { np1_set_error("inconsistent pileup state in the chain DP"); return -1; }
+    memcpy(b->last_counters, hc, sizeof(hc));
     b->votes += S;   // the draft votes once per slot
     if (timing) {
         for (int i = 0; i < NP1_MAX_STAGES; ++i) stage_ms[i] = 0.f;
@@ -657,6 +668,22 @@ int np1_batch_result_copy(np1_batch* b, int64_t c, char* dst, int64_t cap) {
     return 0;
 }
 
+int np1_batch_debug_counters(np1_batch* b, uint32_t* out, int n) {
+    if (!b) return -1;
+    for (int i = 0; i < n && i < (int)CNT_WORDS; ++i) out[i] = b->last_counters[i];
+    return 0;
+}
+// diagnostics: raw per-slot arrays of the last run.  kind 0 = slot_info (u8), 1 = slot_res (u16), 2 = slot_rec (u32);
+// returns the slot count, copies min(n, S) elements
+int64_t np1_batch_debug_slots(np1_batch* b, int kind, void* out, int64_t n) {
+    if (!b || !b->ran) return -1;
+    (void)hipSetDevice(b->ctx->device);
+    const size_t m = (size_t)std::min<int64_t>(n, (int64_t)b->S);
+    const void* src = kind == 0 ? b->slot_info.p : kind == 1 ? b->slot_res.p : b->slot_rec.p;
+    const size_t w = kind == 0 ? 1 : kind == 1 ? 2 : 4;
+    if (m && hipMemcpy(out, src, m * w, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)b->S;
+}
 int64_t np1_batch_update_count(np1_batch* b) { return b && b->ran ? (int64_t)b->votes : -1; }
 int64_t np1_batch_device_bytes(np1_batch* b) { return b ? (int64_t)b->device_bytes() : -1; }
 

@@ -23,6 +23,7 @@
 
 #include "np1_core.h"
 #include "np1_desc.h"
+#include "np1_events.h"
 #include "np1_kernels.h"
 
 namespace np1k {
@@ -299,6 +300,76 @@ __global__ __launch_bounds__(256) void k_desc(ReadsDev R, int64_t n_reads, const
 // the record's symbol at its own (draft index, insertion column) straight from the staged bases, takes
 // its two left neighbours' symbols with DPP shifts and tallies the 3-base context.  HBM traffic: the
 // record stream once per overlapped tile (x1.3), slot_info/slot_g, per-slot results, DP records.
+// Shared tail of the fused kernels: single-state slots are final; multi-state runs spill DP records.  Pool space
+// and run-head slots are claimed ONCE PER WORKGROUP on a counter sharded 8 ways (a single device-scope counter
+// bumped by every wave saturates at ~90 atomics/us and used to cost as much as the voting itself).
+// Must be reached by every wave of the workgroup (two barriers inside).
+template <int E, int NW>
+__device__ __forceinline__ void tile_epilogue(const VoteLane<E>& vl, const uint32_t* L, int tid, uint32_t c, bool live, bool redo,
+                                              bool valid, uint32_t s, uint32_t info, uint32_t dsym, bool first,
+                                              uint32_t prev_dsym, bool single, bool prev_is_single, uint32_t total,
+                                              uint16_t* __restrict__ slot_res, uint32_t* __restrict__ slot_rec,
+                                              uint32_t* __restrict__ pool, uint32_t pool_cap, uint32_t* __restrict__ counters,
+                                              uint32_t* __restrict__ heads, uint32_t heads_cap, uint32_t* __restrict__ redo_out,
+                                              uint32_t redo_ci, uint32_t flag_single) {
+    __shared__ uint32_t sh_e[2 * NW + 4];
+    const int wave = tid >> 6, lane = tid & 63;
+    if (redo && lane == 0) {   // redo this chunk with a roomier instantiation
+        if (redo_out) redo_out[atomicAdd(&counters[redo_ci], 1u)] = c;
+        else atomicOr(&counters[CNT_ERR], ERR_CTX_OVERFLOW);
+    }
+    const bool own = live && lane >= 2 && valid;
+    const bool is_head = own && !single && prev_is_single;
+    const bool need_rec = own && (!single || !prev_is_single);
+    if (own) {
+        uint32_t res = 0xffu;
+        if (single) res = dsym | (((total == 1 ? 1u : 0u) | flag_single) << 8);
+        slot_res[s] = (uint16_t)res;
+    }
+    const uint32_t words = need_rec ? vl.n + REC_FIXED_WORDS : 0u;
+    uint32_t incl = words;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const unsigned long long hb = __ballot(is_head);
+    if (lane == 63) sh_e[wave] = incl;
+    if (lane == 0) sh_e[NW + wave] = (uint32_t)__popcll(hb);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t wsum = 0, hsum = 0;
+        for (int w = 0; w < NW; ++w) { wsum += sh_e[w]; hsum += sh_e[NW + w]; }
+        const uint32_t shard = blockIdx.x & (POOL_SHARDS - 1);
+        const uint32_t pregion = pool_cap / POOL_SHARDS, hregion = heads_cap / POOL_SHARDS;
+        uint32_t pbase = 0xffffffffu, hbase = 0;
+        if (wsum) {
+            const uint32_t o = atomicAdd(&counters[CNT_POOL_S0 + shard], wsum);
+            if ((uint64_t)o + wsum <= pregion) pbase = shard * pregion + o;
+            else atomicOr(&counters[CNT_ERR], ERR_POOL_OVERFLOW);
+        }
+        if (hsum) {
+            const uint32_t o = atomicAdd(&counters[CNT_HEADS_S0 + shard], hsum);
+            if ((uint64_t)o + hsum <= hregion) hbase = shard * hregion + o;
+            else { atomicOr(&counters[CNT_ERR], ERR_POOL_OVERFLOW); pbase = 0xffffffffu; }
+        }
+        sh_e[2 * NW] = pbase;
+        sh_e[2 * NW + 1] = hbase;
+    }
+    __syncthreads();
+    uint32_t pbase = sh_e[2 * NW], hbase = sh_e[2 * NW + 1];
+    const bool fits = pbase != 0xffffffffu;
+    for (int w = 0; w < wave; ++w) { pbase += sh_e[w]; hbase += sh_e[NW + w]; }
+    uint32_t my_off = 0xffffffffu;
+    if (need_rec && fits) {
+        my_off = pbase + incl - words;
+        const uint32_t hdr = (single ? REC_SINGLE : 0u) | ((info & SI_LAST) ? REC_CTG_LAST : 0u) |
+                             (first ? REC_CTG_FIRST : 0u) | (prev_dsym << 4);
+        vl.write_record(pool + my_off, s, total, hdr, L, lane);
+    }
+    if (own) slot_rec[s] = my_off;
+    if (is_head && fits) heads[hbase + __popcll(hb & ((1ull << lane) - 1ull))] = my_off;
+}
+
 // one part of one record against this wave's 64 slots (d may live in LDS or, for overflow parts, in HBM: the two
 // call sites keep the address spaces apart so the common path compiles to ds_read)
 template <int E>
@@ -428,7 +499,7 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
                     for (uint32_t i = a; i <= b; ++i) {
                         const uint4 hn = *reinterpret_cast<const uint4*>(dsc + (i + 1) * DESC_WORDS);
                         const uint2 sgn = *reinterpret_cast<const uint2*>(dsc + (i + 1) * DESC_WORDS + DESC_SEG0);
-                        if (!(h.z & DESC_CHAIN)) {
+                        if (!(h.z & DESC_CHAIN) && !(ablate & 32u)) {
                             // wave-uniform shape test; the body is branch-free apart from uniform trip counts
                             const uint32_t nseg = h.z & 0xffu, nins = (h.z >> 8) & 0xffu;
                             const bool cov = sv >= h.x && sv <= h.y;
@@ -489,72 +560,249 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
             __syncthreads();
         }
     }
-    // ---- epilogue: single-state slots are final; multi-state runs spill DP records.  Pool space and run-head
-    // slots are claimed ONCE PER WORKGROUP on a counter sharded 8 ways (a single device-scope counter bumped by
-    // every wave saturates at ~90 atomics/us and used to cost as much as the voting itself).
-    __shared__ uint32_t sh_e[2 * NW + 4];
     for (int o = 32; o > 0; o >>= 1) nvotes += __shfl_down(nvotes, o);
     const bool ovf_any = chunk_ok && __ballot(vl.ovf) != 0ull;
     if (lane == 0 && nvotes && !ovf_any && chunk_ok) atomicAdd(votes, (unsigned long long)nvotes);
-    if (ovf_any && lane == 0) {   // a slot holds more distinct contexts than this instantiation keeps: redo the chunk with a larger E
-        if (redo_out) redo_out[atomicAdd(&counters[redo_ci], 1u)] = c;
-        else atomicOr(&counters[CNT_ERR], ERR_CTX_OVERFLOW);
-    }
-    const bool live = chunk_ok && !ovf_any;
-    const bool own = live && lane >= 2 && valid;
-    const uint32_t total = vl.total(L, lane);
     const bool single = __popc(basemask) == 1;
-    const uint32_t psingle = wave_shr1((uint32_t)single);
+    const uint32_t psingle = wave_shr1((uint32_t)single);   // every lane must execute the DPP move: keep it out of the || below
     const bool prev_is_single = first || psingle != 0;
-    const bool is_head = own && !single && prev_is_single;
-    const bool need_rec = own && (!single || !prev_is_single);
-    if (own) {
-        uint32_t res = 0xffu;
-        if (single) res = dsym | (((total == 1 ? 1u : 0u) | flag_single) << 8);
-        slot_res[s] = (uint16_t)res;
+    tile_epilogue<E, NW>(vl, L, tid, c, chunk_ok && !ovf_any, ovf_any, valid, s, info, dsym, first, prev_dsym, single, prev_is_single,
+                         vl.total(L, lane), slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci,
+                         flag_single);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tile5 (default): event form of the pileup vote (np1_events.h).  Same tile geometry, staging and epilogue as
+// k_tile3, but the per-(record, slot) vote loop is gone:
+//   phase R  one lane per candidate record: +1/-1 into the tile's coverage difference array, and the record's
+//            EVENTS (votes whose 3-base context differs from the draft's) found by XOR-ing packed bases eight at a
+//            time against the draft's packed symbols, exact per-slot evaluation only around disagreements
+//   phase S  block scan -> coverage per slot; counting sort of the events by slot; one lane per slot orders its few
+//            events by record (= first-seen order) and tallies them; count(k0) = 1 + coverage - #events
+// Instruction count per record drops from ~475 wave-instructions (k_tile3) to a few dozen.
+template <int NW>
+struct Tile5Lds {
+    static constexpr uint32_t NWIN = NW * VOTE_CH + 2;
+};
+
+struct Tile5Sink {
+    uint32_t* ev_total;
+    uint32_t* ev_unsorted;
+    uint32_t* evcnt;
+    uint32_t ev_max, w0, rec_local;
+    uint32_t* overflow;
+    __device__ __forceinline__ void event(uint32_t slot, uint32_t ctx) {
+        const uint32_t idx = atomicAdd(ev_total, 1u);
+        if (idx < ev_max) {
+            ev_unsorted[idx] = (slot - w0) << 23 | rec_local << 12 | (ctx & 0xfffu);
+            atomicAdd(&evcnt[slot - w0], 1u);
+        } else {
+            *overflow = 1u;
+        }
     }
-    const uint32_t words = need_rec ? vl.n + REC_FIXED_WORDS : 0u;
-    uint32_t incl = words;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    const unsigned long long hb = __ballot(is_head);
-    if (lane == 63) sh_e[wave] = incl;
-    if (lane == 0) sh_e[NW + wave] = (uint32_t)__popcll(hb);
-    __syncthreads();
+};
+
+template <int E, int NW>
+__global__ __launch_bounds__(NW * 64) void k_tile5(ReadsDev R, const uint32_t* __restrict__ soff,
+                                                   const uint32_t* __restrict__ desc,
+                                                   const uint32_t* __restrict__ ovf_pool,
+                                                   const uint32_t* __restrict__ chunk_first,
+                                                   const uint32_t* __restrict__ chunk_last, uint32_t n_chunks,
+                                                   const uint8_t* __restrict__ slot_info,
+                                                   const uint32_t* __restrict__ slot_g, uint32_t S, uint32_t seq_w,
+                                                   uint32_t nb_max, uint32_t ev_max, uint16_t* __restrict__ slot_res,
+                                                   uint32_t* __restrict__ slot_rec, uint32_t* __restrict__ pool,
+                                                   uint32_t pool_cap, uint32_t* __restrict__ counters,
+                                                   uint32_t* __restrict__ heads, uint32_t heads_cap,
+                                                   uint32_t* __restrict__ redo_out, uint32_t redo_ci, uint32_t flag_single,
+                                                   unsigned long long* __restrict__ votes, uint32_t ablate) {
+    constexpr uint32_t NWIN = NW * VOTE_CH + 2;
+    constexpr uint32_t T = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ __attribute__((aligned(16))) uint32_t sh_r[8];   // r0, r1, ev_total, overflow
+    uint32_t* lists = lds;                                   // NW * (E-2) * 64
+    uint32_t* dsc = lists + NW * (E - 2) * 64;               // (nb_max + 1) * DESC_WORDS
+    uint32_t* seqst = dsc + (nb_max + 1) * DESC_WORDS;       // nb_max * seq_w + 8
+    uint32_t* win_sg = seqst + nb_max * seq_w + 8;           // NWIN
+    uint32_t* cover = win_sg + NWIN;                         // NWIN + 1 : difference array, then coverage
+    uint32_t* evcnt = cover + NWIN + 1;                      // NWIN
+    uint32_t* evoff = evcnt + NWIN;                          // NWIN + 1
+    uint32_t* evcur = evoff + NWIN + 1;                      // NWIN
+    uint32_t* bmask = evcur + NWIN;                          // NWIN : base mask per slot
+    uint32_t* dpk_w = bmask + NWIN;                          // NWIN / 8 + 4 words : packed draft symbols
+    uint16_t* win_k0 = reinterpret_cast<uint16_t*>(dpk_w + NWIN / 8 + 4);   // NWIN (+pad)
+    uint8_t* win_sinfo = reinterpret_cast<uint8_t*>(win_k0 + NWIN + 2);     // NWIN (+pad)
+    uint32_t* ev_unsorted = reinterpret_cast<uint32_t*>(win_sinfo + ((NWIN + 7) & ~3u));   // ev_max
+    uint32_t* ev_sorted = ev_unsorted + ev_max;              // ev_max
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t cbase = blockIdx.x * NW;
+    if (cbase >= n_chunks || (uint64_t)cbase * VOTE_CH >= S) return;   // (the chunk count is rounded up by one: nothing to own here)
+    const uint32_t c = cbase + wave;
+    const bool chunk_ok = c < n_chunks;
+    const uint32_t T0 = cbase * VOTE_CH;
+    const uint32_t w0 = T0 >= 2 ? T0 - 2 : 0u;
+    const uint32_t T1 = (uint64_t)T0 + NW * VOTE_CH < S ? T0 + NW * VOTE_CH : S;   // exclusive
+    const uint32_t wn = T1 - w0;
     if (tid == 0) {
-        uint32_t wsum = 0, hsum = 0;
-        for (int w = 0; w < NW; ++w) { wsum += sh_e[w]; hsum += sh_e[NW + w]; }
-        const uint32_t shard = blockIdx.x & (POOL_SHARDS - 1);
-        const uint32_t pregion = pool_cap / POOL_SHARDS, hregion = heads_cap / POOL_SHARDS;
-        uint32_t pbase = 0xffffffffu, hbase = 0;
-        if (wsum) {
-            const uint32_t o = atomicAdd(&counters[CNT_POOL_S0 + shard], wsum);
-            if ((uint64_t)o + wsum <= pregion) pbase = shard * pregion + o;
-            else atomicOr(&counters[CNT_ERR], ERR_POOL_OVERFLOW);
+        uint32_t r0 = 0xffffffffu, r1 = 0;
+        for (int w = 0; w < NW; ++w) {
+            uint32_t cc = cbase + w;
+            if (cc < n_chunks) {
+                uint32_t f = chunk_first[cc];
+                if (f != 0xffffffffu) {
+                    if (f < r0) r0 = f;
+                    uint32_t l = chunk_last[cc];
+                    if (l > r1) r1 = l;
+                }
+            }
         }
-        if (hsum) {
-            const uint32_t o = atomicAdd(&counters[CNT_HEADS_S0 + shard], hsum);
-            if ((uint64_t)o + hsum <= hregion) hbase = shard * hregion + o;
-            else { atomicOr(&counters[CNT_ERR], ERR_POOL_OVERFLOW); pbase = 0xffffffffu; }
-        }
-        sh_e[2 * NW] = pbase;
-        sh_e[2 * NW + 1] = hbase;
+        sh_r[0] = r0;
+        sh_r[1] = r1;
+        sh_r[2] = 0;
+        sh_r[3] = 0;
+    }
+    // ---- window arrays
+    for (uint32_t k = tid; k < NWIN + 1; k += T) {
+        cover[k] = 0;
+        if (k < NWIN) { evcnt[k] = 0; evcur[k] = 0; }
+    }
+    for (uint32_t k = tid; k < NWIN / 8 + 4; k += T) dpk_w[k] = 0;
+    for (uint32_t k = tid; k < wn; k += T) {
+        win_sinfo[k] = slot_info[w0 + k];
+        win_sg[k] = slot_g[w0 + k];
     }
     __syncthreads();
-    uint32_t pbase = sh_e[2 * NW], hbase = sh_e[2 * NW + 1];
-    const bool fits = pbase != 0xffffffffu;
-    for (int w = 0; w < wave; ++w) { pbase += sh_e[w]; hbase += sh_e[NW + w]; }
-    uint32_t my_off = 0xffffffffu;
-    if (need_rec && fits) {
-        my_off = pbase + incl - words;
-        const uint32_t hdr = (single ? REC_SINGLE : 0u) | ((info & SI_LAST) ? REC_CTG_LAST : 0u) |
-                             (first ? REC_CTG_FIRST : 0u) | (prev_dsym << 4);
-        vl.write_record(pool + my_off, s, total, hdr, L, lane);
+    const uint32_t dpk_g0 = win_sg[0] & ~1u;
+    for (uint32_t k = tid; k < wn; k += T) {
+        const uint32_t info = win_sinfo[k];
+        uint32_t d1 = 0, d2 = 0;
+        if (!(info & SI_FIRST) && k >= 1) {
+            d1 = win_sinfo[k - 1] & 0xfu;
+            if (!(win_sinfo[k - 1] & SI_FIRST) && k >= 2) d2 = win_sinfo[k - 2] & 0xfu;
+        }
+        win_k0[k] = (uint16_t)(d2 << 8 | d1 << 4 | (info & 0xfu));   // valid for every owned slot (k >= 2, or contig starts)
+        if (!(info & SI_INSERT)) {
+            const uint32_t i = win_sg[k] - dpk_g0;   // nibble index, BAM packing: even index = high nibble
+            atomicOr(&dpk_w[i >> 3], (info & 0xfu) << (((i >> 1) & 3u) * 8u + ((~i & 1u) << 2)));
+        }
     }
-    if (own) slot_rec[s] = my_off;
-    if (is_head && fits) heads[hbase + __popcll(hb & ((1ull << lane) - 1ull))] = my_off;
+    __syncthreads();
+    const uint32_t r0 = sh_r[0], r1 = sh_r[1];
+    EvWindow win{w0, wn, T0 >= 2 ? T0 : 0u, win_sinfo, win_sg, win_k0, reinterpret_cast<const uint8_t*>(dpk_w), dpk_g0, soff};
+    bool bad_tile = false;   // more candidates than the event words can index: fall back to k_tile3 for this tile
+    if (r0 != 0xffffffffu) {
+        if ((uint64_t)r1 - r0 + 1 > 2048) bad_tile = true;
+        for (uint64_t rb = r0; rb <= r1 && !bad_tile; rb += nb_max) {
+            const uint32_t nb = (uint32_t)((r1 - rb + 1 < nb_max) ? (r1 - rb + 1) : nb_max);
+            {
+                const uint4* dsrc = reinterpret_cast<const uint4*>(desc + rb * DESC_WORDS);
+                uint4* ddst = reinterpret_cast<uint4*>(dsc);
+                for (uint32_t i = tid; i < nb * (DESC_WORDS / 4); i += T) ddst[i] = dsrc[i];
+            }
+            const uint64_t sq0 = R.seq_off[rb] & ~15ull;
+            const uint64_t sq1 = R.seq_off[rb + nb - 1] + (((uint64_t)R.l_qseq[rb + nb - 1] + 1) >> 1);
+            const uint32_t sq_quads = (uint32_t)((sq1 - sq0 + 15) >> 4) + 1;   // +1: nib8_be may peek 4 bytes past a record
+            const uint32_t sq_fit = sq_quads * 4 <= nb_max * seq_w + 8 ? sq_quads : (nb_max * seq_w + 8) / 4;
+            if (sq_fit != sq_quads && tid == 0) atomicOr(&counters[CNT_ERR], ERR_BAD_RECORD);
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(R.seq + sq0);
+                uint4* dst = reinterpret_cast<uint4*>(seqst);
+                for (uint32_t i = tid; i < sq_fit; i += T) dst[i] = src[i];
+            }
+            const uint32_t sq0_lo = (uint32_t)sq0;
+            __syncthreads();
+            // ---- phase R: one lane per record
+            for (uint32_t k = tid; k < nb; k += T) {
+                const uint32_t* d = dsc + k * DESC_WORDS;
+                const uint32_t sf = d[0], sl = d[DESC_NEXT + 1];
+                if (sf <= sl && d[1] >= sf && sl >= w0 && sf < T1) {
+                    const uint32_t lo = sf > w0 ? sf : w0, hi = sl < T1 - 1 ? sl : T1 - 1;
+                    atomicAdd(&cover[lo - w0], 1u);
+                    atomicAdd(&cover[hi - w0 + 1], 0xffffffffu);
+                    Tile5Sink sink{&sh_r[2], ev_unsorted, evcnt, ev_max, w0, (uint32_t)(rb - r0) + k, &sh_r[3]};
+                    const uint8_t* sqb = reinterpret_cast<const uint8_t*>(seqst) + (d[3] - sq0_lo);
+                    if (ablate & 2u) continue;
+                    if (d[2] & DESC_CHAIN) { if (!(ablate & 1u)) record_events<true>(d, ovf_pool, sqb, win, sink); }   // rare: parts live in HBM
+                    else record_events<false>(d, nullptr, sqb, win, sink);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (sh_r[3]) bad_tile = true;
+    if (tid == 0) { atomicAdd(&counters[CNT_STAT_EVENTS], sh_r[2]); if (bad_tile) atomicAdd(&counters[CNT_STAT_FALLBACK], 1u); }   // statistics: events, fallback tiles
+    // ---- phase S0: coverage = inclusive scan of the difference array; event offsets = exclusive scan of the counts
+    {
+        // NWIN <= T (498 <= 512): one element per lane, Hillis-Steele in LDS
+        uint32_t cv = tid < NWIN ? cover[tid] : 0u, ec = tid < NWIN ? evcnt[tid] : 0u;
+        uint32_t* sc_a = ev_sorted;          // scratch (the sorted buffer is not in use yet): 2 * T words needed
+        uint32_t* sc_b = ev_sorted + T;
+        sc_a[tid] = cv;
+        sc_b[tid] = ec;
+        __syncthreads();
+        for (uint32_t o = 1; o < T; o <<= 1) {
+            const uint32_t a = tid >= o ? sc_a[tid - o] : 0u, b = tid >= o ? sc_b[tid - o] : 0u;
+            __syncthreads();
+            sc_a[tid] += a;
+            sc_b[tid] += b;
+            __syncthreads();
+        }
+        if (tid < NWIN) { cover[tid] = sc_a[tid]; evoff[tid] = sc_b[tid] - ec; }
+        __syncthreads();
+    }
+    const uint32_t ev_total = sh_r[2] < ev_max ? sh_r[2] : ev_max;
+    for (uint32_t i = tid; i < ev_total; i += T) {   // counting sort by slot (order inside a slot fixed below)
+        const uint32_t e = ev_unsorted[i];
+        const uint32_t k = e >> 23;
+        ev_sorted[evoff[k] + atomicAdd(&evcur[k], 1u)] = e & 0x7fffffu;
+    }
+    __syncthreads();
+    // ---- phase S1: one lane per slot
+    uint32_t* L = lists + wave * (E - 2) * 64;
+    const int64_t s64 = (int64_t)c * VOTE_CH - 2 + lane;
+    const bool valid = chunk_ok && s64 >= 0 && s64 < (int64_t)S;
+    const uint32_t s = (uint32_t)s64;
+    const uint32_t k = valid ? s - w0 : 0u;
+    const uint32_t info = valid ? win_sinfo[k] : 0u;
+    const uint32_t dsym = info & 0xfu;
+    const bool first = (info & SI_FIRST) != 0;
+    const uint32_t prev_dsym = (valid && k >= 1) ? (win_sinfo[k - 1] & 0xfu) : 0u;
+    VoteLane<E> vl;
+    vl.init(valid ? win_k0[k] : 0u);
+    uint32_t basemask = 1u << dsym, total = 0, nvotes = 0;
+    if (valid && !bad_tile && !(ablate & 4u)) {
+        const uint32_t ne = evcnt[k], eb = evoff[k];
+        // order this slot's events by record (insertion sort; a record votes a slot at most once), then tally
+        if (lane >= 2) {
+            for (uint32_t i = 1; i < ne; ++i) {
+                const uint32_t key = ev_sorted[eb + i];
+                uint32_t j = i;
+                while (j > 0 && ev_sorted[eb + j - 1] > key) { ev_sorted[eb + j] = ev_sorted[eb + j - 1]; --j; }
+                ev_sorted[eb + j] = key;
+            }
+            for (uint32_t i = 0; i < ne; ++i) {
+                const uint32_t ctx = ev_sorted[eb + i] & 0xfffu;
+                basemask |= 1u << (ctx & 0xfu);
+                vl.tally(ctx, L, lane);
+            }
+            const uint32_t cv = cover[k];
+            vl.c0 += cv - ne;   // every other covering vote carries the draft's own context
+            total = (1u + cv) & 0xffffu;
+            nvotes = cv;
+            bmask[k] = basemask;
+        } else if (wave == 0) {   // the tile's two left-context slots: only their base mask matters
+            for (uint32_t i = 0; i < ne; ++i) basemask |= 1u << (ev_sorted[eb + i] & 0xfu);
+            bmask[k] = basemask;
+        }
+    }
+    __syncthreads();
+    const bool single = __popc(basemask) == 1;
+    const bool prev_is_single = first || (valid && k >= 1 && __popc(bmask[k - 1]) == 1) || !valid || k == 0;
+    for (int o = 32; o > 0; o >>= 1) nvotes += __shfl_down(nvotes, o);
+    const bool ovf_any = chunk_ok && (bad_tile || __ballot(vl.ovf) != 0ull);
+    if (lane == 0 && nvotes && !ovf_any && chunk_ok) atomicAdd(votes, (unsigned long long)nvotes);
+    tile_epilogue<E, NW>(vl, L, tid, c, chunk_ok && !ovf_any, ovf_any, valid, s, info, dsym, first, prev_dsym, single, prev_is_single,
+                         total, slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci, flag_single);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -765,6 +1013,11 @@ void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint3
                                                chunk_last, counters);
 }
 
+static uint32_t ablate_env() {   // timing experiments only (results are wrong when set)
+    static const uint32_t v = getenv("NP1_ABLATE") ? (uint32_t)atoi(getenv("NP1_ABLATE")) : 0u;
+    return v;
+}
+
 int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc,
                  const uint32_t* ovf_pool, const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint32_t* redo_in,
                  uint32_t n_redo_in, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S, uint32_t max_lq,
@@ -773,7 +1026,7 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
                  unsigned long long* votes) {
     const uint32_t seq_w = (((max_lq + 1) >> 1) + 3) / 4 + 1;   // packed bases per record, in words (upper bound)
     const uint32_t per = (uint32_t)DESC_WORDS + seq_w;
-    static const uint32_t ablate = getenv("NP1_ABLATE") ? (uint32_t)atoi(getenv("NP1_ABLATE")) : 0u;   // timing experiments only
+    const uint32_t ablate = ablate_env();
 #define NP1_TILE3(EE, NWW, BUDGET)                                                                                   \
     do {                                                                                                             \
         const uint32_t fixed = (uint32_t)(NWW) * (uint32_t)((EE)-2) * 64u + 8u + (uint32_t)DESC_WORDS;               \
@@ -801,6 +1054,39 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
     else if (level == 1) NP1_TILE3(64, 1, 13312u);
     else NP1_TILE3(160, 1, 24576u);
 #undef NP1_TILE3
+    return 0;
+}
+
+int launch_tile5(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool,
+                 const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info,
+                 const uint32_t* slot_g, uint32_t S, uint32_t max_lq, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool,
+                 uint32_t pool_cap, uint32_t* counters, uint32_t* heads, uint32_t heads_cap, uint32_t* redo_out, uint32_t redo_ci,
+                 uint32_t flag_single, unsigned long long* votes) {
+    constexpr int E5 = 8, NW5 = 8;
+    constexpr uint32_t NWIN = NW5 * VOTE_CH + 2;
+    const uint32_t seq_w = (((max_lq + 1) >> 1) + 3) / 4 + 2;
+    const uint32_t ev_max = 2048;
+    const uint32_t fixed = (uint32_t)NW5 * (E5 - 2) * 64u + (uint32_t)DESC_WORDS + 8u + NWIN * 6u + 3u + NWIN / 8 + 4 +
+                           (NWIN + 2) / 2 + 1 + ((NWIN + 7) & ~3u) / 4 + 2 * ev_max + 16;
+    const uint32_t per = (uint32_t)DESC_WORDS + seq_w;
+    const uint32_t budget = 20352u;   // 79.5 KiB: two workgroups per CU
+    if (fixed + per > 40960u - 64u) return -1;
+    uint32_t nb_max = budget > fixed + per ? (budget - fixed) / per : 1u;
+    if (nb_max > 512u) nb_max = 512u;
+    if (nb_max < 1u) nb_max = 1u;
+    const uint32_t bytes = (fixed + nb_max * per) * 4u;
+    if (bytes > 160u * 1024u - 256u) return -1;
+    const uint32_t items = (n_chunks + NW5 - 1) / NW5;
+    if (items == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile5<E5, NW5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 256);
+        attr_set = true;
+    }
+    k_tile5<E5, NW5><<<items, NW5 * 64, bytes, st>>>(R, soff, desc, ovf_pool, chunk_first, chunk_last, n_chunks, slot_info, slot_g, S,
+                                                      seq_w, nb_max, ev_max, slot_res, slot_rec, pool, pool_cap, counters, heads,
+                                                      heads_cap, redo_out, redo_ci, flag_single, votes, ablate_env());
     return 0;
 }
 

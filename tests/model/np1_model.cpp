@@ -8,12 +8,14 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/nextpolish1.h"
 #include "../../nextpolish_amd/csrc/np1_core.h"
 #include "../../nextpolish_amd/csrc/np1_desc.h"
 #include "../../nextpolish_amd/csrc/np1_kmer.h"
+#include "../../nextpolish_amd/csrc/np1_events.h"
 
 using namespace np1k;
 
@@ -183,6 +185,108 @@ bool vote_chunk_desc(uint32_t c, const std::vector<uint32_t>& desc, const std::v
     }
     return true;
 }
+// event sequence (k_desc + k_tile5): agreeing votes are counted through the coverage, disagreeing ones as events
+struct ModelEvSink {
+    std::vector<std::vector<uint32_t>>* per_slot;   // window-relative
+    uint32_t w0;
+    void event(uint32_t slot, uint32_t ctx) { (*per_slot)[slot - w0].push_back(ctx); }
+};
+
+template <int E>
+bool vote_chunk_events(uint32_t c, const std::vector<uint32_t>& desc, const std::vector<uint32_t>& ovf, const ReadsDev& R,
+                       const uint8_t* seq_padded, const std::vector<uint32_t>& soff, const std::vector<uint8_t>& slot_info,
+                       const std::vector<uint32_t>& slot_g, uint32_t S, const std::vector<uint32_t>& chunk_first,
+                       const std::vector<uint32_t>& chunk_last, std::vector<uint16_t>& slot_res, std::vector<uint32_t>& slot_rec,
+                       std::vector<uint32_t>& pool, std::vector<uint32_t>& heads, uint32_t flag_single) {
+    const int64_t first64 = (int64_t)c * VOTE_CH - 2;
+    const uint32_t w0 = first64 < 0 ? 0u : (uint32_t)first64;
+    const uint32_t wend = std::min<uint64_t>((uint64_t)c * VOTE_CH + VOTE_CH, S);   // exclusive
+    if (w0 >= wend) return true;
+    const uint32_t n = wend - w0;
+    // window arrays
+    std::vector<uint8_t> sinfo(n);
+    std::vector<uint32_t> sg(n);
+    std::vector<uint16_t> k0(n);
+    for (uint32_t k = 0; k < n; ++k) { sinfo[k] = slot_info[w0 + k]; sg[k] = slot_g[w0 + k]; }
+    for (uint32_t k = 0; k < n; ++k) {   // draft context in slot space, restarted at contig starts (contig.c:373-383)
+        uint32_t d0 = sinfo[k] & 0xf, d1 = 0, d2 = 0;
+        if (!(sinfo[k] & SI_FIRST)) {
+            const uint32_t s = w0 + k;
+            d1 = slot_info[s - 1] & 0xf;
+            if (!(slot_info[s - 1] & SI_FIRST)) d2 = slot_info[s - 2] & 0xf;
+        }
+        k0[k] = (uint16_t)(d2 << 8 | d1 << 4 | d0);
+    }
+    const uint32_t dpk_g0 = sg[0] & ~1u;
+    const uint32_t g_last = sg[n - 1];
+    std::vector<uint8_t> dpk((g_last - dpk_g0) / 2 + 8, 0);
+    for (uint32_t k = 0; k < n; ++k)
+        if (!(sinfo[k] & SI_INSERT)) {
+            const uint32_t i = sg[k] - dpk_g0;
+            dpk[i >> 1] |= (uint8_t)((sinfo[k] & 0xf) << ((~i & 1) << 2));
+        }
+    EvWindow w{w0, n, (uint32_t)std::max<int64_t>(first64 + 2, 0), sinfo.data(), sg.data(), k0.data(), dpk.data(), dpk_g0, soff.data()};
+    std::vector<std::vector<uint32_t>> events(n);
+    std::vector<uint32_t> cover(n, 0);
+    ModelEvSink sink{&events, w0};
+    const uint32_t r0 = chunk_first[c], r1 = chunk_last[c];
+    if (r0 != 0xffffffffu)
+        for (uint32_t r = r0; r <= r1; ++r) {
+            const uint32_t* d = desc.data() + (uint64_t)r * DESC_WORDS;
+            if (d[0] > d[DESC_NEXT + 1]) continue;
+            for (uint32_t k = 0; k < n; ++k) cover[k] += (w0 + k >= d[0] && w0 + k <= d[DESC_NEXT + 1]);
+            record_events<true>(d, ovf.data(), seq_padded + R.seq_off[r], w, sink);
+        }
+    // per-slot tally
+    std::vector<uint32_t> L((E - 2) * 64);
+    VoteLane<E> vl[64];
+    uint32_t basemask[64], total[64];
+    bool single[64], valid[64], first[64];
+    uint32_t dsym[64], info[64], sl[64], prev_dsym[64];
+    for (int l = 0; l < 64; ++l) {
+        const int64_t s64 = first64 + l;
+        valid[l] = s64 >= 0 && s64 < (int64_t)S;
+        sl[l] = (uint32_t)s64;
+        info[l] = valid[l] ? slot_info[sl[l]] : 0u;
+        dsym[l] = info[l] & 0xf;
+        first[l] = (info[l] & SI_FIRST) != 0;
+        prev_dsym[l] = (l >= 1) ? (info[l - 1] & 0xf) : 0;
+        basemask[l] = 1u << dsym[l];
+        total[l] = 0;
+        if (!valid[l]) { vl[l].init(0); continue; }
+        const uint32_t k = sl[l] - w0;
+        vl[l].init(k0[k]);
+        for (uint32_t ctx : events[k]) {
+            basemask[l] |= 1u << (ctx & 0xf);
+            if (l >= 2) vl[l].tally(ctx, L.data(), l);
+        }
+        vl[l].c0 += cover[k] - (uint32_t)events[k].size();   // every other covering vote is the draft's own context
+        total[l] = (1u + cover[k]) & 0xffffu;
+    }
+    for (int l = 0; l < 64; ++l)
+        if (vl[l].ovf) return false;
+    for (int l = 0; l < 64; ++l) single[l] = __builtin_popcount(basemask[l]) == 1;
+    for (int l = 2; l < 64; ++l) {
+        if (!valid[l]) continue;
+        bool prev_is_single = first[l] || single[l - 1];
+        bool is_head = !single[l] && prev_is_single;
+        bool need_rec = !single[l] || !prev_is_single;
+        uint32_t res = 0xffu;
+        if (single[l]) res = dsym[l] | (((total[l] == 1 ? 1u : 0u) | flag_single) << 8);
+        slot_res[sl[l]] = (uint16_t)res;
+        uint32_t my_off = 0xffffffffu;
+        if (need_rec) {
+            my_off = (uint32_t)pool.size();
+            pool.resize(pool.size() + vl[l].n + REC_FIXED_WORDS, 0xdeadbeefu);
+            uint32_t hdr = (single[l] ? REC_SINGLE : 0u) | ((info[l] & SI_LAST) ? REC_CTG_LAST : 0u) |
+                           (first[l] ? REC_CTG_FIRST : 0u) | (prev_dsym[l] << 4);
+            vl[l].write_record(pool.data() + my_off, sl[l], total[l], hdr, L.data(), l);
+        }
+        slot_rec[sl[l]] = my_off;
+        if (is_head) heads.push_back(my_off);
+    }
+    return true;
+}
 }  // namespace
 
 extern "C" {
@@ -238,7 +342,14 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
             }
         }
         if (stats) stats[3] = counters[CNT_OVFDESC];
-        for (uint32_t c = 0; c < n_chunks; ++c) {
+        std::vector<uint8_t> seq_padded((size_t)v->seq_len + 16, 0);
+        if (v->seq_len) memcpy(seq_padded.data(), v->seq, (size_t)v->seq_len);
+        for (uint32_t c = 0; np1m_fused == 2 && c < n_chunks; ++c) {
+            if (vote_chunk_events<8>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
+            if (vote_chunk_events<64>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
+            if (!vote_chunk_events<160>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) return -3;
+        }
+        for (uint32_t c = 0; np1m_fused == 1 && c < n_chunks; ++c) {
             if (vote_chunk_desc<8>(c, desc, ovf, R, soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
             ++escal;
             if (vote_chunk_desc<64>(c, desc, ovf, R, soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;

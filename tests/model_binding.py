@@ -25,7 +25,7 @@ def lib():
 def score_chain(stream, cfg=None, want_stats=False, fused=False):
     """fused=False: staged launch sequence (symbol rows); fused=True: descriptor-based sequence (k_desc + k_tile3)."""
     cfg = cfg or nat.default_config()
-    C.c_int.in_dll(lib(), "np1m_fused").value = 1 if fused else 0
+    C.c_int.in_dll(lib(), "np1m_fused").value = int(fused)   # 0 staged, 1 descriptors (k_tile3), 2 events (k_tile5)
     out = C.c_void_p()
     bounds = (C.c_uint32 * (stream.n_contigs + 1))()
     stats = (C.c_uint64 * 4)()
