@@ -74,7 +74,7 @@ struct np1_batch {
     // inputs
     DevBuf draft, ctg_off, pos, ctg, flag, ncig, lq, cigoff, seqoff, cigar, seq;
     // work
-    DevBuf desc, ovf_desc, slot_g;
+    DevBuf desc, ovf_desc, slot_g, dbg;
     // kmer_count inputs (uploaded only when the stream carries qualities) and work buffers
     DevBuf mapq, isize, qualoff, qual, read_begin;
     DevBuf kc_level, kc_endpos, kc_code, kc_flag, kc_fpos, kc_flagged, kc_work, kc_nd_ctg, kc_nd_se, kc_kr_ctg, kc_kr_se, kc_cnt,
@@ -257,17 +257,17 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     if (b->qs.ensure(4 * nn) || b->qe.ensure(4 * nn) || b->span.ensure(4 * nn) || b->rbase.ensure(4 * nn) ||
         b->capb.ensure(4 * nn) || b->rowoff.ensure(8 * (nn + 1)) || b->meta.ensure(16 * nn) ||
         b->ins.ensure(4 * (G + 1)) || b->soff.ensure(4 * (G + 2)) || b->counters.ensure(4 * CNT_WORDS) ||
-        b->totals.ensure(8 * 8) || b->bounds.ensure(4 * ((size_t)nc + 1)) ||
+        b->totals.ensure(16 * 8) || b->bounds.ensure(4 * ((size_t)nc + 1)) ||
         b->scan_tmp.ensure(8 * (scan_tmp_words(G + G / 8 + 1024) + scan_tmp_words(nn))))
         return -1;
-    uint64_t* totals = b->totals.as<uint64_t>();   // [0] slots, [1] row bytes, [2] out chars, [3] votes
+    uint64_t* totals = b->totals.as<uint64_t>();   // [0] slots, [1] row bytes, [2] out chars, [3] votes (staged), [8..15] vote shards (fused)
     uint32_t* counters = b->counters.as<uint32_t>();
     uint64_t* scan_tmp = b->scan_tmp.as<uint64_t>();
 
     // ---- stage 0: prep
     HIPCHK(hipMemsetAsync(b->ins.p, 0, 4 * (G + 1), q));
     HIPCHK(hipMemsetAsync(b->counters.p, 0, 4 * CNT_WORDS, q));
-    HIPCHK(hipMemsetAsync(b->totals.p, 0, 64, q));
+    HIPCHK(hipMemsetAsync(b->totals.p, 0, 128, q));
     t0(0);
     launch_prep(q, R, n, ctg_off, cfg->trim_len_edge, b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->span.as<int32_t>(),
                 b->ins.as<uint32_t>(), counters);
@@ -386,7 +386,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
         // ---- stage 5 (fused): votes through LDS (+ escalation for crowded slots, + pool growth)
         for (int attempt = 0;; ++attempt) {
             uint32_t pool_cap = (uint32_t)std::min<size_t>(b->pool.cap / 4, 0xfffffff0u);
-            unsigned long long* votes = reinterpret_cast<unsigned long long*>(&totals[3]);
+            unsigned long long* votes = reinterpret_cast<unsigned long long*>(&totals[8]);   // POOL_SHARDS words
             auto tile = [&](int level, const uint32_t* redo_in, uint32_t n_redo, uint32_t* redo_out, uint32_t redo_ci) {
                 return launch_tile3(q, level, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
                                     b->chunk_first.as<uint32_t>(),
@@ -396,17 +396,40 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                                     b->heads.as<uint32_t>(), (uint32_t)std::min<size_t>(b->heads.cap / 4, 0xfffffff0u), redo_out,
                                     redo_ci, flag_single, votes);
             };
-            HIPCHK(hipMemsetAsync(&totals[3], 0, 8, q));
+            HIPCHK(hipMemsetAsync(&totals[8], 0, 8 * POOL_SHARDS, q));
             t0(5);
-            static const bool use_tile3 = !(getenv("NP1_TILE") && atoi(getenv("NP1_TILE")) == 5);   // NP1_TILE=5: event kernel (exact, slower so far)
-            const int rc5 = use_tile3
-                ? tile(0, nullptr, 0, b->redo.as<uint32_t>(), CNT_REDO)
-                : launch_tile5(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
-                               b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(),
-                               b->slot_g.as<uint32_t>(), S, b->max_lq, b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(),
-                               b->pool.as<uint32_t>(), pool_cap, counters, b->heads.as<uint32_t>(),
-                               (uint32_t)std::min<size_t>(b->heads.cap / 4, 0xfffffff0u), b->redo.as<uint32_t>(), CNT_REDO,
-                               flag_single, votes);
+            static const int tile_kind = getenv("NP1_TILE") ? atoi(getenv("NP1_TILE")) : 3;   // 3: per-vote kernel; 5, 6: event kernels
+            static const bool phase_timing = getenv("NP1_PHASE_TIMING") != nullptr;            // k_tile6 phase cycles to stderr
+            const uint32_t heads_cap5 = (uint32_t)std::min<size_t>(b->heads.cap / 4, 0xfffffff0u);
+            unsigned long long* dbg = nullptr;
+            if (phase_timing && tile_kind == 6) {
+                if (b->dbg.ensure(64)) return -1;
+                dbg = b->dbg.as<unsigned long long>();
+                HIPCHK(hipMemsetAsync(dbg, 0, 64, q));
+            }
+            int rc5;
+            if (tile_kind == 6)
+                rc5 = launch_tile6(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
+                                   b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(),
+                                   b->slot_g.as<uint32_t>(), S, b->max_lq, b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(),
+                                   b->pool.as<uint32_t>(), pool_cap, counters, b->heads.as<uint32_t>(), heads_cap5,
+                                   b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes, dbg);
+            else if (tile_kind == 5)
+                rc5 = launch_tile5(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
+                                   b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(),
+                                   b->slot_g.as<uint32_t>(), S, b->max_lq, b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(),
+                                   b->pool.as<uint32_t>(), pool_cap, counters, b->heads.as<uint32_t>(), heads_cap5,
+                                   b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes);
+            else
+                rc5 = tile(0, nullptr, 0, b->redo.as<uint32_t>(), CNT_REDO);
+            if (dbg) {
+                unsigned long long h[8];
+                HIPCHK(hipMemcpyAsync(h, dbg, 64, hipMemcpyDeviceToHost, q));
+                HIPCHK(hipStreamSynchronize(q));
+                const double n = h[7] ? (double)h[7] : 1.0;
+                fprintf(stderr, "[k_tile6 cycles/tile] setup %.0f  records %.0f (clean %.0f, exact %.0f)  sort %.0f  tally %.0f  epilogue %.0f  tiles %llu\n",
+                        h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n, h[7]);
+            }
             if (rc5 != 0) {
                 np1_set_error("records are too long for the LDS-staged path (long reads belong to nextpolish2)");
                 return -1;
@@ -466,9 +489,13 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     t1(7);
     b->h_bounds.resize((size_t)nc + 1);
     HIPCHK(hipMemcpyAsync(b->h_bounds.data(), b->bounds.p, 4 * ((size_t)nc + 1), hipMemcpyDeviceToHost, q));
-    HIPCHK(hipMemcpyAsync(&b->votes, &totals[3], 8, hipMemcpyDeviceToHost, q));
+    uint64_t h_votes[1 + POOL_SHARDS];
+    HIPCHK(hipMemcpyAsync(&h_votes[0], &totals[3], 8, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipMemcpyAsync(&h_votes[1], &totals[8], 8 * POOL_SHARDS, hipMemcpyDeviceToHost, q));
     HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
     HIPCHK(hipStreamSynchronize(q));
+    b->votes = 0;
+    for (uint32_t i = 0; i < 1 + POOL_SHARDS; ++i) b->votes += h_votes[i];
     if (hc[CNT_ERR] & ERR_DP_INCONSISTENT) { np1_set_error("inconsistent pileup state in the chain DP"); return -1; }
     memcpy(b->last_counters, hc, sizeof(hc));
     b->votes += S;   // the draft votes once per slot

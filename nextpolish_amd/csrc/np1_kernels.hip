@@ -311,9 +311,11 @@ __device__ __forceinline__ void tile_epilogue(const VoteLane<E>& vl, const uint3
                                               uint16_t* __restrict__ slot_res, uint32_t* __restrict__ slot_rec,
                                               uint32_t* __restrict__ pool, uint32_t pool_cap, uint32_t* __restrict__ counters,
                                               uint32_t* __restrict__ heads, uint32_t heads_cap, uint32_t* __restrict__ redo_out,
-                                              uint32_t redo_ci, uint32_t flag_single) {
-    __shared__ uint32_t sh_e[2 * NW + 4];
+                                              uint32_t redo_ci, uint32_t flag_single, uint32_t nvotes_wave,
+                                              unsigned long long* __restrict__ votes) {
+    __shared__ uint32_t sh_e[3 * NW + 4];
     const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) sh_e[2 * NW + 2 + wave] = live ? nvotes_wave : 0u;   // vote statistic: one atomic per workgroup, sharded
     if (redo && lane == 0) {   // redo this chunk with a roomier instantiation
         if (redo_out) redo_out[atomicAdd(&counters[redo_ci], 1u)] = c;
         else atomicOr(&counters[CNT_ERR], ERR_CTX_OVERFLOW);
@@ -337,9 +339,10 @@ __device__ __forceinline__ void tile_epilogue(const VoteLane<E>& vl, const uint3
     if (lane == 0) sh_e[NW + wave] = (uint32_t)__popcll(hb);
     __syncthreads();
     if (tid == 0) {
-        uint32_t wsum = 0, hsum = 0;
-        for (int w = 0; w < NW; ++w) { wsum += sh_e[w]; hsum += sh_e[NW + w]; }
+        uint32_t wsum = 0, hsum = 0, vsum = 0;
+        for (int w = 0; w < NW; ++w) { wsum += sh_e[w]; hsum += sh_e[NW + w]; vsum += sh_e[2 * NW + 2 + w]; }
         const uint32_t shard = blockIdx.x & (POOL_SHARDS - 1);
+        if (vsum) atomicAdd(&votes[shard], (unsigned long long)vsum);
         const uint32_t pregion = pool_cap / POOL_SHARDS, hregion = heads_cap / POOL_SHARDS;
         uint32_t pbase = 0xffffffffu, hbase = 0;
         if (wsum) {
@@ -562,13 +565,12 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
     }
     for (int o = 32; o > 0; o >>= 1) nvotes += __shfl_down(nvotes, o);
     const bool ovf_any = chunk_ok && __ballot(vl.ovf) != 0ull;
-    if (lane == 0 && nvotes && !ovf_any && chunk_ok) atomicAdd(votes, (unsigned long long)nvotes);
     const bool single = __popc(basemask) == 1;
     const uint32_t psingle = wave_shr1((uint32_t)single);   // every lane must execute the DPP move: keep it out of the || below
     const bool prev_is_single = first || psingle != 0;
     tile_epilogue<E, NW>(vl, L, tid, c, chunk_ok && !ovf_any, ovf_any, valid, s, info, dsym, first, prev_dsym, single, prev_is_single,
                          vl.total(L, lane), slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci,
-                         flag_single);
+                         flag_single, nvotes, votes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -800,9 +802,375 @@ __global__ __launch_bounds__(NW * 64) void k_tile5(ReadsDev R, const uint32_t* _
     const bool prev_is_single = first || (valid && k >= 1 && __popc(bmask[k - 1]) == 1) || !valid || k == 0;
     for (int o = 32; o > 0; o >>= 1) nvotes += __shfl_down(nvotes, o);
     const bool ovf_any = chunk_ok && (bad_tile || __ballot(vl.ovf) != 0ull);
-    if (lane == 0 && nvotes && !ovf_any && chunk_ok) atomicAdd(votes, (unsigned long long)nvotes);
     tile_epilogue<E, NW>(vl, L, tid, c, chunk_ok && !ovf_any, ovf_any, valid, s, info, dsym, first, prev_dsym, single, prev_is_single,
-                         total, slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci, flag_single);
+                         total, slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci, flag_single, nvotes, votes);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tile6: the event form with independent work items (np1_events.h, group form).  k_tile5 walks each record
+// sequentially in one lane, which leaves the workgroup waiting on LDS latency chains; here the unit of work is one
+// (record, 8-slot group) pair, ~3000 per tile, spread over all 512 lanes:
+//   phase C  clean test per item: ten packed bases of the record XOR ten packed draft symbols (three aligned LDS
+//            words each); a clean item contributes nothing but the record's two start events
+//   phase X  dirty items (mismatch, indel, insertion column, chained record: ~15 %) go through an LDS queue and are
+//            evaluated exactly, ten lanes per item, contexts from the neighbouring lanes (DPP)
+//   phase S  coverage scan, counting sort of the events by slot, rank by record inside a slot (= first-seen order),
+//            one lane per slot tallies its few events; count(k0) = 1 + coverage - #events
+struct RegSink2 {   // the (at most two) start events of a clean item, kept in registers
+    uint32_t n, w0, rec_local, e0, e1;
+    __device__ __forceinline__ void event(uint32_t slot, uint32_t ctx) {
+        const uint32_t word = (slot - w0) << 23 | rec_local << 12 | (ctx & 0xfffu);
+        if (n == 0) e0 = word; else e1 = word;
+        ++n;
+    }
+};
+
+// wave-aggregated append of one event per flagged lane (one LDS atomic per wave instead of one per event)
+__device__ __forceinline__ void ev_push(bool has, uint32_t word, uint32_t* ev_total, uint32_t* ev_buf, uint32_t* evcnt,
+                                        uint32_t ev_max, uint32_t* overflow, int lane) {
+    const unsigned long long m = __ballot(has);
+    if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(ev_total, (uint32_t)__popcll(m));
+        base = __shfl(base, 0);
+        if (has) {
+            const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (idx < ev_max) {
+                ev_buf[idx] = word;
+                atomicAdd(&evcnt[word >> 23], 1u);
+            } else {
+                *overflow = 1u;
+            }
+        }
+    }
+}
+
+template <int E, int NW>
+__global__ __launch_bounds__(NW * 64) void k_tile6(ReadsDev R, const uint32_t* __restrict__ soff,
+                                                   const uint32_t* __restrict__ desc,
+                                                   const uint32_t* __restrict__ ovf_pool,
+                                                   const uint32_t* __restrict__ chunk_first,
+                                                   const uint32_t* __restrict__ chunk_last, uint32_t n_chunks,
+                                                   const uint8_t* __restrict__ slot_info,
+                                                   const uint32_t* __restrict__ slot_g, uint32_t S, uint32_t seq_w,
+                                                   uint32_t nb_max, uint32_t ev_max, uint32_t it_max,
+                                                   uint16_t* __restrict__ slot_res, uint32_t* __restrict__ slot_rec,
+                                                   uint32_t* __restrict__ pool, uint32_t pool_cap,
+                                                   uint32_t* __restrict__ counters, uint32_t* __restrict__ heads,
+                                                   uint32_t heads_cap, uint32_t* __restrict__ redo_out, uint32_t redo_ci,
+                                                   uint32_t flag_single, unsigned long long* __restrict__ votes,
+                                                   uint32_t ablate, unsigned long long* __restrict__ dbg) {
+    constexpr uint32_t NWIN = NW * VOTE_CH + 2;
+    constexpr uint32_t NGRP = (NWIN + EV_G - 1) / EV_G;
+    constexpr uint32_t T = NW * 64;
+    static_assert(NWIN <= T && NGRP <= 64, "one lane per window slot; group index in 6 bits");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ __attribute__((aligned(16))) uint32_t sh_r[8];   // r0, r1, ev_total, overflow, dirty count
+    __shared__ uint32_t sh_w[2 * NW];
+    uint32_t* lists = lds;                                   // NW * (E-2) * 64
+    uint32_t* dsc = lists + NW * (E - 2) * 64;               // (nb_max + 1) * DESC_WORDS
+    uint32_t* seqst = dsc + (nb_max + 1) * DESC_WORDS;       // nb_max * seq_w + 8
+    uint32_t* win_sg = seqst + nb_max * seq_w + 8;           // NWIN
+    uint32_t* cover = win_sg + NWIN;                         // NWIN + 1 : difference array, then coverage
+    uint32_t* evcnt = cover + NWIN + 1;                      // NWIN
+    uint32_t* evoff = evcnt + NWIN;                          // NWIN + 1
+    uint32_t* bmask = evoff + NWIN + 1;                      // NWIN : base mask per slot
+    uint32_t* dpk_w = bmask + NWIN;                          // NWIN / 8 + 4 words : packed draft symbols
+    uint16_t* win_k0 = reinterpret_cast<uint16_t*>(dpk_w + NWIN / 8 + 4);   // NWIN (+pad)
+    uint8_t* win_sinfo = reinterpret_cast<uint8_t*>(win_k0 + NWIN + 2);     // NWIN (+pad)
+    uint16_t* gins = reinterpret_cast<uint16_t*>(win_sinfo + ((NWIN + 7) & ~3u));   // 64
+    uint16_t* dirtyq = gins + 64;                            // it_max
+    uint32_t* ev_a = reinterpret_cast<uint32_t*>(dirtyq + it_max);   // ev_max : events as produced, later ordered
+    uint32_t* ev_b = ev_a + ev_max;                          // ev_max : item list (phase C/X), then events by slot
+    uint16_t* items = reinterpret_cast<uint16_t*>(ev_b);     // it_max <= 2 * ev_max
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    long long tm[7] = {0, 0, 0, 0, 0, 0, 0};   // phase timestamps (diagnostics, dbg != nullptr)
+    long long tc = 0, tx = 0;
+    if (dbg) tm[0] = clock64();
+    const uint32_t cbase = blockIdx.x * NW;
+    if (cbase >= n_chunks || (uint64_t)cbase * VOTE_CH >= S) return;   // (the chunk count is rounded up by one: nothing to own here)
+    const uint32_t c = cbase + wave;
+    const bool chunk_ok = c < n_chunks;
+    const uint32_t T0 = cbase * VOTE_CH;
+    const uint32_t w0 = T0 >= 2 ? T0 - 2 : 0u;
+    const uint32_t T1 = (uint64_t)T0 + NW * VOTE_CH < S ? T0 + NW * VOTE_CH : S;   // exclusive
+    const uint32_t wn = T1 - w0;
+    if (tid == 0) {
+        uint32_t r0 = 0xffffffffu, r1 = 0;
+        for (int w = 0; w < NW; ++w) {
+            uint32_t cc = cbase + w;
+            if (cc < n_chunks) {
+                uint32_t f = chunk_first[cc];
+                if (f != 0xffffffffu) {
+                    if (f < r0) r0 = f;
+                    uint32_t l = chunk_last[cc];
+                    if (l > r1) r1 = l;
+                }
+            }
+        }
+        sh_r[0] = r0;
+        sh_r[1] = r1;
+        sh_r[2] = 0;
+        sh_r[3] = 0;
+    }
+    // ---- window arrays
+    for (uint32_t k = tid; k < NWIN + 1; k += T) {
+        cover[k] = 0;
+        if (k < NWIN) evcnt[k] = 0;
+    }
+    for (uint32_t k = tid; k < NWIN / 8 + 4; k += T) dpk_w[k] = 0;
+    for (uint32_t k = tid; k < wn; k += T) {
+        win_sinfo[k] = slot_info[w0 + k];
+        win_sg[k] = slot_g[w0 + k];
+    }
+    __syncthreads();
+    const uint32_t dpk_g0 = win_sg[0] & ~1u;
+    for (uint32_t k = tid; k < wn; k += T) {
+        const uint32_t info = win_sinfo[k];
+        uint32_t d1 = 0, d2 = 0;
+        if (!(info & SI_FIRST) && k >= 1) {
+            d1 = win_sinfo[k - 1] & 0xfu;
+            if (!(win_sinfo[k - 1] & SI_FIRST) && k >= 2) d2 = win_sinfo[k - 2] & 0xfu;
+        }
+        win_k0[k] = (uint16_t)(d2 << 8 | d1 << 4 | (info & 0xfu));   // valid for every owned slot (k >= 2, or contig starts)
+        if (!(info & SI_INSERT)) {
+            const uint32_t i = win_sg[k] - dpk_g0;   // nibble index, BAM packing: even index = high nibble
+            atomicOr(&dpk_w[i >> 3], (info & 0xfu) << (((i >> 1) & 3u) * 8u + ((~i & 1u) << 2)));
+        }
+    }
+    if (tid < 64) gins[tid] = (uint16_t)group_ins_mask(win_sinfo, wn, (uint32_t)tid);
+    __syncthreads();
+    if (dbg) tm[1] = clock64();
+    const uint32_t r0 = sh_r[0], r1 = sh_r[1];
+    const EvWindow win{w0, wn, T0 >= 2 ? T0 : 0u, win_sinfo, win_sg, win_k0, reinterpret_cast<const uint8_t*>(dpk_w), dpk_g0, soff};
+    const GroupWin gw{gins};
+    bool bad_tile = false;   // more candidates than the event words can index: fall back to k_tile3 for this tile
+    if (r0 != 0xffffffffu) {
+        if ((uint64_t)r1 - r0 + 1 > 2048) bad_tile = true;
+        for (uint64_t rb = r0; rb <= r1 && !bad_tile; rb += nb_max) {
+            const uint32_t nb = (uint32_t)((r1 - rb + 1 < nb_max) ? (r1 - rb + 1) : nb_max);
+            {
+                const uint4* dsrc = reinterpret_cast<const uint4*>(desc + rb * DESC_WORDS);
+                uint4* ddst = reinterpret_cast<uint4*>(dsc);
+                for (uint32_t i = tid; i < nb * (DESC_WORDS / 4); i += T) ddst[i] = dsrc[i];
+            }
+            const uint64_t sq0 = R.seq_off[rb] & ~15ull;
+            const uint64_t sq1 = R.seq_off[rb + nb - 1] + (((uint64_t)R.l_qseq[rb + nb - 1] + 1) >> 1);
+            const uint32_t sq_quads = (uint32_t)((sq1 - sq0 + 15) >> 4) + 1;   // +1: the packed compare may peek past a record
+            const uint32_t sq_fit = sq_quads * 4 <= nb_max * seq_w + 8 ? sq_quads : (nb_max * seq_w + 8) / 4;
+            if (sq_fit != sq_quads && tid == 0) atomicOr(&counters[CNT_ERR], ERR_BAD_RECORD);
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(R.seq + sq0);
+                uint4* dst = reinterpret_cast<uint4*>(seqst);
+                for (uint32_t i = tid; i < sq_fit; i += T) dst[i] = src[i];
+            }
+            const uint32_t sq0_lo = (uint32_t)sq0;
+            __syncthreads();
+            // ---- one lane per record: coverage difference array, number of groups the record touches
+            uint32_t my_ng = 0, my_g0 = 0;
+            if ((uint32_t)tid < nb) {
+                uint32_t lo, hi;
+                bool sb;
+                if (record_window_range(dsc + tid * DESC_WORDS, win, &lo, &hi, &sb)) {
+                    atomicAdd(&cover[lo], 1u);
+                    atomicAdd(&cover[hi + 1], 0xffffffffu);
+                    my_g0 = lo / EV_G;
+                    my_ng = hi / EV_G - my_g0 + 1;
+                }
+            }
+            uint32_t incl = my_ng;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) sh_w[wave] = incl;
+            __syncthreads();
+            uint32_t my_off = incl - my_ng, total = 0;
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t v = sh_w[w];
+                if (w < wave) my_off += v;
+                total += v;
+            }
+            for (uint32_t round0 = 0; round0 < total; round0 += it_max) {
+                for (uint32_t t = 0; t < my_ng; ++t) {
+                    const uint32_t pos = my_off + t - round0;
+                    if (pos < it_max) items[pos] = (uint16_t)((uint32_t)tid << 6 | (my_g0 + t));
+                }
+                if (tid == 0) sh_r[4] = 0;
+                __syncthreads();
+                const uint32_t cnt = total - round0 < it_max ? total - round0 : it_max;
+                long long ta = 0;
+                if (dbg) ta = clock64();
+                // ---- phase C: clean test per item
+                for (uint32_t base = 0; base < cnt; base += T) {
+                    const uint32_t it = base + tid;
+                    bool dirty = false;
+                    uint32_t code = 0;
+                    RegSink2 rs{0, w0, 0, 0, 0};
+                    if (it < cnt && !(ablate & 2u)) {
+                        code = items[it];
+                        const uint32_t i = code >> 6, j = code & 63u;
+                        const uint32_t* d = dsc + i * DESC_WORDS;
+                        uint32_t lo, hi;
+                        bool sb;
+                        (void)record_window_range(d, win, &lo, &hi, &sb);
+                        rs.rec_local = (uint32_t)(rb - r0) + i;
+                        if (d[2] & DESC_CHAIN) dirty = true;
+                        else {
+                            const uint8_t* sqb = reinterpret_cast<const uint8_t*>(seqst) + (d[3] - sq0_lo);
+                            dirty = !group_clean(d, sqb, win, gw, j, lo, hi, sb, rs);
+                        }
+                    }
+                    const unsigned long long dm = __ballot(dirty);
+                    if (dm) {
+                        uint32_t qb = 0;
+                        if (lane == 0) qb = atomicAdd(&sh_r[4], (uint32_t)__popcll(dm));
+                        qb = __shfl(qb, 0);
+                        if (dirty) dirtyq[qb + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint16_t)code;
+                    }
+                    ev_push(rs.n >= 1, rs.e0, &sh_r[2], ev_a, evcnt, ev_max, &sh_r[3], lane);
+                    ev_push(rs.n >= 2, rs.e1, &sh_r[2], ev_a, evcnt, ev_max, &sh_r[3], lane);
+                }
+                __syncthreads();
+                if (dbg) { const long long tb = clock64(); tc += tb - ta; ta = tb; }
+                // ---- phase X: dirty items, ten lanes each (two context slots + the group)
+                const uint32_t nd = (ablate & 1u) ? 0u : sh_r[4];
+                const uint32_t e6 = (uint32_t)lane / EV_GL, t6 = (uint32_t)lane - e6 * EV_GL;
+                for (uint32_t base = 0; base < nd; base += NW * 6) {
+                    const uint32_t idx = base + (uint32_t)wave * 6 + e6;
+                    const bool active = lane < 60 && idx < nd;
+                    uint32_t sym = 0, k = 0, rec_local = 0;
+                    bool cov = false;
+                    if (active) {
+                        const uint32_t code = dirtyq[idx];
+                        const uint32_t i = code >> 6, j = code & 63u;
+                        const uint32_t* d = dsc + i * DESC_WORDS;
+                        uint32_t lo, hi;
+                        bool sb;
+                        (void)record_window_range(d, win, &lo, &hi, &sb);
+                        rec_local = (uint32_t)(rb - r0) + i;
+                        const int32_t kk = (int32_t)(EV_G * j) - 2 + (int32_t)t6;
+                        cov = kk >= (int32_t)lo && kk <= (int32_t)hi;
+                        if (cov) {
+                            k = (uint32_t)kk;
+                            const uint32_t s = w0 + k, info = win_sinfo[k], g = win_sg[k];
+                            const int32_t jj = (info & SI_INSERT) ? (int32_t)(s - soff[g]) - 1 : -1;
+                            const SeqLds sq{reinterpret_cast<const uint8_t*>(seqst) + (d[3] - sq0_lo)};
+                            if (s <= d[1]) {
+                                sym = desc_symbol(d, g, jj, sq);   // head part: LDS
+                            } else {                               // rare: overflow parts of a chained record live in HBM
+                                uint32_t nx = d[DESC_NEXT];
+                                while (nx) {
+                                    const uint32_t* part = ovf_pool + (uint64_t)(nx - 1) * DESC_WORDS;
+                                    if (s <= part[1]) {
+                                        if (s >= part[0]) sym = desc_symbol(part, g, jj, sq);
+                                        break;
+                                    }
+                                    nx = part[DESC_NEXT];
+                                }
+                            }
+                        }
+                    }
+                    const uint32_t p1 = wave_shr1(sym), p2 = wave_shr1(p1);
+                    const uint32_t ctx = p2 << 8 | p1 << 4 | sym;
+                    bool emit = false;
+                    uint32_t val = ctx;
+                    if (cov && t6 >= 2) {
+                        if (w0 + k >= win.own0) emit = ctx != win_k0[k];
+                        else { emit = sym != (uint32_t)(win_sinfo[k] & 0xfu); val = sym; }
+                    }
+                    ev_push(emit, k << 23 | rec_local << 12 | (val & 0xfffu), &sh_r[2], ev_a, evcnt, ev_max, &sh_r[3], lane);
+                }
+                __syncthreads();
+                if (dbg) tx += clock64() - ta;
+            }
+        }
+    }
+    if (dbg) tm[2] = clock64();
+    if (sh_r[3]) bad_tile = true;
+    if (tid == 0) { atomicAdd(&counters[CNT_STAT_EVENTS], sh_r[2]); if (bad_tile) atomicAdd(&counters[CNT_STAT_FALLBACK], 1u); }
+    // ---- phase S0: coverage = inclusive scan of the difference array; event offsets = exclusive scan of the counts
+    const uint32_t ev_total = sh_r[2] < ev_max ? sh_r[2] : ev_max;
+    {
+        const uint32_t cv = (uint32_t)tid < NWIN ? cover[tid] : 0u, ec = (uint32_t)tid < NWIN ? evcnt[tid] : 0u;
+        uint32_t ci = cv, ei = ec;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(ci, o), b = __shfl_up(ei, o);
+            if (lane >= o) { ci += a; ei += b; }
+        }
+        __syncthreads();   // (sh_w is free again)
+        if (lane == 63) { sh_w[wave] = ci; sh_w[NW + wave] = ei; }
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) { ci += sh_w[w]; ei += sh_w[NW + w]; }
+        if ((uint32_t)tid < NWIN) { cover[tid] = ci; evoff[tid] = ei - ec; evcnt[tid] = 0; }
+        if (tid == 0) evoff[NWIN] = ev_total;
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < ev_total; i += T) {   // counting sort by slot
+        const uint32_t e = ev_a[i];
+        const uint32_t k = e >> 23;
+        ev_b[evoff[k] + atomicAdd(&evcnt[k], 1u)] = e;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < ev_total; i += T) {   // order inside a slot by record = first-seen order (a record votes a slot once)
+        const uint32_t e = ev_b[i];
+        const uint32_t k = e >> 23, eb = evoff[k], ne = evcnt[k];
+        uint32_t rank = 0;
+        for (uint32_t x = 0; x < ne; ++x) rank += ev_b[eb + x] < e ? 1u : 0u;
+        ev_a[eb + rank] = e;
+    }
+    __syncthreads();
+    if (dbg) tm[3] = clock64();
+    // ---- phase S1: one lane per slot
+    uint32_t* L = lists + wave * (E - 2) * 64;
+    const int64_t s64 = (int64_t)c * VOTE_CH - 2 + lane;
+    const bool valid = chunk_ok && s64 >= 0 && s64 < (int64_t)S;
+    const uint32_t s = (uint32_t)s64;
+    const uint32_t k = valid ? s - w0 : 0u;
+    const uint32_t info = valid ? win_sinfo[k] : 0u;
+    const uint32_t dsym = info & 0xfu;
+    const bool first = (info & SI_FIRST) != 0;
+    const uint32_t prev_dsym = (valid && k >= 1) ? (win_sinfo[k - 1] & 0xfu) : 0u;
+    VoteLane<E> vl;
+    vl.init(valid ? win_k0[k] : 0u);
+    uint32_t basemask = 1u << dsym, total = 0, nvotes = 0;
+    if (valid && !bad_tile && !(ablate & 4u)) {
+        const uint32_t ne = evcnt[k], eb = evoff[k];
+        if (lane >= 2) {
+            for (uint32_t i = 0; i < ne; ++i) {
+                const uint32_t ctx = ev_a[eb + i] & 0xfffu;
+                basemask |= 1u << (ctx & 0xfu);
+                vl.tally(ctx, L, lane);
+            }
+            const uint32_t cv = cover[k];
+            vl.c0 += cv - ne;   // every other covering vote carries the draft's own context
+            total = (1u + cv) & 0xffffu;
+            nvotes = cv;
+            bmask[k] = basemask;
+        } else if (wave == 0) {   // the tile's two left-context slots: only their base mask matters
+            for (uint32_t i = 0; i < ne; ++i) basemask |= 1u << (ev_a[eb + i] & 0xfu);
+            bmask[k] = basemask;
+        }
+    }
+    __syncthreads();
+    if (dbg) tm[4] = clock64();
+    const bool single = __popc(basemask) == 1;
+    const bool prev_is_single = first || (valid && k >= 1 && __popc(bmask[k - 1]) == 1) || !valid || k == 0;
+    for (int o = 32; o > 0; o >>= 1) nvotes += __shfl_down(nvotes, o);
+    const bool ovf_any = chunk_ok && (bad_tile || __ballot(vl.ovf) != 0ull);
+    tile_epilogue<E, NW>(vl, L, tid, c, chunk_ok && !ovf_any, ovf_any, valid, s, info, dsym, first, prev_dsym, single, prev_is_single,
+                         total, slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci, flag_single, nvotes, votes);
+    if (dbg && tid == 0) {   // cycles: setup, record loop (of which clean tests, exact items), scans + sort, tally, epilogue; tiles
+        tm[5] = clock64();
+        atomicAdd(&dbg[0], (unsigned long long)(tm[1] - tm[0]));
+        atomicAdd(&dbg[1], (unsigned long long)(tm[2] - tm[1]));
+        atomicAdd(&dbg[2], (unsigned long long)tc);
+        atomicAdd(&dbg[3], (unsigned long long)tx);
+        atomicAdd(&dbg[4], (unsigned long long)(tm[3] - tm[2]));
+        atomicAdd(&dbg[5], (unsigned long long)(tm[4] - tm[3]));
+        atomicAdd(&dbg[6], (unsigned long long)(tm[5] - tm[4]));
+        atomicAdd(&dbg[7], 1ull);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1087,6 +1455,39 @@ int launch_tile5(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const 
     k_tile5<E5, NW5><<<items, NW5 * 64, bytes, st>>>(R, soff, desc, ovf_pool, chunk_first, chunk_last, n_chunks, slot_info, slot_g, S,
                                                       seq_w, nb_max, ev_max, slot_res, slot_rec, pool, pool_cap, counters, heads,
                                                       heads_cap, redo_out, redo_ci, flag_single, votes, ablate_env());
+    return 0;
+}
+
+int launch_tile6(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool,
+                 const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info,
+                 const uint32_t* slot_g, uint32_t S, uint32_t max_lq, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool,
+                 uint32_t pool_cap, uint32_t* counters, uint32_t* heads, uint32_t heads_cap, uint32_t* redo_out, uint32_t redo_ci,
+                 uint32_t flag_single, unsigned long long* votes, unsigned long long* dbg) {
+    constexpr int E6 = 8, NW6 = 8;
+    constexpr uint32_t NWIN = NW6 * VOTE_CH + 2;
+    const uint32_t seq_w = (((max_lq + 1) >> 1) + 3) / 4 + 2;
+    const uint32_t ev_max = 2048, it_max = 4096;   // it_max u16 item codes share the second event buffer
+    const uint32_t fixed = (uint32_t)NW6 * (E6 - 2) * 64u + (uint32_t)DESC_WORDS + 8u + NWIN * 5u + 2u + NWIN / 8 + 4 +
+                           (NWIN + 2) / 2 + 1 + ((NWIN + 7) & ~3u) / 4 + 32 + it_max / 2 + 2 * ev_max + 16;
+    const uint32_t per = (uint32_t)DESC_WORDS + seq_w;
+    const uint32_t budget = 20352u;   // 79.5 KiB: two workgroups per CU
+    if (fixed + per > 40960u - 64u) return -1;
+    uint32_t nb_max = budget > fixed + per ? (budget - fixed) / per : 1u;
+    if (nb_max > 512u) nb_max = 512u;
+    if (nb_max < 1u) nb_max = 1u;
+    const uint32_t bytes = (fixed + nb_max * per) * 4u;
+    if (bytes > 160u * 1024u - 256u) return -1;
+    const uint32_t items = (n_chunks + NW6 - 1) / NW6;
+    if (items == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile6<E6, NW6>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 256);
+        attr_set = true;
+    }
+    k_tile6<E6, NW6><<<items, NW6 * 64, bytes, st>>>(R, soff, desc, ovf_pool, chunk_first, chunk_last, n_chunks, slot_info, slot_g, S,
+                                                      seq_w, nb_max, ev_max, it_max, slot_res, slot_rec, pool, pool_cap, counters,
+                                                      heads, heads_cap, redo_out, redo_ci, flag_single, votes, ablate_env(), dbg);
     return 0;
 }
 

@@ -19,6 +19,7 @@
 
 using namespace np1k;
 
+extern "C" int np1m_fused;
 namespace {
 struct HostState {
     long long sc_[2][16];
@@ -226,6 +227,9 @@ bool vote_chunk_events(uint32_t c, const std::vector<uint32_t>& desc, const std:
             dpk[i >> 1] |= (uint8_t)((sinfo[k] & 0xf) << ((~i & 1) << 2));
         }
     EvWindow w{w0, n, (uint32_t)std::max<int64_t>(first64 + 2, 0), sinfo.data(), sg.data(), k0.data(), dpk.data(), dpk_g0, soff.data()};
+    std::vector<uint16_t> gins((n + EV_G - 1) / EV_G + 1);
+    for (uint32_t j = 0; j < gins.size(); ++j) gins[j] = (uint16_t)group_ins_mask(sinfo.data(), n, j);
+    const GroupWin gw{gins.data()};
     std::vector<std::vector<uint32_t>> events(n);
     std::vector<uint32_t> cover(n, 0);
     ModelEvSink sink{&events, w0};
@@ -235,7 +239,8 @@ bool vote_chunk_events(uint32_t c, const std::vector<uint32_t>& desc, const std:
             const uint32_t* d = desc.data() + (uint64_t)r * DESC_WORDS;
             if (d[0] > d[DESC_NEXT + 1]) continue;
             for (uint32_t k = 0; k < n; ++k) cover[k] += (w0 + k >= d[0] && w0 + k <= d[DESC_NEXT + 1]);
-            record_events<true>(d, ovf.data(), seq_padded + R.seq_off[r], w, sink);
+            if (np1m_fused == 3) record_groups(d, ovf.data(), seq_padded + R.seq_off[r], w, gw, sink);   // k_tile6's item form
+            else record_events<true>(d, ovf.data(), seq_padded + R.seq_off[r], w, sink);
         }
     // per-slot tally
     std::vector<uint32_t> L((E - 2) * 64);
@@ -290,7 +295,7 @@ bool vote_chunk_events(uint32_t c, const std::vector<uint32_t>& desc, const std:
 }  // namespace
 
 extern "C" {
-int np1m_fused = 0;   // 0: staged sequence (rows in memory), 1: fused sequence (descriptors)
+int np1m_fused = 0;   // 0: staged sequence (rows in memory), 1: descriptors (k_tile3), 2: events (k_tile5), 3: event groups (k_tile6)
 
 
 // Returns 0 on success; *out is malloc'd concatenation of the polished contigs, bounds[n_contigs+1].
@@ -344,7 +349,7 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
         if (stats) stats[3] = counters[CNT_OVFDESC];
         std::vector<uint8_t> seq_padded((size_t)v->seq_len + 16, 0);
         if (v->seq_len) memcpy(seq_padded.data(), v->seq, (size_t)v->seq_len);
-        for (uint32_t c = 0; np1m_fused == 2 && c < n_chunks; ++c) {
+        for (uint32_t c = 0; np1m_fused >= 2 && c < n_chunks; ++c) {
             if (vote_chunk_events<8>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
             if (vote_chunk_events<64>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
             if (!vote_chunk_events<160>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) return -3;

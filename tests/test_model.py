@@ -9,21 +9,21 @@ import model_binding as mb
 from fuzzgen import random_case
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2, 3])   # staged rows, descriptors (k_tile3), events (k_tile5), event groups (k_tile6)
 def test_model_micro_cases(fused):
     parts = 0
     for seed in range(250):
         contigs, reads = random_case(seed)
         st = nat.Stream.from_reads(contigs, reads)
         got, stats = mb.score_chain(st, fused=fused, want_stats=True)
-        parts += stats["escalations"] if fused else 0
+        parts += stats["escalations"] if fused == 1 else 0
         for i in range(st.n_contigs):
             assert got[i] == ob.score_chain(st, i), "seed %d contig %d fused=%s" % (seed, i, fused)
-    if fused:
+    if fused == 1:
         assert parts > 100   # the chained-descriptor path is really exercised
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2, 3])
 @pytest.mark.parametrize("seed", range(5))
 def test_model_synth(fused, seed):
     st = nat.Stream.synth([3000 + seed * 137, 900 + seed * 11, 200], depth=[5, 15, 30, 60, 120][seed % 5], seed=1000 + seed,
@@ -40,7 +40,7 @@ def test_model_parameters():
         cfg = nat.default_config()
         cfg.indel_balance_factor_sgs, cfg.min_count_ratio_skip, cfg.trim_len_edge = rate, ratio, trim
         ocfg = ob.default_config(indel_balance_factor_sgs=rate, min_count_ratio_skip=ratio, trim_len_edge=trim)
-        for fused in (False, True):
+        for fused in (0, 1, 2, 3):
             assert mb.score_chain(st, cfg, fused=fused)[0] == ob.score_chain(st, 0, ocfg)
 
 
