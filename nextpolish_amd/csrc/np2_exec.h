@@ -1,0 +1,60 @@
+// Window executor interface of the long-read path: the host pipeline (np2_pipeline.cpp) prepares one window's
+// records in merge order and hands them to an executor that runs alignment spans -> tags -> link graph -> chain DP
+// -> backtrace.  The product links the HIP executor (np2_exec_hip.hip); the tests' lockstep model links a host
+// executor that runs the same per-lane bodies (tests/model/np2_exec_host.cpp).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "np2_core.h"
+
+namespace np2 {
+
+struct ConsBase {   // consensus_base, ctg_cns.h:103-107
+    uint32_t pos;   // window-relative draft position
+    char qv;
+    char base;
+};
+
+struct WindowInput {
+    const char* contig_seq = nullptr;   // decoded contig (A/C/G/T), indexable by contig coordinate
+    int32_t s = 0, e = 0;               // window [s, e)
+    uint32_t gap_min_len = 3;           // 3 ONT, 5 otherwise (ctg_cns.c:3436-3442)
+    int read_type = np2k::READS_ONT;
+    // candidate records in merge order (the seed -- the window against itself -- is added by the executor)
+    std::vector<int32_t> pos;
+    std::vector<uint32_t> n_cigar;
+    std::vector<uint32_t> l_qseq;       // cal_l_qseq of the record (for the 0.9 aligned-fraction term of the coverage cap)
+    std::vector<uint32_t> aligned_q;    // rdp1.e - rdp1.s
+    std::vector<uint64_t> cigar_off, seq_off;
+    std::vector<uint32_t> cigar;
+    std::vector<uint8_t> seq;
+    size_t n_reads() const { return pos.size(); }
+};
+
+struct WindowOutput {
+    // per candidate record: kept (1) or dropped by the 500 bp / coverage-cap rules (0)
+    std::vector<uint8_t> kept;
+    uint32_t seq_count = 0;                       // seed + kept records (aligned_seq_count of the reference)
+    std::vector<np2k::ColStat> stat;              // e - s + 1 columns
+    // tag streams of the seed (index 0) and the kept records, in order: stream i = tags[tag_off[i] ..), window-relative
+    // start / exclusive end positions
+    std::vector<uint64_t> tag_off;
+    std::vector<uint32_t> aln_t_s, aln_t_e;
+    std::vector<uint8_t> tags;
+    std::vector<ConsBase> cons;                   // main-line consensus, window order (before the LQ stage)
+    bool bad_cigar = false;                       // a record carried an op the reference aborts on
+};
+
+class Exec {
+  public:
+    virtual ~Exec() {}
+    // false + *err on failure (never a silent fallback)
+    virtual bool run_window(const WindowInput& in, WindowOutput* out, std::string* err) = 0;
+};
+
+// provided by whichever executor is linked (HIP in the product library)
+Exec* make_exec(std::string* err);
+
+}  // namespace np2
