@@ -19,6 +19,7 @@ struct ConsBase {   // consensus_base, ctg_cns.h:103-107
 
 struct WindowInput {
     const char* contig_seq = nullptr;   // decoded contig (A/C/G/T), indexable by contig coordinate
+    uint64_t contig_serial = 0;         // changes whenever contig_seq holds a different contig (executors may cache the upload)
     int32_t s = 0, e = 0;               // window [s, e)
     uint32_t gap_min_len = 3;           // 3 ONT, 5 otherwise (ctg_cns.c:3436-3442)
     int read_type = np2k::READS_ONT;

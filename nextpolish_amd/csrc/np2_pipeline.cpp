@@ -482,6 +482,8 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
     long fra_map = 0, total_map = 0;
     np2::WindowInput in;
     np2::WindowOutput out;
+    static uint64_t contig_serial = 0;
+    in.contig_serial = ++contig_serial;
     while (e < (int32_t)ref->length) {
         e = s + b > (int32_t)ref->length ? (int32_t)ref->length : s + b;
         in.contig_seq = rfseq.data();

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Generates tests/golden/np2_golden.json: expected ctg_cns_core output of the COMPILED REFERENCE
+(oracle/_ref/nextpolish2.so, built by oracle/Makefile from /root/reference) for the cases in tests/np2_cases.py,
+plus known answers of the 2-bit codec and read_ref.  Run in the build container (needs oracle/_ref)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, ".."))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+import np2_cases  # noqa: E402
+import ref2_binding as rb  # noqa: E402
+
+
+def main():
+    L = rb.bind(rb.REF_SO)
+    out = {"cases": {}, "codec": []}
+    for cid, kw, rt in np2_cases.CASES:
+        fa, fofn, contigs = np2_cases.materialise(kw)
+        res = rb.polish(L, fa, fofn, read_type=rt)
+        out["cases"][cid] = {
+            "read_type": rt,
+            "draft_md5": {n: hashlib.md5(d.encode()).hexdigest() for n, d in contigs},
+            "expected": {n: res[n][0][0] for n, _ in contigs},
+            "pieces": {n: len(res[n]) for n, _ in contigs},
+        }
+    # codec known answers: pack then unpack through the reference (incl. the non-ACGT spill of bseq.c:91)
+    for s in ["ACGT", "AANAA", "GGNGG", "acgtn", "TTTTTTTTTTTTTTTTA", "NACGT", "ACGTACGTACGTACGTN", "RYKM", "A", "TU"]:
+        words = (C.c_uint32 * (len(s) // 16 + 1))()
+        L.seq2bit1(words, len(s), s.encode())
+        buf = C.create_string_buffer(len(s) + 1)
+        L.bit2seq1(words, len(s), buf)
+        out["codec"].append({"seq": s, "words": [int(w) for w in words][: (len(s) + 15) // 16], "round_trip": buf.value.decode()})
+    with open(os.path.join(HERE, "np2_golden.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("wrote", len(out["cases"]), "cases")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""Long-read path on the GPU: nextpolish_amd/lib/nextpolish2.so (HIP window executor) through the reference's own C
+ABI against the golden vectors of the compiled reference (and against oracle/_ref directly when it travelled)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import np2_cases
+import ref2_binding as rb
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "np2_golden.json")))
+PRODUCT_SO = os.path.join(HERE, "..", "nextpolish_amd", "lib", "nextpolish2.so")
+LQ_CASES = {"ont_lq_regions", "clr_lq_regions"}
+
+
+def run_polish(so_path, fa, fofn, read_type):
+    code = ("import sys, json; sys.path.insert(0, %r); import ref2_binding as rb; L = rb.bind(%r); "
+            "print(json.dumps(rb.polish(L, %r, %r, read_type=%d)))" % (HERE, so_path, fa, fofn, read_type))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    if p.returncode != 0:
+        return None, p.stderr
+    return json.loads(p.stdout.strip().splitlines()[-1]), p.stderr
+
+
+@pytest.mark.parametrize("cid", [c[0] for c in np2_cases.CASES])
+def test_gpu_matches_reference_goldens(cid, tmp_path):
+    kw, rt = next((k, r) for c, k, r in np2_cases.CASES if c == cid)
+    fa, fofn, contigs = np2_cases.materialise(kw, str(tmp_path))
+    got, err = run_polish(PRODUCT_SO, fa, fofn, rt)
+    if cid in LQ_CASES:
+        assert got is None and "not built yet" in err
+        return
+    assert got is not None, err
+    for n, _ in contigs:
+        assert got[n][0][0] == GOLD["cases"][cid]["expected"][n], "%s %s" % (cid, n)
+
+
+def test_gpu_cli_prints_reference_format(tmp_path):
+    kw, rt = np2_cases.CASES[0][1], np2_cases.CASES[0][2]
+    fa, fofn, contigs = np2_cases.materialise(kw, str(tmp_path))
+    exe = os.path.join(HERE, "..", "nextpolish_amd", "bin", "nextpolish2")
+    p = subprocess.run([exe, fa, fofn], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().split("\n")
+    want = GOLD["cases"][np2_cases.CASES[0][0]]["expected"]
+    assert lines[0] == ">ctg0_lgs %d %f" % (len(want["ctg0"]), 0.0) and lines[1] == want["ctg0"]
+    assert lines[3] == want["ctg1"]
+
+
+@pytest.mark.skipif(not rb.available(), reason="oracle/_ref did not travel")
+def test_gpu_matches_compiled_reference_on_fresh_inputs(tmp_path):
+    L = rb.bind(rb.REF_SO)
+    n_checked = 0
+    for seed in range(100, 112):
+        kw = dict(seed=seed, contig_lens=[(15000,), (8000, 3000)][seed % 2], depth=[10, 25][seed % 2], max_indel=[1, 2][seed % 2],
+                  sub=[0.02, 0.06][(seed // 2) % 2])
+        d = tmp_path / ("s%d" % seed)
+        d.mkdir()
+        fa, fofn, contigs = np2_cases.materialise(kw, str(d))
+        got, err = run_polish(PRODUCT_SO, fa, fofn, 1)
+        if got is None:
+            assert "not built yet" in err
+            continue
+        want = rb.polish(L, fa, fofn, read_type=1)
+        for n, _ in contigs:
+            assert got[n][0][0] == want[n][0][0], "seed %d %s" % (seed, n)
+        n_checked += 1
+    assert n_checked >= 6
