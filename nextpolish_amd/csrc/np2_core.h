@@ -247,20 +247,25 @@ struct ColStat {
     uint16_t max_size, coverage, l_del, l_ins;
 };
 
-// get_align_tags (ctg_cns.c:1213-1256) over the kept columns of one read.  tags: nibble stream (first column in the
-// high nibble), zero-initialised by the caller with (aln_len + 1) / 2 + 1 bytes.  Adds the read to the column
-// statistics through St (atomic on the device).  win_s: window start (contig coordinate); gap_min_len: 3 ONT, 5 else.
-template <class St>
-NP2_HD uint32_t emit_tags(const ReadView& r, const char* rfseq, const AlnSpan& a, int32_t win_s, uint32_t gap_min_len,
-                          uint8_t* tags, St& st) {
-    ColIter f;
-    f.begin(&r, rfseq);
-    for (uint32_t i = 0; i < a.col0; ++i) f.next();
-    uint32_t tpos = a.aln_t_s - (uint32_t)win_s;   // window-relative
+// columns of an already gapped pair of strings (the concatenated low-quality regions, ctg_cns.c:1287-1414)
+struct StrColIter {
+    const char* t;
+    const char* q;
+    uint32_t i;
+    NP2_HD void get(char* tc, char* qc) const { *tc = t[i]; *qc = q[i]; }
+    NP2_HD void next() { ++i; }
+};
+
+// get_align_tags (ctg_cns.c:1213-1256) over aln_len columns delivered by `f`.  tags: nibble stream (first column in
+// the high nibble), zero-initialised by the caller with (aln_len + 1) / 2 + 1 bytes.  Adds the stream to the column
+// statistics through St (atomic on the device).  tpos: window-relative position of the first draft base;
+// gap_min_len: 3 ONT, 5 else.  Returns the window-relative exclusive end.
+template <class It, class St>
+NP2_HD uint32_t emit_tags_from(It& f, uint32_t aln_len, uint32_t tpos, uint32_t gap_min_len, uint8_t* tags, St& st) {
     uint32_t te = tpos - 1;
     uint32_t delta = 0, l = 0, p = 0;
     char t, q;
-    for (; p < a.aln_len; ++p) {
+    for (; p < aln_len; ++p) {
         f.get(&t, &q);
         uint32_t b = base_to_int((unsigned char)q);
         if (t == '-') { b |= 8; ++delta; }
@@ -274,7 +279,17 @@ NP2_HD uint32_t emit_tags(const ReadView& r, const char* rfseq, const AlnSpan& a
     }
     if ((p - 1) & 1) tags[p >> 1] |= 255;
     else tags[p >> 1] |= 15;
-    return te + 1;   // window-relative exclusive end
+    return te + 1;
+}
+
+// the kept columns of one record (win_s: window start in contig coordinates)
+template <class St>
+NP2_HD uint32_t emit_tags(const ReadView& r, const char* rfseq, const AlnSpan& a, int32_t win_s, uint32_t gap_min_len,
+                          uint8_t* tags, St& st) {
+    ColIter f;
+    f.begin(&r, rfseq);
+    for (uint32_t i = 0; i < a.col0; ++i) f.next();
+    return emit_tags_from(f, a.aln_len, a.aln_t_s - (uint32_t)win_s, gap_min_len, tags, st);
 }
 
 // ---- tag stream walker (get_align_tag, ctg_cns.c:304-322)
@@ -444,6 +459,51 @@ NP2_HD void dp_column(const MsaView& m, int32_t p, int32_t len, long long* gbest
         if (pb.len && p == len - 1 && E[pb.best].score >= *gbest_score) {
             *gbest_key = node_key(p, pb.key >> 8, b);
             if (E[pb.best].score > *gbest_score) *gbest_score = E[pb.best].score;
+        }
+    }
+}
+
+// Column of the DP variant used on the concatenated low-quality regions (get_lqseqs_from_align_tags, non-HiFi branch,
+// ctg_cns.c:1043-1094): coefficient 2, its own best-predecessor rule, no global best (the caller starts the backtrace
+// at the last node of the last column).
+NP2_HD void dp_column_lq(const MsaView& m, int32_t p) {
+    const long long cov = m.stat[p].coverage;
+    Node* nd = m.nodes + m.col_off[p];
+    const uint32_t nn = m.col_nn[p];
+    for (uint32_t j = 0; j < nn; ++j) {
+        Node& pb = nd[j];
+        Entry* E = m.entries + m.col_off[p] + pb.start;
+        const uint32_t b = pb.key & 0xffu;
+        pb.best = 0;
+        long long p_pp_score_ = INT64_MIN, p_pp_score = INT64_MIN;
+        for (uint32_t mi = 0; mi < pb.len; ++mi) {
+            Entry& em = E[mi];
+            if (key_tpos(em.pp) == -1) {
+                em.score = 10 * (long long)em.link - 2 * cov;
+            } else {
+                Node* ppn = find_node(m, key_tpos(em.pp), key_delta(em.pp) << 8 | key_base(em.pp));
+                const uint32_t pl = ppn ? ppn->len : 0u;
+                const Entry* PE = ppn ? m.entries + m.col_off[key_tpos(em.pp)] + ppn->start : nullptr;
+                for (uint32_t n = 0; n < pl; ++n) {
+                    const Entry& en = PE[n];
+                    if (en.pp != em.ppp) continue;
+                    const long long cand = en.score + 10 * (long long)em.link - 2 * cov;
+                    if (cand > em.score) {
+                        em.score = cand;
+                        p_pp_score_ = en.score;
+                    }
+                    const uint32_t ppb = key_base(em.pp), pppb = key_base(em.ppp);
+                    if ((int)em.link > (int)E[pb.best].link / 2 && en.score > p_pp_score &&
+                        (ppb == 4 || ppb == b || pppb == b || ppb == pppb)) {
+                        pb.best = mi;
+                        p_pp_score = en.score;
+                    }
+                }
+            }
+            if (em.score > E[pb.best].score || (em.score == E[pb.best].score && key_base(em.pp) != 4)) {
+                pb.best = mi;
+                p_pp_score = p_pp_score_;
+            }
         }
     }
 }

@@ -48,11 +48,22 @@ struct WindowOutput {
     bool bad_cigar = false;                       // a record carried an op the reference aborts on
 };
 
+// the concatenated low-quality regions of a window: up to 30 gapped string pairs over one target coordinate space
+// (generate_consensus_trimed, ctg_cns.c:1287-1414)
+struct LqInput {
+    std::vector<std::string> t, q;   // same length per pair; t uses '-' for insertion columns
+    uint32_t t_len = 0;              // target positions (non-gap characters of every t)
+    uint32_t gap_min_len = 3;
+};
+
 class Exec {
   public:
     virtual ~Exec() {}
     // false + *err on failure (never a silent fallback)
     virtual bool run_window(const WindowInput& in, WindowOutput* out, std::string* err) = 0;
+    // link graph + DP variant + backtrace of get_lqseqs_from_align_tags (ctg_cns.c:986-1163, non-HiFi branch):
+    // *cons_rev = consensus characters in backtrace order (last column first), as the reference leaves them
+    virtual bool run_lq(const LqInput& in, std::string* cons_rev, std::string* err) = 0;
 };
 
 // provided by whichever executor is linked (HIP in the product library)

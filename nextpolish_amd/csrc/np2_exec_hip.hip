@@ -231,6 +231,46 @@ __global__ void k2_backtrace(MsaView mv, DpResult* res, ConsBase* cons, uint32_t
     res->cons_len = n;
 }
 
+// tag streams of gapped string pairs (the concatenated low-quality regions); one lane per pair
+__global__ void k2_tags_str(const char* pool, const uint64_t* str_off, const uint32_t* str_len, uint32_t n, uint32_t gap_min_len,
+                            const uint64_t* tag_off, uint8_t* tags, DevStat st, uint32_t* te_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    StrColIter f{pool + str_off[2 * i], pool + str_off[2 * i + 1], 0};
+    DevStatSink sink{st};
+    te_out[i] = emit_tags_from(f, str_len[i], 0u, gap_min_len, tags + tag_off[i], sink);
+}
+
+__global__ void k2_dp_lq(MsaView mv, int32_t len, const uint32_t* max_size, DpResult* res) {
+    if (blockIdx.x || threadIdx.x) return;
+    for (int32_t p = 0; p < len; ++p) dp_column_lq(mv, p);
+    res->gkey = node_key(len - 1, max_size[len - 1] - 1, 5);   // last node the reference's loops visit (ctg_cns.c:1036-1038,1090-1092)
+    res->status = 0;
+    res->gbest = 0;
+}
+
+// backtrace of get_lqseqs_from_align_tags (ctg_cns.c:1104-1143): characters in backtrace order, no reversal
+__global__ void k2_backtrace_lq(MsaView mv, DpResult* res, char* out, uint32_t cap) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t cur = res->gkey;
+    uint32_t n = 0;
+    for (;;) {
+        const int32_t tp = key_tpos(cur);
+        Node* nd = find_node(mv, tp, key_delta(cur) << 8 | key_base(cur));
+        if (!nd || nd->len == 0) { res->status = 2; break; }
+        const Entry& be = mv.entries[mv.col_off[tp] + nd->start + nd->best];
+        if (key_base(cur) != 4) {
+            if (n >= cap) { res->status = 3; break; }
+            const char up = int_to_base(key_base(cur));
+            const uint32_t q = be.link & 0xffffu;
+            out[n++] = (q * 5 > mv.stat[tp].coverage || up == 'N') ? up : (char)(up >= 'A' && up <= 'Z' ? up + 32 : up);
+        }
+        cur = be.pp;
+        if (key_tpos(cur) == -1) break;
+    }
+    res->cons_len = n;
+}
+
 // ---- exclusive scan of uint32 counts (three launches: block sums, scan of the sums, final)
 constexpr uint32_t SCAN_T = 256, SCAN_PER = 16, SCAN_TILE = SCAN_T * SCAN_PER;
 __global__ __launch_bounds__(SCAN_T) void k2_scan_sums(const uint32_t* v, uint32_t n, uint32_t* sums) {
@@ -293,12 +333,15 @@ class HipExec : public Exec {
         return true;
     }
     bool run_window(const WindowInput& in, WindowOutput* out, std::string* err) override;
+    bool run_lq(const LqInput& in, std::string* cons_rev, std::string* err) override;
 
   private:
+    // link observations -> column buckets -> nodes/entries for n_streams tag streams over n_cols columns; *total = entries
+    bool build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total, std::string* err);
     int device_;
     hipStream_t stream_ = nullptr;
     DevBuf contig_, pos_, ncig_, cigoff_, seqoff_, cigar_, seq_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
-        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_;
+        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_;
     uint64_t contig_serial_ = ~0ull;
     size_t contig_len_ = 0;
 };
@@ -408,25 +451,9 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>());
     HIPOK(hipMemcpyAsync(tagoff_.p, out->tag_off.data(), 8ull * n_streams, hipMemcpyHostToDevice, q));
     HIPOK(hipMemcpyAsync(alnts_.p, out->aln_t_s.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
-    // ---- link observations -> column buckets
-    k2_links<false><<<nblk(n_streams, 64), 64, 0, q>>>(tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), n_streams, tags_.as<uint8_t>(),
-                                                        colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
-    const uint32_t nsb = nblk(n_cols + 1, SCAN_TILE);
-    k2_scan_sums<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
-    k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb);
-    k2_scan_final<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), coloff_.as<uint32_t>());
     uint32_t total = 0;
-    HIPOK(hipMemcpyAsync(&total, coloff_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
-    HIPOK(hipStreamSynchronize(q));
-    if (!obs_.ensure(sizeof(LinkObs) * (size_t)total + 64) || !entries_.ensure(sizeof(Entry) * (size_t)total + 64) ||
-        !nodes_.ensure(sizeof(Node) * (size_t)total + 64) || !cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) {
-        *err = "out of device memory (link graph)";
-        return false;
-    }
-    k2_links<true><<<nblk(n_streams, 64), 64, 0, q>>>(tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), n_streams, tags_.as<uint8_t>(),
-                                                       nullptr, coloff_.as<uint32_t>(), cursor_.as<uint32_t>(), obs_.as<LinkObs>());
-    k2_build<<<nblk(n_cols, 64), 64, 0, q>>>(obs_.as<LinkObs>(), coloff_.as<uint32_t>(), n_cols, entries_.as<Entry>(), nodes_.as<Node>(),
-                                              colnn_.as<uint32_t>());
+    if (!build_graph(n_streams, n_cols, &total, err)) return false;
+    if (!cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) { *err = "out of device memory (consensus)"; return false; }
     // ---- chain DP + backtrace
     MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
     const uint32_t cons_cap = total + 8;
@@ -450,6 +477,89 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     if (n_streams > 1) HIPOK(hipMemcpyAsync(out->aln_t_e.data() + 1, te_.as<uint32_t>() + 1, 4ull * (n_streams - 1), hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
     out->aln_t_e[0] = (uint32_t)l;
+    return true;
+}
+
+bool HipExec::build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total_out, std::string* err) {
+    hipStream_t q = stream_;
+    k2_links<false><<<nblk(n_streams, 64), 64, 0, q>>>(tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), n_streams, tags_.as<uint8_t>(),
+                                                        colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
+    const uint32_t nsb = nblk(n_cols + 1, SCAN_TILE);
+    k2_scan_sums<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
+    k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb);
+    k2_scan_final<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), coloff_.as<uint32_t>());
+    uint32_t total = 0;
+    HIPOK(hipMemcpyAsync(&total, coloff_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
+    HIPOK(hipStreamSynchronize(q));
+    if (!obs_.ensure(sizeof(LinkObs) * (size_t)total + 64) || !entries_.ensure(sizeof(Entry) * (size_t)total + 64) ||
+        !nodes_.ensure(sizeof(Node) * (size_t)total + 64)) {
+        *err = "out of device memory (link graph)";
+        return false;
+    }
+    k2_links<true><<<nblk(n_streams, 64), 64, 0, q>>>(tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), n_streams, tags_.as<uint8_t>(),
+                                                       nullptr, coloff_.as<uint32_t>(), cursor_.as<uint32_t>(), obs_.as<LinkObs>());
+    k2_build<<<nblk(n_cols, 64), 64, 0, q>>>(obs_.as<LinkObs>(), coloff_.as<uint32_t>(), n_cols, entries_.as<Entry>(), nodes_.as<Node>(),
+                                              colnn_.as<uint32_t>());
+    *total_out = total;
+    return true;
+}
+
+bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err) {
+    HIPOK(hipSetDevice(device_));
+    hipStream_t q = stream_;
+    const uint32_t n_streams = (uint32_t)in.t.size();
+    const uint32_t n_cols = in.t_len + 1 + 32;   // slack: see the fill quirk in np2_lq.cpp
+    std::vector<char> pool;
+    std::vector<uint64_t> str_off, tag_off;
+    std::vector<uint32_t> str_len, zeros(n_streams, 0);
+    uint64_t tag_bytes = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        str_off.push_back(pool.size());
+        pool.insert(pool.end(), in.t[i].begin(), in.t[i].end());
+        pool.push_back('\0');
+        str_off.push_back(pool.size());
+        pool.insert(pool.end(), in.q[i].begin(), in.q[i].end());
+        pool.push_back('\0');
+        str_len.push_back((uint32_t)in.t[i].size());
+        tag_off.push_back(tag_bytes);
+        tag_bytes += ((uint64_t)in.t[i].size() + 1) / 2 + 1;
+        tag_bytes = (tag_bytes + 3) & ~3ull;
+    }
+    if (!strpool_.ensure(pool.size() + 16) || !stroff_.ensure(8ull * str_off.size() + 16) || !strlen_.ensure(4ull * n_streams + 16) ||
+        !tags_.ensure(tag_bytes + 16) || !cnt4_.ensure(16ull * n_cols + 64) || !stat_.ensure(sizeof(ColStat) * (size_t)n_cols) ||
+        !tagoff_.ensure(8ull * n_streams + 16) || !alnts_.ensure(4ull * n_streams + 16) || !te_.ensure(4ull * n_streams + 16) ||
+        !colcnt_.ensure(4ull * (n_cols + 2)) || !coloff_.ensure(4ull * (n_cols + 2)) || !cursor_.ensure(4ull * (n_cols + 2)) ||
+        !sums_.ensure(4ull * (nblk(n_cols + 1, SCAN_TILE) + 2)) || !colnn_.ensure(4ull * n_cols) || !res_.ensure(sizeof(DpResult))) {
+        *err = "out of device memory (low-quality regions)";
+        return false;
+    }
+    HIPOK(hipMemcpyAsync(strpool_.p, pool.data(), pool.size(), hipMemcpyHostToDevice, q));
+    HIPOK(hipMemcpyAsync(stroff_.p, str_off.data(), 8ull * str_off.size(), hipMemcpyHostToDevice, q));
+    HIPOK(hipMemcpyAsync(strlen_.p, str_len.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
+    HIPOK(hipMemcpyAsync(tagoff_.p, tag_off.data(), 8ull * n_streams, hipMemcpyHostToDevice, q));
+    HIPOK(hipMemcpyAsync(alnts_.p, zeros.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
+    HIPOK(hipMemsetAsync(tags_.p, 0, tag_bytes + 16, q));
+    HIPOK(hipMemsetAsync(cnt4_.p, 0, 16ull * n_cols + 64, q));
+    HIPOK(hipMemsetAsync(colcnt_.p, 0, 4ull * (n_cols + 2), q));
+    HIPOK(hipMemsetAsync(cursor_.p, 0, 4ull * (n_cols + 2), q));
+    DevStat st{cnt4_.as<uint32_t>(), cnt4_.as<uint32_t>() + n_cols, cnt4_.as<uint32_t>() + 2ull * n_cols, cnt4_.as<uint32_t>() + 3ull * n_cols};
+    k2_tags_str<<<nblk(n_streams, 64), 64, 0, q>>>(strpool_.as<char>(), stroff_.as<uint64_t>(), strlen_.as<uint32_t>(), n_streams, in.gap_min_len,
+                                                   tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), st, te_.as<uint32_t>());
+    k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>());
+    uint32_t total = 0;
+    if (!build_graph(n_streams, n_cols, &total, err)) return false;
+    const uint32_t cap = total + 8;
+    if (!cons_.ensure((size_t)cap + 16)) { *err = "out of device memory (low-quality consensus)"; return false; }
+    MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
+    k2_dp_lq<<<1, 64, 0, q>>>(mv, (int32_t)in.t_len, st.max_size, res_.as<DpResult>());
+    k2_backtrace_lq<<<1, 64, 0, q>>>(mv, res_.as<DpResult>(), cons_.as<char>(), cap);
+    DpResult res;
+    HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));
+    HIPOK(hipStreamSynchronize(q));
+    if (res.status) { *err = "low-quality backtrace left the graph"; return false; }
+    cons_rev->resize(res.cons_len);
+    if (res.cons_len) HIPOK(hipMemcpyAsync(&(*cons_rev)[0], cons_.p, res.cons_len, hipMemcpyDeviceToHost, q));
+    HIPOK(hipStreamSynchronize(q));
     return true;
 }
 

@@ -1,0 +1,32 @@
+// Low-quality-region stage of the long-read consensus (host side): candidate extraction, pseudo-seed by partial-order
+// alignment, banded O(ND) alignment of the candidates to the seed, and the splice back into the window consensus.
+// reference: source/lib/ctg_cns.c:405-449,620-633,822-1473, dag.c, align.c
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "np2_exec.h"
+
+namespace np2 {
+
+// heaviest-path consensus of up to 50 strings (poa_to_consensus, dag.c:658-694)
+std::string poa_consensus(const std::vector<std::string>& seqs);
+
+struct OndAln {
+    int aln_len = 0, aln_t_len = 0, aln_q_len = 0;
+    std::string t_aln_str, q_aln_str;
+};
+// align (align.c:39-177); false = no alignment within the diagonal/band limits
+bool ond_align(const char* query_seq, int q_len, const char* target_seq, int t_len, OndAln* aln);
+
+struct LqRegionIn {   // one low-quality region of the window consensus (window-relative draft positions, inclusive)
+    uint32_t start, end;
+    uint8_t l;         // 0 insertion-driven, 2 / 3 deletion-driven (ctg_cns.c:1577-1583)
+};
+// Re-consensus of the regions (given in DEscending position order, as the reference builds them) and splice into
+// *cons (the window's main-line consensus).  The graph consensus of the concatenated regions runs in `exec`.
+bool lq_stage(Exec* exec, uint32_t gap_min_len, const std::vector<LqRegionIn>& regions, const WindowOutput& wo,
+              std::vector<ConsBase>* cons, std::string* err);
+
+}  // namespace np2

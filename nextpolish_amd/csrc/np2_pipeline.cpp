@@ -7,8 +7,10 @@
 // Everything per alignment column -- spans, tags, link graph, chain DP, backtrace -- runs in the window executor
 // (np2_exec.h): HIP kernels in the product.
 //
-// Not built yet (fails loudly, never silently): the low-quality-region re-consensus (B10-B14 apply step), the HiFi
-// variant of it, and the structural gap-cluster layer (B15).  See DESIGN.md section "path B".
+// Low-quality regions go through np2_lq.cpp (candidates, POA pseudo-seed, O(ND) alignment on the host; the graph
+// consensus of the concatenated regions in the executor).
+// Not built yet (fails loudly, never silently): the HiFi variant (ctg_cns.c:636-820,1727-1826) and the structural
+// gap-cluster layer (B15).  See DESIGN.md section "path B".
 #include <cassert>
 #include <cctype>
 #include <climits>
@@ -23,6 +25,7 @@
 
 #include "../../include/nextpolish2.h"
 #include "np2_exec.h"
+#include "np2_lq.h"
 #include "np_bam.h"
 
 namespace {
@@ -567,9 +570,9 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
         LqCtx lx{&out.stat, &out.cons, reads_type, gap_min_ratio1};
         std::vector<LqReg> lq = lq_regions(lx);
         if (!lq.empty()) {
-            char msg[160];
-            snprintf(msg, sizeof(msg), "%zu low-quality regions need the POA re-consensus (ctg_cns.c:822-1473), which is not built yet", lq.size());
-            np2_die(msg, ref->n);
+            std::vector<np2::LqRegionIn> regs;
+            for (const LqReg& r : lq) regs.push_back(np2::LqRegionIn{r.start, r.end, r.l});
+            if (!np2::lq_stage(cfg->exec, gap_min_len, regs, out, &out.cons, &err)) np2_die(err.c_str(), ref->n);
         }
         WindowCons wc;
         wc.b = out.cons;   // update_consensus_trimed with no regions: a copy (ctg_cns.c:1165-1211)

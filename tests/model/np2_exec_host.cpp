@@ -19,8 +19,94 @@ struct HostStat {
     void l_del(uint32_t p) { ++st[p].l_del; }
 };
 
+// link graph of a set of tag streams (update_msa, ctg_cns.c:324-365)
+struct HostGraph {
+    std::vector<uint32_t> col_cnt, col_off, col_nn;
+    std::vector<Entry> entries;
+    std::vector<Node> nodes;
+    void build(const std::vector<uint64_t>& tag_off, const std::vector<uint32_t>& aln_t_s, const std::vector<uint8_t>& tags,
+               uint32_t n_streams, uint32_t n_cols) {
+        col_cnt.assign((size_t)n_cols + 1, 0);
+        std::vector<LinkObs> obs;
+        std::vector<uint32_t> cursor;
+        auto walk = [&](bool count_only) {
+            for (uint32_t rd = 0; rd < n_streams; ++rd) {
+                const uint8_t* tg = tags.data() + tag_off[rd];
+                uint32_t d = 0;
+                Tag p1{0, 0, 0};
+                uint64_t pp = KEY_HEAD, ppp = KEY_HEAD;
+                uint32_t pp_base = 0;
+                while (next_tag(tg, aln_t_s[rd], &d, &p1)) {
+                    const uint64_t key = node_key(p1.t_pos, p1.delta, p1.q_base);
+                    if (p1.q_base == 6 || pp_base == 6) { ppp = pp; pp = key; pp_base = p1.q_base; continue; }
+                    if (count_only) ++col_cnt[(size_t)p1.t_pos];
+                    else {
+                        LinkObs& o = obs[cursor[(size_t)p1.t_pos]++];
+                        o.pp = pp; o.ppp = ppp; o.rd = rd; o.delta = (uint16_t)p1.delta; o.base = (uint8_t)p1.q_base; o.pad = 0;
+                    }
+                    ppp = pp; pp = key; pp_base = p1.q_base;
+                }
+            }
+        };
+        walk(true);
+        col_off.assign((size_t)n_cols + 1, 0);
+        for (uint32_t p = 0; p < n_cols; ++p) col_off[(size_t)p + 1] = col_off[p] + col_cnt[p];
+        const size_t total = col_off[n_cols];
+        obs.resize(total);
+        cursor.assign(col_off.begin(), col_off.end());
+        walk(false);
+        // (streams are walked in order here, so every bucket is already ordered by (rd, delta); the device sorts)
+        entries.assign(total, Entry{});
+        nodes.assign(total, Node{});
+        col_nn.assign(n_cols, 0);
+        for (uint32_t p = 0; p < n_cols; ++p)
+            col_nn[p] = build_column(obs.data() + col_off[p], col_cnt[p], entries.data() + col_off[p], nodes.data() + col_off[p]);
+    }
+};
+
 class HostExec : public Exec {
   public:
+    bool run_lq(const LqInput& in, std::string* cons_rev, std::string* err) override {
+        const uint32_t n_streams = (uint32_t)in.t.size();
+        const uint32_t n_cols = in.t_len + 1;
+        std::vector<ColStat> stat((size_t)n_cols + 64, ColStat{0, 0, 0, 0});   // (slack: see the fill quirk in np2_lq.cpp)
+        HostStat hs{stat.data()};
+        std::vector<uint64_t> tag_off;
+        std::vector<uint32_t> aln_t_s;
+        std::vector<uint8_t> tags;
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            const uint32_t len = (uint32_t)in.t[i].size();
+            tag_off.push_back(tags.size());
+            tags.resize(tags.size() + (len + 1) / 2 + 1, 0);
+            StrColIter f{in.t[i].c_str(), in.q[i].c_str(), 0};
+            const uint32_t te = emit_tags_from(f, len, 0u, in.gap_min_len, tags.data() + tag_off.back(), hs);
+            if (te > n_cols + 32) { *err = "low-quality concatenation overruns its target length"; return false; }
+            aln_t_s.push_back(0);
+        }
+        HostGraph g;
+        g.build(tag_off, aln_t_s, tags, n_streams, n_cols + 32);
+        MsaView mv{g.col_off.data(), g.col_nn.data(), g.nodes.data(), g.entries.data(), stat.data()};
+        const int32_t len = (int32_t)in.t_len;
+        for (int32_t p = 0; p < len; ++p) dp_column_lq(mv, p);
+        // start: the last node visited by the reference's loops = (len - 1, max_size - 1, base 5)
+        uint64_t cur = node_key(len - 1, (uint32_t)stat[(size_t)len - 1].max_size - 1, 5);
+        cons_rev->clear();
+        for (;;) {
+            const int32_t tp = key_tpos(cur);
+            Node* nd = find_node(mv, tp, key_delta(cur) << 8 | key_base(cur));
+            if (!nd || nd->len == 0) { *err = "low-quality backtrace left the graph"; return false; }
+            const Entry& be = g.entries[g.col_off[(size_t)tp] + nd->start + nd->best];
+            if (key_base(cur) != 4) {
+                const char up = int_to_base(key_base(cur));
+                const uint32_t q = be.link & 0xffffu;
+                cons_rev->push_back((q * 5 > stat[(size_t)tp].coverage || up == 'N') ? up : (char)tolower(up));
+            }
+            cur = be.pp;
+            if (key_tpos(cur) == -1) break;
+        }
+        return true;
+    }
+
     bool run_window(const WindowInput& in, WindowOutput* out, std::string* err) override {
         const int32_t s = in.s, e = in.e, l = e - s;
         const size_t n = in.n_reads();
@@ -67,45 +153,13 @@ class HostExec : public Exec {
             add_stream(rv, a);
         }
         out->seq_count = (uint32_t)out->tag_off.size();
-        // ---- link observations per column (update_msa, ctg_cns.c:324-365)
-        std::vector<uint32_t> col_cnt((size_t)l + 2, 0);
-        auto walk = [&](bool count_only, std::vector<LinkObs>* obs, std::vector<uint32_t>* cursor) {
-            for (uint32_t rd = 0; rd < out->seq_count; ++rd) {
-                const uint8_t* tg = out->tags.data() + out->tag_off[rd];
-                uint32_t d = 0;
-                Tag p1{0, 0, 0};
-                uint64_t pp = KEY_HEAD, ppp = KEY_HEAD;
-                uint32_t pp_base = 0;
-                while (next_tag(tg, out->aln_t_s[rd], &d, &p1)) {
-                    const uint64_t key = node_key(p1.t_pos, p1.delta, p1.q_base);
-                    if (p1.q_base == 6 || pp_base == 6) { ppp = pp; pp = key; pp_base = p1.q_base; continue; }
-                    if (count_only) ++col_cnt[(size_t)p1.t_pos];
-                    else {
-                        LinkObs& o = (*obs)[(*cursor)[(size_t)p1.t_pos]++];
-                        o.pp = pp; o.ppp = ppp; o.rd = rd; o.delta = (uint16_t)p1.delta; o.base = (uint8_t)p1.q_base; o.pad = 0;
-                    }
-                    ppp = pp; pp = key; pp_base = p1.q_base;
-                }
-            }
-        };
-        walk(true, nullptr, nullptr);
-        std::vector<uint32_t> col_off((size_t)l + 2, 0);
-        for (int32_t p = 0; p <= l; ++p) col_off[(size_t)p + 1] = col_off[(size_t)p] + col_cnt[(size_t)p];
-        const size_t total = col_off[(size_t)l + 1];
-        std::vector<LinkObs> obs(total);
-        {
-            std::vector<uint32_t> cursor(col_off.begin(), col_off.end());
-            walk(false, &obs, &cursor);
-        }
-        // (streams are walked in order here, so every bucket is already ordered by (rd, delta); the device sorts)
-        std::vector<Entry> entries(total);
-        std::vector<Node> nodes(total);
-        std::vector<uint32_t> col_nn((size_t)l + 1, 0);
-        for (int32_t p = 0; p <= l; ++p)
-            col_nn[(size_t)p] = build_column(obs.data() + col_off[(size_t)p], col_cnt[(size_t)p], entries.data() + col_off[(size_t)p],
-                                             nodes.data() + col_off[(size_t)p]);
+        // ---- link graph (update_msa, ctg_cns.c:324-365)
+        HostGraph g;
+        g.build(out->tag_off, out->aln_t_s, out->tags, out->seq_count, (uint32_t)l + 1);
+        std::vector<uint32_t>& col_off = g.col_off;
+        std::vector<Entry>& entries = g.entries;
         // ---- chain DP, column after column
-        MsaView mv{col_off.data(), col_nn.data(), nodes.data(), entries.data(), out->stat.data()};
+        MsaView mv{g.col_off.data(), g.col_nn.data(), g.nodes.data(), g.entries.data(), out->stat.data()};
         long long gbest = INT64_MIN;
         uint64_t gkey = node_key(0, 0, 0xff);
         for (int32_t p = 0; p < l; ++p) {

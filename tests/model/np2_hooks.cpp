@@ -1,0 +1,30 @@
+// C hooks around host-side pieces of the long-read path so the tests can compare them with the functions the
+// compiled reference exports (poa_to_consensus, align).  TEST INFRASTRUCTURE ONLY.
+#include <cstring>
+
+#include "../../nextpolish_amd/csrc/np2_lq.h"
+
+extern "C" {
+
+int np2m_poa(const char** seqs, int n, char* out, int cap) {
+    std::vector<std::string> v;
+    for (int i = 0; i < n; ++i) v.emplace_back(seqs[i]);
+    const std::string r = np2::poa_consensus(v);
+    if ((int)r.size() + 1 > cap) return -1;
+    memcpy(out, r.c_str(), r.size() + 1);
+    return (int)r.size();
+}
+
+// returns aln_len (0 when no alignment); t/q strings into the buffers; lens[0] = aln_t_len, lens[1] = aln_q_len
+int np2m_align(const char* q, int ql, const char* t, int tl, char* out_t, char* out_q, int cap, int* lens) {
+    np2::OndAln a;
+    if (!np2::ond_align(q, ql, t, tl, &a)) return 0;
+    if (a.aln_len + 1 > cap) return -1;
+    memcpy(out_t, a.t_aln_str.c_str(), (size_t)a.aln_len + 1);
+    memcpy(out_q, a.q_aln_str.c_str(), (size_t)a.aln_len + 1);
+    lens[0] = a.aln_t_len;
+    lens[1] = a.aln_q_len;
+    return a.aln_len;
+}
+
+}

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "np2_golden.json")))
 MODEL_SO = os.path.join(HERE, "model", "libnp2_model.so")
 PRODUCT_SO = os.path.join(HERE, "..", "nextpolish_amd", "lib", "nextpolish2.so")
-LQ_CASES = {"ont_lq_regions", "clr_lq_regions"}   # need the low-quality-region re-consensus (not built yet)
+LQ_CASES = {"ont_lq_regions", "clr_lq_regions"}   # windows with low-quality regions: POA pseudo-seeds + graph re-consensus
 
 
 @pytest.fixture(scope="module")
@@ -42,13 +42,17 @@ def test_model_matches_reference_goldens(model, cid, tmp_path):
     kw, rt = next((k, r) for c, k, r in np2_cases.CASES if c == cid)
     fa, fofn, contigs = np2_cases.materialise(kw, str(tmp_path))
     got, err = run_polish(model, fa, fofn, rt)
-    if cid in LQ_CASES:
-        assert got is None and "not built yet" in err      # fails loudly, never a silent approximation
-        return
     assert got is not None, err
     for n, _ in contigs:
         assert len(got[n]) == GOLD["cases"][cid]["pieces"][n]
         assert got[n][0][0] == GOLD["cases"][cid]["expected"][n], "%s %s" % (cid, n)
+
+
+def test_unbuilt_variants_fail_loudly(model, tmp_path):
+    """HiFi consensus variant is not built yet: the library must say so and exit, never approximate."""
+    fa, fofn, contigs = np2_cases.materialise(np2_cases.CASES[1][1], str(tmp_path))
+    got, err = run_polish(model, fa, fofn, 3)
+    assert got is None and "not built yet" in err
 
 
 @pytest.mark.skipif(not rb.available(), reason="oracle/_ref not built (reference sources absent)")
