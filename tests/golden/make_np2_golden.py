@@ -34,6 +34,19 @@ def main():
         buf = C.create_string_buffer(len(s) + 1)
         L.bit2seq1(words, len(s), buf)
         out["codec"].append({"seq": s, "words": [int(w) for w in words][: (len(s) + 15) // 16], "round_trip": buf.value.decode()})
+    # known answers of the two string algorithms the reference exports: poa_to_consensus (dag.c) and align (align.c)
+    import random
+    import np2_strings
+    R = C.CDLL(rb.REF_SO)
+    out["poa"], out["align"] = [], []
+    for seed in range(60):
+        seqs = np2_strings.poa_case(random.Random(seed))
+        out["poa"].append({"seqs": seqs, "consensus": np2_strings.ref_poa(R, seqs)})
+    for seed in range(80):
+        q, t = np2_strings.align_case(random.Random(seed), seed)
+        n, ts, qs, tl, ql = np2_strings.ref_align(R, q, t)
+        out["align"].append({"q": q, "t": t, "aln_len": n, "t_aln": ts if n > 2 else "", "q_aln": qs if n > 2 else "",
+                             "t_len": tl if n > 2 else 0, "q_len": ql if n > 2 else 0})
     with open(os.path.join(HERE, "np2_golden.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
     print("wrote", len(out["cases"]), "cases")

@@ -65,3 +65,16 @@ def test_gpu_matches_compiled_reference_on_fresh_inputs(tmp_path):
             assert got[n][0][0] == want[n][0][0], "seed %d %s" % (seed, n)
         n_checked += 1
     assert n_checked == 12
+
+
+def test_gpu_harness_with_forked_workers(tmp_path):
+    """The reference forks its worker pool after read_ref/ctg_cns_init: every worker must bring up its own HIP context."""
+    cid, kw, rt = np2_cases.CASES[0]
+    fa, fofn, contigs = np2_cases.materialise(kw, str(tmp_path))
+    want = GOLD["cases"][cid]["expected"]
+    exe = os.path.join(HERE, "..", "nextpolish_amd", "nextpolish2.py")
+    p = subprocess.run([sys.executable, exe, "-g", fa, "-l", fofn, "-r", "ont", "-p", "2"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    recs = p.stdout.strip().split("\n")
+    got = {recs[i][1:].split()[0]: recs[i + 1] for i in range(0, len(recs), 2)}
+    assert got == want

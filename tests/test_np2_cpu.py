@@ -112,3 +112,64 @@ def test_product_library_exports_the_abi():
                 "free_consensus_trimed_data", "np2_last_error", "np2_device_index"]:
         assert sym in header
         assert getattr(L, sym) is not None
+
+
+def test_poa_consensus_known_answers(model):
+    import np2_strings
+    M = C.CDLL(model)
+    for k in GOLD["poa"]:
+        assert np2_strings.model_poa(M, k["seqs"]) == k["consensus"]
+
+
+def test_ond_align_known_answers(model):
+    import np2_strings
+    M = C.CDLL(model)
+    for k in GOLD["align"]:
+        n, ts, qs, tl, ql = np2_strings.model_align(M, k["q"], k["t"])
+        assert n == k["aln_len"]
+        if n > 2:
+            assert (ts, qs, tl, ql) == (k["t_aln"], k["q_aln"], k["t_len"], k["q_len"])
+
+
+@pytest.mark.skipif(not rb.available(), reason="oracle/_ref not built (reference sources absent)")
+def test_string_algorithms_against_compiled_reference(model):
+    import random
+    import np2_strings
+    M, R = C.CDLL(model), C.CDLL(rb.REF_SO)
+    for seed in range(1000, 1120):
+        seqs = np2_strings.poa_case(random.Random(seed))
+        assert np2_strings.model_poa(M, seqs) == np2_strings.ref_poa(R, seqs), seed
+        q, t = np2_strings.align_case(random.Random(seed), seed)
+        want, got = np2_strings.ref_align(R, q, t), np2_strings.model_align(M, q, t)
+        assert got[0] == want[0] and (want[0] <= 2 or got == want), seed
+
+
+def _run_harness(argv, lib):
+    exe = os.path.join(HERE, "..", "nextpolish_amd", "nextpolish2.py")
+    return subprocess.run([sys.executable, exe] + argv + ["--library", lib], capture_output=True, text=True)
+
+
+def test_harness_mirrors_reference_caller(model, tmp_path):
+    cid, kw, rt = np2_cases.CASES[0]
+    fa, fofn, contigs = np2_cases.materialise(kw, str(tmp_path))
+    want = GOLD["cases"][cid]["expected"]
+    p = _run_harness(["-g", fa, "-l", fofn, "-r", "ont", "-p", "1"], model)
+    assert p.returncode == 0, p.stderr
+    recs = p.stdout.strip().split("\n")
+    assert recs == [">ctg0 %d" % len(want["ctg0"]), want["ctg0"], ">ctg1 %d" % len(want["ctg1"]), want["ctg1"]]
+    # -u, block file selection, sharding over two node-level ranks
+    blc = tmp_path / "g.blc"
+    blc.write_text("ctg0 0\nctg1 1\n")
+    p = _run_harness(["-g", fa, "-l", fofn, "-r", "ont", "-p", "1", "-u", "-b", str(blc), "-i", "1"], model)
+    assert p.stdout.strip().split("\n") == [">ctg1 %d" % len(want["ctg1"]), want["ctg1"].upper()]
+    got = []
+    for rank in (0, 1):
+        p = _run_harness(["-g", fa, "-l", fofn, "-r", "ont", "-p", "1", "--world", "2", "--rank", str(rank)], model)
+        got.append(p.stdout.strip().split("\n")[0])
+    assert got == [">ctg0 %d" % len(want["ctg0"]), ">ctg1 %d" % len(want["ctg1"])]
+    # resume: a finished first contig is skipped, a trailing (possibly truncated) record is redone
+    out = tmp_path / "o.fa"
+    out.write_text(">ctg0 %d\n%s\n>ctg1 5\nACG" % (len(want["ctg0"]), want["ctg0"]))
+    p = _run_harness(["-g", fa, "-l", fofn, "-r", "ont", "-p", "1", "-o", str(out)], model)
+    assert p.returncode == 0, p.stderr
+    assert out.read_text().strip().split("\n") == [">ctg0 %d" % len(want["ctg0"]), want["ctg0"], ">ctg1 %d" % len(want["ctg1"]), want["ctg1"]]
