@@ -16,6 +16,7 @@
 // Bounds: tags/links/build stream every alignment column once (HBM); k2_dp is latency bound -- the (A, C)
 // run decomposition described in DESIGN.md is the next step for it.
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -314,6 +315,28 @@ __global__ __launch_bounds__(SCAN_T) void k2_scan_final(const uint32_t* v, uint3
 
 inline uint32_t nblk(uint64_t n, uint32_t t) { return (uint32_t)((n + t - 1) / t); }
 
+// NP2_TIMING=1: per-stage wall time (with stream syncs) of every window on stderr
+struct StageClock {
+    bool on;
+    hipStream_t q;
+    double t0;
+    std::string line;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    StageClock(hipStream_t s) : on(getenv("NP2_TIMING") != nullptr), q(s), t0(0) { if (on) t0 = now(); }
+    void mark(const char* name) {
+        if (!on) return;
+        (void)hipStreamSynchronize(q);
+        const double t = now();
+        char b[64];
+        snprintf(b, sizeof(b), " %s %.2f", name, t - t0);
+        line += b;
+        t0 = t;
+    }
+    void flush(const char* what, long cols, long streams, long entries) {
+        if (on) fprintf(stderr, "[np2 %s] cols %ld streams %ld entries %ld | ms:%s\n", what, cols, streams, entries, line.c_str());
+    }
+};
+
 int pick_device(std::string* err) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { *err = "no HIP device (the long-read consensus has no CPU fallback)"; return -1; }
@@ -351,6 +374,7 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     hipStream_t q = stream_;
     const int32_t s = in.s, e = in.e, l = e - s;
     const uint32_t n = (uint32_t)in.n_reads();
+    StageClock clk(q);
     out->kept.assign(n, 0);
     out->bad_cigar = false;
     out->cons.clear();
@@ -378,6 +402,7 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
         HIPOK(hipMemcpyAsync(spans.data(), spans_.p, sizeof(SpanOut) * (size_t)n, hipMemcpyDeviceToHost, q));
     }
     HIPOK(hipStreamSynchronize(q));
+    clk.mark("upload+span");
     for (uint32_t i = 0; i < n; ++i)
         if (spans[i].bad) { out->bad_cigar = true; return true; }
     // ---- 500 bp rule + coverage caps (ctg_cns.c:3540-3545).  Coverage of a column = number of kept streams whose
@@ -451,13 +476,16 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>());
     HIPOK(hipMemcpyAsync(tagoff_.p, out->tag_off.data(), 8ull * n_streams, hipMemcpyHostToDevice, q));
     HIPOK(hipMemcpyAsync(alnts_.p, out->aln_t_s.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
+    clk.mark("tags");
     uint32_t total = 0;
     if (!build_graph(n_streams, n_cols, &total, err)) return false;
     if (!cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) { *err = "out of device memory (consensus)"; return false; }
+    clk.mark("links+build");
     // ---- chain DP + backtrace
     MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
     const uint32_t cons_cap = total + 8;
     k2_dp<<<1, 64, 0, q>>>(mv, l, in.read_type, res_.as<DpResult>());
+    clk.mark("dp");
     k2_backtrace<<<1, 64, 0, q>>>(mv, res_.as<DpResult>(), cons_.as<ConsBase>(), cons_cap);
     DpResult res;
     HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));
@@ -476,6 +504,8 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     HIPOK(hipMemcpyAsync(out->tags.data(), tags_.p, tag_bytes, hipMemcpyDeviceToHost, q));
     if (n_streams > 1) HIPOK(hipMemcpyAsync(out->aln_t_e.data() + 1, te_.as<uint32_t>() + 1, 4ull * (n_streams - 1), hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
+    clk.mark("backtrace+download");
+    clk.flush("window", l, n_streams, total);
     out->aln_t_e[0] = (uint32_t)l;
     return true;
 }

@@ -27,6 +27,11 @@ def main():
             "expected": {n: res[n][0][0] for n, _ in contigs},
             "pieces": {n: len(res[n]) for n, _ in contigs},
         }
+    # one contig longer than the (minimum-size) window: two windows with 1 Mb overlap, stitched by link_consensus
+    fa, fofn, contigs = np2_cases.materialise(np2_cases.TWO_WINDOW_CASE)
+    res = rb.polish(L, fa, fofn, window=np2_cases.TWO_WINDOW_W)
+    s = res["ctg0"][0][0]
+    out["two_windows"] = {"md5": hashlib.md5(s.encode()).hexdigest(), "len": len(s), "pieces": len(res["ctg0"])}
     # codec known answers: pack then unpack through the reference (incl. the non-ACGT spill of bseq.c:91)
     for s in ["ACGT", "AANAA", "GGNGG", "acgtn", "TTTTTTTTTTTTTTTTA", "NACGT", "ACGTACGTACGTACGTN", "RYKM", "A", "TU"]:
         words = (C.c_uint32 * (len(s) // 16 + 1))()

@@ -18,6 +18,10 @@ CASES = [
     ("clr_lq_regions", dict(seed=13, contig_lens=(9000,), depth=60, max_indel=6, sub=0.08), 2),
 ]
 
+# a contig longer than the smallest window the reference accepts (window must exceed 4 x the 1 Mb overlap)
+TWO_WINDOW_CASE = dict(seed=77, contig_lens=(4300000,), depth=3, mean_len=12000, max_indel=3)
+TWO_WINDOW_W = 4100000
+
 
 def materialise(case_kw, workdir=None):
     """Writes FASTA + BAM(+BAI) + BAM list for one case; returns (fasta, bam_list, contigs)."""

@@ -27,10 +27,10 @@ def model():
     return MODEL_SO
 
 
-def run_polish(so_path, fa, fofn, read_type):
+def run_polish(so_path, fa, fofn, read_type, window=5000000):
     """ctg_cns_core exits the process on unsupported input (the reference's error convention): run it in a child."""
     code = ("import sys, json; sys.path.insert(0, %r); import ref2_binding as rb; L = rb.bind(%r); "
-            "print(json.dumps(rb.polish(L, %r, %r, read_type=%d)))" % (HERE, so_path, fa, fofn, read_type))
+            "print(json.dumps(rb.polish(L, %r, %r, read_type=%d, window=%d)))" % (HERE, so_path, fa, fofn, read_type, window))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     if p.returncode != 0:
         return None, p.stderr
@@ -173,3 +173,14 @@ def test_harness_mirrors_reference_caller(model, tmp_path):
     p = _run_harness(["-g", fa, "-l", fofn, "-r", "ont", "-p", "1", "-o", str(out)], model)
     assert p.returncode == 0, p.stderr
     assert out.read_text().strip().split("\n") == [">ctg0 %d" % len(want["ctg0"]), want["ctg0"], ">ctg1 %d" % len(want["ctg1"]), want["ctg1"]]
+
+
+def test_two_windows_are_stitched_like_the_reference(model, tmp_path):
+    """4.3 Mb contig, 4.1 Mb window: two windows overlapping by 1 Mb, joined at 50 agreeing bases (link_consensus)."""
+    import hashlib
+    fa, fofn, contigs = np2_cases.materialise(np2_cases.TWO_WINDOW_CASE, str(tmp_path))
+    got, err = run_polish(model, fa, fofn, 1, window=np2_cases.TWO_WINDOW_W)
+    assert got is not None, err
+    s = got["ctg0"][0][0]
+    assert len(got["ctg0"]) == GOLD["two_windows"]["pieces"] and len(s) == GOLD["two_windows"]["len"]
+    assert hashlib.md5(s.encode()).hexdigest() == GOLD["two_windows"]["md5"]
