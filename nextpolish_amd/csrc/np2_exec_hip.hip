@@ -185,6 +185,7 @@ struct DpResult {
     long long gbest;
     uint64_t gkey;
     uint32_t cons_len, status;   // status: 0 ok, 1 no end column, 2 backtrace left the graph, 3 zero coverage
+    unsigned long long cyc[4];   // k2_dp_wave: cycles in tile staging, entry phase, node phase, tiles
 };
 
 __global__ void k2_dp(MsaView mv, int32_t l, int read_type, DpResult* res) {
@@ -240,6 +241,229 @@ __global__ void k2_tags_str(const char* pool, const uint64_t* str_off, const uin
     StrColIter f{pool + str_off[2 * i], pool + str_off[2 * i + 1], 0};
     DevStatSink sink{st};
     te_out[i] = emit_tags_from(f, str_len[i], 0u, gap_min_len, tags + tag_off[i], sink);
+}
+
+// ---- wave-per-window chain DP --------------------------------------------------------------------------------
+// k2_resolve (lane per column): for every entry the position of its predecessor node's entry list and the mask of
+// the entries in it whose pp equals this entry's ppp -- everything the DP needs besides the running scores.
+struct EntryDp {
+    uint32_t pred_first;   // global index of the predecessor node's first entry
+    uint32_t pred_mask;    // bit n: predecessor entry n matches (n < 32)
+    uint16_t link;
+    uint16_t meta;         // bit0 head, bits1-3 pp.base, bits4-6 ppp.base, bit7 pp.delta > 0, bit8 ppp.delta > 1, bits9-15 own delta
+};
+__global__ void k2_resolve(MsaView mv, uint32_t n_cols, EntryDp* dp, uint32_t* deep_flag) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_cols) return;
+    const uint32_t e0 = mv.col_off[p], e1 = mv.col_off[p + 1];
+    // only the entries that belong to a node are live: nodes[] holds their ranges
+    const Node* nd = mv.nodes + e0;
+    const uint32_t nn = mv.col_nn[p];
+    if (e1 - e0 > 1024u) atomicOr(deep_flag, 1u);
+    for (uint32_t j = 0; j < nn; ++j) {
+        for (uint32_t m = 0; m < nd[j].len; ++m) {
+            const uint32_t g = e0 + nd[j].start + m;
+            const Entry& em = mv.entries[g];
+            EntryDp d;
+            d.link = (uint16_t)em.link;
+            d.meta = (uint16_t)((key_base(em.pp) & 7u) << 1 | (key_base(em.ppp) & 7u) << 4 | (key_delta(em.pp) > 0 ? 0x80u : 0u) |
+                                (key_delta(em.ppp) > 1 ? 0x100u : 0u) | ((nd[j].key >> 8) < 127u ? (nd[j].key >> 8) : 127u) << 9);
+            if ((nd[j].key >> 8) >= 127u) atomicOr(deep_flag, 1u);
+            d.pred_first = 0;
+            d.pred_mask = 0;
+            if (key_tpos(em.pp) == -1) {
+                d.meta |= 1u;
+            } else {
+                const int32_t tp = key_tpos(em.pp);
+                const Node* ppn = find_node(mv, tp, key_delta(em.pp) << 8 | key_base(em.pp));
+                if (ppn) {
+                    d.pred_first = mv.col_off[tp] + ppn->start;
+                    const Entry* PE = mv.entries + d.pred_first;
+                    for (uint32_t n = 0; n < ppn->len; ++n)
+                        if (PE[n].pp == em.ppp) {
+                            if (n < 32) d.pred_mask |= 1u << n;
+                            else atomicOr(deep_flag, 1u);
+                        }
+                }
+            }
+            dp[g] = d;
+        }
+    }
+}
+
+constexpr uint32_t DPW_RING = 8192, DPW_TILE = 1024;   // score ring (entries), static data staged per tile (entries)
+
+// The per-node loop of get_cns_from_align_tags (dp_column in np2_core.h) touches the predecessor scores only through
+// three aggregates per entry m over its matching predecessor entries n (in list order): whether any matched, the
+// maximum score and the score of the last match.  Proof sketch (rules as in the reference, ens = predecessor score):
+//   score(m) = max(0, max_n(ens) + w)                     [entries start at 0 and are only raised; w = 10 link - C cov]
+//   p_pp_score_ <- max_n(ens) iff max_n(ens) + w > 0        [the last raise happens at the first n attaining the max]
+//   ONT   : if (pp/ppp insertion flags && link test) every match fires: best = m, p_pp_score = ens(last match);
+//           else fires iff link > link(best)/2 && base test && ens > p_pp_score, and once fired best = m keeps the
+//           link test true, so the net effect is best = m iff max_n(ens) > p_pp_score, p_pp_score = max of the two
+//   CLR/HiFi: ens > p || (ens == p && pp.base != '-')  ==>  best = m iff max_n(ens) > p (or >= p when pp.base != '-')
+// so the aggregates are computed by one lane per ENTRY (independent LDS reads), and only the cheap best-index
+// recurrence stays serial per node.
+template <int TYPE>
+__device__ __forceinline__ uint32_t dp_node_select(const EntryDp* E, const long long* emax, const long long* elast, const uint8_t* eany,
+                                                   uint32_t len, uint32_t g0, uint32_t b, long long cov, const long long* ring) {
+    uint32_t best = 0;
+    long long ps_ = INT64_MIN, ps = INT64_MIN;
+    constexpr long long C = TYPE == READS_HIFI ? 4 : 3;
+    int tmp = 0;
+    if (TYPE == READS_ONT)
+        for (uint32_t mi = 0; mi < len; ++mi)
+            if ((int)E[mi].link > tmp) tmp = (int)E[mi].link;
+    for (uint32_t mi = 0; mi < len; ++mi) {
+        const EntryDp em = E[mi];
+        const uint32_t ppb = (em.meta >> 1) & 7u, pppb = (em.meta >> 4) & 7u;
+        const long long score = ring[(g0 + mi) & (DPW_RING - 1)];
+        if (!(em.meta & 1u) && eany[mi]) {
+            const long long mx = emax[mi];
+            if (mx + 10 * (long long)em.link - C * cov > 0) ps_ = mx;
+            if (TYPE == READS_CLR || TYPE == READS_HIFI) {
+                if (mx > ps || (mx == ps && ppb != 4)) { best = mi; ps = mx > ps ? mx : ps; }
+            } else if (TYPE == READS_ONT) {
+                if (((em.meta & 0x100u) || (em.meta & 0x80u)) && ((double)em.link > (double)cov * 0.2 || (int)em.link > tmp / 2)) {
+                    best = mi;
+                    ps = elast[mi];
+                } else if ((int)em.link > (int)E[best].link / 2 && (ppb == 4 || ppb == b || pppb == b || ppb == pppb) && mx > ps) {
+                    best = mi;
+                    ps = mx;
+                }
+            }
+        }
+        const long long bs = ring[(g0 + best) & (DPW_RING - 1)];
+        if (TYPE == READS_RS) {
+            if (score >= bs) { best = mi; ps = ps_; }
+        } else if (score > bs || (score == bs && ppb != 4)) {
+            best = mi;
+            ps = ps_;
+        }
+    }
+    return best;
+}
+
+// One wave walks the window's columns.  Per column and insertion level: lanes = entries (scores + aggregates from the
+// LDS score ring), then lanes = nodes (best-index recurrence).  Static data of up to DPW_TILE entries (<= 64
+// columns) is staged through LDS per tile with coalesced loads.
+template <int TYPE>
+__global__ __launch_bounds__(64) void k2_dp_wave(MsaView mv, const EntryDp* dp, int32_t l, DpResult* res) {
+    __shared__ long long ring[DPW_RING];
+    __shared__ long long s_max[DPW_TILE], s_last[DPW_TILE];
+    __shared__ EntryDp s_e[DPW_TILE];
+    __shared__ Node s_n[DPW_TILE];
+    __shared__ uint8_t s_any[DPW_TILE];
+    __shared__ uint32_t s_off[66];
+    __shared__ uint32_t s_nn[64], s_cov[64], s_lvl[64];   // per column of the tile: nodes, coverage, insertion levels
+    constexpr long long C = TYPE == READS_HIFI ? 4 : 3;
+    const int lane = threadIdx.x;
+    long long gbest = INT64_MIN;
+    uint64_t gkey = node_key(0, 0, 0xff);
+    int32_t p0 = 0;
+    unsigned long long cy0 = 0, cy1 = 0, cy2 = 0, ntile = 0;
+    while (p0 < l) {
+        long long tc = clock64();
+        ++ntile;
+        // ---- tile = columns [p0, p1): as many as fit DPW_TILE entries (at least one, at most 64)
+        const int32_t pc = p0 + lane + 1 <= l ? p0 + lane + 1 : l;
+        const uint32_t base = mv.col_off[p0];
+        const uint32_t myoff = mv.col_off[pc];
+        const unsigned long long fits = __ballot(myoff - base <= DPW_TILE && p0 + lane + 1 <= l);   // a prefix mask (offsets are monotone)
+        int ncol = (int)__popcll(fits);
+        if (ncol == 0) ncol = 1;   // (a single column never exceeds the tile: k2_resolve flags it)
+        const int32_t p1 = p0 + ncol;
+        if (lane < ncol) {
+            s_off[lane + 1] = myoff - base;
+            s_nn[lane] = mv.col_nn[p0 + lane];
+            const ColStat cs = mv.stat[p0 + lane];
+            s_cov[lane] = cs.coverage;
+            s_lvl[lane] = cs.max_size;
+        }
+        if (lane == 0) s_off[0] = 0;
+        const uint32_t ne = __shfl(myoff, ncol - 1) - base;
+        for (uint32_t i = lane; i < ne; i += 64) {
+            s_e[i] = dp[base + i];
+            s_n[i] = mv.nodes[base + i];
+        }
+        __syncthreads();
+        { const long long t = clock64(); cy0 += (unsigned long long)(t - tc); tc = t; }
+        for (int32_t p = p0; p < p1; ++p) {
+            const uint32_t co = s_off[p - p0], cn = s_off[p - p0 + 1] - co;   // entries of the column: [co, co + cn)
+            const uint32_t nn = s_nn[p - p0];
+            const long long cov = s_cov[p - p0];
+            const uint32_t levels = s_lvl[p - p0];
+            for (uint32_t lvl = 0; lvl < levels; ++lvl) {
+                // ---- lanes = entries of this level: score + aggregates
+                for (uint32_t ib = 0; ib < cn; ib += 64) {
+                    const uint32_t i = co + ib + lane;
+                    if (ib + lane < cn) {
+                        const EntryDp em = s_e[i];
+                        if ((uint32_t)(em.meta >> 9) == lvl) {
+                            long long score = 0, mx = INT64_MIN, last = 0;
+                            uint8_t any = 0;
+                            if (em.meta & 1u) {
+                                score = 10 * (long long)em.link - C * cov;
+                            } else {
+                                uint32_t mask = em.pred_mask;
+                                while (mask) {
+                                    const uint32_t n = (uint32_t)__builtin_ctz(mask);
+                                    mask &= mask - 1;
+                                    const long long ens = ring[(em.pred_first + n) & (DPW_RING - 1)];
+                                    if (ens > mx) mx = ens;
+                                    last = ens;
+                                    any = 1;
+                                }
+                                if (any) {
+                                    const long long cand = mx + 10 * (long long)em.link - C * cov;
+                                    if (cand > 0) score = cand;
+                                }
+                            }
+                            ring[(base + i) & (DPW_RING - 1)] = score;
+                            s_max[i] = mx;
+                            s_last[i] = last;
+                            s_any[i] = any;
+                        }
+                    }
+                }
+                __syncthreads();
+                { const long long t = clock64(); cy1 += (unsigned long long)(t - tc); tc = t; }
+                // ---- lanes = nodes of this level: best index
+                for (uint32_t jb = 0; jb < nn; jb += 64) {
+                    const uint32_t j = jb + lane;
+                    if (j < nn) {
+                        Node& nd = s_n[co + j];
+                        if ((nd.key >> 8) == lvl) {
+                            const uint32_t o = co + nd.start;
+                            nd.best = dp_node_select<TYPE>(s_e + o, s_max + o, s_last + o, s_any + o, nd.len, base + o, nd.key & 0xffu, cov, ring);
+                        }
+                    }
+                }
+                __syncthreads();
+                { const long long t = clock64(); cy2 += (unsigned long long)(t - tc); tc = t; }
+            }
+            if (p == l - 1 && lane == 0) {
+                for (uint32_t j = 0; j < nn; ++j) {
+                    const Node& nd = s_n[co + j];
+                    if (!nd.len) continue;
+                    const long long bs = ring[(base + co + nd.start + nd.best) & (DPW_RING - 1)];
+                    if (bs >= gbest) {
+                        gkey = node_key(p, nd.key >> 8, nd.key & 0xffu);
+                        if (bs > gbest) gbest = bs;
+                    }
+                }
+            }
+        }
+        for (uint32_t i = lane; i < ne; i += 64) mv.nodes[base + i].best = s_n[i].best;
+        __syncthreads();
+        p0 = p1;
+    }
+    if (lane == 0) {
+        res->gbest = gbest;
+        res->gkey = gkey;
+        res->status = key_base(gkey) == 0xff ? 1u : 0u;
+        res->cyc[0] = cy0; res->cyc[1] = cy1; res->cyc[2] = cy2; res->cyc[3] = ntile;
+    }
 }
 
 __global__ void k2_dp_lq(MsaView mv, int32_t len, const uint32_t* max_size, DpResult* res) {
@@ -364,7 +588,7 @@ class HipExec : public Exec {
     int device_;
     hipStream_t stream_ = nullptr;
     DevBuf contig_, pos_, ncig_, cigoff_, seqoff_, cigar_, seq_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
-        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_;
+        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, edp_, flag_;
     uint64_t contig_serial_ = ~0ull;
     size_t contig_len_ = 0;
 };
@@ -484,12 +708,37 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     // ---- chain DP + backtrace
     MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
     const uint32_t cons_cap = total + 8;
-    k2_dp<<<1, 64, 0, q>>>(mv, l, in.read_type, res_.as<DpResult>());
+    {
+        // parallel resolve + wave DP; windows with a column too deep for the LDS staging fall back to the one-lane walk
+        static const bool force_lane = getenv("NP2_DP") && strcmp(getenv("NP2_DP"), "lane") == 0;
+        bool wave_ok = !force_lane;
+        if (wave_ok) {
+            if (!edp_.ensure(sizeof(EntryDp) * (size_t)total + 64) || !flag_.ensure(16)) { *err = "out of device memory (dp)"; return false; }
+            HIPOK(hipMemsetAsync(flag_.p, 0, 4, q));
+            k2_resolve<<<nblk(n_cols, 64), 64, 0, q>>>(mv, n_cols, edp_.as<EntryDp>(), flag_.as<uint32_t>());
+            uint32_t deep = 0;
+            HIPOK(hipMemcpyAsync(&deep, flag_.p, 4, hipMemcpyDeviceToHost, q));
+            HIPOK(hipStreamSynchronize(q));
+            clk.mark("resolve");
+            wave_ok = deep == 0;
+        }
+        if (wave_ok) {
+            switch (in.read_type) {
+                case READS_CLR: k2_dp_wave<READS_CLR><<<1, 64, 0, q>>>(mv, edp_.as<EntryDp>(), l, res_.as<DpResult>()); break;
+                case READS_HIFI: k2_dp_wave<READS_HIFI><<<1, 64, 0, q>>>(mv, edp_.as<EntryDp>(), l, res_.as<DpResult>()); break;
+                case READS_RS: k2_dp_wave<READS_RS><<<1, 64, 0, q>>>(mv, edp_.as<EntryDp>(), l, res_.as<DpResult>()); break;
+                default: k2_dp_wave<READS_ONT><<<1, 64, 0, q>>>(mv, edp_.as<EntryDp>(), l, res_.as<DpResult>()); break;
+            }
+        } else {
+            k2_dp<<<1, 64, 0, q>>>(mv, l, in.read_type, res_.as<DpResult>());
+        }
+    }
     clk.mark("dp");
     k2_backtrace<<<1, 64, 0, q>>>(mv, res_.as<DpResult>(), cons_.as<ConsBase>(), cons_cap);
     DpResult res;
     HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
+    if (clk.on) fprintf(stderr, "[np2 dp cycles] tile staging %llu, entry phase %llu, node phase %llu, tiles %llu\n", res.cyc[0], res.cyc[1], res.cyc[2], res.cyc[3]);
     if (res.status == 1) { *err = "no alignment column reaches the end of the window"; return false; }
     if (res.status == 2) { *err = "backtrace left the graph"; return false; }
     if (res.status == 3) { *err = "zero coverage on the consensus path"; return false; }
