@@ -466,7 +466,9 @@ NP2_HD void dp_column(const MsaView& m, int32_t p, int32_t len, long long* gbest
 // Column of the DP variant used on the concatenated low-quality regions (get_lqseqs_from_align_tags, non-HiFi branch,
 // ctg_cns.c:1043-1094): coefficient 2, its own best-predecessor rule, no global best (the caller starts the backtrace
 // at the last node of the last column).
+template <bool kHifi>
 NP2_HD void dp_column_lq(const MsaView& m, int32_t p) {
+    constexpr long long C = kHifi ? 4 : 2;   // HiFi branch: ctg_cns.c:998-1042
     const long long cov = m.stat[p].coverage;
     Node* nd = m.nodes + m.col_off[p];
     const uint32_t nn = m.col_nn[p];
@@ -479,7 +481,7 @@ NP2_HD void dp_column_lq(const MsaView& m, int32_t p) {
         for (uint32_t mi = 0; mi < pb.len; ++mi) {
             Entry& em = E[mi];
             if (key_tpos(em.pp) == -1) {
-                em.score = 10 * (long long)em.link - 2 * cov;
+                em.score = 10 * (long long)em.link - C * cov;
             } else {
                 Node* ppn = find_node(m, key_tpos(em.pp), key_delta(em.pp) << 8 | key_base(em.pp));
                 const uint32_t pl = ppn ? ppn->len : 0u;
@@ -487,14 +489,19 @@ NP2_HD void dp_column_lq(const MsaView& m, int32_t p) {
                 for (uint32_t n = 0; n < pl; ++n) {
                     const Entry& en = PE[n];
                     if (en.pp != em.ppp) continue;
-                    const long long cand = en.score + 10 * (long long)em.link - 2 * cov;
+                    const long long cand = en.score + 10 * (long long)em.link - C * cov;
                     if (cand > em.score) {
                         em.score = cand;
                         p_pp_score_ = en.score;
                     }
                     const uint32_t ppb = key_base(em.pp), pppb = key_base(em.ppp);
-                    if ((int)em.link > (int)E[pb.best].link / 2 && en.score > p_pp_score &&
-                        (ppb == 4 || ppb == b || pppb == b || ppb == pppb)) {
+                    if (kHifi) {
+                        if (en.score > p_pp_score || (en.score == p_pp_score && ppb != 4)) {
+                            pb.best = mi;
+                            p_pp_score = en.score;
+                        }
+                    } else if ((int)em.link > (int)E[pb.best].link / 2 && en.score > p_pp_score &&
+                               (ppb == 4 || ppb == b || pppb == b || ppb == pppb)) {
                         pb.best = mi;
                         p_pp_score = en.score;
                     }

@@ -54,6 +54,7 @@ struct LqInput {
     std::vector<std::string> t, q;   // same length per pair; t uses '-' for insertion columns
     uint32_t t_len = 0;              // target positions (non-gap characters of every t)
     uint32_t gap_min_len = 3;
+    bool hifi = false;               // HiFi branch of the DP (coefficient 4, CLR-style tie rule)
 };
 
 class Exec {

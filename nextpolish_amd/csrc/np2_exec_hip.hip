@@ -466,9 +466,10 @@ __global__ __launch_bounds__(64) void k2_dp_wave(MsaView mv, const EntryDp* dp, 
     }
 }
 
-__global__ void k2_dp_lq(MsaView mv, int32_t len, const uint32_t* max_size, DpResult* res) {
+__global__ void k2_dp_lq(MsaView mv, int32_t len, const uint32_t* max_size, int hifi, DpResult* res) {
     if (blockIdx.x || threadIdx.x) return;
-    for (int32_t p = 0; p < len; ++p) dp_column_lq(mv, p);
+    if (hifi) for (int32_t p = 0; p < len; ++p) dp_column_lq<true>(mv, p);
+    else for (int32_t p = 0; p < len; ++p) dp_column_lq<false>(mv, p);
     res->gkey = node_key(len - 1, max_size[len - 1] - 1, 5);   // last node the reference's loops visit (ctg_cns.c:1036-1038,1090-1092)
     res->status = 0;
     res->gbest = 0;
@@ -830,7 +831,7 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
     const uint32_t cap = total + 8;
     if (!cons_.ensure((size_t)cap + 16)) { *err = "out of device memory (low-quality consensus)"; return false; }
     MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
-    k2_dp_lq<<<1, 64, 0, q>>>(mv, (int32_t)in.t_len, st.max_size, res_.as<DpResult>());
+    k2_dp_lq<<<1, 64, 0, q>>>(mv, (int32_t)in.t_len, st.max_size, in.hifi ? 1 : 0, res_.as<DpResult>());
     k2_backtrace_lq<<<1, 64, 0, q>>>(mv, res_.as<DpResult>(), cons_.as<char>(), cap);
     DpResult res;
     HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));

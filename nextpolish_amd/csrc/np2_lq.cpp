@@ -86,8 +86,64 @@ void remove_short(Region& r) {   // ctg_cns.c:620-633
     reverse_cands(r);
 }
 
-// generate_lqseqs_from_tags; returns max_aln_length
-int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo) {
+// shared tail of the two candidate routines: length-outlier trimming, k-mer ranking, choice of the POA inputs and the
+// pseudo-seed.  min_span: indexe - indexs must exceed it (3, or 1 in the HiFi variant).  Returns false when the region
+// is dropped (r.len = 0).
+bool rank_and_seed(Region& r, std::vector<uint16_t>& kmers, bool trim, int min_span) {
+    int k;
+    if (trim) {
+        sort_by_len_asc(r);
+        k = r.len / 2;
+        while (r.len > k && (r.seqs[(size_t)r.len - 1].len > 2 * r.seqs[(size_t)k].len ||
+                             r.seqs[(size_t)r.len - 1].len >= 1.4 * r.seqs[(size_t)r.len - 2].len)) --r.len;
+        if (k == r.len) { r.len = 0; return false; }
+        k = r.len / 2;
+        if (r.seqs[0].len < r.seqs[(size_t)k].len / 2) {
+            reverse_cands(r);
+            while (r.seqs[(size_t)r.len - 1].len < r.seqs[(size_t)k].len / 2) --r.len;
+            if (k == r.len) { r.len = 0; return false; }
+        }
+    }
+    count_kmers(r, kmers, LQSEQ_MAX_CAN_COUNT, 0);
+    count_kscore(r, kmers, 0);
+    unsigned kmaxlen = r.seqs[0].len;
+    if (kmaxlen > 100) {
+        uint16_t score[LQSEQ_MAX_CAN_COUNT];
+        for (int j = 0; j < r.len; ++j) score[r.seqs[(size_t)j].order] = r.seqs[(size_t)j].kscore;
+        count_kmers(r, kmers, LQSEQ_MAX_CAN_COUNT, 1);
+        count_kscore(r, kmers, 1);
+        for (int j = 0; j < r.len; ++j) r.seqs[(size_t)j].kscore = (uint16_t)(r.seqs[(size_t)j].kscore + score[r.seqs[(size_t)j].order]);
+    }
+    sort_by_kscore_desc(r);
+    kmaxlen = r.seqs[0].len;
+    unsigned klastscore, kmaxscore;
+    klastscore = kmaxscore = r.seqs[0].kscore;
+    int j;
+    for (k = j = 0; j < r.len; ++j) {
+        const Cand& cd = r.seqs[(size_t)j];
+        if ((unsigned)cd.kscore * 10 < kmaxscore || j >= LQSEQ_MAX_COUNT || (unsigned)cd.kscore * 2 < klastscore) break;
+        klastscore = cd.kscore;
+        if (j < KMER_MAX_SEQ && cd.kscore > kmaxscore * 0.8 && cd.len > kmaxlen) { kmaxlen = cd.len; k = j; }
+    }
+    r.indexs = 0;
+    r.indexe = (uint8_t)(kmaxlen > LQSEQ_MAX_REV_LEN && j > 6 ? 5 : j - 1);
+    if (r.indexe - r.indexs <= min_span || (r.seqs[0].len > 20000 && r.len < LQSEQ_MAX_CAN_COUNT / 3)) { r.len = 0; return false; }
+    j = r.indexs;
+    if (r.seqs[0].len < 3000) k = j + 6 < r.indexe ? 6 : r.indexe - j + 1;
+    else k = j + 2 < r.indexe ? 2 : r.indexe - j + 1;
+    if (r.seqs[0].len < 20000) {
+        std::vector<std::string> v;
+        for (int q = 0; q < k; ++q) v.push_back(r.seqs[(size_t)(j + q)].seq);
+        r.sudoseed = poa_consensus(v);
+    } else {
+        r.sudoseed = r.seqs[0].seq;
+    }
+    r.sudoseed_len = (unsigned)r.sudoseed.size();
+    return true;
+}
+
+// generate_lqseqs_from_tags (kmer = false) / generate_lqseqs_from_tags_kmer (HiFi, ctg_cns.c:636-820); returns max_aln_length
+int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo, bool kmer) {
     const int count = (int)lq.size();
     for (Region& r : lq) {
         r.sudoseed.clear();
@@ -118,7 +174,7 @@ int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo) {
             for (uint32_t q = r.start - ts; q < at.size() && (uint32_t)at[q].t_pos <= r.end; ++q)
                 if ((uint32_t)at[q].t_pos >= r.start && at[q].q_base != 4) out.push_back(np2k::int_to_base(at[q].q_base));
             const uint32_t index = (uint32_t)out.size();
-            if ((r.l && index) || index > r.end - r.start + 1) {
+            if (kmer ? index != 0 : ((r.l && index) || index > r.end - r.start + 1)) {
                 r.seqs[(size_t)r.len].len = index;
                 r.seqs[(size_t)r.len].order = (uint16_t)r.len;
                 if (index > r.lqcount) r.lqcount = index;
@@ -132,54 +188,34 @@ int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo) {
     std::vector<uint16_t> kmers(65536);
     for (int i = 0; i < count; ++i) {
         Region& r = lq[(size_t)i];
+        if (kmer) {
+            if (!r.len) continue;
+            // identical candidates vote: a dominant (or the only short) string is taken as it is (ctg_cns.c:719-737)
+            int8_t used[LQSEQ_MAX_CAN_COUNT] = {0};
+            int s = 0;
+            for (int j = 0; j < r.len; ++j) {
+                r.seqs[(size_t)j].kscore = 1;
+                if (used[j]) continue;
+                for (int k = j + 1; k < r.len; ++k)
+                    if (r.seqs[(size_t)j].seq == r.seqs[(size_t)k].seq) { used[k] = 1; ++r.seqs[(size_t)j].kscore; }
+                if (r.seqs[(size_t)j].kscore > r.seqs[(size_t)s].kscore ||
+                    (r.seqs[(size_t)j].kscore == r.seqs[(size_t)s].kscore && r.seqs[(size_t)j].len > r.seqs[(size_t)s].len)) s = j;
+            }
+            const Cand& top = r.seqs[(size_t)s];
+            if ((top.kscore > r.len / 3 || top.len < 10 || r.len <= 4) && (top.kscore != 1 || (r.len != 3 && r.len != 4))) {
+                r.sudoseed = top.seq;
+                r.sudoseed_len = top.len;
+                r.len = -2;
+                r.l = 4;
+            } else if (!rank_and_seed(r, kmers, r.len > 4, 1)) {
+                continue;
+            }
+            if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
+            continue;
+        }
         if (r.l > 1 && r.len > 4) remove_short(r);
         if (r.len <= 4 || r.len < r.sudoseed_len * 0.5) { r.len = 0; continue; }
-        sort_by_len_asc(r);
-        int k = r.len / 2;
-        while (r.len > k && (r.seqs[(size_t)r.len - 1].len > 2 * r.seqs[(size_t)k].len ||
-                             r.seqs[(size_t)r.len - 1].len >= 1.4 * r.seqs[(size_t)r.len - 2].len)) --r.len;
-        if (k == r.len) { r.len = 0; continue; }
-        k = r.len / 2;
-        if (r.seqs[0].len < r.seqs[(size_t)k].len / 2) {
-            reverse_cands(r);
-            while (r.seqs[(size_t)r.len - 1].len < r.seqs[(size_t)k].len / 2) --r.len;
-            if (k == r.len) { r.len = 0; continue; }
-        }
-        count_kmers(r, kmers, LQSEQ_MAX_CAN_COUNT, 0);
-        count_kscore(r, kmers, 0);
-        unsigned kmaxlen = r.seqs[0].len;
-        if (kmaxlen > 100) {
-            uint16_t score[LQSEQ_MAX_CAN_COUNT];
-            for (int j = 0; j < r.len; ++j) score[r.seqs[(size_t)j].order] = r.seqs[(size_t)j].kscore;
-            count_kmers(r, kmers, LQSEQ_MAX_CAN_COUNT, 1);
-            count_kscore(r, kmers, 1);
-            for (int j = 0; j < r.len; ++j) r.seqs[(size_t)j].kscore = (uint16_t)(r.seqs[(size_t)j].kscore + score[r.seqs[(size_t)j].order]);
-        }
-        sort_by_kscore_desc(r);
-        kmaxlen = r.seqs[0].len;
-        unsigned klastscore, kmaxscore;
-        klastscore = kmaxscore = r.seqs[0].kscore;
-        int j;
-        for (k = j = 0; j < r.len; ++j) {
-            const Cand& cd = r.seqs[(size_t)j];
-            if ((unsigned)cd.kscore * 10 < kmaxscore || j >= LQSEQ_MAX_COUNT || (unsigned)cd.kscore * 2 < klastscore) break;
-            klastscore = cd.kscore;
-            if (j < KMER_MAX_SEQ && cd.kscore > kmaxscore * 0.8 && cd.len > kmaxlen) { kmaxlen = cd.len; k = j; }
-        }
-        r.indexs = 0;
-        r.indexe = (uint8_t)(kmaxlen > LQSEQ_MAX_REV_LEN && j > 6 ? 5 : j - 1);
-        if (r.indexe - r.indexs <= 3 || (r.seqs[0].len > 20000 && r.len < LQSEQ_MAX_CAN_COUNT / 3)) { r.len = 0; continue; }
-        j = r.indexs;
-        if (r.seqs[0].len < 3000) k = j + 6 < r.indexe ? 6 : r.indexe - j + 1;
-        else k = j + 2 < r.indexe ? 2 : r.indexe - j + 1;
-        if (r.seqs[0].len < 20000) {
-            std::vector<std::string> v;
-            for (int q = 0; q < k; ++q) v.push_back(r.seqs[(size_t)(j + q)].seq);
-            r.sudoseed = poa_consensus(v);
-        } else {
-            r.sudoseed = r.seqs[0].seq;
-        }
-        r.sudoseed_len = (unsigned)r.sudoseed.size();
+        if (!rank_and_seed(r, kmers, true, 3)) continue;
         if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
     }
     return max_aln_length;
@@ -214,10 +250,11 @@ void fill_with_lqseq(LinkAln& a, const std::string& seed, int seed_len, const st
 }
 
 // generate_consensus_trimed: builds the 30 concatenated alignments and runs the graph consensus on them
-bool consensus_of_regions(Exec* exec, std::vector<Region>& lq, uint32_t gap_min_len, std::string* cons_rev, std::string* err) {
+bool consensus_of_regions(Exec* exec, std::vector<Region>& lq, uint32_t gap_min_len, bool hifi, std::string* cons_rev, std::string* err) {
     const int count = (int)lq.size();
     LqInput in;
     in.gap_min_len = gap_min_len;
+    in.hifi = hifi;
     for (Region& r : lq) r.lqcount = 0;
     int aligned_linkseq_len = 0;
     for (int i = 0; i < LQSEQ_MAX_COUNT; ++i) {
@@ -272,16 +309,16 @@ uint32_t min_cand_len(const Region& r) {
 
 }  // namespace
 
-bool lq_stage(Exec* exec, uint32_t gap_min_len, const std::vector<LqRegionIn>& regions, const WindowOutput& wo,
+bool lq_stage(Exec* exec, uint32_t gap_min_len, bool hifi, const std::vector<LqRegionIn>& regions, const WindowOutput& wo,
               std::vector<ConsBase>* cons, std::string* err) {
     const int count = (int)regions.size();
     std::vector<Region> lq((size_t)count);
     for (int i = 0; i < count; ++i) { lq[(size_t)i].start = regions[(size_t)i].start; lq[(size_t)i].end = regions[(size_t)i].end; lq[(size_t)i].l = regions[(size_t)i].l; }
-    collect_candidates(lq, wo);
+    collect_candidates(lq, wo, hifi);
     // ---- iterate_generate_consensus_trimed (two rounds)
     for (int it = 1; it <= 2; ++it) {
         std::string cr;
-        if (!consensus_of_regions(exec, lq, gap_min_len, &cr, err)) return false;
+        if (!consensus_of_regions(exec, lq, gap_min_len, hifi, &cr, err)) return false;
         int j = count;
         for (size_t k = cr.size(); k; --k) {
             const char c = cr[k - 1];

@@ -22,11 +22,11 @@ bool ond_align(const char* query_seq, int q_len, const char* target_seq, int t_l
 
 struct LqRegionIn {   // one low-quality region of the window consensus (window-relative draft positions, inclusive)
     uint32_t start, end;
-    uint8_t l;         // 0 insertion-driven, 2 / 3 deletion-driven (ctg_cns.c:1577-1583)
+    uint8_t l;         // 0 insertion-driven, 2 / 3 deletion-driven (ctg_cns.c:1577-1583), 4 HiFi low-qv run (ctg_cns.c:1786)
 };
 // Re-consensus of the regions (given in DEscending position order, as the reference builds them) and splice into
 // *cons (the window's main-line consensus).  The graph consensus of the concatenated regions runs in `exec`.
-bool lq_stage(Exec* exec, uint32_t gap_min_len, const std::vector<LqRegionIn>& regions, const WindowOutput& wo,
+bool lq_stage(Exec* exec, uint32_t gap_min_len, bool hifi, const std::vector<LqRegionIn>& regions, const WindowOutput& wo,
               std::vector<ConsBase>* cons, std::string* err);
 
 }  // namespace np2

@@ -9,8 +9,7 @@
 //
 // Low-quality regions go through np2_lq.cpp (candidates, POA pseudo-seed, O(ND) alignment on the host; the graph
 // consensus of the concatenated regions in the executor).
-// Not built yet (fails loudly, never silently): the HiFi variant (ctg_cns.c:636-820,1727-1826) and the structural
-// gap-cluster layer (B15).  See DESIGN.md section "path B".
+// Not built yet (fails loudly, never silently): the structural gap-cluster layer (B15).  See DESIGN.md section "path B".
 #include <cassert>
 #include <cctype>
 #include <climits>
@@ -348,6 +347,42 @@ std::vector<LqReg> lq_regions(const LqCtx& x) {
     return lq;
 }
 
+// HiFi: low-quality runs are found while walking the best path backwards (generate_cns_from_best_score_lq,
+// ctg_cns.c:1727-1826): a run of bases with qv < 80 closed by more than 4 good bases becomes a region (l = 4), padded
+// by 2 bases and merged with the previous one when they touch.  Upper case needs coverage > 4 and qv > 80.
+std::vector<np2::LqRegionIn> hifi_regions(std::vector<ConsBase>* cons, const std::vector<ColStat>& st) {
+    std::vector<np2::LqRegionIn> regs;
+    const int len = (int)cons->size();
+    auto R = [&](int p) -> ConsBase& { return (*cons)[(size_t)(len - 1 - p)]; };   // backtrace order
+    const int lq_min_length = 2;
+    int lq = 0, lq_s = -1, lq_e = -1;
+    for (int p = 0; p < len; ++p) {
+        const uint32_t cov = st[R(p).pos].coverage;
+        const int qv = (int)R(p).qv;
+        if (cov < 4) {
+            lq = 0;
+            lq_s = -1;
+        } else if (qv < 80) {
+            if (lq_s == -1) lq_s = p;
+            lq_e = p;
+            lq = 1;
+        } else if (lq && p - lq_e > 2 * lq_min_length && R(p).pos != R(p - 1).pos) {
+            lq_e = p - lq_min_length - 1;
+            lq_s = lq_s > lq_min_length ? lq_s - lq_min_length : 1;
+            if (!regs.empty() && R(lq_s).pos >= regs.back().start) {
+                regs.back().start = R(lq_e).pos;
+            } else {
+                regs.push_back(np2::LqRegionIn{R(lq_e).pos, R(lq_s).pos, 4});
+            }
+            lq = 0;
+            lq_s = -1;
+        }
+        const char up = (char)toupper(R(p).base);
+        R(p).base = (cov > 4 && qv > 80) ? up : (char)tolower(up);
+    }
+    return regs;
+}
+
 struct WindowCons {
     std::vector<ConsBase> b;
     uint32_t lstrip = 0, rstrip = 0;
@@ -472,7 +507,6 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
     const uint32_t gap_min_len = reads_type != np2k::READS_ONT ? 5 : 3;
     const float gap_min_ratio1 = reads_type != np2k::READS_ONT ? 0.3f : 0.01f;
     const float max_clip_ratio = reads_type == np2k::READS_HIFI ? 0.1f : 0.7f;
-    if (reads_type == np2k::READS_HIFI) np2_die("the HiFi consensus variant (ctg_cns.c:1727-1826) is not built yet", ref->n);
 
     assert(ref->length < INT_MAX);
     std::vector<char> rfseq((size_t)ref->length + 1);
@@ -567,12 +601,15 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
         if (out.seq_count < 150 || rreads_i < 150 || sup_aln_i == 0) brk_g = 0;
         if (brk_g) np2_die("split-read structural layer (gap clusters, ctg_cns.c:3559-3580) is not built yet", ref->n);
         // ---- low-quality regions: their re-consensus is not built yet
-        LqCtx lx{&out.stat, &out.cons, reads_type, gap_min_ratio1};
-        std::vector<LqReg> lq = lq_regions(lx);
-        if (!lq.empty()) {
-            std::vector<np2::LqRegionIn> regs;
-            for (const LqReg& r : lq) regs.push_back(np2::LqRegionIn{r.start, r.end, r.l});
-            if (!np2::lq_stage(cfg->exec, gap_min_len, regs, out, &out.cons, &err)) np2_die(err.c_str(), ref->n);
+        std::vector<np2::LqRegionIn> regs;
+        if (reads_type == np2k::READS_HIFI) {
+            regs = hifi_regions(&out.cons, out.stat);   // also applies the HiFi case rule (qv > 80)
+        } else {
+            LqCtx lx{&out.stat, &out.cons, reads_type, gap_min_ratio1};
+            for (const LqReg& r : lq_regions(lx)) regs.push_back(np2::LqRegionIn{r.start, r.end, r.l});
+        }
+        if (!regs.empty() || reads_type == np2k::READS_HIFI) {
+            if (!np2::lq_stage(cfg->exec, gap_min_len, reads_type == np2k::READS_HIFI, regs, out, &out.cons, &err)) np2_die(err.c_str(), ref->n);
         }
         WindowCons wc;
         wc.b = out.cons;   // update_consensus_trimed with no regions: a copy (ctg_cns.c:1165-1211)
@@ -581,6 +618,9 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
         s = e - cfg->s;
     }
     const double fra = (double)fra_map / (double)(total_map + 1);
-    (void)fra;
+    if (reads_type == np2k::READS_HIFI && fra > 0.1)   // ctg_cns.c:3593-3597
+        fprintf(stderr, "Warning, Too many (%.3f%%) fragment mappings in %s, please polish the genome with other reads first, or"
+                " adjust the mapping parameters to tolerate more errors, such as use asm20/map-pb instead of asm5 for minimap2,"
+                " continue anyway...\n", (double)fra_map * 100 / (double)(total_map + 1), ref->n);
     return link_windows(windows, (int)ref->length, 50, cfg->split, cfg->s);
 }

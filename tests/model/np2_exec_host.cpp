@@ -87,7 +87,10 @@ class HostExec : public Exec {
         g.build(tag_off, aln_t_s, tags, n_streams, n_cols + 32);
         MsaView mv{g.col_off.data(), g.col_nn.data(), g.nodes.data(), g.entries.data(), stat.data()};
         const int32_t len = (int32_t)in.t_len;
-        for (int32_t p = 0; p < len; ++p) dp_column_lq(mv, p);
+        for (int32_t p = 0; p < len; ++p) {
+            if (in.hifi) dp_column_lq<true>(mv, p);
+            else dp_column_lq<false>(mv, p);
+        }
         // start: the last node visited by the reference's loops = (len - 1, max_size - 1, base 5)
         uint64_t cur = node_key(len - 1, (uint32_t)stat[(size_t)len - 1].max_size - 1, 5);
         cons_rev->clear();

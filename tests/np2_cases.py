@@ -16,6 +16,10 @@ CASES = [
     # inputs whose windows contain low-quality regions (>= 3 bp insertions): the re-consensus stage decides the result
     ("ont_lq_regions", dict(seed=10, contig_lens=(30000, 1500, 700), depth=35, max_indel=6), 1),
     ("clr_lq_regions", dict(seed=13, contig_lens=(9000,), depth=60, max_indel=6, sub=0.08), 2),
+    # HiFi (read type 3): its own DP tie rule, low-qv-run regions and identical-candidate vote
+    ("hifi_20x", dict(seed=40, contig_lens=(20000, 6000), depth=20, sub=0.002, ins=0.002, dele=0.002, mean_len=9000, clip_rate=0.02), 3),
+    ("hifi_35x_indels", dict(seed=46, contig_lens=(20000, 6000), depth=35, sub=0.002, ins=0.01, dele=0.008, max_indel=6, mean_len=9000,
+                             clip_rate=0.02), 3),
 ]
 
 # a contig longer than the smallest window the reference accepts (window must exceed 4 x the 1 Mb overlap)

@@ -11,6 +11,7 @@ import sys
 import pytest
 
 import np2_cases
+import np2_gen
 import ref2_binding as rb
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -48,11 +49,17 @@ def test_model_matches_reference_goldens(model, cid, tmp_path):
         assert got[n][0][0] == GOLD["cases"][cid]["expected"][n], "%s %s" % (cid, n)
 
 
-def test_unbuilt_variants_fail_loudly(model, tmp_path):
-    """HiFi consensus variant is not built yet: the library must say so and exit, never approximate."""
-    fa, fofn, contigs = np2_cases.materialise(np2_cases.CASES[1][1], str(tmp_path))
-    got, err = run_polish(model, fa, fofn, 3)
-    assert got is None and "not built yet" in err
+def test_unsupported_cigar_ops_abort_like_the_reference(model, tmp_path):
+    """'=' / 'X' ops: the reference's bam2aln reports "unexpected cigar" and ctg_cns_core exits with "bamaln error"."""
+    from nextpolish_amd import _native as nat
+    contigs, reads = np2_gen.make_case(3, contig_lens=(3000,), depth=6, mean_len=1500)
+    reads[2]["cigar"] = [("=" if o == "M" else o, n) for o, n in reads[2]["cigar"]]
+    st = nat.Stream.from_reads(contigs, reads)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "r.bam")
+    st.write_files(fa, bam)
+    (tmp_path / "bam.fofn").write_text(bam + "\n")
+    got, err = run_polish(model, fa, str(tmp_path / "bam.fofn"), 1)
+    assert got is None and "bamaln error" in err
 
 
 @pytest.mark.skipif(not rb.available(), reason="oracle/_ref not built (reference sources absent)")
