@@ -11,10 +11,13 @@
 //   scan         exclusive scan of the counts -> column buckets
 //   k2_links<1>  lane / stream             scatter the observations
 //   k2_build     lane / column             order the bucket by (stream, delta), first-seen entry lists with link counts
-//   k2_dp        one lane                  chain DP, column after column (sequential in the reference too)  [get_cns_from_align_tags]
-//   k2_backtrace one lane                  best path -> consensus bases                       [generate_cns_from_best_score]
-// Bounds: tags/links/build stream every alignment column once (HBM); k2_dp is latency bound -- the (A, C)
-// run decomposition described in DESIGN.md is the next step for it.
+//   k2_cut_flags/scan/k2_cut_list          single-entry columns = cuts between independent runs
+//   k2_run_ac    wave / run (first lane)   (a, c) of every entry, (A, C) of the run: x -> max(C, x + A)        [get_cns_from_align_tags]
+//   k2_run_scan  one lane                  score at every cut
+//   k2_run_dp    wave / run (first lane)   the reference's literal DP on the run's columns with its true entry score
+//   k2_bt_runs   wave / run (first lane)   best path per run: count, scan, write               [generate_cns_from_best_score]
+// Bounds: tags/links/build stream every alignment column once (HBM); the run kernels are latency bound per run and
+// parallel across the thousands of runs of a window.
 #include <hip/hip_runtime.h>
 #include <time.h>
 #include <unistd.h>
@@ -185,53 +188,7 @@ struct DpResult {
     long long gbest;
     uint64_t gkey;
     uint32_t cons_len, status;   // status: 0 ok, 1 no end column, 2 backtrace left the graph, 3 zero coverage
-    unsigned long long cyc[4];   // k2_dp_wave: cycles in tile staging, entry phase, node phase, tiles
 };
-
-__global__ void k2_dp(MsaView mv, int32_t l, int read_type, DpResult* res) {
-    if (blockIdx.x || threadIdx.x) return;
-    long long gbest = INT64_MIN;
-    uint64_t gkey = node_key(0, 0, 0xff);
-    for (int32_t p = 0; p < l; ++p) {
-        switch (read_type) {
-            case READS_CLR: dp_column<READS_CLR>(mv, p, l, &gbest, &gkey); break;
-            case READS_HIFI: dp_column<READS_HIFI>(mv, p, l, &gbest, &gkey); break;
-            case READS_RS: dp_column<READS_RS>(mv, p, l, &gbest, &gkey); break;
-            default: dp_column<READS_ONT>(mv, p, l, &gbest, &gkey); break;
-        }
-    }
-    res->gbest = gbest;
-    res->gkey = gkey;
-    res->status = key_base(gkey) == 0xff ? 1u : 0u;
-}
-
-// writes the consensus backwards into cons[cap-1], cons[cap-2], ...; the host reads the last cons_len items
-__global__ void k2_backtrace(MsaView mv, DpResult* res, ConsBase* cons, uint32_t cap) {
-    if (blockIdx.x || threadIdx.x) return;
-    if (res->status) return;
-    uint64_t cur = res->gkey;
-    uint32_t n = 0;
-    for (;;) {
-        const int32_t tp = key_tpos(cur);
-        Node* nd = find_node(mv, tp, key_delta(cur) << 8 | key_base(cur));
-        if (!nd) { res->status = 2; break; }
-        const Entry& be = mv.entries[mv.col_off[tp] + nd->start + nd->best];
-        if (key_base(cur) != 4) {
-            const uint32_t cov = mv.stat[tp].coverage;
-            if (cov == 0 || n >= cap) { res->status = 3; break; }
-            ConsBase cb;
-            cb.qv = (char)(100 * be.link / cov);
-            const char up = int_to_base(key_base(cur));
-            cb.base = (cov > 4u && cb.qv > 20) ? up : (char)(up >= 'A' && up <= 'Z' ? up + 32 : up);
-            cb.pos = (uint32_t)tp;
-            cons[cap - 1 - n] = cb;
-            ++n;
-        }
-        cur = be.pp;
-        if (key_tpos(cur) == -1) break;
-    }
-    res->cons_len = n;
-}
 
 // tag streams of gapped string pairs (the concatenated low-quality regions); one lane per pair
 __global__ void k2_tags_str(const char* pool, const uint64_t* str_off, const uint32_t* str_len, uint32_t n, uint32_t gap_min_len,
@@ -243,258 +200,191 @@ __global__ void k2_tags_str(const char* pool, const uint64_t* str_off, const uin
     te_out[i] = emit_tags_from(f, str_len[i], 0u, gap_min_len, tags + tag_off[i], sink);
 }
 
-// ---- wave-per-window chain DP --------------------------------------------------------------------------------
-// k2_resolve (lane per column): for every entry the position of its predecessor node's entry list and the mask of
-// the entries in it whose pp equals this entry's ppp -- everything the DP needs besides the running scores.
-struct EntryDp {
-    uint32_t pred_first;   // global index of the predecessor node's first entry
-    uint32_t pred_mask;    // bit n: predecessor entry n matches (n < 32)
-    uint16_t link;
-    uint16_t meta;         // bit0 head, bits1-3 pp.base, bits4-6 ppp.base, bit7 pp.delta > 0, bit8 ppp.delta > 1, bits9-15 own delta
-};
-__global__ void k2_resolve(MsaView mv, uint32_t n_cols, EntryDp* dp, uint32_t* deep_flag) {
+// ---- run-decomposed chain DP ---------------------------------------------------------------------------------
+// A column that holds ONE node with ONE entry and no insertion level is a cut: everything to its right depends on
+// the left part of the window only through that entry's score x.  Scores obey v = max(0, max_n(v_n) + w) (entries
+// start at 0 and are only raised; stream heads inject constants), so along a run between two cuts every entry is a
+// function f(x) = max(c, x + a) and the run as a whole maps x -> max(C, x + A):
+//   k2_cut_flags / scan / k2_cut_list   the cuts, in order
+//   k2_run_ac     lane per run: (a, c) of every entry of the run, (A, C) of the run        [parallel]
+//   k2_run_scan   x at every cut from the (A, C) chain, written into the cut entries      [one lane, #runs steps]
+//   k2_run_dp     lane per run: the literal DP of the reference on its columns, with the true x at its left cut
+// Best-index rules compare real scores, which is why the literal pass runs after the scan instead of being patched.
+constexpr int RULE_LQ = 5, RULE_LQ_HIFI = 6;   // DP rules of the low-quality re-consensus, next to READS_ONT..READS_RS
+constexpr long long AC_NEG = INT64_MIN / 4;   // "-infinity" that survives adding a column weight
+
+__global__ void k2_cut_flags(MsaView mv, uint32_t n_cols, uint32_t* flag) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_cols) return;
-    const uint32_t e0 = mv.col_off[p], e1 = mv.col_off[p + 1];
-    // only the entries that belong to a node are live: nodes[] holds their ranges
-    const Node* nd = mv.nodes + e0;
-    const uint32_t nn = mv.col_nn[p];
-    if (e1 - e0 > 1024u) atomicOr(deep_flag, 1u);
-    for (uint32_t j = 0; j < nn; ++j) {
-        for (uint32_t m = 0; m < nd[j].len; ++m) {
-            const uint32_t g = e0 + nd[j].start + m;
-            const Entry& em = mv.entries[g];
-            EntryDp d;
-            d.link = (uint16_t)em.link;
-            d.meta = (uint16_t)((key_base(em.pp) & 7u) << 1 | (key_base(em.ppp) & 7u) << 4 | (key_delta(em.pp) > 0 ? 0x80u : 0u) |
-                                (key_delta(em.ppp) > 1 ? 0x100u : 0u) | ((nd[j].key >> 8) < 127u ? (nd[j].key >> 8) : 127u) << 9);
-            if ((nd[j].key >> 8) >= 127u) atomicOr(deep_flag, 1u);
-            d.pred_first = 0;
-            d.pred_mask = 0;
-            if (key_tpos(em.pp) == -1) {
-                d.meta |= 1u;
-            } else {
-                const int32_t tp = key_tpos(em.pp);
-                const Node* ppn = find_node(mv, tp, key_delta(em.pp) << 8 | key_base(em.pp));
-                if (ppn) {
-                    d.pred_first = mv.col_off[tp] + ppn->start;
-                    const Entry* PE = mv.entries + d.pred_first;
-                    for (uint32_t n = 0; n < ppn->len; ++n)
-                        if (PE[n].pp == em.ppp) {
-                            if (n < 32) d.pred_mask |= 1u << n;
-                            else atomicOr(deep_flag, 1u);
+    if (p > n_cols) return;
+    uint32_t f = 0;
+    if (p < n_cols) f = (mv.col_nn[p] == 1 && mv.nodes[mv.col_off[p]].len == 1 && mv.stat[p].max_size == 1) ? 1u : 0u;
+    flag[p] = f;
+}
+__global__ void k2_cut_list(const uint32_t* flag, const uint32_t* pos, uint32_t n_cols, uint32_t* cuts) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_cols && flag[p]) cuts[pos[p]] = p;
+}
+
+struct RunAC { long long A, C; };
+
+// run r covers columns (lo, hi]: lo = cuts[r-1] (or -1), hi = cuts[r] (or l-1 for the last run)
+__device__ __forceinline__ void run_bounds(const uint32_t* cuts, uint32_t n_cuts, uint32_t r, int32_t l, int32_t* lo, int32_t* hi) {
+    *lo = r == 0 ? -1 : (int32_t)cuts[r - 1];
+    *hi = r < n_cuts ? (int32_t)cuts[r] : l - 1;
+}
+
+__global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, long long C, long long* ea, long long* ec, RunAC* out) {
+    // one run per WAVE, walked by its first lane: the loops are data dependent, and 64 unrelated runs in one wave would
+    // serialise each other's branches; the chip has room for thousands of such waves
+    const uint32_t r = blockIdx.x;
+    if (r >= n_runs || threadIdx.x) return;
+    int32_t lo, hi;
+    run_bounds(cuts, n_cuts, r, l, &lo, &hi);
+    // the left cut's single entry is the identity f(x) = x; it is also the right cut of the previous run, whose lane
+    // keeps that entry's (a, c) in registers, so neither lane stores it
+    const uint32_t gl = lo >= 0 ? mv.col_off[lo] + mv.nodes[mv.col_off[lo]].start : 0xffffffffu;
+    RunAC o{AC_NEG, AC_NEG};
+    for (int32_t p = lo + 1; p <= hi; ++p) {
+        const long long cov = mv.stat[p].coverage;
+        const Node* nd = mv.nodes + mv.col_off[p];
+        const uint32_t nn = mv.col_nn[p];
+        for (uint32_t j = 0; j < nn; ++j) {
+            for (uint32_t m = 0; m < nd[j].len; ++m) {
+                const uint32_t g = mv.col_off[p] + nd[j].start + m;
+                const Entry& em = mv.entries[g];
+                const long long w = 10 * (long long)em.link - C * cov;
+                long long a = AC_NEG, c = 0;
+                if (key_tpos(em.pp) == -1) {
+                    c = w;   // assigned directly, may be negative
+                } else {
+                    const int32_t tp = key_tpos(em.pp);
+                    const Node* ppn = find_node(mv, tp, key_delta(em.pp) << 8 | key_base(em.pp));
+                    long long am = AC_NEG, cm = AC_NEG;
+                    if (ppn) {
+                        const uint32_t g0 = mv.col_off[tp] + ppn->start;
+                        for (uint32_t n = 0; n < ppn->len; ++n) {
+                            if (mv.entries[g0 + n].pp != em.ppp) continue;
+                            const long long an = g0 + n == gl ? 0 : ea[g0 + n], cn = g0 + n == gl ? AC_NEG : ec[g0 + n];
+                            if (an > am) am = an;
+                            if (cn > cm) cm = cn;
                         }
+                    }
+                    a = am > AC_NEG ? am + w : AC_NEG;
+                    const long long cw = cm > AC_NEG ? cm + w : AC_NEG;
+                    c = cw > 0 ? cw : 0;
                 }
+                if (p == hi && r < n_cuts) { o.A = a; o.C = c; }   // the right cut's single entry
+                else { ea[g] = a; ec[g] = c; }
             }
-            dp[g] = d;
         }
+    }
+    out[r] = o;
+}
+
+// x at every cut; the cut entries get their true score so the literal pass can start from it
+__global__ void k2_run_scan(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, const RunAC* ac) {
+    if (blockIdx.x || threadIdx.x) return;
+    long long x = AC_NEG;
+    for (uint32_t r = 0; r < n_cuts; ++r) {
+        const long long via = (x > AC_NEG && ac[r].A > AC_NEG) ? x + ac[r].A : AC_NEG;
+        x = via > ac[r].C ? via : ac[r].C;
+        const uint32_t p = cuts[r];
+        mv.entries[mv.col_off[p] + mv.nodes[mv.col_off[p]].start].score = x;
     }
 }
 
-constexpr uint32_t DPW_RING = 8192, DPW_TILE = 1024;   // score ring (entries), static data staged per tile (entries)
-
-// The per-node loop of get_cns_from_align_tags (dp_column in np2_core.h) touches the predecessor scores only through
-// three aggregates per entry m over its matching predecessor entries n (in list order): whether any matched, the
-// maximum score and the score of the last match.  Proof sketch (rules as in the reference, ens = predecessor score):
-//   score(m) = max(0, max_n(ens) + w)                     [entries start at 0 and are only raised; w = 10 link - C cov]
-//   p_pp_score_ <- max_n(ens) iff max_n(ens) + w > 0        [the last raise happens at the first n attaining the max]
-//   ONT   : if (pp/ppp insertion flags && link test) every match fires: best = m, p_pp_score = ens(last match);
-//           else fires iff link > link(best)/2 && base test && ens > p_pp_score, and once fired best = m keeps the
-//           link test true, so the net effect is best = m iff max_n(ens) > p_pp_score, p_pp_score = max of the two
-//   CLR/HiFi: ens > p || (ens == p && pp.base != '-')  ==>  best = m iff max_n(ens) > p (or >= p when pp.base != '-')
-// so the aggregates are computed by one lane per ENTRY (independent LDS reads), and only the cheap best-index
-// recurrence stays serial per node.
 template <int TYPE>
-__device__ __forceinline__ uint32_t dp_node_select(const EntryDp* E, const long long* emax, const long long* elast, const uint8_t* eany,
-                                                   uint32_t len, uint32_t g0, uint32_t b, long long cov, const long long* ring) {
-    uint32_t best = 0;
-    long long ps_ = INT64_MIN, ps = INT64_MIN;
-    constexpr long long C = TYPE == READS_HIFI ? 4 : 3;
-    int tmp = 0;
-    if (TYPE == READS_ONT)
-        for (uint32_t mi = 0; mi < len; ++mi)
-            if ((int)E[mi].link > tmp) tmp = (int)E[mi].link;
-    for (uint32_t mi = 0; mi < len; ++mi) {
-        const EntryDp em = E[mi];
-        const uint32_t ppb = (em.meta >> 1) & 7u, pppb = (em.meta >> 4) & 7u;
-        const long long score = ring[(g0 + mi) & (DPW_RING - 1)];
-        if (!(em.meta & 1u) && eany[mi]) {
-            const long long mx = emax[mi];
-            if (mx + 10 * (long long)em.link - C * cov > 0) ps_ = mx;
-            if (TYPE == READS_CLR || TYPE == READS_HIFI) {
-                if (mx > ps || (mx == ps && ppb != 4)) { best = mi; ps = mx > ps ? mx : ps; }
-            } else if (TYPE == READS_ONT) {
-                if (((em.meta & 0x100u) || (em.meta & 0x80u)) && ((double)em.link > (double)cov * 0.2 || (int)em.link > tmp / 2)) {
-                    best = mi;
-                    ps = elast[mi];
-                } else if ((int)em.link > (int)E[best].link / 2 && (ppb == 4 || ppb == b || pppb == b || ppb == pppb) && mx > ps) {
-                    best = mi;
-                    ps = mx;
-                }
-            }
-        }
-        const long long bs = ring[(g0 + best) & (DPW_RING - 1)];
-        if (TYPE == READS_RS) {
-            if (score >= bs) { best = mi; ps = ps_; }
-        } else if (score > bs || (score == bs && ppb != 4)) {
-            best = mi;
-            ps = ps_;
-        }
-    }
-    return best;
-}
-
-// One wave walks the window's columns.  Per column and insertion level: lanes = entries (scores + aggregates from the
-// LDS score ring), then lanes = nodes (best-index recurrence).  Static data of up to DPW_TILE entries (<= 64
-// columns) is staged through LDS per tile with coalesced loads.
-template <int TYPE>
-__global__ __launch_bounds__(64) void k2_dp_wave(MsaView mv, const EntryDp* dp, int32_t l, DpResult* res) {
-    __shared__ long long ring[DPW_RING];
-    __shared__ long long s_max[DPW_TILE], s_last[DPW_TILE];
-    __shared__ EntryDp s_e[DPW_TILE];
-    __shared__ Node s_n[DPW_TILE];
-    __shared__ uint8_t s_any[DPW_TILE];
-    __shared__ uint32_t s_off[66];
-    __shared__ uint32_t s_nn[64], s_cov[64], s_lvl[64];   // per column of the tile: nodes, coverage, insertion levels
-    constexpr long long C = TYPE == READS_HIFI ? 4 : 3;
-    const int lane = threadIdx.x;
+__global__ void k2_run_dp(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, DpResult* res) {
+    const uint32_t r = blockIdx.x;
+    if (r >= n_runs || threadIdx.x) return;
+    int32_t lo, hi;
+    run_bounds(cuts, n_cuts, r, l, &lo, &hi);
     long long gbest = INT64_MIN;
     uint64_t gkey = node_key(0, 0, 0xff);
-    int32_t p0 = 0;
-    unsigned long long cy0 = 0, cy1 = 0, cy2 = 0, ntile = 0;
-    while (p0 < l) {
-        long long tc = clock64();
-        ++ntile;
-        // ---- tile = columns [p0, p1): as many as fit DPW_TILE entries (at least one, at most 64)
-        const int32_t pc = p0 + lane + 1 <= l ? p0 + lane + 1 : l;
-        const uint32_t base = mv.col_off[p0];
-        const uint32_t myoff = mv.col_off[pc];
-        const unsigned long long fits = __ballot(myoff - base <= DPW_TILE && p0 + lane + 1 <= l);   // a prefix mask (offsets are monotone)
-        int ncol = (int)__popcll(fits);
-        if (ncol == 0) ncol = 1;   // (a single column never exceeds the tile: k2_resolve flags it)
-        const int32_t p1 = p0 + ncol;
-        if (lane < ncol) {
-            s_off[lane + 1] = myoff - base;
-            s_nn[lane] = mv.col_nn[p0 + lane];
-            const ColStat cs = mv.stat[p0 + lane];
-            s_cov[lane] = cs.coverage;
-            s_lvl[lane] = cs.max_size;
-        }
-        if (lane == 0) s_off[0] = 0;
-        const uint32_t ne = __shfl(myoff, ncol - 1) - base;
-        for (uint32_t i = lane; i < ne; i += 64) {
-            s_e[i] = dp[base + i];
-            s_n[i] = mv.nodes[base + i];
-        }
-        __syncthreads();
-        { const long long t = clock64(); cy0 += (unsigned long long)(t - tc); tc = t; }
-        for (int32_t p = p0; p < p1; ++p) {
-            const uint32_t co = s_off[p - p0], cn = s_off[p - p0 + 1] - co;   // entries of the column: [co, co + cn)
-            const uint32_t nn = s_nn[p - p0];
-            const long long cov = s_cov[p - p0];
-            const uint32_t levels = s_lvl[p - p0];
-            for (uint32_t lvl = 0; lvl < levels; ++lvl) {
-                // ---- lanes = entries of this level: score + aggregates
-                for (uint32_t ib = 0; ib < cn; ib += 64) {
-                    const uint32_t i = co + ib + lane;
-                    if (ib + lane < cn) {
-                        const EntryDp em = s_e[i];
-                        if ((uint32_t)(em.meta >> 9) == lvl) {
-                            long long score = 0, mx = INT64_MIN, last = 0;
-                            uint8_t any = 0;
-                            if (em.meta & 1u) {
-                                score = 10 * (long long)em.link - C * cov;
-                            } else {
-                                uint32_t mask = em.pred_mask;
-                                while (mask) {
-                                    const uint32_t n = (uint32_t)__builtin_ctz(mask);
-                                    mask &= mask - 1;
-                                    const long long ens = ring[(em.pred_first + n) & (DPW_RING - 1)];
-                                    if (ens > mx) mx = ens;
-                                    last = ens;
-                                    any = 1;
-                                }
-                                if (any) {
-                                    const long long cand = mx + 10 * (long long)em.link - C * cov;
-                                    if (cand > 0) score = cand;
-                                }
-                            }
-                            ring[(base + i) & (DPW_RING - 1)] = score;
-                            s_max[i] = mx;
-                            s_last[i] = last;
-                            s_any[i] = any;
-                        }
-                    }
-                }
-                __syncthreads();
-                { const long long t = clock64(); cy1 += (unsigned long long)(t - tc); tc = t; }
-                // ---- lanes = nodes of this level: best index
-                for (uint32_t jb = 0; jb < nn; jb += 64) {
-                    const uint32_t j = jb + lane;
-                    if (j < nn) {
-                        Node& nd = s_n[co + j];
-                        if ((nd.key >> 8) == lvl) {
-                            const uint32_t o = co + nd.start;
-                            nd.best = dp_node_select<TYPE>(s_e + o, s_max + o, s_last + o, s_any + o, nd.len, base + o, nd.key & 0xffu, cov, ring);
-                        }
-                    }
-                }
-                __syncthreads();
-                { const long long t = clock64(); cy2 += (unsigned long long)(t - tc); tc = t; }
-            }
-            if (p == l - 1 && lane == 0) {
-                for (uint32_t j = 0; j < nn; ++j) {
-                    const Node& nd = s_n[co + j];
-                    if (!nd.len) continue;
-                    const long long bs = ring[(base + co + nd.start + nd.best) & (DPW_RING - 1)];
-                    if (bs >= gbest) {
-                        gkey = node_key(p, nd.key >> 8, nd.key & 0xffu);
-                        if (bs > gbest) gbest = bs;
-                    }
-                }
-            }
-        }
-        for (uint32_t i = lane; i < ne; i += 64) mv.nodes[base + i].best = s_n[i].best;
-        __syncthreads();
-        p0 = p1;
+    // the right cut column is left to the scan's value for its score; its node still needs its (trivial) best index
+    for (int32_t p = lo + 1; p <= hi; ++p) {
+        if (p == hi && r < n_cuts) { mv.nodes[mv.col_off[p]].best = 0; continue; }
+        if (TYPE == RULE_LQ) dp_column_lq<false>(mv, p);
+        else if (TYPE == RULE_LQ_HIFI) dp_column_lq<true>(mv, p);
+        else dp_column<TYPE == RULE_LQ || TYPE == RULE_LQ_HIFI ? READS_ONT : TYPE>(mv, p, l, &gbest, &gkey);
     }
-    if (lane == 0) {
+    if (hi == l - 1) {
+        if (r < n_cuts) {   // the window ends on a cut column: the global best is its single node
+            const Node& nd = mv.nodes[mv.col_off[hi]];
+            gbest = mv.entries[mv.col_off[hi] + nd.start].score;
+            gkey = node_key(hi, nd.key >> 8, nd.key & 0xffu);
+        } else if (TYPE == RULE_LQ || TYPE == RULE_LQ_HIFI) {
+            gkey = node_key(hi, (uint32_t)mv.stat[hi].max_size - 1, 5);   // last node the reference's loops visit (ctg_cns.c:1036-1038,1090-1092)
+        }
         res->gbest = gbest;
         res->gkey = gkey;
         res->status = key_base(gkey) == 0xff ? 1u : 0u;
-        res->cyc[0] = cy0; res->cyc[1] = cy1; res->cyc[2] = cy2; res->cyc[3] = ntile;
     }
 }
 
-__global__ void k2_dp_lq(MsaView mv, int32_t len, const uint32_t* max_size, int hifi, DpResult* res) {
-    if (blockIdx.x || threadIdx.x) return;
-    if (hifi) for (int32_t p = 0; p < len; ++p) dp_column_lq<true>(mv, p);
-    else for (int32_t p = 0; p < len; ++p) dp_column_lq<false>(mv, p);
-    res->gkey = node_key(len - 1, max_size[len - 1] - 1, 5);   // last node the reference's loops visit (ctg_cns.c:1036-1038,1090-1092)
-    res->status = 0;
-    res->gbest = 0;
-}
+// ---- parallel backtrace over the runs --------------------------------------------------------------------------
+// The best path passes through the single node of every cut column, so the walk of one run (from its right cut, or
+// from the global best node for the last run, down to its left cut) is independent of the others.  Pass 1 counts the
+// emitted bases per run and notes runs whose walk ends on a stream head before reaching the left cut (the whole
+// path ends there); a scan places the runs; pass 2 walks again and writes.  kLq: character output of the
+// low-quality re-consensus (ctg_cns.c:1104-1143) instead of consensus bases (:1836-1858).
+struct BtCtl { uint32_t r_end; uint32_t pad; };
 
-// backtrace of get_lqseqs_from_align_tags (ctg_cns.c:1104-1143): characters in backtrace order, no reversal
-__global__ void k2_backtrace_lq(MsaView mv, DpResult* res, char* out, uint32_t cap) {
-    if (blockIdx.x || threadIdx.x) return;
-    uint64_t cur = res->gkey;
+template <bool kLq, bool kWrite>
+__global__ void k2_bt_runs(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, uint32_t* cnt,
+                           BtCtl* ctl, const uint32_t* off, ConsBase* cons, char* chars, uint32_t* status) {
+    const uint32_t r = blockIdx.x;
+    if (r >= n_runs || threadIdx.x) return;
+    if (kWrite && r < ctl->r_end) return;
+    int32_t lo, hi;
+    run_bounds(cuts, n_cuts, r, l, &lo, &hi);
+    uint64_t cur;
+    if (r < n_cuts) {
+        const Node& nd = mv.nodes[mv.col_off[hi]];
+        cur = node_key(hi, nd.key >> 8, nd.key & 0xffu);
+    } else {
+        cur = res->gkey;
+    }
     uint32_t n = 0;
+    const uint32_t base_off = kWrite ? off[r] : 0u, total = kWrite ? cnt[r] : 0u;
+    bool ended = false;
     for (;;) {
         const int32_t tp = key_tpos(cur);
         Node* nd = find_node(mv, tp, key_delta(cur) << 8 | key_base(cur));
-        if (!nd || nd->len == 0) { res->status = 2; break; }
+        if (!nd || nd->len == 0) { atomicMax(status, 2u); break; }
         const Entry& be = mv.entries[mv.col_off[tp] + nd->start + nd->best];
         if (key_base(cur) != 4) {
-            if (n >= cap) { res->status = 3; break; }
-            const char up = int_to_base(key_base(cur));
-            const uint32_t q = be.link & 0xffffu;
-            out[n++] = (q * 5 > mv.stat[tp].coverage || up == 'N') ? up : (char)(up >= 'A' && up <= 'Z' ? up + 32 : up);
+            if (kWrite) {
+                const uint32_t at = base_off + (total - 1 - n);   // forward order inside the run
+                const uint32_t cov = mv.stat[tp].coverage;
+                const char up = int_to_base(key_base(cur));
+                const char low = (char)(up >= 'A' && up <= 'Z' ? up + 32 : up);
+                if (kLq) {
+                    chars[at] = ((be.link & 0xffffu) * 5 > cov || up == 'N') ? up : low;
+                } else {
+                    ConsBase cb;
+                    cb.qv = (char)(100 * be.link / cov);
+                    cb.base = (cov > 4u && cb.qv > 20) ? up : low;
+                    cb.pos = (uint32_t)tp;
+                    cons[at] = cb;
+                }
+            } else if (!kLq && mv.stat[tp].coverage == 0) {
+                atomicMax(status, 3u);
+            }
+            ++n;
         }
         cur = be.pp;
-        if (key_tpos(cur) == -1) break;
+        if (key_tpos(cur) == -1) { ended = true; break; }
+        if (key_tpos(cur) <= lo) break;   // reached the left cut's node: it starts the previous run's walk
     }
-    res->cons_len = n;
+    if (!kWrite) {
+        cnt[r] = n;
+        if (ended) atomicMax(&ctl->r_end, r);
+    }
+}
+__global__ void k2_bt_mask(uint32_t* cnt, uint32_t n_runs, const BtCtl* ctl) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_runs && r < ctl->r_end) cnt[r] = 0;
 }
 
 // ---- exclusive scan of uint32 counts (three launches: block sums, scan of the sums, final)
@@ -585,11 +475,12 @@ class HipExec : public Exec {
 
   private:
     // link observations -> column buckets -> nodes/entries for n_streams tag streams over n_cols columns; *total = entries
-    bool build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total, std::string* err);
+    bool build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total, std::string* err, struct StageClock* clk = nullptr);
+    bool solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t total, int rule, uint32_t* cons_len, struct StageClock* clk, std::string* err);
     int device_;
     hipStream_t stream_ = nullptr;
     DevBuf contig_, pos_, ncig_, cigoff_, seqoff_, cigar_, seq_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
-        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, edp_, flag_;
+        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, cutflag_, cutpos_, cuts_, ea_, ec_, runac_, btcnt_, btoff_;
     uint64_t contig_serial_ = ~0ull;
     size_t contig_len_ = 0;
 };
@@ -703,64 +594,101 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     HIPOK(hipMemcpyAsync(alnts_.p, out->aln_t_s.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
     clk.mark("tags");
     uint32_t total = 0;
-    if (!build_graph(n_streams, n_cols, &total, err)) return false;
+    if (!build_graph(n_streams, n_cols, &total, err, &clk)) return false;
     if (!cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) { *err = "out of device memory (consensus)"; return false; }
-    clk.mark("links+build");
+    clk.mark("build");
     // ---- chain DP + backtrace
     MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
-    const uint32_t cons_cap = total + 8;
-    {
-        // parallel resolve + wave DP; windows with a column too deep for the LDS staging fall back to the one-lane walk
-        static const bool force_lane = getenv("NP2_DP") && strcmp(getenv("NP2_DP"), "lane") == 0;
-        bool wave_ok = !force_lane;
-        if (wave_ok) {
-            if (!edp_.ensure(sizeof(EntryDp) * (size_t)total + 64) || !flag_.ensure(16)) { *err = "out of device memory (dp)"; return false; }
-            HIPOK(hipMemsetAsync(flag_.p, 0, 4, q));
-            k2_resolve<<<nblk(n_cols, 64), 64, 0, q>>>(mv, n_cols, edp_.as<EntryDp>(), flag_.as<uint32_t>());
-            uint32_t deep = 0;
-            HIPOK(hipMemcpyAsync(&deep, flag_.p, 4, hipMemcpyDeviceToHost, q));
-            HIPOK(hipStreamSynchronize(q));
-            clk.mark("resolve");
-            wave_ok = deep == 0;
-        }
-        if (wave_ok) {
-            switch (in.read_type) {
-                case READS_CLR: k2_dp_wave<READS_CLR><<<1, 64, 0, q>>>(mv, edp_.as<EntryDp>(), l, res_.as<DpResult>()); break;
-                case READS_HIFI: k2_dp_wave<READS_HIFI><<<1, 64, 0, q>>>(mv, edp_.as<EntryDp>(), l, res_.as<DpResult>()); break;
-                case READS_RS: k2_dp_wave<READS_RS><<<1, 64, 0, q>>>(mv, edp_.as<EntryDp>(), l, res_.as<DpResult>()); break;
-                default: k2_dp_wave<READS_ONT><<<1, 64, 0, q>>>(mv, edp_.as<EntryDp>(), l, res_.as<DpResult>()); break;
-            }
-        } else {
-            k2_dp<<<1, 64, 0, q>>>(mv, l, in.read_type, res_.as<DpResult>());
-        }
-    }
-    clk.mark("dp");
-    k2_backtrace<<<1, 64, 0, q>>>(mv, res_.as<DpResult>(), cons_.as<ConsBase>(), cons_cap);
-    DpResult res;
-    HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));
-    HIPOK(hipStreamSynchronize(q));
-    if (clk.on) fprintf(stderr, "[np2 dp cycles] tile staging %llu, entry phase %llu, node phase %llu, tiles %llu\n", res.cyc[0], res.cyc[1], res.cyc[2], res.cyc[3]);
-    if (res.status == 1) { *err = "no alignment column reaches the end of the window"; return false; }
-    if (res.status == 2) { *err = "backtrace left the graph"; return false; }
-    if (res.status == 3) { *err = "zero coverage on the consensus path"; return false; }
-    out->cons.resize(res.cons_len);
+    uint32_t cons_len = 0;
+    if (!solve(mv, l, n_cols, total, in.read_type, &cons_len, &clk, err)) return false;
+    out->cons.resize(cons_len);
     out->stat.resize(n_cols);
     out->tags.resize(tag_bytes);
     out->aln_t_e.assign(n_streams, 0);
-    if (res.cons_len)
-        HIPOK(hipMemcpyAsync(out->cons.data(), cons_.as<ConsBase>() + (cons_cap - res.cons_len), sizeof(ConsBase) * (size_t)res.cons_len,
-                             hipMemcpyDeviceToHost, q));
+    if (cons_len) HIPOK(hipMemcpyAsync(out->cons.data(), cons_.p, sizeof(ConsBase) * (size_t)cons_len, hipMemcpyDeviceToHost, q));
     HIPOK(hipMemcpyAsync(out->stat.data(), stat_.p, sizeof(ColStat) * (size_t)n_cols, hipMemcpyDeviceToHost, q));
     HIPOK(hipMemcpyAsync(out->tags.data(), tags_.p, tag_bytes, hipMemcpyDeviceToHost, q));
     if (n_streams > 1) HIPOK(hipMemcpyAsync(out->aln_t_e.data() + 1, te_.as<uint32_t>() + 1, 4ull * (n_streams - 1), hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
-    clk.mark("backtrace+download");
+    clk.mark("download");
     clk.flush("window", l, n_streams, total);
     out->aln_t_e[0] = (uint32_t)l;
     return true;
 }
 
-bool HipExec::build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total_out, std::string* err) {
+// Chain DP + backtrace over a built link graph.  rule: READS_ONT..READS_RS for a window, RULE_LQ / RULE_LQ_HIFI for the
+// concatenated low-quality regions.  Leaves the consensus in cons_ in FORWARD order (ConsBase items, or characters
+// for the LQ rules) and returns its length.
+bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t total, int rule, uint32_t* cons_len, StageClock* clk,
+                    std::string* err) {
+    hipStream_t q = stream_;
+    const bool lq = rule == RULE_LQ || rule == RULE_LQ_HIFI;
+    if (!cutflag_.ensure(4ull * (n_cols + 2)) || !cutpos_.ensure(4ull * (n_cols + 2)) || !cuts_.ensure(4ull * (n_cols + 2)) ||
+        !ea_.ensure(8ull * (size_t)total + 64) || !ec_.ensure(8ull * (size_t)total + 64) || !flag_.ensure(32) ||
+        !cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) { *err = "out of device memory (dp runs)"; return false; }
+    k2_cut_flags<<<nblk(n_cols + 1, 256), 256, 0, q>>>(mv, n_cols, cutflag_.as<uint32_t>());
+    const uint32_t nsb2 = nblk(n_cols + 1, SCAN_TILE);
+    k2_scan_sums<<<nsb2, SCAN_T, 0, q>>>(cutflag_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
+    k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb2);
+    k2_scan_final<<<nsb2, SCAN_T, 0, q>>>(cutflag_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), cutpos_.as<uint32_t>());
+    uint32_t n_cuts = 0;
+    HIPOK(hipMemcpyAsync(&n_cuts, cutpos_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
+    HIPOK(hipStreamSynchronize(q));
+    k2_cut_list<<<nblk(n_cols, 256), 256, 0, q>>>(cutflag_.as<uint32_t>(), cutpos_.as<uint32_t>(), n_cols, cuts_.as<uint32_t>());
+    uint32_t last_cut = 0xffffffffu;
+    if (n_cuts) HIPOK(hipMemcpyAsync(&last_cut, cuts_.as<uint32_t>() + (n_cuts - 1), 4, hipMemcpyDeviceToHost, q));
+    HIPOK(hipStreamSynchronize(q));
+    // cuts beyond column l - 1 cannot occur (column l holds no node); a window ending on a cut has no open run behind it
+    const uint32_t n_runs = (n_cuts && (int32_t)last_cut == l - 1) ? n_cuts : n_cuts + 1;
+    if (!runac_.ensure(sizeof(RunAC) * (size_t)n_runs + 64) || !btcnt_.ensure(4ull * (n_runs + 2)) || !btoff_.ensure(4ull * (n_runs + 2))) {
+        *err = "out of device memory (dp runs)";
+        return false;
+    }
+    if (clk && clk->on) fprintf(stderr, "[np2 dp] %u cuts, %u runs over %d columns\n", n_cuts, n_runs, l);
+    HIPOK(hipMemsetAsync(flag_.p, 0, 32, q));
+    HIPOK(hipMemsetAsync(res_.p, 0, sizeof(DpResult), q));
+    const long long C = rule == RULE_LQ ? 2 : (rule == READS_HIFI || rule == RULE_LQ_HIFI) ? 4 : 3;
+    k2_run_ac<<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, ea_.as<long long>(), ec_.as<long long>(), runac_.as<RunAC>());
+    k2_run_scan<<<1, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, runac_.as<RunAC>());
+#define NP2_RUN_DP(T) k2_run_dp<T><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>())
+    switch (rule) {
+        case READS_CLR: NP2_RUN_DP(READS_CLR); break;
+        case READS_HIFI: NP2_RUN_DP(READS_HIFI); break;
+        case READS_RS: NP2_RUN_DP(READS_RS); break;
+        case RULE_LQ: NP2_RUN_DP(RULE_LQ); break;
+        case RULE_LQ_HIFI: NP2_RUN_DP(RULE_LQ_HIFI); break;
+        default: NP2_RUN_DP(READS_ONT); break;
+    }
+#undef NP2_RUN_DP
+    if (clk) clk->mark("dp");
+    // ---- backtrace: count per run, place, write
+    BtCtl* ctl = reinterpret_cast<BtCtl*>(flag_.as<uint32_t>() + 2);
+    uint32_t* status = flag_.as<uint32_t>() + 4;
+    if (lq) k2_bt_runs<true, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btcnt_.as<uint32_t>(), ctl, nullptr, nullptr, nullptr, status);
+    else k2_bt_runs<false, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btcnt_.as<uint32_t>(), ctl, nullptr, nullptr, nullptr, status);
+    k2_bt_mask<<<nblk(n_runs, 256), 256, 0, q>>>(btcnt_.as<uint32_t>(), n_runs, ctl);
+    const uint32_t nsb3 = nblk(n_runs + 1, SCAN_TILE);
+    HIPOK(hipMemsetAsync(btcnt_.as<uint32_t>() + n_runs, 0, 4, q));
+    k2_scan_sums<<<nsb3, SCAN_T, 0, q>>>(btcnt_.as<uint32_t>(), n_runs + 1, sums_.as<uint32_t>());
+    k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb3);
+    k2_scan_final<<<nsb3, SCAN_T, 0, q>>>(btcnt_.as<uint32_t>(), n_runs + 1, sums_.as<uint32_t>(), btoff_.as<uint32_t>());
+    if (lq) k2_bt_runs<true, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btcnt_.as<uint32_t>(), ctl, btoff_.as<uint32_t>(), nullptr, cons_.as<char>(), status);
+    else k2_bt_runs<false, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btcnt_.as<uint32_t>(), ctl, btoff_.as<uint32_t>(), cons_.as<ConsBase>(), nullptr, status);
+    DpResult res;
+    uint32_t st = 0, total_len = 0;
+    HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));
+    HIPOK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, q));
+    HIPOK(hipMemcpyAsync(&total_len, btoff_.as<uint32_t>() + n_runs, 4, hipMemcpyDeviceToHost, q));
+    HIPOK(hipStreamSynchronize(q));
+    if (clk) clk->mark("backtrace");
+    if (!lq && res.status == 1) { *err = "no alignment column reaches the end of the window"; return false; }
+    if (st == 2) { *err = lq ? "low-quality backtrace left the graph" : "backtrace left the graph"; return false; }
+    if (st == 3) { *err = "zero coverage on the consensus path"; return false; }
+    *cons_len = total_len;
+    return true;
+}
+
+bool HipExec::build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total_out, std::string* err, StageClock* clk) {
     hipStream_t q = stream_;
     k2_links<false><<<nblk(n_streams, 64), 64, 0, q>>>(tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), n_streams, tags_.as<uint8_t>(),
                                                         colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
@@ -771,6 +699,7 @@ bool HipExec::build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total_o
     uint32_t total = 0;
     HIPOK(hipMemcpyAsync(&total, coloff_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
+    if (clk) clk->mark("links.count+scan");
     if (!obs_.ensure(sizeof(LinkObs) * (size_t)total + 64) || !entries_.ensure(sizeof(Entry) * (size_t)total + 64) ||
         !nodes_.ensure(sizeof(Node) * (size_t)total + 64)) {
         *err = "out of device memory (link graph)";
@@ -778,6 +707,7 @@ bool HipExec::build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total_o
     }
     k2_links<true><<<nblk(n_streams, 64), 64, 0, q>>>(tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), n_streams, tags_.as<uint8_t>(),
                                                        nullptr, coloff_.as<uint32_t>(), cursor_.as<uint32_t>(), obs_.as<LinkObs>());
+    if (clk) clk->mark("links.scatter");
     k2_build<<<nblk(n_cols, 64), 64, 0, q>>>(obs_.as<LinkObs>(), coloff_.as<uint32_t>(), n_cols, entries_.as<Entry>(), nodes_.as<Node>(),
                                               colnn_.as<uint32_t>());
     *total_out = total;
@@ -828,18 +758,13 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>());
     uint32_t total = 0;
     if (!build_graph(n_streams, n_cols, &total, err)) return false;
-    const uint32_t cap = total + 8;
-    if (!cons_.ensure((size_t)cap + 16)) { *err = "out of device memory (low-quality consensus)"; return false; }
     MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
-    k2_dp_lq<<<1, 64, 0, q>>>(mv, (int32_t)in.t_len, st.max_size, in.hifi ? 1 : 0, res_.as<DpResult>());
-    k2_backtrace_lq<<<1, 64, 0, q>>>(mv, res_.as<DpResult>(), cons_.as<char>(), cap);
-    DpResult res;
-    HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));
+    uint32_t cons_len = 0;
+    if (!solve(mv, (int32_t)in.t_len, n_cols, total, in.hifi ? RULE_LQ_HIFI : RULE_LQ, &cons_len, nullptr, err)) return false;
+    std::string fwd(cons_len, '\0');
+    if (cons_len) HIPOK(hipMemcpyAsync(&fwd[0], cons_.p, cons_len, hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
-    if (res.status) { *err = "low-quality backtrace left the graph"; return false; }
-    cons_rev->resize(res.cons_len);
-    if (res.cons_len) HIPOK(hipMemcpyAsync(&(*cons_rev)[0], cons_.p, res.cons_len, hipMemcpyDeviceToHost, q));
-    HIPOK(hipStreamSynchronize(q));
+    cons_rev->assign(fwd.rbegin(), fwd.rend());   // the reference leaves this string in backtrace order
     return true;
 }
 

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <time.h>
 #include <unistd.h>
 #include <string>
 #include <vector>
@@ -609,7 +610,11 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
             for (const LqReg& r : lq_regions(lx)) regs.push_back(np2::LqRegionIn{r.start, r.end, r.l});
         }
         if (!regs.empty() || reads_type == np2k::READS_HIFI) {
+            timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
             if (!np2::lq_stage(cfg->exec, gap_min_len, reads_type == np2k::READS_HIFI, regs, out, &out.cons, &err)) np2_die(err.c_str(), ref->n);
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (getenv("NP2_TIMING")) fprintf(stderr, "[np2 lq stage] %zu regions, %.2f ms\n", regs.size(), (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
         }
         WindowCons wc;
         wc.b = out.cons;   // update_consensus_trimed with no regions: a copy (ctg_cns.c:1165-1211)
