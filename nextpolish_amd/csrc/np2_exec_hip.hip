@@ -129,30 +129,79 @@ __global__ void k2_tags(const StreamDesc* sd, uint32_t n_streams, const int32_t*
     te_out[k] = emit_tags(rv, contig_seq, a, s, gap_min_len, tags + d.tag_off, sink);
 }
 
-// link observations of one stream; kFill = false counts per column, true scatters
-template <bool kFill>
-__global__ void k2_links(const uint64_t* tag_off, const uint32_t* aln_t_s, uint32_t n_streams, const uint8_t* tags,
-                         uint32_t* col_cnt, const uint32_t* col_off, uint32_t* cursor, LinkObs* obs) {
-    const uint32_t rd = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rd >= n_streams) return;
-    const uint8_t* tg = tags + tag_off[rd];
+// ---- link observations from the tag streams, chunk-parallel ----------------------------------------------------
+// A stream is cut into chunks of LINK_CHUNK tags; the position of a tag is aln_t_s + (# non-insertion tags up to it)
+// - 1, so a per-chunk popcount + scan gives every chunk its starting position, and the two previous tags (pp, ppp)
+// and the open insertion run are recovered by a short look-back.  Lanes = chunks (tens of thousands per window)
+// instead of streams (hundreds, one of them -- the seed -- as long as the window).
+constexpr uint32_t LINK_CHUNK = 512;
+struct ChunkDesc { uint32_t stream, first_tag, n_tags, first_chunk_of_stream; };
+
+__device__ __forceinline__ uint32_t tag_nib(const uint8_t* tg, uint32_t i) {
+    const uint32_t t = tg[i >> 1];
+    return (i & 1) ? (t & 15u) : (t >> 4);
+}
+__global__ void k2_chunk_count(const ChunkDesc* cd, uint32_t n_chunks, const uint64_t* tag_off, const uint8_t* tags, uint32_t* cnt) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const ChunkDesc d = cd[c];
+    const uint8_t* tg = tags + tag_off[d.stream];
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < d.n_tags; ++i) n += (tag_nib(tg, d.first_tag + i) & 8u) ? 0u : 1u;
+    cnt[c] = n;
+}
+// position (t_pos, delta) of tag j of a stream given T = number of non-insertion tags among tags 0..j
+__device__ __forceinline__ void tag_pos(const uint8_t* tg, uint32_t j, uint32_t T, uint32_t aln_t_s, int32_t* t_pos, uint32_t* delta) {
+    *t_pos = (int32_t)(aln_t_s + T) - 1;
     uint32_t d = 0;
-    Tag p1{0, 0, 0};
+    while ((tag_nib(tg, j - d) & 8u)) ++d;   // a stream never starts with an insertion column, so this stops at or before tag 0
+    *delta = d & 0xffffu;
+}
+template <bool kFill>
+__global__ void k2_chunk_links(const ChunkDesc* cd, uint32_t n_chunks, const uint32_t* pre, const uint64_t* tag_off, const uint32_t* aln_t_s,
+                               const uint8_t* tags, uint32_t* col_cnt, const uint32_t* col_off, uint32_t* cursor, LinkObs* obs) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const ChunkDesc d = cd[c];
+    const uint8_t* tg = tags + tag_off[d.stream];
+    const uint32_t ts = aln_t_s[d.stream];
+    uint32_t T = pre[c] - pre[d.first_chunk_of_stream];   // non-insertion tags before this chunk
     uint64_t pp = KEY_HEAD, ppp = KEY_HEAD;
     uint32_t pp_base = 0;
-    while (next_tag(tg, aln_t_s[rd], &d, &p1)) {
-        const uint64_t key = node_key(p1.t_pos, p1.delta, p1.q_base);
-        if (p1.q_base != 6 && pp_base != 6) {
+    int32_t t_pos = (int32_t)(ts + T) - 1;
+    uint32_t delta = 0;
+    if (d.first_tag >= 1) {
+        const uint32_t j = d.first_tag - 1;
+        int32_t tp;
+        uint32_t dl;
+        tag_pos(tg, j, T, ts, &tp, &dl);
+        const uint32_t nb = tag_nib(tg, j);
+        pp = node_key(tp, dl, nb & 7u);
+        pp_base = nb & 7u;
+        delta = dl;   // the open insertion run continues into this chunk
+        if (d.first_tag >= 2) {
+            const uint32_t T2 = T - ((nb & 8u) ? 0u : 1u);
+            tag_pos(tg, j - 1, T2, ts, &tp, &dl);
+            ppp = node_key(tp, dl, tag_nib(tg, j - 1) & 7u);
+        }
+    }
+    for (uint32_t i = 0; i < d.n_tags; ++i) {
+        const uint32_t nb = tag_nib(tg, d.first_tag + i);
+        const uint32_t base = nb & 7u;
+        if (nb & 8u) delta = (delta + 1) & 0xffffu;
+        else { delta = 0; ++t_pos; }
+        const uint64_t key = node_key(t_pos, delta, base);
+        if (base != 6 && pp_base != 6) {
             if (!kFill) {
-                atomicAdd(&col_cnt[p1.t_pos], 1u);
+                atomicAdd(&col_cnt[t_pos], 1u);
             } else {
-                const uint32_t at = col_off[p1.t_pos] + atomicAdd(&cursor[p1.t_pos], 1u);
+                const uint32_t at = col_off[t_pos] + atomicAdd(&cursor[t_pos], 1u);
                 LinkObs o;
-                o.pp = pp; o.ppp = ppp; o.rd = rd; o.delta = (uint16_t)p1.delta; o.base = (uint8_t)p1.q_base; o.pad = 0;
+                o.pp = pp; o.ppp = ppp; o.rd = d.stream; o.delta = (uint16_t)delta; o.base = (uint8_t)base; o.pad = 0;
                 obs[at] = o;
             }
         }
-        ppp = pp; pp = key; pp_base = p1.q_base;
+        ppp = pp; pp = key; pp_base = base;
     }
 }
 
@@ -475,12 +524,12 @@ class HipExec : public Exec {
 
   private:
     // link observations -> column buckets -> nodes/entries for n_streams tag streams over n_cols columns; *total = entries
-    bool build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total, std::string* err, struct StageClock* clk = nullptr);
+    bool build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, uint32_t* total, std::string* err, struct StageClock* clk = nullptr);
     bool solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t total, int rule, uint32_t* cons_len, struct StageClock* clk, std::string* err);
     int device_;
     hipStream_t stream_ = nullptr;
     DevBuf contig_, pos_, ncig_, cigoff_, seqoff_, cigar_, seq_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
-        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, cutflag_, cutpos_, cuts_, ea_, ec_, runac_, btcnt_, btoff_;
+        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, ea_, ec_, runac_, btcnt_, btoff_;
     uint64_t contig_serial_ = ~0ull;
     size_t contig_len_ = 0;
 };
@@ -594,7 +643,10 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     HIPOK(hipMemcpyAsync(alnts_.p, out->aln_t_s.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
     clk.mark("tags");
     uint32_t total = 0;
-    if (!build_graph(n_streams, n_cols, &total, err, &clk)) return false;
+    std::vector<uint32_t> n_tags;
+    n_tags.push_back((uint32_t)l);
+    for (const StreamDesc& d : sd) n_tags.push_back(d.aln_len);
+    if (!build_graph(n_tags, n_cols, &total, err, &clk)) return false;
     if (!cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) { *err = "out of device memory (consensus)"; return false; }
     clk.mark("build");
     // ---- chain DP + backtrace
@@ -688,10 +740,28 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     return true;
 }
 
-bool HipExec::build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total_out, std::string* err, StageClock* clk) {
+bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, uint32_t* total_out, std::string* err, StageClock* clk) {
     hipStream_t q = stream_;
-    k2_links<false><<<nblk(n_streams, 64), 64, 0, q>>>(tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), n_streams, tags_.as<uint8_t>(),
-                                                        colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
+    // ---- chunk list (host: O(streams)), non-insertion tag counts per chunk, scan
+    std::vector<ChunkDesc> cd;
+    for (uint32_t s = 0; s < (uint32_t)n_tags.size(); ++s) {
+        const uint32_t first_chunk = (uint32_t)cd.size();
+        for (uint32_t t = 0; t < n_tags[s]; t += LINK_CHUNK) cd.push_back(ChunkDesc{s, t, std::min(LINK_CHUNK, n_tags[s] - t), first_chunk});
+    }
+    const uint32_t n_chunks = (uint32_t)cd.size();
+    if (!chunks_.ensure(sizeof(ChunkDesc) * (size_t)n_chunks + 64) || !chcnt_.ensure(4ull * (n_chunks + 2)) || !chpre_.ensure(4ull * (n_chunks + 2)) ||
+        !sums2_.ensure(4ull * (nblk(n_chunks + 1, SCAN_TILE) + 2))) { *err = "out of device memory (chunks)"; return false; }
+    if (n_chunks) {
+        HIPOK(hipMemcpyAsync(chunks_.p, cd.data(), sizeof(ChunkDesc) * (size_t)n_chunks, hipMemcpyHostToDevice, q));
+        HIPOK(hipMemsetAsync(chcnt_.as<uint32_t>() + n_chunks, 0, 4, q));
+        k2_chunk_count<<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), chcnt_.as<uint32_t>());
+        const uint32_t nsc = nblk(n_chunks + 1, SCAN_TILE);
+        k2_scan_sums<<<nsc, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), n_chunks + 1, sums2_.as<uint32_t>());
+        k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nsc);
+        k2_scan_final<<<nsc, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), n_chunks + 1, sums2_.as<uint32_t>(), chpre_.as<uint32_t>());
+        k2_chunk_links<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
+                                                                 alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
+    }
     const uint32_t nsb = nblk(n_cols + 1, SCAN_TILE);
     k2_scan_sums<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
     k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb);
@@ -705,8 +775,10 @@ bool HipExec::build_graph(uint32_t n_streams, uint32_t n_cols, uint32_t* total_o
         *err = "out of device memory (link graph)";
         return false;
     }
-    k2_links<true><<<nblk(n_streams, 64), 64, 0, q>>>(tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), n_streams, tags_.as<uint8_t>(),
-                                                       nullptr, coloff_.as<uint32_t>(), cursor_.as<uint32_t>(), obs_.as<LinkObs>());
+    if (n_chunks)
+        k2_chunk_links<true><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
+                                                                alnts_.as<uint32_t>(), tags_.as<uint8_t>(), nullptr, coloff_.as<uint32_t>(), cursor_.as<uint32_t>(),
+                                                                obs_.as<LinkObs>());
     if (clk) clk->mark("links.scatter");
     k2_build<<<nblk(n_cols, 64), 64, 0, q>>>(obs_.as<LinkObs>(), coloff_.as<uint32_t>(), n_cols, entries_.as<Entry>(), nodes_.as<Node>(),
                                               colnn_.as<uint32_t>());
@@ -757,7 +829,7 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
                                                    tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), st, te_.as<uint32_t>());
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>());
     uint32_t total = 0;
-    if (!build_graph(n_streams, n_cols, &total, err)) return false;
+    if (!build_graph(str_len, n_cols, &total, err)) return false;
     MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
     uint32_t cons_len = 0;
     if (!solve(mv, (int32_t)in.t_len, n_cols, total, in.hifi ? RULE_LQ_HIFI : RULE_LQ, &cons_len, nullptr, err)) return false;
