@@ -250,49 +250,78 @@ __global__ void k2_tags_str(const char* pool, const uint64_t* str_off, const uin
 }
 
 // ---- run-decomposed chain DP ---------------------------------------------------------------------------------
-// A column that holds ONE node with ONE entry and no insertion level is a cut: everything to its right depends on
-// the left part of the window only through that entry's score x.  Scores obey v = max(0, max_n(v_n) + w) (entries
-// start at 0 and are only raised; stream heads inject constants), so along a run between two cuts every entry is a
-// function f(x) = max(c, x + a) and the run as a whole maps x -> max(C, x + A):
+// Everything to the right of a column depends on the left part of the window only through the scores of that
+// column's entries.  Scores obey v = max(0, max_n(v_n) + w) (entries start at 0 and are only raised; stream heads
+// inject constants), so every entry of a run is a function f(x) = max(c, max_i(x_i + a_i)) of the scores x of the
+// entries of the run's left cut column, and a run maps x -> max(C, A (x) x) in the (max, +) semiring.
+// Cuts are columns with at most CUT_K live entries (at most one per block of CUT_BLOCK columns):
 //   k2_cut_flags / scan / k2_cut_list   the cuts, in order
-//   k2_run_ac     lane per run: (a, c) of every entry of the run, (A, C) of the run        [parallel]
-//   k2_run_scan   x at every cut from the (A, C) chain, written into the cut entries      [one lane, #runs steps]
-//   k2_run_dp     lane per run: the literal DP of the reference on its columns, with the true x at its left cut
-// Best-index rules compare real scores, which is why the literal pass runs after the scan instead of being patched.
+//   k2_run_ac     wave per run, lane i = input i (lane CUT_K = constants): (a, c) of every entry, (A, C) of the run
+//   k2_run_scan   x at every cut from the (A, C) chain, written into the cut columns' entries   [one lane, #runs steps]
+//   k2_run_dp_a   wave per run (first lane): the reference's literal DP on the run's interior columns
+//   k2_run_dp_b   the same on the cut columns themselves (their scores are recomputed to the same values; the
+//                 best-index rules need the literal pass)
+// Best-index rules compare real scores, which is why the literal passes run after the scan.
 constexpr int RULE_LQ = 5, RULE_LQ_HIFI = 6;   // DP rules of the low-quality re-consensus, next to READS_ONT..READS_RS
 constexpr long long AC_NEG = INT64_MIN / 4;   // "-infinity" that survives adding a column weight
+constexpr uint32_t CUT_K = 8, CUT_BLOCK = 32;
 
-__global__ void k2_cut_flags(MsaView mv, uint32_t n_cols, uint32_t* flag) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > n_cols) return;
-    uint32_t f = 0;
-    if (p < n_cols) f = (mv.col_nn[p] == 1 && mv.nodes[mv.col_off[p]].len == 1 && mv.stat[p].max_size == 1) ? 1u : 0u;
-    flag[p] = f;
+__device__ __forceinline__ uint32_t live_entries(const MsaView& mv, uint32_t p) {
+    const Node* nd = mv.nodes + mv.col_off[p];
+    uint32_t n = 0;
+    for (uint32_t j = 0; j < mv.col_nn[p]; ++j) n += nd[j].len;
+    return n;
+}
+// one candidate per block of CUT_BLOCK columns: the first column with 1..CUT_K live entries among the block's first
+// CUT_BLOCK - 2 columns (so two cuts are never adjacent: k2_run_dp_b relies on the column before a cut being interior)
+__global__ void k2_cut_flags(MsaView mv, uint32_t n_cols, int32_t l, uint32_t* flag) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p0 = b * CUT_BLOCK;
+    if (p0 > n_cols) return;
+    bool found = false;
+    for (uint32_t o = 0; o < CUT_BLOCK && p0 + o <= n_cols; ++o) {
+        const uint32_t p = p0 + o;
+        uint32_t f = 0;
+        if (!found && o < CUT_BLOCK - 2 && (int32_t)p < l) {
+            const uint32_t e = live_entries(mv, p);
+            if (e >= 1 && e <= CUT_K) { f = 1; found = true; }
+        }
+        flag[p] = f;
+    }
 }
 __global__ void k2_cut_list(const uint32_t* flag, const uint32_t* pos, uint32_t n_cols, uint32_t* cuts) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n_cols && flag[p]) cuts[pos[p]] = p;
 }
 
-struct RunAC { long long A, C; };
+struct RunT {
+    long long A[CUT_K][CUT_K];   // A[j][i]: output j from input i
+    long long C[CUT_K];
+};
 
-// run r covers columns (lo, hi]: lo = cuts[r-1] (or -1), hi = cuts[r] (or l-1 for the last run)
+// run r covers columns (lo, hi]: lo = cuts[r-1] (or -1), hi = cuts[r] (or l-1 for the last, open run)
 __device__ __forceinline__ void run_bounds(const uint32_t* cuts, uint32_t n_cuts, uint32_t r, int32_t l, int32_t* lo, int32_t* hi) {
     *lo = r == 0 ? -1 : (int32_t)cuts[r - 1];
     *hi = r < n_cuts ? (int32_t)cuts[r] : l - 1;
 }
+// state index of entry n of node `nd` inside its column = live entries of the nodes before it + n
+__device__ __forceinline__ uint32_t state_index(const MsaView& mv, int32_t p, const Node* nd, uint32_t n) {
+    const Node* first = mv.nodes + mv.col_off[p];
+    uint32_t idx = n;
+    for (const Node* q = first; q < nd; ++q) idx += q->len;
+    return idx;
+}
 
-__global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, long long C, long long* ea, long long* ec, RunAC* out) {
-    // one run per WAVE, walked by its first lane: the loops are data dependent, and 64 unrelated runs in one wave would
-    // serialise each other's branches; the chip has room for thousands of such waves
+__global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, long long C, long long* eav, RunT* out) {
+    // one run per WAVE; lanes 0..CUT_K-1 carry the coefficient of one input each, lane CUT_K the constant.  All
+    // lanes run the same loops (wave-uniform control flow); the other lanes idle: the chip has room for thousands of waves.
     const uint32_t r = blockIdx.x;
-    if (r >= n_runs || threadIdx.x) return;
+    const uint32_t lane = threadIdx.x;
+    if (r >= n_runs || lane > CUT_K) return;
     int32_t lo, hi;
     run_bounds(cuts, n_cuts, r, l, &lo, &hi);
-    // the left cut's single entry is the identity f(x) = x; it is also the right cut of the previous run, whose lane
-    // keeps that entry's (a, c) in registers, so neither lane stores it
-    const uint32_t gl = lo >= 0 ? mv.col_off[lo] + mv.nodes[mv.col_off[lo]].start : 0xffffffffu;
-    RunAC o{AC_NEG, AC_NEG};
+    constexpr uint32_t W = CUT_K + 1;
+    uint32_t jout = 0;
     for (int32_t p = lo + 1; p <= hi; ++p) {
         const long long cov = mv.stat[p].coverage;
         const Node* nd = mv.nodes + mv.col_off[p];
@@ -302,105 +331,140 @@ __global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uin
                 const uint32_t g = mv.col_off[p] + nd[j].start + m;
                 const Entry& em = mv.entries[g];
                 const long long w = 10 * (long long)em.link - C * cov;
-                long long a = AC_NEG, c = 0;
+                long long v;   // this lane's component of the entry's function
                 if (key_tpos(em.pp) == -1) {
-                    c = w;   // assigned directly, may be negative
+                    v = lane == CUT_K ? w : AC_NEG;   // assigned directly, may be negative
                 } else {
                     const int32_t tp = key_tpos(em.pp);
                     const Node* ppn = find_node(mv, tp, key_delta(em.pp) << 8 | key_base(em.pp));
-                    long long am = AC_NEG, cm = AC_NEG;
+                    long long best = AC_NEG;
                     if (ppn) {
                         const uint32_t g0 = mv.col_off[tp] + ppn->start;
                         for (uint32_t n = 0; n < ppn->len; ++n) {
                             if (mv.entries[g0 + n].pp != em.ppp) continue;
-                            const long long an = g0 + n == gl ? 0 : ea[g0 + n], cn = g0 + n == gl ? AC_NEG : ec[g0 + n];
-                            if (an > am) am = an;
-                            if (cn > cm) cm = cn;
+                            long long vn;
+                            if (tp == lo) vn = state_index(mv, tp, ppn, n) == lane ? 0 : AC_NEG;   // the left cut's entries are the inputs
+                            else vn = eav[(uint64_t)(g0 + n) * W + lane];
+                            if (vn > best) best = vn;
                         }
                     }
-                    a = am > AC_NEG ? am + w : AC_NEG;
-                    const long long cw = cm > AC_NEG ? cm + w : AC_NEG;
-                    c = cw > 0 ? cw : 0;
+                    v = best > AC_NEG ? best + w : AC_NEG;
+                    if (lane == CUT_K && v < 0) v = 0;   // clamp lives in the constant
                 }
-                if (p == hi && r < n_cuts) { o.A = a; o.C = c; }   // the right cut's single entry
-                else { ea[g] = a; ec[g] = c; }
+                if (p == hi && r < n_cuts) {   // an entry of the right cut: a row of the run's transfer
+                    if (lane < CUT_K) out[r].A[jout][lane] = v;
+                    else out[r].C[jout] = v;
+                    ++jout;
+                }
+                eav[(uint64_t)g * W + lane] = v;
             }
         }
     }
-    out[r] = o;
 }
 
-// x at every cut; the cut entries get their true score so the literal pass can start from it
-__global__ void k2_run_scan(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, const RunAC* ac) {
+// x at every cut; the cut columns' entries get their true scores so the literal passes can start from them
+__global__ void k2_run_scan(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, const RunT* rt) {
     if (blockIdx.x || threadIdx.x) return;
-    long long x = AC_NEG;
+    long long x[CUT_K], xn[CUT_K];
+    uint32_t n_in = 0;
     for (uint32_t r = 0; r < n_cuts; ++r) {
-        const long long via = (x > AC_NEG && ac[r].A > AC_NEG) ? x + ac[r].A : AC_NEG;
-        x = via > ac[r].C ? via : ac[r].C;
         const uint32_t p = cuts[r];
-        mv.entries[mv.col_off[p] + mv.nodes[mv.col_off[p]].start].score = x;
+        const Node* nd = mv.nodes + mv.col_off[p];
+        uint32_t jo = 0;
+        for (uint32_t j = 0; j < mv.col_nn[p]; ++j)
+            for (uint32_t m = 0; m < nd[j].len; ++m) {
+                long long v = rt[r].C[jo];
+                for (uint32_t i = 0; i < n_in; ++i)
+                    if (x[i] > AC_NEG && rt[r].A[jo][i] > AC_NEG && x[i] + rt[r].A[jo][i] > v) v = x[i] + rt[r].A[jo][i];
+                xn[jo] = v;
+                mv.entries[mv.col_off[p] + nd[j].start + m].score = v;
+                ++jo;
+            }
+        n_in = jo;
+        for (uint32_t i = 0; i < n_in; ++i) x[i] = xn[i];
     }
 }
 
 template <int TYPE>
-__global__ void k2_run_dp(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, DpResult* res) {
+__device__ __forceinline__ void dp_any(const MsaView& mv, int32_t p, int32_t l, long long* gbest, uint64_t* gkey) {
+    if (TYPE == RULE_LQ) dp_column_lq<false>(mv, p);
+    else if (TYPE == RULE_LQ_HIFI) dp_column_lq<true>(mv, p);
+    else dp_column<TYPE == RULE_LQ || TYPE == RULE_LQ_HIFI ? READS_ONT : TYPE>(mv, p, l, gbest, gkey);
+}
+template <int TYPE>
+__device__ __forceinline__ void publish_best(const MsaView& mv, int32_t l, long long gbest, uint64_t gkey, DpResult* res) {
+    if (TYPE == RULE_LQ || TYPE == RULE_LQ_HIFI) gkey = node_key(l - 1, (uint32_t)mv.stat[l - 1].max_size - 1, 5);   // last node the reference's loops visit (ctg_cns.c:1036-1038,1090-1092)
+    res->gbest = gbest;
+    res->gkey = gkey;
+    res->status = key_base(gkey) == 0xff ? 1u : 0u;
+}
+
+// interior columns of every run (and the last column of the open run)
+template <int TYPE>
+__global__ void k2_run_dp_a(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, DpResult* res) {
     const uint32_t r = blockIdx.x;
     if (r >= n_runs || threadIdx.x) return;
     int32_t lo, hi;
     run_bounds(cuts, n_cuts, r, l, &lo, &hi);
     long long gbest = INT64_MIN;
     uint64_t gkey = node_key(0, 0, 0xff);
-    // the right cut column is left to the scan's value for its score; its node still needs its (trivial) best index
-    for (int32_t p = lo + 1; p <= hi; ++p) {
-        if (p == hi && r < n_cuts) { mv.nodes[mv.col_off[p]].best = 0; continue; }
-        if (TYPE == RULE_LQ) dp_column_lq<false>(mv, p);
-        else if (TYPE == RULE_LQ_HIFI) dp_column_lq<true>(mv, p);
-        else dp_column<TYPE == RULE_LQ || TYPE == RULE_LQ_HIFI ? READS_ONT : TYPE>(mv, p, l, &gbest, &gkey);
-    }
-    if (hi == l - 1) {
-        if (r < n_cuts) {   // the window ends on a cut column: the global best is its single node
-            const Node& nd = mv.nodes[mv.col_off[hi]];
-            gbest = mv.entries[mv.col_off[hi] + nd.start].score;
-            gkey = node_key(hi, nd.key >> 8, nd.key & 0xffu);
-        } else if (TYPE == RULE_LQ || TYPE == RULE_LQ_HIFI) {
-            gkey = node_key(hi, (uint32_t)mv.stat[hi].max_size - 1, 5);   // last node the reference's loops visit (ctg_cns.c:1036-1038,1090-1092)
-        }
-        res->gbest = gbest;
-        res->gkey = gkey;
-        res->status = key_base(gkey) == 0xff ? 1u : 0u;
-    }
+    const int32_t last = r < n_cuts ? hi - 1 : hi;
+    for (int32_t p = lo + 1; p <= last; ++p) dp_any<TYPE>(mv, p, l, &gbest, &gkey);
+    if (r >= n_cuts && hi == l - 1) publish_best<TYPE>(mv, l, gbest, gkey, res);
+}
+// the cut columns: scores back to the state update_msa left them in, then the literal column
+template <int TYPE>
+__global__ void k2_run_dp_b(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, int32_t l, DpResult* res) {
+    const uint32_t r = blockIdx.x;
+    if (r >= n_cuts || threadIdx.x) return;
+    const int32_t p = (int32_t)cuts[r];
+    const Node* nd = mv.nodes + mv.col_off[p];
+    for (uint32_t j = 0; j < mv.col_nn[p]; ++j)
+        for (uint32_t m = 0; m < nd[j].len; ++m) mv.entries[mv.col_off[p] + nd[j].start + m].score = 0;
+    long long gbest = INT64_MIN;
+    uint64_t gkey = node_key(0, 0, 0xff);
+    dp_any<TYPE>(mv, p, l, &gbest, &gkey);
+    if (p == l - 1) publish_best<TYPE>(mv, l, gbest, gkey, res);
 }
 
 // ---- parallel backtrace over the runs --------------------------------------------------------------------------
-// The best path passes through the single node of every cut column, so the walk of one run (from its right cut, or
-// from the global best node for the last run, down to its left cut) is independent of the others.  Pass 1 counts the
-// emitted bases per run and notes runs whose walk ends on a stream head before reaching the left cut (the whole
-// path ends there); a scan places the runs; pass 2 walks again and writes.  kLq: character output of the
-// low-quality re-consensus (ctg_cns.c:1104-1143) instead of consensus bases (:1836-1858).
-struct BtCtl { uint32_t r_end; uint32_t pad; };
+// The walk of a run (from a node of its right cut column, or from the global best node for the open run, down to
+// the first node it reaches in its left cut column) does not depend on the other runs.  Pass 0 walks from every
+// node of the right cut column (lanes = start nodes) and records exit node, base count and whether the walk ended on
+// a stream head; a one-lane chain picks the start of every run from right to left and places the runs; pass 1 walks
+// again from the chosen starts and writes.  kLq: character output of the low-quality re-consensus
+// (ctg_cns.c:1104-1143) instead of consensus bases (:1836-1858).
+struct BtWalk { uint64_t exit_key; uint32_t count; uint32_t ended; };   // per (run, start node)
+struct BtPick { uint32_t start; uint32_t count; uint32_t off; uint32_t used; };   // per run
 
 template <bool kLq, bool kWrite>
-__global__ void k2_bt_runs(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, uint32_t* cnt,
-                           BtCtl* ctl, const uint32_t* off, ConsBase* cons, char* chars, uint32_t* status) {
+__global__ void k2_bt_runs(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, BtWalk* walks,
+                           const BtPick* pick, ConsBase* cons, char* chars, uint32_t* status) {
     const uint32_t r = blockIdx.x;
-    if (r >= n_runs || threadIdx.x) return;
-    if (kWrite && r < ctl->r_end) return;
+    if (r >= n_runs) return;
     int32_t lo, hi;
     run_bounds(cuts, n_cuts, r, l, &lo, &hi);
+    uint32_t s = threadIdx.x;
     uint64_t cur;
+    if (kWrite) {
+        if (s != 0 || !pick[r].used) return;
+        s = pick[r].start;
+    }
     if (r < n_cuts) {
-        const Node& nd = mv.nodes[mv.col_off[hi]];
+        if (s >= mv.col_nn[hi]) return;
+        const Node& nd = mv.nodes[mv.col_off[hi] + s];
         cur = node_key(hi, nd.key >> 8, nd.key & 0xffu);
     } else {
+        if (s != 0) return;
         cur = res->gkey;
     }
     uint32_t n = 0;
-    const uint32_t base_off = kWrite ? off[r] : 0u, total = kWrite ? cnt[r] : 0u;
+    const uint32_t base_off = kWrite ? pick[r].off : 0u, total = kWrite ? pick[r].count : 0u;
     bool ended = false;
     for (;;) {
         const int32_t tp = key_tpos(cur);
         Node* nd = find_node(mv, tp, key_delta(cur) << 8 | key_base(cur));
-        if (!nd || nd->len == 0) { atomicMax(status, 2u); break; }
+        if (!nd || nd->len == 0) { if (kWrite) atomicMax(status, 2u); else { ended = true; n = 0xffffffffu; } break; }
         const Entry& be = mv.entries[mv.col_off[tp] + nd->start + nd->best];
         if (key_base(cur) != 4) {
             if (kWrite) {
@@ -411,29 +475,51 @@ __global__ void k2_bt_runs(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, ui
                 if (kLq) {
                     chars[at] = ((be.link & 0xffffu) * 5 > cov || up == 'N') ? up : low;
                 } else {
+                    if (cov == 0) { atomicMax(status, 3u); break; }
                     ConsBase cb;
                     cb.qv = (char)(100 * be.link / cov);
                     cb.base = (cov > 4u && cb.qv > 20) ? up : low;
                     cb.pos = (uint32_t)tp;
                     cons[at] = cb;
                 }
-            } else if (!kLq && mv.stat[tp].coverage == 0) {
-                atomicMax(status, 3u);
             }
             ++n;
         }
         cur = be.pp;
         if (key_tpos(cur) == -1) { ended = true; break; }
-        if (key_tpos(cur) <= lo) break;   // reached the left cut's node: it starts the previous run's walk
+        if (key_tpos(cur) <= lo) break;   // reached the left cut column: that node starts the previous run's walk
     }
-    if (!kWrite) {
-        cnt[r] = n;
-        if (ended) atomicMax(&ctl->r_end, r);
-    }
+    if (!kWrite) walks[(uint64_t)r * CUT_K + s] = BtWalk{cur, n, ended ? 1u : 0u};
 }
-__global__ void k2_bt_mask(uint32_t* cnt, uint32_t n_runs, const BtCtl* ctl) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n_runs && r < ctl->r_end) cnt[r] = 0;
+
+// one lane: choose the start node of every run from the right, then place the runs from the left
+__global__ void k2_bt_chain(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, const BtWalk* walks,
+                            BtPick* pick, uint32_t* total_out, uint32_t* status) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t cur = res->gkey;
+    int64_t r = (int64_t)n_runs - 1;
+    int64_t first_used = r + 1;
+    for (; r >= 0; --r) {
+        uint32_t s = 0;
+        if ((uint32_t)r < n_cuts) {   // locate `cur` among the nodes of the run's right cut column
+            const int32_t hi = (int32_t)cuts[r];
+            const Node* nd = mv.nodes + mv.col_off[hi];
+            const uint32_t key = key_delta(cur) << 8 | key_base(cur);
+            const uint32_t nn = mv.col_nn[hi];
+            while (s < nn && nd[s].key != key) ++s;
+            if (key_tpos(cur) != hi || s >= nn || s >= CUT_K) { *status = 2; break; }
+        }
+        const BtWalk w = walks[(uint64_t)r * CUT_K + s];
+        if (w.count == 0xffffffffu) { *status = 2; break; }
+        pick[r] = BtPick{s, w.count, 0, 1};
+        first_used = r;
+        if (w.ended) break;
+        cur = w.exit_key;
+    }
+    for (int64_t q = 0; q < first_used; ++q) pick[q] = BtPick{0, 0, 0, 0};
+    uint32_t off = 0;
+    for (int64_t q = first_used; q < (int64_t)n_runs; ++q) { pick[q].off = off; off += pick[q].count; }
+    *total_out = off;
 }
 
 // ---- exclusive scan of uint32 counts (three launches: block sums, scan of the sums, final)
@@ -529,7 +615,7 @@ class HipExec : public Exec {
     int device_;
     hipStream_t stream_ = nullptr;
     DevBuf contig_, pos_, ncig_, cigoff_, seqoff_, cigar_, seq_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
-        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, ea_, ec_, runac_, btcnt_, btoff_;
+        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, btwalk_, btpick_;
     uint64_t contig_serial_ = ~0ull;
     size_t contig_len_ = 0;
 };
@@ -675,10 +761,12 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
                     std::string* err) {
     hipStream_t q = stream_;
     const bool lq = rule == RULE_LQ || rule == RULE_LQ_HIFI;
-    if (!cutflag_.ensure(4ull * (n_cols + 2)) || !cutpos_.ensure(4ull * (n_cols + 2)) || !cuts_.ensure(4ull * (n_cols + 2)) ||
-        !ea_.ensure(8ull * (size_t)total + 64) || !ec_.ensure(8ull * (size_t)total + 64) || !flag_.ensure(32) ||
-        !cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) { *err = "out of device memory (dp runs)"; return false; }
-    k2_cut_flags<<<nblk(n_cols + 1, 256), 256, 0, q>>>(mv, n_cols, cutflag_.as<uint32_t>());
+    if (!cutflag_.ensure(4ull * (n_cols + CUT_BLOCK + 2)) || !cutpos_.ensure(4ull * (n_cols + 2)) || !cuts_.ensure(4ull * (n_cols + 2)) ||
+        !eav_.ensure(8ull * (CUT_K + 1) * (size_t)total + 64) || !flag_.ensure(32) || !cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) {
+        *err = "out of device memory (dp runs)";
+        return false;
+    }
+    k2_cut_flags<<<nblk(n_cols / CUT_BLOCK + 1, 64), 64, 0, q>>>(mv, n_cols, l, cutflag_.as<uint32_t>());
     const uint32_t nsb2 = nblk(n_cols + 1, SCAN_TILE);
     k2_scan_sums<<<nsb2, SCAN_T, 0, q>>>(cutflag_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
     k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb2);
@@ -690,19 +778,27 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     uint32_t last_cut = 0xffffffffu;
     if (n_cuts) HIPOK(hipMemcpyAsync(&last_cut, cuts_.as<uint32_t>() + (n_cuts - 1), 4, hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
-    // cuts beyond column l - 1 cannot occur (column l holds no node); a window ending on a cut has no open run behind it
+    // a window ending on a cut column has no open run behind it
     const uint32_t n_runs = (n_cuts && (int32_t)last_cut == l - 1) ? n_cuts : n_cuts + 1;
-    if (!runac_.ensure(sizeof(RunAC) * (size_t)n_runs + 64) || !btcnt_.ensure(4ull * (n_runs + 2)) || !btoff_.ensure(4ull * (n_runs + 2))) {
-        *err = "out of device memory (dp runs)";
-        return false;
+    if (!runt_.ensure(sizeof(RunT) * (size_t)n_runs + 64) || !btwalk_.ensure(sizeof(BtWalk) * CUT_K * (size_t)n_runs + 64) ||
+        !btpick_.ensure(sizeof(BtPick) * (size_t)n_runs + 64)) { *err = "out of device memory (dp runs)"; return false; }
+    if (clk && clk->on) {
+        std::vector<uint32_t> hc(n_cuts);
+        if (n_cuts) (void)hipMemcpy(hc.data(), cuts_.p, 4ull * n_cuts, hipMemcpyDeviceToHost);
+        uint32_t mx = n_cuts ? hc[0] + 1 : (uint32_t)l, over1k = 0;
+        for (uint32_t i = 1; i < n_cuts; ++i) { mx = std::max(mx, hc[i] - hc[i - 1]); over1k += hc[i] - hc[i - 1] > 1000; }
+        fprintf(stderr, "[np2 dp] %u cuts, %u runs over %d columns; longest run %u columns, %u runs > 1000\n", n_cuts, n_runs, l, mx, over1k);
     }
-    if (clk && clk->on) fprintf(stderr, "[np2 dp] %u cuts, %u runs over %d columns\n", n_cuts, n_runs, l);
     HIPOK(hipMemsetAsync(flag_.p, 0, 32, q));
     HIPOK(hipMemsetAsync(res_.p, 0, sizeof(DpResult), q));
     const long long C = rule == RULE_LQ ? 2 : (rule == READS_HIFI || rule == RULE_LQ_HIFI) ? 4 : 3;
-    k2_run_ac<<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, ea_.as<long long>(), ec_.as<long long>(), runac_.as<RunAC>());
-    k2_run_scan<<<1, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, runac_.as<RunAC>());
-#define NP2_RUN_DP(T) k2_run_dp<T><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>())
+    k2_run_ac<<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, eav_.as<long long>(), runt_.as<RunT>());
+    k2_run_scan<<<1, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, runt_.as<RunT>());
+#define NP2_RUN_DP(T)                                                                                                         \
+    do {                                                                                                                      \
+        k2_run_dp_a<T><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>());               \
+        if (n_cuts) k2_run_dp_b<T><<<n_cuts, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, l, res_.as<DpResult>());          \
+    } while (0)
     switch (rule) {
         case READS_CLR: NP2_RUN_DP(READS_CLR); break;
         case READS_HIFI: NP2_RUN_DP(READS_HIFI); break;
@@ -713,30 +809,24 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     }
 #undef NP2_RUN_DP
     if (clk) clk->mark("dp");
-    // ---- backtrace: count per run, place, write
-    BtCtl* ctl = reinterpret_cast<BtCtl*>(flag_.as<uint32_t>() + 2);
+    // ---- backtrace: walk every start, chain the runs, write
     uint32_t* status = flag_.as<uint32_t>() + 4;
-    if (lq) k2_bt_runs<true, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btcnt_.as<uint32_t>(), ctl, nullptr, nullptr, nullptr, status);
-    else k2_bt_runs<false, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btcnt_.as<uint32_t>(), ctl, nullptr, nullptr, nullptr, status);
-    k2_bt_mask<<<nblk(n_runs, 256), 256, 0, q>>>(btcnt_.as<uint32_t>(), n_runs, ctl);
-    const uint32_t nsb3 = nblk(n_runs + 1, SCAN_TILE);
-    HIPOK(hipMemsetAsync(btcnt_.as<uint32_t>() + n_runs, 0, 4, q));
-    k2_scan_sums<<<nsb3, SCAN_T, 0, q>>>(btcnt_.as<uint32_t>(), n_runs + 1, sums_.as<uint32_t>());
-    k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb3);
-    k2_scan_final<<<nsb3, SCAN_T, 0, q>>>(btcnt_.as<uint32_t>(), n_runs + 1, sums_.as<uint32_t>(), btoff_.as<uint32_t>());
-    if (lq) k2_bt_runs<true, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btcnt_.as<uint32_t>(), ctl, btoff_.as<uint32_t>(), nullptr, cons_.as<char>(), status);
-    else k2_bt_runs<false, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btcnt_.as<uint32_t>(), ctl, btoff_.as<uint32_t>(), cons_.as<ConsBase>(), nullptr, status);
+    uint32_t* total_dev = flag_.as<uint32_t>() + 5;
+    if (lq) k2_bt_runs<true, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status);
+    else k2_bt_runs<false, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status);
+    k2_bt_chain<<<1, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), btpick_.as<BtPick>(), total_dev, status);
+    if (lq) k2_bt_runs<true, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), nullptr, cons_.as<char>(), status);
+    else k2_bt_runs<false, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), cons_.as<ConsBase>(), nullptr, status);
     DpResult res;
-    uint32_t st = 0, total_len = 0;
+    uint32_t st2[2] = {0, 0};
     HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));
-    HIPOK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, q));
-    HIPOK(hipMemcpyAsync(&total_len, btoff_.as<uint32_t>() + n_runs, 4, hipMemcpyDeviceToHost, q));
+    HIPOK(hipMemcpyAsync(st2, status, 8, hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
     if (clk) clk->mark("backtrace");
     if (!lq && res.status == 1) { *err = "no alignment column reaches the end of the window"; return false; }
-    if (st == 2) { *err = lq ? "low-quality backtrace left the graph" : "backtrace left the graph"; return false; }
-    if (st == 3) { *err = "zero coverage on the consensus path"; return false; }
-    *cons_len = total_len;
+    if (st2[0] == 2) { *err = lq ? "low-quality backtrace left the graph" : "backtrace left the graph"; return false; }
+    if (st2[0] == 3) { *err = "zero coverage on the consensus path"; return false; }
+    *cons_len = st2[1];
     return true;
 }
 
