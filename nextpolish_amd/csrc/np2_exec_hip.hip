@@ -297,6 +297,7 @@ __global__ void k2_cut_list(const uint32_t* flag, const uint32_t* pos, uint32_t 
 struct RunT {
     long long A[CUT_K][CUT_K];   // A[j][i]: output j from input i
     long long C[CUT_K];
+    uint32_t n_out, pad;         // live entries of the right cut column
 };
 
 // run r covers columns (lo, hi]: lo = cuts[r-1] (or -1), hi = cuts[r] (or l-1 for the last, open run)
@@ -360,22 +361,94 @@ __global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uin
             }
         }
     }
+    if (lane == 0) out[r].n_out = jout;
 }
 
-// x at every cut; the cut columns' entries get their true scores so the literal passes can start from them
-__global__ void k2_run_scan(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, const RunT* rt) {
+// ---- scores at the cuts: scan of the run transfers, grouped ------------------------------------------------------
+// T2 o T1 in the (max, +) semiring with constants: A = A2 (x) A1, C = max(C2, A2 (x) C1).  Groups of SCAN_G runs are
+// composed in parallel (one wave per group, lane (j, i) owns A[j][i]), one lane chains the groups, then every group
+// replays its runs from its true entry vector and writes the cut columns' scores.
+constexpr uint32_t SCAN_G = 32;
+__device__ __forceinline__ long long mp_add(long long a, long long b) { return (a > AC_NEG && b > AC_NEG) ? a + b : AC_NEG; }
+
+__global__ __launch_bounds__(64) void k2_scan_groups(const RunT* rt, uint32_t n_cuts, RunT* gt) {
+    __shared__ long long sA[CUT_K][CUT_K], sC[CUT_K], tA[CUT_K][CUT_K], tC[CUT_K];
+    const uint32_t g = blockIdx.x, lane = threadIdx.x, j = lane / CUT_K, i = lane % CUT_K;
+    const uint32_t r0 = g * SCAN_G, r1 = r0 + SCAN_G < n_cuts ? r0 + SCAN_G : n_cuts;
+    // running transfer = run r0
+    sA[j][i] = rt[r0].A[j][i];
+    if (lane < CUT_K) sC[lane] = rt[r0].C[lane];
+    uint32_t n_mid = rt[r0].n_out;   // outputs of the running transfer = inputs of the next run
+    __syncthreads();
+    for (uint32_t r = r0 + 1; r < r1; ++r) {
+        tA[j][i] = rt[r].A[j][i];
+        if (lane < CUT_K) tC[lane] = rt[r].C[lane];
+        const uint32_t n_out = rt[r].n_out;
+        __syncthreads();
+        long long a = AC_NEG, c = AC_NEG;
+        if (j < n_out) {
+            for (uint32_t k = 0; k < n_mid; ++k) {
+                const long long v = mp_add(tA[j][k], sA[k][i]);
+                if (v > a) a = v;
+            }
+            if (i == 0) {
+                c = tC[j];
+                for (uint32_t k = 0; k < n_mid; ++k) {
+                    const long long v = mp_add(tA[j][k], sC[k]);
+                    if (v > c) c = v;
+                }
+            }
+        }
+        __syncthreads();
+        sA[j][i] = a;
+        if (i == 0) sC[j] = c;
+        n_mid = n_out;
+        __syncthreads();
+    }
+    gt[g].A[j][i] = sA[j][i];
+    if (lane < CUT_K) gt[g].C[lane] = sC[lane];
+    if (lane == 0) gt[g].n_out = n_mid;
+}
+// entry vector of every group (x before its first run); group 0 starts from nothing
+__global__ void k2_scan_chain(const RunT* gt, uint32_t n_groups, long long* gx, uint32_t* gn) {
     if (blockIdx.x || threadIdx.x) return;
     long long x[CUT_K], xn[CUT_K];
     uint32_t n_in = 0;
-    for (uint32_t r = 0; r < n_cuts; ++r) {
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        for (uint32_t i = 0; i < CUT_K; ++i) gx[(uint64_t)g * CUT_K + i] = i < n_in ? x[i] : AC_NEG;
+        gn[g] = n_in;
+        const uint32_t n_out = gt[g].n_out;
+        for (uint32_t j = 0; j < n_out; ++j) {
+            long long v = gt[g].C[j];
+            for (uint32_t i = 0; i < n_in; ++i) {
+                const long long t = mp_add(x[i], gt[g].A[j][i]);
+                if (t > v) v = t;
+            }
+            xn[j] = v;
+        }
+        n_in = n_out;
+        for (uint32_t i = 0; i < n_in; ++i) x[i] = xn[i];
+    }
+}
+// every group replays its runs; the cut columns' entries get their true scores so the literal passes can start from them
+__global__ void k2_scan_apply(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, const RunT* rt, const long long* gx, const uint32_t* gn) {
+    const uint32_t g = blockIdx.x;
+    if (threadIdx.x) return;
+    const uint32_t r0 = g * SCAN_G, r1 = r0 + SCAN_G < n_cuts ? r0 + SCAN_G : n_cuts;
+    long long x[CUT_K], xn[CUT_K];
+    uint32_t n_in = gn[g];
+    for (uint32_t i = 0; i < n_in; ++i) x[i] = gx[(uint64_t)g * CUT_K + i];
+    for (uint32_t r = r0; r < r1; ++r) {
         const uint32_t p = cuts[r];
         const Node* nd = mv.nodes + mv.col_off[p];
         uint32_t jo = 0;
         for (uint32_t j = 0; j < mv.col_nn[p]; ++j)
             for (uint32_t m = 0; m < nd[j].len; ++m) {
                 long long v = rt[r].C[jo];
-                for (uint32_t i = 0; i < n_in; ++i)
-                    if (x[i] > AC_NEG && rt[r].A[jo][i] > AC_NEG && x[i] + rt[r].A[jo][i] > v) v = x[i] + rt[r].A[jo][i];
+                for (uint32_t i = 0; i < n_in; ++i) {
+                    const long long t = mp_add(x[i], rt[r].A[jo][i]);
+                    if (t > v) v = t;
+                }
                 xn[jo] = v;
                 mv.entries[mv.col_off[p] + nd[j].start + m].score = v;
                 ++jo;
@@ -615,7 +688,7 @@ class HipExec : public Exec {
     int device_;
     hipStream_t stream_ = nullptr;
     DevBuf contig_, pos_, ncig_, cigoff_, seqoff_, cigar_, seq_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
-        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, btwalk_, btpick_;
+        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_;
     uint64_t contig_serial_ = ~0ull;
     size_t contig_len_ = 0;
 };
@@ -791,9 +864,21 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     }
     HIPOK(hipMemsetAsync(flag_.p, 0, 32, q));
     HIPOK(hipMemsetAsync(res_.p, 0, sizeof(DpResult), q));
+    if (clk) clk->mark("dp.cuts");
     const long long C = rule == RULE_LQ ? 2 : (rule == READS_HIFI || rule == RULE_LQ_HIFI) ? 4 : 3;
     k2_run_ac<<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, eav_.as<long long>(), runt_.as<RunT>());
-    k2_run_scan<<<1, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, runt_.as<RunT>());
+    if (clk) clk->mark("dp.ac");
+    if (n_cuts) {
+        const uint32_t n_groups = nblk(n_cuts, SCAN_G);
+        if (!grpt_.ensure(sizeof(RunT) * (size_t)n_groups + 64) || !grpx_.ensure(8ull * CUT_K * n_groups + 64) || !grpn_.ensure(4ull * n_groups + 64)) {
+            *err = "out of device memory (dp scan)";
+            return false;
+        }
+        k2_scan_groups<<<n_groups, 64, 0, q>>>(runt_.as<RunT>(), n_cuts, grpt_.as<RunT>());
+        k2_scan_chain<<<1, 64, 0, q>>>(grpt_.as<RunT>(), n_groups, grpx_.as<long long>(), grpn_.as<uint32_t>());
+        k2_scan_apply<<<n_groups, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, runt_.as<RunT>(), grpx_.as<long long>(), grpn_.as<uint32_t>());
+    }
+    if (clk) clk->mark("dp.scan");
 #define NP2_RUN_DP(T)                                                                                                         \
     do {                                                                                                                      \
         k2_run_dp_a<T><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>());               \
@@ -808,7 +893,7 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
         default: NP2_RUN_DP(READS_ONT); break;
     }
 #undef NP2_RUN_DP
-    if (clk) clk->mark("dp");
+    if (clk) clk->mark("dp.replay");
     // ---- backtrace: walk every start, chain the runs, write
     uint32_t* status = flag_.as<uint32_t>() + 4;
     uint32_t* total_dev = flag_.as<uint32_t>() + 5;
