@@ -260,12 +260,19 @@ struct StrColIter {
 // the high nibble), zero-initialised by the caller with (aln_len + 1) / 2 + 1 bytes.  Adds the stream to the column
 // statistics through St (atomic on the device).  tpos: window-relative position of the first draft base;
 // gap_min_len: 3 ONT, 5 else.  Returns the window-relative exclusive end.
+// state of the tag emission between two columns (checkpoints let lanes own chunks of a stream)
+struct EmitState {
+    uint32_t te;      // window-relative position of the last draft column seen (tpos - 1 before the first)
+    uint32_t delta;   // length of the open insertion run
+    uint32_t l;       // the open insertion run was already counted in l_ins
+};
+// columns [p0, p0 + n) of a stream (p = column index inside the stream = nibble index); `last`: this call ends the
+// stream and writes the terminator
 template <class It, class St>
-NP2_HD uint32_t emit_tags_from(It& f, uint32_t aln_len, uint32_t tpos, uint32_t gap_min_len, uint8_t* tags, St& st) {
-    uint32_t te = tpos - 1;
-    uint32_t delta = 0, l = 0, p = 0;
+NP2_HD void emit_tags_range(It& f, uint32_t p0, uint32_t n, EmitState* es, bool last, uint32_t gap_min_len, uint8_t* tags, St& st) {
+    uint32_t te = es->te, delta = es->delta, l = es->l, p = p0;
     char t, q;
-    for (; p < aln_len; ++p) {
+    for (; p < p0 + n; ++p) {
         f.get(&t, &q);
         uint32_t b = base_to_int((unsigned char)q);
         if (t == '-') { b |= 8; ++delta; }
@@ -277,9 +284,17 @@ NP2_HD uint32_t emit_tags_from(It& f, uint32_t aln_len, uint32_t tpos, uint32_t 
         if (delta == 0 && q == '-') st.l_del(te);
         f.next();
     }
-    if ((p - 1) & 1) tags[p >> 1] |= 255;
-    else tags[p >> 1] |= 15;
-    return te + 1;
+    if (last) {
+        if ((p - 1) & 1) tags[p >> 1] |= 255;
+        else tags[p >> 1] |= 15;
+    }
+    es->te = te; es->delta = delta; es->l = l;
+}
+template <class It, class St>
+NP2_HD uint32_t emit_tags_from(It& f, uint32_t aln_len, uint32_t tpos, uint32_t gap_min_len, uint8_t* tags, St& st) {
+    EmitState es{tpos - 1, 0, 0};
+    emit_tags_range(f, 0u, aln_len, &es, true, gap_min_len, tags, st);
+    return es.te + 1;
 }
 
 // the kept columns of one record (win_s: window start in contig coordinates)

@@ -117,16 +117,66 @@ struct StreamDesc {   // one kept record
     uint64_t tag_off;
 };
 
-__global__ void k2_tags(const StreamDesc* sd, uint32_t n_streams, const int32_t* pos, const uint32_t* n_cigar,
-                        const uint64_t* cigar_off, const uint64_t* seq_off, const uint32_t* cigar, const uint8_t* seq,
-                        const char* contig_seq, int32_t s, uint32_t gap_min_len, uint8_t* tags, DevStat st, uint32_t* te_out) {
+// ---- chunk-parallel tag emission -------------------------------------------------------------------------------
+// k2_tag_ckpt (lane per kept record, O(#CIGAR ops)): the CIGAR cursor and the emission state at every
+// TAG_CHUNK-th kept column; k2_tags_chunk (lane per chunk): get_align_tags on its columns.  TAG_CHUNK is even, so
+// a chunk owns whole tag bytes.
+constexpr uint32_t TAG_CHUNK = 256;
+struct TagCkpt { uint32_t op_i, in_op, rfi, rdi, te_before, delta_before; };
+struct TagChunk { uint32_t stream, c0, n, last; };   // stream = index into the StreamDesc array
+
+__global__ void k2_tag_ckpt(const StreamDesc* sd, uint32_t n_streams, const uint32_t* chunk_off, const int32_t* pos, const uint32_t* n_cigar,
+                            const uint64_t* cigar_off, const uint32_t* cigar, int32_t s, TagCkpt* ck) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_streams) return;
     const StreamDesc d = sd[k];
+    const uint32_t* cg = cigar + cigar_off[d.read];
+    const uint32_t nc = n_cigar[d.read];
+    const uint32_t n_chunks = (d.aln_len + TAG_CHUNK - 1) / TAG_CHUNK;
+    TagCkpt* out = ck + chunk_off[k];
+    uint32_t col = 0, rfi = (uint32_t)pos[d.read], rdi = 0, tcount = 0, run = 0, ci = 0;
+    uint32_t target = d.col0;
+    const uint32_t te0 = d.aln_t_s - (uint32_t)s - 1;
+    for (uint32_t i = 0; i < nc && ci < n_chunks; ++i) {
+        const uint32_t c = cg[i] & 0xf, n = cg[i] >> 4;
+        if (c == 4 || c == 5) { rdi += n; continue; }
+        if (c == 3) { rfi += n; continue; }
+        if (c > 2 || n == 0) continue;
+        while (ci < n_chunks && target < col + n) {
+            const uint32_t o = target - col;
+            TagCkpt t;
+            t.op_i = i; t.in_op = o;
+            t.rfi = rfi + (c != 1 ? o : 0u);
+            t.rdi = rdi + (c != 2 ? o : 0u);
+            const uint32_t from = col > d.col0 ? col : d.col0;   // counting starts at the first kept column
+            t.te_before = te0 + tcount + (c != 1 ? target - from : 0u);
+            t.delta_before = ci == 0 ? 0u : (o > 0 ? (c == 1 ? run + o : 0u) : run);
+            out[ci++] = t;
+            target += TAG_CHUNK;
+        }
+        if (c != 1 && col + n > d.col0) tcount += col + n - (col > d.col0 ? col : d.col0);
+        if (c != 1) rfi += n;
+        if (c != 2) rdi += n;
+        run = c == 1 ? run + n : 0u;
+        col += n;
+    }
+}
+
+__global__ void k2_tags_chunk(const TagChunk* tc, uint32_t n_chunks, const TagCkpt* ck, const StreamDesc* sd, const int32_t* pos,
+                              const uint32_t* n_cigar, const uint64_t* cigar_off, const uint64_t* seq_off, const uint32_t* cigar,
+                              const uint8_t* seq, const char* contig_seq, uint32_t gap_min_len, uint8_t* tags, DevStat st, uint32_t* te_out) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const TagChunk ch = tc[c];
+    const StreamDesc d = sd[ch.stream];
+    const TagCkpt t = ck[c];
     ReadView rv{pos[d.read], n_cigar[d.read], cigar + cigar_off[d.read], seq + seq_off[d.read]};
-    AlnSpan a{d.col0, d.aln_len, d.aln_t_s, 0};
+    ColIter f;
+    f.r = &rv; f.rf = contig_seq; f.op_i = t.op_i; f.in_op = t.in_op; f.rfi = t.rfi; f.rdi = t.rdi;
+    EmitState es{t.te_before, t.delta_before, t.delta_before >= gap_min_len ? 1u : 0u};
     DevStatSink sink{st};
-    te_out[k] = emit_tags(rv, contig_seq, a, s, gap_min_len, tags + d.tag_off, sink);
+    emit_tags_range(f, ch.c0, ch.n, &es, ch.last != 0, gap_min_len, tags + d.tag_off, sink);
+    if (ch.last) te_out[ch.stream] = es.te + 1;
 }
 
 // ---- link observations from the tag streams, chunk-parallel ----------------------------------------------------
@@ -688,7 +738,7 @@ class HipExec : public Exec {
     int device_;
     hipStream_t stream_ = nullptr;
     DevBuf contig_, pos_, ncig_, cigoff_, seqoff_, cigar_, seq_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
-        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_;
+        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_;
     uint64_t contig_serial_ = ~0ull;
     size_t contig_len_ = 0;
 };
@@ -793,9 +843,35 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     k2_seed_tags<<<nblk(((uint64_t)l + 1) / 2 + 1, 256), 256, 0, q>>>(contig_.as<char>(), s, (uint32_t)l, tags_.as<uint8_t>(), st.coverage, st.max_size);
     if (!sd.empty()) {
         HIPOK(hipMemcpyAsync(sd_.p, sd.data(), sizeof(StreamDesc) * sd.size(), hipMemcpyHostToDevice, q));
-        k2_tags<<<nblk(sd.size(), 64), 64, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), pos_.as<int32_t>(), ncig_.as<uint32_t>(),
-                                                   cigoff_.as<uint64_t>(), seqoff_.as<uint64_t>(), cigar_.as<uint32_t>(), seq_.as<uint8_t>(),
-                                                   contig_.as<char>(), s, in.gap_min_len, tags_.as<uint8_t>(), st, te_.as<uint32_t>() + 1);
+        // chunk list (host, O(records)); empty streams still need their terminator and end position
+        std::vector<TagChunk> tcs;
+        std::vector<uint32_t> choff(sd.size());
+        for (uint32_t k = 0; k < (uint32_t)sd.size(); ++k) {
+            choff[k] = (uint32_t)tcs.size();
+            const uint32_t nch = (sd[k].aln_len + TAG_CHUNK - 1) / TAG_CHUNK;
+            for (uint32_t c = 0; c < nch; ++c)
+                tcs.push_back(TagChunk{k, c * TAG_CHUNK, std::min(TAG_CHUNK, sd[k].aln_len - c * TAG_CHUNK), c + 1 == nch ? 1u : 0u});
+        }
+        const uint32_t n_tchunks = (uint32_t)tcs.size();
+        if (!tchunks_.ensure(sizeof(TagChunk) * (size_t)n_tchunks + 64) || !tckpt_.ensure(sizeof(TagCkpt) * (size_t)n_tchunks + 64) ||
+            !tchoff_.ensure(4ull * sd.size() + 64)) { *err = "out of device memory (tag chunks)"; return false; }
+        // streams without columns (aln_len 0): terminator byte 0xff and end = start, written from the host
+        for (uint32_t k = 0; k < (uint32_t)sd.size(); ++k)
+            if (sd[k].aln_len == 0) {
+                const uint8_t ff = 0xff;
+                const uint32_t te = sd[k].aln_t_s - (uint32_t)s;
+                HIPOK(hipMemcpyAsync(tags_.as<uint8_t>() + sd[k].tag_off, &ff, 1, hipMemcpyHostToDevice, q));
+                HIPOK(hipMemcpyAsync(te_.as<uint32_t>() + 1 + k, &te, 4, hipMemcpyHostToDevice, q));
+            }
+        if (n_tchunks) {
+            HIPOK(hipMemcpyAsync(tchunks_.p, tcs.data(), sizeof(TagChunk) * (size_t)n_tchunks, hipMemcpyHostToDevice, q));
+            HIPOK(hipMemcpyAsync(tchoff_.p, choff.data(), 4ull * sd.size(), hipMemcpyHostToDevice, q));
+            k2_tag_ckpt<<<nblk(sd.size(), 64), 64, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), tchoff_.as<uint32_t>(), pos_.as<int32_t>(),
+                                                           ncig_.as<uint32_t>(), cigoff_.as<uint64_t>(), cigar_.as<uint32_t>(), s, tckpt_.as<TagCkpt>());
+            k2_tags_chunk<<<nblk(n_tchunks, 64), 64, 0, q>>>(tchunks_.as<TagChunk>(), n_tchunks, tckpt_.as<TagCkpt>(), sd_.as<StreamDesc>(), pos_.as<int32_t>(),
+                                                             ncig_.as<uint32_t>(), cigoff_.as<uint64_t>(), seqoff_.as<uint64_t>(), cigar_.as<uint32_t>(),
+                                                             seq_.as<uint8_t>(), contig_.as<char>(), in.gap_min_len, tags_.as<uint8_t>(), st, te_.as<uint32_t>() + 1);
+        }
     }
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>());
     HIPOK(hipMemcpyAsync(tagoff_.p, out->tag_off.data(), 8ull * n_streams, hipMemcpyHostToDevice, q));

@@ -11,7 +11,10 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <time.h>
 
 namespace np2 {
 namespace {
@@ -34,8 +37,12 @@ struct Region {      // lqseq (ctg_cns.h:73-90)
     std::vector<Cand> seqs;
 };
 
+// the 65 536-bin table is cleared through the list of bins the previous call touched (the reference memsets 128 KB
+// per call; the counts are the same)
+thread_local std::vector<uint16_t> g_touched;
 void count_kmers(const Region& lq, std::vector<uint16_t>& kmers, int c, int l) {
-    std::fill(kmers.begin(), kmers.end(), 0);
+    for (uint16_t k : g_touched) kmers[k] = 0;
+    g_touched.clear();
     for (int j = 0; j < std::min(lq.len, c); ++j) {
         const Cand& cd = lq.seqs[(size_t)j];
         if (cd.len < (uint32_t)KMER_LEN) continue;
@@ -45,7 +52,7 @@ void count_kmers(const Region& lq, std::vector<uint16_t>& kmers, int c, int l) {
             if (k) kmer = (uint16_t)(kmer << 2 | np2k::base_to_int((unsigned char)cd.seq[(size_t)(s + k + KMER_LEN - 1)]));
             else
                 for (int index = 0; index < KMER_LEN; ++index) kmer = (uint16_t)(kmer << 2 | np2k::base_to_int((unsigned char)cd.seq[(size_t)(s + k + index)]));
-            ++kmers[kmer];
+            if (kmers[kmer]++ == 0) g_touched.push_back(kmer);
         }
     }
 }
@@ -145,6 +152,7 @@ bool rank_and_seed(Region& r, std::vector<uint16_t>& kmers, bool trim, int min_s
 // generate_lqseqs_from_tags (kmer = false) / generate_lqseqs_from_tags_kmer (HiFi, ctg_cns.c:636-820); returns max_aln_length
 int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo, bool kmer) {
     const int count = (int)lq.size();
+    if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   collect start (t=%.2f)\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6); }
     for (Region& r : lq) {
         r.sudoseed.clear();
         r.lqcount = 0; r.len = 0; r.sudoseed_len = 0;
@@ -184,6 +192,7 @@ int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo, bool kme
             }
         }
     }
+    if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   tag walk done (t=%.2f)\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6); }
     int max_aln_length = 0;
     std::vector<uint16_t> kmers(65536);
     for (int i = 0; i < count; ++i) {
@@ -298,6 +307,11 @@ bool consensus_of_regions(Exec* exec, std::vector<Region>& lq, uint32_t gap_min_
         in.q.push_back(a.q.substr(0, a.len));
     }
     in.t_len = (uint32_t)aligned_linkseq_len;
+    if (getenv("NP2_TIMING")) {
+        timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        static double last = 0; const double t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+        fprintf(stderr, "[np2 lq]   alignments built, %u target columns (t=%.2f)\n", in.t_len, t - last); last = t;
+    }
     return exec->run_lq(in, cons_rev, err);
 }
 
@@ -314,11 +328,16 @@ bool lq_stage(Exec* exec, uint32_t gap_min_len, bool hifi, const std::vector<LqR
     const int count = (int)regions.size();
     std::vector<Region> lq((size_t)count);
     for (int i = 0; i < count; ++i) { lq[(size_t)i].start = regions[(size_t)i].start; lq[(size_t)i].end = regions[(size_t)i].end; lq[(size_t)i].l = regions[(size_t)i].l; }
+    const bool timing = getenv("NP2_TIMING") != nullptr;
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    double t0 = now();
     collect_candidates(lq, wo, hifi);
+    if (timing) { const double t = now(); fprintf(stderr, "[np2 lq] candidates+poa %.2f ms\n", t - t0); t0 = t; }
     // ---- iterate_generate_consensus_trimed (two rounds)
     for (int it = 1; it <= 2; ++it) {
         std::string cr;
         if (!consensus_of_regions(exec, lq, gap_min_len, hifi, &cr, err)) return false;
+        if (timing) { const double t = now(); fprintf(stderr, "[np2 lq] round %d (align + graph consensus) %.2f ms\n", it, t - t0); t0 = t; }
         int j = count;
         for (size_t k = cr.size(); k; --k) {
             const char c = cr[k - 1];

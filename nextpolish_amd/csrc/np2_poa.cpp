@@ -51,19 +51,19 @@ struct Graph {
     uint16_t node_count = 0;
     uint32_t edge_count = 0;
     int32_t insert_node(char base) {
-        if (nodes.size() <= node_count) nodes.resize(nodes.size() + 1000);
+        if (nodes.size() <= node_count) nodes.resize(nodes.size() + 256);
         nodes[node_count].base = (uint8_t)base;
         ++node_count;
-        if (nodes.size() <= node_count) nodes.resize(nodes.size() + 1000);
+        if (nodes.size() <= node_count) nodes.resize(nodes.size() + 256);
         return node_count - 1;
     }
     uint32_t insert_edge(uint16_t in, uint16_t out, uint8_t lable) {
-        if (edges.size() <= edge_count) edges.resize(edges.size() + 2000);
+        if (edges.size() <= edge_count) edges.resize(edges.size() + 512);
         edges[edge_count].innode_index = in;
         edges[edge_count].outnode_index = out;
         edges[edge_count].lable[lable] = 1;
         ++edge_count;
-        if (edges.size() <= edge_count) edges.resize(edges.size() + 2000);
+        if (edges.size() <= edge_count) edges.resize(edges.size() + 512);
         return edge_count - 1;
     }
     void link(int32_t head, int32_t node, uint32_t e) {
@@ -276,9 +276,11 @@ void align_seq_to_graph(uint16_t x, uint16_t y, size_t seq_index, const char* se
 
 std::string poa_consensus(const std::vector<std::string>& seqs) {
     Graph g;
-    g.nodes.resize(10000);
-    g.edges.resize(20000);
-    g.sorted_nodes.resize(10000);
+    size_t total = 0;
+    for (const std::string& s : seqs) total += s.size() + 2;
+    g.nodes.resize(total + 16);          // (the reference starts at 10 000 nodes and grows; capacity is not observable)
+    g.edges.resize(2 * total + 32);
+    g.sorted_nodes.resize(total + 16);
     assert((int)seqs.size() <= SEQ_MAX_COUNT);
     for (size_t si = 0; si < seqs.size(); ++si) {
         const std::string& s = seqs[si];
