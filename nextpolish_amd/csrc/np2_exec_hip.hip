@@ -289,14 +289,33 @@ struct DpResult {
     uint32_t cons_len, status;   // status: 0 ok, 1 no end column, 2 backtrace left the graph, 3 zero coverage
 };
 
-// tag streams of gapped string pairs (the concatenated low-quality regions); one lane per pair
-__global__ void k2_tags_str(const char* pool, const uint64_t* str_off, const uint32_t* str_len, uint32_t n, uint32_t gap_min_len,
-                            const uint64_t* tag_off, uint8_t* tags, DevStat st, uint32_t* te_out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    StrColIter f{pool + str_off[2 * i], pool + str_off[2 * i + 1], 0};
+// tag streams of gapped string pairs (the concatenated low-quality regions), chunk-parallel: the target position of
+// a column is the number of non-gap target characters before it (count per chunk + scan), the open insertion run is
+// found by a short look-back
+struct StrChunk { uint32_t stream, c0, n, first_chunk_of_stream, last, pad0, pad1, pad2; };
+__global__ void k2_str_count(const StrChunk* sc, uint32_t n_chunks, const char* pool, const uint64_t* str_off, uint32_t* cnt) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const StrChunk d = sc[c];
+    const char* t = pool + str_off[2 * d.stream] + d.c0;
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < d.n; ++i) n += t[i] != '-' ? 1u : 0u;
+    cnt[c] = n;
+}
+__global__ void k2_tags_str_chunk(const StrChunk* sc, uint32_t n_chunks, const uint32_t* pre, const char* pool, const uint64_t* str_off,
+                                  uint32_t gap_min_len, const uint64_t* tag_off, uint8_t* tags, DevStat st, uint32_t* te_out) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const StrChunk d = sc[c];
+    const char* t = pool + str_off[2 * d.stream];
+    const char* qs = pool + str_off[2 * d.stream + 1];
+    uint32_t delta = 0;
+    if (d.c0) while (delta < d.c0 && t[d.c0 - 1 - delta] == '-') ++delta;
+    EmitState es{pre[c] - pre[d.first_chunk_of_stream] - 1u, delta, delta >= gap_min_len ? 1u : 0u};
+    StrColIter f{t, qs, d.c0};
     DevStatSink sink{st};
-    te_out[i] = emit_tags_from(f, str_len[i], 0u, gap_min_len, tags + tag_off[i], sink);
+    emit_tags_range(f, d.c0, d.n, &es, d.last != 0, gap_min_len, tags + tag_off[d.stream], sink);
+    if (d.last) te_out[d.stream] = es.te + 1;
 }
 
 // ---- run-decomposed chain DP ---------------------------------------------------------------------------------
@@ -557,7 +576,7 @@ __global__ void k2_run_dp_b(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, i
 // a stream head; a one-lane chain picks the start of every run from right to left and places the runs; pass 1 walks
 // again from the chosen starts and writes.  kLq: character output of the low-quality re-consensus
 // (ctg_cns.c:1104-1143) instead of consensus bases (:1836-1858).
-struct BtWalk { uint64_t exit_key; uint32_t count; uint32_t ended; };   // per (run, start node)
+struct BtWalk { uint32_t exit_idx; uint32_t count; uint32_t ended; uint32_t pad; };   // per (run, start node); exit_idx = node index in the left cut column
 struct BtPick { uint32_t start; uint32_t count; uint32_t off; uint32_t used; };   // per run
 
 template <bool kLq, bool kWrite>
@@ -612,37 +631,86 @@ __global__ void k2_bt_runs(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, ui
         if (key_tpos(cur) == -1) { ended = true; break; }
         if (key_tpos(cur) <= lo) break;   // reached the left cut column: that node starts the previous run's walk
     }
-    if (!kWrite) walks[(uint64_t)r * CUT_K + s] = BtWalk{cur, n, ended ? 1u : 0u};
+    if (!kWrite) {
+        uint32_t xi = 0xffffffffu;
+        if (!ended && lo >= 0) {   // index of the exit node among the nodes of the left cut column
+            const Node* nl = mv.nodes + mv.col_off[lo];
+            const uint32_t key = key_delta(cur) << 8 | key_base(cur), nn = mv.col_nn[lo];
+            for (uint32_t j = 0; j < nn && j < CUT_K; ++j)
+                if (nl[j].key == key && key_tpos(cur) == lo) xi = j;
+            if (xi == 0xffffffffu) n = 0xffffffffu;   // cannot happen on a consistent graph
+        }
+        walks[(uint64_t)r * CUT_K + s] = BtWalk{xi, n, ended ? 1u : 0u, 0};
+    }
 }
 
-// one lane: choose the start node of every run from the right, then place the runs from the left
-__global__ void k2_bt_chain(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, const BtWalk* walks,
-                            BtPick* pick, uint32_t* total_out, uint32_t* status) {
-    if (blockIdx.x || threadIdx.x) return;
-    uint64_t cur = res->gkey;
-    int64_t r = (int64_t)n_runs - 1;
-    int64_t first_used = r + 1;
-    for (; r >= 0; --r) {
-        uint32_t s = 0;
-        if ((uint32_t)r < n_cuts) {   // locate `cur` among the nodes of the run's right cut column
-            const int32_t hi = (int32_t)cuts[r];
-            const Node* nd = mv.nodes + mv.col_off[hi];
-            const uint32_t key = key_delta(cur) << 8 | key_base(cur);
-            const uint32_t nn = mv.col_nn[hi];
-            while (s < nn && nd[s].key != key) ++s;
-            if (key_tpos(cur) != hi || s >= nn || s >= CUT_K) { *status = 2; break; }
-        }
-        const BtWalk w = walks[(uint64_t)r * CUT_K + s];
-        if (w.count == 0xffffffffu) { *status = 2; break; }
-        pick[r] = BtPick{s, w.count, 0, 1};
-        first_used = r;
-        if (w.ended) break;
-        cur = w.exit_key;
+// The chain "start node of run r -> exit node = start node of run r - 1" is a composition of maps on at most CUT_K
+// states, so it is grouped like the score scan: groups of BT_G runs are composed for every possible start (lanes =
+// starts), one lane chains the groups, then every group replays its runs and places them.
+constexpr uint32_t BT_G = 32;
+struct BtGroup { uint32_t exit_idx, count, ended, invalid; };   // per (group, start at the group's right-most run)
+struct BtGroupPick { uint32_t start, off, used, pad; };
+
+__global__ void k2_bt_groups(const BtWalk* walks, uint32_t n_runs, BtGroup* grp) {
+    const uint32_t g = blockIdx.x, s = threadIdx.x;
+    if (s >= CUT_K) return;
+    const uint32_t r0 = g * BT_G, r1 = r0 + BT_G < n_runs ? r0 + BT_G : n_runs;
+    uint32_t cur = s, cnt = 0, ended = 0, invalid = 0;
+    for (uint32_t r = r1; r-- > r0;) {
+        const BtWalk w = walks[(uint64_t)r * CUT_K + cur];
+        if (w.count == 0xffffffffu) { invalid = 1; break; }
+        cnt += w.count;
+        if (w.ended) { ended = 1; break; }
+        cur = w.exit_idx;
+        if (cur >= CUT_K) { invalid = 1; break; }
     }
-    for (int64_t q = 0; q < first_used; ++q) pick[q] = BtPick{0, 0, 0, 0};
+    grp[(uint64_t)g * CUT_K + s] = BtGroup{cur, cnt, ended, invalid};
+}
+__global__ void k2_bt_chain(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, const BtGroup* grp,
+                            uint32_t n_groups, BtGroupPick* gp, uint32_t* total_out, uint32_t* status) {
+    if (blockIdx.x || threadIdx.x) return;
+    // start of the right-most run: the open run has a single start (the global best node); a window ending on a cut
+    // column starts from that node's index among the cut's nodes
+    uint32_t s = 0;
+    if (n_runs - 1 < n_cuts) {
+        const uint64_t cur = res->gkey;
+        const int32_t hi = (int32_t)cuts[n_runs - 1];
+        const Node* nd = mv.nodes + mv.col_off[hi];
+        const uint32_t key = key_delta(cur) << 8 | key_base(cur), nn = mv.col_nn[hi];
+        while (s < nn && nd[s].key != key) ++s;
+        if (key_tpos(cur) != hi || s >= nn || s >= CUT_K) { *status = 2; *total_out = 0; return; }
+    }
+    int64_t g = (int64_t)n_groups - 1, first_used = (int64_t)n_groups;
+    for (; g >= 0; --g) {
+        const BtGroup e = grp[(uint64_t)g * CUT_K + s];
+        if (e.invalid) { *status = 2; break; }
+        gp[g] = BtGroupPick{s, e.count, 1, 0};   // off holds the count until the prefix pass below
+        first_used = g;
+        if (e.ended) break;
+        s = e.exit_idx;
+    }
+    for (int64_t q = 0; q < first_used; ++q) gp[q] = BtGroupPick{0, 0, 0, 0};
     uint32_t off = 0;
-    for (int64_t q = first_used; q < (int64_t)n_runs; ++q) { pick[q].off = off; off += pick[q].count; }
+    for (int64_t q = first_used; q < (int64_t)n_groups; ++q) { const uint32_t c = gp[q].off; gp[q].off = off; off += c; }
     *total_out = off;
+}
+__global__ void k2_bt_place(const BtWalk* walks, uint32_t n_runs, const BtGroupPick* gp, BtPick* pick) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r0 = g * BT_G;
+    if (r0 >= n_runs) return;
+    const uint32_t r1 = r0 + BT_G < n_runs ? r0 + BT_G : n_runs;
+    for (uint32_t r = r0; r < r1; ++r) pick[r] = BtPick{0, 0, 0, 0};
+    if (!gp[g].used) return;
+    uint32_t cur = gp[g].start, first = r1;
+    for (uint32_t r = r1; r-- > r0;) {
+        const BtWalk w = walks[(uint64_t)r * CUT_K + cur];
+        pick[r] = BtPick{cur, w.count, 0, 1};
+        first = r;
+        if (w.ended) break;
+        cur = w.exit_idx;
+    }
+    uint32_t off = gp[g].off;
+    for (uint32_t r = first; r < r1; ++r) { pick[r].off = off; off += pick[r].count; }
 }
 
 // ---- exclusive scan of uint32 counts (three launches: block sums, scan of the sums, final)
@@ -738,7 +806,7 @@ class HipExec : public Exec {
     int device_;
     hipStream_t stream_ = nullptr;
     DevBuf contig_, pos_, ncig_, cigoff_, seqoff_, cigar_, seq_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
-        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_;
+        coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
     uint64_t contig_serial_ = ~0ull;
     size_t contig_len_ = 0;
 };
@@ -975,7 +1043,17 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     uint32_t* total_dev = flag_.as<uint32_t>() + 5;
     if (lq) k2_bt_runs<true, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status);
     else k2_bt_runs<false, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status);
-    k2_bt_chain<<<1, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), btpick_.as<BtPick>(), total_dev, status);
+    {
+        const uint32_t n_bgroups = nblk(n_runs, BT_G);
+        if (!btgrp_.ensure(sizeof(BtGroup) * CUT_K * (size_t)n_bgroups + 64) || !btgpick_.ensure(sizeof(BtGroupPick) * (size_t)n_bgroups + 64)) {
+            *err = "out of device memory (backtrace)";
+            return false;
+        }
+        k2_bt_groups<<<n_bgroups, 64, 0, q>>>(btwalk_.as<BtWalk>(), n_runs, btgrp_.as<BtGroup>());
+        k2_bt_chain<<<1, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btgrp_.as<BtGroup>(), n_bgroups,
+                                     btgpick_.as<BtGroupPick>(), total_dev, status);
+        k2_bt_place<<<nblk(n_bgroups, 64), 64, 0, q>>>(btwalk_.as<BtWalk>(), n_runs, btgpick_.as<BtGroupPick>(), btpick_.as<BtPick>());
+    }
     if (lq) k2_bt_runs<true, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), nullptr, cons_.as<char>(), status);
     else k2_bt_runs<false, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), cons_.as<ConsBase>(), nullptr, status);
     DpResult res;
@@ -1076,8 +1154,27 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
     HIPOK(hipMemsetAsync(colcnt_.p, 0, 4ull * (n_cols + 2), q));
     HIPOK(hipMemsetAsync(cursor_.p, 0, 4ull * (n_cols + 2), q));
     DevStat st{cnt4_.as<uint32_t>(), cnt4_.as<uint32_t>() + n_cols, cnt4_.as<uint32_t>() + 2ull * n_cols, cnt4_.as<uint32_t>() + 3ull * n_cols};
-    k2_tags_str<<<nblk(n_streams, 64), 64, 0, q>>>(strpool_.as<char>(), stroff_.as<uint64_t>(), strlen_.as<uint32_t>(), n_streams, in.gap_min_len,
-                                                   tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), st, te_.as<uint32_t>());
+    {
+        std::vector<StrChunk> scs;
+        for (uint32_t i = 0; i < n_streams; ++i) {
+            const uint32_t first = (uint32_t)scs.size(), nch = (str_len[i] + TAG_CHUNK - 1) / TAG_CHUNK;
+            for (uint32_t c = 0; c < nch; ++c)
+                scs.push_back(StrChunk{i, c * TAG_CHUNK, std::min(TAG_CHUNK, str_len[i] - c * TAG_CHUNK), first, c + 1 == nch ? 1u : 0u, 0, 0, 0});
+            if (nch == 0) { *err = "empty low-quality alignment"; return false; }
+        }
+        const uint32_t nsc = (uint32_t)scs.size();
+        if (!tchunks_.ensure(sizeof(StrChunk) * (size_t)nsc + 64) || !chcnt_.ensure(4ull * (nsc + 2)) || !chpre_.ensure(4ull * (nsc + 2)) ||
+            !sums2_.ensure(4ull * (nblk(nsc + 1, SCAN_TILE) + 2))) { *err = "out of device memory (low-quality chunks)"; return false; }
+        HIPOK(hipMemcpyAsync(tchunks_.p, scs.data(), sizeof(StrChunk) * (size_t)nsc, hipMemcpyHostToDevice, q));
+        HIPOK(hipMemsetAsync(chcnt_.as<uint32_t>() + nsc, 0, 4, q));
+        k2_str_count<<<nblk(nsc, 64), 64, 0, q>>>(tchunks_.as<StrChunk>(), nsc, strpool_.as<char>(), stroff_.as<uint64_t>(), chcnt_.as<uint32_t>());
+        const uint32_t nss = nblk(nsc + 1, SCAN_TILE);
+        k2_scan_sums<<<nss, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), nsc + 1, sums2_.as<uint32_t>());
+        k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nss);
+        k2_scan_final<<<nss, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), nsc + 1, sums2_.as<uint32_t>(), chpre_.as<uint32_t>());
+        k2_tags_str_chunk<<<nblk(nsc, 64), 64, 0, q>>>(tchunks_.as<StrChunk>(), nsc, chpre_.as<uint32_t>(), strpool_.as<char>(), stroff_.as<uint64_t>(),
+                                                       in.gap_min_len, tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), st, te_.as<uint32_t>());
+    }
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>());
     uint32_t total = 0;
     if (!build_graph(str_len, n_cols, &total, err)) return false;

@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    name = name.replace("np1k::", "")
+    name = name.replace("np1k::", "").replace("np2::(anonymous namespace)::", "np2::").replace("(anonymous namespace)::", "")
     return name.split("(")[0][:60]
 
 
