@@ -78,3 +78,15 @@ def test_gpu_harness_with_forked_workers(tmp_path):
     recs = p.stdout.strip().split("\n")
     got = {recs[i][1:].split()[0]: recs[i + 1] for i in range(0, len(recs), 2)}
     assert got == want
+
+
+def test_gpu_two_windows_are_stitched_like_the_reference(tmp_path):
+    """4.3 Mb contig, 4.1 Mb window: two windows overlapping by 1 Mb, joined at 50 agreeing bases (link_consensus)."""
+    import hashlib
+    fa, fofn, contigs = np2_cases.materialise(np2_cases.TWO_WINDOW_CASE, str(tmp_path))
+    code = ("import sys, json; sys.path.insert(0, %r); import ref2_binding as rb; L = rb.bind(%r); "
+            "print(json.dumps(rb.polish(L, %r, %r, read_type=1, window=%d)))" % (HERE, PRODUCT_SO, fa, fofn, np2_cases.TWO_WINDOW_W))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    s = json.loads(p.stdout.strip().splitlines()[-1])["ctg0"][0][0]
+    assert len(s) == GOLD["two_windows"]["len"] and hashlib.md5(s.encode()).hexdigest() == GOLD["two_windows"]["md5"]
