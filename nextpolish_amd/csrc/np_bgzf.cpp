@@ -3,7 +3,11 @@
 
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace np {
 
@@ -29,8 +33,9 @@ bool BgzfReader::open(const std::string& path) {
     close();
     fp_ = fopen(path.c_str(), "rb");
     if (!fp_) return false;
-    cbuf_.resize(kMaxBlock + 64);
-    ubuf_.resize(kMaxBlock);
+    win_.clear();
+    win_i_ = 0;
+    ubuf_ = nullptr;
     block_coff_ = next_coff_ = 0;
     ulen_ = upos_ = 0;
     eof_ = false;
@@ -42,39 +47,96 @@ void BgzfReader::close() {
     fp_ = nullptr;
 }
 
-bool BgzfReader::load_block() {
-    // gzip member header with the BGZF 'BC' extra subfield
-    uint8_t hdr[18];
-    if (fseeko(fp_, (off_t)next_coff_, SEEK_SET) != 0) return false;
-    size_t got = fread(hdr, 1, 18, fp_);
-    if (got == 0) { eof_ = true; ulen_ = upos_ = 0; block_coff_ = next_coff_; return true; }
-    if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return false;
-    uint32_t xlen = hdr[10] | (hdr[11] << 8);
-    // find BC subfield (almost always the first one)
-    std::vector<uint8_t> extra(xlen);
-    memcpy(extra.data(), hdr + 12, xlen < 6 ? xlen : 6);
-    if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fp_) != xlen - 6) return false;
-    int bsize = -1;
-    for (uint32_t i = 0; i + 4 <= xlen;) {
-        uint32_t slen = extra[i + 2] | (extra[i + 3] << 8);
-        if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen)
-            bsize = extra[i + 4] | (extra[i + 5] << 8);
-        i += 4 + slen;
+static unsigned io_threads() {
+    static unsigned n = 0;
+    if (!n) {
+        const char* e = getenv("NP_IO_THREADS");
+        unsigned hw = std::thread::hardware_concurrency();
+        n = e ? (unsigned)atoi(e) : (hw ? (hw < 8 ? hw : 8) : 4);
+        if (n < 1) n = 1;
+        if (n > 64) n = 64;
     }
-    if (bsize < 0) return false;
-    size_t total = (size_t)bsize + 1;
-    size_t hdr_len = 12 + xlen;
-    if (total < hdr_len + 8) return false;
-    size_t clen = total - hdr_len - 8;
-    if (clen + 8 > cbuf_.size()) cbuf_.resize(clen + 8);
-    if (fread(cbuf_.data(), 1, clen + 8, fp_) != clen + 8) return false;
-    uint32_t isize;
-    memcpy(&isize, cbuf_.data() + clen + 4, 4);
-    if (isize > kMaxBlock) return false;
-    if (isize && !bgzf_inflate_block(cbuf_.data(), clen, ubuf_.data(), isize)) return false;
-    block_coff_ = next_coff_;
-    next_coff_ += total;
-    ulen_ = isize;
+    return n;
+}
+
+// Reads kWindow compressed bytes from `coff`, splits them into BGZF blocks (gzip member header with the 'BC' extra
+// subfield, SAMv1 4.1) and inflates the complete ones in parallel.
+bool BgzfReader::fill_window(uint64_t coff) {
+    static const size_t kWindow = 4u << 20;
+    win_.clear();
+    win_i_ = 0;
+    if (fseeko(fp_, (off_t)coff, SEEK_SET) != 0) return false;
+    cwin_.resize(kWindow + kMaxBlock + 64);
+    const size_t got = fread(cwin_.data(), 1, cwin_.size(), fp_);
+    size_t p = 0, utotal = 0;
+    while (p + 18 <= got) {
+        const uint8_t* h = cwin_.data() + p;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return false;
+        const uint32_t xlen = h[10] | (h[11] << 8);
+        if (p + 12 + xlen > got) break;
+        int bsize = -1;
+        for (uint32_t i = 0; i + 4 <= xlen;) {
+            const uint8_t* x = h + 12 + i;
+            const uint32_t slen = x[2] | (x[3] << 8);
+            if (x[0] == 'B' && x[1] == 'C' && slen == 2 && i + 6 <= xlen) bsize = x[4] | (x[5] << 8);
+            i += 4 + slen;
+        }
+        if (bsize < 0) return false;
+        const size_t total = (size_t)bsize + 1, hdr_len = 12 + xlen;
+        if (total < hdr_len + 8) return false;
+        if (p + total > got) break;   // incomplete block: the next window starts here
+        uint32_t isize;
+        memcpy(&isize, h + total - 4, 4);
+        if (isize > kMaxBlock) return false;
+        win_.push_back(WinBlock{coff + p, (uint32_t)total, isize, p + hdr_len, utotal});
+        utotal += isize;
+        p += total;
+        if (p >= kWindow) break;
+    }
+    if (win_.empty()) return got == 0 || got < 18 ? (got == 0) : false;   // clean EOF only when nothing is left
+    uwin_.resize(utotal + 8);
+    const unsigned nt = io_threads();
+    std::atomic<size_t> next(0);
+    std::atomic<bool> ok(true);
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= win_.size()) break;
+            const WinBlock& b = win_[i];
+            const size_t clen = b.total - (b.cpos - (size_t)(b.coff - coff)) - 8;
+            if (b.isize && !bgzf_inflate_block(cwin_.data() + b.cpos, clen, uwin_.data() + b.upos, b.isize)) ok = false;
+        }
+    };
+    if (nt <= 1 || win_.size() < 4) {
+        work();
+    } else {
+        std::vector<std::thread> th;
+        const unsigned n = (unsigned)std::min<size_t>(nt, win_.size());
+        for (unsigned t = 1; t < n; ++t) th.emplace_back(work);
+        work();
+        for (std::thread& t : th) t.join();
+    }
+    return ok;
+}
+
+bool BgzfReader::load_block() {
+    // the next block of the current window?
+    size_t i = win_.size();
+    if (win_i_ + 1 < win_.size() && win_[win_i_ + 1].coff == next_coff_) i = win_i_ + 1;
+    else
+        for (size_t k = 0; k < win_.size(); ++k)
+            if (win_[k].coff == next_coff_) { i = k; break; }
+    if (i == win_.size()) {
+        if (!fill_window(next_coff_)) return false;
+        if (win_.empty()) { eof_ = true; ulen_ = upos_ = 0; block_coff_ = next_coff_; return true; }
+        i = 0;
+    }
+    win_i_ = i;
+    const WinBlock& b = win_[i];
+    ubuf_ = uwin_.data() + b.upos;
+    block_coff_ = b.coff;
+    next_coff_ = b.coff + b.total;
+    ulen_ = b.isize;
     upos_ = 0;
     return true;
 }
@@ -91,7 +153,7 @@ int64_t BgzfReader::read(void* dst, size_t n) {
         }
         size_t take = ulen_ - upos_;
         if (take > n - done) take = n - done;
-        memcpy(out + done, ubuf_.data() + upos_, take);
+        memcpy(out + done, ubuf_ + upos_, take);
         upos_ += (uint32_t)take;
         done += take;
     }

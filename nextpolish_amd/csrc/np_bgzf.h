@@ -29,12 +29,21 @@ public:
     bool is_open() const { return fp_ != nullptr; }
 
 private:
-    bool load_block();   // inflate the block at file offset next_coff_
+    // Blocks are independent deflate streams, so the reader inflates a window of consecutive blocks at once on a few
+    // threads (NP_IO_THREADS, default min(8, cores); threads live only inside fill_window: fork-safe) and serves
+    // read()/seek() from that window.  This is the "BGZF ingest" row of SURVEY.md section 8(f): inflate is ~60 % of
+    // the reference's wall time.
+    struct WinBlock { uint64_t coff; uint32_t total, isize; size_t cpos, upos; };
+    bool load_block();                 // make the block at file offset next_coff_ current
+    bool fill_window(uint64_t coff);   // read + inflate the blocks starting at coff
     FILE* fp_ = nullptr;
-    std::vector<uint8_t> cbuf_;   // compressed block
-    std::vector<uint8_t> ubuf_;   // inflated block (<= 64 KiB)
-    uint64_t block_coff_ = 0;     // file offset of the block in ubuf_
-    uint64_t next_coff_ = 0;      // file offset of the next block
+    std::vector<uint8_t> cwin_;        // compressed window
+    std::vector<uint8_t> uwin_;        // inflated window
+    std::vector<WinBlock> win_;
+    size_t win_i_ = 0;                 // current block inside win_
+    const uint8_t* ubuf_ = nullptr;    // inflated current block (<= 64 KiB)
+    uint64_t block_coff_ = 0;          // file offset of the current block
+    uint64_t next_coff_ = 0;           // file offset of the next block
     uint32_t ulen_ = 0, upos_ = 0;
     bool eof_ = false;
 };
