@@ -132,6 +132,9 @@ void np1_stream_get_view(const np1_stream* s, np1_stream_view* out);
 const char* np1_stream_contig_name(const np1_stream* s, int64_t i);
 uint64_t np1_stream_algorithmic_bytes(const np1_stream* s, int with_qual);
 int np1_stream_write_files(const np1_stream* s, const char* fasta, const char* bam, int bgzf_level);
+/* same, with raw BAM optional fields per record (aux_pool[aux_off[i] .. aux_off[i+1])): test data with SA tags */
+int np1_stream_write_files_aux(const np1_stream* st, const char* fasta, const char* bam, int level, const uint8_t* aux_pool,
+                               const uint64_t* aux_off);
 void np1_stream_free(np1_stream* s);
 
 /* Synthetic workload.  Field meanings: nextpolish_amd/csrc/np_synth.h */

@@ -265,7 +265,21 @@ class Stream(object):
     def algorithmic_bytes(self, with_qual=False):
         return int(lib().np1_stream_algorithmic_bytes(self.handle, 1 if with_qual else 0))
 
-    def write_files(self, fasta, bam, level=1):
+    def write_files(self, fasta, bam, level=1, aux=None):
+        """aux: optional list of raw BAM optional-field bytes per record (e.g. b"SAZ" + value + b"\0")."""
+        if aux is not None:
+            L = lib()
+            L.np1_stream_write_files_aux.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_uint64)]
+            pool = b"".join(aux)
+            off = (C.c_uint64 * (len(aux) + 1))()
+            acc = 0
+            for i, a in enumerate(aux):
+                off[i] = acc
+                acc += len(a)
+            off[len(aux)] = acc
+            if L.np1_stream_write_files_aux(self.handle, fasta.encode(), bam.encode(), level, pool + b"\0", off) != 0:
+                raise RuntimeError("write_files: " + last_error())
+            return
         if lib().np1_stream_write_files(self.handle, fasta.encode(), bam.encode(), level) != 0:
             raise RuntimeError("write_files: " + last_error())
 

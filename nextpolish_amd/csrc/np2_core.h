@@ -141,11 +141,12 @@ NP2_HD void cigar_totals(const ReadView& r, uint32_t* n_cols, uint32_t* rf_len, 
 struct AlnSpan {
     uint32_t col0, aln_len;
     uint32_t aln_t_s, aln_t_e;   // contig coordinates: first kept draft base, one past the last
+    uint32_t aln_q_s;            // query coordinate of the first kept column (the reference tracks it for split reads only)
 };
 
 // s, e: window [s, e) in contig coordinates.  Literal restatement incl. the unsigned arithmetic and the
 // "aln_len = 10" outcome of a clip that leaves 500 columns or fewer.
-NP2_HD AlnSpan align_span(const ReadView& r, const char* rfseq, int32_t s, int32_t e) {
+NP2_HD AlnSpan align_span(const ReadView& r, const char* rfseq, int32_t s, int32_t e, uint32_t q0 = 0) {
     uint32_t N, rf_len, rd_len;
     bool bad;
     cigar_totals(r, &N, &rf_len, &rd_len, &bad);
@@ -158,6 +159,7 @@ NP2_HD AlnSpan align_span(const ReadView& r, const char* rfseq, int32_t s, int32
         if ((r.cigar[i] & 0xf) == 3) nskip += r.cigar[i] >> 4;
     a.aln_t_s = (uint32_t)r.pos + nskip;
     a.aln_t_e = (uint32_t)r.pos + rf_len;
+    a.aln_q_s = q0;
     char t, q;
     if ((int64_t)a.aln_t_s < s || (int64_t)a.aln_t_e > e) {   // clip_aln (signed compare: the reference compares uint with int32 -> unsigned; positions are < 2^31)
         uint32_t s_ = 0;
@@ -166,6 +168,7 @@ NP2_HD AlnSpan align_span(const ReadView& r, const char* rfseq, int32_t s, int32
         while ((int64_t)a.aln_t_s < s && !f.done()) {
             f.get(&t, &q);
             if (t != '-') ++a.aln_t_s;
+            if (q != '-') ++a.aln_q_s;
             f.next();
             ++s_;
         }
@@ -205,8 +208,10 @@ NP2_HD AlnSpan align_span(const ReadView& r, const char* rfseq, int32_t s, int32
             f.get(&t, &q);
             if (t == q) ++j; else j = 0;
             if (t != '-') ++a.aln_t_s;
+            if (q != '-') ++a.aln_q_s;
             if (j == k) {
                 a.aln_t_s -= k;
+                a.aln_q_s -= k;
                 a.col0 += i - k + 1;
                 a.aln_len = len0 - i + k - 1;
                 found = true;

@@ -17,35 +17,56 @@ struct ConsBase {   // consensus_base, ctg_cns.h:103-107
     char base;
 };
 
+// alignment records handed to the executor: BAM core fields of the path (position, CIGAR, packed bases)
+struct RecordSet {
+    std::vector<int32_t> pos;
+    std::vector<uint32_t> n_cigar;
+    std::vector<uint32_t> q0;           // leading clip length = query coordinate of the first aligned base
+    std::vector<uint64_t> cigar_off, seq_off;
+    std::vector<uint32_t> cigar;
+    std::vector<uint8_t> seq;
+    size_t size() const { return pos.size(); }
+    void clear() { pos.clear(); n_cigar.clear(); q0.clear(); cigar_off.clear(); seq_off.clear(); cigar.clear(); seq.clear(); }
+    void add(int32_t p, const uint32_t* cg, uint32_t nc, const uint8_t* sq, size_t seq_bytes, uint32_t q_start) {
+        pos.push_back(p); n_cigar.push_back(nc); q0.push_back(q_start);
+        cigar_off.push_back(cigar.size()); seq_off.push_back(seq.size());
+        cigar.insert(cigar.end(), cg, cg + nc);
+        seq.insert(seq.end(), sq, sq + seq_bytes);
+    }
+};
+
+// clip_aln + get_align_shift of one record against the window (np2k::align_span)
+struct SpanOut {
+    uint32_t col0, aln_len, aln_t_s, aln_t_e, aln_q_s;
+    uint32_t bad;   // the CIGAR carries an op the reference aborts on
+};
+
+struct StreamRef {      // one tag stream of the window besides the seed
+    uint32_t set;       // 0: window records, 1: supplementary alignments of split reads (structural layer)
+    uint32_t rec;       // index into that record set
+    SpanOut span;
+};
+
 struct WindowInput {
     const char* contig_seq = nullptr;   // decoded contig (A/C/G/T), indexable by contig coordinate
     uint64_t contig_serial = 0;         // changes whenever contig_seq holds a different contig (executors may cache the upload)
     int32_t s = 0, e = 0;               // window [s, e)
     uint32_t gap_min_len = 3;           // 3 ONT, 5 otherwise (ctg_cns.c:3436-3442)
     int read_type = np2k::READS_ONT;
-    // candidate records in merge order (the seed -- the window against itself -- is added by the executor)
-    std::vector<int32_t> pos;
-    std::vector<uint32_t> n_cigar;
-    std::vector<uint32_t> l_qseq;       // cal_l_qseq of the record (for the 0.9 aligned-fraction term of the coverage cap)
-    std::vector<uint32_t> aligned_q;    // rdp1.e - rdp1.s
-    std::vector<uint64_t> cigar_off, seq_off;
-    std::vector<uint32_t> cigar;
-    std::vector<uint8_t> seq;
-    size_t n_reads() const { return pos.size(); }
+    RecordSet recs;                     // candidate records in merge order
+    RecordSet sup;                      // supplementary alignments (read bases of the primary, CIGAR of the supplementary record)
+    std::vector<StreamRef> streams;     // the streams to pile up, in order (the seed -- the window against itself -- comes first, implicitly)
 };
 
 struct WindowOutput {
-    // per candidate record: kept (1) or dropped by the 500 bp / coverage-cap rules (0)
-    std::vector<uint8_t> kept;
-    uint32_t seq_count = 0;                       // seed + kept records (aligned_seq_count of the reference)
+    uint32_t seq_count = 0;                       // seed + streams (aligned_seq_count of the reference)
     std::vector<np2k::ColStat> stat;              // e - s + 1 columns
-    // tag streams of the seed (index 0) and the kept records, in order: stream i = tags[tag_off[i] ..), window-relative
+    // tag streams of the seed (index 0) and the given streams, in order: stream i = tags[tag_off[i] ..), window-relative
     // start / exclusive end positions
     std::vector<uint64_t> tag_off;
     std::vector<uint32_t> aln_t_s, aln_t_e;
     std::vector<uint8_t> tags;
     std::vector<ConsBase> cons;                   // main-line consensus, window order (before the LQ stage)
-    bool bad_cigar = false;                       // a record carried an op the reference aborts on
 };
 
 // the concatenated low-quality regions of a window: up to 30 gapped string pairs over one target coordinate space
@@ -61,6 +82,9 @@ class Exec {
   public:
     virtual ~Exec() {}
     // false + *err on failure (never a silent fallback)
+    // spans of every record of in.recs (set 0) or in.sup (set 1) against the window
+    virtual bool compute_spans(const WindowInput& in, int set, std::vector<SpanOut>* spans, std::string* err) = 0;
+    // tags of in.streams -> link graph -> chain DP -> backtrace
     virtual bool run_window(const WindowInput& in, WindowOutput* out, std::string* err) = 0;
     // link graph + DP variant + backtrace of get_lqseqs_from_align_tags (ctg_cns.c:986-1163, non-HiFi branch):
     // *cons_rev = consensus characters in backtrace order (last column first), as the reference leaves them

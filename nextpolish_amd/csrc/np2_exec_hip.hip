@@ -68,24 +68,26 @@ struct DevStatSink {
     __device__ void l_del(uint32_t p) { atomicAdd(&d.l_del[p], 1u); }
 };
 
-struct SpanOut {
-    uint32_t col0, aln_len, aln_t_s, aln_t_e;
-    uint32_t bad, pad0, pad1, pad2;
+struct DevRecs {   // one RecordSet in HBM
+    const int32_t* pos;
+    const uint32_t *n_cigar, *q0;
+    const uint64_t *cigar_off, *seq_off;
+    const uint32_t* cigar;
+    const uint8_t* seq;
+    __device__ ReadView view(uint32_t i) const { return ReadView{pos[i], n_cigar[i], cigar + cigar_off[i], seq + seq_off[i]}; }
 };
 
-__global__ void k2_span(const int32_t* pos, const uint32_t* n_cigar, const uint64_t* cigar_off, const uint64_t* seq_off,
-                        const uint32_t* cigar, const uint8_t* seq, uint32_t n, const char* contig_seq, int32_t s, int32_t e,
-                        SpanOut* out) {
+__global__ void k2_span(DevRecs R, uint32_t n, const char* contig_seq, int32_t s, int32_t e, SpanOut* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    ReadView rv{pos[i], n_cigar[i], cigar + cigar_off[i], seq + seq_off[i]};
+    const ReadView rv = R.view(i);
     uint32_t N, rf_len, rd_len;
     bool bad;
     cigar_totals(rv, &N, &rf_len, &rd_len, &bad);
-    SpanOut o{0, 0, 0, 0, bad ? 1u : 0u, 0, 0, 0};
+    SpanOut o{0, 0, 0, 0, 0, bad ? 1u : 0u};
     if (!bad) {
-        const AlnSpan a = align_span(rv, contig_seq, s, e);
-        o.col0 = a.col0; o.aln_len = a.aln_len; o.aln_t_s = a.aln_t_s; o.aln_t_e = a.aln_t_e;
+        const AlnSpan a = align_span(rv, contig_seq, s, e, R.q0[i]);
+        o.col0 = a.col0; o.aln_len = a.aln_len; o.aln_t_s = a.aln_t_s; o.aln_t_e = a.aln_t_e; o.aln_q_s = a.aln_q_s;
     }
     out[i] = o;
 }
@@ -111,9 +113,9 @@ __global__ void k2_seed_tags(const char* contig_seq, int32_t s, uint32_t l, uint
     tags[b] = (uint8_t)v;
 }
 
-struct StreamDesc {   // one kept record
-    uint32_t read;        // index into the candidate arrays
-    uint32_t col0, aln_len, aln_t_s;   // contig coordinate
+struct StreamDesc {   // one stream besides the seed
+    uint32_t set, read;   // record set (0 window records, 1 supplementary alignments) and index into it
+    uint32_t col0, aln_len, aln_t_s, pad;   // aln_t_s: contig coordinate
     uint64_t tag_off;
 };
 
@@ -125,16 +127,16 @@ constexpr uint32_t TAG_CHUNK = 256;
 struct TagCkpt { uint32_t op_i, in_op, rfi, rdi, te_before, delta_before; };
 struct TagChunk { uint32_t stream, c0, n, last; };   // stream = index into the StreamDesc array
 
-__global__ void k2_tag_ckpt(const StreamDesc* sd, uint32_t n_streams, const uint32_t* chunk_off, const int32_t* pos, const uint32_t* n_cigar,
-                            const uint64_t* cigar_off, const uint32_t* cigar, int32_t s, TagCkpt* ck) {
+__global__ void k2_tag_ckpt(const StreamDesc* sd, uint32_t n_streams, const uint32_t* chunk_off, DevRecs R0, DevRecs R1, int32_t s, TagCkpt* ck) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_streams) return;
     const StreamDesc d = sd[k];
-    const uint32_t* cg = cigar + cigar_off[d.read];
-    const uint32_t nc = n_cigar[d.read];
+    const DevRecs& R = d.set ? R1 : R0;
+    const uint32_t* cg = R.cigar + R.cigar_off[d.read];
+    const uint32_t nc = R.n_cigar[d.read];
     const uint32_t n_chunks = (d.aln_len + TAG_CHUNK - 1) / TAG_CHUNK;
     TagCkpt* out = ck + chunk_off[k];
-    uint32_t col = 0, rfi = (uint32_t)pos[d.read], rdi = 0, tcount = 0, run = 0, ci = 0;
+    uint32_t col = 0, rfi = (uint32_t)R.pos[d.read], rdi = 0, tcount = 0, run = 0, ci = 0;
     uint32_t target = d.col0;
     const uint32_t te0 = d.aln_t_s - (uint32_t)s - 1;
     for (uint32_t i = 0; i < nc && ci < n_chunks; ++i) {
@@ -162,15 +164,14 @@ __global__ void k2_tag_ckpt(const StreamDesc* sd, uint32_t n_streams, const uint
     }
 }
 
-__global__ void k2_tags_chunk(const TagChunk* tc, uint32_t n_chunks, const TagCkpt* ck, const StreamDesc* sd, const int32_t* pos,
-                              const uint32_t* n_cigar, const uint64_t* cigar_off, const uint64_t* seq_off, const uint32_t* cigar,
-                              const uint8_t* seq, const char* contig_seq, uint32_t gap_min_len, uint8_t* tags, DevStat st, uint32_t* te_out) {
+__global__ void k2_tags_chunk(const TagChunk* tc, uint32_t n_chunks, const TagCkpt* ck, const StreamDesc* sd, DevRecs R0, DevRecs R1,
+                              const char* contig_seq, uint32_t gap_min_len, uint8_t* tags, DevStat st, uint32_t* te_out) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const TagChunk ch = tc[c];
     const StreamDesc d = sd[ch.stream];
     const TagCkpt t = ck[c];
-    ReadView rv{pos[d.read], n_cigar[d.read], cigar + cigar_off[d.read], seq + seq_off[d.read]};
+    const ReadView rv = (d.set ? R1 : R0).view(d.read);
     ColIter f;
     f.r = &rv; f.rf = contig_seq; f.op_i = t.op_i; f.in_op = t.in_op; f.rfi = t.rfi; f.rdi = t.rdi;
     EmitState es{t.te_before, t.delta_before, t.delta_before >= gap_min_len ? 1u : 0u};
@@ -796,6 +797,7 @@ class HipExec : public Exec {
         HIPOK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         return true;
     }
+    bool compute_spans(const WindowInput& in, int set, std::vector<SpanOut>* spans, std::string* err) override;
     bool run_window(const WindowInput& in, WindowOutput* out, std::string* err) override;
     bool run_lq(const LqInput& in, std::string* cons_rev, std::string* err) override;
 
@@ -805,79 +807,71 @@ class HipExec : public Exec {
     bool solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t total, int rule, uint32_t* cons_len, struct StageClock* clk, std::string* err);
     int device_;
     hipStream_t stream_ = nullptr;
-    DevBuf contig_, pos_, ncig_, cigoff_, seqoff_, cigar_, seq_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
+    bool upload_contig(const WindowInput& in, std::string* err);
+    bool upload_set(const RecordSet& rs, int set, std::string* err);
+    DevRecs dev_set(int set) const {
+        const DevBuf* b = rb_[set];
+        return DevRecs{b[0].as<int32_t>(), b[1].as<uint32_t>(), b[2].as<uint32_t>(), b[3].as<uint64_t>(), b[4].as<uint64_t>(), b[5].as<uint32_t>(), b[6].as<uint8_t>()};
+    }
+    DevBuf rb_[2][7];   // pos, n_cigar, q0, cigar_off, seq_off, cigar, seq of the two record sets
+    DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
     uint64_t contig_serial_ = ~0ull;
     size_t contig_len_ = 0;
 };
 
+bool HipExec::upload_contig(const WindowInput& in, std::string* err) {
+    // contig characters: uploaded once per contig (the pipeline passes the same serial for every window of it)
+    const size_t clen = strlen(in.contig_seq);
+    if (contig_serial_ != in.contig_serial || contig_len_ != clen) {
+        if (!contig_.ensure(clen + 16)) { *err = "out of device memory (contig)"; return false; }
+        HIPOK(hipMemcpyAsync(contig_.p, in.contig_seq, clen + 1, hipMemcpyHostToDevice, stream_));
+        contig_serial_ = in.contig_serial;
+        contig_len_ = clen;
+    }
+    return true;
+}
+
+bool HipExec::upload_set(const RecordSet& rs, int set, std::string* err) {
+    hipStream_t q = stream_;
+    const size_t n = rs.size();
+    DevBuf* b = rb_[set];
+    auto up = [&](DevBuf& d, const void* src, size_t bytes) -> bool {
+        if (!d.ensure(bytes + 16)) return false;
+        return bytes == 0 || hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, q) == hipSuccess;
+    };
+    if (!up(b[0], rs.pos.data(), 4 * n) || !up(b[1], rs.n_cigar.data(), 4 * n) || !up(b[2], rs.q0.data(), 4 * n) ||
+        !up(b[3], rs.cigar_off.data(), 8 * n) || !up(b[4], rs.seq_off.data(), 8 * n) || !up(b[5], rs.cigar.data(), 4 * rs.cigar.size()) ||
+        !up(b[6], rs.seq.data(), rs.seq.size())) { *err = "out of device memory (records)"; return false; }
+    return true;
+}
+
+// spans of a record set; the set stays in HBM for the run_window call of the same window
+bool HipExec::compute_spans(const WindowInput& in, int set, std::vector<SpanOut>* spans, std::string* err) {
+    HIPOK(hipSetDevice(device_));
+    hipStream_t q = stream_;
+    const RecordSet& rs = set ? in.sup : in.recs;
+    const uint32_t n = (uint32_t)rs.size();
+    spans->assign(n, SpanOut{0, 0, 0, 0, 0, 0});
+    if (!upload_contig(in, err) || !upload_set(rs, set, err)) return false;
+    if (n) {
+        if (!spans_.ensure(sizeof(SpanOut) * (size_t)n)) { *err = "out of device memory (spans)"; return false; }
+        k2_span<<<nblk(n, 64), 64, 0, q>>>(dev_set(set), n, contig_.as<char>(), in.s, in.e, spans_.as<SpanOut>());
+        HIPOK(hipMemcpyAsync(spans->data(), spans_.p, sizeof(SpanOut) * (size_t)n, hipMemcpyDeviceToHost, q));
+    }
+    HIPOK(hipStreamSynchronize(q));
+    return true;
+}
+
+// the record sets of `in` were uploaded by the compute_spans calls of this window
 bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* err) {
     HIPOK(hipSetDevice(device_));
     hipStream_t q = stream_;
     const int32_t s = in.s, e = in.e, l = e - s;
-    const uint32_t n = (uint32_t)in.n_reads();
     StageClock clk(q);
-    out->kept.assign(n, 0);
-    out->bad_cigar = false;
     out->cons.clear();
-    // ---- contig characters (uploaded once per contig: the pipeline passes the same pointer for every window)
-    const size_t clen = strlen(in.contig_seq);
-    if (contig_serial_ != in.contig_serial || contig_len_ != clen) {
-        if (!contig_.ensure(clen + 16)) { *err = "out of device memory (contig)"; return false; }
-        HIPOK(hipMemcpyAsync(contig_.p, in.contig_seq, clen + 1, hipMemcpyHostToDevice, q));
-        contig_serial_ = in.contig_serial;
-        contig_len_ = clen;
-    }
-    // ---- candidate records
-    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> bool {
-        if (!b.ensure(bytes + 16)) return false;
-        return bytes == 0 || hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, q) == hipSuccess;
-    };
-    if (!up(pos_, in.pos.data(), 4ull * n) || !up(ncig_, in.n_cigar.data(), 4ull * n) || !up(cigoff_, in.cigar_off.data(), 8ull * n) ||
-        !up(seqoff_, in.seq_off.data(), 8ull * n) || !up(cigar_, in.cigar.data(), 4ull * in.cigar.size()) ||
-        !up(seq_, in.seq.data(), in.seq.size())) { *err = "out of device memory (records)"; return false; }
-    std::vector<SpanOut> spans(n);
-    if (n) {
-        if (!spans_.ensure(sizeof(SpanOut) * (size_t)n)) { *err = "out of device memory (spans)"; return false; }
-        k2_span<<<nblk(n, 64), 64, 0, q>>>(pos_.as<int32_t>(), ncig_.as<uint32_t>(), cigoff_.as<uint64_t>(), seqoff_.as<uint64_t>(),
-                                           cigar_.as<uint32_t>(), seq_.as<uint8_t>(), n, contig_.as<char>(), s, e, spans_.as<SpanOut>());
-        HIPOK(hipMemcpyAsync(spans.data(), spans_.p, sizeof(SpanOut) * (size_t)n, hipMemcpyDeviceToHost, q));
-    }
-    HIPOK(hipStreamSynchronize(q));
-    clk.mark("upload+span");
-    for (uint32_t i = 0; i < n; ++i)
-        if (spans[i].bad) { out->bad_cigar = true; return true; }
-    // ---- 500 bp rule + coverage caps (ctg_cns.c:3540-3545).  Coverage of a column = number of kept streams whose
-    // [aln_t_s, aln_t_e) covers it, so the order-dependent caps can be decided here from the spans alone.
-    std::vector<uint32_t> cand;
-    for (uint32_t i = 0; i < n; ++i) {
-        const SpanOut& a = spans[i];
-        if (a.aln_t_s > a.aln_t_e - 500u) continue;
-        const uint32_t ts = a.aln_t_s - (uint32_t)s, te = a.aln_t_e - (uint32_t)s;
-        if (ts > (uint32_t)l || te > (uint32_t)l) { *err = "alignment outside its window"; return false; }
-        cand.push_back(i);
-    }
-    {
-        std::vector<int32_t> diff((size_t)l + 2, 0);
-        diff[0] += 1; diff[(size_t)l] -= 1;   // seed
-        for (uint32_t i : cand) { ++diff[spans[i].aln_t_s - (uint32_t)s]; --diff[spans[i].aln_t_e - (uint32_t)s]; }
-        int32_t run = 0, mx = 0;
-        for (int32_t p = 0; p <= l; ++p) { run += diff[(size_t)p]; mx = std::max(mx, run); }
-        if (mx <= 500) {
-            for (uint32_t i : cand) out->kept[i] = 1;
-        } else {   // deep pileup: replay the reference's order-dependent decisions on a running coverage track
-            std::vector<uint32_t> cov((size_t)l + 1, 0);
-            for (int32_t p = 0; p < l; ++p) cov[(size_t)p] = 1;
-            for (uint32_t i : cand) {
-                const uint32_t ts = spans[i].aln_t_s - (uint32_t)s, te = spans[i].aln_t_e - (uint32_t)s;
-                if ((cov[ts] > 3000 && cov[te] > 3000) ||
-                    (cov[ts] > 500 && cov[te] > 500 && (double)in.aligned_q[i] < in.l_qseq[i] * 0.9)) continue;
-                out->kept[i] = 1;
-                for (uint32_t p = ts; p < te; ++p) ++cov[p];
-            }
-        }
-    }
-    // ---- stream layout: seed + kept records
+    if (!upload_contig(in, err)) return false;
+    // ---- stream layout: seed + the given streams
     std::vector<StreamDesc> sd;
     out->tag_off.clear(); out->aln_t_s.clear(); out->aln_t_e.clear();
     uint64_t tag_bytes = 0;
@@ -885,14 +879,13 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     out->aln_t_s.push_back(0);
     tag_bytes += ((uint64_t)l + 1) / 2 + 1;
     tag_bytes = (tag_bytes + 3) & ~3ull;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (!out->kept[i]) continue;
+    for (const StreamRef& sr : in.streams) {
         StreamDesc d;
-        d.read = i; d.col0 = spans[i].col0; d.aln_len = spans[i].aln_len; d.aln_t_s = spans[i].aln_t_s; d.tag_off = tag_bytes;
+        d.set = sr.set; d.read = sr.rec; d.col0 = sr.span.col0; d.aln_len = sr.span.aln_len; d.aln_t_s = sr.span.aln_t_s; d.pad = 0; d.tag_off = tag_bytes;
         sd.push_back(d);
         out->tag_off.push_back(tag_bytes);
-        out->aln_t_s.push_back(spans[i].aln_t_s - (uint32_t)s);
-        tag_bytes += ((uint64_t)spans[i].aln_len + 1) / 2 + 1;
+        out->aln_t_s.push_back(sr.span.aln_t_s - (uint32_t)s);
+        tag_bytes += ((uint64_t)sr.span.aln_len + 1) / 2 + 1;
         tag_bytes = (tag_bytes + 3) & ~3ull;
     }
     const uint32_t n_streams = (uint32_t)out->tag_off.size();
@@ -934,11 +927,10 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
         if (n_tchunks) {
             HIPOK(hipMemcpyAsync(tchunks_.p, tcs.data(), sizeof(TagChunk) * (size_t)n_tchunks, hipMemcpyHostToDevice, q));
             HIPOK(hipMemcpyAsync(tchoff_.p, choff.data(), 4ull * sd.size(), hipMemcpyHostToDevice, q));
-            k2_tag_ckpt<<<nblk(sd.size(), 64), 64, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), tchoff_.as<uint32_t>(), pos_.as<int32_t>(),
-                                                           ncig_.as<uint32_t>(), cigoff_.as<uint64_t>(), cigar_.as<uint32_t>(), s, tckpt_.as<TagCkpt>());
-            k2_tags_chunk<<<nblk(n_tchunks, 64), 64, 0, q>>>(tchunks_.as<TagChunk>(), n_tchunks, tckpt_.as<TagCkpt>(), sd_.as<StreamDesc>(), pos_.as<int32_t>(),
-                                                             ncig_.as<uint32_t>(), cigoff_.as<uint64_t>(), seqoff_.as<uint64_t>(), cigar_.as<uint32_t>(),
-                                                             seq_.as<uint8_t>(), contig_.as<char>(), in.gap_min_len, tags_.as<uint8_t>(), st, te_.as<uint32_t>() + 1);
+            k2_tag_ckpt<<<nblk(sd.size(), 64), 64, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), tchoff_.as<uint32_t>(), dev_set(0), dev_set(1), s,
+                                                           tckpt_.as<TagCkpt>());
+            k2_tags_chunk<<<nblk(n_tchunks, 64), 64, 0, q>>>(tchunks_.as<TagChunk>(), n_tchunks, tckpt_.as<TagCkpt>(), sd_.as<StreamDesc>(), dev_set(0), dev_set(1),
+                                                             contig_.as<char>(), in.gap_min_len, tags_.as<uint8_t>(), st, te_.as<uint32_t>() + 1);
         }
     }
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>());

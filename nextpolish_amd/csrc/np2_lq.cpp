@@ -150,7 +150,7 @@ bool rank_and_seed(Region& r, std::vector<uint16_t>& kmers, bool trim, int min_s
 }
 
 // generate_lqseqs_from_tags (kmer = false) / generate_lqseqs_from_tags_kmer (HiFi, ctg_cns.c:636-820); returns max_aln_length
-int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo, bool kmer) {
+int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo, bool kmer, const std::vector<LqCluster>& clusters) {
     const int count = (int)lq.size();
     if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   collect start (t=%.2f)\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6); }
     for (Region& r : lq) {
@@ -195,8 +195,24 @@ int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo, bool kme
     if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   tag walk done (t=%.2f)\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6); }
     int max_aln_length = 0;
     std::vector<uint16_t> kmers(65536);
+    int clusters_i = (int)clusters.size() - 1;
     for (int i = 0; i < count; ++i) {
         Region& r = lq[(size_t)i];
+        if (r.l == 1) {   // a gap cluster's region: the split reads' substrings join the candidates (ctg_cns.c:585-600,687-695,871-879)
+            while (clusters_i >= 0 && !clusters[(size_t)clusters_i].i_m) --clusters_i;
+            if (clusters_i >= 0) {
+                const LqCluster& c = clusters[(size_t)clusters_i--];
+                for (const std::string& s : c.cands) {
+                    if (r.len >= LQSEQ_MAX_CAN_COUNT) break;
+                    Cand& cd = r.seqs[(size_t)r.len];
+                    cd.seq = s;
+                    cd.len = (uint32_t)s.size();
+                    cd.order = (uint16_t)r.len;
+                    if (cd.len > r.lqcount) r.lqcount = cd.len;
+                    ++r.len;
+                }
+            }
+        }
         if (kmer) {
             if (!r.len) continue;
             // identical candidates vote: a dominant (or the only short) string is taken as it is (ctg_cns.c:719-737)
@@ -222,7 +238,7 @@ int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo, bool kme
             if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
             continue;
         }
-        if (r.l > 1 && r.len > 4) remove_short(r);
+        if (r.l != 1 && r.l > 1 && r.len > 4) remove_short(r);
         if (r.len <= 4 || r.len < r.sudoseed_len * 0.5) { r.len = 0; continue; }
         if (!rank_and_seed(r, kmers, true, 3)) continue;
         if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
@@ -323,15 +339,15 @@ uint32_t min_cand_len(const Region& r) {
 
 }  // namespace
 
-bool lq_stage(Exec* exec, uint32_t gap_min_len, bool hifi, const std::vector<LqRegionIn>& regions, const WindowOutput& wo,
-              std::vector<ConsBase>* cons, std::string* err) {
+bool lq_stage(Exec* exec, uint32_t gap_min_len, bool hifi, const std::vector<LqRegionIn>& regions, const std::vector<LqCluster>& clusters,
+              const WindowOutput& wo, std::vector<ConsBase>* cons, std::string* err) {
     const int count = (int)regions.size();
     std::vector<Region> lq((size_t)count);
     for (int i = 0; i < count; ++i) { lq[(size_t)i].start = regions[(size_t)i].start; lq[(size_t)i].end = regions[(size_t)i].end; lq[(size_t)i].l = regions[(size_t)i].l; }
     const bool timing = getenv("NP2_TIMING") != nullptr;
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     double t0 = now();
-    collect_candidates(lq, wo, hifi);
+    collect_candidates(lq, wo, hifi, clusters);
     if (timing) { const double t = now(); fprintf(stderr, "[np2 lq] candidates+poa %.2f ms\n", t - t0); t0 = t; }
     // ---- iterate_generate_consensus_trimed (two rounds)
     for (int it = 1; it <= 2; ++it) {

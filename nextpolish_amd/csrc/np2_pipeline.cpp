@@ -9,7 +9,7 @@
 //
 // Low-quality regions go through np2_lq.cpp (candidates, POA pseudo-seed, O(ND) alignment on the host; the graph
 // consensus of the concatenated regions in the executor).
-// Not built yet (fails loudly, never silently): the structural gap-cluster layer (B15).  See DESIGN.md section "path B".
+// The split-read structural layer (depth track, gap clusters, supplementary streams, split points) is in np2_sv.cpp.  See DESIGN.md section "path B".
 #include <cassert>
 #include <cctype>
 #include <climits>
@@ -26,6 +26,7 @@
 #include "../../include/nextpolish2.h"
 #include "np2_exec.h"
 #include "np2_lq.h"
+#include "np2_sv.h"
 #include "np_bam.h"
 
 namespace {
@@ -226,6 +227,7 @@ struct LqCtx {
     const std::vector<ConsBase>* c;
     int reads_type;
     float gap_min_ratio1;
+    const std::vector<np2::LqCluster>* clusters;
 };
 
 int cal_del_pos(const std::vector<ColStat>& m, int s, int e) {
@@ -293,8 +295,26 @@ int lq_from_dels(const Del& d, std::vector<LqReg>& lq, int index) {   // get_lqs
     return index;
 }
 
-// regions in DEscending order of position, like the reference builds them (no gap clusters: the structural layer
-// that provides them is not built)
+int lq_from_cluster(const np2::LqCluster& clu, std::vector<LqReg>& lq, int index) {   // get_lqseqs_from_cluster, ctg_cns.c:1512-1530
+    if (clu.i_m) {
+        if (index >= 0) {
+            while (index > 0 && lq[(size_t)index].start <= clu.re) --index;
+            if (lq[(size_t)index].start > clu.re) ++index;
+            if ((size_t)index >= lq.size()) lq.resize((size_t)index + 100);
+            lq[(size_t)index].start = clu.rs;
+            lq[(size_t)index].end = clu.re;
+            lq[(size_t)index].l = 1;
+        } else {
+            ++index;
+            lq[(size_t)index].start = clu.rs;
+            lq[(size_t)index].end = clu.re;
+            lq[(size_t)index].l = 1;
+        }
+    }
+    return index;
+}
+
+// regions in DEscending order of position, like the reference builds them
 std::vector<LqReg> lq_regions(const LqCtx& x) {
     const std::vector<ColStat>& msa = *x.st;
     const std::vector<ConsBase>& cb = *x.c;
@@ -304,6 +324,8 @@ std::vector<LqReg> lq_regions(const LqCtx& x) {
     int index = 0;
     std::vector<Del> dels = l_del_regions(x);
     int dels_i = (int)dels.size();
+    const std::vector<np2::LqCluster>& clusters = *x.clusters;
+    int clusters_i = (int)clusters.size();
     auto st = [&](int i) -> const ColStat& { return msa[(size_t)cb[(size_t)i].pos]; };
     for (int i = len - 1; i >= 0; --i) {
         if ((float)st(i).l_ins < (float)st(i).coverage * x.gap_min_ratio1) continue;
@@ -336,6 +358,12 @@ std::vector<LqReg> lq_regions(const LqCtx& x) {
                 --dels_i;
                 if (++index >= (int)lq.size()) lq.resize(lq.size() + 100);
             }
+            while (clusters_i > 0 && (uint32_t)e < clusters[(size_t)clusters_i - 1].rs) {
+                index = lq_from_cluster(clusters[(size_t)clusters_i - 1], lq, index - 1);
+                --clusters_i;
+                while (clusters_i > 0 && !clusters[(size_t)clusters_i - 1].i_m) --clusters_i;
+                if (++index >= (int)lq.size()) lq.resize(lq.size() + 100);
+            }
             lq[(size_t)index].start = (uint32_t)s;
             lq[(size_t)index].end = (uint32_t)e;
             lq[(size_t)index].l = 0;
@@ -351,8 +379,10 @@ std::vector<LqReg> lq_regions(const LqCtx& x) {
 // HiFi: low-quality runs are found while walking the best path backwards (generate_cns_from_best_score_lq,
 // ctg_cns.c:1727-1826): a run of bases with qv < 80 closed by more than 4 good bases becomes a region (l = 4), padded
 // by 2 bases and merged with the previous one when they touch.  Upper case needs coverage > 4 and qv > 80.
-std::vector<np2::LqRegionIn> hifi_regions(std::vector<ConsBase>* cons, const std::vector<ColStat>& st) {
-    std::vector<np2::LqRegionIn> regs;
+std::vector<np2::LqRegionIn> hifi_regions(std::vector<ConsBase>* cons, const std::vector<ColStat>& st, const std::vector<np2::LqCluster>& clusters) {
+    std::vector<LqReg> regs(200);
+    int idx = 0;
+    int clusters_i = (int)clusters.size();
     const int len = (int)cons->size();
     auto R = [&](int p) -> ConsBase& { return (*cons)[(size_t)(len - 1 - p)]; };   // backtrace order
     const int lq_min_length = 2;
@@ -370,10 +400,19 @@ std::vector<np2::LqRegionIn> hifi_regions(std::vector<ConsBase>* cons, const std
         } else if (lq && p - lq_e > 2 * lq_min_length && R(p).pos != R(p - 1).pos) {
             lq_e = p - lq_min_length - 1;
             lq_s = lq_s > lq_min_length ? lq_s - lq_min_length : 1;
-            if (!regs.empty() && R(lq_s).pos >= regs.back().start) {
-                regs.back().start = R(lq_e).pos;
+            if (idx >= 1 && R(lq_s).pos >= regs[(size_t)idx - 1].start) {
+                regs[(size_t)idx - 1].start = R(lq_e).pos;
             } else {
-                regs.push_back(np2::LqRegionIn{R(lq_e).pos, R(lq_s).pos, 4});
+                while (clusters_i > 0 && R(lq_s).pos < clusters[(size_t)clusters_i - 1].rs) {
+                    idx = lq_from_cluster(clusters[(size_t)clusters_i - 1], regs, idx - 1);
+                    --clusters_i;
+                    while (clusters_i > 0 && !clusters[(size_t)clusters_i - 1].i_m) --clusters_i;
+                    if (++idx >= (int)regs.size()) regs.resize(regs.size() + 100);
+                }
+                regs[(size_t)idx].end = R(lq_s).pos;
+                regs[(size_t)idx].start = R(lq_e).pos;
+                regs[(size_t)idx].l = 4;
+                if (++idx >= (int)regs.size()) regs.resize(regs.size() + 100);
             }
             lq = 0;
             lq_s = -1;
@@ -381,7 +420,9 @@ std::vector<np2::LqRegionIn> hifi_regions(std::vector<ConsBase>* cons, const std
         const char up = (char)toupper(R(p).base);
         R(p).base = (cov > 4 && qv > 80) ? up : (char)tolower(up);
     }
-    return regs;
+    std::vector<np2::LqRegionIn> out;
+    for (int i = 0; i < idx; ++i) out.push_back(np2::LqRegionIn{regs[(size_t)i].start, regs[(size_t)i].end, regs[(size_t)i].l});
+    return out;
 }
 
 struct WindowCons {
@@ -391,7 +432,7 @@ struct WindowCons {
 };
 
 // link_consensus (ctg_cns.c:3121-3223) without split points (the structural layer that produces them is not built)
-consensus_trimed_data* link_windows(std::vector<WindowCons>& w, int len, int k, int split, int overlap_s) {
+consensus_trimed_data* link_windows(std::vector<WindowCons>& w, const std::vector<np2::SvPos>& split_ps, int len, int k, int split, int overlap_s) {
     const int s = overlap_s / 2;
     WindowCons *consensus = nullptr, *consensusnext = nullptr;
     int l = 0;
@@ -432,16 +473,40 @@ consensus_trimed_data* link_windows(std::vector<WindowCons>& w, int len, int k, 
         consensusnext->lstrip += (uint32_t)k;
     }
     consensus_trimed_data* out = (consensus_trimed_data*)malloc(sizeof(consensus_trimed_data));
-    out->i_m = 1;   // split ? split_ps->i + 1 : 1 with no split points
+    out->i_m = split ? (int)split_ps.size() + 1 : 1;
     out->data = (consensus_trimed*)calloc((size_t)out->i_m, sizeof(consensus_trimed));
-    (void)split;
     (void)len;
     size_t total = 0;
     for (auto& c : w) total += c.b.size();
-    consensus_trimed* ct = &out->data[0];
-    ct->seq = (char*)malloc(total + 1);
-    for (auto& c : w)
-        for (size_t j = c.lstrip; j + c.rstrip < c.b.size(); ++j) ct->seq[ct->len++] = c.b[j].base;
+    int index = 0;
+    consensus_trimed* ct = &out->data[index++];
+    ct->seq = (char*)malloc(total + 2);
+    size_t li = 0;
+    int sp = li < split_ps.size() ? (int)((split_ps[li].s + split_ps[li].e) / 2) : -1;
+    ++li;
+    for (auto& c : w) {
+        const int p = c.uncorrected_len;
+        const size_t end = c.b.size() - c.rstrip;
+        for (size_t j = c.lstrip; j < end; ++j) {
+            if (split && c.b[j].pos + (uint32_t)p >= (uint32_t)sp && j >= 1 && c.b[j - 1].pos + (uint32_t)p < (uint32_t)sp) {
+                if (split == 1 && ct->len) {
+                    ct->seq[ct->len] = '\0';
+                    ct = &out->data[index++];
+                    ct->seq = (char*)malloc(total + 2);
+                } else if (split == 2) {
+                    ct->seq[ct->len++] = 'N';
+                }
+                while (j < c.b.size() && c.b[j].pos + (uint32_t)p == (uint32_t)sp) ++j;
+            } else {
+                ct->seq[ct->len++] = c.b[j].base;
+            }
+            if (j < c.b.size() && c.b[j].pos + (uint32_t)p > (uint32_t)sp && li < split_ps.size()) {
+                sp = (int)((split_ps[li].s + split_ps[li].e) / 2);
+                ++li;
+            }
+        }
+    }
+    out->i_m = index;
     ct->seq[ct->len] = '\0';
     return out;
 }
@@ -513,25 +578,31 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
     std::vector<char> rfseq((size_t)ref->length + 1);
     bit2seq1(ref->s, ref->length, rfseq.data());
     const int32_t b = cal_win_len(cfg->w, cfg->s, ref->length);
-    int brk_g = ref->length > 100000 ? 1 : 0;
+    np2::SvContig sv;
+    sv.brk_g = ref->length > 100000 ? 1 : 0;
+    if (sv.brk_g) sv.ref_ide = np2::sv_cal_ref_ide(ref->qv, ref->qv_l);
+    np2::SvWindow svw;
     int32_t s = 0, e = 0;
-    int rreads_i = 0;
     std::vector<WindowCons> windows;
     long fra_map = 0, total_map = 0;
     np2::WindowInput in;
     np2::WindowOutput out;
     static uint64_t contig_serial = 0;
     in.contig_serial = ++contig_serial;
+    struct RecMeta { uint32_t l_qseq, aligned_q; Gap g; bool want_gap; };
     while (e < (int32_t)ref->length) {
         e = s + b > (int32_t)ref->length ? (int32_t)ref->length : s + b;
+        const int32_t l = e - s;
         in.contig_seq = rfseq.data();
         in.s = s;
         in.e = e;
         in.gap_min_len = gap_min_len;
         in.read_type = reads_type;
-        in.pos.clear(); in.n_cigar.clear(); in.l_qseq.clear(); in.aligned_q.clear(); in.cigar_off.clear(); in.seq_off.clear();
-        in.cigar.clear(); in.seq.clear();
-        uint32_t sup_aln_i = 0;
+        in.recs.clear();
+        in.sup.clear();
+        in.streams.clear();
+        std::vector<RecMeta> meta;
+        svw.reset(sv.brk_g ? (size_t)l / 10 + 16 : 0);
         int32_t p = 0;
         int rege = s == 0 ? (e > 15000000 ? e : 15000000) : e;
         std::string err;
@@ -577,42 +648,177 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
                     }
                 }
             }
-            if (rege && (r->flag & 0xD04) && brk_g && g.score) ++sup_aln_i;
+            if (rege && (r->flag & 0xD04) && sv.brk_g && g.score) {   // update_sup_alns (ctg_cns.c:2660-2681)
+                np2::SvSupAln sa_;
+                sa_.fs = rfp1.s;
+                sa_.ds = rdp1.s;
+                sa_.cigar.assign(cigar, cigar + r->n_cigar);
+                svw.sup_alns.push_back(std::move(sa_));
+            }
             if (r->flag & 0xD04) continue;
             ++total_map;
             const double frac = (double)(rdp1.e - rdp1.s) / (double)l_qseq;
             if (frac < 0.7) ++fra_map;
             if (!g.score && frac <= max_clip_ratio) continue;
-            if (brk_g && rreads_i < 50000) ++rreads_i;
+            if (sv.brk_g) {
+                const np2::SvPos rp{rfp1.s, rfp1.e};
+                if (!sv.rreads_w) {
+                    sv.rreads.push_back(rp);
+                    if (sv.rreads.size() >= 50000) {
+                        sv.rreads_w = np2::sv_cal_rreads_w(sv.rreads);
+                        for (const np2::SvPos& q : sv.rreads) np2::sv_update_ref_d(svw.ref_ds, sv.rreads_w, q, s);
+                    }
+                } else {
+                    np2::sv_update_ref_d(svw.ref_ds, sv.rreads_w, rp, s);
+                }
+            }
             if (!rege) continue;
-            in.pos.push_back(r->pos);
-            in.n_cigar.push_back(r->n_cigar);
-            in.l_qseq.push_back((uint32_t)l_qseq);
-            in.aligned_q.push_back(rdp1.e - rdp1.s);
-            in.cigar_off.push_back(in.cigar.size());
-            in.seq_off.push_back(in.seq.size());
-            in.cigar.insert(in.cigar.end(), cigar, cigar + r->n_cigar);
-            const uint8_t* sq = r->seq();
-            in.seq.insert(in.seq.end(), sq, sq + ((size_t)r->l_qseq + 1) / 2);
+            in.recs.add(r->pos, cigar, r->n_cigar, r->seq(), ((size_t)r->l_qseq + 1) / 2, rdp1.s);
+            meta.push_back(RecMeta{(uint32_t)l_qseq, rdp1.e - rdp1.s, g, false});
+            meta.back().want_gap = sv.brk_g && g.score && g.gap.s >= (uint32_t)s && g.gap.e <= (uint32_t)e;
         }
         if (it.failed()) np2_die(err.c_str(), ref->n);
-        in.seq.resize(in.seq.size() + 8, 0);
+        in.recs.seq.resize(in.recs.seq.size() + 8, 0);
+        // ---- spans of every candidate, then the order-dependent keep rules (ctg_cns.c:3540-3545)
+        std::vector<np2::SpanOut> spans;
+        if (!cfg->exec->compute_spans(in, 0, &spans, &err)) np2_die(err.c_str(), ref->n);
+        for (const np2::SpanOut& a : spans)
+            if (a.bad) { fprintf(stderr, "bamaln error, %s\n", ref->n); exit(1); }   // ctg_cns.c:3534-3537
+        {
+            // coverage of a column = number of kept streams whose [aln_t_s, aln_t_e) covers it (every draft position of
+            // a stream has exactly one non-insertion column), so the caps are decided from the spans alone
+            std::vector<uint32_t> cand;
+            for (uint32_t i = 0; i < spans.size(); ++i) {
+                const np2::SpanOut& a = spans[i];
+                if (a.aln_t_s > a.aln_t_e - 500u) continue;   // unsigned, as in the reference
+                const uint32_t ts = a.aln_t_s - (uint32_t)s, te = a.aln_t_e - (uint32_t)s;
+                if (ts > (uint32_t)l || te > (uint32_t)l) np2_die("alignment outside its window", ref->n);
+                cand.push_back(i);
+            }
+            std::vector<int32_t> diff((size_t)l + 2, 0);
+            diff[0] += 1;
+            diff[(size_t)l] -= 1;   // seed
+            for (uint32_t i : cand) { ++diff[spans[i].aln_t_s - (uint32_t)s]; --diff[spans[i].aln_t_e - (uint32_t)s]; }
+            int32_t run = 0, mx = 0;
+            for (int32_t q = 0; q <= l; ++q) { run += diff[(size_t)q]; mx = std::max(mx, run); }
+            std::vector<uint32_t> cov;
+            if (mx > 500) {   // deep pileup: replay the reference's decisions on a running coverage track
+                cov.assign((size_t)l + 1, 0);
+                for (int32_t q = 0; q < l; ++q) cov[(size_t)q] = 1;
+            }
+            for (uint32_t i : cand) {
+                const uint32_t ts = spans[i].aln_t_s - (uint32_t)s, te = spans[i].aln_t_e - (uint32_t)s;
+                if (mx > 500) {
+                    if ((cov[ts] > 3000 && cov[te] > 3000) ||
+                        (cov[ts] > 500 && cov[te] > 500 && (double)meta[i].aligned_q < meta[i].l_qseq * 0.9)) continue;
+                    for (uint32_t q = ts; q < te; ++q) ++cov[q];
+                }
+                np2::StreamRef sr;
+                sr.set = 0;
+                sr.rec = i;
+                sr.span = spans[i];
+                in.streams.push_back(sr);
+                if (meta[i].want_gap) {   // update_gap_info (ctg_cns.c:2627-2652)
+                    np2::SvGapRead gr;
+                    gr.gap = np2::SvPos{meta[i].g.gap.s, meta[i].g.gap.e};
+                    gr.p_id = (uint32_t)in.streams.size();   // stream index with the seed at 0
+                    gr.p_s = spans[i].aln_q_s;
+                    gr.s_id = meta[i].g.fs;
+                    gr.s_s = meta[i].g.ds;
+                    gr.l = 0;
+                    const uint8_t* sq = in.recs.seq.data() + in.recs.seq_off[i];
+                    const size_t nb = (i + 1 < in.recs.seq_off.size() ? in.recs.seq_off[i + 1] : in.recs.seq.size() - 8) - in.recs.seq_off[i];
+                    gr.dseq.assign(sq, sq + nb);
+                    gr.dseq.resize(nb + 8, 0);
+                    svw.gaps.push_back(std::move(gr));
+                }
+            }
+        }
+        uint32_t seq_count = 1 + (uint32_t)in.streams.size();
+        if (seq_count < 150 || sv.rreads.size() < 150 || svw.sup_alns.empty()) sv.brk_g = 0;
+        // ---- structural layer: depth track, low-depth regions, gap clusters, supplementary streams (ctg_cns.c:3559-3580)
+        if (sv.brk_g) {
+            if (!sv.rreads_w) {
+                sv.rreads_w = np2::sv_cal_rreads_w(sv.rreads);
+                for (const np2::SvPos& q : sv.rreads) np2::sv_update_ref_d(svw.ref_ds, sv.rreads_w, q, s);
+            }
+            if (!sv.ref_d) sv.ref_d = np2::sv_cal_ref_d(svw.ref_ds, l / 10);
+            np2::sv_update_ld_regs(&svw.ld_regs, svw.ref_ds, l / 10, sv.rreads_w, sv.ref_d);
+            FILE* lg = getenv("NP2_SV_LOG") ? fopen(getenv("NP2_SV_LOG"), "a") : nullptr;   // same lines as tests/shim/np2_ref_shim.c
+            if (lg) {
+                fprintf(lg, "update_ld_regs l %d w %d d %d s %d -> %zu regions\n", l / 10, sv.rreads_w, sv.ref_d, s, svw.ld_regs.size());
+                for (size_t i = 0; i < svw.ld_regs.size(); ++i) fprintf(lg, "  ld %zu %u %u\n", i, svw.ld_regs[i].s, svw.ld_regs[i].e);
+            }
+            if (sv.ref_ide) {
+                const int32_t d_t = (int32_t)(sv.ref_d * 0.3);
+                const uint32_t ide_t = (uint32_t)(sv.ref_ide * cfg->ide_t);
+                np2::sv_update_ld_regs_with_refqv(&svw.ld_regs, svw.ref_ds, ref, sv.rreads_w * 20, s, e, d_t, ide_t, cfg->ort_t, cfg->irt_t);
+                if (lg) {
+                    fprintf(lg, "update_ld_regs_with_refqv w %d d_t %d ide_t %u ort_t %u irt_t %u -> %zu regions\n", sv.rreads_w * 20, d_t, ide_t, cfg->ort_t,
+                            cfg->irt_t, svw.ld_regs.size());
+                    for (size_t i = 0; i < svw.ld_regs.size(); ++i) fprintf(lg, "  ld %zu %u %u\n", i, svw.ld_regs[i].s, svw.ld_regs[i].e);
+                }
+            }
+            const uint32_t n_gaps_before = (uint32_t)svw.gaps.size();
+            const int cl_total = np2::sv_update_gap_cluster(&svw, sv.rreads_w, sv.ref_d, s);
+            if (lg) {
+                fprintf(lg, "update_gap_cluster gaps %u w %d d %d ref_s %d -> clusters %zu total %d\n", n_gaps_before, sv.rreads_w, sv.ref_d, s, svw.clusters.size(), cl_total);
+                for (size_t i = 0; i < svw.clusters.size(); ++i) fprintf(lg, "  cluster %zu i_m %u median %u\n", i, svw.clusters[i].i_m, svw.clusters[i].median);
+                fclose(lg);
+            }
+            // the supplementary alignment of every split read: bases of the primary, CIGAR of the supplementary record
+            for (const np2::SvGapRead& gr : svw.gaps) {
+                const np2::SvSupAln* sa_ = nullptr;
+                for (const np2::SvSupAln& x : svw.sup_alns)
+                    if (x.fs == gr.s_id && x.ds == gr.s_s) { sa_ = &x; break; }
+                assert(sa_ != nullptr);   // find_sup_alns (ctg_cns.c:2828-2835)
+                in.sup.add((int32_t)sa_->fs, sa_->cigar.data(), (uint32_t)sa_->cigar.size(), gr.dseq.data(), gr.dseq.size(), sa_->ds);
+            }
+            std::vector<np2::SpanOut> sup_span;
+            if (!cfg->exec->compute_spans(in, 1, &sup_span, &err)) np2_die(err.c_str(), ref->n);
+            const uint32_t sc0 = seq_count;
+            seq_count = np2::sv_update_align_tags(&svw, sup_span, seq_count, s, &in.streams);
+            if (getenv("NP2_SV_LOG")) { FILE* lg2 = fopen(getenv("NP2_SV_LOG"), "a"); if (lg2) { fprintf(lg2, "update_align_tags streams %u -> %u\n", sc0, seq_count); fclose(lg2); } }
+        }
         if (!cfg->exec->run_window(in, &out, &err)) np2_die(err.c_str(), ref->n);
-        if (out.bad_cigar) { fprintf(stderr, "bamaln error, %s\n", ref->n); exit(1); }   // ctg_cns.c:3534-3537
-        if (out.seq_count < 150 || rreads_i < 150 || sup_aln_i == 0) brk_g = 0;
-        if (brk_g) np2_die("split-read structural layer (gap clusters, ctg_cns.c:3559-3580) is not built yet", ref->n);
-        // ---- low-quality regions: their re-consensus is not built yet
+        std::vector<np2::LqCluster> clusters;
+        if (sv.brk_g) {
+            np2::sv_generate_gapseqs(&svw, out, s);
+            FILE* lg = getenv("NP2_SV_LOG") ? fopen(getenv("NP2_SV_LOG"), "a") : nullptr;
+            if (lg) {
+                for (size_t i = 0; i < svw.clusters.size(); ++i) {
+                    const np2::SvCluster& c = svw.clusters[i];
+                    uint32_t l2 = 0;
+                    for (uint32_t j = 0; j < c.i_m; ++j) l2 += svw.gaps[c.gap[j]].l == 2;
+                    fprintf(lg, "generate_gapseqs cluster %zu r %u %u i_m %u usable %u\n", i, c.r.s, c.r.e, c.i_m, l2);
+                    for (uint32_t j = 0; j < c.i_m; ++j) {
+                        const np2::SvGapRead& g = svw.gaps[c.gap[j]];
+                        fprintf(lg, "    gap %u l %u read %u..%u p_id %u s_id %u\n", j, g.l, g.gap.s, g.gap.e, g.p_id, g.s_id);
+                    }
+                }
+            }
+            if (sv.ref_d > 15) np2::sv_update_split_p(&sv.split_ps, svw, s, e - s, ref);
+            if (lg) {
+                if (sv.ref_d > 15) {
+                    fprintf(lg, "update_split_p -> %zu split points\n", sv.split_ps.size());
+                    for (size_t i = 0; i < sv.split_ps.size(); ++i) fprintf(lg, "  split %zu %u %u\n", i, sv.split_ps[i].s, sv.split_ps[i].e);
+                }
+                fclose(lg);
+            }
+            clusters = np2::sv_lq_clusters(svw);
+        }
+        // ---- low-quality regions
         std::vector<np2::LqRegionIn> regs;
         if (reads_type == np2k::READS_HIFI) {
-            regs = hifi_regions(&out.cons, out.stat);   // also applies the HiFi case rule (qv > 80)
+            regs = hifi_regions(&out.cons, out.stat, clusters);   // also applies the HiFi case rule (qv > 80)
         } else {
-            LqCtx lx{&out.stat, &out.cons, reads_type, gap_min_ratio1};
-            for (const LqReg& r : lq_regions(lx)) regs.push_back(np2::LqRegionIn{r.start, r.end, r.l});
+            LqCtx lx{&out.stat, &out.cons, reads_type, gap_min_ratio1, &clusters};
+            for (const LqReg& q : lq_regions(lx)) regs.push_back(np2::LqRegionIn{q.start, q.end, q.l});
         }
         if (!regs.empty() || reads_type == np2k::READS_HIFI) {
             timespec t0, t1;
             clock_gettime(CLOCK_MONOTONIC, &t0);
-            if (!np2::lq_stage(cfg->exec, gap_min_len, reads_type == np2k::READS_HIFI, regs, out, &out.cons, &err)) np2_die(err.c_str(), ref->n);
+            if (!np2::lq_stage(cfg->exec, gap_min_len, reads_type == np2k::READS_HIFI, regs, clusters, out, &out.cons, &err)) np2_die(err.c_str(), ref->n);
             clock_gettime(CLOCK_MONOTONIC, &t1);
             if (getenv("NP2_TIMING")) fprintf(stderr, "[np2 lq stage] %zu regions, %.2f ms\n", regs.size(), (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
         }
@@ -627,5 +833,5 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
         fprintf(stderr, "Warning, Too many (%.3f%%) fragment mappings in %s, please polish the genome with other reads first, or"
                 " adjust the mapping parameters to tolerate more errors, such as use asm20/map-pb instead of asm5 for minimap2,"
                 " continue anyway...\n", (double)fra_map * 100 / (double)(total_map + 1), ref->n);
-    return link_windows(windows, (int)ref->length, 50, cfg->split, cfg->s);
+    return link_windows(windows, sv.split_ps, (int)ref->length, 50, cfg->split, cfg->s);
 }

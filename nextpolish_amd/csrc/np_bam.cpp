@@ -210,7 +210,7 @@ void BamWriter::index_record(int32_t tid, int32_t beg, int32_t end, voff_t v0, v
 
 bool BamWriter::write(int32_t tid, int32_t pos, uint8_t mapq, uint16_t flag, int32_t mtid, int32_t mpos,
                       int32_t isize, const std::string& qname, const uint32_t* cigar, uint32_t n_cigar,
-                      const uint8_t* seq4, const uint8_t* qual, int32_t l_qseq) {
+                      const uint8_t* seq4, const uint8_t* qual, int32_t l_qseq, const uint8_t* aux, size_t aux_len) {
     int32_t rl = 0;
     for (uint32_t i = 0; i < n_cigar; ++i) {
         uint32_t op = cigar[i] & 0xf;
@@ -220,7 +220,7 @@ bool BamWriter::write(int32_t tid, int32_t pos, uint8_t mapq, uint16_t flag, int
     int32_t end = pos + ((mapped && rl > 0) ? rl : 1);
     uint32_t bin = (uint32_t)reg2bin(pos < 0 ? 0 : pos, end < 1 ? 1 : end);
     uint32_t l_qname = (uint32_t)qname.size() + 1;
-    size_t body = 32 + l_qname + 4 * (size_t)n_cigar + ((size_t)l_qseq + 1) / 2 + (size_t)l_qseq;
+    size_t body = 32 + l_qname + 4 * (size_t)n_cigar + ((size_t)l_qseq + 1) / 2 + (size_t)l_qseq + aux_len;
     buf_.resize(4 + body);
     uint8_t* p = buf_.data();
     int32_t block_len = (int32_t)body;
@@ -244,6 +244,8 @@ bool BamWriter::write(int32_t tid, int32_t pos, uint8_t mapq, uint16_t flag, int
     if (l_qseq) {
         if (qual) memcpy(p, qual, l_qseq); else memset(p, 0xff, l_qseq);
     }
+    p += l_qseq;
+    if (aux_len) memcpy(p, aux, aux_len);
     voff_t v0 = bg_.tell();
     if (!bg_.write(buf_.data(), buf_.size())) return false;
     voff_t v1 = bg_.tell();

@@ -82,7 +82,7 @@ public:
     // cigar: BAM-encoded ops; seq4: 4-bit packed ((l_qseq+1)/2 bytes); qual: l_qseq bytes
     bool write(int32_t tid, int32_t pos, uint8_t mapq, uint16_t flag, int32_t mtid, int32_t mpos, int32_t isize,
                const std::string& qname, const uint32_t* cigar, uint32_t n_cigar, const uint8_t* seq4,
-               const uint8_t* qual, int32_t l_qseq);
+               const uint8_t* qual, int32_t l_qseq, const uint8_t* aux = nullptr, size_t aux_len = 0);   // aux: raw optional fields
     bool close();   // also writes <path>.bai
 private:
     void index_record(int32_t tid, int32_t beg, int32_t end, voff_t v0, voff_t v1, bool mapped);

@@ -71,6 +71,13 @@ int np1_stream_write_files(const np1_stream* st, const char* fasta, const char* 
     return 0;
 }
 
+int np1_stream_write_files_aux(const np1_stream* st, const char* fasta, const char* bam, int level, const uint8_t* aux_pool,
+                                const uint64_t* aux_off) {
+    std::string err;
+    if (!np::write_stream_files(st->s, fasta, bam, level, &err, aux_pool, aux_off)) { g_err = err; return -1; }
+    return 0;
+}
+
 void np1_stream_free(np1_stream* st) { delete st; }
 
 np1_stream* np1_stream_build(const np1_stream_view* v, const char* const* names) {

@@ -301,7 +301,7 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
 }
 
 bool write_stream_files(const ReadStream& s, const std::string& fasta, const std::string& bam, int level,
-                        std::string* err) {
+                        std::string* err, const uint8_t* aux_pool, const uint64_t* aux_off) {
     FILE* fp = fopen(fasta.c_str(), "w");
     if (!fp) { *err = "cannot write " + fasta; return false; }
     FILE* fi = fopen((fasta + ".fai").c_str(), "w");
@@ -337,7 +337,8 @@ bool write_stream_files(const ReadStream& s, const std::string& fasta, const std
         snprintf(qn, sizeof(qn), "r%zu", i);
         const uint8_t* q = have_q ? s.qual.data() + s.qual_off[i] : nullptr;
         if (!w.write((int32_t)s.ctg[i], s.pos[i], s.mapq[i], s.flag[i], (int32_t)s.ctg[i], s.pos[i], s.isize[i], qn,
-                     s.cigar.data() + s.cigar_off[i], s.n_cigar[i], s.seq.data() + s.seq_off[i], q, s.l_qseq[i])) {
+                     s.cigar.data() + s.cigar_off[i], s.n_cigar[i], s.seq.data() + s.seq_off[i], q, s.l_qseq[i],
+                     aux_pool ? aux_pool + aux_off[i] : nullptr, aux_pool ? (size_t)(aux_off[i + 1] - aux_off[i]) : 0)) {
             *err = "BAM write failed";
             return false;
         }

@@ -25,5 +25,6 @@ void synth_default_params(np_synth_params* p);
 bool synth_stream(const np_synth_params& p, const std::string& contig_name_prefix, ReadStream* out);
 // Serialises a stream (needs qualities loaded unless write_qual_ff) to fasta(+.fai) and bam(+.bai).
 bool write_stream_files(const ReadStream& s, const std::string& fasta, const std::string& bam, int bgzf_level,
-                        std::string* err);
+                        std::string* err, const uint8_t* aux_pool = nullptr,
+                        const uint64_t* aux_off = nullptr);   // aux: raw optional fields per record (tests: SA tags)
 }  // namespace np

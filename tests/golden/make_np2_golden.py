@@ -32,6 +32,12 @@ def main():
     res = rb.polish(L, fa, fofn, window=np2_cases.TWO_WINDOW_W)
     s = res["ctg0"][0][0]
     out["two_windows"] = {"md5": hashlib.md5(s.encode()).hexdigest(), "len": len(s), "pieces": len(res["ctg0"])}
+    # split-read structural layer: md5 + piece lengths of the reference's output
+    out["sv"] = {}
+    for cid, kw, rt, split, qvs in np2_cases.SV_CASES:
+        fa, fofn, contigs = np2_cases.materialise_sv(kw, qvs)
+        res = rb.polish(L, fa, fofn, read_type=rt, split=split)["ctg0"]
+        out["sv"][cid] = {"lens": [r[1] for r in res], "md5": [hashlib.md5(r[0].encode()).hexdigest() for r in res]}
     # codec known answers: pack then unpack through the reference (incl. the non-ACGT spill of bseq.c:91)
     for s in ["ACGT", "AANAA", "GGNGG", "acgtn", "TTTTTTTTTTTTTTTTA", "NACGT", "ACGTACGTACGTACGTN", "RYKM", "A", "TU"]:
         words = (C.c_uint32 * (len(s) // 16 + 1))()

@@ -110,13 +110,25 @@ class HostExec : public Exec {
         return true;
     }
 
+    bool compute_spans(const WindowInput& in, int set, std::vector<SpanOut>* spans, std::string*) override {
+        const RecordSet& rs = set ? in.sup : in.recs;
+        spans->assign(rs.size(), SpanOut{0, 0, 0, 0, 0, 0});
+        for (size_t i = 0; i < rs.size(); ++i) {
+            ReadView rv{rs.pos[i], rs.n_cigar[i], rs.cigar.data() + rs.cigar_off[i], rs.seq.data() + rs.seq_off[i]};
+            uint32_t N, rf_len, rd_len;
+            bool bad;
+            cigar_totals(rv, &N, &rf_len, &rd_len, &bad);
+            if (bad) { (*spans)[i].bad = 1; continue; }
+            const AlnSpan a = align_span(rv, in.contig_seq, in.s, in.e, rs.q0[i]);
+            (*spans)[i] = SpanOut{a.col0, a.aln_len, a.aln_t_s, a.aln_t_e, a.aln_q_s, 0};
+        }
+        return true;
+    }
+
     bool run_window(const WindowInput& in, WindowOutput* out, std::string* err) override {
         const int32_t s = in.s, e = in.e, l = e - s;
-        const size_t n = in.n_reads();
-        out->kept.assign(n, 0);
         out->stat.assign((size_t)l + 1, ColStat{0, 0, 0, 0});
         out->tag_off.clear(); out->aln_t_s.clear(); out->aln_t_e.clear(); out->tags.clear(); out->cons.clear();
-        out->bad_cigar = false;
         HostStat hs{out->stat.data()};
         // ---- seed: the window against itself (ctg_cns.c:3458-3469)
         std::vector<uint8_t> seed_seq(((size_t)l + 1) / 2 + 1, 0);
@@ -135,25 +147,12 @@ class HostExec : public Exec {
         };
         {
             ReadView rv{s, 1, &seed_cigar, seed_seq.data()};
-            add_stream(rv, AlnSpan{0, (uint32_t)l, (uint32_t)s, (uint32_t)e});
+            add_stream(rv, AlnSpan{0, (uint32_t)l, (uint32_t)s, (uint32_t)e, 0});
         }
-        // ---- candidate records in merge order
-        for (size_t i = 0; i < n; ++i) {
-            ReadView rv{in.pos[i], in.n_cigar[i], in.cigar.data() + in.cigar_off[i], in.seq.data() + in.seq_off[i]};
-            uint32_t N, rf_len, rd_len;
-            bool bad;
-            cigar_totals(rv, &N, &rf_len, &rd_len, &bad);
-            if (bad) { out->bad_cigar = true; return true; }
-            const AlnSpan a = align_span(rv, in.contig_seq, s, e);
-            if (a.aln_t_s > a.aln_t_e - 500u) continue;                   // unsigned, as in the reference (ctg_cns.c:3540)
-            const uint32_t ts = a.aln_t_s - (uint32_t)s, te = a.aln_t_e - (uint32_t)s;
-            if (ts > (uint32_t)l || te > (uint32_t)l) { *err = "alignment outside its window"; return false; }
-            const ColStat& cs = out->stat[ts];
-            const ColStat& ce = out->stat[te];
-            if ((cs.coverage > 3000 && ce.coverage > 3000) ||
-                (cs.coverage > 500 && ce.coverage > 500 && (double)in.aligned_q[i] < in.l_qseq[i] * 0.9)) continue;
-            out->kept[i] = 1;
-            add_stream(rv, a);
+        for (const StreamRef& sr : in.streams) {
+            const RecordSet& rs = sr.set ? in.sup : in.recs;
+            ReadView rv{rs.pos[sr.rec], rs.n_cigar[sr.rec], rs.cigar.data() + rs.cigar_off[sr.rec], rs.seq.data() + rs.seq_off[sr.rec]};
+            add_stream(rv, AlnSpan{sr.span.col0, sr.span.aln_len, sr.span.aln_t_s, sr.span.aln_t_e, sr.span.aln_q_s});
         }
         out->seq_count = (uint32_t)out->tag_off.size();
         // ---- link graph (update_msa, ctg_cns.c:324-365)

@@ -42,3 +42,42 @@ def materialise(case_kw, workdir=None):
     with open(fofn, "w") as f:
         f.write(bam + "\n")
     return fa, fofn, contigs
+
+
+# split-read structural layer (contig > 100 kb, >= 150 reads, SA-split supplementary records): gap clusters from
+# blocks the draft lacks, a stretch no read crosses (split point), an assembly QV track in the FASTA comment
+# (id, make_sv_case keywords, read type, split mode, [(pos, ide, ort, irt)] or None)
+SV_CASES = [
+    ("sv_ont_two_blocks", dict(seed=2, depth=40), 1, 1, None),
+    ("sv_hifi_blocks_recovered", dict(seed=6, depth=40, sub=0.005, ins=0.003, dele=0.003), 3, 1, None),
+    ("sv_clr", dict(seed=7, depth=40, mean_len=12000), 2, 1, None),
+    ("sv_hole_split_pieces", dict(seed=9, depth=40, hole=(70000, 70300)), 1, 1, None),
+    ("sv_hole_split_N", dict(seed=9, depth=40, hole=(70000, 70300)), 1, 2, None),
+    ("sv_refqv_split_point", dict(seed=14, depth=40, hole=(70000, 70300)), 1, 1,
+     [(10000, 800, 900, 900), (30000, 790, 900, 900), (69800, 800, 900, 990), (100000, 805, 800, 820)]),
+    ("sv_refqv_merged_regions", dict(seed=12, depth=40, hole=(70000, 70300)), 1, 1,
+     [(20000, 700, 900, 900), (50000, 300, 300, 300), (69500, 200, 250, 240), (70100, 100, 100, 100), (100000, 650, 800, 820)]),
+]
+
+
+def materialise_sv(case_kw, qvs=None, workdir=None):
+    from nextpolish_amd import _native as nat
+    kw = dict(case_kw)
+    seed = kw.pop("seed")
+    contigs, reads, aux = np2_gen.make_sv_case(seed, **kw)
+    d = workdir or tempfile.mkdtemp(prefix="np2sv_")
+    st = nat.Stream.from_reads(contigs, reads)
+    fa, bam = os.path.join(d, "g.fa"), os.path.join(d, "r.bam")
+    st.write_files(fa, bam, aux=aux)
+    st.close()
+    if qvs:   # per-contig QV track in the FASTA comment (set_ref_qv, ctg_cns.c:2233-2267)
+        hexes = ":".join("%x" % (p << 32 | ide << 20 | ort << 10 | irt) for p, ide, ort, irt in qvs)
+        lines = open(fa).read().split("\n")
+        lines[0] = ">%s node_c=%d qv_h=%s" % (contigs[0][0], len(qvs), hexes)
+        with open(fa, "w") as f:
+            f.write("\n".join(lines))
+        os.remove(fa + ".fai")
+    fofn = os.path.join(d, "bam.fofn")
+    with open(fofn, "w") as f:
+        f.write(bam + "\n")
+    return fa, fofn, contigs

@@ -17,9 +17,9 @@ PRODUCT_SO = os.path.join(HERE, "..", "nextpolish_amd", "lib", "nextpolish2.so")
 LQ_CASES = {"ont_lq_regions", "clr_lq_regions"}   # windows with low-quality regions: POA pseudo-seeds + graph re-consensus
 
 
-def run_polish(so_path, fa, fofn, read_type):
+def run_polish(so_path, fa, fofn, read_type, split=0):
     code = ("import sys, json; sys.path.insert(0, %r); import ref2_binding as rb; L = rb.bind(%r); "
-            "print(json.dumps(rb.polish(L, %r, %r, read_type=%d)))" % (HERE, so_path, fa, fofn, read_type))
+            "print(json.dumps(rb.polish(L, %r, %r, read_type=%d, split=%d)))" % (HERE, so_path, fa, fofn, read_type, split))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     if p.returncode != 0:
         return None, p.stderr
@@ -90,3 +90,16 @@ def test_gpu_two_windows_are_stitched_like_the_reference(tmp_path):
     assert p.returncode == 0, p.stderr
     s = json.loads(p.stdout.strip().splitlines()[-1])["ctg0"][0][0]
     assert len(s) == GOLD["two_windows"]["len"] and hashlib.md5(s.encode()).hexdigest() == GOLD["two_windows"]["md5"]
+
+
+@pytest.mark.parametrize("cid", [c[0] for c in np2_cases.SV_CASES])
+def test_gpu_structural_layer_matches_reference_goldens(cid, tmp_path):
+    """Contigs > 100 kb with split (SA) reads: supplementary tag streams, cluster candidates, split points, QV track."""
+    import hashlib
+    kw, rt, split, qvs = next((k, r, s, q) for c, k, r, s, q in np2_cases.SV_CASES if c == cid)
+    fa, fofn, contigs = np2_cases.materialise_sv(kw, qvs, str(tmp_path))
+    got, err = run_polish(PRODUCT_SO, fa, fofn, rt, split=split)
+    assert got is not None, err
+    want = GOLD["sv"][cid]
+    assert [p[1] for p in got["ctg0"]] == want["lens"]
+    assert [hashlib.md5(p[0].encode()).hexdigest() for p in got["ctg0"]] == want["md5"]

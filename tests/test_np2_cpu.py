@@ -28,11 +28,11 @@ def model():
     return MODEL_SO
 
 
-def run_polish(so_path, fa, fofn, read_type, window=5000000):
+def run_polish(so_path, fa, fofn, read_type, window=5000000, split=0, env=None):
     """ctg_cns_core exits the process on unsupported input (the reference's error convention): run it in a child."""
     code = ("import sys, json; sys.path.insert(0, %r); import ref2_binding as rb; L = rb.bind(%r); "
-            "print(json.dumps(rb.polish(L, %r, %r, read_type=%d, window=%d)))" % (HERE, so_path, fa, fofn, read_type, window))
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+            "print(json.dumps(rb.polish(L, %r, %r, read_type=%d, window=%d, split=%d)))" % (HERE, so_path, fa, fofn, read_type, window, split))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     if p.returncode != 0:
         return None, p.stderr
     return json.loads(p.stdout.strip().splitlines()[-1]), p.stderr
@@ -191,3 +191,36 @@ def test_two_windows_are_stitched_like_the_reference(model, tmp_path):
     s = got["ctg0"][0][0]
     assert len(got["ctg0"]) == GOLD["two_windows"]["pieces"] and len(s) == GOLD["two_windows"]["len"]
     assert hashlib.md5(s.encode()).hexdigest() == GOLD["two_windows"]["md5"]
+
+
+@pytest.mark.parametrize("cid", [c[0] for c in np2_cases.SV_CASES])
+def test_structural_layer_matches_reference_goldens(model, cid, tmp_path):
+    """Split reads: gap clusters, supplementary streams, cluster candidates, split points, QV-track regions."""
+    import hashlib
+    kw, rt, split, qvs = next((k, r, s, q) for c, k, r, s, q in np2_cases.SV_CASES if c == cid)
+    fa, fofn, contigs = np2_cases.materialise_sv(kw, qvs, str(tmp_path))
+    got, err = run_polish(model, fa, fofn, rt, split=split)
+    assert got is not None, err
+    want = GOLD["sv"][cid]
+    assert [p[1] for p in got["ctg0"]] == want["lens"]
+    assert [hashlib.md5(p[0].encode()).hexdigest() for p in got["ctg0"]] == want["md5"]
+
+
+@pytest.mark.skipif(not rb.available(), reason="oracle/_ref not built (reference sources absent)")
+def test_structural_layer_stage_by_stage_against_reference(model, tmp_path):
+    """The reference's helper functions are interposed (tests/shim) and their results logged; this library logs the
+    same lines (NP2_SV_LOG): low-depth regions, clusters and medians, supplementary streams, per-gap read
+    coordinates, split points must agree line by line."""
+    shim_src = os.path.join(HERE, "shim", "np2_ref_shim.c")
+    shim = str(tmp_path / "libshim.so")
+    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-o", shim, shim_src, "-ldl"], check=True)
+    ref_so = os.path.realpath(rb.REF_SO)
+    for cid, kw, rt, split, qvs in np2_cases.SV_CASES[3:6]:
+        d = tmp_path / cid
+        d.mkdir()
+        fa, fofn, contigs = np2_cases.materialise_sv(kw, qvs, str(d))
+        want, _ = run_polish(ref_so, fa, fofn, rt, split=split, env=dict(LD_PRELOAD=shim, NP2_SHIM_LOG=str(d / "ref.log"), NP2_REF_SO=ref_so))
+        got, err = run_polish(model, fa, fofn, rt, split=split, env=dict(NP2_SV_LOG=str(d / "mine.log")))
+        assert got is not None, err
+        assert (d / "ref.log").read_text() == (d / "mine.log").read_text(), cid
+        assert got == want
