@@ -431,7 +431,7 @@ struct WindowCons {
     int32_t uncorrected_len = 0;
 };
 
-// link_consensus (ctg_cns.c:3121-3223) without split points (the structural layer that produces them is not built)
+// link_consensus (ctg_cns.c:3121-3223): windows stitched at an 8-mer shared in the overlap, cut at the split points
 consensus_trimed_data* link_windows(std::vector<WindowCons>& w, const std::vector<np2::SvPos>& split_ps, int len, int k, int split, int overlap_s) {
     const int s = overlap_s / 2;
     WindowCons *consensus = nullptr, *consensusnext = nullptr;
