@@ -78,6 +78,10 @@ struct LqInput {
     bool hifi = false;               // HiFi branch of the DP (coefficient 4, CLR-style tie rule)
 };
 
+// "the bases of stream `stream` at window positions [start, end]" (inclusive; gap tags dropped): one candidate string
+// of a low-quality region (generate_lqseqs_from_tags, ctg_cns.c:822-870)
+struct SubReq { uint32_t stream, start, end; };
+
 class Exec {
   public:
     virtual ~Exec() {}
@@ -89,6 +93,9 @@ class Exec {
     // link graph + DP variant + backtrace of get_lqseqs_from_align_tags (ctg_cns.c:986-1163, non-HiFi branch):
     // *cons_rev = consensus characters in backtrace order (last column first), as the reference leaves them
     virtual bool run_lq(const LqInput& in, std::string* cons_rev, std::string* err) = 0;
+    // candidate strings from the tag streams of the LAST run_window call (they stay with the executor until the next
+    // run_window / run_lq): request i -> bases[off[i] .. off[i + 1]).  Requests come grouped by ascending stream.
+    virtual bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) = 0;
 };
 
 // provided by whichever executor is linked (HIP in the product library)

@@ -293,6 +293,61 @@ struct DpResult {
 // tag streams of gapped string pairs (the concatenated low-quality regions), chunk-parallel: the target position of
 // a column is the number of non-gap target characters before it (count per chunk + scan), the open insertion run is
 // found by a short look-back
+// ------------------------------------------------------------------------------------------------
+// Candidate strings of the low-quality regions straight from the tag streams in HBM (one lane per (stream, region)
+// request): the tag holding window position `start` is found through the per-chunk counts of non-insertion tags the
+// link stage already scanned (binary search over the stream's chunks, then 8 tags per word inside the chunk), then the
+// bases up to position `end` are counted (kWrite = false) or written (kWrite = true).
+struct SubReqDev { uint32_t stream, start, end, first_chunk, n_chunks; };
+template <bool kWrite>
+__global__ void k2_extract(const SubReqDev* rq, uint32_t n, const uint32_t* pre, const uint64_t* tag_off, const uint32_t* aln_t_s,
+                           const uint8_t* tags, uint32_t* first_tag, uint32_t* len, const uint32_t* out_off, char* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SubReqDev r = rq[i];
+    const uint8_t* tg = tags + tag_off[r.stream];
+    const uint32_t ts = aln_t_s[r.stream];
+    uint32_t j;
+    if (!kWrite) {
+        const uint32_t need = r.start - ts + 1;   // tag j is the need-th non-insertion tag of the stream
+        uint32_t lo = 0, hi = r.n_chunks;         // last chunk whose prefix count is < need
+        const uint32_t base = pre[r.first_chunk];
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pre[r.first_chunk + mid] - base < need) lo = mid;
+            else hi = mid;
+        }
+        uint32_t have = pre[r.first_chunk + lo] - base;
+        j = lo * LINK_CHUNK;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(tg) + (j >> 3);   // streams start 4-byte aligned, chunks are 256 bytes
+        for (;;) {   // whole words while the target lies beyond them (a terminator nibble has bit 3 set: it never counts)
+            const uint32_t c = 8u - (uint32_t)__popc(*w & 0x88888888u);
+            if (have + c >= need) break;
+            have += c;
+            ++w;
+            j += 8;
+        }
+        for (;; ++j)
+            if (!(tag_nib(tg, j) & 8u) && ++have == need) break;
+        first_tag[i] = j;
+    } else {
+        j = first_tag[i];
+    }
+    uint32_t t_pos = r.start, n_out = 0;
+    char* o = kWrite ? out + out_off[i] : nullptr;
+    const uint32_t j0 = j;
+    for (;; ++j) {
+        const uint32_t nb = tag_nib(tg, j);
+        if (nb == 15u) break;
+        if (!(nb & 8u) && j != j0 && ++t_pos > r.end) break;
+        if ((nb & 7u) != 4u) {
+            if (kWrite) o[n_out] = int_to_base(nb & 7u);
+            ++n_out;
+        }
+    }
+    if (!kWrite) len[i] = n_out;
+}
+
 struct StrChunk { uint32_t stream, c0, n, first_chunk_of_stream, last, pad0, pad1, pad2; };
 __global__ void k2_str_count(const StrChunk* sc, uint32_t n_chunks, const char* pool, const uint64_t* str_off, uint32_t* cnt) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -800,6 +855,7 @@ class HipExec : public Exec {
     bool compute_spans(const WindowInput& in, int set, std::vector<SpanOut>* spans, std::string* err) override;
     bool run_window(const WindowInput& in, WindowOutput* out, std::string* err) override;
     bool run_lq(const LqInput& in, std::string* cons_rev, std::string* err) override;
+    bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) override;
 
   private:
     // link observations -> column buckets -> nodes/entries for n_streams tag streams over n_cols columns; *total = entries
@@ -816,6 +872,9 @@ class HipExec : public Exec {
     DevBuf rb_[2][7];   // pos, n_cigar, q0, cigar_off, seq_off, cigar, seq of the two record sets
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
+    DevBuf xreq_, xfirst_, xlen_, xoff_, xout_;
+    std::vector<uint32_t> win_first_chunk_, win_n_chunks_;   // chunk range of every stream of the last run_window
+    bool win_tags_live_ = false;
     uint64_t contig_serial_ = ~0ull;
     size_t contig_len_ = 0;
 };
@@ -960,6 +1019,7 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     clk.mark("download");
     clk.flush("window", l, n_streams, total);
     out->aln_t_e[0] = (uint32_t)l;
+    win_tags_live_ = true;
     return true;
 }
 
@@ -1065,9 +1125,13 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
     hipStream_t q = stream_;
     // ---- chunk list (host: O(streams)), non-insertion tag counts per chunk, scan
     std::vector<ChunkDesc> cd;
+    win_first_chunk_.assign(n_tags.size(), 0);
+    win_n_chunks_.assign(n_tags.size(), 0);
     for (uint32_t s = 0; s < (uint32_t)n_tags.size(); ++s) {
         const uint32_t first_chunk = (uint32_t)cd.size();
         for (uint32_t t = 0; t < n_tags[s]; t += LINK_CHUNK) cd.push_back(ChunkDesc{s, t, std::min(LINK_CHUNK, n_tags[s] - t), first_chunk});
+        win_first_chunk_[s] = first_chunk;
+        win_n_chunks_[s] = (uint32_t)cd.size() - first_chunk;
     }
     const uint32_t n_chunks = (uint32_t)cd.size();
     if (!chunks_.ensure(sizeof(ChunkDesc) * (size_t)n_chunks + 64) || !chcnt_.ensure(4ull * (n_chunks + 2)) || !chpre_.ensure(4ull * (n_chunks + 2)) ||
@@ -1107,8 +1171,46 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
     return true;
 }
 
+bool HipExec::extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) {
+    HIPOK(hipSetDevice(device_));
+    hipStream_t q = stream_;
+    const uint32_t n = (uint32_t)req.size();
+    off->assign((size_t)n + 1, 0);
+    bases->clear();
+    if (!n) return true;
+    if (!win_tags_live_) { *err = "extract without a window in HBM"; return false; }
+    std::vector<SubReqDev> rd(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (req[i].stream >= win_n_chunks_.size() || !win_n_chunks_[req[i].stream]) { *err = "extract: bad stream"; return false; }
+        rd[i] = SubReqDev{req[i].stream, req[i].start, req[i].end, win_first_chunk_[req[i].stream], win_n_chunks_[req[i].stream]};
+    }
+    const uint32_t nsb = nblk(n + 1, SCAN_TILE);
+    if (!xreq_.ensure(sizeof(SubReqDev) * (size_t)n) || !xfirst_.ensure(4ull * n) || !xlen_.ensure(4ull * (n + 2)) || !xoff_.ensure(4ull * (n + 2)) ||
+        !sums2_.ensure(4ull * (nsb + 2))) { *err = "out of device memory (candidates)"; return false; }
+    HIPOK(hipMemcpyAsync(xreq_.p, rd.data(), sizeof(SubReqDev) * (size_t)n, hipMemcpyHostToDevice, q));
+    HIPOK(hipMemsetAsync(xlen_.as<uint32_t>() + n, 0, 4, q));
+    k2_extract<false><<<nblk(n, 64), 64, 0, q>>>(xreq_.as<SubReqDev>(), n, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), tags_.as<uint8_t>(),
+                                                  xfirst_.as<uint32_t>(), xlen_.as<uint32_t>(), nullptr, nullptr);
+    k2_scan_sums<<<nsb, SCAN_T, 0, q>>>(xlen_.as<uint32_t>(), n + 1, sums2_.as<uint32_t>());
+    k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nsb);
+    k2_scan_final<<<nsb, SCAN_T, 0, q>>>(xlen_.as<uint32_t>(), n + 1, sums2_.as<uint32_t>(), xoff_.as<uint32_t>());
+    HIPOK(hipMemcpyAsync(off->data(), xoff_.p, 4ull * (n + 1), hipMemcpyDeviceToHost, q));
+    HIPOK(hipStreamSynchronize(q));
+    const uint32_t total = (*off)[n];
+    if (total) {
+        if (!xout_.ensure((size_t)total + 16)) { *err = "out of device memory (candidates)"; return false; }
+        k2_extract<true><<<nblk(n, 64), 64, 0, q>>>(xreq_.as<SubReqDev>(), n, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), tags_.as<uint8_t>(),
+                                                     xfirst_.as<uint32_t>(), nullptr, xoff_.as<uint32_t>(), xout_.as<char>());
+        bases->resize(total);
+        HIPOK(hipMemcpyAsync(&(*bases)[0], xout_.p, total, hipMemcpyDeviceToHost, q));
+        HIPOK(hipStreamSynchronize(q));
+    }
+    return true;
+}
+
 bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err) {
     HIPOK(hipSetDevice(device_));
+    win_tags_live_ = false;   // the chunk tables are rebuilt for the concatenated regions
     hipStream_t q = stream_;
     const uint32_t n_streams = (uint32_t)in.t.size();
     const uint32_t n_cols = in.t_len + 1 + 32;   // slack: see the fill quirk in np2_lq.cpp

@@ -8,8 +8,10 @@
 // (:1425-1473), update_consensus_trimed (:1165-1211).  Candidate ordering uses a stable sort: the reference calls
 // glibc qsort, which is a merge sort for these sizes.
 #include "np2_lq.h"
+#include "np_threads.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +42,7 @@ struct Region {      // lqseq (ctg_cns.h:73-90)
 // the 65 536-bin table is cleared through the list of bins the previous call touched (the reference memsets 128 KB
 // per call; the counts are the same)
 thread_local std::vector<uint16_t> g_touched;
+thread_local std::vector<uint16_t> g_kmers;   // the table itself, one per host thread (paired with g_touched)
 void count_kmers(const Region& lq, std::vector<uint16_t>& kmers, int c, int l) {
     for (uint16_t k : g_touched) kmers[k] = 0;
     g_touched.clear();
@@ -150,7 +153,7 @@ bool rank_and_seed(Region& r, std::vector<uint16_t>& kmers, bool trim, int min_s
 }
 
 // generate_lqseqs_from_tags (kmer = false) / generate_lqseqs_from_tags_kmer (HiFi, ctg_cns.c:636-820); returns max_aln_length
-int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo, bool kmer, const std::vector<LqCluster>& clusters) {
+int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& wo, bool kmer, const std::vector<LqCluster>& clusters, std::string* err) {
     const int count = (int)lq.size();
     if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   collect start (t=%.2f)\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6); }
     for (Region& r : lq) {
@@ -158,33 +161,39 @@ int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo, bool kme
         r.lqcount = 0; r.len = 0; r.sudoseed_len = 0;
         r.seqs.assign(LQSEQ_MAX_CAN_COUNT, Cand());
     }
-    std::vector<Tag> at;
-    Tag tag{0, 0, 0};
-    int s = count - 1;
-    for (uint32_t i = 1; i < wo.seq_count; ++i) {
-        const uint32_t ts = wo.aln_t_s[i], te = wo.aln_t_e[i] - 1;   // the reference's aln_t_e of a stream is inclusive
-        while (s >= 0 && (lq[(size_t)s].start < ts || lq[(size_t)s].len >= LQSEQ_MAX_CAN_COUNT)) --s;
-        int j = s;
-        for (; j >= 0 && lq[(size_t)j].end <= te; --j) {}
-        if (j == s) continue;
-        at.clear();
-        uint32_t p = 0;
-        const uint8_t* tg = wo.tags.data() + wo.tag_off[i];
-        while (np2k::next_tag(tg, ts, &p, &tag)) {
-            at.push_back(tag);
-            if (!((uint32_t)tag.t_pos <= lq[(size_t)j + 1].end)) break;
+    // every (stream, region) pair with the region inside the stream's span, in the reference's visiting order (streams
+    // ascending, regions from the lowest position up); the strings come from the executor (tag streams in HBM)
+    struct Visit { uint32_t stream; int hi, lo; size_t req0; };   // regions lq[hi] .. lq[lo] (hi >= lo), requests req0 ..
+    std::vector<Visit> visits;
+    std::vector<SubReq> req;
+    {
+        int s = count - 1;
+        for (uint32_t i = 1; i < wo.seq_count; ++i) {
+            const uint32_t ts = wo.aln_t_s[i], te = wo.aln_t_e[i] - 1;   // the reference's aln_t_e of a stream is inclusive
+            while (s >= 0 && lq[(size_t)s].start < ts) --s;
+            int j = s;
+            for (; j >= 0 && lq[(size_t)j].end <= te; --j) {}
+            if (j == s) continue;
+            visits.push_back(Visit{i, s, j + 1, req.size()});
+            for (int k = s; k > j; --k) req.push_back(SubReq{i, lq[(size_t)k].start, lq[(size_t)k].end});
         }
-        for (int k = s; k > j; --k) {
+    }
+    std::vector<uint32_t> off;
+    std::string bases;
+    if (!exec->extract(req, &off, &bases, err)) return -1;
+    // the acceptance rules and the 60-candidate cap depend on the visiting order: replayed here (a region that is full
+    // is skipped whether it sits on top of the range or inside it, ctg_cns.c:838,852)
+    for (const Visit& v : visits) {
+        for (int k = v.hi; k >= v.lo; --k) {
             Region& r = lq[(size_t)k];
             if (r.len >= LQSEQ_MAX_CAN_COUNT) continue;
-            std::string& out = r.seqs[(size_t)r.len].seq;
-            out.clear();
-            for (uint32_t q = r.start - ts; q < at.size() && (uint32_t)at[q].t_pos <= r.end; ++q)
-                if ((uint32_t)at[q].t_pos >= r.start && at[q].q_base != 4) out.push_back(np2k::int_to_base(at[q].q_base));
-            const uint32_t index = (uint32_t)out.size();
+            const size_t rq = v.req0 + (size_t)(v.hi - k);
+            const uint32_t index = off[rq + 1] - off[rq];
             if (kmer ? index != 0 : ((r.l && index) || index > r.end - r.start + 1)) {
-                r.seqs[(size_t)r.len].len = index;
-                r.seqs[(size_t)r.len].order = (uint16_t)r.len;
+                Cand& cd = r.seqs[(size_t)r.len];
+                cd.seq.assign(bases, off[rq], index);
+                cd.len = index;
+                cd.order = (uint16_t)r.len;
                 if (index > r.lqcount) r.lqcount = index;
                 ++r.len;
             } else {
@@ -193,56 +202,68 @@ int collect_candidates(std::vector<Region>& lq, const WindowOutput& wo, bool kme
         }
     }
     if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   tag walk done (t=%.2f)\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6); }
-    int max_aln_length = 0;
-    std::vector<uint16_t> kmers(65536);
+    // a gap cluster's region: the split reads' substrings join the candidates (ctg_cns.c:585-600,687-695,871-879); the
+    // cluster cursor is shared by the regions, so this part stays in region order
     int clusters_i = (int)clusters.size() - 1;
     for (int i = 0; i < count; ++i) {
         Region& r = lq[(size_t)i];
-        if (r.l == 1) {   // a gap cluster's region: the split reads' substrings join the candidates (ctg_cns.c:585-600,687-695,871-879)
-            while (clusters_i >= 0 && !clusters[(size_t)clusters_i].i_m) --clusters_i;
-            if (clusters_i >= 0) {
-                const LqCluster& c = clusters[(size_t)clusters_i--];
-                for (const std::string& s : c.cands) {
-                    if (r.len >= LQSEQ_MAX_CAN_COUNT) break;
-                    Cand& cd = r.seqs[(size_t)r.len];
-                    cd.seq = s;
-                    cd.len = (uint32_t)s.size();
-                    cd.order = (uint16_t)r.len;
-                    if (cd.len > r.lqcount) r.lqcount = cd.len;
-                    ++r.len;
-                }
-            }
+        if (r.l != 1) continue;
+        while (clusters_i >= 0 && !clusters[(size_t)clusters_i].i_m) --clusters_i;
+        if (clusters_i < 0) continue;
+        const LqCluster& c = clusters[(size_t)clusters_i--];
+        for (const std::string& s : c.cands) {
+            if (r.len >= LQSEQ_MAX_CAN_COUNT) break;
+            Cand& cd = r.seqs[(size_t)r.len];
+            cd.seq = s;
+            cd.len = (uint32_t)s.size();
+            cd.order = (uint16_t)r.len;
+            if (cd.len > r.lqcount) r.lqcount = cd.len;
+            ++r.len;
         }
-        if (kmer) {
-            if (!r.len) continue;
-            // identical candidates vote: a dominant (or the only short) string is taken as it is (ctg_cns.c:719-737)
-            int8_t used[LQSEQ_MAX_CAN_COUNT] = {0};
-            int s = 0;
-            for (int j = 0; j < r.len; ++j) {
-                r.seqs[(size_t)j].kscore = 1;
-                if (used[j]) continue;
-                for (int k = j + 1; k < r.len; ++k)
-                    if (r.seqs[(size_t)j].seq == r.seqs[(size_t)k].seq) { used[k] = 1; ++r.seqs[(size_t)j].kscore; }
-                if (r.seqs[(size_t)j].kscore > r.seqs[(size_t)s].kscore ||
-                    (r.seqs[(size_t)j].kscore == r.seqs[(size_t)s].kscore && r.seqs[(size_t)j].len > r.seqs[(size_t)s].len)) s = j;
-            }
-            const Cand& top = r.seqs[(size_t)s];
-            if ((top.kscore > r.len / 3 || top.len < 10 || r.len <= 4) && (top.kscore != 1 || (r.len != 3 && r.len != 4))) {
-                r.sudoseed = top.seq;
-                r.sudoseed_len = top.len;
-                r.len = -2;
-                r.l = 4;
-            } else if (!rank_and_seed(r, kmers, r.len > 4, 1)) {
+    }
+    // ranking + pseudo-seed: the regions are independent of each other
+    std::atomic<int> max_aln{0};
+    np::parallel_for((size_t)count, 16, [&](size_t lo, size_t hi) {
+        if (g_kmers.size() != 65536) { g_kmers.assign(65536, 0); g_touched.clear(); }
+        std::vector<uint16_t>& kmers = g_kmers;
+        int max_aln_length = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            Region& r = lq[i];
+            if (kmer) {
+                if (!r.len) continue;
+                // identical candidates vote: a dominant (or the only short) string is taken as it is (ctg_cns.c:719-737)
+                int8_t used[LQSEQ_MAX_CAN_COUNT] = {0};
+                int s = 0;
+                for (int j = 0; j < r.len; ++j) {
+                    r.seqs[(size_t)j].kscore = 1;
+                    if (used[j]) continue;
+                    for (int k = j + 1; k < r.len; ++k)
+                        if (r.seqs[(size_t)j].seq == r.seqs[(size_t)k].seq) { used[k] = 1; ++r.seqs[(size_t)j].kscore; }
+                    if (r.seqs[(size_t)j].kscore > r.seqs[(size_t)s].kscore ||
+                        (r.seqs[(size_t)j].kscore == r.seqs[(size_t)s].kscore && r.seqs[(size_t)j].len > r.seqs[(size_t)s].len)) s = j;
+                }
+                const Cand& top = r.seqs[(size_t)s];
+                if ((top.kscore > r.len / 3 || top.len < 10 || r.len <= 4) && (top.kscore != 1 || (r.len != 3 && r.len != 4))) {
+                    r.sudoseed = top.seq;
+                    r.sudoseed_len = top.len;
+                    r.len = -2;
+                    r.l = 4;
+                } else if (!rank_and_seed(r, kmers, r.len > 4, 1)) {
+                    continue;
+                }
+                if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
                 continue;
             }
+            if (r.l != 1 && r.l > 1 && r.len > 4) remove_short(r);
+            if (r.len <= 4 || r.len < r.sudoseed_len * 0.5) { r.len = 0; continue; }
+            if (!rank_and_seed(r, kmers, true, 3)) continue;
             if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
-            continue;
         }
-        if (r.l != 1 && r.l > 1 && r.len > 4) remove_short(r);
-        if (r.len <= 4 || r.len < r.sudoseed_len * 0.5) { r.len = 0; continue; }
-        if (!rank_and_seed(r, kmers, true, 3)) continue;
-        if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
-    }
+        int cur = max_aln.load();
+        while (max_aln_length > cur && !max_aln.compare_exchange_weak(cur, max_aln_length)) {}
+    });
+    const int max_aln_length = max_aln.load();
+    if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   rank + poa done (t=%.2f)\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6); }
     return max_aln_length;
 }
 
@@ -274,53 +295,74 @@ void fill_with_lqseq(LinkAln& a, const std::string& seed, int seed_len, const st
     a.len += (size_t)lqseq_len;
 }
 
-// generate_consensus_trimed: builds the 30 concatenated alignments and runs the graph consensus on them
+// generate_consensus_trimed: builds the 30 concatenated alignments and runs the graph consensus on them.
+// The reference appends, per round i and region j, one gapped piece (a helper writes more than it advances, the excess
+// is overwritten by what follows or cut at the end: only the first `advance` characters of a piece survive).  A
+// region's pieces depend on that region's own counter only, so the regions are aligned in parallel and the 30
+// strings are concatenated afterwards.
 bool consensus_of_regions(Exec* exec, std::vector<Region>& lq, uint32_t gap_min_len, bool hifi, std::string* cons_rev, std::string* err) {
     const int count = (int)lq.size();
     LqInput in;
     in.gap_min_len = gap_min_len;
     in.hifi = hifi;
     for (Region& r : lq) r.lqcount = 0;
+    struct Pieces { std::string t[LQSEQ_MAX_COUNT], q[LQSEQ_MAX_COUNT]; };
+    std::vector<Pieces> pieces((size_t)count);
+    np::parallel_for((size_t)count, 8, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+            Region& r = lq[j];
+            if (r.len <= 0) continue;
+            const int seed_len = (int)r.sudoseed_len;
+            for (int i = 0; i < LQSEQ_MAX_COUNT; ++i) {
+                LinkAln a;
+                const bool beyond = (i + r.indexs) > r.indexe;
+                const int query_len = beyond ? seed_len : (int)r.seqs[(size_t)(i + r.indexs)].len;
+                if (beyond) r.lqcount = 0;
+                bool fallback = false;
+                if (beyond || (i && (query_len < seed_len * 0.5 || query_len > seed_len * 1.3))) {
+                    fallback = true;
+                } else {
+                    const Cand& cd = r.seqs[(size_t)(i + r.indexs)];
+                    OndAln al;
+                    ond_align(cd.seq.c_str(), query_len, r.sudoseed.c_str(), seed_len, &al);
+                    if (al.aln_len > 2) {
+                        a.put(al.t_aln_str, al.q_aln_str);
+                        a.len += (size_t)al.aln_len;
+                        int tl = al.aln_t_len, ql = al.aln_q_len;
+                        while (tl < seed_len) a.push(r.sudoseed[(size_t)tl++], '-');
+                        int delta = 0;
+                        while (ql < (int)cd.len && delta++ < 250) a.push('-', cd.seq[(size_t)ql++]);
+                    } else {
+                        fallback = true;
+                    }
+                }
+                if (fallback) {
+                    if ((int)(r.lqcount++) < r.indexe - r.indexs) fill_with_seed(a, seed_len);
+                    else fill_with_lqseq(a, r.sudoseed, seed_len, r.seqs[r.indexs].seq, (int)r.seqs[r.indexs].len);
+                }
+                pieces[j].t[i].assign(a.t, 0, a.len);
+                pieces[j].q[i].assign(a.q, 0, a.len);
+            }
+        }
+    });
     int aligned_linkseq_len = 0;
     for (int i = 0; i < LQSEQ_MAX_COUNT; ++i) {
         aligned_linkseq_len = 0;
-        LinkAln a;
+        std::string t, q;
         for (int j = count - 1; j >= 0; --j) {
-            Region& r = lq[(size_t)j];
+            const Region& r = lq[(size_t)j];
             if (r.len <= 0) continue;
-            const int seed_len = (int)r.sudoseed_len;
-            aligned_linkseq_len += seed_len + 1;
-            a.push('N', 'N');
-            const bool beyond = (i + r.indexs) > r.indexe;
-            const int query_len = beyond ? seed_len : (int)r.seqs[(size_t)(i + r.indexs)].len;
-            if (beyond) r.lqcount = 0;
-            bool fallback = false;
-            if (beyond || (i && (query_len < seed_len * 0.5 || query_len > seed_len * 1.3))) {
-                fallback = true;
-            } else {
-                const Cand& cd = r.seqs[(size_t)(i + r.indexs)];
-                OndAln al;
-                ond_align(cd.seq.c_str(), query_len, r.sudoseed.c_str(), seed_len, &al);
-                if (al.aln_len > 2) {
-                    a.put(al.t_aln_str, al.q_aln_str);
-                    a.len += (size_t)al.aln_len;
-                    int tl = al.aln_t_len, ql = al.aln_q_len;
-                    while (tl < seed_len) a.push(r.sudoseed[(size_t)tl++], '-');
-                    int delta = 0;
-                    while (ql < (int)cd.len && delta++ < 250) a.push('-', cd.seq[(size_t)ql++]);
-                } else {
-                    fallback = true;
-                }
-            }
-            if (fallback) {
-                if ((int)(r.lqcount++) < r.indexe - r.indexs) fill_with_seed(a, seed_len);
-                else fill_with_lqseq(a, r.sudoseed, seed_len, r.seqs[r.indexs].seq, (int)r.seqs[r.indexs].len);
-            }
+            aligned_linkseq_len += (int)r.sudoseed_len + 1;
+            t.push_back('N');
+            q.push_back('N');
+            t += pieces[(size_t)j].t[i];
+            q += pieces[(size_t)j].q[i];
         }
         ++aligned_linkseq_len;
-        a.push('N', 'N');
-        in.t.push_back(a.t.substr(0, a.len));
-        in.q.push_back(a.q.substr(0, a.len));
+        t.push_back('N');
+        q.push_back('N');
+        in.t.push_back(std::move(t));
+        in.q.push_back(std::move(q));
     }
     in.t_len = (uint32_t)aligned_linkseq_len;
     if (getenv("NP2_TIMING")) {
@@ -347,7 +389,7 @@ bool lq_stage(Exec* exec, uint32_t gap_min_len, bool hifi, const std::vector<LqR
     const bool timing = getenv("NP2_TIMING") != nullptr;
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     double t0 = now();
-    collect_candidates(lq, wo, hifi, clusters);
+    if (collect_candidates(exec, lq, wo, hifi, clusters, err) < 0) return false;
     if (timing) { const double t = now(); fprintf(stderr, "[np2 lq] candidates+poa %.2f ms\n", t - t0); t0 = t; }
     // ---- iterate_generate_consensus_trimed (two rounds)
     for (int it = 1; it <= 2; ++it) {

@@ -590,6 +590,16 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
     static uint64_t contig_serial = 0;
     in.contig_serial = ++contig_serial;
     struct RecMeta { uint32_t l_qseq, aligned_q; Gap g; bool want_gap; };
+    const bool timing = getenv("NP2_TIMING") != nullptr;   // wall time of the host stages of every window on stderr
+    timespec lap_t;
+    clock_gettime(CLOCK_MONOTONIC, &lap_t);
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        fprintf(stderr, "[np2 host] %-22s %9.2f ms\n", what, (t.tv_sec - lap_t.tv_sec) * 1e3 + (t.tv_nsec - lap_t.tv_nsec) * 1e-6);
+        lap_t = t;
+    };
     while (e < (int32_t)ref->length) {
         e = s + b > (int32_t)ref->length ? (int32_t)ref->length : s + b;
         const int32_t l = e - s;
@@ -679,11 +689,13 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
         }
         if (it.failed()) np2_die(err.c_str(), ref->n);
         in.recs.seq.resize(in.recs.seq.size() + 8, 0);
+        lap("decode + merge");
         // ---- spans of every candidate, then the order-dependent keep rules (ctg_cns.c:3540-3545)
         std::vector<np2::SpanOut> spans;
         if (!cfg->exec->compute_spans(in, 0, &spans, &err)) np2_die(err.c_str(), ref->n);
         for (const np2::SpanOut& a : spans)
             if (a.bad) { fprintf(stderr, "bamaln error, %s\n", ref->n); exit(1); }   // ctg_cns.c:3534-3537
+        lap("spans");
         {
             // coverage of a column = number of kept streams whose [aln_t_s, aln_t_e) covers it (every draft position of
             // a stream has exactly one non-insertion column), so the caps are decided from the spans alone
@@ -780,7 +792,9 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
             seq_count = np2::sv_update_align_tags(&svw, sup_span, seq_count, s, &in.streams);
             if (getenv("NP2_SV_LOG")) { FILE* lg2 = fopen(getenv("NP2_SV_LOG"), "a"); if (lg2) { fprintf(lg2, "update_align_tags streams %u -> %u\n", sc0, seq_count); fclose(lg2); } }
         }
+        lap("keep rules + structural");
         if (!cfg->exec->run_window(in, &out, &err)) np2_die(err.c_str(), ref->n);
+        lap("window (executor)");
         std::vector<np2::LqCluster> clusters;
         if (sv.brk_g) {
             np2::sv_generate_gapseqs(&svw, out, s);
@@ -815,12 +829,11 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
             LqCtx lx{&out.stat, &out.cons, reads_type, gap_min_ratio1, &clusters};
             for (const LqReg& q : lq_regions(lx)) regs.push_back(np2::LqRegionIn{q.start, q.end, q.l});
         }
+        lap("lq regions");
         if (!regs.empty() || reads_type == np2k::READS_HIFI) {
-            timespec t0, t1;
-            clock_gettime(CLOCK_MONOTONIC, &t0);
             if (!np2::lq_stage(cfg->exec, gap_min_len, reads_type == np2k::READS_HIFI, regs, clusters, out, &out.cons, &err)) np2_die(err.c_str(), ref->n);
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            if (getenv("NP2_TIMING")) fprintf(stderr, "[np2 lq stage] %zu regions, %.2f ms\n", regs.size(), (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
+            if (timing) fprintf(stderr, "[np2 host] %zu low-quality regions\n", regs.size());
+            lap("lq stage");
         }
         WindowCons wc;
         wc.b = out.cons;   // update_consensus_trimed with no regions: a copy (ctg_cns.c:1165-1211)

@@ -194,8 +194,45 @@ class HostExec : public Exec {
             if (key_tpos(cur) == -1) break;
         }
         std::reverse(out->cons.begin(), out->cons.end());
+        win_tags_ = out->tags;
+        win_tag_off_ = out->tag_off;
+        win_ts_ = out->aln_t_s;
         return true;
     }
+
+    // plain walk of the stream (the reference's order: every tag from the stream start up to the last region)
+    bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) override {
+        off->assign(req.size() + 1, 0);
+        bases->clear();
+        std::vector<Tag> at;
+        size_t i = 0;
+        while (i < req.size()) {
+            const uint32_t st = req[i].stream;
+            if (st >= win_tag_off_.size()) { *err = "extract: bad stream"; return false; }
+            size_t k = i;
+            uint32_t last_end = 0;
+            for (; k < req.size() && req[k].stream == st; ++k) last_end = std::max(last_end, req[k].end);
+            at.clear();
+            Tag tag{0, 0, 0};
+            uint32_t p = 0;
+            const uint8_t* tg = win_tags_.data() + win_tag_off_[st];
+            while (next_tag(tg, win_ts_[st], &p, &tag)) {
+                if ((uint32_t)tag.t_pos > last_end) break;
+                at.push_back(tag);
+            }
+            for (; i < k; ++i) {
+                for (const Tag& t : at)
+                    if ((uint32_t)t.t_pos >= req[i].start && (uint32_t)t.t_pos <= req[i].end && t.q_base != 4) bases->push_back(int_to_base(t.q_base));
+                (*off)[i + 1] = (uint32_t)bases->size();
+            }
+        }
+        return true;
+    }
+
+  private:
+    std::vector<uint8_t> win_tags_;
+    std::vector<uint64_t> win_tag_off_;
+    std::vector<uint32_t> win_ts_;
 };
 
 }  // namespace
