@@ -210,7 +210,7 @@ __device__ __forceinline__ void tag_pos(const uint8_t* tg, uint32_t j, uint32_t 
 }
 template <bool kFill>
 __global__ void k2_chunk_links(const ChunkDesc* cd, uint32_t n_chunks, const uint32_t* pre, const uint64_t* tag_off, const uint32_t* aln_t_s,
-                               const uint8_t* tags, uint32_t* col_cnt, const uint32_t* col_off, uint32_t* cursor, LinkObs* obs) {
+                               const uint8_t* tags, uint32_t* col_cnt, const uint32_t* col_off, uint32_t* cursor, LinkObs* obs, uint32_t* obs_col) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const ChunkDesc d = cd[c];
@@ -250,26 +250,80 @@ __global__ void k2_chunk_links(const ChunkDesc* cd, uint32_t n_chunks, const uin
                 LinkObs o;
                 o.pp = pp; o.ppp = ppp; o.rd = d.stream; o.delta = (uint16_t)delta; o.base = (uint8_t)base; o.pad = 0;
                 obs[at] = o;
+                obs_col[at] = (uint32_t)t_pos;
             }
         }
         ppp = pp; pp = key; pp_base = base;
     }
 }
 
-__global__ void k2_build(LinkObs* obs, const uint32_t* col_off, uint32_t n_cols, Entry* entries, Node* nodes, uint32_t* col_nn) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_cols) return;
-    LinkObs* o = obs + col_off[p];
-    const uint32_t n = col_off[p + 1] - col_off[p];
-    // order by (stream, delta): the order update_msa meets the observations in (insertion sort, buckets hold ~depth items)
-    for (uint32_t i = 1; i < n; ++i) {
-        const LinkObs x = o[i];
-        const uint64_t kx = (uint64_t)x.rd << 16 | x.delta;
-        uint32_t j = i;
-        while (j > 0 && ((uint64_t)o[j - 1].rd << 16 | o[j - 1].delta) > kx) { o[j] = o[j - 1]; --j; }
-        o[j] = x;
+// Nodes and entries of every column from its link observations, one lane per OBSERVATION (np2_core.h build_column is
+// the per-column statement of the same result).  Within a node (t_pos, delta, base) every stream appears at most once,
+// so "first seen" order is stream order and nothing has to be sorted: an observation is the first of its node / of its
+// (pp, ppp) pair when no observation of a smaller stream shares it, an entry's slot is the number of pair-firsts before
+// it, a node's region starts after the observations of all smaller nodes, a node's index is the number of distinct
+// smaller nodes.  Pass A leaves (observations in smaller nodes, pair multiplicity, the two "first" flags) per
+// observation, pass B turns the flags of the column into slots and writes.  A column's bucket is a few hundred bytes and
+// neighbouring lanes work on the same bucket, so the loops read through L1.
+__device__ __forceinline__ uint32_t obs_nkey(uint64_t meta) { return (uint32_t)((meta >> 32) & 0xffffu) << 8 | (uint32_t)((meta >> 48) & 0xffu); }
+constexpr uint64_t AUX_NODE_FIRST = 1ull << 48, AUX_PAIR_FIRST = 1ull << 49;
+__global__ __launch_bounds__(256) void k2_build_a(const LinkObs* __restrict__ obs, const uint32_t* __restrict__ obs_col, const uint32_t* __restrict__ col_off,
+                                                  uint32_t total, uint64_t* __restrict__ aux) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t p = obs_col[i];
+    const uint32_t lo = col_off[p], hi = col_off[p + 1];
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(obs);
+    const uint64_t pp = w[3ull * i], ppp = w[3ull * i + 1], meta = w[3ull * i + 2];
+    const uint32_t nk = obs_nkey(meta), rd = (uint32_t)meta;
+    uint32_t less = 0, pairs = 0;
+    bool node_first = true, pair_first = true;
+    for (uint32_t j = lo; j < hi; ++j) {
+        const uint64_t mj = w[3ull * j + 2];
+        const uint32_t nkj = obs_nkey(mj);
+        less += nkj < nk ? 1u : 0u;
+        if (nkj == nk) {
+            const bool before = (uint32_t)mj < rd;
+            node_first = node_first && !before;
+            if (w[3ull * j] == pp && w[3ull * j + 1] == ppp) { ++pairs; pair_first = pair_first && !before; }
+        }
     }
-    col_nn[p] = build_column(o, n, entries + col_off[p], nodes + col_off[p]);
+    aux[i] = (uint64_t)less | (uint64_t)pairs << 24 | (node_first ? AUX_NODE_FIRST : 0ull) | (pair_first ? AUX_PAIR_FIRST : 0ull);
+}
+__global__ __launch_bounds__(256) void k2_build_b(const LinkObs* __restrict__ obs, const uint32_t* __restrict__ obs_col, const uint32_t* __restrict__ col_off,
+                                                  uint32_t total, const uint64_t* __restrict__ aux, Entry* __restrict__ entries, Node* __restrict__ nodes,
+                                                  uint32_t* __restrict__ col_nn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t a = aux[i];
+    if (!(a & AUX_PAIR_FIRST)) return;
+    const uint32_t p = obs_col[i];
+    const uint32_t lo = col_off[p], hi = col_off[p + 1];
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(obs);
+    const uint64_t meta = w[3ull * i + 2];
+    const uint32_t nk = obs_nkey(meta), rd = (uint32_t)meta;
+    const bool node_first = (a & AUX_NODE_FIRST) != 0;
+    uint32_t slot = 0, node_len = 0, node_idx = 0, n_nodes = 0;
+    for (uint32_t j = lo; j < hi; ++j) {
+        const uint64_t aj = aux[j];
+        if (!(aj & (AUX_NODE_FIRST | AUX_PAIR_FIRST))) continue;
+        const uint64_t mj = w[3ull * j + 2];
+        const uint32_t nkj = obs_nkey(mj);
+        if (aj & AUX_NODE_FIRST) { ++n_nodes; node_idx += nkj < nk ? 1u : 0u; }
+        if ((aj & AUX_PAIR_FIRST) && nkj == nk) { ++node_len; slot += (uint32_t)mj < rd ? 1u : 0u; }
+    }
+    const uint32_t start = (uint32_t)a & 0xffffffu;
+    Entry e;
+    e.pp = w[3ull * i];
+    e.ppp = w[3ull * i + 1];
+    e.score = 0;
+    e.link = (uint32_t)(a >> 24) & 0xffffu;   // the reference counts in 16 bits
+    e.node = nk;
+    entries[lo + start + slot] = e;
+    if (node_first) {
+        nodes[lo + node_idx] = Node{nk, start, node_len, 0u};
+        if (node_idx == 0) col_nn[p] = n_nodes;
+    }
 }
 
 __global__ void k2_pack_stat(const uint32_t* coverage, const uint32_t* max_size, const uint32_t* l_ins, const uint32_t* l_del,
@@ -872,7 +926,7 @@ class HipExec : public Exec {
     DevBuf rb_[2][7];   // pos, n_cigar, q0, cigar_off, seq_off, cigar, seq of the two record sets
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
-    DevBuf xreq_, xfirst_, xlen_, xoff_, xout_;
+    DevBuf xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_;
     std::vector<uint32_t> win_first_chunk_, win_n_chunks_;   // chunk range of every stream of the last run_window
     bool win_tags_live_ = false;
     uint64_t contig_serial_ = ~0ull;
@@ -1145,7 +1199,7 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
         k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nsc);
         k2_scan_final<<<nsc, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), n_chunks + 1, sums2_.as<uint32_t>(), chpre_.as<uint32_t>());
         k2_chunk_links<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
-                                                                 alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
+                                                                 alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
     }
     const uint32_t nsb = nblk(n_cols + 1, SCAN_TILE);
     k2_scan_sums<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
@@ -1155,7 +1209,8 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
     HIPOK(hipMemcpyAsync(&total, coloff_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
     if (clk) clk->mark("links.count+scan");
-    if (!obs_.ensure(sizeof(LinkObs) * (size_t)total + 64) || !entries_.ensure(sizeof(Entry) * (size_t)total + 64) ||
+    if (!obs_.ensure(sizeof(LinkObs) * (size_t)total + 64) || !obscol_.ensure(4ull * total + 64) || !obsaux_.ensure(8ull * total + 64) ||
+        !entries_.ensure(sizeof(Entry) * (size_t)total + 64) ||
         !nodes_.ensure(sizeof(Node) * (size_t)total + 64)) {
         *err = "out of device memory (link graph)";
         return false;
@@ -1163,10 +1218,14 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
     if (n_chunks)
         k2_chunk_links<true><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
                                                                 alnts_.as<uint32_t>(), tags_.as<uint8_t>(), nullptr, coloff_.as<uint32_t>(), cursor_.as<uint32_t>(),
-                                                                obs_.as<LinkObs>());
+                                                                obs_.as<LinkObs>(), obscol_.as<uint32_t>());
     if (clk) clk->mark("links.scatter");
-    k2_build<<<nblk(n_cols, 64), 64, 0, q>>>(obs_.as<LinkObs>(), coloff_.as<uint32_t>(), n_cols, entries_.as<Entry>(), nodes_.as<Node>(),
-                                              colnn_.as<uint32_t>());
+    HIPOK(hipMemsetAsync(colnn_.p, 0, 4ull * n_cols, q));
+    if (total) {
+        k2_build_a<<<nblk(total, 256), 256, 0, q>>>(obs_.as<LinkObs>(), obscol_.as<uint32_t>(), coloff_.as<uint32_t>(), total, obsaux_.as<uint64_t>());
+        k2_build_b<<<nblk(total, 256), 256, 0, q>>>(obs_.as<LinkObs>(), obscol_.as<uint32_t>(), coloff_.as<uint32_t>(), total, obsaux_.as<uint64_t>(),
+                                                     entries_.as<Entry>(), nodes_.as<Node>(), colnn_.as<uint32_t>());
+    }
     *total_out = total;
     return true;
 }
