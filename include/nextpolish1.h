@@ -156,6 +156,17 @@ typedef struct {
 } np1_synth_params;
 void np1_synth_defaults(np1_synth_params* p);
 np1_stream* np1_stream_synth(const np1_synth_params* p, const char* contig_name_prefix);
+/* Long-read workload (nextpolish2 path): random drafts + noisy reads of log-normal length with known CIGARs */
+typedef struct {
+    uint64_t seed;
+    int32_t n_contigs;
+    const int32_t* contig_len;
+    double depth, mean_len;
+    double sub, ins, dele;
+    int32_t max_indel;
+    double clip_rate;
+} np1_synth_long_params;
+np1_stream* np1_stream_synth_long(const np1_synth_long_params* p, const char* contig_name_prefix);
 
 /* Device context: one per process per GPU; created lazily AFTER any fork (the reference's callers
  * fork worker pools after config_init, nextpolish1.py:219-223). */

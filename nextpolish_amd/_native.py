@@ -71,6 +71,12 @@ NP1_MAX_STAGES = 16
 _lib = None
 
 
+class SynthLongParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_contigs", C.c_int32), ("contig_len", C.POINTER(C.c_int32)), ("depth", C.c_double),
+                ("mean_len", C.c_double), ("sub", C.c_double), ("ins", C.c_double), ("dele", C.c_double), ("max_indel", C.c_int32),
+                ("clip_rate", C.c_double)]
+
+
 def lib():
     """Loads nextpolish1.so once; raises if it has not been built."""
     global _lib
@@ -108,6 +114,8 @@ def lib():
     L.np1_synth_defaults.restype = None
     L.np1_stream_synth.argtypes = [C.POINTER(SynthParams), C.c_char_p]
     L.np1_stream_synth.restype = C.c_void_p
+    L.np1_stream_synth_long.argtypes = [C.POINTER(SynthLongParams), C.c_char_p]
+    L.np1_stream_synth_long.restype = C.c_void_p
     L.np1_device_count.restype = C.c_int
     L.np1_ctx_create.argtypes = [C.c_int]
     L.np1_ctx_create.restype = C.c_void_p
@@ -218,6 +226,16 @@ class Stream(object):
                 raise TypeError("unknown synth parameter " + k)
             setattr(p, k, val)
         return cls(lib().np1_stream_synth(C.byref(p), prefix.encode()))
+
+    @classmethod
+    def synth_long(cls, contig_len, depth=20.0, mean_len=8000.0, sub=0.03, ins=0.02, dele=0.02, max_indel=4, clip_rate=0.2,
+                   seed=20250117, prefix="ctg"):
+        """Long-read workload of the nextpolish2 path (random drafts, noisy reads with known CIGARs)."""
+        p = SynthLongParams()
+        lens = (C.c_int32 * len(contig_len))(*contig_len)
+        p.seed, p.n_contigs, p.contig_len, p.depth, p.mean_len = seed, len(contig_len), lens, depth, mean_len
+        p.sub, p.ins, p.dele, p.max_indel, p.clip_rate = sub, ins, dele, max_indel, clip_rate
+        return cls(lib().np1_stream_synth_long(C.byref(p), prefix.encode()))
 
     @classmethod
     def from_reads(cls, contigs, reads):

@@ -55,6 +55,7 @@ struct WindowInput {
     int read_type = np2k::READS_ONT;
     RecordSet recs;                     // candidate records in merge order
     RecordSet sup;                      // supplementary alignments (read bases of the primary, CIGAR of the supplementary record)
+    bool want_tags = false;             // copy the tag streams back to the host too (only the structural layer reads them there)
     std::vector<StreamRef> streams;     // the streams to pile up, in order (the seed -- the window against itself -- comes first, implicitly)
 };
 

@@ -588,12 +588,20 @@ __global__ __launch_bounds__(64) void k2_scan_groups(const RunT* rt, uint32_t n_
     if (lane < CUT_K) gt[g].C[lane] = sC[lane];
     if (lane == 0) gt[g].n_out = n_mid;
 }
-// entry vector of every group (x before its first run); group 0 starts from nothing
-__global__ void k2_scan_chain(const RunT* gt, uint32_t n_groups, long long* gx, uint32_t* gn) {
-    if (blockIdx.x || threadIdx.x) return;
+// entry vector of every group (x before its first run).  x_in == nullptr: one block walks all groups, group 0 starts
+// from nothing.  Otherwise block s walks groups [s * SCAN_G, (s + 1) * SCAN_G) starting from x_in[s] (two-level scan:
+// the groups are themselves composed in groups by k2_scan_groups and chained once at the top).
+__global__ void k2_scan_chain(const RunT* gt, uint32_t n_groups, const long long* x_in, const uint32_t* n_in_arr, long long* gx, uint32_t* gn) {
+    if (threadIdx.x) return;
+    const uint32_t s = blockIdx.x;
+    const uint32_t g0 = x_in ? s * SCAN_G : 0u, g1 = x_in ? (g0 + SCAN_G < n_groups ? g0 + SCAN_G : n_groups) : n_groups;
     long long x[CUT_K], xn[CUT_K];
     uint32_t n_in = 0;
-    for (uint32_t g = 0; g < n_groups; ++g) {
+    if (x_in) {
+        n_in = n_in_arr[s];
+        for (uint32_t i = 0; i < n_in; ++i) x[i] = x_in[(uint64_t)s * CUT_K + i];
+    }
+    for (uint32_t g = g0; g < g1; ++g) {
         for (uint32_t i = 0; i < CUT_K; ++i) gx[(uint64_t)g * CUT_K + i] = i < n_in ? x[i] : AC_NEG;
         gn[g] = n_in;
         const uint32_t n_out = gt[g].n_out;
@@ -903,6 +911,8 @@ class HipExec : public Exec {
     ~HipExec() override { if (stream_) (void)hipStreamDestroy(stream_); }
     bool init(std::string* err) {
         HIPOK(hipSetDevice(device_));
+        // workers share the host cores of a GPU (the reference's -p model): waiting for the GPU must not spin on one
+        if (!getenv("NP2_SPIN_SYNC")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
         HIPOK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         return true;
     }
@@ -926,7 +936,7 @@ class HipExec : public Exec {
     DevBuf rb_[2][7];   // pos, n_cigar, q0, cigar_off, seq_off, cigar, seq of the two record sets
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
-    DevBuf xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_;
+    DevBuf xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_;
     std::vector<uint32_t> win_first_chunk_, win_n_chunks_;   // chunk range of every stream of the last run_window
     bool win_tags_live_ = false;
     uint64_t contig_serial_ = ~0ull;
@@ -1063,11 +1073,11 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     if (!solve(mv, l, n_cols, total, in.read_type, &cons_len, &clk, err)) return false;
     out->cons.resize(cons_len);
     out->stat.resize(n_cols);
-    out->tags.resize(tag_bytes);
+    out->tags.resize(in.want_tags ? tag_bytes : 0);
     out->aln_t_e.assign(n_streams, 0);
     if (cons_len) HIPOK(hipMemcpyAsync(out->cons.data(), cons_.p, sizeof(ConsBase) * (size_t)cons_len, hipMemcpyDeviceToHost, q));
     HIPOK(hipMemcpyAsync(out->stat.data(), stat_.p, sizeof(ColStat) * (size_t)n_cols, hipMemcpyDeviceToHost, q));
-    HIPOK(hipMemcpyAsync(out->tags.data(), tags_.p, tag_bytes, hipMemcpyDeviceToHost, q));
+    if (in.want_tags) HIPOK(hipMemcpyAsync(out->tags.data(), tags_.p, tag_bytes, hipMemcpyDeviceToHost, q));
     if (n_streams > 1) HIPOK(hipMemcpyAsync(out->aln_t_e.data() + 1, te_.as<uint32_t>() + 1, 4ull * (n_streams - 1), hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
     clk.mark("download");
@@ -1089,7 +1099,9 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
         *err = "out of device memory (dp runs)";
         return false;
     }
+    if (clk) clk->mark("dp.alloc");
     k2_cut_flags<<<nblk(n_cols / CUT_BLOCK + 1, 64), 64, 0, q>>>(mv, n_cols, l, cutflag_.as<uint32_t>());
+    if (clk) clk->mark("dp.cutflags");
     const uint32_t nsb2 = nblk(n_cols + 1, SCAN_TILE);
     k2_scan_sums<<<nsb2, SCAN_T, 0, q>>>(cutflag_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
     k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb2);
@@ -1097,10 +1109,12 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     uint32_t n_cuts = 0;
     HIPOK(hipMemcpyAsync(&n_cuts, cutpos_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
+    if (clk) clk->mark("dp.cutscan");
     k2_cut_list<<<nblk(n_cols, 256), 256, 0, q>>>(cutflag_.as<uint32_t>(), cutpos_.as<uint32_t>(), n_cols, cuts_.as<uint32_t>());
     uint32_t last_cut = 0xffffffffu;
     if (n_cuts) HIPOK(hipMemcpyAsync(&last_cut, cuts_.as<uint32_t>() + (n_cuts - 1), 4, hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
+    if (clk) clk->mark("dp.cutlist");
     // a window ending on a cut column has no open run behind it
     const uint32_t n_runs = (n_cuts && (int32_t)last_cut == l - 1) ? n_cuts : n_cuts + 1;
     if (!runt_.ensure(sizeof(RunT) * (size_t)n_runs + 64) || !btwalk_.ensure(sizeof(BtWalk) * CUT_K * (size_t)n_runs + 64) ||
@@ -1125,7 +1139,18 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
             return false;
         }
         k2_scan_groups<<<n_groups, 64, 0, q>>>(runt_.as<RunT>(), n_cuts, grpt_.as<RunT>());
-        k2_scan_chain<<<1, 64, 0, q>>>(grpt_.as<RunT>(), n_groups, grpx_.as<long long>(), grpn_.as<uint32_t>());
+        if (n_groups > 2 * SCAN_G) {   // second level: groups of groups, one short chain on top
+            const uint32_t n_super = nblk(n_groups, SCAN_G);
+            if (!grpt2_.ensure(sizeof(RunT) * (size_t)n_super + 64) || !grpx2_.ensure(8ull * CUT_K * n_super + 64) || !grpn2_.ensure(4ull * n_super + 64)) {
+                *err = "out of device memory (dp scan)";
+                return false;
+            }
+            k2_scan_groups<<<n_super, 64, 0, q>>>(grpt_.as<RunT>(), n_groups, grpt2_.as<RunT>());
+            k2_scan_chain<<<1, 64, 0, q>>>(grpt2_.as<RunT>(), n_super, nullptr, nullptr, grpx2_.as<long long>(), grpn2_.as<uint32_t>());
+            k2_scan_chain<<<n_super, 64, 0, q>>>(grpt_.as<RunT>(), n_groups, grpx2_.as<long long>(), grpn2_.as<uint32_t>(), grpx_.as<long long>(), grpn_.as<uint32_t>());
+        } else {
+            k2_scan_chain<<<1, 64, 0, q>>>(grpt_.as<RunT>(), n_groups, nullptr, nullptr, grpx_.as<long long>(), grpn_.as<uint32_t>());
+        }
         k2_scan_apply<<<n_groups, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, runt_.as<RunT>(), grpx_.as<long long>(), grpn_.as<uint32_t>());
     }
     if (clk) clk->mark("dp.scan");

@@ -544,8 +544,7 @@ ctg_cns_cfg* ctg_cns_init(int consensus_w, int reads_type, int split, float ide_
 
 void ctg_cns_destroy(ctg_cns_cfg* cfg) {
     if (!cfg) return;
-    if (cfg->exec && cfg->exec_pid == (int)getpid()) delete cfg->exec;
-    free(cfg);
+    free(cfg);   // the executor (device context + buffers) belongs to the process, not to the configuration
 }
 
 void free_consensus_trimed_data(consensus_trimed_data* d) {
@@ -564,10 +563,18 @@ static void np2_die(const char* what, const char* ctg) {
 extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char* bam_list) {
     g_err.clear();
     if (!cfg->exec || cfg->exec_pid != (int)getpid()) {   // lazily, per process: the caller forks after ctg_cns_init
-        std::string err;
-        cfg->exec = np2::make_exec(&err);
-        cfg->exec_pid = (int)getpid();
-        if (!cfg->exec) { fprintf(stderr, "nextpolish2 (MI355X): %s\n", err.c_str()); exit(1); }
+        // one executor per process, shared by every configuration and kept until the process ends: its buffers in HBM
+        // only ever grow, so a worker allocates for its largest window once
+        static np2::Exec* proc_exec = nullptr;
+        static int proc_exec_pid = 0;
+        if (!proc_exec || proc_exec_pid != (int)getpid()) {
+            std::string err;
+            proc_exec = np2::make_exec(&err);   // (an executor inherited through fork is abandoned, never used or freed)
+            proc_exec_pid = (int)getpid();
+            if (!proc_exec) { fprintf(stderr, "nextpolish2 (MI355X): %s\n", err.c_str()); exit(1); }
+        }
+        cfg->exec = proc_exec;
+        cfg->exec_pid = proc_exec_pid;
     }
     const int reads_type = cfg->reads_type;
     const uint32_t gap_min_len = reads_type != np2k::READS_ONT ? 5 : 3;
@@ -793,6 +800,7 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
             if (getenv("NP2_SV_LOG")) { FILE* lg2 = fopen(getenv("NP2_SV_LOG"), "a"); if (lg2) { fprintf(lg2, "update_align_tags streams %u -> %u\n", sc0, seq_count); fclose(lg2); } }
         }
         lap("keep rules + structural");
+        in.want_tags = sv.brk_g != 0;   // generate_gapseqs walks the split reads' streams on the host
         if (!cfg->exec->run_window(in, &out, &err)) np2_die(err.c_str(), ref->n);
         lap("window (executor)");
         std::vector<np2::LqCluster> clusters;

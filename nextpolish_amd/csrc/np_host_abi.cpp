@@ -117,4 +117,14 @@ np1_stream* np1_stream_synth(const np1_synth_params* p, const char* prefix) {
     return st;
 }
 
+np1_stream* np1_stream_synth_long(const np1_synth_long_params* p, const char* prefix) {
+    np1_stream* st = new np1_stream();
+    if (!np::synth_long_stream(*p, prefix ? prefix : "ctg", &st->s)) {
+        g_err = "synthetic generation failed";
+        delete st;
+        return nullptr;
+    }
+    return st;
+}
+
 }  // extern "C"

@@ -300,6 +300,92 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
     return true;
 }
 
+// Long-read workload of the nextpolish2 path (BASELINE configs[3]): a random draft per contig and noisy reads with
+// log-normal lengths whose CIGAR against the draft follows from the error process (substitution / insertion /
+// deletion per draft base, indel lengths uniform in 1..max_indel, first and last column always a match, optional
+// soft clips).  Reads come out sorted by position.
+bool synth_long_stream(const np_synth_long_params& p, const std::string& prefix, ReadStream* out) {
+    out->clear();
+    out->ctg_off.push_back(0);
+    Rng rng(p.seed);
+    static const char B[4] = {'A', 'C', 'G', 'T'};
+    std::vector<char> seq;
+    std::vector<uint32_t> cig;
+    for (int c = 0; c < p.n_contigs; ++c) {
+        const int32_t L = p.contig_len[c];
+        std::string D((size_t)L, 'A');
+        for (int32_t i = 0; i < L; ++i) D[(size_t)i] = B[rng.below(4)];
+        char nm[64];
+        snprintf(nm, sizeof(nm), "%s%d", prefix.c_str(), c);
+        out->names.push_back(nm);
+        out->ctg_len.push_back(L);
+        out->draft += D;
+        out->ctg_off.push_back((uint32_t)out->draft.size());
+        out->read_begin.push_back(out->n_reads());
+        const uint32_t n_reads = std::max<uint32_t>(1, (uint32_t)(p.depth * L / p.mean_len));
+        std::vector<int32_t> starts(n_reads);
+        for (uint32_t k = 0; k < n_reads; ++k) starts[k] = (int32_t)rng.below((uint32_t)std::max(1, L - 600));
+        std::sort(starts.begin(), starts.end());
+        for (int32_t st : starts) {
+            const int32_t rl = std::max(700, (int32_t)(std::exp(0.5 * rng.normal()) * p.mean_len));
+            const int32_t en = std::min(L, st + rl);
+            seq.clear();
+            cig.clear();
+            auto push = [&](uint32_t op, uint32_t n) {
+                if (!cig.empty() && (cig.back() & 15u) == op) cig.back() += n << 4;
+                else cig.push_back(n << 4 | op);
+            };
+            if (rng.chance(p.clip_rate)) {
+                const uint32_t n = 1 + rng.below(300);
+                push(4, n);
+                for (uint32_t k = 0; k < n; ++k) seq.push_back(B[rng.below(4)]);
+            }
+            int32_t pos = st;
+            while (pos < en) {
+                const bool edge = pos == st || pos >= en - 1;
+                const double x = rng.uni();
+                if (!edge && x < p.dele) {
+                    const int32_t n = std::min<int32_t>(1 + (int32_t)rng.below((uint32_t)p.max_indel), en - 1 - pos);
+                    if (n > 0) { push(2, (uint32_t)n); pos += n; continue; }
+                }
+                if (!edge && x < p.dele + p.ins) {
+                    const uint32_t n = 1 + rng.below((uint32_t)p.max_indel);
+                    push(1, n);
+                    for (uint32_t k = 0; k < n; ++k) seq.push_back(B[rng.below(4)]);
+                }
+                char b = D[(size_t)pos];
+                if (rng.chance(p.sub)) { char o; do { o = B[rng.below(4)]; } while (o == b); b = o; }
+                push(0, 1);
+                seq.push_back(b);
+                ++pos;
+            }
+            if (rng.chance(p.clip_rate)) {
+                const uint32_t n = 1 + rng.below(300);
+                push(4, n);
+                for (uint32_t k = 0; k < n; ++k) seq.push_back(B[rng.below(4)]);
+            }
+            if (cig.size() > 65535) continue;   // the stream keeps n_cigar in 16 bits
+            out->pos.push_back(st);
+            out->ctg.push_back((uint32_t)c);
+            out->flag.push_back((uint16_t)(rng.chance(0.5) ? 16 : 0));
+            out->n_cigar.push_back((uint16_t)cig.size());
+            out->l_qseq.push_back((int32_t)seq.size());
+            out->mapq.push_back(60);
+            out->isize.push_back(0);
+            out->cigar_off.push_back(out->cigar.size());
+            out->seq_off.push_back(out->seq.size());
+            out->qual_off.push_back(0);
+            out->cigar.insert(out->cigar.end(), cig.begin(), cig.end());
+            for (size_t k = 0; k < seq.size(); k += 2) {
+                const uint8_t hi4 = nt16(seq[k]), lo4 = k + 1 < seq.size() ? nt16(seq[k + 1]) : 0;
+                out->seq.push_back((uint8_t)(hi4 << 4 | lo4));
+            }
+        }
+    }
+    out->read_begin.push_back(out->n_reads());
+    return true;
+}
+
 bool write_stream_files(const ReadStream& s, const std::string& fasta, const std::string& bam, int level,
                         std::string* err, const uint8_t* aux_pool, const uint64_t* aux_off) {
     FILE* fp = fopen(fasta.c_str(), "w");

@@ -19,7 +19,10 @@ typedef np1_synth_params np_synth_params;   // field documentation: see the comm
 // softclip_rate (0.005); dup/supp/sec/unmapped_rate (flag mix); lowmapq_rate (mapq in [0,30]);
 // weird_rate (rare CIGAR shapes: H on a primary record, N, =/X ...; 0 for benchmarks); with_qual.
 
+typedef np1_synth_long_params np_synth_long_params;
+
 namespace np {
+bool synth_long_stream(const np_synth_long_params& p, const std::string& contig_name_prefix, ReadStream* out);
 void synth_default_params(np_synth_params* p);
 // Generates the batch.  `contig_name_prefix` + index names the contigs.
 bool synth_stream(const np_synth_params& p, const std::string& contig_name_prefix, ReadStream* out);
