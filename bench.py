@@ -96,6 +96,87 @@ def pmc_traffic(args, kernel_substr):
             "write_size_kib_raw": round(vals["WRITE_SIZE"], 1), "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950)"}, None
 
 
+LGS_WORKER = r"""
+import ctypes as C, os, resource, sys, time
+sys.path.insert(0, %(root)r)
+from nextpolish_amd import nextpolish2 as h
+P = h.load_library(%(lib)r)
+refs = P.read_ref(%(fa)r.encode(), None, 0)
+cfg = P.ctg_cns_init(5000000, 1, 0, 0.8, 0.8, 0.8)
+def once():
+    n = 0
+    for i in range(refs.contents.i):
+        d = P.ctg_cns_core(cfg, C.byref(refs.contents.ref[i]), %(fofn)r.encode())
+        n += sum(int(d.contents.data[k].len) for k in range(d.contents.i_m))
+        P.free_consensus_trimed_data(d)
+    return n
+once()                                    # warm-up: HIP context + buffers in HBM
+open(%(ready)r, "w").close()
+while not os.path.exists(%(go)r): time.sleep(0.002)
+t0 = time.time(); c0 = resource.getrusage(resource.RUSAGE_SELF)
+bp = sum(once() for _ in range(%(calls)d))
+c1 = resource.getrusage(resource.RUSAGE_SELF)
+print(t0, time.time(), bp, c1.ru_utime + c1.ru_stime - c0.ru_utime - c0.ru_stime)
+"""
+
+
+def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref):
+    """Long-read path (BASELINE configs[3] shape: 20x ONT-like reads, lib/nextpolish2.so ctg_cns_core, BAM -> consensus):
+    `workers` worker processes share this rank's GPU (the reference's -p model), each polishes its contig `calls`
+    times after a warm-up; rate = polished bp of all workers / span from the common start to the last end."""
+    import shutil, subprocess, tempfile
+    from nextpolish_amd import _native as nat
+    d = tempfile.mkdtemp(prefix="np2bench_r%d_" % rank)
+    L = int(contig_mb * 1e6)
+    st = nat.Stream.synth_long([L], depth=20.0, seed=9000 + rank)
+    fa, bam, fofn = os.path.join(d, "g.fa"), os.path.join(d, "r.bam"), os.path.join(d, "bam.fofn")
+    st.write_files(fa, bam)
+    st.close()
+    with open(fofn, "w") as f:
+        f.write(bam + "\n")
+    go = os.path.join(d, "go")
+    env = dict(os.environ, NP2_DEVICE=str(local_rank))
+    ps = []
+    for w in range(workers):
+        code = LGS_WORKER % dict(root=ROOT, lib=os.path.join(ROOT, "nextpolish_amd", "lib", "nextpolish2.so"), fa=fa, fofn=fofn,
+                                 ready=os.path.join(d, "ready%d" % w), go=go, calls=calls)
+        ps.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    t_wait = time.time()
+    while not all(os.path.exists(os.path.join(d, "ready%d" % w)) for w in range(workers)):
+        if any(p.poll() not in (None, 0) for p in ps) or time.time() - t_wait > 300:
+            break
+        time.sleep(0.01)
+    open(go, "w").close()
+    outs = [p.communicate() for p in ps]
+    bad = [o[1][-300:] for p, o in zip(ps, outs) if p.returncode != 0]
+    if bad:
+        shutil.rmtree(d, ignore_errors=True)
+        return {"error": bad[0]}
+    rows = [[float(x) for x in o[0].strip().splitlines()[-1].split()] for o in outs]
+    t0, t1 = min(r[0] for r in rows), max(r[1] for r in rows)
+    bp = sum(r[2] for r in rows)
+    res = {"bp": bp, "seconds": t1 - t0, "workers": workers, "calls_per_worker": calls,
+           "s_per_call": round(sum(r[1] - r[0] for r in rows) / (workers * calls), 4),
+           "cpu_s_per_mbp": round(sum(r[3] for r in rows) / (bp / 1e6), 4)}
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "nextpolish2.so")
+    if with_ref and os.path.exists(ref_so):   # the compiled reference, one core, on a 1 Mb contig of the same shape
+        st = nat.Stream.synth_long([1000000], depth=20.0, seed=4242)
+        fa1, bam1, fofn1 = os.path.join(d, "g1.fa"), os.path.join(d, "r1.bam"), os.path.join(d, "bam1.fofn")
+        st.write_files(fa1, bam1)
+        st.close()
+        with open(fofn1, "w") as f:
+            f.write(bam1 + "\n")
+        code = LGS_WORKER % dict(root=ROOT, lib=ref_so, fa=fa1, fofn=fofn1, ready=os.path.join(d, "readyref"), go=go, calls=1)
+        code = code.replace("once()                                    # warm-up", "pass  #")
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+        if p.returncode == 0:
+            r = [float(x) for x in p.stdout.strip().splitlines()[-1].split()]
+            res["cpu_baseline"] = {"value": round(r[2] / 1e6 / (r[1] - r[0]), 4), "unit": "Mbp/s", "cores": 1, "kind": "reference",
+                                   "sample": "1 Mb synthetic contig, 20x ONT-like reads, ctg_cns_core of oracle/_ref/nextpolish2.so, %.1f s" % (r[1] - r[0])}
+    shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +187,10 @@ def main():
     ap.add_argument("--cpu-sample-mb", type=float, default=3.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes (roofline.traffic = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-lgs", action="store_true", help="skip the long-read (nextpolish2) leg")
+    ap.add_argument("--lgs-workers", type=int, default=4, help="worker processes per GPU of the long-read leg")
+    ap.add_argument("--lgs-mb", type=float, default=5.0, help="contig length (Mb) each long-read worker polishes")
+    ap.add_argument("--lgs-calls", type=int, default=2)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,6 +269,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_pmc:
         sub = {"tile": "k_tile3", "vote": "k_vote", "rows": "k_rows"}.get(dom, dom)
         traffic, traffic_note = pmc_traffic(args, sub)
+    lgs = None
+    if not args.no_lgs and not args.pmc_child:
+        if world > 1:
+            dist.barrier()
+        lgs = lgs_leg(rank, local_rank, args.lgs_workers, args.lgs_mb, args.lgs_calls, rank == 0 and world == 1 and not args.no_cpu_baseline)
+        if world > 1:   # whole job: bp of all ranks over the slowest rank's span
+            tt = torch.tensor([float(lgs.get("bp", 0)), float(lgs.get("seconds", 0)), 1.0 if "error" in lgs else 0.0], device="cuda", dtype=torch.float64)
+            bp_sum = tt.clone()
+            dist.all_reduce(bp_sum, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if bp_sum[2].item() == 0:
+                lgs["bp"], lgs["seconds"] = bp_sum[0].item(), tt[1].item()
+            else:
+                lgs.setdefault("error", "a rank failed")
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * draft_bp / 1e6 / (dt / args.steps)
@@ -204,6 +303,17 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_total, "kernel_ms": round(dom_ms, 4),
                          "stage_ms": {k: round(v, 4) for k, v in stage_acc.items()}},
         }
+        if lgs is not None:
+            if "error" in lgs:
+                out["lgs"] = lgs
+            else:
+                out["lgs"] = {"metric": "polished Mbp/s (ctg_cns_core, long reads, sorted BAM in the page cache -> consensus, warm workers)",
+                              "value": round(lgs["bp"] / 1e6 / lgs["seconds"], 3), "unit": "Mbp/s", "n_gpus": world,
+                              "config": {"workload": "%.1f Mb synthetic contig + 20x ONT-like reads (8 kb, 7%% errors) per worker, %d worker processes per GPU, "
+                                                     "%d calls each" % (args.lgs_mb, args.lgs_workers, args.lgs_calls)},
+                              "s_per_call": lgs["s_per_call"], "host_cpu_s_per_mbp": lgs["cpu_s_per_mbp"]}
+                if "cpu_baseline" in lgs:
+                    out["lgs"]["cpu_baseline"] = lgs["cpu_baseline"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(make_stream, int(args.cpu_sample_mb * 1e6), depth, 424242)
         print(json.dumps(out))
