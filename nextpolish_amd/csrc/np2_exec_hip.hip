@@ -29,6 +29,7 @@
 
 #include "../../include/nextpolish2.h"
 #include "np2_exec.h"
+#include "np_threads.h"
 
 namespace np2 {
 namespace {
@@ -54,6 +55,20 @@ struct DevBuf {
     }
     ~DevBuf() { if (p) (void)hipFree(p); }
     template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct PinBuf {   // pinned host staging, grow-only
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap && p) return true;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 4 + 256;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
 };
 
 struct DevStat {   // column statistics as 32-bit device counters (packed to the reference's 16-bit fields afterwards)
@@ -492,12 +507,15 @@ __device__ __forceinline__ uint32_t state_index(const MsaView& mv, int32_t p, co
     return idx;
 }
 
-__global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, long long C, long long* eav, RunT* out) {
-    // one run per WAVE; lanes 0..CUT_K-1 carry the coefficient of one input each, lane CUT_K the constant.  All
-    // lanes run the same loops (wave-uniform control flow); the other lanes idle: the chip has room for thousands of waves.
-    const uint32_t r = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
-    if (r >= n_runs || lane > CUT_K) return;
+__global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, long long C, long long* eav, RunT* out,
+                          uint32_t rpw) {
+    // `rpw` runs per wave (1 or 7), CUT_K + 1 lanes each: lanes 0..CUT_K-1 carry the coefficient of one input, lane CUT_K
+    // the constant.  A run is a serial chain of dependent loads (~1 ms), so what counts is how many runs are in flight:
+    // small graphs (the low-quality re-consensus) take one run per wave (uniform control flow, thousands of waves fit),
+    // whole windows pack 7 runs per wave and let them diverge.
+    const uint32_t r = blockIdx.x * rpw + threadIdx.x / (CUT_K + 1);
+    const uint32_t lane = threadIdx.x % (CUT_K + 1);
+    if (r >= n_runs || threadIdx.x >= rpw * (CUT_K + 1)) return;
     int32_t lo, hi;
     run_bounds(cuts, n_cuts, r, l, &lo, &hi);
     constexpr uint32_t W = CUT_K + 1;
@@ -661,9 +679,9 @@ __device__ __forceinline__ void publish_best(const MsaView& mv, int32_t l, long 
 
 // interior columns of every run (and the last column of the open run)
 template <int TYPE>
-__global__ void k2_run_dp_a(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, DpResult* res) {
-    const uint32_t r = blockIdx.x;
-    if (r >= n_runs || threadIdx.x) return;
+__global__ void k2_run_dp_a(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, DpResult* res, uint32_t rpw) {
+    const uint32_t r = blockIdx.x * rpw + threadIdx.x;   // rpw runs per wave, one lane each (see k2_run_ac)
+    if (r >= n_runs || threadIdx.x >= rpw) return;
     int32_t lo, hi;
     run_bounds(cuts, n_cuts, r, l, &lo, &hi);
     long long gbest = INT64_MIN;
@@ -674,9 +692,9 @@ __global__ void k2_run_dp_a(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, u
 }
 // the cut columns: scores back to the state update_msa left them in, then the literal column
 template <int TYPE>
-__global__ void k2_run_dp_b(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, int32_t l, DpResult* res) {
-    const uint32_t r = blockIdx.x;
-    if (r >= n_cuts || threadIdx.x) return;
+__global__ void k2_run_dp_b(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, int32_t l, DpResult* res, uint32_t rpw) {
+    const uint32_t r = blockIdx.x * rpw + threadIdx.x;
+    if (r >= n_cuts || threadIdx.x >= rpw) return;
     const int32_t p = (int32_t)cuts[r];
     const Node* nd = mv.nodes + mv.col_off[p];
     for (uint32_t j = 0; j < mv.col_nn[p]; ++j)
@@ -937,6 +955,7 @@ class HipExec : public Exec {
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
     DevBuf xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_;
+    PinBuf pin_;
     std::vector<uint32_t> win_first_chunk_, win_n_chunks_;   // chunk range of every stream of the last run_window
     bool win_tags_live_ = false;
     uint64_t contig_serial_ = ~0ull;
@@ -992,7 +1011,6 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     hipStream_t q = stream_;
     const int32_t s = in.s, e = in.e, l = e - s;
     StageClock clk(q);
-    out->cons.clear();
     if (!upload_contig(in, err)) return false;
     // ---- stream layout: seed + the given streams
     std::vector<StreamDesc> sd;
@@ -1075,11 +1093,28 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     out->stat.resize(n_cols);
     out->tags.resize(in.want_tags ? tag_bytes : 0);
     out->aln_t_e.assign(n_streams, 0);
-    if (cons_len) HIPOK(hipMemcpyAsync(out->cons.data(), cons_.p, sizeof(ConsBase) * (size_t)cons_len, hipMemcpyDeviceToHost, q));
-    HIPOK(hipMemcpyAsync(out->stat.data(), stat_.p, sizeof(ColStat) * (size_t)n_cols, hipMemcpyDeviceToHost, q));
+    // consensus + column statistics (8 B per draft base each) come back through a pinned staging buffer (DMA at link
+    // speed) and are copied out by the host thread pool; pageable targets would cost ~4x the time on one core
+    const size_t cons_bytes = sizeof(ConsBase) * (size_t)cons_len, stat_bytes = sizeof(ColStat) * (size_t)n_cols;
+    if (!pin_.ensure(cons_bytes + stat_bytes + 64)) { *err = "out of pinned host memory (window download)"; return false; }
+    uint8_t* pin = static_cast<uint8_t*>(pin_.p);
+    if (cons_len) HIPOK(hipMemcpyAsync(pin, cons_.p, cons_bytes, hipMemcpyDeviceToHost, q));
+    HIPOK(hipMemcpyAsync(pin + cons_bytes, stat_.p, stat_bytes, hipMemcpyDeviceToHost, q));
     if (in.want_tags) HIPOK(hipMemcpyAsync(out->tags.data(), tags_.p, tag_bytes, hipMemcpyDeviceToHost, q));
     if (n_streams > 1) HIPOK(hipMemcpyAsync(out->aln_t_e.data() + 1, te_.as<uint32_t>() + 1, 4ull * (n_streams - 1), hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
+    {
+        uint8_t* dst_c = reinterpret_cast<uint8_t*>(out->cons.data());
+        uint8_t* dst_s = reinterpret_cast<uint8_t*>(out->stat.data());
+        const size_t total_b = cons_bytes + stat_bytes, blk = 1u << 20;
+        np::parallel_for((total_b + blk - 1) / blk, 1, [&](size_t lo, size_t hi) {
+            for (size_t b = lo; b < hi; ++b) {
+                size_t o = b * blk, e = std::min(total_b, o + blk);
+                if (o < cons_bytes) { const size_t e1 = std::min(e, cons_bytes); memcpy(dst_c + o, pin + o, e1 - o); o = e1; }
+                if (o < e) memcpy(dst_s + (o - cons_bytes), pin + o, e - o);
+            }
+        });
+    }
     clk.mark("download");
     clk.flush("window", l, n_streams, total);
     out->aln_t_e[0] = (uint32_t)l;
@@ -1130,7 +1165,9 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     HIPOK(hipMemsetAsync(res_.p, 0, sizeof(DpResult), q));
     if (clk) clk->mark("dp.cuts");
     const long long C = rule == RULE_LQ ? 2 : (rule == READS_HIFI || rule == RULE_LQ_HIFI) ? 4 : 3;
-    k2_run_ac<<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, eav_.as<long long>(), runt_.as<RunT>());
+    const bool dense = n_runs >= 16384 && !getenv("NP2_RUN_PER_WAVE");   // enough runs to fill the chip with several per wave
+    const uint32_t rpw_ac = dense ? 7u : 1u, rpw_dp = dense ? 64u : 1u;
+    k2_run_ac<<<nblk(n_runs, rpw_ac), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, eav_.as<long long>(), runt_.as<RunT>(), rpw_ac);
     if (clk) clk->mark("dp.ac");
     if (n_cuts) {
         const uint32_t n_groups = nblk(n_cuts, SCAN_G);
@@ -1156,8 +1193,8 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     if (clk) clk->mark("dp.scan");
 #define NP2_RUN_DP(T)                                                                                                         \
     do {                                                                                                                      \
-        k2_run_dp_a<T><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>());               \
-        if (n_cuts) k2_run_dp_b<T><<<n_cuts, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, l, res_.as<DpResult>());          \
+        k2_run_dp_a<T><<<nblk(n_runs, rpw_dp), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), rpw_dp);               \
+        if (n_cuts) k2_run_dp_b<T><<<nblk(n_cuts, rpw_dp), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, l, res_.as<DpResult>(), rpw_dp);          \
     } while (0)
     switch (rule) {
         case READS_CLR: NP2_RUN_DP(READS_CLR); break;

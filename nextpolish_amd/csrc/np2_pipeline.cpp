@@ -592,8 +592,10 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
     int32_t s = 0, e = 0;
     std::vector<WindowCons> windows;
     long fra_map = 0, total_map = 0;
-    np2::WindowInput in;
-    np2::WindowOutput out;
+    // window buffers of this process: kept between calls so the ~100 MB of records and ~80 MB of results of a 5 Mb
+    // window are not re-allocated (and page-faulted in again) for every contig
+    static np2::WindowInput in;
+    static np2::WindowOutput out;
     static uint64_t contig_serial = 0;
     in.contig_serial = ++contig_serial;
     struct RecMeta { uint32_t l_qseq, aligned_q; Gap g; bool want_gap; };
@@ -844,7 +846,7 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
             lap("lq stage");
         }
         WindowCons wc;
-        wc.b = out.cons;   // update_consensus_trimed with no regions: a copy (ctg_cns.c:1165-1211)
+        wc.b.swap(out.cons);   // (update_consensus_trimed with no regions would copy, ctg_cns.c:1165-1211)
         wc.uncorrected_len = s;
         windows.push_back(std::move(wc));
         s = e - cfg->s;

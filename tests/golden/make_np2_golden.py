@@ -5,6 +5,7 @@ plus known answers of the 2-bit codec and read_ref.  Run in the build container 
 import ctypes as C
 import hashlib
 import json
+import tempfile
 import os
 import sys
 
@@ -38,6 +39,15 @@ def main():
         fa, fofn, contigs = np2_cases.materialise_sv(kw, qvs)
         res = rb.polish(L, fa, fofn, read_type=rt, split=split)["ctg0"]
         out["sv"][cid] = {"lens": [r[1] for r in res], "md5": [hashlib.md5(r[0].encode()).hexdigest() for r in res]}
+    # a megabase window from the native generator (enough runs for the several-runs-per-wave DP kernels and the two-level scan)
+    from nextpolish_amd import _native as nat
+    d = tempfile.mkdtemp(prefix="np2mb_")
+    st = nat.Stream.synth_long([1200000], depth=20.0, seed=31)
+    st.write_files(os.path.join(d, "g.fa"), os.path.join(d, "r.bam"))
+    st.close()
+    open(os.path.join(d, "bam.fofn"), "w").write(os.path.join(d, "r.bam") + "\n")
+    res = rb.polish(L, os.path.join(d, "g.fa"), os.path.join(d, "bam.fofn"), read_type=1)["ctg0"]
+    out["mb_window"] = {"lens": [r[1] for r in res], "md5": [hashlib.md5(r[0].encode()).hexdigest() for r in res]}
     # codec known answers: pack then unpack through the reference (incl. the non-ACGT spill of bseq.c:91)
     for s in ["ACGT", "AANAA", "GGNGG", "acgtn", "TTTTTTTTTTTTTTTTA", "NACGT", "ACGTACGTACGTACGTN", "RYKM", "A", "TU"]:
         words = (C.c_uint32 * (len(s) // 16 + 1))()

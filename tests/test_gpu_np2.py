@@ -103,3 +103,19 @@ def test_gpu_structural_layer_matches_reference_goldens(cid, tmp_path):
     want = GOLD["sv"][cid]
     assert [p[1] for p in got["ctg0"]] == want["lens"]
     assert [hashlib.md5(p[0].encode()).hexdigest() for p in got["ctg0"]] == want["md5"]
+
+
+def test_gpu_megabase_window_matches_reference_golden(tmp_path):
+    """1.2 Mb window: several DP runs per wave, two-level (max, +) scan, chunked tag/link kernels at scale."""
+    import hashlib
+    from nextpolish_amd import _native as nat
+    st = nat.Stream.synth_long([1200000], depth=20.0, seed=31)
+    fa, bam, fofn = str(tmp_path / "g.fa"), str(tmp_path / "r.bam"), str(tmp_path / "bam.fofn")
+    st.write_files(fa, bam)
+    st.close()
+    open(fofn, "w").write(bam + "\n")
+    got, err = run_polish(PRODUCT_SO, fa, fofn, 1)
+    assert got is not None, err
+    want = GOLD["mb_window"]
+    assert [p[1] for p in got["ctg0"]] == want["lens"]
+    assert [hashlib.md5(p[0].encode()).hexdigest() for p in got["ctg0"]] == want["md5"]

@@ -224,3 +224,19 @@ def test_structural_layer_stage_by_stage_against_reference(model, tmp_path):
         assert got is not None, err
         assert (d / "ref.log").read_text() == (d / "mine.log").read_text(), cid
         assert got == want
+
+
+def test_megabase_window_matches_reference_golden(model, tmp_path):
+    """1.2 Mb window from the native generator through the host model (thread pool over ~4 000 low-quality regions)."""
+    import hashlib
+    from nextpolish_amd import _native as nat
+    st = nat.Stream.synth_long([1200000], depth=20.0, seed=31)
+    fa, bam, fofn = str(tmp_path / "g.fa"), str(tmp_path / "r.bam"), str(tmp_path / "bam.fofn")
+    st.write_files(fa, bam)
+    st.close()
+    open(fofn, "w").write(bam + "\n")
+    got, err = run_polish(model, fa, fofn, 1)
+    assert got is not None, err
+    want = GOLD["mb_window"]
+    assert [p[1] for p in got["ctg0"]] == want["lens"]
+    assert [hashlib.md5(p[0].encode()).hexdigest() for p in got["ctg0"]] == want["md5"]
