@@ -107,8 +107,9 @@ __global__ void k2_span(DevRecs R, uint32_t n, const char* contig_seq, int32_t s
     out[i] = o;
 }
 
-// the seed stream: window against itself, two columns per byte; coverage +1 on every column
-__global__ void k2_seed_tags(const char* contig_seq, int32_t s, uint32_t l, uint8_t* tags, uint32_t* coverage, uint32_t* max_size) {
+// the seed stream: window against itself, two columns per byte (its coverage +1 and max_size 1 on every column are
+// added by k2_pack_stat)
+__global__ void k2_seed_tags(const char* contig_seq, int32_t s, uint32_t l, uint8_t* tags) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;   // tag byte
     const uint32_t nbytes = (l + 1) / 2 + 1;
     if (b >= nbytes) return;
@@ -118,8 +119,6 @@ __global__ void k2_seed_tags(const char* contig_seq, int32_t s, uint32_t l, uint
         uint32_t nib;
         if (p < l) {
             nib = base_to_int((unsigned char)contig_seq[s + (int32_t)p]);
-            atomicAdd(&coverage[p], 1u);
-            atomicMax(&max_size[p], 1u);
         } else {
             nib = 15;   // terminator (the reference sets the trailing nibble(s) of the last byte(s) to 15)
         }
@@ -179,20 +178,85 @@ __global__ void k2_tag_ckpt(const StreamDesc* sd, uint32_t n_streams, const uint
     }
 }
 
+// get_align_tags on one chunk of a record's kept columns, by CIGAR op (np2_core.h emit_tags_range is the per-column
+// statement of the same result).  Eight tags are packed per 32-bit store (a chunk owns whole words of the zeroed tag
+// area).  Column statistics: coverage is NOT counted here -- a stream covers a contiguous range of positions, so it is
+// +1/-1 into a difference array (k2_cov_diff) and a scan; max_size only moves on insertion columns (the seed already
+// holds 1 everywhere); l_ins / l_del are counted where they happen.  The one exception to "coverage = streams over the
+// position" is a read base with the IUPAC code M, which the reference's marker test skips (ctg_cns.c:1232): fixed up
+// in the difference array.
 __global__ void k2_tags_chunk(const TagChunk* tc, uint32_t n_chunks, const TagCkpt* ck, const StreamDesc* sd, DevRecs R0, DevRecs R1,
-                              const char* contig_seq, uint32_t gap_min_len, uint8_t* tags, DevStat st, uint32_t* te_out) {
+                              uint32_t gap_min_len, uint8_t* tags, DevStat st, uint32_t* cov_diff, uint32_t* te_out) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const TagChunk ch = tc[c];
     const StreamDesc d = sd[ch.stream];
     const TagCkpt t = ck[c];
     const ReadView rv = (d.set ? R1 : R0).view(d.read);
-    ColIter f;
-    f.r = &rv; f.rf = contig_seq; f.op_i = t.op_i; f.in_op = t.in_op; f.rfi = t.rfi; f.rdi = t.rdi;
-    EmitState es{t.te_before, t.delta_before, t.delta_before >= gap_min_len ? 1u : 0u};
-    DevStatSink sink{st};
-    emit_tags_range(f, ch.c0, ch.n, &es, ch.last != 0, gap_min_len, tags + d.tag_off, sink);
-    if (ch.last) te_out[ch.stream] = es.te + 1;
+    // base_to_int(nt16_char(code)) for the 16 BAM base codes "=ACMGRSVTWYHKDBN": A0 T1 G2 C3 N5 M6, everything else 4
+    constexpr uint64_t LUT = 0x5444444144426304ull;
+    uint32_t op_i = t.op_i, in_op = t.in_op, rdi = t.rdi;
+    uint32_t te = t.te_before, delta = t.delta_before, l = t.delta_before >= gap_min_len ? 1u : 0u;
+    uint32_t* tw = reinterpret_cast<uint32_t*>(tags + d.tag_off) + (ch.c0 >> 3);
+    uint32_t word = 0, nn = 0, left = ch.n;
+    auto put = [&](uint32_t b) {
+        word |= b << (((nn >> 1) << 3) + ((nn & 1u) ? 0u : 4u));
+        if (++nn == 8) { *tw++ = word; word = 0; nn = 0; }
+    };
+    while (left) {
+        const uint32_t cg = rv.cigar[op_i];
+        const uint32_t op = cg & 0xfu, n = cg >> 4;
+        if (op > 2 || n == 0) {   // no columns: clips move the query cursor
+            if (op == 4 || op == 5) rdi += n;
+            ++op_i;
+            in_op = 0;
+            continue;
+        }
+        const uint32_t take = n - in_op < left ? n - in_op : left;
+        if (op == 0) {
+            for (uint32_t k = 0; k < take; ++k, ++rdi) {
+                const uint32_t code = (uint32_t)(rv.seq[rdi >> 1] >> ((~rdi & 1u) << 2)) & 15u;
+                const uint32_t b = (uint32_t)(LUT >> (code << 2)) & 15u;
+                ++te;
+                if (b == 6) { atomicSub(&cov_diff[te], 1u); atomicAdd(&cov_diff[te + 1], 1u); }
+                put(b);
+            }
+            l = 0;
+            delta = 0;
+        } else if (op == 1) {
+            for (uint32_t k = 0; k < take; ++k, ++rdi) {
+                const uint32_t code = (uint32_t)(rv.seq[rdi >> 1] >> ((~rdi & 1u) << 2)) & 15u;
+                ++delta;
+                atomicMax(&st.max_size[te], delta + 1);
+                if (delta >= gap_min_len && !l) { atomicAdd(&st.l_ins[te], 1u); l = 1; }
+                put(((uint32_t)(LUT >> (code << 2)) & 15u) | 8u);
+            }
+        } else {
+            for (uint32_t k = 0; k < take; ++k) {
+                ++te;
+                atomicAdd(&st.l_del[te], 1u);
+                put(4u);
+            }
+            l = 0;
+            delta = 0;
+        }
+        in_op += take;
+        left -= take;
+        if (in_op >= n) { in_op = 0; ++op_i; }
+    }
+    if (ch.last) {
+        put(15u);
+        if (!((ch.c0 + ch.n) & 1u)) put(15u);   // the reference fills the whole next byte when the stream ends on a byte boundary
+        te_out[ch.stream] = te + 1;
+    }
+    if (nn) *tw = word;
+}
+// coverage of the reads as a difference array: +1 where a stream starts, -1 behind its last position
+__global__ void k2_cov_diff(const StreamDesc* sd, uint32_t n_streams, int32_t s, const uint32_t* te, uint32_t* cov_diff) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_streams) return;
+    const uint32_t ts = sd[k].aln_t_s - (uint32_t)s;
+    if (te[k] > ts) { atomicAdd(&cov_diff[ts], 1u); atomicSub(&cov_diff[te[k]], 1u); }
 }
 
 // ---- link observations from the tag streams, chunk-parallel ----------------------------------------------------
@@ -341,13 +405,20 @@ __global__ __launch_bounds__(256) void k2_build_b(const LinkObs* __restrict__ ob
     }
 }
 
+// seed_len > 0 (a window): coverage = seed + scanned difference array of the reads (cov_pre exclusive prefix, cov_diff the
+// array itself), max_size at least the seed's 1; seed_len == 0 (concatenated low-quality regions): counted directly
 __global__ void k2_pack_stat(const uint32_t* coverage, const uint32_t* max_size, const uint32_t* l_ins, const uint32_t* l_del,
-                             uint32_t n, ColStat* st) {
+                             uint32_t n, ColStat* st, uint32_t seed_len, const uint32_t* cov_pre, const uint32_t* cov_diff) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     ColStat c;
-    c.coverage = (uint16_t)coverage[p];
-    c.max_size = (uint16_t)max_size[p];
+    uint32_t cov = coverage[p], ms = max_size[p];
+    if (seed_len) {
+        cov = cov_pre[p] + cov_diff[p] + (p < seed_len ? 1u : 0u);
+        if (p < seed_len && ms < 1u) ms = 1u;
+    }
+    c.coverage = (uint16_t)cov;
+    c.max_size = (uint16_t)ms;
     c.l_ins = (uint16_t)l_ins[p];
     c.l_del = (uint16_t)l_del[p];
     st[p] = c;
@@ -954,7 +1025,7 @@ class HipExec : public Exec {
     DevBuf rb_[2][7];   // pos, n_cigar, q0, cigar_off, seq_off, cigar, seq of the two record sets
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
-    DevBuf xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_;
+    DevBuf xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
     PinBuf pin_;
     std::vector<uint32_t> win_first_chunk_, win_n_chunks_;   // chunk range of every stream of the last run_window
     bool win_tags_live_ = false;
@@ -1042,7 +1113,9 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     HIPOK(hipMemsetAsync(colcnt_.p, 0, 4ull * (n_cols + 2), q));
     HIPOK(hipMemsetAsync(cursor_.p, 0, 4ull * (n_cols + 2), q));
     DevStat st{cnt4_.as<uint32_t>(), cnt4_.as<uint32_t>() + n_cols, cnt4_.as<uint32_t>() + 2ull * n_cols, cnt4_.as<uint32_t>() + 3ull * n_cols};
-    k2_seed_tags<<<nblk(((uint64_t)l + 1) / 2 + 1, 256), 256, 0, q>>>(contig_.as<char>(), s, (uint32_t)l, tags_.as<uint8_t>(), st.coverage, st.max_size);
+    if (!covdiff_.ensure(4ull * (n_cols + 4)) || !covpre_.ensure(4ull * (n_cols + 4))) { *err = "out of device memory (window)"; return false; }
+    HIPOK(hipMemsetAsync(covdiff_.p, 0, 4ull * (n_cols + 4), q));
+    k2_seed_tags<<<nblk(((uint64_t)l + 1) / 2 + 1, 256), 256, 0, q>>>(contig_.as<char>(), s, (uint32_t)l, tags_.as<uint8_t>());
     if (!sd.empty()) {
         HIPOK(hipMemcpyAsync(sd_.p, sd.data(), sizeof(StreamDesc) * sd.size(), hipMemcpyHostToDevice, q));
         // chunk list (host, O(records)); empty streams still need their terminator and end position
@@ -1071,10 +1144,18 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
             k2_tag_ckpt<<<nblk(sd.size(), 64), 64, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), tchoff_.as<uint32_t>(), dev_set(0), dev_set(1), s,
                                                            tckpt_.as<TagCkpt>());
             k2_tags_chunk<<<nblk(n_tchunks, 64), 64, 0, q>>>(tchunks_.as<TagChunk>(), n_tchunks, tckpt_.as<TagCkpt>(), sd_.as<StreamDesc>(), dev_set(0), dev_set(1),
-                                                             contig_.as<char>(), in.gap_min_len, tags_.as<uint8_t>(), st, te_.as<uint32_t>() + 1);
+                                                             in.gap_min_len, tags_.as<uint8_t>(), st, covdiff_.as<uint32_t>(), te_.as<uint32_t>() + 1);
         }
+        k2_cov_diff<<<nblk(sd.size(), 256), 256, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), s, te_.as<uint32_t>() + 1, covdiff_.as<uint32_t>());
     }
-    k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>());
+    {
+        const uint32_t nsb = nblk(n_cols + 1, SCAN_TILE);
+        k2_scan_sums<<<nsb, SCAN_T, 0, q>>>(covdiff_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
+        k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb);
+        k2_scan_final<<<nsb, SCAN_T, 0, q>>>(covdiff_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), covpre_.as<uint32_t>());
+    }
+    k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>(), (uint32_t)l, covpre_.as<uint32_t>(),
+                                                    covdiff_.as<uint32_t>());
     HIPOK(hipMemcpyAsync(tagoff_.p, out->tag_off.data(), 8ull * n_streams, hipMemcpyHostToDevice, q));
     HIPOK(hipMemcpyAsync(alnts_.p, out->aln_t_s.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
     clk.mark("tags");
@@ -1390,7 +1471,7 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
         k2_tags_str_chunk<<<nblk(nsc, 64), 64, 0, q>>>(tchunks_.as<StrChunk>(), nsc, chpre_.as<uint32_t>(), strpool_.as<char>(), stroff_.as<uint64_t>(),
                                                        in.gap_min_len, tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), st, te_.as<uint32_t>());
     }
-    k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>());
+    k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>(), 0u, nullptr, nullptr);
     uint32_t total = 0;
     if (!build_graph(str_len, n_cols, &total, err)) return false;
     MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
