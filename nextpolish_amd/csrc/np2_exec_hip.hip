@@ -184,9 +184,10 @@ __global__ void k2_tag_ckpt(const StreamDesc* sd, uint32_t n_streams, const uint
 // +1/-1 into a difference array (k2_cov_diff) and a scan; max_size only moves on insertion columns (the seed already
 // holds 1 everywhere); l_ins / l_del are counted where they happen.  The one exception to "coverage = streams over the
 // position" is a read base with the IUPAC code M, which the reference's marker test skips (ctg_cns.c:1232): fixed up
-// in the difference array.
+// in the difference array; such a base also drops two link observations, so *m_seen sends the link count back to
+// its exact pass (k2_chunk_links<false>) instead of tags-per-position = coverage + insertion tags.
 __global__ void k2_tags_chunk(const TagChunk* tc, uint32_t n_chunks, const TagCkpt* ck, const StreamDesc* sd, DevRecs R0, DevRecs R1,
-                              uint32_t gap_min_len, uint8_t* tags, DevStat st, uint32_t* cov_diff, uint32_t* te_out) {
+                              uint32_t gap_min_len, uint8_t* tags, DevStat st, uint32_t* cov_diff, uint32_t* m_seen, uint32_t* te_out) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const TagChunk ch = tc[c];
@@ -218,14 +219,16 @@ __global__ void k2_tags_chunk(const TagChunk* tc, uint32_t n_chunks, const TagCk
                 const uint32_t code = (uint32_t)(rv.seq[rdi >> 1] >> ((~rdi & 1u) << 2)) & 15u;
                 const uint32_t b = (uint32_t)(LUT >> (code << 2)) & 15u;
                 ++te;
-                if (b == 6) { atomicSub(&cov_diff[te], 1u); atomicAdd(&cov_diff[te + 1], 1u); }
+                if (b == 6) { atomicSub(&cov_diff[te], 1u); atomicAdd(&cov_diff[te + 1], 1u); *m_seen = 1u; }
                 put(b);
             }
             l = 0;
             delta = 0;
         } else if (op == 1) {
+            atomicAdd(&st.coverage[te], take);   // (windows do not count coverage here: the array holds the insertion tags per position)
             for (uint32_t k = 0; k < take; ++k, ++rdi) {
                 const uint32_t code = (uint32_t)(rv.seq[rdi >> 1] >> ((~rdi & 1u) << 2)) & 15u;
+                if (code == 3u) *m_seen = 1u;
                 ++delta;
                 atomicMax(&st.max_size[te], delta + 1);
                 if (delta >= gap_min_len && !l) { atomicAdd(&st.l_ins[te], 1u); l = 1; }
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256) void k2_build_b(const LinkObs* __restrict__ ob
 // seed_len > 0 (a window): coverage = seed + scanned difference array of the reads (cov_pre exclusive prefix, cov_diff the
 // array itself), max_size at least the seed's 1; seed_len == 0 (concatenated low-quality regions): counted directly
 __global__ void k2_pack_stat(const uint32_t* coverage, const uint32_t* max_size, const uint32_t* l_ins, const uint32_t* l_del,
-                             uint32_t n, ColStat* st, uint32_t seed_len, const uint32_t* cov_pre, const uint32_t* cov_diff) {
+                             uint32_t n, ColStat* st, uint32_t seed_len, const uint32_t* cov_pre, const uint32_t* cov_diff, uint32_t* col_cnt) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     ColStat c;
@@ -416,6 +419,7 @@ __global__ void k2_pack_stat(const uint32_t* coverage, const uint32_t* max_size,
     if (seed_len) {
         cov = cov_pre[p] + cov_diff[p] + (p < seed_len ? 1u : 0u);
         if (p < seed_len && ms < 1u) ms = 1u;
+        col_cnt[p] = cov + coverage[p];   // link observations of the column = its tags: one per covering stream + the insertion tags
     }
     c.coverage = (uint16_t)cov;
     c.max_size = (uint16_t)ms;
@@ -1012,7 +1016,9 @@ class HipExec : public Exec {
 
   private:
     // link observations -> column buckets -> nodes/entries for n_streams tag streams over n_cols columns; *total = entries
-    bool build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, uint32_t* total, std::string* err, struct StageClock* clk = nullptr);
+    // m_seen != nullptr: colcnt_ already holds the tags per column (valid unless *m_seen, a device flag, is set)
+    bool build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, uint32_t* total, std::string* err, struct StageClock* clk = nullptr,
+                     const uint32_t* m_seen = nullptr);
     bool solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t total, int rule, uint32_t* cons_len, struct StageClock* clk, std::string* err);
     int device_;
     hipStream_t stream_ = nullptr;
@@ -1144,7 +1150,8 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
             k2_tag_ckpt<<<nblk(sd.size(), 64), 64, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), tchoff_.as<uint32_t>(), dev_set(0), dev_set(1), s,
                                                            tckpt_.as<TagCkpt>());
             k2_tags_chunk<<<nblk(n_tchunks, 64), 64, 0, q>>>(tchunks_.as<TagChunk>(), n_tchunks, tckpt_.as<TagCkpt>(), sd_.as<StreamDesc>(), dev_set(0), dev_set(1),
-                                                             in.gap_min_len, tags_.as<uint8_t>(), st, covdiff_.as<uint32_t>(), te_.as<uint32_t>() + 1);
+                                                             in.gap_min_len, tags_.as<uint8_t>(), st, covdiff_.as<uint32_t>(), covdiff_.as<uint32_t>() + n_cols + 3,
+                                                             te_.as<uint32_t>() + 1);
         }
         k2_cov_diff<<<nblk(sd.size(), 256), 256, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), s, te_.as<uint32_t>() + 1, covdiff_.as<uint32_t>());
     }
@@ -1155,7 +1162,7 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
         k2_scan_final<<<nsb, SCAN_T, 0, q>>>(covdiff_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), covpre_.as<uint32_t>());
     }
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>(), (uint32_t)l, covpre_.as<uint32_t>(),
-                                                    covdiff_.as<uint32_t>());
+                                                    covdiff_.as<uint32_t>(), colcnt_.as<uint32_t>());
     HIPOK(hipMemcpyAsync(tagoff_.p, out->tag_off.data(), 8ull * n_streams, hipMemcpyHostToDevice, q));
     HIPOK(hipMemcpyAsync(alnts_.p, out->aln_t_s.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
     clk.mark("tags");
@@ -1163,7 +1170,7 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     std::vector<uint32_t> n_tags;
     n_tags.push_back((uint32_t)l);
     for (const StreamDesc& d : sd) n_tags.push_back(d.aln_len);
-    if (!build_graph(n_tags, n_cols, &total, err, &clk)) return false;
+    if (!build_graph(n_tags, n_cols, &total, err, &clk, covdiff_.as<uint32_t>() + n_cols + 3)) return false;
     if (!cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) { *err = "out of device memory (consensus)"; return false; }
     clk.mark("build");
     // ---- chain DP + backtrace
@@ -1318,7 +1325,8 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     return true;
 }
 
-bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, uint32_t* total_out, std::string* err, StageClock* clk) {
+bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, uint32_t* total_out, std::string* err, StageClock* clk,
+                          const uint32_t* m_seen) {
     hipStream_t q = stream_;
     // ---- chunk list (host: O(streams)), non-insertion tag counts per chunk, scan
     std::vector<ChunkDesc> cd;
@@ -1341,16 +1349,27 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
         k2_scan_sums<<<nsc, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), n_chunks + 1, sums2_.as<uint32_t>());
         k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nsc);
         k2_scan_final<<<nsc, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), n_chunks + 1, sums2_.as<uint32_t>(), chpre_.as<uint32_t>());
-        k2_chunk_links<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
-                                                                 alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
+        if (!m_seen)
+            k2_chunk_links<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
+                                                                     alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
     }
     const uint32_t nsb = nblk(n_cols + 1, SCAN_TILE);
-    k2_scan_sums<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
-    k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb);
-    k2_scan_final<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), coloff_.as<uint32_t>());
     uint32_t total = 0;
-    HIPOK(hipMemcpyAsync(&total, coloff_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
-    HIPOK(hipStreamSynchronize(q));
+    for (int pass = 0; pass < 2; ++pass) {
+        k2_scan_sums<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
+        k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb);
+        k2_scan_final<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), coloff_.as<uint32_t>());
+        uint32_t flag = 0;
+        HIPOK(hipMemcpyAsync(&total, coloff_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
+        if (m_seen && pass == 0) HIPOK(hipMemcpyAsync(&flag, m_seen, 4, hipMemcpyDeviceToHost, q));
+        HIPOK(hipStreamSynchronize(q));
+        if (!flag) break;
+        // a read carries the base code M: count the observations exactly (rare)
+        HIPOK(hipMemsetAsync(colcnt_.p, 0, 4ull * (n_cols + 2), q));
+        if (n_chunks)
+            k2_chunk_links<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
+                                                                     alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
+    }
     if (clk) clk->mark("links.count+scan");
     if (!obs_.ensure(sizeof(LinkObs) * (size_t)total + 64) || !obscol_.ensure(4ull * total + 64) || !obsaux_.ensure(8ull * total + 64) ||
         !entries_.ensure(sizeof(Entry) * (size_t)total + 64) ||
@@ -1471,7 +1490,7 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
         k2_tags_str_chunk<<<nblk(nsc, 64), 64, 0, q>>>(tchunks_.as<StrChunk>(), nsc, chpre_.as<uint32_t>(), strpool_.as<char>(), stroff_.as<uint64_t>(),
                                                        in.gap_min_len, tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), st, te_.as<uint32_t>());
     }
-    k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>(), 0u, nullptr, nullptr);
+    k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>(), 0u, nullptr, nullptr, nullptr);
     uint32_t total = 0;
     if (!build_graph(str_len, n_cols, &total, err)) return false;
     MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};

@@ -4,7 +4,7 @@ import random
 
 
 def make_case(seed, contig_lens=(20000,), depth=20, mean_len=4000, sub=0.03, ins=0.02, dele=0.02, max_indel=2,
-              clip_rate=0.2, lower=False, n_rate=0.0, name_prefix="ctg"):
+              clip_rate=0.2, lower=False, n_rate=0.0, name_prefix="ctg", iupac_rate=0.0):
     rng = random.Random(seed)
     contigs, reads = [], []
     for ci, L in enumerate(contig_lens):
@@ -58,6 +58,14 @@ def make_case(seed, contig_lens=(20000,), depth=20, mean_len=4000, sub=0.03, ins
                 cig = cig + [("S", n)]
                 seq = seq + [rng.choice("ACGT") for _ in range(n)]
             reads.append(dict(ctg=ci, pos=st, flag=16 if rng.random() < 0.5 else 0, mapq=60, cigar=cig, seq="".join(seq)))
+    if iupac_rate:   # ambiguity codes in the reads (M is also the reference's internal marker character); own generator,
+        rng2 = random.Random(seed * 7919 + 1)   # so the cases without them keep their sequences
+        for r in reads:
+            s = list(r["seq"])
+            for i in range(len(s)):
+                if rng2.random() < iupac_rate:
+                    s[i] = rng2.choice("MMMRN")
+            r["seq"] = "".join(s)
     return contigs, reads
 
 
