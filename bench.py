@@ -136,6 +136,8 @@ def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref):
         f.write(bam + "\n")
     go = os.path.join(d, "go")
     env = dict(os.environ, NP2_DEVICE=str(local_rank))
+    env.setdefault("NP_HOST_THREADS", "4")   # several workers share the host cores of one GPU
+    env.setdefault("NP_IO_THREADS", "4")
     ps = []
     for w in range(workers):
         code = LGS_WORKER % dict(root=ROOT, lib=os.path.join(ROOT, "nextpolish_amd", "lib", "nextpolish2.so"), fa=fa, fofn=fofn,
@@ -188,7 +190,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes (roofline.traffic = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-lgs", action="store_true", help="skip the long-read (nextpolish2) leg")
-    ap.add_argument("--lgs-workers", type=int, default=4, help="worker processes per GPU of the long-read leg")
+    ap.add_argument("--lgs-workers", type=int, default=8, help="worker processes per GPU of the long-read leg")
     ap.add_argument("--lgs-mb", type=float, default=5.0, help="contig length (Mb) each long-read worker polishes")
     ap.add_argument("--lgs-calls", type=int, default=2)
     args = ap.parse_args()
@@ -310,7 +312,7 @@ def main():
                 out["lgs"] = {"metric": "polished Mbp/s (ctg_cns_core, long reads, sorted BAM in the page cache -> consensus, warm workers)",
                               "value": round(lgs["bp"] / 1e6 / lgs["seconds"], 3), "unit": "Mbp/s", "n_gpus": world,
                               "config": {"workload": "%.1f Mb synthetic contig + 20x ONT-like reads (8 kb, 7%% errors) per worker, %d worker processes per GPU, "
-                                                     "%d calls each" % (args.lgs_mb, args.lgs_workers, args.lgs_calls)},
+                                                     "%d calls each, %s host threads per worker" % (args.lgs_mb, args.lgs_workers, args.lgs_calls, os.environ.get("NP_HOST_THREADS", "4"))},
                               "s_per_call": lgs["s_per_call"], "host_cpu_s_per_mbp": lgs["cpu_s_per_mbp"]}
                 if "cpu_baseline" in lgs:
                     out["lgs"]["cpu_baseline"] = lgs["cpu_baseline"]
