@@ -411,6 +411,15 @@ struct MsaView {
 NP2_HD Node* find_node(const MsaView& m, int32_t t_pos, uint32_t key) {
     Node* nd = m.nodes + m.col_off[t_pos];
     const uint32_t nn = m.col_nn[t_pos];
+    if (nn > 16) {   // a column under a long insertion holds thousands of nodes, sorted by key = (delta, base)
+        uint32_t lo = 0, hi = nn;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (nd[mid].key < key) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo < nn && nd[lo].key == key ? nd + lo : nullptr;
+    }
     for (uint32_t j = 0; j < nn; ++j)
         if (nd[j].key == key) return nd + j;
     return nullptr;

@@ -23,6 +23,8 @@ CASES = [
     # ambiguity codes in the READS: M is also the marker character of the reference's low-quality concatenation, so an
     # M base is skipped by the coverage count and drops its own and the next link (ctg_cns.c:1232,334)
     ("ont_reads_with_iupac_codes", dict(seed=52, contig_lens=(15000, 4000), depth=25, max_indel=4, iupac_rate=0.002), 1),
+    # single reads carrying insertions of 300-2500 bases: columns with thousands of nodes (real ONT data has them)
+    ("ont_long_insertions", dict(seed=71, contig_lens=(40000,), depth=25, max_indel=4, mean_len=8000, long_ins_rate=2e-5), 1),
     ("hifi_reads_with_iupac_codes", dict(seed=53, contig_lens=(15000,), depth=25, sub=0.002, ins=0.002, dele=0.002, mean_len=9000, iupac_rate=0.001), 3),
 ]
 

@@ -4,8 +4,9 @@ import random
 
 
 def make_case(seed, contig_lens=(20000,), depth=20, mean_len=4000, sub=0.03, ins=0.02, dele=0.02, max_indel=2,
-              clip_rate=0.2, lower=False, n_rate=0.0, name_prefix="ctg", iupac_rate=0.0):
+              clip_rate=0.2, lower=False, n_rate=0.0, name_prefix="ctg", iupac_rate=0.0, long_ins_rate=0.0):
     rng = random.Random(seed)
+    rng3 = random.Random(seed * 104729 + 7)   # long insertions (own generator: the other cases keep their sequences)
     contigs, reads = [], []
     for ci, L in enumerate(contig_lens):
         draft = "".join(rng.choice("ACGT") for _ in range(L))
@@ -42,6 +43,10 @@ def make_case(seed, contig_lens=(20000,), depth=20, mean_len=4000, sub=0.03, ins
                     push("I", n)
                     seq += [rng.choice("ACGT") for _ in range(n)]
                     # an insertion is followed by a match column
+                if long_ins_rate and not first_or_last and rng3.random() < long_ins_rate:
+                    n = rng3.randint(300, 2500)   # one read carries a long insertion: a column with thousands of nodes
+                    push("I", n)
+                    seq += [rng3.choice("ACGT") for _ in range(n)]
                 c = up[pos] if up[pos] in "ACGT" else rng.choice("ACGT")
                 if rng.random() < sub:
                     c = rng.choice([b for b in "ACGT" if b != c])
