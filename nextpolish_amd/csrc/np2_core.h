@@ -401,12 +401,24 @@ NP2_HD uint32_t build_column(const LinkObs* obs, uint32_t n, Entry* entries, Nod
 
 // ---- link graph of a window as the kernels keep it: per column p the nodes nodes[col_off[p] .. + col_nn[p]) in
 // (delta, base) order and their entries entries[col_off[p] + node.start .. + node.len)
+// Predecessor entries of an entry, resolved once (the keys never change, only the scores do): the entries en of the
+// node named by pp with en.pp == ppp, as offsets from that node's first entry, in list order.  n > MATCH_INLINE means
+// "more than fit": the consumer scans the node's list like the reference does.
+constexpr uint32_t MATCH_INLINE = 4;
+struct EMatch {
+    uint32_t pe0;        // global index of the predecessor node's first entry
+    uint16_t n;          // number of matching entries (0: stream head, missing node or no match)
+    uint16_t ps0;        // state index (live entries before it in its column) of the predecessor node's first entry
+    uint64_t m4;         // the offsets of up to MATCH_INLINE matching entries, 16 bits each (no indexed array: stays in registers)
+    NP2_HD uint32_t at(uint32_t k) const { return (uint32_t)(m4 >> (16 * k)) & 0xffffu; }
+};
 struct MsaView {
     const uint32_t* col_off;   // len + 2 offsets (column bucket starts; shared by nodes[] and entries[])
     const uint32_t* col_nn;    // nodes per column
     Node* nodes;
     Entry* entries;
     const ColStat* stat;
+    const EMatch* match = nullptr;   // per entry (same index as entries[]), optional: without it every lookup searches
 };
 NP2_HD Node* find_node(const MsaView& m, int32_t t_pos, uint32_t key) {
     Node* nd = m.nodes + m.col_off[t_pos];
@@ -424,6 +436,24 @@ NP2_HD Node* find_node(const MsaView& m, int32_t t_pos, uint32_t key) {
         if (nd[j].key == key) return nd + j;
     return nullptr;
 }
+
+// the predecessor entries of entry `em` (global index g): from the resolved match list when there is one, else the whole
+// list of the predecessor node (the caller then tests en.pp == em.ppp itself)
+struct PredList {
+    const Entry* PE = nullptr;
+    uint32_t cnt = 0;
+    bool listed = false;
+    EMatch mt;
+    NP2_HD void open(const MsaView& m, const Entry& em, uint32_t g) {
+        if (m.match) {
+            mt = m.match[g];
+            if (mt.n <= MATCH_INLINE) { listed = true; cnt = mt.n; PE = m.entries + mt.pe0; return; }
+        }
+        Node* ppn = find_node(m, key_tpos(em.pp), key_delta(em.pp) << 8 | key_base(em.pp));
+        cnt = ppn ? ppn->len : 0u;
+        PE = ppn ? m.entries + m.col_off[key_tpos(em.pp)] + ppn->start : nullptr;
+    }
+};
 
 // One column of the chain DP of get_cns_from_align_tags (ctg_cns.c:1876-2125), literal per read type: entry score
 // = max(0, best matching predecessor entry + 10 * link - C * coverage) (entries start at 0 and are only raised;
@@ -450,12 +480,11 @@ NP2_HD void dp_column(const MsaView& m, int32_t p, int32_t len, long long* gbest
             if (key_tpos(em.pp) == -1) {
                 em.score = 10 * (long long)em.link - C * cov;
             } else {
-                Node* ppn = find_node(m, key_tpos(em.pp), key_delta(em.pp) << 8 | key_base(em.pp));
-                const uint32_t pl = ppn ? ppn->len : 0u;
-                const Entry* PE = ppn ? m.entries + m.col_off[key_tpos(em.pp)] + ppn->start : nullptr;
-                for (uint32_t n = 0; n < pl; ++n) {
-                    const Entry& en = PE[n];
-                    if (en.pp != em.ppp) continue;
+                PredList pr;
+                pr.open(m, em, m.col_off[p] + pb.start + mi);
+                for (uint32_t it = 0; it < pr.cnt; ++it) {
+                    const Entry& en = pr.PE[pr.listed ? pr.mt.at(it) : it];
+                    if (!pr.listed && en.pp != em.ppp) continue;
                     const long long cand = en.score + 10 * (long long)em.link - C * cov;
                     if (cand > em.score) {
                         em.score = cand;
@@ -512,12 +541,11 @@ NP2_HD void dp_column_lq(const MsaView& m, int32_t p) {
             if (key_tpos(em.pp) == -1) {
                 em.score = 10 * (long long)em.link - C * cov;
             } else {
-                Node* ppn = find_node(m, key_tpos(em.pp), key_delta(em.pp) << 8 | key_base(em.pp));
-                const uint32_t pl = ppn ? ppn->len : 0u;
-                const Entry* PE = ppn ? m.entries + m.col_off[key_tpos(em.pp)] + ppn->start : nullptr;
-                for (uint32_t n = 0; n < pl; ++n) {
-                    const Entry& en = PE[n];
-                    if (en.pp != em.ppp) continue;
+                PredList pr;
+                pr.open(m, em, m.col_off[p] + pb.start + mi);
+                for (uint32_t it = 0; it < pr.cnt; ++it) {
+                    const Entry& en = pr.PE[pr.listed ? pr.mt.at(it) : it];
+                    if (!pr.listed && en.pp != em.ppp) continue;
                     const long long cand = en.score + 10 * (long long)em.link - C * cov;
                     if (cand > em.score) {
                         em.score = cand;

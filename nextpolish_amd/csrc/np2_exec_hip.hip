@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void k2_build_a(const LinkObs* __restrict__ ob
 }
 __global__ __launch_bounds__(256) void k2_build_b(const LinkObs* __restrict__ obs, const uint32_t* __restrict__ obs_col, const uint32_t* __restrict__ col_off,
                                                   uint32_t total, const uint64_t* __restrict__ aux, Entry* __restrict__ entries, Node* __restrict__ nodes,
-                                                  uint32_t* __restrict__ col_nn) {
+                                                  uint32_t* __restrict__ col_nn, uint8_t* __restrict__ live) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const uint64_t a = aux[i];
@@ -402,6 +402,7 @@ __global__ __launch_bounds__(256) void k2_build_b(const LinkObs* __restrict__ ob
     e.link = (uint32_t)(a >> 24) & 0xffffu;   // the reference counts in 16 bits
     e.node = nk;
     entries[lo + start + slot] = e;
+    live[lo + start + slot] = 1;
     if (node_first) {
         nodes[lo + node_idx] = Node{nk, start, node_len, 0u};
         if (node_idx == 0) col_nn[p] = n_nodes;
@@ -410,6 +411,40 @@ __global__ __launch_bounds__(256) void k2_build_b(const LinkObs* __restrict__ ob
 
 // seed_len > 0 (a window): coverage = seed + scanned difference array of the reads (cov_pre exclusive prefix, cov_diff the
 // array itself), max_size at least the seed's 1; seed_len == 0 (concatenated low-quality regions): counted directly
+// predecessor entries of every entry, resolved once for both DP passes (np2_core.h EMatch): lane per entry slot
+__global__ __launch_bounds__(256) void k2_match(MsaView mv, const uint32_t* __restrict__ slot_col, const uint8_t* __restrict__ live, uint32_t total,
+                                                EMatch* __restrict__ match) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total || !live[g]) return;
+    const Entry em = mv.entries[g];
+    EMatch mt;
+    mt.pe0 = 0;
+    mt.n = 0;
+    mt.ps0 = 0;
+    mt.m4 = 0;
+    (void)slot_col;
+    if (key_tpos(em.pp) != -1) {
+        const int32_t tp = key_tpos(em.pp);
+        const Node* first = mv.nodes + mv.col_off[tp];
+        const Node* ppn = find_node(mv, tp, key_delta(em.pp) << 8 | key_base(em.pp));
+        if (ppn) {
+            mt.pe0 = mv.col_off[tp] + ppn->start;
+            uint32_t before = 0;
+            for (const Node* qn = first; qn < ppn; ++qn) before += qn->len;
+            mt.ps0 = (uint16_t)(before < 0xffffu ? before : 0xffffu);
+            uint32_t n_found = 0;
+            for (uint32_t n = 0; n < ppn->len; ++n)
+                if (mv.entries[mt.pe0 + n].pp == em.ppp) {
+                    if (n_found < MATCH_INLINE && n < 65536u) mt.m4 |= (uint64_t)n << (16 * n_found);
+                    else n_found = MATCH_INLINE;   // does not fit: the consumers scan (n = MATCH_INLINE + 1 below)
+                    ++n_found;
+                }
+            mt.n = (uint16_t)(n_found > MATCH_INLINE ? MATCH_INLINE + 1 : n_found);
+        }
+    }
+    match[g] = mt;
+}
+
 __global__ void k2_pack_stat(const uint32_t* coverage, const uint32_t* max_size, const uint32_t* l_ins, const uint32_t* l_del,
                              uint32_t n, ColStat* st, uint32_t seed_len, const uint32_t* cov_pre, const uint32_t* cov_diff, uint32_t* col_cnt) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,12 +609,17 @@ __device__ __forceinline__ void run_bounds(const uint32_t* cuts, uint32_t n_cuts
     *lo = r == 0 ? -1 : (int32_t)cuts[r - 1];
     *hi = r < n_cuts ? (int32_t)cuts[r] : l - 1;
 }
-// state index of entry n of node `nd` inside its column = live entries of the nodes before it + n
-__device__ __forceinline__ uint32_t state_index(const MsaView& mv, int32_t p, const Node* nd, uint32_t n) {
-    const Node* first = mv.nodes + mv.col_off[p];
-    uint32_t idx = n;
-    for (const Node* q = first; q < nd; ++q) idx += q->len;
-    return idx;
+// state index of the entry with global index ge inside its (cut) column: live entries of the nodes before its node + its
+// offset inside the node
+__device__ __forceinline__ uint32_t cut_state_index(const MsaView& mv, int32_t p, uint32_t ge) {
+    const Node* nd = mv.nodes + mv.col_off[p];
+    const uint32_t rel = ge - mv.col_off[p];
+    uint32_t idx = 0;
+    for (uint32_t j = 0; j < mv.col_nn[p]; ++j) {
+        if (rel >= nd[j].start && rel < nd[j].start + nd[j].len) return idx + (rel - nd[j].start);
+        idx += nd[j].len;
+    }
+    return 0xffffffffu;
 }
 
 __global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, long long C, long long* eav, RunT* out,
@@ -609,14 +649,16 @@ __global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uin
                     v = lane == CUT_K ? w : AC_NEG;   // assigned directly, may be negative
                 } else {
                     const int32_t tp = key_tpos(em.pp);
-                    const Node* ppn = find_node(mv, tp, key_delta(em.pp) << 8 | key_base(em.pp));
                     long long best = AC_NEG;
-                    if (ppn) {
-                        const uint32_t g0 = mv.col_off[tp] + ppn->start;
-                        for (uint32_t n = 0; n < ppn->len; ++n) {
-                            if (mv.entries[g0 + n].pp != em.ppp) continue;
+                    PredList pr;
+                    pr.open(mv, em, g);
+                    if (pr.cnt) {
+                        const uint32_t g0 = (uint32_t)(pr.PE - mv.entries);
+                        for (uint32_t it = 0; it < pr.cnt; ++it) {
+                            const uint32_t n = pr.listed ? pr.mt.at(it) : it;
+                            if (!pr.listed && mv.entries[g0 + n].pp != em.ppp) continue;
                             long long vn;
-                            if (tp == lo) vn = state_index(mv, tp, ppn, n) == lane ? 0 : AC_NEG;   // the left cut's entries are the inputs
+                            if (tp == lo) vn = cut_state_index(mv, tp, g0 + n) == lane ? 0 : AC_NEG;   // the left cut's entries are the inputs
                             else vn = eav[(uint64_t)(g0 + n) * W + lane];
                             if (vn > best) best = vn;
                         }
@@ -1031,7 +1073,7 @@ class HipExec : public Exec {
     DevBuf rb_[2][7];   // pos, n_cigar, q0, cigar_off, seq_off, cigar, seq of the two record sets
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
-    DevBuf xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
+    DevBuf live_, ematch_, xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
     PinBuf pin_;
     std::vector<uint32_t> win_first_chunk_, win_n_chunks_;   // chunk range of every stream of the last run_window
     bool win_tags_live_ = false;
@@ -1174,7 +1216,8 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     if (!cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) { *err = "out of device memory (consensus)"; return false; }
     clk.mark("build");
     // ---- chain DP + backtrace
-    MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
+    MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>(),
+               getenv("NP2_NO_MATCH") ? nullptr : ematch_.as<EMatch>()};
     uint32_t cons_len = 0;
     if (!solve(mv, l, n_cols, total, in.read_type, &cons_len, &clk, err)) return false;
     out->cons.resize(cons_len);
@@ -1372,7 +1415,7 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
     }
     if (clk) clk->mark("links.count+scan");
     if (!obs_.ensure(sizeof(LinkObs) * (size_t)total + 64) || !obscol_.ensure(4ull * total + 64) || !obsaux_.ensure(8ull * total + 64) ||
-        !entries_.ensure(sizeof(Entry) * (size_t)total + 64) ||
+        !entries_.ensure(sizeof(Entry) * (size_t)total + 64) || !live_.ensure((size_t)total + 64) || !ematch_.ensure(sizeof(EMatch) * (size_t)total + 64) ||
         !nodes_.ensure(sizeof(Node) * (size_t)total + 64)) {
         *err = "out of device memory (link graph)";
         return false;
@@ -1385,8 +1428,11 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
     HIPOK(hipMemsetAsync(colnn_.p, 0, 4ull * n_cols, q));
     if (total) {
         k2_build_a<<<nblk(total, 256), 256, 0, q>>>(obs_.as<LinkObs>(), obscol_.as<uint32_t>(), coloff_.as<uint32_t>(), total, obsaux_.as<uint64_t>());
+        HIPOK(hipMemsetAsync(live_.p, 0, total, q));
         k2_build_b<<<nblk(total, 256), 256, 0, q>>>(obs_.as<LinkObs>(), obscol_.as<uint32_t>(), coloff_.as<uint32_t>(), total, obsaux_.as<uint64_t>(),
-                                                     entries_.as<Entry>(), nodes_.as<Node>(), colnn_.as<uint32_t>());
+                                                     entries_.as<Entry>(), nodes_.as<Node>(), colnn_.as<uint32_t>(), live_.as<uint8_t>());
+        MsaView bare{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), nullptr};
+        k2_match<<<nblk(total, 256), 256, 0, q>>>(bare, obscol_.as<uint32_t>(), live_.as<uint8_t>(), total, ematch_.as<EMatch>());
     }
     *total_out = total;
     return true;
@@ -1493,7 +1539,8 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>(), 0u, nullptr, nullptr, nullptr);
     uint32_t total = 0;
     if (!build_graph(str_len, n_cols, &total, err)) return false;
-    MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>()};
+    MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>(),
+               getenv("NP2_NO_MATCH") ? nullptr : ematch_.as<EMatch>()};
     uint32_t cons_len = 0;
     if (!solve(mv, (int32_t)in.t_len, n_cols, total, in.hifi ? RULE_LQ_HIFI : RULE_LQ, &cons_len, nullptr, err)) return false;
     std::string fwd(cons_len, '\0');
