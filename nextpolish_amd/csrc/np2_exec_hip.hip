@@ -558,9 +558,10 @@ __global__ void k2_tags_str_chunk(const StrChunk* sc, uint32_t n_chunks, const u
 // column's entries.  Scores obey v = max(0, max_n(v_n) + w) (entries start at 0 and are only raised; stream heads
 // inject constants), so every entry of a run is a function f(x) = max(c, max_i(x_i + a_i)) of the scores x of the
 // entries of the run's left cut column, and a run maps x -> max(C, A (x) x) in the (max, +) semiring.
-// Cuts are columns with at most CUT_K live entries (at most one per block of CUT_BLOCK columns):
+// Cuts are columns with at most K live entries (K = 8, or 32 where deep pileups leave too few narrow columns; at most one
+// per block of CUT_BLOCK columns):
 //   k2_cut_flags / scan / k2_cut_list   the cuts, in order
-//   k2_run_ac     wave per run, lane i = input i (lane CUT_K = constants): (a, c) of every entry, (A, C) of the run
+//   k2_run_ac     K + 1 lanes per run, lane i = input i (lane K = constants): (a, c) of every entry in a two-column ring, (A, C) of the run
 //   k2_run_scan   x at every cut from the (A, C) chain, written into the cut columns' entries   [one lane, #runs steps]
 //   k2_run_dp_a   wave per run (first lane): the reference's literal DP on the run's interior columns
 //   k2_run_dp_b   the same on the cut columns themselves (their scores are recomputed to the same values; the
@@ -568,7 +569,7 @@ __global__ void k2_tags_str_chunk(const StrChunk* sc, uint32_t n_chunks, const u
 // Best-index rules compare real scores, which is why the literal passes run after the scan.
 constexpr int RULE_LQ = 5, RULE_LQ_HIFI = 6;   // DP rules of the low-quality re-consensus, next to READS_ONT..READS_RS
 constexpr long long AC_NEG = INT64_MIN / 4;   // "-infinity" that survives adding a column weight
-constexpr uint32_t CUT_K = 8, CUT_BLOCK = 32;
+constexpr uint32_t CUT_K_SMALL = 8, CUT_K_LARGE = 32, CUT_BLOCK = 32;   // cut width: 8, or 32 where deep pileups leave few narrow columns
 
 __device__ __forceinline__ uint32_t live_entries(const MsaView& mv, uint32_t p) {
     const Node* nd = mv.nodes + mv.col_off[p];
@@ -576,9 +577,9 @@ __device__ __forceinline__ uint32_t live_entries(const MsaView& mv, uint32_t p) 
     for (uint32_t j = 0; j < mv.col_nn[p]; ++j) n += nd[j].len;
     return n;
 }
-// one candidate per block of CUT_BLOCK columns: the first column with 1..CUT_K live entries among the block's first
+// one candidate per block of CUT_BLOCK columns: the first column with 1..K live entries among the block's first
 // CUT_BLOCK - 2 columns (so two cuts are never adjacent: k2_run_dp_b relies on the column before a cut being interior)
-__global__ void k2_cut_flags(MsaView mv, uint32_t n_cols, int32_t l, uint32_t* flag) {
+__global__ void k2_cut_flags(MsaView mv, uint32_t n_cols, int32_t l, uint32_t* flag, uint32_t K) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t p0 = b * CUT_BLOCK;
     if (p0 > n_cols) return;
@@ -588,7 +589,7 @@ __global__ void k2_cut_flags(MsaView mv, uint32_t n_cols, int32_t l, uint32_t* f
         uint32_t f = 0;
         if (!found && o < CUT_BLOCK - 2 && (int32_t)p < l) {
             const uint32_t e = live_entries(mv, p);
-            if (e >= 1 && e <= CUT_K) { f = 1; found = true; }
+            if (e >= 1 && e <= K) { f = 1; found = true; }
         }
         flag[p] = f;
     }
@@ -598,9 +599,10 @@ __global__ void k2_cut_list(const uint32_t* flag, const uint32_t* pos, uint32_t 
     if (p < n_cols && flag[p]) cuts[pos[p]] = p;
 }
 
+template <uint32_t K>
 struct RunT {
-    long long A[CUT_K][CUT_K];   // A[j][i]: output j from input i
-    long long C[CUT_K];
+    long long A[K][K];   // A[j][i]: output j from input i
+    long long C[K];
     uint32_t n_out, pad;         // live entries of the right cut column
 };
 
@@ -609,9 +611,9 @@ __device__ __forceinline__ void run_bounds(const uint32_t* cuts, uint32_t n_cuts
     *lo = r == 0 ? -1 : (int32_t)cuts[r - 1];
     *hi = r < n_cuts ? (int32_t)cuts[r] : l - 1;
 }
-// state index of the entry with global index ge inside its (cut) column: live entries of the nodes before its node + its
-// offset inside the node
-__device__ __forceinline__ uint32_t cut_state_index(const MsaView& mv, int32_t p, uint32_t ge) {
+// state index of the entry with global index ge inside its column: live entries of the nodes before its node + its offset
+// inside the node
+__device__ __forceinline__ uint32_t col_state_index(const MsaView& mv, int32_t p, uint32_t ge) {
     const Node* nd = mv.nodes + mv.col_off[p];
     const uint32_t rel = ge - mv.col_off[p];
     uint32_t idx = 0;
@@ -621,57 +623,81 @@ __device__ __forceinline__ uint32_t cut_state_index(const MsaView& mv, int32_t p
     }
     return 0xffffffffu;
 }
-
-__global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, long long C, long long* eav, RunT* out,
-                          uint32_t rpw) {
-    // `rpw` runs per wave (1 or 7), CUT_K + 1 lanes each: lanes 0..CUT_K-1 carry the coefficient of one input, lane CUT_K
-    // the constant.  A run is a serial chain of dependent loads (~1 ms), so what counts is how many runs are in flight:
-    // small graphs (the low-quality re-consensus) take one run per wave (uniform control flow, thousands of waves fit),
-    // whole windows pack 7 runs per wave and let them diverge.
-    const uint32_t r = blockIdx.x * rpw + threadIdx.x / (CUT_K + 1);
-    const uint32_t lane = threadIdx.x % (CUT_K + 1);
-    if (r >= n_runs || threadIdx.x >= rpw * (CUT_K + 1)) return;
+// the coefficient vectors of a run live in a ring of two columns (an entry only ever looks at its own column and the one
+// before it): size of the ring of every run = 2 * (most live entries of one of its columns), scanned into offsets
+__global__ void k2_run_size(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, uint32_t* size) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_runs) return;
+    if (r == n_runs) { size[r] = 0; return; }
     int32_t lo, hi;
     run_bounds(cuts, n_cuts, r, l, &lo, &hi);
-    constexpr uint32_t W = CUT_K + 1;
+    uint32_t mx = 0;
+    for (int32_t p = lo + 1; p <= hi; ++p) {
+        const uint32_t e = live_entries(mv, (uint32_t)p);
+        if (e > mx) mx = e;
+    }
+    size[r] = 2 * mx;
+}
+
+template <uint32_t K>
+__global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, long long C, long long* ring,
+                          const uint32_t* ring_off, RunT<K>* out, uint32_t rpw, uint32_t* status) {
+    // `rpw` runs per wave, K + 1 lanes each: lanes 0..K-1 carry the coefficient of one input (= one live entry of the
+    // run's left cut column), lane K the constant.  A run is a serial chain of dependent loads, so what counts is how
+    // many runs are in flight: small graphs (the low-quality re-consensus) take one run per wave, whole windows pack
+    // 64 / (K + 1) runs per wave and let them diverge.
+    constexpr uint32_t W = K + 1;
+    const uint32_t r = blockIdx.x * rpw + threadIdx.x / W;
+    const uint32_t lane = threadIdx.x % W;
+    if (r >= n_runs || threadIdx.x >= rpw * W) return;
+    int32_t lo, hi;
+    run_bounds(cuts, n_cuts, r, l, &lo, &hi);
+    long long* R = ring + (uint64_t)ring_off[r] * W;
+    const uint64_t half = (uint64_t)((ring_off[r + 1] - ring_off[r]) / 2) * W;
     uint32_t jout = 0;
     for (int32_t p = lo + 1; p <= hi; ++p) {
         const long long cov = mv.stat[p].coverage;
         const Node* nd = mv.nodes + mv.col_off[p];
         const uint32_t nn = mv.col_nn[p];
+        long long* cur = R + (uint64_t)(p & 1) * half;
+        const long long* prev = R + (uint64_t)((p & 1) ^ 1) * half;
+        uint32_t s = 0;   // state index of the entry inside its column
         for (uint32_t j = 0; j < nn; ++j) {
-            for (uint32_t m = 0; m < nd[j].len; ++m) {
+            for (uint32_t m = 0; m < nd[j].len; ++m, ++s) {
                 const uint32_t g = mv.col_off[p] + nd[j].start + m;
                 const Entry& em = mv.entries[g];
                 const long long w = 10 * (long long)em.link - C * cov;
                 long long v;   // this lane's component of the entry's function
                 if (key_tpos(em.pp) == -1) {
-                    v = lane == CUT_K ? w : AC_NEG;   // assigned directly, may be negative
+                    v = lane == K ? w : AC_NEG;   // assigned directly, may be negative
                 } else {
                     const int32_t tp = key_tpos(em.pp);
+                    if (tp != p && tp != p - 1) { if (lane == 0) atomicMax(status, 4u); return; }   // a tag's predecessor is its neighbour
                     long long best = AC_NEG;
                     PredList pr;
                     pr.open(mv, em, g);
                     if (pr.cnt) {
                         const uint32_t g0 = (uint32_t)(pr.PE - mv.entries);
+                        const bool fast = pr.listed && pr.mt.ps0 != 0xffffu;
                         for (uint32_t it = 0; it < pr.cnt; ++it) {
                             const uint32_t n = pr.listed ? pr.mt.at(it) : it;
                             if (!pr.listed && mv.entries[g0 + n].pp != em.ppp) continue;
+                            const uint32_t sidx = fast ? pr.mt.ps0 + n : col_state_index(mv, tp, g0 + n);
                             long long vn;
-                            if (tp == lo) vn = cut_state_index(mv, tp, g0 + n) == lane ? 0 : AC_NEG;   // the left cut's entries are the inputs
-                            else vn = eav[(uint64_t)(g0 + n) * W + lane];
+                            if (tp == lo) vn = sidx == lane ? 0 : AC_NEG;   // the left cut's entries are the inputs
+                            else vn = (tp == p ? cur : prev)[(uint64_t)sidx * W + lane];
                             if (vn > best) best = vn;
                         }
                     }
                     v = best > AC_NEG ? best + w : AC_NEG;
-                    if (lane == CUT_K && v < 0) v = 0;   // clamp lives in the constant
+                    if (lane == K && v < 0) v = 0;   // clamp lives in the constant
                 }
                 if (p == hi && r < n_cuts) {   // an entry of the right cut: a row of the run's transfer
-                    if (lane < CUT_K) out[r].A[jout][lane] = v;
+                    if (lane < K) out[r].A[jout][lane] = v;
                     else out[r].C[jout] = v;
                     ++jout;
                 }
-                eav[(uint64_t)g * W + lane] = v;
+                cur[(uint64_t)s * W + lane] = v;
             }
         }
     }
@@ -680,103 +706,118 @@ __global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uin
 
 // ---- scores at the cuts: scan of the run transfers, grouped ------------------------------------------------------
 // T2 o T1 in the (max, +) semiring with constants: A = A2 (x) A1, C = max(C2, A2 (x) C1).  Groups of SCAN_G runs are
-// composed in parallel (one wave per group, lane (j, i) owns A[j][i]), one lane chains the groups, then every group
-// replays its runs from its true entry vector and writes the cut columns' scores.
+// composed in parallel (one wave per group, the K x K outputs spread over the lanes), a wave chains the groups (two
+// levels), then every group replays its runs from its true entry vector and writes the cut columns' scores.
 constexpr uint32_t SCAN_G = 32;
 __device__ __forceinline__ long long mp_add(long long a, long long b) { return (a > AC_NEG && b > AC_NEG) ? a + b : AC_NEG; }
 
-__global__ __launch_bounds__(64) void k2_scan_groups(const RunT* rt, uint32_t n_cuts, RunT* gt) {
-    __shared__ long long sA[CUT_K][CUT_K], sC[CUT_K], tA[CUT_K][CUT_K], tC[CUT_K];
-    const uint32_t g = blockIdx.x, lane = threadIdx.x, j = lane / CUT_K, i = lane % CUT_K;
+template <uint32_t K>
+__global__ __launch_bounds__(64) void k2_scan_groups(const RunT<K>* rt, uint32_t n_cuts, RunT<K>* gt) {
+    __shared__ long long sA[K][K], sC[K], tA[K][K], tC[K], nA[K][K], nC[K];
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
     const uint32_t r0 = g * SCAN_G, r1 = r0 + SCAN_G < n_cuts ? r0 + SCAN_G : n_cuts;
     // running transfer = run r0
-    sA[j][i] = rt[r0].A[j][i];
-    if (lane < CUT_K) sC[lane] = rt[r0].C[lane];
+    for (uint32_t x = lane; x < K * K; x += 64) sA[x / K][x % K] = rt[r0].A[x / K][x % K];
+    for (uint32_t x = lane; x < K; x += 64) sC[x] = rt[r0].C[x];
     uint32_t n_mid = rt[r0].n_out;   // outputs of the running transfer = inputs of the next run
     __syncthreads();
     for (uint32_t r = r0 + 1; r < r1; ++r) {
-        tA[j][i] = rt[r].A[j][i];
-        if (lane < CUT_K) tC[lane] = rt[r].C[lane];
+        for (uint32_t x = lane; x < K * K; x += 64) tA[x / K][x % K] = rt[r].A[x / K][x % K];
+        for (uint32_t x = lane; x < K; x += 64) tC[x] = rt[r].C[x];
         const uint32_t n_out = rt[r].n_out;
         __syncthreads();
-        long long a = AC_NEG, c = AC_NEG;
-        if (j < n_out) {
-            for (uint32_t k = 0; k < n_mid; ++k) {
-                const long long v = mp_add(tA[j][k], sA[k][i]);
-                if (v > a) a = v;
-            }
-            if (i == 0) {
+        for (uint32_t x = lane; x < K * K; x += 64) {
+            const uint32_t j = x / K, i = x % K;
+            long long a = AC_NEG;
+            if (j < n_out)
+                for (uint32_t k = 0; k < n_mid; ++k) {
+                    const long long v = mp_add(tA[j][k], sA[k][i]);
+                    if (v > a) a = v;
+                }
+            nA[j][i] = a;
+        }
+        for (uint32_t j = lane; j < K; j += 64) {
+            long long c = AC_NEG;
+            if (j < n_out) {
                 c = tC[j];
                 for (uint32_t k = 0; k < n_mid; ++k) {
                     const long long v = mp_add(tA[j][k], sC[k]);
                     if (v > c) c = v;
                 }
             }
+            nC[j] = c;
         }
         __syncthreads();
-        sA[j][i] = a;
-        if (i == 0) sC[j] = c;
+        for (uint32_t x = lane; x < K * K; x += 64) sA[x / K][x % K] = nA[x / K][x % K];
+        for (uint32_t x = lane; x < K; x += 64) sC[x] = nC[x];
         n_mid = n_out;
         __syncthreads();
     }
-    gt[g].A[j][i] = sA[j][i];
-    if (lane < CUT_K) gt[g].C[lane] = sC[lane];
+    for (uint32_t x = lane; x < K * K; x += 64) gt[g].A[x / K][x % K] = sA[x / K][x % K];
+    for (uint32_t x = lane; x < K; x += 64) gt[g].C[x] = sC[x];
     if (lane == 0) gt[g].n_out = n_mid;
 }
 // entry vector of every group (x before its first run).  x_in == nullptr: one block walks all groups, group 0 starts
 // from nothing.  Otherwise block s walks groups [s * SCAN_G, (s + 1) * SCAN_G) starting from x_in[s] (two-level scan:
-// the groups are themselves composed in groups by k2_scan_groups and chained once at the top).
-__global__ void k2_scan_chain(const RunT* gt, uint32_t n_groups, const long long* x_in, const uint32_t* n_in_arr, long long* gx, uint32_t* gn) {
-    if (threadIdx.x) return;
-    const uint32_t s = blockIdx.x;
+// the groups are themselves composed in groups by k2_scan_groups and chained once at the top).  Lane j owns x[j].
+template <uint32_t K>
+__global__ __launch_bounds__(64) void k2_scan_chain(const RunT<K>* gt, uint32_t n_groups, const long long* x_in, const uint32_t* n_in_arr, long long* gx,
+                                                    uint32_t* gn) {
+    __shared__ long long xs[K];
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
     const uint32_t g0 = x_in ? s * SCAN_G : 0u, g1 = x_in ? (g0 + SCAN_G < n_groups ? g0 + SCAN_G : n_groups) : n_groups;
-    long long x[CUT_K], xn[CUT_K];
-    uint32_t n_in = 0;
-    if (x_in) {
-        n_in = n_in_arr[s];
-        for (uint32_t i = 0; i < n_in; ++i) x[i] = x_in[(uint64_t)s * CUT_K + i];
-    }
+    uint32_t n_in = x_in ? n_in_arr[s] : 0u;
+    if (lane < K) xs[lane] = (x_in && lane < n_in) ? x_in[(uint64_t)s * K + lane] : AC_NEG;
+    __syncthreads();
     for (uint32_t g = g0; g < g1; ++g) {
-        for (uint32_t i = 0; i < CUT_K; ++i) gx[(uint64_t)g * CUT_K + i] = i < n_in ? x[i] : AC_NEG;
-        gn[g] = n_in;
+        if (lane < K) gx[(uint64_t)g * K + lane] = lane < n_in ? xs[lane] : AC_NEG;
+        if (lane == 0) gn[g] = n_in;
         const uint32_t n_out = gt[g].n_out;
-        for (uint32_t j = 0; j < n_out; ++j) {
-            long long v = gt[g].C[j];
+        long long v = AC_NEG;
+        if (lane < n_out) {
+            v = gt[g].C[lane];
             for (uint32_t i = 0; i < n_in; ++i) {
-                const long long t = mp_add(x[i], gt[g].A[j][i]);
+                const long long t = mp_add(xs[i], gt[g].A[lane][i]);
                 if (t > v) v = t;
             }
-            xn[j] = v;
         }
+        __syncthreads();
+        if (lane < K) xs[lane] = v;
         n_in = n_out;
-        for (uint32_t i = 0; i < n_in; ++i) x[i] = xn[i];
+        __syncthreads();
     }
 }
 // every group replays its runs; the cut columns' entries get their true scores so the literal passes can start from them
-__global__ void k2_scan_apply(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, const RunT* rt, const long long* gx, const uint32_t* gn) {
-    const uint32_t g = blockIdx.x;
-    if (threadIdx.x) return;
+template <uint32_t K>
+__global__ __launch_bounds__(64) void k2_scan_apply(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, const RunT<K>* rt, const long long* gx, const uint32_t* gn) {
+    __shared__ long long xs[K];
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
     const uint32_t r0 = g * SCAN_G, r1 = r0 + SCAN_G < n_cuts ? r0 + SCAN_G : n_cuts;
-    long long x[CUT_K], xn[CUT_K];
     uint32_t n_in = gn[g];
-    for (uint32_t i = 0; i < n_in; ++i) x[i] = gx[(uint64_t)g * CUT_K + i];
+    if (lane < K) xs[lane] = lane < n_in ? gx[(uint64_t)g * K + lane] : AC_NEG;
+    __syncthreads();
     for (uint32_t r = r0; r < r1; ++r) {
         const uint32_t p = cuts[r];
-        const Node* nd = mv.nodes + mv.col_off[p];
-        uint32_t jo = 0;
-        for (uint32_t j = 0; j < mv.col_nn[p]; ++j)
-            for (uint32_t m = 0; m < nd[j].len; ++m) {
-                long long v = rt[r].C[jo];
-                for (uint32_t i = 0; i < n_in; ++i) {
-                    const long long t = mp_add(x[i], rt[r].A[jo][i]);
-                    if (t > v) v = t;
-                }
-                xn[jo] = v;
-                mv.entries[mv.col_off[p] + nd[j].start + m].score = v;
-                ++jo;
+        const uint32_t n_out = rt[r].n_out;
+        long long v = AC_NEG;
+        if (lane < n_out) {   // lane = state index of the entry inside the cut column
+            v = rt[r].C[lane];
+            for (uint32_t i = 0; i < n_in; ++i) {
+                const long long t = mp_add(xs[i], rt[r].A[lane][i]);
+                if (t > v) v = t;
             }
-        n_in = jo;
-        for (uint32_t i = 0; i < n_in; ++i) x[i] = xn[i];
+            // the entry with this state index
+            const Node* nd = mv.nodes + mv.col_off[p];
+            uint32_t left = lane;
+            for (uint32_t j = 0; j < mv.col_nn[p]; ++j) {
+                if (left < nd[j].len) { mv.entries[mv.col_off[p] + nd[j].start + left].score = v; break; }
+                left -= nd[j].len;
+            }
+        }
+        __syncthreads();
+        if (lane < K) xs[lane] = v;
+        n_in = n_out;
+        __syncthreads();
     }
 }
 
@@ -834,7 +875,7 @@ struct BtPick { uint32_t start; uint32_t count; uint32_t off; uint32_t used; }; 
 
 template <bool kLq, bool kWrite>
 __global__ void k2_bt_runs(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, BtWalk* walks,
-                           const BtPick* pick, ConsBase* cons, char* chars, uint32_t* status) {
+                           const BtPick* pick, ConsBase* cons, char* chars, uint32_t* status, uint32_t K) {
     const uint32_t r = blockIdx.x;
     if (r >= n_runs) return;
     int32_t lo, hi;
@@ -889,38 +930,38 @@ __global__ void k2_bt_runs(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, ui
         if (!ended && lo >= 0) {   // index of the exit node among the nodes of the left cut column
             const Node* nl = mv.nodes + mv.col_off[lo];
             const uint32_t key = key_delta(cur) << 8 | key_base(cur), nn = mv.col_nn[lo];
-            for (uint32_t j = 0; j < nn && j < CUT_K; ++j)
+            for (uint32_t j = 0; j < nn && j < K; ++j)
                 if (nl[j].key == key && key_tpos(cur) == lo) xi = j;
             if (xi == 0xffffffffu) n = 0xffffffffu;   // cannot happen on a consistent graph
         }
-        walks[(uint64_t)r * CUT_K + s] = BtWalk{xi, n, ended ? 1u : 0u, 0};
+        walks[(uint64_t)r * K + s] = BtWalk{xi, n, ended ? 1u : 0u, 0};
     }
 }
 
-// The chain "start node of run r -> exit node = start node of run r - 1" is a composition of maps on at most CUT_K
+// The chain "start node of run r -> exit node = start node of run r - 1" is a composition of maps on at most K (cut width)
 // states, so it is grouped like the score scan: groups of BT_G runs are composed for every possible start (lanes =
 // starts), one lane chains the groups, then every group replays its runs and places them.
 constexpr uint32_t BT_G = 32;
 struct BtGroup { uint32_t exit_idx, count, ended, invalid; };   // per (group, start at the group's right-most run)
 struct BtGroupPick { uint32_t start, off, used, pad; };
 
-__global__ void k2_bt_groups(const BtWalk* walks, uint32_t n_runs, BtGroup* grp) {
+__global__ void k2_bt_groups(const BtWalk* walks, uint32_t n_runs, BtGroup* grp, uint32_t K) {
     const uint32_t g = blockIdx.x, s = threadIdx.x;
-    if (s >= CUT_K) return;
+    if (s >= K) return;
     const uint32_t r0 = g * BT_G, r1 = r0 + BT_G < n_runs ? r0 + BT_G : n_runs;
     uint32_t cur = s, cnt = 0, ended = 0, invalid = 0;
     for (uint32_t r = r1; r-- > r0;) {
-        const BtWalk w = walks[(uint64_t)r * CUT_K + cur];
+        const BtWalk w = walks[(uint64_t)r * K + cur];
         if (w.count == 0xffffffffu) { invalid = 1; break; }
         cnt += w.count;
         if (w.ended) { ended = 1; break; }
         cur = w.exit_idx;
-        if (cur >= CUT_K) { invalid = 1; break; }
+        if (cur >= K) { invalid = 1; break; }
     }
-    grp[(uint64_t)g * CUT_K + s] = BtGroup{cur, cnt, ended, invalid};
+    grp[(uint64_t)g * K + s] = BtGroup{cur, cnt, ended, invalid};
 }
 __global__ void k2_bt_chain(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, const BtGroup* grp,
-                            uint32_t n_groups, BtGroupPick* gp, uint32_t* total_out, uint32_t* status) {
+                            uint32_t n_groups, BtGroupPick* gp, uint32_t* total_out, uint32_t* status, uint32_t K) {
     if (blockIdx.x || threadIdx.x) return;
     // start of the right-most run: the open run has a single start (the global best node); a window ending on a cut
     // column starts from that node's index among the cut's nodes
@@ -931,11 +972,11 @@ __global__ void k2_bt_chain(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, u
         const Node* nd = mv.nodes + mv.col_off[hi];
         const uint32_t key = key_delta(cur) << 8 | key_base(cur), nn = mv.col_nn[hi];
         while (s < nn && nd[s].key != key) ++s;
-        if (key_tpos(cur) != hi || s >= nn || s >= CUT_K) { *status = 2; *total_out = 0; return; }
+        if (key_tpos(cur) != hi || s >= nn || s >= K) { *status = 2; *total_out = 0; return; }
     }
     int64_t g = (int64_t)n_groups - 1, first_used = (int64_t)n_groups;
     for (; g >= 0; --g) {
-        const BtGroup e = grp[(uint64_t)g * CUT_K + s];
+        const BtGroup e = grp[(uint64_t)g * K + s];
         if (e.invalid) { *status = 2; break; }
         gp[g] = BtGroupPick{s, e.count, 1, 0};   // off holds the count until the prefix pass below
         first_used = g;
@@ -947,7 +988,7 @@ __global__ void k2_bt_chain(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, u
     for (int64_t q = first_used; q < (int64_t)n_groups; ++q) { const uint32_t c = gp[q].off; gp[q].off = off; off += c; }
     *total_out = off;
 }
-__global__ void k2_bt_place(const BtWalk* walks, uint32_t n_runs, const BtGroupPick* gp, BtPick* pick) {
+__global__ void k2_bt_place(const BtWalk* walks, uint32_t n_runs, const BtGroupPick* gp, BtPick* pick, uint32_t K) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r0 = g * BT_G;
     if (r0 >= n_runs) return;
@@ -956,7 +997,7 @@ __global__ void k2_bt_place(const BtWalk* walks, uint32_t n_runs, const BtGroupP
     if (!gp[g].used) return;
     uint32_t cur = gp[g].start, first = r1;
     for (uint32_t r = r1; r-- > r0;) {
-        const BtWalk w = walks[(uint64_t)r * CUT_K + cur];
+        const BtWalk w = walks[(uint64_t)r * K + cur];
         pick[r] = BtPick{cur, w.count, 0, 1};
         first = r;
         if (w.ended) break;
@@ -1062,6 +1103,9 @@ class HipExec : public Exec {
     bool build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, uint32_t* total, std::string* err, struct StageClock* clk = nullptr,
                      const uint32_t* m_seen = nullptr);
     bool solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t total, int rule, uint32_t* cons_len, struct StageClock* clk, std::string* err);
+    template <uint32_t K>
+    bool solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t total, int rule, uint32_t n_cuts, uint32_t n_runs, uint32_t* cons_len,
+                    struct StageClock* clk, std::string* err);
     int device_;
     hipStream_t stream_ = nullptr;
     bool upload_contig(const WindowInput& in, std::string* err);
@@ -1073,7 +1117,7 @@ class HipExec : public Exec {
     DevBuf rb_[2][7];   // pos, n_cigar, q0, cigar_off, seq_off, cigar, seq of the two record sets
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
-    DevBuf live_, ematch_, xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
+    DevBuf runsz_, runoff_, live_, ematch_, xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
     PinBuf pin_;
     std::vector<uint32_t> win_first_chunk_, win_n_chunks_;   // chunk range of every stream of the last run_window
     bool win_tags_live_ = false;
@@ -1259,22 +1303,29 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
 bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t total, int rule, uint32_t* cons_len, StageClock* clk,
                     std::string* err) {
     hipStream_t q = stream_;
-    const bool lq = rule == RULE_LQ || rule == RULE_LQ_HIFI;
     if (!cutflag_.ensure(4ull * (n_cols + CUT_BLOCK + 2)) || !cutpos_.ensure(4ull * (n_cols + 2)) || !cuts_.ensure(4ull * (n_cols + 2)) ||
-        !eav_.ensure(8ull * (CUT_K + 1) * (size_t)total + 64) || !flag_.ensure(32) || !cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) {
+        !flag_.ensure(32) || !cons_.ensure(sizeof(ConsBase) * ((size_t)total + 16))) {
         *err = "out of device memory (dp runs)";
         return false;
     }
     if (clk) clk->mark("dp.alloc");
-    k2_cut_flags<<<nblk(n_cols / CUT_BLOCK + 1, 64), 64, 0, q>>>(mv, n_cols, l, cutflag_.as<uint32_t>());
-    if (clk) clk->mark("dp.cutflags");
-    const uint32_t nsb2 = nblk(n_cols + 1, SCAN_TILE);
-    k2_scan_sums<<<nsb2, SCAN_T, 0, q>>>(cutflag_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
-    k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb2);
-    k2_scan_final<<<nsb2, SCAN_T, 0, q>>>(cutflag_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), cutpos_.as<uint32_t>());
+    // ---- the cuts: narrow columns (<= 8 live entries) where every block of 32 columns has one; deep pileups rarely do,
+    // and runs that span many blocks are serial, so the cut width goes up to 32 when more than ~a third of the blocks
+    // come up empty
+    uint32_t K = getenv("NP2_CUT_K") ? (uint32_t)atoi(getenv("NP2_CUT_K")) : CUT_K_SMALL;
+    if (K != CUT_K_SMALL && K != CUT_K_LARGE) K = CUT_K_SMALL;
     uint32_t n_cuts = 0;
-    HIPOK(hipMemcpyAsync(&n_cuts, cutpos_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
-    HIPOK(hipStreamSynchronize(q));
+    const uint32_t nsb2 = nblk(n_cols + 1, SCAN_TILE);
+    for (;;) {
+        k2_cut_flags<<<nblk(n_cols / CUT_BLOCK + 1, 64), 64, 0, q>>>(mv, n_cols, l, cutflag_.as<uint32_t>(), K);
+        k2_scan_sums<<<nsb2, SCAN_T, 0, q>>>(cutflag_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
+        k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb2);
+        k2_scan_final<<<nsb2, SCAN_T, 0, q>>>(cutflag_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), cutpos_.as<uint32_t>());
+        HIPOK(hipMemcpyAsync(&n_cuts, cutpos_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
+        HIPOK(hipStreamSynchronize(q));
+        if (K == CUT_K_LARGE || (uint64_t)n_cuts * 3 >= (uint64_t)(n_cols / CUT_BLOCK) * 2 || getenv("NP2_CUT_K")) break;
+        K = CUT_K_LARGE;
+    }
     if (clk) clk->mark("dp.cutscan");
     k2_cut_list<<<nblk(n_cols, 256), 256, 0, q>>>(cutflag_.as<uint32_t>(), cutpos_.as<uint32_t>(), n_cols, cuts_.as<uint32_t>());
     uint32_t last_cut = 0xffffffffu;
@@ -1283,43 +1334,70 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     if (clk) clk->mark("dp.cutlist");
     // a window ending on a cut column has no open run behind it
     const uint32_t n_runs = (n_cuts && (int32_t)last_cut == l - 1) ? n_cuts : n_cuts + 1;
-    if (!runt_.ensure(sizeof(RunT) * (size_t)n_runs + 64) || !btwalk_.ensure(sizeof(BtWalk) * CUT_K * (size_t)n_runs + 64) ||
-        !btpick_.ensure(sizeof(BtPick) * (size_t)n_runs + 64)) { *err = "out of device memory (dp runs)"; return false; }
     if (clk && clk->on) {
         std::vector<uint32_t> hc(n_cuts);
         if (n_cuts) (void)hipMemcpy(hc.data(), cuts_.p, 4ull * n_cuts, hipMemcpyDeviceToHost);
         uint32_t mx = n_cuts ? hc[0] + 1 : (uint32_t)l, over1k = 0;
         for (uint32_t i = 1; i < n_cuts; ++i) { mx = std::max(mx, hc[i] - hc[i - 1]); over1k += hc[i] - hc[i - 1] > 1000; }
-        fprintf(stderr, "[np2 dp] %u cuts, %u runs over %d columns; longest run %u columns, %u runs > 1000\n", n_cuts, n_runs, l, mx, over1k);
+        fprintf(stderr, "[np2 dp] cut width %u: %u cuts, %u runs over %d columns; longest run %u columns, %u runs > 1000\n", K, n_cuts, n_runs, l, mx, over1k);
     }
+    return K == CUT_K_LARGE ? solve_runs<CUT_K_LARGE>(mv, l, n_cols, total, rule, n_cuts, n_runs, cons_len, clk, err)
+                            : solve_runs<CUT_K_SMALL>(mv, l, n_cols, total, rule, n_cuts, n_runs, cons_len, clk, err);
+}
+
+template <uint32_t K>
+bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t total, int rule, uint32_t n_cuts, uint32_t n_runs, uint32_t* cons_len,
+                         StageClock* clk, std::string* err) {
+    hipStream_t q = stream_;
+    (void)n_cols; (void)total;
+    const bool lq = rule == RULE_LQ || rule == RULE_LQ_HIFI;
+    typedef RunT<K> RT;
+    if (!runt_.ensure(sizeof(RT) * (size_t)n_runs + 64) || !btwalk_.ensure(sizeof(BtWalk) * K * (size_t)n_runs + 64) ||
+        !btpick_.ensure(sizeof(BtPick) * (size_t)n_runs + 64) || !runsz_.ensure(4ull * (n_runs + 2)) || !runoff_.ensure(4ull * (n_runs + 2)) ||
+        !sums2_.ensure(4ull * (nblk(n_runs + 1, SCAN_TILE) + 2))) { *err = "out of device memory (dp runs)"; return false; }
     HIPOK(hipMemsetAsync(flag_.p, 0, 32, q));
     HIPOK(hipMemsetAsync(res_.p, 0, sizeof(DpResult), q));
+    uint32_t* status = flag_.as<uint32_t>() + 4;
+    uint32_t* total_dev = flag_.as<uint32_t>() + 5;
+    // ring of two columns of coefficient vectors per run
+    k2_run_size<<<nblk(n_runs + 1, 256), 256, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, runsz_.as<uint32_t>());
+    {
+        const uint32_t nsr = nblk(n_runs + 1, SCAN_TILE);
+        k2_scan_sums<<<nsr, SCAN_T, 0, q>>>(runsz_.as<uint32_t>(), n_runs + 1, sums2_.as<uint32_t>());
+        k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nsr);
+        k2_scan_final<<<nsr, SCAN_T, 0, q>>>(runsz_.as<uint32_t>(), n_runs + 1, sums2_.as<uint32_t>(), runoff_.as<uint32_t>());
+    }
+    uint32_t ring_units = 0;
+    HIPOK(hipMemcpyAsync(&ring_units, runoff_.as<uint32_t>() + n_runs, 4, hipMemcpyDeviceToHost, q));
+    HIPOK(hipStreamSynchronize(q));
+    if (!eav_.ensure(8ull * (K + 1) * (size_t)ring_units + 64)) { *err = "out of device memory (dp runs)"; return false; }
     if (clk) clk->mark("dp.cuts");
     const long long C = rule == RULE_LQ ? 2 : (rule == READS_HIFI || rule == RULE_LQ_HIFI) ? 4 : 3;
     const bool dense = n_runs >= 16384 && !getenv("NP2_RUN_PER_WAVE");   // enough runs to fill the chip with several per wave
-    const uint32_t rpw_ac = dense ? 7u : 1u, rpw_dp = dense ? 64u : 1u;
-    k2_run_ac<<<nblk(n_runs, rpw_ac), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, eav_.as<long long>(), runt_.as<RunT>(), rpw_ac);
+    const uint32_t rpw_ac = dense ? 64u / (K + 1) : 1u, rpw_dp = dense ? 64u : 1u;
+    k2_run_ac<K><<<nblk(n_runs, rpw_ac), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, eav_.as<long long>(), runoff_.as<uint32_t>(), runt_.as<RT>(),
+                                                      rpw_ac, status);
     if (clk) clk->mark("dp.ac");
     if (n_cuts) {
         const uint32_t n_groups = nblk(n_cuts, SCAN_G);
-        if (!grpt_.ensure(sizeof(RunT) * (size_t)n_groups + 64) || !grpx_.ensure(8ull * CUT_K * n_groups + 64) || !grpn_.ensure(4ull * n_groups + 64)) {
+        if (!grpt_.ensure(sizeof(RT) * (size_t)n_groups + 64) || !grpx_.ensure(8ull * K * n_groups + 64) || !grpn_.ensure(4ull * n_groups + 64)) {
             *err = "out of device memory (dp scan)";
             return false;
         }
-        k2_scan_groups<<<n_groups, 64, 0, q>>>(runt_.as<RunT>(), n_cuts, grpt_.as<RunT>());
+        k2_scan_groups<K><<<n_groups, 64, 0, q>>>(runt_.as<RT>(), n_cuts, grpt_.as<RT>());
         if (n_groups > 2 * SCAN_G) {   // second level: groups of groups, one short chain on top
             const uint32_t n_super = nblk(n_groups, SCAN_G);
-            if (!grpt2_.ensure(sizeof(RunT) * (size_t)n_super + 64) || !grpx2_.ensure(8ull * CUT_K * n_super + 64) || !grpn2_.ensure(4ull * n_super + 64)) {
+            if (!grpt2_.ensure(sizeof(RT) * (size_t)n_super + 64) || !grpx2_.ensure(8ull * K * n_super + 64) || !grpn2_.ensure(4ull * n_super + 64)) {
                 *err = "out of device memory (dp scan)";
                 return false;
             }
-            k2_scan_groups<<<n_super, 64, 0, q>>>(grpt_.as<RunT>(), n_groups, grpt2_.as<RunT>());
-            k2_scan_chain<<<1, 64, 0, q>>>(grpt2_.as<RunT>(), n_super, nullptr, nullptr, grpx2_.as<long long>(), grpn2_.as<uint32_t>());
-            k2_scan_chain<<<n_super, 64, 0, q>>>(grpt_.as<RunT>(), n_groups, grpx2_.as<long long>(), grpn2_.as<uint32_t>(), grpx_.as<long long>(), grpn_.as<uint32_t>());
+            k2_scan_groups<K><<<n_super, 64, 0, q>>>(grpt_.as<RT>(), n_groups, grpt2_.as<RT>());
+            k2_scan_chain<K><<<1, 64, 0, q>>>(grpt2_.as<RT>(), n_super, nullptr, nullptr, grpx2_.as<long long>(), grpn2_.as<uint32_t>());
+            k2_scan_chain<K><<<n_super, 64, 0, q>>>(grpt_.as<RT>(), n_groups, grpx2_.as<long long>(), grpn2_.as<uint32_t>(), grpx_.as<long long>(), grpn_.as<uint32_t>());
         } else {
-            k2_scan_chain<<<1, 64, 0, q>>>(grpt_.as<RunT>(), n_groups, nullptr, nullptr, grpx_.as<long long>(), grpn_.as<uint32_t>());
+            k2_scan_chain<K><<<1, 64, 0, q>>>(grpt_.as<RT>(), n_groups, nullptr, nullptr, grpx_.as<long long>(), grpn_.as<uint32_t>());
         }
-        k2_scan_apply<<<n_groups, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, runt_.as<RunT>(), grpx_.as<long long>(), grpn_.as<uint32_t>());
+        k2_scan_apply<K><<<n_groups, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, runt_.as<RT>(), grpx_.as<long long>(), grpn_.as<uint32_t>());
     }
     if (clk) clk->mark("dp.scan");
 #define NP2_RUN_DP(T)                                                                                                         \
@@ -1338,29 +1416,28 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
 #undef NP2_RUN_DP
     if (clk) clk->mark("dp.replay");
     // ---- backtrace: walk every start, chain the runs, write
-    uint32_t* status = flag_.as<uint32_t>() + 4;
-    uint32_t* total_dev = flag_.as<uint32_t>() + 5;
-    if (lq) k2_bt_runs<true, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status);
-    else k2_bt_runs<false, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status);
+    if (lq) k2_bt_runs<true, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status, K);
+    else k2_bt_runs<false, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status, K);
     {
         const uint32_t n_bgroups = nblk(n_runs, BT_G);
-        if (!btgrp_.ensure(sizeof(BtGroup) * CUT_K * (size_t)n_bgroups + 64) || !btgpick_.ensure(sizeof(BtGroupPick) * (size_t)n_bgroups + 64)) {
+        if (!btgrp_.ensure(sizeof(BtGroup) * K * (size_t)n_bgroups + 64) || !btgpick_.ensure(sizeof(BtGroupPick) * (size_t)n_bgroups + 64)) {
             *err = "out of device memory (backtrace)";
             return false;
         }
-        k2_bt_groups<<<n_bgroups, 64, 0, q>>>(btwalk_.as<BtWalk>(), n_runs, btgrp_.as<BtGroup>());
+        k2_bt_groups<<<n_bgroups, 64, 0, q>>>(btwalk_.as<BtWalk>(), n_runs, btgrp_.as<BtGroup>(), K);
         k2_bt_chain<<<1, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btgrp_.as<BtGroup>(), n_bgroups,
-                                     btgpick_.as<BtGroupPick>(), total_dev, status);
-        k2_bt_place<<<nblk(n_bgroups, 64), 64, 0, q>>>(btwalk_.as<BtWalk>(), n_runs, btgpick_.as<BtGroupPick>(), btpick_.as<BtPick>());
+                                     btgpick_.as<BtGroupPick>(), total_dev, status, K);
+        k2_bt_place<<<nblk(n_bgroups, 64), 64, 0, q>>>(btwalk_.as<BtWalk>(), n_runs, btgpick_.as<BtGroupPick>(), btpick_.as<BtPick>(), K);
     }
-    if (lq) k2_bt_runs<true, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), nullptr, cons_.as<char>(), status);
-    else k2_bt_runs<false, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), cons_.as<ConsBase>(), nullptr, status);
+    if (lq) k2_bt_runs<true, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), nullptr, cons_.as<char>(), status, K);
+    else k2_bt_runs<false, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), cons_.as<ConsBase>(), nullptr, status, K);
     DpResult res;
     uint32_t st2[2] = {0, 0};
     HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));
     HIPOK(hipMemcpyAsync(st2, status, 8, hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
     if (clk) clk->mark("backtrace");
+    if (st2[0] == 4) { *err = "a link reaches further back than the previous column"; return false; }
     if (!lq && res.status == 1) { *err = "no alignment column reaches the end of the window"; return false; }
     if (st2[0] == 2) { *err = lq ? "low-quality backtrace left the graph" : "backtrace left the graph"; return false; }
     if (st2[0] == 3) { *err = "zero coverage on the consensus path"; return false; }
