@@ -48,6 +48,14 @@ def main():
     open(os.path.join(d, "bam.fofn"), "w").write(os.path.join(d, "r.bam") + "\n")
     res = rb.polish(L, os.path.join(d, "g.fa"), os.path.join(d, "bam.fofn"), read_type=1)["ctg0"]
     out["mb_window"] = {"lens": [r[1] for r in res], "md5": [hashlib.md5(r[0].encode()).hexdigest() for r in res]}
+    # a deep pileup (100x): narrow columns are rare, the GPU path widens its cuts from 8 to 32 live entries
+    d = tempfile.mkdtemp(prefix="np2deep_")
+    st = nat.Stream.synth_long([150000], depth=100.0, seed=32)
+    st.write_files(os.path.join(d, "g.fa"), os.path.join(d, "r.bam"))
+    st.close()
+    open(os.path.join(d, "bam.fofn"), "w").write(os.path.join(d, "r.bam") + "\n")
+    res = rb.polish(L, os.path.join(d, "g.fa"), os.path.join(d, "bam.fofn"), read_type=1)["ctg0"]
+    out["deep_window"] = {"lens": [r[1] for r in res], "md5": [hashlib.md5(r[0].encode()).hexdigest() for r in res]}
     # codec known answers: pack then unpack through the reference (incl. the non-ACGT spill of bseq.c:91)
     for s in ["ACGT", "AANAA", "GGNGG", "acgtn", "TTTTTTTTTTTTTTTTA", "NACGT", "ACGTACGTACGTACGTN", "RYKM", "A", "TU"]:
         words = (C.c_uint32 * (len(s) // 16 + 1))()

@@ -119,3 +119,19 @@ def test_gpu_megabase_window_matches_reference_golden(tmp_path):
     want = GOLD["mb_window"]
     assert [p[1] for p in got["ctg0"]] == want["lens"]
     assert [hashlib.md5(p[0].encode()).hexdigest() for p in got["ctg0"]] == want["md5"]
+
+
+def test_gpu_deep_pileup_matches_reference_golden(tmp_path):
+    """100x: few columns with <= 8 live entries, so the run decomposition switches to cuts of width 32."""
+    import hashlib
+    from nextpolish_amd import _native as nat
+    st = nat.Stream.synth_long([150000], depth=100.0, seed=32)
+    fa, bam, fofn = str(tmp_path / "g.fa"), str(tmp_path / "r.bam"), str(tmp_path / "bam.fofn")
+    st.write_files(fa, bam)
+    st.close()
+    open(fofn, "w").write(bam + "\n")
+    got, err = run_polish(PRODUCT_SO, fa, fofn, 1)
+    assert got is not None, err
+    want = GOLD["deep_window"]
+    assert [p[1] for p in got["ctg0"]] == want["lens"]
+    assert [hashlib.md5(p[0].encode()).hexdigest() for p in got["ctg0"]] == want["md5"]
