@@ -135,3 +135,22 @@ def test_gpu_deep_pileup_matches_reference_golden(tmp_path):
     want = GOLD["deep_window"]
     assert [p[1] for p in got["ctg0"]] == want["lens"]
     assert [hashlib.md5(p[0].encode()).hexdigest() for p in got["ctg0"]] == want["md5"]
+
+
+@pytest.mark.skipif(not rb.available(), reason="oracle/_ref did not travel")
+def test_gpu_full_5mb_window_matches_compiled_reference(tmp_path):
+    """The reference's window size at BASELINE configs[3] shape (20x ONT-like reads): one 5 Mb window, 12 500 reads,
+    123 M link observations; the compiled reference needs ~8 s for it."""
+    import hashlib
+    from nextpolish_amd import _native as nat
+    st = nat.Stream.synth_long([5000000], depth=20.0, seed=5)
+    fa, bam, fofn = str(tmp_path / "g.fa"), str(tmp_path / "r.bam"), str(tmp_path / "bam.fofn")
+    st.write_files(fa, bam)
+    st.close()
+    open(fofn, "w").write(bam + "\n")
+    got, err = run_polish(PRODUCT_SO, fa, fofn, 1)
+    assert got is not None, err
+    want, err = run_polish(os.path.realpath(rb.REF_SO), fa, fofn, 1)
+    assert want is not None, err
+    assert got == want
+    assert abs(len(got["ctg0"][0][0]) - 5000000) < 50000

@@ -249,3 +249,12 @@ def test_one_round_score_chain_then_kmer_count(ctx, tmp_path):
     if ref_binary():
         ref = run_ref("kmercount", fa, bam)
         assert [ref[n] for n in st.names] == want
+
+
+def test_full_size_config2_matches_oracle(ctx):
+    """BASELINE config 2 at full size (5 Mb draft in 3 contigs, 50x PE150, 1.67 M records: the bench.py workload): every
+    contig bit-identical to the CPU oracle, and the pass is repeatable."""
+    st = nat.Stream.synth([2500000, 1500000, 1000000], depth=50.0, seed=20250119)
+    got = _check(ctx, st)
+    assert ctx.score_chain(st) == got
+    st.close()
