@@ -167,6 +167,8 @@ typedef struct {
     double clip_rate;
 } np1_synth_long_params;
 np1_stream* np1_stream_synth_long(const np1_synth_long_params* p, const char* contig_name_prefix);
+/* Test hook: the BGZF block decoder (own raw-DEFLATE implementation) on one stream; 1 = accepted and dst filled. */
+int np1_debug_inflate(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len);
 
 /* Device context: one per process per GPU; created lazily AFTER any fork (the reference's callers
  * fork worker pools after config_init, nextpolish1.py:219-223). */

@@ -1,5 +1,6 @@
 // BGZF reader/writer (SAMv1 §4.1).  See np_bgzf.h for the reference call sites this replaces.
 #include "np_bgzf.h"
+#include "np_inflate.h"
 
 #include <zlib.h>
 
@@ -15,6 +16,8 @@ static const size_t kMaxBlock = 65536;       // inflated size limit of one BGZF 
 static const size_t kWriteFill = 0xff00;     // flush threshold used by common writers
 
 bool bgzf_inflate_block(const uint8_t* cdata, size_t clen, uint8_t* out, size_t out_len) {
+    static const bool use_zlib_only = getenv("NP_INFLATE_ZLIB") != nullptr;
+    if (!use_zlib_only && inflate_raw(cdata, clen, out, out_len)) return true;   // own decoder first (np_inflate.cpp), zlib as the referee
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, -15) != Z_OK) return false;

@@ -6,6 +6,7 @@
 #include "../../include/nextpolish1.h"
 #include "np_stream.h"
 #include "np_synth.h"
+#include "np_inflate.h"
 
 struct np1_stream { np::ReadStream s; };
 
@@ -125,6 +126,11 @@ np1_stream* np1_stream_synth_long(const np1_synth_long_params* p, const char* pr
         return nullptr;
     }
     return st;
+}
+
+/* test hook: the BGZF block decoder on a raw DEFLATE stream (1 = accepted and dst filled) */
+int np1_debug_inflate(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) {
+    return np::inflate_raw(src, (size_t)src_len, dst, (size_t)dst_len) ? 1 : 0;
 }
 
 }  // extern "C"

@@ -1,0 +1,89 @@
+"""The BGZF block decoder (nextpolish_amd/csrc/np_inflate.cpp, own raw-DEFLATE implementation) against zlib: every block
+type (stored, fixed, dynamic), every compression level and strategy, data from constant to incompressible, sizes from 0 to
+the 64 KiB of a BGZF block and beyond, and rejection (never a wrong answer) of damaged streams."""
+import ctypes as C
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from nextpolish_amd import _native as nat
+
+
+def _inflate(raw, n):
+    L = nat.lib()
+    L.np1_debug_inflate.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
+    L.np1_debug_inflate.restype = C.c_int
+    out = C.create_string_buffer(max(1, n))
+    ok = L.np1_debug_inflate(raw, len(raw), out, n)
+    return bool(ok), out.raw[:n]
+
+
+def _deflate(data, level, strategy=zlib.Z_DEFAULT_STRATEGY):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    return c.compress(data) + c.flush()
+
+
+def _samples():
+    rng = random.Random(5)
+    nrng = np.random.default_rng(5)
+    yield b""
+    yield b"A"
+    yield b"ACGT" * 16384
+    yield bytes(65536)
+    yield bytes(rng.randrange(256) for _ in range(70000))                      # incompressible: stored blocks at level 0, near-stored above
+    yield bytes(rng.choice(b"ACGT") for _ in range(65280))                     # sequence-like
+    yield nrng.integers(0, 4, 65280, dtype=np.uint8).tobytes()
+    yield (b"".join(bytes([rng.randrange(256)]) * rng.randrange(1, 400) for _ in range(600)))[:65536]   # long runs: distance-1 copies
+    yield bytes((i * i) & 0xff for i in range(65536))
+    yield b"".join(rng.choice([b"the ", b"quick ", b"brown ", b"fox ", b"jumps "]) for _ in range(12000))
+    yield nrng.integers(0, 256, 300, dtype=np.uint8).tobytes() * 200          # far matches (distance up to 300 * n)
+    yield nrng.normal(128, 3, 65536).astype(np.uint8).tobytes()               # skewed alphabet: long Huffman codes
+    for n in (1, 2, 3, 7, 8, 9, 257, 258, 259, 32767, 32768, 32769, 65535):
+        yield bytes(rng.choice(b"ACGTN") for _ in range(n))
+
+
+@pytest.mark.parametrize("level", [0, 1, 4, 6, 9])
+def test_matches_zlib_on_every_block_kind(level):
+    for data in _samples():
+        for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+            raw = _deflate(data, level, strategy)
+            ok, got = _inflate(raw, len(data))
+            assert ok, "level %d strategy %d len %d rejected" % (level, strategy, len(data))
+            assert got == data
+
+
+def test_multi_block_streams_and_flushes():
+    rng = random.Random(9)
+    for _ in range(20):
+        c = zlib.compressobj(rng.choice([1, 6, 9]), zlib.DEFLATED, -15)
+        parts, raw = [], b""
+        for _ in range(rng.randrange(1, 8)):
+            p = bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(0, 9000)))
+            parts.append(p)
+            raw += c.compress(p) + c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_NO_FLUSH]))   # sync flushes add empty stored blocks
+        raw += c.flush()
+        data = b"".join(parts)
+        ok, got = _inflate(raw, len(data))
+        assert ok and got == data
+
+
+def test_damaged_or_mismatched_streams_are_never_wrong():
+    rng = random.Random(3)
+    data = bytes(rng.choice(b"ACGT") for _ in range(40000))
+    raw = _deflate(data, 6)
+    assert _inflate(raw, len(data) - 1)[0] is False       # declared size too small
+    assert _inflate(raw, len(data) + 1)[0] is False       # ... too large
+    assert _inflate(raw[:len(raw) // 2], len(data))[0] is False   # truncated
+    for _ in range(300):                                    # random corruption: rejected, or (rarely) still the right bytes
+        b = bytearray(raw)
+        for _ in range(rng.randrange(1, 4)):
+            b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        ok, got = _inflate(bytes(b), len(data))
+        if ok:
+            try:
+                want = zlib.decompress(bytes(b), -15)
+            except zlib.error:
+                want = None
+            assert want is not None and got == want[:len(data)] and len(want) == len(data)
