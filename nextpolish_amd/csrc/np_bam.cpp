@@ -83,6 +83,49 @@ int BamReader::next(BamRec& r) {
     r.data.resize(rest + 8);   // small tail pad: the trim loops may peek one nibble past the sequence
     if (rest && bg_.read(r.data.data(), rest) != (int64_t)rest) return -1;
     memset(r.data.data() + rest, 0, 8);
+    // A CIGAR with more than 65 535 operations does not fit the 16-bit count: the record then carries the placeholder
+    // "<l_qseq>S<rlen>N" and the real operations in the tag CG:B:I (SAMv1 section 4.2.2).  htslib swaps them in while
+    // reading (bam_tag2cigar), so the reference never sees the placeholder; same here.
+    if (r.n_cigar >= 1 && r.tid >= 0 && r.pos >= 0) {
+        uint32_t c0;
+        memcpy(&c0, r.data.data() + r.l_qname, 4);
+        if ((c0 & 0xfu) == 4 && (int64_t)(c0 >> 4) == (int64_t)r.l_qseq) {
+            const size_t aux0 = (size_t)r.l_qname + 4 * (size_t)r.n_cigar + ((size_t)r.l_qseq + 1) / 2 + (size_t)r.l_qseq;
+            const uint8_t* p = r.data.data() + aux0;
+            const uint8_t* end = r.data.data() + rest;
+            while (p + 3 <= end) {
+                const uint8_t* tag = p;
+                const char ty = (char)p[2];
+                p += 3;
+                size_t sz = 0;
+                if (ty == 'B') {
+                    if (p + 5 > end) break;
+                    const char sub = (char)p[0];
+                    uint32_t cnt;
+                    memcpy(&cnt, p + 1, 4);
+                    const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                    sz = 5 + w * (size_t)cnt;
+                    if (tag[0] == 'C' && tag[1] == 'G' && sub == 'I' && cnt >= r.n_cigar && cnt < (1u << 29) && p + sz <= end) {
+                        std::vector<uint8_t> nd;
+                        nd.reserve(rest + 4 * (size_t)cnt + 8);
+                        nd.insert(nd.end(), r.data.begin(), r.data.begin() + r.l_qname);                       // name
+                        nd.insert(nd.end(), p + 5, p + 5 + 4 * (size_t)cnt);                                  // real CIGAR
+                        nd.insert(nd.end(), r.data.begin() + r.l_qname + 4 * (size_t)r.n_cigar, r.data.begin() + (tag - r.data.data()));   // seq, qual, aux before CG
+                        nd.insert(nd.end(), p + sz, end);                                                       // aux behind CG
+                        nd.resize(nd.size() + 8, 0);
+                        r.data.swap(nd);
+                        r.n_cigar = cnt;
+                        break;
+                    }
+                } else if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+                else if (ty == 's' || ty == 'S') sz = 2;
+                else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+                else if (ty == 'Z' || ty == 'H') { const uint8_t* z = p; while (z < end && *z) ++z; sz = (size_t)(z - p) + 1; }
+                else break;
+                p += sz;
+            }
+        }
+    }
     return 1;
 }
 
