@@ -65,7 +65,10 @@ int BamReader::next(BamRec& r) {
     if (got == 0) return 0;
     if (got != 4 || block_len < 32) return -1;
     uint32_t x[8];
-    if (bg_.read(x, 32) != 32) return -1;
+    r.ext = nullptr;
+    const uint8_t* view = zero_copy_ ? bg_.take_contiguous((size_t)block_len, 16) : nullptr;
+    if (view) memcpy(x, view, 32);
+    else if (bg_.read(x, 32) != 32) return -1;
     r.tid = (int32_t)x[0];
     r.pos = (int32_t)x[1];
     r.l_qname = (uint8_t)(x[2] & 0xff);
@@ -80,8 +83,17 @@ int BamReader::next(BamRec& r) {
     size_t rest = (size_t)block_len - 32;
     if (r.l_qseq < 0 || (size_t)r.l_qname + 4 * (size_t)r.n_cigar + ((size_t)r.l_qseq + 1) / 2 + (size_t)r.l_qseq > rest)
         return -1;
+    if (view) {
+        uint32_t c0 = 0;
+        if (r.n_cigar) memcpy(&c0, view + 32 + r.l_qname, 4);
+        if (!(r.n_cigar && (c0 & 0xfu) == 4 && (int64_t)(c0 >> 4) == (int64_t)r.l_qseq)) {   // (a CG placeholder takes the copying path)
+            r.ext = view + 32;
+            return 1;
+        }
+    }
     r.data.resize(rest + 8);   // small tail pad: the trim loops may peek one nibble past the sequence
-    if (rest && bg_.read(r.data.data(), rest) != (int64_t)rest) return -1;
+    if (view) memcpy(r.data.data(), view + 32, rest);
+    else if (rest && bg_.read(r.data.data(), rest) != (int64_t)rest) return -1;
     memset(r.data.data() + rest, 0, 8);
     // A CIGAR with more than 65 535 operations does not fit the 16-bit count: the record then carries the placeholder
     // "<l_qseq>S<rlen>N" and the real operations in the tag CG:B:I (SAMv1 section 4.2.2).  htslib swaps them in while

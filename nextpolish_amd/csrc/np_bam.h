@@ -32,9 +32,11 @@ struct BamRec {
     int32_t l_qseq = 0, mtid = -1, mpos = -1, isize = 0;
     uint8_t l_qname = 0;
     std::vector<uint8_t> data;   // qname | cigar | seq | qual | aux   (as stored in BAM)
-    const char* qname() const { return reinterpret_cast<const char*>(data.data()); }
-    const uint32_t* cigar() const { return reinterpret_cast<const uint32_t*>(data.data() + l_qname); }
-    const uint8_t* seq() const { return data.data() + l_qname + 4 * (size_t)n_cigar; }
+    const uint8_t* ext = nullptr;   // zero-copy readers: the same bytes inside the BGZF window (valid until the next record)
+    const uint8_t* base() const { return ext ? ext : data.data(); }
+    const char* qname() const { return reinterpret_cast<const char*>(base()); }
+    const uint32_t* cigar() const { return reinterpret_cast<const uint32_t*>(base() + l_qname); }
+    const uint8_t* seq() const { return base() + l_qname + 4 * (size_t)n_cigar; }
     const uint8_t* qual() const { return seq() + ((size_t)l_qseq + 1) / 2; }
     // reference-consumed length, htslib bam_cigar2rlen semantics (M,D,N,=,X consume the reference)
     int32_t rlen() const;
@@ -48,6 +50,9 @@ public:
     const BamHeader& header() const { return hdr_; }
     // returns 1 on success, 0 on clean EOF, -1 on error
     int next(BamRec& r);
+    // records may point into the reader's window instead of owning a copy (r.ext; r.data is then stale): for callers
+    // that consume a record before asking for the next one and only use the accessors
+    void set_zero_copy(bool on) { zero_copy_ = on; }
     bool seek(voff_t v) { return bg_.seek(v); }
     voff_t tell() const { return bg_.tell(); }
     voff_t first_record_offset() const { return first_rec_; }
@@ -56,6 +61,7 @@ private:
     BgzfReader bg_;
     BamHeader hdr_;
     voff_t first_rec_ = 0;
+    bool zero_copy_ = false;
 };
 
 // BAI index (SAMv1 §5.2).

@@ -163,6 +163,30 @@ int64_t BgzfReader::read(void* dst, size_t n) {
     return (int64_t)done;
 }
 
+const uint8_t* BgzfReader::take_contiguous(size_t n, size_t slack) {
+    if (upos_ == ulen_) {
+        if (eof_ || !load_block() || eof_) return nullptr;
+    }
+    if (win_.empty() || win_i_ >= win_.size()) return nullptr;
+    const uint8_t* p = ubuf_ + upos_;
+    const uint8_t* win_end = uwin_.data() + win_.back().upos + win_.back().isize;
+    if ((size_t)(win_end - p) < n + slack) return nullptr;
+    // advance over the blocks the bytes span (the window holds them inflated back to back)
+    size_t left = n;
+    for (;;) {
+        const size_t here = ulen_ - upos_;
+        if (left <= here) { upos_ += (uint32_t)left; break; }
+        left -= here;
+        const WinBlock& b = win_[++win_i_];   // exists: n fits before the end of the window
+        ubuf_ = uwin_.data() + b.upos;
+        block_coff_ = b.coff;
+        next_coff_ = b.coff + b.total;
+        ulen_ = b.isize;
+        upos_ = 0;
+    }
+    return p;
+}
+
 bool BgzfReader::seek(voff_t v) {
     uint64_t coff = v >> 16;
     uint32_t uoff = (uint32_t)(v & 0xffff);

@@ -24,6 +24,10 @@ public:
     void close();
     // Reads exactly n bytes unless EOF; returns bytes read, or -1 on a corrupt block.
     int64_t read(void* dst, size_t n);
+    // The next n inflated bytes as a pointer into the reader's window when they lie there contiguously with `slack`
+    // readable bytes behind them (then they are consumed; valid until the next call on this reader), else nullptr and
+    // nothing is consumed (the caller falls back to read()).
+    const uint8_t* take_contiguous(size_t n, size_t slack);
     bool seek(voff_t v);
     voff_t tell() const;
     bool is_open() const { return fp_ != nullptr; }

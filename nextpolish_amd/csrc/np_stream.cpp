@@ -42,6 +42,7 @@ bool load_stream(const std::string& fasta, const std::string& bam, const std::ve
     if (!fai.load(fasta)) { *err = "cannot load FASTA/index: " + fasta; return false; }
     BamReader rd;
     if (!rd.open(bam)) { *err = "cannot open BAM: " + bam; return false; }
+    rd.set_zero_copy(true);   // every record is consumed (append_record) before the next one is read
     const BamHeader& hdr = rd.header();
 
     std::vector<int> fai_ids;
