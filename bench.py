@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--no-lgs", action="store_true", help="skip the long-read (nextpolish2) leg")
     ap.add_argument("--lgs-workers", type=int, default=8, help="worker processes per GPU of the long-read leg")
     ap.add_argument("--lgs-mb", type=float, default=5.0, help="contig length (Mb) each long-read worker polishes")
-    ap.add_argument("--lgs-calls", type=int, default=2)
+    ap.add_argument("--lgs-calls", type=int, default=4)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
