@@ -1374,7 +1374,9 @@ bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t
     if (clk) clk->mark("dp.cuts");
     const long long C = rule == RULE_LQ ? 2 : (rule == READS_HIFI || rule == RULE_LQ_HIFI) ? 4 : 3;
     const bool dense = n_runs >= 16384 && !getenv("NP2_RUN_PER_WAVE");   // enough runs to fill the chip with several per wave
-    const uint32_t rpw_ac = dense ? 64u / (K + 1) : 1u, rpw_dp = dense ? 64u : 1u;
+    uint32_t rpw_ac = dense ? 64u / (K + 1) : 1u, rpw_dp = dense ? 64u : 1u;
+    if (getenv("NP2_RPW_DP")) rpw_dp = std::min(64u, std::max(1u, (uint32_t)atoi(getenv("NP2_RPW_DP"))));   // tuning experiments
+    if (getenv("NP2_RPW_AC")) rpw_ac = std::min(64u / (K + 1), std::max(1u, (uint32_t)atoi(getenv("NP2_RPW_AC"))));
     k2_run_ac<K><<<nblk(n_runs, rpw_ac), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, eav_.as<long long>(), runoff_.as<uint32_t>(), runt_.as<RT>(),
                                                       rpw_ac, status);
     if (clk) clk->mark("dp.ac");
