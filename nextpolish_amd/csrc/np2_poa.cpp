@@ -8,6 +8,7 @@
 //                                                 heaviest path with -0.5 * indegree :555-595)
 //   align              source/lib/align.c:39-177 (band pruning at best_m - 150, gap runs > 250 abort)
 // including their integer widths (16-bit node ids and score back-pointers, 8-bit degrees).
+#include <algorithm>
 #include <cassert>
 #include <cstdint>
 #include <cstdlib>
@@ -66,6 +67,21 @@ struct Graph {
         if (edges.size() <= edge_count) edges.resize(edges.size() + 512);
         return edge_count - 1;
     }
+    // the graph object is kept per host thread and reused: only what the previous consensus touched is cleaned
+    void reset(size_t want_nodes, size_t want_edges) {
+        const size_t un = std::min(nodes.size(), (size_t)node_count + 2), ue = std::min(edges.size(), (size_t)edge_count + 2);
+        for (size_t i = 0; i < un; ++i) {
+            PNode& n = nodes[i];
+            n.base = 0; n.indegree = 0; n.outdegree = 0; n.alignedto.clear(); n.best_pnode = -1; n.best_score = 0;
+        }
+        for (size_t i = 0; i < ue; ++i) { edges[i].innode_index = 0; edges[i].outnode_index = 0; memset(edges[i].lable, 0, sizeof(edges[i].lable)); }
+        node_count = 0;
+        edge_count = 0;
+        sorted_nodes_index = 0;
+        if (nodes.size() < want_nodes) nodes.resize(want_nodes);
+        if (edges.size() < want_edges) edges.resize(want_edges);
+        if (sorted_nodes.size() < nodes.size()) sorted_nodes.resize(nodes.size());
+    }
     void link(int32_t head, int32_t node, uint32_t e) {
         nodes[(size_t)head].outedge[nodes[(size_t)head].outdegree++] = e;
         nodes[(size_t)node].inedge[nodes[(size_t)node].indegree++] = e;
@@ -93,8 +109,10 @@ uint16_t predecessors(const Graph& g, uint16_t i) {
 
 void topo_visit(int32_t found, uint16_t pnid_count, const std::vector<uint16_t>& pn_to_nodes, const std::vector<int32_t>& node_to_pn,
                 std::vector<int8_t>& completed, Graph* g) {
-    std::vector<int8_t> started(pnid_count, -1);
-    std::vector<uint16_t> stack;
+    static thread_local std::vector<int8_t> started;
+    static thread_local std::vector<uint16_t> stack;
+    started.assign(pnid_count, -1);
+    stack.clear();
     stack.push_back((uint16_t)found);
     while (!stack.empty()) {
         const uint16_t pnid = stack.back();
@@ -119,8 +137,10 @@ void topo_visit(int32_t found, uint16_t pnid_count, const std::vector<uint16_t>&
 }
 
 void toposort(Graph* g) {
-    std::vector<int32_t> node_to_pn(g->node_count, -1);
-    std::vector<uint16_t> pn_to_nodes(g->node_count);
+    static thread_local std::vector<int32_t> node_to_pn;
+    static thread_local std::vector<uint16_t> pn_to_nodes;
+    node_to_pn.assign(g->node_count, -1);
+    pn_to_nodes.assign(g->node_count, 0);
     uint16_t cur_pnid = 0;
     for (uint16_t i = 0; i < g->node_count; ++i) {
         if (node_to_pn[i] == -1) {
@@ -130,7 +150,8 @@ void toposort(Graph* g) {
             ++cur_pnid;
         }
     }
-    std::vector<int8_t> completed(cur_pnid, -1);
+    static thread_local std::vector<int8_t> completed;
+    completed.assign(cur_pnid, -1);
     g->sorted_nodes_index = (int32_t)g->node_count - 1;
     while (g->sorted_nodes_index >= 0) {
         int32_t found = -1;
@@ -144,10 +165,12 @@ void toposort(Graph* g) {
 void align_seq_to_graph(uint16_t x, uint16_t y, size_t seq_index, const char* seq, Graph* g) {
     // ---- score table ((x + 1) x (y + 1)), row 0 = before any node (score_init, dag.c:88-138)
     const size_t W = (size_t)y + 1;
-    std::vector<PScore> tab(((size_t)x + 1) * W);
+    static thread_local std::vector<PScore> tab;
+    tab.assign(((size_t)x + 1) * W, PScore());
     auto S = [&](size_t i, size_t j) -> PScore& { return tab[i * W + j]; };
     for (size_t i = 0; i < W; ++i) S(0, i).s = (long)i * SCORE_GAP;
-    std::vector<uint16_t> sorted_nodes_index(g->node_count);
+    static thread_local std::vector<uint16_t> sorted_nodes_index;
+    sorted_nodes_index.assign(g->node_count, 0);
     for (uint16_t i = 0; i < g->node_count; ++i) {
         const uint16_t node_index = g->sorted_nodes[i];
         sorted_nodes_index[node_index] = i;
@@ -202,7 +225,8 @@ void align_seq_to_graph(uint16_t x, uint16_t y, size_t seq_index, const char* se
     }
     uint16_t besty = y;
     // ---- match route (dag.c:327-343)
-    std::vector<MatchRoute> route((size_t)x + y + 1, MatchRoute{-1, -1});
+    static thread_local std::vector<MatchRoute> route;
+    route.assign((size_t)x + y + 1, MatchRoute{-1, -1});
     int64_t starty = -1, endy = -1;
     uint32_t mroute_count = 0;
     while (bestx != 0 || besty != 0) {
@@ -275,12 +299,11 @@ void align_seq_to_graph(uint16_t x, uint16_t y, size_t seq_index, const char* se
 }  // namespace
 
 std::string poa_consensus(const std::vector<std::string>& seqs) {
-    Graph g;
+    static thread_local Graph tl_graph;
+    Graph& g = tl_graph;
     size_t total = 0;
     for (const std::string& s : seqs) total += s.size() + 2;
-    g.nodes.resize(total + 16);          // (the reference starts at 10 000 nodes and grows; capacity is not observable)
-    g.edges.resize(2 * total + 32);
-    g.sorted_nodes.resize(total + 16);
+    g.reset(total + 16, 2 * total + 32);   // (the reference starts at 10 000 nodes and grows; capacity is not observable)
     assert((int)seqs.size() <= SEQ_MAX_COUNT);
     for (size_t si = 0; si < seqs.size(); ++si) {
         const std::string& s = seqs[si];
