@@ -159,7 +159,7 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
     for (Region& r : lq) {
         r.sudoseed.clear();
         r.lqcount = 0; r.len = 0; r.sudoseed_len = 0;
-        r.seqs.assign(LQSEQ_MAX_CAN_COUNT, Cand());
+        r.seqs.clear();   // grown on acceptance (at most LQSEQ_MAX_CAN_COUNT)
     }
     // every (stream, region) pair with the region inside the stream's span, in the reference's visiting order (streams
     // ascending, regions from the lowest position up); the strings come from the executor (tag streams in HBM)
@@ -190,6 +190,7 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
             const size_t rq = v.req0 + (size_t)(v.hi - k);
             const uint32_t index = off[rq + 1] - off[rq];
             if (kmer ? index != 0 : ((r.l && index) || index > r.end - r.start + 1)) {
+                if (r.seqs.size() <= (size_t)r.len) r.seqs.emplace_back();
                 Cand& cd = r.seqs[(size_t)r.len];
                 cd.seq.assign(bases, off[rq], index);
                 cd.len = index;
@@ -213,6 +214,7 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
         const LqCluster& c = clusters[(size_t)clusters_i--];
         for (const std::string& s : c.cands) {
             if (r.len >= LQSEQ_MAX_CAN_COUNT) break;
+            if (r.seqs.size() <= (size_t)r.len) r.seqs.emplace_back();
             Cand& cd = r.seqs[(size_t)r.len];
             cd.seq = s;
             cd.len = (uint32_t)s.size();
