@@ -567,7 +567,7 @@ int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
         HIPCHK(hipMemcpyAsync(&M, &totals[0], 8, hipMemcpyDeviceToHost, q));
         HIPCHK(hipStreamSynchronize(q));
         const uint32_t reg_cap = (uint32_t)(M + nc + 16);
-        if (b->kc_flagged.ensure(4 * (M + 4)) || b->kc_work.ensure(4 * (2 * M + 4ull * nc + 16)) || b->kc_nd_ctg.ensure(4ull * reg_cap) ||
+        if (b->kc_flagged.ensure(4 * (M + 4)) || b->kc_work.ensure(4 * (12 * M + 4ull * nc + 64)) || b->kc_nd_ctg.ensure(4ull * reg_cap) ||
             b->kc_nd_se.ensure(8ull * reg_cap) || b->kc_kr_ctg.ensure(4ull * reg_cap) || b->kc_kr_se.ensure(8ull * reg_cap))
             return -1;
         kc_launch_compact(q, b->kc_flag.as<uint8_t>(), b->kc_fpos.as<uint32_t>(), (uint32_t)G, b->kc_flagged.as<uint32_t>());

@@ -53,14 +53,50 @@ __global__ __launch_bounds__(256) void k_kc_compact(const uint8_t* __restrict__ 
     if (g < G && flag[g]) flagged[fpos[g]] = g;
 }
 
-// one lane per contig: no-depth and k-mer regions on the compacted list, merged (kmercount.c:97-106).
+// one workgroup (one wave) per contig: no-depth and k-mer regions on the compacted list, merged (kmercount.c:97-106).
 // Regions of a contig land contiguously and in order in the flat arrays (block allocated per contig).
+//
+// The reference walks the contig base by base (np1_kmer.h kc_find_regions is its sparse, still sequential, statement).
+// A region never spans two flagged positions more than `gap` apart, so the list falls into RUNS at those gaps and a
+// run's region (first/last position, adjacent streak at its end, closing position, edge extension incl. the
+// homopolymer walk through the draft) does not depend on the other runs -- computed one run per lane.  What couples
+// runs is only the walk's cursor: an extended region can swallow the first positions of the runs behind it.  A last
+// sequential pass (one lane, run records staged 64 at a time through LDS) replays exactly that: a run whose first
+// position lies behind the cursor is recomputed from its first surviving position (rare), the others are taken as they
+// are.  Then the literal merge.
+struct KcRun { int32_t first_pos, s, e, close_i; uint32_t emit, first_k, last_k, pad; };   // one run of one pass
+constexpr uint32_t KC_REG_LDS_WORDS = 36864;   // 144 KiB of dynamic LDS
+
+// the region of the run F[k0..k1] (inclusive) as the walk would close it when it starts at k0
+__device__ __forceinline__ void kc_run_region(const uint32_t* F, uint32_t k0, uint32_t k1, const uint8_t* code, const uint8_t* flag, int32_t L,
+                                              uint32_t gap, uint32_t con, int32_t ext, bool with_ext, KcRun* out) {
+    const int32_t end = L - 1;
+    int32_t qstart = (int32_t)F[k0], qend = (int32_t)F[k1];
+    uint32_t pcon = 1;   // adjacent flagged positions ending at the run's last one; a uint16 counter in the reference (it wraps)
+    for (uint32_t k = k1; k > k0 && F[k] - F[k - 1] == 1u; --k) ++pcon;
+    const int64_t close_i = (int64_t)F[k1] + (int64_t)gap + 1;
+    const bool open_end = close_i > end;
+    const bool emit = open_end || (pcon & 0xffffu) > con;
+    if (emit) kc_brim(code, flag, ext, with_ext, 0, end, &qstart, &qend);
+    out->first_pos = (int32_t)F[k0];
+    out->s = qstart;
+    out->e = qend;
+    out->close_i = close_i > 0x7fffffff ? 0x7fffffff : (int32_t)close_i;
+    out->emit = emit ? (open_end ? 2u : 1u) : 0u;
+    out->first_k = k0;
+    out->last_k = k1;
+    out->pad = 0;
+}
+
 __global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const uint32_t* __restrict__ fpos,
                                                    uint32_t* __restrict__ flagged_local, int32_t* __restrict__ work,
                                                    uint32_t* __restrict__ nd_ctg, int32_t* __restrict__ nd_se,
                                                    uint32_t* __restrict__ kr_ctg, int32_t* __restrict__ kr_se,
                                                    uint32_t reg_cap, uint32_t* __restrict__ counters) {
-    const uint32_t ct = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ uint32_t sh_words[];
+    __shared__ KcRun sh_run[64];
+    __shared__ uint32_t sh_nr, sh_o, sh_fail;
+    const uint32_t ct = blockIdx.x, lane = threadIdx.x;
     if (ct >= nc) return;
     const uint32_t g0 = c.ctg_off[ct], g1 = c.ctg_off[ct + 1];
     const int32_t L = (int32_t)(g1 - g0);
@@ -69,30 +105,103 @@ __global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const u
     const uint32_t m = f1 - f0;
     if (m == 0) return;
     uint32_t* fl = flagged_local + f0;
-    for (uint32_t k = 0; k < m; ++k) fl[k] -= g0;   // global draft index -> position inside the contig
-    int32_t* buf = work + 2ull * f0 + 4ull * ct;   // room for 2*m + 4 values
-    const int32_t cap = (int32_t)(2 * m + 4);
+    const bool list_in_lds = m <= KC_REG_LDS_WORDS;
+    const bool buf_in_lds = (uint64_t)m + 2ull * m + 4 <= KC_REG_LDS_WORDS;
+    for (uint32_t k = lane; k < m; k += 64) {   // global draft index -> position inside the contig
+        const uint32_t v = fl[k] - g0;
+        fl[k] = v;
+        if (list_in_lds) sh_words[k] = v;
+    }
+    __syncthreads();
+    const uint32_t* F = list_in_lds ? sh_words : fl;
+    // per-contig scratch in HBM: 2m + 4 values for the walk's output, m run starts, then the run records
+    int32_t* gbuf = work + 12ull * f0 + 4ull * ct;
+    uint32_t* rs = reinterpret_cast<uint32_t*>(gbuf + 2ull * m + 4);
+    KcRun* runs = reinterpret_cast<KcRun*>(rs + m + (m & 1u));   // 8-byte aligned: 12 f0 + 4 ct + 2m + 4 + m (+1) is even
+    int32_t* buf = buf_in_lds ? reinterpret_cast<int32_t*>(sh_words + m) : gbuf;
+    const uint8_t* code = c.draft_code + g0;
+    const uint8_t* flag = c.draft_flag + g0;
     for (int pass = 0; pass < 2; ++pass) {
-        int32_t k = pass == 0 ? kc_find_regions(c.draft_code + g0, c.draft_flag + g0, L, fl, m, 0, (uint32_t)c.min_len_ldr,
-                                                c.ext_len_edge, false, buf, cap)
-                              : kc_find_regions(c.draft_code + g0, c.draft_flag + g0, L, fl, m, (uint32_t)c.min_len_inter_kmer, 0,
-                                                c.ext_len_edge, true, buf, cap);
-        if (k < 0) { atomicOr(c.err, ERR_KC_REGIONS); return; }
-        k = kc_merge_regions(buf, k);
-        const uint32_t nr = (uint32_t)k / 2;
-        if (nr == 0) continue;
-        const uint32_t o = atomicAdd(&counters[pass == 0 ? KCC_NODEPTH : KCC_KREG], nr);
-        if (o + nr > reg_cap) { atomicOr(c.err, ERR_KC_REGIONS); return; }
+        const uint32_t gap = pass == 0 ? 0u : (uint32_t)c.min_len_inter_kmer, con = pass == 0 ? (uint32_t)c.min_len_ldr : 0u;
+        const bool with_ext = pass == 1;
+        // ---- runs: starts where the distance to the previous flagged position exceeds the gap (wave compaction)
+        uint32_t n_runs = 0;
+        for (uint32_t base = 0; base < m; base += 64) {
+            const uint32_t k = base + lane;
+            const bool st = k < m && (k == 0 || F[k] - F[k - 1] - 1u > gap);
+            const unsigned long long mk = __ballot(st);
+            if (st) rs[n_runs + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = k;
+            n_runs += (uint32_t)__popcll(mk);
+        }
+        __threadfence_block();
+        __syncthreads();
+        // ---- every run on its own (the edge extension reads the draft: this is where the latency is, now in parallel)
+        for (uint32_t r = lane; r < n_runs; r += 64) {
+            const uint32_t k0 = rs[r], k1 = (r + 1 < n_runs ? rs[r + 1] : m) - 1;
+            KcRun rr;
+            kc_run_region(F, k0, k1, code, flag, L, gap, con, c.ext_len_edge, with_ext, &rr);
+            runs[r] = rr;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // ---- the cursor, sequentially over the runs (staged 64 at a time)
+        int32_t n_out = 0;
+        int64_t cursor = 0;
+        bool done = false;
+        for (uint32_t base = 0; base < n_runs; base += 64) {
+            if (base + lane < n_runs) sh_run[lane] = runs[base + lane];
+            __syncthreads();
+            if (lane == 0 && !done) {
+                const uint32_t cnt = n_runs - base < 64u ? n_runs - base : 64u;
+                for (uint32_t t = 0; t < cnt; ++t) {
+                    KcRun rr = sh_run[t];
+                    if ((int64_t)rr.first_pos < cursor) {   // the previous region's extension swallowed the run's first positions
+                        uint32_t k0 = rr.first_k;
+                        while (k0 <= rr.last_k && (int64_t)F[k0] < cursor) ++k0;
+                        if (k0 > rr.last_k) continue;       // the whole run lies behind the cursor
+                        kc_run_region(F, k0, rr.last_k, code, flag, L, gap, con, c.ext_len_edge, with_ext, &rr);
+                    }
+                    cursor = (int64_t)rr.close_i + 1;
+                    if (rr.emit) {
+                        buf[n_out++] = rr.s;
+                        buf[n_out++] = rr.e;
+                        if (rr.emit == 2u) { done = true; break; }   // the walk ended with the region still open
+                        if ((int64_t)rr.e > (int64_t)rr.close_i) cursor = (int64_t)rr.e + 1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (lane == 0) {
+            uint32_t fail = 0, nr = 0, o = 0;
+            const int32_t k = kc_merge_regions(buf, n_out);
+            nr = (uint32_t)k / 2;
+            if (nr) {
+                o = atomicAdd(&counters[pass == 0 ? KCC_NODEPTH : KCC_KREG], nr);
+                if (o + nr > reg_cap) fail = 1;
+            }
+            if (fail) atomicOr(c.err, ERR_KC_REGIONS);
+            sh_nr = nr; sh_o = o; sh_fail = fail;
+            __threadfence_block();
+        }
+        __syncthreads();
+        if (sh_fail) return;
+        const uint32_t nr = sh_nr, o = sh_o;
         uint32_t* dc = pass == 0 ? nd_ctg : kr_ctg;
         int32_t* ds = pass == 0 ? nd_se : kr_se;
         unsigned long long len_sum = 0;
-        for (uint32_t i = 0; i < nr; ++i) {
+        for (uint32_t i = lane; i < nr; i += 64) {
+            const int32_t a = buf[2 * i], b = buf[2 * i + 1];
             dc[o + i] = ct;
-            ds[2 * (o + i)] = buf[2 * i];
-            ds[2 * (o + i) + 1] = buf[2 * i + 1];
-            len_sum += (unsigned long long)(buf[2 * i + 1] - buf[2 * i] + 1);
+            ds[2 * (o + i)] = a;
+            ds[2 * (o + i) + 1] = b;
+            len_sum += (unsigned long long)(b - a + 1);
         }
-        if (pass == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[KCC_ND_LEN]), len_sum);
+        if (pass == 0) {
+            for (int sft = 32; sft > 0; sft >>= 1) len_sum += __shfl_down(len_sum, sft);
+            if (lane == 0 && len_sum) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[KCC_ND_LEN]), len_sum);
+        }
+        __syncthreads();
     }
 }
 
@@ -211,7 +320,14 @@ void kc_launch_compact(hipStream_t st, const uint8_t* flag, const uint32_t* fpos
 }
 void kc_launch_regions(hipStream_t st, const KcCtx& c, uint32_t nc, const uint32_t* fpos, uint32_t* flagged, int32_t* work,
                        uint32_t* nd_ctg, int32_t* nd_se, uint32_t* kr_ctg, int32_t* kr_se, uint32_t reg_cap, uint32_t* counters) {
-    if (nc) k_kc_regions<<<kblk(nc, 64), 64, 0, st>>>(c, nc, fpos, flagged, work, nd_ctg, nd_se, kr_ctg, kr_se, reg_cap, counters);
+    if (nc) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kc_regions), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KC_REG_LDS_WORDS * 4));
+            attr_set = true;
+        }
+        k_kc_regions<<<nc, 64, KC_REG_LDS_WORDS * 4, st>>>(c, nc, fpos, flagged, work, nd_ctg, nd_se, kr_ctg, kr_se, reg_cap, counters);
+    }
 }
 void kc_launch_inserts(hipStream_t st, const KcCtx& c, const uint32_t* kr_ctg, const int32_t* kr_se, uint32_t n_kr,
                        const uint32_t* nd_ctg, const int32_t* nd_se, uint32_t n_nd, uint32_t* ins) {

@@ -258,3 +258,12 @@ def test_full_size_config2_matches_oracle(ctx):
     got = _check(ctx, st)
     assert ctx.score_chain(st) == got
     st.close()
+
+
+def test_full_size_kmer_count_matches_oracle(ctx):
+    """kmer_count at the bench shape (5 Mb draft in 3 contigs, 50x PE150 with qualities, 0.4 % of the draft flagged): ~10 000
+    flagged positions per contig, so the run-parallel region discovery, its sequential cursor pass and the scratch
+    layout are exercised at scale."""
+    st = nat.Stream.synth([2500000, 1500000, 1000000], depth=50.0, seed=20250120, with_qual=1, draft_lower=0.004)
+    _check_kmer(ctx, st)
+    st.close()
