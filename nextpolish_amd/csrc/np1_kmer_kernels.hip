@@ -7,6 +7,7 @@
 // positions, insertion columns, level-2/level-1 score chain on the no-depth regions, region splitting,
 // spanning-read haplotype vote), and the shared scan + k_emit for the output.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "np1_core.h"
@@ -16,6 +17,11 @@
 namespace np1k {
 
 static inline unsigned kblk(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+// active lanes per wave of the lane-per-region kernels (NP1_KC_LANES, default 4: measured 27 / 18 / 16 ms per pass at 64 / 8 / 4)
+static inline unsigned kc_lanes() {
+    static const unsigned v = [] { const char* e = getenv("NP1_KC_LANES"); const int x = e ? atoi(e) : 4; return (unsigned)(x < 1 ? 1 : x > 64 ? 64 : x); }();
+    return v;
+}
 
 // per record: filter level, end position, longest reference span
 __global__ __launch_bounds__(256) void k_kc_records(KcCtx c, int64_t n_all, uint8_t* __restrict__ level,
@@ -88,13 +94,40 @@ __device__ __forceinline__ void kc_run_region(const uint32_t* F, uint32_t k0, ui
     out->pad = 0;
 }
 
+// contig_merge_region (np1_kmer.h kc_merge_regions is the literal statement) walked by the whole wave with uniform control
+// flow: lane t preloads input region base + t, the last output region lives in registers, lane 0 stores.  Needs the
+// first region to have start < end (then the output never runs ahead of the input); the caller checks.
+__device__ __forceinline__ int32_t kc_merge_wave(int32_t* v, int32_t n, uint32_t lane) {
+    const int32_t nreg = n / 2;
+    int32_t qi = 0, qs = v[0], qe = v[1], length = 2;
+    for (int32_t base = 0; base < nreg; base += 64) {
+        const int32_t mine = base + (int32_t)lane < nreg ? base + (int32_t)lane : nreg - 1;
+        const int32_t ms = v[2 * mine], me = v[2 * mine + 1];
+        const int32_t cnt = nreg - base < 64 ? nreg - base : 64;
+        for (int32_t t = 0; t < cnt; ++t) {
+            const int32_t ps = __builtin_amdgcn_readlane(ms, t), pe = __builtin_amdgcn_readlane(me, t);
+            if (ps >= qe) {
+                ++qi;
+                qs = ps;
+                qe = pe;
+                if (lane == 0) { v[2 * qi] = qs; v[2 * qi + 1] = qe; }
+                length += 2;
+            } else {
+                while (ps < qs) { --qi; qs = v[2 * qi]; }
+                qe = pe;
+                if (lane == 0) v[2 * qi + 1] = qe;
+            }
+        }
+    }
+    return length;
+}
+
 __global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const uint32_t* __restrict__ fpos,
                                                    uint32_t* __restrict__ flagged_local, int32_t* __restrict__ work,
                                                    uint32_t* __restrict__ nd_ctg, int32_t* __restrict__ nd_se,
                                                    uint32_t* __restrict__ kr_ctg, int32_t* __restrict__ kr_se,
                                                    uint32_t reg_cap, uint32_t* __restrict__ counters) {
     extern __shared__ uint32_t sh_words[];
-    __shared__ KcRun sh_run[64];
     __shared__ uint32_t sh_nr, sh_o, sh_fail;
     const uint32_t ct = blockIdx.x, lane = threadIdx.x;
     if (ct >= nc) return;
@@ -144,37 +177,88 @@ __global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const u
         }
         __threadfence_block();
         __syncthreads();
-        // ---- the cursor, sequentially over the runs (staged 64 at a time)
-        int32_t n_out = 0;
-        int64_t cursor = 0;
-        bool done = false;
+        // ---- the cursor.  It only moves past the next run's first position when an extended region reaches that far.
+        // Neighbour test in parallel: a run that starts at or behind the cursor its predecessor leaves (closing position
+        // + 1, or the extended end + 1) is taken as computed.  The others start short chains that are replayed like the
+        // reference's walk (recompute from the first surviving position, or drop a swallowed run) until a run is again
+        // taken as computed; the chains update the run records in place.  Output = the emitted runs in order.
+        auto reach_of = [](const KcRun& x) -> int64_t {
+            return (x.emit == 1u && (int64_t)x.e > (int64_t)x.close_i) ? (int64_t)x.e + 1 : (int64_t)x.close_i + 1;
+        };
+        uint32_t* bad_list = rs;   // (the run starts are not needed any more)
+        uint32_t n_bad = 0;
         for (uint32_t base = 0; base < n_runs; base += 64) {
-            if (base + lane < n_runs) sh_run[lane] = runs[base + lane];
-            __syncthreads();
-            if (lane == 0 && !done) {
-                const uint32_t cnt = n_runs - base < 64u ? n_runs - base : 64u;
-                for (uint32_t t = 0; t < cnt; ++t) {
-                    KcRun rr = sh_run[t];
-                    if ((int64_t)rr.first_pos < cursor) {   // the previous region's extension swallowed the run's first positions
-                        uint32_t k0 = rr.first_k;
-                        while (k0 <= rr.last_k && (int64_t)F[k0] < cursor) ++k0;
-                        if (k0 > rr.last_k) continue;       // the whole run lies behind the cursor
-                        kc_run_region(F, k0, rr.last_k, code, flag, L, gap, con, c.ext_len_edge, with_ext, &rr);
+            const uint32_t r = base + lane;
+            bool bad = false;
+            if (r < n_runs && r > 0) {
+                const KcRun pv = runs[r - 1];
+                bad = pv.emit == 2u || (int64_t)runs[r].first_pos < reach_of(pv);
+            }
+            const unsigned long long mb = __ballot(bad);
+            if (bad) bad_list[n_bad + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull))] = r;
+            n_bad += (uint32_t)__popcll(mb);
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (n_bad) {   // wave-uniform: every lane follows the same chain, lane 0 writes
+            uint32_t next_q = 0;
+            bool ended = false;
+            for (uint32_t b = 0; b < n_bad && !ended; ++b) {
+                uint32_t q = bad_list[b];
+                if (q < next_q) continue;               // inside the previous chain
+                int64_t cursor = reach_of(runs[q - 1]);
+                for (; q < n_runs; ++q) {
+                    KcRun rr = runs[q];
+                    if ((int64_t)rr.first_pos >= cursor) break;     // taken as computed: back in step with the parallel result
+                    uint32_t k0 = rr.first_k;
+                    while (k0 <= rr.last_k && (int64_t)F[k0] < cursor) ++k0;
+                    if (k0 > rr.last_k) {                           // the whole run lies behind the cursor: no region, cursor stays
+                        rr.emit = 0;
+                        rr.close_i = (int32_t)(cursor - 1);         // so that a later chain starting behind it sees the same cursor
+                        rr.e = rr.close_i;
+                        if (lane == 0) runs[q] = rr;
+                        continue;
                     }
-                    cursor = (int64_t)rr.close_i + 1;
-                    if (rr.emit) {
-                        buf[n_out++] = rr.s;
-                        buf[n_out++] = rr.e;
-                        if (rr.emit == 2u) { done = true; break; }   // the walk ended with the region still open
-                        if ((int64_t)rr.e > (int64_t)rr.close_i) cursor = (int64_t)rr.e + 1;
-                    }
+                    kc_run_region(F, k0, rr.last_k, code, flag, L, gap, con, c.ext_len_edge, with_ext, &rr);
+                    rr.first_k = k0;
+                    if (lane == 0) runs[q] = rr;
+                    cursor = reach_of(rr);
+                    if (rr.emit == 2u) { ended = true; break; }     // the walk ended with the region still open
                 }
+                next_q = q + 1;
+                __threadfence_block();
             }
             __syncthreads();
         }
+        int32_t n_out = 0;
+        for (uint32_t base = 0; base < n_runs; base += 64) {
+            const uint32_t r = base + lane;
+            KcRun me;
+            me.s = 0; me.e = 0; me.emit = 0;
+            if (r < n_runs) me = runs[r];
+            const bool em = r < n_runs && me.emit != 0u;
+            const unsigned long long mk = __ballot(em);
+            if (em) {
+                const int32_t idx = n_out + 2 * (int32_t)__popcll(mk & ((1ull << lane) - 1ull));
+                buf[idx] = me.s;
+                buf[idx + 1] = me.e;
+            }
+            n_out += 2 * (int32_t)__popcll(mk);
+        }
+        __threadfence_block();
+        __syncthreads();
+        // merge: nothing to do when no region starts before its predecessor ends (the usual case; contig.c:595-620 then copies)
+        bool overlap = false;
+        for (int32_t i = (int32_t)lane + 1; i < n_out / 2; i += 64) overlap = overlap || buf[2 * i] < buf[2 * (i - 1) + 1];
+        const bool any_overlap = __ballot(overlap) != 0ull;
+        int32_t merged = n_out;
+        if (any_overlap) {
+            if (buf[0] < buf[1]) merged = kc_merge_wave(buf, n_out, lane);                 // (all lanes)
+            else { if (lane == 0) sh_nr = (uint32_t)kc_merge_regions(buf, n_out); __syncthreads(); merged = (int32_t)sh_nr; __syncthreads(); }
+        }
         if (lane == 0) {
             uint32_t fail = 0, nr = 0, o = 0;
-            const int32_t k = kc_merge_regions(buf, n_out);
+            const int32_t k = merged;
             nr = (uint32_t)k / 2;
             if (nr) {
                 o = atomicAdd(&counters[pass == 0 ? KCC_NODEPTH : KCC_KREG], nr);
@@ -230,9 +314,11 @@ __global__ __launch_bounds__(256) void k_kc_slots(const uint8_t* __restrict__ sl
 // one lane per chain of no-depth regions (regions sharing an end point are solved in order by the same lane,
 // like the reference's sequential loop, kmercount.c:107-114)
 __global__ __launch_bounds__(64) void k_kc_nodepth(KcCtx c, const uint32_t* __restrict__ nd_ctg, const int32_t* __restrict__ nd_se,
-                                                   uint32_t n_nd) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nd) return;
+                                                   uint32_t n_nd, uint32_t lanes) {
+    // every lane walks one region serially (records, slots, DP): few regions per wave keep the waves short and spread
+    // them over all SIMDs (`lanes` active lanes per wave)
+    const uint32_t i = blockIdx.x * lanes + threadIdx.x;
+    if (threadIdx.x >= lanes || i >= n_nd) return;
     const uint32_t ct = nd_ctg[i];
     if (i > 0 && nd_ctg[i - 1] == ct && nd_se[2 * (i - 1) + 1] == nd_se[2 * i]) return;   // not a chain head
     for (uint32_t k = i;; ++k) {
@@ -273,9 +359,9 @@ __global__ __launch_bounds__(64) void k_kc_split(KcCtx c, const uint32_t* __rest
 __global__ __launch_bounds__(64) void k_kc_winner(KcCtx c, const uint32_t* __restrict__ pt_ctg, const int32_t* __restrict__ pt_se,
                                                   const uint32_t* __restrict__ pt_len, const uint32_t* __restrict__ woff,
                                                   uint32_t n_parts, int64_t n_all, uint8_t* __restrict__ wpool,
-                                                  uint8_t* __restrict__ has_winner) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_parts) return;
+                                                  uint8_t* __restrict__ has_winner, uint32_t lanes) {
+    const uint32_t p = blockIdx.x * lanes + threadIdx.x;   // `lanes` parts per wave (see k_kc_nodepth)
+    if (threadIdx.x >= lanes || p >= n_parts) return;
     const uint32_t ct = pt_ctg[p];
     const bool has_next = (int64_t)c.read_begin[ct + 1] < n_all;
     has_winner[p] = (uint8_t)kc_part_winner(c, ct, pt_se[2 * p], pt_se[2 * p + 1], has_next, wpool + woff[p], (int32_t)pt_len[p]);
@@ -338,7 +424,7 @@ void kc_launch_slots(hipStream_t st, const uint8_t* slot_info, uint32_t S, uint8
     if (S) k_kc_slots<<<kblk(S, 256), 256, 0, st>>>(slot_info, S, sbase, sflag, scount, lhead);
 }
 void kc_launch_nodepth(hipStream_t st, const KcCtx& c, const uint32_t* nd_ctg, const int32_t* nd_se, uint32_t n_nd) {
-    if (n_nd) k_kc_nodepth<<<kblk(n_nd, 64), 64, 0, st>>>(c, nd_ctg, nd_se, n_nd);
+    if (n_nd) k_kc_nodepth<<<kblk(n_nd, kc_lanes()), 64, 0, st>>>(c, nd_ctg, nd_se, n_nd, kc_lanes());
 }
 void kc_launch_split(hipStream_t st, const KcCtx& c, const uint32_t* kr_ctg, const int32_t* kr_se, uint32_t n_kr, int32_t* work,
                      const uint32_t* work_off, uint32_t* n_parts, const uint32_t* part_off, uint32_t* pt_ctg, int32_t* pt_se,
@@ -347,7 +433,7 @@ void kc_launch_split(hipStream_t st, const KcCtx& c, const uint32_t* kr_ctg, con
 }
 void kc_launch_winner(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len,
                       const uint32_t* woff, uint32_t n_parts, int64_t n_all, uint8_t* wpool, uint8_t* has_winner) {
-    if (n_parts) k_kc_winner<<<kblk(n_parts, 64), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, n_all, wpool, has_winner);
+    if (n_parts) k_kc_winner<<<kblk(n_parts, kc_lanes()), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, n_all, wpool, has_winner, kc_lanes());
 }
 void kc_launch_apply(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len,
                      const uint32_t* woff, uint32_t n_parts, const uint8_t* wpool, const uint8_t* has_winner) {
