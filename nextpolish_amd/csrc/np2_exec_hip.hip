@@ -92,9 +92,12 @@ struct DevRecs {   // one RecordSet in HBM
     __device__ ReadView view(uint32_t i) const { return ReadView{pos[i], n_cigar[i], cigar + cigar_off[i], seq + seq_off[i]}; }
 };
 
+// (lane-per-record kernels with long serial walks launch SERIAL_LANES records per wave: a window has ~10^4 records, 64 per
+// wave would leave most SIMDs idle and every wave as slow as its longest CIGAR)
+constexpr uint32_t SERIAL_LANES = 8;
 __global__ void k2_span(DevRecs R, uint32_t n, const char* contig_seq, int32_t s, int32_t e, SpanOut* out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const uint32_t i = blockIdx.x * SERIAL_LANES + threadIdx.x;
+    if (threadIdx.x >= SERIAL_LANES || i >= n) return;
     const ReadView rv = R.view(i);
     uint32_t N, rf_len, rd_len;
     bool bad;
@@ -142,8 +145,8 @@ struct TagCkpt { uint32_t op_i, in_op, rfi, rdi, te_before, delta_before; };
 struct TagChunk { uint32_t stream, c0, n, last; };   // stream = index into the StreamDesc array
 
 __global__ void k2_tag_ckpt(const StreamDesc* sd, uint32_t n_streams, const uint32_t* chunk_off, DevRecs R0, DevRecs R1, int32_t s, TagCkpt* ck) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_streams) return;
+    const uint32_t k = blockIdx.x * SERIAL_LANES + threadIdx.x;
+    if (threadIdx.x >= SERIAL_LANES || k >= n_streams) return;
     const StreamDesc d = sd[k];
     const DevRecs& R = d.set ? R1 : R0;
     const uint32_t* cg = R.cigar + R.cigar_off[d.read];
@@ -1161,7 +1164,7 @@ bool HipExec::compute_spans(const WindowInput& in, int set, std::vector<SpanOut>
     if (!upload_contig(in, err) || !upload_set(rs, set, err)) return false;
     if (n) {
         if (!spans_.ensure(sizeof(SpanOut) * (size_t)n)) { *err = "out of device memory (spans)"; return false; }
-        k2_span<<<nblk(n, 64), 64, 0, q>>>(dev_set(set), n, contig_.as<char>(), in.s, in.e, spans_.as<SpanOut>());
+        k2_span<<<nblk(n, SERIAL_LANES), 64, 0, q>>>(dev_set(set), n, contig_.as<char>(), in.s, in.e, spans_.as<SpanOut>());
         HIPOK(hipMemcpyAsync(spans->data(), spans_.p, sizeof(SpanOut) * (size_t)n, hipMemcpyDeviceToHost, q));
     }
     HIPOK(hipStreamSynchronize(q));
@@ -1233,7 +1236,7 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
         if (n_tchunks) {
             HIPOK(hipMemcpyAsync(tchunks_.p, tcs.data(), sizeof(TagChunk) * (size_t)n_tchunks, hipMemcpyHostToDevice, q));
             HIPOK(hipMemcpyAsync(tchoff_.p, choff.data(), 4ull * sd.size(), hipMemcpyHostToDevice, q));
-            k2_tag_ckpt<<<nblk(sd.size(), 64), 64, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), tchoff_.as<uint32_t>(), dev_set(0), dev_set(1), s,
+            k2_tag_ckpt<<<nblk(sd.size(), SERIAL_LANES), 64, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), tchoff_.as<uint32_t>(), dev_set(0), dev_set(1), s,
                                                            tckpt_.as<TagCkpt>());
             k2_tags_chunk<<<nblk(n_tchunks, 64), 64, 0, q>>>(tchunks_.as<TagChunk>(), n_tchunks, tckpt_.as<TagCkpt>(), sd_.as<StreamDesc>(), dev_set(0), dev_set(1),
                                                              in.gap_min_len, tags_.as<uint8_t>(), st, covdiff_.as<uint32_t>(), covdiff_.as<uint32_t>() + n_cols + 3,
