@@ -139,24 +139,23 @@ __global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const u
     if (m == 0) return;
     uint32_t* fl = flagged_local + f0;
     const bool list_in_lds = m <= KC_REG_LDS_WORDS;
-    const bool buf_in_lds = (uint64_t)m + 2ull * m + 4 <= KC_REG_LDS_WORDS;
-    for (uint32_t k = lane; k < m; k += 64) {   // global draft index -> position inside the contig
-        const uint32_t v = fl[k] - g0;
-        fl[k] = v;
-        if (list_in_lds) sh_words[k] = v;
-    }
+    for (uint32_t k = lane; k < m; k += 64) fl[k] -= g0;   // global draft index -> position inside the contig
+    __threadfence_block();
     __syncthreads();
     const uint32_t* F = list_in_lds ? sh_words : fl;
     // per-contig scratch in HBM: 2m + 4 values for the walk's output, m run starts, then the run records
     int32_t* gbuf = work + 12ull * f0 + 4ull * ct;
     uint32_t* rs = reinterpret_cast<uint32_t*>(gbuf + 2ull * m + 4);
     KcRun* runs = reinterpret_cast<KcRun*>(rs + m + (m & 1u));   // 8-byte aligned: 12 f0 + 4 ct + 2m + 4 + m (+1) is even
-    int32_t* buf = buf_in_lds ? reinterpret_cast<int32_t*>(sh_words + m) : gbuf;
     const uint8_t* code = c.draft_code + g0;
     const uint8_t* flag = c.draft_flag + g0;
     for (int pass = 0; pass < 2; ++pass) {
         const uint32_t gap = pass == 0 ? 0u : (uint32_t)c.min_len_inter_kmer, con = pass == 0 ? (uint32_t)c.min_len_ldr : 0u;
         const bool with_ext = pass == 1;
+        if (list_in_lds) {   // the list in LDS while the runs are worked out; the pass's output overlays it afterwards
+            for (uint32_t k = lane; k < m; k += 64) sh_words[k] = fl[k];
+            __syncthreads();
+        }
         // ---- runs: starts where the distance to the previous flagged position exceeds the gap (wave compaction)
         uint32_t n_runs = 0;
         for (uint32_t base = 0; base < m; base += 64) {
@@ -230,6 +229,8 @@ __global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const u
             }
             __syncthreads();
         }
+        // the list is not needed any more in this pass: the regions go where it was when they fit
+        int32_t* buf = 2ull * n_runs + 4 <= KC_REG_LDS_WORDS ? reinterpret_cast<int32_t*>(sh_words) : gbuf;
         int32_t n_out = 0;
         for (uint32_t base = 0; base < n_runs; base += 64) {
             const uint32_t r = base + lane;
