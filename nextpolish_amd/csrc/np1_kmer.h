@@ -257,6 +257,84 @@ NP1_HD int32_t kc_find_regions(const uint8_t* code, const uint8_t* flag, int32_t
     return n;
 }
 
+// ---- run-parallel form of the region walk (used by k_kc_regions; the CPU tests replay it against kc_find_regions) ----
+struct KcRun { int32_t first_pos, s, e, close_i; uint32_t emit, first_k, last_k, pad; };   // one run of one pass
+// the region of the run F[k0..k1] (inclusive) as the walk would close it when it starts at k0
+NP1_HD void kc_run_region(const uint32_t* F, uint32_t k0, uint32_t k1, const uint8_t* code, const uint8_t* flag, int32_t L,
+                                              uint32_t gap, uint32_t con, int32_t ext, bool with_ext, KcRun* out) {
+    const int32_t end = L - 1;
+    int32_t qstart = (int32_t)F[k0], qend = (int32_t)F[k1];
+    uint32_t pcon = 1;   // adjacent flagged positions ending at the run's last one; a uint16 counter in the reference (it wraps)
+    for (uint32_t k = k1; k > k0 && F[k] - F[k - 1] == 1u; --k) ++pcon;
+    const int64_t close_i = (int64_t)F[k1] + (int64_t)gap + 1;
+    const bool open_end = close_i > end;
+    const bool emit = open_end || (pcon & 0xffffu) > con;
+    if (emit) kc_brim(code, flag, ext, with_ext, 0, end, &qstart, &qend);
+    out->first_pos = (int32_t)F[k0];
+    out->s = qstart;
+    out->e = qend;
+    out->close_i = close_i > 0x7fffffff ? 0x7fffffff : (int32_t)close_i;
+    out->emit = emit ? (open_end ? 2u : 1u) : 0u;
+    out->first_k = k0;
+    out->last_k = k1;
+    out->pad = 0;
+}
+
+// the cursor the walk holds after a run it took (closing position + 1, or behind the extended region)
+NP1_HD int64_t kc_reach(const KcRun& x) {
+    return (x.emit == 1u && (int64_t)x.e > (int64_t)x.close_i) ? (int64_t)x.e + 1 : (int64_t)x.close_i + 1;
+}
+// Replays the reference's walk from run q, whose first position lies behind the cursor its predecessor leaves, until
+// a run is again taken as computed; returns that run's index (n_runs when the runs are used up).  Swallowed runs lose
+// their region, cut runs are recomputed from their first surviving position; `writer` stores the updated records (on
+// the GPU every lane follows the same chain and one of them writes).  *ended: the walk ended with a region still open.
+NP1_HD uint32_t kc_chain(const uint32_t* F, KcRun* runs, uint32_t n_runs, uint32_t q, const uint8_t* code, const uint8_t* flag, int32_t L,
+                         uint32_t gap, uint32_t con, int32_t ext, bool with_ext, bool writer, bool* ended) {
+    int64_t cursor = kc_reach(runs[q - 1]);
+    for (; q < n_runs; ++q) {
+        KcRun rr = runs[q];
+        if ((int64_t)rr.first_pos >= cursor) break;     // taken as computed: back in step with the parallel result
+        uint32_t k0 = rr.first_k;
+        while (k0 <= rr.last_k && (int64_t)F[k0] < cursor) ++k0;
+        if (k0 > rr.last_k) {                           // the whole run lies behind the cursor: no region, the cursor stays
+            rr.emit = 0;
+            rr.close_i = (int32_t)(cursor - 1);         // (a chain starting right behind it would see the same cursor)
+            rr.e = rr.close_i;
+            if (writer) runs[q] = rr;
+            continue;
+        }
+        kc_run_region(F, k0, rr.last_k, code, flag, L, gap, con, ext, with_ext, &rr);
+        rr.first_k = k0;
+        if (writer) runs[q] = rr;
+        cursor = kc_reach(rr);
+        if (rr.emit == 2u) { *ended = true; break; }    // the walk ended with the region still open
+    }
+    return q;
+}
+// contig_merge_region with the last output region held in registers (kc_merge_regions below is the literal statement).
+// Needs v[0] < v[1]: then the output never runs ahead of the input.  The GPU kernel walks the same steps with the inputs
+// preloaded 64 at a time (kc_merge_wave).
+NP1_HD int32_t kc_merge_fast(int32_t* v, int32_t n) {
+    const int32_t nreg = n / 2;
+    int32_t qi = 0, qs = v[0], qe = v[1], length = 2;
+    for (int32_t i = 0; i < nreg; ++i) {
+        const int32_t ps = v[2 * i], pe = v[2 * i + 1];
+        if (ps >= qe) {
+            ++qi;
+            qs = ps;
+            qe = pe;
+            v[2 * qi] = qs;
+            v[2 * qi + 1] = qe;
+            length += 2;
+        } else {
+            while (ps < qs) { --qi; qs = v[2 * qi]; }
+            qe = pe;
+            v[2 * qi + 1] = qe;
+        }
+    }
+    return length;
+}
+
 // contig_merge_region, literal (contig.c:595-620); returns the new number of values
 NP1_HD int32_t kc_merge_regions(int32_t* v, int32_t n) {
     if (n == 0) return 0;

@@ -70,29 +70,7 @@ __global__ __launch_bounds__(256) void k_kc_compact(const uint8_t* __restrict__ 
 // sequential pass (one lane, run records staged 64 at a time through LDS) replays exactly that: a run whose first
 // position lies behind the cursor is recomputed from its first surviving position (rare), the others are taken as they
 // are.  Then the literal merge.
-struct KcRun { int32_t first_pos, s, e, close_i; uint32_t emit, first_k, last_k, pad; };   // one run of one pass
 constexpr uint32_t KC_REG_LDS_WORDS = 36864;   // 144 KiB of dynamic LDS
-
-// the region of the run F[k0..k1] (inclusive) as the walk would close it when it starts at k0
-__device__ __forceinline__ void kc_run_region(const uint32_t* F, uint32_t k0, uint32_t k1, const uint8_t* code, const uint8_t* flag, int32_t L,
-                                              uint32_t gap, uint32_t con, int32_t ext, bool with_ext, KcRun* out) {
-    const int32_t end = L - 1;
-    int32_t qstart = (int32_t)F[k0], qend = (int32_t)F[k1];
-    uint32_t pcon = 1;   // adjacent flagged positions ending at the run's last one; a uint16 counter in the reference (it wraps)
-    for (uint32_t k = k1; k > k0 && F[k] - F[k - 1] == 1u; --k) ++pcon;
-    const int64_t close_i = (int64_t)F[k1] + (int64_t)gap + 1;
-    const bool open_end = close_i > end;
-    const bool emit = open_end || (pcon & 0xffffu) > con;
-    if (emit) kc_brim(code, flag, ext, with_ext, 0, end, &qstart, &qend);
-    out->first_pos = (int32_t)F[k0];
-    out->s = qstart;
-    out->e = qend;
-    out->close_i = close_i > 0x7fffffff ? 0x7fffffff : (int32_t)close_i;
-    out->emit = emit ? (open_end ? 2u : 1u) : 0u;
-    out->first_k = k0;
-    out->last_k = k1;
-    out->pad = 0;
-}
 
 // contig_merge_region (np1_kmer.h kc_merge_regions is the literal statement) walked by the whole wave with uniform control
 // flow: lane t preloads input region base + t, the last output region lives in registers, lane 0 stores.  Needs the
@@ -181,9 +159,6 @@ __global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const u
         // + 1, or the extended end + 1) is taken as computed.  The others start short chains that are replayed like the
         // reference's walk (recompute from the first surviving position, or drop a swallowed run) until a run is again
         // taken as computed; the chains update the run records in place.  Output = the emitted runs in order.
-        auto reach_of = [](const KcRun& x) -> int64_t {
-            return (x.emit == 1u && (int64_t)x.e > (int64_t)x.close_i) ? (int64_t)x.e + 1 : (int64_t)x.close_i + 1;
-        };
         uint32_t* bad_list = rs;   // (the run starts are not needed any more)
         uint32_t n_bad = 0;
         for (uint32_t base = 0; base < n_runs; base += 64) {
@@ -191,7 +166,7 @@ __global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const u
             bool bad = false;
             if (r < n_runs && r > 0) {
                 const KcRun pv = runs[r - 1];
-                bad = pv.emit == 2u || (int64_t)runs[r].first_pos < reach_of(pv);
+                bad = pv.emit == 2u || (int64_t)runs[r].first_pos < kc_reach(pv);
             }
             const unsigned long long mb = __ballot(bad);
             if (bad) bad_list[n_bad + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull))] = r;
@@ -205,25 +180,7 @@ __global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const u
             for (uint32_t b = 0; b < n_bad && !ended; ++b) {
                 uint32_t q = bad_list[b];
                 if (q < next_q) continue;               // inside the previous chain
-                int64_t cursor = reach_of(runs[q - 1]);
-                for (; q < n_runs; ++q) {
-                    KcRun rr = runs[q];
-                    if ((int64_t)rr.first_pos >= cursor) break;     // taken as computed: back in step with the parallel result
-                    uint32_t k0 = rr.first_k;
-                    while (k0 <= rr.last_k && (int64_t)F[k0] < cursor) ++k0;
-                    if (k0 > rr.last_k) {                           // the whole run lies behind the cursor: no region, cursor stays
-                        rr.emit = 0;
-                        rr.close_i = (int32_t)(cursor - 1);         // so that a later chain starting behind it sees the same cursor
-                        rr.e = rr.close_i;
-                        if (lane == 0) runs[q] = rr;
-                        continue;
-                    }
-                    kc_run_region(F, k0, rr.last_k, code, flag, L, gap, con, c.ext_len_edge, with_ext, &rr);
-                    rr.first_k = k0;
-                    if (lane == 0) runs[q] = rr;
-                    cursor = reach_of(rr);
-                    if (rr.emit == 2u) { ended = true; break; }     // the walk ended with the region still open
-                }
+                q = kc_chain(F, runs, n_runs, q, code, flag, L, gap, con, c.ext_len_edge, with_ext, lane == 0, &ended);
                 next_q = q + 1;
                 __threadfence_block();
             }
@@ -253,9 +210,13 @@ __global__ __launch_bounds__(64) void k_kc_regions(KcCtx c, uint32_t nc, const u
         for (int32_t i = (int32_t)lane + 1; i < n_out / 2; i += 64) overlap = overlap || buf[2 * i] < buf[2 * (i - 1) + 1];
         const bool any_overlap = __ballot(overlap) != 0ull;
         int32_t merged = n_out;
-        if (any_overlap) {
-            if (buf[0] < buf[1]) merged = kc_merge_wave(buf, n_out, lane);                 // (all lanes)
-            else { if (lane == 0) sh_nr = (uint32_t)kc_merge_regions(buf, n_out); __syncthreads(); merged = (int32_t)sh_nr; __syncthreads(); }
+        if (n_out && !(buf[0] < buf[1])) {   // a first region of one base sends the reference's merge into its copy-everything quirk: literal
+            if (lane == 0) sh_nr = (uint32_t)kc_merge_regions(buf, n_out);
+            __syncthreads();
+            merged = (int32_t)sh_nr;
+            __syncthreads();
+        } else if (any_overlap) {
+            merged = kc_merge_wave(buf, n_out, lane);   // (all lanes)
         }
         if (lane == 0) {
             uint32_t fail = 0, nr = 0, o = 0;

@@ -524,4 +524,46 @@ int np1m_kmer_count(const np1_stream_view* v, const Configure* cfg, char** out, 
 }
 
 void np1m_free(void* p) { free(p); }
+
+// The region walk in its run-parallel form (what k_kc_regions does, one step after the other) and in its literal form, on
+// a bare contig: code / flag per base, the ascending list of flagged positions.  mode 0 = literal (kc_find_regions +
+// kc_merge_regions), 1 = runs, neighbour test, replay chains, compaction, register merge.  Returns the value count.
+int np1m_regions(const uint8_t* code, const uint8_t* flag, int32_t L, const uint32_t* F, uint32_t m, uint32_t gap, uint32_t con, int32_t ext,
+                 int with_ext, int mode, int32_t* out, int32_t cap) {
+    using namespace np1k;
+    if (m == 0) return 0;
+    if (mode == 0) {
+        const int32_t k = kc_find_regions(code, flag, L, F, m, gap, con, ext, with_ext != 0, out, cap);
+        return k < 0 ? k : kc_merge_regions(out, k);
+    }
+    std::vector<uint32_t> rs;
+    for (uint32_t k = 0; k < m; ++k)
+        if (k == 0 || F[k] - F[k - 1] - 1u > gap) rs.push_back(k);
+    const uint32_t n_runs = (uint32_t)rs.size();
+    std::vector<KcRun> runs(n_runs);
+    for (uint32_t r = 0; r < n_runs; ++r)
+        kc_run_region(F, rs[r], (r + 1 < n_runs ? rs[r + 1] : m) - 1, code, flag, L, gap, con, ext, with_ext != 0, &runs[r]);
+    std::vector<uint32_t> bad;
+    for (uint32_t r = 1; r < n_runs; ++r)   // (on the snapshot before any chain ran, like the kernel)
+        if (runs[r - 1].emit == 2u || (int64_t)runs[r].first_pos < kc_reach(runs[r - 1])) bad.push_back(r);
+    uint32_t next_q = 0;
+    bool ended = false;
+    for (size_t b = 0; b < bad.size() && !ended; ++b) {
+        uint32_t q = bad[b];
+        if (q < next_q) continue;
+        q = kc_chain(F, runs.data(), n_runs, q, code, flag, L, gap, con, ext, with_ext != 0, true, &ended);
+        next_q = q + 1;
+    }
+    int32_t n = 0;
+    for (uint32_t r = 0; r < n_runs; ++r)
+        if (runs[r].emit) {
+            if (n + 2 > cap) return -1;
+            out[n++] = runs[r].s;
+            out[n++] = runs[r].e;
+        }
+    bool overlap = false;
+    for (int32_t i = 1; i < n / 2; ++i) overlap = overlap || out[2 * i] < out[2 * (i - 1) + 1];
+    if (n && !(out[0] < out[1])) return kc_merge_regions(out, n);   // (needs cap >= n + 2, like the walk's own buffer)
+    return overlap ? kc_merge_fast(out, n) : n;
+}
 }

@@ -87,3 +87,46 @@ def test_model_kmer_count_synth(seed):
     got = mb.kmer_count(st, cfg)
     for i in range(st.n_contigs):
         assert got[i] == ob.kmer_count(st, i, ob.default_config(read_tlen=1500))
+
+
+def test_region_walk_run_parallel_form_equals_the_literal_walk():
+    """k_kc_regions does not walk a contig base by base: it cuts the flagged positions into runs, takes each run's region
+    on its own, replays the walk only where an extended region swallows the head of the next runs, and merges with the
+    last region in registers (np1_kmer.h).  Its steps, executed one after the other on the CPU, must give what the literal
+    walk gives -- on draft shapes chosen to make regions collide: dense flags, homopolymers, flagged runs next to each
+    other, every gap / minimum-run / extension setting."""
+    import ctypes as C
+    import random
+    import numpy as np
+    L = mb.lib()
+    L.np1m_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int, C.c_int,
+                               C.c_void_p, C.c_int32]
+    L.np1m_regions.restype = C.c_int
+    rng = random.Random(11)
+    n_cases = 0
+    for case in range(12000):
+        n = rng.choice([1, 2, 5, 30, 200, 1500])
+        hp = rng.choice([0.0, 0.3, 0.7, 0.95])            # chance that a base repeats its neighbour
+        dens = rng.choice([0.002, 0.02, 0.1, 0.4, 0.9])   # flagged fraction
+        clump = rng.choice([0.0, 0.5, 0.9])               # chance that a flagged base is followed by another one
+        code = np.zeros(n, dtype=np.uint8)
+        flag = np.zeros(n, dtype=np.uint8)
+        for i in range(n):
+            code[i] = code[i - 1] if i and rng.random() < hp else rng.choice([1, 2, 4, 8])
+            f = rng.random() < (clump if i and flag[i - 1] & 1 else dens)
+            flag[i] = 1 if f else 0                        # KC_FLAG_ZERO is bit 0 of the flag byte
+        F = np.nonzero(flag)[0].astype(np.uint32)
+        if F.size == 0:
+            continue
+        gap, con = rng.choice([(0, 0), (0, 2), (0, 5), (3, 0), (5, 0), (10, 1), (1, 1)])
+        ext = rng.choice([0, 1, 2, 5])
+        with_ext = rng.choice([0, 1])
+        cap = 2 * int(F.size) + 8
+        outs = []
+        for mode in (0, 1):
+            out = np.zeros(cap, dtype=np.int32)
+            k = L.np1m_regions(code.ctypes.data, flag.ctypes.data, n, F.ctypes.data, int(F.size), gap, con, ext, with_ext, mode, out.ctypes.data, cap)
+            outs.append((k, out[:max(k, 0)].tolist()))
+        assert outs[0] == outs[1], (case, n, gap, con, ext, with_ext, F.tolist()[:40], outs)
+        n_cases += 1
+    assert n_cases > 6000
