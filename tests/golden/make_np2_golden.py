@@ -56,6 +56,11 @@ def main():
     open(os.path.join(d, "bam.fofn"), "w").write(os.path.join(d, "r.bam") + "\n")
     res = rb.polish(L, os.path.join(d, "g.fa"), os.path.join(d, "bam.fofn"), read_type=1)["ctg0"]
     out["deep_window"] = {"lens": [r[1] for r in res], "md5": [hashlib.md5(r[0].encode()).hexdigest() for r in res]}
+    # several BAM files in the fofn (merge by position, strand, file)
+    cid, kw, rt = np2_cases.CASES[1]
+    fa, fofn, contigs = np2_cases.materialise_multi(kw, 3)
+    res = rb.polish(L, fa, fofn, read_type=rt)
+    out["multi_bam"] = {"case": cid, "expected": {n: res[n][0][0] for n, _ in contigs}}
     # codec known answers: pack then unpack through the reference (incl. the non-ACGT spill of bseq.c:91)
     for s in ["ACGT", "AANAA", "GGNGG", "acgtn", "TTTTTTTTTTTTTTTTA", "NACGT", "ACGTACGTACGTACGTN", "RYKM", "A", "TU"]:
         words = (C.c_uint32 * (len(s) // 16 + 1))()

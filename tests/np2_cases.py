@@ -87,3 +87,26 @@ def materialise_sv(case_kw, qvs=None, workdir=None):
     with open(fofn, "w") as f:
         f.write(bam + "\n")
     return fa, fofn, contigs
+
+
+def materialise_multi(case_kw, n_files=3, workdir=None):
+    """The reads of a case dealt over several BAM files (the reference merges the files of the fofn by position,
+    strand and file order, bsort.c:174-199): FASTA, fofn, contigs."""
+    from nextpolish_amd import _native as nat
+    kw = dict(case_kw)
+    seed = kw.pop("seed")
+    contigs, reads = np2_gen.make_case(seed, **kw)
+    d = workdir or tempfile.mkdtemp(prefix="np2mf_")
+    fa = os.path.join(d, "g.fa")
+    bams = []
+    for f in range(n_files):
+        part = [r for i, r in enumerate(reads) if (i * 7 + i // 5) % n_files == f]
+        st = nat.Stream.from_reads(contigs, part)
+        bam = os.path.join(d, "r%d.bam" % f)
+        st.write_files(fa, bam)
+        st.close()
+        bams.append(bam)
+    fofn = os.path.join(d, "bam.fofn")
+    with open(fofn, "w") as fh:
+        fh.write("\n".join(bams) + "\n")
+    return fa, fofn, contigs

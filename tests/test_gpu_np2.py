@@ -154,3 +154,13 @@ def test_gpu_full_5mb_window_matches_compiled_reference(tmp_path):
     assert want is not None, err
     assert got == want
     assert abs(len(got["ctg0"][0][0]) - 5000000) < 50000
+
+
+def test_gpu_reads_dealt_over_three_bam_files(tmp_path):
+    """Several BAM files in the fofn: records merged by (position, strand, file order) like the reference's iterator."""
+    cid, kw, rt = np2_cases.CASES[1]
+    fa, fofn, contigs = np2_cases.materialise_multi(kw, 3, str(tmp_path))
+    got, err = run_polish(PRODUCT_SO, fa, fofn, rt)
+    assert got is not None, err
+    for n, _ in contigs:
+        assert got[n][0][0] == GOLD["multi_bam"]["expected"][n]

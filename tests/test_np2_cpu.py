@@ -280,3 +280,15 @@ def test_long_cigars_in_the_cg_tag_are_swapped_in(model, tmp_path):
     if rb.available():
         want, err = run_polish(os.path.realpath(rb.REF_SO), fa, fofn, rt)
         assert want == got
+
+
+def test_reads_dealt_over_three_bam_files(model, tmp_path):
+    """The fofn may list several BAM files: the records are merged by (position, strand, file order) like the reference's
+    multi-file iterator; the order decides the first-seen order of links."""
+    cid, kw, rt = np2_cases.CASES[1]
+    assert GOLD["multi_bam"]["case"] == cid
+    fa, fofn, contigs = np2_cases.materialise_multi(kw, 3, str(tmp_path))
+    got, err = run_polish(model, fa, fofn, rt)
+    assert got is not None, err
+    for n, _ in contigs:
+        assert got[n][0][0] == GOLD["multi_bam"]["expected"][n]
