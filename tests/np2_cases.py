@@ -25,6 +25,9 @@ CASES = [
     ("ont_reads_with_iupac_codes", dict(seed=52, contig_lens=(15000, 4000), depth=25, max_indel=4, iupac_rate=0.002), 1),
     # single reads carrying insertions of 300-2500 bases: columns with thousands of nodes (real ONT data has them)
     ("ont_long_insertions", dict(seed=71, contig_lens=(40000,), depth=25, max_indel=4, mean_len=8000, long_ins_rate=2e-5), 1),
+    # a contig without a single read (comes back as the draft in lower case), and a contig two reads touch
+    ("contig_without_reads", dict(seed=3, contig_lens=(6000, 3000, 400), depth=12, mean_len=2000, drop_ctg=1), 1),
+    ("two_reads_only", dict(seed=4, contig_lens=(5000,), depth=1, mean_len=3000, keep_reads=2), 1),
     ("hifi_reads_with_iupac_codes", dict(seed=53, contig_lens=(15000,), depth=25, sub=0.002, ins=0.002, dele=0.002, mean_len=9000, iupac_rate=0.001), 3),
 ]
 
@@ -38,7 +41,12 @@ def materialise(case_kw, workdir=None):
     from nextpolish_amd import _native as nat
     kw = dict(case_kw)
     seed = kw.pop("seed")
+    drop_ctg, keep_reads = kw.pop("drop_ctg", None), kw.pop("keep_reads", None)
     contigs, reads = np2_gen.make_case(seed, **kw)
+    if drop_ctg is not None:     # a contig no read maps to
+        reads = [r for r in reads if r["ctg"] != drop_ctg]
+    if keep_reads is not None:   # only the first few reads
+        reads = reads[:keep_reads]
     d = workdir or tempfile.mkdtemp(prefix="np2case_")
     st = nat.Stream.from_reads(contigs, reads)
     fa, bam = os.path.join(d, "g.fa"), os.path.join(d, "r.bam")
