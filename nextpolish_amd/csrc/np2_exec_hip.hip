@@ -293,9 +293,12 @@ __device__ __forceinline__ void tag_pos(const uint8_t* tg, uint32_t j, uint32_t 
     while ((tag_nib(tg, j - d) & 8u)) ++d;   // a stream never starts with an insertion column, so this stops at or before tag 0
     *delta = d & 0xffffu;
 }
+// link observation as the device keeps it: pp, ppp, (stream | delta << 32 | base << 48), column -- 32 bytes, aligned
+struct __attribute__((aligned(32))) DevObs { uint64_t pp, ppp, meta, col; };
+
 template <bool kFill>
 __global__ void k2_chunk_links(const ChunkDesc* cd, uint32_t n_chunks, const uint32_t* pre, const uint64_t* tag_off, const uint32_t* aln_t_s,
-                               const uint8_t* tags, uint32_t* col_cnt, const uint32_t* col_off, uint32_t* cursor, LinkObs* obs, uint32_t* obs_col) {
+                               const uint8_t* tags, uint32_t* col_cnt, const uint32_t* col_off, uint32_t* cursor, DevObs* obs) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const ChunkDesc d = cd[c];
@@ -332,10 +335,12 @@ __global__ void k2_chunk_links(const ChunkDesc* cd, uint32_t n_chunks, const uin
                 atomicAdd(&col_cnt[t_pos], 1u);
             } else {
                 const uint32_t at = col_off[t_pos] + atomicAdd(&cursor[t_pos], 1u);
-                LinkObs o;
-                o.pp = pp; o.ppp = ppp; o.rd = d.stream; o.delta = (uint16_t)delta; o.base = (uint8_t)base; o.pad = 0;
-                obs[at] = o;
-                obs_col[at] = (uint32_t)t_pos;
+                // one aligned 32-byte record per observation, written as two 16-byte stores: a 24-byte record + a separate
+                // column word cost four times their size in HBM writes (partial lines) and as much again in fetches
+                uint4* dst = reinterpret_cast<uint4*>(obs + at);
+                const uint64_t meta = (uint64_t)d.stream | (uint64_t)(delta & 0xffffu) << 32 | (uint64_t)(base & 0xffu) << 48;
+                dst[0] = make_uint4((uint32_t)pp, (uint32_t)(pp >> 32), (uint32_t)ppp, (uint32_t)(ppp >> 32));
+                dst[1] = make_uint4((uint32_t)meta, (uint32_t)(meta >> 32), (uint32_t)t_pos, 0u);
             }
         }
         ppp = pp; pp = key; pp_base = base;
@@ -352,55 +357,55 @@ __global__ void k2_chunk_links(const ChunkDesc* cd, uint32_t n_chunks, const uin
 // neighbouring lanes work on the same bucket, so the loops read through L1.
 __device__ __forceinline__ uint32_t obs_nkey(uint64_t meta) { return (uint32_t)((meta >> 32) & 0xffffu) << 8 | (uint32_t)((meta >> 48) & 0xffu); }
 constexpr uint64_t AUX_NODE_FIRST = 1ull << 48, AUX_PAIR_FIRST = 1ull << 49;
-__global__ __launch_bounds__(256) void k2_build_a(const LinkObs* __restrict__ obs, const uint32_t* __restrict__ obs_col, const uint32_t* __restrict__ col_off,
+__global__ __launch_bounds__(256) void k2_build_a(const DevObs* __restrict__ obs, const uint32_t* __restrict__ col_off,
                                                   uint32_t total, uint64_t* __restrict__ aux) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const uint32_t p = obs_col[i];
+    const uint32_t p = (uint32_t)obs[i].col;
     const uint32_t lo = col_off[p], hi = col_off[p + 1];
     const uint64_t* w = reinterpret_cast<const uint64_t*>(obs);
-    const uint64_t pp = w[3ull * i], ppp = w[3ull * i + 1], meta = w[3ull * i + 2];
+    const uint64_t pp = w[4ull * i], ppp = w[4ull * i + 1], meta = w[4ull * i + 2];
     const uint32_t nk = obs_nkey(meta), rd = (uint32_t)meta;
     uint32_t less = 0, pairs = 0;
     bool node_first = true, pair_first = true;
     for (uint32_t j = lo; j < hi; ++j) {
-        const uint64_t mj = w[3ull * j + 2];
+        const uint64_t mj = w[4ull * j + 2];
         const uint32_t nkj = obs_nkey(mj);
         less += nkj < nk ? 1u : 0u;
         if (nkj == nk) {
             const bool before = (uint32_t)mj < rd;
             node_first = node_first && !before;
-            if (w[3ull * j] == pp && w[3ull * j + 1] == ppp) { ++pairs; pair_first = pair_first && !before; }
+            if (w[4ull * j] == pp && w[4ull * j + 1] == ppp) { ++pairs; pair_first = pair_first && !before; }
         }
     }
     aux[i] = (uint64_t)less | (uint64_t)pairs << 24 | (node_first ? AUX_NODE_FIRST : 0ull) | (pair_first ? AUX_PAIR_FIRST : 0ull);
 }
-__global__ __launch_bounds__(256) void k2_build_b(const LinkObs* __restrict__ obs, const uint32_t* __restrict__ obs_col, const uint32_t* __restrict__ col_off,
+__global__ __launch_bounds__(256) void k2_build_b(const DevObs* __restrict__ obs, const uint32_t* __restrict__ col_off,
                                                   uint32_t total, const uint64_t* __restrict__ aux, Entry* __restrict__ entries, Node* __restrict__ nodes,
                                                   uint32_t* __restrict__ col_nn, uint8_t* __restrict__ live) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const uint64_t a = aux[i];
     if (!(a & AUX_PAIR_FIRST)) return;
-    const uint32_t p = obs_col[i];
+    const uint32_t p = (uint32_t)obs[i].col;
     const uint32_t lo = col_off[p], hi = col_off[p + 1];
     const uint64_t* w = reinterpret_cast<const uint64_t*>(obs);
-    const uint64_t meta = w[3ull * i + 2];
+    const uint64_t meta = w[4ull * i + 2];
     const uint32_t nk = obs_nkey(meta), rd = (uint32_t)meta;
     const bool node_first = (a & AUX_NODE_FIRST) != 0;
     uint32_t slot = 0, node_len = 0, node_idx = 0, n_nodes = 0;
     for (uint32_t j = lo; j < hi; ++j) {
         const uint64_t aj = aux[j];
         if (!(aj & (AUX_NODE_FIRST | AUX_PAIR_FIRST))) continue;
-        const uint64_t mj = w[3ull * j + 2];
+        const uint64_t mj = w[4ull * j + 2];
         const uint32_t nkj = obs_nkey(mj);
         if (aj & AUX_NODE_FIRST) { ++n_nodes; node_idx += nkj < nk ? 1u : 0u; }
         if ((aj & AUX_PAIR_FIRST) && nkj == nk) { ++node_len; slot += (uint32_t)mj < rd ? 1u : 0u; }
     }
     const uint32_t start = (uint32_t)a & 0xffffffu;
     Entry e;
-    e.pp = w[3ull * i];
-    e.ppp = w[3ull * i + 1];
+    e.pp = w[4ull * i];
+    e.ppp = w[4ull * i + 1];
     e.score = 0;
     e.link = (uint32_t)(a >> 24) & 0xffffu;   // the reference counts in 16 bits
     e.node = nk;
@@ -1476,7 +1481,7 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
         k2_scan_final<<<nsc, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), n_chunks + 1, sums2_.as<uint32_t>(), chpre_.as<uint32_t>());
         if (!m_seen)
             k2_chunk_links<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
-                                                                     alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
+                                                                     alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
     }
     const uint32_t nsb = nblk(n_cols + 1, SCAN_TILE);
     uint32_t total = 0;
@@ -1493,10 +1498,10 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
         HIPOK(hipMemsetAsync(colcnt_.p, 0, 4ull * (n_cols + 2), q));
         if (n_chunks)
             k2_chunk_links<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
-                                                                     alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
+                                                                     alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
     }
     if (clk) clk->mark("links.count+scan");
-    if (!obs_.ensure(sizeof(LinkObs) * (size_t)total + 64) || !obscol_.ensure(4ull * total + 64) || !obsaux_.ensure(8ull * total + 64) ||
+    if (!obs_.ensure(sizeof(DevObs) * (size_t)total + 64) || !obsaux_.ensure(8ull * total + 64) ||
         !entries_.ensure(sizeof(Entry) * (size_t)total + 64) || !live_.ensure((size_t)total + 64) || !ematch_.ensure(sizeof(EMatch) * (size_t)total + 64) ||
         !nodes_.ensure(sizeof(Node) * (size_t)total + 64)) {
         *err = "out of device memory (link graph)";
@@ -1505,16 +1510,16 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
     if (n_chunks)
         k2_chunk_links<true><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
                                                                 alnts_.as<uint32_t>(), tags_.as<uint8_t>(), nullptr, coloff_.as<uint32_t>(), cursor_.as<uint32_t>(),
-                                                                obs_.as<LinkObs>(), obscol_.as<uint32_t>());
+                                                                obs_.as<DevObs>());
     if (clk) clk->mark("links.scatter");
     HIPOK(hipMemsetAsync(colnn_.p, 0, 4ull * n_cols, q));
     if (total) {
-        k2_build_a<<<nblk(total, 256), 256, 0, q>>>(obs_.as<LinkObs>(), obscol_.as<uint32_t>(), coloff_.as<uint32_t>(), total, obsaux_.as<uint64_t>());
+        k2_build_a<<<nblk(total, 256), 256, 0, q>>>(obs_.as<DevObs>(), coloff_.as<uint32_t>(), total, obsaux_.as<uint64_t>());
         HIPOK(hipMemsetAsync(live_.p, 0, total, q));
-        k2_build_b<<<nblk(total, 256), 256, 0, q>>>(obs_.as<LinkObs>(), obscol_.as<uint32_t>(), coloff_.as<uint32_t>(), total, obsaux_.as<uint64_t>(),
+        k2_build_b<<<nblk(total, 256), 256, 0, q>>>(obs_.as<DevObs>(), coloff_.as<uint32_t>(), total, obsaux_.as<uint64_t>(),
                                                      entries_.as<Entry>(), nodes_.as<Node>(), colnn_.as<uint32_t>(), live_.as<uint8_t>());
         MsaView bare{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), nullptr};
-        k2_match<<<nblk(total, 256), 256, 0, q>>>(bare, obscol_.as<uint32_t>(), live_.as<uint8_t>(), total, ematch_.as<EMatch>());
+        k2_match<<<nblk(total, 256), 256, 0, q>>>(bare, nullptr, live_.as<uint8_t>(), total, ematch_.as<EMatch>());
     }
     *total_out = total;
     return true;
