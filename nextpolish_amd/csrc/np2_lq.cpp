@@ -423,7 +423,11 @@ bool lq_stage(Exec* exec, uint32_t gap_min_len, bool hifi, const std::vector<LqR
         }
     }
     // ---- update_consensus_trimed (ctg_cns.c:1165-1211): regions are in descending position order
-    std::vector<ConsBase> out;
+    // the spliced consensus is built in a buffer this thread keeps and then swapped with the window's: the two 40 MB
+    // vectors of a 5 Mb window change places from call to call instead of being allocated and paged in every time
+    static thread_local std::vector<ConsBase> spare;
+    std::vector<ConsBase>& out = spare;
+    out.clear();
     out.reserve(cons->size() + 1024);
     int lqi = count - 1;
     int update = 1;

@@ -856,5 +856,7 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
         fprintf(stderr, "Warning, Too many (%.3f%%) fragment mappings in %s, please polish the genome with other reads first, or"
                 " adjust the mapping parameters to tolerate more errors, such as use asm20/map-pb instead of asm5 for minimap2,"
                 " continue anyway...\n", (double)fra_map * 100 / (double)(total_map + 1), ref->n);
-    return link_windows(windows, sv.split_ps, (int)ref->length, 50, cfg->split, cfg->s);
+    consensus_trimed_data* result = link_windows(windows, sv.split_ps, (int)ref->length, 50, cfg->split, cfg->s);
+    if (!windows.empty()) out.cons.swap(windows.back().b);   // keep the buffer (its capacity) for the next contig's window
+    return result;
 }
