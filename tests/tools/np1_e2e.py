@@ -2,7 +2,7 @@
 compiled reference binary, on the bench workload.  usage: np1_e2e.py [threads] [total Mb] [depth] [ref: 0|1]"""
 import os, subprocess, sys, tempfile, time
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(here, ".."))
+sys.path.insert(0, os.path.join(here, "..", ".."))
 from nextpolish_amd import _native as nat
 d = tempfile.mkdtemp(prefix="np1e2e_")
 t = time.time()
@@ -15,8 +15,8 @@ fa, bam = os.path.join(d, "g.fa"), os.path.join(d, "r.bam")
 st.write_files(fa, bam)
 st.close()
 print("generated %.1f Mb, %.0fx PE150 in %.1f s; BAM %.0f MB" % (MB, DEPTH, time.time() - t, os.path.getsize(bam) / 1e6), flush=True)
-exe = os.path.join(here, "..", "nextpolish_amd", "bin", "nextpolish1")
-ref = os.path.join(here, "..", "oracle", "_ref", "nextpolish1")
+exe = os.path.join(here, "..", "..", "nextpolish_amd", "bin", "nextpolish1")
+ref = os.path.join(here, "..", "..", "oracle", "_ref", "nextpolish1")
 for th in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["8"]):
     env = dict(os.environ, NP_IO_THREADS=th)
     best = 1e9

@@ -2,7 +2,7 @@
 leaves behind): GPU batch time vs the CPU oracle and, when it travelled, the compiled reference CLI from files."""
 import os, subprocess, sys, tempfile, time
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(here, "..")); sys.path.insert(0, os.path.join(here, "..", "tests"))
+sys.path.insert(0, os.path.join(here, "..", "..")); sys.path.insert(0, os.path.join(here, ".."))
 from nextpolish_amd import _native as nat
 from nextpolish_amd.device import Context
 import oracle_binding as ob
@@ -23,7 +23,7 @@ t = time.time()
 same = all(ob.kmer_count(st, i, ob.default_config(read_tlen=1500)) == got[i] for i in range(3))
 dto = time.time() - t
 print("CPU oracle (C restatement), the 5 Mb: %.2f s -> %.2f Mbp/s; identical: %s" % (dto, 5.0 / dto, same))
-ref = os.path.join(here, "..", "oracle", "_ref", "nextpolish1")
+ref = os.path.join(here, "..", "..", "oracle", "_ref", "nextpolish1")
 if os.path.exists(ref):
     d = tempfile.mkdtemp(prefix="np1k_")
     one = nat.Stream.synth([1000000], depth=50.0, seed=77, with_qual=1, draft_lower=0.004)

@@ -2,10 +2,10 @@
 np2_fuzz_gpu.py <first seed> <last seed> [sv]"""
 import os, shutil, subprocess, sys, tempfile, json
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(here, "..")); sys.path.insert(0, os.path.join(here, "..", "tests"))
+sys.path.insert(0, os.path.join(here, "..", "..")); sys.path.insert(0, os.path.join(here, ".."))
 import np2_cases, np2_gen, ref2_binding as rb
 from nextpolish_amd import _native as nat
-PRODUCT = os.path.join(here, "..", "nextpolish_amd", "lib", "nextpolish2.so")
+PRODUCT = os.path.join(here, "..", "..", "nextpolish_amd", "lib", "nextpolish2.so")
 sv = len(sys.argv) > 3 and sys.argv[3] == "sv"
 bad = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
@@ -31,10 +31,10 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     # the reference runs in a child too: some inputs crash it (e.g. read bases with the IUPAC code M can leave a node
     # without links, and its backtrace then walks off the graph)
     rcode = ("import sys, json; sys.path.insert(0, %r); import ref2_binding as rb; L = rb.bind(rb.REF_SO); "
-             "print(json.dumps(rb.polish(L, %r, %r, read_type=%d, split=%d)))" % (os.path.join(here, "..", "tests"), fa, fofn, rt, split))
+             "print(json.dumps(rb.polish(L, %r, %r, read_type=%d, split=%d)))" % (os.path.join(here, ".."), fa, fofn, rt, split))
     pr = subprocess.run([sys.executable, "-c", rcode], capture_output=True, text=True)
     code = ("import sys, json; sys.path.insert(0, %r); import ref2_binding as rb; L = rb.bind(%r); "
-            "print(json.dumps(rb.polish(L, %r, %r, read_type=%d, split=%d)))" % (os.path.join(here, "..", "tests"), PRODUCT, fa, fofn, rt, split))
+            "print(json.dumps(rb.polish(L, %r, %r, read_type=%d, split=%d)))" % (os.path.join(here, ".."), PRODUCT, fa, fofn, rt, split))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     if pr.returncode != 0:
         print(seed, "rt", rt, "REFERENCE CRASHED (rc %d); this library: rc %d %s" % (pr.returncode, p.returncode, p.stderr.strip()[-100:]), flush=True)
