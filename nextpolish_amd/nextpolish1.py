@@ -27,6 +27,7 @@ import sys
 if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.realpath(__file__))))
 from nextpolish_amd import _native as nat  # noqa: E402
+from nextpolish_amd.shard import deal_contigs, fasta_lengths  # noqa: E402
 
 
 def parse_num_unit(s):
@@ -57,14 +58,15 @@ def read_polished_seqs(infile, polished_seqs):
     return last_seq_position
 
 
-def read_unpolished_seqs(infile, index, polished_seqs):
-    """reference: nextpolish1.py:148-161, but order preserving."""
+def read_unpolished_seqs(infile, index, polished_seqs, keep_polished=False):
+    """reference: nextpolish1.py:148-161, but order preserving.  keep_polished=True returns the block's full list (what the
+    ranks of a node are dealt from, so that the deal does not depend on how far each rank got before a restart)."""
     names = []
     if index != "all":
         with open(infile) as IN:
             for line in IN:
                 lines = line.strip().split()
-                if lines and lines[0].split("_np")[0] not in polished_seqs and lines[1] == index:
+                if lines and (keep_polished or lines[0].split("_np")[0] not in polished_seqs) and lines[1] == index:
                     names.append(lines[0])
     else:
         with open(infile) as IN:
@@ -130,30 +132,18 @@ def plan_batches(names, lengths, max_bp):
     return batches
 
 
-def shard_batches(batches, world, rank):
-    """Batch k goes to GPU k mod world (the reference's own unit of distribution is the contig block)."""
-    return [b for k, b in enumerate(batches) if k % world == rank]
-
-
-def fasta_lengths(genome):
-    """Contig lengths from <genome>.fai, or from the FASTA itself when the index does not exist yet."""
-    lens = {}
-    fai = genome + ".fai"
-    if os.path.exists(fai):
-        with open(fai) as IN:
-            for line in IN:
-                f = line.rstrip("\n").split("\t")
-                lens[f[0]] = int(f[1])
-        return lens
-    name = None
-    with open(genome) as IN:
-        for line in IN:
-            if line.startswith(">"):
-                name = line[1:].split()[0]
-                lens[name] = 0
-            elif name is not None:
-                lens[name] += len("".join(line.split()))
-    return lens
+def rank_share(all_names, lengths, world, rank, polished_seqs, filter_polished):
+    """This rank's contigs of the block in list order, minus those already in its own output (block mode only, like the
+    reference: nextpolish1.py:154)."""
+    owner = deal_contigs(all_names, lengths, world) if world > 1 else None
+    out = []
+    for n in all_names:
+        if owner is not None and owner[n] != rank:
+            continue
+        if filter_polished and n.split("_np")[0] in polished_seqs:
+            continue
+        out.append(n)
+    return out
 
 
 def polish_score_chain_batched(args, cfg, names, device, emit):
@@ -163,7 +153,7 @@ def polish_score_chain_batched(args, cfg, names, device, emit):
     batches = plan_batches(names, lengths, args.batch_bp)
     ctx = Context(device)
     try:
-        for b in shard_batches(batches, args.world, args.rank):
+        for b in batches:
             st = nat.Stream.load(args.genome, args.bam_sgs, names=b)
             batch = ctx.upload(st)
             batch.score_chain(cfg.contents)
@@ -177,9 +167,7 @@ def polish_score_chain_batched(args, cfg, names, device, emit):
 
 def polish_per_contig(args, cfg, names, fun, emit):
     L = nat.lib()
-    for k, name in enumerate(names):
-        if k % args.world != args.rank:
-            continue
+    for name in names:
         r = fun(name.encode(), cfg)
         seq = C.string_at(r.contents.contig).decode()
         pts = [(r.contents.data[p].pos, r.contents.data[p].index, r.contents.data[p].curbase.decode(),
@@ -203,7 +191,9 @@ def main(args):
     if args.block_index == "all" or not args.block:
         args.block_index = "all"
         blockfile = args.genome
-    names = read_unpolished_seqs(blockfile, args.block_index, polished_seqs)
+    all_names = read_unpolished_seqs(blockfile, args.block_index, polished_seqs, keep_polished=True)
+    names = rank_share(all_names, fasta_lengths(args.genome) if args.world > 1 else {}, args.world, args.rank, polished_seqs,
+                       args.block_index != "all")
 
     L = nat.lib()
     cfg = L.config_init(args.genome.encode(), (args.bam_sgs or "").encode() or None,

@@ -8,8 +8,8 @@ the consensus goes through the in-tree HIP library ``lib/nextpolish2.so`` instea
 Process model = the reference's: ``read_ref`` and ``ctg_cns_init`` run in the parent, the worker pool is forked
 afterwards (nextpolish2.py:184-194) and every worker creates its HIP context lazily on its first contig; worker k uses
 GPU ``pid mod n_gpus`` (``NP2_DEVICE`` pins it).  ``--world N --rank r`` additionally shards the contigs of the
-block over N node-level processes (contig i of the pending list goes to rank i mod N): contigs are independent, so no
-collective is involved.  Records are written in completion order, like the reference (``imap_unordered``).
+block over N node-level processes (dealt longest-first from the block's full list, nextpolish_amd/shard.py: the deal does
+not depend on what a rank already wrote, so a restart resumes the same share): contigs are independent, so no collective is involved.  Records are written in completion order, like the reference (``imap_unordered``).
 """
 from __future__ import print_function
 
@@ -84,19 +84,20 @@ def read_corrected_seqs(infile, corrected_seqs):
     return last_seq_position
 
 
-def read_uncorrected_seqs(infile, index, corrected_seqs):
+def read_uncorrected_seqs(infile, index, corrected_seqs, keep_corrected=False):
     """nextpolish2.py:97-115: contigs of block `index` of a block file, or every FASTA header when index == 'all'.
-    Returned in file order (the reference keeps a set)."""
+    Returned in file order (the reference keeps a set).  keep_corrected=True: the block's full list (the ranks of a node are
+    dealt from it, so the deal does not move when a rank restarts with part of its output already written)."""
     names = []
     with open(infile) as IN:
         for line in IN:
             if index != "all":
                 f = line.strip().split()
-                if f and f[0] not in corrected_seqs and f[1] == index:
+                if f and (keep_corrected or f[0] not in corrected_seqs) and f[1] == index:
                     names.append(f[0])
             elif line.startswith(">"):
                 n = line.strip().split()[0][1:]
-                if n not in corrected_seqs:
+                if keep_corrected or n not in corrected_seqs:
                     names.append(n)
     return names
 
@@ -149,9 +150,13 @@ def main(args):
     if args.block_index == "all" or not args.block:
         args.block_index = "all"
         blockfile = args.genome
-    names = read_uncorrected_seqs(blockfile, args.block_index, corrected_seqs)
+    names = read_uncorrected_seqs(blockfile, args.block_index, corrected_seqs, keep_corrected=args.world > 1)
     if args.world > 1:
-        names = [n for k, n in enumerate(names) if k % args.world == args.rank]
+        # deal on the block's full list (longest first, order-stable), only then drop what this rank already wrote
+        sys.path.insert(0, os.path.dirname(HERE))
+        from nextpolish_amd.shard import deal_contigs, fasta_lengths
+        owner = deal_contigs(names, fasta_lengths(args.genome), args.world)
+        names = [n for n in names if owner[n] == args.rank and n not in corrected_seqs]
     if not names:
         return 0
     _P = load_library(args.library)

@@ -44,8 +44,23 @@ def test_batch_planning_partitions_contigs():
     names = list(lens)
     b = np1.plan_batches(names, lens, 800)
     assert b == [["a", "b"], ["c", "d"], ["e"], ["f"]]
-    flat = [n for w in range(3) for bb in np1.shard_batches(b, 3, w) for n in bb]
-    assert sorted(flat) == sorted(names)
+
+
+def test_deal_is_longest_first_and_resume_stable():
+    """the deal must be a function of the block's full list, not of what a rank still has to do."""
+    lens = {"A": 100, "B": 90, "C": 80, "D": 10, "E": 1000}
+    names = ["A", "B", "C", "D", "E"]
+    owner = np1.deal_contigs(names, lens, 2)
+    assert owner["E"] == 0 and {owner[n] for n in "ABCD"} == {1}          # one giant contig does not drag others with it
+    # rank 0 finished A-equivalent work and restarts: its share is its old share minus what is in its own output
+    lens = {n: 100 for n in "ABCD"}
+    full = np1.rank_share(list("ABCD"), lens, 2, 0, set(), True)
+    again = np1.rank_share(list("ABCD"), lens, 2, 0, {full[0]}, True)
+    assert again == full[1:]
+    other = np1.rank_share(list("ABCD"), lens, 2, 1, set(), True)
+    assert sorted(full + other) == list("ABCD") and not set(full) & set(other)
+    loads = [sum(lens[n] for n in sh) for sh in (full, other)]
+    assert max(loads) - min(loads) <= 100
 
 
 WORKER = r'''
@@ -57,9 +72,10 @@ dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.
 rank, world = dist.get_rank(), dist.get_world_size()
 lens = {"c%%02d" %% i: 1000 + 137 * i for i in range(23)}
 names = sorted(lens)
-mine = [n for b in np1.shard_batches(np1.plan_batches(names, lens, 3000), world, rank) for n in b]
+lens["c07"] = 40000          # one long contig: longest-first keeps the ranks within one contig of each other
+mine = [n for b in np1.plan_batches(np1.rank_share(names, lens, world, rank, set(), True), lens, 3000) for n in b]
 gathered = [None] * world
-dist.all_gather_object(gathered, mine)
+dist.all_gather_object(gathered, (mine, sum(lens[n] for n in mine)))
 if rank == 0:
     json.dump(gathered, open(sys.argv[1], "w"))
 dist.barrier()
@@ -76,7 +92,9 @@ def test_two_rank_gloo_sharding(tmp_path):
     for p in procs:
         assert p.wait(timeout=300) == 0
     import json
-    shards = json.load(open(str(out)))
+    got = json.load(open(str(out)))
+    shards, loads = [g[0] for g in got], [g[1] for g in got]
+    assert abs(loads[0] - loads[1]) <= 40000 and min(loads) > 0.4 * max(loads)
     assert len(shards) == 2 and shards[0] and shards[1]
     assert not set(shards[0]) & set(shards[1])
     assert sorted(shards[0] + shards[1]) == ["c%02d" % i for i in range(23)]
