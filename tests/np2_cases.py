@@ -118,3 +118,41 @@ def materialise_multi(case_kw, n_files=3, workdir=None):
     with open(fofn, "w") as fh:
         fh.write("\n".join(bams) + "\n")
     return fa, fofn, contigs
+
+
+# BASELINE config 4 at its stated size: ~100 Mb draft, many contigs, 20x ONT-like reads; contigs longer than the 5 Mb window
+# are polished in overlapping windows and stitched (12.5 Mb = 3 windows, 9 Mb = 2 ...).  Groups = one FASTA + BAM + fofn
+# each (one per worker process of the harness); golden md5s of the compiled reference: tests/golden/config4_golden.json
+# (tests/golden/make_config4_golden.py).
+def config4_groups(total=100000000, seed=20250117 + 4, n_groups=8):
+    import math
+    import random
+    rng = random.Random(seed)
+    lens = [12500000, 9000000, 6000000, 5200000]
+    acc = sum(lens)
+    while acc < total:
+        L = int(math.exp(rng.uniform(math.log(50e3), math.log(5e6))))
+        L = min(L, total - acc) if total - acc > 50000 else total - acc
+        lens.append(L)
+        acc += L
+    groups = [[] for _ in range(n_groups)]
+    load = [0] * n_groups
+    for L in sorted(lens, reverse=True):        # longest first onto the lightest group
+        k = load.index(min(load))
+        groups[k].append(L)
+        load[k] += L
+    return groups
+
+
+def materialise_config4_group(k, lens, workdir, depth=20.0):
+    from nextpolish_amd import _native as nat
+    d = os.path.join(workdir, "g%d" % k)
+    os.makedirs(d, exist_ok=True)
+    st = nat.Stream.synth_long(lens, depth=depth, seed=9000 + k, prefix="g%dc" % k)
+    fa, bam, fofn = os.path.join(d, "g.fa"), os.path.join(d, "r.bam"), os.path.join(d, "bam.fofn")
+    st.write_files(fa, bam)
+    names = list(st.names)
+    st.close()
+    with open(fofn, "w") as f:
+        f.write(bam + "\n")
+    return fa, fofn, names

@@ -1,0 +1,32 @@
+"""BASELINE configs 3 and 4 at their stated sizes on one MI355X (the checks themselves live in tests/tools/ so they can be run
+by hand; each prints one JSON line and exits non-zero on a mismatch)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_tool(name, *args):
+    p = subprocess.run([sys.executable, os.path.join(HERE, "tools", name)] + list(args), capture_output=True, text=True)
+    assert p.stdout.strip(), p.stderr[-2000:]
+    info = json.loads(p.stdout.strip().splitlines()[-1])
+    assert p.returncode == 0, (info, p.stderr[-2000:])
+    return info
+
+
+def test_config3_size_short_reads_100mb_in_batches_matches_oracle():
+    """~100 Mb in 94 contigs, 30x PE150 (20 M records), eight HBM batches, every contig bit-identical to the CPU oracle."""
+    info = run_tool("check_config3.py")
+    assert info["mismatches"] == 0 and info["draft_bp"] == 100000000 and info["batches"] >= 8 and info["contigs"] >= 50
+
+
+def test_config4_size_long_reads_100mb_many_contigs_matches_reference_golden():
+    """~100 Mb in 67 contigs, 20x ONT-like reads, four contigs of two or three windows, eight worker processes on the GPU:
+    every contig identical (md5 + length) to what the compiled reference produced for the same files."""
+    info = run_tool("check_config4.py")
+    assert info["mismatches"] == 0 and info["missing"] == 0 and info["contigs"] == 67 and info["contigs_over_one_window"] >= 4
