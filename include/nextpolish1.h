@@ -181,6 +181,34 @@ void np1_ctx_destroy(np1_ctx* ctx);
 typedef struct np1_batch np1_batch;
 np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* s);
 void np1_batch_free(np1_batch* b);
+/* Streaming use: an empty batch object bound to a context, (re)filled from successive host streams.  Its HBM buffers only
+ * grow, so nothing is allocated in steady state; np1_batch_reload leaves the H2D copies in flight on the context's stream
+ * (the stream's arrays must stay alive until the pass is complete; pin them with np1_stream_pin for full-rate asynchronous
+ * copies).  np1_batch_results_fetch moves the polished strings of the whole batch into a pinned host buffer with one D2H
+ * copy on the same stream and waits for it; np1_batch_results_ptr()[bounds[c] .. bounds[c+1]) is contig c. */
+np1_batch* np1_batch_create(np1_ctx* ctx);
+int np1_batch_reload(np1_batch* b, const np1_stream* s);
+int np1_stream_pin(np1_stream* s);
+int np1_batch_results_fetch(np1_batch* b);
+const char* np1_batch_results_ptr(np1_batch* b);
+const uint32_t* np1_batch_results_bounds(np1_batch* b);
+
+/* Streamed polishing (SURVEY.md 8d timing scope 1): batches flow  pinned host arrays -> H2D -> score_chain kernels -> D2H
+ * on `lanes` device lanes (one HIP stream + one reusable HBM batch + one host thread each), so the copies of one batch
+ * overlap the kernels of another.  np1_pipe_run polishes the given streams (batch k = streams[k]) and keeps the polished
+ * strings inside the pipe until the next run: np1_pipe_result(p, k, c, &len) is contig c of batch k.
+ * task: 1 = score_chain, 2 = kmer_count.  Returns 0 on success (np1_last_error otherwise). */
+typedef struct np1_pipe np1_pipe;
+np1_pipe* np1_pipe_open(int device, int lanes);
+int np1_pipe_run(np1_pipe* p, np1_stream* const* streams, int n, const Configure* cfg, int task);
+const char* np1_pipe_result(np1_pipe* p, int batch, int64_t contig, int64_t* len);
+void np1_pipe_close(np1_pipe* p);
+/* From files: contigs of the FASTA index (all when names == NULL) are packed in index order into batches of at most
+ * batch_bp draft bases; host threads load batch k+1.. (BGZF inflate + record split) while the lanes polish batch k.
+ * Every finished contig is handed to `sink` in index order (user, name, sequence, length).  Returns 0 on success. */
+typedef void (*np1_sink_fn)(void* user, const char* name, const char* seq, int64_t len);
+int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const char* const* names, int n_names, int64_t batch_bp,
+                       const Configure* cfg, int task, np1_sink_fn sink, void* user);
 
 /* Names of the timed stages of one score_chain pass, in launch order (for profiles / roofline). */
 #define NP1_MAX_STAGES 16

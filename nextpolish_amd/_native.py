@@ -77,6 +77,9 @@ class SynthLongParams(C.Structure):
                 ("clip_rate", C.c_double)]
 
 
+SINK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64)   # (user, name, seq pointer, length)
+
+
 def lib():
     """Loads nextpolish1.so once; raises if it has not been built."""
     global _lib
@@ -148,6 +151,25 @@ def lib():
     L.np1_batch_device_bytes.restype = C.c_int64
     L.calgs.argtypes = [C.c_char_p]
     L.calgs.restype = C.c_uint64
+    L.np1_stream_pin.argtypes = [C.c_void_p]
+    L.np1_stream_pin.restype = C.c_int
+    L.np1_batch_create.argtypes = [C.c_void_p]
+    L.np1_batch_create.restype = C.c_void_p
+    L.np1_batch_reload.argtypes = [C.c_void_p, C.c_void_p]
+    L.np1_batch_reload.restype = C.c_int
+    L.np1_batch_results_fetch.argtypes = [C.c_void_p]
+    L.np1_batch_results_fetch.restype = C.c_int
+    L.np1_pipe_open.argtypes = [C.c_int, C.c_int]
+    L.np1_pipe_open.restype = C.c_void_p
+    L.np1_pipe_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(Configure), C.c_int]
+    L.np1_pipe_run.restype = C.c_int
+    L.np1_pipe_result.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_int64)]
+    L.np1_pipe_result.restype = C.c_void_p
+    L.np1_pipe_close.argtypes = [C.c_void_p]
+    L.np1_pipe_close.restype = None
+    L.np1_pipe_run_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int64,
+                                     C.POINTER(Configure), C.c_int, SINK_FN, C.c_void_p]
+    L.np1_pipe_run_files.restype = C.c_int
     _lib = L
     return L
 
@@ -279,6 +301,11 @@ class Stream(object):
         v.draft_len, v.cigar_len, v.seq_len, v.qual_len = len(draft), len(cig), len(seq), len(qual)
         names = (C.c_char_p * max(1, nc))(*[n.encode() for n, _ in contigs])
         return cls(lib().np1_stream_build(C.byref(v), names))
+
+    def pin(self):
+        """Page-locks the stream's arrays (asynchronous full-rate H2D copies; needs a HIP device)."""
+        if lib().np1_stream_pin(self.handle) != 0:
+            raise RuntimeError("np1_stream_pin: " + last_error())
 
     def algorithmic_bytes(self, with_qual=False):
         return int(lib().np1_stream_algorithmic_bytes(self.handle, 1 if with_qual else 0))

@@ -2,8 +2,8 @@
 // (reference: source/lib/main.c:12-75, contig_total source/lib/contig.c:1056-1110):
 //   nextpolish1 <scorechain|kmercount|snpphase|snpvalid|lgspolish> fasta bam [bam3]
 // prints ">name_<step>\nseq" per contig in FASTA-index order.  Unlike the reference, which loops
-// score_chain contig by contig, all contigs travel to the GPU as ONE batch (the records are read in a
-// single sequential pass over the BAM).
+// score_chain contig by contig, the contigs travel to the GPU in batches of NP1_BATCH_BP draft bases (default 16 M) on
+// NP1_LANES device lanes (default 2) while host threads inflate and split the records of the next batches (np1_pipe.cpp).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,26 +46,25 @@ int main(int argc, char* argv[]) {
     Configure* cfg = (step == 5) ? config_init(argv[2], nullptr, argv[3]) : config_init(argv[2], argv[3], argc > 4 ? argv[4] : nullptr);
     if (step == 1 || step == 2) {
         if (!cfg->bamfn) { fprintf(stderr, "cannot access BAM %s\n", argv[3]); return 1; }
-        np1_stream* st = np1_stream_load(cfg->fastafn, cfg->bamfn, nullptr, 0, step == 2 ? 1 : 0);
-        if (!st) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
-        int dev = 0;
+        // contigs flow through the device in batches (FASTA-index order), loaders and lanes overlapped: np1_pipe.cpp
+        int dev = 0, lanes = 2;
+        long long batch_bp = 16000000;
         if (const char* e = getenv("NP1_DEVICE")) dev = atoi(e);
-        np1_ctx* ctx = np1_ctx_create(dev);
-        if (!ctx) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
-        np1_batch* b = np1_batch_upload(ctx, st);
-        if (!b || (step == 1 ? np1_batch_score_chain(b, cfg, nullptr) : np1_batch_kmer_count(b, cfg, nullptr)) != 0) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
-        np1_stream_view v;
-        np1_stream_get_view(st, &v);
-        std::vector<char> buf;
-        for (int64_t c = 0; c < v.n_contigs; ++c) {
-            int64_t len = np1_batch_result_len(b, c);
-            buf.resize((size_t)len + 1);
-            if (np1_batch_result_copy(b, c, buf.data(), len + 1) != 0) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
-            printf(">%s_%d\n%s\n", np1_stream_contig_name(st, c), step, buf.data());
+        if (const char* e = getenv("NP1_LANES")) lanes = atoi(e);
+        if (const char* e = getenv("NP1_BATCH_BP")) batch_bp = atoll(e);
+        np1_pipe* pipe = np1_pipe_open(dev, lanes);
+        if (!pipe) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+        struct Out { int step; } out{step};
+        auto sink = [](void* user, const char* name, const char* seq, int64_t len) {
+            printf(">%s_%d\n", name, static_cast<Out*>(user)->step);
+            fwrite(seq, 1, (size_t)len, stdout);
+            fputc('\n', stdout);
+        };
+        if (np1_pipe_run_files(pipe, cfg->fastafn, cfg->bamfn, nullptr, 0, batch_bp, cfg, step, sink, &out) != 0) {
+            fprintf(stderr, "%s\n", np1_last_error());
+            return 1;
         }
-        np1_batch_free(b);
-        np1_ctx_destroy(ctx);
-        np1_stream_free(st);
+        np1_pipe_close(pipe);
     } else {
         PolishResult* (*fn)(const char*, Configure*) = step == 2 ? kmer_count : step == 3 ? snp_phase : step == 4 ? snp_valid : lgspolish;
         np1_stream* st = np1_stream_load(cfg->fastafn, cfg->bamfn ? cfg->bamfn : argv[3], nullptr, 0, 0);

@@ -15,8 +15,8 @@
 #include "../../include/nextpolish1.h"
 #include "np_bam.h"
 #include "np_stream.h"
+#include "np1_priv.h"
 
-struct np1_stream { np::ReadStream s; };
 int np1_batch_download_slots(np1_batch* b, int64_t c, std::vector<uint32_t>* soff, std::vector<uint16_t>* res);
 
 namespace {

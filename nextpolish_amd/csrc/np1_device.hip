@@ -13,9 +13,8 @@
 #include "np1_kernels.h"
 #include "np1_kmer_kernels.h"
 #include "np_stream.h"
+#include "np1_priv.h"
 
-void np1_set_error(const std::string& e);   // np_host_abi.cpp
-struct np1_stream { np::ReadStream s; };
 
 using namespace np1k;
 
@@ -91,7 +90,9 @@ struct np1_batch {
     // results of the last run
     uint32_t S = 0;
     uint64_t votes = 0;
-    bool ran = false, out_cached = false;
+    bool ran = false, out_cached = false, out_pinned = false;
+    uint8_t* h_pin = nullptr;   // pinned copy of `out` (np1_batch_results_fetch)
+    size_t h_pin_cap = 0;
     std::vector<uint32_t> h_bounds;
     std::vector<uint8_t> h_out;
     std::vector<uint32_t> h_ctg_off;
@@ -165,17 +166,24 @@ static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t st) {
     return 0;
 }
 
-np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* st) {
-    if (!ctx || !st) { np1_set_error("np1_batch_upload: null argument"); return nullptr; }
+// (Re)fills a batch object from a host stream: the HBM buffers only grow, so a batch object that is reused for a sequence of
+// similar batches allocates nothing in steady state.  sync = false leaves the copies in flight on the context's stream (the
+// kernels that follow are ordered behind them); the host arrays must then stay alive and -- for the copies to overlap with
+// other lanes' work -- pinned (np1_stream_pin).
+static int fill_batch(np1_batch* b, const np1_stream* st, bool sync) {
+    np1_ctx* ctx = b->ctx;
     const np::ReadStream& s = st->s;
-    if (s.draft.size() >= 0xfff00000ull) { np1_set_error("batch too large: draft must stay below 2^32 slots"); return nullptr; }
+    if (s.draft.size() >= 0xfff00000ull) { np1_set_error("batch too large: draft must stay below 2^32 slots"); return -1; }
     (void)hipSetDevice(ctx->device);
-    np1_batch* b = new np1_batch();
-    b->ctx = ctx;
     b->nc = (uint32_t)s.n_contigs();
     b->G = s.draft.size();
     b->n_reads = (int64_t)s.n_reads();
     b->h_ctg_off = s.ctg_off;
+    b->max_lq = 0;
+    b->force_staged = false;
+    b->ran = false;
+    b->out_cached = false;
+    b->out_pinned = false;
     for (int32_t l : s.l_qseq)
         if (l > 0 && (uint32_t)l > b->max_lq) b->max_lq = (uint32_t)l;
     hipStream_t q = ctx->stream;
@@ -191,7 +199,6 @@ np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* st) {
     rc |= upload(b->cigoff, s.cigar_off.data(), 8 * n, q);
     rc |= upload(b->seqoff, s.seq_off.data(), 8 * n, q);
     rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);
-    // +8 bytes of slack: the trim loops never read past l_qseq, but keep loads inside the allocation anyway
     rc |= upload(b->seq, s.seq.data(), s.seq.size(), q);
     b->h_read_begin = s.read_begin;
     rc |= upload(b->read_begin, s.read_begin.data(), 8 * s.read_begin.size(), q);
@@ -202,10 +209,49 @@ np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* st) {
         rc |= upload(b->qualoff, s.qual_off.data(), 8 * n, q);
         rc |= upload(b->qual, s.qual.data(), s.qual.size(), q);
     }
-    if (rc == 0 && hipStreamSynchronize(q) != hipSuccess) { np1_set_error("upload failed"); rc = -1; }
-    if (rc != 0) { b->release_all(); delete b; return nullptr; }
+    if (rc == 0 && sync && hipStreamSynchronize(q) != hipSuccess) { np1_set_error("upload failed"); rc = -1; }
     b->input_bytes = s.draft.size() + 32 * n + 4 * s.cigar.size() + s.seq.size();
+    return rc;
+}
+
+np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* st) {
+    if (!ctx || !st) { np1_set_error("np1_batch_upload: null argument"); return nullptr; }
+    np1_batch* b = new np1_batch();
+    b->ctx = ctx;
+    if (fill_batch(b, st, true) != 0) { b->release_all(); delete b; return nullptr; }
     return b;
+}
+
+np1_batch* np1_batch_create(np1_ctx* ctx) {
+    if (!ctx) { np1_set_error("np1_batch_create: null context"); return nullptr; }
+    np1_batch* b = new np1_batch();
+    b->ctx = ctx;
+    return b;
+}
+
+int np1_batch_reload(np1_batch* b, const np1_stream* st) {
+    if (!b || !st) { np1_set_error("np1_batch_reload: null argument"); return -1; }
+    return fill_batch(b, st, false);
+}
+
+// Registers the arrays of a host stream with the HIP runtime (page-locked): H2D copies from them run asynchronously at
+// full PCIe rate.  What an ingest stage that writes straight into pinned staging gets for free.
+int np1_stream_pin(np1_stream* st) {
+    if (!st) return -1;
+    if (st->pinned) return 0;
+    np::ReadStream& s = st->s;
+    auto reg = [](const void* p, size_t bytes) {
+        if (!p || !bytes) return true;
+        return hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess;
+    };
+    bool ok = reg(s.draft.data(), s.draft.size()) && reg(s.pos.data(), 4 * s.pos.size()) && reg(s.ctg.data(), 4 * s.ctg.size()) &&
+              reg(s.flag.data(), 2 * s.flag.size()) && reg(s.n_cigar.data(), 2 * s.n_cigar.size()) && reg(s.l_qseq.data(), 4 * s.l_qseq.size()) &&
+              reg(s.cigar_off.data(), 8 * s.cigar_off.size()) && reg(s.seq_off.data(), 8 * s.seq_off.size()) &&
+              reg(s.cigar.data(), 4 * s.cigar.size()) && reg(s.seq.data(), s.seq.size()) && reg(s.mapq.data(), s.mapq.size()) &&
+              reg(s.isize.data(), 4 * s.isize.size()) && reg(s.qual_off.data(), 8 * s.qual_off.size()) && reg(s.qual.data(), s.qual.size());
+    st->pinned = true;   // also after a partial failure: unpin releases what was registered
+    if (!ok) { np1_stream_unpin(st); np1_set_error("hipHostRegister failed"); return -1; }
+    return 0;
 }
 
 void np1_batch_free(np1_batch* b) {
@@ -213,6 +259,7 @@ void np1_batch_free(np1_batch* b) {
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     b->release_all();
+    if (b->h_pin) (void)hipHostFree(b->h_pin);
     delete b;
 }
 
@@ -233,6 +280,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     hipStream_t q = ctx->stream;
     b->ran = false;
     b->out_cached = false;
+    b->out_pinned = false;
     int K = 0;
     long long Rfix = 0;
     if (!rate_fixed_point(cfg->indel_balance_factor_sgs, &K, &Rfix)) {
@@ -518,6 +566,7 @@ int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
     hipStream_t q = ctx->stream;
     b->ran = false;
     b->out_cached = false;
+    b->out_pinned = false;
     int K = 0;
     long long Rfix = 0;
     if (!rate_fixed_point(cfg->indel_balance_factor_sgs, &K, &Rfix)) {
@@ -680,10 +729,34 @@ int64_t np1_batch_result_len(np1_batch* b, int64_t c) {
     return (int64_t)b->h_bounds[(size_t)c + 1] - (int64_t)b->h_bounds[(size_t)c];
 }
 
+// Polished strings of the whole batch -> pinned host buffer, on the batch's stream (one D2H copy), then waits for it.
+int np1_batch_results_fetch(np1_batch* b) {
+    if (!b || !b->ran) { np1_set_error("np1_batch_results_fetch: no completed run"); return -1; }
+    (void)hipSetDevice(b->ctx->device);
+    const size_t total = b->h_bounds[b->nc];
+    if (total + 1 > b->h_pin_cap) {
+        if (b->h_pin) (void)hipHostFree(b->h_pin);
+        b->h_pin = nullptr;
+        b->h_pin_cap = total + total / 8 + 4096;
+        if (!hip_ok(hipHostMalloc((void**)&b->h_pin, b->h_pin_cap, hipHostMallocDefault), "hipHostMalloc")) { b->h_pin_cap = 0; return -1; }
+    }
+    if (total) HIPCHK(hipMemcpyAsync(b->h_pin, b->out.p, total, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    b->out_pinned = true;
+    return 0;
+}
+const char* np1_batch_results_ptr(np1_batch* b) { return (b && b->out_pinned) ? (const char*)b->h_pin : nullptr; }
+const uint32_t* np1_batch_results_bounds(np1_batch* b) { return (b && b->ran) ? b->h_bounds.data() : nullptr; }
+
 int np1_batch_result_copy(np1_batch* b, int64_t c, char* dst, int64_t cap) {
     int64_t len = np1_batch_result_len(b, c);
     if (len < 0 || cap < len + 1) { np1_set_error("np1_batch_result_copy: no result or buffer too small"); return -1; }
     (void)hipSetDevice(b->ctx->device);
+    if (b->out_pinned) {
+        memcpy(dst, b->h_pin + b->h_bounds[(size_t)c], (size_t)len);
+        dst[len] = '\0';
+        return 0;
+    }
     if (!b->out_cached) {
         size_t total = b->h_bounds[b->nc];
         b->h_out.resize(total + 1);
@@ -715,6 +788,16 @@ int64_t np1_batch_update_count(np1_batch* b) { return b && b->ran ? (int64_t)b->
 int64_t np1_batch_device_bytes(np1_batch* b) { return b ? (int64_t)b->device_bytes() : -1; }
 
 }  // extern "C"
+
+void np1_stream_unpin(np1_stream* st) {
+    if (!st || !st->pinned) return;
+    np::ReadStream& s = st->s;
+    const void* ptrs[] = {s.draft.data(), s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), s.l_qseq.data(), s.cigar_off.data(),
+                          s.seq_off.data(), s.cigar.data(), s.seq.data(), s.mapq.data(), s.isize.data(), s.qual_off.data(), s.qual.data()};
+    for (const void* p : ptrs)
+        if (p) (void)hipHostUnregister(const_cast<void*>(p));   // fails harmlessly for arrays that were empty / never registered
+    st->pinned = false;
+}
 
 // ---- internal accessors used by the drop-in entry points (np1_abi.cpp) for the -debug trace list
 int np1_batch_download_slots(np1_batch* b, int64_t c, std::vector<uint32_t>* soff, std::vector<uint16_t>* res) {

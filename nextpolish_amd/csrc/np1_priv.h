@@ -1,0 +1,13 @@
+// Definitions shared by the translation units behind include/nextpolish1.h, Part 2 (not part of the ABI).
+#pragma once
+#include <string>
+
+#include "np_stream.h"
+
+struct np1_stream {
+    np::ReadStream s;
+    bool pinned = false;   // the arrays are registered with the HIP runtime (np1_stream_pin): H2D copies from them are asynchronous
+};
+
+void np1_set_error(const std::string& e);   // np_host_abi.cpp
+void np1_stream_unpin(np1_stream* st);      // np1_device.hip (no-op when the stream was never pinned)

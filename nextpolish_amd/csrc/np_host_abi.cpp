@@ -5,10 +5,10 @@
 
 #include "../../include/nextpolish1.h"
 #include "np_stream.h"
+#include "np1_priv.h"
 #include "np_synth.h"
 #include "np_inflate.h"
 
-struct np1_stream { np::ReadStream s; };
 
 static thread_local std::string g_err;
 extern "C" const char* np1_last_error(void) { return g_err.c_str(); }
@@ -79,7 +79,11 @@ int np1_stream_write_files_aux(const np1_stream* st, const char* fasta, const ch
     return 0;
 }
 
-void np1_stream_free(np1_stream* st) { delete st; }
+void np1_stream_free(np1_stream* st) {
+    if (!st) return;
+    np1_stream_unpin(st);
+    delete st;
+}
 
 np1_stream* np1_stream_build(const np1_stream_view* v, const char* const* names) {
     np1_stream* st = new np1_stream();

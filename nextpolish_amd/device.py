@@ -86,3 +86,64 @@ class Context(object):
         if self.handle:
             nat.lib().np1_ctx_destroy(self.handle)
             self.handle = None
+
+
+class Pipe(object):
+    """Streamed polishing on several device lanes (np1_pipe_* in include/nextpolish1.h): pinned host arrays -> H2D -> kernels
+    -> D2H with the copies of one batch behind the kernels of another."""
+
+    def __init__(self, device=0, lanes=2):
+        if nat.lib().np1_device_count() <= 0:
+            raise RuntimeError("no HIP device available; nextpolish_amd has no CPU fallback")
+        self.handle = nat.lib().np1_pipe_open(device, lanes)
+        if not self.handle:
+            raise RuntimeError("np1_pipe_open: " + nat.last_error())
+
+    def run(self, streams, cfg=None, task=1, fetch=True):
+        """Polishes the host streams (one batch each); returns [[sequence per contig] per batch] (or None when fetch=False)."""
+        cfg = cfg or nat.default_config()
+        arr = (C.c_void_p * len(streams))(*[s.handle for s in streams])
+        if nat.lib().np1_pipe_run(self.handle, arr, len(streams), C.byref(cfg), task) != 0:
+            raise RuntimeError("np1_pipe_run: " + nat.last_error())
+        if not fetch:
+            return None
+        out = []
+        n = C.c_int64(0)
+        for k, st in enumerate(streams):
+            row = []
+            for c in range(st.n_contigs):
+                p = nat.lib().np1_pipe_result(self.handle, k, c, C.byref(n))
+                row.append(C.string_at(p, n.value).decode())
+            out.append(row)
+        return out
+
+    def result_lengths(self, streams):
+        n = C.c_int64(0)
+        tot = 0
+        for k, st in enumerate(streams):
+            for c in range(st.n_contigs):
+                nat.lib().np1_pipe_result(self.handle, k, c, C.byref(n))
+                tot += n.value
+        return tot
+
+    def run_files(self, fasta, bam, names=None, batch_bp=16000000, cfg=None, task=1, sink=None):
+        """BAM + FASTA on disk -> sink(name, sequence) per contig in FASTA-index order (loaders, lanes and sink overlapped)."""
+        cfg = cfg or nat.default_config()
+        got = []
+
+        def _sink(_user, name, seq, length):
+            s = C.string_at(seq, length).decode()
+            (sink or (lambda a, b: got.append((a, b))))(name.decode(), s)
+
+        cb = nat.SINK_FN(_sink)
+        names = list(names or [])
+        arr = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        if nat.lib().np1_pipe_run_files(self.handle, fasta.encode(), bam.encode(), arr if names else None, len(names), batch_bp,
+                                        C.byref(cfg), task, cb, None) != 0:
+            raise RuntimeError("np1_pipe_run_files: " + nat.last_error())
+        return got
+
+    def close(self):
+        if self.handle:
+            nat.lib().np1_pipe_close(self.handle)
+            self.handle = None

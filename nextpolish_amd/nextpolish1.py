@@ -5,14 +5,14 @@ Same command line, same block-file / resume / naming behaviour, same output reco
 (``>name_np1 length`` + sequence); the compute goes through the in-tree HIP library instead of a
 ``multiprocessing.Pool`` of CPU workers:
 
-* task 1 (score_chain): the still-unpolished contigs of this block are decoded once, sequentially,
-  into a record stream, split into batches that fit the HBM budget, and each batch is polished by the
-  fused launch sequence (include/nextpolish1.h, np1_batch_*).  ``--gpus N`` shards the batches over N
-  GPUs of the node, one process per GPU (contigs are independent: no collective on the data path;
+* tasks 1 and 2 (score_chain, kmer_count): the still-unpolished contigs of this block are packed into batches of
+  ``--batch_bp`` draft bases that flow loader threads -> pinned host arrays -> H2D -> kernels -> D2H on ``--lanes``
+  device lanes (include/nextpolish1.h, np1_pipe_*).  ``--world N --rank r`` deals the block's contigs over N
+  GPUs of the node longest-first, one process per GPU (contigs are independent: no collective on the data path;
   reference: nextpolish1.py:181-189,223-224 and source/nextPolish:93-117 for the block split).
 * ``-debug`` needs the per-base change list of the drop-in ABI and therefore goes contig by contig through
   ``score_chain(tigname, cfg)`` exactly like the reference worker (nextpolish1.py:181-189).
-* tasks 2-5 call the library's drop-in symbols, which report what is (not) available on the GPU path.
+* tasks 3-5 call the library's drop-in symbols, which report what is (not) available on the GPU path.
 
 Record order is the order of the block file / FASTA (the reference's order is nondeterministic: it
 iterates a Python set through imap_unordered, nextpolish1.py:148-161,224).
@@ -146,23 +146,20 @@ def rank_share(all_names, lengths, world, rank, polished_seqs, filter_polished):
     return out
 
 
-def polish_score_chain_batched(args, cfg, names, device, emit):
-    from nextpolish_amd.device import Context
+def polish_batched(args, cfg, names, device, emit):
+    """Tasks 1 and 2 without -debug: the rank's contigs flow through the device in batches of --batch_bp draft bases on
+    --lanes device lanes while host threads inflate and split the records of the next batches (np1_pipe_run_files)."""
+    from nextpolish_amd.device import Pipe
     lengths = fasta_lengths(args.genome)
     names = [n for n in names if n in lengths]
-    batches = plan_batches(names, lengths, args.batch_bp)
-    ctx = Context(device)
+    if not names:
+        return
+    pipe = Pipe(device, args.lanes)
     try:
-        for b in batches:
-            st = nat.Stream.load(args.genome, args.bam_sgs, names=b)
-            batch = ctx.upload(st)
-            batch.score_chain(cfg.contents)
-            for name, seq in zip(st.names, batch.results()):
-                emit(name, seq, [])
-            batch.close()
-            st.close()
+        pipe.run_files(args.genome, args.bam_sgs, names=names, batch_bp=args.batch_bp, cfg=cfg.contents, task=args.task,
+                       sink=lambda name, seq: emit(name, seq, []))
     finally:
-        ctx.close()
+        pipe.close()
 
 
 def polish_per_contig(args, cfg, names, fun, emit):
@@ -208,9 +205,9 @@ def main(args):
             print(name + " %d %d %c %c" % p, file=sys.stderr)
 
     fun = {1: L.score_chain, 2: L.kmer_count, 3: L.snp_phase, 4: L.snp_valid, 5: L.lgspolish}[args.task]
-    if args.task == 1 and not args.debug:
+    if args.task in (1, 2) and not args.debug:
         device = args.device if args.device >= 0 else args.rank
-        polish_score_chain_batched(args, cfg, names, device, emit)
+        polish_batched(args, cfg, names, device, emit)
     else:
         polish_per_contig(args, cfg, names, fun, emit)
     if args.out != "stdout":
@@ -264,8 +261,9 @@ def build_parser():
     gpu.add_argument("--rank", type=int, default=int(os.environ.get("LOCAL_RANK", "0")))
     gpu.add_argument("--world", type=int, default=int(os.environ.get("WORLD_SIZE", "1")),
                      help="number of processes sharing this block (one per GPU); each writes its own -o part")
-    gpu.add_argument("--batch_bp", type=parse_num_unit, default=parse_num_unit("500m"),
-                     help="draft bases per HBM-resident batch")
+    gpu.add_argument("--batch_bp", type=parse_num_unit, default=parse_num_unit("16m"),
+                     help="draft bases per HBM-resident batch (a longer contig is a batch of its own)")
+    gpu.add_argument("--lanes", type=int, default=2, help="batches in flight on the device (HIP stream + host thread each)")
     return p
 
 

@@ -267,3 +267,34 @@ def test_full_size_kmer_count_matches_oracle(ctx):
     st = nat.Stream.synth([2500000, 1500000, 1000000], depth=50.0, seed=20250120, with_qual=1, draft_lower=0.004)
     _check_kmer(ctx, st)
     st.close()
+
+
+def test_streamed_pipe_matches_oracle_and_direct_path(tmp_path):
+    """np1_pipe_*: batches on two device lanes with reused HBM buffers and pinned host arrays (sizes shrink and grow between
+    batches), from memory and from files (loader threads + in-order sink), score_chain and kmer_count."""
+    from nextpolish_amd.device import Pipe
+    sts = [nat.Stream.synth(lens, depth=d, seed=900 + k, with_qual=1, draft_lower=0.01, prefix="b%dc" % k)
+           for k, (lens, d) in enumerate([([40000, 9000], 30), ([3000], 60), ([120000, 500, 70000], 25), ([15000], 8), ([60000, 60000], 40)])]
+    for st in sts:
+        st.pin()
+    pipe = Pipe(0, lanes=2)
+    for rep in range(2):      # second pass: every buffer is reused
+        got = pipe.run(sts)
+        for k, st in enumerate(sts):
+            assert got[k] == [ob.score_chain(st, i) for i in range(st.n_contigs)], "batch %d pass %d" % (k, rep)
+    cfg = nat.default_config()
+    cfg.read_tlen = 1500
+    got = pipe.run(sts, cfg=cfg, task=2)
+    for k, st in enumerate(sts):
+        assert got[k] == [ob.kmer_count(st, i, ob.default_config(read_tlen=1500)) for i in range(st.n_contigs)], "kmer_count batch %d" % k
+    # from files: five contigs, batches of at most 50 kb -> three batches, two loaders; sink order = FASTA index order
+    big = nat.Stream.synth([40000, 9000, 30000, 45000, 2000], depth=30, seed=77, with_qual=1, draft_lower=0.01)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "g.bam")
+    big.write_files(fa, bam)
+    out = pipe.run_files(fa, bam, batch_bp=50000)
+    assert [n for n, _ in out] == big.names
+    assert [s for _, s in out] == [ob.score_chain(big, i) for i in range(big.n_contigs)]
+    out = pipe.run_files(fa, bam, names=[big.names[3], big.names[1]], batch_bp=50000, cfg=cfg, task=2)
+    assert [n for n, _ in out] == [big.names[3], big.names[1]]
+    assert [s for _, s in out] == [ob.kmer_count(big, i, ob.default_config(read_tlen=1500)) for i in (3, 1)]
+    pipe.close()

@@ -123,7 +123,7 @@ def test_configure_layout_matches_reference_abi():
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "nextpolish1.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b([a-z_][a-z0-9_]*)\s*\(", hdr)) - {"defined", "float"}
+    names = set(re.findall(r"\b([a-z_][a-z0-9_]*)\s*\(", hdr)) - {"defined", "float", "void"}   # "void (" = the function-pointer typedef
     names = {n for n in names if not n.startswith("__")}
     assert {"config_init", "config_destory", "score_chain", "kmer_count", "snp_phase", "snp_valid", "lgspolish",
             "polishresult_destory", "np1_batch_score_chain", "calgs"} <= names
