@@ -1,96 +1,149 @@
 #!/usr/bin/env python
-"""Headline benchmark: short-read score_chain polishing throughput (BASELINE.json metric).
+"""Headline benchmark: short-read score_chain polishing throughput (BASELINE.json metric) on the metric's 30x shape.
 
-One "step" = one full score_chain pass (every kernel of nextpolish_amd/csrc/np1_device.hip's launch
-sequence) over one batch of synthetic draft contigs + position-sorted short reads that is already
-resident in HBM.  Default workload = BASELINE.json configs[1]: 5 Mb draft, 50x PE150.
-With --gpus N every rank polishes its own 5 Mb shard (contigs are independent units: weak scaling,
-no data-path collective; reference: source/lib/nextpolish1.py:181-189,223-224).
+Workload (default c3_100mb_30x = BASELINE.json configs[2], the largest 30x draft that is generated and polished within the
+default run's budget; c5_3gb_30x is the metric's own 3 Gb shape for manual runs): a FIXED synthetic draft (contig lengths
+log-uniform in [50 kb, 5 Mb]) + 30x simulated 2x150 bp PE reads.  The contigs are dealt longest-first over the
+N ranks (contigs are independent units: strong scaling of one fixed draft, no data-path collective; reference:
+source/lib/nextpolish1.py:181-189,223-224) and packed into HBM batches of <= 13 Mb.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task description), including
-  roofline     : achieved algorithmic HBM bytes/s of the dominant kernel (k_vote) vs the 8 TB/s peak
-  cpu_baseline : the reference CPU path (oracle/_ref/nextpolish1, or the oracle port) timed on a
-                 bounded sample of the same workload on this box's host cores (rank 0, N=1 only).
+One "step" = one full score_chain pass (every kernel of np1_device.hip's launch sequence) over the WHOLE draft, i.e. over all
+of the rank's batches, the batches already resident in HBM (`value`, the contract's scope); two device lanes keep two batches
+in flight so the host-side syncs of one hide behind the kernels of the other.  Beside it, in the same JSON line:
+  streamed          pinned host arrays -> async H2D -> kernels -> D2H of the polished strings, double-buffered on the device
+                    lanes, everything inside the timed region (SURVEY.md 8d timing scope 1)
+  e2e_from_files    FASTA + sorted BAM on disk (page cache) -> polished FASTA, cold process of the CLI (scope 2), N=1 only
+  roofline          dominant kernel: algorithmic bytes per launch / HIP-event time per launch vs the 8 TB/s HBM peak, and
+                    the PMC traffic per launch (two rocprofv3 --pmc passes)
+  cpu_baseline      the compiled reference (oracle/_ref/nextpolish1) on this box's host cores, one process per core like -p N,
+                    and one core alone, on a bounded sample of the same shape (rank 0, N=1 only)
+  lgs               the long-read path (lib/nextpolish2.so ctg_cns_core) with its own roofline and cpu_baseline
 """
 import argparse
 import json
+import math
 import os
+import random
+import shutil
 import subprocess
 import sys
 import tempfile
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 WORKLOADS = {
-    # name: (contig truth lengths, depth)            -- SURVEY.md §8d synthetic shapes
-    "c2_5mb_50x": ([2500000, 1500000, 1000000], 50.0),
-    "small_1mb_50x": ([600000, 400000], 50.0),
-    "c3shard_12mb_30x": ([3000000, 2500000, 2000000, 1500000, 1200000, 1000000, 800000], 30.0),
+    # name: (total draft bp, depth, min contig, max contig, batch bp)      -- SURVEY.md 8d synthetic shapes
+    "c3_100mb_30x": (100000000, 30.0, 50e3, 5e6, 13000000),
+    "c2_5mb_50x": (5000000, 50.0, 1e6, 2.5e6, 13000000),
+    "c5_3gb_30x": (3000000000, 30.0, 2e6, 250e6, 260000000),
+    "small_8mb_30x": (8000000, 30.0, 50e3, 2e6, 3000000),
 }
 
 
-def cpu_baseline(stream_factory, sample_len, depth, seed):
-    """Times the reference C path on a bounded sample (own process, 1 thread)."""
+def contig_lengths(total, lo, hi, seed=20250117 + 3):
+    rng = random.Random(seed)
+    lens, acc = [], 0
+    while acc < total:
+        L = int(math.exp(rng.uniform(math.log(lo), math.log(hi))))
+        L = min(L, total - acc) if total - acc > lo else total - acc
+        lens.append(L)
+        acc += L
+    return lens
+
+
+def host_cores():
+    n = len(os.sched_getaffinity(0))
+    try:   # cgroup v2 CPU quota, when the box has one
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(depth, sample_mb, procs):
+    """The compiled reference CLI (BAM + BGZF inflate -> FASTA): `procs` processes at once, one sample each (the reference's
+    -p N model), then one process alone.  Falls back to the oracle port (1 core) when oracle/_ref did not travel."""
     from nextpolish_amd import _native as nat
-    st = stream_factory([sample_len], depth, seed)
-    bp = int(st.ctg_len.sum())
     ref = os.path.join(ROOT, "oracle", "_ref", "nextpolish1")
-    if os.path.exists(ref):
-        with tempfile.TemporaryDirectory() as td:
-            fa, bam = os.path.join(td, "s.fa"), os.path.join(td, "s.bam")
-            st.write_files(fa, bam, 1)
-            t0 = time.time()
-            subprocess.run([ref, "scorechain", fa, bam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-            dt = time.time() - t0
-        kind = "reference"
-    else:
+    L = int(sample_mb * 1e6)
+    if not os.path.exists(ref):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding as ob
+        st = nat.Stream.synth([L], depth=depth, seed=424242)
         t0 = time.time()
-        for i in range(st.n_contigs):
-            ob.score_chain(st, i)
+        ob.score_chain(st, 0)
         dt = time.time() - t0
-        kind = "port"
-    return {"value": round(bp / 1e6 / dt, 4), "unit": "Mbp/s", "cores": 1, "kind": kind,
-            "sample": "%.1f Mb synthetic draft, %.0fx PE150, score_chain, BAM(+BGZF inflate) -> FASTA, %.1f s"
-                      % (bp / 1e6, depth, dt)}
+        return {"value": round(L / 1e6 / dt, 4), "unit": "Mbp/s", "cores": 1, "kind": "port",
+                "sample": "%.1f Mb synthetic draft, %.0fx PE150, score_chain of the oracle port in memory, %.1f s" % (L / 1e6, depth, dt)}
+    td = tempfile.mkdtemp(prefix="np1cpu_")
+    try:
+        def make(k):
+            st = nat.Stream.synth([L], depth=depth, seed=424242 + k, prefix="s%dctg" % k)
+            fa, bam = os.path.join(td, "s%d.fa" % k), os.path.join(td, "s%d.bam" % k)
+            st.write_files(fa, bam, 1)
+            st.close()
+            return fa, bam
+        with ThreadPoolExecutor(min(8, procs)) as ex:
+            files = list(ex.map(make, range(procs)))
+        t0 = time.time()
+        ps = [subprocess.Popen([ref, "scorechain", fa, bam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for fa, bam in files]
+        for p in ps:
+            p.wait()
+        dt_all = time.time() - t0
+        t0 = time.time()
+        subprocess.run([ref, "scorechain", files[0][0], files[0][1]], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        dt_one = time.time() - t0
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    return {"value": round(procs * L / 1e6 / dt_all, 4), "unit": "Mbp/s", "cores": procs, "kind": "reference",
+            "one_core": round(L / 1e6 / dt_one, 4),
+            "sample": "%d processes x %.1f Mb synthetic draft, %.0fx PE150, nextpolish1 scorechain, BAM(+BGZF inflate) -> FASTA, %.1f s; "
+                      "one process alone %.1f s" % (procs, L / 1e6, depth, dt_all, dt_one)}
 
 
-def pmc_traffic(args, kernel_substr):
-    """HBM bytes of the dominant kernel per launch from rocprofv3 PMC counters: two separate --pmc passes
-    (FETCH_SIZE, WRITE_SIZE: they do not fit one pass on gfx950) over a short child run of this script.
-    Units/corrections per MI355X_MICROARCH.md (HBM section): both counters are KiB per dispatch; on gfx950
-    FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced reads, which is how this kernel stages its
-    inputs, so the read side is doubled; WRITE_SIZE is taken as is."""
-    import shutil
+def rocprof_counter(cmd, ctr, env=None):
+    """One rocprofv3 --pmc pass over `cmd`; returns {kernel_name: (avg value per dispatch, dispatches)}."""
     import sqlite3
     exe = shutil.which("rocprofv3")
     if not exe:
-        return None, "rocprofv3 not found"
+        raise RuntimeError("rocprofv3 not found")
+    td = tempfile.mkdtemp(prefix="np1pmc_", dir="/tmp")
+    try:
+        subprocess.run([exe, "--pmc", ctr, "-d", td, "-o", "p", "--"] + cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=600, check=True, cwd="/tmp", env=dict(env or os.environ, TMPDIR="/tmp"))
+        db = None
+        for root, _d, files in os.walk(td):
+            for f in files:
+                if f.endswith(".db"):
+                    db = os.path.join(root, f)
+        c = sqlite3.connect(db)
+        rows = c.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name=? group by kernel_name",
+                         (ctr,)).fetchall()
+        return {r[0]: (float(r[1]), int(r[2])) for r in rows}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def pmc_traffic(args, kernel_substr):
+    """HBM bytes of the dominant kernel per launch: two separate --pmc passes (FETCH_SIZE, WRITE_SIZE do not fit one pass on
+    gfx950) over a short child run of this script on the same workload.  Units/corrections per MI355X_MICROARCH.md (HBM
+    section): both counters are KiB per dispatch; on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced
+    reads, which is how this kernel stages its inputs, so the read side is doubled; WRITE_SIZE is taken as is."""
     vals = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        td = tempfile.mkdtemp(prefix="np1pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", ctr, "-d", td, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
-               "--workload", args.workload, "--steps", "2", "--warmup", "1"]
         try:
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True,
-                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
-            db = None
-            for root, _d, files in os.walk(td):
-                for f in files:
-                    if f.endswith(".db"):
-                        db = os.path.join(root, f)
-            c = sqlite3.connect(db)
-            row = c.execute("select avg(value) from counters_collection where counter_name=? and kernel_name like ?",
-                            (ctr, "%" + kernel_substr + "%")).fetchone()
-            vals[ctr] = float(row[0])
+            rows = rocprof_counter([sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload,
+                                    "--steps", "1", "--warmup", "0"], ctr)
+            hit = [v for k, v in rows.items() if kernel_substr in k]
+            vals[ctr] = sum(a * n for a, n in hit) / max(1, sum(n for _a, n in hit))
         except Exception as e:   # profiling is best effort: the bench line stays valid without it
             return None, "pmc pass failed: %r" % (e,)
-        finally:
-            shutil.rmtree(td, ignore_errors=True)
     fetch_b, write_b = vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
     return {"bytes": int(2 * fetch_b + write_b), "fetch_size_kib_raw": round(vals["FETCH_SIZE"], 1),
             "write_size_kib_raw": round(vals["WRITE_SIZE"], 1), "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950)"}, None
@@ -120,15 +173,60 @@ print(t0, time.time(), bp, c1.ru_utime + c1.ru_stime - c0.ru_utime - c0.ru_stime
 """
 
 
-def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref):
+def lgs_roofline(worker_code, env, alg_bytes, with_pmc):
+    """Per-window device time of the long-read path from the library's own stage clock (NP2_TIMING: stream-synchronised wall
+    time per stage, second call = warm), the dominant stage, and the PMC traffic of ALL its kernels per window."""
+    code = worker_code.replace("while not os.path.exists", "while False and os.path.exists")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, NP2_TIMING="1"))
+    if p.returncode != 0:
+        return {"error": p.stderr[-300:]}
+    stages = {}
+    n_windows = 0
+    for line in p.stderr.splitlines():
+        if line.startswith("[np2 window]") and "| ms:" in line:
+            n_windows += 1
+            toks = line.split("| ms:")[1].split()
+            for k in range(0, len(toks) - 1, 2):
+                stages[toks[k]] = stages.get(toks[k], 0.0) + float(toks[k + 1])
+    if not stages:
+        return {"error": "no stage lines"}
+    last = {}
+    for line in p.stderr.splitlines():          # the last window line = the warm call
+        if line.startswith("[np2 window]") and "| ms:" in line:
+            toks = line.split("| ms:")[1].split()
+            last = {toks[k]: float(toks[k + 1]) for k in range(0, len(toks) - 1, 2)}
+    dev = {k: v for k, v in last.items() if k != "download"}
+    dom = max(dev, key=lambda k: dev[k])
+    total_ms = sum(dev.values())
+    out = {"bound": "hbm", "kernel": "stage '%s' of the window executor (np2_exec_hip.hip)" % dom,
+           "achieved": round(alg_bytes / (dev[dom] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(alg_bytes / (dev[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "kernel_ms": round(dev[dom], 3),
+           "algorithmic_bytes_per_window": int(alg_bytes), "device_ms_per_window": round(total_ms, 2),
+           "achieved_all_kernels_gbs": round(alg_bytes / (total_ms * 1e-3) / 1e9, 3),
+           "stage_ms": {k: round(v, 2) for k, v in last.items()}, "traffic": None}
+    if with_pmc:
+        try:
+            tot = {}
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                rows = rocprof_counter([sys.executable, "-c", code], ctr, env=env)
+                tot[ctr] = sum(a * n for a, n in rows.values()) * 1024.0
+            calls = 2     # the worker's warm-up call + its one timed call
+            out["traffic"] = int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / calls)
+            out["traffic_detail"] = "all kernels of one window: (2*FETCH_SIZE + WRITE_SIZE) summed over every dispatch of %d calls / %d" % (calls, calls)
+        except Exception as e:
+            out["traffic_detail"] = "pmc pass failed: %r" % (e,)
+    return out
+
+
+def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref, with_pmc):
     """Long-read path (BASELINE configs[3] shape: 20x ONT-like reads, lib/nextpolish2.so ctg_cns_core, BAM -> consensus):
     `workers` worker processes share this rank's GPU (the reference's -p model), each polishes its contig `calls`
     times after a warm-up; rate = polished bp of all workers / span from the common start to the last end."""
-    import shutil, subprocess, tempfile
     from nextpolish_amd import _native as nat
     d = tempfile.mkdtemp(prefix="np2bench_r%d_" % rank)
     L = int(contig_mb * 1e6)
     st = nat.Stream.synth_long([L], depth=20.0, seed=9000 + rank)
+    alg_bytes = st.algorithmic_bytes(False) - L + (L + 3) // 4 + L    # records + 2-bit draft + polished string (SURVEY.md 8d, path B)
     fa, bam, fofn = os.path.join(d, "g.fa"), os.path.join(d, "r.bam"), os.path.join(d, "bam.fofn")
     st.write_files(fa, bam)
     st.close()
@@ -138,10 +236,10 @@ def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref):
     env = dict(os.environ, NP2_DEVICE=str(local_rank))
     env.setdefault("NP_HOST_THREADS", "4")   # several workers share the host cores of one GPU
     env.setdefault("NP_IO_THREADS", "4")
+    lib2 = os.path.join(ROOT, "nextpolish_amd", "lib", "nextpolish2.so")
     ps = []
     for w in range(workers):
-        code = LGS_WORKER % dict(root=ROOT, lib=os.path.join(ROOT, "nextpolish_amd", "lib", "nextpolish2.so"), fa=fa, fofn=fofn,
-                                 ready=os.path.join(d, "ready%d" % w), go=go, calls=calls)
+        code = LGS_WORKER % dict(root=ROOT, lib=lib2, fa=fa, fofn=fofn, ready=os.path.join(d, "ready%d" % w), go=go, calls=calls)
         ps.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     t_wait = time.time()
     while not all(os.path.exists(os.path.join(d, "ready%d" % w)) for w in range(workers)):
@@ -160,35 +258,89 @@ def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref):
     res = {"bp": bp, "seconds": t1 - t0, "workers": workers, "calls_per_worker": calls,
            "s_per_call": round(sum(r[1] - r[0] for r in rows) / (workers * calls), 4),
            "cpu_s_per_mbp": round(sum(r[3] for r in rows) / (bp / 1e6), 4)}
+    if rank == 0:
+        one = LGS_WORKER % dict(root=ROOT, lib=lib2, fa=fa, fofn=fofn, ready=os.path.join(d, "ready_rf"), go=go, calls=1)
+        res["roofline"] = lgs_roofline(one, dict(env, NP_HOST_THREADS="8", NP_IO_THREADS="8"), alg_bytes, with_pmc)
     ref_so = os.path.join(ROOT, "oracle", "_ref", "nextpolish2.so")
-    if with_ref and os.path.exists(ref_so):   # the compiled reference, one core, on a 1 Mb contig of the same shape
-        st = nat.Stream.synth_long([1000000], depth=20.0, seed=4242)
-        fa1, bam1, fofn1 = os.path.join(d, "g1.fa"), os.path.join(d, "r1.bam"), os.path.join(d, "bam1.fofn")
-        st.write_files(fa1, bam1)
-        st.close()
-        with open(fofn1, "w") as f:
-            f.write(bam1 + "\n")
-        code = LGS_WORKER % dict(root=ROOT, lib=ref_so, fa=fa1, fofn=fofn1, ready=os.path.join(d, "readyref"), go=go, calls=1)
-        code = code.replace("once()                                    # warm-up", "pass  #")
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
-        if p.returncode == 0:
-            r = [float(x) for x in p.stdout.strip().splitlines()[-1].split()]
-            res["cpu_baseline"] = {"value": round(r[2] / 1e6 / (r[1] - r[0]), 4), "unit": "Mbp/s", "cores": 1, "kind": "reference",
-                                   "sample": "1 Mb synthetic contig, 20x ONT-like reads, ctg_cns_core of oracle/_ref/nextpolish2.so, %.1f s" % (r[1] - r[0])}
+    if with_ref and os.path.exists(ref_so):   # the compiled reference on contigs of the same shape: all cores (one process each), one core
+        ncore = host_cores()
+        files = []
+
+        def make(k):
+            s1 = nat.Stream.synth_long([1000000], depth=20.0, seed=4242 + k)
+            fa1, bam1, fofn1 = os.path.join(d, "g1_%d.fa" % k), os.path.join(d, "r1_%d.bam" % k), os.path.join(d, "bam1_%d.fofn" % k)
+            s1.write_files(fa1, bam1)
+            s1.close()
+            with open(fofn1, "w") as f:
+                f.write(bam1 + "\n")
+            return fa1, fofn1
+        with ThreadPoolExecutor(min(8, ncore)) as ex:
+            files = list(ex.map(make, range(ncore)))
+
+        def run_ref(sel):
+            pp = []
+            for k in sel:
+                code = LGS_WORKER % dict(root=ROOT, lib=ref_so, fa=files[k][0], fofn=files[k][1], ready=os.path.join(d, "readyref%d" % k), go=go, calls=1)
+                code = code.replace("once()                                    # warm-up", "pass  #")
+                pp.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+            rr = []
+            for p in pp:
+                o, _ = p.communicate()
+                if p.returncode != 0:
+                    return None
+                rr.append([float(x) for x in o.strip().splitlines()[-1].split()])
+            return sum(r[2] for r in rr) / 1e6 / (max(r[1] for r in rr) - min(r[0] for r in rr)), max(r[1] for r in rr) - min(r[0] for r in rr)
+        allc, one = run_ref(range(ncore)), run_ref([0])
+        if allc and one:
+            res["cpu_baseline"] = {"value": round(allc[0], 4), "unit": "Mbp/s", "cores": ncore, "kind": "reference", "one_core": round(one[0], 4),
+                                   "sample": "%d processes x 1 Mb synthetic contig, 20x ONT-like reads, ctg_cns_core of oracle/_ref/nextpolish2.so, %.1f s; "
+                                             "one process alone %.1f s" % (ncore, allc[1], one[1])}
     shutil.rmtree(d, ignore_errors=True)
     return res
+
+
+def e2e_from_files(streams, draft_bp, threads):
+    """Scope 2: one FASTA + one sorted BAM on disk (page cache) -> polished FASTA through the CLI, cold process each time
+    (HIP start-up, BGZF inflate, record split, H2D, kernels, D2H, FASTA text all inside)."""
+    from nextpolish_amd import _native as nat
+    import ctypes as C
+    d = tempfile.mkdtemp(prefix="np1e2e_")
+    try:
+        fa, bam = os.path.join(d, "g.fa"), os.path.join(d, "r.bam")
+        arr = (C.c_void_p * len(streams))(*[s.handle for s in streams])
+        L = nat.lib()
+        L.np1_streams_write_files.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+        t0 = time.time()
+        if L.np1_streams_write_files(arr, len(streams), fa.encode(), bam.encode(), 1) != 0:
+            return {"error": nat.last_error()}
+        t_write = time.time() - t0
+        exe = os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1")
+        env = dict(os.environ, NP_IO_THREADS=str(threads))
+        best, nbytes = 1e9, 0
+        for _ in range(3):
+            t0 = time.time()
+            out = subprocess.run([exe, "scorechain", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, check=True).stdout
+            best = min(best, time.time() - t0)
+            nbytes = len(out)
+        return {"mbp_s": round(draft_bp / 1e6 / best, 2), "seconds": round(best, 3), "bam_mb": round(os.path.getsize(bam) / 1e6, 1),
+                "what": "nextpolish1 scorechain g.fa r.bam > out.fa, cold process, best of 3, files in the page cache, %d host threads; "
+                        "%d bytes of FASTA out; files written in %.1f s" % (threads, nbytes, t_write)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2_5mb_50x", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3_100mb_30x", choices=sorted(WORKLOADS))
+    ap.add_argument("--lanes", type=int, default=2, help="batches in flight on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=3.0)
-    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes (roofline.traffic = null)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the from-files leg")
     ap.add_argument("--no-lgs", action="store_true", help="skip the long-read (nextpolish2) leg")
     ap.add_argument("--lgs-workers", type=int, default=8, help="worker processes per GPU of the long-read leg")
     ap.add_argument("--lgs-mb", type=float, default=5.0, help="contig length (Mb) each long-read worker polishes")
@@ -207,24 +359,46 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    import ctypes as C
     from nextpolish_amd import _native as nat
-    from nextpolish_amd.device import Context
+    from nextpolish_amd.device import Pipe
+    from nextpolish_amd.nextpolish1 import plan_batches
+    from nextpolish_amd.shard import deal_contigs
 
-    lens, depth = WORKLOADS[args.workload]
-
-    def make_stream(contig_lens, d, seed):
-        return nat.Stream.synth(contig_lens, depth=d, seed=seed, prefix="r%dctg" % rank)
-
-    # per-rank shard: same shape, different seed (weak scaling)
-    st = make_stream(lens, depth, 20250117 + 2 + 1000 * rank)
-    draft_bp = int(st.ctg_len.sum())
-    alg_bytes = st.algorithmic_bytes(False)   # records (32 + 4 n_cigar + ceil(l/2)) + draft
-    ctx = Context(local_rank)
-    ctx.upload(st).close()        # first upload pays hipMalloc; time the second one (pageable host memory -> HBM)
-    t_up = time.perf_counter()
-    batch = ctx.upload(st)
-    upload_ms = (time.perf_counter() - t_up) * 1e3
+    total, depth, lo, hi, batch_bp = WORKLOADS[args.workload]
+    lens = contig_lengths(total, lo, hi)
+    names = ["c%04d" % i for i in range(len(lens))]
+    lmap = dict(zip(names, lens))
+    owner = deal_contigs(names, lmap, world)                      # the fixed draft is split over the ranks (strong scaling)
+    mine = [n for n in names if owner[n] == rank]
+    batches = plan_batches(mine, lmap, batch_bp)
+    blens = [[lmap[n] for n in b] for b in batches]
+    draft_bp_total = sum(lens)
+    my_bp = sum(lmap[n] for n in mine)
+    ncpu = host_cores()
+    t_gen = time.time()
+    with ThreadPoolExecutor(max(1, min(ncpu, len(blens)))) as ex:
+        streams = list(ex.map(lambda k: nat.Stream.synth(blens[k], depth=depth, seed=20250117 + 1000 * int(batches[k][0][1:]),
+                                                         prefix="b%dc" % int(batches[k][0][1:])), range(len(blens))))
+    t_gen = time.time() - t_gen
+    n_reads = sum(s.n_reads for s in streams)
+    alg_in = [s.algorithmic_bytes(False) for s in streams]   # records (32 + 4 n_cigar + ceil(l/2)) + draft, per batch
+    for s in streams:
+        s.pin()
+    pipe = Pipe(local_rank, lanes=args.lanes)
     cfg = nat.default_config()
+    L = nat.lib()
+    L.np1_pipe_upload.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]
+    L.np1_pipe_run_resident.argtypes = [C.c_void_p, C.POINTER(nat.Configure), C.c_int, C.c_int]
+    L.np1_pipe_resident_batch.argtypes = [C.c_void_p, C.c_int]
+    L.np1_pipe_resident_batch.restype = C.c_void_p
+    harr = (C.c_void_p * len(streams))(*[s.handle for s in streams])
+    if L.np1_pipe_upload(pipe.handle, harr, len(streams)) != 0:
+        raise SystemExit("upload: " + nat.last_error())
+
+    def resident(passes):
+        if passes > 0 and L.np1_pipe_run_resident(pipe.handle, C.byref(cfg), 1, passes) != 0:
+            raise SystemExit("run_resident: " + nat.last_error())
 
     def sync_all():
         torch.cuda.synchronize()
@@ -232,50 +406,71 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        batch.score_chain(cfg)
-    nat.lib().np1_batch_sync(batch.handle)
+    resident(args.warmup)
     if args.pmc_child:   # short profiled run for pmc_traffic(): no JSON, no baseline
-        for _ in range(args.steps):
-            batch.score_chain(cfg)
-        nat.lib().np1_batch_sync(batch.handle)
-        batch.close()
+        resident(args.steps)
+        pipe.close()
         return
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.score_chain(cfg)
-    nat.lib().np1_batch_sync(batch.handle)
+    resident(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    polished_len = sum(len(s) for s in batch.results())
-    alg_bytes_total = alg_bytes + polished_len
-    updates = batch.update_count()
 
-    # per-stage HIP-event timing on the pipeline's own stream (separate instrumented passes)
-    stage_acc = {}
-    n_inst = 5
-    for _ in range(n_inst):
-        ms = batch.score_chain(cfg, timed=True)
-        for k, v in ms.items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v / n_inst
-    dom = max(stage_acc, key=lambda k: stage_acc[k])
-    dom_ms = stage_acc[dom]
-    achieved = alg_bytes_total / (dom_ms * 1e-3) / 1e9
+    # ---- per-stage HIP-event timing on the pipeline's own stream (separate instrumented passes, one lane, batch by batch)
+    stage_acc, launches, polished, updates = {}, 0, [], 0
+    n_inst = 2
+    for k in range(len(streams)):
+        b = L.np1_pipe_resident_batch(pipe.handle, k)
+        for _ in range(n_inst):
+            ms = (C.c_float * nat.NP1_MAX_STAGES)()
+            if L.np1_batch_score_chain(b, C.byref(cfg), ms) != 0:
+                raise SystemExit("timed pass: " + nat.last_error())
+            for i in range(L.np1_stage_count()):
+                nm = L.np1_stage_name(i).decode()
+                stage_acc[nm] = stage_acc.get(nm, 0.0) + float(ms[i])
+            launches += 1
+        polished.append(sum(int(L.np1_batch_result_len(b, c)) for c in range(streams[k].n_contigs)))
+        updates += int(L.np1_batch_update_count(b))
+    stage_ms = {k: v / launches for k, v in stage_acc.items()}          # average per launch (= per batch)
+    dom = max(stage_ms, key=lambda k: stage_ms[k])
+    alg_per_launch = (sum(alg_in) + sum(polished)) / float(len(streams))
+    achieved = alg_per_launch / (stage_ms[dom] * 1e-3) / 1e9
+
+    # ---- scope 1: pinned host -> H2D -> kernels -> D2H, double-buffered on the lanes, all inside the timed region
+    pipe.run(streams, cfg=cfg, fetch=False)          # warm: lane batches grow to their final size
+    sync_all()
+    t0 = time.perf_counter()
+    n_stream_passes = 3
+    for _ in range(n_stream_passes):
+        pipe.run(streams, cfg=cfg, fetch=False)
+    sync_all()
+    dt_stream = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_stream], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_stream = float(t.item())
+    h2d_bytes = sum(alg_in)
+    assert pipe.result_lengths(streams) == sum(polished)
 
     traffic, traffic_note = None, "not collected"
     if rank == 0 and world == 1 and not args.no_pmc:
         sub = {"tile": "k_tile3", "vote": "k_vote", "rows": "k_rows"}.get(dom, dom)
         traffic, traffic_note = pmc_traffic(args, sub)
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        e2e = e2e_from_files(streams, draft_bp_total, ncpu)
+    pipe.close()
     lgs = None
-    if not args.no_lgs and not args.pmc_child:
+    if not args.no_lgs:
         if world > 1:
             dist.barrier()
-        lgs = lgs_leg(rank, local_rank, args.lgs_workers, args.lgs_mb, args.lgs_calls, rank == 0 and world == 1 and not args.no_cpu_baseline)
+        lgs = lgs_leg(rank, local_rank, args.lgs_workers, args.lgs_mb, args.lgs_calls,
+                      rank == 0 and world == 1 and not args.no_cpu_baseline, rank == 0 and world == 1 and not args.no_pmc)
         if world > 1:   # whole job: bp of all ranks over the slowest rank's span
             tt = torch.tensor([float(lgs.get("bp", 0)), float(lgs.get("seconds", 0)), 1.0 if "error" in lgs else 0.0], device="cuda", dtype=torch.float64)
             bp_sum = tt.clone()
@@ -287,24 +482,33 @@ def main():
                 lgs.setdefault("error", "a rank failed")
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * draft_bp / 1e6 / (dt / args.steps)
+        value = draft_bp_total / 1e6 / (dt / args.steps)
+        streamed = draft_bp_total * n_stream_passes / 1e6 / dt_stream
         out = {
-            "metric": "polished Mbp/s (score_chain, short reads, inputs resident in HBM)",
+            "metric": "polished Mbp/s (score_chain, 30x short reads, one fixed draft, batches resident in HBM)",
             "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8/int64", "data": "synthetic",
-            "config": {"workload": "%s: %.2f Mb synthetic draft (%d contigs) + %.0fx simulated 2x150 bp PE reads per GPU, "
-                                   "one score_chain pass" % (args.workload, draft_bp / 1e6, st.n_contigs, depth),
-                       "reads_per_gpu": st.n_reads, "slot_votes_per_step": updates,
-                       "parallelism": "contig-sharded x%d (no collective)" % world,
-                       "h2d_upload_ms_not_in_value": round(upload_ms, 3),
-                       "pcie_inclusive_mbp_s": round(draft_bp / 1e6 / ((ms_per_step + upload_ms) * 1e-3), 1)},
+            "config": {"workload": "%s: %.1f Mb synthetic draft in %d contigs (log-uniform %g-%g bp) + %.0fx simulated 2x150 bp PE reads "
+                                   "(%d records on rank 0), dealt longest-first over %d GPU(s), %d HBM batches of <= %.0f Mb on rank 0; "
+                                   "one step = one score_chain pass over the whole draft"
+                                   % (args.workload, draft_bp_total / 1e6, len(lens), lo, hi, depth, n_reads, world, len(batches), batch_bp / 1e6),
+                       "slot_votes_per_step_rank0": updates // n_inst, "lanes": args.lanes,
+                       "parallelism": "contigs dealt longest-first x%d (no collective)" % world,
+                       "synth_seconds": round(t_gen, 1), "host_cores": ncpu},
+            "streamed": {"mbp_s": round(streamed, 2), "what": "pinned host arrays -> async H2D -> kernels -> D2H of the polished strings, "
+                         "%d lanes, %d passes over the draft, all inside the timed region (SURVEY 8d scope 1)" % (args.lanes, n_stream_passes),
+                         "seconds_per_pass": round(dt_stream / n_stream_passes, 4),
+                         "h2d_gb_per_s_rank0": round(h2d_bytes * n_stream_passes / dt_stream / 1e9, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic["bytes"] if traffic else None,
                          "traffic_detail": traffic if traffic else traffic_note,
-                         "algorithmic_bytes_per_launch": alg_bytes_total, "kernel_ms": round(dom_ms, 4),
-                         "stage_ms": {k: round(v, 4) for k, v in stage_acc.items()}},
+                         "algorithmic_bytes_per_launch": int(alg_per_launch), "kernel_ms": round(stage_ms[dom], 4),
+                         "launches_averaged": launches, "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                         "achieved_whole_pass_gbs": round((sum(alg_in) + sum(polished)) / (dt / args.steps) / 1e9, 2)},
         }
+        if e2e is not None:
+            out["e2e_from_files"] = e2e
         if lgs is not None:
             if "error" in lgs:
                 out["lgs"] = lgs
@@ -314,12 +518,12 @@ def main():
                               "config": {"workload": "%.1f Mb synthetic contig + 20x ONT-like reads (8 kb, 7%% errors) per worker, %d worker processes per GPU, "
                                                      "%d calls each, %s host threads per worker" % (args.lgs_mb, args.lgs_workers, args.lgs_calls, os.environ.get("NP_HOST_THREADS", "4"))},
                               "s_per_call": lgs["s_per_call"], "host_cpu_s_per_mbp": lgs["cpu_s_per_mbp"]}
-                if "cpu_baseline" in lgs:
-                    out["lgs"]["cpu_baseline"] = lgs["cpu_baseline"]
+                for k in ("roofline", "cpu_baseline"):
+                    if k in lgs:
+                        out["lgs"][k] = lgs[k]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(make_stream, int(args.cpu_sample_mb * 1e6), depth, 424242)
+            out["cpu_baseline"] = cpu_baseline(depth, args.cpu_sample_mb, ncpu)
         print(json.dumps(out))
-    batch.close()
     if world > 1:
         dist.destroy_process_group()
 

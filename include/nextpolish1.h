@@ -135,6 +135,8 @@ int np1_stream_write_files(const np1_stream* s, const char* fasta, const char* b
 /* same, with raw BAM optional fields per record (aux_pool[aux_off[i] .. aux_off[i+1])): test data with SA tags */
 int np1_stream_write_files_aux(const np1_stream* st, const char* fasta, const char* bam, int level, const uint8_t* aux_pool,
                                const uint64_t* aux_off);
+/* several streams as ONE FASTA(+.fai) + ONE coordinate-sorted BAM(+.bai): contigs of streams[0], then of streams[1], ... */
+int np1_streams_write_files(np1_stream* const* streams, int n, const char* fasta, const char* bam, int bgzf_level);
 void np1_stream_free(np1_stream* s);
 
 /* Synthetic workload.  Field meanings: nextpolish_amd/csrc/np_synth.h */
@@ -202,6 +204,12 @@ typedef struct np1_pipe np1_pipe;
 np1_pipe* np1_pipe_open(int device, int lanes);
 int np1_pipe_run(np1_pipe* p, np1_stream* const* streams, int n, const Configure* cfg, int task);
 const char* np1_pipe_result(np1_pipe* p, int batch, int64_t contig, int64_t* len);
+/* Resident mode (kernel-path measurements): np1_pipe_upload keeps one HBM batch per stream (dealt round-robin over the
+ * lanes, replacing any earlier set); np1_pipe_run_resident polishes every resident batch `passes` times, the lanes
+ * working concurrently, outputs staying on the device; np1_pipe_resident_batch(p, k) is batch k for np1_batch_* calls. */
+int np1_pipe_upload(np1_pipe* p, np1_stream* const* streams, int n);
+int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passes);
+np1_batch* np1_pipe_resident_batch(np1_pipe* p, int k);
 void np1_pipe_close(np1_pipe* p);
 /* From files: contigs of the FASTA index (all when names == NULL) are packed in index order into batches of at most
  * batch_bp draft bases; host threads load batch k+1.. (BGZF inflate + record split) while the lanes polish batch k.

@@ -28,6 +28,7 @@ struct np1_pipe {
     // results of the last np1_pipe_run
     std::vector<std::vector<char>> out;            // per batch: concatenated strings
     std::vector<std::vector<uint32_t>> bounds;     // per batch: nc + 1 offsets
+    std::vector<np1_batch*> resident;              // np1_pipe_upload: batch k lives on lane k % lanes
 };
 
 namespace {
@@ -68,8 +69,56 @@ np1_pipe* np1_pipe_open(int device, int lanes) {
     return p;
 }
 
+static void drop_resident(np1_pipe* p) {
+    for (np1_batch* b : p->resident) np1_batch_free(b);
+    p->resident.clear();
+}
+
+int np1_pipe_upload(np1_pipe* p, np1_stream* const* streams, int n) {
+    if (!p || (n > 0 && !streams)) { np1_set_error("np1_pipe_upload: null argument"); return -1; }
+    drop_resident(p);
+    for (int k = 0; k < n; ++k) {
+        np1_batch* b = np1_batch_upload(p->lanes[(size_t)k % p->lanes.size()].ctx, streams[k]);
+        if (!b) { drop_resident(p); return -1; }
+        p->resident.push_back(b);
+    }
+    return 0;
+}
+
+np1_batch* np1_pipe_resident_batch(np1_pipe* p, int k) {
+    return (p && k >= 0 && (size_t)k < p->resident.size()) ? p->resident[(size_t)k] : nullptr;
+}
+
+int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passes) {
+    if (!p || !cfg) { np1_set_error("np1_pipe_run_resident: null argument"); return -1; }
+    std::atomic<bool> failed(false);
+    std::string err;
+    std::mutex err_mu;
+    const size_t nl = p->lanes.size();
+    auto work = [&](size_t lane) {
+        for (int pass = 0; pass < passes && !failed; ++pass)
+            for (size_t k = lane; k < p->resident.size(); k += nl) {
+                np1_batch* b = p->resident[k];
+                const int rc = task == 2 ? np1_batch_kmer_count(b, cfg, nullptr) : np1_batch_score_chain(b, cfg, nullptr);
+                if (rc != 0) {
+                    std::lock_guard<std::mutex> g(err_mu);
+                    if (!failed) err = np1_last_error();
+                    failed = true;
+                    return;
+                }
+            }
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < nl; ++i) th.emplace_back(work, i);
+    work(0);
+    for (std::thread& t : th) t.join();
+    if (failed) { np1_set_error(err); return -1; }
+    return 0;
+}
+
 void np1_pipe_close(np1_pipe* p) {
     if (!p) return;
+    drop_resident(p);
     for (np1_pipe::Lane& ln : p->lanes) {
         if (ln.batch) np1_batch_free(ln.batch);
         if (ln.ctx) np1_ctx_destroy(ln.ctx);

@@ -311,6 +311,15 @@ bool BamWriter::write(int32_t tid, int32_t pos, uint8_t mapq, uint16_t flag, int
 bool BamWriter::close() {
     // tell() of the last record may point inside an unflushed block; offsets stay valid after flush
     if (!bg_.close()) return false;
+    // the offsets collected while writing are provisional (block sequence numbers): make them real
+    for (size_t i = 0; i < refs_.size(); ++i) {
+        for (auto& kv : refs_[i].bins)
+            for (BaiChunk& c : kv.second) { c.beg = bg_.resolve(c.beg); c.end = bg_.resolve(c.end); }
+        for (voff_t& v : refs_[i].linear)
+            if (v != (voff_t)-1) v = bg_.resolve(v);
+        ref_beg_[i] = bg_.resolve(ref_beg_[i]);
+        ref_end_[i] = bg_.resolve(ref_end_[i]);
+    }
     FILE* fp = fopen((path_ + ".bai").c_str(), "wb");
     if (!fp) return false;
     auto wr = [&](const void* p, size_t n) { return fwrite(p, 1, n, fp) == n; };

@@ -213,21 +213,23 @@ bool BgzfWriter::open(const std::string& path, int level) {
     if (!fp_) return false;
     level_ = level;
     ubuf_.resize(kMaxBlock);
-    cbuf_.resize(kMaxBlock + 1024);
+    pending_.clear();
+    block_coff_.clear();
     fill_ = 0;
     coff_ = 0;
     return true;
 }
 
-bool BgzfWriter::flush_block() {
-    if (fill_ == 0) return true;
+// One BGZF block (gzip member with the BC subfield) from `n` bytes; false if deflate fails.
+static bool deflate_block(const uint8_t* in, uint32_t n, int level, std::vector<uint8_t>* out) {
+    out->resize(kMaxBlock + 1024);
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    zs.next_in = ubuf_.data();
-    zs.avail_in = fill_;
-    zs.next_out = cbuf_.data() + 18;
-    zs.avail_out = (uInt)(cbuf_.size() - 18 - 8);
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef*>(in);
+    zs.avail_in = n;
+    zs.next_out = out->data() + 18;
+    zs.avail_out = (uInt)(out->size() - 18 - 8);
     int ret = deflate(&zs, Z_FINISH);
     size_t clen = zs.total_out;
     deflateEnd(&zs);
@@ -235,17 +237,55 @@ bool BgzfWriter::flush_block() {
     size_t total = 18 + clen + 8;
     if (total > 65536) return false;  // cannot happen with fill <= 0xff00
     static const uint8_t magic[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-    memcpy(cbuf_.data(), magic, 16);
-    cbuf_[16] = (uint8_t)((total - 1) & 0xff);
-    cbuf_[17] = (uint8_t)((total - 1) >> 8);
-    uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), ubuf_.data(), fill_);
-    memcpy(cbuf_.data() + 18 + clen, &crc, 4);
-    uint32_t isize = fill_;
-    memcpy(cbuf_.data() + 18 + clen + 4, &isize, 4);
-    if (fwrite(cbuf_.data(), 1, total, fp_) != total) return false;
-    coff_ += total;
-    fill_ = 0;
+    memcpy(out->data(), magic, 16);
+    (*out)[16] = (uint8_t)((total - 1) & 0xff);
+    (*out)[17] = (uint8_t)((total - 1) >> 8);
+    uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, n);
+    memcpy(out->data() + 18 + clen, &crc, 4);
+    memcpy(out->data() + 18 + clen + 4, &n, 4);
+    out->resize(total);
     return true;
+}
+
+bool BgzfWriter::drain() {
+    if (pending_.empty()) return true;
+    std::vector<std::vector<uint8_t>> comp(pending_.size());
+    std::atomic<size_t> next(0);
+    std::atomic<bool> ok(true);
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= pending_.size()) break;
+            if (!deflate_block(pending_[i].data(), (uint32_t)pending_[i].size(), level_, &comp[i])) ok = false;
+        }
+    };
+    const unsigned nt = (unsigned)std::min<size_t>(io_threads(), pending_.size());
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (std::thread& t : th) t.join();
+    if (!ok) return false;
+    for (size_t i = 0; i < comp.size(); ++i) {
+        if (fwrite(comp[i].data(), 1, comp[i].size(), fp_) != comp[i].size()) return false;
+        block_coff_.push_back(coff_);
+        coff_ += comp[i].size();
+    }
+    pending_.clear();
+    return true;
+}
+
+bool BgzfWriter::flush_block() {
+    if (fill_ == 0) return true;
+    pending_.emplace_back(ubuf_.begin(), ubuf_.begin() + fill_);
+    fill_ = 0;
+    if (pending_.size() >= 512) return drain();
+    return true;
+}
+
+voff_t BgzfWriter::resolve(voff_t v) const {
+    const uint64_t seq = v >> 16;
+    const uint64_t c = seq < block_coff_.size() ? block_coff_[seq] : coff_;   // seq == #blocks: the position after the last one
+    return (c << 16) | (v & 0xffff);
 }
 
 bool BgzfWriter::write(const void* src, size_t n) {
@@ -264,7 +304,7 @@ bool BgzfWriter::write(const void* src, size_t n) {
 
 bool BgzfWriter::close() {
     if (!fp_) return true;
-    bool ok = flush_block();
+    bool ok = flush_block() && drain();
     static const uint8_t eof_marker[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43,
                                            0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
     ok = ok && fwrite(eof_marker, 1, 28, fp_) == 28;

@@ -58,14 +58,21 @@ public:
     ~BgzfWriter();
     bool open(const std::string& path, int level = 1);
     bool write(const void* src, size_t n);
-    voff_t tell() const { return (coff_ << 16) | (uint64_t)fill_; }
+    // Blocks are deflated a batch at a time on a few threads (NP_IO_THREADS), so the file offset of the current block is
+    // not known while records are written: tell() returns a PROVISIONAL offset (block sequence number << 16 | offset in
+    // the block), monotone in the real one; resolve() turns it into the real virtual offset once close() has run.
+    voff_t tell() const { return ((uint64_t)(block_coff_.size() + pending_.size()) << 16) | (uint64_t)fill_; }
+    voff_t resolve(voff_t provisional) const;
     bool flush_block();
     bool close();   // flushes and appends the 28-byte EOF marker block
 
 private:
+    bool drain();                      // deflate + write the pending blocks
     FILE* fp_ = nullptr;
     int level_ = 1;
-    std::vector<uint8_t> ubuf_, cbuf_;
+    std::vector<uint8_t> ubuf_;
+    std::vector<std::vector<uint8_t>> pending_;   // full blocks waiting for the deflate threads
+    std::vector<uint64_t> block_coff_;            // file offset of every block written so far
     uint32_t fill_ = 0;
     uint64_t coff_ = 0;
 };

@@ -386,51 +386,68 @@ bool synth_long_stream(const np_synth_long_params& p, const std::string& prefix,
     return true;
 }
 
-bool write_stream_files(const ReadStream& s, const std::string& fasta, const std::string& bam, int level,
-                        std::string* err, const uint8_t* aux_pool, const uint64_t* aux_off) {
+bool write_streams_files(const std::vector<const ReadStream*>& ss, const std::string& fasta, const std::string& bam, int level,
+                         std::string* err, const uint8_t* aux_pool, const uint64_t* aux_off) {
     FILE* fp = fopen(fasta.c_str(), "w");
     if (!fp) { *err = "cannot write " + fasta; return false; }
     FILE* fi = fopen((fasta + ".fai").c_str(), "w");
     if (!fi) { fclose(fp); *err = "cannot write " + fasta + ".fai"; return false; }
     const int W = 60;
     int64_t off = 0;
-    for (size_t c = 0; c < s.n_contigs(); ++c) {
-        off += fprintf(fp, ">%s\n", s.names[c].c_str());
-        int64_t L = s.ctg_len[c];
-        fprintf(fi, "%s\t%lld\t%lld\t%d\t%d\n", s.names[c].c_str(), (long long)L, (long long)off, W, W + 1);
-        const char* d = s.draft.data() + s.ctg_off[c];
-        for (int64_t i = 0; i < L; i += W) {
-            int n = (int)std::min<int64_t>(W, L - i);
-            fwrite(d + i, 1, n, fp);
-            fputc('\n', fp);
-            off += n + 1;
+    std::string lines;
+    BamHeader h;
+    h.text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (const ReadStream* sp : ss) {
+        const ReadStream& s = *sp;
+        for (size_t c = 0; c < s.n_contigs(); ++c) {
+            off += fprintf(fp, ">%s\n", s.names[c].c_str());
+            int64_t L = s.ctg_len[c];
+            fprintf(fi, "%s\t%lld\t%lld\t%d\t%d\n", s.names[c].c_str(), (long long)L, (long long)off, W, W + 1);
+            const char* d = s.draft.data() + s.ctg_off[c];
+            lines.clear();
+            lines.reserve((size_t)L + (size_t)L / W + 2);
+            for (int64_t i = 0; i < L; i += W) {
+                int n = (int)std::min<int64_t>(W, L - i);
+                lines.append(d + i, (size_t)n);
+                lines.push_back('\n');
+            }
+            fwrite(lines.data(), 1, lines.size(), fp);
+            off += (int64_t)lines.size();
+            h.names.push_back(s.names[c]);
+            h.lens.push_back((uint32_t)s.ctg_len[c]);
+            h.text += "@SQ\tSN:" + s.names[c] + "\tLN:" + std::to_string(s.ctg_len[c]) + "\n";
         }
     }
     fclose(fp);
     fclose(fi);
-    BamHeader h;
-    h.text = "@HD\tVN:1.6\tSO:coordinate\n";
-    for (size_t c = 0; c < s.n_contigs(); ++c) {
-        h.names.push_back(s.names[c]);
-        h.lens.push_back((uint32_t)s.ctg_len[c]);
-        h.text += "@SQ\tSN:" + s.names[c] + "\tLN:" + std::to_string(s.ctg_len[c]) + "\n";
-    }
     BamWriter w;
     if (!w.open(bam, h, level)) { *err = "cannot write " + bam; return false; }
-    bool have_q = !s.qual.empty();
     char qn[32];
-    for (size_t i = 0; i < s.n_reads(); ++i) {
-        snprintf(qn, sizeof(qn), "r%zu", i);
-        const uint8_t* q = have_q ? s.qual.data() + s.qual_off[i] : nullptr;
-        if (!w.write((int32_t)s.ctg[i], s.pos[i], s.mapq[i], s.flag[i], (int32_t)s.ctg[i], s.pos[i], s.isize[i], qn,
-                     s.cigar.data() + s.cigar_off[i], s.n_cigar[i], s.seq.data() + s.seq_off[i], q, s.l_qseq[i],
-                     aux_pool ? aux_pool + aux_off[i] : nullptr, aux_pool ? (size_t)(aux_off[i + 1] - aux_off[i]) : 0)) {
-            *err = "BAM write failed";
-            return false;
+    size_t serial = 0;
+    int32_t tid0 = 0;
+    for (const ReadStream* sp : ss) {
+        const ReadStream& s = *sp;
+        const bool have_q = !s.qual.empty();
+        for (size_t i = 0; i < s.n_reads(); ++i, ++serial) {
+            snprintf(qn, sizeof(qn), "r%zu", serial);
+            const uint8_t* q = have_q ? s.qual.data() + s.qual_off[i] : nullptr;
+            const int32_t tid = tid0 + (int32_t)s.ctg[i];
+            if (!w.write(tid, s.pos[i], s.mapq[i], s.flag[i], tid, s.pos[i], s.isize[i], qn,
+                         s.cigar.data() + s.cigar_off[i], s.n_cigar[i], s.seq.data() + s.seq_off[i], q, s.l_qseq[i],
+                         aux_pool ? aux_pool + aux_off[serial] : nullptr, aux_pool ? (size_t)(aux_off[serial + 1] - aux_off[serial]) : 0)) {
+                *err = "BAM write failed";
+                return false;
+            }
         }
+        tid0 += (int32_t)s.n_contigs();
     }
     if (!w.close()) { *err = "BAM/BAI close failed"; return false; }
     return true;
+}
+
+bool write_stream_files(const ReadStream& s, const std::string& fasta, const std::string& bam, int level,
+                        std::string* err, const uint8_t* aux_pool, const uint64_t* aux_off) {
+    return write_streams_files({&s}, fasta, bam, level, err, aux_pool, aux_off);
 }
 
 }  // namespace np

@@ -30,4 +30,7 @@ bool synth_stream(const np_synth_params& p, const std::string& contig_name_prefi
 bool write_stream_files(const ReadStream& s, const std::string& fasta, const std::string& bam, int bgzf_level,
                         std::string* err, const uint8_t* aux_pool = nullptr,
                         const uint64_t* aux_off = nullptr);   // aux: raw optional fields per record (tests: SA tags)
+// Several streams as ONE FASTA + ONE coordinate-sorted BAM (contigs of stream 0, then of stream 1, ...).
+bool write_streams_files(const std::vector<const ReadStream*>& ss, const std::string& fasta, const std::string& bam, int bgzf_level,
+                         std::string* err, const uint8_t* aux_pool = nullptr, const uint64_t* aux_off = nullptr);
 }  // namespace np
