@@ -14,40 +14,20 @@
 #include "np1_kmer_kernels.h"
 #include "np_stream.h"
 #include "np1_priv.h"
+#include "np1_batch_priv.h"
 
 
 using namespace np1k;
 
+using namespace np1dev;
+
 namespace {
-
-bool hip_ok(hipError_t e, const char* what) {
-    if (e == hipSuccess) return true;
-    np1_set_error(std::string(what) + ": " + hipGetErrorString(e));
-    return false;
-}
-#define HIPCHK(x) do { if (!hip_ok((x), #x)) return -1; } while (0)
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes, double slack = 1.0) {
-        if (bytes <= cap && p) return 0;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = (size_t)((double)bytes * slack) + 256;
-        if (!hip_ok(hipMalloc(&p, want), "hipMalloc")) { p = nullptr; return -1; }
-        cap = want;
-        return 0;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
 
 // Two launch sequences share everything but the middle: the default FUSED one stages pileup columns through
 // LDS (k_place + k_tile); the STAGED one (NP1_PIPELINE=staged, kept for A/B measurements and mirrored by the
 // host model in tests/model) materialises symbol rows in HBM (k_rowcap + scan + k_rows + k_vote).
 const char* kStageNamesStaged[] = {"prep", "scan_slots", "slotinfo", "rowcap_scan", "rows", "vote", "dp", "emit"};
 const char* kStageNamesFused[] = {"prep", "scan_slots", "slotinfo", "desc", "-", "tile", "dp", "emit"};
-constexpr int kStages = 8;
 bool use_staged() {
     static int v = -1;
     if (v < 0) {
@@ -58,70 +38,6 @@ bool use_staged() {
 }
 
 }  // namespace
-
-struct np1_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0[kStages], ev1[kStages];
-};
-
-struct np1_batch {
-    np1_ctx* ctx = nullptr;
-    uint32_t nc = 0;
-    uint64_t G = 0;
-    int64_t n_reads = 0;
-    // inputs
-    DevBuf draft, ctg_off, pos, ctg, flag, ncig, lq, cigoff, seqoff, cigar, seq;
-    // work
-    DevBuf desc, ovf_desc, slot_g, dbg;
-    // kmer_count inputs (uploaded only when the stream carries qualities) and work buffers
-    DevBuf mapq, isize, qualoff, qual, read_begin;
-    DevBuf kc_level, kc_endpos, kc_code, kc_flag, kc_fpos, kc_flagged, kc_work, kc_nd_ctg, kc_nd_se, kc_kr_ctg, kc_kr_se, kc_cnt,
-        kc_sbase, kc_sflag, kc_srefk, kc_scount, kc_lhead, kc_lpool, kc_stsc, kc_stkm, kc_strk, kc_hpool, kc_workoff, kc_nparts,
-        kc_partoff, kc_pt_ctg, kc_pt_se, kc_pt_len, kc_woff, kc_wpool, kc_haswin;
-    bool has_qual = false;
-    std::vector<uint64_t> h_read_begin;
-    DevBuf qs, qe, span, ins, soff, slot_info, rbase, capb, rowoff, rows, meta, chunk_first, chunk_last, slot_res,
-        slot_rec, pool, heads, redo, redo2, counters, opos, out, bounds, scan_tmp, totals;
-    size_t input_bytes = 0;
-    uint32_t max_lq = 0;   // longest record of the batch (bases)
-    uint32_t last_counters[CNT_WORDS] = {0};
-    bool force_staged = false;   // a record exceeded the descriptor capacity once: this batch uses the staged sequence
-    // results of the last run
-    uint32_t S = 0;
-    uint64_t votes = 0;
-    bool ran = false, out_cached = false, out_pinned = false;
-    uint8_t* h_pin = nullptr;   // pinned copy of `out` (np1_batch_results_fetch)
-    size_t h_pin_cap = 0;
-    std::vector<uint32_t> h_bounds;
-    std::vector<uint8_t> h_out;
-    std::vector<uint32_t> h_ctg_off;
-
-    size_t device_bytes() const {
-        const DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
-                               &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
-                               &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out,
-                               &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &mapq, &isize, &qualoff, &qual, &read_begin,
-                               &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg, &kc_nd_se,
-                               &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool,
-                               &kc_stsc, &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg,
-                               &kc_pt_se, &kc_pt_len, &kc_woff, &kc_wpool, &kc_haswin};
-        size_t t = 0;
-        for (const DevBuf* b : all) t += b->cap;
-        return t;
-    }
-    void release_all() {
-        DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
-                         &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
-                         &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out,
-                         &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &mapq, &isize, &qualoff, &qual, &read_begin,
-                         &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg, &kc_nd_se,
-                         &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool,
-                         &kc_stsc, &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg, &kc_pt_se,
-                         &kc_pt_len, &kc_woff, &kc_wpool, &kc_haswin};
-        for (DevBuf* b : all) b->release();
-    }
-};
 
 extern "C" {
 

@@ -1,0 +1,552 @@
+// Device-side ingest of the short-read path: the compressed BAM bytes of a batch of contigs go to HBM as they lie in the
+// file, and the GPU does what the reference does per record on the host with htslib (bgzf_read_block + bam_read1 behind
+// sam_itr_next, source/lib/contig.c:172-174,692-694):
+//
+//   k_inflate        one wave per BGZF block (np_inflate_dev.h)                        compressed -> inflated BAM bytes
+//   k_chase<false>   one lane per anchor segment: hop from record to record            records per segment
+//   k_chase<true>    the same walk, writing the byte offset of every record            record offsets
+//   k_rec_measure    one lane per record: the iterator's overlap test + pool sizes     keep flag, #CIGAR words, seq / qual bytes
+//   k_rec_scatter    one lane per kept record: fixed fields -> SoA, CIGAR / bases / qualities -> aligned pools
+//
+// The hops need a known record start to begin from; the BAM index supplies one per 16 kb window (linear index) besides the
+// first record of every contig (metadata pseudo-bin), so a 100 Mb batch is ~6 000 independent chains of a few thousand
+// hops.  The result is exactly the record stream the host loader (np_stream.cpp:load_stream) builds, already in HBM.
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nextpolish1.h"
+#include "np1_batch_priv.h"
+#include "np1_ingest.h"
+#include "np1_kmer_kernels.h"
+#include "np_bgzf.h"
+#include "np_inflate_dev.h"
+
+using namespace np1dev;
+
+namespace {
+
+constexpr uint32_t IG_ERR_CHAIN = 1u, IG_ERR_CGTAG = 2u, IG_ERR_RECORD = 4u;
+
+struct Segment { uint64_t beg, end; uint32_t ctg; int32_t tid; int32_t ctg_len; uint32_t pad; };
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) {
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    return *reinterpret_cast<const u32u*>(p);
+}
+__device__ __forceinline__ uint16_t ld16(const uint8_t* p) {
+    typedef uint16_t __attribute__((aligned(1))) u16u;
+    return *reinterpret_cast<const u16u*>(p);
+}
+
+__global__ __launch_bounds__(256) void k_inflate(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+                                                 uint8_t* out, uint32_t* __restrict__ status) {
+    __shared__ npdev::InflateLds lds[4];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * 4 + wave;
+    if (b >= n_blocks) return;
+    const npdev::BlockDesc d = blocks[b];
+    int rc = 0;
+    if (d.out_len) rc = npdev::inflate_block_wave(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, lds[wave]);
+    if ((threadIdx.x & 63u) == 0) status[b] = (uint32_t)rc;
+}
+
+// one lane per segment [beg, end) of the inflated stream that starts on a record boundary
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_chase(const uint8_t* __restrict__ u, const Segment* __restrict__ segs, uint32_t n_segs, uint32_t* __restrict__ counts,
+                                              const uint64_t* __restrict__ rec_base, uint64_t* __restrict__ rec_off, uint32_t* __restrict__ rec_seg,
+                                              uint32_t* __restrict__ err) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_segs) return;
+    const Segment s = segs[i];
+    uint64_t p = s.beg, n = 0;
+    const uint64_t base = FILL ? rec_base[i] : 0;
+    while (p < s.end) {
+        const uint32_t bs = ld32(u + p);
+        if (bs < 32 || bs > (1u << 28) || p + 4 + bs > s.end) { atomicOr(err, IG_ERR_CHAIN); break; }
+        if (FILL) { rec_off[base + n] = p; rec_seg[base + n] = i; }
+        ++n;
+        p += 4ull + bs;
+    }
+    if (!FILL) counts[i] = (uint32_t)n;
+}
+
+// record layout (SAMv1 4.2): block_size refID pos l_read_name mapq bin n_cigar_op flag l_seq next_refID next_pos tlen | name cigar seq qual aux
+__global__ __launch_bounds__(256) void k_rec_measure(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ rec_seg,
+                                                     const Segment* __restrict__ segs, uint64_t n_rec, int with_qual, uint32_t* __restrict__ keep,
+                                                     uint32_t* __restrict__ ncw, uint32_t* __restrict__ seqb, uint32_t* __restrict__ qualb,
+                                                     uint32_t* __restrict__ max_lq, uint32_t* __restrict__ err) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t lq_keep = 0;
+    if (r < n_rec) {
+        const uint8_t* p = u + rec_off[r];
+        const Segment s = segs[rec_seg[r]];
+        const uint32_t bs = ld32(p);
+        const int32_t tid = (int32_t)ld32(p + 4), pos = (int32_t)ld32(p + 8);
+        const uint32_t l_name = p[12];
+        const uint32_t n_cigar = ld16(p + 16), flag = ld16(p + 18);
+        const int32_t l_seq = (int32_t)ld32(p + 20);
+        bool k = tid == s.tid && pos >= 0 && pos < s.ctg_len && l_seq >= 0;
+        if (tid != s.tid || l_seq < 0 || 32u + l_name + 4u * n_cigar + (uint32_t)((l_seq + 1) / 2) + (uint32_t)l_seq > bs) { atomicOr(err, IG_ERR_RECORD); k = false; }
+        if (k && pos == 0 && !(flag & 4u) && n_cigar > 0) {   // the iterator keeps a record iff its end is > 0: pos + rlen (htslib 1.9 bam_endpos)
+            const uint8_t* c = p + 36 + l_name;
+            uint32_t rl = 0;
+            for (uint32_t j = 0; j < n_cigar; ++j) {
+                const uint32_t op = ld32(c + 4 * j);
+                const uint32_t o = op & 15u;
+                if (o == 0 || o == 2 || o == 3 || o == 7 || o == 8) rl += op >> 4;
+            }
+            if (rl == 0) k = false;
+        }
+        if (k && n_cigar == 2) {   // placeholder CIGAR "<l_seq>S<rlen>N" of a record whose real CIGAR sits in the CG tag: the host loader swaps it in
+            const uint8_t* c = p + 36 + l_name;
+            const uint32_t o0 = ld32(c), o1 = ld32(c + 4);
+            if ((o0 & 15u) == 4 && (o0 >> 4) == (uint32_t)l_seq && (o1 & 15u) == 3) atomicOr(err, IG_ERR_CGTAG);
+        }
+        keep[r] = k ? 1u : 0u;
+        ncw[r] = k ? n_cigar : 0u;
+        seqb[r] = k ? (uint32_t)((l_seq + 1) / 2) : 0u;
+        if (with_qual) qualb[r] = k ? (uint32_t)l_seq : 0u;
+        lq_keep = k ? (uint32_t)l_seq : 0u;
+    }
+    // one atomic per wave
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) lq_keep = max(lq_keep, (uint32_t)__shfl_xor(lq_keep, d, 64));
+    if ((threadIdx.x & 63u) == 0 && lq_keep) atomicMax(max_lq, lq_keep);
+}
+
+struct ScatterOut {
+    int32_t* pos; uint32_t* ctg; uint16_t* flag; uint16_t* ncig; int32_t* lq; uint64_t* cigoff; uint64_t* seqoff;
+    uint32_t* cigar; uint8_t* seq; uint8_t* mapq; int32_t* isize; uint64_t* qualoff; uint8_t* qual;
+};
+
+__global__ __launch_bounds__(256) void k_rec_scatter(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ rec_seg,
+                                                     const Segment* __restrict__ segs, uint64_t n_rec, const uint32_t* __restrict__ keep,
+                                                     const uint32_t* __restrict__ kidx, const uint64_t* __restrict__ cig_at, const uint64_t* __restrict__ seq_at,
+                                                     const uint64_t* __restrict__ qual_at, int with_qual, ScatterOut o) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec || !keep[r]) return;
+    const uint8_t* p = u + rec_off[r];
+    const uint32_t j = kidx[r];
+    const uint32_t l_name = p[12];
+    const uint32_t n_cigar = ld16(p + 16);
+    const int32_t l_seq = (int32_t)ld32(p + 20);
+    o.pos[j] = (int32_t)ld32(p + 8);
+    o.ctg[j] = segs[rec_seg[r]].ctg;
+    o.flag[j] = ld16(p + 18);
+    o.ncig[j] = (uint16_t)n_cigar;
+    o.lq[j] = l_seq;
+    const uint64_t ca = cig_at[r], sa = seq_at[r];
+    o.cigoff[j] = ca;
+    o.seqoff[j] = sa;
+    const uint8_t* c = p + 36 + l_name;
+    for (uint32_t i = 0; i < n_cigar; ++i) o.cigar[ca + i] = ld32(c + 4 * i);
+    const uint8_t* sq = c + 4 * n_cigar;
+    const uint32_t sb = (uint32_t)((l_seq + 1) / 2);
+    uint32_t i = 0;
+    for (; i + 4 <= sb; i += 4) {   // the pool is only byte aligned per record: assemble words, store bytes
+        const uint32_t w = ld32(sq + i);
+        o.seq[sa + i] = (uint8_t)w; o.seq[sa + i + 1] = (uint8_t)(w >> 8); o.seq[sa + i + 2] = (uint8_t)(w >> 16); o.seq[sa + i + 3] = (uint8_t)(w >> 24);
+    }
+    for (; i < sb; ++i) o.seq[sa + i] = sq[i];
+    if (with_qual) {
+        o.mapq[j] = p[13];
+        o.isize[j] = (int32_t)ld32(p + 32);
+        const uint64_t qa = qual_at[r];
+        o.qualoff[j] = qa;
+        const uint8_t* ql = sq + sb;
+        for (uint32_t t = 0; t < (uint32_t)l_seq; ++t) o.qual[qa + t] = ql[t];
+    }
+}
+
+__global__ void k_read_begin(const uint32_t* __restrict__ first_seg, uint32_t nc, const uint64_t* __restrict__ rec_base, const uint32_t* __restrict__ kidx,
+                             uint64_t n_rec, uint64_t* __restrict__ read_begin) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > nc) return;
+    // first_seg[c] = index of the first segment of contig c (n_segs for c == nc or a contig without records: then the next one's)
+    const uint64_t r = rec_base[first_seg[c]];
+    read_begin[c] = r < n_rec ? kidx[r] : kidx[n_rec];
+}
+
+inline unsigned nblk(uint64_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+namespace np1ingest {
+
+struct Scratch {
+    DevBuf comp, inflated, blocks, status, segs, counts, rec_base, first_seg, small, scan_tmp, rec_off, rec_seg, keep, kidx, ncw, seqb, qualb, cig_at, seq_at, qual_at;
+    std::vector<uint32_t> h_status;
+    uint64_t n_host_blocks = 0;
+    ~Scratch() {
+        DevBuf* all[] = {&comp, &inflated, &blocks, &status, &segs, &counts, &rec_base, &first_seg, &small, &scan_tmp, &rec_off, &rec_seg, &keep, &kidx, &ncw,
+                         &seqb, &qualb, &cig_at, &seq_at, &qual_at};
+        for (DevBuf* b : all) b->release();
+    }
+};
+Scratch* scratch_create() { return new Scratch(); }
+void scratch_destroy(Scratch* s) { delete s; }
+uint64_t scratch_host_blocks(const Scratch* s) { return s ? s->n_host_blocks : 0; }
+
+struct HostPin {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + (1u << 20);
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    ~HostPin() { if (p) (void)hipHostFree(p); }
+};
+
+struct Staging::Impl {
+    HostPin comp, draft;
+    std::vector<npdev::BlockDesc> blocks;
+    std::vector<uint64_t> block_coff;          // file offset of every block, ascending
+    std::vector<uint32_t> block_size;          // its size in the file
+    std::vector<Segment> segs;
+    std::vector<uint32_t> first_seg;           // nc + 1
+    std::vector<uint32_t> ctg_off;             // nc + 1
+    std::vector<int32_t> ctg_len;
+    std::vector<std::string> names;
+    uint64_t comp_bytes = 0, inflated_bytes = 0;
+};
+
+Staging::Staging() : impl(new Impl()) {}
+Staging::~Staging() { delete impl; }
+const std::vector<std::string>& Staging::names() const { return impl->names; }
+uint64_t Staging::compressed_bytes() const { return impl->comp_bytes; }
+
+// Host half: FASTA strings, the compressed extents of the batch's contigs into pinned memory, the block table, the anchors.
+// Returns 1 when this batch cannot take the device path (index without the per-contig offsets), 0 on success, -1 on error.
+int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, std::string* err) {
+    Staging::Impl& S = *st->impl;
+    S.names = names;
+    S.blocks.clear(); S.block_coff.clear(); S.block_size.clear(); S.segs.clear(); S.first_seg.clear(); S.ctg_off.assign(1, 0); S.ctg_len.clear();
+    const size_t nc = names.size();
+    // ---- drafts
+    std::vector<int> fid(nc), tid(nc);
+    size_t draft_total = 0;
+    for (size_t c = 0; c < nc; ++c) {
+        fid[c] = src.fai.find(names[c]);
+        if (fid[c] < 0) { *err = "contig not in FASTA index: " + names[c]; return -1; }
+        draft_total += (size_t)src.fai.entry(fid[c]).len;
+        tid[c] = src.hdr.name2id(names[c]);
+    }
+    if (draft_total >= 0xfff00000ull) { *err = "batch too large: draft must stay below 2^32 slots"; return -1; }
+    if (!S.draft.ensure(draft_total + 64)) { *err = "hipHostMalloc failed"; return -1; }
+    std::string seq;
+    size_t at = 0;
+    for (size_t c = 0; c < nc; ++c) {
+        if (!src.fai.fetch(fid[c], &seq)) { *err = "cannot fetch contig: " + names[c]; return -1; }
+        memcpy((char*)S.draft.p + at, seq.data(), seq.size());
+        at += seq.size();
+        S.ctg_len.push_back((int32_t)seq.size());
+        S.ctg_off.push_back((uint32_t)at);
+    }
+    // ---- compressed extents: [block of the contig's first record, block of the end of its last record]
+    std::vector<std::pair<np::voff_t, np::voff_t>> vr(nc, {0, 0});
+    for (size_t c = 0; c < nc; ++c) {
+        if (tid[c] < 0 || tid[c] >= (int)src.bai.refs.size()) continue;
+        const np::BaiRef& r = src.bai.refs[(size_t)tid[c]];
+        auto it = r.bins.find(37450u);
+        if (it == r.bins.end() || it->second.size() < 2) {
+            if (r.bins.empty()) continue;      // no records at all
+            return 1;                          // an index without the metadata pseudo-bin: host loader
+        }
+        if (it->second[0].end > it->second[0].beg) vr[c] = {it->second[0].beg, it->second[0].end};
+    }
+    // walk the BGZF headers of every extent (extents of consecutive contigs abut or share a block: merge on the fly)
+    // order the contigs' ranges by file position
+    std::vector<size_t> order;
+    for (size_t c = 0; c < nc; ++c) if (vr[c].second > vr[c].first) order.push_back(c);
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return vr[a].first < vr[b].first; });
+    uint64_t comp_at = 0, u_at = 0;
+    uint64_t next_coff = (uint64_t)-1;    // file offset right behind the last block taken
+    // first pass: block list (file offsets + sizes) by reading headers; the payloads are read in one pread per run of blocks
+    struct Run { uint64_t coff, bytes, comp_at; };
+    std::vector<Run> runs;
+    for (size_t oi = 0; oi < order.size(); ++oi) {
+        const size_t c = order[oi];
+        const uint64_t c0 = vr[c].first >> 16;
+        const uint64_t cend_incl = (vr[c].second & 0xffffu) ? (vr[c].second >> 16) : (uint64_t)-2;   // last block to include (-2: up to, not including, ve's block)
+        const uint64_t stop_excl = (vr[c].second & 0xffffu) ? (uint64_t)-1 : (vr[c].second >> 16);
+        uint64_t coff = c0;
+        if (next_coff != (uint64_t)-1 && coff < next_coff) coff = next_coff;   // blocks already taken for the previous contig
+        for (;;) {
+            if (cend_incl != (uint64_t)-2 && coff > cend_incl) break;
+            if (stop_excl != (uint64_t)-1 && coff >= stop_excl) break;
+            uint8_t h[18];
+            if (pread(src.fd, h, 18, (off_t)coff) != 18) { *err = "BAM truncated inside the indexed range"; return -1; }
+            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { *err = "not a BGZF block where the index points"; return -1; }
+            const uint32_t xlen = h[10] | (h[11] << 8);
+            uint32_t bsize = 0;
+            if (xlen == 6 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0) bsize = (uint32_t)(h[16] | (h[17] << 8)) + 1;
+            else {   // other extra subfields before BC: read the whole extra field
+                std::vector<uint8_t> x(xlen);
+                if (pread(src.fd, x.data(), xlen, (off_t)coff + 12) != (ssize_t)xlen) { *err = "BAM truncated"; return -1; }
+                for (uint32_t i = 0; i + 4 <= xlen;) {
+                    const uint32_t slen = x[i + 2] | (x[i + 3] << 8);
+                    if (x[i] == 'B' && x[i + 1] == 'C' && slen == 2 && i + 6 <= xlen) bsize = (uint32_t)(x[i + 4] | (x[i + 5] << 8)) + 1;
+                    i += 4 + slen;
+                }
+            }
+            if (bsize < 12 + xlen + 8) { *err = "bad BGZF block size"; return -1; }
+            if (runs.empty() || runs.back().coff + runs.back().bytes != coff) runs.push_back(Run{coff, 0, comp_at});
+            runs.back().bytes += bsize;
+            npdev::BlockDesc d;
+            d.in_off = comp_at + 12 + xlen;
+            d.in_len = bsize - (12 + xlen) - 8;
+            d.out_off = 0;
+            d.out_len = 0;            // ISIZE: filled after the payload is in memory
+            S.blocks.push_back(d);
+            S.block_coff.push_back(coff);
+            S.block_size.push_back(bsize);
+            comp_at += bsize;
+            coff += bsize;
+            next_coff = coff;
+        }
+    }
+    if (!S.comp.ensure(comp_at + 4096)) { *err = "hipHostMalloc failed"; return -1; }
+    for (const Run& r : runs) {
+        uint64_t done = 0;
+        while (done < r.bytes) {
+            const ssize_t g = pread(src.fd, (char*)S.comp.p + r.comp_at + done, r.bytes - done, (off_t)(r.coff + done));
+            if (g <= 0) { *err = "BAM read failed"; return -1; }
+            done += (uint64_t)g;
+        }
+    }
+    memset((char*)S.comp.p + comp_at, 0, 4096);
+    for (size_t b = 0; b < S.blocks.size(); ++b) {
+        npdev::BlockDesc& d = S.blocks[b];
+        uint32_t isize;
+        memcpy(&isize, (const char*)S.comp.p + d.in_off + d.in_len + 4, 4);
+        if (isize > 65536) { *err = "BGZF block larger than 64 KiB"; return -1; }
+        d.out_len = isize;
+        d.out_off = u_at;
+        u_at += isize;
+    }
+    S.comp_bytes = comp_at;
+    S.inflated_bytes = u_at;
+    // ---- anchors -> segments (inflated-stream offsets)
+    auto to_u = [&](np::voff_t v, uint64_t* out) {
+        const uint64_t coff = v >> 16;
+        auto it = std::lower_bound(S.block_coff.begin(), S.block_coff.end(), coff);
+        if (it == S.block_coff.end() || *it != coff) {
+            // the position right behind a block that was read (the end of a contig's last record at a block boundary)
+            if ((v & 0xffffu) == 0 && it != S.block_coff.begin()) {
+                const size_t pb = (size_t)(it - S.block_coff.begin()) - 1;
+                const npdev::BlockDesc& d = S.blocks[pb];
+                if (S.block_coff[pb] + S.block_size[pb] == coff) { *out = d.out_off + d.out_len; return true; }
+            }
+            return false;
+        }
+        const size_t b = (size_t)(it - S.block_coff.begin());
+        if ((v & 0xffffu) > S.blocks[b].out_len) return false;
+        *out = S.blocks[b].out_off + (v & 0xffffu);
+        return true;
+    };
+    S.first_seg.assign(nc + 1, 0);
+    std::vector<uint64_t> anchors;
+    for (size_t c = 0; c < nc; ++c) {
+        S.first_seg[c] = (uint32_t)S.segs.size();
+        if (vr[c].second <= vr[c].first) continue;
+        uint64_t ub, ue;
+        if (!to_u(vr[c].first, &ub) || !to_u(vr[c].second, &ue)) { *err = "BAM index points outside the blocks read"; return -1; }
+        anchors.clear();
+        anchors.push_back(ub);
+        const np::BaiRef& r = src.bai.refs[(size_t)tid[c]];
+        for (np::voff_t v : r.linear) {
+            if (v <= vr[c].first || v >= vr[c].second) continue;
+            uint64_t x;
+            if (to_u(v, &x) && x > ub && x < ue) anchors.push_back(x);
+        }
+        std::sort(anchors.begin(), anchors.end());
+        anchors.erase(std::unique(anchors.begin(), anchors.end()), anchors.end());
+        for (size_t a = 0; a < anchors.size(); ++a)
+            S.segs.push_back(Segment{anchors[a], a + 1 < anchors.size() ? anchors[a + 1] : ue, (uint32_t)c, (int32_t)tid[c], S.ctg_len[c], 0});
+    }
+    S.first_seg[nc] = (uint32_t)S.segs.size();
+    return 0;
+}
+
+// Device half: fills the batch object.  Returns 0, 1 (take the host loader for this batch: CG-tag CIGARs) or -1.
+int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
+    Staging::Impl& S = *st->impl;
+    np1_ctx* ctx = b->ctx;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t q = ctx->stream;
+    const uint32_t nc = (uint32_t)S.names.size();
+    const uint32_t n_blocks = (uint32_t)S.blocks.size(), n_segs = (uint32_t)S.segs.size();
+    b->nc = nc;
+    b->G = S.ctg_off.back();
+    b->h_ctg_off = S.ctg_off;
+    b->max_lq = 0;
+    b->force_staged = false;
+    b->ran = false;
+    b->out_cached = false;
+    b->out_pinned = false;
+    Scratch& W = *scr;
+    if (b->draft.ensure(b->G + 64) || b->ctg_off.ensure(4 * (size_t)(nc + 1)) || b->read_begin.ensure(8 * (size_t)(nc + 2)) ||
+        W.comp.ensure(S.comp_bytes + 4096) || W.inflated.ensure(S.inflated_bytes + 4096) || W.blocks.ensure(sizeof(npdev::BlockDesc) * (size_t)(n_blocks + 1)) ||
+        W.status.ensure(4 * (size_t)(n_blocks + 1)) || W.segs.ensure(sizeof(Segment) * (size_t)(n_segs + 1)) || W.counts.ensure(4 * (size_t)(n_segs + 2)) ||
+        W.rec_base.ensure(8 * (size_t)(n_segs + 2)) || W.first_seg.ensure(4 * (size_t)(nc + 2)) || W.small.ensure(256) ||
+        W.scan_tmp.ensure(8 * (np1k::scan_tmp_words((uint64_t)n_segs + 1) + 8)))
+        return -1;
+    if (b->G) HIPCHK(hipMemcpyAsync(b->draft.p, S.draft.p, b->G, hipMemcpyHostToDevice, q));
+    HIPCHK(hipMemcpyAsync(b->ctg_off.p, S.ctg_off.data(), 4 * (size_t)(nc + 1), hipMemcpyHostToDevice, q));
+    if (S.comp_bytes) HIPCHK(hipMemcpyAsync(W.comp.p, S.comp.p, S.comp_bytes + 4096, hipMemcpyHostToDevice, q));
+    if (n_blocks) HIPCHK(hipMemcpyAsync(W.blocks.p, S.blocks.data(), sizeof(npdev::BlockDesc) * (size_t)n_blocks, hipMemcpyHostToDevice, q));
+    if (n_segs) HIPCHK(hipMemcpyAsync(W.segs.p, S.segs.data(), sizeof(Segment) * (size_t)n_segs, hipMemcpyHostToDevice, q));
+    HIPCHK(hipMemcpyAsync(W.first_seg.p, S.first_seg.data(), 4 * (size_t)(nc + 1), hipMemcpyHostToDevice, q));
+    HIPCHK(hipMemsetAsync(W.small.p, 0, 256, q));
+    uint32_t* d_err = W.small.as<uint32_t>();           // [0] error bits, [1] max l_qseq
+    uint64_t* d_tot = reinterpret_cast<uint64_t*>(W.small.as<uint8_t>() + 64);   // scan totals
+    uint64_t n_rec = 0;
+    if (n_blocks) {
+        k_inflate<<<nblk(n_blocks, 4), 256, 0, q>>>(W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>());
+        W.h_status.resize(n_blocks);
+        HIPCHK(hipMemcpyAsync(W.h_status.data(), W.status.p, 4 * (size_t)n_blocks, hipMemcpyDeviceToHost, q));
+    }
+    if (n_segs) {
+        k_chase<false><<<nblk(n_segs, 64), 64, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, W.counts.as<uint32_t>(), nullptr, nullptr, nullptr, d_err);
+        np1k::launch_scan_rows(q, W.counts.as<uint32_t>(), n_segs, W.rec_base.as<uint64_t>(), W.scan_tmp.as<uint64_t>(), &d_tot[0]);
+        HIPCHK(hipMemcpyAsync(&n_rec, &d_tot[0], 8, hipMemcpyDeviceToHost, q));
+    } else {
+        HIPCHK(hipMemsetAsync(W.rec_base.p, 0, 16, q));
+    }
+    HIPCHK(hipStreamSynchronize(q));
+    // blocks the device decoder did not accept: inflate them on the host and patch them in, then redo the count
+    bool patched = false;
+    for (uint32_t i = 0; i < n_blocks; ++i) {
+        if (!W.h_status[i]) continue;
+        const npdev::BlockDesc& d = S.blocks[i];
+        std::vector<uint8_t> tmp(d.out_len ? d.out_len : 1);
+        if (!np::bgzf_inflate_block((const uint8_t*)S.comp.p + d.in_off, d.in_len, tmp.data(), d.out_len)) { np1_set_error("corrupt BGZF block in the BAM"); return -1; }
+        HIPCHK(hipMemcpy(W.inflated.as<uint8_t>() + d.out_off, tmp.data(), d.out_len, hipMemcpyHostToDevice));
+        patched = true;
+        ++W.n_host_blocks;
+    }
+    if (patched && n_segs) {
+        HIPCHK(hipMemsetAsync(d_err, 0, 4, q));
+        k_chase<false><<<nblk(n_segs, 64), 64, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, W.counts.as<uint32_t>(), nullptr, nullptr, nullptr, d_err);
+        np1k::launch_scan_rows(q, W.counts.as<uint32_t>(), n_segs, W.rec_base.as<uint64_t>(), W.scan_tmp.as<uint64_t>(), &d_tot[0]);
+        HIPCHK(hipMemcpyAsync(&n_rec, &d_tot[0], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(hipStreamSynchronize(q));
+    }
+    if (n_rec >= 0xfffffff0ull) { np1_set_error("batch too large: more than 2^32 records"); return -1; }
+    const size_t nr = (size_t)(n_rec ? n_rec : 1);
+    if (W.rec_off.ensure(8 * nr) || W.rec_seg.ensure(4 * nr) || W.keep.ensure(4 * (nr + 1)) || W.kidx.ensure(4 * (nr + 2)) || W.ncw.ensure(4 * (nr + 1)) ||
+        W.seqb.ensure(4 * (nr + 1)) || W.qualb.ensure(4 * (nr + 1)) || W.cig_at.ensure(8 * (nr + 2)) || W.seq_at.ensure(8 * (nr + 2)) ||
+        W.qual_at.ensure(8 * (nr + 2)) || W.scan_tmp.ensure(8 * (np1k::scan_tmp_words((uint64_t)nr + 1) + np1k::scan_tmp_words((uint64_t)n_segs + 1) + 8)))
+        return -1;
+    uint64_t totals[4] = {0, 0, 0, 0};   // kept records, cigar words, seq bytes, qual bytes
+    uint32_t h_small[2] = {0, 0};
+    if (n_rec) {
+        k_chase<true><<<nblk(n_segs, 64), 64, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, nullptr, W.rec_base.as<uint64_t>(), W.rec_off.as<uint64_t>(),
+                                                     W.rec_seg.as<uint32_t>(), d_err);
+        k_rec_measure<<<nblk(n_rec, 256), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.rec_off.as<uint64_t>(), W.rec_seg.as<uint32_t>(), W.segs.as<Segment>(), n_rec,
+                                                      with_qual ? 1 : 0, W.keep.as<uint32_t>(), W.ncw.as<uint32_t>(), W.seqb.as<uint32_t>(), W.qualb.as<uint32_t>(),
+                                                      d_err + 1, d_err);
+        uint64_t* tmp = W.scan_tmp.as<uint64_t>();
+        np1k::launch_scan_u32(q, W.keep.as<uint32_t>(), n_rec, W.kidx.as<uint32_t>(), tmp, &d_tot[1]);
+        np1k::launch_scan_rows(q, W.ncw.as<uint32_t>(), n_rec, W.cig_at.as<uint64_t>(), tmp, &d_tot[2]);
+        np1k::launch_scan_rows(q, W.seqb.as<uint32_t>(), n_rec, W.seq_at.as<uint64_t>(), tmp, &d_tot[3]);
+        if (with_qual) np1k::launch_scan_rows(q, W.qualb.as<uint32_t>(), n_rec, W.qual_at.as<uint64_t>(), tmp, &d_tot[4]);
+        HIPCHK(hipMemcpyAsync(totals, &d_tot[1], with_qual ? 32 : 24, hipMemcpyDeviceToHost, q));
+    } else {
+        HIPCHK(hipMemsetAsync(W.kidx.p, 0, 8, q));
+    }
+    HIPCHK(hipMemcpyAsync(h_small, d_err, 8, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipStreamSynchronize(q));
+    if (h_small[0] & IG_ERR_CGTAG) return 1;
+    if (h_small[0] & (IG_ERR_CHAIN | IG_ERR_RECORD)) { np1_set_error("BAM records do not line up with the index (corrupt BAM or stale .bai)"); return -1; }
+    const size_t n = (size_t)totals[0];
+    b->n_reads = (int64_t)n;
+    b->max_lq = h_small[1];
+    const size_t nn = n ? n : 1;
+    if (b->pos.ensure(4 * nn) || b->ctg.ensure(4 * nn) || b->flag.ensure(2 * nn) || b->ncig.ensure(2 * nn) || b->lq.ensure(4 * nn) || b->cigoff.ensure(8 * nn) ||
+        b->seqoff.ensure(8 * nn) || b->cigar.ensure(4 * (size_t)totals[1] + 64) || b->seq.ensure((size_t)totals[2] + 64))
+        return -1;
+    b->has_qual = with_qual;
+    if (with_qual && (b->mapq.ensure(nn) || b->isize.ensure(4 * nn) || b->qualoff.ensure(8 * nn) || b->qual.ensure((size_t)totals[3] + 64))) return -1;
+    if (n_rec) {
+        ScatterOut o{b->pos.as<int32_t>(), b->ctg.as<uint32_t>(), b->flag.as<uint16_t>(), b->ncig.as<uint16_t>(), b->lq.as<int32_t>(), b->cigoff.as<uint64_t>(),
+                     b->seqoff.as<uint64_t>(), b->cigar.as<uint32_t>(), b->seq.as<uint8_t>(), b->mapq.as<uint8_t>(), b->isize.as<int32_t>(),
+                     b->qualoff.as<uint64_t>(), b->qual.as<uint8_t>()};
+        k_rec_scatter<<<nblk(n_rec, 256), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.rec_off.as<uint64_t>(), W.rec_seg.as<uint32_t>(), W.segs.as<Segment>(), n_rec,
+                                                      W.keep.as<uint32_t>(), W.kidx.as<uint32_t>(), W.cig_at.as<uint64_t>(), W.seq_at.as<uint64_t>(),
+                                                      W.qual_at.as<uint64_t>(), with_qual ? 1 : 0, o);
+    }
+    k_read_begin<<<nblk(nc + 1, 64), 64, 0, q>>>(W.first_seg.as<uint32_t>(), nc, W.rec_base.as<uint64_t>(), W.kidx.as<uint32_t>(), n_rec, b->read_begin.as<uint64_t>());
+    b->h_read_begin.resize((size_t)nc + 1);
+    HIPCHK(hipMemcpyAsync(b->h_read_begin.data(), b->read_begin.p, 8 * (size_t)(nc + 1), hipMemcpyDeviceToHost, q));
+    HIPCHK(hipStreamSynchronize(q));
+    b->input_bytes = b->G + 32 * n + 4 * (size_t)totals[1] + (size_t)totals[2];
+    return 0;
+}
+
+bool BamSource::open(const std::string& fasta, const std::string& bam, std::string* err) {
+    if (!fai.load(fasta)) { *err = "cannot load FASTA/index: " + fasta; return false; }
+    np::BamReader rd;
+    if (!rd.open(bam)) { *err = "cannot open BAM: " + bam; return false; }
+    hdr = rd.header();
+    have_bai = bai.load(bam + ".bai");
+    fd = ::open(bam.c_str(), O_RDONLY);
+    if (fd < 0) { *err = "cannot open BAM: " + bam; return false; }
+    return true;
+}
+BamSource::~BamSource() { if (fd >= 0) ::close(fd); }
+
+}  // namespace np1ingest
+
+// test / diagnostics hook: inflates a buffer of concatenated BGZF blocks on the device; out receives the inflated bytes,
+// status one word per block (0 = accepted).  Returns the number of blocks or -1.
+extern "C" int64_t np1_debug_inflate_device(int device, const uint8_t* bgzf, uint64_t n, uint8_t* out, uint64_t out_cap, uint32_t* status, int64_t status_cap) {
+    if (hipSetDevice(device) != hipSuccess) { np1_set_error("hipSetDevice failed"); return -1; }
+    std::vector<npdev::BlockDesc> blocks;
+    uint64_t p = 0, u = 0;
+    while (p + 18 <= n) {
+        const uint8_t* h = bgzf + p;
+        if (h[0] != 31 || h[1] != 139) { np1_set_error("not BGZF"); return -1; }
+        const uint32_t xlen = h[10] | (h[11] << 8);
+        uint32_t bsize = 0;
+        for (uint32_t i = 0; i + 4 <= xlen;) {
+            const uint8_t* x = h + 12 + i;
+            const uint32_t slen = x[2] | (x[3] << 8);
+            if (x[0] == 'B' && x[1] == 'C' && slen == 2) bsize = (uint32_t)(x[4] | (x[5] << 8)) + 1;
+            i += 4 + slen;
+        }
+        if (!bsize || p + bsize > n) { np1_set_error("truncated BGZF"); return -1; }
+        uint32_t isize;
+        memcpy(&isize, h + bsize - 4, 4);
+        blocks.push_back(npdev::BlockDesc{p + 12 + xlen, u, bsize - (12 + xlen) - 8, isize});
+        u += isize;
+        p += bsize;
+    }
+    if (u > out_cap || (int64_t)blocks.size() > status_cap) { np1_set_error("output buffers too small"); return -1; }
+    DevBuf dc, du, db, ds;
+    if (dc.ensure(n + 4096) || du.ensure(u + 64) || db.ensure(sizeof(npdev::BlockDesc) * (blocks.size() + 1)) || ds.ensure(4 * (blocks.size() + 1))) return -1;
+    HIPCHK(hipMemset(dc.p, 0, n + 4096));
+    HIPCHK(hipMemcpy(dc.p, bgzf, n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db.p, blocks.data(), sizeof(npdev::BlockDesc) * blocks.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(du.p, 0xEE, u + 64));
+    if (!blocks.empty()) k_inflate<<<nblk(blocks.size(), 4), 256>>>(dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>());
+    HIPCHK(hipDeviceSynchronize());
+    if (u) HIPCHK(hipMemcpy(out, du.p, u, hipMemcpyDeviceToHost));
+    if (!blocks.empty()) HIPCHK(hipMemcpy(status, ds.p, 4 * blocks.size(), hipMemcpyDeviceToHost));
+    dc.release(); du.release(); db.release(); ds.release();
+    return (int64_t)blocks.size();
+}

@@ -25,10 +25,9 @@ int32_t BamRec::rlen() const {
 }
 
 int32_t BamRec::endpos() const {
-    if (!(flag & 4) && n_cigar > 0) {
-        int32_t l = rlen();
-        return pos + (l > 0 ? l : 1);   // htslib: a zero-length alignment still occupies one base
-    }
+    // the reference's vendored htslib 1.9 (sam.c:391-397): pos + rlen for a mapped record with a CIGAR -- also when the CIGAR
+    // consumes no reference base (only S/I/H/P ops), where later htslib versions return pos + 1
+    if (!(flag & 4) && n_cigar > 0) return pos + rlen();
     return pos + 1;
 }
 

@@ -40,7 +40,7 @@ struct BamRec {
     const uint8_t* qual() const { return seq() + ((size_t)l_qseq + 1) / 2; }
     // reference-consumed length, htslib bam_cigar2rlen semantics (M,D,N,=,X consume the reference)
     int32_t rlen() const;
-    // htslib bam_endpos: pos + rlen, or pos + 1 for unmapped / CIGAR-less records
+    // bam_endpos of the reference's htslib 1.9: pos + rlen (also when rlen is 0), or pos + 1 for unmapped / CIGAR-less records
     int32_t endpos() const;
 };
 

@@ -1,0 +1,423 @@
+// Device-side raw-DEFLATE (RFC 1951) decoder for BGZF blocks: ONE WAVE PER BLOCK, written for gfx950 from the RFC.
+//
+// The reference inflates every BGZF block on the host, twice per contig (htslib bgzf.c behind source/lib/contig.c:172-174,
+// 692-694).  Here the compressed file bytes go to HBM as they are and the 256 CUs inflate the independent blocks:
+//
+//  * the Huffman decode is sequential by nature, so all 64 lanes of the wave run it REDUNDANTLY on wave-uniform state (bit
+//    buffer, positions): no divergence, table lookups are LDS broadcasts, and uniform values can live in scalar registers;
+//  * the compressed bytes are fetched 256 B at a time as one coalesced load (one dword per lane) and handed to the bit
+//    buffer with v_readlane; the next 256 B are already in flight while the current ones are consumed;
+//  * decoded symbols are collected as up to 64 TOKENS (literal or length/distance), one per lane, in a register; a full
+//    group is resolved by the whole wave: an exclusive scan of the token lengths places every token, literal lanes store
+//    their byte, match lanes copy their bytes -- a match whose source lies inside the group waits for the lanes before it
+//    (rounds over a frontier, one workgroup-scope fence per round; cf. Sitaridi et al., "Massively-Parallel Lossless Data
+//    Decompression", ICPP 2016);
+//  * code tables are built by the wave: code lengths sit in registers (symbol s -> lane s % 64 of register s / 64),
+//    canonical codes come from ballots + popcounts, every lane fills the primary-table slots of its own symbols.  Codes
+//    longer than the primary index (10 bits literal/length, 8 bits distance) are decoded arithmetically from the
+//    canonical first-code table (they are < 1 % of the symbols), so there are no second-level tables to build.
+//
+// Anything the decoder does not accept (malformed stream, size mismatch) sets the block's status word; the host inflates
+// those blocks itself (np_bgzf.cpp) -- a false negative costs time, never correctness.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace npdev {
+
+constexpr int LIT_BITS = 10, DIST_BITS = 8;
+constexpr uint32_t K_LITERAL = 0, K_LENGTH = 1, K_END = 2, K_LONG = 3;   // K_LONG: code longer than the primary index (or no code)
+
+// LDS of one wave
+struct InflateLds {
+    uint32_t lit[1 << LIT_BITS];     // bits 0..3 code length, 4..7 extra bits, 8..9 kind, 16..31 value (literal, base length)
+    uint32_t dist[1 << DIST_BITS];   // same layout, value = base distance
+    uint16_t lit_sorted[288];        // symbols ordered by (code length, symbol): canonical decode of long codes
+    uint16_t dist_sorted[32];
+    uint16_t lit_first[16], lit_count[16], lit_offs[16];    // per code length: first canonical code, number of codes, offset into *_sorted
+    uint16_t dist_first[16], dist_count[16], dist_offs[16];
+    uint8_t cl_len[320];             // code lengths while a dynamic header is read
+    uint32_t cl_tab[128];            // code-length alphabet, 7-bit direct table
+};
+
+struct BlockDesc {          // one BGZF block (host-built table)
+    uint64_t in_off;        // offset of the raw-deflate payload in the compressed buffer
+    uint64_t out_off;       // offset of its inflated bytes in the output buffer
+    uint32_t in_len;        // payload bytes
+    uint32_t out_len;       // ISIZE
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__device__ const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// ---- wave-uniform bit reader over a coalesced register window of the input
+struct BitReader {
+    const uint32_t* words;   // 4-byte aligned base of the payload (may start up to 3 bytes early)
+    uint32_t cur, nxt;       // lane l holds word (chunk * 64 + l) of the current / the next 256-byte chunk
+    uint32_t widx;           // next word to feed into the bit buffer (global word index)
+    uint64_t bb;
+    uint32_t nb;
+    uint64_t consumed;       // bits handed out, for the overrun check
+    __device__ __forceinline__ void init(const uint8_t* p) {
+        const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
+        words = reinterpret_cast<const uint32_t*>(p - mis);
+        cur = words[lane_id()];
+        nxt = words[64 + lane_id()];
+        widx = 0;
+        bb = 0;
+        nb = 0;
+        consumed = 0;
+        refill();
+        bb >>= 8 * mis;
+        nb -= 8 * mis;
+    }
+    __device__ __forceinline__ uint32_t next_word() {
+        const uint32_t w = rdlane(cur, widx & 63u);
+        ++widx;
+        if ((widx & 63u) == 0) {   // crossed into the next chunk: rotate the windows, start the load after next
+            cur = nxt;
+            nxt = words[(size_t)widx + 64 + lane_id()];
+        }
+        return w;
+    }
+    __device__ __forceinline__ void refill() {   // keeps >= 32 valid bits
+        if (nb <= 32) {
+            bb |= (uint64_t)next_word() << nb;
+            nb += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(uint32_t n) { bb >>= n; nb -= n; consumed += n; }
+    __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+    // byte position (relative to words) of the next unread bit, which must be byte aligned
+    __device__ __forceinline__ uint64_t byte_pos() const { return (uint64_t)widx * 4u - (nb >> 3); }
+};
+
+// ---- canonical Huffman tables from code lengths held in registers.
+// lens[k] on lane l = code length of symbol 64 k + l (0 beyond n_sym).  Fills the primary table and the canonical arrays.
+// Returns false (uniformly) for an over-subscribed code.
+template <int NREG, int TBITS, bool IS_DIST>
+__device__ bool build_tables(const uint32_t (&lens)[NREG], uint32_t* table, uint16_t* sorted, uint16_t* first, uint16_t* count, uint16_t* offs) {
+    const uint32_t lane = lane_id();
+    uint32_t cnt[16];
+#pragma unroll
+    for (int L = 0; L < 16; ++L) cnt[L] = 0;
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+#pragma unroll
+        for (int L = 1; L < 16; ++L) cnt[L] += (uint32_t)__popcll(__ballot(lens[k] == (uint32_t)L));
+    }
+    // Kraft check + canonical first codes (wave-uniform scalar work)
+    int left = 1;
+    uint32_t code = 0, off = 0;
+    uint32_t firstc[16], offc[16];
+    firstc[0] = 0; offc[0] = 0;
+    bool over = false;
+#pragma unroll
+    for (int L = 1; L < 16; ++L) {
+        left = (left << 1) - (int)cnt[L];
+        if (left < 0) over = true;
+        code = (code + cnt[L - 1]) << 1;
+        firstc[L] = code;
+        offc[L] = off;
+        off += cnt[L];
+    }
+    if (over) return false;
+    if (lane < 16) {
+        uint32_t f = 0, c = 0, o = 0;
+#pragma unroll
+        for (int L = 1; L < 16; ++L)
+            if (lane == (uint32_t)L) { f = firstc[L]; c = cnt[L]; o = offc[L]; }
+        first[lane] = (uint16_t)f;
+        count[lane] = (uint16_t)c;
+        offs[lane] = (uint16_t)o;
+    }
+    // every slot starts as "long / no code"
+    for (uint32_t i = lane; i < (1u << TBITS); i += 64) table[i] = (K_LONG << 8) | 1u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // rank of every symbol among the symbols of its length (in symbol order) -> canonical code
+    uint32_t seen[16];
+#pragma unroll
+    for (int L = 0; L < 16; ++L) seen[L] = 0;
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+        const uint32_t len = lens[k];
+        uint32_t rank = 0, fc = 0, oc = 0;
+#pragma unroll
+        for (int L = 1; L < 16; ++L) {
+            const uint64_t m = __ballot(len == (uint32_t)L);
+            if (len == (uint32_t)L) {
+                rank = seen[L] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                fc = firstc[L];
+                oc = offc[L];
+            }
+            seen[L] += (uint32_t)__popcll(m);
+        }
+        if (len) {
+            const uint32_t sym = 64u * (uint32_t)k + lane;
+            sorted[oc + rank] = (uint16_t)sym;
+            if (len <= (uint32_t)TBITS) {
+                const uint32_t c = fc + rank;                                   // canonical code, MSB first
+                const uint32_t rev = __builtin_bitreverse32(c) >> (32u - len);   // as it appears in the LSB-first stream
+                uint32_t e;
+                if (IS_DIST) {
+                    e = sym < 30 ? ((uint32_t)kDistBase[sym] << 16 | K_LENGTH << 8 | (uint32_t)kDistExtra[sym] << 4 | len) : ((K_LONG << 8) | 1u);
+                } else if (sym < 256) e = sym << 16 | K_LITERAL << 8 | len;
+                else if (sym == 256) e = K_END << 8 | len;
+                else if (sym <= 285) e = (uint32_t)kLenBase[sym - 257] << 16 | K_LENGTH << 8 | (uint32_t)kLenExtra[sym - 257] << 4 | len;
+                else e = (K_LONG << 8) | 1u;
+                for (uint32_t i = rev; i < (1u << TBITS); i += 1u << len) table[i] = e;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
+// Canonical decode of a code longer than TBITS from the next 15 stream bits; returns the symbol and its length, or len = 0.
+template <int TBITS>
+__device__ __forceinline__ uint32_t decode_long(uint32_t bits15, const uint16_t* sorted, const uint16_t* first, const uint16_t* count,
+                                                const uint16_t* offs, uint32_t* len_out) {
+    const uint32_t msb = __builtin_bitreverse32(bits15) >> 17;   // 15 bits, first stream bit on top
+    for (uint32_t L = TBITS + 1; L <= 15; ++L) {
+        const uint32_t c = msb >> (15u - L);
+        const uint32_t d = c - (uint32_t)first[L];
+        if (c >= (uint32_t)first[L] && d < (uint32_t)count[L]) {
+            *len_out = L;
+            return (uint32_t)sorted[(uint32_t)offs[L] + d];
+        }
+    }
+    *len_out = 0;
+    return 0;
+}
+
+// Token group: lane j of `tok` holds token j.  literal: byte in 0..7; match: bit 31, length in 16..24, distance - 1 in 0..14.
+// Resolves ntok tokens at output position op; returns the new position or ~0u on a bad distance / overflow.
+__device__ __forceinline__ uint32_t flush_tokens(uint8_t* out, uint32_t op, uint32_t out_len, uint32_t tok, uint32_t ntok) {
+    const uint32_t lane = lane_id();
+    const bool act = lane < ntok;
+    const bool is_match = act && (tok >> 31);
+    const uint32_t len = is_match ? ((tok >> 16) & 0x1ffu) : (act ? 1u : 0u);
+    const uint32_t dist = (tok & 0x7fffu) + 1u;
+    // inclusive scan of the lengths
+    uint32_t inc = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += v;
+    }
+    const uint32_t total = rdlane(inc, 63);
+    const uint32_t start = op + inc - len;
+    if (op + total > out_len) return ~0u;
+    const uint64_t mm = __ballot(is_match);
+    if (__ballot(is_match && dist > start)) return ~0u;
+    if (act && !is_match) out[start] = (uint8_t)tok;
+    if (mm) {
+        uint64_t undone = mm;
+        const uint32_t src = start - dist;
+        const uint32_t src_end = src + (len < dist ? len : dist);
+        while (undone) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // everything stored so far is visible to the wave
+            const uint32_t k = (uint32_t)__ffsll((long long)undone) - 1u;
+            const uint32_t W = rdlane(start, k);                        // all bytes below W are final
+            const bool ready = ((undone >> lane) & 1ull) && src_end <= W;
+            if (ready) {
+                if (dist >= len) {
+                    for (uint32_t i = 0; i < len; ++i) out[start + i] = out[src + i];
+                } else {   // self-overlapping match: the pattern of `dist` bytes repeats; read only below `start`
+                    uint32_t r = 0;
+                    for (uint32_t i = 0; i < len; ++i) {
+                        out[start + i] = out[src + r];
+                        if (++r == dist) r = 0;
+                    }
+                }
+            }
+            undone &= ~__ballot(ready);
+        }
+    }
+    return op + total;
+}
+
+// Inflates one block; all 64 lanes call it with the same arguments.  Returns 0 on success.
+__device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateLds& L) {
+    const uint32_t lane = lane_id();
+    BitReader br;
+    br.init(in);
+    uint32_t op = 0;
+    uint32_t tok = 0, ntok = 0;
+    const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+    for (;;) {
+        br.refill();
+        const uint32_t final_block = br.take(1), type = br.take(2);
+        if (type == 0) {
+            // stored: pending tokens first, then a wave copy
+            if (ntok) { op = flush_tokens(out, op, out_len, tok, ntok); ntok = 0; if (op == ~0u) return 1; }
+            br.drop(br.nb & 7u);
+            br.refill();
+            const uint32_t len = br.take(16);
+            br.refill();
+            const uint32_t nlen = br.take(16);
+            if ((len ^ 0xffffu) != nlen) return 2;
+            const uint64_t bp = br.byte_pos();                 // relative to br.words
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(br.words) + bp;
+            if (bp - mis + len > in_len || op + len > out_len) return 3;
+            for (uint32_t i = lane; i < len; i += 64) out[op + i] = src[i];
+            op += len;
+            // restart the bit reader behind the stored bytes
+            const uint64_t used_bits = br.consumed + 0;   // consumed counts header bits only; recompute from the byte position
+            (void)used_bits;
+            const uint8_t* np = src + len;
+            const uint64_t consumed_bytes = (uint64_t)(np - in);
+            br.init(np);
+            br.consumed = consumed_bytes * 8u;
+            if (final_block) break;
+            continue;
+        }
+        if (type == 3) return 4;
+        uint32_t ll[5], dl[1];
+        uint32_t hlit = 288, hdist = 30;
+        if (type == 1) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint32_t s = 64u * k + lane;
+                ll[k] = s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : s < 288 ? 8u : 0u;
+            }
+            dl[0] = lane < 30 ? 5u : 0u;   // fixed distance codes 30, 31 never occur in valid data
+        } else {
+            br.refill();
+            hlit = br.take(5) + 257;
+            hdist = br.take(5) + 1;
+            const uint32_t hclen = br.take(4) + 4;
+            if (hlit > 286 || hdist > 30) return 5;
+            // code-length alphabet: 19 lengths of 3 bits, lane s keeps the length of symbol s
+            uint32_t cl = 0;
+            for (uint32_t i = 0; i < hclen; ++i) {
+                br.refill();
+                const uint32_t v = br.take(3);
+                if (lane == (uint32_t)kClOrder[i]) cl = v;
+            }
+            {   // 7-bit direct table of the code-length code (Kraft-checked, incomplete codes leave empty slots)
+                uint32_t cnt[8], firstc[8];
+                int left = 1;
+                uint32_t code = 0;
+                cnt[0] = 0; firstc[0] = 0;
+                bool over = false;
+#pragma unroll
+                for (int b = 1; b < 8; ++b) cnt[b] = (uint32_t)__popcll(__ballot(cl == (uint32_t)b));
+#pragma unroll
+                for (int b = 1; b < 8; ++b) {
+                    left = (left << 1) - (int)cnt[b];
+                    if (left < 0) over = true;
+                    code = (code + cnt[b - 1]) << 1;
+                    firstc[b] = code;
+                }
+                if (over) return 6;
+                L.cl_tab[lane] = 0xffu;
+                L.cl_tab[64 + lane] = 0xffu;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                uint32_t rank = 0, fc = 0;
+#pragma unroll
+                for (int b = 1; b < 8; ++b) {
+                    const uint64_t m = __ballot(cl == (uint32_t)b);
+                    if (cl == (uint32_t)b) { rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); fc = firstc[b]; }
+                }
+                if (cl) {
+                    const uint32_t rev = __builtin_bitreverse32(fc + rank) >> (32u - cl);
+                    for (uint32_t i = rev; i < 128; i += 1u << cl) L.cl_tab[i] = lane << 4 | cl;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // the hlit + hdist code lengths (run-length coded), decoded uniformly; lane 0 writes them to LDS
+            uint32_t n = 0, prev = 0;
+            const uint32_t want = hlit + hdist;
+            while (n < want) {
+                br.refill();
+                const uint32_t e = L.cl_tab[br.peek(7)];
+                if (e == 0xffu) return 7;
+                br.drop(e & 15u);
+                const uint32_t sym = e >> 4;
+                uint32_t rep = 1, val = sym;
+                if (sym == 16) { if (!n) return 8; val = prev; rep = 3 + br.take(2); }
+                else if (sym == 17) { val = 0; rep = 3 + br.take(3); }
+                else if (sym == 18) { val = 0; rep = 11 + br.take(7); }
+                if (n + rep > want) return 9;
+                if (lane < rep) L.cl_len[n + lane] = (uint8_t)val;
+                if (rep > 64 && lane + 64 < rep) L.cl_len[n + 64 + lane] = (uint8_t)val;
+                if (rep > 128 && lane + 128 < rep) L.cl_len[n + 128 + lane] = (uint8_t)val;
+                n += rep;
+                prev = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint32_t s = 64u * k + lane;
+                ll[k] = s < hlit ? (uint32_t)L.cl_len[s] : 0u;
+            }
+            dl[0] = lane < hdist ? (uint32_t)L.cl_len[hlit + lane] : 0u;
+            if (rdlane(ll[4], 0) == 0) return 10;   // no end-of-block code
+        }
+        if (!build_tables<5, LIT_BITS, false>(ll, L.lit, L.lit_sorted, L.lit_first, L.lit_count, L.lit_offs)) return 11;
+        if (!build_tables<1, DIST_BITS, true>(dl, L.dist, L.dist_sorted, L.dist_first, L.dist_count, L.dist_offs)) return 12;
+        // ---- symbols
+        for (;;) {
+            br.refill();
+            uint32_t e = L.lit[br.peek(LIT_BITS)];
+            uint32_t kind = (e >> 8) & 3u;
+            if (kind == K_LONG) {
+                uint32_t len;
+                const uint32_t sym = decode_long<LIT_BITS>(br.peek(15), L.lit_sorted, L.lit_first, L.lit_count, L.lit_offs, &len);
+                if (!len || sym > 285) return 13;
+                if (sym < 256) { e = sym << 16 | K_LITERAL << 8 | len; kind = K_LITERAL; }
+                else if (sym == 256) { e = K_END << 8 | len; kind = K_END; }
+                else { e = (uint32_t)kLenBase[sym - 257] << 16 | K_LENGTH << 8 | (uint32_t)kLenExtra[sym - 257] << 4 | len; kind = K_LENGTH; }
+            }
+            br.drop(e & 15u);
+            if (kind == K_LITERAL) {
+                if (lane == ntok) tok = e >> 16;
+                ++ntok;
+            } else if (kind == K_END) {
+                break;
+            } else {
+                const uint32_t mlen = (e >> 16) + br.take((e >> 4) & 15u);
+                br.refill();
+                uint32_t d = L.dist[br.peek(DIST_BITS)];
+                if (((d >> 8) & 3u) == K_LONG) {
+                    uint32_t len;
+                    const uint32_t sym = decode_long<DIST_BITS>(br.peek(15), L.dist_sorted, L.dist_first, L.dist_count, L.dist_offs, &len);
+                    if (!len || sym >= 30) return 14;
+                    d = (uint32_t)kDistBase[sym] << 16 | K_LENGTH << 8 | (uint32_t)kDistExtra[sym] << 4 | len;
+                }
+                br.drop(d & 15u);
+                const uint32_t xb = (d >> 4) & 15u;
+                br.refill();
+                const uint32_t off = (d >> 16) + br.take(xb);
+                if (lane == ntok) tok = 0x80000000u | mlen << 16 | (off - 1u);
+                ++ntok;
+            }
+            if (ntok == 64) {
+                op = flush_tokens(out, op, out_len, tok, 64);
+                ntok = 0;
+                if (op == ~0u) return 15;
+            }
+            if (br.consumed > (uint64_t)in_len * 8u + 64u) return 16;   // ran off the payload
+        }
+        if (final_block) break;
+    }
+    if (ntok) { op = flush_tokens(out, op, out_len, tok, ntok); if (op == ~0u) return 17; }
+    if (br.consumed > (uint64_t)in_len * 8u) return 18;
+    return op == out_len ? 0 : 19;
+}
+
+}  // namespace npdev

