@@ -204,7 +204,7 @@ struct HostPin {
         p = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 4 + (1u << 20);
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) { p = nullptr; return false; }
         cap = want;
         return true;
     }

@@ -20,6 +20,7 @@
 #include "../../include/nextpolish1.h"
 #include "np1_priv.h"
 #include "np_bam.h"
+#include "np1_ingest.h"
 
 struct np1_pipe {
     int device = 0;
@@ -29,6 +30,7 @@ struct np1_pipe {
     std::vector<std::vector<char>> out;            // per batch: concatenated strings
     std::vector<std::vector<uint32_t>> bounds;     // per batch: nc + 1 offsets
     std::vector<np1_batch*> resident;              // np1_pipe_upload: batch k lives on lane k % lanes
+    uint64_t host_inflated_blocks = 0;             // last np1_pipe_run_files: BGZF blocks the device decoder handed back to the host
 };
 
 namespace {
@@ -171,8 +173,12 @@ const char* np1_pipe_result(np1_pipe* p, int batch, int64_t contig, int64_t* len
 int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const char* const* names, int n_names, int64_t batch_bp,
                        const Configure* cfg, int task, np1_sink_fn sink, void* user) {
     if (!p || !fasta || !bam || !cfg) { np1_set_error("np1_pipe_run_files: null argument"); return -1; }
-    np::Fai fai;
-    if (!fai.load(fasta)) { np1_set_error(std::string("cannot load FASTA/index: ") + fasta); return -1; }
+    np1ingest::BamSource src;
+    {
+        std::string e;
+        if (!src.open(fasta, bam, &e)) { np1_set_error(e); return -1; }
+    }
+    const np::Fai& fai = src.fai;
     std::vector<std::string> want;
     if (names && n_names > 0) for (int i = 0; i < n_names; ++i) want.push_back(names[i]);
     else for (int i = 0; i < fai.nseq(); ++i) want.push_back(fai.entry(i).name);
@@ -188,90 +194,128 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
         cur_bp += L;
     }
     const int n = (int)plan.size();
+    const bool with_qual = task == 2;
+    // NP1_INGEST=host: inflate and split the records on host threads (np_stream.cpp) instead of on the device (np1_ingest.hip)
+    const char* ing = getenv("NP1_INGEST");
+    const bool device_ingest = src.have_bai && !(ing && strcmp(ing, "host") == 0);
+    // One work item per batch: either a staging buffer (compressed blocks for the device) or a host-decoded stream.
+    struct Item { np1ingest::Staging* staging = nullptr; np1_stream* stream = nullptr; };
     const size_t depth = p->lanes.size() + loader_threads();    // loaded-but-unpolished batches allowed in memory
+    std::vector<np1ingest::Staging*> free_staging;
+    std::vector<np1ingest::Staging*> all_staging;
+    if (device_ingest)
+        for (size_t i = 0; i < depth; ++i) { all_staging.push_back(new np1ingest::Staging()); free_staging.push_back(all_staging.back()); }
+    std::vector<np1ingest::Scratch*> scratch(p->lanes.size(), nullptr);
     std::mutex mu;
     std::condition_variable cv;
-    std::map<int, np1_stream*> ready;      // loaded batches waiting for a lane
-    std::map<int, np1_stream*> done;       // polished batches waiting for their turn at the sink (stream kept for the names)
-    std::map<int, std::pair<std::vector<char>, std::vector<uint32_t>>> done_out;
+    std::map<int, Item> ready;             // loaded batches waiting for a lane
+    struct Done { std::vector<std::string> names; std::vector<char> out; std::vector<uint32_t> bounds; };
+    std::map<int, Done> done;              // polished batches waiting for their turn at the sink
     int next_load = 0, next_polish = 0, next_emit = 0, in_memory = 0;
-    bool failed = false;
+    bool failed = false, emitting = false;
     std::string err;
-    const bool with_qual = task == 2;
     auto fail = [&](const std::string& e) {
         std::lock_guard<std::mutex> g(mu);
         if (!failed) err = e;
         failed = true;
         cv.notify_all();
     };
+    auto load_host = [&](int k) -> np1_stream* {
+        std::vector<const char*> nm;
+        for (const std::string& s : plan[(size_t)k]) nm.push_back(s.c_str());
+        np1_stream* st = np1_stream_load(fasta, bam, nm.data(), (int)nm.size(), with_qual ? 1 : 0);
+        if (st) (void)np1_stream_pin(st);   // best effort: an unpinned stream still uploads, just synchronously
+        return st;
+    };
     auto loader = [&]() {
         for (;;) {
             int k;
+            np1ingest::Staging* sg = nullptr;
             {
                 std::unique_lock<std::mutex> g(mu);
-                cv.wait(g, [&] { return failed || next_load >= n || (size_t)in_memory < depth; });
+                cv.wait(g, [&] { return failed || next_load >= n || ((size_t)in_memory < depth && (!device_ingest || !free_staging.empty())); });
                 if (failed || next_load >= n) return;
                 k = next_load++;
                 ++in_memory;
+                if (device_ingest) { sg = free_staging.back(); free_staging.pop_back(); }
             }
-            std::vector<const char*> nm;
-            for (const std::string& s : plan[(size_t)k]) nm.push_back(s.c_str());
-            np1_stream* st = np1_stream_load(fasta, bam, nm.data(), (int)nm.size(), with_qual ? 1 : 0);
-            if (!st) { fail(np1_last_error()); return; }
-            (void)np1_stream_pin(st);   // best effort: an unpinned stream still uploads, just synchronously
+            Item it;
+            if (sg) {
+                std::string e;
+                const int rc = np1ingest::prepare(src, plan[(size_t)k], sg, &e);
+                if (rc < 0) { fail(e); return; }
+                if (rc == 0) it.staging = sg;
+                else { std::lock_guard<std::mutex> g(mu); free_staging.push_back(sg); }
+            }
+            if (!it.staging) {
+                it.stream = load_host(k);
+                if (!it.stream) { fail(np1_last_error()); return; }
+            }
             std::lock_guard<std::mutex> g(mu);
-            ready[k] = st;
+            ready[k] = it;
             cv.notify_all();
         }
     };
-    auto emit_ready = [&](std::unique_lock<std::mutex>& g) {   // called with mu held
+    auto emit_ready = [&](std::unique_lock<std::mutex>& g) {   // called with mu held; one thread at a time
         while (done.count(next_emit)) {
-            np1_stream* st = done[next_emit];
-            auto res = std::move(done_out[next_emit]);
+            Done d = std::move(done[next_emit]);
             done.erase(next_emit);
-            done_out.erase(next_emit);
-            const int k = next_emit++;
-            (void)k;
+            ++next_emit;
             g.unlock();
-            if (sink) {
-                np1_stream_view v;
-                np1_stream_get_view(st, &v);
-                for (int64_t c = 0; c < v.n_contigs; ++c)
-                    sink(user, np1_stream_contig_name(st, c), res.first.data() + res.second[(size_t)c],
-                         (int64_t)res.second[(size_t)c + 1] - (int64_t)res.second[(size_t)c]);
-            }
-            np1_stream_free(st);
+            if (sink)
+                for (size_t c = 0; c < d.names.size(); ++c)
+                    sink(user, d.names[c].c_str(), d.out.data() + d.bounds[c], (int64_t)d.bounds[c + 1] - (int64_t)d.bounds[c]);
             g.lock();
             --in_memory;
             cv.notify_all();
         }
     };
-    bool emitting = false;
-    auto lane_work = [&](np1_pipe::Lane& ln) {
+    auto lane_work = [&](size_t li) {
+        np1_pipe::Lane& ln = p->lanes[li];
         for (;;) {
             int k;
-            np1_stream* st;
+            Item it;
             {
                 std::unique_lock<std::mutex> g(mu);
                 cv.wait(g, [&] { return failed || next_polish >= n || ready.count(next_polish); });
                 if (failed || next_polish >= n) return;
                 k = next_polish++;
-                st = ready[k];
+                it = ready[k];
                 ready.erase(k);
             }
-            if (polish_on_lane(ln, st, cfg, task) != 0) { fail(np1_last_error()); return; }
-            np1_stream_view v;
-            np1_stream_get_view(st, &v);
+            Done d;
+            int rc = 0;
+            if (it.staging) {
+                if (!scratch[li]) scratch[li] = np1ingest::scratch_create();
+                d.names = it.staging->names();
+                rc = np1ingest::ingest(ln.batch, it.staging, with_qual, scratch[li]);
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    free_staging.push_back(it.staging);
+                    cv.notify_all();
+                }
+                if (rc == 1) {      // records the device path does not take (CIGARs in CG tags): the host loader decodes this batch
+                    it.stream = load_host(k);
+                    if (!it.stream) rc = -1;
+                }
+            }
+            if (rc >= 0 && it.stream) {
+                np1_stream_view v;
+                np1_stream_get_view(it.stream, &v);
+                d.names.clear();
+                for (int64_t c = 0; c < v.n_contigs; ++c) d.names.push_back(np1_stream_contig_name(it.stream, c));
+                rc = np1_batch_reload(ln.batch, it.stream);
+            }
+            if (rc == 0) rc = task == 2 ? np1_batch_kmer_count(ln.batch, cfg, nullptr) : np1_batch_score_chain(ln.batch, cfg, nullptr);
+            if (rc == 0) rc = np1_batch_results_fetch(ln.batch);
+            if (it.stream) np1_stream_free(it.stream);     // after the pass: its arrays were the source of asynchronous copies
+            if (rc != 0) { fail(np1_last_error()); return; }
             const uint32_t* b = np1_batch_results_bounds(ln.batch);
             const char* s = np1_batch_results_ptr(ln.batch);
-            std::pair<std::vector<char>, std::vector<uint32_t>> res;
-            res.second.assign(b, b + v.n_contigs + 1);
-            res.first.assign(s, s + b[v.n_contigs]);
-            for (uint32_t& x : res.second) (void)x;
-            // strings are not NUL-terminated inside the blob: the sink gets (pointer, length)
+            d.bounds.assign(b, b + d.names.size() + 1);
+            d.out.assign(s, s + b[d.names.size()]);     // strings are not NUL-terminated inside the blob: the sink gets (pointer, length)
             std::unique_lock<std::mutex> g(mu);
-            done[k] = st;
-            done_out[k] = std::move(res);
+            done[k] = std::move(d);
             if (!emitting) {          // one thread at a time drains the in-order queue
                 emitting = true;
                 emit_ready(g);
@@ -283,15 +327,18 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
     std::vector<std::thread> th;
     const unsigned nl = std::min<unsigned>(loader_threads(), (unsigned)std::max(1, n));
     for (unsigned i = 0; i < nl; ++i) th.emplace_back(loader);
-    for (size_t i = 1; i < p->lanes.size(); ++i) th.emplace_back(lane_work, std::ref(p->lanes[i]));
-    lane_work(p->lanes[0]);
+    for (size_t i = 1; i < p->lanes.size(); ++i) th.emplace_back(lane_work, i);
+    lane_work(0);
     for (std::thread& t : th) t.join();
     {   // whatever finished out of turn while another thread was emitting
         std::unique_lock<std::mutex> g(mu);
         if (!failed) emit_ready(g);
-        for (auto& kv : ready) np1_stream_free(kv.second);
-        for (auto& kv : done) np1_stream_free(kv.second);
+        for (auto& kv : ready) if (kv.second.stream) np1_stream_free(kv.second.stream);
     }
+    uint64_t host_blocks = 0;
+    for (np1ingest::Scratch* s : scratch) { host_blocks += np1ingest::scratch_host_blocks(s); np1ingest::scratch_destroy(s); }
+    for (np1ingest::Staging* s : all_staging) delete s;
+    p->host_inflated_blocks = host_blocks;
     if (failed) { np1_set_error(err); return -1; }
     return 0;
 }

@@ -125,3 +125,88 @@ def test_device_inflate_rejects_damaged_streams_without_writing_past_the_block()
         else:
             n_flagged += 1
     assert n_flagged >= 20
+
+
+# ------------------------------------------------------------------------------------------------- record stream from raw BAM bytes
+
+
+def _run_files(pipe, fa, bam, env_ingest, **kw):
+    old = os.environ.get("NP1_INGEST")
+    if env_ingest:
+        os.environ["NP1_INGEST"] = env_ingest
+    else:
+        os.environ.pop("NP1_INGEST", None)
+    try:
+        return pipe.run_files(fa, bam, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("NP1_INGEST", None)
+        else:
+            os.environ["NP1_INGEST"] = old
+
+
+def test_device_ingest_equals_host_loader_and_oracle(tmp_path):
+    """Same files through the device ingest (inflate + record chase + SoA on the GPU) and through the host loader: identical
+    polished strings for score_chain and for kmer_count (which also consumes mapq / isize / qualities), in whole-file order, for
+    a subset in another order, with a contig no read maps to, with batches of one contig and of several."""
+    from nextpolish_amd.device import Pipe
+    st = nat.Stream.synth([40000, 9000, 30000, 45000, 2000, 70000], depth=35, seed=78, with_qual=1, draft_lower=0.01, softclip_rate=0.05)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "g.bam")
+    st.write_files(fa, bam)
+    pipe = Pipe(0, lanes=2)
+    cfg = nat.default_config()
+    cfg.read_tlen = 1500
+    want1 = [ob.score_chain(st, i) for i in range(st.n_contigs)]
+    want2 = [ob.kmer_count(st, i, ob.default_config(read_tlen=1500)) for i in range(st.n_contigs)]
+    for batch_bp in (50000, 1000, 10000000):
+        dev = _run_files(pipe, fa, bam, None, batch_bp=batch_bp)
+        assert [n for n, _ in dev] == st.names and [s for _, s in dev] == want1, "device ingest, batch_bp %d" % batch_bp
+    host = _run_files(pipe, fa, bam, "host", batch_bp=50000)
+    assert [s for _, s in host] == want1
+    dev2 = _run_files(pipe, fa, bam, None, batch_bp=60000, cfg=cfg, task=2)
+    assert [s for _, s in dev2] == want2
+    sub = [st.names[4], st.names[1], st.names[5]]
+    dev3 = _run_files(pipe, fa, bam, None, names=sub, batch_bp=60000, cfg=cfg, task=2)
+    assert [n for n, _ in dev3] == sub and [s for _, s in dev3] == [want2[4], want2[1], want2[5]]
+    pipe.close()
+
+
+def test_device_ingest_on_real_bwa_bam_and_edge_records(tmp_path):
+    """samtools-written BGZF + bwa records with aux fields through the device ingest; then hand-made records at the contig
+    start whose CIGAR consumes no reference base (the iterator of the reference's htslib drops them: end = pos + 0)."""
+    import json
+    from nextpolish_amd.device import Pipe
+    gold = json.load(open(os.path.join(REAL, "real_golden.json")))["sr"]
+    pipe = Pipe(0, lanes=2)
+    import hashlib
+    for tag in ("sgs.s30", "r1.slice"):
+        g = gold[tag]
+        out = _run_files(pipe, os.path.join(REAL, g["fasta"]), os.path.join(REAL, g["bam"]), None, batch_bp=55000)
+        assert {n: {"len": len(s), "md5": hashlib.md5(s.encode()).hexdigest()} for n, s in out} == g["score_chain"], tag
+    g = gold["r1.slice"]
+    cfg = nat.default_config()
+    cfg.read_tlen, cfg.read_len = g["read_tlen"], g["read_len"]
+    out = _run_files(pipe, os.path.join(REAL, g["fasta"]), os.path.join(REAL, g["bam"]), None, cfg=cfg, task=2)
+    assert {n: {"len": len(s), "md5": hashlib.md5(s.encode()).hexdigest()} for n, s in out} == g["kmer_count"]
+    # edge records
+    rng = random.Random(3)
+    draft = "".join(rng.choice("ACGT") for _ in range(3000))
+    reads = [dict(ctg=0, pos=0, flag=0, cigar=[("S", 20), ("I", 30)], seq=draft[:50]),            # rlen 0 at pos 0: not returned by the iterator
+             dict(ctg=0, pos=0, flag=0, cigar=[("S", 5), ("M", 95)], seq="TTTTT" + draft[:95]),
+             dict(ctg=0, pos=0, flag=4, cigar=[], seq=draft[:40])]                                 # unmapped but placed: end = pos + 1
+    for p in range(0, 2800, 37):
+        reads.append(dict(ctg=0, pos=p, flag=0, cigar=[("M", 150)], seq=draft[p:p + 150]))
+    reads.sort(key=lambda r: r["pos"])
+    st = nat.Stream.from_reads([("e0", draft), ("e1", draft[::-1])], reads)
+    fa, bam = str(tmp_path / "e.fa"), str(tmp_path / "e.bam")
+    st.write_files(fa, bam)
+    loaded = nat.Stream.load(fa, bam)
+    want = [ob.score_chain(loaded, i) for i in range(loaded.n_contigs)]
+    assert loaded.n_reads == len(reads) - 1          # the zero-length alignment at position 0 is gone (htslib 1.9 bam_endpos)
+    dev = _run_files(pipe, fa, bam, None)
+    assert [s for _, s in dev] == want
+    from conftest import ref_binary, run_ref
+    if ref_binary():
+        ref = run_ref("scorechain", fa, bam)
+        assert [ref[n] for n in loaded.names] == want
+    pipe.close()
