@@ -52,7 +52,9 @@ int main(int argc, char* argv[]) {
         if (const char* e = getenv("NP1_DEVICE")) dev = atoi(e);
         if (const char* e = getenv("NP1_LANES")) lanes = atoi(e);
         if (const char* e = getenv("NP1_BATCH_BP")) batch_bp = atoll(e);
+        timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
         np1_pipe* pipe = np1_pipe_open(dev, lanes);
+        if (getenv("NP1_TIMING")) { timespec ts1; clock_gettime(CLOCK_MONOTONIC, &ts1); fprintf(stderr, "[np1 cli] device lanes open after %.1f ms\n", (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6); }
         if (!pipe) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
         struct Out { int step; } out{step};
         auto sink = [](void* user, const char* name, const char* seq, int64_t len) {

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -383,8 +384,13 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
 }
 
 // Device half: fills the batch object.  Returns 0, 1 (take the host loader for this batch: CG-tag CIGARs) or -1.
+static double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
 int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
     Staging::Impl& S = *st->impl;
+    static const bool timing = getenv("NP1_TIMING") != nullptr;
+    const double t_0 = timing ? now_ms() : 0;
+    double t_1 = 0, t_2 = 0;
     np1_ctx* ctx = b->ctx;
     (void)hipSetDevice(ctx->device);
     hipStream_t q = ctx->stream;
@@ -428,6 +434,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
         HIPCHK(hipMemsetAsync(W.rec_base.p, 0, 16, q));
     }
     HIPCHK(hipStreamSynchronize(q));
+    if (timing) t_1 = now_ms();
     // blocks the device decoder did not accept: inflate them on the host and patch them in, then redo the count
     bool patched = false;
     for (uint32_t i = 0; i < n_blocks; ++i) {
@@ -471,6 +478,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
     }
     HIPCHK(hipMemcpyAsync(h_small, d_err, 8, hipMemcpyDeviceToHost, q));
     HIPCHK(hipStreamSynchronize(q));
+    if (timing) t_2 = now_ms();
     if (h_small[0] & IG_ERR_CGTAG) return 1;
     if (h_small[0] & (IG_ERR_CHAIN | IG_ERR_RECORD)) { np1_set_error("BAM records do not line up with the index (corrupt BAM or stale .bai)"); return -1; }
     const size_t n = (size_t)totals[0];
@@ -495,6 +503,9 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
     HIPCHK(hipMemcpyAsync(b->h_read_begin.data(), b->read_begin.p, 8 * (size_t)(nc + 1), hipMemcpyDeviceToHost, q));
     HIPCHK(hipStreamSynchronize(q));
     b->input_bytes = b->G + 32 * n + 4 * (size_t)totals[1] + (size_t)totals[2];
+    if (timing)
+        fprintf(stderr, "[np1 ingest] %.1f MB compressed, %.1f MB inflated, %u blocks, %u segments, %llu records (%zu kept) | ms: h2d+inflate+count %.2f  offsets+measure+scans %.2f  scatter %.2f\n",
+                S.comp_bytes / 1e6, S.inflated_bytes / 1e6, n_blocks, n_segs, (unsigned long long)n_rec, n, t_1 - t_0, t_2 - t_1, now_ms() - t_2);
     return 0;
 }
 

@@ -9,7 +9,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -41,6 +43,9 @@ int polish_on_lane(np1_pipe::Lane& ln, np1_stream* st, const Configure* cfg, int
     if (rc != 0) return -1;
     return np1_batch_results_fetch(ln.batch);
 }
+
+double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+bool timing_on() { static const bool t = getenv("NP1_TIMING") != nullptr; return t; }
 
 unsigned loader_threads() {
     const char* e = getenv("NP1_LOADERS");
@@ -240,6 +245,7 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
                 if (device_ingest) { sg = free_staging.back(); free_staging.pop_back(); }
             }
             Item it;
+            const double t_l0 = now_ms();
             if (sg) {
                 std::string e;
                 const int rc = np1ingest::prepare(src, plan[(size_t)k], sg, &e);
@@ -251,6 +257,7 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
                 it.stream = load_host(k);
                 if (!it.stream) { fail(np1_last_error()); return; }
             }
+            if (timing_on()) fprintf(stderr, "[np1 pipe] batch %d staged on the host in %.1f ms (%s)\n", k, now_ms() - t_l0, it.staging ? "compressed blocks" : "host loader");
             std::lock_guard<std::mutex> g(mu);
             ready[k] = it;
             cv.notify_all();
@@ -285,6 +292,8 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
             }
             Done d;
             int rc = 0;
+            const double t_p0 = now_ms();
+            double t_p1 = t_p0, t_p2 = t_p0;
             if (it.staging) {
                 if (!scratch[li]) scratch[li] = np1ingest::scratch_create();
                 d.names = it.staging->names();
@@ -306,8 +315,11 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
                 for (int64_t c = 0; c < v.n_contigs; ++c) d.names.push_back(np1_stream_contig_name(it.stream, c));
                 rc = np1_batch_reload(ln.batch, it.stream);
             }
+            t_p1 = now_ms();
             if (rc == 0) rc = task == 2 ? np1_batch_kmer_count(ln.batch, cfg, nullptr) : np1_batch_score_chain(ln.batch, cfg, nullptr);
+            t_p2 = now_ms();
             if (rc == 0) rc = np1_batch_results_fetch(ln.batch);
+            if (timing_on()) fprintf(stderr, "[np1 pipe] batch %d lane %zu: ingest %.1f ms, kernels %.1f ms, fetch %.1f ms\n", k, li, t_p1 - t_p0, t_p2 - t_p1, now_ms() - t_p2);
             if (it.stream) np1_stream_free(it.stream);     // after the pass: its arrays were the source of asynchronous copies
             if (rc != 0) { fail(np1_last_error()); return; }
             const uint32_t* b = np1_batch_results_bounds(ln.batch);
