@@ -47,7 +47,7 @@ __device__ __forceinline__ uint16_t ld16(const uint8_t* p) {
     return *reinterpret_cast<const u16u*>(p);
 }
 
-__global__ __launch_bounds__(256) void k_inflate(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+__global__ __launch_bounds__(256, 6) void k_inflate(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
                                                  uint8_t* out, uint32_t* __restrict__ status) {
     __shared__ npdev::InflateLds lds[4];
     const uint32_t wave = threadIdx.x >> 6;
@@ -57,6 +57,24 @@ __global__ __launch_bounds__(256) void k_inflate(const uint8_t* __restrict__ com
     int rc = 0;
     if (d.out_len) rc = npdev::inflate_block_wave(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, lds[wave]);
     if ((threadIdx.x & 63u) == 0) status[b] = (uint32_t)rc;
+}
+
+// the same with phase clocks (diagnostics only)
+__global__ __launch_bounds__(256, 6) void k_inflate_prof(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+                                                      uint8_t* out, uint32_t* __restrict__ status, unsigned long long* __restrict__ prof) {
+    __shared__ npdev::InflateLds lds[4];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * 4 + wave;
+    if (b >= n_blocks) return;
+    const npdev::BlockDesc d = blocks[b];
+    npdev::Prof pf;
+    int rc = 0;
+    if (d.out_len) rc = npdev::inflate_block_wave(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, lds[wave], &pf);
+    if ((threadIdx.x & 63u) == 0) {
+        status[b] = (uint32_t)rc;
+        const unsigned long long v[8] = {pf.t_tables, pf.t_decode, pf.t_flush, pf.tokens, pf.groups, pf.rounds, pf.matches, pf.match_bytes};
+        for (int i = 0; i < 8; ++i) atomicAdd(&prof[i], v[i]);
+    }
 }
 
 // one lane per segment [beg, end) of the inflated stream that starts on a record boundary
@@ -525,7 +543,13 @@ BamSource::~BamSource() { if (fd >= 0) ::close(fd); }
 
 // test / diagnostics hook: inflates a buffer of concatenated BGZF blocks on the device; out receives the inflated bytes,
 // status one word per block (0 = accepted).  Returns the number of blocks or -1.
+extern "C" int64_t np1_debug_inflate_device_prof(int device, const uint8_t* bgzf, uint64_t n, uint8_t* out, uint64_t out_cap, uint32_t* status, int64_t status_cap,
+                                                 unsigned long long* prof /* 8 words or NULL */, float* kernel_ms);
 extern "C" int64_t np1_debug_inflate_device(int device, const uint8_t* bgzf, uint64_t n, uint8_t* out, uint64_t out_cap, uint32_t* status, int64_t status_cap) {
+    return np1_debug_inflate_device_prof(device, bgzf, n, out, out_cap, status, status_cap, nullptr, nullptr);
+}
+extern "C" int64_t np1_debug_inflate_device_prof(int device, const uint8_t* bgzf, uint64_t n, uint8_t* out, uint64_t out_cap, uint32_t* status, int64_t status_cap,
+                                                 unsigned long long* prof, float* kernel_ms) {
     if (hipSetDevice(device) != hipSuccess) { np1_set_error("hipSetDevice failed"); return -1; }
     std::vector<npdev::BlockDesc> blocks;
     uint64_t p = 0, u = 0;
@@ -554,8 +578,22 @@ extern "C" int64_t np1_debug_inflate_device(int device, const uint8_t* bgzf, uin
     HIPCHK(hipMemcpy(dc.p, bgzf, n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(db.p, blocks.data(), sizeof(npdev::BlockDesc) * blocks.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(du.p, 0xEE, u + 64));
-    if (!blocks.empty()) k_inflate<<<nblk(blocks.size(), 4), 256>>>(dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>());
+    DevBuf dp;
+    if (dp.ensure(64)) return -1;
+    HIPCHK(hipMemset(dp.p, 0, 64));
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
+    if (!blocks.empty()) {
+        if (prof) k_inflate_prof<<<nblk(blocks.size(), 4), 256>>>(dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>(), dp.as<unsigned long long>());
+        else k_inflate<<<nblk(blocks.size(), 4), 256>>>(dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>());
+    }
+    (void)hipEventRecord(e1, nullptr);
     HIPCHK(hipDeviceSynchronize());
+    if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (prof) HIPCHK(hipMemcpy(prof, dp.p, 64, hipMemcpyDeviceToHost));
+    dp.release();
     if (u) HIPCHK(hipMemcpy(out, du.p, u, hipMemcpyDeviceToHost));
     if (!blocks.empty()) HIPCHK(hipMemcpy(status, ds.p, 4 * blocks.size(), hipMemcpyDeviceToHost));
     dc.release(); du.release(); db.release(); ds.release();

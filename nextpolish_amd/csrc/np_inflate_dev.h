@@ -26,6 +26,7 @@
 namespace npdev {
 
 constexpr int LIT_BITS = 10, DIST_BITS = 8;
+constexpr uint32_t GROUP_BYTES = 2048;   // a token group is closed when 64 tokens are collected or its output could exceed this
 constexpr uint32_t K_LITERAL = 0, K_LENGTH = 1, K_END = 2, K_LONG = 3;   // K_LONG: code longer than the primary index (or no code)
 
 // LDS of one wave
@@ -38,6 +39,7 @@ struct InflateLds {
     uint16_t dist_first[16], dist_count[16], dist_offs[16];
     uint8_t cl_len[320];             // code lengths while a dynamic header is read
     uint32_t cl_tab[128];            // code-length alphabet, 7-bit direct table
+    uint32_t gbuf[(GROUP_BYTES + 8) / 4];   // output of the token group being resolved (same dword phase as its place in HBM)
 };
 
 struct BlockDesc {          // one BGZF block (host-built table)
@@ -103,9 +105,13 @@ struct BitReader {
 // ---- canonical Huffman tables from code lengths held in registers.
 // lens[k] on lane l = code length of symbol 64 k + l (0 beyond n_sym).  Fills the primary table and the canonical arrays.
 // Returns false (uniformly) for an over-subscribed code.
+template <int NREG> struct Lens { uint32_t v[NREG]; };
 template <int NREG, int TBITS, bool IS_DIST>
-__device__ bool build_tables(const uint32_t (&lens)[NREG], uint32_t* table, uint16_t* sorted, uint16_t* first, uint16_t* count, uint16_t* offs) {
+__device__ __noinline__ bool build_tables(const Lens<NREG> lens_in, uint32_t* table, uint16_t* sorted, uint16_t* first, uint16_t* count, uint16_t* offs) {
     const uint32_t lane = lane_id();
+    uint32_t lens[NREG];
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) lens[k] = lens_in.v[k];
     uint32_t cnt[16];
 #pragma unroll
     for (int L = 0; L < 16; ++L) cnt[L] = 0;
@@ -190,20 +196,30 @@ __device__ __forceinline__ uint32_t decode_long(uint32_t bits15, const uint16_t*
     const uint32_t msb = __builtin_bitreverse32(bits15) >> 17;   // 15 bits, first stream bit on top
     for (uint32_t L = TBITS + 1; L <= 15; ++L) {
         const uint32_t c = msb >> (15u - L);
-        const uint32_t d = c - (uint32_t)first[L];
-        if (c >= (uint32_t)first[L] && d < (uint32_t)count[L]) {
+        const uint32_t f = uni((uint32_t)first[L]), n = uni((uint32_t)count[L]);
+        const uint32_t d = c - f;
+        if (c >= f && d < n) {
             *len_out = L;
-            return (uint32_t)sorted[(uint32_t)offs[L] + d];
+            return uni((uint32_t)sorted[uni((uint32_t)offs[L]) + d]);
         }
     }
     *len_out = 0;
     return 0;
 }
 
+// Optional phase clocks (diagnostics: np1_debug_inflate_device with prof != NULL): cycles and counts per block, wave-uniform.
+struct Prof { unsigned long long t_tables = 0, t_decode = 0, t_flush = 0, tokens = 0, groups = 0, rounds = 0, matches = 0, match_bytes = 0; };
+__device__ __forceinline__ unsigned long long clk() { return __builtin_readcyclecounter(); }
+
 // Token group: lane j of `tok` holds token j.  literal: byte in 0..7; match: bit 31, length in 16..24, distance - 1 in 0..14.
-// Resolves ntok tokens at output position op; returns the new position or ~0u on a bad distance / overflow.
-__device__ __forceinline__ uint32_t flush_tokens(uint8_t* out, uint32_t op, uint32_t out_len, uint32_t tok, uint32_t ntok) {
+// Resolves ntok tokens (at most GROUP_BYTES of output) at output position op; returns the new position or ~0u on a bad
+// distance / overflow.  The group's bytes are assembled in LDS: literals and the parts of matches that come from before the
+// group (HBM, written by earlier groups) go in at once; matches that copy from inside the group wait for the lanes before
+// them (rounds over a frontier, LDS latency, no fence); then the wave writes the group out with coalesced dword stores.
+__device__ __noinline__ uint32_t flush_tokens(uint8_t* out, uint32_t op, uint32_t out_len, uint32_t tok, uint32_t ntok, uint32_t* gbuf32, Prof* pf = nullptr) {
     const uint32_t lane = lane_id();
+    const unsigned long long t_in = pf ? clk() : 0;
+    uint8_t* gbuf = reinterpret_cast<uint8_t*>(gbuf32);
     const bool act = lane < ntok;
     const bool is_match = act && (tok >> 31);
     const uint32_t len = is_match ? ((tok >> 16) & 0x1ffu) : (act ? 1u : 0u);
@@ -216,51 +232,95 @@ __device__ __forceinline__ uint32_t flush_tokens(uint8_t* out, uint32_t op, uint
         if (lane >= (uint32_t)d) inc += v;
     }
     const uint32_t total = rdlane(inc, 63);
-    const uint32_t start = op + inc - len;
-    if (op + total > out_len) return ~0u;
+    const uint32_t start = op + inc - len;           // position in the block's output
+    if (op + total > out_len || total > GROUP_BYTES) return ~0u;
     const uint64_t mm = __ballot(is_match);
     if (__ballot(is_match && dist > start)) return ~0u;
-    if (act && !is_match) out[start] = (uint8_t)tok;
+    const uint32_t gbase = op & 3u;                  // the group sits in gbuf at the dword phase it has in HBM
+    const uint32_t rel = gbase + (start - op);
+    if (act && !is_match) gbuf[rel] = (uint8_t)tok;
     if (mm) {
-        uint64_t undone = mm;
-        const uint32_t src = start - dist;
-        const uint32_t src_end = src + (len < dist ? len : dist);
+        const uint32_t src = start - dist;           // first source byte (output position)
+        // bytes that come from before the group: straight from HBM (the stores of earlier groups must have landed)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        uint32_t n_glob = 0;
+        if (is_match && src < op) {
+            const uint32_t span = len < dist ? len : dist;          // distinct source bytes
+            n_glob = op - src < span ? op - src : span;
+#pragma clang loop unroll_count(4)
+            for (uint32_t i = 0; i < n_glob; ++i) gbuf[rel + i] = out[src + i];
+        }
+        // the rest copies from inside the group (or repeats the pattern just placed): wait for the lanes before
+        uint64_t undone = __ballot(is_match && n_glob < len);
+        const uint32_t need = (src + len < start ? src + len : start);   // everything below `need` has to be final
         while (undone) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // everything stored so far is visible to the wave
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             const uint32_t k = (uint32_t)__ffsll((long long)undone) - 1u;
-            const uint32_t W = rdlane(start, k);                        // all bytes below W are final
-            const bool ready = ((undone >> lane) & 1ull) && src_end <= W;
+            const uint32_t W = rdlane(start, k);                         // all bytes below W are final
+            const bool ready = ((undone >> lane) & 1ull) && need <= W;
             if (ready) {
+                // byte i comes from source byte i % dist; source bytes below op are already in place (copied above)
                 if (dist >= len) {
-                    for (uint32_t i = 0; i < len; ++i) out[start + i] = out[src + i];
-                } else {   // self-overlapping match: the pattern of `dist` bytes repeats; read only below `start`
-                    uint32_t r = 0;
-                    for (uint32_t i = 0; i < len; ++i) {
-                        out[start + i] = out[src + r];
-                        if (++r == dist) r = 0;
-                    }
+                    const uint32_t s0 = gbase + (src + n_glob - op);      // src + n_glob >= op here
+#pragma clang loop unroll(disable)
+                    for (uint32_t i = n_glob; i < len; ++i) gbuf[rel + i] = gbuf[s0 + (i - n_glob)];
+                } else {
+                    // self-overlapping: the first `dist` bytes are the pattern (from HBM up to n_glob, else from the group), then it repeats
+#pragma clang loop unroll(disable)
+                    for (uint32_t i = n_glob; i < dist; ++i) gbuf[rel + i] = gbuf[gbase + (src + i - op)];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma clang loop unroll(disable)
+                    for (uint32_t i = dist; i < len; ++i) gbuf[rel + i] = gbuf[rel + i - dist];
                 }
             }
             undone &= ~__ballot(ready);
+            if (pf) ++pf->rounds;
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // write-out: dword w of gbuf <-> dword at out + (op - gbase) + 4 w
+    {
+        uint8_t* obase = out + (op - gbase);          // 4-byte aligned relative to `out`'s own alignment phase only if out is aligned; handled below
+        const uint32_t end = gbase + total;           // bytes [gbase, end) of gbuf are the group
+        const bool out_aligned = ((uintptr_t)out & 3u) == 0;
+#pragma clang loop unroll(disable)
+        for (uint32_t w = lane; 4u * w < end; w += 64) {
+            const uint32_t b0 = 4u * w;
+            if (out_aligned && b0 >= gbase && b0 + 4u <= end) {
+                *reinterpret_cast<uint32_t*>(obase + b0) = gbuf32[w];
+            } else {
+                for (uint32_t j = 0; j < 4; ++j)
+                    if (b0 + j >= gbase && b0 + j < end) obase[b0 + j] = gbuf[b0 + j];
+            }
+        }
+    }
+    if (pf) {
+        pf->t_flush += clk() - t_in;
+        pf->tokens += ntok;
+        ++pf->groups;
+        pf->matches += (unsigned long long)__popcll(mm);
+        pf->match_bytes += total - (ntok - (uint32_t)__popcll(mm));
     }
     return op + total;
 }
 
 // Inflates one block; all 64 lanes call it with the same arguments.  Returns 0 on success.
-__device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateLds& L) {
+__device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateLds& L, Prof* pf = nullptr) {
     const uint32_t lane = lane_id();
     BitReader br;
     br.init(in);
     uint32_t op = 0;
-    uint32_t tok = 0, ntok = 0;
+    uint32_t tok = 0, ntok = 0, gbytes = 0;
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
     for (;;) {
         br.refill();
+        const unsigned long long t_hdr = pf ? clk() : 0;
         const uint32_t final_block = br.take(1), type = br.take(2);
         if (type == 0) {
             // stored: pending tokens first, then a wave copy
-            if (ntok) { op = flush_tokens(out, op, out_len, tok, ntok); ntok = 0; if (op == ~0u) return 1; }
+            if (ntok) { op = flush_tokens(out, op, out_len, tok, ntok, L.gbuf, pf); ntok = 0; gbytes = 0; if (op == ~0u) return 1; }
             br.drop(br.nb & 7u);
             br.refill();
             const uint32_t len = br.take(16);
@@ -283,7 +343,7 @@ __device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* o
             continue;
         }
         if (type == 3) return 4;
-        uint32_t ll[5], dl[1];
+        Lens<5> llv; Lens<1> dlv; uint32_t (&ll)[5] = llv.v; uint32_t (&dl)[1] = dlv.v;
         uint32_t hlit = 288, hdist = 30;
         if (type == 1) {
 #pragma unroll
@@ -343,7 +403,7 @@ __device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* o
             const uint32_t want = hlit + hdist;
             while (n < want) {
                 br.refill();
-                const uint32_t e = L.cl_tab[br.peek(7)];
+                const uint32_t e = uni(L.cl_tab[br.peek(7)]);
                 if (e == 0xffu) return 7;
                 br.drop(e & 15u);
                 const uint32_t sym = e >> 4;
@@ -368,12 +428,15 @@ __device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* o
             dl[0] = lane < hdist ? (uint32_t)L.cl_len[hlit + lane] : 0u;
             if (rdlane(ll[4], 0) == 0) return 10;   // no end-of-block code
         }
-        if (!build_tables<5, LIT_BITS, false>(ll, L.lit, L.lit_sorted, L.lit_first, L.lit_count, L.lit_offs)) return 11;
-        if (!build_tables<1, DIST_BITS, true>(dl, L.dist, L.dist_sorted, L.dist_first, L.dist_count, L.dist_offs)) return 12;
+        if (!build_tables<5, LIT_BITS, false>(llv, L.lit, L.lit_sorted, L.lit_first, L.lit_count, L.lit_offs)) return 11;
+        if (!build_tables<1, DIST_BITS, true>(dlv, L.dist, L.dist_sorted, L.dist_first, L.dist_count, L.dist_offs)) return 12;
+        const unsigned long long t_sym = pf ? clk() : 0;
+        if (pf) pf->t_tables += t_sym - t_hdr;
+        const unsigned long long fl0 = pf ? pf->t_flush : 0;
         // ---- symbols
         for (;;) {
             br.refill();
-            uint32_t e = L.lit[br.peek(LIT_BITS)];
+            uint32_t e = uni(L.lit[br.peek(LIT_BITS)]);
             uint32_t kind = (e >> 8) & 3u;
             if (kind == K_LONG) {
                 uint32_t len;
@@ -387,12 +450,13 @@ __device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* o
             if (kind == K_LITERAL) {
                 if (lane == ntok) tok = e >> 16;
                 ++ntok;
+                ++gbytes;
             } else if (kind == K_END) {
                 break;
             } else {
                 const uint32_t mlen = (e >> 16) + br.take((e >> 4) & 15u);
                 br.refill();
-                uint32_t d = L.dist[br.peek(DIST_BITS)];
+                uint32_t d = uni(L.dist[br.peek(DIST_BITS)]);
                 if (((d >> 8) & 3u) == K_LONG) {
                     uint32_t len;
                     const uint32_t sym = decode_long<DIST_BITS>(br.peek(15), L.dist_sorted, L.dist_first, L.dist_count, L.dist_offs, &len);
@@ -405,17 +469,20 @@ __device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* o
                 const uint32_t off = (d >> 16) + br.take(xb);
                 if (lane == ntok) tok = 0x80000000u | mlen << 16 | (off - 1u);
                 ++ntok;
+                gbytes += mlen;
             }
-            if (ntok == 64) {
-                op = flush_tokens(out, op, out_len, tok, 64);
+            if (ntok == 64 || gbytes + 258u > GROUP_BYTES) {
+                op = flush_tokens(out, op, out_len, tok, ntok, L.gbuf, pf);
                 ntok = 0;
+                gbytes = 0;
                 if (op == ~0u) return 15;
             }
             if (br.consumed > (uint64_t)in_len * 8u + 64u) return 16;   // ran off the payload
         }
+        if (pf) pf->t_decode += (clk() - t_sym) - (pf->t_flush - fl0);
         if (final_block) break;
     }
-    if (ntok) { op = flush_tokens(out, op, out_len, tok, ntok); if (op == ~0u) return 17; }
+    if (ntok) { op = flush_tokens(out, op, out_len, tok, ntok, L.gbuf, pf); if (op == ~0u) return 17; }
     if (br.consumed > (uint64_t)in_len * 8u) return 18;
     return op == out_len ? 0 : 19;
 }
