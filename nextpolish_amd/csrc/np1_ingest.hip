@@ -50,7 +50,7 @@ __device__ __forceinline__ uint16_t ld16(const uint8_t* p) {
 __global__ __launch_bounds__(256, 6) void k_inflate(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
                                                  uint8_t* out, uint32_t* __restrict__ status) {
     __shared__ npdev::InflateLds lds[4];
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = npdev::uni(threadIdx.x >> 6);     // wave-uniform by construction: tell the compiler (scalar loads, scalar decode state)
     const uint32_t b = blockIdx.x * 4 + wave;
     if (b >= n_blocks) return;
     const npdev::BlockDesc d = blocks[b];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 6) void k_inflate(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(256, 6) void k_inflate_prof(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
                                                       uint8_t* out, uint32_t* __restrict__ status, unsigned long long* __restrict__ prof) {
     __shared__ npdev::InflateLds lds[4];
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = npdev::uni(threadIdx.x >> 6);
     const uint32_t b = blockIdx.x * 4 + wave;
     if (b >= n_blocks) return;
     const npdev::BlockDesc d = blocks[b];

@@ -107,7 +107,7 @@ struct BitReader {
 // Returns false (uniformly) for an over-subscribed code.
 template <int NREG> struct Lens { uint32_t v[NREG]; };
 template <int NREG, int TBITS, bool IS_DIST>
-__device__ __noinline__ bool build_tables(const Lens<NREG> lens_in, uint32_t* table, uint16_t* sorted, uint16_t* first, uint16_t* count, uint16_t* offs) {
+__device__ __forceinline__ bool build_tables(const Lens<NREG> lens_in, uint32_t* table, uint16_t* sorted, uint16_t* first, uint16_t* count, uint16_t* offs) {
     const uint32_t lane = lane_id();
     uint32_t lens[NREG];
 #pragma unroll
@@ -216,10 +216,18 @@ __device__ __forceinline__ unsigned long long clk() { return __builtin_readcycle
 // distance / overflow.  The group's bytes are assembled in LDS: literals and the parts of matches that come from before the
 // group (HBM, written by earlier groups) go in at once; matches that copy from inside the group wait for the lanes before
 // them (rounds over a frontier, LDS latency, no fence); then the wave writes the group out with coalesced dword stores.
-__device__ __noinline__ uint32_t flush_tokens(uint8_t* out, uint32_t op, uint32_t out_len, uint32_t tok, uint32_t ntok, uint32_t* gbuf32, Prof* pf = nullptr) {
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)uni((uint32_t)v) | (uint64_t)uni((uint32_t)(v >> 32)) << 32; }
+
+__device__ __noinline__ uint32_t flush_tokens(uint8_t* out_, uint32_t op_, uint32_t out_len_, uint32_t tok, uint32_t ntok_, lds_u32* gbuf32_, Prof* pf = nullptr) {
+    // a real call: the arguments arrive in vector registers; everything but `tok` is wave-uniform -> back to scalars
+    uint8_t* out = reinterpret_cast<uint8_t*>(uni64((uint64_t)(uintptr_t)out_));
+    const uint32_t op = uni(op_), out_len = uni(out_len_), ntok = uni(ntok_);
+    lds_u32* gbuf32 = (lds_u32*)(uintptr_t)uni((uint32_t)(uintptr_t)gbuf32_);
     const uint32_t lane = lane_id();
     const unsigned long long t_in = pf ? clk() : 0;
-    uint8_t* gbuf = reinterpret_cast<uint8_t*>(gbuf32);
+    lds_u8* gbuf = (lds_u8*)gbuf32;
     const bool act = lane < ntok;
     const bool is_match = act && (tok >> 31);
     const uint32_t len = is_match ? ((tok >> 16) & 0x1ffu) : (act ? 1u : 0u);
@@ -307,7 +315,7 @@ __device__ __noinline__ uint32_t flush_tokens(uint8_t* out, uint32_t op, uint32_
 }
 
 // Inflates one block; all 64 lanes call it with the same arguments.  Returns 0 on success.
-__device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateLds& L, Prof* pf = nullptr) {
+__device__ __forceinline__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateLds& L, Prof* pf = nullptr) {
     const uint32_t lane = lane_id();
     BitReader br;
     br.init(in);
@@ -320,7 +328,7 @@ __device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* o
         const uint32_t final_block = br.take(1), type = br.take(2);
         if (type == 0) {
             // stored: pending tokens first, then a wave copy
-            if (ntok) { op = flush_tokens(out, op, out_len, tok, ntok, L.gbuf, pf); ntok = 0; gbytes = 0; if (op == ~0u) return 1; }
+            if (ntok) { op = uni(flush_tokens(out, op, out_len, tok, ntok, (lds_u32*)L.gbuf, pf)); ntok = 0; gbytes = 0; if (op == ~0u) return 1; }
             br.drop(br.nb & 7u);
             br.refill();
             const uint32_t len = br.take(16);
@@ -472,7 +480,7 @@ __device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* o
                 gbytes += mlen;
             }
             if (ntok == 64 || gbytes + 258u > GROUP_BYTES) {
-                op = flush_tokens(out, op, out_len, tok, ntok, L.gbuf, pf);
+                op = uni(flush_tokens(out, op, out_len, tok, ntok, (lds_u32*)L.gbuf, pf));
                 ntok = 0;
                 gbytes = 0;
                 if (op == ~0u) return 15;
@@ -482,7 +490,7 @@ __device__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* o
         if (pf) pf->t_decode += (clk() - t_sym) - (pf->t_flush - fl0);
         if (final_block) break;
     }
-    if (ntok) { op = flush_tokens(out, op, out_len, tok, ntok, L.gbuf, pf); if (op == ~0u) return 17; }
+    if (ntok) { op = uni(flush_tokens(out, op, out_len, tok, ntok, (lds_u32*)L.gbuf, pf)); if (op == ~0u) return 17; }
     if (br.consumed > (uint64_t)in_len * 8u) return 18;
     return op == out_len ? 0 : 19;
 }
