@@ -16,6 +16,7 @@ struct BamSource {
     np::BaiIndex bai;
     bool have_bai = false;
     int fd = -1;
+    uint64_t file_size = 0;
     bool open(const std::string& fasta, const std::string& bam, std::string* err);
     ~BamSource();
 };

@@ -47,7 +47,7 @@ __device__ __forceinline__ uint16_t ld16(const uint8_t* p) {
     return *reinterpret_cast<const u16u*>(p);
 }
 
-__global__ __launch_bounds__(256, 6) void k_inflate(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+__global__ __launch_bounds__(256, 4) void k_inflate(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
                                                  uint8_t* out, uint32_t* __restrict__ status) {
     __shared__ npdev::InflateLds lds[4];
     const uint32_t wave = npdev::uni(threadIdx.x >> 6);     // wave-uniform by construction: tell the compiler (scalar loads, scalar decode state)
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 6) void k_inflate(const uint8_t* __restrict__ 
 }
 
 // the same with phase clocks (diagnostics only)
-__global__ __launch_bounds__(256, 6) void k_inflate_prof(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+__global__ __launch_bounds__(256, 4) void k_inflate_prof(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
                                                       uint8_t* out, uint32_t* __restrict__ status, unsigned long long* __restrict__ prof) {
     __shared__ npdev::InflateLds lds[4];
     const uint32_t wave = npdev::uni(threadIdx.x >> 6);
@@ -287,57 +287,30 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
         }
         if (it->second[0].end > it->second[0].beg) vr[c] = {it->second[0].beg, it->second[0].end};
     }
-    // walk the BGZF headers of every extent (extents of consecutive contigs abut or share a block: merge on the fly)
-    // order the contigs' ranges by file position
+    // ---- the file bytes of the contigs' record ranges, a few large reads into pinned memory, then the BGZF headers in memory
+    // byte range of contig c: from the block of its first record up to (and with) the block that holds the end of its last one;
+    // that block's size is not known before its header is read, so up to 64 KiB more are taken (never beyond the file)
     std::vector<size_t> order;
     for (size_t c = 0; c < nc; ++c) if (vr[c].second > vr[c].first) order.push_back(c);
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return vr[a].first < vr[b].first; });
-    uint64_t comp_at = 0, u_at = 0;
-    uint64_t next_coff = (uint64_t)-1;    // file offset right behind the last block taken
-    // first pass: block list (file offsets + sizes) by reading headers; the payloads are read in one pread per run of blocks
-    struct Run { uint64_t coff, bytes, comp_at; };
+    struct Run { uint64_t coff, bytes, comp_at, last_block; };   // last_block: highest file offset at which a needed block may start
     std::vector<Run> runs;
-    for (size_t oi = 0; oi < order.size(); ++oi) {
-        const size_t c = order[oi];
+    for (size_t c : order) {
         const uint64_t c0 = vr[c].first >> 16;
-        const uint64_t cend_incl = (vr[c].second & 0xffffu) ? (vr[c].second >> 16) : (uint64_t)-2;   // last block to include (-2: up to, not including, ve's block)
-        const uint64_t stop_excl = (vr[c].second & 0xffffu) ? (uint64_t)-1 : (vr[c].second >> 16);
-        uint64_t coff = c0;
-        if (next_coff != (uint64_t)-1 && coff < next_coff) coff = next_coff;   // blocks already taken for the previous contig
-        for (;;) {
-            if (cend_incl != (uint64_t)-2 && coff > cend_incl) break;
-            if (stop_excl != (uint64_t)-1 && coff >= stop_excl) break;
-            uint8_t h[18];
-            if (pread(src.fd, h, 18, (off_t)coff) != 18) { *err = "BAM truncated inside the indexed range"; return -1; }
-            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { *err = "not a BGZF block where the index points"; return -1; }
-            const uint32_t xlen = h[10] | (h[11] << 8);
-            uint32_t bsize = 0;
-            if (xlen == 6 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0) bsize = (uint32_t)(h[16] | (h[17] << 8)) + 1;
-            else {   // other extra subfields before BC: read the whole extra field
-                std::vector<uint8_t> x(xlen);
-                if (pread(src.fd, x.data(), xlen, (off_t)coff + 12) != (ssize_t)xlen) { *err = "BAM truncated"; return -1; }
-                for (uint32_t i = 0; i + 4 <= xlen;) {
-                    const uint32_t slen = x[i + 2] | (x[i + 3] << 8);
-                    if (x[i] == 'B' && x[i + 1] == 'C' && slen == 2 && i + 6 <= xlen) bsize = (uint32_t)(x[i + 4] | (x[i + 5] << 8)) + 1;
-                    i += 4 + slen;
-                }
-            }
-            if (bsize < 12 + xlen + 8) { *err = "bad BGZF block size"; return -1; }
-            if (runs.empty() || runs.back().coff + runs.back().bytes != coff) runs.push_back(Run{coff, 0, comp_at});
-            runs.back().bytes += bsize;
-            npdev::BlockDesc d;
-            d.in_off = comp_at + 12 + xlen;
-            d.in_len = bsize - (12 + xlen) - 8;
-            d.out_off = 0;
-            d.out_len = 0;            // ISIZE: filled after the payload is in memory
-            S.blocks.push_back(d);
-            S.block_coff.push_back(coff);
-            S.block_size.push_back(bsize);
-            comp_at += bsize;
-            coff += bsize;
-            next_coff = coff;
+        const bool partial = (vr[c].second & 0xffffu) != 0;
+        const uint64_t last = partial ? (vr[c].second >> 16) : (vr[c].second >> 16) - 1;    // no block starts inside another: "< ve's block" == "<= ve's block - 1"
+        uint64_t end = partial ? (vr[c].second >> 16) + 65536 : (vr[c].second >> 16);
+        if (end > src.file_size) end = src.file_size;
+        if (!runs.empty() && c0 <= runs.back().coff + runs.back().bytes) {
+            Run& r = runs.back();
+            if (end > r.coff + r.bytes) r.bytes = end - r.coff;
+            if (last > r.last_block) r.last_block = last;
+        } else {
+            runs.push_back(Run{c0, end - c0, 0, last});
         }
     }
+    uint64_t comp_at = 0, u_at = 0;
+    for (Run& r : runs) { r.comp_at = comp_at; comp_at += r.bytes; }
     if (!S.comp.ensure(comp_at + 4096)) { *err = "hipHostMalloc failed"; return -1; }
     for (const Run& r : runs) {
         uint64_t done = 0;
@@ -348,14 +321,36 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
         }
     }
     memset((char*)S.comp.p + comp_at, 0, 4096);
-    for (size_t b = 0; b < S.blocks.size(); ++b) {
-        npdev::BlockDesc& d = S.blocks[b];
-        uint32_t isize;
-        memcpy(&isize, (const char*)S.comp.p + d.in_off + d.in_len + 4, 4);
-        if (isize > 65536) { *err = "BGZF block larger than 64 KiB"; return -1; }
-        d.out_len = isize;
-        d.out_off = u_at;
-        u_at += isize;
+    for (const Run& r : runs) {
+        uint64_t p = 0;
+        while (r.coff + p <= r.last_block) {
+            if (p + 18 > r.bytes) { *err = "BAM truncated inside the indexed range"; return -1; }
+            const uint8_t* h = (const uint8_t*)S.comp.p + r.comp_at + p;
+            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { *err = "not a BGZF block where the index points"; return -1; }
+            const uint32_t xlen = h[10] | (h[11] << 8);
+            if (p + 12 + xlen > r.bytes) { *err = "BAM truncated inside the indexed range"; return -1; }
+            uint32_t bsize = 0;
+            for (uint32_t i = 0; i + 4 <= xlen;) {
+                const uint8_t* x = h + 12 + i;
+                const uint32_t slen = x[2] | (x[3] << 8);
+                if (x[0] == 'B' && x[1] == 'C' && slen == 2 && i + 6 <= xlen) bsize = (uint32_t)(x[4] | (x[5] << 8)) + 1;
+                i += 4 + slen;
+            }
+            if (bsize < 12 + xlen + 8 || p + bsize > r.bytes) { *err = "bad BGZF block size"; return -1; }
+            uint32_t isize;
+            memcpy(&isize, h + bsize - 4, 4);
+            if (isize > 65536) { *err = "BGZF block larger than 64 KiB"; return -1; }
+            npdev::BlockDesc d;
+            d.in_off = r.comp_at + p + 12 + xlen;
+            d.in_len = bsize - (12 + xlen) - 8;
+            d.out_off = u_at;
+            d.out_len = isize;
+            S.blocks.push_back(d);
+            S.block_coff.push_back(r.coff + p);
+            S.block_size.push_back(bsize);
+            u_at += isize;
+            p += bsize;
+        }
     }
     S.comp_bytes = comp_at;
     S.inflated_bytes = u_at;
@@ -365,7 +360,7 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
         auto it = std::lower_bound(S.block_coff.begin(), S.block_coff.end(), coff);
         if (it == S.block_coff.end() || *it != coff) {
             // the position right behind a block that was read (the end of a contig's last record at a block boundary)
-            if ((v & 0xffffu) == 0 && it != S.block_coff.begin()) {
+            if ((v & 0xffffu) == 0 && it != S.block_coff.begin()) {   // (binary search works: block_coff is ascending, runs are in file order)
                 const size_t pb = (size_t)(it - S.block_coff.begin()) - 1;
                 const npdev::BlockDesc& d = S.blocks[pb];
                 if (S.block_coff[pb] + S.block_size[pb] == coff) { *out = d.out_off + d.out_len; return true; }
@@ -535,6 +530,8 @@ bool BamSource::open(const std::string& fasta, const std::string& bam, std::stri
     have_bai = bai.load(bam + ".bai");
     fd = ::open(bam.c_str(), O_RDONLY);
     if (fd < 0) { *err = "cannot open BAM: " + bam; return false; }
+    const off_t sz = lseek(fd, 0, SEEK_END);
+    file_size = sz > 0 ? (uint64_t)sz : 0;
     return true;
 }
 BamSource::~BamSource() { if (fd >= 0) ::close(fd); }
