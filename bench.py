@@ -329,7 +329,7 @@ def e2e_from_files(streams, draft_bp, threads):
         for _ in range(3):
             got = [0]
             t0 = time.time()
-            pipe.run_files(fa, bam, sink=lambda name, seq: got.__setitem__(0, got[0] + len(seq)))
+            pipe.run_files(fa, bam, raw_sink=lambda name, ptr, n: got.__setitem__(0, got[0] + n))
             warm = min(warm, time.time() - t0)
             nout = got[0]
         pipe.close()

@@ -33,6 +33,9 @@ struct np1_pipe {
     std::vector<std::vector<uint32_t>> bounds;     // per batch: nc + 1 offsets
     std::vector<np1_batch*> resident;              // np1_pipe_upload: batch k lives on lane k % lanes
     uint64_t host_inflated_blocks = 0;             // last np1_pipe_run_files: BGZF blocks the device decoder handed back to the host
+    // from-files mode: pinned staging buffers and per-lane HBM scratch live as long as the pipe (allocated on first use)
+    std::vector<np1ingest::Staging*> staging;
+    std::vector<np1ingest::Scratch*> scratch;
 };
 
 namespace {
@@ -126,6 +129,8 @@ int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passe
 void np1_pipe_close(np1_pipe* p) {
     if (!p) return;
     drop_resident(p);
+    for (np1ingest::Scratch* s : p->scratch) np1ingest::scratch_destroy(s);
+    for (np1ingest::Staging* s : p->staging) delete s;
     for (np1_pipe::Lane& ln : p->lanes) {
         if (ln.batch) np1_batch_free(ln.batch);
         if (ln.ctx) np1_ctx_destroy(ln.ctx);
@@ -207,10 +212,12 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
     struct Item { np1ingest::Staging* staging = nullptr; np1_stream* stream = nullptr; };
     const size_t depth = p->lanes.size() + loader_threads();    // loaded-but-unpolished batches allowed in memory
     std::vector<np1ingest::Staging*> free_staging;
-    std::vector<np1ingest::Staging*> all_staging;
-    if (device_ingest)
-        for (size_t i = 0; i < depth; ++i) { all_staging.push_back(new np1ingest::Staging()); free_staging.push_back(all_staging.back()); }
-    std::vector<np1ingest::Scratch*> scratch(p->lanes.size(), nullptr);
+    if (device_ingest) {
+        while (p->staging.size() < depth) p->staging.push_back(new np1ingest::Staging());
+        free_staging = p->staging;
+    }
+    p->scratch.resize(p->lanes.size(), nullptr);
+    std::vector<np1ingest::Scratch*>& scratch = p->scratch;
     std::mutex mu;
     std::condition_variable cv;
     std::map<int, Item> ready;             // loaded batches waiting for a lane
@@ -348,9 +355,8 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
         for (auto& kv : ready) if (kv.second.stream) np1_stream_free(kv.second.stream);
     }
     uint64_t host_blocks = 0;
-    for (np1ingest::Scratch* s : scratch) { host_blocks += np1ingest::scratch_host_blocks(s); np1ingest::scratch_destroy(s); }
-    for (np1ingest::Staging* s : all_staging) delete s;
-    p->host_inflated_blocks = host_blocks;
+    for (np1ingest::Scratch* s : scratch) host_blocks += np1ingest::scratch_host_blocks(s);
+    p->host_inflated_blocks = host_blocks;     // cumulative over the life of the pipe
     if (failed) { np1_set_error(err); return -1; }
     return 0;
 }

@@ -126,12 +126,16 @@ class Pipe(object):
                 tot += n.value
         return tot
 
-    def run_files(self, fasta, bam, names=None, batch_bp=16000000, cfg=None, task=1, sink=None):
-        """BAM + FASTA on disk -> sink(name, sequence) per contig in FASTA-index order (loaders, lanes and sink overlapped)."""
+    def run_files(self, fasta, bam, names=None, batch_bp=16000000, cfg=None, task=1, sink=None, raw_sink=None):
+        """BAM + FASTA on disk -> sink(name, sequence) per contig in FASTA-index order (loaders, lanes and sink overlapped).
+        raw_sink(name bytes, pointer, length) skips the copy into a Python string."""
         cfg = cfg or nat.default_config()
         got = []
 
         def _sink(_user, name, seq, length):
+            if raw_sink is not None:
+                raw_sink(name, seq, length)
+                return
             s = C.string_at(seq, length).decode()
             (sink or (lambda a, b: got.append((a, b))))(name.decode(), s)
 
