@@ -120,7 +120,7 @@ void parse_ref_qv(char* s, ref_* r) {
         sep[0] = ':';
         r->qv = (ref_qv*)malloc(r->qv_l * sizeof(ref_qv));
         token = strtok(qv, sep);
-        while (token != nullptr) {
+        while (token != nullptr && i < r->qv_l) {   // the reference writes past its array when the header lists more words than node=<n> (ctg_cns.c:2259); stop at n
             ref_qv* q = &r->qv[i++];
             const uint64_t t = strtoull(token, nullptr, 16);
             q->p = (uint32_t)(t >> 32);

@@ -99,6 +99,7 @@ bool BgzfReader::fill_window(uint64_t coff) {
     if (win_.empty()) return got == 0 || got < 18 ? (got == 0) : false;   // clean EOF only when nothing is left
     uwin_.resize(utotal + 8);
     const unsigned nt = io_threads();
+    static const bool check_crc = getenv("NP_BGZF_NO_CRC") == nullptr;   // on unless switched off
     std::atomic<size_t> next(0);
     std::atomic<bool> ok(true);
     auto work = [&]() {
@@ -108,6 +109,11 @@ bool BgzfReader::fill_window(uint64_t coff) {
             const WinBlock& b = win_[i];
             const size_t clen = b.total - (b.cpos - (size_t)(b.coff - coff)) - 8;
             if (b.isize && !bgzf_inflate_block(cwin_.data() + b.cpos, clen, uwin_.data() + b.upos, b.isize)) ok = false;
+            if (b.isize && check_crc) {   // gzip trailer: CRC32 of the inflated bytes (htslib rejects a block whose CRC does not match)
+                uint32_t want;
+                memcpy(&want, cwin_.data() + b.cpos + clen, 4);
+                if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), uwin_.data() + b.upos, b.isize) != want) ok = false;
+            }
         }
     };
     if (nt <= 1 || win_.size() < 4) {

@@ -44,11 +44,14 @@ extern "C" uint64_t calgs(const char* file) {
         // header line
         while ((c = in.getc()) >= 0 && c != '\n') {}
         uint64_t seq_len = 0;
-        // sequence lines: every character except '\n' counts (kseq keeps them all)
+        // sequence lines: every character except '\n' counts; a '\r' that ends a line is dropped once the sequence is longer than
+        // one character (kseq's line reader, source/util/kseq.h:141, so CRLF files give the same size as LF files)
         while ((c = in.getc()) >= 0 && c != '>' && c != '+' && c != '@') {
             if (c == '\n') continue;
             ++seq_len;
-            while ((c = in.getc()) >= 0 && c != '\n') ++seq_len;
+            int last = c;
+            while ((c = in.getc()) >= 0 && c != '\n') { ++seq_len; last = c; }
+            if (seq_len > 1 && last == '\r') --seq_len;
             if (c < 0) break;
         }
         gs += seq_len;

@@ -109,6 +109,10 @@ bool load_stream(const std::string& fasta, const std::string& bam, const std::ve
             if (r.tid < tid) continue;
             if (r.pos >= L) { pending = true; break; }                  // iterator stop: beg >= end
             if (r.pos < 0 || r.endpos() <= 0) continue;
+            if (r.n_cigar > 0xffffu) {   // a CG-tag CIGAR swapped in by the reader: the short-read stream keeps 16-bit operation counts
+                *err = "alignment with more than 65535 CIGAR operations in " + bam + " (long reads belong to nextpolish2)";
+                return false;
+            }
             append_record(r, (uint32_t)c, with_qual, out);
         }
         if (r.tid < 0 && pending) { /* unplaced reads follow: nothing more for any contig */ }
