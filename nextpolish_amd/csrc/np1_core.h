@@ -4,6 +4,7 @@
 // by the product).  Everything here is integer/byte logic; citations point at the reference lines
 // each body restates.
 #pragma once
+#include <string.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -34,6 +35,7 @@ constexpr uint32_t SI_INSERT = 0x10, SI_LOWER = 0x20, SI_LAST = 0x40, SI_FIRST =
 // k_vote geometry: a wave owns 62 consecutive slots; lanes 0,1 are left-context halo
 constexpr uint32_t VOTE_CH = 62;
 // DP record: [slot][n<<16|total][refk | hdr<<16][n x (kmer<<16|count)][8 words state kmers][fmax base | mask<<8]
+constexpr uint32_t FLAG_ALL_RECORDS = 0x100;   // or-ed into the tile kernel's flag_single argument: every slot spills a DP record
 constexpr uint32_t REC_SINGLE = 1, REC_CTG_LAST = 2, REC_CTG_FIRST = 4;   // hdr bits; hdr bits 4..7 = previous slot's draft symbol
 constexpr uint32_t REC_FIXED_WORDS = 12;
 enum { CNT_POOL = 0, CNT_HEADS = 1, CNT_REDO = 2, CNT_ERR = 3, CNT_REDO2 = 4, CNT_OVFDESC = 5,
@@ -352,9 +354,34 @@ struct VoteLane {
 // chain DP over one multi-state run (contig.c:424-496).  Scores are exact integers: value * 2^K with
 // rate = Rfix / 2^K.  `St` provides sc(buf,b), km(buf,b), rk(buf,b) lvalues for the two 16-entry state
 // buffers (LDS on the device, plain arrays in the host model).
-template <class St>
+//
+// FP = true is the general-rate path: `rate` is any double (indel_balance_factor_sgs = 0.3, 0.55 ...), scores are the
+// reference's own doubles evaluated in its order -- score = S0; score += count - total * rate (contig.c:448, no contraction) --
+// and the "run" is the WHOLE CONTIG from its first slot (every slot carries a record): with rounding in play a run can no
+// longer start from 0 independently of what precedes it.  The 64-bit state cells then hold the bit patterns of the doubles.
+template <bool FP> struct DpScore;
+template <> struct DpScore<false> {
+    typedef long long T;
+    static NP1_HD T get(long long cell) { return cell; }
+    static NP1_HD long long put(T v) { return v; }
+    static NP1_HD T step(T s0, uint32_t cnt, uint32_t tot, int K, long long Rfix, double) { return s0 + ((long long)cnt << K) - (long long)tot * Rfix; }
+};
+template <> struct DpScore<true> {
+    typedef double T;
+    static NP1_HD T get(long long cell) { T v; memcpy(&v, &cell, 8); return v; }
+    static NP1_HD long long put(T v) { long long c; memcpy(&c, &v, 8); return c; }
+    static NP1_HD T step(T s0, uint32_t cnt, uint32_t tot, int, long long, double rate) {
+        const double prod = (double)(int)tot * rate;      // total * rate
+        const double inc = (double)(int)cnt - prod;       // count - total * rate
+        return s0 + inc;                                  // score += ...
+    }
+};
+
+template <bool FP, class St>
 NP1_HD bool dp_run(uint32_t head_off, uint32_t* pool, const uint32_t* slot_rec, uint16_t* slot_res, int K,
-                   long long Rfix, double min_ratio, St& st) {
+                   long long Rfix, double rate, double min_ratio, St& st) {
+    typedef DpScore<FP> SC;
+    typedef typename SC::T score_t;
     uint32_t* rec = pool + head_off;
     const uint32_t s_head = rec[0];
     uint32_t hdr = rec[2] >> 16;
@@ -362,16 +389,16 @@ NP1_HD bool dp_run(uint32_t head_off, uint32_t* pool, const uint32_t* slot_rec, 
     // predecessor: all-zero seed at a contig start (contig.c:459-464), else the single state of slot-1 at score 0
     bool seed = (hdr & REC_CTG_FIRST) != 0;
     uint32_t pmask = 0;
-    long long pfmax = 0;
+    score_t pfmax = 0;
     if (!seed) {
         uint32_t pb = (hdr >> 4) & 0xf;
         pmask = 1u << pb;
-        st.sc(1, pb) = 0;
+        st.sc(1, pb) = SC::put((score_t)0);
     }
     uint32_t s = s_head;
     bool ok = true;
     for (uint32_t guard = 0;; ++guard) {   // ---- forward
-        if (guard > (1u << 26)) { ok = false; break; }
+        if (guard > (FP ? 0xfffffff0u : (1u << 26))) { ok = false; break; }
         const uint32_t n = rec[1] >> 16, total = rec[1] & 0xffffu, refk = rec[2] & 0xffffu;
         hdr = rec[2] >> 16;
         const uint32_t tot = total > 1 ? total - 1 : total;
@@ -382,44 +409,44 @@ NP1_HD bool dp_run(uint32_t head_off, uint32_t* pool, const uint32_t* slot_rec, 
             const uint32_t k = ent >> 16;
             uint32_t cnt = ent & 0xffffu;
             const uint32_t p = (k >> 4) & 0xf;
-            long long S0 = 0;
+            score_t S0 = 0;
             if (!seed) {
                 if (p == 0) S0 = pfmax;
-                else if (pmask >> p & 1u) S0 = st.sc(prv, p);
+                else if (pmask >> p & 1u) S0 = SC::get(st.sc(prv, p));
                 else ok = false;   // the reference would dereference NULL here
             }
             if (k == refk && total > 1) cnt = (cnt - 1) & 0xffffu;
-            const long long v = S0 + ((long long)cnt << K) - (long long)tot * Rfix;
+            const score_t v = SC::step(S0, cnt, tot, K, Rfix, rate);
             const uint32_t b = k & 0xf;
             if (k != 0) {
                 if (!(cmask >> b & 1u)) {
                     cmask |= 1u << b;
-                    st.sc(cur, b) = v; st.km(cur, b) = (uint16_t)k; st.rk(cur, b) = (uint8_t)ncur++;
-                } else if (st.sc(cur, b) < v) {
-                    st.sc(cur, b) = v; st.km(cur, b) = (uint16_t)k;
+                    st.sc(cur, b) = SC::put(v); st.km(cur, b) = (uint16_t)k; st.rk(cur, b) = (uint8_t)ncur++;
+                } else if (SC::get(st.sc(cur, b)) < v) {
+                    st.sc(cur, b) = SC::put(v); st.km(cur, b) = (uint16_t)k;
                 }
             } else {   // base_get_score(cur, 0) is base_max_score(cur) (base.c:171-178)
                 bool take = ncur == 0;
                 if (!take) {
-                    long long best = 0; uint32_t br = 0xff;
+                    score_t best = 0; uint32_t br = 0xff;
                     for (uint32_t bb = 0; bb < 16; ++bb)
                         if (cmask >> bb & 1u) {
-                            long long x = st.sc(cur, bb); uint32_t rr = st.rk(cur, bb);
+                            score_t x = SC::get(st.sc(cur, bb)); uint32_t rr = st.rk(cur, bb);
                             if (br == 0xff || x > best || (x == best && rr < br)) { best = x; br = rr; }
                         }
                     take = best < v;
                 }
                 if (take) {
                     if (!(cmask & 1u)) { cmask |= 1u; st.rk(cur, 0) = (uint8_t)ncur++; }
-                    st.sc(cur, 0) = v; st.km(cur, 0) = 0;
+                    st.sc(cur, 0) = SC::put(v); st.km(cur, 0) = 0;
                 }
             }
         }
         // first strict maximum in insertion order (base.c:185-197)
-        long long best = 0; uint32_t br = 0xff, bbase = 0;
+        score_t best = 0; uint32_t br = 0xff, bbase = 0;
         for (uint32_t bb = 0; bb < 16; ++bb)
             if (cmask >> bb & 1u) {
-                long long x = st.sc(cur, bb); uint32_t rr = st.rk(cur, bb);
+                score_t x = SC::get(st.sc(cur, bb)); uint32_t rr = st.rk(cur, bb);
                 if (br == 0xff || x > best || (x == best && rr < br)) { best = x; br = rr; bbase = bb; }
             }
         uint32_t* scr = rec + 3 + n;   // per-slot backtrace table
@@ -429,7 +456,7 @@ NP1_HD bool dp_run(uint32_t head_off, uint32_t* pool, const uint32_t* slot_rec, 
             scr[w] = lo | hi2 << 16;
         }
         scr[8] = bbase | cmask << 8;
-        if ((hdr & REC_SINGLE) || (hdr & REC_CTG_LAST)) break;
+        if ((!FP && (hdr & REC_SINGLE)) || (hdr & REC_CTG_LAST)) break;   // FP: the run is the whole contig
         uint32_t noff = slot_rec[s + 1];
         if (noff == 0xffffffffu) { ok = false; break; }
         seed = false;

@@ -199,11 +199,12 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     b->out_pinned = false;
     int K = 0;
     long long Rfix = 0;
-    if (!rate_fixed_point(cfg->indel_balance_factor_sgs, &K, &Rfix)) {
-        np1_set_error("indel_balance_factor_sgs must be a multiple of 2^-10 on the GPU path (default 0.5)");
-        return -1;
-    }
-    const uint32_t flag_single = (1.0 < cfg->min_count_ratio_skip) ? 2u : 0u;
+    // rate = R / 2^K (the default 0.5, 0.25, 0.75 ...): exact integer scores, multi-state runs are independent (fast path).
+    // Any other double: the reference's own fp64 arithmetic in its own order, one sequential run per contig (np1_core.h).
+    const bool fp_rate = !rate_fixed_point(cfg->indel_balance_factor_sgs, &K, &Rfix);
+    if (fp_rate && !std::isfinite(cfg->indel_balance_factor_sgs)) { np1_set_error("indel_balance_factor_sgs is not a finite number"); return -1; }
+    if (fp_rate && (use_staged() || b->force_staged)) { np1_set_error("a general indel_balance_factor_sgs needs the default (fused) launch sequence"); return -1; }
+    const uint32_t flag_single = ((1.0 < cfg->min_count_ratio_skip) ? 2u : 0u) | (fp_rate ? FLAG_ALL_RECORDS : 0u);
     const uint64_t G = b->G;
     const int64_t n = b->n_reads;
     const uint32_t nc = b->nc;
@@ -255,6 +256,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     if (scan_tmp_words((uint64_t)S + 1) * 8 > b->scan_tmp.cap && b->scan_tmp.ensure(8 * (scan_tmp_words((uint64_t)S + 1) + scan_tmp_words(nn)))) return -1;
     scan_tmp = b->scan_tmp.as<uint64_t>();
     if (b->pool.cap == 0 && b->pool.ensure(4 * (3 * (size_t)S + (1u << 20)))) return -1;
+    if (fp_rate && b->pool.ensure(std::min<size_t>(4 * (20 * (size_t)S + (1u << 20)), (size_t)0xfffffff0u * 4))) return -1;   // every slot spills a record
     // ---- stage 2: per-slot draft symbols
     t0(2);
     if (!(use_staged() || b->force_staged) && b->slot_g.ensure(4 * ((size_t)S + 64))) return -1;
@@ -362,7 +364,8 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
             };
             HIPCHK(hipMemsetAsync(&totals[8], 0, 8 * POOL_SHARDS, q));
             t0(5);
-            static const int tile_kind = getenv("NP1_TILE") ? atoi(getenv("NP1_TILE")) : 3;   // 3: per-vote kernel; 5, 6: event kernels
+            static const int tile_kind_env = getenv("NP1_TILE") ? atoi(getenv("NP1_TILE")) : 3;   // 3: per-vote kernel; 5, 6: event kernels
+            const int tile_kind = fp_rate ? 3 : tile_kind_env;
             static const bool phase_timing = getenv("NP1_PHASE_TIMING") != nullptr;            // k_tile6 phase cycles to stderr
             const uint32_t heads_cap5 = (uint32_t)std::min<size_t>(b->heads.cap / 4, 0xfffffff0u);
             unsigned long long* dbg = nullptr;
@@ -441,7 +444,8 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
         const uint32_t heads_cap = (uint32_t)std::min<size_t>(b->heads.cap / 4, 0xfffffff0u);
         launch_dp(q, b->heads.as<uint32_t>(), counters, staged ? (uint32_t)CNT_HEADS : (uint32_t)CNT_HEADS_S0,
                   staged ? 1u : POOL_SHARDS, staged ? 0u : heads_cap / POOL_SHARDS, b->pool.as<uint32_t>(),
-                  b->slot_rec.as<uint32_t>(), b->slot_res.as<uint16_t>(), K, Rfix, cfg->min_count_ratio_skip, grid);
+                  b->slot_rec.as<uint32_t>(), b->slot_res.as<uint16_t>(), K, Rfix, cfg->min_count_ratio_skip, grid, fp_rate,
+                  cfg->indel_balance_factor_sgs);
     }
     t1(6);
     // ---- stage 7: emit

@@ -49,7 +49,7 @@ int launch_tile6(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const 
                  uint32_t flag_single, unsigned long long* votes, unsigned long long* dbg);
 void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t cnt0, uint32_t n_shards,
                uint32_t heads_region, uint32_t* pool, const uint32_t* slot_rec, uint16_t* slot_res, int K, long long Rfix,
-               double min_ratio, uint32_t grid);
+               double min_ratio, uint32_t grid, bool fp = false, double rate = 0.0);   // fp: general-rate path (doubles, whole-contig runs)
 void launch_fixfirst(hipStream_t st, const uint32_t* ctg_off, uint32_t nc, const uint32_t* soff, const uint8_t* slot_info,
                      uint16_t* slot_res);
 void launch_emit(hipStream_t st, const uint16_t* slot_res, const uint8_t* slot_info, const uint32_t* opos, uint32_t S,

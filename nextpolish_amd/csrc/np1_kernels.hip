@@ -312,7 +312,7 @@ __device__ __forceinline__ void tile_epilogue(const VoteLane<E>& vl, const uint3
                                               uint32_t* __restrict__ pool, uint32_t pool_cap, uint32_t* __restrict__ counters,
                                               uint32_t* __restrict__ heads, uint32_t heads_cap, uint32_t* __restrict__ redo_out,
                                               uint32_t redo_ci, uint32_t flag_single, uint32_t nvotes_wave,
-                                              unsigned long long* __restrict__ votes) {
+                                              unsigned long long* __restrict__ votes, bool all_rec = false) {
     __shared__ uint32_t sh_e[3 * NW + 4];
     const int wave = tid >> 6, lane = tid & 63;
     if (lane == 0) sh_e[2 * NW + 2 + wave] = live ? nvotes_wave : 0u;   // vote statistic: one atomic per workgroup, sharded
@@ -321,8 +321,9 @@ __device__ __forceinline__ void tile_epilogue(const VoteLane<E>& vl, const uint3
         else atomicOr(&counters[CNT_ERR], ERR_CTX_OVERFLOW);
     }
     const bool own = live && lane >= 2 && valid;
-    const bool is_head = own && !single && prev_is_single;
-    const bool need_rec = own && (!single || !prev_is_single);
+    // all_rec (general-rate fp64 path): every slot carries a record and a contig is one run headed by its first slot
+    const bool is_head = own && (all_rec ? first : (!single && prev_is_single));
+    const bool need_rec = own && (all_rec || !single || !prev_is_single);
     if (own) {
         uint32_t res = 0xffu;
         if (single) res = dsym | (((total == 1 ? 1u : 0u) | flag_single) << 8);
@@ -568,9 +569,10 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
     const bool single = __popc(basemask) == 1;
     const uint32_t psingle = wave_shr1((uint32_t)single);   // every lane must execute the DPP move: keep it out of the || below
     const bool prev_is_single = first || psingle != 0;
+    // flag_single bit 8 (FLAG_ALL_RECORDS): general-rate path, every slot spills a record (np1_core.h:dp_run<true>)
     tile_epilogue<E, NW>(vl, L, tid, c, chunk_ok && !ovf_any, ovf_any, valid, s, info, dsym, first, prev_dsym, single, prev_is_single,
                          vl.total(L, lane), slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci,
-                         flag_single, nvotes, votes);
+                         flag_single & 0xffu, nvotes, votes, (flag_single & FLAG_ALL_RECORDS) != 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1254,10 +1256,11 @@ struct DpLds {
     __device__ __forceinline__ uint8_t& rk(int buf, uint32_t b) { return rk_[buf][b][t]; }
 };
 
+template <bool FP>
 __global__ __launch_bounds__(DP_T) void k_dp(const uint32_t* __restrict__ heads, const uint32_t* __restrict__ counters,
                                              uint32_t cnt0, uint32_t n_shards, uint32_t heads_region,
                                              uint32_t* __restrict__ pool, const uint32_t* __restrict__ slot_rec,
-                                             uint16_t* __restrict__ slot_res, int K, long long Rfix, double min_ratio,
+                                             uint16_t* __restrict__ slot_res, int K, long long Rfix, double rate, double min_ratio,
                                              uint32_t* __restrict__ err) {
     __shared__ long long sc[2][16][DP_T];
     __shared__ uint16_t km[2][16][DP_T];
@@ -1268,7 +1271,7 @@ __global__ __launch_bounds__(DP_T) void k_dp(const uint32_t* __restrict__ heads,
     for (uint32_t hi = blockIdx.x * DP_T + threadIdx.x; hi < n_heads; hi += gridDim.x * DP_T) {
         uint32_t k = hi, sh = 0;   // run-head lists are sharded like the record pool
         while (sh + 1 < n_shards && k >= counters[cnt0 + sh]) { k -= counters[cnt0 + sh]; ++sh; }
-        if (!dp_run(heads[sh * heads_region + k], pool, slot_rec, slot_res, K, Rfix, min_ratio, st))
+        if (!dp_run<FP>(heads[sh * heads_region + k], pool, slot_rec, slot_res, K, Rfix, rate, min_ratio, st))
             atomicOr(err, ERR_DP_INCONSISTENT);
     }
 }
@@ -1493,9 +1496,13 @@ int launch_tile6(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const 
 
 void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t cnt0, uint32_t n_shards,
                uint32_t heads_region, uint32_t* pool, const uint32_t* slot_rec, uint16_t* slot_res, int K, long long Rfix,
-               double min_ratio, uint32_t grid) {
-    k_dp<<<grid, DP_T, 0, st>>>(heads, counters, cnt0, n_shards, heads_region, pool, slot_rec, slot_res, K, Rfix, min_ratio,
-                                &counters[CNT_ERR]);
+               double min_ratio, uint32_t grid, bool fp, double rate) {
+    if (fp)
+        k_dp<true><<<grid, DP_T, 0, st>>>(heads, counters, cnt0, n_shards, heads_region, pool, slot_rec, slot_res, K, Rfix, rate, min_ratio,
+                                          &counters[CNT_ERR]);
+    else
+        k_dp<false><<<grid, DP_T, 0, st>>>(heads, counters, cnt0, n_shards, heads_region, pool, slot_rec, slot_res, K, Rfix, rate, min_ratio,
+                                           &counters[CNT_ERR]);
 }
 
 void launch_fixfirst(hipStream_t st, const uint32_t* ctg_off, uint32_t nc, const uint32_t* soff, const uint8_t* slot_info,

@@ -60,6 +60,26 @@ def digest(d):
     return {n: {"len": len(s), "md5": md5(s)} for n, s in d.items()}
 
 
+def ref_rates(fa, bam, rates):
+    """score_chain of the reference's shared library for other values of indel_balance_factor_sgs (the caller mutates the
+    Configure after config_init, source/lib/nextpolish1.py:102-133)."""
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "nextpolish1.so"))
+    L.config_init.restype = C.POINTER(nat.Configure)
+    L.config_init.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.score_chain.restype = C.POINTER(nat.PolishResult)
+    L.score_chain.argtypes = [C.c_char_p, C.POINTER(nat.Configure)]
+    cfg = L.config_init(fa.encode(), bam.encode(), None)
+    out = {}
+    for rate in rates:
+        cfg.contents.indel_balance_factor_sgs = rate
+        out[repr(rate)] = {}
+        for line in open(fa + ".fai"):
+            name = line.split("\t")[0]
+            r = L.score_chain(name.encode(), cfg)
+            out[repr(rate)][name] = md5(C.string_at(r.contents.contig).decode())
+    return out
+
+
 def ref_trace(fa, bam):
     """score_chain through the reference's own shared library with trace_polish_open=1 (what nextpolish1.py -debug does)."""
     L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "nextpolish1.so"))
@@ -99,6 +119,7 @@ def main():
                            "score_chain": digest(run_ref("scorechain", os.path.join(w, "g.fa"), bam))}
         if tag == "sgs.s30":
             gold["sr"][tag]["points"] = tr["points"]
+            gold["sr"][tag]["rates"] = ref_rates(os.path.join(w, "g.fa"), bam, [0.3, 0.55, 0.9])
     # task 2 round: the reference's own task-1 output, re-mapped
     sc = run_ref("scorechain", os.path.join(w, "g.fa"), os.path.join(w, "sgs.sort.bam"))
     with open(os.path.join(w, "r1.fa"), "w") as f:

@@ -385,7 +385,7 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
     }
     HostState st;
     for (uint32_t h : heads)
-        if (!dp_run(h, pool.data(), slot_rec.data(), slot_res.data(), K, Rfix, cfg->min_count_ratio_skip, st)) return -4;
+        if (!dp_run<false>(h, pool.data(), slot_rec.data(), slot_res.data(), K, Rfix, 0.0, cfg->min_count_ratio_skip, st)) return -4;
     for (uint32_t c = 0; c < nc; ++c) fixfirst_contig(v->ctg_off[c], v->ctg_off[c + 1], soff.data(), slot_info.data(), slot_res.data());
     std::vector<uint32_t> opos(S + 1);
     uint32_t o = 0;

@@ -71,6 +71,27 @@ def test_parameters(ctx):
         _check(ctx, st, cfg, ocfg)
 
 
+def test_general_indel_balance_factor_takes_the_sequential_fp64_path(ctx):
+    """-indel_balance_factor_sgs that is not R / 2^K (the reference takes any double, contig.c:448): scores are the
+    reference's doubles in its order, one sequential run per contig; checked against the oracle, which is pinned to the compiled
+    reference for the same rates (tests/test_oracle.py).  Noisy, deep and multi-contig inputs, incl. the real bwa records."""
+    import hashlib, json
+    sts = [nat.Stream.synth([20000, 3000], depth=40, seed=77, softclip_rate=0.05),
+           nat.Stream.synth([6000], depth=200, seed=5, read_sub=0.06, read_indel=0.01),
+           nat.Stream.load(os.path.join(ROOT, "tests", "golden", "real", "g.fa"), os.path.join(ROOT, "tests", "golden", "real", "sgs.s30.bam"))]
+    for rate, ratio in [(0.3, 0.8), (0.55, 0.8), (0.33, 1.1), (1.0 / 3.0, 0.6)]:
+        for st in sts:
+            cfg = nat.default_config()
+            cfg.indel_balance_factor_sgs, cfg.min_count_ratio_skip = rate, ratio
+            _check(ctx, st, cfg, ob.default_config(indel_balance_factor_sgs=rate, min_count_ratio_skip=ratio))
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "real", "real_golden.json")))["sr"]["sgs.s30"]["rates"]
+    for rate, exp in gold.items():      # the compiled reference's own output for these rates, committed
+        cfg = nat.default_config()
+        cfg.indel_balance_factor_sgs = float(rate)
+        got = ctx.score_chain(sts[2], cfg)
+        assert {n: hashlib.md5(s.encode()).hexdigest() for n, s in zip(sts[2].names, got)} == exp, rate
+
+
 def test_crowded_slots_escalate(ctx):
     """Very noisy reads: more than 16 distinct contexts per slot forces the larger k_vote instantiations."""
     st = nat.Stream.synth([4000], depth=300, seed=5, read_sub=0.08, read_indel=0.01)

@@ -83,3 +83,30 @@ def test_oracle_vs_reference_synth(tmp_path, seed):
     for i, n in enumerate(st.names):
         assert ob.score_chain(st, i) == sc[n]
         assert ob.kmer_count(st, i, cfg) == kc[n]
+
+
+@needs_ref
+def test_oracle_equals_reference_library_for_general_indel_balance_factor():
+    """indel_balance_factor_sgs that is not a dyadic fraction: the reference accumulates doubles (contig.c:448); the oracle
+    does the same arithmetic in the same order.  Through the reference's shared library (the CLI takes no options)."""
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "nextpolish1.so"))
+    L.config_init.restype = C.POINTER(nat.Configure)
+    L.config_init.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.score_chain.restype = C.POINTER(nat.PolishResult)
+    L.score_chain.argtypes = [C.c_char_p, C.POINTER(nat.Configure)]
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        for seed, kw in ((1, dict(contig_len=[15000, 4000], depth=40.0)), (2, dict(contig_len=[5000], depth=150.0, read_sub=0.05, read_indel=0.01))):
+            kw = dict(kw)
+            lens = kw.pop("contig_len")
+            st = nat.Stream.synth(lens, seed=seed, **kw)
+            fa, bam = os.path.join(td, "g%d.fa" % seed), os.path.join(td, "g%d.bam" % seed)
+            st.write_files(fa, bam)
+            cfg = L.config_init(fa.encode(), bam.encode(), None)
+            for rate in (0.3, 0.55, 1.0 / 3.0, 0.9):
+                cfg.contents.indel_balance_factor_sgs = rate
+                ocfg = ob.default_config(indel_balance_factor_sgs=rate)
+                for i, n in enumerate(st.names):
+                    r = L.score_chain(n.encode(), cfg)
+                    assert C.string_at(r.contents.contig).decode() == ob.score_chain(st, i, ocfg), "rate %r contig %s" % (rate, n)
