@@ -489,9 +489,10 @@ int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
     b->out_pinned = false;
     int K = 0;
     long long Rfix = 0;
-    if (!rate_fixed_point(cfg->indel_balance_factor_sgs, &K, &Rfix)) {
-        np1_set_error("indel_balance_factor_sgs must be a multiple of 2^-10 on the GPU path (default 0.5)");
-        return -1;
+    if (!rate_fixed_point(cfg->indel_balance_factor_sgs, &K, &Rfix)) {   // general rate: the region DP keeps doubles (np1_kmer.h)
+        if (!std::isfinite(cfg->indel_balance_factor_sgs)) { np1_set_error("indel_balance_factor_sgs is not a finite number"); return -1; }
+        K = -1;
+        Rfix = 0;
     }
     const uint64_t G = b->G;
     const int64_t n = b->n_reads;
@@ -520,7 +521,7 @@ int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
     c.min_len_inter_kmer = cfg->min_len_inter_kmer; c.max_len_kmer = cfg->max_len_kmer; c.max_count_kmer = cfg->max_count_kmer;
     c.min_map_quality = cfg->min_map_quality; c.read_tlen = cfg->read_tlen;
     c.max_clip_ratio_sgs = cfg->max_clip_ratio_sgs; c.min_count_ratio_skip = cfg->min_count_ratio_skip;
-    c.K = K; c.Rfix = Rfix;
+    c.K = K; c.Rfix = Rfix; c.rate = cfg->indel_balance_factor_sgs;
     c.err = &kcnt[KCC_ERR];
 
     for (int attempt = 0; attempt < 5; ++attempt) {

@@ -5,6 +5,7 @@
 // HBM-resident record stream (np1_kernels.hip: k_kc_*).  The same bodies compile for the host model the CPU
 // test-suite checks against the oracle (tests/model).
 #pragma once
+#include <string.h>
 #include "np1_core.h"
 
 namespace np1k {
@@ -49,8 +50,9 @@ struct KcCtx {
     // parameters (reference: Configure)
     int32_t trim, ext_len_edge, min_len_ldr, min_len_inter_kmer, max_len_kmer, max_count_kmer, min_map_quality, read_tlen;
     double max_clip_ratio_sgs, min_count_ratio_skip;
-    int K;
+    int K;                       // < 0: indel_balance_factor_sgs is no dyadic fraction, scores are doubles (rate below)
     long long Rfix;
+    double rate;
     int32_t max_span;            // longest reference span of any record (lower bound for overlap scans)
     uint32_t* err;
 };
@@ -414,15 +416,23 @@ NP1_HD void kc_parse_region(const KcCtx& c, uint32_t ctg, int32_t start, int32_t
 
 // ---- region DP (contig.c:424-496) with exact fixed-point scores ------------------------------------------------
 // states of slot k of the region live at st_*[ (sb + k) * 16 + base ]
+// Scores are exact integers (value * 2^K, rate = Rfix / 2^K) or, when the rate is no such fraction (K < 0), the reference's own
+// doubles kept as bit patterns in the same 64-bit cells and evaluated in its order (score += count - total * rate, contig.c:448).
+NP1_HD double kc_as_double(long long c) { double v; memcpy(&v, &c, 8); return v; }
+NP1_HD long long kc_as_cell(double v) { long long c; memcpy(&c, &v, 8); return c; }
+NP1_HD bool kc_less(long long a, long long b, bool fp) { return fp ? kc_as_double(a) < kc_as_double(b) : a < b; }
+NP1_HD bool kc_equal(long long a, long long b, bool fp) { return fp ? kc_as_double(a) == kc_as_double(b) : a == b; }
+
 struct KcStates {
     long long* sc;
     uint16_t* km;
     uint8_t* rk;
+    bool fp = false;
     NP1_HD void clear() { for (int b = 0; b < 16; ++b) rk[b] = 0xff; }
     NP1_HD int first_max() const {   // first strict maximum in insertion order (base.c:185-197); -1 when empty
         int best = -1;
         for (int b = 0; b < 16; ++b)
-            if (rk[b] != 0xff && (best < 0 || sc[b] > sc[best] || (sc[b] == sc[best] && rk[b] < rk[best]))) best = b;
+            if (rk[b] != 0xff && (best < 0 || kc_less(sc[best], sc[b], fp) || (kc_equal(sc[b], sc[best], fp) && rk[b] < rk[best]))) best = b;
         return best;
     }
     NP1_HD uint32_t count() const { uint32_t n = 0; for (int b = 0; b < 16; ++b) n += rk[b] != 0xff; return n; }
@@ -430,12 +440,13 @@ struct KcStates {
 
 // contig_region_score + contig_region_correct on [start,end]; returns false on an inconsistent pileup or scratch overflow
 NP1_HD bool kc_region_solve(const KcCtx& c, uint32_t g0, int32_t start, int32_t end, int K, long long Rfix) {
+    const bool fp = K < 0;
     const uint32_t s0 = c.soff[g0 + (uint32_t)start], s1 = c.soff[g0 + (uint32_t)end];
     const uint32_t n = s1 - s0 + 1;
     const uint32_t sb = kc_bump(c.st_count, n + 1);
     if ((uint64_t)sb + n + 1 > c.st_cap) { np1_atomic_or(c.err, ERR_KC_POOL); return false; }
     // seed: one zero-score state per distinct previous byte of the first slot's contexts (contig.c:459-464)
-    KcStates seed{c.st_score + 16ull * sb, c.st_kmer + 16ull * sb, c.st_rank + 16ull * sb};
+    KcStates seed{c.st_score + 16ull * sb, c.st_kmer + 16ull * sb, c.st_rank + 16ull * sb, fp};
     seed.clear();
     {
         uint32_t rank = 0;
@@ -450,8 +461,8 @@ NP1_HD bool kc_region_solve(const KcCtx& c, uint32_t g0, int32_t start, int32_t 
     bool ok = true;
     for (uint32_t k = 0; k < n; ++k) {   // forward (contig.c:424-454)
         const uint32_t s = s0 + k;
-        KcStates prev{c.st_score + 16ull * (sb + k), c.st_kmer + 16ull * (sb + k), c.st_rank + 16ull * (sb + k)};
-        KcStates cur{c.st_score + 16ull * (sb + k + 1), c.st_kmer + 16ull * (sb + k + 1), c.st_rank + 16ull * (sb + k + 1)};
+        KcStates prev{c.st_score + 16ull * (sb + k), c.st_kmer + 16ull * (sb + k), c.st_rank + 16ull * (sb + k), fp};
+        KcStates cur{c.st_score + 16ull * (sb + k + 1), c.st_kmer + 16ull * (sb + k + 1), c.st_rank + 16ull * (sb + k + 1), fp};
         cur.clear();
         const uint32_t cnt_all = c.scount[s];
         const uint32_t tot = cnt_all > 1 ? cnt_all - 1 : cnt_all;
@@ -467,14 +478,21 @@ NP1_HD bool kc_region_solve(const KcCtx& c, uint32_t g0, int32_t start, int32_t 
             else if (prev.rk[p] != 0xff) S0 = prev.sc[p];
             else ok = false;
             if (kmer == c.srefk[s] && cnt_all > 1) cnt = (cnt - 1) & 0xffffu;
-            const long long v = S0 + ((long long)cnt << K) - (long long)tot * Rfix;
+            long long v;
+            if (fp) {   // a zero cell is +0.0: the seeds need no conversion
+                const double prod = (double)(int)tot * c.rate;
+                const double inc = (double)(int)cnt - prod;
+                v = kc_as_cell(kc_as_double(S0) + inc);
+            } else {
+                v = S0 + ((long long)cnt << K) - (long long)tot * Rfix;
+            }
             const uint32_t b = kmer & 0xf;
             if (kmer != 0) {
                 if (cur.rk[b] == 0xff) { cur.rk[b] = (uint8_t)ncur++; cur.sc[b] = v; cur.km[b] = (uint16_t)kmer; }
-                else if (cur.sc[b] < v) { cur.sc[b] = v; cur.km[b] = (uint16_t)kmer; }
+                else if (kc_less(cur.sc[b], v, fp)) { cur.sc[b] = v; cur.km[b] = (uint16_t)kmer; }
             } else {
                 const int fm = cur.first_max();
-                if (fm < 0 || cur.sc[fm] < v) {
+                if (fm < 0 || kc_less(cur.sc[fm], v, fp)) {
                     if (cur.rk[0] == 0xff) cur.rk[0] = (uint8_t)ncur++;
                     cur.sc[0] = v; cur.km[0] = 0;
                 }
@@ -489,13 +507,13 @@ NP1_HD bool kc_region_solve(const KcCtx& c, uint32_t g0, int32_t start, int32_t 
         const uint32_t nins0 = c.soff[g0 + (uint32_t)start + 1] - s0 - 1;
         if (nins0 > 0) stop = s0 + nins0 + 1;
     }
-    KcStates lastst{c.st_score + 16ull * (sb + n), c.st_kmer + 16ull * (sb + n), c.st_rank + 16ull * (sb + n)};
+    KcStates lastst{c.st_score + 16ull * (sb + n), c.st_kmer + 16ull * (sb + n), c.st_rank + 16ull * (sb + n), fp};
     int b = lastst.first_max();
     for (uint32_t k = n; k-- > 0;) {
         const uint32_t s = s0 + k;
         if (s < stop) break;
         if (b < 0) { np1_atomic_or(c.err, ERR_KC_INCONSISTENT); return false; }
-        KcStates cur{c.st_score + 16ull * (sb + k + 1), c.st_kmer + 16ull * (sb + k + 1), c.st_rank + 16ull * (sb + k + 1)};
+        KcStates cur{c.st_score + 16ull * (sb + k + 1), c.st_kmer + 16ull * (sb + k + 1), c.st_rank + 16ull * (sb + k + 1), fp};
         const uint32_t kk = cur.km[b];
         c.sbase[s] = (uint8_t)b;
         uint32_t fl = c.sflag[s];
@@ -507,7 +525,7 @@ NP1_HD bool kc_region_solve(const KcCtx& c, uint32_t g0, int32_t start, int32_t 
         }
         if ((double)cntb / (double)c.scount[s] < c.min_count_ratio_skip) fl |= KC_FLAG_COVERAGE; else fl &= ~KC_FLAG_COVERAGE;
         c.sflag[s] = (uint8_t)fl;
-        KcStates prev{c.st_score + 16ull * (sb + k), c.st_kmer + 16ull * (sb + k), c.st_rank + 16ull * (sb + k)};
+        KcStates prev{c.st_score + 16ull * (sb + k), c.st_kmer + 16ull * (sb + k), c.st_rank + 16ull * (sb + k), fp};
         const uint32_t arg = kk >> 4;
         if (arg) b = prev.rk[arg & 0xf] != 0xff ? (int)(arg & 0xf) : -1;
         else b = prev.first_max();

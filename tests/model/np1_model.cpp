@@ -419,7 +419,7 @@ int np1m_kmer_count(const np1_stream_view* v, const Configure* cfg, char** out, 
         double x = cfg->indel_balance_factor_sgs * (double)(1 << k);
         if (x == (double)(long long)x) { c.K = k; c.Rfix = (long long)x; break; }
     }
-    if (c.K < 0) return -2;
+    c.rate = cfg->indel_balance_factor_sgs;   // K < 0: general rate, doubles
     uint32_t err = 0;
     c.err = &err;
     std::vector<uint8_t> level(n ? n : 1);

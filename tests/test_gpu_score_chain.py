@@ -84,6 +84,17 @@ def test_general_indel_balance_factor_takes_the_sequential_fp64_path(ctx):
             cfg = nat.default_config()
             cfg.indel_balance_factor_sgs, cfg.min_count_ratio_skip = rate, ratio
             _check(ctx, st, cfg, ob.default_config(indel_balance_factor_sgs=rate, min_count_ratio_skip=ratio))
+    # kmer_count's no-depth regions use the same DP (np1_kmer.h:kc_region_solve): low depth makes many of them
+    for seed in range(3):
+        kst = nat.Stream.synth([4000 + seed * 97, 700], depth=[4, 6, 10][seed], seed=3100 + seed, with_qual=1, draft_lower=0.03,
+                               read_indel=0.002, softclip_rate=0.05, lowmapq_rate=0.2)
+        for rate in (0.3, 0.55):
+            cfg = nat.default_config()
+            cfg.read_tlen, cfg.indel_balance_factor_sgs = 1500, rate
+            b = ctx.upload(kst)
+            b.kmer_count(cfg)
+            assert b.results() == [ob.kmer_count(kst, i, ob.default_config(read_tlen=1500, indel_balance_factor_sgs=rate)) for i in range(kst.n_contigs)]
+            b.close()
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "real", "real_golden.json")))["sr"]["sgs.s30"]["rates"]
     for rate, exp in gold.items():      # the compiled reference's own output for these rates, committed
         cfg = nat.default_config()

@@ -130,3 +130,18 @@ def test_region_walk_run_parallel_form_equals_the_literal_walk():
         assert outs[0] == outs[1], (case, n, gap, con, ext, with_ext, F.tolist()[:40], outs)
         n_cases += 1
     assert n_cases > 6000
+
+
+@pytest.mark.parametrize("rate", [0.3, 0.55])
+def test_model_kmer_count_general_indel_balance_factor(rate):
+    """kmer_count's no-depth fallback scores regions with the chain DP: for a rate that is no dyadic fraction the region DP
+    keeps the reference's doubles (np1_kmer.h:kc_region_solve); low depth makes many such regions."""
+    for seed in range(4):
+        st = nat.Stream.synth([4000 + seed * 97, 700], depth=[4, 6, 10, 20][seed], seed=3100 + seed, with_qual=1, draft_lower=0.03,
+                              read_indel=0.002, softclip_rate=0.05, lowmapq_rate=0.2)
+        cfg = nat.default_config()
+        cfg.read_tlen = 1500
+        cfg.indel_balance_factor_sgs = rate
+        got = mb.kmer_count(st, cfg)
+        for i in range(st.n_contigs):
+            assert got[i] == ob.kmer_count(st, i, ob.default_config(read_tlen=1500, indel_balance_factor_sgs=rate)), "seed %d" % seed

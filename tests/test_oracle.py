@@ -110,3 +110,27 @@ def test_oracle_equals_reference_library_for_general_indel_balance_factor():
                 for i, n in enumerate(st.names):
                     r = L.score_chain(n.encode(), cfg)
                     assert C.string_at(r.contents.contig).decode() == ob.score_chain(st, i, ocfg), "rate %r contig %s" % (rate, n)
+
+
+@needs_ref
+def test_oracle_kmer_count_equals_reference_library_for_general_indel_balance_factor():
+    import ctypes as C
+    import tempfile
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "nextpolish1.so"))
+    L.config_init.restype = C.POINTER(nat.Configure)
+    L.config_init.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.kmer_count.restype = C.POINTER(nat.PolishResult)
+    L.kmer_count.argtypes = [C.c_char_p, C.POINTER(nat.Configure)]
+    with tempfile.TemporaryDirectory() as td:
+        for seed in range(3):
+            st = nat.Stream.synth([4000 + seed * 97, 700], depth=[4, 6, 10][seed], seed=3100 + seed, with_qual=1, draft_lower=0.03,
+                                  read_indel=0.002, softclip_rate=0.05, lowmapq_rate=0.2)
+            fa, bam = os.path.join(td, "k%d.fa" % seed), os.path.join(td, "k%d.bam" % seed)
+            st.write_files(fa, bam)
+            cfg = L.config_init(fa.encode(), bam.encode(), None)
+            for rate in (0.3, 0.55):
+                cfg.contents.indel_balance_factor_sgs = rate
+                ocfg = ob.default_config(read_tlen=cfg.contents.read_tlen, read_len=cfg.contents.read_len, indel_balance_factor_sgs=rate)
+                for i, n in enumerate(st.names):
+                    r = L.kmer_count(n.encode(), cfg)
+                    assert C.string_at(r.contents.contig).decode() == ob.kmer_count(st, i, ocfg), "rate %r contig %s seed %d" % (rate, n, seed)
