@@ -79,6 +79,23 @@ struct LqInput {
     bool hifi = false;               // HiFi branch of the DP (coefficient 4, CLR-style tie rule)
 };
 
+// generate_consensus_trimed (ctg_cns.c:1287-1414) with the candidate-to-seed alignments done by the executor: per valid
+// low-quality region (in the order of concatenation: descending position) its current seed and its ranked candidates; the
+// executor aligns every candidate that qualifies to the seed (align.c:39-177), applies the fill rules for the others, builds
+// the LQSEQ_MAX_COUNT concatenated gapped string pairs and runs the graph consensus on them.
+struct LqAlignRegion {
+    uint32_t seed_off, seed_len;     // into LqAlignInput::chars
+    uint32_t first_cand, n_cand;     // candidates [first_cand, first_cand + n_cand) of cand_off / cand_len, best first; n_cand >= 1
+};
+struct LqAlignInput {
+    std::string chars;                       // seeds and candidate strings
+    std::vector<uint32_t> cand_off, cand_len;
+    std::vector<LqAlignRegion> regions;
+    uint32_t gap_min_len = 3;
+    bool hifi = false;
+};
+constexpr int LQ_ROUNDS = 30;   // LQSEQ_MAX_COUNT of the reference: concatenated alignments per consensus
+
 // "the bases of stream `stream` at window positions [start, end]" (inclusive; gap tags dropped): one candidate string
 // of a low-quality region (generate_lqseqs_from_tags, ctg_cns.c:822-870)
 struct SubReq { uint32_t stream, start, end; };
@@ -94,6 +111,7 @@ class Exec {
     // link graph + DP variant + backtrace of get_lqseqs_from_align_tags (ctg_cns.c:986-1163, non-HiFi branch):
     // *cons_rev = consensus characters in backtrace order (last column first), as the reference leaves them
     virtual bool run_lq(const LqInput& in, std::string* cons_rev, std::string* err) = 0;
+    virtual bool run_lq_aligned(const LqAlignInput& in, std::string* cons_rev, std::string* err) = 0;
     // candidate strings from the tag streams of the LAST run_window call (they stay with the executor until the next
     // run_window / run_lq): request i -> bases[off[i] .. off[i + 1]).  Requests come grouped by ascending stream.
     virtual bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) = 0;

@@ -29,6 +29,7 @@
 
 #include "../../include/nextpolish2.h"
 #include "np2_exec.h"
+#include "np2_ond_dev.h"
 #include "np_threads.h"
 
 namespace np2 {
@@ -1058,6 +1059,138 @@ __global__ __launch_bounds__(SCAN_T) void k2_scan_final(const uint32_t* v, uint3
 
 inline uint32_t nblk(uint64_t n, uint32_t t) { return (uint32_t)((n + t - 1) / t); }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Low-quality regions: candidate-to-seed alignment and assembly of the concatenated gapped strings on the device
+// (generate_consensus_trimed, ctg_cns.c:1287-1414; align.c:39-177 -> np2_ond_dev.h)
+struct OndRegion { uint64_t seed_off; uint32_t seed_len, first_cand, n_cand, first_pair; };   // first_pair: pair index of round 0 (pair_of below)
+constexpr uint32_t PIECE_SEED = 0, PIECE_LQSEQ = 1, PIECE_ALN = 2;
+
+__global__ __launch_bounds__(256) void k2_ond_align(const uint8_t* __restrict__ pool, const np2ond::Pair* __restrict__ pairs, uint32_t n_pairs,
+                                                    uint8_t* out_pool, np2ond::PairResult* __restrict__ res, int32_t* vbuf, int32_t* lobuf, uint64_t* chbuf,
+                                                    uint32_t max_d_cap, uint32_t row_words) {
+    __shared__ uint8_t sq[4][np2ond::STR_CAP];
+    __shared__ uint8_t st[4][np2ond::STR_CAP];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t slot = blockIdx.x * 4 + wave, n_slots = gridDim.x * 4;
+    np2ond::WaveScratch W{vbuf + (size_t)slot * (2 * (size_t)max_d_cap + 4), lobuf + (size_t)slot * ((size_t)max_d_cap + 1),
+                          chbuf + (size_t)slot * (size_t)(max_d_cap + 1) * row_words, max_d_cap, row_words};
+    for (uint32_t p = slot; p < n_pairs; p += n_slots) {
+        const np2ond::Pair P = pairs[p];
+        np2ond::align_pair_wave(pool, P, out_pool, &res[p], W, sq[wave], st[wave]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// one lane per region: which piece every round contributes (the fill rules and the region's fallback counter are sequential
+// over the rounds) and how long it is
+__global__ void k2_ond_pieces(const OndRegion* __restrict__ regs, uint32_t n_regs, const uint32_t* __restrict__ cand_len,
+                              const int32_t* __restrict__ pair_of, const np2ond::PairResult* __restrict__ res,
+                              uint32_t* __restrict__ piece_len, uint8_t* __restrict__ piece_kind) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_regs) return;
+    const OndRegion R = regs[j];
+    const int32_t seed_len = (int32_t)R.seed_len;
+    int32_t lqcount = 0;
+    const int32_t lq0_len = (int32_t)cand_len[R.first_cand];
+    for (int i = 0; i < LQ_ROUNDS; ++i) {
+        const bool beyond = (uint32_t)i >= R.n_cand;
+        if (beyond) lqcount = 0;
+        bool fallback = true;
+        uint32_t len = 0, kind = PIECE_SEED;
+        const int32_t pi = pair_of[(size_t)j * LQ_ROUNDS + i];
+        if (pi >= 0) {
+            const np2ond::PairResult r = res[pi];
+            if (r.aln_len > 2) {
+                const int32_t cl = (int32_t)cand_len[R.first_cand + (uint32_t)i];
+                int32_t tail_t = seed_len - r.aln_t_len; if (tail_t < 0) tail_t = 0;
+                int32_t tail_q = cl - r.aln_q_len; if (tail_q < 0) tail_q = 0; if (tail_q > 250) tail_q = 250;
+                len = (uint32_t)(r.aln_len + tail_t + tail_q);
+                kind = PIECE_ALN;
+                fallback = false;
+            }
+        }
+        if (fallback) {
+            if (lqcount++ < (int32_t)R.n_cand - 1) { kind = PIECE_SEED; len = (uint32_t)seed_len; }
+            else { kind = PIECE_LQSEQ; len = (uint32_t)lq0_len; }
+        }
+        piece_len[(size_t)i * n_regs + j] = len;
+        piece_kind[(size_t)i * n_regs + j] = (uint8_t)kind;
+    }
+}
+
+// one workgroup per round: position of every region's piece in the round's string ('N' + piece per region, a final 'N')
+__global__ __launch_bounds__(256) void k2_ond_scan(const uint32_t* __restrict__ piece_len, uint32_t n_regs, uint32_t* __restrict__ piece_pos,
+                                                   uint32_t* __restrict__ total) {
+    __shared__ uint32_t sh[256];
+    __shared__ uint32_t carry;
+    const uint32_t i = blockIdx.x;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_regs; base += 256) {
+        const uint32_t j = base + threadIdx.x;
+        const uint32_t v = j < n_regs ? piece_len[(size_t)i * n_regs + j] + 1u : 0u;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t o = 1; o < 256; o <<= 1) {
+            const uint32_t a = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (j < n_regs) piece_pos[(size_t)i * n_regs + j] = carry + sh[threadIdx.x] - v + 1u;   // after this region's 'N'
+        __syncthreads();
+        if (threadIdx.x == 255) carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[i] = carry + 1u;   // + the closing 'N'
+}
+
+// one wave per (round, region) piece: 'N' + the gapped characters into the round's t and q strings
+__global__ __launch_bounds__(256) void k2_ond_emit(const OndRegion* __restrict__ regs, uint32_t n_regs, const uint8_t* __restrict__ pool,
+                                                   const uint64_t* __restrict__ cand_off, const uint32_t* __restrict__ cand_len,
+                                                   const int32_t* __restrict__ pair_of, const np2ond::Pair* __restrict__ pairs,
+                                                   const np2ond::PairResult* __restrict__ res, const uint8_t* __restrict__ out_pool,
+                                                   const uint32_t* __restrict__ piece_len, const uint8_t* __restrict__ piece_kind,
+                                                   const uint32_t* __restrict__ piece_pos, const uint32_t* __restrict__ total,
+                                                   const uint64_t* __restrict__ str_off, char* __restrict__ strpool) {
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (w >= (uint32_t)LQ_ROUNDS * n_regs) return;
+    const uint32_t i = w / n_regs, j = w % n_regs;
+    const OndRegion R = regs[j];
+    char* T = strpool + str_off[2 * i];
+    char* Q = strpool + str_off[2 * i + 1];
+    const uint32_t pos = piece_pos[(size_t)i * n_regs + j], len = piece_len[(size_t)i * n_regs + j], kind = piece_kind[(size_t)i * n_regs + j];
+    if (lane == 0) {
+        T[pos - 1] = 'N'; Q[pos - 1] = 'N';
+        if (j == n_regs - 1) { const uint32_t e = total[i]; T[e - 1] = 'N'; Q[e - 1] = 'N'; T[e] = 0; Q[e] = 0; }
+    }
+    const uint8_t* seed = pool + R.seed_off;
+    if (kind == PIECE_SEED) {
+        for (uint32_t p = lane; p < len; p += 64) { T[pos + p] = 'M'; Q[pos + p] = 'M'; }
+    } else if (kind == PIECE_LQSEQ) {
+        const uint8_t* lq0 = pool + cand_off[R.first_cand];
+        for (uint32_t p = lane; p < len; p += 64) { T[pos + p] = p < R.seed_len ? (char)seed[p] : '-'; Q[pos + p] = (char)lq0[p]; }
+    } else {
+        const int32_t pi = pair_of[(size_t)j * LQ_ROUNDS + i];
+        const np2ond::PairResult r = res[pi];
+        const np2ond::Pair P = pairs[pi];
+        const uint8_t* rt = out_pool + P.out_off;       // traceback order: column c of the alignment is at aln_len - 1 - c
+        const uint8_t* rq = rt + P.out_cap;
+        const uint8_t* cand = pool + cand_off[R.first_cand + i];
+        const uint32_t a = (uint32_t)r.aln_len;
+        const uint32_t tail_t = (int32_t)R.seed_len > r.aln_t_len ? R.seed_len - (uint32_t)r.aln_t_len : 0u;
+        for (uint32_t p = lane; p < len; p += 64) {
+            char tc, qc;
+            if (p < a) { tc = (char)rt[a - 1 - p]; qc = (char)rq[a - 1 - p]; }
+            else if (p < a + tail_t) { tc = (char)seed[(uint32_t)r.aln_t_len + (p - a)]; qc = '-'; }
+            else { tc = '-'; qc = (char)cand[(uint32_t)r.aln_q_len + (p - a - tail_t)]; }
+            T[pos + p] = tc; Q[pos + p] = qc;
+        }
+    }
+}
+
 // NP2_TIMING=1: per-stage wall time (with stream syncs) of every window on stderr
 struct StageClock {
     bool on;
@@ -1103,9 +1236,11 @@ class HipExec : public Exec {
     bool compute_spans(const WindowInput& in, int set, std::vector<SpanOut>* spans, std::string* err) override;
     bool run_window(const WindowInput& in, WindowOutput* out, std::string* err) override;
     bool run_lq(const LqInput& in, std::string* cons_rev, std::string* err) override;
+    bool run_lq_aligned(const LqAlignInput& in, std::string* cons_rev, std::string* err) override;
     bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) override;
 
   private:
+    bool lq_from_pool(const std::vector<uint32_t>& str_len, uint32_t t_len, uint32_t gap_min_len, bool hifi, std::string* cons_rev, std::string* err);
     // link observations -> column buckets -> nodes/entries for n_streams tag streams over n_cols columns; *total = entries
     // m_seen != nullptr: colcnt_ already holds the tags per column (valid unless *m_seen, a device flag, is set)
     bool build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, uint32_t* total, std::string* err, struct StageClock* clk = nullptr,
@@ -1126,6 +1261,7 @@ class HipExec : public Exec {
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
     DevBuf runsz_, runoff_, live_, ematch_, xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
+    DevBuf ondpool_, ondregs_, ondcoff_, ondclen_, ondpairof_, ondpairs_, ondres_, ondout_, ondv_, ondlo_, ondch_, ondplen_, ondpkind_, ondppos_, ondtot_;
     PinBuf pin_;
     std::vector<uint32_t> win_first_chunk_, win_n_chunks_;   // chunk range of every stream of the last run_window
     bool win_tags_live_ = false;
@@ -1564,14 +1700,11 @@ bool HipExec::extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off
 
 bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err) {
     HIPOK(hipSetDevice(device_));
-    win_tags_live_ = false;   // the chunk tables are rebuilt for the concatenated regions
     hipStream_t q = stream_;
     const uint32_t n_streams = (uint32_t)in.t.size();
-    const uint32_t n_cols = in.t_len + 1 + 32;   // slack: see the fill quirk in np2_lq.cpp
     std::vector<char> pool;
-    std::vector<uint64_t> str_off, tag_off;
-    std::vector<uint32_t> str_len, zeros(n_streams, 0);
-    uint64_t tag_bytes = 0;
+    std::vector<uint64_t> str_off;
+    std::vector<uint32_t> str_len;
     for (uint32_t i = 0; i < n_streams; ++i) {
         str_off.push_back(pool.size());
         pool.insert(pool.end(), in.t[i].begin(), in.t[i].end());
@@ -1580,11 +1713,104 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
         pool.insert(pool.end(), in.q[i].begin(), in.q[i].end());
         pool.push_back('\0');
         str_len.push_back((uint32_t)in.t[i].size());
+    }
+    if (!strpool_.ensure(pool.size() + 16) || !stroff_.ensure(8ull * str_off.size() + 16)) { *err = "out of device memory (low-quality regions)"; return false; }
+    HIPOK(hipMemcpyAsync(strpool_.p, pool.data(), pool.size(), hipMemcpyHostToDevice, q));
+    HIPOK(hipMemcpyAsync(stroff_.p, str_off.data(), 8ull * str_off.size(), hipMemcpyHostToDevice, q));
+    HIPOK(hipStreamSynchronize(q));   // pool / str_off are locals
+    return lq_from_pool(str_len, in.t_len, in.gap_min_len, in.hifi, cons_rev, err);
+}
+
+bool HipExec::run_lq_aligned(const LqAlignInput& in, std::string* cons_rev, std::string* err) {
+    HIPOK(hipSetDevice(device_));
+    hipStream_t q = stream_;
+    const uint32_t n_regs = (uint32_t)in.regions.size();
+    if (n_regs == 0) { *err = "no low-quality region to align"; return false; }
+    // ---- host: the regions, and the (region, round) pairs that are aligned at all (length rule of ctg_cns.c:1343-1344)
+    std::vector<OndRegion> regs(n_regs);
+    std::vector<int32_t> pair_of((size_t)n_regs * LQ_ROUNDS, -1);
+    std::vector<np2ond::Pair> pairs;
+    std::vector<uint64_t> coff(in.cand_off.begin(), in.cand_off.end());
+    uint64_t out_at = 0;
+    uint32_t t_len = 1, max_sum = 0;
+    for (uint32_t j = 0; j < n_regs; ++j) {
+        const LqAlignRegion& r = in.regions[j];
+        regs[j] = OndRegion{r.seed_off, r.seed_len, r.first_cand, r.n_cand, (uint32_t)pairs.size()};
+        t_len += r.seed_len + 1;
+        for (uint32_t i = 0; i < (uint32_t)LQ_ROUNDS && i < r.n_cand; ++i) {
+            const int query_len = (int)in.cand_len[r.first_cand + i], seed_len = (int)r.seed_len;
+            if (i && (query_len < seed_len * 0.5 || query_len > seed_len * 1.3)) continue;
+            np2ond::Pair P;
+            P.q_off = in.cand_off[r.first_cand + i]; P.t_off = r.seed_off; P.q_len = (uint32_t)query_len; P.t_len = r.seed_len;
+            P.out_cap = P.q_len + P.t_len + 2; P.out_off = out_at; P.pad = 0;
+            out_at += 2ull * P.out_cap;
+            pair_of[(size_t)j * LQ_ROUNDS + i] = (int32_t)pairs.size();
+            pairs.push_back(P);
+            if (P.q_len + P.t_len > max_sum) max_sum = P.q_len + P.t_len;
+        }
+    }
+    const uint32_t n_pairs = (uint32_t)pairs.size();
+    const uint32_t max_d_cap = (uint32_t)(0.4 * (double)max_sum) + 1, row_words = (max_d_cap + 1 + 63) / 64;
+    const uint32_t grid = std::min<uint32_t>(nblk(std::max(1u, n_pairs), 4), 2048u), n_slots = grid * 4;
+    if (!ondpool_.ensure(in.chars.size() + 64) || !ondregs_.ensure(sizeof(OndRegion) * (size_t)n_regs) || !ondcoff_.ensure(8ull * coff.size() + 16) ||
+        !ondclen_.ensure(4ull * in.cand_len.size() + 16) || !ondpairof_.ensure(4ull * pair_of.size()) || !ondpairs_.ensure(sizeof(np2ond::Pair) * (size_t)(n_pairs + 1)) ||
+        !ondres_.ensure(sizeof(np2ond::PairResult) * (size_t)(n_pairs + 1)) || !ondout_.ensure(out_at + 64) ||
+        !ondv_.ensure(4ull * n_slots * (2ull * max_d_cap + 4)) || !ondlo_.ensure(4ull * n_slots * ((size_t)max_d_cap + 1)) ||
+        !ondch_.ensure(8ull * n_slots * (size_t)(max_d_cap + 1) * row_words) || !ondplen_.ensure(4ull * LQ_ROUNDS * n_regs) ||
+        !ondpkind_.ensure((size_t)LQ_ROUNDS * n_regs + 16) || !ondppos_.ensure(4ull * LQ_ROUNDS * n_regs) || !ondtot_.ensure(4ull * LQ_ROUNDS + 16) ||
+        !stroff_.ensure(16ull * LQ_ROUNDS + 16)) {
+        *err = "out of device memory (low-quality alignments)";
+        return false;
+    }
+    HIPOK(hipMemcpyAsync(ondpool_.p, in.chars.data(), in.chars.size(), hipMemcpyHostToDevice, q));
+    HIPOK(hipMemcpyAsync(ondregs_.p, regs.data(), sizeof(OndRegion) * (size_t)n_regs, hipMemcpyHostToDevice, q));
+    HIPOK(hipMemcpyAsync(ondcoff_.p, coff.data(), 8ull * coff.size(), hipMemcpyHostToDevice, q));
+    HIPOK(hipMemcpyAsync(ondclen_.p, in.cand_len.data(), 4ull * in.cand_len.size(), hipMemcpyHostToDevice, q));
+    HIPOK(hipMemcpyAsync(ondpairof_.p, pair_of.data(), 4ull * pair_of.size(), hipMemcpyHostToDevice, q));
+    if (n_pairs) HIPOK(hipMemcpyAsync(ondpairs_.p, pairs.data(), sizeof(np2ond::Pair) * (size_t)n_pairs, hipMemcpyHostToDevice, q));
+    if (n_pairs)
+        k2_ond_align<<<grid, 256, 0, q>>>(ondpool_.as<uint8_t>(), ondpairs_.as<np2ond::Pair>(), n_pairs, ondout_.as<uint8_t>(), ondres_.as<np2ond::PairResult>(),
+                                         ondv_.as<int32_t>(), ondlo_.as<int32_t>(), ondch_.as<uint64_t>(), max_d_cap, row_words);
+    k2_ond_pieces<<<nblk(n_regs, 64), 64, 0, q>>>(ondregs_.as<OndRegion>(), n_regs, ondclen_.as<uint32_t>(), ondpairof_.as<int32_t>(),
+                                                 ondres_.as<np2ond::PairResult>(), ondplen_.as<uint32_t>(), ondpkind_.as<uint8_t>());
+    k2_ond_scan<<<LQ_ROUNDS, 256, 0, q>>>(ondplen_.as<uint32_t>(), n_regs, ondppos_.as<uint32_t>(), ondtot_.as<uint32_t>());
+    std::vector<uint32_t> str_len(LQ_ROUNDS);
+    HIPOK(hipMemcpyAsync(str_len.data(), ondtot_.p, 4ull * LQ_ROUNDS, hipMemcpyDeviceToHost, q));
+    HIPOK(hipStreamSynchronize(q));
+    std::vector<uint64_t> str_off;
+    uint64_t at = 0;
+    for (int i = 0; i < LQ_ROUNDS; ++i) {
+        str_off.push_back(at); at += (uint64_t)str_len[(size_t)i] + 1;
+        str_off.push_back(at); at += (uint64_t)str_len[(size_t)i] + 1;
+    }
+    if (!strpool_.ensure(at + 16)) { *err = "out of device memory (low-quality regions)"; return false; }
+    HIPOK(hipMemcpyAsync(stroff_.p, str_off.data(), 8ull * str_off.size(), hipMemcpyHostToDevice, q));
+    k2_ond_emit<<<nblk((uint64_t)LQ_ROUNDS * n_regs, 4), 256, 0, q>>>(ondregs_.as<OndRegion>(), n_regs, ondpool_.as<uint8_t>(), ondcoff_.as<uint64_t>(),
+                                                                     ondclen_.as<uint32_t>(), ondpairof_.as<int32_t>(), ondpairs_.as<np2ond::Pair>(),
+                                                                     ondres_.as<np2ond::PairResult>(), ondout_.as<uint8_t>(), ondplen_.as<uint32_t>(),
+                                                                     ondpkind_.as<uint8_t>(), ondppos_.as<uint32_t>(), ondtot_.as<uint32_t>(),
+                                                                     stroff_.as<uint64_t>(), strpool_.as<char>());
+    HIPOK(hipStreamSynchronize(q));   // str_off is a local
+    return lq_from_pool(str_len, t_len, in.gap_min_len, in.hifi, cons_rev, err);
+}
+
+// The concatenated gapped strings are in strpool_ (string i: t at stroff_[2 i], q at stroff_[2 i + 1], NUL-terminated, str_len[i]
+// characters each): tags -> link graph -> DP -> backtrace (get_lqseqs_from_align_tags, ctg_cns.c:986-1163).
+bool HipExec::lq_from_pool(const std::vector<uint32_t>& str_len, uint32_t t_len, uint32_t gap_min_len, bool hifi, std::string* cons_rev, std::string* err) {
+    HIPOK(hipSetDevice(device_));
+    win_tags_live_ = false;   // the chunk tables are rebuilt for the concatenated regions
+    hipStream_t q = stream_;
+    const uint32_t n_streams = (uint32_t)str_len.size();
+    const uint32_t n_cols = t_len + 1 + 32;   // slack: see the fill quirk in np2_lq.cpp
+    std::vector<uint64_t> tag_off;
+    std::vector<uint32_t> zeros(n_streams, 0);
+    uint64_t tag_bytes = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
         tag_off.push_back(tag_bytes);
-        tag_bytes += ((uint64_t)in.t[i].size() + 1) / 2 + 1;
+        tag_bytes += ((uint64_t)str_len[i] + 1) / 2 + 1;
         tag_bytes = (tag_bytes + 3) & ~3ull;
     }
-    if (!strpool_.ensure(pool.size() + 16) || !stroff_.ensure(8ull * str_off.size() + 16) || !strlen_.ensure(4ull * n_streams + 16) ||
+    if (!strlen_.ensure(4ull * n_streams + 16) ||
         !tags_.ensure(tag_bytes + 16) || !cnt4_.ensure(16ull * n_cols + 64) || !stat_.ensure(sizeof(ColStat) * (size_t)n_cols) ||
         !tagoff_.ensure(8ull * n_streams + 16) || !alnts_.ensure(4ull * n_streams + 16) || !te_.ensure(4ull * n_streams + 16) ||
         !colcnt_.ensure(4ull * (n_cols + 2)) || !coloff_.ensure(4ull * (n_cols + 2)) || !cursor_.ensure(4ull * (n_cols + 2)) ||
@@ -1592,8 +1818,6 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
         *err = "out of device memory (low-quality regions)";
         return false;
     }
-    HIPOK(hipMemcpyAsync(strpool_.p, pool.data(), pool.size(), hipMemcpyHostToDevice, q));
-    HIPOK(hipMemcpyAsync(stroff_.p, str_off.data(), 8ull * str_off.size(), hipMemcpyHostToDevice, q));
     HIPOK(hipMemcpyAsync(strlen_.p, str_len.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
     HIPOK(hipMemcpyAsync(tagoff_.p, tag_off.data(), 8ull * n_streams, hipMemcpyHostToDevice, q));
     HIPOK(hipMemcpyAsync(alnts_.p, zeros.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
@@ -1621,7 +1845,7 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
         k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nss);
         k2_scan_final<<<nss, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), nsc + 1, sums2_.as<uint32_t>(), chpre_.as<uint32_t>());
         k2_tags_str_chunk<<<nblk(nsc, 64), 64, 0, q>>>(tchunks_.as<StrChunk>(), nsc, chpre_.as<uint32_t>(), strpool_.as<char>(), stroff_.as<uint64_t>(),
-                                                       in.gap_min_len, tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), st, te_.as<uint32_t>());
+                                                       gap_min_len, tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), st, te_.as<uint32_t>());
     }
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>(), 0u, nullptr, nullptr, nullptr);
     uint32_t total = 0;
@@ -1629,7 +1853,7 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
     MsaView mv{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), stat_.as<ColStat>(),
                getenv("NP2_NO_MATCH") ? nullptr : ematch_.as<EMatch>()};
     uint32_t cons_len = 0;
-    if (!solve(mv, (int32_t)in.t_len, n_cols, total, in.hifi ? RULE_LQ_HIFI : RULE_LQ, &cons_len, nullptr, err)) return false;
+    if (!solve(mv, (int32_t)t_len, n_cols, total, hifi ? RULE_LQ_HIFI : RULE_LQ, &cons_len, nullptr, err)) return false;
     std::string fwd(cons_len, '\0');
     if (cons_len) HIPOK(hipMemcpyAsync(&fwd[0], cons_.p, cons_len, hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));

@@ -269,110 +269,40 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
     return max_aln_length;
 }
 
-// gapped string pair under construction: the reference writes with strcpy at a logical length that one of its fill
-// helpers advances by less than it wrote (fill_aln_with_lqseq, ctg_cns.c:1268-1285), so keep position semantics
-struct LinkAln {
-    std::string t, q;
-    size_t len = 0;
-    void put(const std::string& ts, const std::string& qs) {   // strcpy both at `len` (does not advance)
-        if (t.size() < len + ts.size()) { t.resize(len + ts.size(), '\0'); q.resize(len + ts.size(), '\0'); }
-        if (q.size() < len + qs.size()) { t.resize(len + qs.size(), '\0'); q.resize(len + qs.size(), '\0'); }
-        t.replace(len, ts.size(), ts);
-        q.replace(len, qs.size(), qs);
-    }
-    void push(char tc, char qc) {
-        if (t.size() <= len) { t.resize(len + 1, '\0'); q.resize(len + 1, '\0'); }
-        t[len] = tc; q[len] = qc;
-        ++len;
-    }
-};
-void fill_with_seed(LinkAln& a, int seed_len) {
-    const std::string m((size_t)seed_len, 'M');
-    a.put(m, m);
-    a.len += (size_t)seed_len;
-}
-void fill_with_lqseq(LinkAln& a, const std::string& seed, int seed_len, const std::string& lqseq, int lqseq_len) {
-    if (lqseq_len > seed_len) a.put(seed.substr(0, (size_t)seed_len) + std::string((size_t)(lqseq_len - seed_len), '-'), lqseq.substr(0, (size_t)lqseq_len));
-    else a.put(seed.substr(0, (size_t)seed_len), lqseq.substr(0, (size_t)lqseq_len) + std::string((size_t)(seed_len - lqseq_len), '-'));
-    a.len += (size_t)lqseq_len;
-}
-
-// generate_consensus_trimed: builds the 30 concatenated alignments and runs the graph consensus on them.
-// The reference appends, per round i and region j, one gapped piece (a helper writes more than it advances, the excess
-// is overwritten by what follows or cut at the end: only the first `advance` characters of a piece survive).  A
-// region's pieces depend on that region's own counter only, so the regions are aligned in parallel and the 30
-// strings are concatenated afterwards.
+// generate_consensus_trimed (ctg_cns.c:1287-1414): every valid region hands its current seed and its ranked candidates to the
+// executor, which aligns the candidates to the seed, builds the 30 concatenated gapped string pairs and runs the graph
+// consensus on them -- all on the device (np2_exec_hip.hip:run_lq_aligned).  Regions go in the order of concatenation.
 bool consensus_of_regions(Exec* exec, std::vector<Region>& lq, uint32_t gap_min_len, bool hifi, std::string* cons_rev, std::string* err) {
-    const int count = (int)lq.size();
-    LqInput in;
+    LqAlignInput in;
     in.gap_min_len = gap_min_len;
     in.hifi = hifi;
-    for (Region& r : lq) r.lqcount = 0;
-    struct Pieces { std::string t[LQSEQ_MAX_COUNT], q[LQSEQ_MAX_COUNT]; };
-    std::vector<Pieces> pieces((size_t)count);
-    np::parallel_for((size_t)count, 8, [&](size_t lo, size_t hi) {
-        for (size_t j = lo; j < hi; ++j) {
-            Region& r = lq[j];
-            if (r.len <= 0) continue;
-            const int seed_len = (int)r.sudoseed_len;
-            for (int i = 0; i < LQSEQ_MAX_COUNT; ++i) {
-                LinkAln a;
-                const bool beyond = (i + r.indexs) > r.indexe;
-                const int query_len = beyond ? seed_len : (int)r.seqs[(size_t)(i + r.indexs)].len;
-                if (beyond) r.lqcount = 0;
-                bool fallback = false;
-                if (beyond || (i && (query_len < seed_len * 0.5 || query_len > seed_len * 1.3))) {
-                    fallback = true;
-                } else {
-                    const Cand& cd = r.seqs[(size_t)(i + r.indexs)];
-                    OndAln al;
-                    ond_align(cd.seq.c_str(), query_len, r.sudoseed.c_str(), seed_len, &al);
-                    if (al.aln_len > 2) {
-                        a.put(al.t_aln_str, al.q_aln_str);
-                        a.len += (size_t)al.aln_len;
-                        int tl = al.aln_t_len, ql = al.aln_q_len;
-                        while (tl < seed_len) a.push(r.sudoseed[(size_t)tl++], '-');
-                        int delta = 0;
-                        while (ql < (int)cd.len && delta++ < 250) a.push('-', cd.seq[(size_t)ql++]);
-                    } else {
-                        fallback = true;
-                    }
-                }
-                if (fallback) {
-                    if ((int)(r.lqcount++) < r.indexe - r.indexs) fill_with_seed(a, seed_len);
-                    else fill_with_lqseq(a, r.sudoseed, seed_len, r.seqs[r.indexs].seq, (int)r.seqs[r.indexs].len);
-                }
-                pieces[j].t[i].assign(a.t, 0, a.len);
-                pieces[j].q[i].assign(a.q, 0, a.len);
-            }
+    size_t need = 0;
+    for (const Region& r : lq)
+        if (r.len > 0) { need += r.sudoseed_len; for (int k = r.indexs; k <= r.indexe && k < r.indexs + LQSEQ_MAX_COUNT; ++k) need += r.seqs[(size_t)k].len; }
+    in.chars.reserve(need + 16);
+    for (size_t j = lq.size(); j-- > 0;) {
+        Region& r = lq[j];
+        r.lqcount = 0;
+        if (r.len <= 0) continue;
+        LqAlignRegion a;
+        a.seed_off = (uint32_t)in.chars.size();
+        a.seed_len = (uint32_t)r.sudoseed_len;
+        in.chars.append(r.sudoseed, 0, (size_t)r.sudoseed_len);
+        in.chars.resize((size_t)a.seed_off + a.seed_len, '\0');
+        a.first_cand = (uint32_t)in.cand_off.size();
+        a.n_cand = (uint32_t)(r.indexe - r.indexs + 1);
+        for (int k = r.indexs; k <= r.indexe && k < r.indexs + LQSEQ_MAX_COUNT; ++k) {
+            const Cand& cd = r.seqs[(size_t)k];
+            in.cand_off.push_back((uint32_t)in.chars.size());
+            in.cand_len.push_back((uint32_t)cd.len);
+            const size_t at = in.chars.size();
+            in.chars.append(cd.seq, 0, (size_t)cd.len);
+            in.chars.resize(at + (size_t)cd.len, '\0');
         }
-    });
-    int aligned_linkseq_len = 0;
-    for (int i = 0; i < LQSEQ_MAX_COUNT; ++i) {
-        aligned_linkseq_len = 0;
-        std::string t, q;
-        for (int j = count - 1; j >= 0; --j) {
-            const Region& r = lq[(size_t)j];
-            if (r.len <= 0) continue;
-            aligned_linkseq_len += (int)r.sudoseed_len + 1;
-            t.push_back('N');
-            q.push_back('N');
-            t += pieces[(size_t)j].t[i];
-            q += pieces[(size_t)j].q[i];
-        }
-        ++aligned_linkseq_len;
-        t.push_back('N');
-        q.push_back('N');
-        in.t.push_back(std::move(t));
-        in.q.push_back(std::move(q));
+        in.regions.push_back(a);
     }
-    in.t_len = (uint32_t)aligned_linkseq_len;
-    if (getenv("NP2_TIMING")) {
-        timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
-        static double last = 0; const double t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-        fprintf(stderr, "[np2 lq]   alignments built, %u target columns (t=%.2f)\n", in.t_len, t - last); last = t;
-    }
-    return exec->run_lq(in, cons_rev, err);
+    if (in.regions.empty()) { cons_rev->assign("N"); return true; }
+    return exec->run_lq_aligned(in, cons_rev, err);
 }
 
 uint32_t min_cand_len(const Region& r) {

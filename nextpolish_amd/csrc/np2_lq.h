@@ -1,5 +1,6 @@
 // Low-quality-region stage of the long-read consensus (host side): candidate extraction, pseudo-seed by partial-order
-// alignment, banded O(ND) alignment of the candidates to the seed, and the splice back into the window consensus.
+// alignment, and the splice back into the window consensus; the alignment of the candidates to the seed and the graph
+// consensus of the concatenated regions run in the executor (device).
 // reference: source/lib/ctg_cns.c:405-449,620-633,822-1473, dag.c, align.c
 #pragma once
 #include <cstdint>
@@ -12,13 +13,6 @@ namespace np2 {
 
 // heaviest-path consensus of up to 50 strings (poa_to_consensus, dag.c:658-694)
 std::string poa_consensus(const std::vector<std::string>& seqs);
-
-struct OndAln {
-    int aln_len = 0, aln_t_len = 0, aln_q_len = 0;
-    std::string t_aln_str, q_aln_str;
-};
-// align (align.c:39-177); false = no alignment within the diagonal/band limits
-bool ond_align(const char* query_seq, int q_len, const char* target_seq, int t_len, OndAln* aln);
 
 // a split-read gap cluster as the low-quality stage sees it (ctg_cns.h:210-215; generate_lqseqs_from_cluster)
 struct LqCluster {

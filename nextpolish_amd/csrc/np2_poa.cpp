@@ -1,12 +1,11 @@
-// Partial-order alignment consensus of a few candidate strings (pseudo-seed of a low-quality region) and the banded
-// O(ND) pairwise aligner used to map every candidate onto that seed.  Host code: small, branchy, sequential graph
+// Partial-order alignment consensus of a few candidate strings (pseudo-seed of a low-quality region).  (The pairwise
+// alignment of every candidate onto that seed runs on the device: np2_ond_dev.h.)  Host code: small, branchy, sequential graph
 // work on strings of a few hundred bases (the reference runs them on the CPU as well and they are not on the
 // per-column hot path).
 //
 // Restated from the behaviour of
 //   poa_to_consensus   source/lib/dag.c:658-694  (graph :24-70, NW to graph :261-300, toposort :469-508,
 //                                                 heaviest path with -0.5 * indegree :555-595)
-//   align              source/lib/align.c:39-177 (band pruning at best_m - 150, gap runs > 250 abort)
 // including their integer widths (16-bit node ids and score back-pointers, 8-bit degrees).
 #include <algorithm>
 #include <cassert>
@@ -350,93 +349,6 @@ std::string poa_consensus(const std::vector<std::string>& seqs) {
     const size_t z = out.find('\0');
     if (z != std::string::npos) out.resize(z);
     return out;
-}
-
-// ---- banded O(ND) alignment (align.c:39-177).  Returns false when no alignment was produced (aln untouched).
-bool ond_align(const char* query_seq, int q_len, const char* target_seq, int t_len, OndAln* aln) {
-    int max_d = (int)(0.4 * (q_len + t_len));
-    const float band_factor = q_len + t_len > 5000 ? 0.1f : 1.0f;
-    const int band_size = (int)(band_factor * (float)(q_len + t_len));
-    const int k_offset = max_d;
-    std::vector<int> V((size_t)2 * (size_t)(max_d + 2) + 4, 0);
-    std::vector<std::vector<uint8_t>> D;
-    int x = 0, y = 0, kk = 0, min_k = 0, max_k = 0, best_m = -1, k = 0, d;
-    bool aligned = false;
-    aln->aln_len = 0;
-    for (d = 0; d < max_d && max_k - min_k <= band_size; ++d) {
-        D.emplace_back((size_t)d + 2, (uint8_t)0);
-        for (k = min_k; k <= max_k; k += 2) {
-            kk = k < 0 ? -1 * k - 1 : k;
-            if ((k == min_k) || ((k != max_k) && (V[(size_t)(k - 1 + k_offset)] < V[(size_t)(k + 1 + k_offset)]))) {
-                x = V[(size_t)(k + 1 + k_offset)];
-                D[(size_t)d][(size_t)kk] = 0;
-            } else {
-                x = V[(size_t)(k - 1 + k_offset)] + 1;
-                D[(size_t)d][(size_t)kk] = 1;
-            }
-            y = x - k;
-            while (x < q_len && y < t_len && query_seq[x] == target_seq[y]) { ++x; ++y; }
-            V[(size_t)(k + k_offset)] = x;
-            if (x + y > best_m) best_m = x + y;
-            if (x >= q_len && y >= t_len) { aligned = true; break; }
-        }
-        int new_min_k = max_k, new_max_k = min_k;
-        int k2 = min_k;
-        while (k2 < new_min_k) {
-            if (V[(size_t)(k2 + k_offset)] * 2 - k2 >= best_m - 150) new_min_k = k2;
-            k2 += 2;
-        }
-        k2 = max_k;
-        while (k2 > new_max_k) {
-            if (V[(size_t)(k2 + k_offset)] * 2 - k2 >= best_m - 150) new_max_k = k2;
-            k2 -= 2;
-        }
-        max_k = new_max_k + 1;
-        min_k = new_min_k - 1;
-        if (aligned) {
-            --x;
-            aln->aln_t_len = y;
-            aln->aln_q_len = x + 1;
-            int gap = 0;
-            std::string ts, qs;
-            for (;;) {
-                while (x >= 0 && x >= k && query_seq[x] == target_seq[x - k]) {
-                    ts.push_back(query_seq[x]);
-                    qs.push_back(query_seq[x]);
-                    --x;
-                    gap = 0;
-                }
-                const int pre_d = d - 1;
-                if (x < 0 && x - k < 0) break;
-                int pre_k, pre_x;
-                if (D[(size_t)d][(size_t)kk]) { pre_k = k - 1; pre_x = x - 1; }
-                else { pre_k = k + 1; pre_x = x; }
-                const int pre_y = pre_x - pre_k;
-                const int pre_kk = pre_k < 0 ? -1 * pre_k - 1 : pre_k;
-                if (pre_x == x && pre_y != x - k) {
-                    if (x - k < 0) gap = 260;
-                    else { qs.push_back('-'); ts.push_back(target_seq[x - k]); }
-                } else {
-                    if (x < 0) gap = 260;
-                    else { qs.push_back(query_seq[x]); ts.push_back('-'); }
-                }
-                if (gap++ > 250) {   // a gap run longer than 250: give up (the reference leaves two columns of junk, caller tests aln_len > 2)
-                    ts.resize(2, '-');
-                    qs.resize(2, '-');
-                    break;
-                }
-                d = pre_d;
-                k = pre_k;
-                kk = pre_kk;
-                x = pre_x;
-            }
-            aln->aln_len = (int)ts.size();
-            aln->t_aln_str.assign(ts.rbegin(), ts.rend());
-            aln->q_aln_str.assign(qs.rbegin(), qs.rend());
-            return true;
-        }
-    }
-    return false;
 }
 
 }  // namespace np2

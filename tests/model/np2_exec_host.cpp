@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "../../nextpolish_amd/csrc/np2_exec.h"
+#include "np2_lq_host.h"
 
 namespace np2 {
 namespace {
@@ -66,6 +67,11 @@ struct HostGraph {
 
 class HostExec : public Exec {
   public:
+    bool run_lq_aligned(const LqAlignInput& in, std::string* cons_rev, std::string* err) override {
+        LqInput li;
+        lq_concatenate_host(in, &li);      // sequential alignment + piece rules (tests/model/np2_lq_host.cpp)
+        return run_lq(li, cons_rev, err);
+    }
     bool run_lq(const LqInput& in, std::string* cons_rev, std::string* err) override {
         const uint32_t n_streams = (uint32_t)in.t.size();
         const uint32_t n_cols = in.t_len + 1;

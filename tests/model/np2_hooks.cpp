@@ -1,5 +1,6 @@
 // C hooks around host-side pieces of the long-read path so the tests can compare them with the functions the
 // compiled reference exports (poa_to_consensus, align).  TEST INFRASTRUCTURE ONLY.
+#include "np2_lq_host.h"
 #include <cstring>
 
 #include "../../nextpolish_amd/csrc/np2_lq.h"
