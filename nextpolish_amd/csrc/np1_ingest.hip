@@ -3,7 +3,7 @@
 // sam_itr_next, source/lib/contig.c:172-174,692-694):
 //
 //   k_inflate        one wave per BGZF block (np_inflate_dev.h)                        compressed -> inflated BAM bytes
-//   k_chase<false>   one lane per anchor segment: hop from record to record            records per segment
+//   k_chase<false>   one wave per anchor segment: hop from record to record (LDS window)  records per segment
 //   k_chase<true>    the same walk, writing the byte offset of every record            record offsets
 //   k_rec_measure    one lane per record: the iterator's overlap test + pool sizes     keep flag, #CIGAR words, seq / qual bytes
 //   k_rec_scatter    one lane per kept record: fixed fields -> SoA, CIGAR / bases / qualities -> aligned pools
@@ -77,24 +77,49 @@ __global__ __launch_bounds__(256, 4) void k_inflate_prof(const uint8_t* __restri
     }
 }
 
-// one lane per segment [beg, end) of the inflated stream that starts on a record boundary
+// One WAVE per segment [beg, end) of the inflated stream that starts on a record boundary.  The hop from record to record is a
+// chain of dependent 4-byte reads a few hundred bytes apart: straight from HBM every hop costs a memory round trip, so the wave
+// pulls the stream through an 8 KiB LDS window with coalesced 16-byte loads and hops inside it (the hop is wave-uniform: the
+// position lives in scalar registers, the size word is an LDS broadcast); record offsets leave 64 at a time, one per lane.
+constexpr uint32_t CHASE_WIN = 8192;
 template <bool FILL>
-__global__ __launch_bounds__(64) void k_chase(const uint8_t* __restrict__ u, const Segment* __restrict__ segs, uint32_t n_segs, uint32_t* __restrict__ counts,
-                                              const uint64_t* __restrict__ rec_base, uint64_t* __restrict__ rec_off, uint32_t* __restrict__ rec_seg,
-                                              uint32_t* __restrict__ err) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_chase(const uint8_t* __restrict__ u, const Segment* __restrict__ segs, uint32_t n_segs, uint32_t* __restrict__ counts,
+                                               const uint64_t* __restrict__ rec_base, uint64_t* __restrict__ rec_off, uint32_t* __restrict__ rec_seg,
+                                               uint32_t* __restrict__ err) {
+    __shared__ uint4 win4[4][CHASE_WIN / 16 + 1];
+    const uint32_t wave = npdev::uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t i = blockIdx.x * 4 + wave;
     if (i >= n_segs) return;
     const Segment s = segs[i];
+    const uint8_t* win = reinterpret_cast<const uint8_t*>(win4[wave]);
     uint64_t p = s.beg, n = 0;
     const uint64_t base = FILL ? rec_base[i] : 0;
+    uint64_t wbase = ~0ull;          // 16-byte aligned stream offset of the window's first byte
+    uint64_t mine = 0;               // FILL: offset of record (n & ~63) + lane
+    bool bad = false;
     while (p < s.end) {
-        const uint32_t bs = ld32(u + p);
-        if (bs < 32 || bs > (1u << 28) || p + 4 + bs > s.end) { atomicOr(err, IG_ERR_CHAIN); break; }
-        if (FILL) { rec_off[base + n] = p; rec_seg[base + n] = i; }
+        if (wbase == ~0ull || p < wbase || p + 4 > wbase + CHASE_WIN) {     // (re)load the window at p
+            wbase = p & ~15ull;
+            const uint4* src = reinterpret_cast<const uint4*>(u + wbase);   // the inflated buffer has slack behind its end
+#pragma unroll
+            for (uint32_t t = 0; t < CHASE_WIN / 16 / 64; ++t) win4[wave][t * 64 + lane] = src[t * 64 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t o = (uint32_t)(p - wbase);
+        const uint32_t bs = npdev::uni((uint32_t)win[o] | (uint32_t)win[o + 1] << 8 | (uint32_t)win[o + 2] << 16 | (uint32_t)win[o + 3] << 24);
+        if (bs < 32 || bs > (1u << 28) || p + 4 + bs > s.end) { bad = true; break; }
+        if (FILL) {
+            if (lane == (uint32_t)(n & 63u)) mine = p;
+            if ((n & 63u) == 63u) { rec_off[base + (n & ~63ull) + lane] = mine; rec_seg[base + (n & ~63ull) + lane] = i; }
+        }
         ++n;
         p += 4ull + bs;
     }
-    if (!FILL) counts[i] = (uint32_t)n;
+    if (bad && lane == 0) atomicOr(err, IG_ERR_CHAIN);
+    if (FILL) {
+        if ((n & 63u) && lane < (uint32_t)(n & 63u)) { rec_off[base + (n & ~63ull) + lane] = mine; rec_seg[base + (n & ~63ull) + lane] = i; }
+    } else if (lane == 0) counts[i] = (uint32_t)n;
 }
 
 // record layout (SAMv1 4.2): block_size refID pos l_read_name mapq bin n_cigar_op flag l_seq next_refID next_pos tlen | name cigar seq qual aux
@@ -419,7 +444,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
     b->out_pinned = false;
     Scratch& W = *scr;
     if (b->draft.ensure(b->G + 64) || b->ctg_off.ensure(4 * (size_t)(nc + 1)) || b->read_begin.ensure(8 * (size_t)(nc + 2)) ||
-        W.comp.ensure(S.comp_bytes + 4096) || W.inflated.ensure(S.inflated_bytes + 4096) || W.blocks.ensure(sizeof(npdev::BlockDesc) * (size_t)(n_blocks + 1)) ||
+        W.comp.ensure(S.comp_bytes + 4096) || W.inflated.ensure(S.inflated_bytes + 2 * CHASE_WIN + 4096) || W.blocks.ensure(sizeof(npdev::BlockDesc) * (size_t)(n_blocks + 1)) ||
         W.status.ensure(4 * (size_t)(n_blocks + 1)) || W.segs.ensure(sizeof(Segment) * (size_t)(n_segs + 1)) || W.counts.ensure(4 * (size_t)(n_segs + 2)) ||
         W.rec_base.ensure(8 * (size_t)(n_segs + 2)) || W.first_seg.ensure(4 * (size_t)(nc + 2)) || W.small.ensure(256) ||
         W.scan_tmp.ensure(8 * (np1k::scan_tmp_words((uint64_t)n_segs + 1) + 8)))
@@ -440,7 +465,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
         HIPCHK(hipMemcpyAsync(W.h_status.data(), W.status.p, 4 * (size_t)n_blocks, hipMemcpyDeviceToHost, q));
     }
     if (n_segs) {
-        k_chase<false><<<nblk(n_segs, 64), 64, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, W.counts.as<uint32_t>(), nullptr, nullptr, nullptr, d_err);
+        k_chase<false><<<nblk(n_segs, 4), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, W.counts.as<uint32_t>(), nullptr, nullptr, nullptr, d_err);
         np1k::launch_scan_rows(q, W.counts.as<uint32_t>(), n_segs, W.rec_base.as<uint64_t>(), W.scan_tmp.as<uint64_t>(), &d_tot[0]);
         HIPCHK(hipMemcpyAsync(&n_rec, &d_tot[0], 8, hipMemcpyDeviceToHost, q));
     } else {
@@ -461,7 +486,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
     }
     if (patched && n_segs) {
         HIPCHK(hipMemsetAsync(d_err, 0, 4, q));
-        k_chase<false><<<nblk(n_segs, 64), 64, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, W.counts.as<uint32_t>(), nullptr, nullptr, nullptr, d_err);
+        k_chase<false><<<nblk(n_segs, 4), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, W.counts.as<uint32_t>(), nullptr, nullptr, nullptr, d_err);
         np1k::launch_scan_rows(q, W.counts.as<uint32_t>(), n_segs, W.rec_base.as<uint64_t>(), W.scan_tmp.as<uint64_t>(), &d_tot[0]);
         HIPCHK(hipMemcpyAsync(&n_rec, &d_tot[0], 8, hipMemcpyDeviceToHost, q));
         HIPCHK(hipStreamSynchronize(q));
@@ -475,7 +500,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
     uint64_t totals[4] = {0, 0, 0, 0};   // kept records, cigar words, seq bytes, qual bytes
     uint32_t h_small[2] = {0, 0};
     if (n_rec) {
-        k_chase<true><<<nblk(n_segs, 64), 64, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, nullptr, W.rec_base.as<uint64_t>(), W.rec_off.as<uint64_t>(),
+        k_chase<true><<<nblk(n_segs, 4), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, nullptr, W.rec_base.as<uint64_t>(), W.rec_off.as<uint64_t>(),
                                                      W.rec_seg.as<uint32_t>(), d_err);
         k_rec_measure<<<nblk(n_rec, 256), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.rec_off.as<uint64_t>(), W.rec_seg.as<uint32_t>(), W.segs.as<Segment>(), n_rec,
                                                       with_qual ? 1 : 0, W.keep.as<uint32_t>(), W.ncw.as<uint32_t>(), W.seqb.as<uint32_t>(), W.qualb.as<uint32_t>(),

@@ -21,7 +21,7 @@ arr = (C.c_void_p * len(sts))(*[s.handle for s in sts])
 assert L.np1_streams_write_files(arr, len(sts), fa.encode(), bam.encode(), 1) == 0
 print("generated %.0f Mb %.0fx in %.1f s; BAM %.0f MB" % (MB, DEPTH, time.time() - t, os.path.getsize(bam) / 1e6), flush=True)
 exe = os.path.join(here, "..", "..", "nextpolish_amd", "bin", "nextpolish1")
-for env in (dict(NP1_TIMING="1"), dict(NP1_TIMING="1", NP1_LANES="3"), dict(NP1_INGEST="host"), {}):
+for env in (dict(NP1_TIMING="1"), dict(NP1_LANES="3", NP1_LOADERS="4"), dict(NP1_LANES="3", NP1_LOADERS="6"), dict(NP1_LANES="4", NP1_LOADERS="6"), dict(NP1_INGEST="host"), {}):
     best = 1e9
     for k in range(3):
         t = time.time()
