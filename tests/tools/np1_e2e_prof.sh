@@ -20,14 +20,6 @@ PY
 EXE=$PWD/nextpolish_amd/bin/nextpolish1
 OUT=$PWD/gpurun_out/e2e_prof
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
+OLDPWD_=$PWD; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT -o e2e -- $EXE scorechain /tmp/prof_g.fa /tmp/prof_r.bam > /dev/null 2> $OUT/cli.err || true
-python - <<PY
-import csv, glob
-f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)
-rows = list(csv.DictReader(open(f[0])))
-rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-print("%-60s %8s %12s %10s %6s" % ("kernel", "calls", "total ms", "avg us", "%"))
-for r in rows[:25]:
-    print("%-60s %8s %12.3f %10.1f %6.1f" % (r["Name"][:60], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
-PY
+python $OLDPWD_/tools/rocprof_summary.py stats $OUT/e2e_results.db
