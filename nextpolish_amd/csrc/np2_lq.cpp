@@ -3,7 +3,7 @@
 // the link-graph consensus on the concatenation" (the graph + DP run in the window executor, i.e. on the GPU), and
 // the splice of the accepted seeds back into the window consensus.
 //
-// Restated from: generate_lqseqs_from_tags (source/lib/ctg_cns.c:822-984), count_kmers / count_kscore (:405-449),
+// Behaviour of: generate_lqseqs_from_tags (source/lib/ctg_cns.c:822-984), count_kmers / count_kscore (:405-449),
 // remove_short_lqseq (:620-633), generate_consensus_trimed (:1287-1414), iterate_generate_consensus_trimed
 // (:1425-1473), update_consensus_trimed (:1165-1211).  Candidate ordering uses a stable sort: the reference calls
 // glibc qsort, which is a merge sort for these sizes.
@@ -39,111 +39,132 @@ struct Region {      // lqseq (ctg_cns.h:73-90)
     std::vector<Cand> seqs;
 };
 
-// the 65 536-bin table is cleared through the list of bins the previous call touched (the reference memsets 128 KB
-// per call; the counts are the same)
-thread_local std::vector<uint16_t> g_touched;
-thread_local std::vector<uint16_t> g_kmers;   // the table itself, one per host thread (paired with g_touched)
-void count_kmers(const Region& lq, std::vector<uint16_t>& kmers, int c, int l) {
-    for (uint16_t k : g_touched) kmers[k] = 0;
-    g_touched.clear();
-    for (int j = 0; j < std::min(lq.len, c); ++j) {
-        const Cand& cd = lq.seqs[(size_t)j];
-        if (cd.len < (uint32_t)KMER_LEN) continue;
-        const int s = l && cd.len > (uint32_t)KMER_RANGE ? (int)cd.len - KMER_RANGE : 0;
-        uint16_t kmer = 0;
-        for (int k = 0; k < (int)std::min<uint32_t>(cd.len, KMER_RANGE) - KMER_LEN; ++k) {
-            if (k) kmer = (uint16_t)(kmer << 2 | np2k::base_to_int((unsigned char)cd.seq[(size_t)(s + k + KMER_LEN - 1)]));
-            else
-                for (int index = 0; index < KMER_LEN; ++index) kmer = (uint16_t)(kmer << 2 | np2k::base_to_int((unsigned char)cd.seq[(size_t)(s + k + index)]));
-            if (kmers[kmer]++ == 0) g_touched.push_back(kmer);
-        }
-    }
-}
-void count_kscore(Region& lq, const std::vector<uint16_t>& kmers, int l) {
-    for (int j = 0; j < lq.len; ++j) {
-        Cand& cd = lq.seqs[(size_t)j];
-        cd.kscore = 0;
-        if (cd.len < (uint32_t)KMER_LEN) continue;
-        const int s = l && cd.len > (uint32_t)KMER_RANGE ? (int)cd.len - KMER_RANGE : 0;
-        uint16_t kmer = 0;
-        for (int k = 0; k < (int)std::min<uint32_t>(cd.len, KMER_RANGE) - KMER_LEN; ++k) {
-            if (k) kmer = (uint16_t)(kmer << 2 | np2k::base_to_int((unsigned char)cd.seq[(size_t)(s + k + KMER_LEN - 1)]));
-            else
-                for (int index = 0; index < KMER_LEN; ++index) kmer = (uint16_t)(kmer << 2 | np2k::base_to_int((unsigned char)cd.seq[(size_t)(s + k + index)]));
-            cd.kscore = (uint16_t)(cd.kscore + kmers[kmer]);
-        }
+// ---- candidate ranking (what the reference does in ctg_cns.c:405-449,620-633,880-960, reformulated) -------------------------------
+//
+// A candidate is scored by how well the 8-mers of its first 40 bases (and, when the region is long, of its last 40) are
+// shared with the other candidates: score = sum over its window's 8-mers of how often that 8-mer occurs in the windows of
+// the region's candidates.  The reference fills a 65 536-bin table per region; here the occurrences are sorted once and a
+// candidate's 8-mers are looked up by binary search (<= 60 candidates x 32 8-mers).  Scores are 16-bit and wrap like the
+// reference's counters.  Order matters everywhere below (stable sorts, "last of equals" cuts), so the candidates are ranked
+// through a permutation and moved once at the end.
+
+// 2-bit codes of the 8-mers of a candidate's head (or tail) window, in window order.  The window holds min(len, 40) bases
+// and contributes that many minus 8 codes (the loop bound of the reference: the last 8-mer of the window is not used).
+void window_codes(const Cand& c, bool tail, std::vector<uint16_t>* out) {
+    out->clear();
+    if (c.len < (uint32_t)KMER_LEN) return;
+    const uint32_t span = std::min<uint32_t>(c.len, KMER_RANGE);
+    const uint32_t first = tail && c.len > (uint32_t)KMER_RANGE ? c.len - KMER_RANGE : 0;
+    if (span <= (uint32_t)KMER_LEN) return;
+    uint16_t code = 0;
+    for (uint32_t p = 0; p < (uint32_t)KMER_LEN; ++p) code = (uint16_t)(code << 2 | np2k::base_to_int((unsigned char)c.seq[first + p]));
+    out->push_back(code);
+    for (uint32_t k = 1; k < span - KMER_LEN; ++k) {
+        code = (uint16_t)(code << 2 | np2k::base_to_int((unsigned char)c.seq[first + k + KMER_LEN - 1]));
+        out->push_back(code);
     }
 }
 
-void reverse_cands(Region& r) { std::reverse(r.seqs.begin(), r.seqs.begin() + std::max(r.len, 0)); }
-void sort_by_len_asc(Region& r) {
-    std::stable_sort(r.seqs.begin(), r.seqs.begin() + r.len, [](const Cand& a, const Cand& b) { return a.len < b.len; });
-}
-void sort_by_len_desc(Region& r) {
-    std::stable_sort(r.seqs.begin(), r.seqs.begin() + r.len, [](const Cand& a, const Cand& b) { return a.len > b.len; });
-}
-void sort_by_kscore_desc(Region& r) {
-    std::stable_sort(r.seqs.begin(), r.seqs.begin() + r.len, [](const Cand& a, const Cand& b) { return a.kscore > b.kscore; });
+struct Ranker {
+    Region& r;
+    std::vector<uint16_t> at;        // at[i] = index into r.seqs of the candidate ranked i; the first `live` are in play
+    int live;
+    explicit Ranker(Region& reg) : r(reg), live(reg.len) {
+        at.resize((size_t)std::max(reg.len, 0));
+        for (size_t i = 0; i < at.size(); ++i) at[i] = (uint16_t)i;
+    }
+    uint32_t len_at(int i) const { return r.seqs[at[(size_t)i]].len; }
+    template <class Less> void stable_by(Less less) {
+        std::stable_sort(at.begin(), at.begin() + live, [&](uint16_t a, uint16_t b) { return less(r.seqs[a], r.seqs[b]); });
+    }
+    void flip() { std::reverse(at.begin(), at.begin() + std::max(live, 0)); }
+    // moves the candidates into ranked order (the rest of the stage indexes r.seqs by rank)
+    void commit() {
+        std::vector<Cand> tmp(r.seqs.size());
+        for (size_t i = 0; i < at.size(); ++i) tmp[i] = std::move(r.seqs[at[i]]);
+        for (size_t i = at.size(); i < r.seqs.size(); ++i) tmp[i] = std::move(r.seqs[i]);
+        r.seqs.swap(tmp);
+        r.len = live;
+    }
+
+    // k-mer support of every candidate in play; `tail` selects the window
+    void add_support(bool tail, std::vector<uint32_t>* total) {
+        static thread_local std::vector<uint16_t> pool, mine;
+        pool.clear();
+        const int voters = std::min(live, LQSEQ_MAX_CAN_COUNT);
+        for (int i = 0; i < voters; ++i) {
+            window_codes(r.seqs[at[(size_t)i]], tail, &mine);
+            pool.insert(pool.end(), mine.begin(), mine.end());
+        }
+        std::sort(pool.begin(), pool.end());
+        for (int i = 0; i < live; ++i) {
+            window_codes(r.seqs[at[(size_t)i]], tail, &mine);
+            uint32_t sum = 0;
+            for (uint16_t c : mine) {
+                const auto range = std::equal_range(pool.begin(), pool.end(), c);
+                sum += (uint32_t)(range.second - range.first);
+            }
+            (*total)[(size_t)i] += sum & 0xffffu;      // each pass is a 16-bit counter of its own
+        }
+    }
+};
+
+// Regions found by deletions: the shortest candidates are cut while they are outliers against the upper quartile or against
+// their neighbour, at most 30 stay, shortest first (ctg_cns.c:620-633).
+void remove_short(Region& r) {
+    Ranker k(r);
+    k.stable_by([](const Cand& a, const Cand& b) { return a.len > b.len; });
+    const int quart = k.live / 4;
+    while (k.live > quart && (k.len_at(k.live - 1) < k.len_at(quart) / 2 || k.len_at(k.live - 1) * 1.4 < k.len_at(k.live - 2))) --k.live;
+    if (quart == k.live) k.live = 0;
+    if (k.live > LQSEQ_MAX_COUNT) k.live = LQSEQ_MAX_COUNT;
+    k.flip();
+    k.commit();
 }
 
-void remove_short(Region& r) {   // ctg_cns.c:620-633
-    sort_by_len_desc(r);
-    const int k = r.len / 4;
-    while (r.len > k && (r.seqs[(size_t)r.len - 1].len < r.seqs[(size_t)k].len / 2 ||
-                         r.seqs[(size_t)r.len - 1].len * 1.4 < r.seqs[(size_t)r.len - 2].len)) --r.len;
-    if (k == r.len) r.len = 0;
-    if (r.len > LQSEQ_MAX_COUNT) r.len = LQSEQ_MAX_COUNT;
-    reverse_cands(r);
-}
-
-// shared tail of the two candidate routines: length-outlier trimming, k-mer ranking, choice of the POA inputs and the
-// pseudo-seed.  min_span: indexe - indexs must exceed it (3, or 1 in the HiFi variant).  Returns false when the region
-// is dropped (r.len = 0).
-bool rank_and_seed(Region& r, std::vector<uint16_t>& kmers, bool trim, int min_span) {
-    int k;
+// Length outliers out (optional), support scores, best-supported candidates first, how many of them are aligned later
+// (indexs .. indexe) and which ones seed the partial-order consensus.  min_span: indexe - indexs must exceed it (3, or 1 in
+// the HiFi variant).  Returns false when the region is dropped (r.len = 0).
+bool rank_and_seed(Region& r, bool trim, int min_span) {
+    Ranker k(r);
     if (trim) {
-        sort_by_len_asc(r);
-        k = r.len / 2;
-        while (r.len > k && (r.seqs[(size_t)r.len - 1].len > 2 * r.seqs[(size_t)k].len ||
-                             r.seqs[(size_t)r.len - 1].len >= 1.4 * r.seqs[(size_t)r.len - 2].len)) --r.len;
-        if (k == r.len) { r.len = 0; return false; }
-        k = r.len / 2;
-        if (r.seqs[0].len < r.seqs[(size_t)k].len / 2) {
-            reverse_cands(r);
-            while (r.seqs[(size_t)r.len - 1].len < r.seqs[(size_t)k].len / 2) --r.len;
-            if (k == r.len) { r.len = 0; return false; }
+        k.stable_by([](const Cand& a, const Cand& b) { return a.len < b.len; });
+        int mid = k.live / 2;
+        while (k.live > mid && (k.len_at(k.live - 1) > 2 * k.len_at(mid) || k.len_at(k.live - 1) >= 1.4 * k.len_at(k.live - 2))) --k.live;   // too long
+        if (mid == k.live) { r.len = 0; return false; }
+        mid = k.live / 2;
+        if (k.len_at(0) < k.len_at(mid) / 2) {        // too short: they are at the front, turn the list over and cut from the back
+            k.flip();
+            while (k.len_at(k.live - 1) < k.len_at(mid) / 2) --k.live;
+            if (mid == k.live) { r.len = 0; return false; }
         }
     }
-    count_kmers(r, kmers, LQSEQ_MAX_CAN_COUNT, 0);
-    count_kscore(r, kmers, 0);
-    unsigned kmaxlen = r.seqs[0].len;
-    if (kmaxlen > 100) {
-        uint16_t score[LQSEQ_MAX_CAN_COUNT];
-        for (int j = 0; j < r.len; ++j) score[r.seqs[(size_t)j].order] = r.seqs[(size_t)j].kscore;
-        count_kmers(r, kmers, LQSEQ_MAX_CAN_COUNT, 1);
-        count_kscore(r, kmers, 1);
-        for (int j = 0; j < r.len; ++j) r.seqs[(size_t)j].kscore = (uint16_t)(r.seqs[(size_t)j].kscore + score[r.seqs[(size_t)j].order]);
-    }
-    sort_by_kscore_desc(r);
-    kmaxlen = r.seqs[0].len;
-    unsigned klastscore, kmaxscore;
-    klastscore = kmaxscore = r.seqs[0].kscore;
-    int j;
-    for (k = j = 0; j < r.len; ++j) {
-        const Cand& cd = r.seqs[(size_t)j];
-        if ((unsigned)cd.kscore * 10 < kmaxscore || j >= LQSEQ_MAX_COUNT || (unsigned)cd.kscore * 2 < klastscore) break;
-        klastscore = cd.kscore;
-        if (j < KMER_MAX_SEQ && cd.kscore > kmaxscore * 0.8 && cd.len > kmaxlen) { kmaxlen = cd.len; k = j; }
+    std::vector<uint32_t> support((size_t)k.live, 0);
+    k.add_support(false, &support);
+    if (k.len_at(0) > 100) k.add_support(true, &support);
+    for (int i = 0; i < k.live; ++i) r.seqs[k.at[(size_t)i]].kscore = (uint16_t)support[(size_t)i];
+    k.stable_by([](const Cand& a, const Cand& b) { return a.kscore > b.kscore; });
+    k.commit();
+    // how far down the ranking the support holds up: stop at a tenth of the best score, at half of the previous one, or at 30
+    const unsigned top_score = r.seqs[0].kscore;
+    unsigned prev_score = top_score, longest = r.seqs[0].len;
+    int n_good = 0;
+    for (; n_good < r.len; ++n_good) {
+        const Cand& c = r.seqs[(size_t)n_good];
+        if ((unsigned)c.kscore * 10 < top_score || n_good >= LQSEQ_MAX_COUNT || (unsigned)c.kscore * 2 < prev_score) break;
+        prev_score = c.kscore;
+        if (n_good < KMER_MAX_SEQ && c.kscore > top_score * 0.8 && c.len > longest) longest = c.len;
     }
     r.indexs = 0;
-    r.indexe = (uint8_t)(kmaxlen > LQSEQ_MAX_REV_LEN && j > 6 ? 5 : j - 1);
+    r.indexe = (uint8_t)(longest > LQSEQ_MAX_REV_LEN && n_good > 6 ? 5 : n_good - 1);
     if (r.indexe - r.indexs <= min_span || (r.seqs[0].len > 20000 && r.len < LQSEQ_MAX_CAN_COUNT / 3)) { r.len = 0; return false; }
-    j = r.indexs;
-    if (r.seqs[0].len < 3000) k = j + 6 < r.indexe ? 6 : r.indexe - j + 1;
-    else k = j + 2 < r.indexe ? 2 : r.indexe - j + 1;
+    // pseudo-seed: partial-order consensus of the best six (two for long regions), the best candidate itself beyond 20 kb
+    const int first = r.indexs;
+    const int want = r.seqs[0].len < 3000 ? 6 : 2;
+    const int n_poa = first + want < r.indexe ? want : r.indexe - first + 1;
     if (r.seqs[0].len < 20000) {
         std::vector<std::string> v;
-        for (int q = 0; q < k; ++q) v.push_back(r.seqs[(size_t)(j + q)].seq);
+        for (int q = 0; q < n_poa; ++q) v.push_back(r.seqs[(size_t)(first + q)].seq);
         r.sudoseed = poa_consensus(v);
     } else {
         r.sudoseed = r.seqs[0].seq;
@@ -226,8 +247,6 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
     // ranking + pseudo-seed: the regions are independent of each other
     std::atomic<int> max_aln{0};
     np::parallel_for((size_t)count, 16, [&](size_t lo, size_t hi) {
-        if (g_kmers.size() != 65536) { g_kmers.assign(65536, 0); g_touched.clear(); }
-        std::vector<uint16_t>& kmers = g_kmers;
         int max_aln_length = 0;
         for (size_t i = lo; i < hi; ++i) {
             Region& r = lq[i];
@@ -250,7 +269,7 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
                     r.sudoseed_len = top.len;
                     r.len = -2;
                     r.l = 4;
-                } else if (!rank_and_seed(r, kmers, r.len > 4, 1)) {
+                } else if (!rank_and_seed(r, r.len > 4, 1)) {
                     continue;
                 }
                 if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
@@ -258,7 +277,7 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
             }
             if (r.l != 1 && r.l > 1 && r.len > 4) remove_short(r);
             if (r.len <= 4 || r.len < r.sudoseed_len * 0.5) { r.len = 0; continue; }
-            if (!rank_and_seed(r, kmers, true, 3)) continue;
+            if (!rank_and_seed(r, true, 3)) continue;
             if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
         }
         int cur = max_aln.load();
