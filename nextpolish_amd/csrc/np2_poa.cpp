@@ -1,12 +1,15 @@
-// Partial-order alignment consensus of a few candidate strings (pseudo-seed of a low-quality region).  (The pairwise
-// alignment of every candidate onto that seed runs on the device: np2_ond_dev.h.)  Host code: small, branchy, sequential graph
-// work on strings of a few hundred bases (the reference runs them on the CPU as well and they are not on the
-// per-column hot path).
+// Pseudo-seed of a low-quality region: partial-order alignment of a few candidate strings and the heaviest path through the
+// resulting graph.  Host code: a graph of a few hundred nodes that is re-threaded and re-ordered after every string --
+// pointer work with a strict visiting order, not data-parallel work (the pairwise alignment of every candidate onto the seed
+// runs on the device: np2_ond_dev.h).
 //
-// Restated from the behaviour of
-//   poa_to_consensus   source/lib/dag.c:658-694  (graph :24-70, NW to graph :261-300, toposort :469-508,
-//                                                 heaviest path with -0.5 * indegree :555-595)
-// including their integer widths (16-bit node ids and score back-pointers, 8-bit degrees).
+// The result has to equal the reference's poa_to_consensus (source/lib/dag.c:658-694) character for character, and that is
+// decided by details of its procedure: which of equal-scoring alignment moves wins (dag.c:261-300), which sink the alignment
+// ends in (:302-314), when a node is reused / joins an aligned group / is created (:345-405), the depth-first order in which
+// groups are emitted (:469-508; it decides ties of the two scans that walk "the first best in order"), 16-bit node ids, and
+// the path weight `support - 0.5 * indegree` in double (:555-595).  Those decisions are kept; the data layout is this file's
+// own: structure-of-arrays graph, edge support as one 64-bit mask (<= 50 strings), aligned groups as explicit id lists, one
+// flat score table with packed back-references.
 #include <algorithm>
 #include <cassert>
 #include <cstdint>
@@ -19,332 +22,263 @@
 namespace np2 {
 namespace {
 
-constexpr int SEQ_MAX_COUNT = 50;
-constexpr long SCORE_MATCH = 1, SCORE_MISMATCH = -2, SCORE_GAP = -2;
-inline long match_score(char a, char b) { return a == b ? SCORE_MATCH : SCORE_MISMATCH; }
+constexpr int MAX_STRINGS = 50;
+constexpr int32_t W_MATCH = 1, W_MISMATCH = -2, W_GAP = -2;
 
-struct PNode {
-    uint8_t base = 0;
-    uint8_t indegree = 0, outdegree = 0;
-    uint32_t inedge[SEQ_MAX_COUNT];
-    uint32_t outedge[SEQ_MAX_COUNT];
-    std::vector<uint16_t> alignedto;
-    int32_t best_pnode = -1;
-    double best_score = 0;
-};
-struct PEdge {
-    uint16_t innode_index = 0, outnode_index = 0;
-    uint8_t lable[SEQ_MAX_COUNT];
-    PEdge() { memset(lable, 0, sizeof(lable)); }
-};
-struct PScore {
-    uint16_t x = 0, y = 0;
-    long s = 0;
-};
-struct MatchRoute { int32_t x, y; };
+// ---- the alignment graph ----------------------------------------------------------------------------------------------
+struct PoGraph {
+    // nodes
+    std::vector<uint8_t> base;
+    std::vector<std::vector<uint32_t>> in, out;       // edge ids in the order they were attached
+    std::vector<std::vector<uint16_t>> peers;         // nodes aligned to this one (same column, other base), in joining order
+    // edges
+    std::vector<uint16_t> src, dst;
+    std::vector<uint64_t> support;                    // bit q: string q runs along this edge
+    // emission order of the nodes (sources first) and its inverse
+    std::vector<uint16_t> order, rank;
 
-struct Graph {
-    std::vector<PNode> nodes;
-    std::vector<PEdge> edges;
-    std::vector<uint16_t> sorted_nodes;
-    int32_t sorted_nodes_index = 0;
-    uint16_t node_count = 0;
-    uint32_t edge_count = 0;
-    int32_t insert_node(char base) {
-        if (nodes.size() <= node_count) nodes.resize(nodes.size() + 256);
-        nodes[node_count].base = (uint8_t)base;
-        ++node_count;
-        if (nodes.size() <= node_count) nodes.resize(nodes.size() + 256);
-        return node_count - 1;
+    size_t used = 0;                                   // nodes in use (the per-node vectors are kept and reused from region to region)
+    uint16_t n_nodes() const { return (uint16_t)used; }
+    void clear() { used = 0; src.clear(); dst.clear(); support.clear(); order.clear(); rank.clear(); }
+    uint16_t new_node(char b) {
+        if (used == base.size()) { base.push_back(0); in.emplace_back(); out.emplace_back(); peers.emplace_back(); }
+        base[used] = (uint8_t)b;
+        in[used].clear(); out[used].clear(); peers[used].clear();
+        return (uint16_t)used++;
     }
-    uint32_t insert_edge(uint16_t in, uint16_t out, uint8_t lable) {
-        if (edges.size() <= edge_count) edges.resize(edges.size() + 512);
-        edges[edge_count].innode_index = in;
-        edges[edge_count].outnode_index = out;
-        edges[edge_count].lable[lable] = 1;
-        ++edge_count;
-        if (edges.size() <= edge_count) edges.resize(edges.size() + 512);
-        return edge_count - 1;
+    void connect(uint16_t a, uint16_t b, int q) {
+        const uint32_t e = (uint32_t)src.size();
+        src.push_back(a); dst.push_back(b); support.push_back(1ull << q);
+        out[a].push_back(e);
+        in[b].push_back(e);
     }
-    // the graph object is kept per host thread and reused: only what the previous consensus touched is cleaned
-    void reset(size_t want_nodes, size_t want_edges) {
-        const size_t un = std::min(nodes.size(), (size_t)node_count + 2), ue = std::min(edges.size(), (size_t)edge_count + 2);
-        for (size_t i = 0; i < un; ++i) {
-            PNode& n = nodes[i];
-            n.base = 0; n.indegree = 0; n.outdegree = 0; n.alignedto.clear(); n.best_pnode = -1; n.best_score = 0;
+    // a run of fresh nodes for characters that align with nothing: returns through first / last the ends of the run
+    void chain(int q, const char* s, size_t n, int32_t* first, int32_t* last) {
+        for (size_t i = 0; i < n; ++i) {
+            const uint16_t v = new_node(s[i]);
+            if (*first == -1) *first = v;
+            else connect((uint16_t)*last, v, q);
+            *last = v;
         }
-        for (size_t i = 0; i < ue; ++i) { edges[i].innode_index = 0; edges[i].outnode_index = 0; memset(edges[i].lable, 0, sizeof(edges[i].lable)); }
-        node_count = 0;
-        edge_count = 0;
-        sorted_nodes_index = 0;
-        if (nodes.size() < want_nodes) nodes.resize(want_nodes);
-        if (edges.size() < want_edges) edges.resize(want_edges);
-        if (sorted_nodes.size() < nodes.size()) sorted_nodes.resize(nodes.size());
     }
-    void link(int32_t head, int32_t node, uint32_t e) {
-        nodes[(size_t)head].outedge[nodes[(size_t)head].outdegree++] = e;
-        nodes[(size_t)node].inedge[nodes[(size_t)node].indegree++] = e;
-    }
+    void reorder();
 };
 
-void insert_unmatched_nodes(size_t seq_index, const char* seq, size_t seq_len, Graph* g, int32_t* firstnode, int32_t* headnode) {
-    for (size_t i = 0; i < seq_len; ++i) {
-        const uint16_t node_index = (uint16_t)g->insert_node(seq[i]);
-        if (*firstnode == -1) {
-            *firstnode = node_index;
-        } else {
-            const uint32_t e = g->insert_edge((uint16_t)*headnode, node_index, (uint8_t)seq_index);
-            g->link(*headnode, node_index, e);
-        }
-        *headnode = node_index;
+// Emission order: aligned groups are the units; a group is a source when its representative (or, only if the representative has
+// no incoming edge at all, its peers) has no incoming edge; sources are taken in ascending group number, and from each one a
+// depth-first walk (successor edges pushed in attachment order, the representative's before its peers') emits groups when they
+// are finished, filling the order from the back.
+void PoGraph::reorder() {
+    const uint16_t n = n_nodes();
+    std::vector<int32_t> group_of((size_t)n, -1);
+    std::vector<uint16_t> head;                        // representative node of every group = its lowest-numbered member seen first
+    for (uint16_t v = 0; v < n; ++v) {
+        if (group_of[v] != -1) continue;
+        const int32_t g = (int32_t)head.size();
+        head.push_back(v);
+        group_of[v] = g;
+        for (uint16_t p : peers[v]) group_of[p] = g;
     }
-}
-
-uint16_t predecessors(const Graph& g, uint16_t i) {
-    uint16_t c = g.nodes[i].indegree;
-    for (size_t j = 0; j < g.nodes[i].alignedto.size() && c == 0; ++j) c += g.nodes[g.nodes[i].alignedto[j]].indegree;
-    return c;
-}
-
-void topo_visit(int32_t found, uint16_t pnid_count, const std::vector<uint16_t>& pn_to_nodes, const std::vector<int32_t>& node_to_pn,
-                std::vector<int8_t>& completed, Graph* g) {
-    static thread_local std::vector<int8_t> started;
-    static thread_local std::vector<uint16_t> stack;
-    started.assign(pnid_count, -1);
-    stack.clear();
-    stack.push_back((uint16_t)found);
-    while (!stack.empty()) {
-        const uint16_t pnid = stack.back();
-        stack.pop_back();
-        if (completed[pnid] == 1) continue;
-        const PNode& head = g->nodes[pn_to_nodes[pnid]];
-        if (started[pnid] != -1) {
-            completed[pnid] = 1;
-            g->sorted_nodes[(size_t)g->sorted_nodes_index--] = pn_to_nodes[pnid];
-            for (size_t j = 0; j < head.alignedto.size(); ++j) g->sorted_nodes[(size_t)g->sorted_nodes_index--] = head.alignedto[j];
-            started[pnid] = -1;
-            continue;
-        }
-        started[pnid] = 1;
-        stack.push_back(pnid);
-        for (uint16_t k = 0; k < head.outdegree; ++k) stack.push_back((uint16_t)node_to_pn[g->edges[head.outedge[k]].outnode_index]);
-        for (size_t j = 0; j < head.alignedto.size(); ++j) {
-            const PNode& n = g->nodes[head.alignedto[j]];
-            for (uint16_t k = 0; k < n.outdegree; ++k) stack.push_back((uint16_t)node_to_pn[g->edges[n.outedge[k]].outnode_index]);
-        }
-    }
-}
-
-void toposort(Graph* g) {
-    static thread_local std::vector<int32_t> node_to_pn;
-    static thread_local std::vector<uint16_t> pn_to_nodes;
-    node_to_pn.assign(g->node_count, -1);
-    pn_to_nodes.assign(g->node_count, 0);
-    uint16_t cur_pnid = 0;
-    for (uint16_t i = 0; i < g->node_count; ++i) {
-        if (node_to_pn[i] == -1) {
-            pn_to_nodes[cur_pnid] = i;
-            node_to_pn[i] = cur_pnid;
-            for (size_t j = 0; j < g->nodes[i].alignedto.size(); ++j) node_to_pn[g->nodes[i].alignedto[j]] = cur_pnid;
-            ++cur_pnid;
-        }
-    }
-    static thread_local std::vector<int8_t> completed;
-    completed.assign(cur_pnid, -1);
-    g->sorted_nodes_index = (int32_t)g->node_count - 1;
-    while (g->sorted_nodes_index >= 0) {
-        int32_t found = -1;
-        for (uint16_t i = 0; i < cur_pnid; ++i)
-            if (completed[i] == -1 && predecessors(*g, pn_to_nodes[i]) == 0) { found = i; break; }
-        assert(found != -1);
-        topo_visit(found, cur_pnid, pn_to_nodes, node_to_pn, completed, g);
-    }
-}
-
-void align_seq_to_graph(uint16_t x, uint16_t y, size_t seq_index, const char* seq, Graph* g) {
-    // ---- score table ((x + 1) x (y + 1)), row 0 = before any node (score_init, dag.c:88-138)
-    const size_t W = (size_t)y + 1;
-    static thread_local std::vector<PScore> tab;
-    tab.assign(((size_t)x + 1) * W, PScore());
-    auto S = [&](size_t i, size_t j) -> PScore& { return tab[i * W + j]; };
-    for (size_t i = 0; i < W; ++i) S(0, i).s = (long)i * SCORE_GAP;
-    static thread_local std::vector<uint16_t> sorted_nodes_index;
-    sorted_nodes_index.assign(g->node_count, 0);
-    for (uint16_t i = 0; i < g->node_count; ++i) {
-        const uint16_t node_index = g->sorted_nodes[i];
-        sorted_nodes_index[node_index] = i;
-        long bs;
-        const PNode& nd = g->nodes[node_index];
-        if (nd.indegree == 0) bs = 0;
-        else {
-            bs = S((size_t)sorted_nodes_index[g->edges[nd.inedge[0]].innode_index] + 1, 0).s;
-            for (uint16_t k = 1; k < nd.indegree; ++k) {
-                const long s_ = S((size_t)sorted_nodes_index[g->edges[nd.inedge[k]].innode_index] + 1, 0).s;
-                if (s_ > bs) bs = s_;
+    const size_t n_groups = head.size();
+    std::vector<int8_t> finished(n_groups, 0), open(n_groups, 0);
+    order.assign(n, 0);
+    int32_t slot = (int32_t)n - 1;                      // next free place, from the back
+    auto blocked = [&](uint16_t v) {                    // does anything still have to come before this group?
+        size_t c = in[v].size();
+        for (size_t j = 0; j < peers[v].size() && c == 0; ++j) c += in[peers[v][j]].size();
+        return c != 0;
+    };
+    std::vector<uint16_t> stack;
+    while (slot >= 0) {
+        int32_t start = -1;
+        for (size_t g = 0; g < n_groups; ++g)
+            if (!finished[g] && !blocked(head[g])) { start = (int32_t)g; break; }
+        assert(start != -1);
+        std::fill(open.begin(), open.end(), 0);
+        stack.assign(1, (uint16_t)start);
+        while (!stack.empty()) {
+            const uint16_t g = stack.back();
+            stack.pop_back();
+            if (finished[g]) continue;
+            const uint16_t v = head[g];
+            if (open[g]) {                              // second visit: everything below is out, emit the group
+                finished[g] = 1;
+                order[(size_t)slot--] = v;
+                for (uint16_t p : peers[v]) order[(size_t)slot--] = p;
+                open[g] = 0;
+                continue;
             }
-        }
-        S((size_t)i + 1, 0).s = bs + SCORE_GAP;
-    }
-    // ---- fill (align_seq_to_graph_updatescore, dag.c:261-300)
-    for (g->sorted_nodes_index = 0; g->sorted_nodes_index < g->node_count; ++g->sorted_nodes_index) {
-        const uint16_t node_index = g->sorted_nodes[(size_t)g->sorted_nodes_index];
-        const PNode& nd = g->nodes[node_index];
-        const uint16_t i = sorted_nodes_index[node_index];
-        for (uint16_t j = 0; j < y; ++j) {
-            long bests = S((size_t)i + 1, j).s + SCORE_GAP;
-            uint16_t bestx = (uint16_t)(i + 1), besty = j;
-            for (uint16_t k = 0; k < nd.indegree; ++k) {
-                const int32_t pi = sorted_nodes_index[g->edges[nd.inedge[k]].innode_index];
-                const long b1 = S((size_t)pi + 1, (size_t)j + 1).s + SCORE_GAP;
-                const long b2 = S((size_t)pi + 1, j).s + match_score(seq[j], (char)nd.base);
-                if (b1 > bests && b1 >= b2) { bests = b1; bestx = (uint16_t)(pi + 1); besty = (uint16_t)(j + 1); }
-                else if (b2 > bests && b2 >= b1) { bests = b2; bestx = (uint16_t)(pi + 1); besty = j; }
-            }
-            if (nd.indegree == 0) {
-                const long b1 = S(0, (size_t)j + 1).s + SCORE_GAP;
-                const long b2 = S(0, j).s + match_score(seq[j], (char)nd.base);
-                if (b1 > bests && b1 >= b2) { bests = b1; bestx = 0; besty = (uint16_t)(j + 1); }
-                else if (b2 > bests && b2 >= b1) { bests = b2; bestx = 0; besty = j; }
-            }
-            PScore& c = S((size_t)i + 1, (size_t)j + 1);
-            c.s = bests; c.x = bestx; c.y = besty;
+            open[g] = 1;
+            stack.push_back(g);
+            for (uint32_t e : out[v]) stack.push_back((uint16_t)group_of[dst[e]]);
+            for (uint16_t p : peers[v])
+                for (uint32_t e : out[p]) stack.push_back((uint16_t)group_of[dst[e]]);
         }
     }
-    // ---- best end (dag.c:302-314)
-    uint16_t bestx = 0;
+    rank.assign(n, 0);
+    for (uint16_t i = 0; i < n; ++i) rank[order[i]] = i;
+}
+
+// ---- string against graph ----------------------------------------------------------------------------------------------
+// Score table: row 0 = before any node, row r + 1 = node order[r]; column c = c characters of the string consumed.  A cell keeps
+// its score and the cell it was reached from (row, column packed into 32 bits; the two border lines point at the origin).
+struct Cell { int32_t score; uint16_t from_row, from_col; };
+
+struct Step { int32_t node, chr; };     // one column of the alignment: graph node and / or string position (-1 = none)
+
+void add_string(PoGraph& g, int q, const char* s, uint16_t len) {
+    const uint16_t n = g.n_nodes();
+    const size_t width = (size_t)len + 1;
+    static thread_local std::vector<Cell> tab;
+    tab.assign(((size_t)n + 1) * width, Cell{0, 0, 0});
+    auto at = [&](size_t row, size_t col) -> Cell& { return tab[row * width + col]; };
+    for (size_t c = 0; c < width; ++c) at(0, c).score = (int32_t)c * W_GAP;
+    // left border: the best predecessor's border value plus a gap (sources start from 0)
+    for (uint16_t r = 0; r < n; ++r) {
+        const uint16_t v = g.order[r];
+        int32_t best = 0;
+        bool any = false;
+        for (uint32_t e : g.in[v]) {
+            const int32_t x = at((size_t)g.rank[g.src[e]] + 1, 0).score;
+            if (!any || x > best) { best = x; any = true; }
+        }
+        at((size_t)r + 1, 0).score = best + W_GAP;
+    }
+    // interior.  Moves into (row, c + 1): stay on the node and take a character (the default), or come from a predecessor row
+    // either skipping this node's character pairing (gap) or pairing the character with the node.  A move replaces the current
+    // choice only if it is strictly better, and of a predecessor's two moves the gap goes first when they tie.
+    for (uint16_t r = 0; r < n; ++r) {
+        const uint16_t v = g.order[r];
+        const char vb = (char)g.base[v];
+        const size_t row = (size_t)r + 1;
+        const bool source = g.in[v].empty();
+        for (uint16_t c = 0; c < len; ++c) {
+            Cell pick{at(row, c).score + W_GAP, (uint16_t)row, c};
+            auto offer = [&](size_t prow) {
+                const int32_t skip = at(prow, (size_t)c + 1).score + W_GAP;
+                const int32_t pair = at(prow, c).score + (s[c] == vb ? W_MATCH : W_MISMATCH);
+                if (skip > pick.score && skip >= pair) pick = Cell{skip, (uint16_t)prow, (uint16_t)(c + 1)};
+                else if (pair > pick.score && pair >= skip) pick = Cell{pair, (uint16_t)prow, c};
+            };
+            for (uint32_t e : g.in[v]) offer((size_t)g.rank[g.src[e]] + 1);
+            if (source) offer(0);
+            at(row, (size_t)c + 1) = pick;
+        }
+    }
+    // the alignment ends in a sink: the first one in order with the best full-length score
+    size_t row = 0;
     {
-        long bests = 0;
-        uint16_t seen = 0;
-        for (uint16_t i = 0; i < g->node_count; ++i) {
-            if (g->nodes[g->sorted_nodes[i]].outdegree == 0) {
-                const long b = S((size_t)i + 1, y).s;
-                if (seen == 0 || b > bests) { bestx = (uint16_t)(i + 1); bests = b; seen = 1; }
+        int32_t best = 0;
+        bool any = false;
+        for (uint16_t r = 0; r < n; ++r)
+            if (g.out[g.order[r]].empty()) {
+                const int32_t x = at((size_t)r + 1, len).score;
+                if (!any || x > best) { row = (size_t)r + 1; best = x; any = true; }
             }
-        }
     }
-    uint16_t besty = y;
-    // ---- match route (dag.c:327-343)
-    static thread_local std::vector<MatchRoute> route;
-    route.assign((size_t)x + y + 1, MatchRoute{-1, -1});
-    int64_t starty = -1, endy = -1;
-    uint32_t mroute_count = 0;
-    while (bestx != 0 || besty != 0) {
-        const uint16_t nextx = S(bestx, besty).x, nexty = S(bestx, besty).y;
-        if (nextx != bestx) route[mroute_count].x = g->sorted_nodes[(size_t)bestx - 1];
-        if (nexty != besty) {
-            route[mroute_count].y = (int32_t)(starty = besty - 1);
-            if (endy == -1) endy = route[mroute_count].y;
+    // walk back to the origin; every move contributes a column (node, character, or both)
+    static thread_local std::vector<Step> path;
+    path.clear();
+    int64_t lowest_chr = -1, highest_chr = -1;
+    for (size_t col = len; row != 0 || col != 0;) {
+        const Cell& c = at(row, col);
+        Step st{-1, -1};
+        if (c.from_row != row) st.node = g.order[row - 1];
+        if (c.from_col != col) {
+            st.chr = (int32_t)col - 1;
+            lowest_chr = st.chr;
+            if (highest_chr == -1) highest_chr = st.chr;
         }
-        bestx = nextx;
-        besty = nexty;
-        ++mroute_count;
+        path.push_back(st);
+        row = c.from_row;
+        col = c.from_col;
     }
-    for (uint32_t l = 0, r = mroute_count ? mroute_count - 1 : 0; l < r; ++l, --r) { MatchRoute t = route[l]; route[l] = route[r]; route[r] = t; }
-    // ---- thread the sequence into the graph (align_seq_to_graph_updategraphy, dag.c:345-405)
-    int32_t firstnode = -1, headnode = -1, tailnode = -1, node_index = -1;
-    int updated_node = 1, updated_headnode = 1;
-    if (starty > 0) insert_unmatched_nodes(seq_index, seq, (size_t)starty, g, &firstnode, &headnode);
-    if (endy < (int64_t)y - 1) insert_unmatched_nodes(seq_index, seq + endy + 1, (size_t)((int64_t)y - endy), g, &tailnode, &node_index);   // (length as in the reference: includes the terminator)
-    for (uint32_t i = 0; i < mroute_count; ++i) {
-        if (route[i].y == -1) continue;
-        updated_node = 0;
-        const char base = seq[route[i].y];
-        if (route[i].x == -1) updated_node = node_index = g->insert_node(base);
-        else if ((char)g->nodes[(size_t)route[i].x].base == base) node_index = route[i].x;
+    std::reverse(path.begin(), path.end());
+    // ---- thread the string through the graph
+    int32_t first = -1, prev = -1, tail_first = -1, cur = -1;
+    bool cur_is_new = true, prev_is_new = true;
+    if (lowest_chr > 0) g.chain(q, s, (size_t)lowest_chr, &first, &prev);                  // characters before the first aligned one
+    if (highest_chr < (int64_t)len - 1)                                                     // and behind the last one (the run takes the
+        g.chain(q, s + highest_chr + 1, (size_t)((int64_t)len - highest_chr), &tail_first, &cur);   // terminator along, like the reference)
+    for (const Step& st : path) {
+        if (st.chr == -1) continue;
+        cur_is_new = false;
+        const char b = s[st.chr];
+        if (st.node == -1) { cur = g.new_node(b); cur_is_new = true; }
+        else if ((char)g.base[(size_t)st.node] == b) cur = st.node;
         else {
-            int32_t foundnode = -1;
-            const PNode& mx = g->nodes[(size_t)route[i].x];
-            for (size_t j = 0; j < mx.alignedto.size(); ++j)
-                if ((char)g->nodes[mx.alignedto[j]].base == base) node_index = foundnode = mx.alignedto[j];
-            if (foundnode == -1) {
-                updated_node = node_index = g->insert_node(base);
-                {   // insert_node_alignedto(g, node_index, route[i].x)
-                    PNode& nn = g->nodes[(size_t)node_index];
-                    const PNode& mm = g->nodes[(size_t)route[i].x];
-                    nn.alignedto.push_back((uint16_t)route[i].x);
-                    for (size_t j = 0; j < mm.alignedto.size(); ++j) nn.alignedto.push_back(mm.alignedto[j]);
-                }
-                const std::vector<uint16_t> al = g->nodes[(size_t)node_index].alignedto;
-                for (size_t j = 0; j < al.size(); ++j) g->nodes[al[j]].alignedto.push_back((uint16_t)node_index);
+            int32_t same = -1;
+            for (uint16_t p : g.peers[(size_t)st.node])
+                if ((char)g.base[p] == b) cur = same = p;                                   // the last peer with this base
+            if (same == -1) {                                                               // a new member of the column
+                cur = g.new_node(b);
+                cur_is_new = true;
+                std::vector<uint16_t> col{(uint16_t)st.node};
+                col.insert(col.end(), g.peers[(size_t)st.node].begin(), g.peers[(size_t)st.node].end());
+                g.peers[(size_t)cur] = col;
+                for (uint16_t p : col) g.peers[p].push_back((uint16_t)cur);
             }
         }
-        if (headnode != -1) {
-            if (updated_node || updated_headnode) {
-                const uint32_t e = g->insert_edge((uint16_t)headnode, (uint16_t)node_index, (uint8_t)seq_index);
-                g->link(headnode, node_index, e);
-            } else {
-                int not_existed = 1;
-                PNode& hn = g->nodes[(size_t)headnode];
-                for (uint16_t q = 0; q < hn.outdegree; ++q)
-                    if (g->edges[hn.outedge[q]].outnode_index == (uint16_t)node_index) { g->edges[hn.outedge[q]].lable[seq_index] = 1; not_existed = 0; }
-                if (not_existed) {
-                    const uint32_t e = g->insert_edge((uint16_t)headnode, (uint16_t)node_index, (uint8_t)seq_index);
-                    g->link(headnode, node_index, e);
-                }
-            }
+        if (prev != -1) {
+            bool joined = false;
+            if (!cur_is_new && !prev_is_new)
+                for (uint32_t e : g.out[(size_t)prev])
+                    if (g.dst[e] == (uint16_t)cur) { g.support[e] |= 1ull << q; joined = true; }
+            if (!joined) g.connect((uint16_t)prev, (uint16_t)cur, q);
         }
-        headnode = node_index;
-        updated_headnode = updated_node;
-        if (firstnode == -1) firstnode = headnode;
+        prev = cur;
+        prev_is_new = cur_is_new;
+        if (first == -1) first = prev;
     }
-    if (tailnode != -1) {
-        const uint32_t e = g->insert_edge((uint16_t)headnode, (uint16_t)tailnode, (uint8_t)seq_index);
-        g->link(headnode, tailnode, e);
-    }
-    if (g->sorted_nodes.size() < g->nodes.size()) g->sorted_nodes.resize(g->nodes.size());
-    toposort(g);
+    if (tail_first != -1) g.connect((uint16_t)prev, (uint16_t)tail_first, q);
+    g.reorder();
 }
 
 }  // namespace
 
 std::string poa_consensus(const std::vector<std::string>& seqs) {
-    static thread_local Graph tl_graph;
-    Graph& g = tl_graph;
-    size_t total = 0;
-    for (const std::string& s : seqs) total += s.size() + 2;
-    g.reset(total + 16, 2 * total + 32);   // (the reference starts at 10 000 nodes and grows; capacity is not observable)
-    assert((int)seqs.size() <= SEQ_MAX_COUNT);
-    for (size_t si = 0; si < seqs.size(); ++si) {
-        const std::string& s = seqs[si];
-        if (si == 0) {
-            int32_t firstnode = -1, headnode = -1;
-            insert_unmatched_nodes(si, s.c_str(), s.size(), &g, &firstnode, &headnode);
-            if (g.sorted_nodes.size() < g.nodes.size()) g.sorted_nodes.resize(g.nodes.size());
-            for (uint16_t x = 0; x < g.node_count; ++x) g.sorted_nodes[x] = x;
+    static thread_local PoGraph g;      // kept per host thread, its vectors keep their capacity
+    g.clear();
+    assert((int)seqs.size() <= MAX_STRINGS);
+    for (size_t q = 0; q < seqs.size(); ++q) {
+        const std::string& s = seqs[q];
+        if (q == 0) {
+            int32_t first = -1, last = -1;
+            g.chain(0, s.c_str(), s.size(), &first, &last);
+            g.order.resize(g.n_nodes());
+            g.rank.resize(g.n_nodes());
+            for (uint16_t v = 0; v < g.n_nodes(); ++v) g.order[v] = g.rank[v] = v;
         } else {
-            align_seq_to_graph(g.node_count, (uint16_t)s.size(), si, s.c_str(), &g);
+            add_string(g, (int)q, s.c_str(), (uint16_t)s.size());
         }
     }
-    // heaviest path (get_consensus_from_graph, dag.c:555-595)
-    const int seq_count = (int)seqs.size();
-    int32_t global_best_node = -1;
-    double best_score = -1, global_best_score = -1;
-    for (uint16_t ni = 0; ni < g.node_count; ++ni) {
-        const uint16_t nodeid = g.sorted_nodes[ni];
-        PNode& nd = g.nodes[nodeid];
-        int32_t best_pnode = -1;
-        if (nd.indegree) {
-            for (uint16_t i = 0; i < nd.indegree; ++i) {
-                const PEdge& e = g.edges[nd.inedge[i]];
-                int cnt = 0;
-                for (int q = 0; q < seq_count; ++q) cnt += e.lable[q];
-                const double score = g.nodes[e.innode_index].best_score + cnt - 0.5 * nd.indegree;
-                if (score > best_score || best_pnode == -1) { best_score = score; best_pnode = e.innode_index; }
+    // heaviest path: weight of entering a node over an edge = strings on the edge - half the node's indegree; the running
+    // best is carried from node to node in emission order (a node's own best starts from the previous node's value, which is
+    // what the reference's shared variable does), the overall best is the first strict maximum
+    const uint16_t n = g.n_nodes();
+    std::vector<double> best_at((size_t)n, 0.0);
+    std::vector<int32_t> came_from((size_t)n, -1);
+    int32_t top = -1;
+    double carried = -1, top_score = -1;
+    for (uint16_t r = 0; r < n; ++r) {
+        const uint16_t v = g.order[r];
+        int32_t from = -1;
+        if (!g.in[v].empty()) {
+            const double toll = 0.5 * (double)(uint8_t)g.in[v].size();
+            for (uint32_t e : g.in[v]) {
+                const double x = best_at[g.src[e]] + (double)__builtin_popcountll(g.support[e]) - toll;
+                if (x > carried || from == -1) { carried = x; from = g.src[e]; }
             }
         } else {
-            best_score = 0;
-            best_pnode = -1;
+            carried = 0;
         }
-        nd.best_score = best_score;
-        nd.best_pnode = best_pnode;
-        if (best_score > global_best_score) { global_best_score = best_score; global_best_node = nodeid; }
+        best_at[v] = carried;
+        came_from[v] = from;
+        if (carried > top_score) { top_score = carried; top = v; }
     }
     std::string out;
-    while (global_best_node != -1) {
-        out.push_back((char)g.nodes[(size_t)global_best_node].base);
-        global_best_node = g.nodes[(size_t)global_best_node].best_pnode;
-    }
-    for (size_t l = 0, r = out.size() ? out.size() - 1 : 0; l < r; ++l, --r) { char t = out[l]; out[l] = out[r]; out[r] = t; }
+    for (int32_t v = top; v != -1; v = came_from[(size_t)v]) out.push_back((char)g.base[(size_t)v]);
+    std::reverse(out.begin(), out.end());
     // the reference returns a C string: an embedded terminator (a tail node built from the NUL of a candidate) ends it
     const size_t z = out.find('\0');
     if (z != std::string::npos) out.resize(z);
