@@ -685,10 +685,10 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
                     sv.rreads.push_back(rp);
                     if (sv.rreads.size() >= 50000) {
                         sv.rreads_w = np2::sv_cal_rreads_w(sv.rreads);
-                        for (const np2::SvPos& q : sv.rreads) np2::sv_update_ref_d(svw.ref_ds, sv.rreads_w, q, s);
+                        for (const np2::SvPos& q : sv.rreads) np2::sv_update_ref_d(svw, sv.rreads_w, q, s);
                     }
                 } else {
-                    np2::sv_update_ref_d(svw.ref_ds, sv.rreads_w, rp, s);
+                    np2::sv_update_ref_d(svw, sv.rreads_w, rp, s);
                 }
             }
             if (!rege) continue;
@@ -761,8 +761,9 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
         if (sv.brk_g) {
             if (!sv.rreads_w) {
                 sv.rreads_w = np2::sv_cal_rreads_w(sv.rreads);
-                for (const np2::SvPos& q : sv.rreads) np2::sv_update_ref_d(svw.ref_ds, sv.rreads_w, q, s);
+                for (const np2::SvPos& q : sv.rreads) np2::sv_update_ref_d(svw, sv.rreads_w, q, s);
             }
+            svw.finish_depth();
             if (!sv.ref_d) sv.ref_d = np2::sv_cal_ref_d(svw.ref_ds, l / 10);
             np2::sv_update_ld_regs(&svw.ld_regs, svw.ref_ds, l / 10, sv.rreads_w, sv.ref_d);
             FILE* lg = getenv("NP2_SV_LOG") ? fopen(getenv("NP2_SV_LOG"), "a") : nullptr;   // same lines as tests/shim/np2_ref_shim.c

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 
 namespace np2 {
@@ -15,36 +16,26 @@ constexpr uint32_t LQSEQ_MAX_CAN_COUNT = 60;
 
 inline uint32_t mabs(uint32_t x, uint32_t y) { return x > y ? x - y : y - x; }
 
-int quick_select(std::vector<int>& r, uint32_t s, uint32_t e, uint32_t k) {   // ctg_cns.c:3249-3268
-    if (s > e) return (int)(e + 1);
-    for (;;) {
-        uint32_t left = s;
-        const int pivot = r[e];
-        for (uint32_t i = s; i < e; ++i)
-            if (r[i] < pivot) { std::swap(r[i], r[left]); ++left; }
-        std::swap(r[left], r[e]);
-        if (left == k) return pivot;
-        if (left < k) s = left + 1;
-        else e = left - 1;
-    }
+// k-th smallest value (0-based).  The reference selects it with an in-place partition loop (ctg_cns.c:3249-3268); only the value
+// is used, so any selection gives the same answer.
+template <class T> T kth_smallest(std::vector<T>& v, size_t k) {
+    std::nth_element(v.begin(), v.begin() + (std::ptrdiff_t)k, v.end());
+    return v[k];
 }
 
-int cal_ref_d_ave(const std::vector<uint16_t>& r, int32_t l, int clip) {   // ctg_cns.c:3279-3296
-    uint64_t j = 1, t = 150, h = 0;
-    while (j && t / j > h / 3) {
-        h = t / j * 3;
-        t = j = 0;
-        for (int32_t i = clip; i < l - clip; i += 10)
-            if (r[(size_t)i] && r[(size_t)i] < h) { t += r[(size_t)i]; ++j; }
+// Mean depth of the bins that carry reads, sampled every tenth bin, with the high outliers cut off iteratively: the ceiling is
+// three times the previous round's mean and the rounds stop when the mean no longer falls below a third of it (ctg_cns.c:3279-3296).
+int trimmed_mean_depth(const std::vector<uint16_t>& depth, int32_t n_bins, int skip) {
+    uint64_t sum = 150, cnt = 1, ceiling = 0;
+    while (cnt && sum / cnt > ceiling / 3) {
+        ceiling = sum / cnt * 3;
+        sum = cnt = 0;
+        for (int32_t i = skip; i < n_bins - skip; i += 10) {
+            const uint16_t d = depth[(size_t)i];
+            if (d && d < ceiling) { sum += d; ++cnt; }
+        }
     }
-    return j ? (int)(t / j) : 0;
-}
-
-int32_t find_low_depth_edge(const std::vector<uint16_t>& r, int32_t s, int l, int d, int lable) {   // ctg_cns.c:2688-2693
-    const int md = (int)(d * INS_MIN_DEPTH_RATIO * 2);
-    if (lable) while (s > 1 && r[(size_t)s] <= md) --s;
-    else while (s < l && r[(size_t)s] <= md) ++s;
-    return s;
+    return cnt ? (int)(sum / cnt) : 0;
 }
 
 void cluster_median(SvWindow* w, SvCluster* clu) {   // cal_gap_cluster_median, ctg_cns.c:2509-2549
@@ -87,91 +78,87 @@ void cluster_median(SvWindow* w, SvCluster* clu) {   // cal_gap_cluster_median, 
 
 }  // namespace
 
-int sv_cal_rreads_w(std::vector<SvPos>& rs) {   // ctg_cns.c:3224-3246
-    const int l = (int)rs.size();
-    int s = 0, e = l - 1;
-    const int k = l / 2;
-    for (;;) {
-        int left = s;
-        uint32_t pivot = rs[(size_t)e].e - rs[(size_t)e].s;
-        for (int i = s; i < e; ++i)
-            if (rs[(size_t)i].e - rs[(size_t)i].s < pivot) { std::swap(rs[(size_t)left], rs[(size_t)i]); ++left; }
-        std::swap(rs[(size_t)left], rs[(size_t)e]);
-        if (left == k) {
-            pivot = (pivot + 1) / INS_WIN_DIV;
-            return pivot > (uint32_t)INS_WIN_MIN_SIZE ? (int)pivot : INS_WIN_MIN_SIZE;
-        }
-        if (left < k) s = left + 1;
-        else e = left - 1;
-    }
+// Bin width of the depth statistics: a twentieth of the median read span (rounded like the reference), at least 500 (ctg_cns.c:3224-3246).
+int sv_cal_rreads_w(std::vector<SvPos>& rs) {
+    std::vector<uint32_t> span(rs.size());
+    for (size_t i = 0; i < rs.size(); ++i) span[i] = rs[i].e - rs[i].s;
+    const uint32_t w = (kth_smallest(span, span.size() / 2) + 1) / INS_WIN_DIV;
+    return w > (uint32_t)INS_WIN_MIN_SIZE ? (int)w : INS_WIN_MIN_SIZE;
 }
 
-void sv_update_ref_d(std::vector<uint16_t>& r, int w, const SvPos& p, int32_t s) {   // ctg_cns.c:3311-3319
-    uint32_t s_ = p.s > (uint32_t)s ? p.s - (uint32_t)s : 0;
-    uint32_t e_ = p.e - (uint32_t)s;
-    if (e_ - s_ + 1 >= (uint32_t)(w * 3)) {
-        s_ = (s_ + (uint32_t)w) / INS_WIN_STEP;
-        e_ = (e_ - 2 * (uint32_t)w) / INS_WIN_STEP;
-        if (e_ >= r.size()) r.resize((size_t)e_ + 1024, 0);   // (the reference's buffer is over-allocated the same way)
-        while (s_ <= e_) ++r[s_++];
-    }
+// Depth track: a read counts in the 10-bp bins of its span minus a margin of w at the start and 2 w at the end, and only if it is at
+// least 3 w long (ctg_cns.c:3311-3319).  The reference increments the bins one by one; here the two ends go into a difference array
+// and the bins are summed once when the window's records are all in (SvWindow::finish_depth).  Bins are 16-bit counters that wrap.
+void sv_update_ref_d(SvWindow& win, int w, const SvPos& p, int32_t s) {
+    uint32_t lo = p.s > (uint32_t)s ? p.s - (uint32_t)s : 0;
+    uint32_t hi = p.e - (uint32_t)s;
+    if (hi - lo + 1 < (uint32_t)(w * 3)) return;
+    lo = (lo + (uint32_t)w) / INS_WIN_STEP;
+    hi = (hi - 2 * (uint32_t)w) / INS_WIN_STEP;
+    if (lo > hi) return;
+    if (hi + 2 > win.depth_diff.size()) win.depth_diff.resize((size_t)hi + 1026, 0);
+    ++win.depth_diff[lo];
+    --win.depth_diff[(size_t)hi + 1];
 }
 
-int sv_cal_ref_d(const std::vector<uint16_t>& r, int32_t l) {   // ctg_cns.c:3298-3313
-    int ignore5 = l > 20000 ? 10000 : l > 200 ? 100 : 20, ignore3 = 0;
-    while (ignore5 < l && !r[(size_t)ignore5++]) {}
-    while (l - 1 - ignore3 >= 0 && !r[(size_t)(l - 1 - ignore3++)]) {}
-    std::vector<int> t;
-    uint32_t e = 0;
-    for (int32_t i = ignore5; i < l - ignore3; ++i) {
-        t.push_back(r[(size_t)i]);
-        if (t.back() < 4) ++e;
+void SvWindow::finish_depth() {
+    if (ref_ds.size() < depth_diff.size()) ref_ds.resize(depth_diff.size(), 0);
+    int32_t run = 0;
+    for (size_t i = 0; i < depth_diff.size(); ++i) {
+        run += depth_diff[i];
+        ref_ds[i] = (uint16_t)(ref_ds[i] + (uint16_t)run);
     }
-    const uint32_t j = (uint32_t)t.size();
-    if (!j) return 0;
-    if (l > 50000 && (double)e / j > 0.2) return cal_ref_d_ave(r, l, ignore5);
-    return quick_select(t, 0, j - 1, j / 2);
+    std::fill(depth_diff.begin(), depth_diff.end(), 0);
 }
 
-int sv_cal_ref_ide(const ref_qv* qv, uint32_t l) {   // ctg_cns.c:3270-3278
-    if (l == 0 || qv == nullptr) return 0;
-    std::vector<int> t(l);
-    for (uint32_t i = 0; i < l; ++i) t[i] = (int)qv[i].ide;
-    return quick_select(t, 0, l - 1, l / 2);
+// Typical depth of the window: median over the bins between the first and the last bin that carry reads (a margin at the start is
+// never looked at); windows of more than 50 000 bins where a fifth of those bins is nearly empty take the trimmed mean instead
+// (ctg_cns.c:3298-3313).
+int sv_cal_ref_d(const std::vector<uint16_t>& depth, int32_t n_bins) {
+    int head = n_bins > 20000 ? 10000 : n_bins > 200 ? 100 : 20, tail = 0;
+    while (head < n_bins && !depth[(size_t)head++]) {}
+    while (n_bins - 1 - tail >= 0 && !depth[(size_t)(n_bins - 1 - tail++)]) {}
+    std::vector<int> body;
+    uint32_t nearly_empty = 0;
+    for (int32_t i = head; i < n_bins - tail; ++i) {
+        body.push_back(depth[(size_t)i]);
+        if (body.back() < 4) ++nearly_empty;
+    }
+    if (body.empty()) return 0;
+    if (n_bins > 50000 && (double)nearly_empty / (double)body.size() > 0.2) return trimmed_mean_depth(depth, n_bins, head);
+    return kth_smallest(body, body.size() / 2);
 }
 
-void sv_update_ld_regs(std::vector<SvPos>* regs_, const std::vector<uint16_t>& r, int32_t l, int w, int d) {   // ctg_cns.c:2695-2742
-    std::vector<SvPos> regs(1, SvPos{0, 0});
-    size_t ri = 0;
-    int init_data = 0;
-    const int32_t md = (int32_t)(d * INS_MIN_DEPTH_RATIO);
-    for (int32_t i = 0; i < l; ++i) {
-        if (r[(size_t)i] <= md) {
-            int32_t t;
-            if (!init_data) {
-                t = find_low_depth_edge(r, i, l, d, 1);
-                regs[ri].s = t > 1 ? (uint32_t)(t * INS_WIN_STEP) : 0u;
-                t = find_low_depth_edge(r, i, l, d, 0);
-                regs[ri].e = (uint32_t)((t - 1) * INS_WIN_STEP + w);
-                i = t;
-                init_data = 1;
-            } else {
-                t = find_low_depth_edge(r, i, l, d, 1);
-                t = t * INS_WIN_STEP;
-                if ((uint32_t)t > regs[ri].e + (uint32_t)(INS_WIN_DIV / 2 * w)) {
-                    ++ri;
-                    if (regs.size() <= ri) regs.resize(ri + 1, SvPos{0, 0});
-                    regs[ri].s = (uint32_t)t;
-                }
-                t = find_low_depth_edge(r, i, l, d, 0);
-                regs[ri].e = (uint32_t)((t - 1) * INS_WIN_STEP + w);
-                i = t;
-            }
-            if (regs[ri].s > regs[ri].e) std::swap(regs[ri].s, regs[ri].e);
-        }
+// Median identity of the assembler's QV track (ctg_cns.c:3270-3278).
+int sv_cal_ref_ide(const ref_qv* qv, uint32_t n) {
+    if (n == 0 || qv == nullptr) return 0;
+    std::vector<int> ide(n);
+    for (uint32_t i = 0; i < n; ++i) ide[i] = (int)qv[i].ide;
+    return kth_smallest(ide, n / 2);
+}
+
+// Low-depth regions of the window (ctg_cns.c:2688-2742).  A bin whose depth is at most a tenth of the typical depth opens a
+// region; the region reaches as far to both sides as the depth stays at most a fifth of it (the left walk stops at bin 1 and
+// names the first bin above the shoulder); the right end gets one read window on top.  A region that starts within ten read
+// windows of the previous one's end extends it.  Coordinates are window bases (bin * 10).
+void sv_update_ld_regs(std::vector<SvPos>* out, const std::vector<uint16_t>& depth, int32_t n_bins, int w, int d) {
+    const int32_t low = (int32_t)(d * INS_MIN_DEPTH_RATIO);
+    const int32_t shoulder = (int32_t)(d * INS_MIN_DEPTH_RATIO * 2);
+    auto walk_left = [&](int32_t i) { while (i > 1 && depth[(size_t)i] <= shoulder) --i; return i; };
+    auto walk_right = [&](int32_t i) { while (i < n_bins && depth[(size_t)i] <= shoulder) ++i; return i; };
+    std::vector<SvPos> regs;
+    for (int32_t i = 0; i < n_bins; ++i) {
+        if (depth[(size_t)i] > low) continue;
+        const int32_t lo = walk_left(i), hi = walk_right(i);
+        const uint32_t end = (uint32_t)((hi - 1) * INS_WIN_STEP + w);
+        const uint32_t begin = (uint32_t)(lo * INS_WIN_STEP);
+        if (regs.empty()) regs.push_back(SvPos{lo > 1 ? begin : 0u, end});                  // only the very first region snaps to 0
+        else if (begin > regs.back().e + (uint32_t)(INS_WIN_DIV / 2 * w)) regs.push_back(SvPos{begin, end});
+        else regs.back().e = end;
+        if (regs.back().s > regs.back().e) std::swap(regs.back().s, regs.back().e);
+        i = hi;                                                                              // the loop's own step skips the bin above the shoulder
     }
-    regs.resize(init_data ? ri + 1 : 0);
-    regs_->swap(regs);
+    out->swap(regs);
 }
 
 void sv_update_ld_regs_with_refqv(std::vector<SvPos>* regs, const std::vector<uint16_t>& r, const ref_* ref, int32_t w, int32_t s_t, int32_t e_t,

@@ -35,12 +35,14 @@ struct SvCluster {            // gap_cluster (ctg_cns.h:210-215)
 };
 
 struct SvWindow {             // per-window state
-    std::vector<uint16_t> ref_ds;
+    std::vector<uint16_t> ref_ds;      // reads per 10-bp bin (after finish_depth)
+    std::vector<int32_t> depth_diff;   // +1 / -1 at the ends of every counted read span
+    void finish_depth();               // sums the difference array into ref_ds
     std::vector<SvSupAln> sup_alns;
     std::vector<SvGapRead> gaps;
     std::vector<SvPos> ld_regs;
     std::vector<SvCluster> clusters;
-    void reset(size_t n_ds) { ref_ds.assign(n_ds, 0); sup_alns.clear(); gaps.clear(); ld_regs.clear(); clusters.clear(); }
+    void reset(size_t n_ds) { ref_ds.assign(n_ds, 0); depth_diff.assign(n_ds + 2, 0); sup_alns.clear(); gaps.clear(); ld_regs.clear(); clusters.clear(); }
 };
 struct SvContig {             // state that persists across the windows of a contig (ctg_cns.c:3450-3454)
     int brk_g = 0, rreads_w = 0, ref_d = 0, ref_ide = 0;
@@ -49,7 +51,7 @@ struct SvContig {             // state that persists across the windows of a con
 };
 
 int sv_cal_rreads_w(std::vector<SvPos>& rs);                                   // cal_rreads_w (reorders rs like the reference)
-void sv_update_ref_d(std::vector<uint16_t>& r, int w, const SvPos& p, int32_t s);
+void sv_update_ref_d(SvWindow& win, int w, const SvPos& p, int32_t s);
 int sv_cal_ref_d(const std::vector<uint16_t>& r, int32_t l);
 int sv_cal_ref_ide(const ref_qv* qv, uint32_t l);
 void sv_update_ld_regs(std::vector<SvPos>* regs, const std::vector<uint16_t>& r, int32_t l, int w, int d);
