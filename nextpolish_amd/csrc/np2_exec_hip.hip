@@ -32,6 +32,8 @@
 #include "np2_ond_dev.h"
 #include "np_threads.h"
 
+namespace np { void bgzf_device_inflate_enable(int device); }   // np_bgzf_dev.hip
+
 namespace np2 {
 namespace {
 
@@ -1231,6 +1233,7 @@ class HipExec : public Exec {
         // workers share the host cores of a GPU (the reference's -p model): waiting for the GPU must not spin on one
         if (!getenv("NP2_SPIN_SYNC")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
         HIPOK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        np::bgzf_device_inflate_enable(device_);   // the worker's BAM readers inflate their windows on the device from now on
         return true;
     }
     bool compute_spans(const WindowInput& in, int set, std::vector<SpanOut>* spans, std::string* err) override;

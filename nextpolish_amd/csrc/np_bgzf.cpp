@@ -62,10 +62,14 @@ static unsigned io_threads() {
     return n;
 }
 
+static bgzf_batch_inflate_fn g_batch_fn = nullptr;
+static size_t g_batch_window = 0;
+void set_bgzf_batch_inflater(bgzf_batch_inflate_fn fn, size_t window_bytes) { g_batch_fn = fn; g_batch_window = window_bytes; }
+
 // Reads kWindow compressed bytes from `coff`, splits them into BGZF blocks (gzip member header with the 'BC' extra
 // subfield, SAMv1 4.1) and inflates the complete ones in parallel.
 bool BgzfReader::fill_window(uint64_t coff) {
-    static const size_t kWindow = 4u << 20;
+    const size_t kWindow = g_batch_fn && g_batch_window ? g_batch_window : (size_t)(4u << 20);
     win_.clear();
     win_i_ = 0;
     if (fseeko(fp_, (off_t)coff, SEEK_SET) != 0) return false;
@@ -98,6 +102,14 @@ bool BgzfReader::fill_window(uint64_t coff) {
     }
     if (win_.empty()) return got == 0 || got < 18 ? (got == 0) : false;   // clean EOF only when nothing is left
     uwin_.resize(utotal + 8);
+    if (g_batch_fn && win_.size() >= 64) {     // enough blocks to fill a device: one launch for the whole window (no CRC pass here)
+        std::vector<BgzfBatchBlock> bb(win_.size());
+        for (size_t i = 0; i < win_.size(); ++i) {
+            const WinBlock& b = win_[i];
+            bb[i] = BgzfBatchBlock{(uint64_t)b.cpos, (uint64_t)b.upos, (uint32_t)(b.total - (b.cpos - (size_t)(b.coff - coff)) - 8), b.isize};
+        }
+        if (g_batch_fn(cwin_.data(), got, bb.data(), bb.size(), uwin_.data(), utotal)) return true;
+    }
     const unsigned nt = io_threads();
     static const bool check_crc = getenv("NP_BGZF_NO_CRC") == nullptr;   // on unless switched off
     std::atomic<size_t> next(0);

@@ -77,6 +77,15 @@ private:
     uint64_t coff_ = 0;
 };
 
+// A batch inflater takes the blocks of one reader window at once (the long-read workers hand it to the device decoder of
+// np_inflate_dev.h: np_bgzf_dev.hip).  comp = the window's file bytes, blocks[i] = payload offset / length inside comp and
+// output offset / length inside out.  Returns false when it could not do the whole batch (the reader then inflates the
+// window on its host threads).  `window_bytes` = how many compressed bytes the reader should gather per window while the
+// batch inflater is installed (a device wants thousands of blocks per launch, the host threads are fine with 4 MiB).
+struct BgzfBatchBlock { uint64_t in_off, out_off; uint32_t in_len, out_len; };
+typedef bool (*bgzf_batch_inflate_fn)(const uint8_t* comp, size_t comp_len, const BgzfBatchBlock* blocks, size_t n, uint8_t* out, size_t out_len);
+void set_bgzf_batch_inflater(bgzf_batch_inflate_fn fn, size_t window_bytes);
+
 // Inflate one raw-deflate payload (used by the threaded whole-file loader).
 bool bgzf_inflate_block(const uint8_t* cdata, size_t clen, uint8_t* out, size_t out_len);
 

@@ -1,0 +1,109 @@
+// Batch inflater of the BGZF reader on the device: the long-read workers (nextpolish2.so) hand whole reader windows --
+// thousands of independent BGZF blocks -- to the wave-per-block DEFLATE decoder of np_inflate_dev.h instead of inflating them on
+// their few host threads (BGZF inflate was 0.35 of the 0.9 host CPU-seconds of a 5 Mb window).  Blocks the decoder does not
+// accept are inflated by the host decoder afterwards, so a refusal costs time, never correctness.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "np_bgzf.h"
+#include "np_inflate_dev.h"
+
+namespace {
+
+__global__ __launch_bounds__(256, 4) void k_bgzf_inflate(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+                                                         uint8_t* out, uint32_t* __restrict__ status) {
+    __shared__ npdev::InflateLds lds[4];
+    const uint32_t wave = npdev::uni(threadIdx.x >> 6);
+    const uint32_t b = blockIdx.x * 4 + wave;
+    if (b >= n_blocks) return;
+    const npdev::BlockDesc d = blocks[b];
+    int rc = 0;
+    if (d.out_len) rc = npdev::inflate_block_wave(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, lds[wave]);
+    if ((threadIdx.x & 63u) == 0) status[b] = (uint32_t)rc;
+}
+
+struct DevInflater {
+    int device = -1;
+    hipStream_t q = nullptr;
+    void *d_comp = nullptr, *d_out = nullptr, *d_blocks = nullptr, *d_status = nullptr;
+    size_t c_comp = 0, c_out = 0, c_blocks = 0;
+    std::vector<uint32_t> status;
+    std::mutex mu;
+    uint64_t n_batches = 0, n_blocks = 0, n_host_blocks = 0;
+
+    bool grow(void** p, size_t* cap, size_t want, bool host) {
+        if (want <= *cap) return true;
+        if (*p) { if (host) (void)hipHostFree(*p); else (void)hipFree(*p); }
+        *p = nullptr;
+        *cap = 0;
+        const size_t n = want + want / 4 + (1u << 20);
+        const hipError_t e = host ? hipHostMalloc(p, n, hipHostMallocPortable) : hipMalloc(p, n);
+        if (e != hipSuccess) { *p = nullptr; return false; }
+        *cap = n;
+        return true;
+    }
+    bool run(const uint8_t* comp, size_t comp_len, const np::BgzfBatchBlock* bl, size_t n, uint8_t* out, size_t out_len) {
+        std::lock_guard<std::mutex> g(mu);
+        if (hipSetDevice(device) != hipSuccess) return false;
+        if (!q && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return false;
+        size_t cb = c_blocks;
+        if (!grow(&d_comp, &c_comp, comp_len + 4096, false) || !grow(&d_out, &c_out, out_len + 4096, false) ||
+            !grow(&d_blocks, &cb, sizeof(npdev::BlockDesc) * n + 64, false))
+            return false;
+        if (cb != c_blocks) {       // the status words follow the block table's size
+            c_blocks = cb;
+            if (d_status) (void)hipFree(d_status);
+            d_status = nullptr;
+            if (hipMalloc(&d_status, c_blocks / sizeof(npdev::BlockDesc) * 4 + 64) != hipSuccess) return false;
+        }
+        static thread_local std::vector<npdev::BlockDesc> desc;
+        desc.resize(n);
+        for (size_t i = 0; i < n; ++i) desc[i] = npdev::BlockDesc{bl[i].in_off, bl[i].out_off, bl[i].in_len, bl[i].out_len};
+        status.resize(n);
+        // straight from / into the reader's own (pageable) windows: the runtime stages them, no copy of ours in between
+        if (hipMemcpyAsync(d_comp, comp, comp_len, hipMemcpyHostToDevice, q) != hipSuccess) return false;
+        if (hipMemsetAsync((char*)d_comp + comp_len, 0, 4096, q) != hipSuccess) return false;
+        if (hipMemcpyAsync(d_blocks, desc.data(), sizeof(npdev::BlockDesc) * n, hipMemcpyHostToDevice, q) != hipSuccess) return false;
+        k_bgzf_inflate<<<(unsigned)((n + 3) / 4), 256, 0, q>>>((const uint8_t*)d_comp, (const npdev::BlockDesc*)d_blocks, (uint32_t)n, (uint8_t*)d_out, (uint32_t*)d_status);
+        if (hipMemcpyAsync(out, d_out, out_len, hipMemcpyDeviceToHost, q) != hipSuccess) return false;
+        if (hipMemcpyAsync(status.data(), d_status, 4 * n, hipMemcpyDeviceToHost, q) != hipSuccess) return false;
+        if (hipStreamSynchronize(q) != hipSuccess) return false;
+        ++n_batches;
+        n_blocks += n;
+        for (size_t i = 0; i < n; ++i) {
+            if (!status[i]) continue;
+            ++n_host_blocks;
+            if (!np::bgzf_inflate_block(comp + bl[i].in_off, bl[i].in_len, out + bl[i].out_off, bl[i].out_len)) return false;
+        }
+        return true;
+    }
+};
+
+DevInflater g_inf;
+
+bool batch_hook(const uint8_t* comp, size_t comp_len, const np::BgzfBatchBlock* blocks, size_t n, uint8_t* out, size_t out_len) {
+    return g_inf.run(comp, comp_len, blocks, n, out, out_len);
+}
+
+}  // namespace
+
+namespace np {
+
+// Installs the device inflater for every BgzfReader of this process (call after the HIP device of the worker is chosen).
+// NP2_INFLATE=host keeps the host threads; NP2_INFLATE_WINDOW_MB sets the compressed bytes gathered per launch (default 48).
+void bgzf_device_inflate_enable(int device) {
+    const char* e = getenv("NP2_INFLATE");
+    if (e && strcmp(e, "host") == 0) return;
+    g_inf.device = device;
+    size_t mb = 48;
+    if (const char* w = getenv("NP2_INFLATE_WINDOW_MB")) mb = (size_t)atoi(w);
+    if (mb < 4) mb = 4;
+    set_bgzf_batch_inflater(batch_hook, mb << 20);
+}
+
+}  // namespace np
