@@ -324,7 +324,7 @@ def e2e_from_files(streams, draft_bp, threads):
             nbytes = len(out)
         # the same files through an already running process (what a long-lived worker sees: no HIP start-up, buffers in place)
         from nextpolish_amd.device import Pipe
-        pipe = Pipe(int(os.environ.get("LOCAL_RANK", "0")), lanes=2)
+        pipe = Pipe(int(os.environ.get("LOCAL_RANK", "0")), lanes=int(os.environ.get("NP1_E2E_LANES", "2")))
         warm, nout = 1e9, 0
         for _ in range(3):
             got = [0]

@@ -69,7 +69,13 @@ void set_bgzf_batch_inflater(bgzf_batch_inflate_fn fn, size_t window_bytes) { g_
 // Reads kWindow compressed bytes from `coff`, splits them into BGZF blocks (gzip member header with the 'BC' extra
 // subfield, SAMv1 4.1) and inflates the complete ones in parallel.
 bool BgzfReader::fill_window(uint64_t coff) {
-    const size_t kWindow = g_batch_fn && g_batch_window ? g_batch_window : (size_t)(4u << 20);
+    // host threads: 4 MiB windows.  Batch inflater: windows double while the reader keeps reading on sequentially (a short
+    // contig must not pay for tens of MB it will never look at) up to the batch size.
+    size_t kWindow = (size_t)(4u << 20);
+    if (g_batch_fn && g_batch_window) {
+        batch_window_ = (coff == batch_next_coff_ && batch_window_) ? std::min(batch_window_ * 2, g_batch_window) : (size_t)(4u << 20);
+        kWindow = batch_window_;
+    }
     win_.clear();
     win_i_ = 0;
     if (fseeko(fp_, (off_t)coff, SEEK_SET) != 0) return false;
@@ -108,7 +114,10 @@ bool BgzfReader::fill_window(uint64_t coff) {
             const WinBlock& b = win_[i];
             bb[i] = BgzfBatchBlock{(uint64_t)b.cpos, (uint64_t)b.upos, (uint32_t)(b.total - (b.cpos - (size_t)(b.coff - coff)) - 8), b.isize};
         }
+        batch_next_coff_ = win_.back().coff + win_.back().total;
         if (g_batch_fn(cwin_.data(), got, bb.data(), bb.size(), uwin_.data(), utotal)) return true;
+    } else if (g_batch_fn && !win_.empty()) {
+        batch_next_coff_ = win_.back().coff + win_.back().total;
     }
     const unsigned nt = io_threads();
     static const bool check_crc = getenv("NP_BGZF_NO_CRC") == nullptr;   // on unless switched off

@@ -50,6 +50,8 @@ private:
     uint64_t next_coff_ = 0;           // file offset of the next block
     uint32_t ulen_ = 0, upos_ = 0;
     bool eof_ = false;
+    size_t batch_window_ = 0;          // batch inflater: current window size and where the last window ended
+    uint64_t batch_next_coff_ = ~0ull;
 };
 
 class BgzfWriter {

@@ -271,8 +271,16 @@ __device__ __noinline__ uint32_t flush_tokens(uint8_t* out_, uint32_t op_, uint3
                 // byte i comes from source byte i % dist; source bytes below op are already in place (copied above)
                 if (dist >= len) {
                     const uint32_t s0 = gbase + (src + n_glob - op);      // src + n_glob >= op here
+                    uint32_t i = n_glob;
+                    // four bytes in flight per step (source and destination cannot overlap: dist >= len)
 #pragma clang loop unroll(disable)
-                    for (uint32_t i = n_glob; i < len; ++i) gbuf[rel + i] = gbuf[s0 + (i - n_glob)];
+                    for (; i + 4 <= len; i += 4) {
+                        const uint32_t o = s0 + (i - n_glob);
+                        const uint8_t b0 = gbuf[o], b1 = gbuf[o + 1], b2 = gbuf[o + 2], b3 = gbuf[o + 3];
+                        gbuf[rel + i] = b0; gbuf[rel + i + 1] = b1; gbuf[rel + i + 2] = b2; gbuf[rel + i + 3] = b3;
+                    }
+#pragma clang loop unroll(disable)
+                    for (; i < len; ++i) gbuf[rel + i] = gbuf[s0 + (i - n_glob)];
                 } else {
                     // self-overlapping: the first `dist` bytes are the pattern (from HBM up to n_glob, else from the group), then it repeats
 #pragma clang loop unroll(disable)
