@@ -420,6 +420,235 @@ __global__ __launch_bounds__(256) void k2_build_b(const DevObs* __restrict__ obs
     }
 }
 
+// ---- link graph straight from the tag streams, one wave per tile of 64 draft positions ------------------------------------
+// The scatter path above writes one 32-byte observation per tag into its column's bucket and lets every observation scan its
+// bucket twice (k2_chunk_links, k2_build_a/b: ~123 M observations, ~4 GB out and back several times per 5 Mb window, and the
+// entry / node arrays stay as sparse as the buckets).  Here a wave owns a tile of 64 columns.  For every stream that crosses
+// the tile (list built by k2_tile_list: stream + index of its first tag inside the tile; taken in ascending stream order =
+// first-seen order) the LANES ARE THE STREAM'S TAGS: one coalesced nibble fetch, the position of a tag from a ballot + popcount
+// (position = number of non-insertion tags so far), its insertion depth from the distance to the last non-insertion lane, its
+// predecessors pp / ppp from the two lanes below.  Every tag is looked up in its column's chain of entries in LDS (own node +
+// both predecessors packed into 62 bits: positions relative to the column) and either raises the link count or is appended;
+// streams are taken one after the other, so a node's entries come out in first-seen order without sorting observations.
+// A finished tile orders each column's few entries by node, takes its place in the COMPACT entry / node arrays with one
+// atomic, and writes them.  A tile with more than TG_POOL distinct entries or a column with more than TG_COLMAX (deep
+// pileups, thousand-base insertions) raises a flag and the window takes the scatter path instead.
+constexpr uint32_t TG_POOL = 1536, TG_MAXS = 128, TG_COLMAX = 96, TG_NONE = 0xffffu;
+struct TileLds {
+    unsigned long long key[TG_POOL];
+    uint32_t link[TG_POOL];                 // bit 31 (set while the tile is finished): first entry of its node
+    uint16_t next[TG_POOL];
+    uint32_t head[64], tail[64], cnt[64];
+    uint32_t used;
+    uint32_t sid[TG_MAXS], sstart[TG_MAXS], tsid[TG_MAXS], tstart[TG_MAXS];
+};
+struct TileStream { uint32_t stream, start; };
+
+// lane per chunk of a stream: the tiles its non-insertion tags open (position % 64 == 0, or the stream's first tag)
+template <bool kFill>
+__global__ void k2_tile_list(const ChunkDesc* cd, uint32_t n_chunks, const uint32_t* pre, const uint64_t* tag_off, const uint32_t* aln_t_s,
+                             const uint8_t* tags, uint32_t n_tiles, uint32_t* tile_cnt, const uint32_t* tile_off, uint32_t* cursor, TileStream* list) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const ChunkDesc d = cd[c];
+    const uint32_t ts = aln_t_s[d.stream];
+    const uint32_t a = ts + (pre[c] - pre[d.first_chunk_of_stream]), n = pre[c + 1] - pre[c];   // positions [a, a + n)
+    if (!n) return;
+    if (!kFill) {
+        if (d.first_tag == 0 && (ts & 63u) && (ts >> 6) < n_tiles) atomicAdd(&tile_cnt[ts >> 6], 1u);
+        for (uint32_t t = (a + 63u) >> 6; t <= (a + n - 1) >> 6 && t < n_tiles; ++t) atomicAdd(&tile_cnt[t], 1u);
+        return;
+    }
+    const uint8_t* tg = tags + tag_off[d.stream];
+    uint32_t p = a;
+    for (uint32_t i = 0; i < d.n_tags; ++i) {
+        if (tag_nib(tg, d.first_tag + i) & 8u) continue;
+        if ((!(p & 63u) || d.first_tag + i == 0) && (p >> 6) < n_tiles)
+            list[tile_off[p >> 6] + atomicAdd(&cursor[p >> 6], 1u)] = TileStream{d.stream, d.first_tag + i};
+        ++p;
+    }
+}
+
+struct TileArgs {
+    const uint8_t* tags; const uint64_t* tag_off; const uint32_t* aln_t_s; const uint32_t* n_tags;
+    const uint32_t* tile_off; const TileStream* list; uint32_t n_tiles, n_cols;
+    Entry* entries; Node* nodes; uint32_t* col_off; uint32_t* col_nn; uint32_t* counter;   // counter[0] entries placed, [1] overflow flag
+};
+
+// own node + predecessors of an entry in 62 bits; predecessor positions relative to the column (pp: 0..1 back, ppp: 0..2 back)
+__device__ __forceinline__ unsigned long long tg_pack(uint32_t delta, uint32_t base, int32_t tp, unsigned long long pp, unsigned long long ppp) {
+    unsigned long long k = (unsigned long long)(delta & 0xffffu) | (unsigned long long)(base & 7u) << 16;
+    if (key_tpos(pp) == -1) k |= 1ull << 19;
+    else k |= (unsigned long long)((uint32_t)(tp - key_tpos(pp)) & 1u) << 20 | (unsigned long long)key_delta(pp) << 21 | (unsigned long long)(key_base(pp) & 7u) << 37;
+    if (key_tpos(ppp) == -1) k |= 1ull << 40;
+    else k |= (unsigned long long)((uint32_t)(tp - key_tpos(ppp)) & 3u) << 41 | (unsigned long long)key_delta(ppp) << 43 | (unsigned long long)(key_base(ppp) & 7u) << 59;
+    return k;
+}
+__device__ __forceinline__ uint32_t tg_node(unsigned long long k) { return (uint32_t)(k & 0xffffu) << 8 | (uint32_t)((k >> 16) & 7u); }
+__device__ __forceinline__ void tg_unpack(unsigned long long k, int32_t tp, uint64_t* pp, uint64_t* ppp) {
+    *pp = ((k >> 19) & 1ull) ? KEY_HEAD : node_key(tp - (int32_t)((k >> 20) & 1ull), (uint32_t)((k >> 21) & 0xffffu), (uint32_t)((k >> 37) & 7u));
+    *ppp = ((k >> 40) & 1ull) ? KEY_HEAD : node_key(tp - (int32_t)((k >> 41) & 3ull), (uint32_t)((k >> 43) & 0xffffu), (uint32_t)((k >> 59) & 7u));
+}
+__device__ __forceinline__ void tg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A) {
+    __shared__ TileLds L;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t = blockIdx.x;
+    const uint32_t c0 = t << 6, c1 = c0 + 63;
+    const unsigned long long lane_le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    L.head[lane] = TG_NONE; L.tail[lane] = TG_NONE; L.cnt[lane] = 0;
+    if (lane == 0) L.used = 0;
+    // ---- the tile's streams in ascending order
+    const uint32_t l0 = A.tile_off[t], ns = A.tile_off[t + 1] - l0;
+    const bool cached = ns <= TG_MAXS;
+    if (cached) {
+        for (uint32_t j = lane; j < ns; j += 64) { const TileStream e = A.list[l0 + j]; L.tsid[j] = e.stream; L.tstart[j] = e.start; }
+        tg_sync();
+        for (uint32_t j = lane; j < ns; j += 64) {      // rank sort: the list comes out of atomics in any order
+            const uint32_t s = L.tsid[j];
+            uint32_t r = 0;
+            for (uint32_t q = 0; q < ns; ++q) r += L.tsid[q] < s ? 1u : 0u;
+            L.sid[r] = s; L.sstart[r] = L.tstart[j];
+        }
+    }
+    tg_sync();
+    uint32_t prev_s = 0;
+    for (uint32_t j = 0; j < ns; ++j) {
+        uint32_t s, i0;
+        if (cached) { s = L.sid[j]; i0 = L.sstart[j]; }
+        else {            // a very crowded tile: the next stream by selection over the list
+            unsigned long long best = ~0ull;
+            for (uint32_t q = lane; q < ns; q += 64) {
+                const TileStream e = A.list[l0 + q];
+                const unsigned long long v = (unsigned long long)e.stream << 32 | e.start;
+                if ((j == 0 || e.stream > prev_s) && v < best) best = v;
+            }
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(best, o, 64); best = y < best ? y : best; }
+            s = (uint32_t)(best >> 32); i0 = (uint32_t)best;
+        }
+        s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+        i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
+        prev_s = s;
+        const uint8_t* tg = A.tags + A.tag_off[s];
+        const uint32_t ts = A.aln_t_s[s], nt = A.n_tags[s];
+        // state in front of tag i0: position of the last non-insertion tag, the two tags before it (as node keys), the open insertion run
+        int32_t T0 = (int32_t)max(c0, ts) - 1;
+        unsigned long long P1 = KEY_HEAD, P2 = KEY_HEAD;
+        uint32_t D0 = 0;
+        if (i0 >= 1) {
+            int32_t tp; uint32_t dl;
+            const uint32_t nb1 = tag_nib(tg, i0 - 1);
+            tag_pos(tg, i0 - 1, (uint32_t)(T0 + 1) - ts, ts, &tp, &dl);          // tags 0 .. i0-1 hold T0 + 1 - ts non-insertion tags
+            P1 = node_key(tp, dl, nb1 & 7u);
+            D0 = dl;
+            if (i0 >= 2) {
+                tag_pos(tg, i0 - 2, (uint32_t)(T0 + 1) - ts - ((nb1 & 8u) ? 0u : 1u), ts, &tp, &dl);
+                P2 = node_key(tp, dl, tag_nib(tg, i0 - 2) & 7u);
+            }
+        }
+        for (uint32_t b = i0; b < nt; b += 64) {
+            const uint32_t i = b + lane;
+            const bool valid = i < nt;
+            const uint32_t nb = valid ? tag_nib(tg, i) : 8u;
+            const uint32_t base = nb & 7u;
+            const unsigned long long M = __ballot(valid && !(nb & 8u));
+            const unsigned long long Mle = M & lane_le;
+            const uint32_t below = (uint32_t)__popcll(Mle);
+            const int32_t tp = T0 + (int32_t)below;
+            uint32_t delta = below ? lane - (63u - (uint32_t)__clzll((long long)Mle)) : D0 + lane + 1u;
+            delta &= 0xffffu;
+            const unsigned long long own = node_key(tp, delta, base);
+            unsigned long long pp = __shfl_up(own, 1, 64), ppp = __shfl_up(own, 2, 64);
+            if (lane == 0) { pp = P1; ppp = P2; }
+            if (lane == 1) ppp = P1;
+            const unsigned long long beyond = __ballot(valid && tp > (int32_t)c1);
+            const bool obs = valid && tp <= (int32_t)c1 && base != 6u && key_base(pp) != 6u;
+            const uint32_t col = (uint32_t)(tp - (int32_t)c0) & 63u;
+            const unsigned long long k = tg_pack(delta, base, tp, pp, ppp);
+            // the entries the column held before this fetch (a stream visits a node once: no two lanes carry the same entry)
+            uint32_t hit = TG_NONE;
+            if (obs) {
+                uint32_t e = L.head[col];
+                while (e != TG_NONE) {
+                    if (L.key[e] == k) { hit = e; break; }
+                    e = L.next[e];
+                }
+            }
+            tg_sync();
+            if (obs) {
+                if (hit != TG_NONE) atomicAdd(&L.link[hit], 1u);
+                else {
+                    const uint32_t e = atomicAdd(&L.used, 1u);
+                    if (e < TG_POOL) {
+                        L.key[e] = k; L.link[e] = 1u; L.next[e] = (uint16_t)TG_NONE;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        const uint32_t prev = atomicExch(&L.tail[col], e);
+                        if (prev == TG_NONE) L.head[col] = e; else L.next[prev] = (uint16_t)e;
+                        atomicAdd(&L.cnt[col], 1u);
+                    }
+                }
+            }
+            tg_sync();
+            if (beyond) break;
+            T0 += (int32_t)__popcll(M);
+            D0 = (uint32_t)__builtin_amdgcn_readlane((int)delta, 63);
+            P2 = __shfl(own, 62, 64);
+            P1 = __shfl(own, 63, 64);
+        }
+    }
+    tg_sync();
+    // ---- finish the tile: lane = column
+    const uint32_t p = c0 + lane;
+    uint32_t n = p < A.n_cols ? L.cnt[lane] : 0u;
+    const bool over = L.used > TG_POOL || __ballot(n > TG_COLMAX) != 0ull;
+    if (over) {
+        if (lane == 0) atomicOr(&A.counter[1], 1u);
+        if (p < A.n_cols) { A.col_off[p] = 0; A.col_nn[p] = 0; }
+        return;
+    }
+    uint32_t inc = n;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += v; }
+    const uint32_t tile_total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    uint32_t basep = 0;
+    if (lane == 0 && tile_total) basep = atomicAdd(&A.counter[0], tile_total);
+    basep = (uint32_t)__builtin_amdgcn_readfirstlane((int)basep);
+    if (p >= A.n_cols) return;
+    const uint32_t off = basep + inc - n;
+    uint32_t n_nodes = 0;
+    for (uint32_t e = L.head[lane]; e != TG_NONE; e = L.next[e]) {          // mark the first entry of every node
+        const uint32_t nk = tg_node(L.key[e]);
+        bool first = true;
+        for (uint32_t f = L.head[lane]; f != e; f = L.next[f])
+            if (tg_node(L.key[f]) == nk) { first = false; break; }
+        if (first) { L.link[e] |= 0x80000000u; ++n_nodes; }
+    }
+    for (uint32_t e = L.head[lane]; e != TG_NONE; e = L.next[e]) {
+        const unsigned long long k = L.key[e];
+        const uint32_t nk = tg_node(k);
+        uint32_t node_start = 0, node_idx = 0, node_len = 0, pos_in = 0;
+        bool passed = false;
+        for (uint32_t f = L.head[lane]; f != TG_NONE; f = L.next[f]) {
+            const uint32_t nkf = tg_node(L.key[f]);
+            if (f == e) passed = true;
+            if (nkf < nk) { ++node_start; node_idx += L.link[f] >> 31; }
+            else if (nkf == nk) { ++node_len; if (!passed) ++pos_in; }
+        }
+        Entry en;
+        tg_unpack(k, (int32_t)p, &en.pp, &en.ppp);
+        en.score = 0;
+        en.link = L.link[e] & 0xffffu;           // the reference counts in 16 bits
+        en.node = nk;
+        A.entries[off + node_start + pos_in] = en;
+        if (L.link[e] >> 31) A.nodes[off + node_idx] = Node{nk, node_start, node_len, 0u};
+    }
+    A.col_off[p] = off;
+    A.col_nn[p] = n_nodes;
+}
+
 // seed_len > 0 (a window): coverage = seed + scanned difference array of the reads (cov_pre exclusive prefix, cov_diff the
 // array itself), max_size at least the seed's 1; seed_len == 0 (concatenated low-quality regions): counted directly
 // predecessor entries of every entry, resolved once for both DP passes (np2_core.h EMatch): lane per entry slot
@@ -1246,6 +1475,7 @@ class HipExec : public Exec {
     bool lq_from_pool(const std::vector<uint32_t>& str_len, uint32_t t_len, uint32_t gap_min_len, bool hifi, std::string* cons_rev, std::string* err);
     // link observations -> column buckets -> nodes/entries for n_streams tag streams over n_cols columns; *total = entries
     // m_seen != nullptr: colcnt_ already holds the tags per column (valid unless *m_seen, a device flag, is set)
+    int build_graph_tiles(const std::vector<uint32_t>& n_tags, uint32_t n_chunks, uint32_t n_cols, uint32_t* total, std::string* err, struct StageClock* clk);
     bool build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, uint32_t* total, std::string* err, struct StageClock* clk = nullptr,
                      const uint32_t* m_seen = nullptr);
     bool solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t total, int rule, uint32_t* cons_len, struct StageClock* clk, std::string* err);
@@ -1264,6 +1494,7 @@ class HipExec : public Exec {
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
     DevBuf runsz_, runoff_, live_, ematch_, xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
+    DevBuf tilecnt_, tileoff_, tilecur_, tilelist_, tilectr_, ntags_;
     DevBuf ondpool_, ondregs_, ondcoff_, ondclen_, ondpairof_, ondpairs_, ondres_, ondout_, ondv_, ondlo_, ondch_, ondplen_, ondpkind_, ondppos_, ondtot_;
     PinBuf pin_;
     std::vector<uint32_t> win_first_chunk_, win_n_chunks_;   // chunk range of every stream of the last run_window
@@ -1594,6 +1825,52 @@ bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t
     return true;
 }
 
+// The link graph by tiles (k2_tile_graph).  Returns 1 = built, 2 = a tile overflowed (the caller takes the scatter path), 0 = error.
+int HipExec::build_graph_tiles(const std::vector<uint32_t>& n_tags, uint32_t n_chunks, uint32_t n_cols, uint32_t* total_out, std::string* err, StageClock* clk) {
+    hipStream_t q = stream_;
+    const uint32_t n_tiles = (n_cols + 63) / 64, n_streams = (uint32_t)n_tags.size();
+    uint64_t list_cap = 0, tag_total = 0;
+    for (uint32_t v : n_tags) { list_cap += v / 64 + 2; tag_total += v; }
+    const uint32_t nst = nblk(n_tiles + 1, SCAN_TILE);
+#define TILEOK(x) do { if ((x) != hipSuccess) { *err = std::string("HIP error in ") + #x; return 0; } } while (0)
+    if (!tilecnt_.ensure(4ull * (n_tiles + 2)) || !tileoff_.ensure(4ull * (n_tiles + 2)) || !tilecur_.ensure(4ull * (n_tiles + 2)) ||
+        !tilelist_.ensure(sizeof(TileStream) * list_cap + 64) || !tilectr_.ensure(64) || !ntags_.ensure(4ull * n_streams + 16) ||
+        !sums_.ensure(4ull * (nst + 2)) || !entries_.ensure(sizeof(Entry) * tag_total + 64) || !nodes_.ensure(sizeof(Node) * tag_total + 64)) {
+        *err = "out of device memory (link graph)";
+        return 0;
+    }
+    TILEOK(hipMemcpyAsync(ntags_.p, n_tags.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
+    TILEOK(hipMemsetAsync(tilecnt_.p, 0, 4ull * (n_tiles + 2), q));
+    TILEOK(hipMemsetAsync(tilecur_.p, 0, 4ull * (n_tiles + 2), q));
+    TILEOK(hipMemsetAsync(tilectr_.p, 0, 64, q));
+    k2_tile_list<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(),
+                                                           tags_.as<uint8_t>(), n_tiles, tilecnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
+    k2_scan_sums<<<nst, SCAN_T, 0, q>>>(tilecnt_.as<uint32_t>(), n_tiles + 1, sums_.as<uint32_t>());
+    k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nst);
+    k2_scan_final<<<nst, SCAN_T, 0, q>>>(tilecnt_.as<uint32_t>(), n_tiles + 1, sums_.as<uint32_t>(), tileoff_.as<uint32_t>());
+    k2_tile_list<true><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(),
+                                                          tags_.as<uint8_t>(), n_tiles, nullptr, tileoff_.as<uint32_t>(), tilecur_.as<uint32_t>(), tilelist_.as<TileStream>());
+    if (clk) clk->mark("tiles.list");
+    TileArgs A{tags_.as<uint8_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), ntags_.as<uint32_t>(), tileoff_.as<uint32_t>(), tilelist_.as<TileStream>(),
+               n_tiles, n_cols, entries_.as<Entry>(), nodes_.as<Node>(), coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), tilectr_.as<uint32_t>()};
+    k2_tile_graph<<<n_tiles, 64, 0, q>>>(A);
+    uint32_t ctr[2] = {0, 0};
+    TILEOK(hipMemcpyAsync(ctr, tilectr_.p, 8, hipMemcpyDeviceToHost, q));
+    TILEOK(hipStreamSynchronize(q));
+    if (clk) clk->mark("tiles.graph");
+    if (ctr[1]) return 2;
+    const uint32_t total = ctr[0];
+    if (!live_.ensure((size_t)total + 64) || !ematch_.ensure(sizeof(EMatch) * (size_t)total + 64)) { *err = "out of device memory (link graph)"; return 0; }
+    if (total) {
+        TILEOK(hipMemsetAsync(live_.p, 1, total, q));
+        MsaView bare{coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), nodes_.as<Node>(), entries_.as<Entry>(), nullptr};
+        k2_match<<<nblk(total, 256), 256, 0, q>>>(bare, nullptr, live_.as<uint8_t>(), total, ematch_.as<EMatch>());
+    }
+#undef TILEOK
+    *total_out = total;
+    return 1;
+}
+
 bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, uint32_t* total_out, std::string* err, StageClock* clk,
                           const uint32_t* m_seen) {
     hipStream_t q = stream_;
@@ -1618,10 +1895,17 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
         k2_scan_sums<<<nsc, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), n_chunks + 1, sums2_.as<uint32_t>());
         k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nsc);
         k2_scan_final<<<nsc, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), n_chunks + 1, sums2_.as<uint32_t>(), chpre_.as<uint32_t>());
-        if (!m_seen)
-            k2_chunk_links<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
-                                                                     alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
     }
+    static const bool scatter_only = getenv("NP2_GRAPH_SCATTER") != nullptr;
+    if (n_chunks && !scatter_only) {
+        const int r = build_graph_tiles(n_tags, n_chunks, n_cols, total_out, err, clk);
+        if (r == 0) return false;
+        if (r == 1) return true;
+        if (getenv("NP2_TIMING")) fprintf(stderr, "[np2 graph] a tile overflowed: scatter path for this window\n");
+    }
+    if (n_chunks && !m_seen)
+        k2_chunk_links<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(),
+                                                                 alnts_.as<uint32_t>(), tags_.as<uint8_t>(), colcnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
     const uint32_t nsb = nblk(n_cols + 1, SCAN_TILE);
     uint32_t total = 0;
     for (int pass = 0; pass < 2; ++pass) {
