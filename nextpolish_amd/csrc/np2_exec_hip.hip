@@ -472,7 +472,7 @@ __global__ void k2_tile_list(const ChunkDesc* cd, uint32_t n_chunks, const uint3
 struct TileArgs {
     const uint8_t* tags; const uint64_t* tag_off; const uint32_t* aln_t_s; const uint32_t* n_tags;
     const uint32_t* tile_off; const TileStream* list; uint32_t n_tiles, n_cols;
-    Entry* entries; Node* nodes; uint32_t* col_off; uint32_t* col_nn; uint32_t* counter;   // counter[0] entries placed, [1] overflow flag
+    Entry* entries; Node* nodes; uint32_t* col_off; uint32_t* col_nn; uint32_t* col_ne; uint32_t* counter;   // counter[0] entries placed, [1] overflow flag
 };
 
 // own node + predecessors of an entry in 62 bits; predecessor positions relative to the column (pp: 0..1 back, ppp: 0..2 back)
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A) {
     const bool over = L.used > TG_POOL || __ballot(n > TG_COLMAX) != 0ull;
     if (over) {
         if (lane == 0) atomicOr(&A.counter[1], 1u);
-        if (p < A.n_cols) { A.col_off[p] = 0; A.col_nn[p] = 0; }
+        if (p < A.n_cols) { A.col_off[p] = 0; A.col_nn[p] = 0; A.col_ne[p] = 0; }
         return;
     }
     uint32_t inc = n;
@@ -647,6 +647,7 @@ __global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A) {
     }
     A.col_off[p] = off;
     A.col_nn[p] = n_nodes;
+    A.col_ne[p] = n;
 }
 
 // seed_len > 0 (a window): coverage = seed + scanned difference array of the reads (cov_pre exclusive prefix, cov_diff the
@@ -881,15 +882,20 @@ __global__ void k2_run_size(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, u
 
 template <uint32_t K>
 __global__ void k2_run_ac(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, long long C, long long* ring,
-                          const uint32_t* ring_off, RunT<K>* out, uint32_t rpw, uint32_t* status) {
+                          const uint32_t* ring_off, RunT<K>* out, uint32_t rpw, uint32_t* status, const uint32_t* list = nullptr,
+                          const uint32_t* n_list = nullptr) {
     // `rpw` runs per wave, K + 1 lanes each: lanes 0..K-1 carry the coefficient of one input (= one live entry of the
     // run's left cut column), lane K the constant.  A run is a serial chain of dependent loads, so what counts is how
     // many runs are in flight: small graphs (the low-quality re-consensus) take one run per wave, whole windows pack
     // 64 / (K + 1) runs per wave and let them diverge.
     constexpr uint32_t W = K + 1;
-    const uint32_t r = blockIdx.x * rpw + threadIdx.x / W;
+    uint32_t r = blockIdx.x * rpw + threadIdx.x / W;
     const uint32_t lane = threadIdx.x % W;
     if (r >= n_runs || threadIdx.x >= rpw * W) return;
+    if (list) {      // only the runs k2_run_ac_lds left
+        if (r >= *n_list) return;
+        r = list[r];
+    }
     int32_t lo, hi;
     run_bounds(cuts, n_cuts, r, l, &lo, &hi);
     long long* R = ring + (uint64_t)ring_off[r] * W;
@@ -1077,9 +1083,14 @@ __device__ __forceinline__ void publish_best(const MsaView& mv, int32_t l, long 
 
 // interior columns of every run (and the last column of the open run)
 template <int TYPE>
-__global__ void k2_run_dp_a(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, DpResult* res, uint32_t rpw) {
-    const uint32_t r = blockIdx.x * rpw + threadIdx.x;   // rpw runs per wave, one lane each (see k2_run_ac)
+__global__ void k2_run_dp_a(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, DpResult* res, uint32_t rpw,
+                            const uint32_t* list = nullptr, const uint32_t* n_list = nullptr) {
+    uint32_t r = blockIdx.x * rpw + threadIdx.x;   // rpw runs per wave, one lane each (see k2_run_ac)
     if (r >= n_runs || threadIdx.x >= rpw) return;
+    if (list) {      // only the runs k2_run_dp_lds left
+        if (r >= *n_list) return;
+        r = list[r];
+    }
     int32_t lo, hi;
     run_bounds(cuts, n_cuts, r, l, &lo, &hi);
     long long gbest = INT64_MIN;
@@ -1101,6 +1112,267 @@ __global__ void k2_run_dp_b(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, i
     uint64_t gkey = node_key(0, 0, 0xff);
     dp_any<TYPE>(mv, p, l, &gbest, &gkey);
     if (p == l - 1) publish_best<TYPE>(mv, l, gbest, gkey, res);
+}
+
+// ---- the same two passes over a run with its columns staged in LDS ---------------------------------------------------------
+// k2_run_ac / k2_run_dp_a walk a run as one serial chain of dependent loads from HBM (entry -> resolved predecessors -> their
+// coefficients / scores), 7 or 64 runs per wave; what they wait for is latency, and every lane of a load instruction touches
+// its own cache line.  When the graph was built by tiles the entries of a column are live, contiguous and in state order (state
+// index = offset inside the column) and consecutive columns follow each other inside a tile, so a wave can own ONE run and
+//   * fetch up to 64 columns / RL_CAP entries of it (entries, resolved predecessors, nodes) into LDS with a few coalesced
+//     copies (a chunk crosses at most one tile boundary = two contiguous pieces),
+//   * keep the two-column ring of coefficient vectors / scores in LDS,
+//   * work the columns from LDS: entries of one insertion depth are independent (a tag's predecessor is in the column before,
+//     or in its own column one insertion level down), so they are taken 64 / (K + 1) at a time by k2_run_ac_lds (lanes =
+//     entry x input) and a node per lane by k2_run_dp_lds (the best-predecessor rules are sequential inside a node).
+// Runs these kernels cannot take (a column with more than RL_COLMAX entries) are listed and left to the kernels above.
+constexpr uint32_t RL_CAP = 96, RL_COLMAX = 32;
+struct RunStage {
+    uint32_t c_off[64], c_pre[65], c_nn[64];
+    uint16_t c_cov[64];
+    Entry e[RL_CAP];
+    EMatch m[RL_CAP];
+};
+// Fetches columns pf .. of the run (at most 64, at most RL_CAP entries; the first one may be the column in front of the part to
+// work on, staged for its entries' keys) and returns how many were taken, 0 = the run is not for these kernels.  kNodes: the node
+// records too (staged at the same offsets as the column's entries).
+template <bool kNodes>
+__device__ __forceinline__ uint32_t run_stage(const MsaView& mv, const uint32_t* __restrict__ col_ne, int32_t pf, int32_t p_end, RunStage& S, Node* nd_lds,
+                                              uint32_t lane) {
+    const int32_t p = pf + (int32_t)lane;
+    const bool in = p <= p_end;
+    const uint32_t ne = in ? col_ne[p] : 0u, off = in ? mv.col_off[p] : 0u;
+    if (__ballot(ne > RL_COLMAX)) return 0;
+    uint32_t inc = ne;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += v; }
+    const uint32_t nc = (uint32_t)__popcll(__ballot(in && inc <= RL_CAP));      // a prefix of the lanes
+    S.c_off[lane] = off;
+    S.c_pre[lane] = inc - ne;
+    if (lane + 1 == nc) S.c_pre[nc] = inc;
+    if (in) { S.c_cov[lane] = mv.stat[p].coverage; S.c_nn[lane] = kNodes ? mv.col_nn[p] : 0u; }
+    const uint32_t poff = __shfl_up(off, 1, 64), pne = __shfl_up(ne, 1, 64);
+    unsigned long long brk = __ballot(lane < nc && (lane == 0 || off != poff + pne));
+    while (brk) {          // contiguous pieces: columns ca .. cb
+        const uint32_t ca = (uint32_t)__ffsll((long long)brk) - 1u;
+        brk &= brk - 1;
+        const uint32_t cb = brk ? (uint32_t)__ffsll((long long)brk) - 2u : nc - 1;
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)ca);
+        const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)(inc - ne), (int)ca), f1 = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)cb);
+        const uint4* ge = reinterpret_cast<const uint4*>(mv.entries + g0);
+        uint4* le = reinterpret_cast<uint4*>(S.e + f0);
+        for (uint32_t x = lane; x < 2 * (f1 - f0); x += 64) le[x] = ge[x];
+        const uint4* gm = reinterpret_cast<const uint4*>(mv.match + g0);
+        uint4* lm = reinterpret_cast<uint4*>(S.m + f0);
+        for (uint32_t x = lane; x < f1 - f0; x += 64) lm[x] = gm[x];
+        if (kNodes) {       // a column's nodes sit at the start of its range: copy the range, the tail is never read
+            const uint4* gn = reinterpret_cast<const uint4*>(mv.nodes + g0);
+            uint4* ln = reinterpret_cast<uint4*>(nd_lds + f0);
+            for (uint32_t x = lane; x < f1 - f0; x += 64) ln[x] = gn[x];
+        }
+    }
+    tg_sync();
+    return nc;
+}
+// The predecessor entries of `em` when their list is not inline (more than MATCH_INLINE): the entries of the predecessor node
+// (column staged at pbase, pcount entries; the node starts at state index ps0) whose own predecessor is em.ppp, in list order.
+template <class F>
+__device__ __forceinline__ void pred_scan(const RunStage& S, uint32_t pbase, uint32_t pcount, const Entry& em, uint32_t ps0, F&& f) {
+    const uint32_t ppk = key_delta(em.pp) << 8 | key_base(em.pp);
+    for (uint32_t s = ps0; s < pcount && S.e[pbase + s].node == ppk; ++s)
+        if (S.e[pbase + s].pp == em.ppp) f(s);
+}
+
+template <uint32_t K>
+__global__ __launch_bounds__(64) void k2_run_ac_lds(MsaView mv, const uint32_t* __restrict__ col_ne, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs,
+                                                    int32_t l, long long C, RunT<K>* out, uint8_t* __restrict__ runflag, uint32_t* __restrict__ runlist,
+                                                    uint32_t* __restrict__ runctr, uint32_t* status) {
+    constexpr uint32_t W = K + 1, EPP = 64 / W;
+    __shared__ RunStage S;
+    __shared__ long long ring[2][RL_COLMAX][W];
+    const uint32_t r = blockIdx.x, lane = threadIdx.x;
+    const uint32_t sub = lane / W, li = lane % W;
+    int32_t lo, hi;
+    run_bounds(cuts, n_cuts, r, l, &lo, &hi);
+    uint32_t n_last = 0;
+    for (int32_t p0 = lo + 1; p0 <= hi;) {
+        const uint32_t ctx = p0 > 0 ? 1u : 0u;          // the column in front comes along
+        const int32_t pf = p0 - (int32_t)ctx;
+        const uint32_t nc = run_stage<false>(mv, col_ne, pf, hi, S, nullptr, lane);
+        if (nc <= ctx) {       // left to k2_run_ac / k2_run_dp_a: runlist[0 .. runctr[0])
+            if (lane == 0) { runflag[r] = 1; runlist[atomicAdd(&runctr[0], 1u)] = r; }
+            return;
+        }
+        for (uint32_t c = ctx; c < nc; ++c) {
+            const int32_t p = pf + (int32_t)c;
+            const uint32_t base = S.c_pre[c], n = S.c_pre[c + 1] - base;
+            const uint32_t pbase = c ? S.c_pre[c - 1] : 0u, pn = c ? base - pbase : 0u;
+            const long long cov = S.c_cov[c];
+            long long (*cur)[W] = ring[p & 1];
+            long long (*prev)[W] = ring[(p & 1) ^ 1];
+            n_last = n;
+            for (uint32_t s0 = 0; s0 < n;) {
+                // entries of one insertion depth
+                const uint32_t d0 = S.e[base + s0].node >> 8;
+                const unsigned long long same = __ballot(s0 + lane < n && (S.e[base + s0 + lane].node >> 8) == d0);
+                const uint32_t s1 = s0 + (~same ? (uint32_t)__ffsll((long long)~same) - 1u : 64u);
+                for (uint32_t q = s0; q < s1; q += EPP) {
+                    const uint32_t s = q + sub;
+                    if (sub < EPP && s < s1) {
+                        const Entry& em = S.e[base + s];
+                        const long long w = 10 * (long long)em.link - C * cov;
+                        long long v;
+                        if (key_tpos(em.pp) == -1) v = li == K ? w : AC_NEG;
+                        else {
+                            const int32_t tp = key_tpos(em.pp);
+                            if (tp != p && tp != p - 1) { atomicMax(status, 4u); v = AC_NEG; }
+                            else {
+                                const EMatch mt = S.m[base + s];
+                                long long best = AC_NEG;
+                                auto take = [&](uint32_t sidx) {
+                                    long long vn;
+                                    if (tp == lo) vn = sidx == li ? 0 : AC_NEG;        // the left cut's entries are the inputs
+                                    else vn = (tp == p ? cur : prev)[sidx][li];
+                                    if (vn > best) best = vn;
+                                };
+                                if (mt.n <= MATCH_INLINE) for (uint32_t it = 0; it < mt.n; ++it) take((uint32_t)mt.ps0 + mt.at(it));
+                                else pred_scan(S, tp == p ? base : pbase, tp == p ? n : pn, em, mt.ps0, take);
+                                v = best > AC_NEG ? best + w : AC_NEG;
+                                if (li == K && v < 0) v = 0;
+                            }
+                        }
+                        if (p == hi && r < n_cuts) {
+                            if (li < K) out[r].A[s][li] = v;
+                            else out[r].C[s] = v;
+                        }
+                        cur[s][li] = v;
+                    }
+                }
+                tg_sync();
+                s0 = s1;
+            }
+        }
+        p0 = pf + (int32_t)nc;
+    }
+    if (lane == 0) { out[r].n_out = r < n_cuts ? n_last : 0u; runflag[r] = 0; }
+}
+
+template <int TYPE>
+__global__ __launch_bounds__(64) void k2_run_dp_lds(MsaView mv, const uint32_t* __restrict__ col_ne, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs,
+                                                    int32_t l, DpResult* res, const uint8_t* __restrict__ runflag) {
+    __shared__ RunStage S;
+    __shared__ Node nd_lds[RL_CAP];
+    __shared__ long long ring[2][RL_COLMAX];
+    const uint32_t r = blockIdx.x, lane = threadIdx.x;
+    if (runflag[r]) return;
+    constexpr long long C = (TYPE == RULE_LQ ? 2 : (TYPE == READS_HIFI || TYPE == RULE_LQ_HIFI) ? 4 : 3);
+    int32_t lo, hi;
+    run_bounds(cuts, n_cuts, r, l, &lo, &hi);
+    const int32_t last = r < n_cuts ? hi - 1 : hi;
+    if (lo >= 0) {           // the left cut's scores (k2_scan_apply left them in its entries)
+        const uint32_t n = col_ne[lo];
+        if (lane < n && lane < RL_COLMAX) ring[lo & 1][lane] = mv.entries[mv.col_off[lo] + lane].score;
+    }
+    tg_sync();
+    long long gbest = INT64_MIN;
+    uint64_t gkey = node_key(0, 0, 0xff);
+    for (int32_t p0 = lo + 1; p0 <= last;) {
+        const uint32_t ctx = p0 > 0 ? 1u : 0u;
+        const int32_t pf = p0 - (int32_t)ctx;
+        const uint32_t nc = run_stage<true>(mv, col_ne, pf, last, S, nd_lds, lane);
+        if (nc <= ctx) return;          // cannot happen: k2_run_ac_lds took the run (same columns and one more)
+        for (uint32_t c = ctx; c < nc; ++c) {
+            const int32_t p = pf + (int32_t)c;
+            const uint32_t base = S.c_pre[c], n = S.c_pre[c + 1] - base, nn = S.c_nn[c];
+            const uint32_t pbase = c ? S.c_pre[c - 1] : 0u, pn = c ? base - pbase : 0u;
+            const long long cov = S.c_cov[c];
+            long long* cur = ring[p & 1];
+            const long long* prev = ring[(p & 1) ^ 1];
+            for (uint32_t k0 = 0; k0 < nn;) {
+                const uint32_t d0 = nd_lds[base + k0].key >> 8;
+                const unsigned long long same = __ballot(k0 + lane < nn && (nd_lds[base + k0 + lane].key >> 8) == d0);
+                const uint32_t k1 = k0 + (~same ? (uint32_t)__ffsll((long long)~same) - 1u : 64u);
+                if (k0 + lane < k1) {         // lane = node: np2_core.h dp_column / dp_column_lq on staged data
+                    Node& pb = nd_lds[base + k0 + lane];
+                    Entry* E = S.e + base + pb.start;
+                    const EMatch* M = S.m + base + pb.start;
+                    const uint32_t b = pb.key & 0xffu;
+                    uint32_t best = 0;
+                    long long p_pp_score_ = INT64_MIN, p_pp_score = INT64_MIN;
+                    int tmp = 0;
+                    if (TYPE == READS_ONT)
+                        for (uint32_t mi = 0; mi < pb.len; ++mi)
+                            if ((int)E[mi].link > tmp) tmp = (int)E[mi].link;
+                    for (uint32_t mi = 0; mi < pb.len; ++mi) {
+                        Entry& em = E[mi];
+                        long long sc = 0;
+                        const long long w = 10 * (long long)em.link - C * cov;
+                        if (key_tpos(em.pp) == -1) sc = w;
+                        else {
+                            const int32_t tp = key_tpos(em.pp);
+                            const long long* src = tp == p ? cur : prev;
+                            const EMatch mt = M[mi];
+                            const uint32_t ppb = key_base(em.pp), pppb = key_base(em.ppp);
+                            auto take = [&](uint32_t sidx) {
+                                const long long en_score = src[sidx];
+                                const long long cand = en_score + w;
+                                if (cand > sc) { sc = cand; p_pp_score_ = en_score; }
+                                if (TYPE == READS_CLR || TYPE == READS_HIFI || TYPE == RULE_LQ_HIFI) {
+                                    if (en_score > p_pp_score || (en_score == p_pp_score && ppb != 4)) { best = mi; p_pp_score = en_score; }
+                                } else if (TYPE == READS_ONT) {
+                                    if (((key_delta(em.ppp) > 1 || key_delta(em.pp) > 0) && ((double)em.link > (double)cov * 0.2 || (int)em.link > tmp / 2)) ||
+                                        ((int)em.link > (int)E[best].link / 2 && en_score > p_pp_score && (ppb == 4 || ppb == b || pppb == b || ppb == pppb))) {
+                                        best = mi;
+                                        p_pp_score = en_score;
+                                    }
+                                } else if (TYPE == RULE_LQ) {
+                                    if ((int)em.link > (int)E[best].link / 2 && en_score > p_pp_score && (ppb == 4 || ppb == b || pppb == b || ppb == pppb)) {
+                                        best = mi;
+                                        p_pp_score = en_score;
+                                    }
+                                }
+                            };
+                            if (mt.n <= MATCH_INLINE) for (uint32_t it = 0; it < mt.n; ++it) take((uint32_t)mt.ps0 + mt.at(it));
+                            else pred_scan(S, tp == p ? base : pbase, tp == p ? n : pn, em, mt.ps0, take);
+                        }
+                        em.score = sc;
+                        cur[pb.start + mi] = sc;
+                        if (TYPE == READS_RS) {
+                            if (sc >= E[best].score) { best = mi; p_pp_score = p_pp_score_; }
+                        } else if (sc > E[best].score || (sc == E[best].score && key_base(em.pp) != 4)) {
+                            best = mi;
+                            p_pp_score = p_pp_score_;
+                        }
+                    }
+                    pb.best = best;
+                }
+                tg_sync();
+                k0 = k1;
+            }
+            if ((TYPE != RULE_LQ && TYPE != RULE_LQ_HIFI) && p == l - 1) {     // global best node: nodes in order, the last of equals wins
+                for (uint32_t k = 0; k < nn; ++k) {
+                    const Node& pb = nd_lds[base + k];
+                    if (!pb.len) continue;
+                    const long long sc = S.e[base + pb.start + pb.best].score;
+                    if (sc >= gbest) {
+                        gkey = node_key(p, pb.key >> 8, pb.key & 0xffu);
+                        if (sc > gbest) gbest = sc;
+                    }
+                }
+            }
+        }
+        // scores and best indices back to the graph (not the column in front: its staged scores are not the real ones)
+        const uint32_t n_total = S.c_pre[nc];
+        for (uint32_t f = S.c_pre[ctx] + lane; f < n_total; f += 64) {
+            uint32_t clo = 0, chi = nc;          // column of staged entry f
+            while (chi - clo > 1) { const uint32_t mid = (clo + chi) >> 1; if (S.c_pre[mid] <= f) clo = mid; else chi = mid; }
+            const uint32_t g = S.c_off[clo] + (f - S.c_pre[clo]);
+            mv.entries[g].score = S.e[f].score;
+            if (f - S.c_pre[clo] < S.c_nn[clo]) mv.nodes[g].best = nd_lds[f].best;
+        }
+        tg_sync();
+        p0 = pf + (int32_t)nc;
+    }
+    if (r >= n_cuts && hi == l - 1 && lane == 0) publish_best<TYPE>(mv, l, gbest, gkey, res);
 }
 
 // ---- parallel backtrace over the runs --------------------------------------------------------------------------
@@ -1494,7 +1766,8 @@ class HipExec : public Exec {
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
     DevBuf runsz_, runoff_, live_, ematch_, xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
-    DevBuf tilecnt_, tileoff_, tilecur_, tilelist_, tilectr_, ntags_;
+    DevBuf tilecnt_, tileoff_, tilecur_, tilelist_, tilectr_, ntags_, colne_, runflag_, runlist_, runctr_;
+    bool graph_compact_ = false;   // the graph in HBM was built by tiles: columns are contiguous, every entry slot is live
     DevBuf ondpool_, ondregs_, ondcoff_, ondclen_, ondpairof_, ondpairs_, ondres_, ondout_, ondv_, ondlo_, ondch_, ondplen_, ondpkind_, ondppos_, ondtot_;
     PinBuf pin_;
     std::vector<uint32_t> win_first_chunk_, win_n_chunks_;   // chunk range of every stream of the last run_window
@@ -1755,8 +2028,28 @@ bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t
     uint32_t rpw_ac = dense ? 64u / (K + 1) : 1u, rpw_dp = dense ? 64u : 1u;
     if (getenv("NP2_RPW_DP")) rpw_dp = std::min(64u, std::max(1u, (uint32_t)atoi(getenv("NP2_RPW_DP"))));   // tuning experiments
     if (getenv("NP2_RPW_AC")) rpw_ac = std::min(64u / (K + 1), std::max(1u, (uint32_t)atoi(getenv("NP2_RPW_AC"))));
+    // graphs built by tiles: one wave per run, columns staged in LDS; the runs those kernels flag take the kernels that walk HBM
+    const bool staged = graph_compact_ && mv.match && !getenv("NP2_RUN_GLOBAL");
+    const uint8_t* only = nullptr;
+    const uint32_t* list = nullptr;
+    const uint32_t* n_list = nullptr;
+    if (staged) {
+        if (!runflag_.ensure((size_t)n_runs + 64) || !runlist_.ensure(4ull * n_runs + 64) || !runctr_.ensure(64)) { *err = "out of device memory (dp runs)"; return false; }
+        only = runflag_.as<uint8_t>();
+        list = runlist_.as<uint32_t>();
+        n_list = runctr_.as<uint32_t>();
+        HIPOK(hipMemsetAsync(runctr_.p, 0, 64, q));
+        k2_run_ac_lds<K><<<n_runs, 64, 0, q>>>(mv, colne_.as<uint32_t>(), cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, runt_.as<RT>(), runflag_.as<uint8_t>(),
+                                                runlist_.as<uint32_t>(), runctr_.as<uint32_t>(), status);
+        if (clk && clk->on) {
+            uint32_t c[3] = {0, 0, 0};
+            (void)hipMemcpyAsync(c, runctr_.p, 12, hipMemcpyDeviceToHost, q);
+            (void)hipStreamSynchronize(q);
+            fprintf(stderr, "[np2 dp] %u of %u runs left to the kernels that walk HBM (a column over %u entries)\n", c[0], n_runs, RL_COLMAX);
+        }
+    }
     k2_run_ac<K><<<nblk(n_runs, rpw_ac), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, C, eav_.as<long long>(), runoff_.as<uint32_t>(), runt_.as<RT>(),
-                                                      rpw_ac, status);
+                                                      rpw_ac, status, list, n_list);
     if (clk) clk->mark("dp.ac");
     if (n_cuts) {
         const uint32_t n_groups = nblk(n_cuts, SCAN_G);
@@ -1782,7 +2075,8 @@ bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t
     if (clk) clk->mark("dp.scan");
 #define NP2_RUN_DP(T)                                                                                                         \
     do {                                                                                                                      \
-        k2_run_dp_a<T><<<nblk(n_runs, rpw_dp), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), rpw_dp);               \
+        if (staged) k2_run_dp_lds<T><<<n_runs, 64, 0, q>>>(mv, colne_.as<uint32_t>(), cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), only); \
+        k2_run_dp_a<T><<<nblk(n_runs, rpw_dp), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), rpw_dp, list, n_list); \
         if (n_cuts) k2_run_dp_b<T><<<nblk(n_cuts, rpw_dp), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, l, res_.as<DpResult>(), rpw_dp);          \
     } while (0)
     switch (rule) {
@@ -1834,7 +2128,7 @@ int HipExec::build_graph_tiles(const std::vector<uint32_t>& n_tags, uint32_t n_c
     const uint32_t nst = nblk(n_tiles + 1, SCAN_TILE);
 #define TILEOK(x) do { if ((x) != hipSuccess) { *err = std::string("HIP error in ") + #x; return 0; } } while (0)
     if (!tilecnt_.ensure(4ull * (n_tiles + 2)) || !tileoff_.ensure(4ull * (n_tiles + 2)) || !tilecur_.ensure(4ull * (n_tiles + 2)) ||
-        !tilelist_.ensure(sizeof(TileStream) * list_cap + 64) || !tilectr_.ensure(64) || !ntags_.ensure(4ull * n_streams + 16) ||
+        !tilelist_.ensure(sizeof(TileStream) * list_cap + 64) || !tilectr_.ensure(64) || !colne_.ensure(4ull * (n_cols + 2)) || !ntags_.ensure(4ull * n_streams + 16) ||
         !sums_.ensure(4ull * (nst + 2)) || !entries_.ensure(sizeof(Entry) * tag_total + 64) || !nodes_.ensure(sizeof(Node) * tag_total + 64)) {
         *err = "out of device memory (link graph)";
         return 0;
@@ -1852,7 +2146,7 @@ int HipExec::build_graph_tiles(const std::vector<uint32_t>& n_tags, uint32_t n_c
                                                           tags_.as<uint8_t>(), n_tiles, nullptr, tileoff_.as<uint32_t>(), tilecur_.as<uint32_t>(), tilelist_.as<TileStream>());
     if (clk) clk->mark("tiles.list");
     TileArgs A{tags_.as<uint8_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), ntags_.as<uint32_t>(), tileoff_.as<uint32_t>(), tilelist_.as<TileStream>(),
-               n_tiles, n_cols, entries_.as<Entry>(), nodes_.as<Node>(), coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), tilectr_.as<uint32_t>()};
+               n_tiles, n_cols, entries_.as<Entry>(), nodes_.as<Node>(), coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), colne_.as<uint32_t>(), tilectr_.as<uint32_t>()};
     k2_tile_graph<<<n_tiles, 64, 0, q>>>(A);
     uint32_t ctr[2] = {0, 0};
     TILEOK(hipMemcpyAsync(ctr, tilectr_.p, 8, hipMemcpyDeviceToHost, q));
@@ -1868,6 +2162,7 @@ int HipExec::build_graph_tiles(const std::vector<uint32_t>& n_tags, uint32_t n_c
     }
 #undef TILEOK
     *total_out = total;
+    graph_compact_ = true;
     return 1;
 }
 
@@ -1896,6 +2191,7 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
         k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nsc);
         k2_scan_final<<<nsc, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), n_chunks + 1, sums2_.as<uint32_t>(), chpre_.as<uint32_t>());
     }
+    graph_compact_ = false;
     static const bool scatter_only = getenv("NP2_GRAPH_SCATTER") != nullptr;
     if (n_chunks && !scatter_only) {
         const int r = build_graph_tiles(n_tags, n_chunks, n_cols, total_out, err, clk);

@@ -17,10 +17,10 @@ PRODUCT_SO = os.path.join(HERE, "..", "nextpolish_amd", "lib", "nextpolish2.so")
 LQ_CASES = {"ont_lq_regions", "clr_lq_regions"}   # windows with low-quality regions: POA pseudo-seeds + graph re-consensus
 
 
-def run_polish(so_path, fa, fofn, read_type, split=0):
+def run_polish(so_path, fa, fofn, read_type, split=0, env=None):
     code = ("import sys, json; sys.path.insert(0, %r); import ref2_binding as rb; L = rb.bind(%r); "
             "print(json.dumps(rb.polish(L, %r, %r, read_type=%d, split=%d)))" % (HERE, so_path, fa, fofn, read_type, split))
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     if p.returncode != 0:
         return None, p.stderr
     return json.loads(p.stdout.strip().splitlines()[-1]), p.stderr
@@ -164,3 +164,36 @@ def test_gpu_reads_dealt_over_three_bam_files(tmp_path):
     assert got is not None, err
     for n, _ in contigs:
         assert got[n][0][0] == GOLD["multi_bam"]["expected"][n]
+
+
+@pytest.mark.parametrize("cid", ["ont_35x_noisy", "ont_lq_regions", "hifi_35x_indels", "ont_reads_with_iupac_codes"])
+def test_gpu_scatter_graph_path_matches_reference_goldens(cid, tmp_path):
+    """The link graph has two builders: by tiles in LDS (default) and by scattering observations into column buckets (taken by
+    windows whose tiles overflow).  NP2_GRAPH_SCATTER=1 sends every window down the second one."""
+    kw, rt = next((k, r) for c, k, r in np2_cases.CASES if c == cid)
+    fa, fofn, contigs = np2_cases.materialise(kw, str(tmp_path))
+    got, err = run_polish(PRODUCT_SO, fa, fofn, rt, env={"NP2_GRAPH_SCATTER": "1"})
+    assert got is not None, err
+    for n, _ in contigs:
+        assert got[n][0][0] == GOLD["cases"][cid]["expected"][n], "%s %s" % (cid, n)
+
+
+@pytest.mark.skipif(not rb.available(), reason="oracle/_ref did not travel")
+def test_gpu_tiles_with_more_streams_than_the_lds_list_holds(tmp_path):
+    """220x over a short contig: every tile of 64 columns is crossed by more streams than its sorted list in LDS holds (128), so
+    the tile kernel selects the next stream from HBM; tiles that overflow their entry pool send the window down the scatter path.
+    Both must give the compiled reference's consensus."""
+    from nextpolish_amd import _native as nat
+    for seed, depth, sub in ((61, 220.0, None), (62, 160.0, None)):
+        st = nat.Stream.synth_long([30000], depth=depth, seed=seed)
+        d = tmp_path / ("d%d" % seed)
+        d.mkdir()
+        fa, bam, fofn = str(d / "g.fa"), str(d / "r.bam"), str(d / "bam.fofn")
+        st.write_files(fa, bam)
+        st.close()
+        open(fofn, "w").write(bam + "\n")
+        got, err = run_polish(PRODUCT_SO, fa, fofn, 1, env={"NP2_TIMING": "1"})
+        assert got is not None, err
+        want, err2 = run_polish(os.path.realpath(rb.REF_SO), fa, fofn, 1)
+        assert want is not None, err2
+        assert got == want
