@@ -1387,15 +1387,18 @@ struct BtPick { uint32_t start; uint32_t count; uint32_t off; uint32_t used; }; 
 
 template <bool kLq, bool kWrite>
 __global__ void k2_bt_runs(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, BtWalk* walks,
-                           const BtPick* pick, ConsBase* cons, char* chars, uint32_t* status, uint32_t K) {
-    const uint32_t r = blockIdx.x;
-    if (r >= n_runs) return;
+                           const BtPick* pick, ConsBase* cons, char* chars, uint32_t* status, uint32_t K, uint32_t rpw) {
+    // a walk is a chain of dependent loads: `rpw` runs share a wave (K start nodes each on the first pass, the one chosen start
+    // on the second) and diverge
+    const uint32_t lanes_per_run = kWrite ? 1u : K;
+    const uint32_t r = blockIdx.x * rpw + threadIdx.x / lanes_per_run;
+    if (r >= n_runs || threadIdx.x >= rpw * lanes_per_run) return;
     int32_t lo, hi;
     run_bounds(cuts, n_cuts, r, l, &lo, &hi);
-    uint32_t s = threadIdx.x;
+    uint32_t s = threadIdx.x % lanes_per_run;
     uint64_t cur;
     if (kWrite) {
-        if (s != 0 || !pick[r].used) return;
+        if (!pick[r].used) return;
         s = pick[r].start;
     }
     if (r < n_cuts) {
@@ -1472,9 +1475,10 @@ __global__ void k2_bt_groups(const BtWalk* walks, uint32_t n_runs, BtGroup* grp,
     }
     grp[(uint64_t)g * K + s] = BtGroup{cur, cnt, ended, invalid};
 }
-__global__ void k2_bt_chain(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, const BtGroup* grp,
-                            uint32_t n_groups, BtGroupPick* gp, uint32_t* total_out, uint32_t* status, uint32_t K) {
-    if (blockIdx.x || threadIdx.x) return;
+__global__ __launch_bounds__(64) void k2_bt_chain(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, const DpResult* res, const BtGroup* grp,
+                                                   uint32_t n_groups, BtGroupPick* gp, uint32_t* total_out, uint32_t* status, uint32_t K) {
+    if (blockIdx.x) return;
+    const uint32_t lane = threadIdx.x;
     // start of the right-most run: the open run has a single start (the global best node); a window ending on a cut
     // column starts from that node's index among the cut's nodes
     uint32_t s = 0;
@@ -1484,21 +1488,50 @@ __global__ void k2_bt_chain(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, u
         const Node* nd = mv.nodes + mv.col_off[hi];
         const uint32_t key = key_delta(cur) << 8 | key_base(cur), nn = mv.col_nn[hi];
         while (s < nn && nd[s].key != key) ++s;
-        if (key_tpos(cur) != hi || s >= nn || s >= K) { *status = 2; *total_out = 0; return; }
+        if (key_tpos(cur) != hi || s >= nn || s >= K) { if (lane == 0) { *status = 2; *total_out = 0; } return; }
     }
-    int64_t g = (int64_t)n_groups - 1, first_used = (int64_t)n_groups;
-    for (; g >= 0; --g) {
-        const BtGroup e = grp[(uint64_t)g * K + s];
-        if (e.invalid) { *status = 2; break; }
-        gp[g] = BtGroupPick{s, e.count, 1, 0};   // off holds the count until the prefix pass below
-        first_used = g;
-        if (e.ended) break;
-        s = e.exit_idx;
+    // Right to left.  The map of a group does not depend on where the chain enters it, so the maps of 64 / K groups are fetched at
+    // once (lanes = group x start) and the chain is threaded through them with lane reads; the fetch of the next batch is in
+    // flight meanwhile.
+    const uint32_t gpb = 64u / K;                      // groups per batch
+    const uint32_t sub = lane / K, st = lane % K;      // lane = (group gi - sub, start st)
+    int64_t first_used = (int64_t)n_groups;
+    bool stop = false;
+    BtGroup nxt{0, 0, 0, 0};
+    {
+        const int64_t g = (int64_t)n_groups - 1 - (int64_t)sub;
+        if (sub < gpb && g >= 0) nxt = grp[(uint64_t)g * K + st];
     }
-    for (int64_t q = 0; q < first_used; ++q) gp[q] = BtGroupPick{0, 0, 0, 0};
-    uint32_t off = 0;
-    for (int64_t q = first_used; q < (int64_t)n_groups; ++q) { const uint32_t c = gp[q].off; gp[q].off = off; off += c; }
-    *total_out = off;
+    for (int64_t gi = (int64_t)n_groups - 1; gi >= 0 && !stop; gi -= gpb) {
+        const BtGroup e = nxt;
+        {
+            const int64_t g = gi - (int64_t)gpb - (int64_t)sub;
+            if (sub < gpb && g >= 0) nxt = grp[(uint64_t)g * K + st];
+        }
+        for (uint32_t k = 0; k < gpb && gi - (int64_t)k >= 0; ++k) {
+            const int src = (int)(k * K + s);
+            const uint32_t exit_idx = (uint32_t)__builtin_amdgcn_readlane((int)e.exit_idx, src), cnt = (uint32_t)__builtin_amdgcn_readlane((int)e.count, src);
+            const uint32_t ended = (uint32_t)__builtin_amdgcn_readlane((int)e.ended, src), invalid = (uint32_t)__builtin_amdgcn_readlane((int)e.invalid, src);
+            if (invalid) { if (lane == 0) *status = 2; stop = true; break; }
+            if (lane == 0) gp[gi - k] = BtGroupPick{s, cnt, 1, 0};   // off holds the count until the prefix pass below
+            first_used = gi - (int64_t)k;
+            if (ended) { stop = true; break; }
+            s = exit_idx;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t q = lane; q < first_used; q += 64) gp[q] = BtGroupPick{0, 0, 0, 0};
+    uint32_t carry = 0;
+    for (int64_t q0 = first_used; q0 < (int64_t)n_groups; q0 += 64) {
+        const int64_t q = q0 + lane;
+        const uint32_t c = q < (int64_t)n_groups ? gp[q].off : 0u;
+        uint32_t inc = c;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += v; }
+        if (q < (int64_t)n_groups) gp[q].off = carry + inc - c;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    if (lane == 0) *total_out = carry;
 }
 __global__ void k2_bt_place(const BtWalk* walks, uint32_t n_runs, const BtGroupPick* gp, BtPick* pick, uint32_t K) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2090,8 +2123,9 @@ bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t
 #undef NP2_RUN_DP
     if (clk) clk->mark("dp.replay");
     // ---- backtrace: walk every start, chain the runs, write
-    if (lq) k2_bt_runs<true, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status, K);
-    else k2_bt_runs<false, false><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status, K);
+    const uint32_t rpw_bt0 = dense ? 64u / K : 1u, rpw_bt1 = dense ? 64u : 1u;
+    if (lq) k2_bt_runs<true, false><<<nblk(n_runs, rpw_bt0), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status, K, rpw_bt0);
+    else k2_bt_runs<false, false><<<nblk(n_runs, rpw_bt0), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), btwalk_.as<BtWalk>(), nullptr, nullptr, nullptr, status, K, rpw_bt0);
     {
         const uint32_t n_bgroups = nblk(n_runs, BT_G);
         if (!btgrp_.ensure(sizeof(BtGroup) * K * (size_t)n_bgroups + 64) || !btgpick_.ensure(sizeof(BtGroupPick) * (size_t)n_bgroups + 64)) {
@@ -2103,8 +2137,8 @@ bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t
                                      btgpick_.as<BtGroupPick>(), total_dev, status, K);
         k2_bt_place<<<nblk(n_bgroups, 64), 64, 0, q>>>(btwalk_.as<BtWalk>(), n_runs, btgpick_.as<BtGroupPick>(), btpick_.as<BtPick>(), K);
     }
-    if (lq) k2_bt_runs<true, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), nullptr, cons_.as<char>(), status, K);
-    else k2_bt_runs<false, true><<<n_runs, 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), cons_.as<ConsBase>(), nullptr, status, K);
+    if (lq) k2_bt_runs<true, true><<<nblk(n_runs, rpw_bt1), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), nullptr, cons_.as<char>(), status, K, rpw_bt1);
+    else k2_bt_runs<false, true><<<nblk(n_runs, rpw_bt1), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), cons_.as<ConsBase>(), nullptr, status, K, rpw_bt1);
     DpResult res;
     uint32_t st2[2] = {0, 0};
     HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));
