@@ -280,14 +280,25 @@ __device__ __forceinline__ uint32_t tag_nib(const uint8_t* tg, uint32_t i) {
     const uint32_t t = tg[i >> 1];
     return (i & 1) ? (t & 15u) : (t >> 4);
 }
-__global__ void k2_chunk_count(const ChunkDesc* cd, uint32_t n_chunks, const uint64_t* tag_off, const uint8_t* tags, uint32_t* cnt) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+// A chunk is 512 tags = 64 dwords: one wave per chunk, one coalesced dword (8 tags) per lane.  Tag t of a dword sits in byte t / 2,
+// high nibble first; its insertion bit is bit 8 * (t / 2) + (t even ? 7 : 3).
+__device__ __forceinline__ uint32_t dword_ins_mask(uint32_t v) {          // insertion bits of the first v (<= 8) tags of a dword
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 8; ++t) m |= t < v ? 1u << (8u * (t >> 1) + ((t & 1u) ? 3u : 7u)) : 0u;
+    return m;
+}
+__device__ __forceinline__ uint32_t dword_nib(uint32_t w, uint32_t t) { return (w >> (8u * (t >> 1) + ((t & 1u) ? 0u : 4u))) & 15u; }
+__global__ __launch_bounds__(256) void k2_chunk_count(const ChunkDesc* cd, uint32_t n_chunks, const uint64_t* tag_off, const uint8_t* tags, uint32_t* cnt) {
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (c >= n_chunks) return;
     const ChunkDesc d = cd[c];
-    const uint8_t* tg = tags + tag_off[d.stream];
-    uint32_t n = 0;
-    for (uint32_t i = 0; i < d.n_tags; ++i) n += (tag_nib(tg, d.first_tag + i) & 8u) ? 0u : 1u;
-    cnt[c] = n;
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(tags + tag_off[d.stream] + (d.first_tag >> 1));   // streams start on 4-byte boundaries
+    const uint32_t v = 8u * lane < d.n_tags ? min(8u, d.n_tags - 8u * lane) : 0u;
+    const uint32_t w = v ? tw[lane] : 0u;
+    uint32_t n = v - (uint32_t)__popc(w & dword_ins_mask(v));
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (lane == 0) cnt[c] = n;
 }
 // position (t_pos, delta) of tag j of a stream given T = number of non-insertion tags among tags 0..j
 __device__ __forceinline__ void tag_pos(const uint8_t* tg, uint32_t j, uint32_t T, uint32_t aln_t_s, int32_t* t_pos, uint32_t* delta) {
@@ -433,38 +444,53 @@ __global__ __launch_bounds__(256) void k2_build_b(const DevObs* __restrict__ obs
 // A finished tile orders each column's few entries by node, takes its place in the COMPACT entry / node arrays with one
 // atomic, and writes them.  A tile with more than TG_POOL distinct entries or a column with more than TG_COLMAX (deep
 // pileups, thousand-base insertions) raises a flag and the window takes the scatter path instead.
-constexpr uint32_t TG_POOL = 1536, TG_MAXS = 128, TG_COLMAX = 96, TG_NONE = 0xffffu;
+constexpr uint32_t TG_COLMAX = 96, TG_NONE = 0xffffu;
+// LDS of a tile: POOL entries, MAXS streams in the sorted list.  Two sizes are built: the work is one chain of dependent LDS
+// operations per wave, so what decides the speed is how many waves fit a CU next to each other, and a 20x window needs a third of
+// what a 60x window needs.
+template <uint32_t POOL, uint32_t MAXS>
 struct TileLds {
-    unsigned long long key[TG_POOL];
-    uint32_t link[TG_POOL];                 // bit 31 (set while the tile is finished): first entry of its node
-    uint16_t next[TG_POOL];
-    uint32_t head[64], tail[64], cnt[64];
+    unsigned long long key[POOL];
+    uint32_t link[POOL];                    // bit 31 (set while the tile is finished): first entry of its node
+    uint16_t next[POOL];
+    uint8_t col[POOL];                      // column of the entry inside the tile
+    uint32_t head[64], tail[64], cnt[64], nn[64];
     uint32_t used;
-    uint32_t sid[TG_MAXS], sstart[TG_MAXS], tsid[TG_MAXS], tstart[TG_MAXS];
+    uint32_t sid[MAXS], sstart[MAXS], tsid[MAXS], tstart[MAXS];
+    uint64_t stoff[MAXS];                   // per sorted stream: tag offset, start position, number of tags
+    uint32_t sts[MAXS], snt[MAXS];
 };
 struct TileStream { uint32_t stream, start; };
 
-// lane per chunk of a stream: the tiles its non-insertion tags open (position % 64 == 0, or the stream's first tag)
-template <bool kFill>
-__global__ void k2_tile_list(const ChunkDesc* cd, uint32_t n_chunks, const uint32_t* pre, const uint64_t* tag_off, const uint32_t* aln_t_s,
-                             const uint8_t* tags, uint32_t n_tiles, uint32_t* tile_cnt, const uint32_t* tile_off, uint32_t* cursor, TileStream* list) {
+// the tiles the non-insertion tags of a stream open (position % 64 == 0, or the stream's first tag): counted with a lane per chunk
+// from the chunk's position range, listed with a wave per chunk (lane = 8 tags, positions from a prefix sum over the lanes)
+__global__ void k2_tile_count(const ChunkDesc* cd, uint32_t n_chunks, const uint32_t* pre, const uint32_t* aln_t_s, uint32_t n_tiles, uint32_t* tile_cnt) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const ChunkDesc d = cd[c];
     const uint32_t ts = aln_t_s[d.stream];
     const uint32_t a = ts + (pre[c] - pre[d.first_chunk_of_stream]), n = pre[c + 1] - pre[c];   // positions [a, a + n)
     if (!n) return;
-    if (!kFill) {
-        if (d.first_tag == 0 && (ts & 63u) && (ts >> 6) < n_tiles) atomicAdd(&tile_cnt[ts >> 6], 1u);
-        for (uint32_t t = (a + 63u) >> 6; t <= (a + n - 1) >> 6 && t < n_tiles; ++t) atomicAdd(&tile_cnt[t], 1u);
-        return;
-    }
-    const uint8_t* tg = tags + tag_off[d.stream];
-    uint32_t p = a;
-    for (uint32_t i = 0; i < d.n_tags; ++i) {
-        if (tag_nib(tg, d.first_tag + i) & 8u) continue;
-        if ((!(p & 63u) || d.first_tag + i == 0) && (p >> 6) < n_tiles)
-            list[tile_off[p >> 6] + atomicAdd(&cursor[p >> 6], 1u)] = TileStream{d.stream, d.first_tag + i};
+    if (d.first_tag == 0 && (ts & 63u) && (ts >> 6) < n_tiles) atomicAdd(&tile_cnt[ts >> 6], 1u);
+    for (uint32_t t = (a + 63u) >> 6; t <= (a + n - 1) >> 6 && t < n_tiles; ++t) atomicAdd(&tile_cnt[t], 1u);
+}
+__global__ __launch_bounds__(256) void k2_tile_list(const ChunkDesc* cd, uint32_t n_chunks, const uint32_t* pre, const uint64_t* tag_off, const uint32_t* aln_t_s,
+                                                    const uint8_t* tags, uint32_t n_tiles, const uint32_t* tile_off, uint32_t* cursor, TileStream* list) {
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (c >= n_chunks) return;
+    const ChunkDesc d = cd[c];
+    const uint32_t a = aln_t_s[d.stream] + (pre[c] - pre[d.first_chunk_of_stream]);
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(tags + tag_off[d.stream] + (d.first_tag >> 1));
+    const uint32_t v = 8u * lane < d.n_tags ? min(8u, d.n_tags - 8u * lane) : 0u;
+    const uint32_t w = v ? tw[lane] : 0u;
+    const uint32_t n = v - (uint32_t)__popc(w & dword_ins_mask(v));
+    uint32_t inc = n;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
+    uint32_t p = a + inc - n;
+    for (uint32_t t = 0; t < v; ++t) {
+        if (dword_nib(w, t) & 8u) continue;
+        const uint32_t i = d.first_tag + 8u * lane + t;
+        if ((!(p & 63u) || i == 0) && (p >> 6) < n_tiles) list[tile_off[p >> 6] + atomicAdd(&cursor[p >> 6], 1u)] = TileStream{d.stream, i};
         ++p;
     }
 }
@@ -472,7 +498,9 @@ __global__ void k2_tile_list(const ChunkDesc* cd, uint32_t n_chunks, const uint3
 struct TileArgs {
     const uint8_t* tags; const uint64_t* tag_off; const uint32_t* aln_t_s; const uint32_t* n_tags;
     const uint32_t* tile_off; const TileStream* list; uint32_t n_tiles, n_cols;
-    Entry* entries; Node* nodes; uint32_t* col_off; uint32_t* col_nn; uint32_t* col_ne; uint32_t* counter;   // counter[0] entries placed, [1] overflow flag
+    Entry* entries; Node* nodes; uint32_t* col_off; uint32_t* col_nn; uint32_t* col_ne; uint32_t* counter;   // counter[0] entries placed, [1] overflow flag, [2] tiles in redo[]
+    uint32_t* redo;            // tiles that did not fit this launch's pool (nullptr: flag the window instead)
+    const uint32_t* todo;      // nullptr: tile = block; else tile = todo[block] for block < counter[2]
 };
 
 // own node + predecessors of an entry in 62 bits; predecessor positions relative to the column (pp: 0..1 back, ppp: 0..2 back)
@@ -489,18 +517,25 @@ __device__ __forceinline__ void tg_unpack(unsigned long long k, int32_t tp, uint
     *pp = ((k >> 19) & 1ull) ? KEY_HEAD : node_key(tp - (int32_t)((k >> 20) & 1ull), (uint32_t)((k >> 21) & 0xffffu), (uint32_t)((k >> 37) & 7u));
     *ppp = ((k >> 40) & 1ull) ? KEY_HEAD : node_key(tp - (int32_t)((k >> 41) & 3ull), (uint32_t)((k >> 43) & 0xffffu), (uint32_t)((k >> 59) & 7u));
 }
+// lanes of one wave hand LDS data to each other: orders the LDS operations only (a fence over all address spaces would also wait
+// for the global loads that are in flight on purpose)
 __device__ __forceinline__ void tg_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A) {
-    __shared__ TileLds L;
+template <bool kProf, uint32_t TG_POOL, uint32_t TG_MAXS>
+__global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A, unsigned long long* prof) {
+    long long tk = kProf ? clock64() : 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+#define TG_TICK(i) do { if (kProf) { const long long now = clock64(); ph[i] += (unsigned long long)(now - tk); tk = now; } } while (0)
+    __shared__ TileLds<TG_POOL, TG_MAXS> L;
     const uint32_t lane = threadIdx.x;
-    const uint32_t t = blockIdx.x;
+    if (A.todo && blockIdx.x >= A.counter[2]) return;
+    const uint32_t t = A.todo ? A.todo[blockIdx.x] : blockIdx.x;
     const uint32_t c0 = t << 6, c1 = c0 + 63;
     const unsigned long long lane_le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-    L.head[lane] = TG_NONE; L.tail[lane] = TG_NONE; L.cnt[lane] = 0;
+    L.head[lane] = TG_NONE; L.tail[lane] = TG_NONE; L.cnt[lane] = 0; L.nn[lane] = 0;
     if (lane == 0) L.used = 0;
     // ---- the tile's streams in ascending order
     const uint32_t l0 = A.tile_off[t], ns = A.tile_off[t + 1] - l0;
@@ -516,11 +551,32 @@ __global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A) {
         }
     }
     tg_sync();
+    if (cached) {
+        for (uint32_t j = lane; j < ns; j += 64) { const uint32_t s = L.sid[j]; L.stoff[j] = A.tag_off[s]; L.sts[j] = A.aln_t_s[s]; L.snt[j] = A.n_tags[s]; }
+        tg_sync();
+    }
+    // The tags of a stream inside the tile are fetched one stream ahead: lane k holds the nibbles of tags i0 + k and i0 + 64 + k
+    // (64 columns hold at least 64 tags of a stream that crosses them, so the second fetch is the rule) and, for the state in
+    // front of tag i0, of tag i0 - 1 - k.
+    uint32_t pf_back = 0, pf_a = 0, pf_b = 0;          // raw bytes (the loads are unconditional so that they stay in flight; indices are clamped)
+    auto prefetch = [&](uint32_t j) {
+        const uint8_t* tg = A.tags + L.stoff[j];
+        const uint32_t i0 = L.sstart[j], nt = L.snt[j];
+        pf_back = tg[(lane < i0 ? i0 - 1 - lane : 0u) >> 1];
+        pf_a = tg[min(i0 + lane, nt - 1) >> 1];
+        pf_b = tg[min(i0 + 64 + lane, nt - 1) >> 1];
+    };
+    auto nib_of = [](uint32_t byte, uint32_t i) { return (i & 1u) ? (byte & 15u) : (byte >> 4); };
+    if (cached && ns) prefetch(0);
+    TG_TICK(0);
     uint32_t prev_s = 0;
     for (uint32_t j = 0; j < ns; ++j) {
         uint32_t s, i0;
-        if (cached) { s = L.sid[j]; i0 = L.sstart[j]; }
-        else {            // a very crowded tile: the next stream by selection over the list
+        const uint32_t raw_back = pf_back, raw_a = pf_a, raw_b = pf_b;
+        if (cached) {
+            s = L.sid[j]; i0 = L.sstart[j];
+            if (j + 1 < ns) prefetch(j + 1);
+        } else {            // a very crowded tile: the next stream by selection over the list
             unsigned long long best = ~0ull;
             for (uint32_t q = lane; q < ns; q += 64) {
                 const TileStream e = A.list[l0 + q];
@@ -533,27 +589,39 @@ __global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A) {
         s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
         i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
         prev_s = s;
-        const uint8_t* tg = A.tags + A.tag_off[s];
-        const uint32_t ts = A.aln_t_s[s], nt = A.n_tags[s];
+        if (!cached) {      // through the same LDS slots as the cached lists (one kind of load below: no generic pointers)
+            if (lane == 0) { L.stoff[0] = A.tag_off[s]; L.sts[0] = A.aln_t_s[s]; L.snt[0] = A.n_tags[s]; }
+            tg_sync();
+        }
+        const uint32_t jj = cached ? j : 0u;
+        const uint8_t* tg = A.tags + L.stoff[jj];
+        const uint32_t ts = L.sts[jj], nt = L.snt[jj];
+        const uint32_t nb_back = lane < i0 ? nib_of(raw_back, i0 - 1 - lane) : 0u;          // in front of the stream: like a non-insertion tag
+        const uint32_t nb_a = nib_of(raw_a, i0 + lane), nb_b = nib_of(raw_b, i0 + 64 + lane);
         // state in front of tag i0: position of the last non-insertion tag, the two tags before it (as node keys), the open insertion run
         int32_t T0 = (int32_t)max(c0, ts) - 1;
         unsigned long long P1 = KEY_HEAD, P2 = KEY_HEAD;
         uint32_t D0 = 0;
         if (i0 >= 1) {
             int32_t tp; uint32_t dl;
-            const uint32_t nb1 = tag_nib(tg, i0 - 1);
-            tag_pos(tg, i0 - 1, (uint32_t)(T0 + 1) - ts, ts, &tp, &dl);          // tags 0 .. i0-1 hold T0 + 1 - ts non-insertion tags
+            const unsigned long long stop = cached ? __ballot(!(nb_back & 8u)) : 0ull;     // look-back lanes that end an insertion run
+            const uint32_t nb1 = cached ? (uint32_t)__builtin_amdgcn_readlane((int)nb_back, 0) : tag_nib(tg, i0 - 1);
+            if (stop) { tp = T0; dl = (uint32_t)__ffsll((long long)stop) - 1u; }
+            else tag_pos(tg, i0 - 1, (uint32_t)(T0 + 1) - ts, ts, &tp, &dl);          // tags 0 .. i0-1 hold T0 + 1 - ts non-insertion tags
             P1 = node_key(tp, dl, nb1 & 7u);
             D0 = dl;
             if (i0 >= 2) {
-                tag_pos(tg, i0 - 2, (uint32_t)(T0 + 1) - ts - ((nb1 & 8u) ? 0u : 1u), ts, &tp, &dl);
-                P2 = node_key(tp, dl, tag_nib(tg, i0 - 2) & 7u);
+                const uint32_t nb2 = cached ? (uint32_t)__builtin_amdgcn_readlane((int)nb_back, 1) : tag_nib(tg, i0 - 2);
+                if (stop >> 1) { tp = T0 - ((nb1 & 8u) ? 0 : 1); dl = (uint32_t)__ffsll((long long)(stop >> 1)) - 1u; }
+                else tag_pos(tg, i0 - 2, (uint32_t)(T0 + 1) - ts - ((nb1 & 8u) ? 0u : 1u), ts, &tp, &dl);
+                P2 = node_key(tp, dl, nb2 & 7u);
             }
         }
+        TG_TICK(1);
         for (uint32_t b = i0; b < nt; b += 64) {
             const uint32_t i = b + lane;
             const bool valid = i < nt;
-            const uint32_t nb = valid ? tag_nib(tg, i) : 8u;
+            const uint32_t nb = !valid ? 8u : (cached && b == i0) ? nb_a : (cached && b == i0 + 64) ? nb_b : tag_nib(tg, i);
             const uint32_t base = nb & 7u;
             const unsigned long long M = __ballot(valid && !(nb & 8u));
             const unsigned long long Mle = M & lane_le;
@@ -579,13 +647,14 @@ __global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A) {
                 }
             }
             tg_sync();
+            TG_TICK(2);
             if (obs) {
                 if (hit != TG_NONE) atomicAdd(&L.link[hit], 1u);
                 else {
                     const uint32_t e = atomicAdd(&L.used, 1u);
                     if (e < TG_POOL) {
-                        L.key[e] = k; L.link[e] = 1u; L.next[e] = (uint16_t)TG_NONE;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        L.key[e] = k; L.link[e] = 1u; L.next[e] = (uint16_t)TG_NONE; L.col[e] = (uint8_t)col;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
                         const uint32_t prev = atomicExch(&L.tail[col], e);
                         if (prev == TG_NONE) L.head[col] = e; else L.next[prev] = (uint16_t)e;
                         atomicAdd(&L.cnt[col], 1u);
@@ -593,6 +662,7 @@ __global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A) {
                 }
             }
             tg_sync();
+            TG_TICK(3);
             if (beyond) break;
             T0 += (int32_t)__popcll(M);
             D0 = (uint32_t)__builtin_amdgcn_readlane((int)delta, 63);
@@ -601,12 +671,16 @@ __global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A) {
         }
     }
     tg_sync();
+    TG_TICK(1);
     // ---- finish the tile: lane = column
     const uint32_t p = c0 + lane;
     uint32_t n = p < A.n_cols ? L.cnt[lane] : 0u;
     const bool over = L.used > TG_POOL || __ballot(n > TG_COLMAX) != 0ull;
     if (over) {
-        if (lane == 0) atomicOr(&A.counter[1], 1u);
+        if (lane == 0) {
+            if (A.redo) A.redo[atomicAdd(&A.counter[2], 1u)] = t;
+            else atomicOr(&A.counter[1], 1u);
+        }
         if (p < A.n_cols) { A.col_off[p] = 0; A.col_nn[p] = 0; A.col_ne[p] = 0; }
         return;
     }
@@ -616,38 +690,50 @@ __global__ __launch_bounds__(64) void k2_tile_graph(TileArgs A) {
     uint32_t basep = 0;
     if (lane == 0 && tile_total) basep = atomicAdd(&A.counter[0], tile_total);
     basep = (uint32_t)__builtin_amdgcn_readfirstlane((int)basep);
-    if (p >= A.n_cols) return;
-    const uint32_t off = basep + inc - n;
-    uint32_t n_nodes = 0;
-    for (uint32_t e = L.head[lane]; e != TG_NONE; e = L.next[e]) {          // mark the first entry of every node
+    // entries of the pool in any order (balanced over the lanes): position inside the column from one walk along its chain
+    L.tail[lane] = basep + inc - n;          // the column's place in the graph arrays
+    const uint32_t used = L.used;
+    tg_sync();
+    for (uint32_t e = lane; e < used; e += 64) {          // the first entry of every node
+        const uint32_t c = L.col[e];
+        if (c0 + c >= A.n_cols) continue;
         const uint32_t nk = tg_node(L.key[e]);
         bool first = true;
-        for (uint32_t f = L.head[lane]; f != e; f = L.next[f])
+        for (uint32_t f = L.head[c]; f != e; f = L.next[f])
             if (tg_node(L.key[f]) == nk) { first = false; break; }
-        if (first) { L.link[e] |= 0x80000000u; ++n_nodes; }
+        if (first) { L.link[e] |= 0x80000000u; atomicAdd(&L.nn[c], 1u); }
     }
-    for (uint32_t e = L.head[lane]; e != TG_NONE; e = L.next[e]) {
+    tg_sync();
+    for (uint32_t e = lane; e < used; e += 64) {
+        const uint32_t c = L.col[e];
+        if (c0 + c >= A.n_cols) continue;
         const unsigned long long k = L.key[e];
         const uint32_t nk = tg_node(k);
         uint32_t node_start = 0, node_idx = 0, node_len = 0, pos_in = 0;
         bool passed = false;
-        for (uint32_t f = L.head[lane]; f != TG_NONE; f = L.next[f]) {
+        for (uint32_t f = L.head[c]; f != TG_NONE; f = L.next[f]) {
             const uint32_t nkf = tg_node(L.key[f]);
             if (f == e) passed = true;
             if (nkf < nk) { ++node_start; node_idx += L.link[f] >> 31; }
             else if (nkf == nk) { ++node_len; if (!passed) ++pos_in; }
         }
+        const uint32_t off = L.tail[c];
         Entry en;
-        tg_unpack(k, (int32_t)p, &en.pp, &en.ppp);
+        tg_unpack(k, (int32_t)(c0 + c), &en.pp, &en.ppp);
         en.score = 0;
         en.link = L.link[e] & 0xffffu;           // the reference counts in 16 bits
         en.node = nk;
         A.entries[off + node_start + pos_in] = en;
         if (L.link[e] >> 31) A.nodes[off + node_idx] = Node{nk, node_start, node_len, 0u};
     }
-    A.col_off[p] = off;
-    A.col_nn[p] = n_nodes;
-    A.col_ne[p] = n;
+    if (p < A.n_cols) {
+        A.col_off[p] = basep + inc - n;
+        A.col_nn[p] = L.nn[lane];
+        A.col_ne[p] = n;
+    }
+    TG_TICK(4);
+    if (kProf && lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], ph[i]);
+#undef TG_TICK
 }
 
 // seed_len > 0 (a window): coverage = seed + scanned difference array of the reads (cov_pre exclusive prefix, cov_diff the
@@ -1799,7 +1885,7 @@ class HipExec : public Exec {
     DevBuf contig_, spans_, sd_, tags_, tagoff_, alnts_, te_, cnt4_, stat_, colcnt_,
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
     DevBuf runsz_, runoff_, live_, ematch_, xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
-    DevBuf tilecnt_, tileoff_, tilecur_, tilelist_, tilectr_, ntags_, colne_, runflag_, runlist_, runctr_;
+    DevBuf tilecnt_, tileoff_, tilecur_, tilelist_, tilectr_, ntags_, colne_, runflag_, runlist_, runctr_, tileredo_;
     bool graph_compact_ = false;   // the graph in HBM was built by tiles: columns are contiguous, every entry slot is live
     DevBuf ondpool_, ondregs_, ondcoff_, ondclen_, ondpairof_, ondpairs_, ondres_, ondout_, ondv_, ondlo_, ondch_, ondplen_, ondpkind_, ondppos_, ondtot_;
     PinBuf pin_;
@@ -2171,20 +2257,43 @@ int HipExec::build_graph_tiles(const std::vector<uint32_t>& n_tags, uint32_t n_c
     TILEOK(hipMemsetAsync(tilecnt_.p, 0, 4ull * (n_tiles + 2), q));
     TILEOK(hipMemsetAsync(tilecur_.p, 0, 4ull * (n_tiles + 2), q));
     TILEOK(hipMemsetAsync(tilectr_.p, 0, 64, q));
-    k2_tile_list<false><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(),
-                                                           tags_.as<uint8_t>(), n_tiles, tilecnt_.as<uint32_t>(), nullptr, nullptr, nullptr);
+    k2_tile_count<<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), alnts_.as<uint32_t>(), n_tiles, tilecnt_.as<uint32_t>());
     k2_scan_sums<<<nst, SCAN_T, 0, q>>>(tilecnt_.as<uint32_t>(), n_tiles + 1, sums_.as<uint32_t>());
     k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nst);
     k2_scan_final<<<nst, SCAN_T, 0, q>>>(tilecnt_.as<uint32_t>(), n_tiles + 1, sums_.as<uint32_t>(), tileoff_.as<uint32_t>());
-    k2_tile_list<true><<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(),
-                                                          tags_.as<uint8_t>(), n_tiles, nullptr, tileoff_.as<uint32_t>(), tilecur_.as<uint32_t>(), tilelist_.as<TileStream>());
+    k2_tile_list<<<nblk(n_chunks, 4), 256, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(),
+                                                    tags_.as<uint8_t>(), n_tiles, tileoff_.as<uint32_t>(), tilecur_.as<uint32_t>(), tilelist_.as<TileStream>());
     if (clk) clk->mark("tiles.list");
     TileArgs A{tags_.as<uint8_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), ntags_.as<uint32_t>(), tileoff_.as<uint32_t>(), tilelist_.as<TileStream>(),
-               n_tiles, n_cols, entries_.as<Entry>(), nodes_.as<Node>(), coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), colne_.as<uint32_t>(), tilectr_.as<uint32_t>()};
-    k2_tile_graph<<<n_tiles, 64, 0, q>>>(A);
-    uint32_t ctr[2] = {0, 0};
-    TILEOK(hipMemcpyAsync(ctr, tilectr_.p, 8, hipMemcpyDeviceToHost, q));
+               n_tiles, n_cols, entries_.as<Entry>(), nodes_.as<Node>(), coloff_.as<uint32_t>(), colnn_.as<uint32_t>(), colne_.as<uint32_t>(), tilectr_.as<uint32_t>(),
+               nullptr, nullptr};
+    // Every tile first with the small pool; the tiles that do not fit it are listed and taken again with the large one (their place
+    // in the graph arrays comes from the same atomic counter); a tile too big for that sends the window down the scatter path.
+    if (!tileredo_.ensure(4ull * n_tiles + 64)) { *err = "out of device memory (link graph)"; return 0; }
+    TileArgs A1 = A, A2 = A;
+    A1.redo = tileredo_.as<uint32_t>(); A1.todo = nullptr;
+    A2.redo = nullptr; A2.todo = tileredo_.as<uint32_t>();
+    if (getenv("NP2_TILE_PROF")) {     // phase clocks of the tile kernel (cycles summed over the tiles)
+        unsigned long long* d_prof = nullptr;
+        unsigned long long h[12];
+        (void)hipMalloc(&d_prof, 96);
+        (void)hipMemsetAsync(d_prof, 0, 96, q);
+        k2_tile_graph<true, 768, 64><<<n_tiles, 64, 0, q>>>(A1, d_prof);
+        k2_tile_graph<true, 2048, 128><<<n_tiles, 64, 0, q>>>(A2, d_prof + 6);
+        (void)hipMemcpyAsync(h, d_prof, 96, hipMemcpyDeviceToHost, q);
+        (void)hipStreamSynchronize(q);
+        (void)hipFree(d_prof);
+        fprintf(stderr, "[np2 tile prof] %u tiles; cycles per tile: setup %.0f, stream state %.0f, lookup %.0f, insert %.0f, finish %.0f; large pool (all its tiles) %.0f\n", n_tiles,
+                (double)h[0] / n_tiles, (double)h[1] / n_tiles, (double)h[2] / n_tiles, (double)h[3] / n_tiles, (double)h[4] / n_tiles,
+                (double)(h[6] + h[7] + h[8] + h[9] + h[10]));
+    } else {
+        k2_tile_graph<false, 768, 64><<<n_tiles, 64, 0, q>>>(A1, nullptr);
+        k2_tile_graph<false, 2048, 128><<<n_tiles, 64, 0, q>>>(A2, nullptr);
+    }
+    uint32_t ctr[3] = {0, 0, 0};
+    TILEOK(hipMemcpyAsync(ctr, tilectr_.p, 12, hipMemcpyDeviceToHost, q));
     TILEOK(hipStreamSynchronize(q));
+    if (clk && clk->on && ctr[2]) fprintf(stderr, "[np2 graph] %u of %u tiles took the large pool\n", ctr[2], n_tiles);
     if (clk) clk->mark("tiles.graph");
     if (ctr[1]) return 2;
     const uint32_t total = ctr[0];
@@ -2219,7 +2328,7 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
     if (n_chunks) {
         HIPOK(hipMemcpyAsync(chunks_.p, cd.data(), sizeof(ChunkDesc) * (size_t)n_chunks, hipMemcpyHostToDevice, q));
         HIPOK(hipMemsetAsync(chcnt_.as<uint32_t>() + n_chunks, 0, 4, q));
-        k2_chunk_count<<<nblk(n_chunks, 64), 64, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), chcnt_.as<uint32_t>());
+        k2_chunk_count<<<nblk(n_chunks, 4), 256, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), chcnt_.as<uint32_t>());
         const uint32_t nsc = nblk(n_chunks + 1, SCAN_TILE);
         k2_scan_sums<<<nsc, SCAN_T, 0, q>>>(chcnt_.as<uint32_t>(), n_chunks + 1, sums2_.as<uint32_t>());
         k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nsc);
