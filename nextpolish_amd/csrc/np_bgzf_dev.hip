@@ -84,10 +84,23 @@ struct DevInflater {
     }
 };
 
-DevInflater g_inf;
+int g_device = -1;
+std::mutex g_pool_mu;
+std::vector<DevInflater*> g_free;      // inflaters not in use (stream + device buffers each); as many get built as batches overlap
 
+// The decode threads of a worker read different parts of the file and live only for one call: each batch checks an inflater
+// out of the pool, so the batches overlap on the device and the buffers outlive the threads.
 bool batch_hook(const uint8_t* comp, size_t comp_len, const np::BgzfBatchBlock* blocks, size_t n, uint8_t* out, size_t out_len) {
-    return g_inf.run(comp, comp_len, blocks, n, out, out_len);
+    DevInflater* inf = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        if (!g_free.empty()) { inf = g_free.back(); g_free.pop_back(); }
+    }
+    if (!inf) { inf = new DevInflater; inf->device = g_device; }
+    const bool ok = inf->run(comp, comp_len, blocks, n, out, out_len);
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    g_free.push_back(inf);
+    return ok;
 }
 
 }  // namespace
@@ -101,7 +114,7 @@ namespace np {
 void bgzf_device_inflate_enable(int device) {
     const char* e = getenv("NP2_INFLATE");
     if (!e || strcmp(e, "device") != 0) return;
-    g_inf.device = device;
+    g_device = device;
     size_t mb = 48;
     if (const char* w = getenv("NP2_INFLATE_WINDOW_MB")) mb = (size_t)atoi(w);
     if (mb < 4) mb = 4;
