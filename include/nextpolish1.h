@@ -231,6 +231,8 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms);
  * (np1_stream_load(..., with_qual = 1)) and cfg->read_tlen must be set (config_init does).  Returns 0 on success;
  * results are fetched with np1_batch_result_len / np1_batch_result_copy like for score_chain. */
 int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms);
+/* task 4 on an uploaded batch (reference: source/lib/snpvalid.c:3-36 snp_valid; needs a stream loaded with qualities) */
+int np1_batch_snp_valid(np1_batch* b, const Configure* cfg, float* stage_ms);
 /* Blocks until the batch's work is complete. */
 int np1_batch_sync(np1_batch* b);
 /* Polished length of contig i (valid after a completed run), and copy-out of its NUL-terminated string. */

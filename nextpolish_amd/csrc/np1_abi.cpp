@@ -159,35 +159,35 @@ PolishResult* score_chain(const char* tigname, Configure* cfg) {
     return res;
 }
 
-PolishResult* kmer_count(const char* tigname, Configure* cfg) {
-    if (!cfg || !cfg->fastafn) die("kmer_count: configuration without a FASTA");
-    if (!cfg->bamfn) die("kmer_count: short-read BAM missing or unreadable");
+static PolishResult* kmer_task(const char* tigname, Configure* cfg, bool snp_valid_task) {
+    const char* task = snp_valid_task ? "snp_valid" : "kmer_count";
+    if (!cfg || !cfg->fastafn) die(std::string(task) + ": configuration without a FASTA");
+    if (!cfg->bamfn) die(std::string(task) + ": short-read BAM missing or unreadable");
     np1_stream st;
     std::string err;
     if (!np::load_stream(cfg->fastafn, cfg->bamfn, {std::string(tigname)}, true, &st.s, &err)) die(err);
     np1_ctx* ctx = process_ctx();
     np1_batch* b = np1_batch_upload(ctx, &st);
     if (!b) die(np1_last_error());
-    if (np1_batch_kmer_count(b, cfg, nullptr) != 0) die(np1_last_error());
+    if ((snp_valid_task ? np1_batch_snp_valid(b, cfg, nullptr) : np1_batch_kmer_count(b, cfg, nullptr)) != 0) die(np1_last_error());
     int64_t len = np1_batch_result_len(b, 0);
     PolishResult* res = (PolishResult*)calloc(sizeof(PolishResult), 1);
     res->contig = (char*)calloc(1, (size_t)len + 1);
     if (np1_batch_result_copy(b, 0, res->contig, len + 1) != 0) die(np1_last_error());
     res->length = (int32_t)len;
-    if (cfg->trace_polish_open) {   // the change list is not produced for task 2 yet: an empty list, like a run that changed nothing
+    if (cfg->trace_polish_open) {   // the change list is not produced for tasks 2 and 4 yet: an empty list, like a run that changed nothing
         res->data = (PolishPoint*)calloc(1, sizeof(PolishPoint));
         res->datalength = 0;
     }
     np1_batch_free(b);
     return res;
 }
+PolishResult* kmer_count(const char* tigname, Configure* cfg) { return kmer_task(tigname, cfg, false); }
+/* task 4 (reference: source/lib/snpvalid.c:3-36) */
+PolishResult* snp_valid(const char* tigname, Configure* cfg) { return kmer_task(tigname, cfg, true); }
 PolishResult* snp_phase(const char* tigname, Configure* cfg) {
     (void)tigname; (void)cfg;
     die("snp_phase (task 3) is outside the accelerated hot path (experimental upstream; DESIGN.md)");
-}
-PolishResult* snp_valid(const char* tigname, Configure* cfg) {
-    (void)tigname; (void)cfg;
-    die("snp_valid (task 4) is outside the accelerated hot path (experimental upstream; DESIGN.md)");
 }
 PolishResult* lgspolish(const char* tigname, Configure* cfg) {
     (void)tigname; (void)cfg;

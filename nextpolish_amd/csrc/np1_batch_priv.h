@@ -59,6 +59,8 @@ struct np1_batch {
     np1dev::DevBuf kc_level, kc_endpos, kc_code, kc_flag, kc_fpos, kc_flagged, kc_work, kc_nd_ctg, kc_nd_se, kc_kr_ctg, kc_kr_se, kc_cnt,
         kc_sbase, kc_sflag, kc_srefk, kc_scount, kc_lhead, kc_lpool, kc_stsc, kc_stkm, kc_strk, kc_hpool, kc_workoff, kc_nparts,
         kc_partoff, kc_pt_ctg, kc_pt_se, kc_pt_len, kc_woff, kc_wpool, kc_haswin;
+    // snp_valid: second-round work (regions nothing spanned, their split values and parts)
+    np1dev::DevBuf sv_failse, sv_failcnt, sv_vsz, sv_voff, sv_val, sv_p2ctg, sv_p2se, sv_p2len, sv_woff2, sv_haswin2, sv_range;
     bool has_qual = false;
     std::vector<uint64_t> h_read_begin;
     np1dev::DevBuf qs, qe, span, ins, soff, slot_info, rbase, capb, rowoff, rows, meta, chunk_first, chunk_last, slot_res,
@@ -85,7 +87,8 @@ struct np1_batch {
                                &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg, &kc_nd_se,
                                &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool,
                                &kc_stsc, &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg,
-                               &kc_pt_se, &kc_pt_len, &kc_woff, &kc_wpool, &kc_haswin};
+                               &kc_pt_se, &kc_pt_len, &kc_woff, &kc_wpool, &kc_haswin, &sv_failse, &sv_failcnt, &sv_vsz, &sv_voff, &sv_val,
+                               &sv_p2ctg, &sv_p2se, &sv_p2len, &sv_woff2, &sv_haswin2, &sv_range};
         size_t t = 0;
         for (const np1dev::DevBuf* b : all) t += b->cap;
         return t;
@@ -98,7 +101,8 @@ struct np1_batch {
                          &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg, &kc_nd_se,
                          &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool,
                          &kc_stsc, &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg, &kc_pt_se,
-                         &kc_pt_len, &kc_woff, &kc_wpool, &kc_haswin};
+                         &kc_pt_len, &kc_woff, &kc_wpool, &kc_haswin, &sv_failse, &sv_failcnt, &sv_vsz, &sv_voff, &sv_val, &sv_p2ctg,
+                         &sv_p2se, &sv_p2len, &sv_woff2, &sv_haswin2, &sv_range};
         for (np1dev::DevBuf* b : all) b->release();
     }
 };

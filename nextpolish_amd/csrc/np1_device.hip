@@ -476,11 +476,14 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
 }
 
 
-// ---- kmer_count (task 2): launch sequence over the same HBM-resident batch (needs qualities) -------------------
-int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
-    (void)stage_ms;
-    if (!b || !cfg) { np1_set_error("np1_batch_kmer_count: null argument"); return -1; }
-    if (!b->has_qual) { np1_set_error("kmer_count needs a stream loaded with base qualities"); return -1; }
+// ---- kmer_count (task 2) and snp_valid (task 4): launch sequence over the same HBM-resident batch (needs qualities) ----------
+// snp_valid (snpvalid.c:3-36) is kmer_count's haplotype vote without the no-depth regions, run twice: the first round leaves the
+// FLAG_ZERO marks to the winners (a part that gets one loses its marks), the regions nothing spanned are cut again at the middle of
+// their unmarked runs (fts_spilt_region) and voted on once more; the result is emitted without lower case.
+static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
+    const char* task = snp_valid ? "snp_valid" : "kmer_count";
+    if (!b || !cfg) { np1_set_error(std::string(task) + ": null argument"); return -1; }
+    if (!b->has_qual) { np1_set_error(std::string(task) + " needs a stream loaded with base qualities"); return -1; }
     np1_ctx* ctx = b->ctx;
     (void)hipSetDevice(ctx->device);
     hipStream_t q = ctx->stream;
@@ -546,9 +549,10 @@ int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
                           reg_cap, kcnt);
         HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
         HIPCHK(hipStreamSynchronize(q));
-        if (hk[KCC_ERR]) { np1_set_error("kmer_count: region discovery failed"); return -1; }
-        const uint32_t n_nd = hk[KCC_NODEPTH], n_kr = hk[KCC_KREG];
-        const uint64_t nd_len = (uint64_t)hk[KCC_ND_LEN] | (uint64_t)hk[KCC_ND_LEN + 1] << 32;
+        if (hk[KCC_ERR]) { np1_set_error(std::string(task) + ": region discovery failed"); return -1; }
+        const uint32_t n_nd = snp_valid ? 0u : hk[KCC_NODEPTH], n_kr = hk[KCC_KREG];   // snp_valid has no no-depth regions
+        const uint64_t nd_len = snp_valid ? 0ull : ((uint64_t)hk[KCC_ND_LEN] | (uint64_t)hk[KCC_ND_LEN + 1] << 32);
+        c.keep_zero_marks = snp_valid ? 1 : 0;
         c.max_span = (int32_t)(hk[KCC_MAXSPAN] ? hk[KCC_MAXSPAN] : 1);
         // ---- insertion columns of the regions, slot space
         HIPCHK(hipMemsetAsync(b->ins.p, 0, 4 * (G + 1), q));
@@ -579,7 +583,7 @@ int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
         c.st_score = b->kc_stsc.as<long long>(); c.st_kmer = b->kc_stkm.as<uint16_t>(); c.st_rank = b->kc_strk.as<uint8_t>();
         c.st_cap = (uint32_t)stcap; c.st_count = &kcnt[KCC_STCOUNT];
         // ---- no-depth regions: level-2 / level-1 score chain
-        kc_launch_nodepth(q, c, b->kc_nd_ctg.as<uint32_t>(), b->kc_nd_se.as<int32_t>(), n_nd);
+        if (n_nd) kc_launch_nodepth(q, c, b->kc_nd_ctg.as<uint32_t>(), b->kc_nd_se.as<int32_t>(), n_nd);
         // ---- split the k-mer regions into parts (host only lays out the per-region scratch rows)
         uint32_t n_parts = 0;
         uint64_t W = 0;
@@ -616,10 +620,46 @@ int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
             // ---- spanning-read haplotype vote, then the writes in part order
             kc_launch_winner(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(),
                              b->kc_woff.as<uint32_t>(), n_parts, n, b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>());
-            kc_launch_apply(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(),
-                            b->kc_woff.as<uint32_t>(), n_parts, b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>());
+            if (!snp_valid) {
+                kc_launch_apply(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(),
+                                b->kc_woff.as<uint32_t>(), n_parts, b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>());
+            } else {
+                // ---- round 1 in part order per contig, then the second round on what nothing spanned
+                if (b->sv_failse.ensure(8 * ((size_t)n_parts + 1)) || b->sv_failcnt.ensure(4 * ((size_t)nc + 1)) || b->sv_range.ensure(8 * ((size_t)nc + 1)) || b->sv_vsz.ensure(4 * ((size_t)n_parts + 2)) ||
+                    b->sv_voff.ensure(4 * ((size_t)n_parts + 2)))
+                    return -1;
+                HIPCHK(hipMemsetAsync(b->sv_range.p, 0, 8 * ((size_t)nc + 1), q));
+                sv_launch_ranges(q, b->kc_pt_ctg.as<uint32_t>(), n_parts, b->sv_range.as<uint32_t>());
+                sv_launch_round1(q, c, nc, b->sv_range.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(), b->kc_woff.as<uint32_t>(),
+                                 n_parts, b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>(), b->sv_failse.as<int32_t>(), b->sv_failcnt.as<uint32_t>());
+                sv_launch_val_sizes(q, b->kc_pt_len.as<uint32_t>(), n_parts, b->sv_vsz.as<uint32_t>());
+                launch_scan_u32(q, b->sv_vsz.as<uint32_t>(), n_parts, b->sv_voff.as<uint32_t>(), scan_tmp, &totals[5]);
+                uint64_t V = 0;
+                HIPCHK(hipMemcpyAsync(&V, &totals[5], 8, hipMemcpyDeviceToHost, q));
+                HIPCHK(hipStreamSynchronize(q));
+                if (b->sv_val.ensure(4 * (V + 4)) || b->sv_p2ctg.ensure(4 * (V + 4)) || b->sv_p2se.ensure(8 * (V + 4)) || b->sv_p2len.ensure(4 * (V + 4)) ||
+                    b->sv_woff2.ensure(4 * (V + 4)) || b->sv_haswin2.ensure(V + 4))
+                    return -1;
+                HIPCHK(hipMemcpyAsync(b->sv_voff.as<uint32_t>() + n_parts, &totals[5], 4, hipMemcpyDeviceToDevice, q));   // voff[n_parts] = V
+                HIPCHK(hipMemsetAsync(b->sv_p2ctg.p, 0xff, 4 * (V + 4), q));
+                HIPCHK(hipMemsetAsync(b->sv_p2len.p, 0, 4 * (V + 4), q));
+                sv_launch_round2_parts(q, c, nc, b->sv_range.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), n_parts, b->sv_voff.as<uint32_t>(),
+                                       b->sv_failse.as<int32_t>(), b->sv_failcnt.as<uint32_t>(), b->sv_val.as<int32_t>(), b->sv_p2ctg.as<uint32_t>(),
+                                       b->sv_p2se.as<int32_t>(), b->sv_p2len.as<uint32_t>());
+                launch_scan_u32(q, b->sv_p2len.as<uint32_t>(), V, b->sv_woff2.as<uint32_t>(), scan_tmp, &totals[6]);
+                uint64_t W2 = 0;
+                HIPCHK(hipMemcpyAsync(&W2, &totals[6], 8, hipMemcpyDeviceToHost, q));
+                HIPCHK(hipStreamSynchronize(q));
+                if (b->kc_wpool.ensure(W2 + 64)) return -1;     // round 1's winners are in the slots by now
+                kc_launch_winner(q, c, b->sv_p2ctg.as<uint32_t>(), b->sv_p2se.as<int32_t>(), b->sv_p2len.as<uint32_t>(), b->sv_woff2.as<uint32_t>(),
+                                 (uint32_t)V, n, b->kc_wpool.as<uint8_t>(), b->sv_haswin2.as<uint8_t>());
+                sv_launch_round2_apply(q, c, nc, b->sv_range.as<uint32_t>(), n_parts, b->sv_voff.as<uint32_t>(), b->sv_p2ctg.as<uint32_t>(),
+                                       b->sv_p2se.as<int32_t>(), b->sv_p2len.as<uint32_t>(), b->sv_woff2.as<uint32_t>(), b->kc_wpool.as<uint8_t>(),
+                                       b->sv_haswin2.as<uint8_t>());
+            }
         }
-        // ---- emit with mask FLAG_ZERO (kmercount.c:121)
+        // ---- emit with mask FLAG_ZERO (kmercount.c:121); snp_valid emits without marks (snpvalid.c:30: flag 0)
+        if (snp_valid) HIPCHK(hipMemsetAsync(b->kc_sflag.p, 0, S, q));
         kc_launch_result(q, b->kc_sbase.as<uint8_t>(), b->kc_sflag.as<uint8_t>(), S, b->slot_res.as<uint16_t>());
         launch_scan_keep(q, b->slot_res.as<uint16_t>(), S, b->opos.as<uint32_t>(), scan_tmp, &totals[4]);
         launch_emit(q, b->slot_res.as<uint16_t>(), b->slot_info.as<uint8_t>(), b->opos.as<uint32_t>(), S, 1u, b->out.as<uint8_t>());
@@ -629,13 +669,27 @@ int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
         HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
         HIPCHK(hipStreamSynchronize(q));
         if (hk[KCC_ERR] & ERR_KC_POOL) continue;   // a scratch pool ran out: rerun with larger pools
-        if (hk[KCC_ERR]) { np1_set_error("kmer_count: inconsistent pileup or region overflow on the device"); return -1; }
+        if (hk[KCC_ERR] & ERR_KC_UNDEFINED) {
+            np1_set_error("snp_valid: a second-round region reaches outside the insertion columns of its k-mer region; the reference dereferences a null list for this input "
+                          "(snpvalid.c:24-27, kmercount.c:398,431) and has no defined result");
+            return -1;
+        }
+        if (hk[KCC_ERR]) { np1_set_error(std::string(task) + ": inconsistent pileup or region overflow on the device"); return -1; }
         b->votes = 0;
         b->ran = true;
         return 0;
     }
-    np1_set_error("kmer_count: scratch pools keep overflowing");
+    np1_set_error(std::string(task) + ": scratch pools keep overflowing");
     return -1;
+}
+
+int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms) {
+    (void)stage_ms;
+    return kmer_pipeline(b, cfg, false);
+}
+int np1_batch_snp_valid(np1_batch* b, const Configure* cfg, float* stage_ms) {
+    (void)stage_ms;
+    return kmer_pipeline(b, cfg, true);
 }
 
 int np1_batch_sync(np1_batch* b) {

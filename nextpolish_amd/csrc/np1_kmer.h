@@ -11,7 +11,7 @@
 namespace np1k {
 
 constexpr uint32_t KC_FLAG_ZERO = 1, KC_FLAG_COVERAGE = 2;
-constexpr uint32_t ERR_KC_POOL = 64, ERR_KC_REGIONS = 128, ERR_KC_INCONSISTENT = 256;
+constexpr uint32_t ERR_KC_POOL = 64, ERR_KC_REGIONS = 128, ERR_KC_INCONSISTENT = 256, ERR_KC_UNDEFINED = 512;
 
 // everything a region lane needs (plain pointers; device or host memory)
 struct KcCtx {
@@ -54,6 +54,7 @@ struct KcCtx {
     long long Rfix;
     double rate;
     int32_t max_span;            // longest reference span of any record (lower bound for overlap scans)
+    int32_t keep_zero_marks;     // snp_valid: a covering read leaves the FLAG_ZERO marks alone (ss_parse_read_kmer with flagzero = 1)
     uint32_t* err;
 };
 
@@ -626,6 +627,34 @@ NP1_HD int32_t kc_split_region(const KcCtx& c, uint32_t ctg, int32_t rs, int32_t
     return n;
 }
 
+// ---- fts_spilt_region (snpvalid.c:38-66) for one region nothing spanned in snp_valid's first round: appends to out[] (which is
+// NOT started with the region's start); returns the new count or -1 when out_cap is too small
+NP1_HD int32_t kc_fts_split(const KcCtx& c, uint32_t ctg, int32_t start, int32_t end, int32_t* out, int32_t n, int32_t out_cap) {
+    const uint32_t g0 = c.ctg_off[ctg];
+    KcCursor cur{&c, g0, (int32_t)(c.ctg_off[ctg + 1] - g0), start, 0};
+    int32_t qstart = -1, qend = -1;
+    while (cur.in(end)) {
+        if (!(c.sflag[cur.slot()] & KC_FLAG_ZERO)) {
+            if (qstart == -1) qstart = cur.i;
+            qend = cur.i;
+        } else if (qstart != -1) {
+            int32_t count = 2;
+            if (qstart == start) { qend = start; --count; }
+            int32_t mid = (qstart + qend) / 2;
+            for (int32_t k = 0; k < count; ++k) {
+                if (n >= out_cap) return -1;
+                out[n++] = mid;
+                if (qstart != qend) ++mid;
+            }
+            qstart = qend = -1;
+        }
+        cur.next();
+    }
+    if (n >= out_cap) return -1;
+    out[n++] = end;
+    return n;
+}
+
 // ---- ss_kmer_correct for one part [start,end] (kmercount.c:175-261, 332-465) -----------------------------------
 struct KcHapSink {
     const KcCtx* c;
@@ -638,8 +667,11 @@ struct KcHapSink {
         ++length;
         if (qpos >= 0) qual += q[qpos];
         if (pad) ++del;
+        // snp_valid's second round can pair a region start with a leftover end far away: an insertion column that was never created
+        // there is a null list in the reference (undefined upstream), reported instead of written through
+        if (col >= c->soff[g0 + (uint32_t)pos + 1] - c->soff[g0 + (uint32_t)pos]) { np1_atomic_or(c->err, ERR_KC_UNDEFINED); return; }
         const uint32_t s = c->soff[g0 + (uint32_t)pos] + col;
-        c->sflag[s] = (uint8_t)(c->sflag[s] & ~KC_FLAG_ZERO);   // flagzero == 0: a covering read clears the mark (accepted or not)
+        if (!c->keep_zero_marks) c->sflag[s] = (uint8_t)(c->sflag[s] & ~KC_FLAG_ZERO);   // flagzero == 0: a covering read clears the mark (accepted or not)
     }
 };
 

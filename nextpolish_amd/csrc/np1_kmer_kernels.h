@@ -30,6 +30,19 @@ void kc_launch_apply(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, con
                      const uint32_t* woff, uint32_t n_parts, const uint8_t* wpool, const uint8_t* has_winner);
 void kc_launch_result(hipStream_t st, const uint8_t* sbase, const uint8_t* sflag, uint32_t S, uint16_t* slot_res);
 
+// snp_valid (task 4): what happens around the votes of the two rounds (np1_kmer_kernels.hip)
+void sv_launch_val_sizes(hipStream_t st, const uint32_t* pt_len, uint32_t n_parts, uint32_t* vsz);
+void sv_launch_ranges(hipStream_t st, const uint32_t* pt_ctg, uint32_t n_parts, uint32_t* range);   // [first, last) part of every contig
+void sv_launch_round1(hipStream_t st, const KcCtx& c, uint32_t nc, const uint32_t* range, const int32_t* pt_se, const uint32_t* pt_len,
+                      const uint32_t* woff, uint32_t n_parts, const uint8_t* wpool, const uint8_t* has_winner, int32_t* fail_se,
+                      uint32_t* fail_cnt);
+void sv_launch_round2_parts(hipStream_t st, const KcCtx& c, uint32_t nc, const uint32_t* range, const int32_t* pt_se, uint32_t n_parts,
+                            const uint32_t* voff, const int32_t* fail_se, const uint32_t* fail_cnt, int32_t* val, uint32_t* p2_ctg,
+                            int32_t* p2_se, uint32_t* p2_len);
+void sv_launch_round2_apply(hipStream_t st, const KcCtx& c, uint32_t nc, const uint32_t* range, uint32_t n_parts, const uint32_t* voff,
+                            const uint32_t* p2_ctg, const int32_t* p2_se, const uint32_t* p2_len, const uint32_t* woff2,
+                            const uint8_t* wpool, const uint8_t* has_winner);
+
 // generic exclusive scans of np1_kernels.hip reused here
 void launch_scan_u8(hipStream_t st, const uint8_t* v, uint64_t n, uint32_t* out, uint64_t* tmp, uint64_t* total);
 void launch_scan_u32(hipStream_t st, const uint32_t* v, uint64_t n, uint32_t* out, uint64_t* tmp, uint64_t* total);

@@ -325,6 +325,7 @@ __global__ __launch_bounds__(64) void k_kc_winner(KcCtx c, const uint32_t* __res
     const uint32_t p = blockIdx.x * lanes + threadIdx.x;   // `lanes` parts per wave (see k_kc_nodepth)
     if (threadIdx.x >= lanes || p >= n_parts) return;
     const uint32_t ct = pt_ctg[p];
+    if (ct == 0xffffffffu) { has_winner[p] = 0; return; }   // an unused slot of snp_valid's second round
     const bool has_next = (int64_t)c.read_begin[ct + 1] < n_all;
     has_winner[p] = (uint8_t)kc_part_winner(c, ct, pt_se[2 * p], pt_se[2 * p + 1], has_next, wpool + woff[p], (int32_t)pt_len[p]);
 }
@@ -354,6 +355,99 @@ __global__ __launch_bounds__(256) void k_kc_result(const uint8_t* __restrict__ s
                                                    uint16_t* __restrict__ slot_res) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < S) slot_res[s] = (uint16_t)(sbase[s] | (uint32_t)sflag[s] << 8);
+}
+
+
+// ---- snp_valid (task 4, snpvalid.c:3-36): the parts are the ones of kmer_count; what differs is what happens around the votes --
+// The parts of one contig are one contiguous run of pt_ctg[] (its regions come out of k_kc_regions as one block, the blocks of
+// different contigs in any order): range[2 ct], range[2 ct + 1] = first part and one past the last (both 0: no parts).
+__global__ __launch_bounds__(256) void k_sv_ranges(const uint32_t* __restrict__ pt_ctg, uint32_t n_parts, uint32_t* __restrict__ range) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parts) return;
+    const uint32_t ct = pt_ctg[p];
+    if (p == 0 || pt_ctg[p - 1] != ct) range[2 * ct] = p;
+    if (p + 1 == n_parts || pt_ctg[p + 1] != ct) range[2 * ct + 1] = p + 1;
+}
+// Round 1, after the votes (the marks were left alone): one lane per contig takes its parts in order like ss_kmer_correct does
+// (kmercount.c:221-249 with flagzero = 1): a part with a winner loses its FLAG_ZERO marks and takes the winner's bases, a part
+// nothing spanned goes on the contig's list for round 2 (fail_se at the slots of the contig's own parts).
+__global__ __launch_bounds__(64) void k_sv_round1(KcCtx c, uint32_t nc, const uint32_t* __restrict__ range, const int32_t* __restrict__ pt_se,
+                                                  const uint32_t* __restrict__ pt_len, const uint32_t* __restrict__ woff, uint32_t n_parts,
+                                                  const uint8_t* __restrict__ wpool, const uint8_t* __restrict__ has_winner,
+                                                  int32_t* __restrict__ fail_se, uint32_t* __restrict__ fail_cnt) {
+    const uint32_t ct = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ct >= nc) return;
+    const uint32_t p0 = range[2 * ct], p1 = range[2 * ct + 1];
+    const uint32_t g0 = c.ctg_off[ct];
+    uint32_t nf = 0;
+    for (uint32_t p = p0; p < p1; ++p) {
+        if (has_winner[p]) {
+            const uint32_t s0 = c.soff[g0 + (uint32_t)pt_se[2 * p]], n = pt_len[p];
+            const uint8_t* w = wpool + woff[p];
+            for (uint32_t t = 0; t < n; ++t) { c.sflag[s0 + t] = (uint8_t)(c.sflag[s0 + t] & ~KC_FLAG_ZERO); c.sbase[s0 + t] = w[t]; }
+        } else {
+            fail_se[2 * (p0 + nf)] = pt_se[2 * p];
+            fail_se[2 * (p0 + nf) + 1] = pt_se[2 * p + 1];
+            ++nf;
+        }
+    }
+    fail_cnt[ct] = nf;
+}
+// Round 2 parts: fts_spilt_region over the contig's failed parts appends to ONE list -- the reference re-uses the list object that
+// held the round-1 parts (start0, end0, start1, end1 ...) with its length set to 0 and its contents left in place -- and
+// ss_kmer_correct then reads that list pairwise: an odd number of values makes the last pair end at whatever the list held at that
+// index before (a round-1 value, or zero-filled memory behind it).  Pairs with start > end do nothing in the reference (every loop
+// over them is empty) and are dropped here.  val[] / the round-2 part slots of a contig start at voff[first part of the contig].
+__global__ __launch_bounds__(64) void k_sv_round2_parts(KcCtx c, uint32_t nc, const uint32_t* __restrict__ range, const int32_t* __restrict__ pt_se,
+                                                        uint32_t n_parts, const uint32_t* __restrict__ voff, const int32_t* __restrict__ fail_se,
+                                                        const uint32_t* __restrict__ fail_cnt, int32_t* __restrict__ val,
+                                                        uint32_t* __restrict__ p2_ctg, int32_t* __restrict__ p2_se, uint32_t* __restrict__ p2_len) {
+    const uint32_t ct = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ct >= nc) return;
+    const uint32_t p0 = range[2 * ct], p1 = range[2 * ct + 1];
+    if (p0 == p1) return;
+    const uint32_t v0 = voff[p0], cap = voff[p1] - v0;
+    int32_t* out = val + v0;
+    int32_t n = 0;
+    for (uint32_t k = 0; k < fail_cnt[ct] && n >= 0; ++k) n = kc_fts_split(c, ct, fail_se[2 * (p0 + k)], fail_se[2 * (p0 + k) + 1], out, n, (int32_t)cap - 1);
+    if (n < 0) { atomicOr(c.err, ERR_KC_REGIONS); return; }
+    if (n & 1) {
+        const uint32_t n_old = 2 * (p1 - p0);
+        out[n] = (uint32_t)n < n_old ? pt_se[2 * p0 + (uint32_t)n] : 0;
+        ++n;
+    }
+    const uint32_t g0 = c.ctg_off[ct];
+    for (int32_t k = 0; k < n / 2; ++k) {
+        const int32_t a = out[2 * k], b = out[2 * k + 1];
+        const uint32_t q = v0 + (uint32_t)k;
+        if (a > b) continue;          // the slot stays unused (p2_ctg preset to 0xffffffff)
+        p2_ctg[q] = ct;
+        p2_se[2 * q] = a;
+        p2_se[2 * q + 1] = b;
+        p2_len[q] = c.soff[g0 + (uint32_t)b] - c.soff[g0 + (uint32_t)a] + 1;
+    }
+}
+// Round 2, after the votes: the winners' bases in list order (contig_update_contig; later parts overwrite earlier ones)
+__global__ __launch_bounds__(64) void k_sv_round2_apply(KcCtx c, uint32_t nc, const uint32_t* __restrict__ range, uint32_t n_parts,
+                                                        const uint32_t* __restrict__ voff, const uint32_t* __restrict__ p2_ctg,
+                                                        const int32_t* __restrict__ p2_se, const uint32_t* __restrict__ p2_len,
+                                                        const uint32_t* __restrict__ woff2, const uint8_t* __restrict__ wpool,
+                                                        const uint8_t* __restrict__ has_winner) {
+    const uint32_t ct = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ct >= nc) return;
+    const uint32_t p0 = range[2 * ct], p1 = range[2 * ct + 1];
+    if (p0 == p1) return;
+    const uint32_t g0 = c.ctg_off[ct];
+    for (uint32_t q = voff[p0]; q < voff[p1]; ++q) {
+        if (p2_ctg[q] != ct || !has_winner[q]) continue;
+        const uint32_t s0 = c.soff[g0 + (uint32_t)p2_se[2 * q]], n = p2_len[q];
+        const uint8_t* w = wpool + woff2[q];
+        for (uint32_t t = 0; t < n; ++t) c.sbase[s0 + t] = w[t];
+    }
+}
+__global__ __launch_bounds__(256) void k_sv_val_sizes(const uint32_t* __restrict__ pt_len, uint32_t n_parts, uint32_t* __restrict__ vsz) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_parts) vsz[p] = pt_len[p] + 3u;      // values one failed part can append (two per unflagged run + its end) + the odd tail
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -403,6 +497,28 @@ void kc_launch_apply(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, con
 }
 void kc_launch_result(hipStream_t st, const uint8_t* sbase, const uint8_t* sflag, uint32_t S, uint16_t* slot_res) {
     if (S) k_kc_result<<<kblk(S, 256), 256, 0, st>>>(sbase, sflag, S, slot_res);
+}
+
+void sv_launch_val_sizes(hipStream_t st, const uint32_t* pt_len, uint32_t n_parts, uint32_t* vsz) {
+    if (n_parts) k_sv_val_sizes<<<kblk(n_parts, 256), 256, 0, st>>>(pt_len, n_parts, vsz);
+}
+void sv_launch_ranges(hipStream_t st, const uint32_t* pt_ctg, uint32_t n_parts, uint32_t* range) {
+    if (n_parts) k_sv_ranges<<<kblk(n_parts, 256), 256, 0, st>>>(pt_ctg, n_parts, range);
+}
+void sv_launch_round1(hipStream_t st, const KcCtx& c, uint32_t nc, const uint32_t* range, const int32_t* pt_se, const uint32_t* pt_len,
+                      const uint32_t* woff, uint32_t n_parts, const uint8_t* wpool, const uint8_t* has_winner, int32_t* fail_se,
+                      uint32_t* fail_cnt) {
+    if (nc) k_sv_round1<<<kblk(nc, 64), 64, 0, st>>>(c, nc, range, pt_se, pt_len, woff, n_parts, wpool, has_winner, fail_se, fail_cnt);
+}
+void sv_launch_round2_parts(hipStream_t st, const KcCtx& c, uint32_t nc, const uint32_t* range, const int32_t* pt_se, uint32_t n_parts,
+                            const uint32_t* voff, const int32_t* fail_se, const uint32_t* fail_cnt, int32_t* val, uint32_t* p2_ctg,
+                            int32_t* p2_se, uint32_t* p2_len) {
+    if (nc) k_sv_round2_parts<<<kblk(nc, 64), 64, 0, st>>>(c, nc, range, pt_se, n_parts, voff, fail_se, fail_cnt, val, p2_ctg, p2_se, p2_len);
+}
+void sv_launch_round2_apply(hipStream_t st, const KcCtx& c, uint32_t nc, const uint32_t* range, uint32_t n_parts, const uint32_t* voff,
+                            const uint32_t* p2_ctg, const int32_t* p2_se, const uint32_t* p2_len, const uint32_t* woff2,
+                            const uint8_t* wpool, const uint8_t* has_winner) {
+    if (nc) k_sv_round2_apply<<<kblk(nc, 64), 64, 0, st>>>(c, nc, range, n_parts, voff, p2_ctg, p2_se, p2_len, woff2, wpool, has_winner);
 }
 
 }  // namespace np1k

@@ -40,9 +40,14 @@ struct np1_pipe {
 
 namespace {
 
+// task numbers of the reference's caller (nextpolish1.py:220): 1 score_chain, 2 kmer_count, 4 snp_valid
+int run_task(np1_batch* b, const Configure* cfg, int task) {
+    return task == 2 ? np1_batch_kmer_count(b, cfg, nullptr) : task == 4 ? np1_batch_snp_valid(b, cfg, nullptr) : np1_batch_score_chain(b, cfg, nullptr);
+}
+
 int polish_on_lane(np1_pipe::Lane& ln, np1_stream* st, const Configure* cfg, int task) {
     if (np1_batch_reload(ln.batch, st) != 0) return -1;
-    const int rc = task == 2 ? np1_batch_kmer_count(ln.batch, cfg, nullptr) : np1_batch_score_chain(ln.batch, cfg, nullptr);
+    const int rc = run_task(ln.batch, cfg, task);
     if (rc != 0) return -1;
     return np1_batch_results_fetch(ln.batch);
 }
@@ -109,7 +114,7 @@ int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passe
         for (int pass = 0; pass < passes && !failed; ++pass)
             for (size_t k = lane; k < p->resident.size(); k += nl) {
                 np1_batch* b = p->resident[k];
-                const int rc = task == 2 ? np1_batch_kmer_count(b, cfg, nullptr) : np1_batch_score_chain(b, cfg, nullptr);
+                const int rc = run_task(b, cfg, task);
                 if (rc != 0) {
                     std::lock_guard<std::mutex> g(err_mu);
                     if (!failed) err = np1_last_error();
@@ -204,7 +209,7 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
         cur_bp += L;
     }
     const int n = (int)plan.size();
-    const bool with_qual = task == 2;
+    const bool with_qual = task == 2 || task == 4;
     // NP1_INGEST=host: inflate and split the records on host threads (np_stream.cpp) instead of on the device (np1_ingest.hip)
     const char* ing = getenv("NP1_INGEST");
     const bool device_ingest = src.have_bai && !(ing && strcmp(ing, "host") == 0);
@@ -323,7 +328,7 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
                 rc = np1_batch_reload(ln.batch, it.stream);
             }
             t_p1 = now_ms();
-            if (rc == 0) rc = task == 2 ? np1_batch_kmer_count(ln.batch, cfg, nullptr) : np1_batch_score_chain(ln.batch, cfg, nullptr);
+            if (rc == 0) rc = run_task(ln.batch, cfg, task);
             t_p2 = now_ms();
             if (rc == 0) rc = np1_batch_results_fetch(ln.batch);
             if (timing_on()) fprintf(stderr, "[np1 pipe] batch %d lane %zu: ingest %.1f ms, kernels %.1f ms, fetch %.1f ms\n", k, li, t_p1 - t_p0, t_p2 - t_p1, now_ms() - t_p2);

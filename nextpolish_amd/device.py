@@ -29,6 +29,11 @@ class Batch(object):
         if nat.lib().np1_batch_kmer_count(self.handle, C.byref(cfg), None) != 0:
             raise RuntimeError("np1_batch_kmer_count: " + nat.last_error())
 
+    def snp_valid(self, cfg):
+        """Task 4 over the resident batch (reference: source/lib/snpvalid.c; stream loaded with qualities)."""
+        if nat.lib().np1_batch_snp_valid(self.handle, C.byref(cfg), None) != 0:
+            raise RuntimeError("np1_batch_snp_valid: " + nat.last_error())
+
     def results(self):
         L = nat.lib()
         out = []

@@ -5,14 +5,14 @@ Same command line, same block-file / resume / naming behaviour, same output reco
 (``>name_np1 length`` + sequence); the compute goes through the in-tree HIP library instead of a
 ``multiprocessing.Pool`` of CPU workers:
 
-* tasks 1 and 2 (score_chain, kmer_count): the still-unpolished contigs of this block are packed into batches of
+* tasks 1, 2 and 4 (score_chain, kmer_count, snp_valid): the still-unpolished contigs of this block are packed into batches of
   ``--batch_bp`` draft bases that flow loader threads -> pinned host arrays -> H2D -> kernels -> D2H on ``--lanes``
   device lanes (include/nextpolish1.h, np1_pipe_*).  ``--world N --rank r`` deals the block's contigs over N
   GPUs of the node longest-first, one process per GPU (contigs are independent: no collective on the data path;
   reference: nextpolish1.py:181-189,223-224 and source/nextPolish:93-117 for the block split).
 * ``-debug`` needs the per-base change list of the drop-in ABI and therefore goes contig by contig through
   ``score_chain(tigname, cfg)`` exactly like the reference worker (nextpolish1.py:181-189).
-* tasks 3-5 call the library's drop-in symbols, which report what is (not) available on the GPU path.
+* tasks 3 and 5 call the library's drop-in symbols, which report that they are not available on the GPU path.
 
 Record order is the order of the block file / FASTA (the reference's order is nondeterministic: it
 iterates a Python set through imap_unordered, nextpolish1.py:148-161,224).
@@ -147,7 +147,7 @@ def rank_share(all_names, lengths, world, rank, polished_seqs, filter_polished):
 
 
 def polish_batched(args, cfg, names, device, emit):
-    """Tasks 1 and 2 without -debug: the rank's contigs flow through the device in batches of --batch_bp draft bases on
+    """Tasks 1, 2 and 4 without -debug: the rank's contigs flow through the device in batches of --batch_bp draft bases on
     --lanes device lanes while host threads inflate and split the records of the next batches (np1_pipe_run_files)."""
     from nextpolish_amd.device import Pipe
     lengths = fasta_lengths(args.genome)
@@ -205,7 +205,7 @@ def main(args):
             print(name + " %d %d %c %c" % p, file=sys.stderr)
 
     fun = {1: L.score_chain, 2: L.kmer_count, 3: L.snp_phase, 4: L.snp_valid, 5: L.lgspolish}[args.task]
-    if args.task in (1, 2) and not args.debug:
+    if args.task in (1, 2, 4) and not args.debug:
         device = args.device if args.device >= 0 else args.rank
         polish_batched(args, cfg, names, device, emit)
     else:

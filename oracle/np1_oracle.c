@@ -10,6 +10,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 #define BASE_DEL 3
 #define FLAG_ZERO 1
@@ -628,8 +629,13 @@ static ilist split_region(octg* c, ilist* regs, uint8_t flag, uint8_t max) {   /
 
 typedef struct { uint8_t* region; int32_t length, qual, mapqual, num; } okscore;
 
-/* ss_parse_read_kmer with left = right = -1, flagzero = 0 (reference: source/lib/kmercount.c:365-465) */
-static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, okscore* ks) {
+/* set when the walk would touch insertion columns that were never created (a snp_valid second-round pair reaching outside its
+ * region): the reference dereferences a null list there */
+static int g_undefined = 0;
+
+/* ss_parse_read_kmer with left = right = -1 (reference: source/lib/kmercount.c:365-465); flagzero != 0: the FLAG_ZERO marks of
+ * the covered slots are left alone (snp_valid's first round) */
+static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, okscore* ks, int flagzero) {
     const np1o_contig* in = c->in;
     if (!in->n_cigar[r]) return;
     int32_t pos = in->pos[r], qpos = 0, qstart, qend, i, j, k, len, del = 0;
@@ -650,7 +656,7 @@ static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, oksc
                             obase* pb = &c->b[pos - 1];
                             for (k = 0; k < pb->nins; k++) {
                                 ks->region[ks->length++] = BASE_DEL;
-                                pb->ins[k].flag &= (uint8_t)~FLAG_ZERO;
+                                if (!flagzero) pb->ins[k].flag &= (uint8_t)~FLAG_ZERO;
                                 del++;
                             }
                         }
@@ -660,7 +666,7 @@ static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, oksc
                             ks->region[ks->length++] = seqi(seq, qpos);
                             ks->qual += qual[qpos];
                         }
-                        c->b[pos].m.flag &= (uint8_t)~FLAG_ZERO;
+                        if (!flagzero) c->b[pos].m.flag &= (uint8_t)~FLAG_ZERO;
                     }
                     if (curcigar != CDEL) qpos++;
                     lastcigar = curcigar;
@@ -671,15 +677,16 @@ static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, oksc
                     obase* pb = (pos - 1 < c->L) ? &c->b[pos - 1] : NULL;
                     for (j = 0; j < len; j++, qpos++) {
                         if (pos > start && pos <= end && qpos >= qstart && qpos <= qend) {
+                            if (!pb || j >= pb->nins) { g_undefined = 1; return; }
                             ks->region[ks->length++] = seqi(seq, qpos);
                             ks->qual += qual[qpos];
-                            pb->ins[j].flag &= (uint8_t)~FLAG_ZERO;
+                            if (!flagzero) pb->ins[j].flag &= (uint8_t)~FLAG_ZERO;
                         }
                     }
                     if (pos > start && pos <= end && qpos > qstart && qpos <= qend + 1) {
                         for (; j < pb->nins; j++) {
                             ks->region[ks->length++] = BASE_DEL;
-                            pb->ins[j].flag &= (uint8_t)~FLAG_ZERO;
+                            if (!flagzero) pb->ins[j].flag &= (uint8_t)~FLAG_ZERO;
                             del++;
                         }
                     }
@@ -703,9 +710,9 @@ static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, oksc
 typedef struct { okscore* v; int32_t n, cap; } kslist;
 
 /* ss_kmer_get_region (reference: source/lib/kmercount.c:332-363); returns nothing, mutates ks */
-static void kmer_get_region(octg* c, int64_t r, int32_t start, int32_t end, int32_t length, kslist* rd, okscore* ks) {
+static void kmer_get_region(octg* c, int64_t r, int32_t start, int32_t end, int32_t length, kslist* rd, okscore* ks, int flagzero) {
     if (ks->region == NULL) ks->region = (uint8_t*)calloc(1, (size_t)length + 8);
-    parse_read_kmer(c, r, start, end, ks);
+    parse_read_kmer(c, r, start, end, ks, flagzero);
     if (ks->length == length) {
         okscore* hit = NULL;
         for (int32_t i = 0; i < rd->n; i++)
@@ -736,11 +743,13 @@ static int ks_compare(const okscore* a, const okscore* b) {   /* kmercount.c:63-
     return 0;
 }
 
-/* ss_kmer_correct with nodepth = NULL, flagzero = 0 (reference: source/lib/kmercount.c:175-261).
+/* ss_kmer_correct (reference: source/lib/kmercount.c:175-261); the values of `regs` are read pairwise, n_vals of them are valid
+ * (an odd count makes the last pair read one stored value further, as the reference does); nodepth != NULL collects the
+ * regions no record spans; flagzero: see parse_read_kmer.
  * Spanning query = swapped-interval iterator (contig.c:1130-1135): records with pos < start and
  * endpos > end+1 in file order, iteration ends at the first record with pos >= start; that
  * terminating record is the "stale read" the reference's fallback loop keeps re-parsing. */
-static void kmer_correct(octg* c, ilist* regs, int32_t max_span) {
+static void kmer_correct(octg* c, ilist* regs, int32_t max_span, ilist* nodepth, int flagzero) {
     const np1o_contig* in = c->in;
     kslist rd = {0, 0, 0};
     c->filter_kind = 0;
@@ -757,7 +766,7 @@ static void kmer_correct(octg* c, ilist* regs, int32_t max_span) {
             if (!(read_endpos(in, r) > end + 1)) continue;
             n_span++;
             if (read_filter(c, r) == 2) {
-                kmer_get_region(c, r, start, end, length, &rd, &ks);
+                kmer_get_region(c, r, start, end, length, &rd, &ks, flagzero);
                 have_ks = 1;
                 if (ks.mapqual == MAX_MAPQ) {
                     count++;
@@ -777,13 +786,18 @@ static void kmer_correct(octg* c, ilist* regs, int32_t max_span) {
              * testing and parsing the stale record */
             for (int64_t t = 0; t < n_span; t++) {
                 if (read_filter(c, stale) == 1) {
-                    kmer_get_region(c, stale, start, end, length, &rd, &ks);
+                    kmer_get_region(c, stale, start, end, length, &rd, &ks, flagzero);
                     have_ks = 1;
                     ks_clean(&ks, length);
                 }
             }
         }
         if (rd.n > 0) {
+            if (flagzero) {   /* contig_clean_flag(start, end, FLAG_ZERO_N), contig.c:823-831 */
+                int32_t i = start, j = 0;
+                oslot* p = &c->b[start].m;
+                while (IN_RANGE(i, j, end)) { p->flag &= (uint8_t)~FLAG_ZERO; p = ctg_next(c, &i, &j); }
+            }
             okscore* best = NULL;
             if (count == c->cfg->max_count_kmer) {
                 int32_t want = MAX_MAPQ * count;
@@ -804,6 +818,9 @@ static void kmer_correct(octg* c, ilist* regs, int32_t max_span) {
                 p = ctg_next(c, &i, &j);
                 q++;
             }
+        } else if (nodepth) {
+            il_push(nodepth, start);
+            il_push(nodepth, end);
         }
         if (have_ks) free(ks.region);
         for (int32_t i = 0; i < rd.n; i++) free(rd.v[i].region);
@@ -833,11 +850,76 @@ char* np1o_kmer_count(const np1o_contig* in, const np1o_configure* cfg, int32_t*
     free(nodepth.v);
     if (kreg.n > 0) {
         ilist parts = split_region(c, &kreg, 0x1, cfg->max_len_kmer);
-        kmer_correct(c, &parts, max_span);
+        kmer_correct(c, &parts, max_span, NULL, 0);
         free(parts.v);
     }
     free(kreg.v);
     char* out = get_contig(c, 0, c->L - 1, FLAG_ZERO, out_len);
+    ctg_free(c);
+    return out;
+}
+
+/* ================= snp_valid (reference: source/lib/snpvalid.c) ================= */
+
+/* fts_spilt_region (snpvalid.c:38-66): appends to `result` (which is NOT started with `start`) */
+static void fts_split_region(octg* c, int32_t start, int32_t end, uint8_t flag, ilist* result) {
+    int32_t i = start, j = 0, qstart = -1, qend = -1;
+    oslot* p = &c->b[start].m;
+    while (IN_RANGE(i, j, end)) {
+        if ((p->flag & flag) == 0) {
+            if (qstart == -1) qstart = i;
+            qend = i;
+        } else if (qstart != -1) {
+            int32_t count = 2;
+            if (qstart == start) { qend = start; count--; }
+            int32_t mid = (qstart + qend) / 2;
+            for (int32_t k = 0; k < count; k++) {
+                il_push(result, mid);
+                if (qstart != qend) mid++;
+            }
+            qstart = qend = -1;
+        }
+        p = ctg_next(c, &i, &j);
+    }
+    il_push(result, end);
+}
+
+char* np1o_snp_valid(const np1o_contig* in, const np1o_configure* cfg, int32_t* out_len) {   /* snpvalid.c:3-36 */
+    g_updates = 0;
+    if (in->length <= 0) { *out_len = 0; return (char*)calloc(1, 1); }
+    octg* c = ctg_init(in, cfg);
+    c->filter_kind = 0;
+    int32_t max_span = stream_max_span(in);
+    ilist kreg = get_region(c, 0, c->L - 1, cfg->min_len_inter_kmer, 0, FLAG_ZERO, brim_with_ext);
+    if (kreg.n > 0) {
+        merge_region(&kreg);
+        create_insert_region(c, &kreg, max_span);
+    }
+    if (kreg.n > 0) {
+        /* the reference keeps ONE list object: first the parts of ss_spilt_region, then -- its length reset to 0, its
+         * contents left in place -- the values fts_spilt_region appends for the regions nothing spanned.  An odd number of
+         * values makes the last pair take its end from whatever the list held at that index before. */
+        ilist nodepth = split_region(c, &kreg, FLAG_ZERO, cfg->max_len_kmer);
+        kreg.n = 0;
+        kmer_correct(c, &nodepth, max_span, &kreg, 1);
+        int32_t n_old = nodepth.n;
+        nodepth.n = 0;
+        if (kreg.n > 0) {
+            for (int i = 0; i < kreg.n; i += 2) fts_split_region(c, kreg.v[i], kreg.v[i + 1], FLAG_ZERO, &nodepth);
+            g_undefined = 0;
+            if (nodepth.n & 1)       /* the value behind the last one: a leftover of the first list, or never written (zero-filled) */
+                il_push(&nodepth, nodepth.n < n_old ? nodepth.v[nodepth.n] : 0);
+            kmer_correct(c, &nodepth, max_span, NULL, 0);
+            if (g_undefined) {
+                free(nodepth.v); free(kreg.v); ctg_free(c);
+                *out_len = -1;
+                return NULL;
+            }
+        }
+        free(nodepth.v);
+    }
+    free(kreg.v);
+    char* out = get_contig(c, 0, c->L - 1, 0, out_len);
     ctg_free(c);
     return out;
 }

@@ -61,6 +61,7 @@ void np1o_default_config(np1o_configure* cfg);
  * string (caller frees with np1o_free) and its length in *out_len. */
 char* np1o_score_chain(const np1o_contig* c, const np1o_configure* cfg, int32_t* out_len);
 char* np1o_kmer_count(const np1o_contig* c, const np1o_configure* cfg, int32_t* out_len);
+char* np1o_snp_valid(const np1o_contig* c, const np1o_configure* cfg, int32_t* out_len);   /* task 4, source/lib/snpvalid.c */
 void np1o_free(void* p);
 
 /* Algorithmic update count of score_chain's pileup (one per slot vote), for throughput reports. */

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <cstdio>
 #include <vector>
 
 #include "../../include/nextpolish1.h"
@@ -400,7 +401,7 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
 }
 
 // kmer_count through the per-region bodies of np1_kmer.h, driven sequentially (the GPU runs one lane per region)
-int np1m_kmer_count(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds) {
+static int kmer_model(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds, bool snp_valid) {
     const uint32_t nc = (uint32_t)v->n_contigs;
     const int64_t n = v->n_reads;
     const uint64_t G = (uint64_t)v->draft_len;
@@ -460,6 +461,7 @@ int np1m_kmer_count(const np1_stream_view* v, const Configure* cfg, char** out, 
         k = kc_merge_regions(buf.data(), k);
         kreg[ct].assign(buf.begin(), buf.begin() + k);
         for (size_t i = 0; i + 1 < kreg[ct].size(); i += 2) kc_insert_region(c, ct, kreg[ct][i], kreg[ct][i + 1], ins.data());
+        if (snp_valid) nodepth[ct].clear();     // task 4 has no no-depth regions (snpvalid.c:3-36)
         for (size_t i = 0; i + 1 < nodepth[ct].size(); i += 2) kc_insert_region(c, ct, nodepth[ct][i], nodepth[ct][i + 1], ins.data());
     }
     std::vector<uint32_t> soff(G + 2);
@@ -490,9 +492,11 @@ int np1m_kmer_count(const np1_stream_view* v, const Configure* cfg, char** out, 
             kc_score_correct_level2(c, ct, nodepth[ct][i], nodepth[ct][i + 1]);
         }
     if (err) return (int)err;
+    c.keep_zero_marks = snp_valid ? 1 : 0;
     for (uint32_t ct = 0; ct < nc; ++ct) {
         const uint32_t g0 = v->ctg_off[ct];
         const bool has_next = (int64_t)v->read_begin[ct + 1] < n;
+        std::vector<int32_t> all_parts, failed;     // snp_valid: the contig's part list (flat) and the parts nothing spanned
         for (size_t i = 0; i + 1 < kreg[ct].size(); i += 2) {
             std::vector<int32_t> parts(2 * (size_t)(kreg[ct][i + 1] - kreg[ct][i] + 4));
             int32_t np = kc_split_region(c, ct, kreg[ct][i], kreg[ct][i + 1], parts.data(), (int32_t)parts.size());
@@ -502,13 +506,38 @@ int np1m_kmer_count(const np1_stream_view* v, const Configure* cfg, char** out, 
                 const int32_t length = (int32_t)(soff[g0 + pe] - soff[g0 + ps] + 1);
                 std::vector<uint8_t> win(length);
                 hcount = 0;
+                all_parts.push_back(ps); all_parts.push_back(pe);
                 if (kc_part_winner(c, ct, ps, pe, has_next, win.data(), length)) {
                     const uint32_t s0 = soff[g0 + ps];
-                    for (int32_t t = 0; t < length; ++t) sbase[s0 + t] = win[t];   // contig_update_contig (contig.c:811-821)
+                    for (int32_t t = 0; t < length; ++t) {
+                        if (snp_valid) sflag[s0 + t] = (uint8_t)(sflag[s0 + t] & ~KC_FLAG_ZERO);   // contig_clean_flag (contig.c:823-831)
+                        sbase[s0 + t] = win[t];   // contig_update_contig (contig.c:811-821)
+                    }
+                } else if (snp_valid) {
+                    failed.push_back(ps); failed.push_back(pe);
+                }
+            }
+        }
+        if (snp_valid && !failed.empty()) {     // second round (what k_sv_round2_parts / k_sv_round2_apply do)
+            std::vector<int32_t> val(all_parts.size() * 2 + 4 * (size_t)(v->ctg_off[ct + 1] - g0) + 16);
+            int32_t nv = 0;
+            for (size_t k = 0; k + 1 < failed.size() && nv >= 0; k += 2) nv = kc_fts_split(c, ct, failed[k], failed[k + 1], val.data(), nv, (int32_t)val.size() - 1);
+            if (nv < 0) return -13;
+            if (nv & 1) { val[(size_t)nv] = (size_t)nv < all_parts.size() ? all_parts[(size_t)nv] : 0; ++nv; }
+            for (int32_t k = 0; k + 1 < nv; k += 2) {
+                const int32_t ps = val[(size_t)k], pe = val[(size_t)k + 1];
+                if (ps > pe) continue;
+                const int32_t length = (int32_t)(soff[g0 + pe] - soff[g0 + ps] + 1);
+                std::vector<uint8_t> win(length);
+                hcount = 0;
+                if (kc_part_winner(c, ct, ps, pe, has_next, win.data(), length)) {
+                    const uint32_t s0 = soff[g0 + ps];
+                    for (int32_t t = 0; t < length; ++t) sbase[s0 + t] = win[t];
                 }
             }
         }
     }
+    if (snp_valid) for (uint32_t s = 0; s < S; ++s) sflag[s] = 0;     // emitted without marks (snpvalid.c:30)
     if (err) return (int)err;
     std::vector<uint16_t> slot_res(S + 64);
     for (uint32_t s = 0; s < S; ++s) slot_res[s] = (uint16_t)(sbase[s] | sflag[s] << 8);
@@ -522,6 +551,9 @@ int np1m_kmer_count(const np1_stream_view* v, const Configure* cfg, char** out, 
     *out = buf;
     return 0;
 }
+
+int np1m_kmer_count(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds) { return kmer_model(v, cfg, out, bounds, false); }
+int np1m_snp_valid(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds) { return kmer_model(v, cfg, out, bounds, true); }
 
 void np1m_free(void* p) { free(p); }
 

@@ -18,6 +18,8 @@ def lib():
         L.np1m_kmer_count.argtypes = [C.POINTER(nat.StreamView), C.POINTER(nat.Configure), C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_uint32)]
         L.np1m_kmer_count.restype = C.c_int
+        L.np1m_snp_valid.argtypes = L.np1m_kmer_count.argtypes
+        L.np1m_snp_valid.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -47,6 +49,21 @@ def kmer_count(stream, cfg):
     rc = lib().np1m_kmer_count(C.byref(stream.view), C.byref(cfg), C.byref(out), bounds)
     if rc != 0:
         raise RuntimeError("kmer_count model failed rc=%d" % rc)
+    blob = C.string_at(out, bounds[stream.n_contigs])
+    lib().np1m_free(out)
+    return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)]
+
+
+def snp_valid(stream, cfg):
+    """snp_valid (task 4) through the per-region bodies of np1_kmer.h, the rounds driven the way the kernels drive them; raises
+    ValueError for inputs the reference has no defined result for (the product's ERR_KC_UNDEFINED)."""
+    out = C.c_void_p()
+    bounds = (C.c_uint32 * (stream.n_contigs + 1))()
+    rc = lib().np1m_snp_valid(C.byref(stream.view), C.byref(cfg), C.byref(out), bounds)
+    if rc == 512:
+        raise ValueError("undefined upstream")
+    if rc != 0:
+        raise RuntimeError("snp_valid model failed rc=%d" % rc)
     blob = C.string_at(out, bounds[stream.n_contigs])
     lib().np1m_free(out)
     return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)]

@@ -45,6 +45,8 @@ def lib():
         L.np1o_score_chain.restype = C.c_void_p
         L.np1o_kmer_count.argtypes = [C.POINTER(OContig), C.POINTER(OConfigure), C.POINTER(C.c_int32)]
         L.np1o_kmer_count.restype = C.c_void_p
+        L.np1o_snp_valid.argtypes = [C.POINTER(OContig), C.POINTER(OConfigure), C.POINTER(C.c_int32)]
+        L.np1o_snp_valid.restype = C.c_void_p
         L.np1o_free.argtypes = [C.c_void_p]
         L.np1o_last_update_count.restype = C.c_int64
         _LIB = L
@@ -90,6 +92,8 @@ def _run(fn, stream, i, cfg):
     oc = contig_view(stream, i)
     n = C.c_int32(0)
     p = fn(C.byref(oc), C.byref(cfg), C.byref(n))
+    if not p:          # snp_valid on an input the reference itself reads uninitialised memory for
+        return None
     s = C.string_at(p, n.value).decode()
     lib().np1o_free(p)
     return s
@@ -101,3 +105,7 @@ def score_chain(stream, i, cfg=None):
 
 def kmer_count(stream, i, cfg):
     return _run(lib().np1o_kmer_count, stream, i, cfg)
+
+
+def snp_valid(stream, i, cfg):
+    return _run(lib().np1o_snp_valid, stream, i, cfg)
