@@ -406,6 +406,7 @@ def main():
     L.np1_pipe_run_resident.argtypes = [C.c_void_p, C.POINTER(nat.Configure), C.c_int, C.c_int]
     L.np1_pipe_resident_batch.argtypes = [C.c_void_p, C.c_int]
     L.np1_pipe_resident_batch.restype = C.c_void_p
+    L.np1_pipe_run_resident_timed.argtypes = [C.c_void_p, C.c_int, C.POINTER(nat.Configure), C.POINTER(C.c_float)]
     harr = (C.c_void_p * len(streams))(*[s.handle for s in streams])
     if L.np1_pipe_upload(pipe.handle, harr, len(streams)) != 0:
         raise SystemExit("upload: " + nat.last_error())
@@ -442,7 +443,7 @@ def main():
         b = L.np1_pipe_resident_batch(pipe.handle, k)
         for _ in range(n_inst):
             ms = (C.c_float * nat.NP1_MAX_STAGES)()
-            if L.np1_batch_score_chain(b, C.byref(cfg), ms) != 0:
+            if L.np1_pipe_run_resident_timed(pipe.handle, k, C.byref(cfg), ms) != 0:
                 raise SystemExit("timed pass: " + nat.last_error())
             for i in range(L.np1_stage_count()):
                 nm = L.np1_stage_name(i).decode()

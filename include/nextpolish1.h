@@ -206,9 +206,14 @@ int np1_pipe_run(np1_pipe* p, np1_stream* const* streams, int n, const Configure
 const char* np1_pipe_result(np1_pipe* p, int batch, int64_t contig, int64_t* len);
 /* Resident mode (kernel-path measurements): np1_pipe_upload keeps one HBM batch per stream (dealt round-robin over the
  * lanes, replacing any earlier set); np1_pipe_run_resident polishes every resident batch `passes` times, the lanes
- * working concurrently, outputs staying on the device; np1_pipe_resident_batch(p, k) is batch k for np1_batch_* calls. */
+ * working concurrently, outputs staying on the device; np1_pipe_resident_batch(p, k) is batch k for np1_batch_* calls.
+ * A resident batch holds its INPUTS in HBM; the buffers a pass works in (slot arrays, descriptors, DP records, output: ~2.6 x the
+ * inputs) belong to the lane and are lent to the batch for the pass, so a draft of any size stays resident next to `lanes` work
+ * sets.  np1_pipe_run_resident_timed: one instrumented pass of batch k on lane 0 (per-stage HIP-event milliseconds into
+ * stage_ms[np1_stage_count()]); its result lengths stay readable through np1_batch_result_len. */
 int np1_pipe_upload(np1_pipe* p, np1_stream* const* streams, int n);
 int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passes);
+int np1_pipe_run_resident_timed(np1_pipe* p, int k, const Configure* cfg, float* stage_ms);
 np1_batch* np1_pipe_resident_batch(np1_pipe* p, int k);
 void np1_pipe_close(np1_pipe* p);
 /* From files: contigs of the FASTA index (all when names == NULL) are packed in index order into batches of at most

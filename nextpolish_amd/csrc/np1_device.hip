@@ -415,6 +415,11 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                 }
             }
             if (hc[CNT_ERR] & ERR_POOL_OVERFLOW) {
+                if (getenv("NP1_DEBUG_POOL")) {
+                    fprintf(stderr, "[np1 pool] attempt %d: S %u, pool %zu words, heads %zu entries; per shard used (pool / heads):", attempt, S, b->pool.cap / 4, b->heads.cap / 4);
+                    for (uint32_t sh = 0; sh < POOL_SHARDS; ++sh) fprintf(stderr, " %u/%u", hc[CNT_POOL_S0 + sh], hc[CNT_HEADS_S0 + sh]);
+                    fprintf(stderr, "\n");
+                }
                 if (attempt >= 3) { np1_set_error("DP record pool keeps overflowing"); return -1; }
                 size_t need = 2 * b->pool.cap;   // a shard ran out: double the pool (and the run-head list with it)
                 if (b->heads.ensure(2 * b->heads.cap)) return -1;
@@ -786,3 +791,5 @@ int np1_batch_download_slots(np1_batch* b, int64_t c, std::vector<uint32_t>* sof
     if (s1 > s0) HIPCHK(hipMemcpy(res->data(), b->slot_res.as<uint16_t>() + s0, 2 * (size_t)(s1 - s0), hipMemcpyDeviceToHost));
     return 0;
 }
+
+void np1_batch_swap_work(np1_batch* a, np1_batch* b) { if (a && b && a != b) a->swap_work(*b); }

@@ -104,6 +104,18 @@ np1_batch* np1_pipe_resident_batch(np1_pipe* p, int k) {
     return (p && k >= 0 && (size_t)k < p->resident.size()) ? p->resident[(size_t)k] : nullptr;
 }
 
+// One instrumented pass of resident batch k on lane 0's work buffers: per-stage HIP-event times into stage_ms (np1_stage_count()
+// entries); the lengths of its results stay readable through np1_batch_result_len.
+int np1_pipe_run_resident_timed(np1_pipe* p, int k, const Configure* cfg, float* stage_ms) {
+    if (!p || !cfg || k < 0 || (size_t)k >= p->resident.size()) { np1_set_error("np1_pipe_run_resident_timed: bad argument"); return -1; }
+    np1_batch* b = p->resident[(size_t)k];
+    np1_batch* w = p->lanes[0].batch;
+    np1_batch_swap_work(b, w);
+    const int rc = np1_batch_score_chain(b, cfg, stage_ms);
+    np1_batch_swap_work(b, w);
+    return rc;
+}
+
 int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passes) {
     if (!p || !cfg) { np1_set_error("np1_pipe_run_resident: null argument"); return -1; }
     std::atomic<bool> failed(false);
@@ -114,7 +126,10 @@ int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passe
         for (int pass = 0; pass < passes && !failed; ++pass)
             for (size_t k = lane; k < p->resident.size(); k += nl) {
                 np1_batch* b = p->resident[k];
+                np1_batch* w = p->lanes[lane].batch;        // the lane's work buffers (slot arrays, descriptors, DP records ...)
+                np1_batch_swap_work(b, w);
                 const int rc = run_task(b, cfg, task);
+                np1_batch_swap_work(b, w);                           // the batch keeps only its inputs (and its host-side result bounds)
                 if (rc != 0) {
                     std::lock_guard<std::mutex> g(err_mu);
                     if (!failed) err = np1_last_error();

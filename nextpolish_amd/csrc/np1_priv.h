@@ -11,3 +11,7 @@ struct np1_stream {
 
 void np1_set_error(const std::string& e);   // np_host_abi.cpp
 void np1_stream_unpin(np1_stream* st);      // np1_device.hip (no-op when the stream was never pinned)
+
+// np1_device.hip: everything a pass allocates besides the uploaded inputs changes places between the two batches
+struct np1_batch;
+void np1_batch_swap_work(np1_batch* a, np1_batch* b);

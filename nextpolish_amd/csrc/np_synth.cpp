@@ -57,8 +57,10 @@ struct TmpRead {
     uint16_t flag;
     uint8_t mapq;
     int32_t isize;
-    uint32_t cig_beg, cig_n;
-    uint32_t seq_beg, l_qseq;   // into the unpacked base / qual pools
+    uint64_t cig_beg;           // into the CIGAR pool (a 250 Mb contig at 30x holds 4.3 G bases: 32 bits are not enough)
+    uint32_t cig_n;
+    uint64_t seq_beg;           // into the unpacked base / qual pools
+    uint32_t l_qseq;
 };
 
 struct Col { char op; int32_t dcoord; char base; };   // one alignment column of a read against the draft
@@ -192,8 +194,8 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
                 if (lo >= hi) continue;   // nothing aligned (can only happen for absurd parameters)
                 TmpRead r;
                 r.pos = cols[lo].dcoord;
-                r.cig_beg = (uint32_t)cig_pool.size();
-                r.seq_beg = (uint32_t)base_pool.size();
+                r.cig_beg = (uint64_t)cig_pool.size();
+                r.seq_beg = (uint64_t)base_pool.size();
                 // sequence = every non-D column in order (clipped bases stay in SEQ)
                 for (const Col& cl : cols)
                     if (cl.op != 'D') base_pool.push_back(cl.base);
@@ -254,7 +256,7 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
                 if (rng.chance(p.unmapped_rate)) {   // an unmapped mate placed at this position, no CIGAR
                     TmpRead u = r;
                     u.flag = (uint16_t)(0x1 | 0x4 | (m == 0 ? 0x80 : 0x40));
-                    u.cig_beg = (uint32_t)cig_pool.size();
+                    u.cig_beg = (uint64_t)cig_pool.size();
                     u.cig_n = 0;
                     u.mapq = 0;
                     u.isize = 0;
