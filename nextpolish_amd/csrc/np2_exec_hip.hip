@@ -952,7 +952,7 @@ __device__ __forceinline__ uint32_t col_state_index(const MsaView& mv, int32_t p
 }
 // the coefficient vectors of a run live in a ring of two columns (an entry only ever looks at its own column and the one
 // before it): size of the ring of every run = 2 * (most live entries of one of its columns), scanned into offsets
-__global__ void k2_run_size(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, uint32_t* size) {
+__global__ void k2_run_size(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, uint32_t n_runs, int32_t l, uint32_t* size, const uint32_t* col_ne = nullptr) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n_runs) return;
     if (r == n_runs) { size[r] = 0; return; }
@@ -960,7 +960,7 @@ __global__ void k2_run_size(MsaView mv, const uint32_t* cuts, uint32_t n_cuts, u
     run_bounds(cuts, n_cuts, r, l, &lo, &hi);
     uint32_t mx = 0;
     for (int32_t p = lo + 1; p <= hi; ++p) {
-        const uint32_t e = live_entries(mv, (uint32_t)p);
+        const uint32_t e = col_ne ? col_ne[p] : live_entries(mv, (uint32_t)p);     // a graph built by tiles keeps the count per column
         if (e > mx) mx = e;
     }
     size[r] = 2 * mx;
@@ -2130,7 +2130,7 @@ bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t
     uint32_t* status = flag_.as<uint32_t>() + 4;
     uint32_t* total_dev = flag_.as<uint32_t>() + 5;
     // ring of two columns of coefficient vectors per run
-    k2_run_size<<<nblk(n_runs + 1, 256), 256, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, runsz_.as<uint32_t>());
+    k2_run_size<<<nblk(n_runs + 1, 256), 256, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, runsz_.as<uint32_t>(), graph_compact_ ? colne_.as<uint32_t>() : nullptr);
     {
         const uint32_t nsr = nblk(n_runs + 1, SCAN_TILE);
         k2_scan_sums<<<nsr, SCAN_T, 0, q>>>(runsz_.as<uint32_t>(), n_runs + 1, sums2_.as<uint32_t>());
