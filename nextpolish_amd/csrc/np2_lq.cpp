@@ -125,7 +125,11 @@ void remove_short(Region& r) {
 // Length outliers out (optional), support scores, best-supported candidates first, how many of them are aligned later
 // (indexs .. indexe) and which ones seed the partial-order consensus.  min_span: indexe - indexs must exceed it (3, or 1 in
 // the HiFi variant).  Returns false when the region is dropped (r.len = 0).
+static std::atomic<long long> g_prof_rank{0}, g_prof_poa{0};
+static inline long long prof_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1000000000ll + ts.tv_nsec; }
+
 bool rank_and_seed(Region& r, bool trim, int min_span) {
+    const long long t_begin = prof_now();
     Ranker k(r);
     if (trim) {
         k.stable_by([](const Cand& a, const Cand& b) { return a.len < b.len; });
@@ -165,11 +169,14 @@ bool rank_and_seed(Region& r, bool trim, int min_span) {
     if (r.seqs[0].len < 20000) {
         std::vector<std::string> v;
         for (int q = 0; q < n_poa; ++q) v.push_back(r.seqs[(size_t)(first + q)].seq);
+        const long long t_poa = prof_now();
         r.sudoseed = poa_consensus(v);
+        g_prof_poa += prof_now() - t_poa;
     } else {
         r.sudoseed = r.seqs[0].seq;
     }
     r.sudoseed_len = (unsigned)r.sudoseed.size();
+    g_prof_rank += prof_now() - t_begin;
     return true;
 }
 
@@ -284,7 +291,7 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
         while (max_aln_length > cur && !max_aln.compare_exchange_weak(cur, max_aln_length)) {}
     });
     const int max_aln_length = max_aln.load();
-    if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   rank + poa done (t=%.2f)\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6); }
+    if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   rank + poa done (t=%.2f); inside rank_and_seed %.1f ms CPU, of which POA %.1f ms\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6, g_prof_rank.exchange(0) * 1e-6, g_prof_poa.exchange(0) * 1e-6); }
     return max_aln_length;
 }
 

@@ -13,8 +13,10 @@
 #include <algorithm>
 #include <cassert>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <time.h>
 #include <vector>
 
 #include "np2_lq.h"
@@ -70,8 +72,11 @@ struct PoGraph {
 // are finished, filling the order from the back.
 void PoGraph::reorder() {
     const uint16_t n = n_nodes();
-    std::vector<int32_t> group_of((size_t)n, -1);
-    std::vector<uint16_t> head;                        // representative node of every group = its lowest-numbered member seen first
+    static thread_local std::vector<int32_t> group_of;      // scratch kept per host thread: this runs after every string of every region
+    static thread_local std::vector<uint16_t> head, stack;
+    static thread_local std::vector<int8_t> finished, open;
+    group_of.assign((size_t)n, -1);
+    head.clear();                                      // representative node of every group = its lowest-numbered member seen first
     for (uint16_t v = 0; v < n; ++v) {
         if (group_of[v] != -1) continue;
         const int32_t g = (int32_t)head.size();
@@ -80,7 +85,8 @@ void PoGraph::reorder() {
         for (uint16_t p : peers[v]) group_of[p] = g;
     }
     const size_t n_groups = head.size();
-    std::vector<int8_t> finished(n_groups, 0), open(n_groups, 0);
+    finished.assign(n_groups, 0);
+    open.assign(n_groups, 0);
     order.assign(n, 0);
     int32_t slot = (int32_t)n - 1;                      // next free place, from the back
     auto blocked = [&](uint16_t v) {                    // does anything still have to come before this group?
@@ -88,7 +94,6 @@ void PoGraph::reorder() {
         for (size_t j = 0; j < peers[v].size() && c == 0; ++j) c += in[peers[v][j]].size();
         return c != 0;
     };
-    std::vector<uint16_t> stack;
     while (slot >= 0) {
         int32_t start = -1;
         for (size_t g = 0; g < n_groups; ++g)
@@ -121,48 +126,88 @@ void PoGraph::reorder() {
 
 // ---- string against graph ----------------------------------------------------------------------------------------------
 // Score table: row 0 = before any node, row r + 1 = node order[r]; column c = c characters of the string consumed.  A cell keeps
-// its score and the cell it was reached from (row, column packed into 32 bits; the two border lines point at the origin).
-struct Cell { int32_t score; uint16_t from_row, from_col; };
-
+// its score and the cell it was reached from (row << 16 | column; the two border lines point at the origin), in two planes so that
+// the part of a row that does not depend on the row itself -- the best move out of the predecessor rows -- is plain array
+// arithmetic over the columns.
 struct Step { int32_t node, chr; };     // one column of the alignment: graph node and / or string position (-1 = none)
+
+// Best move into (row, c + 1) out of ONE predecessor row P, for every c: skipping this node (gap) or pairing the character with it;
+// the gap goes first when the two tie.  first = this is the first predecessor (assign), else it replaces the current offer only
+// where it is strictly better.
+__attribute__((target_clones("avx2", "default")))
+void offers_from(const int32_t* __restrict__ P, const int32_t* __restrict__ w, uint32_t pr, uint32_t len, bool first,
+                 int32_t* __restrict__ O, uint32_t* __restrict__ F) {
+    const uint32_t tag = pr << 16;
+    if (first) {
+        for (uint32_t c = 0; c < len; ++c) {
+            const int32_t skip = P[c + 1] + W_GAP, pair = P[c] + w[c];
+            const bool sk = skip >= pair;
+            O[c] = sk ? skip : pair;
+            F[c] = tag | (c + (sk ? 1u : 0u));
+        }
+    } else {
+        for (uint32_t c = 0; c < len; ++c) {
+            const int32_t skip = P[c + 1] + W_GAP, pair = P[c] + w[c];
+            const bool sk = skip >= pair;
+            const int32_t cand = sk ? skip : pair;
+            const bool better = cand > O[c];
+            O[c] = better ? cand : O[c];
+            F[c] = better ? (tag | (c + (sk ? 1u : 0u))) : F[c];
+        }
+    }
+}
 
 void add_string(PoGraph& g, int q, const char* s, uint16_t len) {
     const uint16_t n = g.n_nodes();
     const size_t width = (size_t)len + 1;
-    static thread_local std::vector<Cell> tab;
-    tab.assign(((size_t)n + 1) * width, Cell{0, 0, 0});
-    auto at = [&](size_t row, size_t col) -> Cell& { return tab[row * width + col]; };
-    for (size_t c = 0; c < width; ++c) at(0, c).score = (int32_t)c * W_GAP;
-    // left border: the best predecessor's border value plus a gap (sources start from 0)
+    static thread_local std::vector<int32_t> tabS, O, W;
+    static thread_local std::vector<uint32_t> tabF, F;
+    tabS.resize(((size_t)n + 1) * width);          // every cell is written below: no fill
+    tabF.resize(((size_t)n + 1) * width);
+    O.resize(width); F.resize(width); W.resize(width);
+    int32_t* const TS = tabS.data();
+    uint32_t* const TF = tabF.data();
+    for (size_t c = 0; c < width; ++c) { TS[c] = (int32_t)c * W_GAP; TF[c] = 0; }
+    // the rows a row draws from (its in-edges in attachment order, row 0 for a source), resolved once per row
+    static thread_local std::vector<uint32_t> prow_beg, prow;
+    prow_beg.assign((size_t)n + 1, 0);
+    prow.clear();
     for (uint16_t r = 0; r < n; ++r) {
         const uint16_t v = g.order[r];
+        prow_beg[r] = (uint32_t)prow.size();
+        for (uint32_t e : g.in[v]) prow.push_back((uint32_t)g.rank[g.src[e]] + 1u);
+    }
+    prow_beg[n] = (uint32_t)prow.size();
+    // left border: the best predecessor's border value plus a gap (sources start from 0)
+    for (uint16_t r = 0; r < n; ++r) {
         int32_t best = 0;
         bool any = false;
-        for (uint32_t e : g.in[v]) {
-            const int32_t x = at((size_t)g.rank[g.src[e]] + 1, 0).score;
+        for (uint32_t k = prow_beg[r]; k < prow_beg[(size_t)r + 1]; ++k) {
+            const int32_t x = TS[(size_t)prow[k] * width];
             if (!any || x > best) { best = x; any = true; }
         }
-        at((size_t)r + 1, 0).score = best + W_GAP;
+        TS[((size_t)r + 1) * width] = best + W_GAP;
+        TF[((size_t)r + 1) * width] = 0;
     }
     // interior.  Moves into (row, c + 1): stay on the node and take a character (the default), or come from a predecessor row
     // either skipping this node's character pairing (gap) or pairing the character with the node.  A move replaces the current
-    // choice only if it is strictly better, and of a predecessor's two moves the gap goes first when they tie.
+    // choice only if it is strictly better, and of a predecessor's two moves the gap goes first when they tie: so the winner is the
+    // first predecessor (in edge order) with the best move, and it beats staying on the node only when it is strictly better.
     for (uint16_t r = 0; r < n; ++r) {
-        const uint16_t v = g.order[r];
-        const char vb = (char)g.base[v];
-        const size_t row = (size_t)r + 1;
-        const bool source = g.in[v].empty();
-        for (uint16_t c = 0; c < len; ++c) {
-            Cell pick{at(row, c).score + W_GAP, (uint16_t)row, c};
-            auto offer = [&](size_t prow) {
-                const int32_t skip = at(prow, (size_t)c + 1).score + W_GAP;
-                const int32_t pair = at(prow, c).score + (s[c] == vb ? W_MATCH : W_MISMATCH);
-                if (skip > pick.score && skip >= pair) pick = Cell{skip, (uint16_t)prow, (uint16_t)(c + 1)};
-                else if (pair > pick.score && pair >= skip) pick = Cell{pair, (uint16_t)prow, c};
-            };
-            for (uint32_t e : g.in[v]) offer((size_t)g.rank[g.src[e]] + 1);
-            if (source) offer(0);
-            at(row, (size_t)c + 1) = pick;
+        const char vb = (char)g.base[g.order[r]];
+        const uint32_t row = (uint32_t)r + 1;
+        int32_t* const RS = TS + (size_t)row * width;
+        uint32_t* const RF = TF + (size_t)row * width;
+        const uint32_t k0 = prow_beg[r], k1 = prow_beg[(size_t)r + 1];
+        for (uint32_t c = 0; c < len; ++c) W[c] = s[c] == vb ? W_MATCH : W_MISMATCH;
+        if (k0 == k1) offers_from(TS, W.data(), 0u, len, true, O.data(), F.data());          // a source draws from row 0
+        for (uint32_t k = k0; k < k1; ++k) offers_from(TS + (size_t)prow[k] * width, W.data(), prow[k], len, k == k0, O.data(), F.data());
+        const uint32_t stay = row << 16;
+        for (uint32_t c = 0; c < len; ++c) {
+            const int32_t h = RS[c] + W_GAP;
+            const bool take = O[c] > h;
+            RS[c + 1] = take ? O[c] : h;
+            RF[c + 1] = take ? F[c] : (stay | c);
         }
     }
     // the alignment ends in a sink: the first one in order with the best full-length score
@@ -172,7 +217,7 @@ void add_string(PoGraph& g, int q, const char* s, uint16_t len) {
         bool any = false;
         for (uint16_t r = 0; r < n; ++r)
             if (g.out[g.order[r]].empty()) {
-                const int32_t x = at((size_t)r + 1, len).score;
+                const int32_t x = TS[((size_t)r + 1) * width + len];
                 if (!any || x > best) { row = (size_t)r + 1; best = x; any = true; }
             }
     }
@@ -181,17 +226,18 @@ void add_string(PoGraph& g, int q, const char* s, uint16_t len) {
     path.clear();
     int64_t lowest_chr = -1, highest_chr = -1;
     for (size_t col = len; row != 0 || col != 0;) {
-        const Cell& c = at(row, col);
+        const uint32_t from = TF[row * width + col];
+        const size_t from_row = from >> 16, from_col = from & 0xffffu;
         Step st{-1, -1};
-        if (c.from_row != row) st.node = g.order[row - 1];
-        if (c.from_col != col) {
+        if (from_row != row) st.node = g.order[row - 1];
+        if (from_col != col) {
             st.chr = (int32_t)col - 1;
             lowest_chr = st.chr;
             if (highest_chr == -1) highest_chr = st.chr;
         }
         path.push_back(st);
-        row = c.from_row;
-        col = c.from_col;
+        row = from_row;
+        col = from_col;
     }
     std::reverse(path.begin(), path.end());
     // ---- thread the string through the graph
@@ -256,8 +302,10 @@ std::string poa_consensus(const std::vector<std::string>& seqs) {
     // best is carried from node to node in emission order (a node's own best starts from the previous node's value, which is
     // what the reference's shared variable does), the overall best is the first strict maximum
     const uint16_t n = g.n_nodes();
-    std::vector<double> best_at((size_t)n, 0.0);
-    std::vector<int32_t> came_from((size_t)n, -1);
+    static thread_local std::vector<double> best_at;
+    static thread_local std::vector<int32_t> came_from;
+    best_at.assign((size_t)n, 0.0);
+    came_from.assign((size_t)n, -1);
     int32_t top = -1;
     double carried = -1, top_score = -1;
     for (uint16_t r = 0; r < n; ++r) {
