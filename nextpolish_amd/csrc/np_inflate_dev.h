@@ -29,6 +29,8 @@ constexpr int LIT_BITS = 10, DIST_BITS = 8;
 constexpr uint32_t GROUP_BYTES = 2048;   // a token group is closed when 64 tokens are collected or its output could exceed this
 constexpr uint32_t K_LITERAL = 0, K_LENGTH = 1, K_END = 2, K_LONG = 3;   // K_LONG: code longer than the primary index (or no code)
 
+struct SymIo { uint32_t rc, op, ntok, gbytes, widx, nb, bb_lo, bb_hi; };   // scalar state handed to / back from decode_symbols
+
 // LDS of one wave
 struct InflateLds {
     uint32_t lit[1 << LIT_BITS];     // bits 0..3 code length, 4..7 extra bits, 8..9 kind, 16..31 value (literal, base length)
@@ -40,6 +42,7 @@ struct InflateLds {
     uint8_t cl_len[320];             // code lengths while a dynamic header is read
     uint32_t cl_tab[128];            // code-length alphabet, 7-bit direct table
     uint32_t gbuf[(GROUP_BYTES + 8) / 4];   // output of the token group being resolved (same dword phase as its place in HBM)
+    SymIo io;
 };
 
 struct BlockDesc {          // one BGZF block (host-built table)
@@ -190,9 +193,8 @@ __device__ __forceinline__ bool build_tables(const Lens<NREG> lens_in, uint32_t*
 }
 
 // Canonical decode of a code longer than TBITS from the next 15 stream bits; returns the symbol and its length, or len = 0.
-template <int TBITS>
-__device__ __forceinline__ uint32_t decode_long(uint32_t bits15, const uint16_t* sorted, const uint16_t* first, const uint16_t* count,
-                                                const uint16_t* offs, uint32_t* len_out) {
+template <int TBITS, class P16>
+__device__ __forceinline__ uint32_t decode_long(uint32_t bits15, P16 sorted, P16 first, P16 count, P16 offs, uint32_t* len_out) {
     const uint32_t msb = __builtin_bitreverse32(bits15) >> 17;   // 15 bits, first stream bit on top
     for (uint32_t L = TBITS + 1; L <= 15; ++L) {
         const uint32_t c = msb >> (15u - L);
@@ -323,6 +325,126 @@ __device__ __noinline__ uint32_t flush_tokens(uint8_t* out_, uint32_t op_, uint3
 }
 
 // Inflates one block; all 64 lanes call it with the same arguments.  Returns 0 on success.
+
+// ---- the symbols of one deflate block, as a function of its own ------------------------------------------------------------
+// The block decoder below carries the bit reader, the table-building state and the header fields; inlined into it, the symbol loop
+// shared the 100 scalar registers with all of that and spilled its loop counters into vector lanes on every token (the loop is
+// bound by scalar issue: one SALU instruction per cycle and CU, whatever the number of waves).  As a real call the loop gets a
+// register file of its own: the arguments arrive in vector registers and go back to scalars once, the result goes back through a
+// few words of the wave's LDS.
+typedef __attribute__((address_space(3))) InflateLds lds_inflate;
+typedef __attribute__((address_space(3))) const uint16_t* lds_cu16;
+typedef __attribute__((address_space(1))) const uint32_t* glb_cu32;
+struct SymState {
+    glb_cu32 words;
+    lds_inflate* L;
+    uint32_t cur, nxt;        // lane l: word l of the current / the next 256-byte chunk
+    uint32_t chunk, wl;       // word index = chunk * 64 + wl
+    uint64_t bb;
+    uint32_t nb;
+    uint32_t tok, ntok, gbytes;
+    uint32_t lane;
+};
+// one token.  kFast: the current chunk still holds every word this token can need (at most three refills), so the reader only
+// indexes `cur`; otherwise a refill may step into the next chunk (rotate the windows, start the load after next).
+// returns 0 = token taken, 1 = end of block, else the error code
+template <bool kFast>
+__device__ __forceinline__ uint32_t sym_token(SymState& S) {
+    auto refill = [&]() {          // keeps >= 32 valid bits
+        if (S.nb <= 32) {
+            S.bb |= (uint64_t)rdlane(S.cur, S.wl) << S.nb;
+            S.nb += 32;
+            ++S.wl;
+            if (!kFast && S.wl == 64) {
+                S.wl = 0;
+                ++S.chunk;
+                S.cur = S.nxt;
+                S.nxt = S.words[(size_t)(S.chunk + 1) * 64 + S.lane];
+            }
+        }
+    };
+    refill();
+    uint32_t e = uni(S.L->lit[(uint32_t)S.bb & ((1u << LIT_BITS) - 1u)]);
+    uint32_t kind = (e >> 8) & 3u;
+    if (kind == K_LONG) {
+        uint32_t len;
+        const uint32_t sym = decode_long<LIT_BITS>((uint32_t)S.bb & 0x7fffu, (lds_cu16)S.L->lit_sorted, (lds_cu16)S.L->lit_first, (lds_cu16)S.L->lit_count, (lds_cu16)S.L->lit_offs, &len);
+        if (!len || sym > 285) return 13;
+        if (sym < 256) { e = sym << 16 | K_LITERAL << 8 | len; kind = K_LITERAL; }
+        else if (sym == 256) { e = K_END << 8 | len; kind = K_END; }
+        else { e = (uint32_t)kLenBase[sym - 257] << 16 | K_LENGTH << 8 | (uint32_t)kLenExtra[sym - 257] << 4 | len; kind = K_LENGTH; }
+    }
+    { const uint32_t n = e & 15u; S.bb >>= n; S.nb -= n; }
+    if (kind == K_LITERAL) {
+        if (S.lane == S.ntok) S.tok = e >> 16;
+        ++S.ntok;
+        ++S.gbytes;
+        return 0;
+    }
+    if (kind == K_END) return 1;
+    const uint32_t xl = (e >> 4) & 15u;
+    const uint32_t mlen = (e >> 16) + ((uint32_t)S.bb & ((1u << xl) - 1u));
+    S.bb >>= xl; S.nb -= xl;
+    refill();
+    uint32_t d = uni(S.L->dist[(uint32_t)S.bb & ((1u << DIST_BITS) - 1u)]);
+    if (((d >> 8) & 3u) == K_LONG) {
+        uint32_t len;
+        const uint32_t sym = decode_long<DIST_BITS>((uint32_t)S.bb & 0x7fffu, (lds_cu16)S.L->dist_sorted, (lds_cu16)S.L->dist_first, (lds_cu16)S.L->dist_count, (lds_cu16)S.L->dist_offs, &len);
+        if (!len || sym >= 30) return 14;
+        d = (uint32_t)kDistBase[sym] << 16 | K_LENGTH << 8 | (uint32_t)kDistExtra[sym] << 4 | len;
+    }
+    { const uint32_t n = d & 15u; S.bb >>= n; S.nb -= n; }
+    const uint32_t xb = (d >> 4) & 15u;
+    refill();
+    const uint32_t off = (d >> 16) + ((uint32_t)S.bb & ((1u << xb) - 1u));
+    S.bb >>= xb; S.nb -= xb;
+    if (S.lane == S.ntok) S.tok = 0x80000000u | mlen << 16 | (off - 1u);
+    ++S.ntok;
+    S.gbytes += mlen;
+    return 0;
+}
+
+__device__ __noinline__ uint32_t decode_symbols(const uint32_t* words_, uint32_t cur, uint32_t nxt, uint32_t tok, uint8_t* out_, uint32_t out_len_, uint32_t max_words_,
+                                                lds_inflate* L_, uint32_t* cur_out, uint32_t* nxt_out, Prof* pf = nullptr) {
+    lds_inflate* L = (lds_inflate*)(uintptr_t)uni((uint32_t)(uintptr_t)L_);
+    uint8_t* out = reinterpret_cast<uint8_t*>(uni64((uint64_t)(uintptr_t)out_));
+    const uint32_t out_len = uni(out_len_), max_words = uni(max_words_);
+    SymState S;
+    S.words = (glb_cu32)(uintptr_t)uni64((uint64_t)(uintptr_t)words_);
+    S.L = L;
+    S.cur = cur; S.nxt = nxt; S.tok = tok;
+    S.lane = lane_id();
+    const uint32_t widx0 = uni(L->io.widx);
+    S.chunk = widx0 >> 6; S.wl = widx0 & 63u;
+    S.nb = uni(L->io.nb);
+    S.bb = (uint64_t)uni(L->io.bb_lo) | (uint64_t)uni(L->io.bb_hi) << 32;
+    S.ntok = uni(L->io.ntok); S.gbytes = uni(L->io.gbytes);
+    uint32_t op = uni(L->io.op);
+    uint32_t rc = 0;
+    for (;;) {
+        uint32_t r;
+        if (S.wl <= 60) r = sym_token<true>(S);
+        else {
+            r = sym_token<false>(S);
+            if (S.chunk * 64u > max_words) r = r ? r : 16;     // ran off the payload (the input is padded: checked per chunk)
+        }
+        if (r) { rc = r == 1 ? 0 : r; break; }
+        if (S.ntok == 64 || S.gbytes + 258u > GROUP_BYTES) {
+            op = uni(flush_tokens(out, op, out_len, S.tok, S.ntok, (lds_u32*)L->gbuf, pf));
+            S.ntok = 0;
+            S.gbytes = 0;
+            if (op == ~0u) { rc = 15; break; }
+        }
+    }
+    if (S.lane == 0) {
+        L->io.rc = rc; L->io.op = op; L->io.ntok = S.ntok; L->io.gbytes = S.gbytes; L->io.widx = S.chunk * 64u + S.wl; L->io.nb = S.nb;
+        L->io.bb_lo = (uint32_t)S.bb; L->io.bb_hi = (uint32_t)(S.bb >> 32);
+    }
+    *cur_out = S.cur;
+    *nxt_out = S.nxt;
+    return S.tok;
+}
+
 __device__ __forceinline__ int inflate_block_wave(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t out_len, InflateLds& L, Prof* pf = nullptr) {
     const uint32_t lane = lane_id();
     BitReader br;
@@ -449,50 +571,26 @@ __device__ __forceinline__ int inflate_block_wave(const uint8_t* in, uint32_t in
         const unsigned long long t_sym = pf ? clk() : 0;
         if (pf) pf->t_tables += t_sym - t_hdr;
         const unsigned long long fl0 = pf ? pf->t_flush : 0;
-        // ---- symbols
-        for (;;) {
-            br.refill();
-            uint32_t e = uni(L.lit[br.peek(LIT_BITS)]);
-            uint32_t kind = (e >> 8) & 3u;
-            if (kind == K_LONG) {
-                uint32_t len;
-                const uint32_t sym = decode_long<LIT_BITS>(br.peek(15), L.lit_sorted, L.lit_first, L.lit_count, L.lit_offs, &len);
-                if (!len || sym > 285) return 13;
-                if (sym < 256) { e = sym << 16 | K_LITERAL << 8 | len; kind = K_LITERAL; }
-                else if (sym == 256) { e = K_END << 8 | len; kind = K_END; }
-                else { e = (uint32_t)kLenBase[sym - 257] << 16 | K_LENGTH << 8 | (uint32_t)kLenExtra[sym - 257] << 4 | len; kind = K_LENGTH; }
+        // ---- symbols (decode_symbols: a call, see there)
+        {
+            if (lane == 0) {
+                L.io.op = op; L.io.ntok = ntok; L.io.gbytes = gbytes; L.io.widx = br.widx; L.io.nb = br.nb;
+                L.io.bb_lo = (uint32_t)br.bb; L.io.bb_hi = (uint32_t)(br.bb >> 32);
             }
-            br.drop(e & 15u);
-            if (kind == K_LITERAL) {
-                if (lane == ntok) tok = e >> 16;
-                ++ntok;
-                ++gbytes;
-            } else if (kind == K_END) {
-                break;
-            } else {
-                const uint32_t mlen = (e >> 16) + br.take((e >> 4) & 15u);
-                br.refill();
-                uint32_t d = uni(L.dist[br.peek(DIST_BITS)]);
-                if (((d >> 8) & 3u) == K_LONG) {
-                    uint32_t len;
-                    const uint32_t sym = decode_long<DIST_BITS>(br.peek(15), L.dist_sorted, L.dist_first, L.dist_count, L.dist_offs, &len);
-                    if (!len || sym >= 30) return 14;
-                    d = (uint32_t)kDistBase[sym] << 16 | K_LENGTH << 8 | (uint32_t)kDistExtra[sym] << 4 | len;
-                }
-                br.drop(d & 15u);
-                const uint32_t xb = (d >> 4) & 15u;
-                br.refill();
-                const uint32_t off = (d >> 16) + br.take(xb);
-                if (lane == ntok) tok = 0x80000000u | mlen << 16 | (off - 1u);
-                ++ntok;
-                gbytes += mlen;
-            }
-            if (ntok == 64 || gbytes + 258u > GROUP_BYTES) {
-                op = uni(flush_tokens(out, op, out_len, tok, ntok, (lds_u32*)L.gbuf, pf));
-                ntok = 0;
-                gbytes = 0;
-                if (op == ~0u) return 15;
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t max_words = (in_len + mis + 3u) / 4u + 16u + (uint32_t)(reinterpret_cast<const uint32_t*>(in - mis) - br.words);
+            uint32_t ncur, nnxt;
+            tok = decode_symbols(br.words, br.cur, br.nxt, tok, out, out_len, max_words, (lds_inflate*)&L, &ncur, &nnxt, pf);
+            br.cur = ncur; br.nxt = nnxt;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t rc = uni(L.io.rc);
+            op = uni(L.io.op); ntok = uni(L.io.ntok); gbytes = uni(L.io.gbytes);
+            const uint32_t w1 = uni(L.io.widx), n1 = uni(L.io.nb);
+            br.consumed += (uint64_t)(w1 - br.widx) * 32u + br.nb - n1;
+            br.widx = w1; br.nb = n1;
+            br.bb = (uint64_t)uni(L.io.bb_lo) | (uint64_t)uni(L.io.bb_hi) << 32;
+            if (rc) return (int)rc;
             if (br.consumed > (uint64_t)in_len * 8u + 64u) return 16;   // ran off the payload
         }
         if (pf) pf->t_decode += (clk() - t_sym) - (pf->t_flush - fl0);
