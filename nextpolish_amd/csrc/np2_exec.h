@@ -96,6 +96,14 @@ struct LqAlignInput {
 };
 constexpr int LQ_ROUNDS = 30;   // LQSEQ_MAX_COUNT of the reference: concatenated alignments per consensus
 
+// pseudo-seeds of many low-quality regions at once (poa_to_consensus, dag.c:658-694): job j = strings [job_first[j], job_first[j] +
+// job_n[j]) of `chars` (every string followed by a NUL: the reference's graph can pick the terminator up)
+struct PoaBatch {
+    std::string chars;
+    std::vector<uint32_t> str_off, str_len;
+    std::vector<uint32_t> job_first, job_n;
+};
+
 // "the bases of stream `stream` at window positions [start, end]" (inclusive; gap tags dropped): one candidate string
 // of a low-quality region (generate_lqseqs_from_tags, ctg_cns.c:822-870)
 struct SubReq { uint32_t stream, start, end; };
@@ -115,6 +123,8 @@ class Exec {
     // candidate strings from the tag streams of the LAST run_window call (they stay with the executor until the next
     // run_window / run_lq): request i -> bases[off[i] .. off[i + 1]).  Requests come grouped by ascending stream.
     virtual bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) = 0;
+    // one consensus string per job of the batch
+    virtual bool run_poa(const PoaBatch& in, std::vector<std::string>* out, std::string* err) = 0;
 };
 
 // provided by whichever executor is linked (HIP in the product library)

@@ -30,6 +30,8 @@
 #include "../../include/nextpolish2.h"
 #include "np2_exec.h"
 #include "np2_ond_dev.h"
+#include "np2_poa_dev.h"
+#include "np2_lq.h"
 #include "np_threads.h"
 
 namespace np { void bgzf_device_inflate_enable(int device); }   // np_bgzf_dev.hip
@@ -1638,6 +1640,22 @@ __global__ void k2_bt_place(const BtWalk* walks, uint32_t n_runs, const BtGroupP
     for (uint32_t r = first; r < r1; ++r) { pick[r].off = off; off += pick[r].count; }
 }
 
+
+// ---- pseudo-seeds of the low-quality regions: one resident wave per job slot (np2_poa_dev.h) --------------------------------
+__global__ __launch_bounds__(64) void k2_poa(const char* __restrict__ pool, const uint32_t* __restrict__ str_off, const uint32_t* __restrict__ str_len,
+                                             const np2poa::Job* __restrict__ jobs, uint32_t n_jobs, int32_t* tabS, uint32_t* tabF, uint32_t tab_cap,
+                                             char* out_pool, uint32_t* out_len, uint32_t* status) {
+    __shared__ np2poa::PoaLds L;
+    int32_t* TS = tabS + (size_t)blockIdx.x * tab_cap;
+    uint32_t* TF = tabF + (size_t)blockIdx.x * tab_cap;
+    for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) {
+        const np2poa::Job J = jobs[j];
+        const bool ok = np2poa::poa_region(pool, str_off, str_len, J, TS, TF, tab_cap, out_pool, &out_len[j], &L);
+        if (threadIdx.x == 0) status[j] = ok ? 0u : 1u;
+        np2poa::lds_sync();
+    }
+}
+
 // ---- exclusive scan of uint32 counts (three launches: block sums, scan of the sums, final)
 constexpr uint32_t SCAN_T = 256, SCAN_PER = 16, SCAN_TILE = SCAN_T * SCAN_PER;
 __global__ __launch_bounds__(SCAN_T) void k2_scan_sums(const uint32_t* v, uint32_t n, uint32_t* sums) {
@@ -1861,6 +1879,7 @@ class HipExec : public Exec {
     bool run_lq(const LqInput& in, std::string* cons_rev, std::string* err) override;
     bool run_lq_aligned(const LqAlignInput& in, std::string* cons_rev, std::string* err) override;
     bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) override;
+    bool run_poa(const PoaBatch& in, std::vector<std::string>* out, std::string* err) override;
 
   private:
     bool lq_from_pool(const std::vector<uint32_t>& str_len, uint32_t t_len, uint32_t gap_min_len, bool hifi, std::string* cons_rev, std::string* err);
@@ -1886,6 +1905,7 @@ class HipExec : public Exec {
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
     DevBuf runsz_, runoff_, live_, ematch_, xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
     DevBuf tilecnt_, tileoff_, tilecur_, tilelist_, tilectr_, ntags_, colne_, runflag_, runlist_, runctr_, tileredo_;
+    DevBuf poapool_, poaoff_, poalen_, poajobs_, poatabs_, poatabf_, poaout_, poaolen_, poastat_;
     bool graph_compact_ = false;   // the graph in HBM was built by tiles: columns are contiguous, every entry slot is live
     DevBuf ondpool_, ondregs_, ondcoff_, ondclen_, ondpairof_, ondpairs_, ondres_, ondout_, ondv_, ondlo_, ondch_, ondplen_, ondpkind_, ondppos_, ondtot_;
     PinBuf pin_;
@@ -2584,6 +2604,77 @@ bool HipExec::lq_from_pool(const std::vector<uint32_t>& str_len, uint32_t t_len,
     if (cons_len) HIPOK(hipMemcpyAsync(&fwd[0], cons_.p, cons_len, hipMemcpyDeviceToHost, q));
     HIPOK(hipStreamSynchronize(q));
     cons_rev->assign(fwd.rbegin(), fwd.rend());   // the reference leaves this string in backtrace order
+    return true;
+}
+
+
+// The partial-order pseudo-seeds of a window's low-quality regions in one launch.  Jobs the kernel cannot hold (graph larger than
+// its LDS arrays, strings over 255 characters, score table over the slot's scratch) come back flagged and are done by the host
+// version (np2_poa.cpp): same result either way.
+bool HipExec::run_poa(const PoaBatch& in, std::vector<std::string>* out, std::string* err) {
+    HIPOK(hipSetDevice(device_));
+    hipStream_t q = stream_;
+    const uint32_t n_jobs = (uint32_t)in.job_first.size(), n_str = (uint32_t)in.str_off.size();
+    out->assign(n_jobs, std::string());
+    if (!n_jobs) return true;
+    static const bool host_only = getenv("NP2_POA_HOST") != nullptr;
+    std::vector<uint32_t> status(n_jobs, 1u), olen(n_jobs, 0u);
+    std::vector<np2poa::Job> jobs(n_jobs);
+    std::string obuf;
+    if (!host_only) {
+        uint64_t out_total = 0;
+        for (uint32_t j = 0; j < n_jobs; ++j) {
+            uint32_t cap = 0;
+            for (uint32_t k = 0; k < in.job_n[j]; ++k) cap += in.str_len[in.job_first[j] + k] + 1;
+            jobs[j] = np2poa::Job{in.job_first[j], in.job_n[j], out_total, cap, 0};
+            out_total += cap;
+        }
+        const uint32_t slots = std::min<uint32_t>(n_jobs, 1024u);
+        constexpr uint32_t TAB_CAP = 1u << 16;          // cells of score table per resident wave (rows x columns)
+        if (!poapool_.ensure(in.chars.size() + 64) || !poaoff_.ensure(4ull * n_str + 64) || !poalen_.ensure(4ull * n_str + 64) ||
+            !poajobs_.ensure(sizeof(np2poa::Job) * (size_t)n_jobs + 64) || !poatabs_.ensure(4ull * TAB_CAP * slots + 64) ||
+            !poatabf_.ensure(4ull * TAB_CAP * slots + 64) || !poaout_.ensure(out_total + 64) || !poaolen_.ensure(4ull * n_jobs + 64) ||
+            !poastat_.ensure(4ull * n_jobs + 64)) { *err = "out of device memory (pseudo-seeds)"; return false; }
+        HIPOK(hipMemcpyAsync(poapool_.p, in.chars.data(), in.chars.size(), hipMemcpyHostToDevice, q));
+        HIPOK(hipMemcpyAsync(poaoff_.p, in.str_off.data(), 4ull * n_str, hipMemcpyHostToDevice, q));
+        HIPOK(hipMemcpyAsync(poalen_.p, in.str_len.data(), 4ull * n_str, hipMemcpyHostToDevice, q));
+        HIPOK(hipMemcpyAsync(poajobs_.p, jobs.data(), sizeof(np2poa::Job) * (size_t)n_jobs, hipMemcpyHostToDevice, q));
+        k2_poa<<<slots, 64, 0, q>>>(poapool_.as<char>(), poaoff_.as<uint32_t>(), poalen_.as<uint32_t>(), poajobs_.as<np2poa::Job>(), n_jobs, poatabs_.as<int32_t>(),
+                                    poatabf_.as<uint32_t>(), TAB_CAP, poaout_.as<char>(), poaolen_.as<uint32_t>(), poastat_.as<uint32_t>());
+        obuf.resize(out_total);
+        HIPOK(hipMemcpyAsync(&obuf[0], poaout_.p, out_total, hipMemcpyDeviceToHost, q));
+        HIPOK(hipMemcpyAsync(olen.data(), poaolen_.p, 4ull * n_jobs, hipMemcpyDeviceToHost, q));
+        HIPOK(hipMemcpyAsync(status.data(), poastat_.p, 4ull * n_jobs, hipMemcpyDeviceToHost, q));
+        HIPOK(hipStreamSynchronize(q));
+    }
+    std::vector<uint32_t> todo;
+    static const bool check = getenv("NP2_POA_CHECK") != nullptr;     // test hook: every device result against the host version
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        if (status[j] == 0) (*out)[j].assign(obuf.data() + jobs[j].out_off, olen[j]);
+        else todo.push_back(j);
+        if (check && status[j] == 0) {
+            std::vector<std::string> v;
+            for (uint32_t k = 0; k < in.job_n[j]; ++k) v.emplace_back(in.chars.data() + in.str_off[in.job_first[j] + k], in.str_len[in.job_first[j] + k]);
+            const std::string want = poa_consensus(v);
+            if (want != (*out)[j]) {
+                *err = "pseudo-seed of the device differs from the host version (job " + std::to_string(j) + ": '" + (*out)[j] + "' vs '" + want + "')";
+                return false;
+            }
+        }
+    }
+    if (check) fprintf(stderr, "[np2 poa] checked %u device pseudo-seeds against the host version (%zu left to the host)\n", n_jobs - (uint32_t)todo.size(), todo.size());
+    if (!todo.empty()) {
+        if (getenv("NP2_TIMING")) fprintf(stderr, "[np2 poa] %zu of %u pseudo-seeds on the host\n", todo.size(), n_jobs);
+        np::parallel_for(todo.size(), 8, [&](size_t lo, size_t hi) {
+            std::vector<std::string> v;
+            for (size_t t = lo; t < hi; ++t) {
+                const uint32_t j = todo[t];
+                v.clear();
+                for (uint32_t k = 0; k < in.job_n[j]; ++k) v.emplace_back(in.chars.data() + in.str_off[in.job_first[j] + k], in.str_len[in.job_first[j] + k]);
+                (*out)[j] = poa_consensus(v);
+            }
+        });
+    }
     return true;
 }
 

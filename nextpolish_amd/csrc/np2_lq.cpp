@@ -37,6 +37,8 @@ struct Region {      // lqseq (ctg_cns.h:73-90)
     unsigned lqcount = 0, start = 0, end = 0, sudoseed_len = 0;
     std::string sudoseed;
     std::vector<Cand> seqs;
+    int poa_first = -1, poa_n = 0;      // the pseudo-seed is still to be made: partial-order consensus of seqs[poa_first .. + poa_n)
+    bool counts = false;                // the region takes part in the longest-alignment bound of the round
 };
 
 // ---- candidate ranking (what the reference does in ctg_cns.c:405-449,620-633,880-960, reformulated) -------------------------------
@@ -128,7 +130,7 @@ void remove_short(Region& r) {
 static std::atomic<long long> g_prof_rank{0}, g_prof_poa{0};
 static inline long long prof_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1000000000ll + ts.tv_nsec; }
 
-bool rank_and_seed(Region& r, bool trim, int min_span) {
+bool rank_and_seed(Region& r, bool trim, int min_span, bool defer_poa) {
     const long long t_begin = prof_now();
     Ranker k(r);
     if (trim) {
@@ -167,6 +169,12 @@ bool rank_and_seed(Region& r, bool trim, int min_span) {
     const int want = r.seqs[0].len < 3000 ? 6 : 2;
     const int n_poa = first + want < r.indexe ? want : r.indexe - first + 1;
     if (r.seqs[0].len < 20000) {
+        if (defer_poa) {          // all regions of the window go to the executor in one batch (collect_candidates)
+            r.poa_first = first;
+            r.poa_n = n_poa;
+            g_prof_rank += prof_now() - t_begin;
+            return true;
+        }
         std::vector<std::string> v;
         for (int q = 0; q < n_poa; ++q) v.push_back(r.seqs[(size_t)(first + q)].seq);
         const long long t_poa = prof_now();
@@ -187,6 +195,7 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
     for (Region& r : lq) {
         r.sudoseed.clear();
         r.lqcount = 0; r.len = 0; r.sudoseed_len = 0;
+        r.poa_first = -1; r.poa_n = 0; r.counts = false;
         r.seqs.clear();   // grown on acceptance (at most LQSEQ_MAX_CAN_COUNT)
     }
     // every (stream, region) pair with the region inside the stream's span, in the reference's visiting order (streams
@@ -251,10 +260,9 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
             ++r.len;
         }
     }
-    // ranking + pseudo-seed: the regions are independent of each other
-    std::atomic<int> max_aln{0};
+    // ranking: the regions are independent of each other; the partial-order pseudo-seeds are made afterwards, all at once, by the
+    // executor (one wave per region on the device, np2_poa_dev.h)
     np::parallel_for((size_t)count, 16, [&](size_t lo, size_t hi) {
-        int max_aln_length = 0;
         for (size_t i = lo; i < hi; ++i) {
             Region& r = lq[i];
             if (kmer) {
@@ -276,22 +284,55 @@ int collect_candidates(Exec* exec, std::vector<Region>& lq, const WindowOutput& 
                     r.sudoseed_len = top.len;
                     r.len = -2;
                     r.l = 4;
-                } else if (!rank_and_seed(r, r.len > 4, 1)) {
+                } else if (!rank_and_seed(r, r.len > 4, 1, true)) {
                     continue;
                 }
-                if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
+                r.counts = true;
                 continue;
             }
             if (r.l != 1 && r.l > 1 && r.len > 4) remove_short(r);
             if (r.len <= 4 || r.len < r.sudoseed_len * 0.5) { r.len = 0; continue; }
-            if (!rank_and_seed(r, true, 3)) continue;
-            if ((int)(r.lqcount + r.sudoseed_len) > max_aln_length) max_aln_length = (int)(r.lqcount + r.sudoseed_len);
+            if (!rank_and_seed(r, true, 3, true)) continue;
+            r.counts = true;
         }
-        int cur = max_aln.load();
-        while (max_aln_length > cur && !max_aln.compare_exchange_weak(cur, max_aln_length)) {}
     });
+    {
+        PoaBatch pb;
+        std::vector<int> owner;
+        for (int i = 0; i < count; ++i) {
+            Region& r = lq[(size_t)i];
+            if (r.poa_first < 0) continue;
+            owner.push_back(i);
+            pb.job_first.push_back((uint32_t)pb.str_off.size());
+            pb.job_n.push_back((uint32_t)r.poa_n);
+            for (int q = 0; q < r.poa_n; ++q) {
+                const std::string& sq = r.seqs[(size_t)(r.poa_first + q)].seq;
+                pb.str_off.push_back((uint32_t)pb.chars.size());
+                pb.str_len.push_back((uint32_t)sq.size());
+                pb.chars.append(sq);
+                pb.chars.push_back('\0');
+            }
+        }
+        if (!owner.empty()) {
+            const long long t_poa = prof_now();
+            std::vector<std::string> seeds;
+            if (!exec->run_poa(pb, &seeds, err)) return -1;
+            g_prof_poa += prof_now() - t_poa;
+            for (size_t k = 0; k < owner.size(); ++k) {
+                Region& r = lq[(size_t)owner[k]];
+                r.sudoseed.swap(seeds[k]);
+                r.sudoseed_len = (unsigned)r.sudoseed.size();
+                r.poa_first = -1;
+            }
+        }
+    }
+    std::atomic<int> max_aln{0};
+    for (int i = 0; i < count; ++i) {
+        const Region& r = lq[(size_t)i];
+        if (r.counts && (int)(r.lqcount + r.sudoseed_len) > max_aln.load()) max_aln = (int)(r.lqcount + r.sudoseed_len);
+    }
     const int max_aln_length = max_aln.load();
-    if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   rank + poa done (t=%.2f); inside rank_and_seed %.1f ms CPU, of which POA %.1f ms\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6, g_prof_rank.exchange(0) * 1e-6, g_prof_poa.exchange(0) * 1e-6); }
+    if (getenv("NP2_TIMING")) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[np2 lq]   rank + poa done (t=%.2f); ranking %.1f ms CPU, pseudo-seeds (executor) %.1f ms\n", ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6, g_prof_rank.exchange(0) * 1e-6, g_prof_poa.exchange(0) * 1e-6); }
     return max_aln_length;
 }
 

@@ -1,0 +1,364 @@
+// Pseudo-seed of a low-quality region on the device: partial-order alignment of a few candidate strings and the heaviest path
+// through the graph, ONE WAVE PER REGION (reference: source/lib/dag.c:261-405,469-508,555-595,658-694 poa_to_consensus; the
+// decisions that fix its output are listed at the top of np2_poa.cpp, whose host version this follows step by step).
+//
+// What is parallel and what is not:
+//   * a row of the string-against-graph score table depends on the rows of the node's predecessors and, inside the row, on the cell
+//     to its left.  The lanes are the columns: the best move out of the predecessor rows is independent per column, and "stay on the
+//     node and take a character" is a running maximum: with gap cost g, H(j) = max(H(j-1) + g, O(j)) <=> H(j) - g j = prefix-max of
+//     (O(k) - g k), and the offer O(j) is taken exactly where it raises that prefix maximum (ties stay on the node, as the
+//     reference's strict comparison does).  One wave scan per 64 columns;
+//   * the end node is the first sink with the best full-length score: a wave maximum + the lowest set bit of a ballot;
+//   * walking back, threading the string through the graph, re-ordering the graph (depth-first over aligned groups) and the
+//     heaviest path are pointer work with a strict visiting order: every lane runs them redundantly on wave-uniform state that
+//     lives in LDS (no divergence; reads come back through a scalar broadcast), a few thousand dependent LDS operations per string.
+// The score table (rows x columns, 8 bytes a cell) lives in a slice of HBM scratch owned by the resident wave.
+// A region whose graph does not fit the LDS arrays is flagged and done by the host version.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace np2poa {
+
+constexpr uint32_t MAXN = 384, MAXE = 768, MAXLEN = 255, MAXP = MAXN + MAXLEN + 1, MAXS = 1536, NONE16 = 0xffffu;
+constexpr int32_t W_MATCH = 1, W_MISMATCH = -2, W_GAP = -2;
+
+struct PoaLds {
+    uint8_t base[MAXN];
+    uint16_t in_head[MAXN], in_tail[MAXN], out_head[MAXN], out_tail[MAXN];   // edge lists in attachment order (linked through the edges)
+    uint16_t col_of[MAXN], col_next[MAXN];          // aligned group ("column") of a node, next member in joining order
+    uint16_t col_head[MAXN], col_tail[MAXN];        // per group: first (= lowest-numbered) and last member
+    uint16_t order[MAXN], rank[MAXN];
+    uint16_t e_src[MAXE], e_dst[MAXE], e_nin[MAXE], e_nout[MAXE];
+    unsigned long long e_sup[MAXE];                 // bit q: string q runs along this edge
+    int16_t path_node[MAXP], path_chr[MAXP];        // the alignment columns in walk-back order
+    uint16_t stack[MAXS];
+    uint8_t finished[MAXN], open[MAXN];
+    double best_at[MAXN];
+    int16_t came_from[MAXN];
+};
+
+struct Job { uint32_t first_str, n_str; unsigned long long out_off; uint32_t out_cap, pad; };
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void glb_sync() {      // the wave's own table rows: written by some lanes, read by others later
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct Graph {          // wave-uniform counters; the arrays are in LDS
+    PoaLds* L;
+    uint32_t n, ne, ncols;
+    bool fail;
+    __device__ __forceinline__ uint32_t new_node(uint32_t b, uint32_t col) {      // col == NONE16: a group of its own
+        if (n >= MAXN) { fail = true; return 0; }
+        const uint32_t v = n++;
+        L->base[v] = (uint8_t)b;
+        L->in_head[v] = L->in_tail[v] = L->out_head[v] = L->out_tail[v] = (uint16_t)NONE16;
+        L->col_next[v] = (uint16_t)NONE16;
+        if (col == NONE16) {
+            col = ncols++;
+            L->col_head[col] = L->col_tail[col] = (uint16_t)v;
+        } else {
+            const uint32_t t = uni(L->col_tail[col]);
+            L->col_next[t] = (uint16_t)v;
+            L->col_tail[col] = (uint16_t)v;
+        }
+        L->col_of[v] = (uint16_t)col;
+        lds_sync();
+        return v;
+    }
+    __device__ __forceinline__ void connect(uint32_t a, uint32_t b, uint32_t q) {
+        if (ne >= MAXE) { fail = true; return; }
+        const uint32_t e = ne++;
+        L->e_src[e] = (uint16_t)a; L->e_dst[e] = (uint16_t)b; L->e_sup[e] = 1ull << q;
+        L->e_nin[e] = L->e_nout[e] = (uint16_t)NONE16;
+        const uint32_t ot = uni(L->out_tail[a]);
+        if (ot == NONE16) L->out_head[a] = (uint16_t)e; else L->e_nout[ot] = (uint16_t)e;
+        L->out_tail[a] = (uint16_t)e;
+        lds_sync();          // a == b cannot happen, but in-list and out-list updates may touch the same edge record
+        const uint32_t it = uni(L->in_tail[b]);
+        if (it == NONE16) L->in_head[b] = (uint16_t)e; else L->e_nin[it] = (uint16_t)e;
+        L->in_tail[b] = (uint16_t)e;
+        lds_sync();
+    }
+    // a run of fresh nodes for characters that align with nothing
+    __device__ __forceinline__ void chain(uint32_t q, const char* s, uint32_t cnt, int32_t* first, int32_t* last) {
+        for (uint32_t i = 0; i < cnt && !fail; ++i) {
+            const uint32_t v = new_node((uint8_t)s[i], NONE16);
+            if (*first == -1) *first = (int32_t)v;
+            else connect((uint32_t)*last, v, q);
+            *last = (int32_t)v;
+        }
+    }
+    __device__ __forceinline__ bool blocked(uint32_t head) const {      // does anything still have to come before this group?
+        if (uni(L->in_head[head]) != NONE16) return true;
+        for (uint32_t p = uni(L->col_next[head]); p != NONE16; p = uni(L->col_next[p]))
+            if (uni(L->in_head[p]) != NONE16) return true;
+        return false;
+    }
+    // emission order (np2_poa.cpp PoGraph::reorder): groups are the units; sources in ascending group number; from each a
+    // depth-first walk (successor edges pushed in attachment order, the first member's before the others') emits a group when it
+    // is finished, filling the order from the back
+    __device__ void reorder() {
+        const uint32_t lane = __lane_id();
+        for (uint32_t g = lane; g < ncols; g += 64) { L->finished[g] = 0; L->open[g] = 0; }
+        lds_sync();
+        int32_t slot = (int32_t)n - 1;
+        while (slot >= 0 && !fail) {
+            int32_t start = -1;
+            for (uint32_t g = 0; g < ncols; ++g)
+                if (!uni(L->finished[g]) && !blocked(uni(L->col_head[g]))) { start = (int32_t)g; break; }
+            if (start < 0) { fail = true; break; }
+            for (uint32_t g = lane; g < ncols; g += 64) L->open[g] = 0;
+            lds_sync();
+            uint32_t sp = 0;
+            L->stack[sp++] = (uint16_t)start;
+            lds_sync();
+            while (sp) {
+                const uint32_t g = uni(L->stack[--sp]);
+                if (uni(L->finished[g])) continue;
+                const uint32_t v = uni(L->col_head[g]);
+                if (uni(L->open[g])) {          // second visit: everything below is out, emit the group
+                    L->finished[g] = 1;
+                    L->open[g] = 0;
+                    for (uint32_t p = v; p != NONE16; p = uni(L->col_next[p])) {
+                        if (slot < 0) { fail = true; break; }
+                        L->order[slot--] = (uint16_t)p;
+                    }
+                    lds_sync();
+                    continue;
+                }
+                L->open[g] = 1;
+                if (sp >= MAXS) { fail = true; break; }
+                L->stack[sp++] = (uint16_t)g;
+                for (uint32_t p = v; p != NONE16 && !fail; p = uni(L->col_next[p]))
+                    for (uint32_t e = uni(L->out_head[p]); e != NONE16; e = uni(L->e_nout[e])) {
+                        if (sp >= MAXS) { fail = true; break; }
+                        L->stack[sp++] = L->col_of[uni(L->e_dst[e])];
+                    }
+                lds_sync();
+            }
+        }
+        for (uint32_t i = lane; i < n; i += 64) L->rank[L->order[i]] = (uint16_t)i;
+        lds_sync();
+    }
+};
+
+// one string against the graph, then through it (np2_poa.cpp add_string)
+__device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, int32_t* TS, uint32_t* TF, uint32_t tab_cap) {
+    PoaLds* L = G.L;
+    const uint32_t lane = __lane_id();
+    const uint32_t n = G.n, width = len + 1;
+    if ((unsigned long long)(n + 1) * width > tab_cap) { G.fail = true; return; }
+    for (uint32_t c = lane; c < width; c += 64) { TS[c] = (int32_t)c * W_GAP; TF[c] = 0; }
+    glb_sync();
+    // rows in emission order
+    for (uint32_t r = 0; r < n; ++r) {
+        const uint32_t v = uni(L->order[r]);
+        const char vb = (char)uni(L->base[v]);
+        const uint32_t row = r + 1;
+        int32_t* RS = TS + (size_t)row * width;
+        uint32_t* RF = TF + (size_t)row * width;
+        // left border: the best predecessor's border value plus a gap (sources start from 0)
+        const uint32_t e0 = uni(L->in_head[v]);
+        int32_t border = 0;
+        {
+            bool any = false;
+            for (uint32_t e = e0; e != NONE16; e = uni(L->e_nin[e])) {
+                const uint32_t pr = uni(L->rank[uni(L->e_src[e])]) + 1u;
+                const int32_t x = (int32_t)uni((uint32_t)TS[(size_t)pr * width]);
+                if (!any || x > border) { border = x; any = true; }
+            }
+            border += W_GAP;
+        }
+        if (lane == 0) { RS[0] = border; RF[0] = 0; }
+        int32_t run = border;                     // max over k < j of (H(k) + 2 k) = of A(k); A(0) = H(0)
+        for (uint32_t cb = 0; cb < len; cb += 64) {
+            const uint32_t c = cb + lane;         // string position; the cell is column j = c + 1
+            const bool valid = c < len;
+            int32_t O = INT32_MIN;
+            uint32_t F = 0;
+            if (valid) {
+                const int32_t w = s[c] == vb ? W_MATCH : W_MISMATCH;
+                bool first = true;
+                auto offer = [&](uint32_t pr) {
+                    const int32_t* P = TS + (size_t)pr * width;
+                    const int32_t skip = P[c + 1] + W_GAP, pair = P[c] + w;
+                    const bool sk = skip >= pair;
+                    const int32_t cand = sk ? skip : pair;
+                    if (first || cand > O) { O = cand; F = pr << 16 | (c + (sk ? 1u : 0u)); }
+                    first = false;
+                };
+                if (e0 == NONE16) offer(0);
+                for (uint32_t e = e0; e != NONE16; e = uni(L->e_nin[e])) offer(uni(L->rank[uni(L->e_src[e])]) + 1u);
+            }
+            const int32_t j = (int32_t)c + 1;
+            const int32_t A = valid ? O - W_GAP * j : INT32_MIN;
+            int32_t inc = A;                      // inclusive prefix maximum over the lanes
+            for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d && y > inc) inc = y; }
+            int32_t exc = __shfl_up(inc, 1, 64);
+            if (lane == 0 || exc < run) exc = run;
+            if (valid) {
+                const bool take = A > exc;
+                const int32_t M = take ? A : exc;
+                RS[j] = M + W_GAP * j;
+                RF[j] = take ? F : (row << 16 | (uint32_t)(j - 1));
+            }
+            const int32_t last = __shfl(inc, 63, 64);      // invalid lanes carry INT32_MIN: the maximum of the valid ones
+            if (last > run) run = last;
+        }
+        glb_sync();
+    }
+    // the alignment ends in a sink: the first one in order with the best full-length score
+    uint32_t row = 0;
+    {
+        int32_t best = 0;
+        bool any = false;
+        for (uint32_t rb = 0; rb < n; rb += 64) {
+            const uint32_t r = rb + lane;
+            const bool cand = r < n && L->out_head[L->order[r]] == NONE16;
+            const int32_t x = cand ? TS[(size_t)(r + 1) * width + len] : INT32_MIN;
+            int32_t m = x;
+            for (int o = 32; o > 0; o >>= 1) { const int32_t y = __shfl_xor(m, o, 64); m = y > m ? y : m; }
+            const unsigned long long hit = __ballot(cand && x == m);
+            if (hit && (!any || m > best)) { best = m; any = true; row = rb + (uint32_t)__ffsll((long long)hit); }   // = r + 1 of the first lane
+        }
+    }
+    // walk back to the origin; every move contributes a column (node, character, or both)
+    uint32_t np = 0;
+    int32_t lowest_chr = -1, highest_chr = -1;
+    for (uint32_t col = len; row != 0 || col != 0;) {
+        const uint32_t from = uni(TF[(size_t)row * width + col]);
+        const uint32_t from_row = from >> 16, from_col = from & 0xffffu;
+        int32_t node = -1, chr = -1;
+        if (from_row != row) node = (int32_t)uni(L->order[row - 1]);
+        if (from_col != col) {
+            chr = (int32_t)col - 1;
+            lowest_chr = chr;
+            if (highest_chr == -1) highest_chr = chr;
+        }
+        if (np >= MAXP) { G.fail = true; return; }
+        L->path_node[np] = (int16_t)node;
+        L->path_chr[np] = (int16_t)chr;
+        ++np;
+        row = from_row;
+        col = from_col;
+    }
+    lds_sync();
+    // ---- thread the string through the graph
+    int32_t first = -1, prev = -1, tail_first = -1, cur = -1;
+    bool cur_is_new = true, prev_is_new = true;
+    if (lowest_chr > 0) G.chain(q, s, (uint32_t)lowest_chr, &first, &prev);                      // characters before the first aligned one
+    if (highest_chr < (int32_t)len - 1)                                                         // and behind the last one (the run takes the
+        G.chain(q, s + highest_chr + 1, (uint32_t)((int32_t)len - highest_chr), &tail_first, &cur);   // terminator along, like the reference)
+    for (uint32_t k = np; k-- > 0 && !G.fail;) {
+        const int32_t chr = (int16_t)uni((uint32_t)(uint16_t)L->path_chr[k]);
+        if (chr == -1) continue;
+        const int32_t node = (int16_t)uni((uint32_t)(uint16_t)L->path_node[k]);
+        cur_is_new = false;
+        const uint8_t b = (uint8_t)s[chr];
+        if (node == -1) { cur = (int32_t)G.new_node(b, NONE16); cur_is_new = true; }
+        else if ((uint8_t)uni(L->base[node]) == b) cur = node;
+        else {
+            const uint32_t col = uni(L->col_of[node]);
+            int32_t same = -1;
+            for (uint32_t p = uni(L->col_head[col]); p != NONE16; p = uni(L->col_next[p]))
+                if ((int32_t)p != node && (uint8_t)uni(L->base[p]) == b) same = (int32_t)p;
+            if (same != -1) cur = same;
+            else { cur = (int32_t)G.new_node(b, col); cur_is_new = true; }                      // a new member of the column
+        }
+        if (prev != -1) {
+            bool joined = false;
+            if (!cur_is_new && !prev_is_new)
+                for (uint32_t e = uni(L->out_head[prev]); e != NONE16; e = uni(L->e_nout[e]))
+                    if (uni(L->e_dst[e]) == (uint32_t)cur) { L->e_sup[e] |= 1ull << q; joined = true; }
+            if (joined) lds_sync();
+            else G.connect((uint32_t)prev, (uint32_t)cur, q);
+        }
+        prev = cur;
+        prev_is_new = cur_is_new;
+        if (first == -1) first = prev;
+    }
+    if (tail_first != -1 && !G.fail) G.connect((uint32_t)prev, (uint32_t)tail_first, q);
+    if (!G.fail) G.reorder();
+}
+
+// the whole job: strings of one region -> consensus characters; returns false when the region has to go to the host version
+__device__ bool poa_region(const char* pool, const uint32_t* __restrict__ str_off, const uint32_t* __restrict__ str_len, const Job& J, int32_t* TS, uint32_t* TF,
+                           uint32_t tab_cap, char* out_pool, uint32_t* out_len, PoaLds* L) {
+    const uint32_t lane = __lane_id();
+    Graph G{L, 0u, 0u, 0u, false};
+    // the first string is the graph: a chain, every node a group of its own, emission order = string order
+    const uint32_t len0 = str_len[J.first_str];
+    const char* s0 = pool + str_off[J.first_str];
+    if (len0 == 0 || len0 > MAXLEN || len0 > MAXN) return false;
+    for (uint32_t i = lane; i < len0; i += 64) {
+        L->base[i] = (uint8_t)s0[i];
+        L->in_head[i] = L->in_tail[i] = (uint16_t)(i > 0 ? i - 1 : NONE16);
+        L->out_head[i] = L->out_tail[i] = (uint16_t)(i + 1 < len0 ? i : NONE16);
+        L->col_of[i] = (uint16_t)i; L->col_next[i] = (uint16_t)NONE16;
+        L->col_head[i] = L->col_tail[i] = (uint16_t)i;
+        L->order[i] = L->rank[i] = (uint16_t)i;
+        if (i + 1 < len0) { L->e_src[i] = (uint16_t)i; L->e_dst[i] = (uint16_t)(i + 1); L->e_nin[i] = L->e_nout[i] = (uint16_t)NONE16; L->e_sup[i] = 1ull; }
+    }
+    G.n = len0; G.ne = len0 - 1; G.ncols = len0;
+    lds_sync();
+    for (uint32_t q = 1; q < J.n_str && !G.fail; ++q) {
+        const uint32_t len = str_len[J.first_str + q];
+        if (len == 0 || len > MAXLEN) return false;
+        add_string(G, q, pool + str_off[J.first_str + q], len, TS, TF, tab_cap);
+    }
+    if (G.fail) return false;
+    // heaviest path: weight of entering a node over an edge = strings on the edge - half the node's indegree (as uint8); the
+    // running best is carried from node to node in emission order, the overall best is the first strict maximum
+    int32_t top = -1;
+    double carried = -1, top_score = -1;
+    for (uint32_t r = 0; r < G.n; ++r) {
+        const uint32_t v = uni(L->order[r]);
+        int32_t from = -1;
+        const uint32_t e0 = uni(L->in_head[v]);
+        if (e0 != NONE16) {
+            uint32_t indeg = 0;
+            for (uint32_t e = e0; e != NONE16; e = uni(L->e_nin[e])) ++indeg;
+            const double toll = 0.5 * (double)(uint8_t)indeg;
+            for (uint32_t e = e0; e != NONE16; e = uni(L->e_nin[e])) {
+                const uint32_t src = uni(L->e_src[e]);
+                const unsigned long long sup = L->e_sup[e];
+                const double x = L->best_at[src] + (double)__popcll(sup) - toll;
+                if (x > carried || from == -1) { carried = x; from = (int32_t)src; }
+            }
+        } else {
+            carried = 0;
+        }
+        L->best_at[v] = carried;
+        L->came_from[v] = (int16_t)from;
+        lds_sync();
+        if (carried > top_score) { top_score = carried; top = (int32_t)v; }
+    }
+    // characters from the end of the path backwards, then turned over; an embedded terminator (a tail node built from the NUL of
+    // a candidate) ends the string
+    uint32_t m = 0;
+    for (int32_t v = top; v != -1; v = (int16_t)uni((uint32_t)(uint16_t)L->came_from[v])) ++m;
+    if (m > J.out_cap) return false;
+    char* out = out_pool + J.out_off;
+    uint32_t k = m;
+    for (int32_t v = top; v != -1; v = (int16_t)uni((uint32_t)(uint16_t)L->came_from[v])) {
+        --k;
+        if (lane == 0) out[k] = (char)L->base[v];
+    }
+    glb_sync();
+    uint32_t z = m;
+    for (uint32_t cb = 0; cb < m; cb += 64) {
+        const unsigned long long nul = __ballot(cb + lane < m && out[cb + lane] == 0);
+        if (nul) { z = cb + (uint32_t)__ffsll((long long)nul) - 1u; break; }
+    }
+    if (lane == 0) *out_len = z;
+    return true;
+}
+
+}  // namespace np2poa

@@ -6,6 +6,7 @@
 
 #include "../../nextpolish_amd/csrc/np2_exec.h"
 #include "np2_lq_host.h"
+#include "../../nextpolish_amd/csrc/np2_lq.h"
 
 namespace np2 {
 namespace {
@@ -207,6 +208,17 @@ class HostExec : public Exec {
     }
 
     // plain walk of the stream (the reference's order: every tag from the stream start up to the last region)
+    bool run_poa(const PoaBatch& in, std::vector<std::string>* out, std::string* err) override {
+        (void)err;
+        out->assign(in.job_first.size(), std::string());
+        std::vector<std::string> v;
+        for (size_t j = 0; j < in.job_first.size(); ++j) {
+            v.clear();
+            for (uint32_t k = 0; k < in.job_n[j]; ++k) v.emplace_back(in.chars.data() + in.str_off[in.job_first[j] + k], in.str_len[in.job_first[j] + k]);
+            (*out)[j] = poa_consensus(v);
+        }
+        return true;
+    }
     bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) override {
         off->assign(req.size() + 1, 0);
         bases->clear();
