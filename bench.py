@@ -356,7 +356,7 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-e2e", action="store_true", help="skip the from-files leg")
     ap.add_argument("--no-lgs", action="store_true", help="skip the long-read (nextpolish2) leg")
-    ap.add_argument("--lgs-workers", type=int, default=8, help="worker processes per GPU of the long-read leg")
+    ap.add_argument("--lgs-workers", type=int, default=12, help="worker processes per GPU of the long-read leg")
     ap.add_argument("--lgs-mb", type=float, default=5.0, help="contig length (Mb) each long-read worker polishes")
     ap.add_argument("--lgs-calls", type=int, default=4)
     args = ap.parse_args()

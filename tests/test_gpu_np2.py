@@ -197,3 +197,20 @@ def test_gpu_tiles_with_more_streams_than_the_lds_list_holds(tmp_path):
         want, err2 = run_polish(os.path.realpath(rb.REF_SO), fa, fofn, 1)
         assert want is not None, err2
         assert got == want
+
+
+@pytest.mark.parametrize("cid", ["ont_lq_regions", "clr_lq_regions", "hifi_35x_indels", "ont_long_insertions"])
+def test_gpu_device_pseudo_seeds_equal_the_host_version(cid, tmp_path):
+    """The partial-order pseudo-seed of every low-quality region comes from the device (k2_poa, one wave per region); NP2_POA_CHECK=1
+    makes the executor compare each of them with the host version (np2_poa.cpp, pinned to the reference's poa_to_consensus by the
+    known-answer tests) and fail on the first difference; NP2_POA_HOST=1 sends all of them to the host version.  Both runs must give
+    the goldens."""
+    kw, rt = next((k, r) for c, k, r in np2_cases.CASES if c == cid)
+    fa, fofn, contigs = np2_cases.materialise(kw, str(tmp_path))
+    for env in ({"NP2_POA_CHECK": "1", "NP2_TIMING": "1"}, {"NP2_POA_HOST": "1"}):
+        got, err = run_polish(PRODUCT_SO, fa, fofn, rt, env=env)
+        assert got is not None, err
+        if "NP2_POA_CHECK" in env:
+            assert "device pseudo-seeds against the host version" in err
+        for n, _ in contigs:
+            assert got[n][0][0] == GOLD["cases"][cid]["expected"][n], "%s %s %r" % (cid, n, env)
