@@ -1,15 +1,16 @@
 // Pseudo-seed of a low-quality region: partial-order alignment of a few candidate strings and the heaviest path through the
-// resulting graph.  Host code: a graph of a few hundred nodes that is re-threaded and re-ordered after every string --
-// pointer work with a strict visiting order, not data-parallel work (the pairwise alignment of every candidate onto the seed
-// runs on the device: np2_ond_dev.h).
+// resulting graph -- the HOST version.  The product makes the pseudo-seeds on the device (np2_poa_dev.h: one wave per region, the
+// same procedure with the score-table rows spread over the lanes); this file is what the device hands a region to when its graph
+// does not fit the kernel's LDS arrays, what NP2_POA_CHECK=1 compares every device result with, and what the tests' host executor
+// runs.  It is pinned to the reference's poa_to_consensus by 60 known answers and a fuzz against oracle/_ref.
 //
 // The result has to equal the reference's poa_to_consensus (source/lib/dag.c:658-694) character for character, and that is
 // decided by details of its procedure: which of equal-scoring alignment moves wins (dag.c:261-300), which sink the alignment
 // ends in (:302-314), when a node is reused / joins an aligned group / is created (:345-405), the depth-first order in which
 // groups are emitted (:469-508; it decides ties of the two scans that walk "the first best in order"), 16-bit node ids, and
 // the path weight `support - 0.5 * indegree` in double (:555-595).  Those decisions are kept; the data layout is this file's
-// own: structure-of-arrays graph, edge support as one 64-bit mask (<= 50 strings), aligned groups as explicit id lists, one
-// flat score table with packed back-references.
+// own: structure-of-arrays graph, edge support as one 64-bit mask (<= 50 strings), aligned groups as explicit id lists, a score
+// table in two planes (scores, packed back-references) whose per-predecessor part is plain array arithmetic.
 #include <algorithm>
 #include <cassert>
 #include <cstdint>
