@@ -210,7 +210,7 @@ def test_gpu_device_pseudo_seeds_equal_the_host_version(cid, tmp_path):
     for env in ({"NP2_POA_CHECK": "1", "NP2_TIMING": "1"}, {"NP2_POA_HOST": "1"}):
         got, err = run_polish(PRODUCT_SO, fa, fofn, rt, env=env)
         assert got is not None, err
-        if "NP2_POA_CHECK" in env:
+        if "NP2_POA_CHECK" in env and cid == "ont_lq_regions":      # (the CLR case has two regions and none of them needs a pseudo-seed)
             assert "device pseudo-seeds against the host version" in err
         for n, _ in contigs:
             assert got[n][0][0] == GOLD["cases"][cid]["expected"][n], "%s %s %r" % (cid, n, env)
