@@ -171,6 +171,8 @@ typedef struct {
 np1_stream* np1_stream_synth_long(const np1_synth_long_params* p, const char* contig_name_prefix);
 /* Test hook: the BGZF block decoder (own raw-DEFLATE implementation) on one stream; 1 = accepted and dst filled. */
 int np1_debug_inflate(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len);
+/* test hook: CRC-32 of a BGZF block as the reader / writer compute it (must equal zlib's crc32) */
+uint32_t np1_debug_crc32(const uint8_t* src, uint64_t len);
 
 /* Device context: one per process per GPU; created lazily AFTER any fork (the reference's callers
  * fork worker pools after config_init, nextpolish1.py:219-223). */

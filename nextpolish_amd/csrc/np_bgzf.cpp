@@ -1,5 +1,6 @@
 // BGZF reader/writer (SAMv1 §4.1).  See np_bgzf.h for the reference call sites this replaces.
 #include "np_bgzf.h"
+#include "np_crc32.h"
 #include "np_inflate.h"
 
 #include <zlib.h>
@@ -133,7 +134,7 @@ bool BgzfReader::fill_window(uint64_t coff) {
             if (b.isize && check_crc) {   // gzip trailer: CRC32 of the inflated bytes (htslib rejects a block whose CRC does not match)
                 uint32_t want;
                 memcpy(&want, cwin_.data() + b.cpos + clen, 4);
-                if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), uwin_.data() + b.upos, b.isize) != want) ok = false;
+                if (crc32_block(uwin_.data() + b.upos, b.isize) != want) ok = false;
             }
         }
     };
@@ -267,7 +268,7 @@ static bool deflate_block(const uint8_t* in, uint32_t n, int level, std::vector<
     memcpy(out->data(), magic, 16);
     (*out)[16] = (uint8_t)((total - 1) & 0xff);
     (*out)[17] = (uint8_t)((total - 1) >> 8);
-    uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, n);
+    uint32_t crc = crc32_block(in, n);
     memcpy(out->data() + 18 + clen, &crc, 4);
     memcpy(out->data() + 18 + clen + 4, &n, 4);
     out->resize(total);

@@ -8,6 +8,7 @@
 #include "np1_priv.h"
 #include "np_synth.h"
 #include "np_inflate.h"
+#include "np_crc32.h"
 
 
 static thread_local std::string g_err;
@@ -144,5 +145,7 @@ np1_stream* np1_stream_synth_long(const np1_synth_long_params* p, const char* pr
 int np1_debug_inflate(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) {
     return np::inflate_raw(src, (size_t)src_len, dst, (size_t)dst_len) ? 1 : 0;
 }
+/* test hook: the CRC-32 the BGZF reader / writer compute per block (np_crc32.h: carry-less-multiply folding) */
+uint32_t np1_debug_crc32(const uint8_t* src, uint64_t len) { return np::crc32_block(src, (size_t)len); }
 
 }  // extern "C"

@@ -87,3 +87,22 @@ def test_damaged_or_mismatched_streams_are_never_wrong():
             except zlib.error:
                 want = None
             assert want is not None and got == want[:len(data)] and len(want) == len(data)
+
+
+def test_block_crc32_equals_zlib():
+    """The reader checks the gzip CRC of every block like htslib does; the CRC comes from carry-less-multiply folding
+    (nextpolish_amd/csrc/np_crc32.h) where the CPU has PCLMULQDQ, zlib's table code otherwise and for the tail bytes."""
+    import ctypes as C
+    import os
+    import random
+    from nextpolish_amd import _native as nat
+    L = nat.lib()
+    L.np1_debug_crc32.argtypes = [C.c_char_p, C.c_uint64]
+    L.np1_debug_crc32.restype = C.c_uint32
+    rng = random.Random(7)
+    blob = os.urandom(1 << 17)
+    for n in list(range(0, 260)) + [rng.randrange(260, 1 << 17) for _ in range(300)] + [65280, 65536, (1 << 17) - 1]:
+        off = rng.randrange(0, 7)
+        n = min(n, len(blob) - off)
+        piece = blob[off:off + n]
+        assert L.np1_debug_crc32(piece, n) == (zlib.crc32(piece) & 0xffffffff), n
