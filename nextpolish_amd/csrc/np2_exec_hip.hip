@@ -2629,7 +2629,7 @@ bool HipExec::run_poa(const PoaBatch& in, std::vector<std::string>* out, std::st
             jobs[j] = np2poa::Job{in.job_first[j], in.job_n[j], out_total, cap, 0};
             out_total += cap;
         }
-        const uint32_t slots = std::min<uint32_t>(n_jobs, 1024u);
+        const uint32_t slots = std::min<uint32_t>(n_jobs, 1792u);        // resident waves (7 per CU by their LDS), each with its slice of table scratch
         constexpr uint32_t TAB_CAP = 1u << 16;          // cells of score table per resident wave (rows x columns)
         if (!poapool_.ensure(in.chars.size() + 64) || !poaoff_.ensure(4ull * n_str + 64) || !poalen_.ensure(4ull * n_str + 64) ||
             !poajobs_.ensure(sizeof(np2poa::Job) * (size_t)n_jobs + 64) || !poatabs_.ensure(4ull * TAB_CAP * slots + 64) ||

@@ -20,7 +20,7 @@
 
 namespace np2poa {
 
-constexpr uint32_t MAXN = 384, MAXE = 768, MAXLEN = 255, MAXP = MAXN + MAXLEN + 1, MAXS = 1536, NONE16 = 0xffffu;
+constexpr uint32_t MAXN = 256, MAXE = 512, MAXLEN = 255, MAXP = MAXN + MAXLEN + 1, MAXS = 1024, NONE16 = 0xffffu;   // 21 KB of LDS: 7 regions per CU
 constexpr int32_t W_MATCH = 1, W_MISMATCH = -2, W_GAP = -2;
 
 struct PoaLds {
