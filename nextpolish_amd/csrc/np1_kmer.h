@@ -55,6 +55,10 @@ struct KcCtx {
     double rate;
     int32_t max_span;            // longest reference span of any record (lower bound for overlap scans)
     int32_t keep_zero_marks;     // snp_valid: a covering read leaves the FLAG_ZERO marks alone (ss_parse_read_kmer with flagzero = 1)
+    // snp_phase (np1_phase.h): the region chain ends in ts_region_correct instead of contig_region_correct
+    int32_t third_rule;
+    double max_indel_factor_lgs, max_snp_factor_lgs;
+    const uint32_t* sown;        // per slot: global index of the base it belongs to
     uint32_t* err;
 };
 
@@ -516,6 +520,37 @@ NP1_HD bool kc_region_solve(const KcCtx& c, uint32_t g0, int32_t start, int32_t 
         if (b < 0) { np1_atomic_or(c.err, ERR_KC_INCONSISTENT); return false; }
         KcStates cur{c.st_score + 16ull * (sb + k + 1), c.st_kmer + 16ull * (sb + k + 1), c.st_rank + 16ull * (sb + k + 1), fp};
         const uint32_t kk = cur.km[b];
+        if (c.third_rule) {   // ts_region_correct (snpphase.c:843-871): long-read evidence marks, the base only where the rule lets it
+            const bool col0 = s == c.soff[c.sown[s]];
+            if ((c.sflag[s] & KC_FLAG_ZERO) || (col0 && b != 3)) c.sbase[s] = (uint8_t)b;
+            uint32_t mc[16], order[16], nm = 0;   // base_merge_kmer: counts per base symbol, first-seen order, 16-bit sums
+            for (int t = 0; t < 16; ++t) mc[t] = 0xffffffffu;
+            for (uint32_t idx = c.lhead[s]; idx; idx = c.lpool[2ull * (idx - 1) + 1]) {
+                const uint32_t ent = c.lpool[2ull * (idx - 1)];
+                const uint32_t sy = ent & 0xfu;
+                if (mc[sy] == 0xffffffffu) { mc[sy] = ent >> 16; order[nm++] = sy; }
+                else mc[sy] = (mc[sy] + (ent >> 16)) & 0xffffu;
+            }
+            if (nm >= 2) {   // stable top two (base.c:91-121)
+                uint32_t m0 = order[0], m1 = order[1];
+                if (mc[m1] > mc[m0]) { const uint32_t t = m0; m0 = m1; m1 = t; }
+                for (uint32_t t = 2; t < nm; ++t) {
+                    const uint32_t sy = order[t];
+                    if (mc[sy] > mc[m1]) { if (mc[sy] > mc[m0]) { m1 = m0; m0 = sy; } else m1 = sy; }
+                }
+                const double rate = mc[m1] / (double)mc[m0];
+                const uint32_t bb = c.sbase[s];
+                if (m0 != bb || rate > c.max_indel_factor_lgs) {
+                    if (bb == 3 || !col0 || m0 != bb || rate > c.max_snp_factor_lgs) c.sflag[s] = (uint8_t)(c.sflag[s] | 16u);
+                    else c.sflag[s] = (uint8_t)(c.sflag[s] & ~16u);
+                }
+            }
+            KcStates prev3{c.st_score + 16ull * (sb + k), c.st_kmer + 16ull * (sb + k), c.st_rank + 16ull * (sb + k), fp};
+            const uint32_t arg3 = kk >> 4;
+            if (arg3) b = prev3.rk[arg3 & 0xf] != 0xff ? (int)(arg3 & 0xf) : -1;
+            else b = prev3.first_max();
+            continue;
+        }
         c.sbase[s] = (uint8_t)b;
         uint32_t fl = c.sflag[s];
         if (c.scount[s] == 1) fl |= KC_FLAG_ZERO; else fl &= ~KC_FLAG_ZERO;

@@ -53,7 +53,9 @@ typedef struct {
     obase* b;
     int32_t L;
     int32_t inslength;
-    int filter_kind;   /* 1: contig_read_fliter1 (score_chain); 0: contig_read_fliter (kmer_count) */
+    int filter_kind;   /* 1: contig_read_fliter1 (score_chain); 0: contig_read_fliter (kmer_count); 2: contig_read_fliter2 (long reads) */
+    int shift;         /* context shift of the pileup (contig.c:360-363): BASE_SHIFT = 4, snp_phase's first pileup uses 16 */
+    uint8_t insflag;   /* pass 1 makes insertion columns only behind bases carrying one of these marks; 0 = everywhere */
 } octg;
 
 static void slot_init(oslot* s) {   /* base.c:17-32 */
@@ -168,6 +170,10 @@ static double read_cliprate(const np1o_contig* in, int64_t r) {   /* contig.c:63
 static uint8_t read_filter(octg* c, int64_t r) {
     const np1o_contig* in = c->in;
     uint8_t result = 0;
+    if (c->filter_kind == 2) {   /* contig_read_fliter2, contig.c:679-686 */
+        if ((in->flag[r] & 0xD04) == 0 && read_cliprate(in, r) <= c->cfg->max_clip_ratio_lgs) result = 1;
+        return result;
+    }
     if (c->filter_kind == 1) {   /* contig_read_fliter1, contig.c:667-677 */
         if ((in->flag[r] & 0xC04) == 0) result = 1;
         return result;
@@ -216,6 +222,7 @@ static void cut_read(octg* c, int64_t r, int32_t* qstart, int32_t* qend) {
 }
 
 static inline uint16_t left_kmer(uint16_t kmer, uint8_t base) { return (uint16_t)((kmer & 0xff) << 4 | base); }
+static inline uint16_t left_kmer_s(uint16_t kmer, uint8_t base, int shift) { return (uint16_t)((uint32_t)(kmer & 0xff) << shift | base); }
 
 /* PASS 1: insertion columns (reference: source/lib/contig.c:202-245, flag argument 0) */
 static void parse_read_insert(octg* c, int64_t r, int32_t start, int32_t end) {
@@ -227,7 +234,7 @@ static void parse_read_insert(octg* c, int64_t r, int32_t start, int32_t end) {
         switch (OP(cg[i])) {
             case CMATCH: case CDEL: pos += OPLEN(cg[i]); break;
             case CINS:
-                if (pos > start && pos <= end) {
+                if (pos > start && pos <= end && (c->insflag == 0 || (c->b[pos - 1].m.flag & c->insflag))) {
                     int32_t len = OPLEN(cg[i]);
                     obase* b = &c->b[pos - 1];
                     if (b->nins < len) {
@@ -264,12 +271,12 @@ static void parse_read(octg* c, int64_t r, int32_t start, int32_t end) {
                         if (lastcigar != CINS && pos > start && (qpos > qstart || (qpos == qstart && lastcigar == CDEL))) {
                             obase* pb = &c->b[pos - 1];
                             for (k = 0; k < pb->nins; k++) {
-                                kmer = left_kmer(kmer, BASE_DEL);
+                                kmer = left_kmer_s(kmer, BASE_DEL, c->shift);
                                 slot_add_data(&pb->ins[k], kmer);
                             }
                         }
-                        if (curcigar == CDEL) kmer = left_kmer(kmer, BASE_DEL);
-                        else kmer = left_kmer(kmer, seqi(seq, qpos));
+                        if (curcigar == CDEL) kmer = left_kmer_s(kmer, BASE_DEL, c->shift);
+                        else kmer = left_kmer_s(kmer, seqi(seq, qpos), c->shift);
                         slot_add_data(&c->b[pos].m, kmer);
                     }
                     if (curcigar != CDEL) qpos++;
@@ -281,13 +288,13 @@ static void parse_read(octg* c, int64_t r, int32_t start, int32_t end) {
                     obase* pb = (pos - 1 < c->L) ? &c->b[pos - 1] : NULL;
                     for (j = 0; j < len; j++, qpos++) {
                         if (pos > start && pos <= end && qpos >= qstart && qpos <= qend) {
-                            kmer = left_kmer(kmer, seqi(seq, qpos));
+                            kmer = left_kmer_s(kmer, seqi(seq, qpos), c->shift);
                             slot_add_data(&pb->ins[j], kmer);
                         }
                     }
                     if (pos > start && pos <= end && qpos > qstart && qpos <= qend + 1) {
                         for (; j < pb->nins; j++) {
-                            kmer = left_kmer(kmer, BASE_DEL);
+                            kmer = left_kmer_s(kmer, BASE_DEL, c->shift);
                             slot_add_data(&pb->ins[j], kmer);
                         }
                     }
@@ -532,6 +539,7 @@ static octg* ctg_init(const np1o_contig* in, const np1o_configure* cfg) {   /* c
     octg* c = (octg*)calloc(1, sizeof(octg));
     c->in = in;
     c->cfg = cfg;
+    c->shift = 4;
     c->L = in->length;
     c->b = (obase*)calloc((size_t)(in->length > 0 ? in->length : 1), sizeof(obase));
     for (int32_t i = 0; i < in->length; i++) {
@@ -635,9 +643,10 @@ static int g_undefined = 0;
 
 /* ss_parse_read_kmer with left = right = -1 (reference: source/lib/kmercount.c:365-465); flagzero != 0: the FLAG_ZERO marks of
  * the covered slots are left alone (snp_valid's first round) */
-static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, okscore* ks, int flagzero) {
+static int32_t parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, okscore* ks, int32_t left, int32_t right, int flagzero) {
     const np1o_contig* in = c->in;
-    if (!in->n_cigar[r]) return;
+    int32_t result = 0;
+    if (!in->n_cigar[r]) return 0;
     int32_t pos = in->pos[r], qpos = 0, qstart, qend, i, j, k, len, del = 0;
     uint8_t curcigar, lastcigar = CINS;
     const uint32_t* cg = in->cigar + in->cigar_off[r];
@@ -668,6 +677,9 @@ static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, oksc
                         }
                         if (!flagzero) c->b[pos].m.flag &= (uint8_t)~FLAG_ZERO;
                     }
+                    if (left == pos || right == pos) {   /* kmercount.c:416-420: the read agrees with the draft at the two anchor columns */
+                        if (pos < c->L && qpos < in->l_qseq[r] && seqi(seq, qpos) == c->b[pos].m.base) result++;
+                    }
                     if (curcigar != CDEL) qpos++;
                     lastcigar = curcigar;
                 }
@@ -677,7 +689,7 @@ static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, oksc
                     obase* pb = (pos - 1 < c->L) ? &c->b[pos - 1] : NULL;
                     for (j = 0; j < len; j++, qpos++) {
                         if (pos > start && pos <= end && qpos >= qstart && qpos <= qend) {
-                            if (!pb || j >= pb->nins) { g_undefined = 1; return; }
+                            if (!pb || j >= pb->nins) { g_undefined = 1; return result; }
                             ks->region[ks->length++] = seqi(seq, qpos);
                             ks->qual += qual[qpos];
                             if (!flagzero) pb->ins[j].flag &= (uint8_t)~FLAG_ZERO;
@@ -705,6 +717,7 @@ static void parse_read_kmer(octg* c, int64_t r, int32_t start, int32_t end, oksc
     }
     if (ks->length > 0 && ks->length != del) ks->qual /= ks->length - del;
     else ks->qual = 0;
+    return result;
 }
 
 typedef struct { okscore* v; int32_t n, cap; } kslist;
@@ -712,7 +725,7 @@ typedef struct { okscore* v; int32_t n, cap; } kslist;
 /* ss_kmer_get_region (reference: source/lib/kmercount.c:332-363); returns nothing, mutates ks */
 static void kmer_get_region(octg* c, int64_t r, int32_t start, int32_t end, int32_t length, kslist* rd, okscore* ks, int flagzero) {
     if (ks->region == NULL) ks->region = (uint8_t*)calloc(1, (size_t)length + 8);
-    parse_read_kmer(c, r, start, end, ks, flagzero);
+    parse_read_kmer(c, r, start, end, ks, -1, -1, flagzero);
     if (ks->length == length) {
         okscore* hit = NULL;
         for (int32_t i = 0; i < rd->n; i++)
@@ -920,6 +933,812 @@ char* np1o_snp_valid(const np1o_contig* in, const np1o_configure* cfg, int32_t* 
     }
     free(kreg.v);
     char* out = get_contig(c, 0, c->L - 1, 0, out_len);
+    ctg_free(c);
+    return out;
+}
+
+/* ================= snp_phase (task 3; reference: source/lib/snpphase.c) =================
+ * Two record streams: `sr` = the short-read BAM (contig->fp), `lr` = the long-read BAM (contig->tfp).  c->in says which of
+ * them the record helpers look at, as the reference switches fp / read_fliter.  Region iteration is the same model as above:
+ * overlap query (contig_next_iter with flag 2) or the swapped-interval "spanning" query (flag 1); the iterator re-use and the
+ * saved offsets of contig.c:982-1043 only skip records that cannot qualify.
+ * Where the reference's result rests on reading through a null / uninitialised pointer, g_undefined is set and
+ * np1o_snp_phase returns NULL with *out_len = -1. */
+#include <math.h>
+#define FLAG_DEPTH 4
+#define FLAG_SNP 8
+#define FLAG_THIRD 16
+#define FLAG_INSERT 32
+#define FLAG_LEFT 64
+#define FLAG_RIGHT 128
+#define SNP_NUM 2
+#define BASE_QUAL 41
+#define READ_MAPQ 60
+
+/* how often each stage of the last np1o_snp_phase call did something (so that tests can tell a fuzz run reached them):
+ * 0 sites found, 1 sites kept, 2 sites with insertion columns, 3 low-count sites asked of the long reads, 4 long-read votes,
+ * 5 sites settled to one base, 6 low-depth regions, 7 links counted, 8 sites re-written by the phase chain, 9 long-read links */
+static int64_t g_sp_stats[10];
+void np1o_snp_phase_stats(int64_t out[10]) { memcpy(out, g_sp_stats, sizeof(g_sp_stats)); }
+
+typedef struct {   /* snpphase.h:8-16 */
+    int32_t pos, left, right;
+    int16_t length, total;
+    uint8_t* region[SNP_NUM];
+    kslist link;
+} osnp;
+typedef struct { osnp** v; int32_t n, cap; } snplist;
+
+static osnp* snp_new(int32_t right, int32_t length) {   /* snpphase.c:3-13 */
+    osnp* s = (osnp*)calloc(1, sizeof(osnp));
+    for (int i = 0; i < SNP_NUM; i++) s->region[i] = (uint8_t*)calloc(1, (size_t)length + 8);
+    s->right = right;
+    s->length = (int16_t)length;
+    return s;
+}
+static void snp_free(osnp* s) {
+    if (!s) return;
+    for (int i = 0; i < SNP_NUM; i++) free(s->region[i]);
+    free(s->link.v);
+    free(s);
+}
+static int32_t snp_get_index(osnp* s, const uint8_t* region) {   /* snpphase.c:40-48 */
+    for (int i = 0; i < SNP_NUM; i++)
+        if (memcmp(s->region[i], region, (size_t)s->length) == 0) return i;
+    return -1;
+}
+static void kl_push(kslist* l, const okscore* k) {
+    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 16; l->v = (okscore*)realloc(l->v, (size_t)l->cap * sizeof(okscore)); }
+    l->v[l->n++] = *k;
+}
+static int32_t kl_index_by_region(kslist* l, const okscore* item) {   /* seqlist_get_index + ks_compare_region: the LIST element's length decides */
+    for (uint16_t i = 0; i < l->n; i++)
+        if (memcmp(l->v[i].region, item->region, (size_t)l->v[i].length) == 0) return i;
+    return -1;
+}
+
+static int32_t slot_nlargest(oslot* s, okmer** maxn, int32_t n) {   /* base.c:91-121 */
+    int32_t count = 0;
+    if (s->nk > 0) {
+        okmer* p = s->k;
+        maxn[0] = p;
+        p++;
+        count++;
+        for (uint32_t i = 1; i < s->nk; i++, p++) {
+            for (int32_t j = count - 1; j >= 0; j--) {
+                if (p->count > maxn[j]->count) {
+                    if (j < n - 1) maxn[j + 1] = maxn[j];
+                    maxn[j] = p;
+                } else {
+                    if (j < n - 1) maxn[j + 1] = p;
+                    break;
+                }
+            }
+            if (count < n) count++;
+        }
+    }
+    return count;
+}
+static void slot_merge_kmer(oslot* s) {   /* base.c:123-146 */
+    int32_t count = 0;
+    okmer* temp[16];
+    if (s->nk > 0) {
+        memset(temp, 0, sizeof(temp));
+        okmer *p = s->k, *q = p;
+        for (uint32_t i = 0; i < s->nk; i++, p++) {
+            int32_t index = p->kmer & 0xf;
+            if (temp[index] == 0) {
+                count++;
+                q->kmer = (uint16_t)index;
+                q->count = p->count;
+                temp[index] = q;
+                q++;
+            } else {
+                temp[index]->count = (uint16_t)(temp[index]->count + p->count);
+            }
+        }
+        s->nk = (uint32_t)count;
+    }
+}
+static int32_t ks_nlargest(kslist* l, okscore** maxn, int32_t n) {   /* snpphase.c:873-903 */
+    int32_t count = 0;
+    okscore* p = l->v;
+    maxn[0] = p;
+    if (l->n > 0) {
+        p++;
+        count++;
+        for (int i = 1; i < l->n; i++, p++) {
+            for (int j = count - 1; j >= 0; j--) {
+                if (ks_compare(p, maxn[j]) > 0) {
+                    if (j < n - 1) maxn[j + 1] = maxn[j];
+                    maxn[j] = p;
+                } else {
+                    if (j < n - 1) maxn[j + 1] = p;
+                    break;
+                }
+            }
+            if (count < n) count++;
+        }
+    }
+    return count;
+}
+
+static int32_t check_snps(octg* c, int32_t count, double rate, int32_t flag) {   /* snpphase.c:205-214 */
+    if (rate < c->cfg->min_snp_factor_sgs && flag) return 0;
+    if (rate == 0 || (count >= c->cfg->min_count_snp && flag == 0 && rate < c->cfg->min_snp_factor_sgs)) return 2;
+    return 1;
+}
+
+/* ts_find_snps (snpphase.c:136-203) */
+static void sp_find_snps(octg* c, int32_t start, int32_t end, snplist* out) {
+    int32_t i = start, j = 0, k, count, flag = 0, flag1 = 0, lasti = start, lastj = 0;
+    oslot* p = &c->b[start].m;
+    okmer* maxn[SNP_NUM];
+    double rate;
+    while (IN_RANGE(i, j, end)) {
+        if (p->count == 0) p->flag |= FLAG_ZERO; else p->flag &= (uint8_t)~FLAG_ZERO;
+        if (p->count <= c->cfg->min_depth_snp) p->flag |= FLAG_DEPTH; else p->flag &= (uint8_t)~FLAG_DEPTH;
+        flag = 0;
+        if (p->count > 0) {
+            count = slot_nlargest(p, maxn, SNP_NUM);
+            rate = count == 1 ? 0 : maxn[1]->count / (double)maxn[0]->count;
+            flag = check_snps(c, p->count, rate, maxn[0]->kmer == p->base);
+            if (flag == 2) {
+                p->base = (uint8_t)maxn[0]->kmer;
+            } else if (flag == 1) {
+                if (j == 0 || (c->b[i].m.flag & FLAG_SNP) == 0) {
+                    c->b[i].m.flag |= FLAG_SNP;
+                    osnp* s = snp_new(c->L - 1, 1);
+                    s->left = lasti;
+                    s->pos = i;
+                    flag1 = 1;
+                    for (k = 0; k < count; k++) s->region[k][0] = (uint8_t)maxn[k]->kmer;
+                    if (count < SNP_NUM) s->region[count][0] = p->base;
+                    if (out->n == out->cap) { out->cap = out->cap ? out->cap * 2 : 64; out->v = (osnp**)realloc(out->v, (size_t)out->cap * sizeof(osnp*)); }
+                    out->v[out->n++] = s;
+                }
+            }
+        }
+        if (flag != 1 && (c->b[i].m.flag & FLAG_SNP) == 0 && (c->b[i].ins == NULL || j == c->b[i].nins)) {
+            lasti = i;
+            if (flag1) {
+                for (; lastj < out->n; lastj++) out->v[lastj]->right = lasti;
+                flag1 = 0;
+            }
+        }
+        p = ctg_next(c, &i, &j);
+    }
+}
+
+static void update_flag(octg* c, int32_t start, int32_t end, uint8_t flag) {   /* contig.c:833-841 */
+    int32_t i = start, j = 0;
+    oslot* p = &c->b[start].m;
+    while (IN_RANGE(i, j, end)) { p->flag |= flag; p = ctg_next(c, &i, &j); }
+}
+static void update_contig(octg* c, int32_t start, int32_t end, const uint8_t* region, uint16_t index) {   /* contig.c:811-821 */
+    int32_t i = start, j = 0;
+    oslot* p = &c->b[start].m;
+    const uint8_t* q = region;
+    while (i < end || (i == end && j == index)) {
+        p->base = *q;
+        p = ctg_next(c, &i, &j);
+        q++;
+    }
+}
+static void clean_region(octg* c, int32_t start, int32_t end) {   /* contig.c:620-630 */
+    int32_t i = start, j = 0;
+    oslot* p = &c->b[start].m;
+    while (IN_RANGE(i, j, end)) { p->nk = 0; p->count = 0; p = ctg_next(c, &i, &j); }
+}
+
+/* ss_kmer_get_region in full (kmercount.c:332-363): anchors left / right, the length adjustment `flag`, the counter */
+static void sp_get_region(octg* c, int64_t r, int32_t start, int32_t end, int32_t length, kslist* rd, okscore* ks, int32_t* count,
+                          int32_t left, int32_t right, int32_t flag, int flagzero) {
+    int32_t check = left != -1 ? 2 : 0;
+    int32_t result = parse_read_kmer(c, r, start, end, ks, left, right, flagzero);
+    if (ks->length == length && result >= check) {
+        ks->length += flag;
+        okscore* hit = NULL;
+        for (uint16_t i = 0; i < rd->n; i++)
+            if (memcmp(rd->v[i].region, ks->region, (size_t)rd->v[i].length) == 0) { hit = &rd->v[i]; break; }
+        if (!hit) {
+            ks->num = 1;
+            kl_push(rd, ks);
+            ks->region = NULL;
+        } else {
+            hit->num++;
+            hit->mapqual += ks->mapqual;
+            hit->qual += ks->qual;
+        }
+        if (count) (*count)++;
+    } else {
+        ks->mapqual = 0;
+    }
+}
+static okscore* ks_new(int32_t length) {
+    okscore* ks = (okscore*)calloc(1, sizeof(okscore));
+    ks->region = (uint8_t*)calloc(1, (size_t)length + 8);
+    return ks;
+}
+
+/* ts_fliter_snps (snpphase.c:216-349) */
+static void sp_filter_snps(octg* c, snplist* sl, const np1o_contig* sr, const np1o_contig* lr, int32_t span_sr, int32_t span_lr) {
+    if (sl->n <= 0) return;
+    kslist rd = {0, 0, 0};
+    okscore* ks = NULL;
+    okscore* maxn[SNP_NUM];
+    int32_t kept = 0;
+    for (int32_t si = 0; si < sl->n && !g_undefined; si++) {
+        osnp* q = sl->v[si];
+        obase* bb = &c->b[q->pos];
+        oslot* base = &bb->m;
+        int32_t length = 1, start = q->pos, end = q->pos, total = 0, flag = 0, flag1, j;
+        if (bb->ins && bb->nins > 0) {
+            end = q->pos + 1;
+            length += bb->nins + 1;
+            g_sp_stats[2]++;
+            c->in = sr;
+            c->filter_kind = 0;
+            int64_t r0 = lower_bound_pos(sr, start - span_sr), rstop = lower_bound_pos(sr, start);
+            for (int64_t r = r0; r < rstop; r++) {
+                if (!(read_endpos(sr, r) > end + 1)) continue;
+                if (read_filter(c, r) == 2) {
+                    if (!ks) ks = ks_new(length);
+                    sp_get_region(c, r, start, end, length, &rd, ks, &total, -1, -1, -1, 0);
+                    ks_clean(ks, length);
+                }
+            }
+            flag = 1;
+        } else {
+            ks = ks_new(length);
+            total = base->count;
+        }
+        if (total <= c->cfg->min_count_snp) {
+            if (!ks) { g_undefined = 1; break; }   /* snpphase.c:269: memset through the null KmerScore */
+            g_sp_stats[3]++;
+            if (length == 1) {
+                for (uint32_t t = 0; t < base->nk; t++) {
+                    ks->region[0] = (uint8_t)base->k[t].kmer;
+                    ks->num = base->k[t].count;
+                    ks->mapqual = READ_MAPQ * ks->num;
+                    ks->qual = BASE_QUAL * ks->num;
+                    kl_push(&rd, ks);
+                    ks->region = (uint8_t*)calloc(1, (size_t)length + 8);
+                }
+            }
+            memset(ks->region, BASE_DEL, (size_t)length);
+            flag1 = kl_index_by_region(&rd, ks);
+            c->in = lr;
+            c->filter_kind = 2;
+            int64_t r0 = lower_bound_pos(lr, start - span_lr), rstop = lower_bound_pos(lr, start);
+            for (int64_t r = r0; r < rstop; r++) {
+                if (!(read_endpos(lr, r) > end + 1)) continue;
+                if (read_filter(c, r) == 1) {
+                    { int32_t before = total; sp_get_region(c, r, start, end, length, &rd, ks, &total, q->left, q->right, -1, 1); g_sp_stats[4] += total - before; }
+                    ks_clean(ks, length);
+                }
+            }
+            flag = 1;
+            if (flag1 == -1) {
+                memset(ks->region, BASE_DEL, (size_t)length);
+                flag1 = kl_index_by_region(&rd, ks);
+                if (flag1 != -1) {
+                    free(rd.v[flag1].region);
+                    for (int32_t t = flag1; t + 1 < rd.n; t++) rd.v[t] = rd.v[t + 1];
+                    rd.n--;
+                }
+            }
+        }
+        if (flag) {
+            if (rd.n == 0) { g_undefined = 1; break; }   /* ts_get_nlargest on an empty list: maxn[1] is never set */
+            flag1 = ks_nlargest(&rd, maxn, SNP_NUM);
+            double rate = flag1 == 1 ? 0 : maxn[1]->num / (double)maxn[0]->num;
+            memset(ks->region, BASE_DEL, (size_t)length);
+            ks->region[0] = base->base;
+            flag = check_snps(c, total, rate, memcmp(maxn[0]->region, ks->region, (size_t)maxn[0]->length) == 0);
+            if (flag == 1) {
+                if (length != q->length)
+                    for (int t = 0; t < SNP_NUM; t++) q->region[t] = (uint8_t*)realloc(q->region[t], (size_t)length + 8);
+                q->length = (int16_t)maxn[0]->length;
+                for (j = 0; j < flag1; j++) memcpy(q->region[j], maxn[j]->region, (size_t)q->length);
+                if (flag1 < SNP_NUM) memcpy(q->region[flag1], ks->region, (size_t)q->length);
+                sl->v[kept++] = q;
+            } else {
+                if (flag == 2) {
+                    g_sp_stats[5]++;
+                    base->base = maxn[0]->region[0];
+                    update_contig(c, start, end, maxn[0]->region, (uint16_t)-1);
+                }
+                c->b[start].m.flag &= 0xf7;
+                snp_free(q);
+                sl->v[si] = NULL;
+            }
+        } else {
+            sl->v[kept++] = q;
+        }
+        if (ks) { free(ks->region); free(ks); }
+        for (int32_t t = 0; t < rd.n; t++) free(rd.v[t].region);
+        rd.n = 0;
+        ks = NULL;
+    }
+    if (!g_undefined) sl->n = kept;
+    free(rd.v);
+}
+
+/* ts_region_correct (snpphase.c:843-871) */
+static void sp_region_correct(octg* c, int32_t start, int32_t end) {
+    oslot* base = &c->b[end].m;
+    oscore* score = slot_max_score(base);
+    int32_t i = end, j = 0;
+    okmer* maxn[2];
+    while (i > start || (i == start && j == 0)) {
+        if (!score) { g_undefined = 1; return; }
+        if ((base->flag & FLAG_ZERO) || (j == 0 && score->base != BASE_DEL)) base->base = score->base;
+        slot_merge_kmer(base);
+        if (base->nk >= 2) {
+            slot_nlargest(base, maxn, 2);
+            double rate = maxn[1]->count / (double)maxn[0]->count;
+            if (maxn[0]->kmer != base->base || rate > c->cfg->max_indel_factor_lgs) {
+                if (base->base == BASE_DEL || j != 0 || maxn[0]->kmer != base->base || rate > c->cfg->max_snp_factor_lgs) base->flag |= FLAG_THIRD;
+                else base->flag &= (uint8_t)~FLAG_THIRD;
+            }
+        }
+        base = ctg_prev(c, &i, &j);
+        score = slot_get_score(base, score->kmer >> 4);
+    }
+}
+
+/* ts_correct_lower_depth (snpphase.c:797-841) */
+static void sp_correct_lower_depth(octg* c, ilist* nodepth, const np1o_contig* sr, const np1o_contig* lr, int32_t span_sr, int32_t span_lr) {
+    c->in = sr;
+    c->filter_kind = 0;
+    c->shift = 4;
+    for (int i = 0; i < nodepth->n; i += 2) {
+        int32_t s = nodepth->v[i], e = nodepth->v[i + 1];
+        clean_region(c, s, e);
+        as_read(c, s, e);
+        parse_region(c, s, e, 2, span_sr);
+    }
+    c->in = lr;
+    c->filter_kind = 2;
+    for (int i = 0; i < nodepth->n; i += 2) parse_region(c, nodepth->v[i], nodepth->v[i + 1], 1, span_lr);
+    for (int i = 0; i < nodepth->n && !g_undefined; i += 2) {
+        region_score(c, nodepth->v[i], nodepth->v[i + 1], c->cfg->indel_balance_factor_lgs);
+        sp_region_correct(c, nodepth->v[i], nodepth->v[i + 1]);
+    }
+}
+
+/* ts_find_snp_region (snpphase.c:559-613) */
+static ilist sp_find_snp_region(octg* c, snplist* sl, int32_t gap, uint32_t flag) {
+    ilist result = {0, 0, 0};
+    int32_t temp;
+    uint32_t flag1 = FLAG_LEFT | FLAG_RIGHT, flag2;
+    osnp *qstart = NULL, *qend = NULL;
+    for (int32_t i = 0; i < sl->n; i++) {
+        osnp* p = sl->v[i];
+        flag2 = c->b[p->pos].m.flag;
+        if ((flag2 & flag) || (flag2 & flag1)) {
+            if (qstart == NULL) {
+                qend = qstart = p;
+            } else if (flag || (flag2 & FLAG_RIGHT)) {
+                if (flag) temp = p->pos - qend->pos;
+                else temp = p->right - qend->left;
+                if (temp < gap) {
+                    qend = p;
+                } else {
+                    if (qstart != qend) {
+                        if (flag) {
+                            il_push(&result, qstart->pos);
+                            il_push(&result, qend->pos + 1);
+                        } else {
+                            il_push(&result, qstart->left);
+                            il_push(&result, qend->right);
+                        }
+                    }
+                    if (flag || (flag2 & FLAG_LEFT)) qend = qstart = p;
+                    else qend = qstart = NULL;
+                }
+            }
+        }
+    }
+    if (qstart && qstart != qend) {
+        if (flag) {
+            il_push(&result, qstart->pos);
+            il_push(&result, qend->pos);
+        } else {
+            il_push(&result, qstart->left);
+            il_push(&result, qend->right);
+        }
+    }
+    return result;
+}
+
+/* ts_snps_parse_read (snpphase.c:615-776): the haplotype strings of one record at the marked columns, appended to `ld`; their
+ * bytes live one behind the other in the buffer ks->region points into */
+static void sp_parse_read(octg* c, int64_t r, int32_t start, int32_t end, uint32_t flagbrim, kslist* ld, okscore* ks) {
+    const np1o_contig* in = c->in;
+    if (!in->n_cigar[r]) return;
+    int32_t pos = in->pos[r], qpos = 0, qstart, qend, i, j, k, len, del = 0, curpos = 0, sign = 0, comfirmindex = 0,
+            totallength = c->cfg->max_variant_count_lgs;
+    uint8_t curcigar, lastcigar = CINS, *q = ks->region;
+    const uint32_t* cg = in->cigar + in->cigar_off[r];
+    const uint8_t* seq = in->seq + in->seq_off[r];
+    const uint8_t* qual = in->qual + in->qual_off[r];
+    const uint16_t flag = FLAG_LEFT | FLAG_RIGHT;
+    cut_read(c, r, &qstart, &qend);
+    ks->mapqual = in->mapq[r];
+    for (i = 0; i < in->n_cigar[r]; ++i) {
+        len = OPLEN(cg[i]);
+        curcigar = OP(cg[i]);
+        if (totallength - len < 0) break;
+        switch (curcigar) {
+            case CMATCH: case CDEL:
+                for (j = 0; j < len; j++, pos++) {
+                    if (pos >= start && pos <= end && qpos >= qstart && qpos <= qend) {
+                        oslot* base = &c->b[pos].m;
+                        if (lastcigar != CINS && pos > start && (qpos > qstart || (qpos == qstart && lastcigar == CDEL))) {
+                            obase* pb = &c->b[pos - 1];
+                            if (pb->ins != NULL && curpos) {
+                                for (k = 0; k < pb->nins; k++) {
+                                    ks->region[ks->length++] = BASE_DEL;
+                                    totallength--;
+                                    del++;
+                                }
+                            }
+                        }
+                        if (flagbrim == 0 || (base->flag & flag)) {
+                            if (base->flag & FLAG_SNP) {
+                                if (curpos == 0) {
+                                    ks->region = q;
+                                    ks->length = 0;
+                                    ks->num = pos;
+                                    ks->qual = 0;
+                                    del = 0;
+                                    curpos = 1;
+                                    if (flagbrim == 0) sign = 1;
+                                } else {
+                                    sign++;
+                                }
+                            } else if (flagbrim) {
+                                if (base->base == seqi(seq, qpos)) sign++;
+                            } else {
+                                sign++;
+                            }
+                            if (curpos) {
+                                if (curcigar == CDEL) {
+                                    ks->region[ks->length++] = BASE_DEL;
+                                } else {
+                                    ks->region[ks->length++] = seqi(seq, qpos);
+                                    ks->qual += qual[qpos];
+                                }
+                                totallength--;
+                                if (ks->num != pos || c->b[pos].ins == NULL) {
+                                    if (ks->num != pos) {
+                                        if (ks->length != del) ks->qual /= (double)(ks->length - del);
+                                        else ks->qual = 0;
+                                        ks->length--;
+                                    }
+                                    kl_push(ld, ks);
+                                    q += ks->length;
+                                    curpos = 0;
+                                }
+                            }
+                            if (ks->num != pos) {
+                                if (base->flag & FLAG_SNP) {
+                                    ks->region = q;
+                                    ks->length = 1;
+                                    ks->num = pos;
+                                    ks->qual = qual[qpos];
+                                    del = 0;
+                                    curpos = 1;
+                                    if (flagbrim == 0) {
+                                        comfirmindex++;
+                                        sign = 1;
+                                    }
+                                } else if (base->flag & FLAG_RIGHT) {
+                                    if (sign == 2) {
+                                        comfirmindex = ld->n;
+                                    } else if (comfirmindex >= 0 && comfirmindex < ld->n) {
+                                        for (k = comfirmindex; k < ld->n; k++, comfirmindex++) ld->v[k].length = 0;
+                                    }
+                                    curpos = 0;
+                                    sign = 0;
+                                    if (base->flag & FLAG_LEFT) sign++;
+                                }
+                            }
+                        }
+                    }
+                    if (curcigar != CDEL) qpos++;
+                    lastcigar = curcigar;
+                }
+                break;
+            case CINS:
+                if (curpos) {
+                    if (pos) {
+                        obase* pb = (pos - 1 < c->L) ? &c->b[pos - 1] : NULL;
+                        for (j = 0; j < len; j++, qpos++) {
+                            if (pos > start && pos <= end && qpos >= qstart && qpos <= qend) {
+                                ks->region[ks->length++] = seqi(seq, qpos);
+                                ks->qual += qual[qpos];
+                                totallength--;
+                            }
+                        }
+                        if (pos > start && pos <= end && qpos > qstart && qpos <= qend + 1) {
+                            if (!pb || pb->ins == NULL) { g_undefined = 1; return; }   /* snpphase.c:750: p->length of a null list */
+                            for (; j < pb->nins; j++) {
+                                ks->region[ks->length++] = BASE_DEL;
+                                totallength--;
+                                del++;
+                            }
+                        }
+                    } else {
+                        qpos += len;
+                        qstart += len;
+                        lastcigar = curcigar;
+                    }
+                } else {
+                    qpos += len;
+                }
+                lastcigar = curcigar;
+                break;
+            case CHARD: case CSOFT:
+                qpos += len;
+                break;
+        }
+    }
+}
+
+static int32_t sp_list_find(snplist* sl, int32_t pos) {   /* snpphase.c:68-85 */
+    int32_t i = 0, j = sl->n - 1, mid, qpos;
+    while (i <= j) {
+        mid = (i + j) / 2;
+        qpos = sl->v[mid]->pos;
+        if (qpos == pos) return mid;
+        if (qpos < pos) i = mid + 1; else j = mid - 1;
+    }
+    return -1;
+}
+
+/* ts_tranfer_link (snpphase.c:423-448) */
+static void sp_transfer_link(osnp** snp, okscore** ks, int16_t* total, int32_t flag) {
+    if (ks[0]->length == snp[0]->length && ks[1]->length == snp[1]->length && flag == 4) {
+        int32_t index = snp_get_index(snp[0], ks[0]->region);
+        if (index != -1) {
+            index++;
+            ks[1]->length = index << 4;
+            index = snp_get_index(snp[1], ks[1]->region);
+            if (index != -1) {
+                index++;
+                ks[1]->length += index;
+                okscore* p = NULL;
+                for (uint16_t i = 0; i < snp[1]->link.n; i++)
+                    if (snp[1]->link.v[i].length == ks[1]->length) { p = &snp[1]->link.v[i]; break; }
+                if (p == NULL) {
+                    ks[1]->num = 1;
+                    kl_push(&snp[1]->link, ks[1]);
+                } else {
+                    p->num++;
+                    p->mapqual += ks[1]->mapqual;
+                    p->qual += ks[1]->qual;
+                }
+                (*total)++;
+                g_sp_stats[7]++;
+            }
+        }
+    }
+}
+
+/* ts_snps_deal_linkdata (snpphase.c:778-795) */
+static void sp_deal_linkdata(octg* c, kslist* ld, snplist* sl, uint32_t flag) {
+    if (ld->n > 1) {
+        okscore* ks[2];
+        osnp* snps[2];
+        for (int32_t i = 1; i < ld->n; i++) {
+            okscore* p = &ld->v[i];
+            if (p->length && (p - 1)->length &&
+                (flag == 0 || ((c->b[p->num].m.flag & FLAG_RIGHT) && (c->b[(p - 1)->num].m.flag & FLAG_LEFT)))) {
+                int32_t index = sp_list_find(sl, p->num);
+                if (index < 1) { g_undefined = 1; return; }   /* snpslist->data[index - 1] in front of the array */
+                snps[0] = sl->v[index - 1];
+                snps[1] = sl->v[index];
+                ks[0] = p - 1;
+                ks[1] = p;
+                sp_transfer_link(snps, ks, &snps[1]->total, 4);
+            }
+        }
+    }
+}
+
+/* ts_find_snps_link (snpphase.c:351-421) */
+static void sp_find_snps_link(octg* c, snplist* sl, const np1o_contig* sr, const np1o_contig* lr, int32_t span_sr, int32_t span_lr) {
+    if (sl->n <= 1) return;
+    ilist reg = sp_find_snp_region(c, sl, c->cfg->read_len, FLAG_SNP);
+    kslist ld = {0, 0, 0};
+    okscore* ks = ks_new(c->cfg->max_variant_count_lgs > 0 ? c->cfg->max_variant_count_lgs : 1);
+    uint8_t* pks = ks->region;
+    c->in = sr;
+    c->filter_kind = 0;
+    for (int i = 0; i < reg.n && !g_undefined; i += 2) {
+        int32_t s = reg.v[i], e = reg.v[i + 1];
+        for (int64_t r = lower_bound_pos(sr, s - span_sr); r < sr->n_reads && !g_undefined; r++) {
+            if (sr->pos[r] >= e + 1) break;
+            if (read_endpos(sr, r) <= s) continue;
+            if (read_filter(c, r) == 2) {
+                sp_parse_read(c, r, s, e, 0, &ld, ks);
+                if (!g_undefined) sp_deal_linkdata(c, &ld, sl, 0);
+                ld.n = 0;
+                ks->length = 0;
+                ks->region = pks;
+            }
+        }
+    }
+    for (int32_t i = 1; i < sl->n; i++) {
+        if (sl->v[i]->total <= c->cfg->min_count_snp_link) {
+            osnp *a = sl->v[i - 1], *b = sl->v[i];
+            c->b[a->left].m.flag |= FLAG_LEFT;
+            c->b[a->pos].m.flag |= FLAG_LEFT;
+            c->b[a->right].m.flag |= FLAG_RIGHT;
+            c->b[b->left].m.flag |= FLAG_LEFT;
+            c->b[b->pos].m.flag |= FLAG_RIGHT;
+            c->b[b->right].m.flag |= FLAG_RIGHT;
+        }
+    }
+    free(reg.v);
+    reg = sp_find_snp_region(c, sl, c->cfg->max_variant_count_lgs, 0);
+    c->in = lr;
+    c->filter_kind = 2;
+    for (int i = 0; i < reg.n && !g_undefined; i += 2) {
+        int32_t s = reg.v[i], e = reg.v[i + 1];
+        for (int64_t r = lower_bound_pos(lr, s - span_lr); r < lr->n_reads && !g_undefined; r++) {
+            if (lr->pos[r] >= e + 1) break;
+            if (read_endpos(lr, r) <= s) continue;
+            if (read_filter(c, r) == 1) {
+                sp_parse_read(c, r, s, e, 1, &ld, ks);
+                { int64_t before = g_sp_stats[7]; if (!g_undefined) sp_deal_linkdata(c, &ld, sl, 1); g_sp_stats[9] += g_sp_stats[7] - before; }
+                ld.n = 0;
+                ks->length = 0;
+                ks->region = pks;
+            }
+        }
+    }
+    free(reg.v);
+    free(ld.v);
+    free(pks);
+    free(ks);
+}
+
+/* ts_snps_score (snpphase.c:450-516): chain score over the links between neighbouring sites; evaluation order as written */
+static void sp_snps_score(octg* c, snplist* sl) {
+    if (sl->n <= 1) return;
+    oslot* base[SNP_NUM];
+    uint16_t link[2][SNP_NUM + 1], temp;
+    double score;
+    int32_t i, j, k;
+    base[0] = &c->b[sl->v[0]->pos].m;
+    base[0]->ns = 0;
+    for (i = 1; i <= SNP_NUM; i++) slot_add_score(base[0], (uint16_t)i, 0);
+    for (i = 1; i < sl->n; i++) {
+        osnp* q = sl->v[i];
+        base[0] = &c->b[sl->v[i - 1]->pos].m;
+        base[1] = &c->b[q->pos].m;
+        base[1]->ns = 0;
+        if (q->link.n) {
+            memset(link, 0, sizeof(link));
+            for (j = 0; j < q->link.n; j++) {
+                okscore* ks = &q->link.v[j];
+                temp = (uint16_t)(ks->length >> 4);
+                oscore* ps0 = slot_get_score(base[0], temp);
+                if (!ps0) { g_undefined = 1; return; }
+                score = ps0->score;
+                score += ks->num * log10((ks->mapqual + ks->qual) / (double)ks->num + 2) - q->total / c->cfg->ploidy;
+                oscore* pscore = slot_get_score(base[1], (uint16_t)ks->length);
+                if (pscore == NULL || pscore->score < score) {
+                    if (link[0][temp]) {
+                        if (slot_get_score(base[1], link[0][temp])->score >= score) continue;
+                        link[1][link[0][temp]] = 0;
+                    }
+                    if (pscore != NULL) link[0][pscore->kmer >> 4] = 0;
+                    slot_add_score(base[1], (uint16_t)ks->length, score);
+                    link[0][temp] = ks->length & 0xf;
+                    link[1][ks->length & 0xf] = temp;
+                }
+            }
+            k = 1;
+            for (j = 1; j <= SNP_NUM; j++) {
+                if (link[1][j] == 0) {
+                    for (; k <= SNP_NUM; k++) {
+                        if (link[0][k] == 0) {
+                            temp = (uint16_t)((k << 4) + j);
+                            oscore* ps0 = slot_get_score(base[0], (uint16_t)k);
+                            if (!ps0) { g_undefined = 1; return; }
+                            score = ps0->score;
+                            score -= q->total / c->cfg->ploidy;
+                            slot_add_score(base[1], temp, score);
+                            break;
+                        }
+                    }
+                }
+            }
+        } else {
+            for (j = 1; j <= SNP_NUM; j++) slot_add_score(base[1], (uint16_t)j, 0);
+        }
+    }
+}
+
+/* ts_snps_correct (snpphase.c:518-557) */
+static void sp_snps_correct(octg* c, snplist* sl) {
+    if (sl->n <= 1) return;
+    oscore* score = NULL;
+    for (int32_t i = sl->n - 1; i > 0; i--) {
+        osnp* q = sl->v[i];
+        if (q->link.n > 0) {
+            oslot* base;
+            if (score == NULL) {
+                base = &c->b[q->pos].m;
+                score = slot_max_score(base);
+                if (!score) { g_undefined = 1; return; }
+                if (q->length == 1) base->base = q->region[score->base - 1][0];
+                else update_contig(c, q->pos, q->pos + 1, q->region[score->base - 1], (uint16_t)-1);
+            }
+            int32_t index = (score->kmer >> 4) - 1;
+            if (index < 0 || index >= SNP_NUM) { g_undefined = 1; return; }
+            q = sl->v[i - 1];
+            base = &c->b[q->pos].m;
+            g_sp_stats[8]++;
+            if (q->length == 1) base->base = q->region[index][0];
+            else update_contig(c, q->pos, q->pos + 1, q->region[index], (uint16_t)-1);
+            if (q->link.n > 0) {
+                score = slot_get_score(base, (uint16_t)(index + 1));
+                if (!score) { g_undefined = 1; return; }
+            } else {
+                score = NULL;
+            }
+        }
+    }
+}
+
+/* snp_phase (snpphase.c:87-134) */
+char* np1o_snp_phase(const np1o_contig* sr, const np1o_contig* lr, const np1o_configure* cfg, int32_t* out_len) {
+    g_updates = 0;
+    g_undefined = 0;
+    memset(g_sp_stats, 0, sizeof(g_sp_stats));
+    if (sr->length <= 0) { *out_len = 0; return (char*)calloc(1, 1); }
+    octg* c = ctg_init(sr, cfg);
+    int32_t span_sr = stream_max_span(sr), span_lr = stream_max_span(lr);
+    c->filter_kind = 0;
+    create_insert(c, 0, c->L - 1, span_sr);
+    c->shift = 16;
+    parse_region(c, 0, c->L - 1, 2, span_sr);
+    c->shift = 4;
+    snplist sl = {0, 0, 0};
+    sp_find_snps(c, 0, c->L - 1, &sl);
+    g_sp_stats[0] = sl.n;
+    ilist nodepth = get_region(c, 0, c->L - 1, cfg->ext_len_edge, 0, FLAG_DEPTH, brim_no_ext);
+    if (nodepth.n > 0) {
+        merge_region(&nodepth);
+        for (int i = 0; i < nodepth.n; i += 2) update_flag(c, nodepth.v[i], nodepth.v[i + 1], FLAG_INSERT);
+    }
+    c->in = lr;
+    c->filter_kind = 2;
+    c->insflag = FLAG_INSERT | FLAG_SNP;
+    create_insert(c, 0, c->L - 1, span_lr);
+    c->insflag = 0;
+    sp_filter_snps(c, &sl, sr, lr, span_sr, span_lr);
+    g_sp_stats[1] = g_undefined ? 0 : sl.n;
+    g_sp_stats[6] = nodepth.n / 2;
+    if (!g_undefined && nodepth.n > 0) sp_correct_lower_depth(c, &nodepth, sr, lr, span_sr, span_lr);
+    free(nodepth.v);
+    if (!g_undefined && sl.n > 1) {
+        sp_find_snps_link(c, &sl, sr, lr, span_sr, span_lr);
+        if (!g_undefined) sp_snps_score(c, &sl);
+        if (!g_undefined) sp_snps_correct(c, &sl);
+    }
+    for (int32_t i = 0; i < sl.n; i++) snp_free(sl.v[i]);
+    free(sl.v);
+    char* out = NULL;
+    if (g_undefined) *out_len = -1;
+    else out = get_contig(c, 0, c->L - 1, FLAG_THIRD, out_len);
+    c->in = sr;
     ctg_free(c);
     return out;
 }

@@ -62,6 +62,10 @@ void np1o_default_config(np1o_configure* cfg);
 char* np1o_score_chain(const np1o_contig* c, const np1o_configure* cfg, int32_t* out_len);
 char* np1o_kmer_count(const np1o_contig* c, const np1o_configure* cfg, int32_t* out_len);
 char* np1o_snp_valid(const np1o_contig* c, const np1o_configure* cfg, int32_t* out_len);   /* task 4, source/lib/snpvalid.c */
+/* task 3, source/lib/snpphase.c: `sr` = the short-read records of the contig, `lr` = its long-read records (both with
+ * qualities).  NULL with *out_len = -1 where the reference's own result rests on a null / uninitialised read. */
+char* np1o_snp_phase(const np1o_contig* sr, const np1o_contig* lr, const np1o_configure* cfg, int32_t* out_len);
+void np1o_snp_phase_stats(int64_t out[10]);   /* what the stages of the last np1o_snp_phase call did (np1_oracle.c: g_sp_stats) */
 void np1o_free(void* p);
 
 /* Algorithmic update count of score_chain's pileup (one per slot vote), for throughput reports. */

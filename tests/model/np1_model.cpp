@@ -599,3 +599,256 @@ int np1m_regions(const uint8_t* code, const uint8_t* flag, int32_t L, const uint
     return overlap ? kc_merge_fast(out, n) : n;
 }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// snp_phase (task 3): the stage bodies of np1_phase.h driven the way np1_batch_snp_phase drives the kernels
+#include "../../nextpolish_amd/csrc/np1_phase.h"
+#include "../../nextpolish_amd/csrc/np1_phase_host.h"
+
+extern "C" int np1m_snp_phase(const np1_stream_view* vs, const np1_stream_view* vl, const Configure* cfg, char** out, uint32_t* bounds) {
+    using namespace np1p;
+    const uint32_t nc = (uint32_t)vs->n_contigs;
+    const uint64_t G = (uint64_t)vs->draft_len;
+    if ((uint32_t)vl->n_contigs != nc || (uint64_t)vl->draft_len != G) return -20;
+    if ((vs->qual_len == 0 && vs->n_reads > 0) || (vl->qual_len == 0 && vl->n_reads > 0)) return -10;
+    uint32_t err = 0;
+    SpParams P;
+    P.min_depth_snp = cfg->min_depth_snp; P.min_count_snp = cfg->min_count_snp; P.min_count_snp_link = cfg->min_count_snp_link;
+    P.max_variant_count_lgs = cfg->max_variant_count_lgs; P.read_len = cfg->read_len; P.ext_len_edge = cfg->ext_len_edge;
+    P.min_snp_factor_sgs = cfg->min_snp_factor_sgs; P.max_clip_ratio_lgs = cfg->max_clip_ratio_lgs; P.rate_lgs = cfg->indel_balance_factor_lgs;
+    P.max_indel_factor_lgs = cfg->max_indel_factor_lgs; P.max_snp_factor_lgs = cfg->max_snp_factor_lgs; P.ploidy = cfg->ploidy;
+    auto make_ctx = [&](const np1_stream_view* v, bool lr, std::vector<uint8_t>& level, std::vector<int32_t>& endpos) {
+        KcCtx c;
+        memset(&c, 0, sizeof(c));
+        c.R = ReadsDev{v->pos, v->ctg, v->flag, v->n_cigar, v->l_qseq, v->cigar_off, v->seq_off, v->cigar, v->seq};
+        c.mapq = v->mapq; c.isize = v->isize; c.qual_off = v->qual_off; c.qual = v->qual;
+        c.ctg_off = vs->ctg_off; c.read_begin = v->read_begin;
+        c.trim = cfg->trim_len_edge; c.ext_len_edge = cfg->ext_len_edge;
+        c.min_map_quality = cfg->min_map_quality; c.read_tlen = cfg->read_tlen;
+        c.max_clip_ratio_sgs = cfg->max_clip_ratio_sgs; c.min_count_ratio_skip = cfg->min_count_ratio_skip;
+        c.K = -1; c.rate = cfg->indel_balance_factor_lgs;
+        c.third_rule = 1; c.max_indel_factor_lgs = cfg->max_indel_factor_lgs; c.max_snp_factor_lgs = cfg->max_snp_factor_lgs;
+        c.err = &err;
+        const int64_t n = v->n_reads;
+        level.assign(n ? n : 1, 0); endpos.assign(n ? n : 1, 0);
+        int32_t max_span = 1;
+        for (int64_t r = 0; r < n; ++r) {
+            level[r] = lr ? (uint8_t)sp_lr_level(c.R, r, P.max_clip_ratio_lgs)
+                          : (uint8_t)kc_filter_level(c.R, r, c.mapq, c.isize, c.read_tlen, c.max_clip_ratio_sgs, c.min_map_quality);
+            endpos[r] = kc_endpos(c.R, r);
+            if (endpos[r] - v->pos[r] > max_span) max_span = endpos[r] - v->pos[r];
+        }
+        c.level = level.data(); c.endpos = endpos.data(); c.max_span = max_span;
+        return c;
+    };
+    std::vector<uint8_t> lev_s, lev_l;
+    std::vector<int32_t> end_s, end_l;
+    KcCtx cs = make_ctx(vs, false, lev_s, end_s), cl = make_ctx(vl, true, lev_l, end_l);
+    cl.keep_zero_marks = 1;
+    // P1: short-read columns, first slot space
+    std::vector<uint32_t> ins(G + 1, 0);
+    for (int64_t r = 0; r < vs->n_reads; ++r) if (lev_s[r] >= 1) sp_insert_record(cs.R, r, vs->ctg_off, ins.data(), 0, nullptr, nullptr);
+    std::vector<uint32_t> soff1(G + 2);
+    uint64_t acc = 0;
+    for (uint64_t g = 0; g < G; ++g) { soff1[g] = (uint32_t)acc; acc += 1 + ins[g]; }
+    soff1[G] = soff1[G + 1] = (uint32_t)acc;
+    const uint32_t S1 = (uint32_t)acc;
+    std::vector<uint8_t> info1(S1 + 64, 0), sbase1(S1 + 64), sflag1(S1 + 64), dec(S1 + 64, 0), top(S1 + 64, 0);
+    std::vector<uint32_t> sown1(S1 + 64, 0);
+    for (uint32_t ct = 0; ct < nc; ++ct)
+        for (uint32_t g = vs->ctg_off[ct]; g < vs->ctg_off[ct + 1]; ++g)
+            slotinfo_base((const uint8_t*)vs->draft, g, vs->ctg_off[ct], vs->ctg_off[ct + 1], soff1.data(), info1.data(), sown1.data());
+    for (uint32_t s = 0; s < S1; ++s) { sbase1[s] = info1[s] & 0xf; sflag1[s] = (info1[s] & SI_LOWER) ? 1 : 0; }
+    std::vector<uint16_t> scount1(S1 + 64, 0);
+    // P2: histogram
+    std::vector<uint32_t> cnt((size_t)S1 * 16 + 16, 0), first((size_t)S1 * 16 + 16, 0xffffffffu);
+    cs.soff = soff1.data();
+    for (int64_t r = 0; r < vs->n_reads; ++r) sp_hist_record(cs, r, cnt.data(), first.data());
+    // P3: slot verdicts (the walk of ts_find_snps stops on the main slot of each contig's last base)
+    for (uint32_t ct = 0; ct < nc; ++ct) {
+        const uint32_t g0 = vs->ctg_off[ct], g1 = vs->ctg_off[ct + 1];
+        if (g1 == g0) continue;
+        for (uint32_t s = soff1[g0]; s <= soff1[g1 - 1]; ++s)
+            sp_slot_decide(P, s, cnt.data(), first.data(), sbase1.data(), sflag1.data(), scount1.data(), dec.data(), top.data(), &err);
+    }
+    if (err) return (int)err;
+    // P4: sites
+    std::vector<uint8_t> dirty(G + 1, 0), alle(G + 1, 0);
+    std::vector<uint32_t> site_g, site_ctg, site_first(nc + 1, 0);
+    for (uint32_t ct = 0; ct < nc; ++ct) {
+        const uint32_t g0 = vs->ctg_off[ct], g1 = vs->ctg_off[ct + 1];
+        site_first[ct] = (uint32_t)site_g.size();
+        for (uint32_t g = g0; g < g1; ++g) {
+            dirty[g] = (uint8_t)sp_base_site(g, (int32_t)(g - g0), (int32_t)(g1 - g0), soff1.data(), dec.data(), top.data(), &alle[g]);
+            if (dirty[g]) { site_g.push_back(g); site_ctg.push_back(ct); sflag1[soff1[g]] |= F_SNP; }
+        }
+    }
+    site_first[nc] = (uint32_t)site_g.size();
+    const uint32_t NS = (uint32_t)site_g.size();
+    std::vector<int32_t> site_left(NS + 1), site_right(NS + 1), site_len(NS + 1, 1), site_pos(NS + 1);
+    for (uint32_t k = 0; k < NS; ++k) {
+        const uint32_t g0 = vs->ctg_off[site_ctg[k]];
+        site_pos[k] = (int32_t)(site_g[k] - g0);
+        sp_site_anchors(dirty.data() + g0, site_pos[k], (int32_t)(vs->ctg_off[site_ctg[k] + 1] - g0), &site_left[k], &site_right[k]);
+    }
+    // P5: low-depth regions, INSERT marks
+    std::vector<std::vector<int32_t>> nodepth(nc);
+    for (uint32_t ct = 0; ct < nc; ++ct) {
+        const uint32_t g0 = vs->ctg_off[ct], g1 = vs->ctg_off[ct + 1];
+        if (g1 == g0) continue;
+        std::vector<uint32_t> F;
+        for (uint32_t s = soff1[g0]; s <= soff1[g1 - 1]; ++s) if (sflag1[s] & F_DEPTH) F.push_back(s);
+        std::vector<int32_t> buf(2 * F.size() + 4);
+        int32_t n = sp_depth_regions(F.data(), (uint32_t)F.size(), soff1.data(), sown1.data(), g0, (int32_t)(g1 - g0), (uint32_t)P.ext_len_edge, P.ext_len_edge,
+                                     buf.data(), (int32_t)buf.size());
+        if (n < 0) return -21;
+        n = kc_merge_regions(buf.data(), n);
+        nodepth[ct].assign(buf.begin(), buf.begin() + n);
+        for (int32_t i = 0; i + 1 < n; i += 2)
+            for (uint32_t s = soff1[g0 + (uint32_t)buf[i]]; s <= soff1[g0 + (uint32_t)buf[i + 1]]; ++s) sflag1[s] |= F_INSERT;
+    }
+    // P6: long-read columns behind marked bases, second slot space
+    for (int64_t r = 0; r < vl->n_reads; ++r)
+        if (lev_l[r] >= 1) sp_insert_record(cl.R, r, vs->ctg_off, ins.data(), F_INSERT | F_SNP, soff1.data(), sflag1.data());
+    std::vector<uint32_t> soff(G + 2);
+    acc = 0;
+    for (uint64_t g = 0; g < G; ++g) { soff[g] = (uint32_t)acc; acc += 1 + ins[g]; }
+    soff[G] = soff[G + 1] = (uint32_t)acc;
+    const uint32_t S = (uint32_t)acc;
+    std::vector<uint8_t> sbase(S + 64), sflag(S + 64), slot_info(S + 64, 0);
+    std::vector<uint16_t> scount(S + 64, 0), srefk(S + 64, 0);
+    std::vector<uint32_t> sown(S + 64, 0);
+    for (uint64_t g = 0; g < G; ++g)
+        sp_reslot_base((uint32_t)g, soff1.data(), soff.data(), sbase1.data(), sflag1.data(), scount1.data(), sbase.data(), sflag.data(), scount.data(), sown.data());
+    for (uint32_t ct = 0; ct < nc; ++ct)
+        for (uint32_t g = vs->ctg_off[ct]; g < vs->ctg_off[ct + 1]; ++g)
+            slotinfo_base((const uint8_t*)vs->draft, g, vs->ctg_off[ct], vs->ctg_off[ct + 1], soff.data(), slot_info.data());
+    // shared slot state of both contexts
+    std::vector<uint32_t> lhead(S + 64, 0), lpool(2ull * (1u << 22));
+    uint32_t lcount = 0, stcount = 0, hcount = 0;
+    const uint32_t stcap = 1u << 20;
+    std::vector<long long> stsc(16ull * stcap);
+    std::vector<uint16_t> stkm(16ull * stcap);
+    std::vector<uint8_t> strk(16ull * stcap);
+    std::vector<uint8_t> hpool(64u << 20);
+    for (KcCtx* c : {&cs, &cl}) {
+        c->soff = soff.data(); c->sbase = sbase.data(); c->sflag = sflag.data(); c->srefk = srefk.data(); c->scount = scount.data();
+        c->lhead = lhead.data(); c->lpool = lpool.data(); c->lcap = 1u << 22; c->lcount = &lcount;
+        c->st_score = stsc.data(); c->st_kmer = stkm.data(); c->st_rank = strk.data(); c->st_cap = stcap; c->st_count = &stcount;
+        c->hpool = hpool.data(); c->hcap = (uint32_t)hpool.size(); c->hcount = &hcount;
+        c->sown = sown.data();
+    }
+    // P7: site verdicts
+    std::vector<uint32_t> roff(NS + 1, 0), rstride(NS + 1, 0);
+    uint32_t racc = 0;
+    for (uint32_t k = 0; k < NS; ++k) {
+        rstride[k] = soff[site_g[k] + 1] - soff[site_g[k]] + 1 + 8;
+        roff[k] = racc;
+        racc += 2 * rstride[k];
+    }
+    std::vector<uint8_t> rpool(racc + 16, 0), keep(NS + 1, 0);
+    for (uint32_t k = 0; k < NS; ++k) { rpool[roff[k]] = alle[site_g[k]] & 0xf; rpool[roff[k] + rstride[k]] = alle[site_g[k]] >> 4; }
+    SpSites SS{site_g.data(), site_ctg.data(), site_left.data(), site_right.data(), site_len.data(), keep.data(), roff.data(), rstride.data(), rpool.data()};
+    for (uint32_t k = 0; k < NS; ++k) {
+        hcount = 0;
+        sp_site_verdict(cs, cl, P, SS, k, soff1.data(), cnt.data(), first.data());
+    }
+    if (err) return (int)err;
+    // P9: low-depth regions
+    for (uint32_t ct = 0; ct < nc; ++ct)
+        for (size_t i = 0; i + 1 < nodepth[ct].size(); i += 2) {
+            stcount = 0;
+            sp_lowdepth_region(cs, cl, ct, nodepth[ct][i], nodepth[ct][i + 1]);
+        }
+    if (err) return (int)err;
+    // kept sites, per contig
+    std::vector<uint32_t> k_first(nc + 1, 0), k_roff, k_rstride;
+    std::vector<int32_t> k_pos, k_len;
+    std::vector<uint32_t> k_g;
+    for (uint32_t ct = 0; ct < nc; ++ct) {
+        k_first[ct] = (uint32_t)k_pos.size();
+        for (uint32_t k = site_first[ct]; k < site_first[ct + 1]; ++k)
+            if (keep[k]) { k_pos.push_back(site_pos[k]); k_len.push_back((int32_t)(int16_t)site_len[k]); k_roff.push_back(roff[k]); k_rstride.push_back(rstride[k]); k_g.push_back(site_g[k]); }
+    }
+    k_first[nc] = (uint32_t)k_pos.size();
+    const uint32_t NK = (uint32_t)k_pos.size();
+    std::vector<int32_t> lk_num(4ull * NK + 4, 0), lk_mq(4ull * NK + 4, 0), lk_q(4ull * NK + 4, 0), lk_total(NK + 1, 0);
+    std::vector<unsigned long long> lk_first(4ull * NK + 4, ~0ull);
+    SpLinks LK{k_first.data(), k_pos.data(), k_len.data(), k_roff.data(), k_rstride.data(), rpool.data(), lk_num.data(), lk_mq.data(), lk_q.data(), lk_first.data(), lk_total.data()};
+    const int32_t bcap = P.max_variant_count_lgs + 4096;
+    std::vector<uint8_t> lbytes((size_t)bcap + 16);
+    std::vector<SpEntry> lents(1u << 16);
+    // the remembered orientation of every kept site
+    std::vector<std::vector<SpHostSite>> hs(nc);
+    auto host_sites = [&](uint32_t ct) {
+        std::vector<SpHostSite> v;
+        for (uint32_t k = site_first[ct], kk = k_first[ct]; k < site_first[ct + 1]; ++k) {
+            if (!keep[k]) continue;
+            SpHostSite h;
+            memset(&h, 0, sizeof(h));
+            h.pos = site_pos[k]; h.left = site_left[k]; h.right = site_right[k]; h.len = k_len[kk];
+            h.flag = sflag[soff[site_g[k]]];
+            h.total = lk_total[kk];
+            for (int t = 0; t < 4; ++t) { h.num[t] = lk_num[4ull * kk + t]; h.mapqual[t] = lk_mq[4ull * kk + t]; h.qual[t] = lk_q[4ull * kk + t]; h.first[t] = lk_first[4ull * kk + t]; }
+            v.push_back(h);
+            ++kk;
+        }
+        return v;
+    };
+    for (uint32_t ct = 0; ct < nc; ++ct) {
+        if (k_first[ct + 1] - k_first[ct] <= 1) continue;
+        const uint32_t g0 = vs->ctg_off[ct];
+        // P10a: short-read links
+        std::vector<SpHostSite> h = host_sites(ct);
+        std::vector<int32_t> reg = sp_link_regions(h, P.read_len, F_SNP);
+        for (size_t i = 0; i + 1 < reg.size(); i += 2) {
+            const int64_t rb = (int64_t)vs->read_begin[ct], re = (int64_t)vs->read_begin[ct + 1];
+            for (int64_t r = kc_lower_bound_pos(cs.R, rb, re, reg[i] - cs.max_span); r < re; ++r) {
+                if (cs.R.pos[r] >= reg[i + 1] + 1) break;
+                if (end_s[r] <= reg[i] || lev_s[r] != 2) continue;
+                sp_link_record(cs, P, LK, r, ct, reg[i], reg[i + 1], 0, (unsigned long long)(i / 2) << 32 | (unsigned long long)(r - rb), lents.data(), (uint32_t)lents.size(),
+                               lbytes.data(), bcap);
+            }
+        }
+        if (err) return (int)err;
+        // marks, long-read regions
+        h = host_sites(ct);
+        for (auto& m : sp_link_marks(h, P.min_count_snp_link)) sflag[soff[g0 + (uint32_t)m.first]] |= m.second;
+        h = host_sites(ct);
+        reg = sp_link_regions(h, P.max_variant_count_lgs, 0);
+        for (size_t i = 0; i + 1 < reg.size(); i += 2) {
+            const int64_t rb = (int64_t)vl->read_begin[ct], re = (int64_t)vl->read_begin[ct + 1];
+            for (int64_t r = kc_lower_bound_pos(cl.R, rb, re, reg[i] - cl.max_span); r < re; ++r) {
+                if (cl.R.pos[r] >= reg[i + 1] + 1) break;
+                if (end_l[r] <= reg[i] || lev_l[r] != 1) continue;
+                sp_link_record(cl, P, LK, r, ct, reg[i], reg[i + 1], 1, 1ull << 63 | (unsigned long long)(i / 2) << 32 | (unsigned long long)(r - rb), lents.data(),
+                               (uint32_t)lents.size(), lbytes.data(), bcap);
+            }
+        }
+        if (err) return (int)err;
+        // the chain, then the writes
+        h = host_sites(ct);
+        std::vector<int8_t> choice;
+        if (!sp_chain(h, P.ploidy, &choice)) return (int)ERR_SP_UNDEFINED;
+        for (uint32_t t = 0; t < (uint32_t)h.size(); ++t) {
+            if (choice[t] < 0) continue;
+            const uint32_t kk = k_first[ct] + t;
+            const uint8_t* reg_b = rpool.data() + k_roff[kk] + (uint32_t)choice[t] * k_rstride[kk];
+            const uint32_t sb = soff[k_g[kk]];
+            if (k_len[kk] == 1) sbase[sb] = reg_b[0];
+            else for (uint32_t s = sb; s < soff[k_g[kk] + 1]; ++s) sbase[s] = reg_b[s - sb];
+        }
+    }
+    if (err) return (int)err;
+    std::vector<uint16_t> slot_res(S + 64);
+    for (uint32_t s = 0; s < S; ++s) slot_res[s] = (uint16_t)(sbase[s] | sflag[s] << 8);
+    std::vector<uint32_t> opos(S + 1);
+    uint32_t o = 0;
+    for (uint32_t s = 0; s < S; ++s) { opos[s] = o; o += (slot_res[s] & 0xff) != 3; }
+    opos[S] = o;
+    char* buf = (char*)calloc(1, (size_t)o + 1);
+    for (uint32_t s = 0; s < S; ++s) emit_slot(s, slot_res.data(), slot_info.data(), opos.data(), F_THIRD, (uint8_t*)buf);
+    for (uint32_t ct = 0; ct <= nc; ++ct) bounds[ct] = opos[soff[vs->ctg_off[ct]]];
+    *out = buf;
+    return 0;
+}

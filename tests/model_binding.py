@@ -20,6 +20,9 @@ def lib():
         L.np1m_kmer_count.restype = C.c_int
         L.np1m_snp_valid.argtypes = L.np1m_kmer_count.argtypes
         L.np1m_snp_valid.restype = C.c_int
+        L.np1m_snp_phase.argtypes = [C.POINTER(nat.StreamView), C.POINTER(nat.StreamView), C.POINTER(nat.Configure), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_uint32)]
+        L.np1m_snp_phase.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -67,3 +70,18 @@ def snp_valid(stream, cfg):
     blob = C.string_at(out, bounds[stream.n_contigs])
     lib().np1m_free(out)
     return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)]
+
+
+def snp_phase(sr, lr, cfg):
+    """snp_phase (task 3) through the stage bodies of np1_phase.h driven the way the kernels drive them; ValueError where the
+    reference has no defined result (the product's ERR_SP_UNDEFINED)."""
+    out = C.c_void_p()
+    bounds = (C.c_uint32 * (sr.n_contigs + 1))()
+    rc = lib().np1m_snp_phase(C.byref(sr.view), C.byref(lr.view), C.byref(cfg), C.byref(out), bounds)
+    if rc > 0 and rc & 1024:
+        raise ValueError("undefined upstream")
+    if rc != 0:
+        raise RuntimeError("snp_phase model failed rc=%d" % rc)
+    blob = C.string_at(out, bounds[sr.n_contigs])
+    lib().np1m_free(out)
+    return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(sr.n_contigs)]

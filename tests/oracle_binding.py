@@ -47,6 +47,8 @@ def lib():
         L.np1o_kmer_count.restype = C.c_void_p
         L.np1o_snp_valid.argtypes = [C.POINTER(OContig), C.POINTER(OConfigure), C.POINTER(C.c_int32)]
         L.np1o_snp_valid.restype = C.c_void_p
+        L.np1o_snp_phase.argtypes = [C.POINTER(OContig), C.POINTER(OContig), C.POINTER(OConfigure), C.POINTER(C.c_int32)]
+        L.np1o_snp_phase.restype = C.c_void_p
         L.np1o_free.argtypes = [C.c_void_p]
         L.np1o_last_update_count.restype = C.c_int64
         _LIB = L
@@ -109,3 +111,22 @@ def kmer_count(stream, i, cfg):
 
 def snp_valid(stream, i, cfg):
     return _run(lib().np1o_snp_valid, stream, i, cfg)
+
+
+def snp_phase(sr, lr, i, cfg):
+    """task 3: contig i of the short-read stream `sr` and of the long-read stream `lr` (same drafts, both with qualities);
+    None where the reference's own result is undefined"""
+    a, b = contig_view(sr, i), contig_view(lr, i)
+    n = C.c_int32(0)
+    p = lib().np1o_snp_phase(C.byref(a), C.byref(b), C.byref(cfg), C.byref(n))
+    if not p:
+        return None
+    s = C.string_at(p, n.value).decode()
+    lib().np1o_free(p)
+    return s
+
+
+def snp_phase_stats():
+    a = (C.c_int64 * 10)()
+    lib().np1o_snp_phase_stats(a)
+    return list(a)

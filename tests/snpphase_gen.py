@@ -1,0 +1,143 @@
+"""Diploid workloads for task 3 (snp_phase, reference: source/lib/snpphase.c): one draft, short reads and long reads drawn from
+two haplotypes that differ from each other by substitutions and small indels, the draft carrying its own errors.  Deterministic
+per seed.  Returns (contigs, short_reads, long_reads) in the form `nextpolish_amd._native.Stream.from_reads` takes."""
+import random
+
+B = "ACGT"
+
+
+def _other(rng, b):
+    return rng.choice([x for x in B if x != b])
+
+
+def _mutate(rng, seq, sub, ins, dele, max_indel=3):
+    """-> list of (truth_index | None, base) : an edited copy of seq that remembers where each base came from"""
+    out = []
+    i = 0
+    n = len(seq)
+    while i < n:
+        x = rng.random()
+        if x < sub:
+            out.append((i, _other(rng, seq[i]))); i += 1
+        elif x < sub + ins:
+            for _ in range(rng.randint(1, max_indel)):
+                out.append((None, rng.choice(B)))
+            out.append((i, seq[i])); i += 1
+        elif x < sub + ins + dele:
+            i += rng.randint(1, max_indel)
+        else:
+            out.append((i, seq[i])); i += 1
+    return out
+
+
+def _align_columns(hap, draft_of_truth):
+    """hap: list of (truth_index|None, base); draft_of_truth: dict truth_index -> draft_index (monotone) or missing.
+    -> list of (draft_index | None, base) in hap order: None = base absent from the draft"""
+    return [(draft_of_truth.get(t) if t is not None else None, b) for t, b in hap]
+
+
+def _read_from(rng, cols, lo, hi, err, L):
+    """cols[lo:hi] -> (pos, cigar, seq) against the draft; cols entries are (draft_index|None, base) with increasing indices"""
+    seg = cols[lo:hi]
+    # first and last aligned columns
+    a = next((k for k, (d, _) in enumerate(seg) if d is not None), None)
+    if a is None:
+        return None
+    z = max(k for k, (d, _) in enumerate(seg) if d is not None)
+    seq, cig = [], []
+
+    def add(op, n=1):
+        if cig and cig[-1][0] == op:
+            cig[-1] = (op, cig[-1][1] + n)
+        else:
+            cig.append((op, n))
+
+    if a:
+        add("S", a)
+        seq += [b for _, b in seg[:a]]
+    pos = seg[a][0]
+    cur = pos
+    for d, b in seg[a:z + 1]:
+        if rng.random() < err:
+            b = _other(rng, b)
+        if d is None:
+            add("I"); seq.append(b)
+        else:
+            if d > cur:
+                add("D", d - cur)
+            add("M"); seq.append(b)
+            cur = d + 1
+    if z + 1 < len(seg):
+        add("S", len(seg) - z - 1)
+        seq += [b for _, b in seg[z + 1:]]
+    if not any(o == "M" for o, _ in cig):
+        return None
+    # an insertion straight after a deletion or before the first match is legal BAM; keep what falls out
+    return pos, cig, "".join(seq)
+
+
+def make_case(seed, lens=(3000,), sr_depth=40, lr_depth=25, het=0.004, het_indel=0.0005, draft_err=0.002, sr_err=0.003, lr_err=0.04,
+              read_len=100, frag=300, lr_len=1500, lower=0.0, sr_holes=0):
+    rng = random.Random(seed)
+    contigs, srs, lrs = [], [], []
+    for c, Lt in enumerate(lens):
+        truth = [rng.choice(B) for _ in range(Lt)]
+        haps = [[(i, b) for i, b in enumerate(truth)], _mutate(rng, truth, het, het_indel, het_indel)]
+        dr = _mutate(rng, truth, draft_err * 0.5, draft_err * 0.25, draft_err * 0.25)
+        draft = [b for _, b in dr]
+        if lower:
+            draft = [b.lower() if rng.random() < lower else b for b in draft]
+        d_of_t = {}
+        for k, (t, _) in enumerate(dr):
+            if t is not None:
+                d_of_t[t] = k
+        cols = [_align_columns(h, d_of_t) for h in haps]
+        contigs.append(("tig%d" % c, "".join(draft)))
+        holes = []
+        for _ in range(sr_holes):
+            a = rng.randrange(max(1, Lt - 200))
+            holes.append((a, a + rng.randint(40, 200)))
+        n_pairs = int(sr_depth * Lt / (2 * read_len))
+        for _ in range(n_pairs):
+            h = rng.randrange(2)
+            n = len(cols[h])
+            f = max(read_len + 1, int(rng.gauss(frag, 30)))
+            if f >= n:
+                continue
+            s = rng.randrange(n - f)
+            if any(a <= s <= b or a <= s + f <= b for a, b in holes):
+                continue
+            mates = []
+            for lo in (s, s + f - read_len):
+                r = _read_from(rng, cols[h], lo, lo + read_len, sr_err, len(draft))
+                mates.append(r)
+            if mates[0] is None or mates[1] is None:
+                continue
+            isz = mates[1][0] + read_len - mates[0][0]
+            for m, (pos, cig, seq) in enumerate(mates):
+                srs.append(dict(ctg=c, pos=pos, flag=(0x1 | 0x2 | (0x40 if m == 0 else 0x80) | (0x20 if m == 0 else 0x10)), mapq=rng.choice([60, 60, 60, 40, 20, 3]),
+                                isize=isz if m == 0 else -isz, cigar=cig, seq=seq, qual=bytes(rng.randint(20, 40) for _ in seq)))
+        n_lr = int(lr_depth * Lt / lr_len)
+        for _ in range(n_lr):
+            h = rng.randrange(2)
+            n = len(cols[h])
+            ln = min(n - 1, max(200, int(rng.gauss(lr_len, lr_len / 3))))
+            s = rng.randrange(n - ln)
+            # long-read errors: substitutions through err, indels by dropping / doubling columns
+            seg = []
+            for d, b in cols[h][s:s + ln]:
+                x = rng.random()
+                if x < lr_err * 0.3:
+                    continue
+                if x < lr_err * 0.6:
+                    seg.append((None, rng.choice(B)))
+                seg.append((d, b))
+            r = _read_from(rng, seg, 0, len(seg), lr_err * 0.4, len(draft))
+            if r is None:
+                continue
+            pos, cig, seq = r
+            lrs.append(dict(ctg=c, pos=pos, flag=rng.choice([0, 16]), mapq=rng.choice([60, 60, 30, 10]), isize=0, cigar=cig, seq=seq,
+                            qual=bytes(rng.randint(5, 25) for _ in seq)))
+    srs.sort(key=lambda r: (r["ctg"], r["pos"]))
+    lrs.sort(key=lambda r: (r["ctg"], r["pos"]))
+    return contigs, srs, lrs
