@@ -240,6 +240,11 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms);
 int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms);
 /* task 4 on an uploaded batch (reference: source/lib/snpvalid.c:3-36 snp_valid; needs a stream loaded with qualities) */
 int np1_batch_snp_valid(np1_batch* b, const Configure* cfg, float* stage_ms);
+/* task 3 on two uploaded batches of the same contigs (reference: source/lib/snpphase.c:87-134 snp_phase): `sr` = the short-read
+ * records (the reference's -b BAM), `lr` = the long-read records (its third BAM), both loaded with qualities and uploaded on the
+ * same context.  cfg->read_len / read_tlen as config_init sets them.  The result lands in `sr` (np1_batch_result_*).  Inputs for
+ * which the reference itself reads through a null or unset pointer fail with an error message instead of a result. */
+int np1_batch_snp_phase(np1_batch* sr, np1_batch* lr, const Configure* cfg);
 /* Blocks until the batch's work is complete. */
 int np1_batch_sync(np1_batch* b);
 /* Polished length of contig i (valid after a completed run), and copy-out of its NUL-terminated string. */

@@ -185,9 +185,33 @@ static PolishResult* kmer_task(const char* tigname, Configure* cfg, bool snp_val
 PolishResult* kmer_count(const char* tigname, Configure* cfg) { return kmer_task(tigname, cfg, false); }
 /* task 4 (reference: source/lib/snpvalid.c:3-36) */
 PolishResult* snp_valid(const char* tigname, Configure* cfg) { return kmer_task(tigname, cfg, true); }
+/* task 3 (reference: source/lib/snpphase.c:87-134): short reads from cfg->bamfn, long reads from cfg->thirdbamfn */
 PolishResult* snp_phase(const char* tigname, Configure* cfg) {
-    (void)tigname; (void)cfg;
-    die("snp_phase (task 3) is outside the accelerated hot path (experimental upstream; DESIGN.md)");
+    if (!cfg || !cfg->fastafn) die("snp_phase: configuration without a FASTA");
+    if (!cfg->bamfn) die("snp_phase: short-read BAM missing or unreadable");
+    if (!cfg->thirdbamfn) die("snp_phase: long-read BAM missing or unreadable (the reference dereferences a null index here)");
+    np1_stream ss, sl;
+    std::string err;
+    if (!np::load_stream(cfg->fastafn, cfg->bamfn, {std::string(tigname)}, true, &ss.s, &err)) die(err);
+    if (!np::load_stream(cfg->fastafn, cfg->thirdbamfn, {std::string(tigname)}, true, &sl.s, &err)) die(err);
+    np1_ctx* ctx = process_ctx();
+    np1_batch* b = np1_batch_upload(ctx, &ss);
+    if (!b) die(np1_last_error());
+    np1_batch* l = np1_batch_upload(ctx, &sl);
+    if (!l) die(np1_last_error());
+    if (np1_batch_snp_phase(b, l, cfg) != 0) die(np1_last_error());
+    int64_t len = np1_batch_result_len(b, 0);
+    PolishResult* res = (PolishResult*)calloc(sizeof(PolishResult), 1);
+    res->contig = (char*)calloc(1, (size_t)len + 1);
+    if (np1_batch_result_copy(b, 0, res->contig, len + 1) != 0) die(np1_last_error());
+    res->length = (int32_t)len;
+    if (cfg->trace_polish_open) {   // the change list is not produced for tasks 2-4: an empty list, like a run that changed nothing
+        res->data = (PolishPoint*)calloc(1, sizeof(PolishPoint));
+        res->datalength = 0;
+    }
+    np1_batch_free(l);
+    np1_batch_free(b);
+    return res;
 }
 PolishResult* lgspolish(const char* tigname, Configure* cfg) {
     (void)tigname; (void)cfg;

@@ -61,6 +61,7 @@ struct np1_batch {
         kc_partoff, kc_pt_ctg, kc_pt_se, kc_pt_len, kc_woff, kc_wpool, kc_haswin;
     // snp_valid: second-round work (regions nothing spanned, their split values and parts)
     np1dev::DevBuf sv_failse, sv_failcnt, sv_vsz, sv_voff, sv_val, sv_p2ctg, sv_p2se, sv_p2len, sv_woff2, sv_haswin2, sv_range;
+    std::vector<np1dev::DevBuf> spw;   // snp_phase work buffers (np1_phase_device.hip), owned by the short-read batch
     bool has_qual = false;
     std::vector<uint64_t> h_read_begin;
     np1dev::DevBuf qs, qe, span, ins, soff, slot_info, rbase, capb, rowoff, rows, meta, chunk_first, chunk_last, slot_res,
@@ -118,6 +119,7 @@ struct np1_batch {
                                &sv_p2ctg, &sv_p2se, &sv_p2len, &sv_woff2, &sv_haswin2, &sv_range};
         size_t t = 0;
         for (const np1dev::DevBuf* b : all) t += b->cap;
+        for (const np1dev::DevBuf& b : spw) t += b.cap;
         return t;
     }
     void release_all() {
@@ -131,6 +133,7 @@ struct np1_batch {
                          &kc_pt_len, &kc_woff, &kc_wpool, &kc_haswin, &sv_failse, &sv_failcnt, &sv_vsz, &sv_voff, &sv_val, &sv_p2ctg,
                          &sv_p2se, &sv_p2len, &sv_woff2, &sv_haswin2, &sv_range};
         for (np1dev::DevBuf* b : all) b->release();
+        for (np1dev::DevBuf& b : spw) b.release();
     }
 };
 

@@ -78,6 +78,7 @@ NP1_HD void sp_site_verdict(const KcCtx& sr, const KcCtx& lr, const SpParams& P,
     const int32_t nins = (int32_t)(c.soff[g + 1] - sb - 1);
     int32_t length = 1, start = i, end = i, total = 0;
     bool flag = false, have_ks = false;
+    if (nins <= 0 && (int32_t)c.scount[sb] > P.min_count_snp) { S.keep[k] = 1; return; }   // the common site: covered well, no columns -- kept as found
     // spanning records of both streams (swapped-interval query, contig.c:1130-1135): pos < start, endpos > end + 1
     const int32_t end_q = nins > 0 ? i + 1 : i;
     const int64_t srb = (int64_t)sr.read_begin[ct], sre = (int64_t)sr.read_begin[ct + 1];

@@ -34,6 +34,12 @@ class Batch(object):
         if nat.lib().np1_batch_snp_valid(self.handle, C.byref(cfg), None) != 0:
             raise RuntimeError("np1_batch_snp_valid: " + nat.last_error())
 
+    def snp_phase(self, long_reads, cfg):
+        """Task 3 (reference: source/lib/snpphase.c): this batch holds the short reads, `long_reads` is the Batch of the long reads
+        of the same contigs (both streams loaded with qualities, same context).  The result lands in this batch."""
+        if nat.lib().np1_batch_snp_phase(self.handle, long_reads.handle, C.byref(cfg)) != 0:
+            raise RuntimeError("np1_batch_snp_phase: " + nat.last_error())
+
     def results(self):
         L = nat.lib()
         out = []

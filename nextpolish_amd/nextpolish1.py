@@ -12,7 +12,8 @@ Same command line, same block-file / resume / naming behaviour, same output reco
   reference: nextpolish1.py:181-189,223-224 and source/nextPolish:93-117 for the block split).
 * ``-debug`` needs the per-base change list of the drop-in ABI and therefore goes contig by contig through
   ``score_chain(tigname, cfg)`` exactly like the reference worker (nextpolish1.py:181-189).
-* tasks 3 and 5 call the library's drop-in symbols, which report that they are not available on the GPU path.
+* task 3 (snp_phase: short reads + long reads of one contig) goes contig by contig through the drop-in symbol ``snp_phase(tigname, cfg)``,
+  which runs the device pass of np1_phase_device.hip; task 5 reports that it is not available (the reference's own caller refuses it).
 
 Record order is the order of the block file / FASTA (the reference's order is nondeterministic: it
 iterates a Python set through imap_unordered, nextpolish1.py:148-161,224).

@@ -1,0 +1,272 @@
+"""Task 3 (snp_phase, reference: source/lib/snpphase.c:87-903): short reads and long reads of the same contig find the heterozygous
+sites, settle them where the evidence is one-sided, correct the low-depth stretches with both streams and phase neighbouring sites
+through the reads that link them.  CPU: the oracle restatement against goldens the compiled reference produced (real bwa + minimap2
+alignments and seeded diploid workloads) and against the compiled reference itself; the device's stage bodies driven on the host
+(tests/model) against the oracle.  GPU: the product (np1_batch_snp_phase, the drop-in `snp_phase` symbol, the CLI, the Python
+caller) against the oracle and the same goldens.
+
+Inputs for which the reference reads through a null or unset pointer make the oracle return None and the product fail loudly."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import oracle_binding as ob
+import snpphase_gen
+from conftest import parse_cli_fasta, ref_binary
+from nextpolish_amd import _native as nat
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REAL = os.path.join(HERE, "golden", "real")
+GOLD = json.load(open(os.path.join(HERE, "golden", "snpphase_golden.json")))
+
+
+def digest(s):
+    return {"len": len(s), "md5": hashlib.md5(s.encode()).hexdigest()}
+
+
+def streams(params):
+    ctgs, srs, lrs = snpphase_gen.make_case(**params)
+    return nat.Stream.from_reads(ctgs, srs), nat.Stream.from_reads(ctgs, lrs)
+
+
+def fuzz_params(seed):
+    return dict(seed=seed, lens=(600 + 37 * (seed % 13), 2500 + (seed % 7) * 300), sr_depth=[4, 8, 15, 30, 60][seed % 5], lr_depth=[3, 10, 25, 40][seed % 4],
+                het=[0.002, 0.01, 0.03][seed % 3], het_indel=[0.0, 0.001, 0.005][(seed // 3) % 3], draft_err=[0.001, 0.01][(seed // 2) % 2],
+                lower=[0, 0.1][(seed // 5) % 2], sr_holes=[0, 2, 5][(seed // 7) % 3], lr_err=[0.02, 0.08][(seed // 11) % 2], lr_len=[800, 1500, 3000][(seed // 13) % 3])
+
+
+def real_streams(g):
+    fa = os.path.join(REAL, g["fasta"])
+    return nat.Stream.load(fa, os.path.join(REAL, g["sr"]), with_qual=True), nat.Stream.load(fa, os.path.join(REAL, g["lr"]), with_qual=True)
+
+
+def real_cfg(g):
+    """(read_tlen, read_len) as config_init derives them from the short-read BAM"""
+    cfgp = nat.lib().config_init(os.path.join(REAL, g["fasta"]).encode(), os.path.join(REAL, g["sr"]).encode(), os.path.join(REAL, g["lr"]).encode())
+    v = cfgp.contents.read_tlen, cfgp.contents.read_len
+    nat.lib().config_destory(cfgp)
+    return v
+
+
+# ------------------------------------------------------------------------------------------------------------ CPU
+
+
+@pytest.mark.parametrize("k", range(len(GOLD["synth"])))
+def test_oracle_matches_reference_goldens_synth(k):
+    g = GOLD["synth"][k]
+    s, l = streams(g["params"])
+    cfg = ob.default_config(read_tlen=g["read_tlen"], read_len=g["read_len"])
+    for i, exp in enumerate(g["snp_phase"]):
+        assert digest(ob.snp_phase(s, l, i, cfg)) == exp, "synth %d contig %d" % (k, i)
+
+
+@pytest.mark.parametrize("tag", sorted(GOLD["real"]))
+def test_oracle_matches_reference_goldens_real_alignments(tag):
+    g = GOLD["real"][tag]
+    s, l = real_streams(g)
+    tlen, rlen = real_cfg(g)
+    cfg = ob.default_config(read_tlen=tlen, read_len=rlen)
+    for i, n in enumerate(s.names):
+        assert digest(ob.snp_phase(s, l, i, cfg)) == g["snp_phase"][n], "%s %s" % (tag, n)
+
+
+def test_the_workloads_reach_every_stage():
+    """sites found / kept / with insertion columns / asked of the long reads, long-read votes, settled sites, low-depth regions,
+    links, sites re-written by the chain, long-read links: all of it happens in the goldens' inputs (np1_oracle.c: g_sp_stats)"""
+    tot = [0] * 10
+    for g in GOLD["synth"]:
+        s, l = streams(g["params"])
+        cfg = ob.default_config(read_tlen=g["read_tlen"], read_len=g["read_len"])
+        for i in range(s.n_contigs):
+            ob.snp_phase(s, l, i, cfg)
+            tot = [a + b for a, b in zip(tot, ob.snp_phase_stats())]
+    g = GOLD["real"]["s30+ont"]     # (a site settled by its spanning reads is rare in the small synthetic contigs)
+    s, l = real_streams(g)
+    tlen, rlen = real_cfg(g)
+    for i in range(s.n_contigs):
+        ob.snp_phase(s, l, i, ob.default_config(read_tlen=tlen, read_len=rlen))
+        tot = [a + b for a, b in zip(tot, ob.snp_phase_stats())]
+    assert all(t > 0 for t in tot), tot
+
+
+needs_ref = pytest.mark.skipif(ref_binary() is None, reason="oracle/_ref/nextpolish1 not built (needs /root/reference)")
+
+
+def run_ref3(fa, sr, lr):
+    p = subprocess.run([ref_binary(), "snpphase", fa, sr, lr], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+    return parse_cli_fasta(p.stdout.decode()) if p.returncode == 0 else None
+
+
+@needs_ref
+def test_goldens_still_match_compiled_reference():
+    for tag, g in GOLD["real"].items():
+        got = run_ref3(os.path.join(REAL, g["fasta"]), os.path.join(REAL, g["sr"]), os.path.join(REAL, g["lr"]))
+        assert {n: digest(s) for n, s in got.items()} == g["snp_phase"]
+
+
+@needs_ref
+def test_oracle_vs_reference_fuzz(tmp_path):
+    """Diploid contigs over a grid of depths, heterozygosity, indel rates, coverage holes and lower case (during development:
+    1 360 contigs, 0 differences, no crash of the reference)."""
+    fa, sr, lr = str(tmp_path / "s.fa"), str(tmp_path / "sr.bam"), str(tmp_path / "lr.bam")
+    compared = 0
+    for seed in range(1000, 1040):
+        s, l = streams(fuzz_params(seed))
+        s.write_files(fa, sr)
+        l.write_files(str(tmp_path / "l.fa"), lr)
+        ref = run_ref3(fa, sr, lr)
+        if ref is None:
+            continue
+        cfgp = nat.lib().config_init(fa.encode(), sr.encode(), lr.encode())
+        cfg = ob.default_config(read_tlen=cfgp.contents.read_tlen, read_len=cfgp.contents.read_len)
+        nat.lib().config_destory(cfgp)
+        for i, n in enumerate(s.names):
+            got = ob.snp_phase(s, l, i, cfg)
+            if got is None:
+                continue
+            assert got == ref[n], "seed %d contig %s" % (seed, n)
+            compared += 1
+    assert compared > 70
+
+
+def _model_case(s, l, tlen, rlen):
+    import model_binding as mb
+    cfg = nat.default_config()
+    cfg.read_tlen, cfg.read_len = tlen, rlen
+    ocfg = ob.default_config(read_tlen=tlen, read_len=rlen)
+    want = [ob.snp_phase(s, l, i, ocfg) for i in range(s.n_contigs)]
+    if any(w is None for w in want):
+        with pytest.raises(ValueError):
+            mb.snp_phase(s, l, cfg)
+        return False
+    assert mb.snp_phase(s, l, cfg) == want
+    return True
+
+
+def test_host_model_of_the_stage_bodies_matches_oracle():
+    """np1_phase.h (histogram, slot verdicts, sites and anchors, sparse low-depth walk, re-slotting, site verdicts, two-stream region
+    chain with the third-generation rule, link parser) and np1_phase_host.h (link regions, marks, chain) driven on the host the way
+    np1_batch_snp_phase drives the kernels (during development: 780 fuzzed contigs, 0 differences)."""
+    n = 0
+    for g in GOLD["synth"]:
+        s, l = streams(g["params"])
+        n += _model_case(s, l, g["read_tlen"], g["read_len"])
+    for seed in range(2000, 2030):
+        s, l = streams(fuzz_params(seed))
+        n += _model_case(s, l, 500, 100)
+    assert n > 30
+
+
+def test_host_model_on_real_alignments():
+    g = GOLD["real"]["s30+ont"]
+    s, l = real_streams(g)
+    assert _model_case(s, l, *real_cfg(g))
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from nextpolish_amd import device
+    c = device.Context(0)
+    yield c
+    c.close()
+
+
+def _check(ctx, s, l, read_tlen=500, read_len=100):
+    """product == oracle per contig; a batch holding a contig the reference has no result for must fail loudly"""
+    cfg = nat.default_config()
+    cfg.read_tlen, cfg.read_len = read_tlen, read_len
+    ocfg = ob.default_config(read_tlen=read_tlen, read_len=read_len)
+    want = [ob.snp_phase(s, l, i, ocfg) for i in range(s.n_contigs)]
+    b, bl = ctx.upload(s), ctx.upload(l)
+    try:
+        if any(w is None for w in want):
+            with pytest.raises(RuntimeError, match="no defined result"):
+                b.snp_phase(bl, cfg)
+            return False
+        b.snp_phase(bl, cfg)
+        got = b.results()
+    finally:
+        bl.close()
+        b.close()
+    for i in range(s.n_contigs):
+        assert len(got[i]) == len(want[i]), "contig %d: length %d != %d" % (i, len(got[i]), len(want[i]))
+        if got[i] != want[i]:
+            k = next(j for j in range(len(want[i])) if got[i][j] != want[i][j])
+            raise AssertionError("snp_phase contig %d differs at %d: %r vs %r" % (i, k, got[i][max(0, k - 8):k + 8], want[i][max(0, k - 8):k + 8]))
+    return True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(len(GOLD["synth"])))
+def test_gpu_matches_oracle_and_goldens_synth(ctx, k):
+    g = GOLD["synth"][k]
+    s, l = streams(g["params"])
+    assert _check(ctx, s, l, g["read_tlen"], g["read_len"])
+    cfg = nat.default_config()
+    cfg.read_tlen, cfg.read_len = g["read_tlen"], g["read_len"]
+    b, bl = ctx.upload(s), ctx.upload(l)
+    b.snp_phase(bl, cfg)
+    assert [digest(x) for x in b.results()] == g["snp_phase"]
+    bl.close()
+    b.close()
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle_on_fuzzed_diploids(ctx):
+    n = 0
+    for seed in range(3000, 3030):
+        s, l = streams(fuzz_params(seed))
+        n += 1 if _check(ctx, s, l) else 0
+    assert n > 20
+
+
+@pytest.mark.gpu
+def test_gpu_many_contigs_in_one_batch(ctx):
+    s, l = streams(dict(seed=77, lens=tuple(900 + 61 * k for k in range(24)), sr_depth=30, lr_depth=15, het=0.01, het_indel=0.002, sr_holes=1))
+    assert _check(ctx, s, l)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(GOLD["real"]))
+def test_gpu_batches_of_real_alignments(ctx, tag):
+    g = GOLD["real"][tag]
+    s, l = real_streams(g)
+    tlen, rlen = real_cfg(g)
+    assert _check(ctx, s, l, tlen, rlen)
+
+
+@pytest.mark.gpu
+def test_gpu_dropin_symbol_cli_and_caller_on_real_alignments(tmp_path):
+    """snp_phase(tigname, cfg) like source/lib/nextpolish1.py:95-96,220; `nextpolish1 snpphase fa bam bam3` like main.c:7-8,39; the
+    Python caller with -t 3."""
+    g = GOLD["real"]["s30+ont"]
+    fa, sr, lr = os.path.join(REAL, g["fasta"]), os.path.join(REAL, g["sr"]), os.path.join(REAL, g["lr"])
+    L = nat.lib()
+    L.snp_phase.restype = C.POINTER(nat.PolishResult)
+    L.snp_phase.argtypes = [C.c_char_p, C.POINTER(nat.Configure)]
+    cfg = L.config_init(fa.encode(), sr.encode(), lr.encode())
+    for n in sorted(g["snp_phase"]):
+        r = L.snp_phase(n.encode(), cfg)
+        assert digest(C.string_at(r.contents.contig).decode()) == g["snp_phase"][n], n
+        L.polishresult_destory(r)
+    L.config_destory(cfg)
+    exe = os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1")
+    p = subprocess.run([exe, "snpphase", fa, sr, lr], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert {n: digest(x) for n, x in parse_cli_fasta(p.stdout).items()} == g["snp_phase"]
+    out = str(tmp_path / "o.fa")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "nextpolish_amd", "nextpolish1.py"), "-g", fa, "-t", "3", "-s", sr, "-l", lr, "-o", out],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    recs = open(out).read().strip().split("\n")
+    got = {recs[k].split()[0][1:]: recs[k + 1] for k in range(0, len(recs), 2)}
+    assert {n.rsplit("_np", 1)[0]: digest(x) for n, x in got.items()} == {n.rsplit("_np", 1)[0]: d for n, d in g["snp_phase"].items()}
