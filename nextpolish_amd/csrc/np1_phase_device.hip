@@ -174,9 +174,10 @@ __global__ __launch_bounds__(256) void k_sp_region_slots(uint32_t n_reg, const u
     atomicAdd(total, (unsigned long long)(soff[g0 + (uint32_t)reg_se[2 * k + 1]] - soff[g0 + (uint32_t)reg_se[2 * k]] + 1));
 }
 
-__global__ __launch_bounds__(64) void k_sp_lowdepth(KcCtx cs, KcCtx cl, uint32_t n_reg, const uint32_t* __restrict__ reg_ctg, const int32_t* __restrict__ reg_se) {
+__global__ __launch_bounds__(64) void k_sp_lowdepth(KcCtx cs, KcCtx cl, uint32_t n_grp, const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ reg_ctg,
+                                                    const int32_t* __restrict__ reg_se) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_reg) sp_lowdepth_region(cs, cl, reg_ctg[k], reg_se[2 * k], reg_se[2 * k + 1]);
+    if (k < n_grp) sp_lowdepth_group(cs, cl, reg_ctg, reg_se, grp_first[k], grp_first[k + 1]);
 }
 
 __global__ __launch_bounds__(256) void k_sp_gather_flags(uint32_t n, const uint32_t* __restrict__ g, const uint32_t* __restrict__ soff, const uint8_t* __restrict__ sflag,
@@ -242,7 +243,7 @@ int download_vec(std::vector<T>& v, const void* p, size_t n, hipStream_t q) {
 enum { W_SOFF1, W_INFO1, W_SBASE1, W_SFLAG1, W_SCOUNT1, W_SOWN1, W_CNT, W_FIRST, W_DEC, W_TOP, W_DIRTY, W_ALLE, W_DPOS, W_SITE_G, W_SITE_CTG, W_SITE_POS,
        W_SITE_LEFT, W_SITE_RIGHT, W_SITE_LEN, W_KEEP, W_RSTRIDE, W_RBYTES, W_ROFF, W_RPOOL, W_MARK, W_MPOS, W_F, W_DOUT, W_DCNT, W_REG_CTG, W_REG_SE,
        W_K_FIRST, W_K_G, W_K_POS, W_K_LEN, W_K_ROFF, W_K_RSTRIDE, W_K_FLAG, W_LK_NUM, W_LK_MQ, W_LK_Q, W_LK_FIRST, W_LK_TOTAL, W_LREG_CTG, W_LREG_SE, W_LREG_IDX,
-       W_ENTS, W_BYTES, W_MARK_G, W_MARK_B, W_CHOICE, W_LR_CNT, W_COUNT };
+       W_ENTS, W_BYTES, W_MARK_G, W_MARK_B, W_CHOICE, W_LR_CNT, W_GRP, W_COUNT };
 
 extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* cfg) {
     if (!b || !l || !cfg) { np1_set_error("snp_phase: null argument"); return -1; }
@@ -379,7 +380,9 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
         }
         HIPCHK(hipStreamSynchronize(q));
         const uint32_t n_reg = (uint32_t)reg_ctg.size();
-        if (upload_vec(W[W_REG_CTG], reg_ctg, q) || upload_vec(W[W_REG_SE], reg_se, q)) return -1;
+        const std::vector<uint32_t> grp_first = sp_region_groups(reg_ctg, reg_se);
+        const uint32_t n_grp = (uint32_t)grp_first.size() - 1;
+        if (upload_vec(W[W_REG_CTG], reg_ctg, q) || upload_vec(W[W_REG_SE], reg_se, q) || upload_vec(W[W_GRP], grp_first, q)) return -1;
         if (n_reg)
             k_sp_mark_regions<<<nblk(n_reg, 256), 256, 0, q>>>(n_reg, W[W_REG_CTG].as<uint32_t>(), W[W_REG_SE].as<int32_t>(), ctg_off, W[W_SOFF1].as<uint32_t>(), W[W_SFLAG1].as<uint8_t>());
         // ---- P6: long-read columns behind marked bases, second slot space
@@ -439,7 +442,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
             k_sp_verdict<<<nblk(NS, 64), 64, 0, q>>>(cs, cl, P, SS, NS, W[W_SOFF1].as<uint32_t>(), W[W_CNT].as<uint32_t>(), W[W_FIRST].as<uint32_t>());
         }
         // ---- P9: low-depth regions, both streams
-        if (n_reg) k_sp_lowdepth<<<nblk(n_reg, 64), 64, 0, q>>>(cs, cl, n_reg, W[W_REG_CTG].as<uint32_t>(), W[W_REG_SE].as<int32_t>());
+        if (n_reg) k_sp_lowdepth<<<nblk(n_grp, 64), 64, 0, q>>>(cs, cl, n_grp, W[W_GRP].as<uint32_t>(), W[W_REG_CTG].as<uint32_t>(), W[W_REG_SE].as<int32_t>());
         HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
         HIPCHK(hipStreamSynchronize(q));
         if (hk[KCC_ERR] & (ERR_KC_POOL | ERR_SP_POOL)) continue;

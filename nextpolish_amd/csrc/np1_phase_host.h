@@ -17,6 +17,15 @@ struct SpHostSite {
     unsigned long long first[4];
 };
 
+// low-depth regions that touch (same contig, one starts on the base the previous one ends on) form a group: first[k] .. first[k + 1]
+inline std::vector<uint32_t> sp_region_groups(const std::vector<uint32_t>& reg_ctg, const std::vector<int32_t>& reg_se) {
+    std::vector<uint32_t> first;
+    for (size_t k = 0; k < reg_ctg.size(); ++k)
+        if (k == 0 || reg_ctg[k] != reg_ctg[k - 1] || reg_se[2 * k] > reg_se[2 * k - 1]) first.push_back((uint32_t)k);
+    first.push_back((uint32_t)reg_ctg.size());
+    return first;
+}
+
 // ts_find_snp_region: flag != 0 -> groups of sites closer than `gap` (short-read links); flag == 0 -> groups delimited by the
 // LEFT / RIGHT marks, measured between anchors (long-read links).  Pairs of local positions.
 inline std::vector<int32_t> sp_link_regions(const std::vector<SpHostSite>& s, int32_t gap, uint32_t flag) {

@@ -228,15 +228,22 @@ NP1_HD void sp_site_verdict(const KcCtx& sr, const KcCtx& lr, const SpParams& P,
     }
 }
 
-// ---- P9: ts_correct_lower_depth for one region (snpphase.c:797-871): both streams vote, long-read rate, FLAG_THIRD rule ---------
-NP1_HD void sp_lowdepth_region(const KcCtx& sr, const KcCtx& lr, uint32_t ct, int32_t start, int32_t end) {
-    const uint32_t g0 = sr.ctg_off[ct];
-    const uint32_t s0 = sr.soff[g0 + (uint32_t)start], s1 = sr.soff[g0 + (uint32_t)end];
-    for (uint32_t s = s0; s <= s1; ++s) { sr.lhead[s] = 0; sr.scount[s] = 0; }   // contig_clean_region
-    kc_as_read(sr, g0, start, end);
-    kc_parse_region(sr, ct, start, end, 2);
-    kc_parse_region(lr, ct, start, end, 1);
-    kc_region_solve(lr, g0, start, end, -1, 0);   // lr carries rate = indel_balance_factor_lgs and the third-generation rule
+// ---- P9: ts_correct_lower_depth (snpphase.c:797-871): both streams vote, long-read rate, FLAG_THIRD rule ---------------------------
+// The reference runs three loops over ALL regions: clean + draft vote + short reads, then the long reads, then the chains.  Merged
+// regions can touch (one ends on the base the next starts on), and then the later region's clean wipes the earlier one's votes on
+// that base before anything is scored.  Regions that touch form a group; one lane does the three loops over its group, in order.
+NP1_HD void sp_lowdepth_group(const KcCtx& sr, const KcCtx& lr, const uint32_t* reg_ctg, const int32_t* reg_se, uint32_t first, uint32_t last) {
+    for (uint32_t k = first; k < last; ++k) {
+        const uint32_t ct = reg_ctg[k], g0 = sr.ctg_off[ct];
+        const int32_t start = reg_se[2 * k], end = reg_se[2 * k + 1];
+        const uint32_t s0 = sr.soff[g0 + (uint32_t)start], s1 = sr.soff[g0 + (uint32_t)end];
+        for (uint32_t s = s0; s <= s1; ++s) { sr.lhead[s] = 0; sr.scount[s] = 0; }   // contig_clean_region
+        kc_as_read(sr, g0, start, end);
+        kc_parse_region(sr, ct, start, end, 2);
+    }
+    for (uint32_t k = first; k < last; ++k) kc_parse_region(lr, reg_ctg[k], reg_se[2 * k], reg_se[2 * k + 1], 1);
+    for (uint32_t k = first; k < last; ++k)   // lr carries rate = indel_balance_factor_lgs and the third-generation rule
+        if (!kc_region_solve(lr, lr.ctg_off[reg_ctg[k]], reg_se[2 * k], reg_se[2 * k + 1], -1, 0)) return;
 }
 
 // ---- P10: links --------------------------------------------------------------------------------------------------------

@@ -754,12 +754,18 @@ extern "C" int np1m_snp_phase(const np1_stream_view* vs, const np1_stream_view* 
         sp_site_verdict(cs, cl, P, SS, k, soff1.data(), cnt.data(), first.data());
     }
     if (err) return (int)err;
-    // P9: low-depth regions
-    for (uint32_t ct = 0; ct < nc; ++ct)
-        for (size_t i = 0; i + 1 < nodepth[ct].size(); i += 2) {
+    // P9: low-depth regions, touching ones as one group
+    {
+        std::vector<uint32_t> reg_ctg;
+        std::vector<int32_t> reg_se;
+        for (uint32_t ct = 0; ct < nc; ++ct)
+            for (size_t i = 0; i + 1 < nodepth[ct].size(); i += 2) { reg_ctg.push_back(ct); reg_se.push_back(nodepth[ct][i]); reg_se.push_back(nodepth[ct][i + 1]); }
+        const std::vector<uint32_t> grp = sp_region_groups(reg_ctg, reg_se);
+        for (size_t k = 0; k + 1 < grp.size(); ++k) {
             stcount = 0;
-            sp_lowdepth_region(cs, cl, ct, nodepth[ct][i], nodepth[ct][i + 1]);
+            sp_lowdepth_group(cs, cl, reg_ctg.data(), reg_se.data(), grp[k], grp[k + 1]);
         }
+    }
     if (err) return (int)err;
     // kept sites, per contig
     std::vector<uint32_t> k_first(nc + 1, 0), k_roff, k_rstride;

@@ -141,3 +141,31 @@ def make_case(seed, lens=(3000,), sr_depth=40, lr_depth=25, het=0.004, het_indel
     srs.sort(key=lambda r: (r["ctg"], r["pos"]))
     lrs.sort(key=lambda r: (r["ctg"], r["pos"]))
     return contigs, srs, lrs
+
+
+def touching_case(seed):
+    """One 200-base contig whose short reads leave exactly the bases 60 and 64 (and the contig ends) uncovered: the low-depth regions
+    [58,62] and [62,66] touch, so the second region's clean-up wipes the first one's votes on base 62 before anything is scored
+    (snpphase.c:797-841).  The draft is wrong around them; long reads carry the truth."""
+    rng = random.Random(seed)
+    L = 200
+    d = ["ACGT"[(i + i // 7) % 4] for i in range(L)]
+    for i in range(1, L):            # no homopolymers: the trimmed window of a read is exactly its span minus two bases at each end
+        if d[i] == d[i - 1]:
+            d[i] = "ACGT"[("ACGT".index(d[i]) + 1) % 4]
+    truth = "".join(d)
+    dd = list(truth)
+    for p in (59, 60, 62, 64, 65, 1, 198):
+        if rng.random() < 0.7:
+            dd[p] = "ACGT"[("ACGT".index(dd[p]) + 1 + rng.randrange(3)) % 4]
+    draft = "".join(dd)
+
+    def rd(a, b, mut=0.0, q=30):
+        s = [c if rng.random() >= mut else rng.choice(B) for c in truth[a:b + 1]]
+        return dict(ctg=0, pos=a, flag=0, mapq=60, isize=0, cigar=[("M", b - a + 1)], seq="".join(s), qual=bytes([q] * (b - a + 1)))
+
+    sr = [rd(0, 61) for _ in range(6)] + [rd(59, 65) for _ in range(6)] + [rd(63, 199) for _ in range(6)]
+    lr = [rd(0, 199, 0.03, 15) for _ in range(3)] + [rd(20, 150, 0.03, 15) for _ in range(4)] + [rd(40, 90, 0.05, 12) for _ in range(3)]
+    sr.sort(key=lambda r: r["pos"])
+    lr.sort(key=lambda r: r["pos"])
+    return [("tig0", draft)], sr, lr

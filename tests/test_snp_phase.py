@@ -163,6 +163,38 @@ def test_host_model_of_the_stage_bodies_matches_oracle():
     assert n > 30
 
 
+def touching(seed):
+    ctgs, srs, lrs = snpphase_gen.touching_case(seed)
+    return nat.Stream.from_reads(ctgs, srs), nat.Stream.from_reads(ctgs, lrs)
+
+
+def test_low_depth_regions_that_touch():
+    """two merged low-depth regions sharing a base: the three loops of ts_correct_lower_depth over all regions, not region by region"""
+    for seed in range(12):
+        s, l = touching(seed)
+        ob.snp_phase(s, l, 0, ob.default_config(read_tlen=500, read_len=100))
+        assert ob.snp_phase_stats()[6] == 4
+        assert _model_case(s, l, 500, 100)
+
+
+@needs_ref
+def test_low_depth_regions_that_touch_vs_reference(tmp_path):
+    fa, sr, lr = str(tmp_path / "s.fa"), str(tmp_path / "sr.bam"), str(tmp_path / "lr.bam")
+    changed = 0
+    for seed in range(12):
+        s, l = touching(seed)
+        s.write_files(fa, sr)
+        l.write_files(str(tmp_path / "l.fa"), lr)
+        ref = run_ref3(fa, sr, lr)
+        cfgp = nat.lib().config_init(fa.encode(), sr.encode(), lr.encode())
+        cfg = ob.default_config(read_tlen=cfgp.contents.read_tlen, read_len=cfgp.contents.read_len)
+        nat.lib().config_destory(cfgp)
+        got = ob.snp_phase(s, l, 0, cfg)
+        assert got == ref["tig0"], seed
+        changed += got != s.contig_draft(0).decode()
+    assert changed > 6
+
+
 def test_host_model_on_real_alignments():
     g = GOLD["real"]["s30+ont"]
     s, l = real_streams(g)
@@ -227,6 +259,12 @@ def test_gpu_matches_oracle_on_fuzzed_diploids(ctx):
         s, l = streams(fuzz_params(seed))
         n += 1 if _check(ctx, s, l) else 0
     assert n > 20
+
+
+@pytest.mark.gpu
+def test_gpu_low_depth_regions_that_touch(ctx):
+    for seed in range(12):
+        assert _check(ctx, *touching(seed))
 
 
 @pytest.mark.gpu
