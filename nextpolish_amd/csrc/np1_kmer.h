@@ -59,6 +59,8 @@ struct KcCtx {
     int32_t third_rule;
     double max_indel_factor_lgs, max_snp_factor_lgs;
     const uint32_t* sown;        // per slot: global index of the base it belongs to
+    const uint16_t* bmark;       // per base: marks of its main slot | 0x100 when it owns insertion columns (link walk of snp_phase)
+    const unsigned long long* bbits;   // one bit per base: the link walk has to look at it (a site / an anchor mark), 64 bases per word
     uint32_t* err;
 };
 

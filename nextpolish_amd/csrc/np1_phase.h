@@ -250,5 +250,38 @@ NP1_HD void sp_reslot_base(uint32_t g, const uint32_t* soff1, const uint32_t* so
     }
 }
 
+// per base: what the link walk looks at on every step, in one load
+NP1_HD uint16_t sp_base_mark(uint32_t g, const uint32_t* soff, const uint8_t* sflag) {
+    return (uint16_t)(sflag[soff[g]] | (soff[g + 1] - soff[g] > 1 ? 0x100u : 0u));
+}
+
+// 64 bases of the "look here" bitmap: bit set = the base carries one of `mask`
+NP1_HD unsigned long long sp_base_bits_word(uint64_t w, uint64_t G, const uint16_t* bmark, uint32_t mask) {
+    unsigned long long v = 0;
+    for (uint32_t t = 0; t < 64; ++t) {
+        const uint64_t g = w * 64 + t;
+        if (g < G && (bmark[g] & mask)) v |= 1ull << t;
+    }
+    return v;
+}
+// distance from base g to the next marked base, at most maxd
+NP1_HD int32_t sp_next_marked(const unsigned long long* bits, uint64_t g, int32_t maxd) {
+    int32_t d = 0;
+    while (d < maxd) {
+        const uint64_t idx = g + (uint64_t)d;
+        const unsigned long long w = bits[idx >> 6] >> (idx & 63);
+        if (w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int32_t t = __ffsll((long long)w) - 1;
+#else
+            const int32_t t = __builtin_ctzll(w);
+#endif
+            return d + t < maxd ? d + t : maxd;
+        }
+        d += 64 - (int32_t)(idx & 63);
+    }
+    return maxd;
+}
+
 }  // namespace np1p
 #include "np1_phase_sites.h"

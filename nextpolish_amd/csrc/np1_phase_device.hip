@@ -186,24 +186,52 @@ __global__ __launch_bounds__(256) void k_sp_gather_flags(uint32_t n, const uint3
     if (k < n) out[k] = sflag[soff[g[k]]];
 }
 
-// link regions of all contigs in one flat list; every workgroup takes regions in turn, its lanes take the region's records in
-// turn; each lane owns a scratch row (entries + haplotype bytes of one record)
-__global__ __launch_bounds__(64) void k_sp_links(KcCtx c, SpParams P, SpLinks L, uint32_t n_reg, const uint32_t* __restrict__ reg_ctg, const int32_t* __restrict__ reg_se,
-                                                 const uint32_t* __restrict__ reg_idx, uint32_t level, uint32_t flagbrim, SpEntry* ents, uint32_t ecap, uint8_t* bytes,
-                                                 uint32_t bcap) {
+__global__ __launch_bounds__(256) void k_sp_base_marks(uint32_t G, const uint32_t* __restrict__ soff, const uint8_t* __restrict__ sflag, uint16_t* __restrict__ bmark) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G) bmark[g] = sp_base_mark(g, soff, sflag);
+}
+
+__global__ __launch_bounds__(256) void k_sp_base_bits(uint64_t G, const uint16_t* __restrict__ bmark, uint32_t mask, unsigned long long* __restrict__ bits) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < G / 64 + 1) bits[w] = sp_base_bits_word(w, G, bmark, mask);
+}
+
+// records that can overlap a link region: [r0, r1), and how many 64-record chunks that is
+__global__ __launch_bounds__(256) void k_sp_link_ranges(KcCtx c, uint32_t n_reg, const uint32_t* __restrict__ reg_ctg, const int32_t* __restrict__ reg_se,
+                                                        unsigned long long* __restrict__ r0_out, uint32_t* __restrict__ n_rec, uint32_t* __restrict__ n_chunk) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_reg) return;
+    const uint32_t ct = reg_ctg[k];
+    const int64_t rb = (int64_t)c.read_begin[ct], re = (int64_t)c.read_begin[ct + 1];
+    const int64_t r0 = kc_lower_bound_pos(c.R, rb, re, reg_se[2 * k] - c.max_span), r1 = kc_lower_bound_pos(c.R, rb, re, reg_se[2 * k + 1] + 1);
+    r0_out[k] = (unsigned long long)r0;
+    n_rec[k] = (uint32_t)(r1 - r0);
+    n_chunk[k] = (uint32_t)((r1 - r0 + 63) / 64);
+}
+
+// link regions of all contigs in one flat list, cut into chunks of 64 candidate records; every workgroup takes chunks in turn, one
+// record per lane; each lane owns a scratch row (entries + haplotype bytes of one record)
+__global__ __launch_bounds__(64) void k_sp_links(KcCtx c, SpParams P, SpLinks L, uint32_t n_reg, uint32_t n_chunks, const uint32_t* __restrict__ reg_ctg,
+                                                 const int32_t* __restrict__ reg_se, const uint32_t* __restrict__ reg_idx, const unsigned long long* __restrict__ reg_r0,
+                                                 const uint32_t* __restrict__ reg_nrec, const uint32_t* __restrict__ chunk_off, uint32_t level, uint32_t flagbrim, SpEntry* ents,
+                                                 uint32_t ecap, uint8_t* bytes, uint32_t bcap) {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     SpEntry* my_e = ents + (uint64_t)lane * ecap;
     uint8_t* my_b = bytes + (uint64_t)lane * bcap;
-    for (uint32_t k = blockIdx.x; k < n_reg; k += gridDim.x) {
+    for (uint32_t w = blockIdx.x; w < n_chunks; w += gridDim.x) {
+        uint32_t lo = 0, hi = n_reg;   // last region whose first chunk is <= w
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (chunk_off[mid] <= w) lo = mid; else hi = mid;
+        }
+        const uint32_t k = lo, t = (w - chunk_off[k]) * 64 + threadIdx.x;
+        if (t >= reg_nrec[k]) continue;
+        const int64_t r = (int64_t)reg_r0[k] + t;
         const uint32_t ct = reg_ctg[k];
         const int32_t s = reg_se[2 * k], e = reg_se[2 * k + 1];
-        const int64_t rb = (int64_t)c.read_begin[ct], re = (int64_t)c.read_begin[ct + 1];
-        const int64_t r0 = kc_lower_bound_pos(c.R, rb, re, s - c.max_span), r1 = kc_lower_bound_pos(c.R, rb, re, e + 1);
-        for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-            if (c.endpos[r] <= s || c.level[r] != level) continue;
-            const unsigned long long order = (unsigned long long)flagbrim << 63 | (unsigned long long)reg_idx[k] << 32 | (unsigned long long)(r - rb);
-            sp_link_record(c, P, L, r, ct, s, e, flagbrim, order, my_e, ecap, my_b, (int32_t)bcap);
-        }
+        if (c.endpos[r] <= s || c.level[r] != level) continue;
+        const unsigned long long order = (unsigned long long)flagbrim << 63 | (unsigned long long)reg_idx[k] << 32 | (unsigned long long)(r - (int64_t)c.read_begin[ct]);
+        sp_link_record(c, P, L, r, ct, s, e, flagbrim, order, my_e, ecap, my_b, (int32_t)bcap);
     }
 }
 
@@ -243,7 +271,7 @@ int download_vec(std::vector<T>& v, const void* p, size_t n, hipStream_t q) {
 enum { W_SOFF1, W_INFO1, W_SBASE1, W_SFLAG1, W_SCOUNT1, W_SOWN1, W_CNT, W_FIRST, W_DEC, W_TOP, W_DIRTY, W_ALLE, W_DPOS, W_SITE_G, W_SITE_CTG, W_SITE_POS,
        W_SITE_LEFT, W_SITE_RIGHT, W_SITE_LEN, W_KEEP, W_RSTRIDE, W_RBYTES, W_ROFF, W_RPOOL, W_MARK, W_MPOS, W_F, W_DOUT, W_DCNT, W_REG_CTG, W_REG_SE,
        W_K_FIRST, W_K_G, W_K_POS, W_K_LEN, W_K_ROFF, W_K_RSTRIDE, W_K_FLAG, W_LK_NUM, W_LK_MQ, W_LK_Q, W_LK_FIRST, W_LK_TOTAL, W_LREG_CTG, W_LREG_SE, W_LREG_IDX,
-       W_ENTS, W_BYTES, W_MARK_G, W_MARK_B, W_CHOICE, W_LR_CNT, W_GRP, W_COUNT };
+       W_ENTS, W_BYTES, W_MARK_G, W_MARK_B, W_CHOICE, W_LR_CNT, W_GRP, W_BMARK, W_LREG_R0, W_LREG_NREC, W_LREG_NCH, W_LREG_CHOFF, W_BBITS, W_COUNT };
 
 extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* cfg) {
     if (!b || !l || !cfg) { np1_set_error("snp_phase: null argument"); return -1; }
@@ -415,6 +443,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
         }
         const size_t lcap = std::min<size_t>(((size_t)64 * nd_slots + ((size_t)1 << 20)) * scale, (size_t)0x7ffffff0u);
         const size_t stcap = std::min<size_t>((4 * nd_slots + 64ull * n_reg + 4096) * scale, (size_t)0x0ffffff0u);
+        if (W[W_BMARK].ensure(2 * (G + 2)) || W[W_BBITS].ensure(8 * (G / 64 + 2))) return -1;
         const size_t hcap = std::min<size_t>(((size_t)16384 * NS + ((size_t)64 << 20)) * scale, (size_t)0xfffffff0u);
         if (b->kc_lpool.ensure(8 * lcap) || b->kc_stsc.ensure(8 * 16 * stcap) || b->kc_stkm.ensure(2 * 16 * stcap) || b->kc_strk.ensure(16 * stcap) || b->kc_hpool.ensure(hcap)) return -1;
         for (KcCtx* c : {&cs, &cl}) {
@@ -423,6 +452,8 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
             c->lcount = &kcnt[KCC_LCOUNT]; c->st_score = b->kc_stsc.as<long long>(); c->st_kmer = b->kc_stkm.as<uint16_t>(); c->st_rank = b->kc_strk.as<uint8_t>();
             c->st_cap = (uint32_t)stcap; c->st_count = &kcnt[KCC_STCOUNT]; c->hpool = b->kc_hpool.as<uint8_t>(); c->hcap = (uint32_t)hcap; c->hcount = &kcnt[KCC_HCOUNT];
             c->sown = b->slot_g.as<uint32_t>();
+            c->bmark = W[W_BMARK].as<uint16_t>();
+            c->bbits = W[W_BBITS].as<unsigned long long>();
         }
         // ---- P7: site verdicts
         uint64_t RB = 0;
@@ -520,13 +551,24 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
                 }
                 const uint32_t nlr = (uint32_t)lctg.size();
                 if (!nlr) return 0;
-                const uint32_t blocks = phase == 0 ? 256u : 32u;
                 const uint32_t ecap = phase == 0 ? 512u : 16384u;
                 const uint32_t bcap = phase == 0 ? 8192u : (uint32_t)P.max_variant_count_lgs + 4096u;
-                if (upload_vec(W[W_LREG_CTG], lctg, q) || upload_vec(W[W_LREG_SE], lse, q) || upload_vec(W[W_LREG_IDX], lidx, q) ||
-                    W[W_ENTS].ensure(sizeof(SpEntry) * (size_t)ecap * blocks * 64) || W[W_BYTES].ensure((size_t)bcap * blocks * 64))
+                if (upload_vec(W[W_LREG_CTG], lctg, q) || upload_vec(W[W_LREG_SE], lse, q) || upload_vec(W[W_LREG_IDX], lidx, q) || W[W_LREG_R0].ensure(8ull * nlr + 8) ||
+                    W[W_LREG_NREC].ensure(4ull * nlr + 8) || W[W_LREG_NCH].ensure(4ull * nlr + 8) || W[W_LREG_CHOFF].ensure(4ull * nlr + 8))
                     return -1;
-                k_sp_links<<<blocks, 64, 0, q>>>(c, P, LK, nlr, W[W_LREG_CTG].as<uint32_t>(), W[W_LREG_SE].as<int32_t>(), W[W_LREG_IDX].as<uint32_t>(), phase == 0 ? 2u : 1u,
+                k_sp_base_marks<<<nblk(G, 256), 256, 0, q>>>((uint32_t)G, b->soff.as<uint32_t>(), b->kc_sflag.as<uint8_t>(), W[W_BMARK].as<uint16_t>());
+                k_sp_base_bits<<<nblk(G / 64 + 1, 256), 256, 0, q>>>(G, W[W_BMARK].as<uint16_t>(), phase == 0 ? F_SNP : (F_LEFT | F_RIGHT), W[W_BBITS].as<unsigned long long>());
+                k_sp_link_ranges<<<nblk(nlr, 256), 256, 0, q>>>(c, nlr, W[W_LREG_CTG].as<uint32_t>(), W[W_LREG_SE].as<int32_t>(), W[W_LREG_R0].as<unsigned long long>(),
+                                                                W[W_LREG_NREC].as<uint32_t>(), W[W_LREG_NCH].as<uint32_t>());
+                launch_scan_u32(q, W[W_LREG_NCH].as<uint32_t>(), nlr, W[W_LREG_CHOFF].as<uint32_t>(), scan_tmp, &totals[5]);
+                uint64_t n_chunks = 0;
+                HIPCHK(hipMemcpyAsync(&n_chunks, &totals[5], 8, hipMemcpyDeviceToHost, q));
+                HIPCHK(hipStreamSynchronize(q));
+                if (!n_chunks) return 0;
+                const uint32_t blocks = (uint32_t)std::min<uint64_t>(n_chunks, phase == 0 ? 1024u : 128u);
+                if (W[W_ENTS].ensure(sizeof(SpEntry) * (size_t)ecap * blocks * 64) || W[W_BYTES].ensure((size_t)bcap * blocks * 64)) return -1;
+                k_sp_links<<<blocks, 64, 0, q>>>(c, P, LK, nlr, (uint32_t)n_chunks, W[W_LREG_CTG].as<uint32_t>(), W[W_LREG_SE].as<int32_t>(), W[W_LREG_IDX].as<uint32_t>(),
+                                                 W[W_LREG_R0].as<unsigned long long>(), W[W_LREG_NREC].as<uint32_t>(), W[W_LREG_CHOFF].as<uint32_t>(), phase == 0 ? 2u : 1u,
                                                  (uint32_t)phase, W[W_ENTS].as<SpEntry>(), ecap, W[W_BYTES].as<uint8_t>(), bcap);
                 return 0;
             };

@@ -294,7 +294,7 @@ struct SpLinkSink {   // ts_snps_parse_read (snpphase.c:615-776) on the vote str
             if (pad) ++del; else k_qual += qual[qpos];
             return;
         }
-        const uint32_t fl = c->sflag[c->soff[g0 + (uint32_t)pos]];
+        const uint32_t bm = c->bmark[g0 + (uint32_t)pos], fl = bm & 0xffu;
         if (!(flagbrim == 0 || (fl & (F_LEFT | F_RIGHT)))) return;
         if (fl & F_SNP) {
             if (curpos == 0) {
@@ -304,11 +304,11 @@ struct SpLinkSink {   // ts_snps_parse_read (snpphase.c:615-776) on the vote str
                 ++sign;
             }
         } else if (flagbrim) {
-            if (c->sbase[c->soff[g0 + (uint32_t)pos]] == next_sym) ++sign;   // (on a deletion: the next query base, as the reference reads it)
+            if (c->sbase[c->soff[g0 + (uint32_t)pos]] == (cur_q < lq ? seq_nib(seq, cur_q) : 0xffu)) ++sign;   // (on a deletion: the next query base, as the reference reads it)
         } else {
             ++sign;
         }
-        const bool has_cols = c->soff[g0 + (uint32_t)pos + 1] - c->soff[g0 + (uint32_t)pos] > 1;
+        const bool has_cols = (bm & 0x100u) != 0;
         if (curpos) {
             put(sym);
             if (qpos >= 0) k_qual += qual[qpos];
@@ -325,7 +325,7 @@ struct SpLinkSink {   // ts_snps_parse_read (snpphase.c:615-776) on the vote str
         }
         if (k_num != pos) {
             if (fl & F_SNP) {
-                k_off = q_off; k_len = 1; k_num = pos; k_qual = qpos >= 0 ? qual[qpos] : del_qual; del = 0; curpos = 1;
+                k_off = q_off; k_len = 1; k_num = pos; k_qual = cur_q < lq ? qual[cur_q] : 0; del = 0; curpos = 1;   // (quality on a deletion: the next query base's, as the reference reads it)
                 if (flagbrim == 0) { ++comfirm; sign = 1; }
             } else if (fl & F_RIGHT) {
                 if (sign == 2) comfirm = (int32_t)n;
@@ -336,8 +336,8 @@ struct SpLinkSink {   // ts_snps_parse_read (snpphase.c:615-776) on the vote str
             }
         }
     }
-    int32_t del_qual;   // quality / symbol the reference reads at a deletion: the next query base's (set by the walk before each vote)
-    uint32_t next_sym;
+    int32_t cur_q, lq;    // query index the reference has at this step (on a deletion: of the next base), set by the walk; query length
+    const uint8_t* seq;
 };
 
 // the walk of ts_snps_parse_read: kc_walk's order of votes, but (1) a leading insertion at position 0 does not move the query
@@ -348,7 +348,6 @@ NP1_HD void sp_walk_links(const KcCtx& c, int64_t r, uint32_t g0, int32_t start,
     if (!ncig) return;
     const uint32_t* cg = c.R.cigar + c.R.cigar_off[r];
     const uint8_t* seq = c.R.seq + c.R.seq_off[r];
-    const int32_t lq = c.R.l_qseq[r];
     int32_t qs, qe;
     kc_cut_read(c.R, r, c.trim, &qs, &qe);
     int32_t pos = c.R.pos[r], qpos = 0;
@@ -359,13 +358,21 @@ NP1_HD void sp_walk_links(const KcCtx& c, int64_t r, uint32_t g0, int32_t start,
         if (sink.stop_before(len)) break;
         if (op == 0 || op == 2) {
             for (int32_t j = 0; j < len; ++j, ++pos) {
+                if (!sink.curpos) {   // nothing happens on an unmarked base while no string is open: straight to the next marked one
+                    const int32_t d = sp_next_marked(c.bbits, (uint64_t)g0 + (uint64_t)pos, len - j);
+                    if (d > 0) {
+                        pos += d; j += d;
+                        if (op != 2) qpos += d;
+                        last = op;
+                        if (j >= len) break;
+                    }
+                }
                 if (pos >= start && pos <= end && qpos >= qs && qpos <= qe) {
-                    if (last != 1 && pos > start && (qpos > qs || (qpos == qs && last == 2))) {
+                    if (sink.curpos && last != 1 && pos > start && (qpos > qs || (qpos == qs && last == 2))) {   // (the columns matter only to an open string)
                         const uint32_t n = c.soff[g0 + (uint32_t)pos] - c.soff[g0 + (uint32_t)pos - 1] - 1;
                         for (uint32_t k = 0; k < n; ++k) sink.vote(pos - 1, k + 1, SYM_DEL, -1, true);
                     }
-                    sink.del_qual = qpos < lq ? sink.qual[qpos] : 0;
-                    sink.next_sym = qpos < lq ? seq_nib(seq, qpos) : 0xffu;
+                    sink.cur_q = qpos;
                     if (op == 2) sink.vote(pos, 0, SYM_DEL, -1, false);
                     else sink.vote(pos, 0, seq_nib(seq, qpos), qpos, false);
                 }
@@ -426,7 +433,7 @@ NP1_HD void sp_link_record(const KcCtx& c, const SpParams& P, const SpLinks& L, 
     sink.ents = ents; sink.ecap = ecap; sink.n = 0; sink.bytes = bytes; sink.bcap = bcap;
     sink.k_off = 0; sink.k_len = 0; sink.k_num = 0; sink.k_qual = 0; sink.q_off = 0;
     sink.del = 0; sink.curpos = 0; sink.sign = 0; sink.comfirm = 0; sink.budget = P.max_variant_count_lgs; sink.overflow = false;
-    sink.del_qual = 0; sink.next_sym = 0xffu;
+    sink.cur_q = 0; sink.lq = c.R.l_qseq[r]; sink.seq = c.R.seq + c.R.seq_off[r];
     sp_walk_links(c, r, g0, start, end, sink);
     if (sink.overflow) { np1_atomic_or(c.err, ERR_SP_POOL); return; }
     const int32_t mq = c.mapq[r];

@@ -782,6 +782,13 @@ extern "C" int np1m_snp_phase(const np1_stream_view* vs, const np1_stream_view* 
     std::vector<unsigned long long> lk_first(4ull * NK + 4, ~0ull);
     SpLinks LK{k_first.data(), k_pos.data(), k_len.data(), k_roff.data(), k_rstride.data(), rpool.data(), lk_num.data(), lk_mq.data(), lk_q.data(), lk_first.data(), lk_total.data()};
     const int32_t bcap = P.max_variant_count_lgs + 4096;
+    std::vector<uint16_t> bmark(G + 1, 0);
+    std::vector<unsigned long long> bbits(G / 64 + 2, 0);
+    auto refresh_marks = [&](uint32_t mask) {
+        for (uint64_t g = 0; g < G; ++g) bmark[g] = sp_base_mark((uint32_t)g, soff.data(), sflag.data());
+        for (uint64_t w = 0; w < G / 64 + 1; ++w) bbits[w] = sp_base_bits_word(w, G, bmark.data(), mask);
+    };
+    cs.bmark = bmark.data(); cl.bmark = bmark.data(); cs.bbits = bbits.data(); cl.bbits = bbits.data();
     std::vector<uint8_t> lbytes((size_t)bcap + 16);
     std::vector<SpEntry> lents(1u << 16);
     // the remembered orientation of every kept site
@@ -805,6 +812,7 @@ extern "C" int np1m_snp_phase(const np1_stream_view* vs, const np1_stream_view* 
         if (k_first[ct + 1] - k_first[ct] <= 1) continue;
         const uint32_t g0 = vs->ctg_off[ct];
         // P10a: short-read links
+        refresh_marks(F_SNP);
         std::vector<SpHostSite> h = host_sites(ct);
         std::vector<int32_t> reg = sp_link_regions(h, P.read_len, F_SNP);
         for (size_t i = 0; i + 1 < reg.size(); i += 2) {
@@ -820,6 +828,7 @@ extern "C" int np1m_snp_phase(const np1_stream_view* vs, const np1_stream_view* 
         // marks, long-read regions
         h = host_sites(ct);
         for (auto& m : sp_link_marks(h, P.min_count_snp_link)) sflag[soff[g0 + (uint32_t)m.first]] |= m.second;
+        refresh_marks(F_LEFT | F_RIGHT);
         h = host_sites(ct);
         reg = sp_link_regions(h, P.max_variant_count_lgs, 0);
         for (size_t i = 0; i + 1 < reg.size(); i += 2) {
