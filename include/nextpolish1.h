@@ -83,9 +83,11 @@ void config_destory(Configure* config);
 PolishResult* score_chain(const char* tigname, Configure* configure);
 /* reference: source/lib/kmercount.c:93-126 -- re-votes lowercase regions by spanning-read haplotypes */
 PolishResult* kmer_count(const char* tigname, Configure* configure);
-/* reference: source/lib/snpphase.c / snpvalid.c / lgspolish.c -- symbols the ctypes caller resolves at
- * import time (nextpolish1.py:95-100).  Outside the accelerated hot path (task 5 is
- * refused by the caller itself, nextpolish1.py:338-340): they report that and exit(1). */
+/* reference: source/lib/snpphase.c:87-134 (task 3): heterozygous sites from the short reads (configure->bamfn) and the long
+ * reads (configure->thirdbamfn) of one contig, low-depth correction with both, read-backed phasing; result with the
+ * long-read-only evidence in lower case.  source/lib/snpvalid.c:3-36 (task 4): two vote rounds over the lowercase regions.
+ * source/lib/lgspolish.c (task 5): resolved by the ctypes caller at import time (nextpolish1.py:95-100) but refused by the
+ * caller itself (nextpolish1.py:338-340); here it reports that and exit(1). */
 PolishResult* snp_phase(const char* tigname, Configure* configure);
 PolishResult* snp_valid(const char* tigname, Configure* configure);
 PolishResult* lgspolish(const char* tigname, Configure* configure);
