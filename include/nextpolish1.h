@@ -171,6 +171,20 @@ typedef struct {
     double clip_rate;
 } np1_synth_long_params;
 np1_stream* np1_stream_synth_long(const np1_synth_long_params* p, const char* contig_name_prefix);
+/* Diploid workload of task 3 (snp_phase): per contig one draft with its own errors, short read pairs and long reads drawn from two
+ * haplotypes that differ by substitutions (het_sub per base) and small indels (het_indel); sr_holes = stretches per contig no short
+ * fragment touches.  Both streams carry qualities.  Returns 0 and the two streams (same contigs, same drafts). */
+typedef struct {
+    uint64_t seed;
+    int32_t n_contigs;
+    const int32_t* contig_len;
+    double sr_depth, lr_depth;
+    int32_t read_len;
+    double frag_mean, lr_len;
+    double het_sub, het_indel, draft_err, sr_err, lr_err;
+    int32_t sr_holes;
+} np1_diploid_params;
+int np1_stream_synth_diploid(const np1_diploid_params* p, const char* contig_name_prefix, np1_stream** sr, np1_stream** lr);
 /* Test hook: the BGZF block decoder (own raw-DEFLATE implementation) on one stream; 1 = accepted and dst filled. */
 int np1_debug_inflate(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len);
 /* test hook: CRC-32 of a BGZF block as the reader / writer compute it (must equal zlib's crc32) */

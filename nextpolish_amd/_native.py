@@ -71,6 +71,12 @@ NP1_MAX_STAGES = 16
 _lib = None
 
 
+class DiploidParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_contigs", C.c_int32), ("contig_len", C.POINTER(C.c_int32)), ("sr_depth", C.c_double), ("lr_depth", C.c_double),
+                ("read_len", C.c_int32), ("frag_mean", C.c_double), ("lr_len", C.c_double), ("het_sub", C.c_double), ("het_indel", C.c_double),
+                ("draft_err", C.c_double), ("sr_err", C.c_double), ("lr_err", C.c_double), ("sr_holes", C.c_int32)]
+
+
 class SynthLongParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_contigs", C.c_int32), ("contig_len", C.POINTER(C.c_int32)), ("depth", C.c_double),
                 ("mean_len", C.c_double), ("sub", C.c_double), ("ins", C.c_double), ("dele", C.c_double), ("max_indel", C.c_int32),
@@ -119,6 +125,8 @@ def lib():
     L.np1_stream_synth.restype = C.c_void_p
     L.np1_stream_synth_long.argtypes = [C.POINTER(SynthLongParams), C.c_char_p]
     L.np1_stream_synth_long.restype = C.c_void_p
+    L.np1_stream_synth_diploid.argtypes = [C.POINTER(DiploidParams), C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.np1_stream_synth_diploid.restype = C.c_int
     L.np1_device_count.restype = C.c_int
     L.np1_ctx_create.argtypes = [C.c_int]
     L.np1_ctx_create.restype = C.c_void_p
@@ -262,6 +270,17 @@ class Stream(object):
         p.seed, p.n_contigs, p.contig_len, p.depth, p.mean_len = seed, len(contig_len), lens, depth, mean_len
         p.sub, p.ins, p.dele, p.max_indel, p.clip_rate = sub, ins, dele, max_indel, clip_rate
         return cls(lib().np1_stream_synth_long(C.byref(p), prefix.encode()))
+
+    @classmethod
+    def synth_diploid(cls, contig_len, sr_depth=30.0, lr_depth=20.0, seed=7, read_len=150, frag_mean=400.0, lr_len=8000.0, het_sub=0.002, het_indel=0.0003,
+                      draft_err=0.002, sr_err=0.003, lr_err=0.04, sr_holes=0, prefix="ctg"):
+        """(short-read stream, long-read stream) of the same diploid contigs: the workload of task 3 (np1_diploid_params)"""
+        lens = (C.c_int32 * len(contig_len))(*contig_len)
+        p = DiploidParams(seed, len(contig_len), lens, sr_depth, lr_depth, read_len, frag_mean, lr_len, het_sub, het_indel, draft_err, sr_err, lr_err, sr_holes)
+        a, b = C.c_void_p(), C.c_void_p()
+        if lib().np1_stream_synth_diploid(C.byref(p), prefix.encode(), C.byref(a), C.byref(b)) != 0:
+            raise RuntimeError("np1_stream_synth_diploid: " + last_error())
+        return cls(a.value), cls(b.value)
 
     @classmethod
     def from_reads(cls, contigs, reads):

@@ -67,6 +67,50 @@ int main(int argc, char* argv[]) {
             return 1;
         }
         np1_pipe_close(pipe);
+    } else if (step == 3) {
+        // snp_phase: contigs in FASTA-index order, batches of NP1_BATCH_BP draft bases; per batch the short-read and the long-read
+        // records become two resident batches and one np1_batch_snp_phase pass (np1_phase_device.hip)
+        if (!cfg->bamfn) { fprintf(stderr, "cannot access BAM %s\n", argv[3]); return 1; }
+        if (!cfg->thirdbamfn) { fprintf(stderr, "cannot access BAM %s\n", argv[4]); return 1; }
+        int dev = 0;
+        long long batch_bp = 16000000;
+        if (const char* e = getenv("NP1_DEVICE")) dev = atoi(e);
+        if (const char* e = getenv("NP1_BATCH_BP")) batch_bp = atoll(e);
+        np1_stream* all = np1_stream_load(cfg->fastafn, cfg->bamfn, nullptr, 0, 0);
+        if (!all) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+        np1_stream_view v;
+        np1_stream_get_view(all, &v);
+        std::vector<std::string> names;
+        std::vector<long long> lens;
+        for (int64_t c = 0; c < v.n_contigs; ++c) { names.push_back(np1_stream_contig_name(all, c)); lens.push_back(v.ctg_len[c]); }
+        np1_stream_free(all);
+        np1_ctx* ctx = np1_ctx_create(dev);
+        if (!ctx) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+        for (size_t first = 0; first < names.size();) {
+            size_t last = first;
+            long long bp = 0;
+            while (last < names.size() && (last == first || bp + lens[last] <= batch_bp)) bp += lens[last++];
+            std::vector<const char*> nm;
+            for (size_t k = first; k < last; ++k) nm.push_back(names[k].c_str());
+            np1_stream* ss = np1_stream_load(cfg->fastafn, cfg->bamfn, nm.data(), (int)nm.size(), 1);
+            np1_stream* sl = ss ? np1_stream_load(cfg->fastafn, cfg->thirdbamfn, nm.data(), (int)nm.size(), 1) : nullptr;
+            np1_batch* b = sl ? np1_batch_upload(ctx, ss) : nullptr;
+            np1_batch* l = b ? np1_batch_upload(ctx, sl) : nullptr;
+            if (!l || np1_batch_snp_phase(b, l, cfg) != 0 || np1_batch_results_fetch(b) != 0) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+            const char* res = np1_batch_results_ptr(b);
+            const uint32_t* bounds = np1_batch_results_bounds(b);
+            for (size_t k = first; k < last; ++k) {
+                printf(">%s_%d\n", names[k].c_str(), step);
+                fwrite(res + bounds[k - first], 1, bounds[k - first + 1] - bounds[k - first], stdout);
+                fputc('\n', stdout);
+            }
+            np1_batch_free(l);
+            np1_batch_free(b);
+            np1_stream_free(sl);
+            np1_stream_free(ss);
+            first = last;
+        }
+        np1_ctx_destroy(ctx);
     } else {
         PolishResult* (*fn)(const char*, Configure*) = step == 2 ? kmer_count : step == 3 ? snp_phase : step == 4 ? snp_valid : lgspolish;
         np1_stream* st = np1_stream_load(cfg->fastafn, cfg->bamfn ? cfg->bamfn : argv[3], nullptr, 0, 0);

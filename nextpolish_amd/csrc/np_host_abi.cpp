@@ -141,6 +141,19 @@ np1_stream* np1_stream_synth_long(const np1_synth_long_params* p, const char* pr
     return st;
 }
 
+int np1_stream_synth_diploid(const np1_diploid_params* p, const char* prefix, np1_stream** sr, np1_stream** lr) {
+    np1_stream *a = new np1_stream(), *b = new np1_stream();
+    if (!np::synth_diploid_streams(*p, prefix ? prefix : "ctg", &a->s, &b->s)) {
+        g_err = "synthetic generation failed (contigs shorter than 400 bases?)";
+        delete a;
+        delete b;
+        return -1;
+    }
+    *sr = a;
+    *lr = b;
+    return 0;
+}
+
 /* test hook: the BGZF block decoder on a raw DEFLATE stream (1 = accepted and dst filled) */
 int np1_debug_inflate(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) {
     return np::inflate_raw(src, (size_t)src_len, dst, (size_t)dst_len) ? 1 : 0;

@@ -453,3 +453,185 @@ bool write_stream_files(const ReadStream& s, const std::string& fasta, const std
 }
 
 }  // namespace np
+
+
+// Diploid workload of task 3 (snp_phase): one draft per contig, short read pairs and long reads drawn from two haplotypes that
+// differ by substitutions and small indels, the draft carrying its own errors.  Every read's CIGAR follows from the column-wise
+// relation of its haplotype to the draft.  Two streams over the same contigs: `sr` and `lr`, both with qualities.
+namespace np {
+namespace {
+struct DCol { int32_t d; char b; };   // draft coordinate (-1: the base is absent from the draft) and the base
+
+void mutate_cols(Rng& rng, const std::string& seq, double sub, double ins, double dele, int max_indel, std::vector<std::pair<int32_t, char>>* out) {
+    const int32_t n = (int32_t)seq.size();
+    for (int32_t i = 0; i < n;) {
+        const double x = rng.uni();
+        if (x < sub) {
+            char b;
+            do b = kBases[rng.below(4)]; while (b == seq[(size_t)i]);
+            out->push_back({i, b}); ++i;
+        } else if (x < sub + ins) {
+            const uint32_t k = 1 + rng.below((uint32_t)max_indel);
+            for (uint32_t t = 0; t < k; ++t) out->push_back({-1, kBases[rng.below(4)]});
+            out->push_back({i, seq[(size_t)i]}); ++i;
+        } else if (x < sub + ins + dele) {
+            i += 1 + (int32_t)rng.below((uint32_t)max_indel);
+        } else {
+            out->push_back({i, seq[(size_t)i]}); ++i;
+        }
+    }
+}
+
+struct DRead { int32_t pos; std::vector<uint32_t> cig; std::string seq; };
+
+// columns [lo, hi) of a haplotype -> position, CIGAR and bases against the draft; false when no column is aligned
+bool read_from_cols(Rng& rng, const DCol* seg, int32_t n, double err, DRead* out) {
+    int32_t a = -1, z = -1;
+    for (int32_t k = 0; k < n; ++k) if (seg[k].d >= 0) { if (a < 0) a = k; z = k; }
+    if (a < 0) return false;
+    out->cig.clear();
+    out->seq.clear();
+    auto push_op = [&](uint32_t op, uint32_t len) {
+        if (!len) return;
+        if (!out->cig.empty() && (out->cig.back() & 0xf) == op) out->cig.back() += len << 4;
+        else out->cig.push_back(len << 4 | op);
+    };
+    push_op(4, (uint32_t)a);
+    for (int32_t k = 0; k < a; ++k) out->seq.push_back(seg[k].b);
+    out->pos = seg[a].d;
+    int32_t cur = out->pos;
+    bool any_m = false;
+    for (int32_t k = a; k <= z; ++k) {
+        char b = seg[k].b;
+        if (rng.chance(err)) { char c; do c = kBases[rng.below(4)]; while (c == b); b = c; }
+        if (seg[k].d < 0) {
+            push_op(1, 1);
+        } else {
+            if (seg[k].d > cur) push_op(2, (uint32_t)(seg[k].d - cur));
+            push_op(0, 1);
+            cur = seg[k].d + 1;
+            any_m = true;
+        }
+        out->seq.push_back(b);
+    }
+    push_op(4, (uint32_t)(n - z - 1));
+    for (int32_t k = z + 1; k < n; ++k) out->seq.push_back(seg[k].b);
+    return any_m && out->cig.size() <= 0xffffu;
+}
+
+void append_read(np::ReadStream* out, uint32_t c, const DRead& r, uint16_t flag, uint8_t mapq, int32_t isize, Rng& rng, uint32_t qlo, uint32_t qspan) {
+    out->pos.push_back(r.pos);
+    out->ctg.push_back(c);
+    out->flag.push_back(flag);
+    out->n_cigar.push_back((uint16_t)r.cig.size());
+    out->l_qseq.push_back((int32_t)r.seq.size());
+    out->mapq.push_back(mapq);
+    out->isize.push_back(isize);
+    out->cigar_off.push_back(out->cigar.size());
+    out->seq_off.push_back(out->seq.size());
+    out->cigar.insert(out->cigar.end(), r.cig.begin(), r.cig.end());
+    for (size_t k = 0; k < r.seq.size(); k += 2)
+        out->seq.push_back((uint8_t)(nt16(r.seq[k]) << 4 | (k + 1 < r.seq.size() ? nt16(r.seq[k + 1]) : 0)));
+    out->qual_off.push_back(out->qual.size());
+    for (size_t k = 0; k < r.seq.size(); ++k) out->qual.push_back((uint8_t)(qlo + rng.below(qspan)));
+}
+}  // namespace
+
+bool synth_diploid_streams(const np1_diploid_params& p, const std::string& prefix, ReadStream* sr, ReadStream* lr) {
+    sr->clear();
+    lr->clear();
+    Rng rng(p.seed);
+    for (ReadStream* o : {sr, lr}) { o->ctg_off.push_back(0); }
+    for (int32_t c = 0; c < p.n_contigs; ++c) {
+        const int32_t Lt = p.contig_len[c];
+        if (Lt < 400) return false;
+        std::string truth((size_t)Lt, 'A');
+        for (int32_t i = 0; i < Lt; ++i) truth[(size_t)i] = kBases[rng.below(4)];
+        std::vector<std::pair<int32_t, char>> hap[2], dr;
+        hap[0].reserve((size_t)Lt);
+        for (int32_t i = 0; i < Lt; ++i) hap[0].push_back({i, truth[(size_t)i]});
+        mutate_cols(rng, truth, p.het_sub, p.het_indel, p.het_indel, 3, &hap[1]);
+        mutate_cols(rng, truth, p.draft_err * 0.5, p.draft_err * 0.25, p.draft_err * 0.25, 3, &dr);
+        std::string draft;
+        std::vector<int32_t> d_of_t((size_t)Lt, -1);
+        for (size_t k = 0; k < dr.size(); ++k) {
+            draft.push_back(dr[k].second);
+            if (dr[k].first >= 0) d_of_t[(size_t)dr[k].first] = (int32_t)k;
+        }
+        std::vector<DCol> cols[2];
+        for (int h = 0; h < 2; ++h) {
+            cols[h].reserve(hap[h].size());
+            for (auto& e : hap[h]) cols[h].push_back(DCol{e.first >= 0 ? d_of_t[(size_t)e.first] : -1, e.second});
+        }
+        std::vector<std::pair<int32_t, int32_t>> holes;
+        for (int32_t k = 0; k < p.sr_holes; ++k) {
+            const int32_t a = (int32_t)rng.below((uint32_t)std::max(1, Lt - 200));
+            holes.push_back({a, a + 40 + (int32_t)rng.below(161)});
+        }
+        struct Tmp { DRead r; uint16_t flag; uint8_t mapq; int32_t isize; };
+        std::vector<Tmp> srs, lrs;
+        const int32_t RL = p.read_len;
+        const int64_t n_pairs = (int64_t)(p.sr_depth * Lt / (2.0 * RL));
+        static const uint8_t kMapq[6] = {60, 60, 60, 40, 20, 3};
+        for (int64_t t = 0; t < n_pairs; ++t) {
+            const int h = (int)rng.below(2);
+            const int32_t n = (int32_t)cols[h].size();
+            const int32_t f = std::max(RL + 1, (int32_t)std::lround(p.frag_mean + 30.0 * rng.normal()));
+            if (f >= n) continue;
+            const int32_t s = (int32_t)rng.below((uint32_t)(n - f));
+            bool in_hole = false;
+            for (auto& hl : holes) in_hole = in_hole || (hl.first <= s && s <= hl.second) || (hl.first <= s + f && s + f <= hl.second);
+            if (in_hole) continue;
+            Tmp m[2];
+            if (!read_from_cols(rng, cols[h].data() + s, RL, p.sr_err, &m[0].r) || !read_from_cols(rng, cols[h].data() + s + f - RL, RL, p.sr_err, &m[1].r)) continue;
+            const int32_t isz = m[1].r.pos + RL - m[0].r.pos;
+            for (int k = 0; k < 2; ++k) {
+                m[k].flag = (uint16_t)(0x1 | 0x2 | (k == 0 ? 0x40 | 0x20 : 0x80 | 0x10));
+                m[k].mapq = kMapq[rng.below(6)];
+                m[k].isize = k == 0 ? isz : -isz;
+                srs.push_back(m[k]);
+            }
+        }
+        const int64_t n_lr = (int64_t)(p.lr_depth * Lt / p.lr_len);
+        std::vector<DCol> seg;
+        static const uint8_t kMapqL[4] = {60, 60, 30, 10};
+        for (int64_t t = 0; t < n_lr; ++t) {
+            const int h = (int)rng.below(2);
+            const int32_t n = (int32_t)cols[h].size();
+            const int32_t ln = std::min(n - 1, std::max(200, (int32_t)std::lround(p.lr_len + p.lr_len / 3.0 * rng.normal())));
+            const int32_t s = (int32_t)rng.below((uint32_t)(n - ln));
+            seg.clear();
+            for (int32_t k = s; k < s + ln; ++k) {   // long-read indel noise: dropped / extra columns
+                const double x = rng.uni();
+                if (x < p.lr_err * 0.3) continue;
+                if (x < p.lr_err * 0.6) seg.push_back(DCol{-1, kBases[rng.below(4)]});
+                seg.push_back(cols[h][(size_t)k]);
+            }
+            Tmp m;
+            if (!read_from_cols(rng, seg.data(), (int32_t)seg.size(), p.lr_err * 0.4, &m.r)) continue;
+            m.flag = rng.chance(0.5) ? 16 : 0;
+            m.mapq = kMapqL[rng.below(4)];
+            m.isize = 0;
+            lrs.push_back(std::move(m));
+        }
+        char nm[64];
+        snprintf(nm, sizeof(nm), "%s%04d", prefix.c_str(), c + 1);
+        for (int w = 0; w < 2; ++w) {
+            ReadStream* o = w == 0 ? sr : lr;
+            std::vector<Tmp>& v = w == 0 ? srs : lrs;
+            std::vector<uint32_t> order(v.size());
+            std::iota(order.begin(), order.end(), 0u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return v[a].r.pos < v[b].r.pos; });
+            o->names.push_back(nm);
+            o->ctg_len.push_back((int32_t)draft.size());
+            o->draft += draft;
+            o->ctg_off.push_back((uint32_t)o->draft.size());
+            o->read_begin.push_back(o->n_reads());
+            for (uint32_t oi : order) append_read(o, (uint32_t)c, v[oi].r, v[oi].flag, v[oi].mapq, v[oi].isize, rng, w == 0 ? 20u : 5u, 21u);
+        }
+    }
+    sr->read_begin.push_back(sr->n_reads());
+    lr->read_begin.push_back(lr->n_reads());
+    return true;
+}
+}  // namespace np

@@ -33,4 +33,6 @@ bool write_stream_files(const ReadStream& s, const std::string& fasta, const std
 // Several streams as ONE FASTA + ONE coordinate-sorted BAM (contigs of stream 0, then of stream 1, ...).
 bool write_streams_files(const std::vector<const ReadStream*>& ss, const std::string& fasta, const std::string& bam, int bgzf_level,
                          std::string* err, const uint8_t* aux_pool = nullptr, const uint64_t* aux_off = nullptr);
+// diploid workload of task 3: short-read and long-read stream over the same contigs (np1_diploid_params, include/nextpolish1.h)
+bool synth_diploid_streams(const np1_diploid_params& p, const std::string& contig_name_prefix, ReadStream* sr, ReadStream* lr);
 }  // namespace np

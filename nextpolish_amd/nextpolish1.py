@@ -12,8 +12,9 @@ Same command line, same block-file / resume / naming behaviour, same output reco
   reference: nextpolish1.py:181-189,223-224 and source/nextPolish:93-117 for the block split).
 * ``-debug`` needs the per-base change list of the drop-in ABI and therefore goes contig by contig through
   ``score_chain(tigname, cfg)`` exactly like the reference worker (nextpolish1.py:181-189).
-* task 3 (snp_phase: short reads + long reads of one contig) goes contig by contig through the drop-in symbol ``snp_phase(tigname, cfg)``,
-  which runs the device pass of np1_phase_device.hip; task 5 reports that it is not available (the reference's own caller refuses it).
+* task 3 (snp_phase: short reads + long reads): batches of ``--batch_bp`` draft bases, per batch two resident record batches and one
+  ``np1_batch_snp_phase`` pass (np1_phase_device.hip); with ``-debug`` contig by contig through the drop-in symbol.  Task 5 reports that it is
+  not available (the reference's own caller refuses it).
 
 Record order is the order of the block file / FASTA (the reference's order is nondeterministic: it
 iterates a Python set through imap_unordered, nextpolish1.py:148-161,224).
@@ -163,6 +164,34 @@ def polish_batched(args, cfg, names, device, emit):
         pipe.close()
 
 
+def polish_phase_batched(args, cfg, names, device, emit):
+    """Task 3 without -debug: the rank's contigs in batches of --batch_bp draft bases; per batch the short-read and the long-read
+    records of its contigs become two resident batches and one np1_batch_snp_phase pass (reference: one snp_phase(tigname, cfg)
+    call per contig and worker, source/lib/nextpolish1.py:95-96,181-189)."""
+    from nextpolish_amd.device import Context
+    lengths = fasta_lengths(args.genome)
+    names = [n for n in names if n in lengths]
+    if not names:
+        return
+    if not args.bam_sgs or not args.bam_lgs:
+        raise SystemExit("task 3 needs both -s (short-read BAM) and -l (long-read BAM)")
+    ctx = Context(device)
+    try:
+        for batch in plan_batches(names, lengths, args.batch_bp):
+            sr = nat.Stream.load(args.genome, args.bam_sgs, names=batch, with_qual=True)
+            lr = nat.Stream.load(args.genome, args.bam_lgs, names=batch, with_qual=True)
+            b, bl = ctx.upload(sr), ctx.upload(lr)
+            try:
+                b.snp_phase(bl, cfg.contents)
+                for name, seq in zip(batch, b.results()):
+                    emit(name, seq, [])
+            finally:
+                bl.close()
+                b.close()
+    finally:
+        ctx.close()
+
+
 def polish_per_contig(args, cfg, names, fun, emit):
     L = nat.lib()
     for name in names:
@@ -209,6 +238,8 @@ def main(args):
     if args.task in (1, 2, 4) and not args.debug:
         device = args.device if args.device >= 0 else args.rank
         polish_batched(args, cfg, names, device, emit)
+    elif args.task == 3 and not args.debug:
+        polish_phase_batched(args, cfg, names, args.device if args.device >= 0 else args.rank, emit)
     else:
         polish_per_contig(args, cfg, names, fun, emit)
     if args.out != "stdout":

@@ -298,13 +298,17 @@ def test_gpu_dropin_symbol_cli_and_caller_on_real_alignments(tmp_path):
         L.polishresult_destory(r)
     L.config_destory(cfg)
     exe = os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1")
-    p = subprocess.run([exe, "snpphase", fa, sr, lr], capture_output=True, text=True)
-    assert p.returncode == 0, p.stderr
-    assert {n: digest(x) for n, x in parse_cli_fasta(p.stdout).items()} == g["snp_phase"]
+    for batch_bp in ("16000000", "55000"):      # both contigs in one batch; one batch per contig
+        p = subprocess.run([exe, "snpphase", fa, sr, lr], capture_output=True, text=True, env=dict(os.environ, NP1_BATCH_BP=batch_bp))
+        assert p.returncode == 0, p.stderr
+        assert {n: digest(x) for n, x in parse_cli_fasta(p.stdout).items()} == g["snp_phase"]
     out = str(tmp_path / "o.fa")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "nextpolish_amd", "nextpolish1.py"), "-g", fa, "-t", "3", "-s", sr, "-l", lr, "-o", out],
-                       capture_output=True, text=True)
-    assert p.returncode == 0, p.stderr
-    recs = open(out).read().strip().split("\n")
-    got = {recs[k].split()[0][1:]: recs[k + 1] for k in range(0, len(recs), 2)}
-    assert {n.rsplit("_np", 1)[0]: digest(x) for n, x in got.items()} == {n.rsplit("_np", 1)[0]: d for n, d in g["snp_phase"].items()}
+    for extra in ([], ["--batch_bp", "55000"], ["-debug"]):      # batched (one / two batches) and contig by contig through the drop-in symbol
+        if os.path.exists(out):
+            os.remove(out)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "nextpolish_amd", "nextpolish1.py"), "-g", fa, "-t", "3", "-s", sr, "-l", lr, "-o", out] + extra,
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        recs = open(out).read().strip().split("\n")
+        got = {recs[k].split()[0][1:]: recs[k + 1] for k in range(0, len(recs), 2)}
+        assert {n.rsplit("_np", 1)[0]: digest(x) for n, x in got.items()} == {n.rsplit("_np", 1)[0]: d for n, d in g["snp_phase"].items()}, extra
