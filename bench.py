@@ -18,6 +18,7 @@ in flight so the host-side syncs of one hide behind the kernels of the other.  B
   cpu_baseline      the compiled reference (oracle/_ref/nextpolish1) on this box's host cores, one process per core like -p N,
                     and one core alone, on a bounded sample of the same shape (rank 0, N=1 only)
   lgs               the long-read path (lib/nextpolish2.so ctg_cns_core) with its own roofline and cpu_baseline
+  snp_phase         task 3 (np1_batch_snp_phase): diploid draft, short + long reads resident in HBM, with the compiled reference beside it (N=1 only)
 """
 import argparse
 import json
@@ -299,6 +300,73 @@ def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref, with_pmc):
     return res
 
 
+def phase_leg(device_index, mb, passes, procs, with_ref):
+    """snp_phase (task 3, lib/nextpolish1.so np1_batch_snp_phase): one diploid draft, 30x short read pairs + 20x long reads, both
+    record batches resident in HBM; a pass = sites, low-depth correction, links, chain, emit.  Beside it the compiled reference
+    (`nextpolish1 snpphase`, BAM files -> FASTA) on all cores and on one."""
+    from nextpolish_amd import _native as nat
+    from nextpolish_amd import device
+    n_ctg = max(1, int(mb // 4))
+    lens = [int(mb * 1e6 / n_ctg)] * n_ctg
+    t0 = time.time()
+    sr, lr = nat.Stream.synth_diploid(lens, seed=9090, sr_holes=2)
+    t_gen = time.time() - t0
+    bp = int(sr.ctg_len.sum())
+    cfg = nat.default_config()
+    cfg.read_tlen, cfg.read_len = 2000, 150      # what config_init derives from this short-read BAM (mean insert 400 x 5)
+    out = {"metric": "polished Mbp/s (snp_phase, 30x short + 20x long reads, record batches resident in HBM)", "unit": "Mbp/s"}
+    ctx = device.Context(device_index)
+    try:
+        b, bl = ctx.upload(sr), ctx.upload(lr)
+        b.snp_phase(bl, cfg)
+        times = []
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            b.snp_phase(bl, cfg)
+            nat.lib().np1_batch_sync(b.handle)
+            times.append(time.perf_counter() - t0)
+        alg = sr.algorithmic_bytes(True) + lr.algorithmic_bytes(True)
+        best = min(times)
+        out.update({"value": round(bp / 1e6 / best, 2), "ms_per_pass": round(best * 1e3, 2), "passes": passes,
+                    "achieved_whole_pass_gbs": round(alg / best / 1e9, 2),
+                    "config": {"workload": "%.1f Mb diploid draft in %d contigs (0.2 %% heterozygous substitutions, 0.03 %% indel alleles, 0.2 %% draft errors) + 30x PE150 "
+                                           "(%d records) + 20x long reads of 8 kb, 4 %% errors (%d records); synthetic, generated in %.1f s"
+                                           % (bp / 1e6, n_ctg, sr.n_reads, lr.n_reads, t_gen)}})
+        bl.close()
+        b.close()
+    finally:
+        ctx.close()
+    ref = os.path.join(ROOT, "oracle", "_ref", "nextpolish1")
+    if with_ref and os.path.exists(ref):
+        td = tempfile.mkdtemp(prefix="np1phase_")
+        try:
+            Ls = 1000000
+
+            def make(k):
+                a, c = nat.Stream.synth_diploid([Ls], seed=777 + k, sr_holes=2, prefix="s%dctg" % k)
+                fa, s_bam, l_bam = os.path.join(td, "s%d.fa" % k), os.path.join(td, "s%d.sr.bam" % k), os.path.join(td, "s%d.lr.bam" % k)
+                a.write_files(fa, s_bam, 1)
+                c.write_files(os.path.join(td, "l%d.fa" % k), l_bam, 1)
+                return fa, s_bam, l_bam
+            with ThreadPoolExecutor(min(8, procs)) as ex:
+                files = list(ex.map(make, range(procs)))
+            t0 = time.time()
+            ps = [subprocess.Popen([ref, "snpphase", fa, s_bam, l_bam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for fa, s_bam, l_bam in files]
+            for q in ps:
+                q.wait()
+            dt_all = time.time() - t0
+            t0 = time.time()
+            subprocess.run([ref, "snpphase"] + list(files[0]), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            dt_one = time.time() - t0
+            out["cpu_baseline"] = {"value": round(procs * Ls / 1e6 / dt_all, 3), "unit": "Mbp/s", "cores": procs, "kind": "reference",
+                                   "one_core": round(Ls / 1e6 / dt_one, 3),
+                                   "sample": "%d processes x 1 Mb diploid contig of the same kind, nextpolish1 snpphase, two BAM files -> FASTA, %.1f s; one process alone %.1f s"
+                                             % (procs, dt_all, dt_one)}
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    return out
+
+
 def e2e_from_files(streams, draft_bp, threads):
     """Scope 2: one FASTA + one sorted BAM on disk (page cache) -> polished FASTA through the CLI, cold process each time
     (HIP start-up, BGZF inflate, record split, H2D, kernels, D2H, FASTA text all inside)."""
@@ -359,6 +427,8 @@ def main():
     ap.add_argument("--lgs-workers", type=int, default=12, help="worker processes per GPU of the long-read leg")
     ap.add_argument("--lgs-mb", type=float, default=5.0, help="contig length (Mb) each long-read worker polishes")
     ap.add_argument("--lgs-calls", type=int, default=4)
+    ap.add_argument("--no-phase", action="store_true", help="skip the snp_phase (task 3) leg")
+    ap.add_argument("--phase-mb", type=float, default=20.0, help="draft length (Mb) of the snp_phase leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -538,6 +608,11 @@ def main():
                         out["lgs"][k] = lgs[k]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(depth, args.cpu_sample_mb, ncpu)
+        if world == 1 and not args.no_phase:
+            try:
+                out["snp_phase"] = phase_leg(local_rank, args.phase_mb, 3, ncpu, not args.no_cpu_baseline)
+            except Exception as e:   # the headline line must survive a failure of an extra leg
+                out["snp_phase"] = {"error": str(e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
