@@ -336,6 +336,24 @@ def phase_leg(device_index, mb, passes, procs, with_ref):
         b.close()
     finally:
         ctx.close()
+    # the same draft from files: FASTA + two sorted BAM files in the page cache -> polished FASTA, cold process of the CLI
+    td = tempfile.mkdtemp(prefix="np1phase_e2e_")
+    try:
+        fa, s_bam, l_bam = os.path.join(td, "g.fa"), os.path.join(td, "sr.bam"), os.path.join(td, "lr.bam")
+        sr.write_files(fa, s_bam, 1)
+        lr.write_files(os.path.join(td, "l.fa"), l_bam, 1)
+        exe = os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1")
+        env = dict(os.environ, NP1_DEVICE=str(device_index), NP_IO_THREADS=str(procs), NP1_BATCH_BP=str(int(mb * 1e6) + 1000000))
+        t0 = time.time()
+        q = subprocess.run([exe, "snpphase", fa, s_bam, l_bam], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+        dt = time.time() - t0
+        out["e2e_from_files"] = ({"mbp_s": round(bp / 1e6 / dt, 2), "seconds": round(dt, 2), "bam_mb": round((os.path.getsize(s_bam) + os.path.getsize(l_bam)) / 1e6, 1),
+                                  "what": "nextpolish1 snpphase, cold process: BAI-less sequential read of both BAM files on %d host threads, one batch pair, FASTA out" % procs}
+                                 if q.returncode == 0 else {"error": q.stderr.decode()[-300:]})
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    sr.close()
+    lr.close()
     ref = os.path.join(ROOT, "oracle", "_ref", "nextpolish1")
     if with_ref and os.path.exists(ref):
         td = tempfile.mkdtemp(prefix="np1phase_")

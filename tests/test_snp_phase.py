@@ -195,6 +195,23 @@ def test_low_depth_regions_that_touch_vs_reference(tmp_path):
     assert changed > 6
 
 
+@needs_ref
+def test_cpp_diploid_generator_workload_vs_reference(tmp_path):
+    """the workload bench.py's snp_phase leg times (np1_stream_synth_diploid): reference == oracle == host model"""
+    s, l = nat.Stream.synth_diploid([150000, 40000], seed=11, sr_holes=2)
+    fa, sr, lr = str(tmp_path / "s.fa"), str(tmp_path / "sr.bam"), str(tmp_path / "lr.bam")
+    s.write_files(fa, sr)
+    l.write_files(str(tmp_path / "l.fa"), lr)
+    ref = run_ref3(fa, sr, lr)
+    cfgp = nat.lib().config_init(fa.encode(), sr.encode(), lr.encode())
+    tlen, rlen = cfgp.contents.read_tlen, cfgp.contents.read_len
+    nat.lib().config_destory(cfgp)
+    cfg = ob.default_config(read_tlen=tlen, read_len=rlen)
+    for i, n in enumerate(s.names):
+        assert ob.snp_phase(s, l, i, cfg) == ref[n], n
+    assert _model_case(s, l, tlen, rlen)
+
+
 def test_host_model_on_real_alignments():
     g = GOLD["real"]["s30+ont"]
     s, l = real_streams(g)
@@ -271,6 +288,13 @@ def test_gpu_low_depth_regions_that_touch(ctx):
 def test_gpu_many_contigs_in_one_batch(ctx):
     s, l = streams(dict(seed=77, lens=tuple(900 + 61 * k for k in range(24)), sr_depth=30, lr_depth=15, het=0.01, het_indel=0.002, sr_holes=1))
     assert _check(ctx, s, l)
+
+
+@pytest.mark.gpu
+def test_gpu_megabase_contigs(ctx):
+    """2 x 1.5 Mb + a small contig in one batch pair (8 500 sites, 100 000 links): product == oracle"""
+    s, l = nat.Stream.synth_diploid([1500000, 1500000, 30000], seed=5, sr_holes=3)
+    assert _check(ctx, s, l, 2000, 150)
 
 
 @pytest.mark.gpu
