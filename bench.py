@@ -348,7 +348,7 @@ def phase_leg(device_index, mb, passes, procs, with_ref):
         q = subprocess.run([exe, "snpphase", fa, s_bam, l_bam], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
         dt = time.time() - t0
         out["e2e_from_files"] = ({"mbp_s": round(bp / 1e6 / dt, 2), "seconds": round(dt, 2), "bam_mb": round((os.path.getsize(s_bam) + os.path.getsize(l_bam)) / 1e6, 1),
-                                  "what": "nextpolish1 snpphase, cold process: BAI-less sequential read of both BAM files on %d host threads, one batch pair, FASTA out" % procs}
+                                  "what": "nextpolish1 snpphase, cold process: short-read BAM through the device-side ingest, long-read BAM through the host loader (%d threads), one batch pair, FASTA out" % procs}
                                  if q.returncode == 0 else {"error": q.stderr.decode()[-300:]})
     finally:
         shutil.rmtree(td, ignore_errors=True)

@@ -240,6 +240,11 @@ void np1_pipe_close(np1_pipe* p);
 typedef void (*np1_sink_fn)(void* user, const char* name, const char* seq, int64_t len);
 int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const char* const* names, int n_names, int64_t batch_bp,
                        const Configure* cfg, int task, np1_sink_fn sink, void* user);
+/* Task 3 (snp_phase) from files: per batch the short-read BAM goes through the device-side ingest (compressed blocks -> HBM ->
+ * inflate + record split on the GPU), the long-read BAM through the host loader, then one np1_batch_snp_phase pass on lane 0;
+ * a loader thread stages the next batch meanwhile.  Contigs reach `sink` in request order. */
+int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr, const char* bam_lr, const char* const* names, int n_names,
+                             int64_t batch_bp, const Configure* cfg, np1_sink_fn sink, void* user);
 
 /* Names of the timed stages of one score_chain pass, in launch order (for profiles / roofline). */
 #define NP1_MAX_STAGES 16

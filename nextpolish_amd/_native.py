@@ -182,6 +182,9 @@ def lib():
     L.np1_pipe_run_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int64,
                                      C.POINTER(Configure), C.c_int, SINK_FN, C.c_void_p]
     L.np1_pipe_run_files.restype = C.c_int
+    L.np1_pipe_run_phase_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int64,
+                                           C.POINTER(Configure), SINK_FN, C.c_void_p]
+    L.np1_pipe_run_phase_files.restype = C.c_int
     _lib = L
     return L
 

@@ -76,50 +76,19 @@ int main(int argc, char* argv[]) {
         long long batch_bp = 16000000;
         if (const char* e = getenv("NP1_DEVICE")) dev = atoi(e);
         if (const char* e = getenv("NP1_BATCH_BP")) batch_bp = atoll(e);
-        std::vector<std::string> names;
-        std::vector<long long> lens;
-        if (FILE* fai = fopen((std::string(cfg->fastafn) + ".fai").c_str(), "r")) {   // contig names and lengths: the FASTA index when it is there
-            char nm[4096];
-            long long len;
-            while (fscanf(fai, "%4095s %lld %*[^\n]", nm, &len) == 2) { names.push_back(nm); lens.push_back(len); }
-            fclose(fai);
+        np1_pipe* pipe = np1_pipe_open(dev, 1);
+        if (!pipe) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
+        struct Out { int step; } out{step};
+        auto sink = [](void* user, const char* name, const char* seq, int64_t len) {
+            printf(">%s_%d\n", name, static_cast<Out*>(user)->step);
+            fwrite(seq, 1, (size_t)len, stdout);
+            fputc('\n', stdout);
+        };
+        if (np1_pipe_run_phase_files(pipe, cfg->fastafn, cfg->bamfn, cfg->thirdbamfn, nullptr, 0, batch_bp, cfg, sink, &out) != 0) {
+            fprintf(stderr, "%s\n", np1_last_error());
+            return 1;
         }
-        if (names.empty()) {   // else from a first pass over the short-read stream (which also writes the index)
-            np1_stream* all = np1_stream_load(cfg->fastafn, cfg->bamfn, nullptr, 0, 0);
-            if (!all) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
-            np1_stream_view v;
-            np1_stream_get_view(all, &v);
-            for (int64_t c = 0; c < v.n_contigs; ++c) { names.push_back(np1_stream_contig_name(all, c)); lens.push_back(v.ctg_len[c]); }
-            np1_stream_free(all);
-        }
-        np1_ctx* ctx = np1_ctx_create(dev);
-        if (!ctx) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
-        for (size_t first = 0; first < names.size();) {
-            size_t last = first;
-            long long bp = 0;
-            while (last < names.size() && (last == first || bp + lens[last] <= batch_bp)) bp += lens[last++];
-            std::vector<const char*> nm;
-            for (size_t k = first; k < last; ++k) nm.push_back(names[k].c_str());
-            const bool whole = first == 0 && last == names.size();   // every contig: one sequential pass over each BAM file, no index seeks
-            np1_stream* ss = np1_stream_load(cfg->fastafn, cfg->bamfn, whole ? nullptr : nm.data(), whole ? 0 : (int)nm.size(), 1);
-            np1_stream* sl = ss ? np1_stream_load(cfg->fastafn, cfg->thirdbamfn, whole ? nullptr : nm.data(), whole ? 0 : (int)nm.size(), 1) : nullptr;
-            np1_batch* b = sl ? np1_batch_upload(ctx, ss) : nullptr;
-            np1_batch* l = b ? np1_batch_upload(ctx, sl) : nullptr;
-            if (!l || np1_batch_snp_phase(b, l, cfg) != 0 || np1_batch_results_fetch(b) != 0) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
-            const char* res = np1_batch_results_ptr(b);
-            const uint32_t* bounds = np1_batch_results_bounds(b);
-            for (size_t k = first; k < last; ++k) {
-                printf(">%s_%d\n", names[k].c_str(), step);
-                fwrite(res + bounds[k - first], 1, bounds[k - first + 1] - bounds[k - first], stdout);
-                fputc('\n', stdout);
-            }
-            np1_batch_free(l);
-            np1_batch_free(b);
-            np1_stream_free(sl);
-            np1_stream_free(ss);
-            first = last;
-        }
-        np1_ctx_destroy(ctx);
+        np1_pipe_close(pipe);
     } else {
         PolishResult* (*fn)(const char*, Configure*) = step == 2 ? kmer_count : step == 3 ? snp_phase : step == 4 ? snp_valid : lgspolish;
         np1_stream* st = np1_stream_load(cfg->fastafn, cfg->bamfn ? cfg->bamfn : argv[3], nullptr, 0, 0);

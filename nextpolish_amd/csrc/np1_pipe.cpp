@@ -36,6 +36,7 @@ struct np1_pipe {
     // from-files mode: pinned staging buffers and per-lane HBM scratch live as long as the pipe (allocated on first use)
     std::vector<np1ingest::Staging*> staging;
     std::vector<np1ingest::Scratch*> scratch;
+    np1_batch* phase_lr = nullptr;                 // np1_pipe_run_phase_files: the long-read batch, on lane 0's context
 };
 
 namespace {
@@ -148,6 +149,7 @@ int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passe
 
 void np1_pipe_close(np1_pipe* p) {
     if (!p) return;
+    if (p->phase_lr) np1_batch_free(p->phase_lr);
     drop_resident(p);
     for (np1ingest::Scratch* s : p->scratch) np1ingest::scratch_destroy(s);
     for (np1ingest::Staging* s : p->staging) delete s;
@@ -378,6 +380,112 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
     for (np1ingest::Scratch* s : scratch) host_blocks += np1ingest::scratch_host_blocks(s);
     p->host_inflated_blocks = host_blocks;     // cumulative over the life of the pipe
     if (failed) { np1_set_error(err); return -1; }
+    return 0;
+}
+
+// Task 3 from files (reference: one snp_phase(tigname, cfg) call per contig and worker, nextpolish1.py:95-96,181-189): contigs in
+// batches of batch_bp draft bases; per batch the short-read records come in as compressed BGZF blocks and are inflated and split
+// on the device (np1_ingest.hip; host loader where the index or the records do not allow it), the long-read records -- a few
+// per cent of the bytes -- are decoded by the host loader, both land in two batches of lane 0 and one np1_batch_snp_phase pass
+// runs over them.  A loader thread stages batch k + 1 while the device works on batch k.
+int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr, const char* bam_lr, const char* const* names, int n_names, int64_t batch_bp,
+                             const Configure* cfg, np1_sink_fn sink, void* user) {
+    if (!p || !fasta || !bam_sr || !bam_lr || !cfg) { np1_set_error("np1_pipe_run_phase_files: null argument"); return -1; }
+    np1ingest::BamSource src;
+    {
+        std::string e;
+        if (!src.open(fasta, bam_sr, &e)) { np1_set_error(e); return -1; }
+    }
+    const np::Fai& fai = src.fai;
+    std::vector<std::string> want;
+    if (names && n_names > 0) for (int i = 0; i < n_names; ++i) want.push_back(names[i]);
+    else for (int i = 0; i < fai.nseq(); ++i) want.push_back(fai.entry(i).name);
+    std::vector<std::vector<std::string>> plan;
+    int64_t cur_bp = 0;
+    for (const std::string& nm : want) {
+        const int id = fai.find(nm);
+        if (id < 0) { np1_set_error("contig not in FASTA index: " + nm); return -1; }
+        const int64_t L = fai.entry(id).len;
+        if (plan.empty() || (cur_bp > 0 && cur_bp + L > batch_bp)) { plan.emplace_back(); cur_bp = 0; }
+        plan.back().push_back(nm);
+        cur_bp += L;
+    }
+    const int n = (int)plan.size();
+    const bool all_in_one = n == 1 && !(names && n_names > 0);   // every contig: sequential passes over the files, no index seeks
+    const char* ing = getenv("NP1_INGEST");
+    const bool device_ingest = src.have_bai && !(ing && strcmp(ing, "host") == 0);
+    np1_pipe::Lane& ln = p->lanes[0];
+    if (!p->phase_lr) p->phase_lr = np1_batch_create(ln.ctx);
+    if (!p->phase_lr) return -1;
+    while (device_ingest && p->staging.size() < 2) p->staging.push_back(new np1ingest::Staging());
+    p->scratch.resize(p->lanes.size(), nullptr);
+    struct Item { np1ingest::Staging* staging = nullptr; np1_stream* sr = nullptr; np1_stream* lr = nullptr; std::string err; };
+    auto load_host = [&](int k, const char* bam) -> np1_stream* {
+        std::vector<const char*> nm;
+        for (const std::string& s : plan[(size_t)k]) nm.push_back(s.c_str());
+        np1_stream* st = all_in_one ? np1_stream_load(fasta, bam, nullptr, 0, 1) : np1_stream_load(fasta, bam, nm.data(), (int)nm.size(), 1);
+        if (st) (void)np1_stream_pin(st);
+        return st;
+    };
+    auto stage = [&](int k) -> Item {   // host half of batch k
+        Item it;
+        const double t0 = now_ms();
+        std::thread lr_thread([&] { it.lr = load_host(k, bam_lr); if (!it.lr) it.err = np1_last_error(); });
+        if (device_ingest) {
+            np1ingest::Staging* sg = p->staging[(size_t)k % 2];
+            std::string e;
+            const int rc = np1ingest::prepare(src, plan[(size_t)k], sg, &e);
+            if (rc < 0) it.err = e;
+            else if (rc == 0) it.staging = sg;
+        }
+        if (!it.staging && it.err.empty()) {
+            it.sr = load_host(k, bam_sr);
+            if (!it.sr) it.err = np1_last_error();
+        }
+        lr_thread.join();
+        if (timing_on()) fprintf(stderr, "[np1 phase] batch %d staged on the host in %.1f ms (short reads: %s)\n", k, now_ms() - t0, it.staging ? "compressed blocks" : "host loader");
+        return it;
+    };
+    auto drop = [](Item& it) { if (it.sr) np1_stream_free(it.sr); if (it.lr) np1_stream_free(it.lr); it.sr = it.lr = nullptr; };
+    Item cur = n > 0 ? stage(0) : Item();
+    int rc = 0;
+    std::string err;
+    for (int k = 0; k < n && rc == 0; ++k) {
+        Item next;
+        std::thread pre;
+        if (k + 1 < n) pre = std::thread([&, k] { next = stage(k + 1); });
+        std::vector<std::string> nm = plan[(size_t)k];
+        const double t0 = now_ms();
+        if (!cur.err.empty()) { err = cur.err; rc = -1; }
+        if (rc == 0 && cur.staging) {
+            if (!p->scratch[0]) p->scratch[0] = np1ingest::scratch_create();
+            rc = np1ingest::ingest(ln.batch, cur.staging, true, p->scratch[0]);
+            if (rc == 1) {   // records the device path does not take: the host loader decodes this batch
+                cur.sr = load_host(k, bam_sr);
+                rc = cur.sr ? 0 : -1;
+            } else if (rc == 0) {
+                nm = cur.staging->names();
+            }
+        }
+        if (rc == 0 && cur.sr) rc = np1_batch_reload(ln.batch, cur.sr);
+        if (rc == 0) rc = np1_batch_reload(p->phase_lr, cur.lr);
+        const double t1 = now_ms();
+        if (rc == 0) rc = np1_batch_snp_phase(ln.batch, p->phase_lr, cfg);
+        const double t2 = now_ms();
+        if (rc == 0) rc = np1_batch_results_fetch(ln.batch);
+        if (rc != 0 && err.empty()) err = np1_last_error();
+        if (timing_on()) fprintf(stderr, "[np1 phase] batch %d: ingest %.1f ms, snp_phase %.1f ms, fetch %.1f ms\n", k, t1 - t0, t2 - t1, now_ms() - t2);
+        if (rc == 0 && sink) {
+            const uint32_t* b = np1_batch_results_bounds(ln.batch);
+            const char* s = np1_batch_results_ptr(ln.batch);
+            for (size_t c = 0; c < nm.size(); ++c) sink(user, nm[c].c_str(), s + b[c], (int64_t)b[c + 1] - (int64_t)b[c]);
+        }
+        drop(cur);
+        if (pre.joinable()) pre.join();
+        cur = next;
+    }
+    drop(cur);
+    if (rc != 0) { np1_set_error(err); return -1; }
     return 0;
 }
 

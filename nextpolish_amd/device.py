@@ -158,6 +158,23 @@ class Pipe(object):
             raise RuntimeError("np1_pipe_run_files: " + nat.last_error())
         return got
 
+    def run_phase_files(self, fasta, bam_sr, bam_lr, names=None, batch_bp=16000000, cfg=None, sink=None):
+        """Task 3 from files: FASTA + short-read BAM + long-read BAM -> sink(name, sequence) per contig in request order
+        (np1_pipe_run_phase_files: device-side ingest of the short reads, host loader for the long reads, one snp_phase pass per batch)."""
+        cfg = cfg or nat.default_config()
+        got = []
+
+        def _sink(_user, name, seq, length):
+            (sink or (lambda a, b: got.append((a, b))))(name.decode(), C.string_at(seq, length).decode())
+
+        cb = nat.SINK_FN(_sink)
+        names = list(names or [])
+        arr = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        if nat.lib().np1_pipe_run_phase_files(self.handle, fasta.encode(), bam_sr.encode(), bam_lr.encode(), arr if names else None, len(names), batch_bp,
+                                              C.byref(cfg), cb, None) != 0:
+            raise RuntimeError("np1_pipe_run_phase_files: " + nat.last_error())
+        return got
+
     def close(self):
         if self.handle:
             nat.lib().np1_pipe_close(self.handle)

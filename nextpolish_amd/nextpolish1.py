@@ -165,31 +165,22 @@ def polish_batched(args, cfg, names, device, emit):
 
 
 def polish_phase_batched(args, cfg, names, device, emit):
-    """Task 3 without -debug: the rank's contigs in batches of --batch_bp draft bases; per batch the short-read and the long-read
-    records of its contigs become two resident batches and one np1_batch_snp_phase pass (reference: one snp_phase(tigname, cfg)
-    call per contig and worker, source/lib/nextpolish1.py:95-96,181-189)."""
-    from nextpolish_amd.device import Context
+    """Task 3 without -debug: the rank's contigs in batches of --batch_bp draft bases; per batch the short reads come through the
+    device-side ingest, the long reads through the host loader, then one np1_batch_snp_phase pass (np1_pipe_run_phase_files;
+    reference: one snp_phase(tigname, cfg) call per contig and worker, source/lib/nextpolish1.py:95-96,181-189)."""
+    from nextpolish_amd.device import Pipe
     lengths = fasta_lengths(args.genome)
     names = [n for n in names if n in lengths]
     if not names:
         return
     if not args.bam_sgs or not args.bam_lgs:
         raise SystemExit("task 3 needs both -s (short-read BAM) and -l (long-read BAM)")
-    ctx = Context(device)
+    pipe = Pipe(device, 1)
     try:
-        for batch in plan_batches(names, lengths, args.batch_bp):
-            sr = nat.Stream.load(args.genome, args.bam_sgs, names=batch, with_qual=True)
-            lr = nat.Stream.load(args.genome, args.bam_lgs, names=batch, with_qual=True)
-            b, bl = ctx.upload(sr), ctx.upload(lr)
-            try:
-                b.snp_phase(bl, cfg.contents)
-                for name, seq in zip(batch, b.results()):
-                    emit(name, seq, [])
-            finally:
-                bl.close()
-                b.close()
+        pipe.run_phase_files(args.genome, args.bam_sgs, args.bam_lgs, names=names, batch_bp=args.batch_bp, cfg=cfg.contents,
+                             sink=lambda name, seq: emit(name, seq, []))
     finally:
-        ctx.close()
+        pipe.close()
 
 
 def polish_per_contig(args, cfg, names, fun, emit):

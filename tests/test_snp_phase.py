@@ -307,6 +307,33 @@ def test_gpu_batches_of_real_alignments(ctx, tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ingest", ["device", "host"])
+def test_gpu_from_files_in_batches(tmp_path, ingest, monkeypatch):
+    """np1_pipe_run_phase_files: five contigs in three batches, short reads through the device-side ingest (or the host loader),
+    long reads through the host loader, the next batch staged while the device works: every contig == oracle"""
+    from nextpolish_amd.device import Pipe
+    monkeypatch.setenv("NP1_INGEST", ingest)
+    s, l = nat.Stream.synth_diploid([300000, 120000, 200000, 90000, 250000], seed=21, sr_holes=2)
+    fa, sr, lr = str(tmp_path / "g.fa"), str(tmp_path / "sr.bam"), str(tmp_path / "lr.bam")
+    s.write_files(fa, sr)
+    l.write_files(str(tmp_path / "l.fa"), lr)
+    cfgp = nat.lib().config_init(fa.encode(), sr.encode(), lr.encode())
+    ocfg = ob.default_config(read_tlen=cfgp.contents.read_tlen, read_len=cfgp.contents.read_len)
+    want = {n: ob.snp_phase(s, l, i, ocfg) for i, n in enumerate(s.names)}
+    pipe = Pipe(0, 1)
+    try:
+        got = pipe.run_phase_files(fa, sr, lr, batch_bp=450000, cfg=cfgp.contents)
+        assert [n for n, _ in got] == list(s.names)
+        assert dict(got) == want
+        sub = [s.names[3], s.names[1]]                         # a subset, in another order: index seeks
+        got = pipe.run_phase_files(fa, sr, lr, names=sub, batch_bp=16000000, cfg=cfgp.contents)
+        assert [n for n, _ in got] == sub and dict(got) == {n: want[n] for n in sub}
+    finally:
+        pipe.close()
+        nat.lib().config_destory(cfgp)
+
+
+@pytest.mark.gpu
 def test_gpu_dropin_symbol_cli_and_caller_on_real_alignments(tmp_path):
     """snp_phase(tigname, cfg) like source/lib/nextpolish1.py:95-96,220; `nextpolish1 snpphase fa bam bam3` like main.c:7-8,39; the
     Python caller with -t 3."""
