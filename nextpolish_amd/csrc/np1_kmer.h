@@ -525,13 +525,25 @@ NP1_HD bool kc_region_solve(const KcCtx& c, uint32_t g0, int32_t start, int32_t 
         if (c.third_rule) {   // ts_region_correct (snpphase.c:843-871): long-read evidence marks, the base only where the rule lets it
             const bool col0 = s == c.soff[c.sown[s]];
             if ((c.sflag[s] & KC_FLAG_ZERO) || (col0 && b != 3)) c.sbase[s] = (uint8_t)b;
-            uint32_t mc[16], order[16], nm = 0;   // base_merge_kmer: counts per base symbol, first-seen order, 16-bit sums
+            // base_merge_kmer, IN PLACE like the reference (base.c:123-146): one entry per base symbol in first-seen order, 16-bit sums,
+            // contexts dropped.  A slot shared by two touching regions is scored by the second one on this merged list.
+            uint32_t mc[16], order[16], first_idx[16], nm = 0;
             for (int t = 0; t < 16; ++t) mc[t] = 0xffffffffu;
-            for (uint32_t idx = c.lhead[s]; idx; idx = c.lpool[2ull * (idx - 1) + 1]) {
-                const uint32_t ent = c.lpool[2ull * (idx - 1)];
-                const uint32_t sy = ent & 0xfu;
-                if (mc[sy] == 0xffffffffu) { mc[sy] = ent >> 16; order[nm++] = sy; }
-                else mc[sy] = (mc[sy] + (ent >> 16)) & 0xffffu;
+            for (uint32_t idx = c.lhead[s], prev_idx = 0; idx;) {
+                uint32_t* e = c.lpool + 2ull * (idx - 1);
+                const uint32_t sy = e[0] & 0xfu, nxt = e[1];
+                if (mc[sy] == 0xffffffffu) {
+                    mc[sy] = e[0] >> 16;
+                    order[nm++] = sy;
+                    first_idx[sy] = idx;
+                    e[0] = sy | mc[sy] << 16;
+                    prev_idx = idx;
+                } else {
+                    mc[sy] = (mc[sy] + (e[0] >> 16)) & 0xffffu;
+                    c.lpool[2ull * (first_idx[sy] - 1)] = sy | mc[sy] << 16;
+                    c.lpool[2ull * (prev_idx - 1) + 1] = nxt;   // unlink
+                }
+                idx = nxt;
             }
             if (nm >= 2) {   // stable top two (base.c:91-121)
                 uint32_t m0 = order[0], m1 = order[1];

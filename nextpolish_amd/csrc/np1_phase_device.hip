@@ -551,8 +551,11 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
                 }
                 const uint32_t nlr = (uint32_t)lctg.size();
                 if (!nlr) return 0;
-                const uint32_t ecap = phase == 0 ? 512u : 16384u;
-                const uint32_t bcap = phase == 0 ? 8192u : (uint32_t)P.max_variant_count_lgs + 4096u;
+                // scratch row of a lane: one entry per marked base the record passes, one byte per base / column inside open strings; never more
+                // than the reference's own buffer (max_variant_count_lgs); rows grow with the attempt when a record needs more
+                const uint32_t lq_max = std::max<uint32_t>(phase == 0 ? b->max_lq : l->max_lq, 256u);
+                const uint32_t ecap = (uint32_t)std::min<size_t>((phase == 0 ? 512u : 2048u) * scale, 65536u);
+                const uint32_t bcap = (uint32_t)std::min<size_t>(((size_t)2 * lq_max + 4096u) * scale, (size_t)P.max_variant_count_lgs + 4096u);
                 if (upload_vec(W[W_LREG_CTG], lctg, q) || upload_vec(W[W_LREG_SE], lse, q) || upload_vec(W[W_LREG_IDX], lidx, q) || W[W_LREG_R0].ensure(8ull * nlr + 8) ||
                     W[W_LREG_NREC].ensure(4ull * nlr + 8) || W[W_LREG_NCH].ensure(4ull * nlr + 8) || W[W_LREG_CHOFF].ensure(4ull * nlr + 8))
                     return -1;
@@ -565,7 +568,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
                 HIPCHK(hipMemcpyAsync(&n_chunks, &totals[5], 8, hipMemcpyDeviceToHost, q));
                 HIPCHK(hipStreamSynchronize(q));
                 if (!n_chunks) return 0;
-                const uint32_t blocks = (uint32_t)std::min<uint64_t>(n_chunks, phase == 0 ? 1024u : 128u);
+                const uint32_t blocks = (uint32_t)std::min<uint64_t>(n_chunks, phase == 0 ? 1024u : 512u);
                 if (W[W_ENTS].ensure(sizeof(SpEntry) * (size_t)ecap * blocks * 64) || W[W_BYTES].ensure((size_t)bcap * blocks * 64)) return -1;
                 k_sp_links<<<blocks, 64, 0, q>>>(c, P, LK, nlr, (uint32_t)n_chunks, W[W_LREG_CTG].as<uint32_t>(), W[W_LREG_SE].as<int32_t>(), W[W_LREG_IDX].as<uint32_t>(),
                                                  W[W_LREG_R0].as<unsigned long long>(), W[W_LREG_NREC].as<uint32_t>(), W[W_LREG_CHOFF].as<uint32_t>(), phase == 0 ? 2u : 1u,

@@ -1242,7 +1242,7 @@ static void sp_filter_snps(octg* c, snplist* sl, const np1o_contig* sr, const np
                 q->length = (int16_t)maxn[0]->length;
                 for (j = 0; j < flag1; j++) memcpy(q->region[j], maxn[j]->region, (size_t)q->length);
                 if (flag1 < SNP_NUM) memcpy(q->region[flag1], ks->region, (size_t)q->length);
-                sl->v[kept++] = q;
+                { sl->v[si] = NULL; sl->v[kept++] = q; }
             } else {
                 if (flag == 2) {
                     g_sp_stats[5]++;
@@ -1254,7 +1254,7 @@ static void sp_filter_snps(octg* c, snplist* sl, const np1o_contig* sr, const np
                 sl->v[si] = NULL;
             }
         } else {
-            sl->v[kept++] = q;
+            { sl->v[si] = NULL; sl->v[kept++] = q; }
         }
         if (ks) { free(ks->region); free(ks); }
         for (int32_t t = 0; t < rd.n; t++) free(rd.v[t].region);
@@ -1716,6 +1716,7 @@ char* np1o_snp_phase(const np1o_contig* sr, const np1o_contig* lr, const np1o_co
     ilist nodepth = get_region(c, 0, c->L - 1, cfg->ext_len_edge, 0, FLAG_DEPTH, brim_no_ext);
     if (nodepth.n > 0) {
         merge_region(&nodepth);
+        if (getenv("NP1O_SP_DEBUG")) { fprintf(stderr, "regions:"); for (int i = 0; i < nodepth.n; i += 2) fprintf(stderr, " [%d,%d]", nodepth.v[i], nodepth.v[i + 1]); fprintf(stderr, "\n"); }
         for (int i = 0; i < nodepth.n; i += 2) update_flag(c, nodepth.v[i], nodepth.v[i + 1], FLAG_INSERT);
     }
     c->in = lr;
@@ -1723,12 +1724,14 @@ char* np1o_snp_phase(const np1o_contig* sr, const np1o_contig* lr, const np1o_co
     c->insflag = FLAG_INSERT | FLAG_SNP;
     create_insert(c, 0, c->L - 1, span_lr);
     c->insflag = 0;
-    sp_filter_snps(c, &sl, sr, lr, span_sr, span_lr);
+    const char* dbg_stop = getenv("NP1O_SP_STOP");
+    const int stop = dbg_stop ? atoi(dbg_stop) : 99;
+    if (stop >= 2) sp_filter_snps(c, &sl, sr, lr, span_sr, span_lr);
     g_sp_stats[1] = g_undefined ? 0 : sl.n;
     g_sp_stats[6] = nodepth.n / 2;
-    if (!g_undefined && nodepth.n > 0) sp_correct_lower_depth(c, &nodepth, sr, lr, span_sr, span_lr);
+    if (stop >= 3 && !g_undefined && nodepth.n > 0) sp_correct_lower_depth(c, &nodepth, sr, lr, span_sr, span_lr);
     free(nodepth.v);
-    if (!g_undefined && sl.n > 1) {
+    if (stop >= 4 && !g_undefined && sl.n > 1) {
         sp_find_snps_link(c, &sl, sr, lr, span_sr, span_lr);
         if (!g_undefined) sp_snps_score(c, &sl);
         if (!g_undefined) sp_snps_correct(c, &sl);

@@ -749,7 +749,9 @@ extern "C" int np1m_snp_phase(const np1_stream_view* vs, const np1_stream_view* 
     std::vector<uint8_t> rpool(racc + 16, 0), keep(NS + 1, 0);
     for (uint32_t k = 0; k < NS; ++k) { rpool[roff[k]] = alle[site_g[k]] & 0xf; rpool[roff[k] + rstride[k]] = alle[site_g[k]] >> 4; }
     SpSites SS{site_g.data(), site_ctg.data(), site_left.data(), site_right.data(), site_len.data(), keep.data(), roff.data(), rstride.data(), rpool.data()};
-    for (uint32_t k = 0; k < NS; ++k) {
+    const char* dbg_stop = getenv("NP1O_SP_STOP");
+    const int stop = dbg_stop ? atoi(dbg_stop) : 99;
+    for (uint32_t k = 0; k < NS && stop >= 2; ++k) {
         hcount = 0;
         sp_site_verdict(cs, cl, P, SS, k, soff1.data(), cnt.data(), first.data());
     }
@@ -761,7 +763,7 @@ extern "C" int np1m_snp_phase(const np1_stream_view* vs, const np1_stream_view* 
         for (uint32_t ct = 0; ct < nc; ++ct)
             for (size_t i = 0; i + 1 < nodepth[ct].size(); i += 2) { reg_ctg.push_back(ct); reg_se.push_back(nodepth[ct][i]); reg_se.push_back(nodepth[ct][i + 1]); }
         const std::vector<uint32_t> grp = sp_region_groups(reg_ctg, reg_se);
-        for (size_t k = 0; k + 1 < grp.size(); ++k) {
+        for (size_t k = 0; k + 1 < grp.size() && stop >= 3; ++k) {
             stcount = 0;
             sp_lowdepth_group(cs, cl, reg_ctg.data(), reg_se.data(), grp[k], grp[k + 1]);
         }
@@ -808,7 +810,7 @@ extern "C" int np1m_snp_phase(const np1_stream_view* vs, const np1_stream_view* 
         }
         return v;
     };
-    for (uint32_t ct = 0; ct < nc; ++ct) {
+    for (uint32_t ct = 0; ct < nc && stop >= 4; ++ct) {
         if (k_first[ct + 1] - k_first[ct] <= 1) continue;
         const uint32_t g0 = vs->ctg_off[ct];
         // P10a: short-read links

@@ -169,3 +169,23 @@ def touching_case(seed):
     sr.sort(key=lambda r: r["pos"])
     lr.sort(key=lambda r: r["pos"])
     return [("tig0", draft)], sr, lr
+
+
+def adversarial_case(seed):
+    """Two tiny contigs with the odd shapes of tests/fuzzgen.py (N / = / X / P / H operations, insertions at position 0, homopolymer
+    ends, ambiguity letters, filtered flags) as short reads, and a second random read set as long reads: thin, patchy coverage, so
+    nearly every base is a low-depth region or a thinly covered site.  The reference crashes on about one in six of these."""
+    import fuzzgen
+    rng = random.Random(seed)
+    ctgs, sr = fuzzgen.random_case(seed, n_contigs=2, max_len=rng.choice([60, 160, 400]), max_reads=rng.choice([10, 40, 120]), odd_letters=rng.random() < 0.5,
+                                   odd_cigars=rng.random() < 0.7)
+    _, lr0 = fuzzgen.random_case(seed + 100000, n_contigs=2, max_len=400, max_reads=rng.choice([5, 20, 60]), odd_letters=False, odd_cigars=rng.random() < 0.5)
+    lr = []
+    for r in lr0:          # keep the long reads that fit the (shorter) contig
+        span = sum(n for o, n in r["cigar"] if o in "MD=XN")
+        if r["pos"] + span <= len(ctgs[r["ctg"]][1]):
+            lr.append(r)
+    lr.sort(key=lambda r: (r["ctg"], r["pos"]))
+    for r in sr + lr:
+        r["qual"] = bytes(r["qual"])
+    return ctgs, sr, lr
