@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -160,10 +161,12 @@ __global__ __launch_bounds__(256) void k_sp_site_init(uint32_t NS, const uint32_
     rpool[roff[k] + rstride[k]] = alle[site_g[k]] >> 4;
 }
 
-__global__ __launch_bounds__(64) void k_sp_verdict(KcCtx cs, KcCtx cl, SpParams P, SpSites S, uint32_t NS, const uint32_t* __restrict__ soff1,
+// (site and region lanes diverge completely -- each walks its own records: `lanes` active lanes per wave, the rest idle, spreads them over
+// more waves; same finding as for kmer_count's region kernels, np1_kmer_kernels.hip)
+__global__ __launch_bounds__(64) void k_sp_verdict(KcCtx cs, KcCtx cl, SpParams P, SpSites S, uint32_t NS, uint32_t lanes, const uint32_t* __restrict__ soff1,
                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ first) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < NS) sp_site_verdict(cs, cl, P, S, k, soff1, cnt, first);
+    const uint32_t k = blockIdx.x * lanes + threadIdx.x;
+    if (threadIdx.x < lanes && k < NS) sp_site_verdict(cs, cl, P, S, k, soff1, cnt, first);
 }
 
 __global__ __launch_bounds__(256) void k_sp_region_slots(uint32_t n_reg, const uint32_t* __restrict__ reg_ctg, const int32_t* __restrict__ reg_se,
@@ -174,10 +177,10 @@ __global__ __launch_bounds__(256) void k_sp_region_slots(uint32_t n_reg, const u
     atomicAdd(total, (unsigned long long)(soff[g0 + (uint32_t)reg_se[2 * k + 1]] - soff[g0 + (uint32_t)reg_se[2 * k]] + 1));
 }
 
-__global__ __launch_bounds__(64) void k_sp_lowdepth(KcCtx cs, KcCtx cl, uint32_t n_grp, const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ reg_ctg,
-                                                    const int32_t* __restrict__ reg_se) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_grp) sp_lowdepth_group(cs, cl, reg_ctg, reg_se, grp_first[k], grp_first[k + 1]);
+__global__ __launch_bounds__(64) void k_sp_lowdepth(KcCtx cs, KcCtx cl, uint32_t n_grp, uint32_t lanes, const uint32_t* __restrict__ grp_first,
+                                                    const uint32_t* __restrict__ reg_ctg, const int32_t* __restrict__ reg_se) {
+    const uint32_t k = blockIdx.x * lanes + threadIdx.x;
+    if (threadIdx.x < lanes && k < n_grp) sp_lowdepth_group(cs, cl, reg_ctg, reg_se, grp_first[k], grp_first[k + 1]);
 }
 
 __global__ __launch_bounds__(256) void k_sp_gather_flags(uint32_t n, const uint32_t* __restrict__ g, const uint32_t* __restrict__ soff, const uint8_t* __restrict__ sflag,
@@ -323,6 +326,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
     };
     KcCtx cs = make_ctx(b), cl = make_ctx(l);
     cl.keep_zero_marks = 1;
+    static const uint32_t site_lanes = [] { const char* e = getenv("NP1_SP_LANES"); const int x = e ? atoi(e) : 8; return (uint32_t)(x < 1 ? 1 : x > 64 ? 64 : x); }();
 
     for (int attempt = 0; attempt < 5; ++attempt) {
         const size_t scale = (size_t)1 << (2 * attempt);
@@ -470,10 +474,10 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
                                                          W[W_RPOOL].as<uint8_t>());
             SpSites SS{W[W_SITE_G].as<uint32_t>(), W[W_SITE_CTG].as<uint32_t>(), W[W_SITE_LEFT].as<int32_t>(), W[W_SITE_RIGHT].as<int32_t>(), W[W_SITE_LEN].as<int32_t>(),
                        W[W_KEEP].as<uint8_t>(), W[W_ROFF].as<uint32_t>(), W[W_RSTRIDE].as<uint32_t>(), W[W_RPOOL].as<uint8_t>()};
-            k_sp_verdict<<<nblk(NS, 64), 64, 0, q>>>(cs, cl, P, SS, NS, W[W_SOFF1].as<uint32_t>(), W[W_CNT].as<uint32_t>(), W[W_FIRST].as<uint32_t>());
+            k_sp_verdict<<<nblk(NS, site_lanes), 64, 0, q>>>(cs, cl, P, SS, NS, site_lanes, W[W_SOFF1].as<uint32_t>(), W[W_CNT].as<uint32_t>(), W[W_FIRST].as<uint32_t>());
         }
         // ---- P9: low-depth regions, both streams
-        if (n_reg) k_sp_lowdepth<<<nblk(n_grp, 64), 64, 0, q>>>(cs, cl, n_grp, W[W_GRP].as<uint32_t>(), W[W_REG_CTG].as<uint32_t>(), W[W_REG_SE].as<int32_t>());
+        if (n_reg) k_sp_lowdepth<<<nblk(n_grp, site_lanes), 64, 0, q>>>(cs, cl, n_grp, site_lanes, W[W_GRP].as<uint32_t>(), W[W_REG_CTG].as<uint32_t>(), W[W_REG_SE].as<int32_t>());
         HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
         HIPCHK(hipStreamSynchronize(q));
         if (hk[KCC_ERR] & (ERR_KC_POOL | ERR_SP_POOL)) continue;
