@@ -53,6 +53,64 @@ __global__ __launch_bounds__(256) void k_sp_hist(KcCtx c, int64_t n, uint32_t* _
     if (r < n) sp_hist_record(c, r, cnt, first);
 }
 
+// The same histogram through LDS.  Records are position sorted, so the 128 records of a workgroup vote into a short run of slots
+// (128 read starts + one read length); those votes go to a window of HW slots x 6 common symbols (A C G T, deletion, N) in LDS and
+// reach HBM once per (slot, symbol) and workgroup instead of once per vote -- at 30x that is ~20x fewer global atomics.  Votes outside
+// the window or with another symbol take the direct path; the result is the same whatever the window is.
+constexpr uint32_t HW = 1024;
+typedef __attribute__((address_space(3))) uint32_t sp_lds_u32;
+struct SpHistLdsSink {
+    const uint32_t* soff;
+    uint32_t g0, slot_lo;
+    sp_lds_u32* l_cnt;      // typed LDS pointers: the window's atomics must come out as ds_ operations, not flat ones
+    sp_lds_u32* l_first;
+    uint32_t* cnt;
+    uint32_t* first;
+    uint32_t r;
+    __device__ __forceinline__ void vote(int32_t pos, uint32_t col, uint32_t sym, int32_t, bool) {
+        const uint32_t s = soff[g0 + (uint32_t)pos] + col;
+        const uint32_t idx = s - slot_lo;   // (wraps to a huge value below the window)
+        const uint32_t m = sym == 1 ? 0u : sym == 2 ? 1u : sym == 4 ? 2u : sym == 8 ? 3u : sym == 3 ? 4u : sym == 15 ? 5u : 6u;
+        if (idx < HW && m < 6) {
+            __hip_atomic_fetch_add(l_cnt + (idx * 6 + m), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_min(l_first + (idx * 6 + m), r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            const uint64_t k = (uint64_t)s * 16 + sym;
+            atomicAdd(&cnt[k], 1u);
+            atomicMin(&first[k], r);
+        }
+    }
+};
+__global__ __launch_bounds__(128) void k_sp_hist_lds(KcCtx c, int64_t n, uint32_t* __restrict__ cnt, uint32_t* __restrict__ first) {
+    __shared__ uint32_t l_cnt[HW * 6];
+    __shared__ uint32_t l_first[HW * 6];
+    __shared__ uint32_t s_lo;
+    const int64_t r0 = (int64_t)blockIdx.x * 128;
+    for (uint32_t i = threadIdx.x; i < HW * 6; i += 128) { l_cnt[i] = 0; l_first[i] = 0xffffffffu; }
+    if (threadIdx.x == 0) {
+        const uint32_t ct = c.R.ctg[r0];
+        const int32_t p = c.R.pos[r0];
+        s_lo = c.soff[c.ctg_off[ct] + (uint32_t)(p > 0 ? p : 0)];
+    }
+    __syncthreads();
+    const int64_t r = r0 + threadIdx.x;
+    if (r < n && c.level[r] == 2 && c.R.n_cigar[r] != 0) {
+        const uint32_t ct = c.R.ctg[r];
+        const uint32_t g0 = c.ctg_off[ct];
+        SpHistLdsSink sink{c.soff, g0, s_lo, (sp_lds_u32*)l_cnt, (sp_lds_u32*)l_first, cnt, first, (uint32_t)r};
+        kc_walk(c, r, g0, 0, (int32_t)(c.ctg_off[ct + 1] - g0) - 1, sink);
+    }
+    __syncthreads();
+    static const uint32_t kSym[6] = {1, 2, 4, 8, 3, 15};
+    for (uint32_t i = threadIdx.x; i < HW * 6; i += 128) {
+        const uint32_t v = l_cnt[i];
+        if (!v) continue;
+        const uint64_t k = (uint64_t)(s_lo + i / 6) * 16 + kSym[i % 6];
+        atomicAdd(&cnt[k], v);
+        atomicMin(&first[k], l_first[i]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sp_decide(SpParams P, uint32_t S, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ first, uint8_t* sbase,
                                                    uint8_t* sflag, uint16_t* scount, uint8_t* dec, uint8_t* top, uint32_t* err) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,6 +384,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
     };
     KcCtx cs = make_ctx(b), cl = make_ctx(l);
     cl.keep_zero_marks = 1;
+    static const bool hist_lds = [] { const char* e = getenv("NP1_SP_HIST"); return !(e && strcmp(e, "global") == 0); }();   // NP1_SP_HIST=global: every vote straight to HBM
     static const uint32_t site_lanes = [] { const char* e = getenv("NP1_SP_LANES"); const int x = e ? atoi(e) : 8; return (uint32_t)(x < 1 ? 1 : x > 64 ? 64 : x); }();
 
     for (int attempt = 0; attempt < 5; ++attempt) {
@@ -364,7 +423,8 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
         HIPCHK(hipMemsetAsync(W[W_CNT].p, 0, 64ull * S1, q));
         HIPCHK(hipMemsetAsync(W[W_FIRST].p, 0xff, 64ull * S1, q));
         cs.soff = W[W_SOFF1].as<uint32_t>();
-        k_sp_hist<<<nblk((uint64_t)nn, 256), 256, 0, q>>>(cs, n, W[W_CNT].as<uint32_t>(), W[W_FIRST].as<uint32_t>());
+        if (hist_lds && n > 0) k_sp_hist_lds<<<nblk((uint64_t)n, 128), 128, 0, q>>>(cs, n, W[W_CNT].as<uint32_t>(), W[W_FIRST].as<uint32_t>());
+        else k_sp_hist<<<nblk((uint64_t)nn, 256), 256, 0, q>>>(cs, n, W[W_CNT].as<uint32_t>(), W[W_FIRST].as<uint32_t>());
         k_sp_decide<<<nblk(S1, 256), 256, 0, q>>>(P, S1, W[W_CNT].as<uint32_t>(), W[W_FIRST].as<uint32_t>(), W[W_SBASE1].as<uint8_t>(), W[W_SFLAG1].as<uint8_t>(),
                                                   W[W_SCOUNT1].as<uint16_t>(), W[W_DEC].as<uint8_t>(), W[W_TOP].as<uint8_t>(), &kcnt[KCC_ERR]);
         // ---- P4: sites
