@@ -793,10 +793,11 @@ NP1_HD int32_t kc_part_winner(const KcCtx& c, uint32_t ctg, int32_t start, int32
     }
     if (ncand == 0) {
         // bug-compatible fallback (kmercount.c:212-217): one pass per spanning record, always on the record the first
-        // loop stopped on: first record with pos >= start, else the next record in file order, else the last one read
+        // loop stopped on: first record with pos >= start, else the last one read = the contig's last record (the chunk list of
+        // the query ends with the contig's records, the reader never reaches another contig's)
         int64_t stale = -1;
+        (void)has_next_record;
         if (rstop < re) stale = rstop;
-        else if (has_next_record) stale = re;
         else if (re > rb) stale = re - 1;
         if (stale >= 0 && c.level[stale] == 1)
             for (int64_t t = 0; t < n_span; ++t) { int32_t mq; parse(stale, &mq); }

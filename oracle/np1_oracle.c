@@ -788,11 +788,11 @@ static void kmer_correct(octg* c, ilist* regs, int32_t max_span, ilist* nodepth,
                 ks_clean(&ks, length);
             }
         }
-        /* the record the first loop stopped on: first record with pos >= start; when the contig has
-         * none, the next record in file order (another contig's) or, at EOF, the last record read */
+        /* the record the first loop stopped on: first record with pos >= start; when the contig has none, the last record read --
+         * the contig's last one: the chunk list of the query ends with the contig's records (the index closes a chunk where the
+         * reference id changes, hts.c hts_idx_push), so the reader never gets as far as another contig's record */
         int64_t stale = -1;
         if (rstop < in->n_reads) stale = rstop;
-        else if (in->has_next) stale = in->n_reads;
         else if (in->n_reads > 0) stale = in->n_reads - 1;
         if (rd.n == 0 && stale >= 0) {
             /* bug-compatible fallback (kmercount.c:212-217): one pass per spanning record, always
