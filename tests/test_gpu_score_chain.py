@@ -242,6 +242,15 @@ def test_kmer_count_synth_matches_oracle(ctx, seed):
     _check_kmer(ctx, st)
 
 
+def test_kmer_count_lowercase_micro_cases_match_oracle(ctx):
+    """thin coverage, a tenth of the draft in lower case (tests/test_oracle.py lowercase_micro_case): the level-1 fallback of
+    kmer_count incl. the part at a contig's end with no record behind it (seed 10019)"""
+    from test_oracle import lowercase_micro_case
+    for seed in range(10000, 10080):
+        contigs, reads = lowercase_micro_case(seed)
+        _check_kmer(ctx, nat.Stream.from_reads(contigs, reads), read_tlen=1000)
+
+
 def test_kmer_count_micro_cases_match_oracle(ctx):
     import random
     for seed in range(300):
