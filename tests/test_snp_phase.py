@@ -253,6 +253,58 @@ def test_host_model_on_adversarial_inputs():
     assert n > 60
 
 
+PARAM_VALUES = dict(trim_len_edge=[0, 1, 2, 4], ext_len_edge=[1, 2, 3, 5], min_map_quality=[0, 10, 30], min_depth_snp=[1, 3, 6], min_count_snp=[2, 5, 10],
+                    min_count_snp_link=[1, 5, 12], ploidy=[1, 2, 3, 4.0], indel_balance_factor_lgs=[0.1, 0.33, 0.5, 0.77], max_indel_factor_lgs=[0.1, 0.21, 0.4],
+                    max_snp_factor_lgs=[0.3, 0.53, 0.8], min_snp_factor_sgs=[0.1, 0.34, 0.6], max_clip_ratio_lgs=[0.05, 0.4], max_clip_ratio_sgs=[0.05, 0.15, 0.3],
+                    max_variant_count_lgs=[150000, 3000, 500])
+
+
+def random_parameters(seed):
+    """about half of the algorithm parameters of task 3 away from their defaults (config.c:8-38)"""
+    import random
+    rng = random.Random(seed)
+    return {k: rng.choice(v) for k, v in PARAM_VALUES.items() if rng.random() < 0.5}
+
+
+def configs_with(ov, read_tlen, read_len):
+    cfg = nat.default_config()
+    cfg.read_tlen, cfg.read_len = read_tlen, read_len
+    ocfg = ob.default_config(read_tlen=read_tlen, read_len=read_len)
+    for k, v in ov.items():
+        setattr(cfg, k, type(getattr(cfg, k))(v))
+        setattr(ocfg, k, type(getattr(ocfg, k))(v))
+    return cfg, ocfg
+
+
+@needs_ref
+def test_parameters_vs_reference_library(tmp_path):
+    """the CLI takes no options: through the reference's shared library, Configure fields set by hand (during development: 400
+    parameter sets, 0 differences)"""
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "nextpolish1.so"))
+    L.config_init.restype = C.POINTER(nat.Configure)
+    L.config_init.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.snp_phase.restype = C.POINTER(nat.PolishResult)
+    L.snp_phase.argtypes = [C.c_char_p, C.POINTER(nat.Configure)]
+    import model_binding as mb
+    fa, sr, lr = str(tmp_path / "s.fa"), str(tmp_path / "sr.bam"), str(tmp_path / "lr.bam")
+    for seed in range(4000, 4016):
+        s, l = streams(fuzz_params(seed))
+        s.write_files(fa, sr)
+        l.write_files(str(tmp_path / "l.fa"), lr)
+        rcfg = L.config_init(fa.encode(), sr.encode(), lr.encode())
+        ov = random_parameters(seed)
+        for k, v in ov.items():
+            setattr(rcfg.contents, k, type(getattr(rcfg.contents, k))(v))
+        cfg, ocfg = configs_with(ov, rcfg.contents.read_tlen, rcfg.contents.read_len)
+        s2, l2 = nat.Stream.load(fa, sr, with_qual=True), nat.Stream.load(fa, lr, with_qual=True)
+        got_model = mb.snp_phase(s2, l2, cfg)
+        for i, n in enumerate(s2.names):
+            r = L.snp_phase(n.encode(), rcfg)
+            want = C.string_at(r.contents.contig).decode()
+            assert ob.snp_phase(s2, l2, i, ocfg) == want, "seed %d %s %r" % (seed, n, ov)
+            assert got_model[i] == want, "model: seed %d %s %r" % (seed, n, ov)
+
+
 def test_host_model_on_real_alignments():
     g = GOLD["real"]["s30+ont"]
     s, l = real_streams(g)
@@ -333,6 +385,24 @@ def test_gpu_adversarial_inputs(ctx):
         s, l = adversarial(seed)
         n += 1 if _check(ctx, s, l) else 0
     assert n > 60
+
+
+@pytest.mark.gpu
+def test_gpu_parameters(ctx):
+    """algorithm parameters away from their defaults: product == oracle"""
+    for seed in range(4000, 4024):
+        s, l = streams(fuzz_params(seed))
+        cfg, ocfg = configs_with(random_parameters(seed), 500, 100)
+        want = [ob.snp_phase(s, l, i, ocfg) for i in range(s.n_contigs)]
+        if any(w is None for w in want):
+            continue
+        b, bl = ctx.upload(s), ctx.upload(l)
+        try:
+            b.snp_phase(bl, cfg)
+            assert b.results() == want, seed
+        finally:
+            bl.close()
+            b.close()
 
 
 @pytest.mark.gpu
