@@ -132,6 +132,9 @@ np1_stream* np1_stream_load(const char* fasta, const char* bam, const char* cons
 np1_stream* np1_stream_build(const np1_stream_view* v, const char* const* contig_names);
 void np1_stream_get_view(const np1_stream* s, np1_stream_view* out);
 const char* np1_stream_contig_name(const np1_stream* s, int64_t i);
+/* BGZF virtual offsets of the records of a stream loaded from a file: start of each record and the byte behind it (htslib's
+ * bgzf_tell convention).  Returns the record count, or 0 for a stream built in memory. */
+int64_t np1_stream_voffs(const np1_stream* s, const uint64_t** beg, const uint64_t** end);
 uint64_t np1_stream_algorithmic_bytes(const np1_stream* s, int with_qual);
 int np1_stream_write_files(const np1_stream* s, const char* fasta, const char* bam, int bgzf_level);
 /* same, with raw BAM optional fields per record (aux_pool[aux_off[i] .. aux_off[i+1])): test data with SA tags */

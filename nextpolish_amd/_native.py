@@ -127,6 +127,8 @@ def lib():
     L.np1_stream_synth_long.restype = C.c_void_p
     L.np1_stream_synth_diploid.argtypes = [C.POINTER(DiploidParams), C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.np1_stream_synth_diploid.restype = C.c_int
+    L.np1_stream_voffs.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint64))]
+    L.np1_stream_voffs.restype = C.c_int64
     L.np1_device_count.restype = C.c_int
     L.np1_ctx_create.argtypes = [C.c_int]
     L.np1_ctx_create.restype = C.c_void_p
@@ -327,6 +329,14 @@ class Stream(object):
         v.draft_len, v.cigar_len, v.seq_len, v.qual_len = len(draft), len(cig), len(seq), len(qual)
         names = (C.c_char_p * max(1, nc))(*[n.encode() for n, _ in contigs])
         return cls(lib().np1_stream_build(C.byref(v), names))
+
+    def voffs(self):
+        """(start, end) BGZF virtual offsets per record of a stream loaded from a file, as numpy arrays; None for in-memory streams"""
+        b, e = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        n = lib().np1_stream_voffs(self.handle, C.byref(b), C.byref(e))
+        if n <= 0:
+            return None
+        return np.ctypeslib.as_array(b, shape=(n,)), np.ctypeslib.as_array(e, shape=(n,))
 
     def pin(self):
         """Page-locks the stream's arrays (asynchronous full-rate H2D copies; needs a HIP device)."""

@@ -58,6 +58,14 @@ void np1_stream_get_view(const np1_stream* st, np1_stream_view* v) {
     v->qual_len = (int64_t)s.qual.size();
 }
 
+/* virtual offsets of the records of a stream loaded from a BAM file (start of each record, byte behind it); 0 entries for
+ * streams that were built in memory */
+int64_t np1_stream_voffs(const np1_stream* st, const uint64_t** beg, const uint64_t** end) {
+    if (beg) *beg = st->s.voff.data();
+    if (end) *end = st->s.voff_end.data();
+    return st->s.voff.size() == st->s.n_reads() && st->s.voff_end.size() == st->s.n_reads() && st->s.voff.size() && st->s.voff.back() ? (int64_t)st->s.voff.size() : 0;
+}
+
 const char* np1_stream_contig_name(const np1_stream* st, int64_t i) {
     if (i < 0 || i >= (int64_t)st->s.n_contigs()) return nullptr;
     return st->s.names[(size_t)i].c_str();

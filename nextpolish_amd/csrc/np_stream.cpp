@@ -20,7 +20,9 @@ uint64_t ReadStream::algorithmic_input_bytes(bool with_qual) const {
     return b;
 }
 
-static void append_record(const BamRec& r, uint32_t c, bool with_qual, ReadStream* s) {
+static void append_record(const BamRec& r, uint32_t c, bool with_qual, ReadStream* s, voff_t v0 = 0, voff_t v1 = 0) {
+    s->voff.push_back(v0);
+    s->voff_end.push_back(v1);
     s->pos.push_back(r.pos);
     s->ctg.push_back(c);
     s->flag.push_back(r.flag);
@@ -87,6 +89,7 @@ bool load_stream(const std::string& fasta, const std::string& bam, const std::ve
         if (!have_bai) { *err = "cannot load BAM index: " + bam + ".bai"; return false; }
     }
     bool pending = false;   // r holds a record read but not yet consumed (sequential mode)
+    voff_t rec_v0 = 0, rec_v1 = 0;   // virtual offsets of r and of the byte behind it
     for (size_t c = 0; c < nc; ++c) {
         out->read_begin[c] = out->n_reads();
         int tid = tid_of[c];
@@ -100,7 +103,9 @@ bool load_stream(const std::string& fasta, const std::string& bam, const std::ve
         }
         for (;;) {
             if (!pending) {
+                rec_v0 = rd.tell();
                 int st = rd.next(r);
+                rec_v1 = rd.tell();
                 if (st < 0) { *err = "corrupt BAM record in " + bam; return false; }
                 if (st == 0) break;
             }
@@ -113,7 +118,7 @@ bool load_stream(const std::string& fasta, const std::string& bam, const std::ve
                 *err = "alignment with more than 65535 CIGAR operations in " + bam + " (long reads belong to nextpolish2)";
                 return false;
             }
-            append_record(r, (uint32_t)c, with_qual, out);
+            append_record(r, (uint32_t)c, with_qual, out, rec_v0, rec_v1);
         }
         if (r.tid < 0 && pending) { /* unplaced reads follow: nothing more for any contig */ }
     }

@@ -39,6 +39,9 @@ struct ReadStream {
     std::vector<uint32_t> cigar;        // BAM-encoded ops: len<<4 | op
     std::vector<uint8_t> seq;           // 4-bit bases, two per byte, high nibble first; each record byte aligned
     std::vector<uint8_t> qual;          // phred bytes; empty unless requested
+    // ---- only filled by load_stream: BGZF virtual offset of every record and of the byte behind it (htslib's bgzf_tell convention),
+    // what an index-driven reader of the same file sees (the replay of the reference's region iterator needs them)
+    std::vector<uint64_t> voff, voff_end;
 
     size_t n_reads() const { return pos.size(); }
     size_t n_contigs() const { return names.size(); }

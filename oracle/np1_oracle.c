@@ -756,6 +756,170 @@ static int ks_compare(const okscore* a, const okscore* b) {   /* kmercount.c:63-
     return 0;
 }
 
+/* ---- replay of the reference's region iterator (contig.c:982-1043 over htslib 1.9 hts.c:2086-2189,2614-2655) on the decoded
+ * stream: records are addressed by their BGZF virtual offsets, the chunk lists come from the BAI.  Used when the caller hands in
+ * voff / voff_end / idx (a stream read from a file). */
+typedef struct { uint64_t u, v; } opair;
+typedef struct {
+    opair* off;
+    int n_off, i;
+    uint64_t curr_off;
+    int finished;
+    int32_t beg, end, curr_end;
+} oitr;
+typedef struct {      /* one of ss_kmer_correct's two iterators with the variables it is threaded through */
+    oitr* it;
+    int32_t iterend;
+    uint64_t saved_off;
+    int32_t saved_end;
+    uint64_t fpos;    /* file position */
+    int64_t buffer;   /* record last read into the bam1_t: -1 none yet, -2 another contig's */
+} ochan;
+
+static int idx_find(const np1o_index* x, uint32_t bin) {
+    int lo = 0, hi = x->n_bins - 1;
+    while (lo <= hi) {
+        int mid = (lo + hi) / 2;
+        if (x->bin[mid] == bin) return mid;
+        if (x->bin[mid] < bin) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+static int pair_cmp(const void* a, const void* b) {
+    uint64_t x = ((const opair*)a)->u, y = ((const opair*)b)->u;
+    return x < y ? -1 : x > y;
+}
+#define BIN_FIRST(l) (((1 << (((l) << 1) + (l))) - 1) / 7)
+#define BIN_PARENT(b) (((b) - 1) >> 3)
+static oitr* itr_query(const np1o_index* x, int32_t beg, int32_t end) {   /* hts_itr_query, tid >= 0 */
+    const int n_lvls = 5, min_shift = 14, n_bins_all = 37449;
+    oitr* it = (oitr*)calloc(1, sizeof(oitr));
+    if (beg < 0) beg = 0;
+    it->beg = beg; it->end = end; it->i = -1;
+    if (x->n_bins == 0) { it->finished = 1; return it; }
+    int bin = BIN_FIRST(n_lvls) + (beg >> min_shift), k;
+    do {
+        k = idx_find(x, (uint32_t)bin);
+        if (k >= 0) break;
+        int first = (BIN_PARENT(bin) << 3) + 1;
+        if (bin > first) --bin; else bin = BIN_PARENT(bin);
+    } while (bin);
+    if (bin == 0) k = idx_find(x, 0);
+    const uint64_t min_off = k >= 0 ? x->loff[k] : 0;
+    uint64_t max_off;
+    bin = BIN_FIRST(n_lvls) + ((end - 1) >> min_shift) + 1;
+    if (bin >= n_bins_all) bin = 0;
+    for (;;) {
+        while (bin % 8 == 1) bin = BIN_PARENT(bin);
+        if (bin == 0) { max_off = (uint64_t)-1; break; }
+        k = idx_find(x, (uint32_t)bin);
+        if (k >= 0 && x->chunk_first[k + 1] > x->chunk_first[k]) { max_off = x->chunk_u[x->chunk_first[k]]; break; }
+        bin++;
+    }
+    /* reg2bins + the chunks of the bins that exist */
+    int n_off = 0, cap = 64;
+    opair* off = (opair*)malloc((size_t)cap * sizeof(opair));
+    {
+        int64_t e = end;
+        int l, t, s = min_shift + (n_lvls << 1) + n_lvls;
+        if (beg < e) {
+            if (e >= 1LL << s) e = 1LL << s;
+            for (--e, l = 0, t = 0; l <= n_lvls; s -= 3, t += 1 << ((l << 1) + l), ++l) {
+                int b = t + (int)(beg >> s), ee = t + (int)(e >> s);
+                for (int bb = b; bb <= ee; ++bb) {
+                    k = idx_find(x, (uint32_t)bb);
+                    if (k < 0) continue;
+                    for (uint32_t j = x->chunk_first[k]; j < x->chunk_first[k + 1]; ++j)
+                        if (x->chunk_v[j] > min_off && x->chunk_u[j] < max_off) {
+                            if (n_off == cap) { cap *= 2; off = (opair*)realloc(off, (size_t)cap * sizeof(opair)); }
+                            off[n_off].u = x->chunk_u[j]; off[n_off].v = x->chunk_v[j]; ++n_off;
+                        }
+                }
+            }
+        }
+    }
+    if (n_off == 0) { free(off); it->finished = 1; return it; }
+    qsort(off, (size_t)n_off, sizeof(opair), pair_cmp);
+    int i, l;
+    for (i = 1, l = 0; i < n_off; ++i) if (off[l].v < off[i].v) off[++l] = off[i];
+    n_off = l + 1;
+    for (i = 1; i < n_off; ++i) if (off[i - 1].v >= off[i].u) off[i - 1].v = off[i].u;
+    for (i = 1, l = 0; i < n_off; ++i) {
+        if (off[l].v >> 16 == off[i].u >> 16) off[l].v = off[i].v;
+        else off[++l] = off[i];
+    }
+    it->n_off = l + 1;
+    it->off = off;
+    return it;
+}
+static void itr_free(oitr* it) { if (it) { free(it->off); free(it); } }
+
+/* record that starts at (or, for an offset written before a block boundary was crossed, first behind) a virtual offset; -1 when
+ * that is behind this contig's records */
+static int64_t rec_at(const np1o_contig* in, uint64_t v) {
+    int64_t lo = 0, hi = in->n_reads;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (in->voff[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo < in->n_reads ? lo : -1;
+}
+static int64_t itr_next(const np1o_contig* in, ochan* ch) {   /* hts_itr_next + the bam readrec */
+    oitr* it = ch->it;
+    if (it == NULL || it->finished) return -1;
+    int64_t ret = -1;
+    for (;;) {
+        if (it->curr_off == 0 || (it->i >= 0 && it->curr_off >= it->off[it->i].v)) {
+            if (it->i == it->n_off - 1) break;
+            if (it->i < 0 || it->off[it->i].v != it->off[it->i + 1].u) { ch->fpos = it->off[it->i + 1].u; it->curr_off = ch->fpos; }
+            ++it->i;
+        }
+        const int64_t r = rec_at(in, ch->fpos);
+        if (r < 0) {                      /* behind the contig: another contig's record (read, then rejected) or the end of the file */
+            if (in->has_next) ch->buffer = -2;
+            break;
+        }
+        ch->fpos = in->voff_end[r];
+        it->curr_off = ch->fpos;
+        ch->buffer = r;
+        const int32_t beg = in->pos[r], end = read_endpos(in, r);
+        if (beg >= it->end) break;
+        if (end > it->beg && it->end > beg) { it->curr_end = end; return r; }
+    }
+    it->finished = 1;
+    return ret;
+}
+/* contig_next_iter (contig.c:1010-1043) with contig_update_iter (contig.c:982-1008); flag as there */
+static int64_t chan_next(octg* c, ochan* ch, int32_t start, int32_t end, int32_t* nextposend, int flag) {
+    const np1o_contig* in = c->in;
+    if (flag >= 1) {
+        if (ch->it != NULL) {
+            if (end < ch->iterend) { ch->it->beg = start; ch->it->end = end + 1; ch->it->finished = 0; }
+            else { itr_free(ch->it); ch->it = NULL; }
+        }
+        if (ch->it == NULL) {
+            ch->it = itr_query(in->idx, start, end + 1);
+            if (ch->it->off) {
+                const int64_t r = rec_at(in, ch->it->off[0].v);
+                ch->iterend = r >= 0 ? in->pos[r] : c->L;
+            }
+        }
+        if (ch->it->curr_off) {
+            ch->it->curr_off = ch->saved_off;
+            ch->it->curr_end = ch->saved_end;
+            ch->fpos = ch->it->curr_off;
+            if (ch->it->curr_off == 0) ch->it->i = -1;
+        } else {
+            ch->saved_off = 0;
+        }
+        if (flag == 1) { int32_t t = ch->it->beg; ch->it->beg = ch->it->end; ch->it->end = t; }
+    }
+    const int64_t ret = ch->it->off ? itr_next(in, ch) : -1;
+    if (ret >= 0 && ch->it->curr_end <= *nextposend) { ch->saved_off = ch->it->curr_off; ch->saved_end = ch->it->curr_end; }
+    else *nextposend = -1;
+    return ret;
+}
+
 /* ss_kmer_correct (reference: source/lib/kmercount.c:175-261); the values of `regs` are read pairwise, n_vals of them are valid
  * (an odd count makes the last pair read one stored value further, as the reference does); nodepth != NULL collects the
  * regions no record spans; flagzero: see parse_read_kmer.
@@ -766,12 +930,48 @@ static void kmer_correct(octg* c, ilist* regs, int32_t max_span, ilist* nodepth,
     const np1o_contig* in = c->in;
     kslist rd = {0, 0, 0};
     c->filter_kind = 0;
+    const int replay = in->idx != NULL && in->voff != NULL && in->voff_end != NULL;
+    ochan ch1, ch2;
+    memset(&ch1, 0, sizeof(ch1));
+    memset(&ch2, 0, sizeof(ch2));
+    ch1.buffer = ch2.buffer = -1;
     for (int ri = 0; ri < regs->n; ri += 2) {
         int32_t start = regs->v[ri], end = regs->v[ri + 1];
         int32_t length = get_length(c, start, end), count = 0;
         okscore ks;
         memset(&ks, 0, sizeof(ks));
         int have_ks = 0;
+        if (replay) {   /* the two loops of kmercount.c:196-219 on the replayed iterators */
+            const int32_t nextposend = ri + 2 < regs->n ? regs->v[ri + 3] : -1;
+            int32_t np1 = nextposend;
+            int flag = 1;
+            int64_t r;
+            while ((r = chan_next(c, &ch1, start, end, &np1, flag)) >= 0) {
+                if (read_filter(c, r) == 2) {
+                    kmer_get_region(c, r, start, end, length, &rd, &ks, flagzero);
+                    have_ks = 1;
+                    if (ks.mapqual == MAX_MAPQ) {
+                        count++;
+                        if (count >= c->cfg->max_count_kmer) break;
+                    }
+                    ks_clean(&ks, length);
+                }
+                flag = 0;
+            }
+            if (rd.n == 0) {
+                flag = 1;
+                np1 = nextposend;
+                while (chan_next(c, &ch2, start, end, &np1, flag) >= 0) {
+                    if (ch1.buffer >= 0 && read_filter(c, ch1.buffer) == 1) {   /* (kmercount.c:214: the FIRST iterator's record) */
+                        kmer_get_region(c, ch1.buffer, start, end, length, &rd, &ks, flagzero);
+                        have_ks = 1;
+                        ks_clean(&ks, length);
+                    }
+                    flag = 0;
+                }
+            }
+            goto vote;
+        }
         int64_t r0 = lower_bound_pos(in, start - max_span);
         int64_t rstop = lower_bound_pos(in, start);   /* first record with pos >= start */
         int64_t n_span = 0;
@@ -805,6 +1005,7 @@ static void kmer_correct(octg* c, ilist* regs, int32_t max_span, ilist* nodepth,
                 }
             }
         }
+    vote:
         if (rd.n > 0) {
             if (flagzero) {   /* contig_clean_flag(start, end, FLAG_ZERO_N), contig.c:823-831 */
                 int32_t i = start, j = 0;
@@ -840,6 +1041,8 @@ static void kmer_correct(octg* c, ilist* regs, int32_t max_span, ilist* nodepth,
         rd.n = 0;
     }
     free(rd.v);
+    itr_free(ch1.it);
+    itr_free(ch2.it);
 }
 
 char* np1o_kmer_count(const np1o_contig* in, const np1o_configure* cfg, int32_t* out_len) {   /* kmercount.c:93-126 */

@@ -33,6 +33,17 @@ typedef struct {
     char *fastafn, *bamfn, *thirdbamfn;
 } np1o_configure;
 
+/* BAI of one reference sequence, as htslib holds it after hts_idx_load: bins in ascending order with their chunks and their `loff`
+ * (hts.c update_loff), 5 levels, 16 kb windows. */
+typedef struct np1o_index {
+    int32_t n_bins;
+    const uint32_t* bin;
+    const uint64_t* loff;
+    const uint32_t* chunk_first;   /* n_bins + 1 */
+    const uint64_t* chunk_u;
+    const uint64_t* chunk_v;
+} np1o_index;
+
 /* One contig + its records in BAM file order (a slice of a decoded stream). */
 typedef struct {
     const char* draft;      /* raw FASTA characters, case preserved */
@@ -51,7 +62,13 @@ typedef struct {
     const uint8_t* seq;
     const uint8_t* qual;
     int32_t has_next;            /* 1: arrays hold one more record (index n_reads) = the next record in BAM
-                                    file order after this contig's (kmer_count's stale-read quirk) */
+                                    file order after this contig's */
+    /* optional, only for streams read from a BAM + BAI pair: what the reference's region iterator (contig.c:982-1043 over
+     * htslib's hts_itr_query / hts_itr_next) sees -- per record the BGZF virtual offset of its first byte and of the byte behind
+     * it, and the index of this reference sequence.  NULL: kmer_count / snp_valid take "records in file order" instead. */
+    const uint64_t* voff;
+    const uint64_t* voff_end;
+    const struct np1o_index* idx;
 } np1o_contig;
 
 /* Fills *cfg with the defaults of config_init (reference: source/lib/config.c:8-38). */

@@ -32,7 +32,13 @@ class OContig(C.Structure):
         ("mapq", C.c_void_p), ("isize", C.c_void_p), ("cigar_off", C.c_void_p), ("seq_off", C.c_void_p),
         ("qual_off", C.c_void_p), ("cigar", C.c_void_p), ("seq", C.c_void_p), ("qual", C.c_void_p),
         ("has_next", C.c_int32),
+        ("voff", C.c_void_p), ("voff_end", C.c_void_p), ("idx", C.c_void_p),
     ]
+
+
+class OIndex(C.Structure):
+    _fields_ = [("n_bins", C.c_int32), ("bin", C.c_void_p), ("loff", C.c_void_p), ("chunk_first", C.c_void_p), ("chunk_u", C.c_void_p),
+                ("chunk_v", C.c_void_p)]
 
 
 def lib():
@@ -90,8 +96,95 @@ def contig_view(stream, i):
     return oc
 
 
-def _run(fn, stream, i, cfg):
+class Geometry(object):
+    """What the reference's region iterator sees of a stream that was read from `bam` (+ .bai): the records' virtual offsets and the
+    index of every reference sequence as htslib holds it after loading (hts.c hts_idx_load_core + update_loff).  Hand it to
+    kmer_count / snp_valid to make the oracle replay the iterator (contig.c:982-1043) instead of taking records in file order."""
+
+    def __init__(self, stream, bam):
+        import struct
+        v = stream.voffs()
+        if v is None:
+            raise ValueError("the stream was not read from a file")
+        self.voff, self.voff_end = np.ascontiguousarray(v[0]), np.ascontiguousarray(v[1])
+        names = bam_reference_names(bam)
+        raw = open(bam + ".bai", "rb").read()
+        assert raw[:4] == b"BAI\1"
+        n_ref = struct.unpack_from("<i", raw, 4)[0]
+        off = 8
+        per_tid = []
+        for _ in range(n_ref):
+            n_bin = struct.unpack_from("<i", raw, off)[0]
+            off += 4
+            bins = {}
+            for _ in range(n_bin):
+                b, n_chunk = struct.unpack_from("<Ii", raw, off)
+                off += 8
+                ch = [struct.unpack_from("<QQ", raw, off + 16 * k) for k in range(n_chunk)]
+                off += 16 * n_chunk
+                bins[b] = ch
+            n_intv = struct.unpack_from("<i", raw, off)[0]
+            off += 4
+            lin = list(struct.unpack_from("<%dQ" % n_intv, raw, off)) if n_intv else []
+            off += 8 * n_intv
+            for j in range(1, n_intv):            # hts_idx_load_core: a zero takes the value before it
+                if lin[j] == 0:
+                    lin[j] = lin[j - 1]
+            ids = sorted(bins)
+            loff = []
+            for b in ids:                          # update_loff: the linear offset of the bin's first window
+                if b < 37449:
+                    lvl, t = 0, b
+                    while t:
+                        lvl += 1
+                        t = (t - 1) >> 3
+                    bot = (b - ((1 << (3 * lvl)) - 1) // 7) << ((5 - lvl) * 3)
+                    loff.append(lin[bot] if bot < len(lin) else 0)
+                else:
+                    loff.append(0)
+            first = [0]
+            cu, cv = [], []
+            for b in ids:
+                for u, w in bins[b]:
+                    cu.append(u)
+                    cv.append(w)
+                first.append(len(cu))
+            arrs = (np.array(ids, dtype=np.uint32), np.array(loff, dtype=np.uint64), np.array(first, dtype=np.uint32), np.array(cu, dtype=np.uint64),
+                    np.array(cv, dtype=np.uint64))
+            ix = OIndex(len(ids), *[a.ctypes.data if a.size else 0 for a in arrs])
+            per_tid.append((ix, arrs))
+        self.by_name = {names[t]: per_tid[t] for t in range(min(len(names), n_ref))}
+        self.names = list(stream.names)
+
+    def apply(self, oc, stream, i):
+        r0 = int(stream.read_begin[i])
+        oc.voff = self.voff.ctypes.data + 8 * r0
+        oc.voff_end = self.voff_end.ctypes.data + 8 * r0
+        ent = self.by_name.get(self.names[i])
+        oc.idx = C.addressof(ent[0]) if ent else 0
+
+
+def bam_reference_names(bam):
+    """reference names of a BAM header, in order"""
+    import gzip
+    import struct
+    with gzip.open(bam, "rb") as f:
+        assert f.read(4) == b"BAM\1"
+        l_text = struct.unpack("<i", f.read(4))[0]
+        f.read(l_text)
+        n = struct.unpack("<i", f.read(4))[0]
+        out = []
+        for _ in range(n):
+            ln = struct.unpack("<i", f.read(4))[0]
+            out.append(f.read(ln)[:-1].decode())
+            f.read(4)
+        return out
+
+
+def _run(fn, stream, i, cfg, geometry=None):
     oc = contig_view(stream, i)
+    if geometry is not None:
+        geometry.apply(oc, stream, i)
     n = C.c_int32(0)
     p = fn(C.byref(oc), C.byref(cfg), C.byref(n))
     if not p:          # snp_valid on an input the reference itself reads uninitialised memory for
@@ -105,12 +198,12 @@ def score_chain(stream, i, cfg=None):
     return _run(lib().np1o_score_chain, stream, i, cfg or default_config())
 
 
-def kmer_count(stream, i, cfg):
-    return _run(lib().np1o_kmer_count, stream, i, cfg)
+def kmer_count(stream, i, cfg, geometry=None):
+    return _run(lib().np1o_kmer_count, stream, i, cfg, geometry)
 
 
-def snp_valid(stream, i, cfg):
-    return _run(lib().np1o_snp_valid, stream, i, cfg)
+def snp_valid(stream, i, cfg, geometry=None):
+    return _run(lib().np1o_snp_valid, stream, i, cfg, geometry)
 
 
 def snp_phase(sr, lr, i, cfg):
