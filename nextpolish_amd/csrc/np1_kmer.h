@@ -729,15 +729,20 @@ struct KcCand { int32_t num, mapqual, qual; };
 
 // Computes the winner haplotype of one part into winner[0..length) and returns 1, or returns 0 when no spanning
 // record yields a full-length haplotype.  `scratch` holds up to max_cand candidates of `length` bytes + one work row.
+// rp (optional): what the replay of the reference's region iterator says this part gets (np1_replay.h): the records of the first loop
+// in order, the record left in the buffer, the passes of the second loop (n2 < 0: not known yet -- the call then returns 2 when
+// the first loop leaves no candidate, and is repeated with n2 set).  Without it: records in file order.
+struct KcReplay { const uint32_t* list; uint32_t n; int64_t stale; int32_t n2; };
 NP1_HD int32_t kc_part_winner(const KcCtx& c, uint32_t ctg, int32_t start, int32_t end, bool has_next_record,
-                              uint8_t* winner, int32_t length) {
+                              uint8_t* winner, int32_t length, const KcReplay* rp = nullptr) {
     const uint32_t g0 = c.ctg_off[ctg];
     const int64_t rb = (int64_t)c.read_begin[ctg], re = (int64_t)c.read_begin[ctg + 1];
     const int64_t r0 = kc_lower_bound_pos(c.R, rb, re, start - c.max_span);
     const int64_t rstop = kc_lower_bound_pos(c.R, rb, re, start);   // first record with pos >= start ends the swapped-interval scan
     // spanning records: pos < start and endpos > end + 1 (contig.c:1130-1135)
     int64_t n_span = 0;
-    for (int64_t r = r0; r < rstop; ++r) n_span += c.endpos[r] > end + 1;
+    if (rp) n_span = rp->n;
+    else for (int64_t r = r0; r < rstop; ++r) n_span += c.endpos[r] > end + 1;
     // scratch: candidates (distinct haplotypes, first-seen order) + one work row
     const uint32_t max_cand = (uint32_t)(n_span > 0 ? n_span : 1) + 1;
     const uint32_t stride = ((uint32_t)length + 12u + 3u) & ~3u;   // 12 bytes KcCand header + haplotype, 4-byte aligned
@@ -781,6 +786,23 @@ NP1_HD int32_t kc_part_winner(const KcCtx& c, uint32_t ctg, int32_t start, int32
             *out_mapqual = 0;
         }
     };
+    if (rp) {
+        for (uint32_t t = 0; t < rp->n; ++t) {
+            const int64_t r = (int64_t)rp->list[t];
+            if (c.level[r] == 2) {
+                parse(r, &last_mapqual);
+                if (last_mapqual == 60) {
+                    ++count;
+                    if (count >= c.max_count_kmer) break;
+                }
+            }
+        }
+        if (ncand == 0) {
+            if (rp->n2 < 0) return 2;
+            if (rp->stale >= 0 && c.level[rp->stale] == 1)
+                for (int32_t t = 0; t < rp->n2; ++t) { int32_t mq; parse(rp->stale, &mq); }
+        }
+    } else {
     for (int64_t r = r0; r < rstop; ++r) {
         if (!(c.endpos[r] > end + 1)) continue;
         if (c.level[r] == 2) {
@@ -791,7 +813,8 @@ NP1_HD int32_t kc_part_winner(const KcCtx& c, uint32_t ctg, int32_t start, int32
             }
         }
     }
-    if (ncand == 0) {
+    }
+    if (!rp && ncand == 0) {
         // bug-compatible fallback (kmercount.c:212-217): one pass per spanning record, always on the record the first
         // loop stopped on: first record with pos >= start, else the last one read = the contig's last record (the chunk list of
         // the query ends with the contig's records, the reader never reaches another contig's)

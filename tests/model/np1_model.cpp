@@ -17,6 +17,7 @@
 #include "../../nextpolish_amd/csrc/np1_desc.h"
 #include "../../nextpolish_amd/csrc/np1_kmer.h"
 #include "../../nextpolish_amd/csrc/np1_events.h"
+#include "../../nextpolish_amd/csrc/np1_replay.h"
 
 using namespace np1k;
 
@@ -401,7 +402,10 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
 }
 
 // kmer_count through the per-region bodies of np1_kmer.h, driven sequentially (the GPU runs one lane per region)
-static int kmer_model(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds, bool snp_valid) {
+// what the iterator replay needs besides the stream (np1_replay.h): the BAI, the BAM tid of every contig, the records' virtual offsets
+struct ModelGeometry { const np::BaiIndex* bai; const int32_t* tid; const uint64_t* voff; const uint64_t* voff_end; };
+
+static int kmer_model(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds, bool snp_valid, const ModelGeometry* geo = nullptr) {
     const uint32_t nc = (uint32_t)v->n_contigs;
     const int64_t n = v->n_reads;
     const uint64_t G = (uint64_t)v->draft_len;
@@ -496,6 +500,48 @@ static int kmer_model(const np1_stream_view* v, const Configure* cfg, char** out
     for (uint32_t ct = 0; ct < nc; ++ct) {
         const uint32_t g0 = v->ctg_off[ct];
         const bool has_next = (int64_t)v->read_begin[ct + 1] < n;
+        if (geo && !snp_valid) {
+            // the way the device pass would do it with the replay: all parts of the contig, the first loop of every part from the
+            // replayed iterator, winners kept aside; second-loop passes for the parts left empty; then the writes in part order
+            std::vector<int32_t> pse;
+            for (size_t i = 0; i + 1 < kreg[ct].size(); i += 2) {
+                std::vector<int32_t> parts(2 * (size_t)(kreg[ct][i + 1] - kreg[ct][i] + 4));
+                const int32_t np = kc_split_region(c, ct, kreg[ct][i], kreg[ct][i + 1], parts.data(), (int32_t)parts.size());
+                if (np < 0) return -12;
+                pse.insert(pse.end(), parts.begin(), parts.begin() + np);
+            }
+            const uint32_t n_parts = (uint32_t)(pse.size() / 2);
+            if (!n_parts) continue;
+            const int tid = geo->tid[ct];
+            if (tid < 0 || (size_t)tid >= geo->bai->refs.size()) return -30;
+            const np1replay::RefIndex ix(geo->bai->refs[(size_t)tid]);
+            const int64_t rb = (int64_t)v->read_begin[ct], re = (int64_t)v->read_begin[ct + 1];
+            const np1replay::Records rec{geo->voff + rb, geo->voff_end + rb, v->pos + rb, endpos.data() + rb, re - rb, has_next, (int32_t)(v->ctg_off[ct + 1] - g0)};
+            std::vector<int32_t> next_end(n_parts);
+            for (uint32_t p = 0; p < n_parts; ++p) next_end[p] = p + 1 < n_parts ? pse[2 * (p + 1) + 1] : -1;
+            const np1replay::FirstLoop fl = np1replay::first_loop(ix, rec, pse.data(), next_end.data(), n_parts);
+            std::vector<uint32_t> glist(fl.list.size());
+            for (size_t t = 0; t < glist.size(); ++t) glist[t] = fl.list[t] + (uint32_t)rb;
+            std::vector<std::vector<uint8_t>> wins(n_parts);
+            std::vector<uint8_t> state(n_parts, 0), empty(n_parts, 0);
+            auto vote = [&](uint32_t p, int32_t n2) {
+                const int32_t ps = pse[2 * p], pe = pse[2 * p + 1];
+                const int32_t length = (int32_t)(soff[g0 + pe] - soff[g0 + ps] + 1);
+                wins[p].assign((size_t)length, 0);
+                hcount = 0;
+                const KcReplay rp{glist.data() + fl.first[p], fl.first[p + 1] - fl.first[p], fl.stale[p] >= 0 ? fl.stale[p] + rb : -1, n2};
+                return kc_part_winner(c, ct, ps, pe, has_next, wins[p].data(), length, &rp);
+            };
+            for (uint32_t p = 0; p < n_parts; ++p) { state[p] = (uint8_t)vote(p, -1); empty[p] = state[p] == 2; }
+            const std::vector<uint32_t> n2 = np1replay::second_loop_passes(ix, rec, pse.data(), next_end.data(), n_parts, empty.data());
+            for (uint32_t p = 0; p < n_parts; ++p) if (empty[p]) state[p] = (uint8_t)vote(p, (int32_t)n2[p]);
+            for (uint32_t p = 0; p < n_parts; ++p)
+                if (state[p] == 1) {
+                    const uint32_t s0 = soff[g0 + pse[2 * p]];
+                    for (size_t t = 0; t < wins[p].size(); ++t) sbase[s0 + t] = wins[p][t];
+                }
+            continue;
+        }
         std::vector<int32_t> all_parts, failed;     // snp_valid: the contig's part list (flat) and the parts nothing spanned
         for (size_t i = 0; i + 1 < kreg[ct].size(); i += 2) {
             std::vector<int32_t> parts(2 * (size_t)(kreg[ct][i + 1] - kreg[ct][i] + 4));
@@ -554,6 +600,15 @@ static int kmer_model(const np1_stream_view* v, const Configure* cfg, char** out
 
 int np1m_kmer_count(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds) { return kmer_model(v, cfg, out, bounds, false); }
 int np1m_snp_valid(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds) { return kmer_model(v, cfg, out, bounds, true); }
+// kmer_count with the replay of the reference's region iterator: `bai_path` = index of the BAM the stream was read from, tid[c] = BAM
+// reference id of contig c, voff / voff_end = np1_stream_voffs of that stream
+int np1m_kmer_count_replay(const np1_stream_view* v, const Configure* cfg, const char* bai_path, const int32_t* tid, const uint64_t* voff, const uint64_t* voff_end,
+                           char** out, uint32_t* bounds) {
+    np::BaiIndex bai;
+    if (!bai.load(bai_path)) return -31;
+    const ModelGeometry geo{&bai, tid, voff, voff_end};
+    return kmer_model(v, cfg, out, bounds, false, &geo);
+}
 
 void np1m_free(void* p) { free(p); }
 

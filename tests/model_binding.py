@@ -23,6 +23,9 @@ def lib():
         L.np1m_snp_phase.argtypes = [C.POINTER(nat.StreamView), C.POINTER(nat.StreamView), C.POINTER(nat.Configure), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_uint32)]
         L.np1m_snp_phase.restype = C.c_int
+        L.np1m_kmer_count_replay.argtypes = [C.POINTER(nat.StreamView), C.POINTER(nat.Configure), C.c_char_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+        L.np1m_kmer_count_replay.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -85,3 +88,20 @@ def snp_phase(sr, lr, cfg):
     blob = C.string_at(out, bounds[sr.n_contigs])
     lib().np1m_free(out)
     return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(sr.n_contigs)]
+
+
+def kmer_count_replay(stream, cfg, bam):
+    """kmer_count with the region iterator of the reference replayed on the host (np1_replay.h: chunk lists of the BAM index, re-use,
+    saved offsets) feeding kc_part_winner: `stream` must have been read from `bam` (it carries the records' virtual offsets)."""
+    import oracle_binding as ob
+    names = ob.bam_reference_names(bam)
+    tid = (C.c_int32 * stream.n_contigs)(*[names.index(n) if n in names else -1 for n in stream.names])
+    vb, ve = stream.voffs()
+    out = C.c_void_p()
+    bounds = (C.c_uint32 * (stream.n_contigs + 1))()
+    rc = lib().np1m_kmer_count_replay(C.byref(stream.view), C.byref(cfg), (bam + ".bai").encode(), tid, vb.ctypes.data, ve.ctypes.data, C.byref(out), bounds)
+    if rc != 0:
+        raise RuntimeError("kmer_count replay model failed rc=%d" % rc)
+    blob = C.string_at(out, bounds[stream.n_contigs])
+    lib().np1m_free(out)
+    return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)]

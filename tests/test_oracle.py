@@ -156,6 +156,28 @@ def test_iterator_replay_reproduces_the_reference_where_file_order_does_not(tmp_
 
 
 @needs_ref
+def test_product_side_replay_feeding_the_vote_body(tmp_path):
+    """np1_replay.h (the product's host-side replay of the iterator: RefIndex::query, Scanner) handing kc_part_winner the records of
+    the first loop, the buffered record and the passes of the second loop -- driven by the host model the way the device pass will
+    be: kmer_count of the thin multi-window files == the compiled reference, incl. the three seeds file order gets wrong"""
+    import model_binding as mb
+    fa, bam = str(tmp_path / "z.fa"), str(tmp_path / "z.bam")
+    n = 0
+    for seed in (44, 100, 102, 7, 19):
+        st, level = thin_multiwindow_stream(seed)
+        st.write_files(fa, bam, level)
+        cfgp = nat.lib().config_init(fa.encode(), bam.encode(), None)
+        s2 = nat.Stream.load(fa, bam, with_qual=True)
+        got = mb.kmer_count_replay(s2, cfgp.contents, bam)
+        nat.lib().config_destory(cfgp)
+        ref = run_ref("kmercount", fa, bam)
+        for i, name in enumerate(s2.names):
+            assert got[i] == ref[name], "seed %d %s" % (seed, name)
+            n += 1
+    assert n == 15
+
+
+@needs_ref
 @pytest.mark.parametrize("seed", range(6))
 def test_oracle_vs_reference_synth(tmp_path, seed):
     fa, bam = str(tmp_path / "s.fa"), str(tmp_path / "s.bam")
