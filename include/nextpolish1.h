@@ -262,6 +262,12 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms);
  * (np1_stream_load(..., with_qual = 1)) and cfg->read_tlen must be set (config_init does).  Returns 0 on success;
  * results are fetched with np1_batch_result_len / np1_batch_result_copy like for score_chain. */
 int np1_batch_kmer_count(np1_batch* b, const Configure* cfg, float* stage_ms);
+/* Makes np1_batch_kmer_count of this batch replay the reference's region iterator (reference: source/lib/contig.c:982-1043 over htslib's
+ * hts_itr_query / hts_itr_next): per part the records the first loop of ss_kmer_correct gets, the record left in its buffer and the
+ * passes of the second loop come from the BAM index and the records' virtual offsets instead of "records in file order" (DESIGN.md
+ * section 3).  `s` = the stream the batch was uploaded from, read from `bam` (np1_stream_load); it has to stay alive until the pass is
+ * done.  Experimental in round 2: equal to the compiled reference through the host model, not yet validated on a GPU. */
+int np1_batch_enable_replay(np1_batch* b, const np1_stream* s, const char* bam);
 /* task 4 on an uploaded batch (reference: source/lib/snpvalid.c:3-36 snp_valid; needs a stream loaded with qualities) */
 int np1_batch_snp_valid(np1_batch* b, const Configure* cfg, float* stage_ms);
 /* task 3 on two uploaded batches of the same contigs (reference: source/lib/snpphase.c:87-134 snp_phase): `sr` = the short-read

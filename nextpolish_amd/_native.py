@@ -149,6 +149,8 @@ def lib():
     L.np1_batch_snp_valid.restype = C.c_int
     L.np1_batch_snp_phase.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Configure)]
     L.np1_batch_snp_phase.restype = C.c_int
+    L.np1_batch_enable_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+    L.np1_batch_enable_replay.restype = C.c_int
     L.np1_batch_sync.argtypes = [C.c_void_p]
     L.np1_batch_sync.restype = C.c_int
     L.np1_batch_result_len.argtypes = [C.c_void_p, C.c_int64]

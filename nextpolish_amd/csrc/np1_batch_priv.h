@@ -9,6 +9,7 @@
 
 #include "np1_kernels.h"
 #include "np1_priv.h"
+#include "np_bam.h"
 
 namespace np1dev {
 
@@ -62,6 +63,16 @@ struct np1_batch {
     // snp_valid: second-round work (regions nothing spanned, their split values and parts)
     np1dev::DevBuf sv_failse, sv_failcnt, sv_vsz, sv_voff, sv_val, sv_p2ctg, sv_p2se, sv_p2len, sv_woff2, sv_haswin2, sv_range;
     std::vector<np1dev::DevBuf> spw;   // snp_phase work buffers (np1_phase_device.hip), owned by the short-read batch
+    // kmer_count with the reference's region iterator replayed (np1_replay.h, np1_batch_enable_replay): host-side view of the records
+    // (the stream must outlive the pass), the BAM index, the BAM reference id of every contig
+    struct Replay {
+        bool on = false;
+        np::BaiIndex bai;
+        std::vector<int32_t> tid, endpos;
+        const int32_t* pos = nullptr;
+        const uint64_t *voff = nullptr, *voff_end = nullptr, *read_begin = nullptr;
+        np1dev::DevBuf first, list, stale, n2;
+    } replay;
     bool has_qual = false;
     std::vector<uint64_t> h_read_begin;
     np1dev::DevBuf qs, qe, span, ins, soff, slot_info, rbase, capb, rowoff, rows, meta, chunk_first, chunk_last, slot_res,
@@ -134,6 +145,7 @@ struct np1_batch {
                          &sv_p2se, &sv_p2len, &sv_woff2, &sv_haswin2, &sv_range};
         for (np1dev::DevBuf* b : all) b->release();
         for (np1dev::DevBuf& b : spw) b.release();
+        replay.first.release(); replay.list.release(); replay.stale.release(); replay.n2.release();
     }
 };
 

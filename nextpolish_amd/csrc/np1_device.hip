@@ -15,6 +15,7 @@
 #include "np_stream.h"
 #include "np1_priv.h"
 #include "np1_batch_priv.h"
+#include "np1_replay.h"
 
 
 using namespace np1k;
@@ -485,6 +486,74 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
 // snp_valid (snpvalid.c:3-36) is kmer_count's haplotype vote without the no-depth regions, run twice: the first round leaves the
 // FLAG_ZERO marks to the winners (a part that gets one loses its marks), the regions nothing spanned are cut again at the middle of
 // their unmarked runs (fts_spilt_region) and voted on once more; the result is emitted without lower case.
+// kmer_count's votes on what the reference's region iterator hands out (np1_replay.h).  The parts of a contig are one contiguous run of
+// the part arrays, in list order.  Host: first loop of every part (record lists, buffered record); device: votes, 2 = first loop left
+// nothing; host: passes of the second loop over those parts; device: the votes again with them.
+static int replay_votes(np1_batch* b, const KcCtx& c, uint32_t n_parts, int64_t n_all, hipStream_t q) {
+    np1_batch::Replay& R = b->replay;
+    std::vector<uint32_t> pt_ctg(n_parts);
+    std::vector<int32_t> pt_se(2 * (size_t)n_parts);
+    HIPCHK(hipMemcpyAsync(pt_ctg.data(), b->kc_pt_ctg.p, 4 * (size_t)n_parts, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipMemcpyAsync(pt_se.data(), b->kc_pt_se.p, 8 * (size_t)n_parts, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipStreamSynchronize(q));
+    std::vector<uint32_t> first((size_t)n_parts + 1, 0), list;
+    std::vector<long long> stale(n_parts, -1);
+    std::vector<int32_t> next_end(n_parts, -1);
+    struct Run { uint32_t ct, p0, p1; };
+    std::vector<Run> runs;
+    for (uint32_t p = 0; p < n_parts;) {
+        uint32_t e = p;
+        while (e < n_parts && pt_ctg[e] == pt_ctg[p]) ++e;
+        runs.push_back(Run{pt_ctg[p], p, e});
+        p = e;
+    }
+    auto records = [&](uint32_t ct) {
+        const int64_t rb = (int64_t)R.read_begin[ct], re = (int64_t)R.read_begin[ct + 1];
+        return np1replay::Records{R.voff + rb, R.voff_end + rb, R.pos + rb, R.endpos.data() + rb, re - rb, re < n_all,
+                                  (int32_t)(b->h_ctg_off[ct + 1] - b->h_ctg_off[ct])};
+    };
+    for (const Run& r : runs) {
+        if (r.ct == 0xffffffffu) { for (uint32_t p = r.p0; p < r.p1; ++p) first[p + 1] = (uint32_t)list.size(); continue; }
+        const int tid = R.tid[r.ct];
+        if (tid < 0 || (size_t)tid >= R.bai.refs.size()) { np1_set_error("kmer_count: a contig of the batch is not in the BAM index"); return -1; }
+        const np1replay::RefIndex ix(R.bai.refs[(size_t)tid]);
+        for (uint32_t p = r.p0; p < r.p1; ++p) next_end[p] = p + 1 < r.p1 ? pt_se[2 * (size_t)(p + 1) + 1] : -1;
+        const np1replay::FirstLoop fl = np1replay::first_loop(ix, records(r.ct), pt_se.data() + 2 * (size_t)r.p0, next_end.data() + r.p0, r.p1 - r.p0);
+        const uint32_t rb = (uint32_t)R.read_begin[r.ct];
+        for (uint32_t p = r.p0; p < r.p1; ++p) {
+            for (uint32_t t = fl.first[p - r.p0]; t < fl.first[p - r.p0 + 1]; ++t) list.push_back(fl.list[t] + rb);
+            first[p + 1] = (uint32_t)list.size();
+            stale[p] = fl.stale[p - r.p0] >= 0 ? fl.stale[p - r.p0] + (long long)rb : -1;
+        }
+    }
+    if (R.first.ensure(4 * ((size_t)n_parts + 2)) || R.list.ensure(4 * (list.size() + 2)) || R.stale.ensure(8 * ((size_t)n_parts + 1)) || R.n2.ensure(4 * ((size_t)n_parts + 1))) return -1;
+    HIPCHK(hipMemcpyAsync(R.first.p, first.data(), 4 * ((size_t)n_parts + 1), hipMemcpyHostToDevice, q));
+    if (!list.empty()) HIPCHK(hipMemcpyAsync(R.list.p, list.data(), 4 * list.size(), hipMemcpyHostToDevice, q));
+    HIPCHK(hipMemcpyAsync(R.stale.p, stale.data(), 8 * (size_t)n_parts, hipMemcpyHostToDevice, q));
+    kc_launch_winner_replay(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(), b->kc_woff.as<uint32_t>(), n_parts, n_all,
+                            b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>(), R.first.as<uint32_t>(), R.list.as<uint32_t>(), R.stale.as<long long>(), nullptr);
+    std::vector<uint8_t> state(n_parts);
+    HIPCHK(hipMemcpyAsync(state.data(), b->kc_haswin.p, n_parts, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipStreamSynchronize(q));
+    bool any = false;
+    std::vector<uint8_t> empty(n_parts, 0);
+    for (uint32_t p = 0; p < n_parts; ++p) { empty[p] = state[p] == 2; any = any || empty[p]; }
+    if (!any) return 0;
+    std::vector<int32_t> n2(n_parts, 0);
+    for (const Run& r : runs) {
+        if (r.ct == 0xffffffffu) continue;
+        const np1replay::RefIndex ix(R.bai.refs[(size_t)R.tid[r.ct]]);
+        const std::vector<uint32_t> k = np1replay::second_loop_passes(ix, records(r.ct), pt_se.data() + 2 * (size_t)r.p0, next_end.data() + r.p0, r.p1 - r.p0, empty.data() + r.p0);
+        for (uint32_t p = r.p0; p < r.p1; ++p) n2[p] = (int32_t)k[p - r.p0];
+    }
+    HIPCHK(hipMemcpyAsync(R.n2.p, n2.data(), 4 * (size_t)n_parts, hipMemcpyHostToDevice, q));
+    HIPCHK(hipMemsetAsync(c.hcount, 0, 4, q));     // the second pass takes the haplotype pool from its start again
+    kc_launch_winner_replay(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(), b->kc_woff.as<uint32_t>(), n_parts, n_all,
+                            b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>(), R.first.as<uint32_t>(), R.list.as<uint32_t>(), R.stale.as<long long>(), R.n2.as<int32_t>());
+    HIPCHK(hipStreamSynchronize(q));   // (the host vectors of this function are the source of the copies above)
+    return 0;
+}
+
 static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
     const char* task = snp_valid ? "snp_valid" : "kmer_count";
     if (!b || !cfg) { np1_set_error(std::string(task) + ": null argument"); return -1; }
@@ -623,6 +692,9 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
             if (b->kc_wpool.ensure(W + 64) || b->kc_hpool.ensure(hcap)) return -1;
             c.hpool = b->kc_hpool.as<uint8_t>(); c.hcap = (uint32_t)hcap; c.hcount = &kcnt[KCC_HCOUNT];
             // ---- spanning-read haplotype vote, then the writes in part order
+            if (b->replay.on && !snp_valid) {
+                if (replay_votes(b, c, n_parts, n, q) != 0) return -1;
+            } else
             kc_launch_winner(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(),
                              b->kc_woff.as<uint32_t>(), n_parts, n, b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>());
             if (!snp_valid) {
@@ -793,3 +865,28 @@ int np1_batch_download_slots(np1_batch* b, int64_t c, std::vector<uint32_t>* sof
 }
 
 void np1_batch_swap_work(np1_batch* a, np1_batch* b) { if (a && b && a != b) a->swap_work(*b); }
+
+// Makes np1_batch_kmer_count of this batch replay the reference's region iterator (np1_replay.h).  `st` is the stream the batch was
+// uploaded from, read from `bam` (it carries the records' virtual offsets) and has to stay alive until the pass is done.
+extern "C" int np1_batch_enable_replay(np1_batch* b, const np1_stream* st, const char* bam) {
+    if (!b || !st || !bam) { np1_set_error("np1_batch_enable_replay: null argument"); return -1; }
+    const np::ReadStream& s = st->s;
+    if (s.voff.size() != s.n_reads() || s.voff_end.size() != s.n_reads() || (int64_t)s.n_reads() != b->n_reads || s.n_contigs() != b->nc) {
+        np1_set_error("np1_batch_enable_replay: the stream was not read from a file, or is not the one this batch holds");
+        return -1;
+    }
+    np1_batch::Replay& R = b->replay;
+    R.on = false;
+    if (!R.bai.load(std::string(bam) + ".bai")) { np1_set_error(std::string("cannot load BAM index: ") + bam + ".bai"); return -1; }
+    np::BamReader rd;
+    if (!rd.open(bam)) { np1_set_error(std::string("cannot open BAM: ") + bam); return -1; }
+    R.tid.assign(s.n_contigs(), -1);
+    for (size_t c = 0; c < s.n_contigs(); ++c) R.tid[c] = rd.header().name2id(s.names[c]);
+    R.pos = s.pos.data(); R.voff = s.voff.data(); R.voff_end = s.voff_end.data(); R.read_begin = s.read_begin.data();
+    R.endpos.resize(s.n_reads());
+    const np1k::ReadsDev H{s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), s.l_qseq.data(), s.cigar_off.data(), s.seq_off.data(), s.cigar.data(), s.seq.data()};
+    for (size_t r = 0; r < s.n_reads(); ++r) R.endpos[r] = np1k::kc_endpos(H, (int64_t)r);
+    b->h_ctg_off.assign(s.ctg_off.begin(), s.ctg_off.end());
+    R.on = true;
+    return 0;
+}

@@ -321,12 +321,19 @@ __global__ __launch_bounds__(64) void k_kc_split(KcCtx c, const uint32_t* __rest
 __global__ __launch_bounds__(64) void k_kc_winner(KcCtx c, const uint32_t* __restrict__ pt_ctg, const int32_t* __restrict__ pt_se,
                                                   const uint32_t* __restrict__ pt_len, const uint32_t* __restrict__ woff,
                                                   uint32_t n_parts, int64_t n_all, uint8_t* __restrict__ wpool,
-                                                  uint8_t* __restrict__ has_winner, uint32_t lanes) {
+                                                  uint8_t* __restrict__ has_winner, uint32_t lanes, const uint32_t* __restrict__ rp_first,
+                                                  const uint32_t* __restrict__ rp_list, const long long* __restrict__ rp_stale,
+                                                  const int32_t* __restrict__ rp_n2) {
     const uint32_t p = blockIdx.x * lanes + threadIdx.x;   // `lanes` parts per wave (see k_kc_nodepth)
     if (threadIdx.x >= lanes || p >= n_parts) return;
     const uint32_t ct = pt_ctg[p];
     if (ct == 0xffffffffu) { has_winner[p] = 0; return; }   // an unused slot of snp_valid's second round
     const bool has_next = (int64_t)c.read_begin[ct + 1] < n_all;
+    if (rp_first) {   // the records of this part as the replayed iterator hands them out (np1_replay.h); result 2 = second loop not known yet
+        const KcReplay rp{rp_list + rp_first[p], rp_first[p + 1] - rp_first[p], (int64_t)rp_stale[p], rp_n2 ? rp_n2[p] : -1};
+        has_winner[p] = (uint8_t)kc_part_winner(c, ct, pt_se[2 * p], pt_se[2 * p + 1], has_next, wpool + woff[p], (int32_t)pt_len[p], &rp);
+        return;
+    }
     has_winner[p] = (uint8_t)kc_part_winner(c, ct, pt_se[2 * p], pt_se[2 * p + 1], has_next, wpool + woff[p], (int32_t)pt_len[p]);
 }
 
@@ -489,7 +496,13 @@ void kc_launch_split(hipStream_t st, const KcCtx& c, const uint32_t* kr_ctg, con
 }
 void kc_launch_winner(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len,
                       const uint32_t* woff, uint32_t n_parts, int64_t n_all, uint8_t* wpool, uint8_t* has_winner) {
-    if (n_parts) k_kc_winner<<<kblk(n_parts, kc_lanes()), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, n_all, wpool, has_winner, kc_lanes());
+    if (n_parts) k_kc_winner<<<kblk(n_parts, kc_lanes()), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, n_all, wpool, has_winner, kc_lanes(), nullptr, nullptr, nullptr, nullptr);
+}
+void kc_launch_winner_replay(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len, const uint32_t* woff, uint32_t n_parts,
+                             int64_t n_all, uint8_t* wpool, uint8_t* has_winner, const uint32_t* rp_first, const uint32_t* rp_list, const long long* rp_stale,
+                             const int32_t* rp_n2) {
+    if (n_parts)
+        k_kc_winner<<<kblk(n_parts, kc_lanes()), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, n_all, wpool, has_winner, kc_lanes(), rp_first, rp_list, rp_stale, rp_n2);
 }
 void kc_launch_apply(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len,
                      const uint32_t* woff, uint32_t n_parts, const uint8_t* wpool, const uint8_t* has_winner) {

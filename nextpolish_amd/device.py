@@ -29,6 +29,11 @@ class Batch(object):
         if nat.lib().np1_batch_kmer_count(self.handle, C.byref(cfg), None) != 0:
             raise RuntimeError("np1_batch_kmer_count: " + nat.last_error())
 
+    def enable_replay(self, bam):
+        """kmer_count of this batch replays the reference's region iterator (the stream must have been read from `bam`; experimental)"""
+        if nat.lib().np1_batch_enable_replay(self.handle, self.stream.handle, bam.encode()) != 0:
+            raise RuntimeError("np1_batch_enable_replay: " + nat.last_error())
+
     def snp_valid(self, cfg):
         """Task 4 over the resident batch (reference: source/lib/snpvalid.c; stream loaded with qualities)."""
         if nat.lib().np1_batch_snp_valid(self.handle, C.byref(cfg), None) != 0:
