@@ -97,6 +97,7 @@ static int fill_batch(np1_batch* b, const np1_stream* st, bool sync) {
     b->n_reads = (int64_t)s.n_reads();
     b->h_ctg_off = s.ctg_off;
     b->max_lq = 0;
+    b->replay.on = false;   // (its record view belongs to the stream of the previous fill)
     b->force_staged = false;
     b->ran = false;
     b->out_cached = false;

@@ -438,6 +438,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
     b->G = S.ctg_off.back();
     b->h_ctg_off = S.ctg_off;
     b->max_lq = 0;
+    b->replay.on = false;
     b->force_staged = false;
     b->ran = false;
     b->out_cached = false;
