@@ -516,7 +516,10 @@ static int replay_votes(np1_batch* b, const KcCtx& c, uint32_t n_parts, int64_t 
     for (const Run& r : runs) {
         if (r.ct == 0xffffffffu) { for (uint32_t p = r.p0; p < r.p1; ++p) first[p + 1] = (uint32_t)list.size(); continue; }
         const int tid = R.tid[r.ct];
-        if (tid < 0 || (size_t)tid >= R.bai.refs.size()) { np1_set_error("kmer_count: a contig of the batch is not in the BAM index"); return -1; }
+        if (tid < 0 || (size_t)tid >= R.bai.refs.size()) {   // a contig the BAM does not know: no records, nothing to vote with
+            for (uint32_t p = r.p0; p < r.p1; ++p) first[p + 1] = (uint32_t)list.size();
+            continue;
+        }
         const np1replay::RefIndex ix(R.bai.refs[(size_t)tid]);
         for (uint32_t p = r.p0; p < r.p1; ++p) next_end[p] = p + 1 < r.p1 ? pt_se[2 * (size_t)(p + 1) + 1] : -1;
         const np1replay::FirstLoop fl = np1replay::first_loop(ix, records(r.ct), pt_se.data() + 2 * (size_t)r.p0, next_end.data() + r.p0, r.p1 - r.p0);
@@ -542,7 +545,7 @@ static int replay_votes(np1_batch* b, const KcCtx& c, uint32_t n_parts, int64_t 
     if (!any) return 0;
     std::vector<int32_t> n2(n_parts, 0);
     for (const Run& r : runs) {
-        if (r.ct == 0xffffffffu) continue;
+        if (r.ct == 0xffffffffu || R.tid[r.ct] < 0 || (size_t)R.tid[r.ct] >= R.bai.refs.size()) continue;
         const np1replay::RefIndex ix(R.bai.refs[(size_t)R.tid[r.ct]]);
         const std::vector<uint32_t> k = np1replay::second_loop_passes(ix, records(r.ct), pt_se.data() + 2 * (size_t)r.p0, next_end.data() + r.p0, r.p1 - r.p0, empty.data() + r.p0);
         for (uint32_t p = r.p0; p < r.p1; ++p) n2[p] = (int32_t)k[p - r.p0];
