@@ -346,7 +346,7 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
                 // the host loader keeps the records' virtual offsets: kmer_count can replay the reference's region iterator (DESIGN.md
                 // section 3); batches that come through the device-side ingest have no host view of the records and take them in file order
                 const char* e = getenv("NP1_ITER_REPLAY");
-                if (rc == 0 && task == 2 && !(e && e[0] == '0') && np1_batch_enable_replay(ln.batch, it.stream, bam) != 0) rc = -1;
+                if (rc == 0 && task == 2 && src.have_bai && !(e && e[0] == '0') && np1_batch_enable_replay(ln.batch, it.stream, bam) != 0) rc = -1;
             }
             t_p1 = now_ms();
             if (rc == 0) rc = run_task(ln.batch, cfg, task);
