@@ -71,3 +71,16 @@ def test_gpu_dropin_symbol_with_replay(tmp_path, monkeypatch):
         assert digest(C.string_at(r.contents.contig).decode()) == want, n
         L.polishresult_destory(r)
     L.config_destory(cfg)
+
+
+@pytest.mark.gpu
+def test_gpu_cli_on_the_host_loader_with_replay(tmp_path):
+    """`nextpolish1 kmercount` with NP1_INGEST=host: batches decoded by the host loader keep the records' virtual offsets and replay the
+    iterator too (np1_pipe.cpp; batches of the default device-side ingest take the records in file order)"""
+    import subprocess
+    from conftest import parse_cli_fasta
+    exe = os.path.join(os.path.dirname(HERE), "nextpolish_amd", "bin", "nextpolish1")
+    fa, bam = files(44, tmp_path)
+    p = subprocess.run([exe, "kmercount", fa, bam], capture_output=True, text=True, env=dict(os.environ, NP1_INGEST="host"))
+    assert p.returncode == 0, p.stderr
+    assert {n: digest(x) for n, x in parse_cli_fasta(p.stdout).items()} == GOLD["44"]
