@@ -334,6 +334,8 @@ class Stream(object):
 
     def voffs(self):
         """(start, end) BGZF virtual offsets per record of a stream loaded from a file, as numpy arrays; None for in-memory streams"""
+        if self.n_reads == 0:
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)
         b, e = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
         n = lib().np1_stream_voffs(self.handle, C.byref(b), C.byref(e))
         if n <= 0:
