@@ -169,9 +169,9 @@ static PolishResult* kmer_task(const char* tigname, Configure* cfg, bool snp_val
     np1_ctx* ctx = process_ctx();
     np1_batch* b = np1_batch_upload(ctx, &st);
     if (!b) die(np1_last_error());
-    {   // kmer_count replays the reference's region iterator on the BAM index; NP1_ITER_REPLAY=0: records in file order
+    {   // kmer_count and snp_valid replay the reference's region iterator on the BAM index; NP1_ITER_REPLAY=0: records in file order
         const char* e = getenv("NP1_ITER_REPLAY");
-        if (!snp_valid_task && !(e && e[0] == '0') && np1_batch_enable_replay(b, &st, cfg->bamfn) != 0) die(np1_last_error());
+        if (!(e && e[0] == '0') && np1_batch_enable_replay(b, &st, cfg->bamfn) != 0) die(np1_last_error());
     }
     if ((snp_valid_task ? np1_batch_snp_valid(b, cfg, nullptr) : np1_batch_kmer_count(b, cfg, nullptr)) != 0) die(np1_last_error());
     int64_t len = np1_batch_result_len(b, 0);

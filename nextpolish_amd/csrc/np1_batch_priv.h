@@ -35,6 +35,23 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// page-locked host memory that only grows (targets of asynchronous D2H copies)
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap && p) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 constexpr int kStages = 8;
 
 }  // namespace np1dev
@@ -63,15 +80,22 @@ struct np1_batch {
     // snp_valid: second-round work (regions nothing spanned, their split values and parts)
     np1dev::DevBuf sv_failse, sv_failcnt, sv_vsz, sv_voff, sv_val, sv_p2ctg, sv_p2se, sv_p2len, sv_woff2, sv_haswin2, sv_range;
     std::vector<np1dev::DevBuf> spw;   // snp_phase work buffers (np1_phase_device.hip), owned by the short-read batch
-    // kmer_count with the reference's region iterator replayed (np1_replay.h, np1_batch_enable_replay): host-side view of the records
-    // (the stream must outlive the pass), the BAM index, the BAM reference id of every contig
+    // kmer_count / snp_valid with the reference's region iterator replayed (np1_replay.h): the BAM index, the BAM reference id of every
+    // contig and the records' virtual offsets -- a view of the host stream the batch was filled from (np1_batch_enable_replay; the stream
+    // must outlive the pass) or arrays the device-side ingest brought down (np1_ingest.hip); positions and end positions are fetched from
+    // the device once per pass
     struct Replay {
         bool on = false;
-        np::BaiIndex bai;
-        std::vector<int32_t> tid, endpos;
-        const int32_t* pos = nullptr;
-        const uint64_t *voff = nullptr, *voff_end = nullptr, *read_begin = nullptr;
-        np1dev::DevBuf first, list, stale, n2;
+        const np::BaiIndex* bai = nullptr;     // the pipe's index, or own_bai
+        np::BaiIndex own_bai;
+        std::string own_bai_path;
+        std::vector<int32_t> tid;
+        np1dev::PinBuf pos, endpos;            // int32 per record
+        bool have_pos = false;
+        const uint64_t *voff = nullptr, *voff_end = nullptr;
+        np1dev::PinBuf own_voff, own_voff_end; // uint64 per record
+        np1dev::DevBuf first, list, stale, n2, brk, snap;
+        uint32_t revotes = 0;                  // diagnostics: vote launches the max_count_kmer break made necessary in the last pass
     } replay;
     bool has_qual = false;
     std::vector<uint64_t> h_read_begin;
@@ -145,7 +169,11 @@ struct np1_batch {
                          &sv_p2se, &sv_p2len, &sv_woff2, &sv_haswin2, &sv_range};
         for (np1dev::DevBuf* b : all) b->release();
         for (np1dev::DevBuf& b : spw) b.release();
-        replay.first.release(); replay.list.release(); replay.stale.release(); replay.n2.release();
+        replay.first.release(); replay.list.release(); replay.stale.release(); replay.n2.release(); replay.brk.release(); replay.snap.release();
+        replay.pos.release(); replay.endpos.release(); replay.own_voff.release(); replay.own_voff_end.release();
     }
 };
 
+
+// replay of the reference's region iterator for a batch the device-side ingest filled (np1_device.hip)
+int np1_batch_enable_replay_ingested(np1_batch* b, const np::BaiIndex* bai, const std::vector<int32_t>& tid);

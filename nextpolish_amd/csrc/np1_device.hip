@@ -16,6 +16,7 @@
 #include "np1_priv.h"
 #include "np1_batch_priv.h"
 #include "np1_replay.h"
+#include "np_threads.h"
 
 
 using namespace np1k;
@@ -487,75 +488,143 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
 // snp_valid (snpvalid.c:3-36) is kmer_count's haplotype vote without the no-depth regions, run twice: the first round leaves the
 // FLAG_ZERO marks to the winners (a part that gets one loses its marks), the regions nothing spanned are cut again at the middle of
 // their unmarked runs (fts_spilt_region) and voted on once more; the result is emitted without lower case.
-// kmer_count's votes on what the reference's region iterator hands out (np1_replay.h).  The parts of a contig are one contiguous run of
-// the part arrays, in list order.  Host: first loop of every part (record lists, buffered record); device: votes, 2 = first loop left
-// nothing; host: passes of the second loop over those parts; device: the votes again with them.
-static int replay_votes(np1_batch* b, const KcCtx& c, uint32_t n_parts, int64_t n_all, hipStream_t q) {
+// The votes of ss_kmer_correct (kmercount.c:175-261) on what the reference's region iterator hands out (np1_replay.h), for kmer_count,
+// for both rounds of snp_valid, on every path that knows the file geometry (host loader and device-side ingest alike).  The pairs of a
+// contig are one contiguous run of the part arrays, in list order (slots marked 0xffffffff are unused; contig | 1 << 31 marks an
+// inverted pair of snp_valid's second round: nothing is voted there, but its end is the `nextposend` of the pair before it).
+//   host: first loop of every part (record lists, buffered record)  ->  device: votes; 2 = the first loop left nothing; where the
+//   loop left through the max_count_kmer break (kmercount.c:201-203) the device says after how many records  ->  host: the replay
+//   again with those breaks (a re-used iterator resumes from where the break left it); only if that changes a list do the votes run
+//   again, until lists and breaks agree  ->  host: passes of the second loop over the empty parts  ->  device: the votes with them.
+static int replay_votes(np1_batch* b, const KcCtx& c, const uint32_t* d_ctg, const int32_t* d_se, const uint32_t* d_len, const uint32_t* d_woff, uint32_t n_parts,
+                        int64_t n_all, uint8_t* d_wpool, uint8_t* d_haswin, hipStream_t q) {
     np1_batch::Replay& R = b->replay;
+    if (!R.have_pos) {     // once per pass: positions and end positions of the records as the kernels see them
+        if (!R.pos.ensure(4 * (size_t)(n_all + 1)) || !R.endpos.ensure(4 * (size_t)(n_all + 1))) { np1_set_error("hipHostMalloc failed"); return -1; }
+        if (n_all) {
+            HIPCHK(hipMemcpyAsync(R.pos.p, b->pos.p, 4 * (size_t)n_all, hipMemcpyDeviceToHost, q));
+            HIPCHK(hipMemcpyAsync(R.endpos.p, b->kc_endpos.p, 4 * (size_t)n_all, hipMemcpyDeviceToHost, q));
+        }
+        R.have_pos = true;
+    }
     std::vector<uint32_t> pt_ctg(n_parts);
     std::vector<int32_t> pt_se(2 * (size_t)n_parts);
-    HIPCHK(hipMemcpyAsync(pt_ctg.data(), b->kc_pt_ctg.p, 4 * (size_t)n_parts, hipMemcpyDeviceToHost, q));
-    HIPCHK(hipMemcpyAsync(pt_se.data(), b->kc_pt_se.p, 8 * (size_t)n_parts, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipMemcpyAsync(pt_ctg.data(), d_ctg, 4 * (size_t)n_parts, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipMemcpyAsync(pt_se.data(), d_se, 8 * (size_t)n_parts, hipMemcpyDeviceToHost, q));
     HIPCHK(hipStreamSynchronize(q));
-    std::vector<uint32_t> first((size_t)n_parts + 1, 0), list;
-    std::vector<long long> stale(n_parts, -1);
-    std::vector<int32_t> next_end(n_parts, -1);
     struct Run { uint32_t ct, p0, p1; };
     std::vector<Run> runs;
+    std::vector<uint8_t> skip(n_parts, 0);
     for (uint32_t p = 0; p < n_parts;) {
+        if (pt_ctg[p] == 0xffffffffu) { skip[p] = 1; ++p; continue; }
+        const uint32_t ct = pt_ctg[p] & 0x7fffffffu;
         uint32_t e = p;
-        while (e < n_parts && pt_ctg[e] == pt_ctg[p]) ++e;
-        runs.push_back(Run{pt_ctg[p], p, e});
+        while (e < n_parts && pt_ctg[e] != 0xffffffffu && (pt_ctg[e] & 0x7fffffffu) == ct) { skip[e] = (pt_ctg[e] & 0x80000000u) ? 1 : 0; ++e; }
+        runs.push_back(Run{ct, p, e});
         p = e;
     }
+    std::vector<int32_t> next_end(n_parts, -1);
+    for (const Run& r : runs)
+        for (uint32_t p = r.p0; p + 1 < r.p1; ++p) next_end[p] = pt_se[2 * (size_t)(p + 1) + 1];
+    auto known = [&](const Run& r) { return R.tid[r.ct] >= 0 && (size_t)R.tid[r.ct] < R.bai->refs.size(); };   // else: a contig the BAM does not know, no records
     auto records = [&](uint32_t ct) {
-        const int64_t rb = (int64_t)R.read_begin[ct], re = (int64_t)R.read_begin[ct + 1];
-        return np1replay::Records{R.voff + rb, R.voff_end + rb, R.pos + rb, R.endpos.data() + rb, re - rb, re < n_all,
+        const int64_t rb = (int64_t)b->h_read_begin[ct], re = (int64_t)b->h_read_begin[ct + 1];
+        return np1replay::Records{R.voff + rb, R.voff_end + rb, R.pos.as<int32_t>() + rb, R.endpos.as<int32_t>() + rb, re - rb, re < n_all,
                                   (int32_t)(b->h_ctg_off[ct + 1] - b->h_ctg_off[ct])};
     };
-    for (const Run& r : runs) {
-        if (r.ct == 0xffffffffu) { for (uint32_t p = r.p0; p < r.p1; ++p) first[p + 1] = (uint32_t)list.size(); continue; }
-        const int tid = R.tid[r.ct];
-        if (tid < 0 || (size_t)tid >= R.bai.refs.size()) {   // a contig the BAM does not know: no records, nothing to vote with
-            for (uint32_t p = r.p0; p < r.p1; ++p) first[p + 1] = (uint32_t)list.size();
-            continue;
+    struct Lists { std::vector<uint32_t> first, list; std::vector<long long> stale; };
+    auto replay = [&](const std::vector<uint32_t>& limit, Lists* out) {
+        std::vector<np1replay::FirstLoop> per(runs.size());
+        np::parallel_for(runs.size(), 1, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                const Run& r = runs[i];
+                if (!known(r)) continue;
+                const np1replay::RefIndex ix(R.bai->refs[(size_t)R.tid[r.ct]]);
+                per[i] = np1replay::first_loop(ix, records(r.ct), pt_se.data() + 2 * (size_t)r.p0, next_end.data() + r.p0, r.p1 - r.p0, limit.data() + r.p0, skip.data() + r.p0);
+            }
+        });
+        out->first.assign((size_t)n_parts + 1, 0);
+        out->list.clear();
+        out->stale.assign(n_parts, -1);
+        uint32_t p = 0;
+        for (size_t i = 0; i < runs.size(); ++i) {
+            const Run& r = runs[i];
+            for (; p < r.p0; ++p) out->first[p + 1] = (uint32_t)out->list.size();
+            const uint32_t rb = (uint32_t)b->h_read_begin[r.ct];
+            const np1replay::FirstLoop& fl = per[i];
+            for (; p < r.p1; ++p) {
+                if (!fl.first.empty()) {
+                    for (uint32_t t = fl.first[p - r.p0]; t < fl.first[p - r.p0 + 1]; ++t) out->list.push_back(fl.list[t] + rb);
+                    out->stale[p] = fl.stale[p - r.p0] >= 0 ? fl.stale[p - r.p0] + (long long)rb : -1;
+                }
+                out->first[p + 1] = (uint32_t)out->list.size();
+            }
         }
-        const np1replay::RefIndex ix(R.bai.refs[(size_t)tid]);
-        for (uint32_t p = r.p0; p < r.p1; ++p) next_end[p] = p + 1 < r.p1 ? pt_se[2 * (size_t)(p + 1) + 1] : -1;
-        const np1replay::FirstLoop fl = np1replay::first_loop(ix, records(r.ct), pt_se.data() + 2 * (size_t)r.p0, next_end.data() + r.p0, r.p1 - r.p0);
-        const uint32_t rb = (uint32_t)R.read_begin[r.ct];
-        for (uint32_t p = r.p0; p < r.p1; ++p) {
-            for (uint32_t t = fl.first[p - r.p0]; t < fl.first[p - r.p0 + 1]; ++t) list.push_back(fl.list[t] + rb);
-            first[p + 1] = (uint32_t)list.size();
-            stale[p] = fl.stale[p - r.p0] >= 0 ? fl.stale[p - r.p0] + (long long)rb : -1;
-        }
-    }
-    if (R.first.ensure(4 * ((size_t)n_parts + 2)) || R.list.ensure(4 * (list.size() + 2)) || R.stale.ensure(8 * ((size_t)n_parts + 1)) || R.n2.ensure(4 * ((size_t)n_parts + 1))) return -1;
-    HIPCHK(hipMemcpyAsync(R.first.p, first.data(), 4 * ((size_t)n_parts + 1), hipMemcpyHostToDevice, q));
-    if (!list.empty()) HIPCHK(hipMemcpyAsync(R.list.p, list.data(), 4 * list.size(), hipMemcpyHostToDevice, q));
-    HIPCHK(hipMemcpyAsync(R.stale.p, stale.data(), 8 * (size_t)n_parts, hipMemcpyHostToDevice, q));
-    kc_launch_winner_replay(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(), b->kc_woff.as<uint32_t>(), n_parts, n_all,
-                            b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>(), R.first.as<uint32_t>(), R.list.as<uint32_t>(), R.stale.as<long long>(), nullptr);
+        for (; p < n_parts; ++p) out->first[p + 1] = (uint32_t)out->list.size();
+    };
     std::vector<uint8_t> state(n_parts);
-    HIPCHK(hipMemcpyAsync(state.data(), b->kc_haswin.p, n_parts, hipMemcpyDeviceToHost, q));
-    HIPCHK(hipStreamSynchronize(q));
+    std::vector<uint32_t> brk(n_parts, 0), limit(n_parts, 0);
+    if (R.first.ensure(4 * ((size_t)n_parts + 2)) || R.stale.ensure(8 * ((size_t)n_parts + 1)) || R.n2.ensure(4 * ((size_t)n_parts + 1)) || R.brk.ensure(4 * ((size_t)n_parts + 1))) return -1;
+    auto vote = [&](const Lists& L, const int32_t* d_n2) -> int {
+        if (R.list.ensure(4 * (L.list.size() + 2))) return -1;
+        HIPCHK(hipMemcpyAsync(R.first.p, L.first.data(), 4 * ((size_t)n_parts + 1), hipMemcpyHostToDevice, q));
+        if (!L.list.empty()) HIPCHK(hipMemcpyAsync(R.list.p, L.list.data(), 4 * L.list.size(), hipMemcpyHostToDevice, q));
+        HIPCHK(hipMemcpyAsync(R.stale.p, L.stale.data(), 8 * (size_t)n_parts, hipMemcpyHostToDevice, q));
+        HIPCHK(hipMemsetAsync(c.hcount, 0, 4, q));     // every launch takes the haplotype pool from its start
+        kc_launch_winner_replay(q, c, d_ctg, d_se, d_len, d_woff, n_parts, n_all, d_wpool, d_haswin, R.first.as<uint32_t>(), R.list.as<uint32_t>(), R.stale.as<long long>(), d_n2,
+                                d_n2 ? nullptr : R.brk.as<uint32_t>());
+        if (!d_n2) {
+            HIPCHK(hipMemcpyAsync(state.data(), d_haswin, n_parts, hipMemcpyDeviceToHost, q));
+            HIPCHK(hipMemcpyAsync(brk.data(), R.brk.p, 4 * (size_t)n_parts, hipMemcpyDeviceToHost, q));
+        }
+        HIPCHK(hipStreamSynchronize(q));   // (the host vectors are the source of the copies above)
+        return 0;
+    };
+    // a covering record clears FLAG_ZERO marks whether its haplotype counts or not (kmercount.c:398-437): votes that have to be redone
+    // on other records start from the marks as they were
+    if (!c.keep_zero_marks && b->S) {
+        if (R.snap.ensure((size_t)b->S + 64)) return -1;
+        HIPCHK(hipMemcpyAsync(R.snap.p, c.sflag, b->S, hipMemcpyDeviceToDevice, q));
+    }
+    Lists cur, nxt;
+    replay(limit, &cur);
+    if (vote(cur, nullptr) != 0) return -1;
+    R.revotes = 0;
+    for (int it = 0; brk != limit; ++it) {
+        if (it > 256) { np1_set_error("kmer_count: the replay of the region iterator does not settle on this input"); return -1; }
+        limit = brk;
+        replay(limit, &nxt);
+        bool same = true;
+        for (uint32_t p = 0; p < n_parts && same; ++p) {
+            const uint32_t n_old = cur.first[p + 1] - cur.first[p], n_new = nxt.first[p + 1] - nxt.first[p], n_cmp = brk[p] ? brk[p] : n_old;
+            same = n_new == n_cmp && n_cmp <= n_old && std::equal(nxt.list.begin() + nxt.first[p], nxt.list.begin() + nxt.first[p + 1], cur.list.begin() + cur.first[p]) &&
+                   (state[p] != 2 || nxt.stale[p] == cur.stale[p]);
+        }
+        cur.first.swap(nxt.first); cur.list.swap(nxt.list); cur.stale.swap(nxt.stale);
+        if (same) break;                   // the votes that ran saw exactly these records: nothing to redo
+        if (!c.keep_zero_marks && b->S) HIPCHK(hipMemcpyAsync(c.sflag, R.snap.p, b->S, hipMemcpyDeviceToDevice, q));
+        if (vote(cur, nullptr) != 0) return -1;
+        ++R.revotes;
+    }
     bool any = false;
     std::vector<uint8_t> empty(n_parts, 0);
     for (uint32_t p = 0; p < n_parts; ++p) { empty[p] = state[p] == 2; any = any || empty[p]; }
     if (!any) return 0;
     std::vector<int32_t> n2(n_parts, 0);
-    for (const Run& r : runs) {
-        if (r.ct == 0xffffffffu || R.tid[r.ct] < 0 || (size_t)R.tid[r.ct] >= R.bai.refs.size()) continue;
-        const np1replay::RefIndex ix(R.bai.refs[(size_t)R.tid[r.ct]]);
-        const std::vector<uint32_t> k = np1replay::second_loop_passes(ix, records(r.ct), pt_se.data() + 2 * (size_t)r.p0, next_end.data() + r.p0, r.p1 - r.p0, empty.data() + r.p0);
-        for (uint32_t p = r.p0; p < r.p1; ++p) n2[p] = (int32_t)k[p - r.p0];
-    }
+    np::parallel_for(runs.size(), 1, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const Run& r = runs[i];
+            if (!known(r)) continue;
+            bool need = false;
+            for (uint32_t p = r.p0; p < r.p1 && !need; ++p) need = empty[p];
+            if (!need) continue;
+            const np1replay::RefIndex ix(R.bai->refs[(size_t)R.tid[r.ct]]);
+            const std::vector<uint32_t> k = np1replay::second_loop_passes(ix, records(r.ct), pt_se.data() + 2 * (size_t)r.p0, next_end.data() + r.p0, r.p1 - r.p0, empty.data() + r.p0);
+            for (uint32_t p = r.p0; p < r.p1; ++p) n2[p] = (int32_t)k[p - r.p0];
+        }
+    });
     HIPCHK(hipMemcpyAsync(R.n2.p, n2.data(), 4 * (size_t)n_parts, hipMemcpyHostToDevice, q));
-    HIPCHK(hipMemsetAsync(c.hcount, 0, 4, q));     // the second pass takes the haplotype pool from its start again
-    kc_launch_winner_replay(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(), b->kc_woff.as<uint32_t>(), n_parts, n_all,
-                            b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>(), R.first.as<uint32_t>(), R.list.as<uint32_t>(), R.stale.as<long long>(), R.n2.as<int32_t>());
-    HIPCHK(hipStreamSynchronize(q));   // (the host vectors of this function are the source of the copies above)
-    return 0;
+    return vote(cur, R.n2.as<int32_t>());
 }
 
 static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
@@ -568,6 +637,7 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
     b->ran = false;
     b->out_cached = false;
     b->out_pinned = false;
+    b->replay.have_pos = false;
     int K = 0;
     long long Rfix = 0;
     if (!rate_fixed_point(cfg->indel_balance_factor_sgs, &K, &Rfix)) {   // general rate: the region DP keeps doubles (np1_kmer.h)
@@ -696,8 +766,10 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
             if (b->kc_wpool.ensure(W + 64) || b->kc_hpool.ensure(hcap)) return -1;
             c.hpool = b->kc_hpool.as<uint8_t>(); c.hcap = (uint32_t)hcap; c.hcount = &kcnt[KCC_HCOUNT];
             // ---- spanning-read haplotype vote, then the writes in part order
-            if (b->replay.on && !snp_valid) {
-                if (replay_votes(b, c, n_parts, n, q) != 0) return -1;
+            if (b->replay.on) {
+                if (replay_votes(b, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(), b->kc_woff.as<uint32_t>(), n_parts, n,
+                                 b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>(), q) != 0)
+                    return -1;
             } else
             kc_launch_winner(q, c, b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>(),
                              b->kc_woff.as<uint32_t>(), n_parts, n, b->kc_wpool.as<uint8_t>(), b->kc_haswin.as<uint8_t>());
@@ -732,6 +804,12 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
                 HIPCHK(hipMemcpyAsync(&W2, &totals[6], 8, hipMemcpyDeviceToHost, q));
                 HIPCHK(hipStreamSynchronize(q));
                 if (b->kc_wpool.ensure(W2 + 64)) return -1;     // round 1's winners are in the slots by now
+                if (b->replay.on) {
+                    HIPCHK(hipMemsetAsync(c.hcount, 0, 4, q));
+                    if (V && replay_votes(b, c, b->sv_p2ctg.as<uint32_t>(), b->sv_p2se.as<int32_t>(), b->sv_p2len.as<uint32_t>(), b->sv_woff2.as<uint32_t>(), (uint32_t)V, n,
+                                          b->kc_wpool.as<uint8_t>(), b->sv_haswin2.as<uint8_t>(), q) != 0)
+                        return -1;
+                } else
                 kc_launch_winner(q, c, b->sv_p2ctg.as<uint32_t>(), b->sv_p2se.as<int32_t>(), b->sv_p2len.as<uint32_t>(), b->sv_woff2.as<uint32_t>(),
                                  (uint32_t)V, n, b->kc_wpool.as<uint8_t>(), b->sv_haswin2.as<uint8_t>());
                 sv_launch_round2_apply(q, c, nc, b->sv_range.as<uint32_t>(), n_parts, b->sv_voff.as<uint32_t>(), b->sv_p2ctg.as<uint32_t>(),
@@ -870,8 +948,8 @@ int np1_batch_download_slots(np1_batch* b, int64_t c, std::vector<uint32_t>* sof
 
 void np1_batch_swap_work(np1_batch* a, np1_batch* b) { if (a && b && a != b) a->swap_work(*b); }
 
-// Makes np1_batch_kmer_count of this batch replay the reference's region iterator (np1_replay.h).  `st` is the stream the batch was
-// uploaded from, read from `bam` (it carries the records' virtual offsets) and has to stay alive until the pass is done.
+// Makes np1_batch_kmer_count / np1_batch_snp_valid of this batch replay the reference's region iterator (np1_replay.h).  `st` is the stream
+// the batch was uploaded from, read from `bam` (it carries the records' virtual offsets) and has to stay alive until the pass is done.
 extern "C" int np1_batch_enable_replay(np1_batch* b, const np1_stream* st, const char* bam) {
     if (!b || !st || !bam) { np1_set_error("np1_batch_enable_replay: null argument"); return -1; }
     const np::ReadStream& s = st->s;
@@ -881,16 +959,36 @@ extern "C" int np1_batch_enable_replay(np1_batch* b, const np1_stream* st, const
     }
     np1_batch::Replay& R = b->replay;
     R.on = false;
-    if (!R.bai.load(std::string(bam) + ".bai")) { np1_set_error(std::string("cannot load BAM index: ") + bam + ".bai"); return -1; }
+    const std::string bai_path = std::string(bam) + ".bai";
+    if (R.own_bai_path != bai_path) {
+        R.own_bai_path.clear();
+        if (!R.own_bai.load(bai_path)) { np1_set_error("cannot load BAM index: " + bai_path); return -1; }
+        R.own_bai_path = bai_path;
+    }
+    R.bai = &R.own_bai;
     np::BamReader rd;
     if (!rd.open(bam)) { np1_set_error(std::string("cannot open BAM: ") + bam); return -1; }
     R.tid.assign(s.n_contigs(), -1);
     for (size_t c = 0; c < s.n_contigs(); ++c) R.tid[c] = rd.header().name2id(s.names[c]);
-    R.pos = s.pos.data(); R.voff = s.voff.data(); R.voff_end = s.voff_end.data(); R.read_begin = s.read_begin.data();
-    R.endpos.resize(s.n_reads());
-    const np1k::ReadsDev H{s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), s.l_qseq.data(), s.cigar_off.data(), s.seq_off.data(), s.cigar.data(), s.seq.data()};
-    for (size_t r = 0; r < s.n_reads(); ++r) R.endpos[r] = np1k::kc_endpos(H, (int64_t)r);
+    R.voff = s.voff.data(); R.voff_end = s.voff_end.data();
     b->h_ctg_off.assign(s.ctg_off.begin(), s.ctg_off.end());
+    b->h_read_begin.assign(s.read_begin.begin(), s.read_begin.end());
+    R.on = true;
+    return 0;
+}
+
+// The same for a batch the device-side ingest filled (np1_ingest.hip): the records' virtual offsets are in R.own_voff / own_voff_end
+// already; `bai` (the pipe's index) has to stay alive until the pass is done.
+int np1_batch_enable_replay_ingested(np1_batch* b, const np::BaiIndex* bai, const std::vector<int32_t>& tid) {
+    np1_batch::Replay& R = b->replay;
+    R.on = false;
+    if (!bai || tid.size() != b->nc || R.own_voff.cap < 8 * (size_t)b->n_reads || R.own_voff_end.cap < 8 * (size_t)b->n_reads) {
+        np1_set_error("np1_batch_enable_replay_ingested: the batch holds no virtual offsets");
+        return -1;
+    }
+    R.bai = bai;
+    R.tid = tid;
+    R.voff = R.own_voff.as<uint64_t>(); R.voff_end = R.own_voff_end.as<uint64_t>();
     R.on = true;
     return 0;
 }

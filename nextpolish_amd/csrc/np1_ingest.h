@@ -42,6 +42,8 @@ uint64_t scratch_host_blocks(const Scratch* s);   // blocks the device decoder h
 // 0 = staged; 1 = this batch has to take the host loader (index without per-contig offsets); -1 = error (*err set)
 int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, std::string* err);
 // 0 = the batch object holds the decoded record stream; 1 = take the host loader (CIGARs in CG tags); -1 = error (np1_last_error)
-int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr);
+// replay_bai != nullptr (tasks 2 and 4): the records' virtual offsets come down with the batch and kmer_count / snp_valid replay the
+// reference's region iterator on them (np1_replay.h); the index has to stay alive until the pass is done
+int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::BaiIndex* replay_bai = nullptr);
 
 }  // namespace np1ingest

@@ -29,6 +29,8 @@
 #include "np1_kmer_kernels.h"
 #include "np_bgzf.h"
 #include "np_inflate_dev.h"
+#include "np_crc_dev.h"
+#include "np_crc32.h"
 
 using namespace np1dev;
 
@@ -57,6 +59,12 @@ __global__ __launch_bounds__(256, 4) void k_inflate(const uint8_t* __restrict__ 
     int rc = 0;
     if (d.out_len) rc = npdev::inflate_block_wave(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, lds[wave]);
     if ((threadIdx.x & 63u) == 0) status[b] = (uint32_t)rc;
+}
+
+// gzip trailer CRC of every block the decoder accepted (np_crc_dev.h; the reference's htslib rejects a block whose CRC differs)
+__global__ __launch_bounds__(256) void k_crc_check(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+                                                   const uint8_t* __restrict__ out, uint32_t* __restrict__ status, const uint32_t* __restrict__ shift) {
+    npdev::crc_check_body(comp, blocks, n_blocks, out, status, shift);
 }
 
 // the same with phase clocks (diagnostics only)
@@ -210,6 +218,31 @@ __global__ __launch_bounds__(256) void k_rec_scatter(const uint8_t* __restrict__
     }
 }
 
+// BGZF virtual offsets of the kept records, as the reference's reader would report them with bgzf_tell before and behind each record
+// (htslib 1.9 bgzf.c: a position at the end of a block is the start of the next block of the FILE): what the replay of the region
+// iterator addresses records by (np1_replay.h).  geo[3 b .. 3 b + 3) = {file offset << 16, tell at the block's first byte, (file offset
+// + size) << 16} of block b; blocks are in stream order, empty blocks share the stream offset of their successor.
+__device__ __forceinline__ uint32_t block_of(const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks, uint64_t p) {   // last block with out_off <= p
+    uint32_t lo = 0, hi = n_blocks;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (blocks[mid].out_off <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_rec_voff(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rec_off, uint64_t n_rec, const uint32_t* __restrict__ keep,
+                                                  const uint32_t* __restrict__ kidx, const npdev::BlockDesc* __restrict__ blocks, const uint64_t* __restrict__ geo,
+                                                  uint32_t n_blocks, uint64_t* __restrict__ voff, uint64_t* __restrict__ voff_end) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec || !keep[r]) return;
+    const uint64_t p = rec_off[r], e = p + 4ull + ld32(u + p);
+    const uint32_t j = kidx[r];
+    const uint32_t b0 = block_of(blocks, n_blocks, p);
+    voff[j] = p == blocks[b0].out_off ? geo[3 * (size_t)b0 + 1] : geo[3 * (size_t)b0] | (p - blocks[b0].out_off);
+    const uint32_t b1 = block_of(blocks, n_blocks, e - 1);
+    voff_end[j] = e == blocks[b1].out_off + blocks[b1].out_len ? geo[3 * (size_t)b1 + 2] : geo[3 * (size_t)b1] | (e - blocks[b1].out_off);
+}
+
 __global__ void k_read_begin(const uint32_t* __restrict__ first_seg, uint32_t nc, const uint64_t* __restrict__ rec_base, const uint32_t* __restrict__ kidx,
                              uint64_t n_rec, uint64_t* __restrict__ read_begin) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -226,12 +259,13 @@ inline unsigned nblk(uint64_t n, unsigned per) { return (unsigned)((n + per - 1)
 namespace np1ingest {
 
 struct Scratch {
-    DevBuf comp, inflated, blocks, status, segs, counts, rec_base, first_seg, small, scan_tmp, rec_off, rec_seg, keep, kidx, ncw, seqb, qualb, cig_at, seq_at, qual_at;
+    DevBuf comp, inflated, blocks, status, segs, counts, rec_base, first_seg, small, scan_tmp, rec_off, rec_seg, keep, kidx, ncw, seqb, qualb, cig_at, seq_at, qual_at, geo, voff,
+        voff_end, crc_shift;
     std::vector<uint32_t> h_status;
     uint64_t n_host_blocks = 0;
     ~Scratch() {
         DevBuf* all[] = {&comp, &inflated, &blocks, &status, &segs, &counts, &rec_base, &first_seg, &small, &scan_tmp, &rec_off, &rec_seg, &keep, &kidx, &ncw,
-                         &seqb, &qualb, &cig_at, &seq_at, &qual_at};
+                         &seqb, &qualb, &cig_at, &seq_at, &qual_at, &geo, &voff, &voff_end, &crc_shift};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -260,6 +294,8 @@ struct Staging::Impl {
     std::vector<npdev::BlockDesc> blocks;
     std::vector<uint64_t> block_coff;          // file offset of every block, ascending
     std::vector<uint32_t> block_size;          // its size in the file
+    std::vector<uint64_t> block_geo;           // 3 per block: file offset << 16, bgzf_tell at its first byte, (file offset + size) << 16
+    std::vector<int32_t> tid;                  // BAM reference id of every contig (-1: not in the header)
     std::vector<Segment> segs;
     std::vector<uint32_t> first_seg;           // nc + 1
     std::vector<uint32_t> ctg_off;             // nc + 1
@@ -379,6 +415,16 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
     }
     S.comp_bytes = comp_at;
     S.inflated_bytes = u_at;
+    S.tid.assign(tid.begin(), tid.end());
+    S.block_geo.resize(3 * S.blocks.size());
+    for (size_t i = 0; i < S.blocks.size(); ++i) {
+        const uint64_t here = S.block_coff[i] << 16;
+        // the reader's position at the first byte of block i: behind an empty block of the same run it still reports that block's start
+        const bool run_start = i == 0 || S.block_coff[i - 1] + S.block_size[i - 1] != S.block_coff[i];
+        S.block_geo[3 * i] = here;
+        S.block_geo[3 * i + 1] = (!run_start && S.blocks[i - 1].out_len == 0) ? S.block_geo[3 * (i - 1) + 1] : here;
+        S.block_geo[3 * i + 2] = (S.block_coff[i] + S.block_size[i]) << 16;
+    }
     // ---- anchors -> segments (inflated-stream offsets)
     auto to_u = [&](np::voff_t v, uint64_t* out) {
         const uint64_t coff = v >> 16;
@@ -424,7 +470,7 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
 // Device half: fills the batch object.  Returns 0, 1 (take the host loader for this batch: CG-tag CIGARs) or -1.
 static double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
-int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
+int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::BaiIndex* replay_bai) {
     Staging::Impl& S = *st->impl;
     static const bool timing = getenv("NP1_TIMING") != nullptr;
     const double t_0 = timing ? now_ms() : 0;
@@ -462,6 +508,17 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
     uint64_t n_rec = 0;
     if (n_blocks) {
         k_inflate<<<nblk(n_blocks, 4), 256, 0, q>>>(W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>());
+        static const bool check_crc = getenv("NP_BGZF_NO_CRC") == nullptr;      // the same switch as the host reader's (np_bgzf.cpp)
+        if (check_crc) {
+            if (!W.crc_shift.p) {
+                uint32_t t[64];
+                npdev::crc_shift_table(t);
+                if (W.crc_shift.ensure(sizeof(t))) return -1;
+                HIPCHK(hipMemcpy(W.crc_shift.p, t, sizeof(t), hipMemcpyHostToDevice));
+            }
+            k_crc_check<<<nblk(n_blocks, 4), 256, 0, q>>>(W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(),
+                                                         W.crc_shift.as<uint32_t>());
+        }
         W.h_status.resize(n_blocks);
         HIPCHK(hipMemcpyAsync(W.h_status.data(), W.status.p, 4 * (size_t)n_blocks, hipMemcpyDeviceToHost, q));
     }
@@ -481,6 +538,11 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
         const npdev::BlockDesc& d = S.blocks[i];
         std::vector<uint8_t> tmp(d.out_len ? d.out_len : 1);
         if (!np::bgzf_inflate_block((const uint8_t*)S.comp.p + d.in_off, d.in_len, tmp.data(), d.out_len)) { np1_set_error("corrupt BGZF block in the BAM"); return -1; }
+        if (getenv("NP_BGZF_NO_CRC") == nullptr && d.out_len) {     // blocks that come back to the host are checked here (the device checked the others)
+            uint32_t want;
+            memcpy(&want, (const uint8_t*)S.comp.p + d.in_off + d.in_len, 4);
+            if (np::crc32_block(tmp.data(), d.out_len) != want) { np1_set_error("corrupt BGZF block in the BAM (CRC mismatch)"); return -1; }
+        }
         HIPCHK(hipMemcpy(W.inflated.as<uint8_t>() + d.out_off, tmp.data(), d.out_len, hipMemcpyHostToDevice));
         patched = true;
         ++W.n_host_blocks;
@@ -540,7 +602,20 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr) {
     k_read_begin<<<nblk(nc + 1, 64), 64, 0, q>>>(W.first_seg.as<uint32_t>(), nc, W.rec_base.as<uint64_t>(), W.kidx.as<uint32_t>(), n_rec, b->read_begin.as<uint64_t>());
     b->h_read_begin.resize((size_t)nc + 1);
     HIPCHK(hipMemcpyAsync(b->h_read_begin.data(), b->read_begin.p, 8 * (size_t)(nc + 1), hipMemcpyDeviceToHost, q));
+    if (replay_bai) {   // kmer_count / snp_valid replay the reference's region iterator: the records' virtual offsets come down with the batch
+        np1_batch::Replay& R = b->replay;
+        if (W.geo.ensure(8 * (S.block_geo.size() + 3)) || W.voff.ensure(8 * nn) || W.voff_end.ensure(8 * nn)) return -1;
+        if (!R.own_voff.ensure(8 * nn) || !R.own_voff_end.ensure(8 * nn)) { np1_set_error("hipHostMalloc failed"); return -1; }
+        if (n_rec) {
+            HIPCHK(hipMemcpyAsync(W.geo.p, S.block_geo.data(), 8 * S.block_geo.size(), hipMemcpyHostToDevice, q));
+            k_rec_voff<<<nblk(n_rec, 256), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.rec_off.as<uint64_t>(), n_rec, W.keep.as<uint32_t>(), W.kidx.as<uint32_t>(),
+                                                       W.blocks.as<npdev::BlockDesc>(), W.geo.as<uint64_t>(), n_blocks, W.voff.as<uint64_t>(), W.voff_end.as<uint64_t>());
+            HIPCHK(hipMemcpyAsync(R.own_voff.p, W.voff.p, 8 * n, hipMemcpyDeviceToHost, q));
+            HIPCHK(hipMemcpyAsync(R.own_voff_end.p, W.voff_end.p, 8 * n, hipMemcpyDeviceToHost, q));
+        }
+    }
     HIPCHK(hipStreamSynchronize(q));
+    if (replay_bai && np1_batch_enable_replay_ingested(b, replay_bai, S.tid) != 0) return -1;
     b->input_bytes = b->G + 32 * n + 4 * (size_t)totals[1] + (size_t)totals[2];
     if (timing)
         fprintf(stderr, "[np1 ingest] %.1f MB compressed, %.1f MB inflated, %u blocks, %u segments, %llu records (%zu kept) | ms: h2d+inflate+count %.2f  offsets+measure+scans %.2f  scatter %.2f\n",

@@ -732,7 +732,8 @@ struct KcCand { int32_t num, mapqual, qual; };
 // rp (optional): what the replay of the reference's region iterator says this part gets (np1_replay.h): the records of the first loop
 // in order, the record left in the buffer, the passes of the second loop (n2 < 0: not known yet -- the call then returns 2 when
 // the first loop leaves no candidate, and is repeated with n2 set).  Without it: records in file order.
-struct KcReplay { const uint32_t* list; uint32_t n; int64_t stale; int32_t n2; };
+// brk (optional): receives how many records of the list the first loop consumed when it left through the max_count_kmer break, 0 = it did not.
+struct KcReplay { const uint32_t* list; uint32_t n; int64_t stale; int32_t n2; uint32_t* brk; };
 NP1_HD int32_t kc_part_winner(const KcCtx& c, uint32_t ctg, int32_t start, int32_t end, bool has_next_record,
                               uint8_t* winner, int32_t length, const KcReplay* rp = nullptr) {
     const uint32_t g0 = c.ctg_off[ctg];
@@ -787,16 +788,18 @@ NP1_HD int32_t kc_part_winner(const KcCtx& c, uint32_t ctg, int32_t start, int32
         }
     };
     if (rp) {
+        uint32_t consumed = 0;
         for (uint32_t t = 0; t < rp->n; ++t) {
             const int64_t r = (int64_t)rp->list[t];
             if (c.level[r] == 2) {
                 parse(r, &last_mapqual);
                 if (last_mapqual == 60) {
                     ++count;
-                    if (count >= c.max_count_kmer) break;
+                    if (count >= c.max_count_kmer) { consumed = t + 1; break; }
                 }
             }
         }
+        if (rp->brk) *rp->brk = consumed;
         if (ncand == 0) {
             if (rp->n2 < 0) return 2;
             if (rp->stale >= 0 && c.level[rp->stale] == 1)

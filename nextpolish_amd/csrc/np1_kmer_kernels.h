@@ -26,10 +26,11 @@ void kc_launch_split(hipStream_t st, const KcCtx& c, const uint32_t* kr_ctg, con
                      uint32_t* pt_len);
 void kc_launch_winner(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len,
                       const uint32_t* woff, uint32_t n_parts, int64_t n_all, uint8_t* wpool, uint8_t* has_winner);
-// the same vote on what the replayed region iterator hands out per part (np1_replay.h); rp_n2 == nullptr: first pass, has_winner 2 = needs the second loop
+// the same vote on what the replayed region iterator hands out per part (np1_replay.h); rp_n2 == nullptr: first pass, has_winner 2 = needs the second loop;
+// rp_brk (optional): per part, the number of records after which the first loop left through the max_count_kmer break (0 = it did not)
 void kc_launch_winner_replay(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len, const uint32_t* woff, uint32_t n_parts,
                              int64_t n_all, uint8_t* wpool, uint8_t* has_winner, const uint32_t* rp_first, const uint32_t* rp_list, const long long* rp_stale,
-                             const int32_t* rp_n2);
+                             const int32_t* rp_n2, uint32_t* rp_brk);
 void kc_launch_apply(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len,
                      const uint32_t* woff, uint32_t n_parts, const uint8_t* wpool, const uint8_t* has_winner);
 void kc_launch_result(hipStream_t st, const uint8_t* sbase, const uint8_t* sflag, uint32_t S, uint16_t* slot_res);

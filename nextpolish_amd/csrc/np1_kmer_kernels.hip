@@ -323,14 +323,18 @@ __global__ __launch_bounds__(64) void k_kc_winner(KcCtx c, const uint32_t* __res
                                                   uint32_t n_parts, int64_t n_all, uint8_t* __restrict__ wpool,
                                                   uint8_t* __restrict__ has_winner, uint32_t lanes, const uint32_t* __restrict__ rp_first,
                                                   const uint32_t* __restrict__ rp_list, const long long* __restrict__ rp_stale,
-                                                  const int32_t* __restrict__ rp_n2) {
+                                                  const int32_t* __restrict__ rp_n2, uint32_t* __restrict__ rp_brk) {
     const uint32_t p = blockIdx.x * lanes + threadIdx.x;   // `lanes` parts per wave (see k_kc_nodepth)
     if (threadIdx.x >= lanes || p >= n_parts) return;
     const uint32_t ct = pt_ctg[p];
-    if (ct == 0xffffffffu) { has_winner[p] = 0; return; }   // an unused slot of snp_valid's second round
+    if (ct & 0x80000000u) {   // a slot of snp_valid's second round that is unused (0xffffffff) or holds an inverted pair (contig | 1 << 31)
+        has_winner[p] = 0;
+        if (rp_brk) rp_brk[p] = 0;
+        return;
+    }
     const bool has_next = (int64_t)c.read_begin[ct + 1] < n_all;
     if (rp_first) {   // the records of this part as the replayed iterator hands them out (np1_replay.h); result 2 = second loop not known yet
-        const KcReplay rp{rp_list + rp_first[p], rp_first[p + 1] - rp_first[p], (int64_t)rp_stale[p], rp_n2 ? rp_n2[p] : -1};
+        const KcReplay rp{rp_list + rp_first[p], rp_first[p + 1] - rp_first[p], (int64_t)rp_stale[p], rp_n2 ? rp_n2[p] : -1, rp_brk ? rp_brk + p : nullptr};
         has_winner[p] = (uint8_t)kc_part_winner(c, ct, pt_se[2 * p], pt_se[2 * p + 1], has_next, wpool + woff[p], (int32_t)pt_len[p], &rp);
         return;
     }
@@ -427,10 +431,10 @@ __global__ __launch_bounds__(64) void k_sv_round2_parts(KcCtx c, uint32_t nc, co
     for (int32_t k = 0; k < n / 2; ++k) {
         const int32_t a = out[2 * k], b = out[2 * k + 1];
         const uint32_t q = v0 + (uint32_t)k;
-        if (a > b) continue;          // the slot stays unused (p2_ctg preset to 0xffffffff)
-        p2_ctg[q] = ct;
         p2_se[2 * q] = a;
         p2_se[2 * q + 1] = b;
+        if (a > b) { p2_ctg[q] = ct | 0x80000000u; continue; }   // an inverted pair: no votes (p2_len stays 0); the iterator replay still reads its end as the nextposend of the pair before
+        p2_ctg[q] = ct;
         p2_len[q] = c.soff[g0 + (uint32_t)b] - c.soff[g0 + (uint32_t)a] + 1;
     }
 }
@@ -496,13 +500,14 @@ void kc_launch_split(hipStream_t st, const KcCtx& c, const uint32_t* kr_ctg, con
 }
 void kc_launch_winner(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len,
                       const uint32_t* woff, uint32_t n_parts, int64_t n_all, uint8_t* wpool, uint8_t* has_winner) {
-    if (n_parts) k_kc_winner<<<kblk(n_parts, kc_lanes()), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, n_all, wpool, has_winner, kc_lanes(), nullptr, nullptr, nullptr, nullptr);
+    if (n_parts) k_kc_winner<<<kblk(n_parts, kc_lanes()), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, n_all, wpool, has_winner, kc_lanes(), nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 void kc_launch_winner_replay(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len, const uint32_t* woff, uint32_t n_parts,
                              int64_t n_all, uint8_t* wpool, uint8_t* has_winner, const uint32_t* rp_first, const uint32_t* rp_list, const long long* rp_stale,
-                             const int32_t* rp_n2) {
+                             const int32_t* rp_n2, uint32_t* rp_brk) {
     if (n_parts)
-        k_kc_winner<<<kblk(n_parts, kc_lanes()), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, n_all, wpool, has_winner, kc_lanes(), rp_first, rp_list, rp_stale, rp_n2);
+        k_kc_winner<<<kblk(n_parts, kc_lanes()), 64, 0, st>>>(c, pt_ctg, pt_se, pt_len, woff, n_parts, n_all, wpool, has_winner, kc_lanes(), rp_first, rp_list, rp_stale, rp_n2,
+                                                             rp_brk);
 }
 void kc_launch_apply(hipStream_t st, const KcCtx& c, const uint32_t* pt_ctg, const int32_t* pt_se, const uint32_t* pt_len,
                      const uint32_t* woff, uint32_t n_parts, const uint8_t* wpool, const uint8_t* has_winner) {

@@ -227,6 +227,10 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
     }
     const int n = (int)plan.size();
     const bool with_qual = task == 2 || task == 4;
+    // kmer_count / snp_valid follow the reference's region iterator (contig.c:982-1043) replayed on the BAM index and the records' virtual
+    // offsets (np1_replay.h), whichever way a batch is decoded; NP1_ITER_REPLAY=0: records in file order (no index: nothing to replay)
+    const char* rpl = getenv("NP1_ITER_REPLAY");
+    const bool replay = with_qual && src.have_bai && !(rpl && rpl[0] == '0');
     // NP1_INGEST=host: inflate and split the records on host threads (np_stream.cpp) instead of on the device (np1_ingest.hip)
     const char* ing = getenv("NP1_INGEST");
     const bool device_ingest = src.have_bai && !(ing && strcmp(ing, "host") == 0);
@@ -326,7 +330,7 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
             if (it.staging) {
                 if (!scratch[li]) scratch[li] = np1ingest::scratch_create();
                 d.names = it.staging->names();
-                rc = np1ingest::ingest(ln.batch, it.staging, with_qual, scratch[li]);
+                rc = np1ingest::ingest(ln.batch, it.staging, with_qual, scratch[li], replay ? &src.bai : nullptr);
                 {
                     std::lock_guard<std::mutex> g(mu);
                     free_staging.push_back(it.staging);
@@ -343,10 +347,8 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
                 d.names.clear();
                 for (int64_t c = 0; c < v.n_contigs; ++c) d.names.push_back(np1_stream_contig_name(it.stream, c));
                 rc = np1_batch_reload(ln.batch, it.stream);
-                // the host loader keeps the records' virtual offsets: kmer_count can replay the reference's region iterator (DESIGN.md
-                // section 3); batches that come through the device-side ingest have no host view of the records and take them in file order
-                const char* e = getenv("NP1_ITER_REPLAY");
-                if (rc == 0 && task == 2 && src.have_bai && !(e && e[0] == '0') && np1_batch_enable_replay(ln.batch, it.stream, bam) != 0) rc = -1;
+                // the host loader keeps the records' virtual offsets, the device-side ingest brings them down: both replay the iterator
+                if (rc == 0 && replay && np1_batch_enable_replay(ln.batch, it.stream, bam) != 0) rc = -1;
             }
             t_p1 = now_ms();
             if (rc == 0) rc = run_task(ln.batch, cfg, task);
@@ -434,7 +436,8 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
     auto stage = [&](int k) -> Item {   // host half of batch k
         Item it;
         const double t0 = now_ms();
-        std::thread lr_thread([&] { it.lr = load_host(k, bam_lr); if (!it.lr) it.err = np1_last_error(); });
+        std::string lr_err;                // the long-read thread's own error string (merged after the join)
+        std::thread lr_thread([&] { it.lr = load_host(k, bam_lr); if (!it.lr) lr_err = np1_last_error(); });
         if (device_ingest) {
             np1ingest::Staging* sg = p->staging[(size_t)k % 2];
             std::string e;
@@ -447,6 +450,7 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
             if (!it.sr) it.err = np1_last_error();
         }
         lr_thread.join();
+        if (it.err.empty()) it.err = lr_err;
         if (timing_on()) fprintf(stderr, "[np1 phase] batch %d staged on the host in %.1f ms (short reads: %s)\n", k, now_ms() - t0, it.staging ? "compressed blocks" : "host loader");
         return it;
     };

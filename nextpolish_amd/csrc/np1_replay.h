@@ -204,21 +204,32 @@ private:
     int64_t buffer_ = -1;
 };
 
-// First loop of every part of one contig (kmercount.c:196-207), the max_count_kmer break left aside (it cuts a part's list short on
-// the device; what it leaves of the iterator's chunk position is not tracked): per part the records the loop gets, in order, and the
-// record left in the buffer.  part_se: (start, end) pairs in list order; next_end[p] = the end the reference passes as nextposend.
+// First loop of every part of one contig (kmercount.c:196-207): per part the records the loop gets, in order, and the record left in
+// the buffer.  part_se: (start, end) pairs in list order; next_end[p] = the end the reference passes as nextposend.
+// limit (optional): limit[p] > 0 = the loop of part p leaves through the max_count_kmer break (kmercount.c:201-203) after that many
+// records -- the iterator then keeps the chunk position, the saved offset and the buffered record of that moment, and the next part
+// that re-uses it resumes from there (which records count towards the break is decided by the votes: the device reports it,
+// np1_device.hip:replay_votes).  skip[p] != 0: the pair is not iterated at all.
 struct FirstLoop {
     std::vector<uint32_t> first;   // n_parts + 1 offsets into list
     std::vector<uint32_t> list;    // local record indices
     std::vector<int64_t> stale;    // per part: local record index, -1 none, -2 another contig's record
 };
-inline FirstLoop first_loop(const RefIndex& ix, const Records& rec, const int32_t* part_se, const int32_t* next_end, uint32_t n_parts) {
+inline FirstLoop first_loop(const RefIndex& ix, const Records& rec, const int32_t* part_se, const int32_t* next_end, uint32_t n_parts,
+                            const uint32_t* limit = nullptr, const uint8_t* skip = nullptr) {
     FirstLoop o;
     Scanner sc(ix, rec);
     o.first.push_back(0);
     for (uint32_t p = 0; p < n_parts; ++p) {
-        sc.begin(part_se[2 * p], part_se[2 * p + 1], next_end[p]);
-        for (int64_t k; (k = sc.next()) >= 0;) o.list.push_back((uint32_t)k);
+        if (!(skip && skip[p])) {
+            const uint32_t lim = limit ? limit[p] : 0;
+            uint32_t got = 0;
+            sc.begin(part_se[2 * p], part_se[2 * p + 1], next_end[p]);
+            for (int64_t k; (k = sc.next()) >= 0;) {
+                o.list.push_back((uint32_t)k);
+                if (++got == lim) break;
+            }
+        }
         o.first.push_back((uint32_t)o.list.size());
         o.stale.push_back(sc.buffer());
     }
@@ -230,7 +241,7 @@ inline std::vector<uint32_t> second_loop_passes(const RefIndex& ix, const Record
     std::vector<uint32_t> n2(n_parts, 0);
     Scanner sc(ix, rec);
     for (uint32_t p = 0; p < n_parts; ++p) {
-        if (!empty[p]) continue;
+        if (!empty[p]) continue;    // (a skipped pair is never `empty`)
         sc.begin(part_se[2 * p], part_se[2 * p + 1], next_end[p]);
         while (sc.next() >= 0) ++n2[p];
     }

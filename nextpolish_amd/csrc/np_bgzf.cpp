@@ -109,7 +109,7 @@ bool BgzfReader::fill_window(uint64_t coff) {
     }
     if (win_.empty()) return got == 0 || got < 18 ? (got == 0) : false;   // clean EOF only when nothing is left
     uwin_.resize(utotal + 8);
-    if (g_batch_fn && win_.size() >= 64) {     // enough blocks to fill a device: one launch for the whole window (no CRC pass here)
+    if (g_batch_fn && win_.size() >= 64) {     // enough blocks to fill a device: one launch for the whole window (the hook checks the CRCs itself: np_bgzf_dev.hip)
         std::vector<BgzfBatchBlock> bb(win_.size());
         for (size_t i = 0; i < win_.size(); ++i) {
             const WinBlock& b = win_[i];

@@ -12,6 +12,8 @@
 
 #include "np_bgzf.h"
 #include "np_inflate_dev.h"
+#include "np_crc_dev.h"
+#include "np_crc32.h"
 
 namespace {
 
@@ -27,10 +29,16 @@ __global__ __launch_bounds__(256, 4) void k_bgzf_inflate(const uint8_t* __restri
     if ((threadIdx.x & 63u) == 0) status[b] = (uint32_t)rc;
 }
 
+// gzip trailer CRC of the blocks the decoder accepted (np_crc_dev.h), like the host reader and the reference's htslib check it
+__global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+                                                  const uint8_t* __restrict__ out, uint32_t* __restrict__ status, const uint32_t* __restrict__ shift) {
+    npdev::crc_check_body(comp, blocks, n_blocks, out, status, shift);
+}
+
 struct DevInflater {
     int device = -1;
     hipStream_t q = nullptr;
-    void *d_comp = nullptr, *d_out = nullptr, *d_blocks = nullptr, *d_status = nullptr;
+    void *d_comp = nullptr, *d_out = nullptr, *d_blocks = nullptr, *d_status = nullptr, *d_shift = nullptr;
     size_t c_comp = 0, c_out = 0, c_blocks = 0;
     std::vector<uint32_t> status;
     std::mutex mu;
@@ -55,30 +63,54 @@ struct DevInflater {
         if (!grow(&d_comp, &c_comp, comp_len + 4096, false) || !grow(&d_out, &c_out, out_len + 4096, false) ||
             !grow(&d_blocks, &cb, sizeof(npdev::BlockDesc) * n + 64, false))
             return false;
-        if (cb != c_blocks) {       // the status words follow the block table's size
-            c_blocks = cb;
+        if (cb != c_blocks || !d_status) {       // the status words follow the block table's size
             if (d_status) (void)hipFree(d_status);
             d_status = nullptr;
-            if (hipMalloc(&d_status, c_blocks / sizeof(npdev::BlockDesc) * 4 + 64) != hipSuccess) return false;
+            c_blocks = 0;                        // (stays 0 if the allocation fails: the next batch allocates again instead of launching on a null pointer)
+            if (hipMalloc(&d_status, cb / sizeof(npdev::BlockDesc) * 4 + 64) != hipSuccess) { d_status = nullptr; return false; }
+            c_blocks = cb;
+        }
+        static const bool check_crc = getenv("NP_BGZF_NO_CRC") == nullptr;
+        if (check_crc && !d_shift) {
+            uint32_t t[64];
+            npdev::crc_shift_table(t);
+            if (hipMalloc(&d_shift, sizeof(t)) != hipSuccess) { d_shift = nullptr; return false; }
+            if (hipMemcpy(d_shift, t, sizeof(t), hipMemcpyHostToDevice) != hipSuccess) return false;
         }
         static thread_local std::vector<npdev::BlockDesc> desc;
         desc.resize(n);
         for (size_t i = 0; i < n; ++i) desc[i] = npdev::BlockDesc{bl[i].in_off, bl[i].out_off, bl[i].in_len, bl[i].out_len};
         status.resize(n);
-        // straight from / into the reader's own (pageable) windows: the runtime stages them, no copy of ours in between
-        if (hipMemcpyAsync(d_comp, comp, comp_len, hipMemcpyHostToDevice, q) != hipSuccess) return false;
-        if (hipMemsetAsync((char*)d_comp + comp_len, 0, 4096, q) != hipSuccess) return false;
-        if (hipMemcpyAsync(d_blocks, desc.data(), sizeof(npdev::BlockDesc) * n, hipMemcpyHostToDevice, q) != hipSuccess) return false;
-        k_bgzf_inflate<<<(unsigned)((n + 3) / 4), 256, 0, q>>>((const uint8_t*)d_comp, (const npdev::BlockDesc*)d_blocks, (uint32_t)n, (uint8_t*)d_out, (uint32_t*)d_status);
-        if (hipMemcpyAsync(out, d_out, out_len, hipMemcpyDeviceToHost, q) != hipSuccess) return false;
-        if (hipMemcpyAsync(status.data(), d_status, 4 * n, hipMemcpyDeviceToHost, q) != hipSuccess) return false;
-        if (hipStreamSynchronize(q) != hipSuccess) return false;
+        // straight from / into the reader's own (pageable) windows: the runtime stages them, no copy of ours in between.  Once anything
+        // is enqueued every way out waits for the stream first: the caller inflates into the same `out` window on its host threads
+        // when this returns false
+        bool ok = hipMemcpyAsync(d_comp, comp, comp_len, hipMemcpyHostToDevice, q) == hipSuccess &&
+                  hipMemsetAsync((char*)d_comp + comp_len, 0, 4096, q) == hipSuccess &&
+                  hipMemcpyAsync(d_blocks, desc.data(), sizeof(npdev::BlockDesc) * n, hipMemcpyHostToDevice, q) == hipSuccess;
+        if (ok) {
+            k_bgzf_inflate<<<(unsigned)((n + 3) / 4), 256, 0, q>>>((const uint8_t*)d_comp, (const npdev::BlockDesc*)d_blocks, (uint32_t)n, (uint8_t*)d_out, (uint32_t*)d_status);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        if (ok && check_crc) {
+            k_bgzf_crc<<<(unsigned)((n + 3) / 4), 256, 0, q>>>((const uint8_t*)d_comp, (const npdev::BlockDesc*)d_blocks, (uint32_t)n, (const uint8_t*)d_out, (uint32_t*)d_status,
+                                                               (const uint32_t*)d_shift);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        ok = ok && hipMemcpyAsync(out, d_out, out_len, hipMemcpyDeviceToHost, q) == hipSuccess;
+        ok = ok && hipMemcpyAsync(status.data(), d_status, 4 * n, hipMemcpyDeviceToHost, q) == hipSuccess;
+        const bool synced = hipStreamSynchronize(q) == hipSuccess;
+        if (!ok || !synced) return false;
         ++n_batches;
         n_blocks += n;
         for (size_t i = 0; i < n; ++i) {
             if (!status[i]) continue;
-            ++n_host_blocks;
+            ++n_host_blocks;          // refused by the device decoder, or its CRC differs: the host decoder has the last word
             if (!np::bgzf_inflate_block(comp + bl[i].in_off, bl[i].in_len, out + bl[i].out_off, bl[i].out_len)) return false;
+            if (check_crc && bl[i].out_len) {
+                uint32_t want;
+                memcpy(&want, comp + bl[i].in_off + bl[i].in_len, 4);
+                if (np::crc32_block(out + bl[i].out_off, bl[i].out_len) != want) return false;   // the reader's own pass then fails on the same block
+            }
         }
         return true;
     }

@@ -401,6 +401,8 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
     return 0;
 }
 
+// diagnostics: vote rounds the max_count_kmer break made necessary (replay of the region iterator) since the library was loaded
+unsigned long long np1m_replay_revotes = 0, np1m_replay_breaks = 0;
 // kmer_count through the per-region bodies of np1_kmer.h, driven sequentially (the GPU runs one lane per region)
 // what the iterator replay needs besides the stream (np1_replay.h): the BAI, the BAM tid of every contig, the records' virtual offsets
 struct ModelGeometry { const np::BaiIndex* bai; const int32_t* tid; const uint64_t* voff; const uint64_t* voff_end; };
@@ -500,9 +502,65 @@ static int kmer_model(const np1_stream_view* v, const Configure* cfg, char** out
     for (uint32_t ct = 0; ct < nc; ++ct) {
         const uint32_t g0 = v->ctg_off[ct];
         const bool has_next = (int64_t)v->read_begin[ct + 1] < n;
-        if (geo && !snp_valid) {
-            // the way the device pass would do it with the replay: all parts of the contig, the first loop of every part from the
-            // replayed iterator, winners kept aside; second-loop passes for the parts left empty; then the writes in part order
+        if (geo) {
+            // the way the device pass does it with the replay (np1_device.hip:replay_votes): all parts of the contig, the first loop of every
+            // part from the replayed iterator, winners kept aside; the replay again wherever a loop left through the max_count_kmer break;
+            // second-loop passes for the parts left empty; then the writes in part order.  snp_valid: both rounds that way.
+            const int tid = geo->tid[ct];
+            if (tid < 0 || (size_t)tid >= geo->bai->refs.size()) return -30;
+            const np1replay::RefIndex ix(geo->bai->refs[(size_t)tid]);
+            const int64_t rb = (int64_t)v->read_begin[ct], re = (int64_t)v->read_begin[ct + 1];
+            const np1replay::Records rec{geo->voff + rb, geo->voff_end + rb, v->pos + rb, endpos.data() + rb, re - rb, has_next, (int32_t)(v->ctg_off[ct + 1] - g0)};
+            std::vector<std::vector<uint8_t>> wins;
+            std::vector<uint8_t> state;
+            auto replay_votes = [&](const std::vector<int32_t>& pse, const std::vector<uint8_t>& skip) -> int {
+                const uint32_t n_parts = (uint32_t)(pse.size() / 2);
+                std::vector<int32_t> next_end(n_parts, -1);
+                for (uint32_t p = 0; p + 1 < n_parts; ++p) next_end[p] = pse[2 * (p + 1) + 1];
+                wins.assign(n_parts, {});
+                state.assign(n_parts, 0);
+                std::vector<uint32_t> brk(n_parts, 0), limit(n_parts, 0);
+                const std::vector<uint8_t> snap(sflag);
+                np1replay::FirstLoop fl, nx;
+                auto vote = [&](uint32_t p, int32_t n2) {
+                    if (skip[p]) { brk[p] = 0; return 0; }
+                    const int32_t ps = pse[2 * p], pe = pse[2 * p + 1];
+                    const int32_t length = (int32_t)(soff[g0 + pe] - soff[g0 + ps] + 1);
+                    wins[p].assign((size_t)length, 0);
+                    hcount = 0;
+                    std::vector<uint32_t> glist(fl.list.begin() + fl.first[p], fl.list.begin() + fl.first[p + 1]);
+                    for (uint32_t& x : glist) x += (uint32_t)rb;
+                    uint32_t bk = 0;
+                    const KcReplay rp{glist.data(), (uint32_t)glist.size(), fl.stale[p] >= 0 ? fl.stale[p] + rb : -1, n2, n2 < 0 ? &bk : nullptr};
+                    const int32_t st = kc_part_winner(c, ct, ps, pe, has_next, wins[p].data(), length, &rp);
+                    if (n2 < 0) brk[p] = bk;
+                    return (int)st;
+                };
+                fl = np1replay::first_loop(ix, rec, pse.data(), next_end.data(), n_parts, limit.data(), skip.data());
+                for (uint32_t p = 0; p < n_parts; ++p) state[p] = (uint8_t)vote(p, -1);
+                for (uint32_t x : brk) np1m_replay_breaks += x != 0;
+                for (int it = 0; brk != limit; ++it) {
+                    if (it > 256) return -32;
+                    limit = brk;
+                    nx = np1replay::first_loop(ix, rec, pse.data(), next_end.data(), n_parts, limit.data(), skip.data());
+                    bool same = true;
+                    for (uint32_t p = 0; p < n_parts && same; ++p) {
+                        const uint32_t n_old = fl.first[p + 1] - fl.first[p], n_new = nx.first[p + 1] - nx.first[p], n_cmp = brk[p] ? brk[p] : n_old;
+                        same = n_new == n_cmp && n_cmp <= n_old && std::equal(nx.list.begin() + nx.first[p], nx.list.begin() + nx.first[p + 1], fl.list.begin() + fl.first[p]) &&
+                               (state[p] != 2 || nx.stale[p] == fl.stale[p]);
+                    }
+                    fl = nx;
+                    if (same) break;
+                    if (!c.keep_zero_marks) sflag = snap;
+                    ++np1m_replay_revotes;
+                    for (uint32_t p = 0; p < n_parts; ++p) state[p] = (uint8_t)vote(p, -1);
+                }
+                std::vector<uint8_t> empty(n_parts, 0);
+                for (uint32_t p = 0; p < n_parts; ++p) empty[p] = state[p] == 2;
+                const std::vector<uint32_t> n2 = np1replay::second_loop_passes(ix, rec, pse.data(), next_end.data(), n_parts, empty.data());
+                for (uint32_t p = 0; p < n_parts; ++p) if (empty[p]) state[p] = (uint8_t)vote(p, (int32_t)n2[p]);
+                return 0;
+            };
             std::vector<int32_t> pse;
             for (size_t i = 0; i + 1 < kreg[ct].size(); i += 2) {
                 std::vector<int32_t> parts(2 * (size_t)(kreg[ct][i + 1] - kreg[ct][i] + 4));
@@ -512,34 +570,36 @@ static int kmer_model(const np1_stream_view* v, const Configure* cfg, char** out
             }
             const uint32_t n_parts = (uint32_t)(pse.size() / 2);
             if (!n_parts) continue;
-            const int tid = geo->tid[ct];
-            if (tid < 0 || (size_t)tid >= geo->bai->refs.size()) return -30;
-            const np1replay::RefIndex ix(geo->bai->refs[(size_t)tid]);
-            const int64_t rb = (int64_t)v->read_begin[ct], re = (int64_t)v->read_begin[ct + 1];
-            const np1replay::Records rec{geo->voff + rb, geo->voff_end + rb, v->pos + rb, endpos.data() + rb, re - rb, has_next, (int32_t)(v->ctg_off[ct + 1] - g0)};
-            std::vector<int32_t> next_end(n_parts);
-            for (uint32_t p = 0; p < n_parts; ++p) next_end[p] = p + 1 < n_parts ? pse[2 * (p + 1) + 1] : -1;
-            const np1replay::FirstLoop fl = np1replay::first_loop(ix, rec, pse.data(), next_end.data(), n_parts);
-            std::vector<uint32_t> glist(fl.list.size());
-            for (size_t t = 0; t < glist.size(); ++t) glist[t] = fl.list[t] + (uint32_t)rb;
-            std::vector<std::vector<uint8_t>> wins(n_parts);
-            std::vector<uint8_t> state(n_parts, 0), empty(n_parts, 0);
-            auto vote = [&](uint32_t p, int32_t n2) {
-                const int32_t ps = pse[2 * p], pe = pse[2 * p + 1];
-                const int32_t length = (int32_t)(soff[g0 + pe] - soff[g0 + ps] + 1);
-                wins[p].assign((size_t)length, 0);
-                hcount = 0;
-                const KcReplay rp{glist.data() + fl.first[p], fl.first[p + 1] - fl.first[p], fl.stale[p] >= 0 ? fl.stale[p] + rb : -1, n2};
-                return kc_part_winner(c, ct, ps, pe, has_next, wins[p].data(), length, &rp);
-            };
-            for (uint32_t p = 0; p < n_parts; ++p) { state[p] = (uint8_t)vote(p, -1); empty[p] = state[p] == 2; }
-            const std::vector<uint32_t> n2 = np1replay::second_loop_passes(ix, rec, pse.data(), next_end.data(), n_parts, empty.data());
-            for (uint32_t p = 0; p < n_parts; ++p) if (empty[p]) state[p] = (uint8_t)vote(p, (int32_t)n2[p]);
-            for (uint32_t p = 0; p < n_parts; ++p)
+            { const int rc = replay_votes(pse, std::vector<uint8_t>(n_parts, 0)); if (rc) return rc; }
+            std::vector<int32_t> failed;
+            for (uint32_t p = 0; p < n_parts; ++p) {
                 if (state[p] == 1) {
                     const uint32_t s0 = soff[g0 + pse[2 * p]];
-                    for (size_t t = 0; t < wins[p].size(); ++t) sbase[s0 + t] = wins[p][t];
+                    for (size_t t = 0; t < wins[p].size(); ++t) {
+                        if (snp_valid) sflag[s0 + t] = (uint8_t)(sflag[s0 + t] & ~KC_FLAG_ZERO);
+                        sbase[s0 + t] = wins[p][t];
+                    }
+                } else if (snp_valid) {
+                    failed.push_back(pse[2 * p]); failed.push_back(pse[2 * p + 1]);
                 }
+            }
+            if (snp_valid && !failed.empty()) {
+                std::vector<int32_t> val(pse.size() * 2 + 4 * (size_t)(v->ctg_off[ct + 1] - g0) + 16);
+                int32_t nv = 0;
+                for (size_t k = 0; k + 1 < failed.size() && nv >= 0; k += 2) nv = kc_fts_split(c, ct, failed[k], failed[k + 1], val.data(), nv, (int32_t)val.size() - 1);
+                if (nv < 0) return -13;
+                if (nv & 1) { val[(size_t)nv] = (size_t)nv < pse.size() ? pse[(size_t)nv] : 0; ++nv; }
+                val.resize((size_t)nv);
+                std::vector<uint8_t> skip((size_t)nv / 2, 0);
+                for (int32_t k = 0; k + 1 < nv; k += 2) skip[(size_t)k / 2] = val[(size_t)k] > val[(size_t)k + 1];
+                const int rc = replay_votes(val, skip);      // (round 2 has flagzero = 0 upstream; the marks no longer matter: emitted with mask 0)
+                if (rc) return rc;
+                for (uint32_t p = 0; p < (uint32_t)nv / 2; ++p)
+                    if (!skip[p] && state[p] == 1) {
+                        const uint32_t s0 = soff[g0 + val[2 * p]];
+                        for (size_t t = 0; t < wins[p].size(); ++t) sbase[s0 + t] = wins[p][t];
+                    }
+            }
             continue;
         }
         std::vector<int32_t> all_parts, failed;     // snp_valid: the contig's part list (flat) and the parts nothing spanned
@@ -609,6 +669,17 @@ int np1m_kmer_count_replay(const np1_stream_view* v, const Configure* cfg, const
     const ModelGeometry geo{&bai, tid, voff, voff_end};
     return kmer_model(v, cfg, out, bounds, false, &geo);
 }
+
+// task 4 the same way (both rounds of snp_valid on the replayed iterator)
+int np1m_snp_valid_replay(const np1_stream_view* v, const Configure* cfg, const char* bai_path, const int32_t* tid, const uint64_t* voff, const uint64_t* voff_end,
+                          char** out, uint32_t* bounds) {
+    np::BaiIndex bai;
+    if (!bai.load(bai_path)) return -31;
+    const ModelGeometry geo{&bai, tid, voff, voff_end};
+    return kmer_model(v, cfg, out, bounds, true, &geo);
+}
+unsigned long long np1m_replay_revote_count() { return np1m_replay_revotes; }
+unsigned long long np1m_replay_break_count() { return np1m_replay_breaks; }
 
 void np1m_free(void* p) { free(p); }
 

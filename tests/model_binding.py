@@ -26,6 +26,10 @@ def lib():
         L.np1m_kmer_count_replay.argtypes = [C.POINTER(nat.StreamView), C.POINTER(nat.Configure), C.c_char_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         L.np1m_kmer_count_replay.restype = C.c_int
+        L.np1m_snp_valid_replay.argtypes = L.np1m_kmer_count_replay.argtypes
+        L.np1m_snp_valid_replay.restype = C.c_int
+        L.np1m_replay_revote_count.restype = C.c_ulonglong
+        L.np1m_replay_break_count.restype = C.c_ulonglong
         _LIB = L
     return _LIB
 
@@ -90,18 +94,39 @@ def snp_phase(sr, lr, cfg):
     return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(sr.n_contigs)]
 
 
-def kmer_count_replay(stream, cfg, bam):
+ERR_KC_UNDEFINED = 512     # np1_kmer.h: an input the reference has no defined result for
+
+
+def replay_revotes():
+    """vote rounds the max_count_kmer break made necessary in the replay models since the library was loaded"""
+    return int(lib().np1m_replay_revote_count())
+
+
+def replay_breaks():
+    """parts whose first loop left through the max_count_kmer break in the replay models since the library was loaded"""
+    return int(lib().np1m_replay_break_count())
+
+
+def snp_valid_replay(stream, cfg, bam):
+    """task 4 the same way: both rounds of snp_valid on the replayed iterator (None: undefined upstream)"""
+    return kmer_count_replay(stream, cfg, bam, fn="np1m_snp_valid_replay")
+
+
+def kmer_count_replay(stream, cfg, bam, fn="np1m_kmer_count_replay"):
     """kmer_count with the region iterator of the reference replayed on the host (np1_replay.h: chunk lists of the BAM index, re-use,
-    saved offsets) feeding kc_part_winner: `stream` must have been read from `bam` (it carries the records' virtual offsets)."""
+    saved offsets, the max_count_kmer break) feeding kc_part_winner: `stream` must have been read from `bam` (it carries the records'
+    virtual offsets)."""
     import oracle_binding as ob
     names = ob.bam_reference_names(bam)
     tid = (C.c_int32 * stream.n_contigs)(*[names.index(n) if n in names else -1 for n in stream.names])
     vb, ve = stream.voffs()
     out = C.c_void_p()
     bounds = (C.c_uint32 * (stream.n_contigs + 1))()
-    rc = lib().np1m_kmer_count_replay(C.byref(stream.view), C.byref(cfg), (bam + ".bai").encode(), tid, vb.ctypes.data, ve.ctypes.data, C.byref(out), bounds)
+    rc = getattr(lib(), fn)(C.byref(stream.view), C.byref(cfg), (bam + ".bai").encode(), tid, vb.ctypes.data, ve.ctypes.data, C.byref(out), bounds)
+    if rc == ERR_KC_UNDEFINED:
+        return None
     if rc != 0:
-        raise RuntimeError("kmer_count replay model failed rc=%d" % rc)
+        raise RuntimeError("%s failed rc=%d" % (fn, rc))
     blob = C.string_at(out, bounds[stream.n_contigs])
     lib().np1m_free(out)
     return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)]

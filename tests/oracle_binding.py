@@ -206,6 +206,18 @@ def snp_valid(stream, i, cfg, geometry=None):
     return _run(lib().np1o_snp_valid, stream, i, cfg, geometry)
 
 
+def from_files(task, fa, bam, cfg, names=None):
+    """kmer_count / snp_valid of contigs read from FASTA + BAM (+ .bai) the way the reference meets them: the region iterator replayed
+    on the index and the records' virtual offsets (Geometry).  task: "kmer_count" or "snp_valid"; returns {name: string or None}."""
+    from nextpolish_amd import _native as nat
+    st = nat.Stream.load(fa, bam, names=names, with_qual=True)
+    geom = Geometry(st, bam)
+    fn = {"kmer_count": kmer_count, "snp_valid": snp_valid}[task]
+    out = {n: fn(st, i, cfg, geom) for i, n in enumerate(st.names)}
+    st.close()
+    return out
+
+
 def snp_phase(sr, lr, i, cfg):
     """task 3: contig i of the short-read stream `sr` and of the long-read stream `lr` (same drafts, both with qualities);
     None where the reference's own result is undefined"""

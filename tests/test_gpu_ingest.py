@@ -157,7 +157,8 @@ def test_device_ingest_equals_host_loader_and_oracle(tmp_path):
     cfg = nat.default_config()
     cfg.read_tlen = 1500
     want1 = [ob.score_chain(st, i) for i in range(st.n_contigs)]
-    want2 = [ob.kmer_count(st, i, ob.default_config(read_tlen=1500)) for i in range(st.n_contigs)]
+    w2 = ob.from_files("kmer_count", fa, bam, ob.default_config(read_tlen=1500))     # the oracle with the region iterator replayed, like every file-based product path
+    want2 = [w2[n] for n in st.names]
     for batch_bp in (50000, 1000, 10000000):
         dev = _run_files(pipe, fa, bam, None, batch_bp=batch_bp)
         assert [n for n, _ in dev] == st.names and [s for _, s in dev] == want1, "device ingest, batch_bp %d" % batch_bp
@@ -210,3 +211,33 @@ def test_device_ingest_on_real_bwa_bam_and_edge_records(tmp_path):
         ref = run_ref("scorechain", fa, bam)
         assert [ref[n] for n in loaded.names] == want
     pipe.close()
+
+
+def test_corrupt_block_is_rejected_like_htslib_does(tmp_path):
+    """A BGZF block whose payload was damaged but still inflates to ISIZE bytes (stored blocks, one byte flipped): the reference's htslib
+    rejects it by its gzip trailer CRC (bgzf.c), the host reader does (np_bgzf.cpp) and so does the device-side ingest (np_crc_dev.h:
+    k_crc_check marks the block, the host decoder has the last word).  NP_BGZF_NO_CRC=1 switches the check off on both paths."""
+    import subprocess
+    st = nat.Stream.synth([140000, 12000], depth=30, seed=5151)     # 30 000 records: the damaged block lies behind the 10 000 the insert-size probe reads on the host
+    fa, bam = str(tmp_path / "c.fa"), str(tmp_path / "c.bam")
+    st.write_files(fa, bam, 0)          # level 0: stored blocks
+    data = bytearray(open(bam, "rb").read())
+    blocks, p = [], 0
+    while p + 18 <= len(data):
+        bsize = (data[p + 16] | data[p + 17] << 8) + 1
+        blocks.append((p, bsize))
+        p += bsize
+    p, bsize = blocks[len(blocks) * 4 // 5]
+    assert data[p + 18] & 6 == 0 and bsize > 4000          # a stored deflate block
+    data[p + 18 + 5 + 2000] ^= 0x10
+    open(bam, "wb").write(bytes(data))
+    exe = os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1")
+    env = {k: v for k, v in os.environ.items() if k not in ("NP1_INGEST", "NP_BGZF_NO_CRC")}
+    for ingest in ("device", "host"):
+        e = dict(env, NP1_INGEST="host") if ingest == "host" else env
+        r = subprocess.run([exe, "scorechain", fa, bam], capture_output=True, text=True, env=e)
+        assert r.returncode != 0, ingest
+        if ingest == "device":
+            assert "CRC" in r.stderr, r.stderr
+    r = subprocess.run([exe, "scorechain", fa, bam], capture_output=True, text=True, env=dict(env, NP_BGZF_NO_CRC="1"))
+    assert r.returncode == 0 or "CRC" not in r.stderr      # without the check the damaged byte is just a base or a quality (or a broken record chain)

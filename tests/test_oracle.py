@@ -121,6 +121,17 @@ def thin_multiwindow_stream(seed):
     return st, rng.choice([1, 6])
 
 
+def deep_multiwindow_stream(seed):
+    """contigs of one to three 16 kb windows at 80-250x: more than max_count_kmer spanning mapq-60 records per part, so the first loop
+    of kmercount.c:196-207 leaves through its break and a re-used iterator resumes from where the break left it"""
+    import random
+    rng = random.Random(seed)
+    lens = [rng.choice([17000, 24000, 36000]), rng.choice([2500, 16500])]
+    st = nat.Stream.synth(lens, depth=rng.choice([80, 120, 250]), seed=seed, with_qual=1, weird_rate=0.02, softclip_rate=0.05, draft_lower=rng.choice([0.01, 0.05, 0.2]),
+                          read_indel=rng.choice([0.001, 0.01]), lowmapq_rate=rng.choice([0.02, 0.3]), supp_rate=0.01, sec_rate=0.01, unmapped_rate=0.01)
+    return st, rng.choice([1, 6])
+
+
 @needs_ref
 def test_iterator_replay_reproduces_the_reference_where_file_order_does_not(tmp_path):
     """kmer_count / snp_valid with the records' virtual offsets and the BAI handed to the oracle (oracle_binding.Geometry): the
