@@ -1,18 +1,19 @@
 #!/usr/bin/env python
-"""Headline benchmark: short-read score_chain polishing throughput (BASELINE.json metric) on the metric's 30x shape.
+"""Headline benchmark: short-read score_chain polishing throughput (BASELINE.json metric) on the metric's own configuration.
 
-Workload (default c3_100mb_30x = BASELINE.json configs[2], the largest 30x draft that is generated and polished within the
-default run's budget; c5_3gb_30x is the metric's own 3 Gb shape for manual runs): a FIXED synthetic draft (contig lengths
-log-uniform in [50 kb, 5 Mb]) + 30x simulated 2x150 bp PE reads.  The contigs are dealt longest-first over the
-N ranks (contigs are independent units: strong scaling of one fixed draft, no data-path collective; reference:
-source/lib/nextpolish1.py:181-189,223-224) and packed into HBM batches of <= 13 Mb.
+Workload (default c5_3gb_30x = the configuration BASELINE.json's metric is quoted on: a 3 Gb human-scale draft at 30x; it fits one
+MI355X): a FIXED synthetic draft (contig lengths log-uniform) + 30x simulated 2x150 bp PE reads = 600 M records.
+The contigs are dealt longest-first over the N ranks (contigs are independent units: strong scaling of one fixed draft, no
+data-path collective; reference: source/lib/nextpolish1.py:181-189,223-224) and packed into batches of <= 260 Mb.
 
-One "step" = one full score_chain pass (every kernel of np1_device.hip's launch sequence) over the WHOLE draft, i.e. over all
-of the rank's batches, the batches already resident in HBM (`value`, the contract's scope); two device lanes keep two batches
-in flight so the host-side syncs of one hide behind the kernels of the other.  Beside it, in the same JSON line:
-  streamed          pinned host arrays -> async H2D -> kernels -> D2H of the polished strings, double-buffered on the device
-                    lanes, everything inside the timed region (SURVEY.md 8d timing scope 1)
-  e2e_from_files    FASTA + sorted BAM on disk (page cache) -> polished FASTA, cold process of the CLI (scope 2), N=1 only
+One "step" = one full score_chain pass over the WHOLE draft in SURVEY.md 8d's timing scope 1: the decoded record stream in pinned
+host memory -> async H2D -> every kernel of np1_device.hip's launch sequence -> D2H of the polished strings, double-buffered on
+the device lanes, all inside the timed region (`value`).  Beside it, in the same JSON line:
+  resident          the same pass with the batches already resident in HBM (no PCIe inside): what the kernels alone sustain
+  e2e_from_files    FASTA + sorted BAM on disk (page cache) -> polished FASTA at the full size, on a BAM with Illumina-like binned
+                    base qualities: cold process of the CLI and a warm process (scope 2); the BAM's bytes per record; on a one-batch
+                    slice the same with no qualities (9:1) and with incompressible ones
+  parity            contigs of this very run compared with the CPU oracle (md5 of the polished strings)
   roofline          dominant kernel: algorithmic bytes per launch / HIP-event time per launch vs the 8 TB/s HBM peak, and
                     the PMC traffic per launch (two rocprofv3 --pmc passes)
   cpu_baseline      the compiled reference (oracle/_ref/nextpolish1) on this box's host cores, one process per core like -p N,
@@ -140,14 +141,15 @@ def pmc_traffic(args, kernel_substr):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         try:
             rows = rocprof_counter([sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload,
-                                    "--steps", "1", "--warmup", "0"], ctr)
+                                    "--steps", "1", "--warmup", "0", "--pmc-batches", str(args.pmc_batches)], ctr)
             hit = [v for k, v in rows.items() if kernel_substr in k]
             vals[ctr] = sum(a * n for a, n in hit) / max(1, sum(n for _a, n in hit))
         except Exception as e:   # profiling is best effort: the bench line stays valid without it
             return None, "pmc pass failed: %r" % (e,)
     fetch_b, write_b = vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
     return {"bytes": int(2 * fetch_b + write_b), "fetch_size_kib_raw": round(vals["FETCH_SIZE"], 1),
-            "write_size_kib_raw": round(vals["WRITE_SIZE"], 1), "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950)"}, None
+            "write_size_kib_raw": round(vals["WRITE_SIZE"], 1), "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950)",
+            "profiled": "child run of this script over the first %d batches of the workload (same seeds), every launch of the kernel averaged" % args.pmc_batches}, None
 
 
 LGS_WORKER = r"""
@@ -385,61 +387,123 @@ def phase_leg(device_index, mb, passes, procs, with_ref):
     return out
 
 
-def e2e_from_files(streams, draft_bp, threads):
-    """Scope 2: one FASTA + one sorted BAM on disk (page cache) -> polished FASTA through the CLI, cold process each time
-    (HIP start-up, BGZF inflate, record split, H2D, kernels, D2H, FASTA text all inside)."""
+def _write_files(streams, fa, bam, qual_model):
     from nextpolish_amd import _native as nat
     import ctypes as C
+    arr = (C.c_void_p * len(streams))(*[s.handle for s in streams])
+    L = nat.lib()
+    L.np1_streams_write_files_q.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    t0 = time.time()
+    if L.np1_streams_write_files_q(arr, len(streams), fa.encode(), bam.encode(), 1, qual_model) != 0:
+        raise RuntimeError(nat.last_error())
+    return time.time() - t0
+
+
+def _time_files(fa, bam, draft_bp, threads, n_records, cold_runs, warm_runs, pipe):
+    """cold: the CLI, a new process each time; warm: np1_pipe_run_files of this (running) process"""
+    exe = os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1")
+    env = dict(os.environ, NP_IO_THREADS=str(threads))
+    best, nbytes = 1e9, 0
+    for _ in range(cold_runs):
+        t0 = time.time()
+        q = subprocess.Popen([exe, "scorechain", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        n = 0
+        for chunk in iter(lambda: q.stdout.read(1 << 24), b""):     # the FASTA text is counted, not kept (3 GB at full size)
+            n += len(chunk)
+        if q.wait() != 0:
+            raise RuntimeError("nextpolish1 scorechain failed")
+        best = min(best, time.time() - t0)
+        nbytes = n
+    warm, nout = 1e9, 0
+    for i in range(warm_runs + 1):
+        got = [0]
+        t0 = time.time()
+        pipe.run_files(fa, bam, batch_bp=int(os.environ.get("NP1_BATCH_BP", "16000000")), raw_sink=lambda name, ptr, n: got.__setitem__(0, got[0] + n))
+        if i > 0:                            # the first pass grows the buffers to their final size
+            warm = min(warm, time.time() - t0)
+        nout = got[0]
+    size = os.path.getsize(bam)
+    return {"mbp_s": round(draft_bp / 1e6 / best, 2), "seconds": round(best, 3), "warm_mbp_s": round(draft_bp / 1e6 / warm, 2), "warm_seconds": round(warm, 3),
+            "bam_mb": round(size / 1e6, 1), "bam_bytes_per_record": round(size / max(1, n_records), 2), "fasta_bytes_out": nbytes, "bases_out_warm": nout}
+
+
+def e2e_from_files(streams, draft_bp, threads, n_records):
+    """Scope 2: one FASTA + one sorted BAM on disk (page cache) -> polished FASTA.  Full size on a BAM with Illumina-like binned
+    qualities (cold CLI process: HIP start-up, first-touch allocations, BGZF inflate + record split on the device, H2D, kernels,
+    D2H, FASTA text; warm: the same files through np1_pipe_run_files of a running process); the first batch alone on a BAM
+    without qualities and on one with uniformly random qualities, for the two ends of the compressibility range."""
+    from nextpolish_amd.device import Pipe
     d = tempfile.mkdtemp(prefix="np1e2e_")
+    out = {}
+    pipe = Pipe(int(os.environ.get("LOCAL_RANK", "0")), lanes=int(os.environ.get("NP1_E2E_LANES", "2")))
     try:
         fa, bam = os.path.join(d, "g.fa"), os.path.join(d, "r.bam")
-        arr = (C.c_void_p * len(streams))(*[s.handle for s in streams])
-        L = nat.lib()
-        L.np1_streams_write_files.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int]
-        t0 = time.time()
-        if L.np1_streams_write_files(arr, len(streams), fa.encode(), bam.encode(), 1) != 0:
-            return {"error": nat.last_error()}
-        t_write = time.time() - t0
-        exe = os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1")
-        env = dict(os.environ, NP_IO_THREADS=str(threads))
-        best, nbytes = 1e9, 0
-        for _ in range(3):
-            t0 = time.time()
-            out = subprocess.run([exe, "scorechain", fa, bam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, check=True).stdout
-            best = min(best, time.time() - t0)
-            nbytes = len(out)
-        # the same files through an already running process (what a long-lived worker sees: no HIP start-up, buffers in place)
-        from nextpolish_amd.device import Pipe
-        pipe = Pipe(int(os.environ.get("LOCAL_RANK", "0")), lanes=int(os.environ.get("NP1_E2E_LANES", "2")))
-        warm, nout = 1e9, 0
-        for _ in range(3):
-            got = [0]
-            t0 = time.time()
-            pipe.run_files(fa, bam, raw_sink=lambda name, ptr, n: got.__setitem__(0, got[0] + n))
-            warm = min(warm, time.time() - t0)
-            nout = got[0]
-        pipe.close()
-        return {"mbp_s": round(draft_bp / 1e6 / best, 2), "seconds": round(best, 3), "bam_mb": round(os.path.getsize(bam) / 1e6, 1),
-                "warm_mbp_s": round(draft_bp / 1e6 / warm, 2), "warm_seconds": round(warm, 3),
-                "what": "cold: nextpolish1 scorechain g.fa r.bam > out.fa, new process each time (HIP start-up and first-touch allocations "
-                        "inside), best of 3, files in the page cache, %d host threads, %d bytes of FASTA out; warm: the same files through "
-                        "np1_pipe_run_files of a running process (device BGZF inflate + record split + kernels + D2H, %d bases out), best of 3 "
-                        "after one pass; files written in %.1f s" % (threads, nbytes, nout, t_write)}
+        t_write = _write_files(streams, fa, bam, 1)
+        full = _time_files(fa, bam, draft_bp, threads, n_records, 2, 2, pipe)
+        full["qualities"] = "Illumina-like, binned (2/12/23/37; ~93 % in the top bin), BGZF level 1"
+        full["write_seconds"] = round(t_write, 1)
+        full["what"] = ("cold: nextpolish1 scorechain g.fa r.bam > out.fa, new process each time (HIP start-up and first-touch allocations inside), "
+                        "best of 2, files in the page cache, %d host threads; warm: the same files through np1_pipe_run_files of a running "
+                        "process (device BGZF inflate + CRC + record split + kernels + D2H), best of 2 after one pass" % threads)
+        out.update(full)
+        os.remove(bam)
+        one = streams[:1]
+        bp1 = int(sum(int(x) for x in one[0].ctg_len))
+        for key, qm, label in (("no_qualities", 0, "no base qualities (0xff): ~9:1"), ("random_qualities", 2, "uniformly random qualities in [25, 40]: incompressible")):
+            _write_files(one, fa, bam, qm)
+            r = _time_files(fa, bam, bp1, threads, one[0].n_reads, 1, 2, pipe)
+            r["qualities"] = label
+            r["slice"] = "first batch only: %.1f Mb, %d records" % (bp1 / 1e6, one[0].n_reads)
+            out[key] = r
+            os.remove(bam)
+        return out
+    except Exception as e:     # the headline line must survive a failure of this leg
+        out["error"] = repr(e)
+        return out
     finally:
+        pipe.close()
         shutil.rmtree(d, ignore_errors=True)
+
+
+def parity_check(pipe, streams, budget_bp):
+    """Polished strings of this run (the last streamed pass) against the CPU oracle, shortest contigs first up to budget_bp."""
+    import ctypes as C
+    import hashlib
+    from nextpolish_amd import _native as nat
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    cand = sorted((int(st.ctg_len[c]), k, c) for k, st in enumerate(streams) for c in range(st.n_contigs))
+    n, bp, bad = 0, 0, []
+    t0 = time.time()
+    ln = C.c_int64(0)
+    for L, k, c in cand:
+        if n >= 1 and bp + L > budget_bp:
+            break
+        p = nat.lib().np1_pipe_result(pipe.handle, k, c, C.byref(ln))
+        got = C.string_at(p, ln.value)
+        want = ob.score_chain(streams[k], c).encode()
+        if hashlib.md5(got).digest() != hashlib.md5(want).digest():
+            bad.append(streams[k].names[c])
+        n += 1
+        bp += L
+    return {"contigs": n, "draft_bp": bp, "identical": not bad, "differing": bad, "oracle_seconds": round(time.time() - t0, 1),
+            "what": "md5 of the polished strings of the timed streamed passes vs oracle/np1_oracle (CPU restatement), shortest contigs of the draft"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3_100mb_30x", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--resident-passes", type=int, default=5, help="timed passes of the resident (no PCIe) sub-measurement")
+    ap.add_argument("--parity-mb", type=float, default=8.0, help="draft bases compared with the CPU oracle inside the run")
+    ap.add_argument("--workload", default="c5_3gb_30x", choices=sorted(WORKLOADS))
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=3.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-batches", type=int, default=4, help="batches of the workload the two rocprofv3 --pmc child runs polish (generating all 600 M records twice more is most of a full-size run)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the from-files leg")
     ap.add_argument("--no-lgs", action="store_true", help="skip the long-read (nextpolish2) leg")
     ap.add_argument("--lgs-workers", type=int, default=12, help="worker processes per GPU of the long-read leg")
@@ -452,6 +516,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # host threads of this rank = the box's cores / ranks (generator, BAM writer, loaders; read once when the library loads)
+    per_rank = max(1, host_cores() // max(1, world))
+    os.environ.setdefault("NP_HOST_THREADS", str(per_rank))
+    os.environ.setdefault("NP_IO_THREADS", str(per_rank))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
@@ -474,12 +542,16 @@ def main():
     owner = deal_contigs(names, lmap, world)                      # the fixed draft is split over the ranks (strong scaling)
     mine = [n for n in names if owner[n] == rank]
     batches = plan_batches(mine, lmap, batch_bp)
+    if args.pmc_child:
+        batches = batches[:max(1, args.pmc_batches)]
     blens = [[lmap[n] for n in b] for b in batches]
     draft_bp_total = sum(lens)
     my_bp = sum(lmap[n] for n in mine)
     ncpu = host_cores()
     t_gen = time.time()
-    with ThreadPoolExecutor(max(1, min(ncpu, len(blens)))) as ex:
+    # chromosome-sized contigs are generated segment by segment on all of the rank's threads (np_synth.cpp): few streams at a time
+    outer = 2 if max(lens) >= (16 << 20) else max(1, min(per_rank, len(blens)))
+    with ThreadPoolExecutor(outer) as ex:
         streams = list(ex.map(lambda k: nat.Stream.synth(blens[k], depth=depth, seed=20250117 + 1000 * int(batches[k][0][1:]),
                                                          prefix="b%dc" % int(batches[k][0][1:])), range(len(blens))))
     t_gen = time.time() - t_gen
@@ -496,8 +568,6 @@ def main():
     L.np1_pipe_resident_batch.restype = C.c_void_p
     L.np1_pipe_run_resident_timed.argtypes = [C.c_void_p, C.c_int, C.POINTER(nat.Configure), C.POINTER(C.c_float)]
     harr = (C.c_void_p * len(streams))(*[s.handle for s in streams])
-    if L.np1_pipe_upload(pipe.handle, harr, len(streams)) != 0:
-        raise SystemExit("upload: " + nat.last_error())
 
     def resident(passes):
         if passes > 0 and L.np1_pipe_run_resident(pipe.handle, C.byref(cfg), 1, passes) != 0:
@@ -509,20 +579,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    resident(args.warmup)
-    if args.pmc_child:   # short profiled run for pmc_traffic(): no JSON, no baseline
-        resident(args.steps)
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    if args.pmc_child:   # short profiled run for pmc_traffic(): resident passes only, no JSON, no baseline
+        if L.np1_pipe_upload(pipe.handle, harr, len(streams)) != 0:
+            raise SystemExit("upload: " + nat.last_error())
+        resident(args.warmup + args.steps)
         pipe.close()
         return
+
+    # ---- the timed steps (SURVEY 8d scope 1): pinned host -> H2D -> kernels -> D2H, double-buffered on the lanes, all inside
+    for _ in range(args.warmup):
+        pipe.run(streams, cfg=cfg, fetch=False)          # warm: lane batches grow to their final size
     sync_all()
     t0 = time.perf_counter()
-    resident(args.steps)
+    for _ in range(args.steps):
+        pipe.run(streams, cfg=cfg, fetch=False)
     sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
+    h2d_bytes = sum(alg_in)
+    parity = parity_check(pipe, streams, int(args.parity_mb * 1e6)) if rank == 0 else None
+    streamed_lengths = pipe.result_lengths(streams)
+
+    # ---- the same pass with the batches resident in HBM (no PCIe inside the timed region)
+    if L.np1_pipe_upload(pipe.handle, harr, len(streams)) != 0:
+        raise SystemExit("upload: " + nat.last_error())
+    resident(1)
+    sync_all()
+    t0 = time.perf_counter()
+    resident(args.resident_passes)
+    sync_all()
+    dt_res = max_over_ranks(time.perf_counter() - t0)
 
     # ---- per-stage HIP-event timing on the pipeline's own stream (separate instrumented passes, one lane, batch by batch)
     stage_acc, launches, polished, updates = {}, 0, [], 0
@@ -543,36 +635,29 @@ def main():
     dom = max(stage_ms, key=lambda k: stage_ms[k])
     alg_per_launch = (sum(alg_in) + sum(polished)) / float(len(streams))
     achieved = alg_per_launch / (stage_ms[dom] * 1e-3) / 1e9
-
-    # ---- scope 1: pinned host -> H2D -> kernels -> D2H, double-buffered on the lanes, all inside the timed region
-    pipe.run(streams, cfg=cfg, fetch=False)          # warm: lane batches grow to their final size
-    sync_all()
-    t0 = time.perf_counter()
-    n_stream_passes = 3
-    for _ in range(n_stream_passes):
-        pipe.run(streams, cfg=cfg, fetch=False)
-    sync_all()
-    dt_stream = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt_stream], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_stream = float(t.item())
-    h2d_bytes = sum(alg_in)
-    assert pipe.result_lengths(streams) == sum(polished)
+    assert streamed_lengths == sum(polished)
 
     traffic, traffic_note = None, "not collected"
     if rank == 0 and world == 1 and not args.no_pmc:
         sub = {"tile": "k_tile3", "vote": "k_vote", "rows": "k_rows"}.get(dom, dom)
         traffic, traffic_note = pmc_traffic(args, sub)
+        if traffic:
+            nb = min(len(streams), max(1, args.pmc_batches))
+            traffic["algorithmic_bytes_per_launch_of_the_profiled_batches"] = int((sum(alg_in[:nb]) + sum(polished[:nb])) / nb)
+            traffic["ratio_to_algorithmic"] = round(traffic["bytes"] / traffic["algorithmic_bytes_per_launch_of_the_profiled_batches"], 3)
     e2e = None
     if rank == 0 and world == 1 and not args.no_e2e:
-        e2e = e2e_from_files(streams, draft_bp_total, ncpu)
-    pipe.close()
+        pipe.close()
+        pipe = None
+        e2e = e2e_from_files(streams, draft_bp_total, ncpu, n_reads)
+    if pipe is not None:
+        pipe.close()
     lgs = None
     if not args.no_lgs:
         if world > 1:
             dist.barrier()
-        lgs = lgs_leg(rank, local_rank, args.lgs_workers, args.lgs_mb, args.lgs_calls,
+        lgs_workers = args.lgs_workers if world == 1 else max(2, min(args.lgs_workers, (ncpu * 3 // 4) // world))   # the ranks share the host cores
+        lgs = lgs_leg(rank, local_rank, lgs_workers, args.lgs_mb, args.lgs_calls,
                       rank == 0 and world == 1 and not args.no_cpu_baseline, rank == 0 and world == 1 and not args.no_pmc)
         if world > 1:   # whole job: bp of all ranks over the slowest rank's span
             tt = torch.tensor([float(lgs.get("bp", 0)), float(lgs.get("seconds", 0)), 1.0 if "error" in lgs else 0.0], device="cuda", dtype=torch.float64)
@@ -586,30 +671,32 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = draft_bp_total / 1e6 / (dt / args.steps)
-        streamed = draft_bp_total * n_stream_passes / 1e6 / dt_stream
+        resident_v = draft_bp_total / 1e6 / (dt_res / args.resident_passes)
         out = {
-            "metric": "polished Mbp/s (score_chain, 30x short reads, one fixed draft, batches resident in HBM)",
+            "metric": "polished Mbp/s (score_chain, 30x short reads, one fixed draft; decoded records in pinned host memory -> H2D -> kernels -> D2H)",
             "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8/int64", "data": "synthetic",
             "config": {"workload": "%s: %.1f Mb synthetic draft in %d contigs (log-uniform %g-%g bp) + %.0fx simulated 2x150 bp PE reads "
-                                   "(%d records on rank 0), dealt longest-first over %d GPU(s), %d HBM batches of <= %.0f Mb on rank 0; "
-                                   "one step = one score_chain pass over the whole draft"
+                                   "(%d records on rank 0), dealt longest-first over %d GPU(s), %d batches of <= %.0f Mb on rank 0; "
+                                   "one step = one score_chain pass over the whole draft, inputs in pinned host memory, H2D and D2H inside the timed region"
                                    % (args.workload, draft_bp_total / 1e6, len(lens), lo, hi, depth, n_reads, world, len(batches), batch_bp / 1e6),
                        "slot_votes_per_step_rank0": updates // n_inst, "lanes": args.lanes,
                        "parallelism": "contigs dealt longest-first x%d (no collective)" % world,
-                       "synth_seconds": round(t_gen, 1), "host_cores": ncpu},
-            "streamed": {"mbp_s": round(streamed, 2), "what": "pinned host arrays -> async H2D -> kernels -> D2H of the polished strings, "
-                         "%d lanes, %d passes over the draft, all inside the timed region (SURVEY 8d scope 1)" % (args.lanes, n_stream_passes),
-                         "seconds_per_pass": round(dt_stream / n_stream_passes, 4),
-                         "h2d_gb_per_s_rank0": round(h2d_bytes * n_stream_passes / dt_stream / 1e9, 2)},
+                       "synth_seconds": round(t_gen, 1), "host_cores": ncpu, "host_threads_per_rank": per_rank,
+                       "h2d_gb_per_s_rank0": round(h2d_bytes * args.steps / dt / 1e9, 2)},
+            "resident": {"mbp_s": round(resident_v, 2), "ms_per_pass": round(dt_res / args.resident_passes * 1e3, 3), "passes": args.resident_passes,
+                         "what": "the same pass with every batch already resident in HBM (no H2D / D2H inside), %d lanes: what the kernels alone sustain" % args.lanes},
+            "parity": parity,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic["bytes"] if traffic else None,
                          "traffic_detail": traffic if traffic else traffic_note,
                          "algorithmic_bytes_per_launch": int(alg_per_launch), "kernel_ms": round(stage_ms[dom], 4),
                          "launches_averaged": launches, "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-                         "achieved_whole_pass_gbs": round((sum(alg_in) + sum(polished)) / (dt / args.steps) / 1e9, 2)},
+                         "achieved_whole_pass_gbs": round((sum(alg_in) + sum(polished)) / (dt_res / args.resident_passes) / 1e9, 2)},
         }
+        if parity is not None and not parity["identical"]:
+            raise SystemExit("bench: the polished strings differ from the oracle: %r" % (parity,))
         if e2e is not None:
             out["e2e_from_files"] = e2e
         if lgs is not None:

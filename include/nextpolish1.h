@@ -142,6 +142,10 @@ int np1_stream_write_files_aux(const np1_stream* st, const char* fasta, const ch
                                const uint64_t* aux_off);
 /* several streams as ONE FASTA(+.fai) + ONE coordinate-sorted BAM(+.bai): contigs of streams[0], then of streams[1], ... */
 int np1_streams_write_files(np1_stream* const* streams, int n, const char* fasta, const char* bam, int bgzf_level);
+/* the same with a quality model for streams that carry no qualities: 0 = none (0xff bytes), 1 = Illumina-like binned qualities
+ * (2 / 12 / 23 / 37, np_synth.cpp:synth_binned_qualities): what a BAM of a current instrument looks like to the BGZF inflate;
+ * 2 = uniformly random in [25, 40] (incompressible: the decoder's worst case) */
+int np1_streams_write_files_q(np1_stream* const* streams, int n, const char* fasta, const char* bam, int bgzf_level, int qual_model);
 void np1_stream_free(np1_stream* s);
 
 /* Synthetic workload.  Field meanings: nextpolish_amd/csrc/np_synth.h */

@@ -307,9 +307,7 @@ bool BamWriter::write(int32_t tid, int32_t pos, uint8_t mapq, uint16_t flag, int
     return true;
 }
 
-bool BamWriter::close() {
-    // tell() of the last record may point inside an unflushed block; offsets stay valid after flush
-    if (!bg_.close()) return false;
+void BamWriter::resolve_offsets() {
     // the offsets collected while writing are provisional (block sequence numbers): make them real
     for (size_t i = 0; i < refs_.size(); ++i) {
         for (auto& kv : refs_[i].bins)
@@ -319,15 +317,47 @@ bool BamWriter::close() {
         ref_beg_[i] = bg_.resolve(ref_beg_[i]);
         ref_end_[i] = bg_.resolve(ref_end_[i]);
     }
-    FILE* fp = fopen((path_ + ".bai").c_str(), "wb");
+}
+
+BamWriter::PartIndex BamWriter::take_part_index() {
+    PartIndex ix;
+    ix.refs.swap(refs_);
+    ix.n_mapped.swap(n_mapped_);
+    ix.n_unmapped.swap(n_unmapped_);
+    ix.ref_beg.swap(ref_beg_);
+    ix.ref_end.swap(ref_end_);
+    ix.n_no_coor = n_no_coor_;
+    return ix;
+}
+
+bool BamWriter::open_part(size_t n_refs, int level) {
+    path_.clear();
+    if (!bg_.open_memory(level, 1)) return false;
+    refs_.assign(n_refs, BaiRef());
+    n_mapped_.assign(n_refs, 0);
+    n_unmapped_.assign(n_refs, 0);
+    ref_beg_.assign(n_refs, 0);
+    ref_end_.assign(n_refs, 0);
+    n_no_coor_ = 0;
+    return true;
+}
+
+bool BamWriter::finish_part() {
+    if (!bg_.finish_memory()) return false;
+    resolve_offsets();
+    return true;
+}
+
+bool BamWriter::write_bai(const std::string& bai_path, PartIndex& ix) {
+    FILE* fp = fopen(bai_path.c_str(), "wb");
     if (!fp) return false;
     auto wr = [&](const void* p, size_t n) { return fwrite(p, 1, n, fp) == n; };
     bool ok = wr("BAI\1", 4);
-    int32_t n_ref = (int32_t)refs_.size();
+    int32_t n_ref = (int32_t)ix.refs.size();
     ok = ok && wr(&n_ref, 4);
     for (int i = 0; ok && i < n_ref; ++i) {
-        BaiRef& r = refs_[i];
-        bool has = (n_mapped_[i] + n_unmapped_[i]) > 0;
+        BaiRef& r = ix.refs[i];
+        bool has = (ix.n_mapped[i] + ix.n_unmapped[i]) > 0;
         int32_t n_bin = (int32_t)r.bins.size() + (has ? 1 : 0);
         ok = wr(&n_bin, 4);
         for (auto& kv : r.bins) {
@@ -338,7 +368,7 @@ bool BamWriter::close() {
         if (has) {
             uint32_t bin = kMetaBin;
             int32_t n_chunk = 2;
-            uint64_t meta[4] = {ref_beg_[i], ref_end_[i], n_mapped_[i], n_unmapped_[i]};
+            uint64_t meta[4] = {ix.ref_beg[i], ix.ref_end[i], ix.n_mapped[i], ix.n_unmapped[i]};
             ok = ok && wr(&bin, 4) && wr(&n_chunk, 4) && wr(meta, 32);
         }
         // back-fill unset linear slots from the next set one (hts_idx_finish behaviour)
@@ -348,9 +378,17 @@ bool BamWriter::close() {
         ok = ok && wr(&n_intv, 4);
         if (n_intv) ok = ok && wr(r.linear.data(), 8 * (size_t)n_intv);
     }
-    ok = ok && wr(&n_no_coor_, 8);
+    ok = ok && wr(&ix.n_no_coor, 8);
     ok = (fclose(fp) == 0) && ok;
     return ok;
+}
+
+bool BamWriter::close() {
+    // tell() of the last record may point inside an unflushed block; offsets stay valid after flush
+    if (!bg_.close()) return false;
+    resolve_offsets();
+    PartIndex ix = take_part_index();
+    return write_bai(path_ + ".bai", ix);
 }
 
 bool Fai::build(const std::string& fasta, std::vector<FaiEntry>* out) {

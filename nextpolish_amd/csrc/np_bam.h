@@ -90,7 +90,23 @@ public:
                const std::string& qname, const uint32_t* cigar, uint32_t n_cigar, const uint8_t* seq4,
                const uint8_t* qual, int32_t l_qseq, const uint8_t* aux = nullptr, size_t aux_len = 0);   // aux: raw optional fields
     bool close();   // also writes <path>.bai
+    // Part mode (several writers side by side, one thread each: np_synth.cpp write_streams_files): the records of a subset of the
+    // reference sequences into a memory sink, no header, no EOF marker; finish_part() leaves the compressed bytes in part_bytes()
+    // and the index entries in part_index(), their offsets relative to the first byte of the part.
+    struct PartIndex {
+        std::vector<BaiRef> refs;
+        std::vector<uint64_t> n_mapped, n_unmapped;
+        std::vector<voff_t> ref_beg, ref_end;
+        uint64_t n_no_coor = 0;
+    };
+    bool open_part(size_t n_refs, int level);
+    bool finish_part();
+    std::vector<uint8_t>& part_bytes() { return bg_.memory(); }
+    PartIndex take_part_index();
+    // <bam>.bai from index entries whose offsets are final
+    static bool write_bai(const std::string& bai_path, PartIndex& ix);
 private:
+    void resolve_offsets();
     void index_record(int32_t tid, int32_t beg, int32_t end, voff_t v0, voff_t v1, bool mapped);
     std::string path_;
     BgzfWriter bg_;

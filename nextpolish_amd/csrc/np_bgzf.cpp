@@ -237,6 +237,8 @@ voff_t BgzfReader::tell() const {
 BgzfWriter::~BgzfWriter() { if (fp_) close(); }
 
 bool BgzfWriter::open(const std::string& path, int level) {
+    to_memory_ = false;
+    threads_ = 0;
     fp_ = fopen(path.c_str(), "wb");
     if (!fp_) return false;
     level_ = level;
@@ -247,6 +249,22 @@ bool BgzfWriter::open(const std::string& path, int level) {
     coff_ = 0;
     return true;
 }
+
+bool BgzfWriter::open_memory(int level, unsigned threads) {
+    fp_ = nullptr;
+    to_memory_ = true;
+    threads_ = threads ? threads : 1;
+    mem_.clear();
+    level_ = level;
+    ubuf_.resize(kMaxBlock);
+    pending_.clear();
+    block_coff_.clear();
+    fill_ = 0;
+    coff_ = 0;
+    return true;
+}
+
+bool BgzfWriter::finish_memory() { return to_memory_ && flush_block() && drain(); }
 
 // One BGZF block (gzip member with the BC subfield) from `n` bytes; false if deflate fails.
 static bool deflate_block(const uint8_t* in, uint32_t n, int level, std::vector<uint8_t>* out) {
@@ -287,14 +305,15 @@ bool BgzfWriter::drain() {
             if (!deflate_block(pending_[i].data(), (uint32_t)pending_[i].size(), level_, &comp[i])) ok = false;
         }
     };
-    const unsigned nt = (unsigned)std::min<size_t>(io_threads(), pending_.size());
+    const unsigned nt = (unsigned)std::min<size_t>(threads_ ? threads_ : io_threads(), pending_.size());
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
     work();
     for (std::thread& t : th) t.join();
     if (!ok) return false;
     for (size_t i = 0; i < comp.size(); ++i) {
-        if (fwrite(comp[i].data(), 1, comp[i].size(), fp_) != comp[i].size()) return false;
+        if (to_memory_) mem_.insert(mem_.end(), comp[i].begin(), comp[i].end());
+        else if (fwrite(comp[i].data(), 1, comp[i].size(), fp_) != comp[i].size()) return false;
         block_coff_.push_back(coff_);
         coff_ += comp[i].size();
     }
@@ -306,7 +325,7 @@ bool BgzfWriter::flush_block() {
     if (fill_ == 0) return true;
     pending_.emplace_back(ubuf_.begin(), ubuf_.begin() + fill_);
     fill_ = 0;
-    if (pending_.size() >= 512) return drain();
+    if (pending_.size() >= (to_memory_ && threads_ <= 1 ? 16u : 512u)) return drain();
     return true;
 }
 

@@ -59,6 +59,12 @@ public:
     BgzfWriter() = default;
     ~BgzfWriter();
     bool open(const std::string& path, int level = 1);
+    // Memory sink: the compressed blocks are collected in memory() instead of a file, deflated on `threads` threads (several such
+    // writers running side by side is how the big synthetic BAMs are written: one part per thread, np_synth.cpp); finish_memory()
+    // flushes without the EOF marker.  Offsets (tell / resolve) are relative to the first block of this writer.
+    bool open_memory(int level, unsigned threads);
+    bool finish_memory();
+    std::vector<uint8_t>& memory() { return mem_; }
     bool write(const void* src, size_t n);
     // Blocks are deflated a batch at a time on a few threads (NP_IO_THREADS), so the file offset of the current block is
     // not known while records are written: tell() returns a PROVISIONAL offset (block sequence number << 16 | offset in
@@ -71,6 +77,9 @@ public:
 private:
     bool drain();                      // deflate + write the pending blocks
     FILE* fp_ = nullptr;
+    bool to_memory_ = false;
+    unsigned threads_ = 0;                        // 0: NP_IO_THREADS
+    std::vector<uint8_t> mem_;
     int level_ = 1;
     std::vector<uint8_t> ubuf_;
     std::vector<std::vector<uint8_t>> pending_;   // full blocks waiting for the deflate threads

@@ -88,12 +88,15 @@ int np1_stream_write_files_aux(const np1_stream* st, const char* fasta, const ch
     return 0;
 }
 
-int np1_streams_write_files(np1_stream* const* sts, int n, const char* fasta, const char* bam, int level) {
+int np1_streams_write_files_q(np1_stream* const* sts, int n, const char* fasta, const char* bam, int level, int qual_model) {
     std::vector<const np::ReadStream*> ss;
     for (int i = 0; i < n; ++i) ss.push_back(&sts[i]->s);
     std::string err;
-    if (!np::write_streams_files(ss, fasta, bam, level, &err)) { g_err = err; return -1; }
+    if (!np::write_streams_files(ss, fasta, bam, level, &err, nullptr, nullptr, qual_model)) { g_err = err; return -1; }
     return 0;
+}
+int np1_streams_write_files(np1_stream* const* sts, int n, const char* fasta, const char* bam, int level) {
+    return np1_streams_write_files_q(sts, n, fasta, bam, level, 0);
 }
 
 void np1_stream_free(np1_stream* st) {

@@ -31,8 +31,11 @@ bool write_stream_files(const ReadStream& s, const std::string& fasta, const std
                         std::string* err, const uint8_t* aux_pool = nullptr,
                         const uint64_t* aux_off = nullptr);   // aux: raw optional fields per record (tests: SA tags)
 // Several streams as ONE FASTA + ONE coordinate-sorted BAM (contigs of stream 0, then of stream 1, ...).
+// qual_model (streams without qualities): 0 = the BAM's "no qualities" bytes (0xff), 1 = Illumina-like binned qualities
+// (synth_binned_qualities), 2 = uniformly random in [25, 40].  More than one stream: the streams are written side by side on the host threads (parts of one file).
 bool write_streams_files(const std::vector<const ReadStream*>& ss, const std::string& fasta, const std::string& bam, int bgzf_level,
-                         std::string* err, const uint8_t* aux_pool = nullptr, const uint64_t* aux_off = nullptr);
+                         std::string* err, const uint8_t* aux_pool = nullptr, const uint64_t* aux_off = nullptr, int qual_model = 0);
+void synth_binned_qualities(uint64_t serial, bool reverse, int32_t l, uint8_t* out);
 // diploid workload of task 3: short-read and long-read stream over the same contigs (np1_diploid_params, include/nextpolish1.h)
 bool synth_diploid_streams(const np1_diploid_params& p, const std::string& contig_name_prefix, ReadStream* sr, ReadStream* lr);
 }  // namespace np

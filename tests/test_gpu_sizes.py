@@ -1,4 +1,4 @@
-"""BASELINE configs 3 and 4 at their stated sizes on one MI355X (the checks themselves live in tests/tools/ so they can be run
+"""BASELINE configs 3, 4 and (piecewise) 5 at their stated sizes on one MI355X (the checks themselves live in tests/tools/ so they can be run
 by hand; each prints one JSON line and exits non-zero on a mismatch)."""
 import json
 import os
@@ -30,3 +30,12 @@ def test_config4_size_long_reads_100mb_many_contigs_matches_reference_golden():
     every contig identical (md5 + length) to what the compiled reference produced for the same files."""
     info = run_tool("check_config4.py")
     assert info["mismatches"] == 0 and info["missing"] == 0 and info["contigs"] == 67 and info["contigs_over_one_window"] >= 4
+
+
+def test_config5_scale_chromosome_contig_and_multibatch_from_files_match_oracle():
+    """The metric's 3 Gb shape at the sizes its pieces have: one 250 Mb contig at 30x (50 M records, one HBM batch) bit-identical to
+    the CPU oracle, and a 113 Mb slice of four contigs FROM FILES (sorted BAM with Illumina-like binned qualities -> CLI -> device-side
+    inflate + record split, one large contig per batch) identical contig by contig."""
+    info = run_tool("check_config5.py")
+    assert info["mismatches"] == 0 and info["big"]["draft_bp"] >= 249000000 and info["big"]["records"] >= 49000000
+    assert info["slice"]["batches"] >= 4 and info["slice"]["draft_bp"] >= 112000000
