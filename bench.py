@@ -237,8 +237,9 @@ def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref, with_pmc):
         f.write(bam + "\n")
     go = os.path.join(d, "go")
     env = dict(os.environ, NP2_DEVICE=str(local_rank))
-    env.setdefault("NP_HOST_THREADS", "4")   # several workers share the host cores of one GPU
-    env.setdefault("NP_IO_THREADS", "4")
+    wt = os.environ.get("NP2_WORKER_THREADS", "4")   # several workers share the host cores of one GPU
+    env["NP_HOST_THREADS"] = wt
+    env["NP_IO_THREADS"] = wt
     lib2 = os.path.join(ROOT, "nextpolish_amd", "lib", "nextpolish2.so")
     ps = []
     for w in range(workers):
@@ -706,7 +707,7 @@ def main():
                 out["lgs"] = {"metric": "polished Mbp/s (ctg_cns_core, long reads, sorted BAM in the page cache -> consensus, warm workers)",
                               "value": round(lgs["bp"] / 1e6 / lgs["seconds"], 3), "unit": "Mbp/s", "n_gpus": world,
                               "config": {"workload": "%.1f Mb synthetic contig + 20x ONT-like reads (8 kb, 7%% errors) per worker, %d worker processes per GPU, "
-                                                     "%d calls each, %s host threads per worker" % (args.lgs_mb, args.lgs_workers, args.lgs_calls, os.environ.get("NP_HOST_THREADS", "4"))},
+                                                     "%d calls each, %s host threads per worker" % (args.lgs_mb, lgs["workers"], args.lgs_calls, os.environ.get("NP2_WORKER_THREADS", "4"))},
                               "s_per_call": lgs["s_per_call"], "host_cpu_s_per_mbp": lgs["cpu_s_per_mbp"]}
                 for k in ("roofline", "cpu_baseline"):
                     if k in lgs:
