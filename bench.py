@@ -696,7 +696,7 @@ def main():
                          "launches_averaged": launches, "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                          "achieved_whole_pass_gbs": round((sum(alg_in) + sum(polished)) / (dt_res / args.resident_passes) / 1e9, 2)},
         }
-        if parity is not None and not parity["identical"]:
+        if parity is not None and not parity["identical"] and not os.environ.get("NP1_ABLATE"):   # (NP1_ABLATE: timing experiments with wrong results)
             raise SystemExit("bench: the polished strings differ from the oracle: %r" % (parity,))
         if e2e is not None:
             out["e2e_from_files"] = e2e

@@ -17,6 +17,7 @@ constexpr int DESC_NSEG = 5, DESC_NINS = 2;
 constexpr int DESC_SEG0 = 4, DESC_INS0 = DESC_SEG0 + 2 * DESC_NSEG, DESC_NEXT = DESC_INS0 + 2 * DESC_NINS;
 constexpr int DESC_WORDS = DESC_NEXT + 2;   // 20 words = 80 B per record
 constexpr uint32_t DESC_CHAIN = 1u << 16;   // d[2] flag of a head part that continues in the overflow pool
+constexpr uint32_t DESC_SIMPLE = 1u << 17;  // d[2] flag: the whole record is ONE matched segment (no deletion, no insertion, no further part)
 // d[0]=sfirst d[1]=slast (this part)  d[2]=nseg | nins<<8 | flags  d[3]=low word of the record's offset in the base pool
 // seg k: d[SEG0+2k]=g_lo, +1: len | qcode<<16 (qcode = q_lo, or 0xffff for DEL)
 // ins k: d[INS0+2k]=p,    +1: len | q0<<16
@@ -84,6 +85,7 @@ struct DescBuilder {
     NP1_HD void finish() {
         if (!any) { sfirst = 1; slast = 0; }
         d[0] = sfirst; d[1] = slast; d[2] = nseg | nins << 8;
+        if (d == sink.head && any && nseg == 1 && nins == 0 && (d[DESC_SEG0 + 1] >> 16) != 0xffffu) d[2] |= DESC_SIMPLE;
         sink.head[DESC_NEXT + 1] = any ? slast : 0;   // whole-record slast for the candidate test
     }
 };

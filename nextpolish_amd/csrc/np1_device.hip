@@ -384,6 +384,11 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                                    b->slot_g.as<uint32_t>(), S, b->max_lq, b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(),
                                    b->pool.as<uint32_t>(), pool_cap, counters, b->heads.as<uint32_t>(), heads_cap5,
                                    b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes, dbg);
+            else if (tile_kind == 7)
+                rc5 = launch_tile7(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(), b->chunk_first.as<uint32_t>(),
+                                   b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(), b->slot_g.as<uint32_t>(), S, b->max_lq,
+                                   b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
+                                   b->heads.as<uint32_t>(), heads_cap5, b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes);
             else if (tile_kind == 5)
                 rc5 = launch_tile5(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
                                    b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(),

@@ -37,6 +37,11 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
                  uint32_t* heads, uint32_t heads_cap, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single,
                  unsigned long long* votes);
 // event form of the fused kernel (default): chunks that overflow its event buffers land in redo_out for k_tile3
+// k_tile7: the per-vote kernel with the per-record bookkeeping on lane masks in scalar registers (np1_kernels.hip)
+int launch_tile7(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool, const uint32_t* chunk_first,
+                 const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S, uint32_t max_lq,
+                 uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters, uint32_t* heads, uint32_t heads_cap,
+                 uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes);
 int launch_tile5(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool,
                  const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info,
                  const uint32_t* slot_g, uint32_t S, uint32_t max_lq, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool,

@@ -576,6 +576,250 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_tile7 (default since round 3): the per-vote kernel with the bookkeeping of a (record, 64-slot chunk) step moved to the SCALAR unit.
+// k_tile3 spends ~75 vector and ~60 scalar instructions per step and is bound by vector issue.  What a record does to a chunk is
+// nearly always the same thing in every lane -- "covered, and the same three bases as the draft" -- so here it is kept as 64-bit lane
+// masks in scalar registers:
+//   C   lanes the record covers      = one bit field (s_bfm_b64) from its slot run [sfirst, slast]: no per-lane compares
+//   A   lanes where it votes the draft's own symbol (one v_cmp that writes the mask)
+//   M0  lanes whose whole 3-base context is the draft's = A & (A << 1 | F1) & (A << 2 | F2)   (F1 / F2: lanes at a contig start, where
+//       the context has no first / second predecessor)
+// count(draft context) += M0 is one v_addc with the mask as carry-in; "did anything but the draft's base vote here" (which decides
+// whether the slot needs the chain DP at all) is one s_or per record.  Only when some lane's context differs (R = votes & ~M0, a few
+// steps in ten: draft errors, read errors) do the lanes build their contexts with the two DPP shifts and tally them -- in record
+// order, so first-seen order is untouched.  The descriptors are not staged through LDS any more: the step's record is wave-uniform,
+// so its descriptor comes through the scalar data cache (s_load) and every field is born in a scalar register; the candidate
+// records of a chunk are the range k_desc left in chunk_first / chunk_last.  LDS holds the packed bases only.
+__device__ __forceinline__ void add_lane_mask(uint32_t& c, unsigned long long m) {   // c += bit `lane` of m
+    unsigned long long carry_out;
+    asm volatile("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(c), "=s"(carry_out) : "s"(m));
+}
+__device__ __forceinline__ uint32_t sel_lane_mask(uint32_t if0, uint32_t if1, unsigned long long m) {   // bit `lane` of m ? if1 : if0
+    uint32_t r;
+    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(m));
+    return r;
+}
+__device__ __forceinline__ unsigned long long lane_field(int32_t lo, int32_t hi) {   // bits lo..hi (0 <= lo <= hi <= 63)
+    const uint32_t n = (uint32_t)(hi - lo + 1);
+    return (n >= 64u ? ~0ull : ((1ull << n) - 1ull)) << lo;
+}
+
+template <int E, int NW>
+__global__ __launch_bounds__(NW * 64) void k_tile7(ReadsDev R, const uint32_t* __restrict__ soff,
+                                                   const uint32_t* __restrict__ desc,
+                                                   const uint32_t* __restrict__ ovf_pool,
+                                                   const uint32_t* __restrict__ chunk_first,
+                                                   const uint32_t* __restrict__ chunk_last, uint32_t n_chunks,
+                                                   const uint32_t* __restrict__ redo_in, uint32_t n_items,
+                                                   const uint8_t* __restrict__ slot_info,
+                                                   const uint32_t* __restrict__ slot_g, uint32_t S, uint32_t seq_w,
+                                                   uint32_t nb_max, uint16_t* __restrict__ slot_res,
+                                                   uint32_t* __restrict__ slot_rec, uint32_t* __restrict__ pool,
+                                                   uint32_t pool_cap, uint32_t* __restrict__ counters,
+                                                   uint32_t* __restrict__ heads, uint32_t heads_cap,
+                                                   uint32_t* __restrict__ redo_out,
+                                                   uint32_t redo_ci, uint32_t flag_single,
+                                                   unsigned long long* __restrict__ votes, uint32_t ablate) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ __attribute__((aligned(16))) uint32_t sh_r[4];
+    uint32_t* lists = lds;                             // NW * (E-2) * 64
+    uint32_t* dsc = lists + NW * (E - 2) * 64;         // nb_max * DESC_WORDS (+ one spare descriptor slot for the prefetch)
+    uint32_t* seqst = dsc + (nb_max + 1) * DESC_WORDS; // nb_max * seq_w + 8
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    const uint32_t cbase = redo_in ? redo_in[item] : item * NW;
+    const uint32_t c = cbase + (uint32_t)wave;
+    const bool chunk_ok = c < n_chunks;
+    if (tid == 0) {
+        uint32_t r0 = 0xffffffffu, r1 = 0;
+        for (int w = 0; w < NW; ++w) {
+            uint32_t cc = cbase + w;
+            if (cc < n_chunks) {
+                uint32_t f = chunk_first[cc];
+                if (f != 0xffffffffu) {
+                    if (f < r0) r0 = f;
+                    uint32_t l = chunk_last[cc];
+                    if (l > r1) r1 = l;
+                }
+            }
+        }
+        sh_r[0] = r0;
+        sh_r[1] = r1;
+    }
+    uint32_t* L = lists + wave * (E - 2) * 64;
+    const int64_t s64 = (int64_t)c * VOTE_CH - 2 + lane;
+    const bool valid = chunk_ok && s64 >= 0 && s64 < (int64_t)S;
+    const uint32_t s = (uint32_t)s64;
+    const uint32_t info = valid ? slot_info[s] : 0u;
+    const uint32_t g = valid ? slot_g[s] : 0u;
+    const bool is_ins = valid && (info & SI_INSERT);
+    const uint32_t jju = is_ins ? (s - soff[g]) - 1u : 0u;   // insertion column of an insertion slot
+    const uint32_t dsym = info & 0xf;
+    const bool first = (info & SI_FIRST) != 0;
+    uint32_t d1 = wave_shr1(dsym), d2 = wave_shr1(d1);
+    const uint32_t f1 = wave_shr1((uint32_t)first);
+    const uint32_t prev_dsym = d1;
+    if (first) { d1 = 0; d2 = 0; }
+    else if (f1) d2 = 0;
+    VoteLane<E> vl;
+    vl.init(d2 << 8 | d1 << 4 | dsym);
+    // wave-uniform lane masks of this chunk
+    const unsigned long long INS = __ballot(is_ins);   // (lanes 0 and 1 are the halo: they never vote)
+    const unsigned long long F1 = __ballot(first), F2 = __ballot(first || f1 != 0);
+    unsigned long long NS = 0;          // lanes where something other than the draft's own symbol voted
+    uint32_t basemask = 0;              // the same per lane, from the general path (chained / oversize records)
+    const int32_t cs = (int32_t)((int64_t)c * VOTE_CH - 2);   // slot of lane 0 (may be -2 for chunk 0)
+    uint32_t wf = 0xffffffffu, wl = 0;
+    if (chunk_ok) { wf = chunk_first[c]; wl = chunk_last[c]; }
+    wf = (uint32_t)__builtin_amdgcn_readfirstlane((int)wf);
+    wl = (uint32_t)__builtin_amdgcn_readfirstlane((int)wl);
+    __syncthreads();
+    const uint32_t r0 = sh_r[0], r1 = sh_r[1];
+    if (r0 != 0xffffffffu) {
+        for (uint64_t rb = r0; rb <= r1; rb += nb_max) {
+            const uint32_t nb = (uint32_t)((r1 - rb + 1 < nb_max) ? (r1 - rb + 1) : nb_max);
+            // ---- stage descriptors and packed bases of the batch (both contiguous in HBM): 16-byte lanes, coalesced
+            {
+                const uint4* dsrc = reinterpret_cast<const uint4*>(desc + rb * DESC_WORDS);
+                uint4* ddst = reinterpret_cast<uint4*>(dsc);
+                for (uint32_t i = tid; i < nb * (DESC_WORDS / 4); i += NW * 64) ddst[i] = dsrc[i];
+            }
+            const uint64_t sq0 = R.seq_off[rb] & ~15ull;
+            const uint64_t sq1 = R.seq_off[rb + nb - 1] + (((uint64_t)R.l_qseq[rb + nb - 1] + 1) >> 1);
+            const uint32_t sq_quads = (uint32_t)((sq1 - sq0 + 15) >> 4);
+            const uint32_t sq_fit = sq_quads * 4 <= nb_max * seq_w + 8 ? sq_quads : (nb_max * seq_w + 8) / 4;
+            if (sq_fit != sq_quads && tid == 0) atomicOr(&counters[CNT_ERR], ERR_BAD_RECORD);
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(R.seq + sq0);
+                uint4* dst = reinterpret_cast<uint4*>(seqst);
+                for (uint32_t i = tid; i < sq_fit; i += NW * 64) dst[i] = src[i];
+            }
+            const uint32_t sq0_lo = (uint32_t)sq0;   // descriptors carry the low word of their record's pool offset
+            __syncthreads();
+            // ---- this wave's chunk votes over its candidate records of the batch, in record order
+            if (wf != 0xffffffffu) {
+                const uint8_t* seqb = reinterpret_cast<const uint8_t*>(seqst);
+                const uint64_t ia = wf > rb ? wf : rb, ib = (uint64_t)wl < rb + nb - 1 ? (uint64_t)wl : rb + nb - 1;
+                const int32_t lb = ia <= ib ? (int32_t)(ib - rb) : -1;
+                const uint32_t la = lb >= 0 ? (uint32_t)(ia - rb) : 0u;
+                // descriptor head (sfirst, slast, counts, base offset) and first segment of the next record are fetched while this one
+                // votes (LDS broadcast reads; the spare descriptor slot keeps the last prefetch in range); every field becomes scalar
+                uint4 hv = *reinterpret_cast<const uint4*>(dsc + la * DESC_WORDS);
+                uint2 sv = *reinterpret_cast<const uint2*>(dsc + la * DESC_WORDS + DESC_SEG0);
+                for (int32_t li = (int32_t)la; li <= lb; ++li) {
+                    const uint32_t* d = dsc + (uint32_t)li * DESC_WORDS;
+                    const uint32_t sfirst = (uint32_t)__builtin_amdgcn_readfirstlane((int)hv.x), slast_part = (uint32_t)__builtin_amdgcn_readfirstlane((int)hv.y);
+                    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hv.z), boff = (uint32_t)__builtin_amdgcn_readfirstlane((int)hv.w);
+                    const uint32_t seg0_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv.x), seg0_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv.y);
+                    hv = *reinterpret_cast<const uint4*>(dsc + (uint32_t)(li + 1) * DESC_WORDS);
+                    sv = *reinterpret_cast<const uint2*>(dsc + (uint32_t)(li + 1) * DESC_WORDS + DESC_SEG0);
+                    if (ablate & 4u) continue;
+                    uint32_t sym;
+                    unsigned long long C;
+                    if (cnt & DESC_SIMPLE) {
+                        // ---- the common shape, one matched segment: lanes lo..hi of the slot run, base q = q_lo + (g - g_lo), DEL on the
+                        //      insertion columns it passes.  (An empty interval also covers "not in this chunk".)
+                        int32_t lo = (int32_t)sfirst - cs, hi = (int32_t)slast_part - cs;
+                        lo = lo < 0 ? 0 : lo;
+                        hi = hi > 63 ? 63 : hi;
+                        if (lo > hi) continue;
+                        C = (~0ull >> (63 - hi)) & (~0ull << lo);       // (slots of a run exist: C lies inside VALID)
+                        const unsigned long long BASE = C & ~INS;
+                        const uint32_t q = sel_lane_mask(0u, g + ((seg0_w >> 16) - seg0_g), BASE);
+                        const uint32_t byte = seqb[(boff - sq0_lo) + (q >> 1)];
+                        sym = sel_lane_mask(3u, (byte >> ((~q & 1u) << 2)) & 0xfu, BASE);
+                    } else {
+                        // a record that continues in further parts (DESC_CHAIN) is tested with the end of its whole slot run
+                        const uint32_t slast = (cnt & DESC_CHAIN) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)d[DESC_NEXT + 1]) : slast_part;
+                        int32_t lo = (int32_t)sfirst - cs, hi = (int32_t)slast - cs;
+                        lo = lo < 0 ? 0 : lo;
+                        hi = hi > 63 ? 63 : hi;
+                        if ((int32_t)(slast - sfirst) < 0 || lo > hi) continue;      // empty run, or not in this chunk
+                        C = (~0ull >> (63 - hi)) & (~0ull << lo);
+                        const uint32_t rbase = boff - sq0_lo;
+                        if (cnt & DESC_CHAIN) {
+                            if (ablate & 2u) continue;
+                            // indel operations that fill more than one descriptor: the general walk over the parts (they live in HBM)
+                            const SeqLds sq{seqb + rbase};
+                            const int32_t jj = is_ins ? (int32_t)jju : -1;
+                            uint32_t rsym = 0, nv = 0;
+                            vote_part<E>(d, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nv);
+                            uint32_t nx = d[DESC_NEXT];
+                            while (nx) {
+                                const uint32_t* dg = ovf_pool + (uint64_t)(nx - 1) * DESC_WORDS;
+                                vote_part<E>(dg, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nv);
+                                nx = dg[DESC_NEXT];
+                            }
+                            continue;
+                        }
+                        // ---- segments and insertions of one descriptor: which lanes vote a base of the read, and which one
+                        const uint32_t nseg = cnt & 0xffu, nins = (cnt >> 8) & 0xffu;
+                        uint32_t q = 0;
+                        unsigned long long BASE = 0ull;
+                        for (uint32_t k2 = 0; k2 < nseg; ++k2) {
+                            const uint2 sk = *reinterpret_cast<const uint2*>(d + DESC_SEG0 + 2 * k2);
+                            const uint32_t glo = k2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sk.x) : seg0_g;
+                            const uint32_t w = k2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sk.y) : seg0_w;
+                            const uint32_t off = g - glo;
+                            const unsigned long long in = __ballot(off < (w & 0xffffu)) & C & ~INS;
+                            if ((w >> 16) != 0xffffu) {
+                                q = sel_lane_mask(q, (w >> 16) + off, in);
+                                BASE |= in;
+                            }
+                        }
+                        for (uint32_t k2 = 0; k2 < nins; ++k2) {
+                            const uint2 ik = *reinterpret_cast<const uint2*>(d + DESC_INS0 + 2 * k2);
+                            const uint32_t pp = (uint32_t)__builtin_amdgcn_readfirstlane((int)ik.x), w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ik.y);
+                            const unsigned long long in = __ballot(g == pp && jju < (w & 0xffffu)) & C & INS;
+                            q = sel_lane_mask(q, (w >> 16) + jju, in);
+                            BASE |= in;
+                        }
+                        q = sel_lane_mask(0u, q, BASE);
+                        const uint32_t byte = seqb[rbase + (q >> 1)];
+                        sym = sel_lane_mask(3u, (byte >> ((~q & 1u) << 2)) & 0xfu, BASE);
+                    }
+                    // ---- agreement with the draft, all of it on masks
+                    const unsigned long long A = __ballot(sym == dsym) & C;
+                    NS |= C ^ A;
+                    const unsigned long long M0 = A & ((A << 1) | F1) & ((A << 2) | F2);
+                    add_lane_mask(vl.c0, M0 & ~3ull);
+                    const unsigned long long Rm = (C & ~3ull) & ~M0;
+                    if (Rm != 0ull && !(ablate & 1u)) {      // some lane's context is not the draft's: contexts from the neighbours, tallied per lane
+                        const uint32_t symc = sel_lane_mask(0u, sym, C);
+                        const uint32_t p1 = wave_shr1(symc), p2 = wave_shr1(p1);
+                        const uint32_t k = p2 << 8 | p1 << 4 | symc;
+                        const unsigned long long M1 = __ballot(k == vl.k1) & Rm;
+                        add_lane_mask(vl.c1, M1);
+                        const unsigned long long rest = Rm & ~M1;
+                        if (rest != 0ull) {
+                            if ((rest >> lane) & 1ull) vl.tally(k, L, lane);   // a context seen for the first time, or one kept in the LDS list
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const bool ovf_any = chunk_ok && __ballot(vl.ovf) != 0ull;
+    // a slot is single-state when nothing but the draft's own symbol voted on it
+    const bool single = !((NS >> lane) & 1ull) && (basemask & ~(1u << dsym)) == 0u;
+    const uint32_t psingle = wave_shr1((uint32_t)single);
+    const bool prev_is_single = first || psingle != 0;
+    // vote statistic: every tally of an own slot but the draft's own one
+    uint32_t nvotes = 0;
+    if (valid && lane >= 2) {
+        nvotes = vl.c0 + vl.c1 - 1u;
+        for (uint32_t e = 2; e < vl.n; ++e) nvotes += L[(e - 2) * 64 + lane] & 0xffffu;
+    }
+    for (int o = 32; o > 0; o >>= 1) nvotes += __shfl_down(nvotes, o);
+    tile_epilogue<E, NW>(vl, L, tid, c, chunk_ok && !ovf_any, ovf_any, valid, s, info, dsym, first, prev_dsym, single, prev_is_single,
+                         vl.total(L, lane), slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci,
+                         flag_single & 0xffu, nvotes, votes, (flag_single & FLAG_ALL_RECORDS) != 0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_tile5 (default): event form of the pileup vote (np1_events.h).  Same tile geometry, staging and epilogue as
 // k_tile3, but the per-(record, slot) vote loop is gone:
 //   phase R  one lane per candidate record: +1/-1 into the tile's coverage difference array, and the record's
@@ -1425,6 +1669,33 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
     else if (level == 1) NP1_TILE3(64, 1, 13312u);
     else NP1_TILE3(160, 1, 24576u);
 #undef NP1_TILE3
+    return 0;
+}
+
+int launch_tile7(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool, const uint32_t* chunk_first,
+                 const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S, uint32_t max_lq,
+                 uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters, uint32_t* heads, uint32_t heads_cap,
+                 uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes) {
+    constexpr int E7 = 8, NW7 = 8;
+    const uint32_t seq_w = (((max_lq + 1) >> 1) + 3) / 4 + 1;   // packed bases per record, in words (upper bound)
+    const uint32_t fixed = (uint32_t)NW7 * (uint32_t)(E7 - 2) * 64u + 8u + (uint32_t)DESC_WORDS;
+    const uint32_t per = (uint32_t)DESC_WORDS + seq_w;
+    static const uint32_t budget_env = getenv("NP1_TILE7_LDS_WORDS") ? (uint32_t)atoi(getenv("NP1_TILE7_LDS_WORDS")) : 13312u;   // 52 KiB: three workgroups per CU
+    uint32_t budget = budget_env;
+    if (budget < fixed + per) budget = fixed + per;
+    if (budget > 40960u - 64u) return -1;
+    uint32_t nb_max = (budget - fixed) / per;
+    if (nb_max > 512u) nb_max = 512u;
+    const uint32_t bytes = (fixed + nb_max * per) * 4u;
+    const uint32_t items = (n_chunks + NW7 - 1) / NW7;
+    if (items == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile7<E7, NW7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        attr_set = true;
+    }
+    k_tile7<E7, NW7><<<items, NW7 * 64, bytes, st>>>(R, soff, desc, ovf_pool, chunk_first, chunk_last, n_chunks, nullptr, items, slot_info, slot_g, S, seq_w,
+                                                      nb_max, slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci, flag_single, votes, ablate_env());
     return 0;
 }
 
