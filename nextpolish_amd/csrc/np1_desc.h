@@ -13,9 +13,11 @@
 
 namespace np1k {
 
-constexpr int DESC_NSEG = 5, DESC_NINS = 2;
+constexpr int DESC_NSEG = 7, DESC_NINS = 2;
 constexpr int DESC_SEG0 = 4, DESC_INS0 = DESC_SEG0 + 2 * DESC_NSEG, DESC_NEXT = DESC_INS0 + 2 * DESC_NINS;
-constexpr int DESC_WORDS = DESC_NEXT + 2;   // 20 words = 80 B per record
+constexpr int DESC_WORDS = DESC_NEXT + 2;   // 24 words = 96 B per record (seven segments: a read with up to three deletions, or two
+                                            // deletions and two insertions, stays in one descriptor; five segments sent 4 % of the records of a
+                                            // 0.5 %-indel draft to chained parts in HBM, which cost the tile kernels a tenth of their time)
 constexpr uint32_t DESC_CHAIN = 1u << 16;   // d[2] flag of a head part that continues in the overflow pool
 constexpr uint32_t DESC_SIMPLE = 1u << 17;  // d[2] flag: the whole record is ONE matched segment (no deletion, no insertion, no further part)
 // d[0]=sfirst d[1]=slast (this part)  d[2]=nseg | nins<<8 | flags  d[3]=low word of the record's offset in the base pool
@@ -179,6 +181,71 @@ NP1_HD uint32_t desc_symbol(const uint32_t* d, uint32_t g, int32_t jj, Sq sq) {
         if (d[DESC_INS0 + 2 * k] == g && (uint32_t)jj < (w & 0xffffu)) return sq((int32_t)((w >> 16) + (uint32_t)jj));
     }
     return 3u;   // an insertion column this record only passes through (or pads): DEL
+}
+
+// ---- where a record disagrees with the draft (k_tile8) ------------------------------------------------------------------------
+// Most votes repeat the draft: a record adds 1 to the count of the draft's own 3-base context on every slot it covers, and that is
+// all it does -- except around the places where it differs from the draft (a substituted base, a deletion, an insertion) and on the
+// first two slots of its run (whose contexts lack predecessors).  k_tile8 handles the plain stretches of a record with one masked add
+// per 64-slot chunk and evaluates symbols only inside the record's DIRTY HULL, computed here once per record: the slot interval from its
+// first disagreeing vote to two slots behind its last one (a vote at slot m enters the contexts of m, m + 1 and m + 2).  Conservative
+// by construction: anything not proven to agree is inside the hull (deletions, insertions, chained descriptors as a whole).
+// Packed comparison: the read's bases are 4-bit nt16 codes, two per byte, first base in the high nibble (BAM); `dpack` holds the
+// draft's codes (draft_code of the upper-cased letter = the base slot's symbol, slotinfo_base) in the same layout, so eight bases are
+// one XOR of two byte-swapped words.
+NP1_HD uint32_t nib8(const uint8_t* p, uint64_t n) {   // 8 nibbles from nibble index n on, first one in bits 31..28
+    const uint8_t* b = p + (n >> 1);
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    uint32_t v = __builtin_bswap32(*reinterpret_cast<const u32u*>(b));
+    if (n & 1) v = (v << 4) | (uint32_t)(b[4] >> 4);
+    return v;
+}
+constexpr uint32_t DIRTY_NONE = 0xffffffffu;   // every vote of the record agrees with the draft
+// packed result: (first dirty slot - sfirst) | (last dirty slot - sfirst) << 16, offsets saturating at 0xfffe
+template <class So>
+NP1_HD uint32_t desc_dirty_hull(const uint32_t* d, const uint8_t* seq, const uint8_t* dpack, So so) {
+    const uint32_t sfirst = d[0], slast = d[1], cnt = d[2];
+    if ((int32_t)(slast - sfirst) < 0 && !(cnt & DESC_CHAIN)) return DIRTY_NONE;   // votes on nothing
+    if (cnt & DESC_CHAIN) return 0xfffeu << 16;                                    // more parts than this one: all of it
+    uint32_t smin = 0xffffffffu, smax = 0;
+    const uint32_t nseg = cnt & 0xffu, nins = (cnt >> 8) & 0xffu;
+    for (uint32_t k = 0; k < nseg; ++k) {
+        const uint32_t g_lo = d[DESC_SEG0 + 2 * k], w = d[DESC_SEG0 + 2 * k + 1], len = w & 0xffffu, qc = w >> 16;
+        if (!len) continue;
+        uint32_t f = 0xffffffffu, l = 0;          // first / last disagreeing offset inside the segment
+        if (qc == 0xffffu) { f = 0; l = len - 1; }   // a deletion votes DEL on base slots
+        else
+            for (uint32_t t = 0; t < len; t += 8) {
+                uint32_t x = nib8(seq, (uint64_t)qc + t) ^ nib8(dpack, (uint64_t)g_lo + t);
+                const uint32_t left = len - t;
+                if (left < 8) x &= ~0u << (4 * (8 - left));
+                if (x) {
+                    const uint32_t a = t + ((uint32_t)__builtin_clz(x) >> 2), b = t + 7u - ((uint32_t)__builtin_ctz(x) >> 2);
+                    if (a < f) f = a;
+                    if (b > l) l = b;
+                }
+            }
+        if (f != 0xffffffffu) {
+            const uint32_t a = so(g_lo + f), b = so(g_lo + l);
+            if (a < smin) smin = a;
+            if (b > smax) smax = b;
+        }
+    }
+    for (uint32_t k = 0; k < nins; ++k) {         // bases in insertion columns (the draft's symbol there is DEL)
+        const uint32_t p = d[DESC_INS0 + 2 * k], len = d[DESC_INS0 + 2 * k + 1] & 0xffffu;
+        const uint32_t a = so(p) + 1, b = so(p) + len;
+        if (a < smin) smin = a;
+        if (b > smax) smax = b;
+    }
+    if (smin == 0xffffffffu) return DIRTY_NONE;
+    if (smin < sfirst) smin = sfirst;
+    uint32_t e = smax + 2;
+    if (e > slast) e = slast;
+    if (e < smin) e = smin;
+    uint32_t fo = smin - sfirst, lo = e - sfirst;
+    if (fo > 0xfffeu) fo = 0xfffeu;
+    if (lo > 0xfffeu) lo = 0xfffeu;
+    return fo | lo << 16;
 }
 
 // k_desc body: descriptor (+ overflow parts) and the vote chunks the record's votes can touch

@@ -331,6 +331,9 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     } else {
         // ---- stage 3 (fused): record descriptors (+ overflow parts) and the candidate record range of every vote chunk
         if (b->desc.ensure(4 * (size_t)DESC_WORDS * nn)) return -1;
+        static const int tile_kind_desc = getenv("NP1_TILE") ? atoi(getenv("NP1_TILE")) : 3;
+        const bool want_hulls = tile_kind_desc == 8 && !fp_rate;      // k_tile8 reads the records' dirty hulls
+        if (want_hulls && (b->dpack.ensure((size_t)G / 2 + 64) || b->dirty.ensure(4 * nn + 64))) return -1;
         if (b->ovf_desc.cap == 0 && b->ovf_desc.ensure(4 * (size_t)DESC_WORDS * (nn / 64 + 4096))) return -1;
         for (int attempt = 0;; ++attempt) {
             const uint32_t ovf_cap = (uint32_t)std::min<size_t>(b->ovf_desc.cap / (4 * DESC_WORDS), 0x7fffffffu);
@@ -338,8 +341,10 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
             HIPCHK(hipMemsetAsync(b->chunk_last.p, 0, 4 * (size_t)n_chunks, q));
             HIPCHK(hipMemsetAsync(&counters[CNT_OVFDESC], 0, 4, q));
             t0(3);
+            if (want_hulls) launch_dpack(q, b->draft.as<uint8_t>(), (uint32_t)G, b->dpack.as<uint8_t>());
             launch_desc(q, R, n, ctg_off, b->soff.as<uint32_t>(), b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->desc.as<uint32_t>(),
-                        b->ovf_desc.as<uint32_t>(), ovf_cap, b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), counters);
+                        b->ovf_desc.as<uint32_t>(), ovf_cap, b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), counters,
+                        want_hulls ? b->dpack.as<uint8_t>() : nullptr, want_hulls ? b->dirty.as<uint32_t>() : nullptr);
             t1(3);
             HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
             HIPCHK(hipStreamSynchronize(q));
@@ -384,6 +389,11 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                                    b->slot_g.as<uint32_t>(), S, b->max_lq, b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(),
                                    b->pool.as<uint32_t>(), pool_cap, counters, b->heads.as<uint32_t>(), heads_cap5,
                                    b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes, dbg);
+            else if (tile_kind == 8)
+                rc5 = launch_tile8(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->dirty.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
+                                   b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(), b->slot_g.as<uint32_t>(), S,
+                                   b->max_lq, b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
+                                   b->heads.as<uint32_t>(), heads_cap5, b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes);
             else if (tile_kind == 7)
                 rc5 = launch_tile7(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(), b->chunk_first.as<uint32_t>(),
                                    b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(), b->slot_g.as<uint32_t>(), S, b->max_lq,

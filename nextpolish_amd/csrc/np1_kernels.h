@@ -28,7 +28,14 @@ void launch_vote(hipStream_t st, int E, const uint4* meta, const uint8_t* rows, 
                  uint32_t* counters, uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single);
 void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
                  const int32_t* qs, const int32_t* qe, uint32_t* desc, uint32_t* ovf_pool, uint32_t ovf_cap,
-                 uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters);
+                 uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters, const uint8_t* dpack = nullptr, uint32_t* dirty = nullptr);
+// the draft as packed 4-bit codes (the layout of the reads' bases): what k_desc compares the records with for their dirty hulls
+void launch_dpack(hipStream_t st, const uint8_t* draft, uint32_t G, uint8_t* dpack);
+// k_tile8: plain (record, chunk) pairs as one masked add, per-lane evaluation only inside a record's dirty hull (np1_kernels.hip)
+int launch_tile8(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* dirty, const uint32_t* ovf_pool,
+                 const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S,
+                 uint32_t max_lq, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters, uint32_t* heads,
+                 uint32_t heads_cap, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes);
 // default fused kernel (descriptors + packed bases staged through LDS); levels as launch_tile
 int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc,
                  const uint32_t* ovf_pool, const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint32_t* redo_in,

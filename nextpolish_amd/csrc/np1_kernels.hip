@@ -254,6 +254,16 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 }
 
+// the draft's symbols as 4-bit codes, two per byte, first base in the high nibble (the layout of the reads' bases): one lane per byte
+__global__ __launch_bounds__(256) void k_dpack(const uint8_t* __restrict__ draft, uint32_t G, uint8_t* __restrict__ dpack) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * (uint64_t)i >= G) return;
+    uint32_t a = draft[2 * i], b = 2 * i + 1 < G ? draft[2 * i + 1] : (uint32_t)'=';
+    if (a >= 97 && a <= 122) a -= 32;
+    if (b >= 97 && b <= 122) b -= 32;
+    dpack[i] = (uint8_t)(draft_code(a) << 4 | draft_code(b));
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_desc (fused pipeline, default): one lane per record -> its descriptor (np1_core.h build_desc) and the
 // candidate record range of every vote chunk (wave-aggregated min/max instead of per-record atomics)
@@ -262,11 +272,16 @@ __global__ __launch_bounds__(256) void k_desc(ReadsDev R, int64_t n_reads, const
                                               const int32_t* __restrict__ qe, uint32_t* __restrict__ desc,
                                               uint32_t* __restrict__ ovf_pool, uint32_t ovf_cap,
                                               uint32_t* __restrict__ chunk_first, uint32_t* __restrict__ chunk_last,
-                                              uint32_t* __restrict__ counters) {
+                                              uint32_t* __restrict__ counters, const uint8_t* __restrict__ dpack,
+                                              uint32_t* __restrict__ dirty) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t c0 = 1, c1 = 0;
-    if (r < n_reads) desc_record(R, r, ctg_off, soff, qs, qe, desc, ovf_pool, ovf_cap, counters, &c0, &c1);
+    if (r < n_reads) {
+        desc_record(R, r, ctg_off, soff, qs, qe, desc, ovf_pool, ovf_cap, counters, &c0, &c1);
+        // where the record disagrees with the draft (k_tile8 evaluates symbols only there)
+        if (dirty) dirty[r] = desc_dirty_hull(desc + (uint64_t)r * DESC_WORDS, R.seq + R.seq_off[r], dpack, SoGlobal{soff});
+    }
     const bool has = c0 <= c1;
     if (__ballot(has) == 0ull) return;
     uint32_t lo = has ? c0 : 0xffffffffu, hi = has ? c1 : 0u;
@@ -795,6 +810,277 @@ __global__ __launch_bounds__(NW * 64) void k_tile7(ReadsDev R, const uint32_t* _
                         const unsigned long long rest = Rm & ~M1;
                         if (rest != 0ull) {
                             if ((rest >> lane) & 1ull) vl.tally(k, L, lane);   // a context seen for the first time, or one kept in the LDS list
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const bool ovf_any = chunk_ok && __ballot(vl.ovf) != 0ull;
+    // a slot is single-state when nothing but the draft's own symbol voted on it
+    const bool single = !((NS >> lane) & 1ull) && (basemask & ~(1u << dsym)) == 0u;
+    const uint32_t psingle = wave_shr1((uint32_t)single);
+    const bool prev_is_single = first || psingle != 0;
+    // vote statistic: every tally of an own slot but the draft's own one
+    uint32_t nvotes = 0;
+    if (valid && lane >= 2) {
+        nvotes = vl.c0 + vl.c1 - 1u;
+        for (uint32_t e = 2; e < vl.n; ++e) nvotes += L[(e - 2) * 64 + lane] & 0xffffu;
+    }
+    for (int o = 32; o > 0; o >>= 1) nvotes += __shfl_down(nvotes, o);
+    tile_epilogue<E, NW>(vl, L, tid, c, chunk_ok && !ovf_any, ovf_any, valid, s, info, dsym, first, prev_dsym, single, prev_is_single,
+                         vl.total(L, lane), slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci,
+                         flag_single & 0xffu, nvotes, votes, (flag_single & FLAG_ALL_RECORDS) != 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tile8 (default since round 3).  k_tile3 evaluates, for every (record, 64-slot chunk) pair, the record's symbol at every lane and
+// compares contexts -- 75 vector + 60 scalar instructions per pair, and the kernel is bound by exactly that instruction issue (one
+// vector and one scalar instruction per cycle and CU).  But most pairs are PLAIN: the record repeats the draft on every slot of the
+// chunk, so all it does is add 1 to the count of the draft's own context on the lanes it covers (minus the first two slots of its run,
+// whose contexts lack predecessors).  Which pairs are plain is known per record before the kernel starts: k_desc leaves the record's
+// dirty hull (np1_desc.h: from its first disagreeing vote to two slots behind its last one).  So:
+//   phase 1, lanes = 64 candidate records at a time: slot run -> covered lanes C (a 64-bit field per record, built with vector shifts),
+//            plain or dirty from the hull, and for plain pairs the finished mask M0 = C & (C << 1 | F1) & (C << 2 | F2) of the lanes
+//            whose whole context is the draft's (F1 / F2: lanes at a contig start);
+//   phase 2, records in file order (first-seen order of the contexts is the order of this loop): a plain pair is two v_readlane and one
+//            v_addc (count += M0); if the record's run starts inside the chunk its first two lanes tally the contexts (0, 0, d) and
+//            (0, d', d) straight from the draft's symbols; a dirty pair takes the per-lane evaluation (the body of k_tile7: symbols
+//            from the staged bases, agreement as scalar lane masks, DPP contexts only where they differ from the draft's).
+// Same staging, same LDS lists, same epilogue, same results as k_tile3.
+template <int E, int NW>
+__global__ __launch_bounds__(NW * 64) void k_tile8(ReadsDev R, const uint32_t* __restrict__ soff,
+                                                   const uint32_t* __restrict__ desc,
+                                                   const uint32_t* __restrict__ dirty,
+                                                   const uint32_t* __restrict__ ovf_pool,
+                                                   const uint32_t* __restrict__ chunk_first,
+                                                   const uint32_t* __restrict__ chunk_last, uint32_t n_chunks,
+                                                   uint32_t n_items,
+                                                   const uint8_t* __restrict__ slot_info,
+                                                   const uint32_t* __restrict__ slot_g, uint32_t S, uint32_t seq_w,
+                                                   uint32_t nb_max, uint16_t* __restrict__ slot_res,
+                                                   uint32_t* __restrict__ slot_rec, uint32_t* __restrict__ pool,
+                                                   uint32_t pool_cap, uint32_t* __restrict__ counters,
+                                                   uint32_t* __restrict__ heads, uint32_t heads_cap,
+                                                   uint32_t* __restrict__ redo_out,
+                                                   uint32_t redo_ci, uint32_t flag_single,
+                                                   unsigned long long* __restrict__ votes, uint32_t ablate) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ __attribute__((aligned(16))) uint32_t sh_r[4];
+    uint32_t* lists = lds;                             // NW * (E-2) * 64
+    uint32_t* dsc = lists + NW * (E - 2) * 64;         // nb_max * DESC_WORDS
+    uint32_t* dty = dsc + nb_max * DESC_WORDS;         // nb_max (rounded up to 4)
+    uint32_t* seqst = dty + ((nb_max + 3u) & ~3u);     // nb_max * seq_w + 8
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    const uint32_t cbase = item * NW;
+    const uint32_t c = cbase + (uint32_t)wave;
+    const bool chunk_ok = c < n_chunks;
+    if (tid == 0) {
+        uint32_t r0 = 0xffffffffu, r1 = 0;
+        for (int w = 0; w < NW; ++w) {
+            uint32_t cc = cbase + w;
+            if (cc < n_chunks) {
+                uint32_t f = chunk_first[cc];
+                if (f != 0xffffffffu) {
+                    if (f < r0) r0 = f;
+                    uint32_t l = chunk_last[cc];
+                    if (l > r1) r1 = l;
+                }
+            }
+        }
+        sh_r[0] = r0;
+        sh_r[1] = r1;
+    }
+    uint32_t* L = lists + wave * (E - 2) * 64;
+    const int64_t s64 = (int64_t)c * VOTE_CH - 2 + lane;
+    const bool valid = chunk_ok && s64 >= 0 && s64 < (int64_t)S;
+    const uint32_t s = (uint32_t)s64;
+    const uint32_t info = valid ? slot_info[s] : 0u;
+    const uint32_t g = valid ? slot_g[s] : 0u;
+    const bool is_ins = valid && (info & SI_INSERT);
+    const uint32_t jju = is_ins ? (s - soff[g]) - 1u : 0u;   // insertion column of an insertion slot
+    const uint32_t dsym = info & 0xf;
+    const bool first = (info & SI_FIRST) != 0;
+    uint32_t d1 = wave_shr1(dsym), d2 = wave_shr1(d1);
+    const uint32_t f1 = wave_shr1((uint32_t)first);
+    const uint32_t prev_dsym = d1;
+    if (first) { d1 = 0; d2 = 0; }
+    else if (f1) d2 = 0;
+    VoteLane<E> vl;
+    vl.init(d2 << 8 | d1 << 4 | dsym);
+    const uint32_t kstart1 = d1 << 4 | dsym;            // context of the second slot of a run that repeats the draft: (0, d', d)
+    const unsigned long long INS = __ballot(is_ins);   // (lanes 0 and 1 are the halo: they never vote)
+    const unsigned long long F1 = __ballot(first), F2 = __ballot(first || f1 != 0);
+    const uint32_t F1lo = (uint32_t)F1, F1hi = (uint32_t)(F1 >> 32), F2lo = (uint32_t)F2, F2hi = (uint32_t)(F2 >> 32);
+    unsigned long long NS = 0;          // lanes where something other than the draft's own symbol voted
+    uint32_t basemask = 0;              // the same per lane, from the general path (chained records)
+    const int32_t cs = (int32_t)((int64_t)c * VOTE_CH - 2);   // slot of lane 0 (may be -2 for chunk 0)
+    uint32_t wf = 0xffffffffu, wl = 0;
+    if (chunk_ok) { wf = chunk_first[c]; wl = chunk_last[c]; }
+    wf = (uint32_t)__builtin_amdgcn_readfirstlane((int)wf);
+    wl = (uint32_t)__builtin_amdgcn_readfirstlane((int)wl);
+    __syncthreads();
+    const uint32_t r0 = sh_r[0], r1 = sh_r[1];
+    if (r0 != 0xffffffffu) {
+        for (uint64_t rb = r0; rb <= r1; rb += nb_max) {
+            const uint32_t nb = (uint32_t)((r1 - rb + 1 < nb_max) ? (r1 - rb + 1) : nb_max);
+            // ---- stage descriptors, dirty hulls and packed bases of the batch (all contiguous in HBM): coalesced
+            {
+                const uint4* dsrc = reinterpret_cast<const uint4*>(desc + rb * DESC_WORDS);
+                uint4* ddst = reinterpret_cast<uint4*>(dsc);
+                for (uint32_t i = tid; i < nb * (DESC_WORDS / 4); i += NW * 64) ddst[i] = dsrc[i];
+                for (uint32_t i = tid; i < nb; i += NW * 64) dty[i] = dirty[rb + i];
+            }
+            const uint64_t sq0 = R.seq_off[rb] & ~15ull;
+            const uint64_t sq1 = R.seq_off[rb + nb - 1] + (((uint64_t)R.l_qseq[rb + nb - 1] + 1) >> 1);
+            const uint32_t sq_quads = (uint32_t)((sq1 - sq0 + 15) >> 4);
+            const uint32_t sq_fit = sq_quads * 4 <= nb_max * seq_w + 8 ? sq_quads : (nb_max * seq_w + 8) / 4;
+            if (sq_fit != sq_quads && tid == 0) atomicOr(&counters[CNT_ERR], ERR_BAD_RECORD);
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(R.seq + sq0);
+                uint4* dst = reinterpret_cast<uint4*>(seqst);
+                for (uint32_t i = tid; i < sq_fit; i += NW * 64) dst[i] = src[i];
+            }
+            const uint32_t sq0_lo = (uint32_t)sq0;   // descriptors carry the low word of their record's pool offset
+            __syncthreads();
+            if (wf != 0xffffffffu && !(ablate & 16u)) {
+                const uint8_t* seqb = reinterpret_cast<const uint8_t*>(seqst);
+                const uint64_t ia = wf > rb ? wf : rb, ib = (uint64_t)wl < rb + nb - 1 ? (uint64_t)wl : rb + nb - 1;
+                const int32_t lb = ia <= ib ? (int32_t)(ib - rb) : -1;
+                for (int32_t gb = lb >= 0 ? (int32_t)(ia - rb) : 0; gb <= lb; gb += 64) {
+                    // ---- phase 1: my record of this group of 64
+                    const int32_t li = gb + lane;
+                    const bool act = li <= lb;
+                    uint4 hv = make_uint4(1u, 0u, 0u, 0u);
+                    uint2 sg = make_uint2(0u, 0u);
+                    uint32_t dw = DIRTY_NONE, slast = 0;
+                    if (act) {
+                        hv = *reinterpret_cast<const uint4*>(dsc + (uint32_t)li * DESC_WORDS);
+                        sg = *reinterpret_cast<const uint2*>(dsc + (uint32_t)li * DESC_WORDS + DESC_SEG0);
+                        dw = dty[li];
+                        slast = (hv.z & DESC_CHAIN) ? dsc[(uint32_t)li * DESC_WORDS + DESC_NEXT + 1] : hv.y;
+                    }
+                    int32_t lo = (int32_t)hv.x - cs, hi = (int32_t)slast - cs;
+                    lo = lo < 0 ? 0 : lo;
+                    hi = hi > 63 ? 63 : hi;
+                    const bool live = act && (int32_t)(slast - hv.x) >= 0 && lo <= hi;
+                    unsigned long long Cm = live ? (~0ull >> (63 - hi)) & (~0ull << lo) : 0ull;
+                    bool isdirty = (hv.z & DESC_CHAIN) != 0;
+                    if (dw != DIRTY_NONE) {
+                        const int32_t dl = (int32_t)hv.x + (int32_t)(dw & 0xffffu) - cs;
+                        const int32_t dh = (dw >> 16) >= 0xfffeu ? 0x7fffffff : (int32_t)hv.x + (int32_t)(dw >> 16) - cs;
+                        isdirty = isdirty || !(dh < lo || dl > hi);
+                    }
+                    const uint32_t Clo = (uint32_t)Cm, Chi = (uint32_t)(Cm >> 32);
+                    // lanes whose whole context is the draft's, if the record repeats the draft on all of C
+                    const unsigned long long C1 = Cm << 1, C2 = Cm << 2;
+                    const uint32_t M0lo = Clo & ((uint32_t)C1 | F1lo) & ((uint32_t)C2 | F2lo) & ~3u;
+                    const uint32_t M0hi = Chi & ((uint32_t)(C1 >> 32) | F1hi) & ((uint32_t)(C2 >> 32) | F2hi);
+                    const bool starts = ((Clo & ~3u) & ~M0lo) != 0u || (Chi & ~M0hi) != 0u;   // covered voting lanes without the full context
+                    unsigned long long todo = __ballot(live);
+                    const unsigned long long DIRTY = __ballot(live && isdirty), START = __ballot(live && !isdirty && starts);
+                    if (ablate & 4u) todo = 0ull;
+                    // ---- phase 2: the records of the group in file order
+                    while (todo != 0ull) {
+                        const int r = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        if (!((DIRTY >> r) & 1ull)) {
+                            // plain pair: count(draft's context) += 1 on the lanes with the full context
+                            const unsigned long long M0 = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)M0lo, r) |
+                                                          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)M0hi, r) << 32;
+                            add_lane_mask(vl.c0, M0);
+                            if ((START >> r) & 1ull) {
+                                // its run starts inside the chunk: the first two voting lanes see (0, 0, d) and (0, d', d)
+                                const unsigned long long C = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Clo, r) |
+                                                             (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Chi, r) << 32;
+                                const unsigned long long Rm = (C & ~3ull) & ~M0;
+                                const uint32_t k = ((C << 1) >> lane) & 1ull ? kstart1 : dsym;   // lane-1 covered: second slot of the run
+                                const unsigned long long M1 = __ballot(k == vl.k1) & Rm;
+                                add_lane_mask(vl.c1, M1);
+                                const unsigned long long rest = Rm & ~M1;
+                                if (rest != 0ull && !(ablate & 1u)) {
+                                    if ((rest >> lane) & 1ull) vl.tally(k, L, lane);
+                                }
+                            }
+                            continue;
+                        }
+                        if (ablate & 8u) continue;
+                        // ---- dirty pair: per-lane evaluation
+                        const uint32_t sfirst = (uint32_t)__builtin_amdgcn_readlane((int)hv.x, r), cnt = (uint32_t)__builtin_amdgcn_readlane((int)hv.z, r);
+                        const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)hv.w, r);
+                        const uint32_t seg0_g = (uint32_t)__builtin_amdgcn_readlane((int)sg.x, r), seg0_w = (uint32_t)__builtin_amdgcn_readlane((int)sg.y, r);
+                        const unsigned long long C = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Clo, r) |
+                                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Chi, r) << 32;
+                        const uint32_t* d = dsc + (uint32_t)(gb + r) * DESC_WORDS;
+                        const uint32_t rbase = boff - sq0_lo;
+                        (void)sfirst;
+                        uint32_t sym;
+                        if (cnt & DESC_SIMPLE) {
+                            const unsigned long long BASE = C & ~INS;
+                            const uint32_t q = sel_lane_mask(0u, g + ((seg0_w >> 16) - seg0_g), BASE);
+                            const uint32_t byte = seqb[rbase + (q >> 1)];
+                            sym = sel_lane_mask(3u, (byte >> ((~q & 1u) << 2)) & 0xfu, BASE);
+                        } else if (cnt & DESC_CHAIN) {
+                            if (ablate & 2u) continue;
+                            // indel operations that fill more than one descriptor: the general walk over the parts (they live in HBM)
+                            const SeqLds sq{seqb + rbase};
+                            const int32_t jj = is_ins ? (int32_t)jju : -1;
+                            uint32_t rsym = 0, nv = 0;
+                            vote_part<E>(d, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nv);
+                            uint32_t nx = d[DESC_NEXT];
+                            while (nx) {
+                                const uint32_t* dg = ovf_pool + (uint64_t)(nx - 1) * DESC_WORDS;
+                                vote_part<E>(dg, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nv);
+                                nx = dg[DESC_NEXT];
+                            }
+                            continue;
+                        } else {
+                            // segments and insertions of one descriptor: which lanes vote a base of the read, and which one
+                            const uint32_t nseg = cnt & 0xffu, nins = (cnt >> 8) & 0xffu;
+                            uint32_t q = 0;
+                            unsigned long long BASE = 0ull;
+                            for (uint32_t k2 = 0; k2 < nseg; ++k2) {
+                                const uint2 sk = *reinterpret_cast<const uint2*>(d + DESC_SEG0 + 2 * k2);
+                                const uint32_t glo = k2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sk.x) : seg0_g;
+                                const uint32_t w = k2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sk.y) : seg0_w;
+                                const uint32_t off = g - glo;
+                                const unsigned long long in = __ballot(off < (w & 0xffffu)) & C & ~INS;
+                                if ((w >> 16) != 0xffffu) {
+                                    q = sel_lane_mask(q, (w >> 16) + off, in);
+                                    BASE |= in;
+                                }
+                            }
+                            for (uint32_t k2 = 0; k2 < nins; ++k2) {
+                                const uint2 ik = *reinterpret_cast<const uint2*>(d + DESC_INS0 + 2 * k2);
+                                const uint32_t pp = (uint32_t)__builtin_amdgcn_readfirstlane((int)ik.x), w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ik.y);
+                                const unsigned long long in = __ballot(g == pp && jju < (w & 0xffffu)) & C & INS;
+                                q = sel_lane_mask(q, (w >> 16) + jju, in);
+                                BASE |= in;
+                            }
+                            q = sel_lane_mask(0u, q, BASE);
+                            const uint32_t byte = seqb[rbase + (q >> 1)];
+                            sym = sel_lane_mask(3u, (byte >> ((~q & 1u) << 2)) & 0xfu, BASE);
+                        }
+                        // agreement with the draft, all of it on masks
+                        const unsigned long long A = __ballot(sym == dsym) & C;
+                        NS |= C ^ A;
+                        const unsigned long long M0 = A & ((A << 1) | F1) & ((A << 2) | F2);
+                        add_lane_mask(vl.c0, M0 & ~3ull);
+                        const unsigned long long Rm = (C & ~3ull) & ~M0;
+                        if (Rm != 0ull && !(ablate & 1u)) {      // some lane's context is not the draft's: contexts from the neighbours, tallied per lane
+                            const uint32_t symc = sel_lane_mask(0u, sym, C);
+                            const uint32_t p1 = wave_shr1(symc), p2 = wave_shr1(p1);
+                            const uint32_t k = p2 << 8 | p1 << 4 | symc;
+                            const unsigned long long M1 = __ballot(k == vl.k1) & Rm;
+                            add_lane_mask(vl.c1, M1);
+                            const unsigned long long rest = Rm & ~M1;
+                            if (rest != 0ull) {
+                                if ((rest >> lane) & 1ull) vl.tally(k, L, lane);   // a context seen for the first time, or one kept in the LDS list
+                            }
                         }
                     }
                 }
@@ -1622,10 +1908,13 @@ void launch_vote(hipStream_t st, int E, const uint4* meta, const uint8_t* rows, 
 
 void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
                  const int32_t* qs, const int32_t* qe, uint32_t* desc, uint32_t* ovf_pool, uint32_t ovf_cap,
-                 uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters) {
+                 uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters, const uint8_t* dpack, uint32_t* dirty) {
     if (n_reads == 0) return;
     k_desc<<<nblk(n_reads, 256), 256, 0, st>>>(R, n_reads, ctg_off, soff, qs, qe, desc, ovf_pool, ovf_cap, chunk_first,
-                                               chunk_last, counters);
+                                               chunk_last, counters, dpack, dirty);
+}
+void launch_dpack(hipStream_t st, const uint8_t* draft, uint32_t G, uint8_t* dpack) {
+    if (G) k_dpack<<<nblk(((uint64_t)G + 1) / 2, 256), 256, 0, st>>>(draft, G, dpack);
 }
 
 static uint32_t ablate_env() {   // timing experiments only (results are wrong when set)
@@ -1696,6 +1985,34 @@ int launch_tile7(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const 
     }
     k_tile7<E7, NW7><<<items, NW7 * 64, bytes, st>>>(R, soff, desc, ovf_pool, chunk_first, chunk_last, n_chunks, nullptr, items, slot_info, slot_g, S, seq_w,
                                                       nb_max, slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci, flag_single, votes, ablate_env());
+    return 0;
+}
+
+int launch_tile8(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* dirty, const uint32_t* ovf_pool,
+                 const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S,
+                 uint32_t max_lq, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters, uint32_t* heads,
+                 uint32_t heads_cap, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes) {
+    constexpr int E8 = 8, NW8 = 8;
+    const uint32_t seq_w = (((max_lq + 1) >> 1) + 3) / 4 + 1;   // packed bases per record, in words (upper bound)
+    const uint32_t fixed = (uint32_t)NW8 * (uint32_t)(E8 - 2) * 64u + 8u + 4u;
+    const uint32_t per = (uint32_t)DESC_WORDS + 1u + seq_w;
+    static const uint32_t budget_env = getenv("NP1_TILE8_LDS_WORDS") ? (uint32_t)atoi(getenv("NP1_TILE8_LDS_WORDS")) : 13312u;   // 52 KiB: three workgroups per CU
+    uint32_t budget = budget_env;
+    if (budget < fixed + per) budget = fixed + per;
+    if (budget > 40960u - 64u) return -1;
+    uint32_t nb_max = (budget - fixed) / per;
+    if (nb_max > 512u) nb_max = 512u;
+    const uint32_t bytes = (fixed + nb_max * per) * 4u;
+    const uint32_t items = (n_chunks + NW8 - 1) / NW8;
+    if (items == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile8<E8, NW8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        attr_set = true;
+    }
+    k_tile8<E8, NW8><<<items, NW8 * 64, bytes, st>>>(R, soff, desc, dirty, ovf_pool, chunk_first, chunk_last, n_chunks, items, slot_info, slot_g, S, seq_w, nb_max,
+                                                      slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci, flag_single, votes,
+                                                      ablate_env());
     return 0;
 }
 

@@ -110,6 +110,9 @@ bool vote_chunk(uint32_t c, const std::vector<uint4>& meta, const std::vector<ui
     return true;
 }
 // fused sequence (k_desc + k_tile3): lanes evaluate record descriptors instead of reading symbol rows
+// k_tile8 emulation (np1m_fused == 4): the records' dirty hulls (np1_desc.h); plain (record, chunk) pairs take the masked-add path
+static const uint32_t* g_dirty = nullptr;
+
 template <int E>
 bool vote_chunk_desc(uint32_t c, const std::vector<uint32_t>& desc, const std::vector<uint32_t>& ovf, const ReadsDev& R, const std::vector<uint32_t>& soff,
                      const std::vector<uint8_t>& slot_info, const std::vector<uint32_t>& slot_g, uint32_t S,
@@ -118,7 +121,7 @@ bool vote_chunk_desc(uint32_t c, const std::vector<uint32_t>& desc, const std::v
                      std::vector<uint32_t>& heads, uint32_t flag_single) {
     std::vector<uint32_t> L((E - 2) * 64);
     VoteLane<E> vl[64];
-    uint32_t info[64], dsym[64], basemask[64], sym[64], g[64], s[64], prev_dsym[64];
+    uint32_t info[64], dsym[64], basemask[64], sym[64], g[64], s[64], prev_dsym[64], d1eff[64];
     int32_t jj[64];
     bool valid[64], first[64];
     for (int l = 0; l < 64; ++l) {
@@ -138,12 +141,37 @@ bool vote_chunk_desc(uint32_t c, const std::vector<uint32_t>& desc, const std::v
         if (first[l]) { d1 = 0; d2 = 0; }
         else if (f1) d2 = 0;
         vl[l].init(d2 << 8 | d1 << 4 | dsym[l]);
+        d1eff[l] = d1;
         basemask[l] = 1u << dsym[l];
     }
     uint32_t r0 = chunk_first[c], r1 = chunk_last[c];
     if (r0 != 0xffffffffu)
         for (uint32_t r = r0; r <= r1; ++r) {
             const uint32_t* d = desc.data() + (uint64_t)r * DESC_WORDS;
+            if (g_dirty && !(d[2] & DESC_CHAIN)) {     // what k_tile8 does with a pair whose chunk lies outside the record's dirty hull
+                const int32_t cs = (int32_t)((int64_t)c * VOTE_CH - 2);
+                if ((int32_t)(d[1] - d[0]) < 0) continue;
+                int32_t lo = (int32_t)d[0] - cs, hi = (int32_t)d[1] - cs;
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > 63 ? 63 : hi;
+                if (lo > hi) continue;
+                const uint32_t dw = g_dirty[r];
+                bool isdirty = false;
+                if (dw != DIRTY_NONE) {
+                    const int32_t dl = (int32_t)d[0] + (int32_t)(dw & 0xffffu) - cs;
+                    const int32_t dh = (dw >> 16) >= 0xfffeu ? 0x7fffffff : (int32_t)d[0] + (int32_t)(dw >> 16) - cs;
+                    isdirty = !(dh < lo || dl > hi);
+                }
+                if (!isdirty) {
+                    for (int l = lo < 2 ? 2 : lo; l <= hi; ++l) {
+                        const bool has1 = l - 1 >= lo, has2 = l - 2 >= lo;
+                        const bool full = (has1 || first[l]) && (has2 || first[l] || first[l - 1]);
+                        if (full) ++vl[l].c0;
+                        else vl[l].tally(has1 ? (d1eff[l] << 4 | dsym[l]) : dsym[l], L.data(), l);
+                    }
+                    continue;
+                }
+            }
             for (int l = 0; l < 64; ++l) sym[l] = 0;   // rsym: kept across the parts of a chained record
             for (;;) {
                 bool cov[64];
@@ -356,7 +384,22 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
             if (vote_chunk_events<64>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
             if (!vote_chunk_events<160>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) return -3;
         }
-        for (uint32_t c = 0; np1m_fused == 1 && c < n_chunks; ++c) {
+        std::vector<uint32_t> dirty_v;
+        g_dirty = nullptr;
+        if (np1m_fused == 4) {
+            std::vector<uint8_t> dpack((size_t)G / 2 + 64, 0);
+            for (uint64_t i = 0; 2 * i < G; ++i) {
+                uint32_t a = (uint8_t)v->draft[2 * i], b2 = 2 * i + 1 < G ? (uint8_t)v->draft[2 * i + 1] : (uint32_t)'=';
+                if (a >= 97 && a <= 122) a -= 32;
+                if (b2 >= 97 && b2 <= 122) b2 -= 32;
+                dpack[i] = (uint8_t)(draft_code(a) << 4 | draft_code(b2));
+            }
+            dirty_v.assign((size_t)(n ? n : 1), DIRTY_NONE);
+            for (int64_t r = 0; r < n; ++r)
+                dirty_v[(size_t)r] = desc_dirty_hull(desc.data() + (uint64_t)r * DESC_WORDS, seq_padded.data() + R.seq_off[r], dpack.data(), SoGlobal{soff.data()});
+            g_dirty = dirty_v.data();
+        }
+        for (uint32_t c = 0; (np1m_fused == 1 || np1m_fused == 4) && c < n_chunks; ++c) {
             if (vote_chunk_desc<8>(c, desc, ovf, R, soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
             ++escal;
             if (vote_chunk_desc<64>(c, desc, ovf, R, soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
