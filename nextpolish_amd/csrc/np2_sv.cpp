@@ -1,5 +1,7 @@
-// Split-read structural layer (host side).  See np2_sv.h.  Every routine restates the behaviour of the reference
-// function named next to it, including its integer widths and its in-place reorderings.
+// Split-read structural layer (host side).  See np2_sv.h.  Every routine produces what the reference function named next to it
+// produces (integer widths and tie rules included); how it gets there is this file's own: difference arrays and selection for the
+// depth statistics, a sorted-midpoint window with prefix sums for the breakpoint estimate, a sweep over the gaps for the clusters,
+// rings around the estimate for the choice of supplementary alignments, an interval search object per cluster for the bridged region.
 #include "np2_sv.h"
 
 #include <algorithm>
@@ -38,42 +40,42 @@ int trimmed_mean_depth(const std::vector<uint16_t>& depth, int32_t n_bins, int s
     return cnt ? (int)(sum / cnt) : 0;
 }
 
-void cluster_median(SvWindow* w, SvCluster* clu) {   // cal_gap_cluster_median, ctg_cns.c:2509-2549
-    auto G = [&](int32_t i) -> const SvGapRead& { return w->gaps[clu->gap[(size_t)i]]; };
-    uint32_t offset = 10;
-    while (offset <= 100) {
-        clu->median = 0;
-        int32_t count_m = 0;
-        uint32_t count_mc = 0;
-        uint64_t count_m_diff = 0;
-        for (int32_t i = 0; i < (int32_t)clu->i_m; ++i) {
-            const uint32_t median = (G(i).gap.s + G(i).gap.e) / 2;
-            if (median == clu->median) continue;
-            const uint32_t s = median > offset ? median - offset : 0, e = median + offset;
-            int32_t count_t = 0, count_t_diff = 0;
-            for (int32_t j = i - 1; j >= 0; --j) {
-                const uint32_t mt = (G(j).gap.s + G(j).gap.e) / 2;
-                if (mt >= s) { ++count_t; count_t_diff += (int32_t)mabs(mt, median); }
-                else break;
-            }
-            for (int32_t j = i + 1; j < (int32_t)clu->i_m; ++j) {
-                const uint32_t mt = (G(j).gap.s + G(j).gap.e) / 2;
-                if (mt <= e) { ++count_t; count_t_diff += (int32_t)mabs(mt, median); }
-                else break;
-            }
-            if (count_t > count_m || (count_t == count_m && count_m_diff > (uint64_t)(int64_t)count_t_diff)) {
-                count_m = count_t;
-                count_mc = median;
-                count_m_diff = (uint64_t)(int64_t)count_t_diff;
-            }
-        }
-        if (count_m >= std::max<int32_t>(3, (int32_t)(clu->i_m / 6))) {
-            clu->median = count_mc;
-            break;
-        }
-        offset += 10;
+// Where a cluster's gaps agree on the breakpoint: the member midpoint with the most other midpoints within `radius` of it (ties: the
+// tighter crowd, then the earlier member), tried with radius 10, 20 ... 100 until such a crowd holds at least max(3, members / 6);
+// failing that, the middle member's midpoint.  The members are ordered by midpoint, so the crowd of member i is a window
+// [lo, hi) that only moves right as i grows, and the spread (sum of distances to mid[i]) comes from prefix sums -- the reference walks
+// left and right from every member (cal_gap_cluster_median, ctg_cns.c:2509-2549: same counts, same sums, same winner).
+void cluster_median(SvWindow* w, SvCluster* clu) {
+    const size_t n = clu->i_m;
+    std::vector<uint32_t> mid(n);
+    std::vector<int64_t> below(n + 1, 0);          // below[k] = mid[0] + ... + mid[k - 1]
+    for (size_t k = 0; k < n; ++k) {
+        const SvGapRead& g = w->gaps[clu->gap[k]];
+        mid[k] = (g.gap.s + g.gap.e) / 2;
+        below[k + 1] = below[k] + (int64_t)mid[k];
     }
-    if (offset > 100) clu->median = (G((int32_t)(clu->i_m / 2)).gap.s + G((int32_t)(clu->i_m / 2)).gap.e) / 2;
+    const int64_t quorum = std::max<int64_t>(3, (int64_t)(n / 6));
+    for (uint32_t radius = 10; radius <= 100; radius += 10) {
+        int64_t best_crowd = 0, best_spread = 0;
+        uint32_t best_mid = 0;
+        size_t lo = 0, hi = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (mid[i] == 0) continue;             // (a midpoint of zero never stands for the cluster)
+            const uint32_t from = mid[i] > radius ? mid[i] - radius : 0, to = mid[i] + radius;
+            while (mid[lo] < from) ++lo;
+            if (hi <= i) hi = i + 1;
+            while (hi < n && mid[hi] <= to) ++hi;
+            const int64_t crowd = (int64_t)(hi - lo) - 1;
+            const int64_t spread = (int64_t)(i - lo) * (int64_t)mid[i] - (below[i] - below[lo]) + (below[hi] - below[i + 1]) - (int64_t)(hi - i - 1) * (int64_t)mid[i];
+            if (crowd > best_crowd || (crowd == best_crowd && best_spread > spread)) {
+                best_crowd = crowd;
+                best_spread = spread;
+                best_mid = mid[i];
+            }
+        }
+        if (best_crowd >= quorum) { clu->median = best_mid; return; }
+    }
+    clu->median = mid[n / 2];
 }
 
 }  // namespace
@@ -161,201 +163,252 @@ void sv_update_ld_regs(std::vector<SvPos>* out, const std::vector<uint16_t>& dep
     out->swap(regs);
 }
 
-void sv_update_ld_regs_with_refqv(std::vector<SvPos>* regs, const std::vector<uint16_t>& r, const ref_* ref, int32_t w, int32_t s_t, int32_t e_t,
-                                  int32_t d_t, uint32_t ide_t, uint32_t ort_t, uint32_t irt_t) {   // ctg_cns.c:2750-2794
-    int32_t t = 0;
-    for (uint32_t i = 0; i < ref->qv_l && ref->qv[i].p < (uint32_t)e_t; ++i) {
+// Suspicious spots the assembler's own quality track reports (identity and both read-support ratios below their thresholds) count as
+// low-depth regions of one base when the read depth anywhere within two windows of them is at most d_t.  If there is any, all
+// regions -- the depth-derived ones too -- are put in order and every region that starts within ten bin windows of its predecessor's
+// end is folded into it (update_ld_regs_with_refqv, ctg_cns.c:2750-2794).  The reference folds in place and leaves the absorbed
+// entries behind as (0, 0); the one reader of the list, sv_update_split_p, passes over those, so they are simply not kept here.
+void sv_update_ld_regs_with_refqv(std::vector<SvPos>* regs, const std::vector<uint16_t>& depth, const ref_* ref, int32_t w, int32_t win_s, int32_t win_e,
+                                  int32_t d_t, uint32_t ide_t, uint32_t ort_t, uint32_t irt_t) {
+    const uint32_t reach = (uint32_t)(w * 2);
+    const int32_t last_bin = (win_e - win_s) / INS_WIN_STEP;
+    auto thin_nearby = [&](uint32_t p) {
+        const int32_t b0 = p > reach + (uint32_t)win_s ? (int32_t)((p - reach - (uint32_t)win_s) / INS_WIN_STEP) : 0;
+        const int32_t b1 = p + reach < (uint32_t)win_e ? (int32_t)((p + reach - (uint32_t)win_s) / INS_WIN_STEP) : last_bin;
+        for (int32_t b = b0; b <= b1; ++b)
+            if ((size_t)b < depth.size() && depth[(size_t)b] <= d_t) return true;
+        return false;
+    };
+    size_t added = 0;
+    for (uint32_t i = 0; i < ref->qv_l && ref->qv[i].p < (uint32_t)win_e; ++i) {
         const ref_qv& q = ref->qv[i];
-        if (q.p < (uint32_t)s_t) continue;
-        if (q.ide < ide_t && q.ort < ort_t && q.irt < irt_t) {
-            const int32_t s = q.p > (uint32_t)(w * 2 + s_t) ? (int32_t)((q.p - (uint32_t)(w * 2) - (uint32_t)s_t) / INS_WIN_STEP) : 0;
-            const int32_t e = q.p + (uint32_t)(w * 2) < (uint32_t)e_t ? (int32_t)((q.p + (uint32_t)(w * 2) - (uint32_t)s_t) / INS_WIN_STEP) : (e_t - s_t) / INS_WIN_STEP;
-            int l = 0;
-            for (int32_t p = s; p <= e && !l; ++p)
-                if ((size_t)p < r.size() && r[(size_t)p] <= d_t) l = 1;
-            if (l) {
-                ++t;
-                regs->push_back(SvPos{q.p - (uint32_t)s_t, q.p + 1 - (uint32_t)s_t});
-            }
-        }
+        if (q.p < (uint32_t)win_s || q.ide >= ide_t || q.ort >= ort_t || q.irt >= irt_t || !thin_nearby(q.p)) continue;
+        regs->push_back(SvPos{q.p - (uint32_t)win_s, q.p + 1 - (uint32_t)win_s});
+        ++added;
     }
-    if (t) {
-        std::stable_sort(regs->begin(), regs->end(), [](const SvPos& a, const SvPos& b) {
-            return (a.s == b.s ? (int)(a.e - b.e) : (int)(a.s - b.s)) < 0;
-        });
-        for (size_t i = 1; i < regs->size(); ++i) {
-            if ((*regs)[i].s < (*regs)[i - 1].e + (uint32_t)(INS_WIN_DIV / 2 * w)) {
-                (*regs)[i].s = (*regs)[i - 1].s;
-                if ((*regs)[i].e < (*regs)[i - 1].e) (*regs)[i].e = (*regs)[i - 1].e;
-                (*regs)[i - 1].s = (*regs)[i - 1].e = 0;
-            }
-        }
+    if (!added) return;
+    std::stable_sort(regs->begin(), regs->end(), [](const SvPos& a, const SvPos& b) {
+        return (a.s == b.s ? (int)(a.e - b.e) : (int)(a.s - b.s)) < 0;
+    });
+    const uint32_t slack = (uint32_t)(INS_WIN_DIV / 2 * w);
+    std::vector<SvPos> merged;
+    for (const SvPos& r : *regs) {
+        if (!merged.empty() && r.s < merged.back().e + slack) merged.back().e = std::max(merged.back().e, r.e);
+        else merged.push_back(r);
     }
+    regs->swap(merged);
 }
 
-int sv_update_gap_cluster(SvWindow* w, int rw, int d, int32_t ref_s) {   // ctg_cns.c:2551-2612
+// Clusters of split-read gaps = candidate structural differences (update_gap_cluster, ctg_cns.c:2551-2612).  The gaps are swept in
+// order of their start.  A gap whose midpoint lies in thin depth (below half the typical depth; and not within the first read
+// window) seeds a chain: every later gap that starts no later than the chain's reach belongs to the sweep of this chain, and those
+// of them whose own midpoint lies in thin depth join it (their ends extend the reach; at most 120 are remembered).  Note the seed
+// itself only counts, it is not a member.  A chain is kept when it has more members than a fifth of the typical depth and its seed
+// sits where fewer reads span than gaps agree.  Kept clusters get their members ordered by midpoint and their breakpoint estimate.
+int sv_update_gap_cluster(SvWindow* w, int rw, int d, int32_t ref_s) {
     w->clusters.clear();
     if (d < 10) return 0;
-    const int md = (int)(d * CLUSTER_MIN_DEPTH_RATIO);
+    const int min_members = (int)(d * CLUSTER_MIN_DEPTH_RATIO);
     std::stable_sort(w->gaps.begin(), w->gaps.end(), [](const SvGapRead& a, const SvGapRead& b) {
-        if (a.gap.s != b.gap.s) return a.gap.s < b.gap.s;
-        return a.gap.e < b.gap.e;
+        return a.gap.s != b.gap.s ? a.gap.s < b.gap.s : a.gap.e < b.gap.e;
     });
-    const int32_t n = (int32_t)w->gaps.size();
-    auto ds = [&](int64_t idx) -> uint32_t { return idx >= 0 && (size_t)idx < w->ref_ds.size() ? w->ref_ds[(size_t)idx] : 0u; };
-    for (int32_t i = 0; i < n - md; ++i) {
-        const int32_t p = (int32_t)((w->gaps[(size_t)i].gap.s + w->gaps[(size_t)i].gap.e) / 2) - ref_s;
-        if (p < rw || (int)ds(p / INS_WIN_STEP) >= d / 2) continue;
-        int32_t e = (int32_t)w->gaps[(size_t)i].gap.e;
-        SvCluster clu;
-        int32_t t = 1, j;
-        for (j = i + 1; j < n && (int32_t)w->gaps[(size_t)j].gap.s <= e; ++j) {
-            if ((int)ds(((int32_t)((w->gaps[(size_t)j].gap.s + w->gaps[(size_t)j].gap.e) / 2) - ref_s) / INS_WIN_STEP) >= d / 2) continue;
-            ++t;
-            if ((int32_t)w->gaps[(size_t)j].gap.e > e) e = (int32_t)w->gaps[(size_t)j].gap.e;
-            if (clu.i_m < (LQSEQ_MAX_CAN_COUNT << 1)) { clu.gap.push_back((uint32_t)j); ++clu.i_m; }
+    const int64_t n = (int64_t)w->gaps.size();
+    auto midpoint = [&](int64_t k) { return (int32_t)((w->gaps[(size_t)k].gap.s + w->gaps[(size_t)k].gap.e) / 2) - ref_s; };
+    auto spanning_reads = [&](int32_t p) -> int {      // depth track at window coordinate p (bins of ten bases)
+        const int64_t bin = p / INS_WIN_STEP;
+        return bin >= 0 && (size_t)bin < w->ref_ds.size() ? (int)w->ref_ds[(size_t)bin] : 0;
+    };
+    auto thin = [&](int64_t k) { return spanning_reads(midpoint(k)) < d / 2; };
+    int64_t k = 0;
+    while (k + min_members < n) {
+        const int32_t seed_at = midpoint(k);
+        if (seed_at < rw || !thin(k)) { ++k; continue; }
+        SvCluster chain;
+        uint32_t reach = w->gaps[(size_t)k].gap.e;
+        int agreeing = 1;
+        int64_t next = k + 1;
+        for (; next < n && (int32_t)w->gaps[(size_t)next].gap.s <= (int32_t)reach; ++next) {
+            if (!thin(next)) continue;
+            ++agreeing;
+            if ((int32_t)w->gaps[(size_t)next].gap.e > (int32_t)reach) reach = w->gaps[(size_t)next].gap.e;
+            if (chain.i_m < 2 * LQSEQ_MAX_CAN_COUNT) { chain.gap.push_back((uint32_t)next); ++chain.i_m; }
         }
-        i = j - 1;
-        if ((int)clu.i_m > md && (int)ds(p / INS_WIN_STEP) < t) w->clusters.push_back(std::move(clu));
+        if ((int)chain.i_m > min_members && spanning_reads(seed_at) < agreeing) w->clusters.push_back(std::move(chain));
+        k = next;
     }
-    int total = 0;
-    for (SvCluster& clu : w->clusters) {
-        total += (int)clu.i_m;
-        std::stable_sort(clu.gap.begin(), clu.gap.end(), [&](uint32_t a, uint32_t b) {
+    int members = 0;
+    for (SvCluster& c : w->clusters) {
+        members += (int)c.i_m;
+        std::stable_sort(c.gap.begin(), c.gap.end(), [&](uint32_t a, uint32_t b) {
             return w->gaps[a].gap.s + w->gaps[a].gap.e < w->gaps[b].gap.s + w->gaps[b].gap.e;
         });
-        cluster_median(w, &clu);
+        cluster_median(w, &c);
     }
-    return total;
+    return members;
 }
 
+// Which supplementary alignments of a cluster's split reads become tag streams of their own (update_align_tags, ctg_cns.c:2836-2888):
+// the members are taken ring by ring around the breakpoint estimate -- ring r = midpoints within 20 r bases of it, r = 1 .. 14 --
+// and a new ring is opened only while fewer than 60 and fewer than 0.8 x members have been taken.  A member whose supplementary
+// alignment keeps fewer than 500 window columns never qualifies.  Every taken member remembers its ring, its new stream and where
+// that stream starts on the read.
 uint32_t sv_update_align_tags(SvWindow* w, const std::vector<SpanOut>& sup_span, uint32_t seq_count, int32_t ref_s, std::vector<StreamRef>* streams) {
-    // ctg_cns.c:2836-2888
+    (void)ref_s;
+    constexpr uint32_t RING = 20, N_RINGS = 14;
     for (SvCluster& clu : w->clusters) {
-        uint32_t lqseq_count = 0;
-        for (uint32_t offset = 20; lqseq_count < LQSEQ_MAX_CAN_COUNT && lqseq_count < clu.i_m * 0.8 && offset < 300; offset += 20) {
-            const uint32_t s = clu.median > offset ? clu.median - offset : 0, e = clu.median + offset;
-            for (uint32_t j = 0; j < clu.i_m; ++j) {
-                SvGapRead& gap = w->gaps[clu.gap[j]];
-                if (gap.l) continue;
-                const uint32_t median = (gap.gap.s + gap.gap.e) / 2;
-                if (median < s || median > e) continue;
-                const SpanOut& a = sup_span[clu.gap[j]];
-                if (a.aln_t_s > a.aln_t_e - 500u) continue;
+        std::vector<uint32_t> by_ring[N_RINGS + 1];
+        for (uint32_t j = 0; j < clu.i_m; ++j) {
+            const SvGapRead& g = w->gaps[clu.gap[j]];
+            const SpanOut& a = sup_span[clu.gap[j]];
+            if (g.l || a.aln_t_s > a.aln_t_e - 500u) continue;
+            const uint32_t away = mabs((g.gap.s + g.gap.e) / 2, clu.median);
+            const uint32_t ring = away == 0 ? 1 : (away + RING - 1) / RING;
+            if (ring <= N_RINGS) by_ring[ring].push_back(j);
+        }
+        uint32_t taken = 0;
+        for (uint32_t ring = 1; ring <= N_RINGS && taken < LQSEQ_MAX_CAN_COUNT && taken < clu.i_m * 0.8; ++ring)
+            for (uint32_t j : by_ring[ring]) {
+                SvGapRead& g = w->gaps[clu.gap[j]];
                 StreamRef sr;
                 sr.set = 1;
                 sr.rec = clu.gap[j];
-                sr.span = a;
+                sr.span = sup_span[clu.gap[j]];
                 streams->push_back(sr);
-                ++seq_count;
-                gap.l = offset / 20;
-                gap.s_id = seq_count - 1;
-                gap.s_s = a.aln_q_s;
-                ++lqseq_count;
+                g.l = ring;
+                g.s_id = seq_count++;
+                g.s_s = sr.span.aln_q_s;
+                ++taken;
             }
-        }
     }
-    (void)ref_s;
     return seq_count;
 }
 
-void sv_generate_gapseqs(SvWindow* w, const WindowOutput& wo, int32_t s_) {   // ctg_cns.c:2898-2996
-    np2k::Tag tag{0, 0, 0};
-    auto TS = [&](uint32_t id) -> uint32_t { return wo.aln_t_s[id]; };
-    auto TE = [&](uint32_t id) -> uint32_t { return wo.aln_t_e[id] - 1; };   // inclusive, like align_tags_t.aln_t_e
-    for (SvCluster& clu : w->clusters) {
-        uint32_t offset = 10, lqseq_rmcount = 0, lqseq_count = 0, lqseq_pcount = 0;
+namespace {
+
+// One cluster's search for the draft interval its split reads bridge, and the piece of every read that lies across it.
+struct GapBridge {
+    SvWindow* w;
+    SvCluster& clu;
+    const WindowOutput& wo;
+    uint32_t win_s;
+    uint32_t first_col(uint32_t stream) const { return wo.aln_t_s[stream]; }
+    uint32_t last_col(uint32_t stream) const { return wo.aln_t_e[stream] - 1; }     // inclusive, like align_tags_t.aln_t_e
+
+    // members still in play whose primary stream runs across `from` and whose supplementary stream runs across `to`, the two streams
+    // meeting nowhere in between; *idle = members no longer in play.  (A member's two streams are kept in draft order.)
+    uint32_t bridging(uint32_t from, uint32_t to, uint32_t* idle) {
+        uint32_t n = 0;
+        *idle = 0;
+        for (uint32_t j = 0; j < clu.i_m; ++j) {
+            SvGapRead& g = w->gaps[clu.gap[j]];
+            if (!g.l) { ++*idle; continue; }
+            if (first_col(g.p_id) > first_col(g.s_id)) { std::swap(g.p_id, g.s_id); std::swap(g.p_s, g.s_s); }
+            const uint32_t a = g.p_id, b = g.s_id;
+            n += first_col(a) < from && last_col(a) > from && first_col(b) < to && last_col(b) > to && from < first_col(b) && to > last_col(a);
+        }
+        return n;
+    }
+    // read coordinate a stream has reached at draft column `col` (bases of the read consumed up to there; counting starts at q0)
+    uint32_t read_coord(uint32_t stream, uint32_t q0, uint32_t col, bool count_col) const {
+        np2k::Tag tag{0, 0, 0};
+        uint32_t cursor = 0, q = q0;
+        const uint8_t* tg = wo.tags.data() + wo.tag_off[stream];
+        while (np2k::next_tag(tg, first_col(stream), &cursor, &tag)) {
+            if (count_col) { if (tag.q_base != 4) ++q; if ((uint32_t)tag.t_pos == col) break; }
+            else { if ((uint32_t)tag.t_pos == col) break; if (tag.q_base != 4) ++q; }
+        }
+        return q;
+    }
+    // with the interval fixed: every member's read substring across it; returns how many are usable (longer than ten bases) and
+    // the shortest substring length seen (the step by which the search widens if too few are)
+    uint32_t measure(uint32_t* shortest) {
+        uint32_t usable = 0;
+        *shortest = UINT32_MAX;
+        for (uint32_t j = 0; j < clu.i_m; ++j) {
+            SvGapRead& g = w->gaps[clu.gap[j]];
+            if (!g.l) continue;
+            const uint32_t a = g.p_id, b = g.s_id;
+            if (first_col(a) > clu.r.s || last_col(a) < clu.r.s || first_col(b) > clu.r.e || last_col(b) < clu.r.e) { g.l = 1; continue; }
+            g.gap.s = read_coord(a, g.p_s - 1, clu.r.s, true);
+            g.gap.e = read_coord(b, g.s_s, clu.r.e + 1, false);
+            g.l = g.gap.e > g.gap.s + 10 ? 2 : 1;
+            usable += g.l == 2;
+            *shortest = std::min(*shortest, mabs(g.gap.s, g.gap.e));
+        }
+        return usable;
+    }
+    // generate_gapseqs for this cluster (ctg_cns.c:2898-2971): widen the interval around the breakpoint estimate in steps of ten
+    // while that wins bridging members (or until half of them bridge), keep the last interval that won some; cut the reads; if too
+    // few pieces are usable, widen further by half the shortest piece + 20 and try again.
+    void run() {
+        uint32_t radius = 10;
         clu.r.s = clu.r.e = 0;
         for (;;) {
-            for (lqseq_pcount = lqseq_count = 0; offset < 30000 && lqseq_pcount < clu.i_m - lqseq_rmcount &&
-                                                 (lqseq_count >= lqseq_pcount || lqseq_pcount < clu.i_m / 2); offset += 10) {
-                const uint32_t s = clu.median > offset ? clu.median - offset - (uint32_t)s_ : 0;
-                const uint32_t e = clu.median + offset - (uint32_t)s_;
-                lqseq_pcount = lqseq_count;
-                uint32_t j;
-                for (lqseq_rmcount = lqseq_count = j = 0; j < clu.i_m; ++j) {
-                    SvGapRead& g = w->gaps[clu.gap[j]];
-                    if (!g.l) { ++lqseq_rmcount; continue; }
-                    uint32_t f = g.p_id, t = g.s_id;
-                    if (TS(f) > TS(t)) {
-                        std::swap(g.p_id, g.s_id);
-                        std::swap(g.p_s, g.s_s);
-                        std::swap(f, t);
-                    }
-                    if (TS(f) < s && TE(f) > s && TS(t) < e && TE(t) > e && s < TS(t) && e > TE(f)) ++lqseq_count;
-                }
-                if (lqseq_count > lqseq_pcount) { clu.r.s = s; clu.r.e = e; }
+            uint32_t now = 0, before = 0, idle = 0;
+            while (radius < 30000 && before < clu.i_m - idle && (now >= before || before < clu.i_m / 2)) {
+                const uint32_t from = clu.median > radius ? clu.median - radius - win_s : 0, to = clu.median + radius - win_s;
+                before = now;
+                now = bridging(from, to, &idle);
+                if (now > before) { clu.r.s = from; clu.r.e = to; }
+                radius += 10;
             }
-            uint32_t offset_step = UINT32_MAX;
-            lqseq_count = 0;
-            for (uint32_t j = 0; j < clu.i_m; ++j) {
-                SvGapRead& g = w->gaps[clu.gap[j]];
-                if (!g.l) continue;
-                const uint32_t f = g.p_id, t = g.s_id;
-                if (TS(f) > clu.r.s || TE(f) < clu.r.s || TS(t) > clu.r.e || TE(t) < clu.r.e) { g.l = 1; continue; }
-                uint32_t s = 0, e = g.p_s - 1;
-                const uint8_t* tg = wo.tags.data() + wo.tag_off[f];
-                while (np2k::next_tag(tg, TS(f), &s, &tag)) {
-                    if (tag.q_base != 4) ++e;
-                    if ((uint32_t)tag.t_pos == clu.r.s) break;
-                }
-                g.gap.s = e;
-                s = 0;
-                e = g.s_s;
-                tg = wo.tags.data() + wo.tag_off[t];
-                while (np2k::next_tag(tg, TS(t), &s, &tag)) {
-                    if ((uint32_t)tag.t_pos == clu.r.e + 1) break;
-                    if (tag.q_base != 4) ++e;
-                }
-                g.gap.e = e;
-                if (g.gap.e > g.gap.s + 10) { ++lqseq_count; g.l = 2; }
-                else g.l = 1;
-                if (mabs(g.gap.s, g.gap.e) < offset_step) offset_step = mabs(g.gap.s, g.gap.e);
-            }
-            if (lqseq_count >= lqseq_pcount / 2 || lqseq_count >= 10) break;
-            offset += offset_step / 2 + 20;
+            uint32_t shortest;
+            const uint32_t usable = measure(&shortest);
+            if (usable >= before / 2 || usable >= 10) return;
+            radius += shortest / 2 + 20;
         }
     }
-    auto valid = [&](const SvCluster& c) { int n = 0; for (uint32_t j = 0; j < c.i_m; ++j) n += w->gaps[c.gap[j]].l ? 1 : 0; return n; };
-    for (size_t i = 0; i < w->clusters.size(); ++i) {
-        SvCluster& clu = w->clusters[i];
-        if (!clu.i_m) continue;
-        if (i + 1 < w->clusters.size() && clu.r.e + 500 >= w->clusters[i + 1].r.s) {
-            if (valid(w->clusters[i + 1]) > valid(clu)) { clu.i_m = 0; continue; }
-            w->clusters[i + 1].i_m = 0;
-        }
+};
+
+}  // namespace
+
+void sv_generate_gapseqs(SvWindow* w, const WindowOutput& wo, int32_t s_) {
+    for (SvCluster& clu : w->clusters) GapBridge{w, clu, wo, (uint32_t)s_}.run();
+    // of two neighbouring clusters whose intervals come within 500 bases, the one with fewer members in play goes (ctg_cns.c:2973-2996)
+    auto in_play = [&](const SvCluster& c) { int n = 0; for (uint32_t j = 0; j < c.i_m; ++j) n += w->gaps[c.gap[j]].l ? 1 : 0; return n; };
+    for (size_t i = 0; i + 1 < w->clusters.size(); ++i) {
+        SvCluster& here = w->clusters[i];
+        SvCluster& next = w->clusters[i + 1];
+        if (!here.i_m || here.r.e + 500 < next.r.s) continue;
+        if (in_play(next) > in_play(here)) here.i_m = 0;
+        else next.i_m = 0;
     }
 }
 
-void sv_update_split_p(std::vector<SvPos>* split_ps, const SvWindow& w, int32_t s, int32_t l, const ref_* ref) {   // ctg_cns.c:2999-3051
-    const uint32_t ENDING_FLANK = 1000;
-    int j = 0;
-    for (size_t i = 0; i < w.ld_regs.size(); ++i) {
-        const SvPos& reg = w.ld_regs[i];
-        if (reg.s < ENDING_FLANK || reg.e + ENDING_FLANK > (uint32_t)l) continue;
-        j = j > 1 ? j - 1 : 0;
-        int split = 1;
-        for (; j < (int)w.clusters.size() && split; ++j) {
-            const SvCluster& clu = w.clusters[(size_t)j];
-            if (clu.r.s > reg.e) break;
-            if ((reg.s <= clu.r.s && clu.r.s <= reg.e) || (reg.s <= clu.r.e && clu.r.e <= reg.e) || (clu.r.s <= reg.s && reg.s <= clu.r.e) ||
-                (clu.r.s <= reg.e && reg.e <= clu.r.e)) split = 0;
+// Where the contig is cut (update_split_p, ctg_cns.c:2999-3051): a low-depth region away from the window's ends that no cluster
+// interval touches is a split region (regions within 10 kb of the previous one extend it); inside every split region the
+// assembler's quality record with the lowest identity + support sum, if below 2900, becomes the exact split point.
+// The clusters are visited with the reference's moving cursor (it backs up one cluster per region and stops at the first cluster
+// that starts behind the region), which decides the outcome when cluster intervals are not in order.
+void sv_update_split_p(std::vector<SvPos>* split_ps, const SvWindow& w, int32_t s, int32_t l, const ref_* ref) {
+    constexpr uint32_t FLANK = 1000;
+    auto touches = [](const SvPos& a, const SvPos& b) {
+        return (a.s <= b.s && b.s <= a.e) || (a.s <= b.e && b.e <= a.e) || (b.s <= a.s && a.s <= b.e) || (b.s <= a.e && a.e <= b.e);
+    };
+    size_t cursor = 0;
+    for (const SvPos& reg : w.ld_regs) {
+        if (reg.s < FLANK || reg.e + FLANK > (uint32_t)l) continue;
+        cursor = cursor > 1 ? cursor - 1 : 0;
+        bool bridged = false;
+        while (cursor < w.clusters.size() && !bridged) {
+            const SvPos& iv = w.clusters[cursor].r;
+            if (iv.s > reg.e) break;
+            bridged = touches(reg, iv);
+            ++cursor;
         }
-        if (split) {
-            if (split_ps->empty() || reg.s + (uint32_t)s > split_ps->back().e + 10000) split_ps->push_back(SvPos{reg.s + (uint32_t)s, reg.e + (uint32_t)s});
-            else split_ps->back().e = reg.e + (uint32_t)s;
-        }
+        if (bridged) continue;
+        const SvPos abs_reg{reg.s + (uint32_t)s, reg.e + (uint32_t)s};
+        if (split_ps->empty() || abs_reg.s > split_ps->back().e + 10000) split_ps->push_back(abs_reg);
+        else split_ps->back().e = abs_reg.e;
     }
     for (SvPos& reg : *split_ps) {
-        uint32_t sco = 0;
-        int p = 0;
+        uint32_t worst = 0, at = 0;
         for (uint32_t q = 0; q < ref->qv_l && ref->qv[q].p <= reg.e; ++q) {
-            if (ref->qv[q].p >= reg.s) {
-                const uint32_t v = ref->qv[q].ide + ref->qv[q].ort + ref->qv[q].irt;
-                if (sco == 0 || v < sco) { sco = v; p = (int)q; }
-            }
+            if (ref->qv[q].p < reg.s) continue;
+            const uint32_t sum = ref->qv[q].ide + ref->qv[q].ort + ref->qv[q].irt;
+            if (worst == 0 || sum < worst) { worst = sum; at = q; }
         }
-        if (sco && sco < 2900) reg.s = reg.e = ref->qv[p].p;
+        if (worst && worst < 2900) reg.s = reg.e = ref->qv[at].p;
     }
 }
 
