@@ -132,6 +132,28 @@ def rocprof_counter(cmd, ctr, env=None):
         shutil.rmtree(td, ignore_errors=True)
 
 
+def rocprof_kernel_stats(cmd, env=None):
+    """One rocprofv3 --kernel-trace --stats pass over `cmd`; returns [(kernel name, calls, total ns, average ns)] sorted by total time."""
+    import csv
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        raise RuntimeError("rocprofv3 not found")
+    td = tempfile.mkdtemp(prefix="np1kst_", dir="/tmp")
+    try:
+        subprocess.run([exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "-o", "k", "--"] + cmd, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=600, check=True, cwd="/tmp", env=dict(env or os.environ, TMPDIR="/tmp"))
+        rows = []
+        for root, _d, files in os.walk(td):
+            for f in files:
+                if f.endswith("kernel_stats.csv"):
+                    for r in csv.DictReader(open(os.path.join(root, f))):
+                        rows.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"])))
+        rows.sort(key=lambda r: -r[2])
+        return rows
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
 def pmc_traffic(args, kernel_substr):
     """HBM bytes of the dominant kernel per launch: two separate --pmc passes (FETCH_SIZE, WRITE_SIZE do not fit one pass on
     gfx950) over a short child run of this script on the same workload.  Units/corrections per MI355X_MICROARCH.md (HBM
@@ -208,6 +230,19 @@ def lgs_roofline(worker_code, env, alg_bytes, with_pmc):
            "achieved_all_kernels_gbs": round(alg_bytes / (total_ms * 1e-3) / 1e9, 3),
            "stage_ms": {k: round(v, 2) for k, v in last.items()}, "traffic": None}
     if with_pmc:
+        try:   # the dominant KERNEL by rocprofv3 (the stage clock above is host-side wall time around groups of kernels)
+            ks = rocprof_kernel_stats([sys.executable, "-c", code], env=env)
+            calls = 2     # the worker's warm-up call + its one timed call = two windows
+            name, n, tot_ns, avg_ns = ks[0]
+            per_window_ms = tot_ns / calls / 1e6
+            out.update({"kernel": name.split("(")[0], "kernel_ms": round(per_window_ms, 3), "kernel_launches_per_window": n / calls,
+                        "kernel_avg_launch_us": round(avg_ns / 1e3, 1), "achieved": round(alg_bytes / (per_window_ms * 1e-3) / 1e9, 3),
+                        "frac": round(alg_bytes / (per_window_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                        "kernels_ms_per_window": round(sum(r[2] for r in ks) / calls / 1e6, 2),
+                        "top_kernels_ms_per_window": {r[0].split("(")[0][:60]: round(r[2] / calls / 1e6, 3) for r in ks[:6]},
+                        "achieved_all_kernels_gbs": round(alg_bytes / (sum(r[2] for r in ks) / calls * 1e-9) / 1e9, 3)})
+        except Exception as e:
+            out["kernel_stats_error"] = repr(e)
         try:
             tot = {}
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):

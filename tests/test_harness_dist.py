@@ -98,3 +98,64 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert len(shards) == 2 and shards[0] and shards[1]
     assert not set(shards[0]) & set(shards[1])
     assert sorted(shards[0] + shards[1]) == ["c%02d" % i for i in range(23)]
+
+
+def _fasta_records(path):
+    recs = {}
+    lines = open(path).read().strip().split("\n")
+    for k in range(0, len(lines), 2):
+        recs[lines[k].split()[0][1:]] = lines[k + 1]
+    return recs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task", [1, 2])
+def test_gpu_two_ranks_cat_of_parts_equals_one_rank(task, tmp_path):
+    """`--world 2 --rank r` of the short-read caller on ONE GPU (both ranks on device 0, the way a node runs one rank per GPU): the
+    concatenation of the two parts -- what the workflow's `cat` makes of them (source/nextPolish:231-234) -- holds exactly the records
+    of a one-rank run; then rank 1 again on its own output: nothing left to do (resume-stable deal)."""
+    from nextpolish_amd import _native as nat
+    st = nat.Stream.synth([40000, 9000, 30000, 45000, 2000, 70000, 12000], depth=30, seed=4242, with_qual=1, draft_lower=0.01)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "g.bam")
+    st.write_files(fa, bam)
+    exe = [sys.executable, os.path.join(ROOT, "nextpolish_amd", "nextpolish1.py"), "-g", fa, "-s", bam, "-t", str(task), "--batch_bp", "60000"]
+    one = str(tmp_path / "one.fa")
+    p = subprocess.run(exe + ["-o", one], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    parts = [str(tmp_path / ("part%d.fa" % r)) for r in range(2)]
+    procs = [subprocess.Popen(exe + ["-o", parts[r], "--world", "2", "--rank", str(r), "--device", "0"], stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for q in procs:
+        assert q.wait(timeout=600) == 0, q.stderr.read()
+    merged = {}
+    for part in parts:
+        recs = _fasta_records(part)
+        assert recs and not set(recs) & set(merged)
+        merged.update(recs)
+    assert merged == _fasta_records(one)
+    before = open(parts[1]).read()
+    p = subprocess.run(exe + ["-o", parts[1], "--world", "2", "--rank", "1", "--device", "0"], capture_output=True, text=True)
+    assert p.returncode == 0 and open(parts[1]).read() == before
+
+
+@pytest.mark.gpu
+def test_gpu_two_ranks_of_the_long_read_caller(tmp_path):
+    """nextpolish2.py --world 2 --rank r on one GPU: cat of the parts == the one-rank output (records in completion order)"""
+    import np2_cases
+    cid, kw, rt = np2_cases.CASES[0]
+    kw = dict(kw, contig_lens=(9000, 5000, 7000, 3000))
+    fa, fofn, _contigs = np2_cases.materialise(kw, str(tmp_path))
+    exe = [sys.executable, os.path.join(ROOT, "nextpolish_amd", "nextpolish2.py"), "-g", fa, "-l", fofn, "-r", {1: "ont", 2: "clr", 3: "hifi"}[rt], "-p", "1", "-sp"]
+    one = str(tmp_path / "one.fa")
+    p = subprocess.run(exe + ["-o", one], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    parts = [str(tmp_path / ("part%d.fa" % r)) for r in range(2)]
+    procs = [subprocess.Popen(exe + ["-o", parts[r], "--world", "2", "--rank", str(r)], env=dict(os.environ, NP2_DEVICE="0"), stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    for q in procs:
+        assert q.wait(timeout=600) == 0, q.stderr.read()
+    merged = {}
+    for part in parts:
+        recs = _fasta_records(part)
+        assert not set(recs) & set(merged)
+        merged.update(recs)
+    assert merged == _fasta_records(one) and len(merged) == 4
