@@ -193,59 +193,55 @@ NP1_HD uint32_t desc_symbol(const uint32_t* d, uint32_t g, int32_t jj, Sq sq) {
 // Packed comparison: the read's bases are 4-bit nt16 codes, two per byte, first base in the high nibble (BAM); `dpack` holds the
 // draft's codes (draft_code of the upper-cased letter = the base slot's symbol, slotinfo_base) in the same layout, so eight bases are
 // one XOR of two byte-swapped words.
-NP1_HD uint32_t nib8(const uint8_t* p, uint64_t n) {   // 8 nibbles from nibble index n on, first one in bits 31..28
+NP1_HD uint64_t nib16(const uint8_t* p, uint64_t n) {   // 16 nibbles from nibble index n on, first one in bits 63..60
     const uint8_t* b = p + (n >> 1);
-    typedef uint32_t __attribute__((aligned(1))) u32u;
-    uint32_t v = __builtin_bswap32(*reinterpret_cast<const u32u*>(b));
-    if (n & 1) v = (v << 4) | (uint32_t)(b[4] >> 4);
+    typedef uint64_t __attribute__((aligned(1))) u64u;
+    uint64_t v = __builtin_bswap64(*reinterpret_cast<const u64u*>(b));
+    if (n & 1) v = (v << 4) | (uint64_t)(b[8] >> 4);
     return v;
 }
-constexpr uint32_t DIRTY_NONE = 0xffffffffu;   // every vote of the record agrees with the draft
-// packed result: (first dirty slot - sfirst) | (last dirty slot - sfirst) << 16, offsets saturating at 0xfffe
+constexpr uint32_t DIRTY_NONE = 0u;   // every vote of the record agrees with the draft
+// Result: bit j = the record has to be evaluated lane by lane in vote chunk (sfirst / VOTE_CH) + j, i.e. a disagreeing vote at slot m
+// marks the chunks of m .. m + 2 (a vote enters the contexts of its own slot and of the next two; chunk c votes on slots
+// 62 c .. 62 c + 61 and reads the two slots before them); bit 31 stands for every chunk from the 31st on.
 template <class So>
-NP1_HD uint32_t desc_dirty_hull(const uint32_t* d, const uint8_t* seq, const uint8_t* dpack, So so) {
+NP1_HD uint32_t desc_dirty_chunks(const uint32_t* d, const uint8_t* seq, const uint8_t* dpack, So so) {
     const uint32_t sfirst = d[0], slast = d[1], cnt = d[2];
-    if ((int32_t)(slast - sfirst) < 0 && !(cnt & DESC_CHAIN)) return DIRTY_NONE;   // votes on nothing
-    if (cnt & DESC_CHAIN) return 0xfffeu << 16;                                    // more parts than this one: all of it
-    uint32_t smin = 0xffffffffu, smax = 0;
+    if (cnt & DESC_CHAIN) return 0xffffffffu;                                      // more parts than this one: all of it
+    if ((int32_t)(slast - sfirst) < 0) return DIRTY_NONE;                          // votes on nothing
+    const uint32_t c0 = sfirst / VOTE_CH;
+    uint32_t mask = 0;
+    auto mark = [&](uint32_t a, uint32_t b) {       // disagreeing votes on slots a .. b (the part of them inside the record's run)
+        if (a < sfirst) a = sfirst;
+        if (b > slast) b = slast;
+        if (a > b) return;
+        uint32_t lo = a / VOTE_CH - c0, hi = (b + 2) / VOTE_CH - c0;
+        if (lo > 31) lo = 31;
+        if (hi > 31) hi = 31;
+        mask |= (hi >= 31 ? 0xffffffffu : (2u << hi) - 1u) & ~((1u << lo) - 1u);
+    };
     const uint32_t nseg = cnt & 0xffu, nins = (cnt >> 8) & 0xffu;
     for (uint32_t k = 0; k < nseg; ++k) {
         const uint32_t g_lo = d[DESC_SEG0 + 2 * k], w = d[DESC_SEG0 + 2 * k + 1], len = w & 0xffffu, qc = w >> 16;
         if (!len) continue;
-        uint32_t f = 0xffffffffu, l = 0;          // first / last disagreeing offset inside the segment
-        if (qc == 0xffffu) { f = 0; l = len - 1; }   // a deletion votes DEL on base slots
-        else
-            for (uint32_t t = 0; t < len; t += 8) {
-                uint32_t x = nib8(seq, (uint64_t)qc + t) ^ nib8(dpack, (uint64_t)g_lo + t);
-                const uint32_t left = len - t;
-                if (left < 8) x &= ~0u << (4 * (8 - left));
-                if (x) {
-                    const uint32_t a = t + ((uint32_t)__builtin_clz(x) >> 2), b = t + 7u - ((uint32_t)__builtin_ctz(x) >> 2);
-                    if (a < f) f = a;
-                    if (b > l) l = b;
-                }
+        if (qc == 0xffffu) { mark(so(g_lo), so(g_lo + len - 1)); continue; }       // a deletion votes DEL on base slots
+        for (uint32_t t = 0; t < len; t += 16) {
+            uint64_t x = nib16(seq, (uint64_t)qc + t) ^ nib16(dpack, (uint64_t)g_lo + t);
+            const uint32_t left = len - t;
+            if (left < 16) x &= ~0ull << (4 * (16 - left));
+            while (x) {                              // every disagreeing base of the group (they are few)
+                const uint32_t i = (uint32_t)__builtin_clzll(x) >> 2;
+                const uint32_t sl = so(g_lo + t + i);
+                mark(sl, sl);
+                x &= ~(0xfull << (60 - 4 * i));
             }
-        if (f != 0xffffffffu) {
-            const uint32_t a = so(g_lo + f), b = so(g_lo + l);
-            if (a < smin) smin = a;
-            if (b > smax) smax = b;
         }
     }
-    for (uint32_t k = 0; k < nins; ++k) {         // bases in insertion columns (the draft's symbol there is DEL)
+    for (uint32_t k = 0; k < nins; ++k) {           // bases in insertion columns (the draft's symbol there is DEL)
         const uint32_t p = d[DESC_INS0 + 2 * k], len = d[DESC_INS0 + 2 * k + 1] & 0xffffu;
-        const uint32_t a = so(p) + 1, b = so(p) + len;
-        if (a < smin) smin = a;
-        if (b > smax) smax = b;
+        mark(so(p) + 1, so(p) + len);
     }
-    if (smin == 0xffffffffu) return DIRTY_NONE;
-    if (smin < sfirst) smin = sfirst;
-    uint32_t e = smax + 2;
-    if (e > slast) e = slast;
-    if (e < smin) e = smin;
-    uint32_t fo = smin - sfirst, lo = e - sfirst;
-    if (fo > 0xfffeu) fo = 0xfffeu;
-    if (lo > 0xfffeu) lo = 0xfffeu;
-    return fo | lo << 16;
+    return mask;
 }
 
 // k_desc body: descriptor (+ overflow parts) and the vote chunks the record's votes can touch

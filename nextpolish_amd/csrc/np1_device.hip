@@ -88,8 +88,34 @@ static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t st) {
 // similar batches allocates nothing in steady state.  sync = false leaves the copies in flight on the context's stream (the
 // kernels that follow are ordered behind them); the host arrays must then stay alive and -- for the copies to overlap with
 // other lanes' work -- pinned (np1_stream_pin).
-static int fill_batch(np1_batch* b, const np1_stream* st, bool sync) {
+// Longest record, and whether cigar_off / seq_off / ctg are exactly what a device rebuilds from n_cigar, l_qseq and read_begin (true
+// for every stream this library makes: loaders and generators append to the pools in record order).  Found once per stream.
+static void stream_facts(np1_stream* st) {
+    if (st->facts) return;
+    const np::ReadStream& s = st->s;
+    const size_t n = s.n_reads();
+    uint32_t mx = 0;
+    bool dense = s.read_begin.size() == s.n_contigs() + 1 && (n == 0 || (s.cigar_off[0] == 0 && s.seq_off[0] == 0));
+    uint64_t c_at = 0, s_at = 0;
+    size_t ct = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t l = s.l_qseq[i];
+        if (l > 0 && (uint32_t)l > mx) mx = (uint32_t)l;
+        if (dense) {
+            while (ct + 1 < s.read_begin.size() && s.read_begin[ct + 1] <= i) ++ct;
+            dense = s.cigar_off[i] == c_at && s.seq_off[i] == s_at && s.ctg[i] == ct && l >= 0;
+            c_at += s.n_cigar[i];
+            s_at += ((uint64_t)(uint32_t)l + 1) >> 1;
+        }
+    }
+    st->max_lq = mx;
+    st->facts = dense ? 1 : 2;
+}
+
+static int fill_batch(np1_batch* b, const np1_stream* st_, bool sync) {
     np1_ctx* ctx = b->ctx;
+    np1_stream* st = const_cast<np1_stream*>(st_);      // (the cached facts are not part of the stream's value)
+    stream_facts(st);
     const np::ReadStream& s = st->s;
     if (s.draft.size() >= 0xfff00000ull) { np1_set_error("batch too large: draft must stay below 2^32 slots"); return -1; }
     (void)hipSetDevice(ctx->device);
@@ -103,24 +129,36 @@ static int fill_batch(np1_batch* b, const np1_stream* st, bool sync) {
     b->ran = false;
     b->out_cached = false;
     b->out_pinned = false;
-    for (int32_t l : s.l_qseq)
-        if (l > 0 && (uint32_t)l > b->max_lq) b->max_lq = (uint32_t)l;
+    b->max_lq = st->max_lq;
     hipStream_t q = ctx->stream;
     size_t n = s.n_reads();
     int rc = 0;
+    static const bool slim = !(getenv("NP1_UPLOAD") && strcmp(getenv("NP1_UPLOAD"), "full") == 0);   // NP1_UPLOAD=full: every array as the host holds it
+    const bool rebuild = slim && st->facts == 1 && n > 0;
     rc |= upload(b->draft, s.draft.data(), s.draft.size(), q);
     rc |= upload(b->ctg_off, s.ctg_off.data(), 4 * s.ctg_off.size(), q);
     rc |= upload(b->pos, s.pos.data(), 4 * n, q);
-    rc |= upload(b->ctg, s.ctg.data(), 4 * n, q);
     rc |= upload(b->flag, s.flag.data(), 2 * n, q);
     rc |= upload(b->ncig, s.n_cigar.data(), 2 * n, q);
     rc |= upload(b->lq, s.l_qseq.data(), 4 * n, q);
-    rc |= upload(b->cigoff, s.cigar_off.data(), 8 * n, q);
-    rc |= upload(b->seqoff, s.seq_off.data(), 8 * n, q);
     rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);
     rc |= upload(b->seq, s.seq.data(), s.seq.size(), q);
     b->h_read_begin = s.read_begin;
     rc |= upload(b->read_begin, s.read_begin.data(), 8 * s.read_begin.size(), q);
+    if (rebuild) {
+        // 20 of the 32 fixed bytes per record are functions of the rest: pool offsets = running sums, contig = the record's place in
+        // read_begin.  The device rebuilds them (two scans and a search per record) instead of taking them over PCIe.
+        if (b->cigoff.ensure(8 * (n + 2)) || b->seqoff.ensure(8 * (n + 2)) || b->ctg.ensure(4 * n) ||
+            b->scan_tmp.ensure(8 * (scan_tmp_words((uint64_t)n + 1) + 8)) || b->totals.ensure(256))
+            return -1;
+        if (rc == 0)
+            launch_record_offsets(q, b->ncig.as<uint16_t>(), b->lq.as<int32_t>(), b->read_begin.as<uint64_t>(), b->nc, (uint64_t)n, b->cigoff.as<uint64_t>(),
+                                  b->seqoff.as<uint64_t>(), b->ctg.as<uint32_t>(), b->scan_tmp.as<uint64_t>(), b->totals.as<uint64_t>() + 24);
+    } else {
+        rc |= upload(b->ctg, s.ctg.data(), 4 * n, q);
+        rc |= upload(b->cigoff, s.cigar_off.data(), 8 * n, q);
+        rc |= upload(b->seqoff, s.seq_off.data(), 8 * n, q);
+    }
     b->has_qual = !s.qual.empty() || n == 0;
     if (b->has_qual) {   // kmer_count needs mapq / isize / base qualities too (kmercount.c:365-465, contig.c:648-665)
         rc |= upload(b->mapq, s.mapq.data(), n, q);

@@ -29,6 +29,9 @@ void launch_vote(hipStream_t st, int E, const uint4* meta, const uint8_t* rows, 
 void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
                  const int32_t* qs, const int32_t* qe, uint32_t* desc, uint32_t* ovf_pool, uint32_t ovf_cap,
                  uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters, const uint8_t* dpack = nullptr, uint32_t* dirty = nullptr);
+// cigar_off / seq_off / ctg of a dense record stream on the device (cigoff and seqoff get n + 1 entries)
+void launch_record_offsets(hipStream_t st, const uint16_t* ncig, const int32_t* lq, const uint64_t* read_begin, uint32_t nc, uint64_t n, uint64_t* cigoff,
+                           uint64_t* seqoff, uint32_t* ctg, uint64_t* tmp, uint64_t* total);
 // the draft as packed 4-bit codes (the layout of the reads' bases): what k_desc compares the records with for their dirty hulls
 void launch_dpack(hipStream_t st, const uint8_t* draft, uint32_t G, uint8_t* dpack);
 // k_tile8: plain (record, chunk) pairs as one masked add, per-lane evaluation only inside a record's dirty hull (np1_kernels.hip)

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_desc(ReadsDev R, int64_t n_reads, const
     if (r < n_reads) {
         desc_record(R, r, ctg_off, soff, qs, qe, desc, ovf_pool, ovf_cap, counters, &c0, &c1);
         // where the record disagrees with the draft (k_tile8 evaluates symbols only there)
-        if (dirty) dirty[r] = desc_dirty_hull(desc + (uint64_t)r * DESC_WORDS, R.seq + R.seq_off[r], dpack, SoGlobal{soff});
+        if (dirty) dirty[r] = desc_dirty_chunks(desc + (uint64_t)r * DESC_WORDS, R.seq + R.seq_off[r], dpack, SoGlobal{soff});
     }
     const bool has = c0 <= c1;
     if (__ballot(has) == 0ull) return;
@@ -913,11 +913,10 @@ __global__ __launch_bounds__(NW * 64) void k_tile8(ReadsDev R, const uint32_t* _
     VoteLane<E> vl;
     vl.init(d2 << 8 | d1 << 4 | dsym);
     const uint32_t kstart1 = d1 << 4 | dsym;            // context of the second slot of a run that repeats the draft: (0, d', d)
-    const unsigned long long INS = __ballot(is_ins);   // (lanes 0 and 1 are the halo: they never vote)
     const unsigned long long F1 = __ballot(first), F2 = __ballot(first || f1 != 0);
     const uint32_t F1lo = (uint32_t)F1, F1hi = (uint32_t)(F1 >> 32), F2lo = (uint32_t)F2, F2hi = (uint32_t)(F2 >> 32);
-    unsigned long long NS = 0;          // lanes where something other than the draft's own symbol voted
-    uint32_t basemask = 0;              // the same per lane, from the general path (chained records)
+    uint32_t basemask = 0;              // symbols that voted on my slot in dirty pairs (plain pairs only ever vote the draft's)
+    const uint32_t sv = valid ? s : 0xffffffffu;   // slot for coverage tests (never covered when invalid)
     const int32_t cs = (int32_t)((int64_t)c * VOTE_CH - 2);   // slot of lane 0 (may be -2 for chunk 0)
     uint32_t wf = 0xffffffffu, wl = 0;
     if (chunk_ok) { wf = chunk_first[c]; wl = chunk_last[c]; }
@@ -969,12 +968,9 @@ __global__ __launch_bounds__(NW * 64) void k_tile8(ReadsDev R, const uint32_t* _
                     hi = hi > 63 ? 63 : hi;
                     const bool live = act && (int32_t)(slast - hv.x) >= 0 && lo <= hi;
                     unsigned long long Cm = live ? (~0ull >> (63 - hi)) & (~0ull << lo) : 0ull;
-                    bool isdirty = (hv.z & DESC_CHAIN) != 0;
-                    if (dw != DIRTY_NONE) {
-                        const int32_t dl = (int32_t)hv.x + (int32_t)(dw & 0xffffu) - cs;
-                        const int32_t dh = (dw >> 16) >= 0xfffeu ? 0x7fffffff : (int32_t)hv.x + (int32_t)(dw >> 16) - cs;
-                        isdirty = isdirty || !(dh < lo || dl > hi);
-                    }
+                    // dirty = the record disagrees with the draft somewhere in reach of this chunk (k_desc's chunk mask, np1_desc.h)
+                    const uint32_t cj = c - hv.x / VOTE_CH;
+                    const bool isdirty = (hv.z & DESC_CHAIN) != 0 || ((dw >> (cj < 31u ? cj : 31u)) & 1u) != 0;
                     const uint32_t Clo = (uint32_t)Cm, Chi = (uint32_t)(Cm >> 32);
                     // lanes whose whole context is the draft's, if the record repeats the draft on all of C
                     const unsigned long long C1 = Cm << 1, C2 = Cm << 2;
@@ -1009,25 +1005,46 @@ __global__ __launch_bounds__(NW * 64) void k_tile8(ReadsDev R, const uint32_t* _
                             continue;
                         }
                         if (ablate & 8u) continue;
-                        // ---- dirty pair: per-lane evaluation
-                        const uint32_t sfirst = (uint32_t)__builtin_amdgcn_readlane((int)hv.x, r), cnt = (uint32_t)__builtin_amdgcn_readlane((int)hv.z, r);
-                        const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)hv.w, r);
-                        const uint32_t seg0_g = (uint32_t)__builtin_amdgcn_readlane((int)sg.x, r), seg0_w = (uint32_t)__builtin_amdgcn_readlane((int)sg.y, r);
-                        const unsigned long long C = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Clo, r) |
-                                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)Chi, r) << 32;
+                        // ---- dirty pair: every lane evaluates the record's symbol at its slot and its context (the body of k_tile3;
+                        //      the descriptor comes back from LDS as broadcast reads)
                         const uint32_t* d = dsc + (uint32_t)(gb + r) * DESC_WORDS;
-                        const uint32_t rbase = boff - sq0_lo;
-                        (void)sfirst;
-                        uint32_t sym;
-                        if (cnt & DESC_SIMPLE) {
-                            const unsigned long long BASE = C & ~INS;
-                            const uint32_t q = sel_lane_mask(0u, g + ((seg0_w >> 16) - seg0_g), BASE);
-                            const uint32_t byte = seqb[rbase + (q >> 1)];
-                            sym = sel_lane_mask(3u, (byte >> ((~q & 1u) << 2)) & 0xfu, BASE);
-                        } else if (cnt & DESC_CHAIN) {
-                            if (ablate & 2u) continue;
+                        const uint4 h = *reinterpret_cast<const uint4*>(d);
+                        if (!(h.z & DESC_CHAIN)) {
+                            const uint32_t nseg = h.z & 0xffu, nins = (h.z >> 8) & 0xffu;
+                            const bool cov = sv >= h.x && sv <= h.y;
+                            uint32_t q = 0;
+                            bool isdel = true;   // covered insertion column the record merely passes (or pads): DEL
+                            for (uint32_t k2 = 0; k2 < nseg; ++k2) {
+                                const uint2 sk = *reinterpret_cast<const uint2*>(d + DESC_SEG0 + 2 * k2);
+                                const uint32_t off = g - sk.x;
+                                const bool in = !is_ins && off < (sk.y & 0xffffu);
+                                isdel = in ? (sk.y >> 16) == 0xffffu : isdel;
+                                q = in ? (sk.y >> 16) + off : q;
+                            }
+                            for (uint32_t k2 = 0; k2 < nins; ++k2) {
+                                const uint2 ik = *reinterpret_cast<const uint2*>(d + DESC_INS0 + 2 * k2);
+                                const bool in = is_ins && ik.x == g && jju < (ik.y & 0xffffu);
+                                isdel = in ? false : isdel;
+                                q = in ? (ik.y >> 16) + jju : q;
+                            }
+                            q = (cov && !isdel) ? q : 0u;
+                            const uint32_t byte = seqb[(h.w - sq0_lo) + (q >> 1)];
+                            uint32_t sym = (byte >> ((~q & 1u) << 2)) & 0xfu;
+                            sym = cov ? (isdel ? 3u : sym) : 0u;
+                            const uint32_t p1 = wave_shr1(sym), p2 = wave_shr1(p1);
+                            const uint32_t k = p2 << 8 | p1 << 4 | sym;
+                            basemask |= cov ? 1u << sym : 0u;
+                            const bool vote = cov && lane >= 2;
+                            const bool m0 = vote && k == vl.k0, m1 = vote && k == vl.k1;
+                            vl.c0 += m0 ? 1u : 0u;
+                            vl.c1 += m1 ? 1u : 0u;
+                            const bool rest = vote && !m0 && !m1;
+                            if (__ballot(rest) != 0ull && !(ablate & 1u)) {
+                                if (rest) vl.tally(k, L, lane);   // a context seen for the first time, or one kept in the LDS list
+                            }
+                        } else if (!(ablate & 2u)) {
                             // indel operations that fill more than one descriptor: the general walk over the parts (they live in HBM)
-                            const SeqLds sq{seqb + rbase};
+                            const SeqLds sq{seqb + (h.w - sq0_lo)};
                             const int32_t jj = is_ins ? (int32_t)jju : -1;
                             uint32_t rsym = 0, nv = 0;
                             vote_part<E>(d, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nv);
@@ -1037,50 +1054,6 @@ __global__ __launch_bounds__(NW * 64) void k_tile8(ReadsDev R, const uint32_t* _
                                 vote_part<E>(dg, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nv);
                                 nx = dg[DESC_NEXT];
                             }
-                            continue;
-                        } else {
-                            // segments and insertions of one descriptor: which lanes vote a base of the read, and which one
-                            const uint32_t nseg = cnt & 0xffu, nins = (cnt >> 8) & 0xffu;
-                            uint32_t q = 0;
-                            unsigned long long BASE = 0ull;
-                            for (uint32_t k2 = 0; k2 < nseg; ++k2) {
-                                const uint2 sk = *reinterpret_cast<const uint2*>(d + DESC_SEG0 + 2 * k2);
-                                const uint32_t glo = k2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sk.x) : seg0_g;
-                                const uint32_t w = k2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sk.y) : seg0_w;
-                                const uint32_t off = g - glo;
-                                const unsigned long long in = __ballot(off < (w & 0xffffu)) & C & ~INS;
-                                if ((w >> 16) != 0xffffu) {
-                                    q = sel_lane_mask(q, (w >> 16) + off, in);
-                                    BASE |= in;
-                                }
-                            }
-                            for (uint32_t k2 = 0; k2 < nins; ++k2) {
-                                const uint2 ik = *reinterpret_cast<const uint2*>(d + DESC_INS0 + 2 * k2);
-                                const uint32_t pp = (uint32_t)__builtin_amdgcn_readfirstlane((int)ik.x), w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ik.y);
-                                const unsigned long long in = __ballot(g == pp && jju < (w & 0xffffu)) & C & INS;
-                                q = sel_lane_mask(q, (w >> 16) + jju, in);
-                                BASE |= in;
-                            }
-                            q = sel_lane_mask(0u, q, BASE);
-                            const uint32_t byte = seqb[rbase + (q >> 1)];
-                            sym = sel_lane_mask(3u, (byte >> ((~q & 1u) << 2)) & 0xfu, BASE);
-                        }
-                        // agreement with the draft, all of it on masks
-                        const unsigned long long A = __ballot(sym == dsym) & C;
-                        NS |= C ^ A;
-                        const unsigned long long M0 = A & ((A << 1) | F1) & ((A << 2) | F2);
-                        add_lane_mask(vl.c0, M0 & ~3ull);
-                        const unsigned long long Rm = (C & ~3ull) & ~M0;
-                        if (Rm != 0ull && !(ablate & 1u)) {      // some lane's context is not the draft's: contexts from the neighbours, tallied per lane
-                            const uint32_t symc = sel_lane_mask(0u, sym, C);
-                            const uint32_t p1 = wave_shr1(symc), p2 = wave_shr1(p1);
-                            const uint32_t k = p2 << 8 | p1 << 4 | symc;
-                            const unsigned long long M1 = __ballot(k == vl.k1) & Rm;
-                            add_lane_mask(vl.c1, M1);
-                            const unsigned long long rest = Rm & ~M1;
-                            if (rest != 0ull) {
-                                if ((rest >> lane) & 1ull) vl.tally(k, L, lane);   // a context seen for the first time, or one kept in the LDS list
-                            }
                         }
                     }
                 }
@@ -1089,8 +1062,8 @@ __global__ __launch_bounds__(NW * 64) void k_tile8(ReadsDev R, const uint32_t* _
         }
     }
     const bool ovf_any = chunk_ok && __ballot(vl.ovf) != 0ull;
-    // a slot is single-state when nothing but the draft's own symbol voted on it
-    const bool single = !((NS >> lane) & 1ull) && (basemask & ~(1u << dsym)) == 0u;
+    // a slot is single-state when nothing but the draft's own symbol voted on it (plain pairs never vote anything else)
+    const bool single = (basemask & ~(1u << dsym)) == 0u;
     const uint32_t psingle = wave_shr1((uint32_t)single);
     const bool prev_is_single = first || psingle != 0;
     // vote statistic: every tally of an own slot but the draft's own one
@@ -1865,6 +1838,34 @@ struct LoadU8 {
 void launch_scan_u8(hipStream_t st, const uint8_t* v, uint64_t n, uint32_t* out, uint64_t* tmp, uint64_t* total) {
     scan_impl<LoadU8, uint32_t>(st, LoadU8{v}, n, out, tmp, total);
 }
+// the per-record arrays of a dense record stream rebuilt on the device instead of uploaded (np1_device.hip:fill_batch): pool offsets
+// as running sums of the CIGAR lengths / packed base bytes, and the contig of every record from the contigs' record ranges
+struct LoadNcig {
+    const uint16_t* p;
+    __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
+};
+struct LoadSeqBytes {
+    const int32_t* p;
+    __device__ uint64_t operator()(uint64_t i) const { return ((uint64_t)(uint32_t)p[i] + 1) >> 1; }
+};
+__global__ __launch_bounds__(256) void k_record_contig(const uint64_t* __restrict__ read_begin, uint32_t nc, uint64_t n, uint32_t* __restrict__ ctg) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    uint32_t lo = 0, hi = nc;            // largest c with read_begin[c] <= r
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (read_begin[mid] <= r) lo = mid; else hi = mid;
+    }
+    ctg[r] = lo;
+}
+void launch_record_offsets(hipStream_t st, const uint16_t* ncig, const int32_t* lq, const uint64_t* read_begin, uint32_t nc, uint64_t n, uint64_t* cigoff,
+                           uint64_t* seqoff, uint32_t* ctg, uint64_t* tmp, uint64_t* total) {
+    if (n == 0) return;
+    scan_impl<LoadNcig, uint64_t>(st, LoadNcig{ncig}, n, cigoff, tmp, total);
+    scan_impl<LoadSeqBytes, uint64_t>(st, LoadSeqBytes{lq}, n, seqoff, tmp, total);
+    k_record_contig<<<nblk(n, 256), 256, 0, st>>>(read_begin, nc, n, ctg);
+}
+
 void launch_scan_u32(hipStream_t st, const uint32_t* v, uint64_t n, uint32_t* out, uint64_t* tmp, uint64_t* total) {
     scan_impl<LoadU32, uint32_t>(st, LoadU32{v}, n, out, tmp, total);
 }

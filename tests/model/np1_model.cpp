@@ -156,12 +156,8 @@ bool vote_chunk_desc(uint32_t c, const std::vector<uint32_t>& desc, const std::v
                 hi = hi > 63 ? 63 : hi;
                 if (lo > hi) continue;
                 const uint32_t dw = g_dirty[r];
-                bool isdirty = false;
-                if (dw != DIRTY_NONE) {
-                    const int32_t dl = (int32_t)d[0] + (int32_t)(dw & 0xffffu) - cs;
-                    const int32_t dh = (dw >> 16) >= 0xfffeu ? 0x7fffffff : (int32_t)d[0] + (int32_t)(dw >> 16) - cs;
-                    isdirty = !(dh < lo || dl > hi);
-                }
+                const uint32_t cj = c - d[0] / VOTE_CH;
+                const bool isdirty = ((dw >> (cj < 31u ? cj : 31u)) & 1u) != 0;
                 if (!isdirty) {
                     for (int l = lo < 2 ? 2 : lo; l <= hi; ++l) {
                         const bool has1 = l - 1 >= lo, has2 = l - 2 >= lo;
@@ -396,8 +392,26 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
             }
             dirty_v.assign((size_t)(n ? n : 1), DIRTY_NONE);
             for (int64_t r = 0; r < n; ++r)
-                dirty_v[(size_t)r] = desc_dirty_hull(desc.data() + (uint64_t)r * DESC_WORDS, seq_padded.data() + R.seq_off[r], dpack.data(), SoGlobal{soff.data()});
+                dirty_v[(size_t)r] = desc_dirty_chunks(desc.data() + (uint64_t)r * DESC_WORDS, seq_padded.data() + R.seq_off[r], dpack.data(), SoGlobal{soff.data()});
             g_dirty = dirty_v.data();
+            if (getenv("NP1M_CHECK_DIRTY")) {      // brute force: every disagreeing vote must lie in a marked chunk
+                for (int64_t r = 0; r < n; ++r) {
+                    const uint32_t* d = desc.data() + (uint64_t)r * DESC_WORDS;
+                    if ((d[2] & DESC_CHAIN) || (int32_t)(d[1] - d[0]) < 0) continue;
+                    for (uint32_t sl = d[0]; sl <= d[1]; ++sl) {
+                        const uint32_t gg = slot_g[sl];
+                        const int32_t jj = (slot_info[sl] & SI_INSERT) ? (int32_t)(sl - soff[gg]) - 1 : -1;
+                        const uint32_t sym = desc_symbol(d, gg, jj, SeqBytes{R.seq + R.seq_off[r]});
+                        if (sym == (slot_info[sl] & 0xfu)) continue;
+                        for (uint32_t t = sl; t <= sl + 2; ++t) {
+                            const uint32_t cj = t / VOTE_CH - d[0] / VOTE_CH;
+                            if (!((dirty_v[(size_t)r] >> (cj < 31u ? cj : 31u)) & 1u))
+                                fprintf(stderr, "record %lld slot %u (g %u jj %d) sym %u != dsym %u: chunk of slot %u not marked (mask %08x, sfirst %u slast %u cnt %x)\n",
+                                        (long long)r, sl, gg, jj, sym, slot_info[sl] & 0xfu, t, dirty_v[(size_t)r], d[0], d[1], d[2]);
+                        }
+                    }
+                }
+            }
         }
         for (uint32_t c = 0; (np1m_fused == 1 || np1m_fused == 4) && c < n_chunks; ++c) {
             if (vote_chunk_desc<8>(c, desc, ovf, R, soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
