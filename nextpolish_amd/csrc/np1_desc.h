@@ -245,10 +245,10 @@ NP1_HD uint32_t desc_dirty_chunks(const uint32_t* d, const uint8_t* seq, const u
 }
 
 // k_desc body: descriptor (+ overflow parts) and the vote chunks the record's votes can touch
-NP1_HD void desc_record(const ReadsDev& R, int64_t r, const uint32_t* ctg_off, const uint32_t* soff, const int32_t* qs,
-                        const int32_t* qe, uint32_t* desc, uint32_t* ovf_pool, uint32_t ovf_cap, uint32_t* counters,
-                        uint32_t* c0_out, uint32_t* c1_out) {
-    uint32_t* d = desc + (uint64_t)r * DESC_WORDS;
+// (d = where the record's head descriptor is built: its place in the descriptor array, or a staging slot in LDS that the kernel
+// writes out with coalesced stores afterwards)
+NP1_HD void desc_record_at(uint32_t* d, const ReadsDev& R, int64_t r, const uint32_t* ctg_off, const uint32_t* soff, const int32_t* qs,
+                           const int32_t* qe, uint32_t* ovf_pool, uint32_t ovf_cap, uint32_t* counters, uint32_t* c0_out, uint32_t* c1_out) {
     *c0_out = 1;
     *c1_out = 0;
     if (qs[r] <= qe[r]) {
@@ -265,6 +265,11 @@ NP1_HD void desc_record(const ReadsDev& R, int64_t r, const uint32_t* ctg_off, c
     } else {
         d[0] = 1; d[1] = 0; d[2] = 0; d[3] = 0; d[DESC_NEXT] = 0; d[DESC_NEXT + 1] = 0;
     }
+}
+NP1_HD void desc_record(const ReadsDev& R, int64_t r, const uint32_t* ctg_off, const uint32_t* soff, const int32_t* qs,
+                        const int32_t* qe, uint32_t* desc, uint32_t* ovf_pool, uint32_t ovf_cap, uint32_t* counters,
+                        uint32_t* c0_out, uint32_t* c1_out) {
+    desc_record_at(desc + (uint64_t)r * DESC_WORDS, R, r, ctg_off, soff, qs, qe, ovf_pool, ovf_cap, counters, c0_out, c1_out);
 }
 
 }  // namespace np1k

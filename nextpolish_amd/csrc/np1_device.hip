@@ -999,6 +999,24 @@ int np1_batch_download_slots(np1_batch* b, int64_t c, std::vector<uint32_t>* sof
     return 0;
 }
 
+// the same D2H copy straight into a caller's buffer (page-locked for full rate: np1_host_alloc_pinned) -- the streamed pipe keeps the
+// results of a run per batch and used to copy them once more out of the lane's own buffer
+int np1_batch_results_fetch_to(np1_batch* b, char* dst, size_t cap) {
+    if (!b || !b->ran || !dst) { np1_set_error("np1_batch_results_fetch_to: no completed run"); return -1; }
+    (void)hipSetDevice(b->ctx->device);
+    const size_t total = b->h_bounds[b->nc];
+    if (total > cap) { np1_set_error("np1_batch_results_fetch_to: buffer too small"); return -1; }
+    if (total) HIPCHK(hipMemcpyAsync(dst, b->out.p, total, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+size_t np1_batch_results_total(np1_batch* b) { return (b && b->ran) ? (size_t)b->h_bounds[b->nc] : 0; }
+void* np1_host_alloc_pinned(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+    return p;
+}
+void np1_host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 void np1_batch_swap_work(np1_batch* a, np1_batch* b) { if (a && b && a != b) a->swap_work(*b); }
 
 // Makes np1_batch_kmer_count / np1_batch_snp_valid of this batch replay the reference's region iterator (np1_replay.h).  `st` is the stream

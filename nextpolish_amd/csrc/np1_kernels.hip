@@ -274,13 +274,28 @@ __global__ __launch_bounds__(256) void k_desc(ReadsDev R, int64_t n_reads, const
                                               uint32_t* __restrict__ chunk_first, uint32_t* __restrict__ chunk_last,
                                               uint32_t* __restrict__ counters, const uint8_t* __restrict__ dpack,
                                               uint32_t* __restrict__ dirty) {
+    // The 96-byte descriptors of a workgroup's 256 records are one contiguous 24 KB stretch of the array: they are built in LDS (the
+    // builder writes single words, in no particular order, some of them twice) and leave as full 16-byte lanes, coalesced -- written
+    // word by word from the lanes the same bytes cost 2.7 x their size in HBM writes (partial lines evicted between the words).
+    __shared__ __attribute__((aligned(16))) uint32_t stage[256 * DESC_WORDS];
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t c0 = 1, c1 = 0;
+    uint32_t* mine = stage + threadIdx.x * DESC_WORDS;
     if (r < n_reads) {
-        desc_record(R, r, ctg_off, soff, qs, qe, desc, ovf_pool, ovf_cap, counters, &c0, &c1);
+#pragma unroll
+        for (int k = 0; k < DESC_WORDS; ++k) mine[k] = 0u;      // (words a short descriptor never touches: no stale LDS goes to HBM)
+        desc_record_at(mine, R, r, ctg_off, soff, qs, qe, ovf_pool, ovf_cap, counters, &c0, &c1);
         // where the record disagrees with the draft (k_tile8 evaluates symbols only there)
-        if (dirty) dirty[r] = desc_dirty_chunks(desc + (uint64_t)r * DESC_WORDS, R.seq + R.seq_off[r], dpack, SoGlobal{soff});
+        if (dirty) dirty[r] = desc_dirty_chunks(mine, R.seq + R.seq_off[r], dpack, SoGlobal{soff});
+    }
+    __syncthreads();
+    {
+        const int64_t r_block = (int64_t)blockIdx.x * blockDim.x;
+        const int64_t n_here = n_reads - r_block < 256 ? n_reads - r_block : 256;
+        uint4* dst = reinterpret_cast<uint4*>(desc + (uint64_t)r_block * DESC_WORDS);
+        const uint4* src = reinterpret_cast<const uint4*>(stage);
+        for (int64_t i = threadIdx.x; i < n_here * (DESC_WORDS / 4); i += 256) dst[i] = src[i];
     }
     const bool has = c0 <= c1;
     if (__ballot(has) == 0ull) return;

@@ -29,7 +29,8 @@ struct np1_pipe {
     struct Lane { np1_ctx* ctx = nullptr; np1_batch* batch = nullptr; };
     std::vector<Lane> lanes;
     // results of the last np1_pipe_run
-    std::vector<std::vector<char>> out;            // per batch: concatenated strings
+    struct Blob { char* p = nullptr; size_t cap = 0, len = 0; };   // page-locked: the D2H copy of a batch lands here directly
+    std::vector<Blob> out;                         // per batch: concatenated strings
     std::vector<std::vector<uint32_t>> bounds;     // per batch: nc + 1 offsets
     std::vector<np1_batch*> resident;              // np1_pipe_upload: batch k lives on lane k % lanes
     uint64_t host_inflated_blocks = 0;             // last np1_pipe_run_files: BGZF blocks the device decoder handed back to the host
@@ -46,11 +47,19 @@ int run_task(np1_batch* b, const Configure* cfg, int task) {
     return task == 2 ? np1_batch_kmer_count(b, cfg, nullptr) : task == 4 ? np1_batch_snp_valid(b, cfg, nullptr) : np1_batch_score_chain(b, cfg, nullptr);
 }
 
-int polish_on_lane(np1_pipe::Lane& ln, np1_stream* st, const Configure* cfg, int task) {
+int polish_on_lane(np1_pipe::Lane& ln, np1_stream* st, const Configure* cfg, int task, np1_pipe::Blob* out) {
     if (np1_batch_reload(ln.batch, st) != 0) return -1;
     const int rc = run_task(ln.batch, cfg, task);
     if (rc != 0) return -1;
-    return np1_batch_results_fetch(ln.batch);
+    const size_t total = np1_batch_results_total(ln.batch);
+    if (total + 1 > out->cap) {
+        np1_host_free_pinned(out->p);
+        out->cap = total + total / 8 + 4096;
+        out->p = (char*)np1_host_alloc_pinned(out->cap);
+        if (!out->p) { out->cap = 0; np1_set_error("hipHostMalloc failed"); return -1; }
+    }
+    out->len = total;
+    return np1_batch_results_fetch_to(ln.batch, out->p, out->cap);
 }
 
 double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
@@ -150,6 +159,7 @@ int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passe
 void np1_pipe_close(np1_pipe* p) {
     if (!p) return;
     if (p->phase_lr) np1_batch_free(p->phase_lr);
+    for (np1_pipe::Blob& o : p->out) np1_host_free_pinned(o.p);
     drop_resident(p);
     for (np1ingest::Scratch* s : p->scratch) np1ingest::scratch_destroy(s);
     for (np1ingest::Staging* s : p->staging) delete s;
@@ -162,7 +172,9 @@ void np1_pipe_close(np1_pipe* p) {
 
 int np1_pipe_run(np1_pipe* p, np1_stream* const* streams, int n, const Configure* cfg, int task) {
     if (!p || !cfg || (n > 0 && !streams)) { np1_set_error("np1_pipe_run: null argument"); return -1; }
-    p->out.assign((size_t)n, {});
+    if (p->out.size() > (size_t)n)
+        for (size_t k = (size_t)n; k < p->out.size(); ++k) np1_host_free_pinned(p->out[k].p);
+    p->out.resize((size_t)n);                      // the buffers of earlier runs are reused
     p->bounds.assign((size_t)n, {});
     std::atomic<int> next(0);
     std::atomic<bool> failed(false);
@@ -172,7 +184,7 @@ int np1_pipe_run(np1_pipe* p, np1_stream* const* streams, int n, const Configure
         for (;;) {
             const int k = next.fetch_add(1);
             if (k >= n || failed) break;
-            if (polish_on_lane(ln, streams[k], cfg, task) != 0) {
+            if (polish_on_lane(ln, streams[k], cfg, task, &p->out[(size_t)k]) != 0) {
                 std::lock_guard<std::mutex> g(err_mu);
                 if (!failed) err = np1_last_error();
                 failed = true;
@@ -182,8 +194,6 @@ int np1_pipe_run(np1_pipe* p, np1_stream* const* streams, int n, const Configure
             np1_stream_get_view(streams[k], &v);
             const uint32_t* b = np1_batch_results_bounds(ln.batch);
             p->bounds[(size_t)k].assign(b, b + v.n_contigs + 1);
-            const char* s = np1_batch_results_ptr(ln.batch);
-            p->out[(size_t)k].assign(s, s + b[v.n_contigs]);
         }
     };
     std::vector<std::thread> th;
@@ -199,7 +209,7 @@ const char* np1_pipe_result(np1_pipe* p, int batch, int64_t contig, int64_t* len
     const std::vector<uint32_t>& b = p->bounds[(size_t)batch];
     if (contig < 0 || (size_t)contig + 1 >= b.size()) return nullptr;
     if (len) *len = (int64_t)b[(size_t)contig + 1] - (int64_t)b[(size_t)contig];
-    return p->out[(size_t)batch].data() + b[(size_t)contig];
+    return p->out[(size_t)batch].p + b[(size_t)contig];
 }
 
 int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const char* const* names, int n_names, int64_t batch_bp,

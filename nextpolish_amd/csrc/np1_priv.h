@@ -20,3 +20,8 @@ void np1_stream_unpin(np1_stream* st);      // np1_device.hip (no-op when the st
 // np1_device.hip: everything a pass allocates besides the uploaded inputs changes places between the two batches
 struct np1_batch;
 void np1_batch_swap_work(np1_batch* a, np1_batch* b);
+// results of the last run: total bytes, and the D2H copy straight into a caller's (page-locked) buffer
+size_t np1_batch_results_total(np1_batch* b);
+int np1_batch_results_fetch_to(np1_batch* b, char* dst, size_t cap);
+void* np1_host_alloc_pinned(size_t bytes);
+void np1_host_free_pinned(void* p);
