@@ -198,6 +198,12 @@ print(t0, time.time(), bp, c1.ru_utime + c1.ru_stime - c0.ru_utime - c0.ru_stime
 """
 
 
+def _short_kernel(name):
+    """rocprofv3's demangled name without its argument list: 'void np2::(anonymous namespace)::k_x<4>(int*)' -> 'np2::k_x<4>'"""
+    name = name.replace("(anonymous namespace)::", "")
+    return name.split("(")[0].replace("void ", "").strip()
+
+
 def lgs_roofline(worker_code, env, alg_bytes, with_pmc):
     """Per-window device time of the long-read path from the library's own stage clock (NP2_TIMING: stream-synchronised wall
     time per stage, second call = warm), the dominant stage, and the PMC traffic of ALL its kernels per window."""
@@ -235,11 +241,11 @@ def lgs_roofline(worker_code, env, alg_bytes, with_pmc):
             calls = 2     # the worker's warm-up call + its one timed call = two windows
             name, n, tot_ns, avg_ns = ks[0]
             per_window_ms = tot_ns / calls / 1e6
-            out.update({"kernel": name.split("(")[0], "kernel_ms": round(per_window_ms, 3), "kernel_launches_per_window": n / calls,
+            out.update({"kernel": _short_kernel(name), "kernel_ms": round(per_window_ms, 3), "kernel_launches_per_window": n / calls,
                         "kernel_avg_launch_us": round(avg_ns / 1e3, 1), "achieved": round(alg_bytes / (per_window_ms * 1e-3) / 1e9, 3),
                         "frac": round(alg_bytes / (per_window_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                         "kernels_ms_per_window": round(sum(r[2] for r in ks) / calls / 1e6, 2),
-                        "top_kernels_ms_per_window": {r[0].split("(")[0][:60]: round(r[2] / calls / 1e6, 3) for r in ks[:6]},
+                        "top_kernels_ms_per_window": {_short_kernel(r[0])[:60]: round(r[2] / calls / 1e6, 3) for r in ks[:6]},
                         "achieved_all_kernels_gbs": round(alg_bytes / (sum(r[2] for r in ks) / calls * 1e-9) / 1e9, 3)})
         except Exception as e:
             out["kernel_stats_error"] = repr(e)

@@ -29,6 +29,7 @@
 #include "np1_kmer_kernels.h"
 #include "np_bgzf.h"
 #include "np_inflate_dev.h"
+#include "np_inflate_lane.h"
 #include "np_crc_dev.h"
 #include "np_crc32.h"
 
@@ -59,6 +60,20 @@ __global__ __launch_bounds__(256, 4) void k_inflate(const uint8_t* __restrict__ 
     int rc = 0;
     if (d.out_len) rc = npdev::inflate_block_wave(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, lds[wave]);
     if ((threadIdx.x & 63u) == 0) status[b] = (uint32_t)rc;
+}
+
+// Lane-per-block decoder (np_inflate_lane.h): every lane inflates blocks of its own, start to end (lane, lane + lanes, ...), with a
+// table slice of its own in HBM scratch.  Throughput comes from the number of lanes in flight, not from the speed of one stream.
+__global__ __launch_bounds__(64, 4) void k_inflate_lanes(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks,
+                                                         uint8_t* out, uint32_t* __restrict__ status, uint32_t* __restrict__ tables) {
+    const uint32_t lanes = gridDim.x * 64u, me = blockIdx.x * 64u + threadIdx.x;
+    uint32_t* tab = tables + (size_t)me * nplane::LANE_TABLE_WORDS;
+    for (uint32_t b = me; b < n_blocks; b += lanes) {
+        const npdev::BlockDesc d = blocks[b];
+        int rc = 0;
+        if (d.out_len) rc = nplane::inflate_block(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, tab);
+        status[b] = (uint32_t)rc;
+    }
 }
 
 // gzip trailer CRC of every block the decoder accepted (np_crc_dev.h; the reference's htslib rejects a block whose CRC differs)
@@ -260,12 +275,12 @@ namespace np1ingest {
 
 struct Scratch {
     DevBuf comp, inflated, blocks, status, segs, counts, rec_base, first_seg, small, scan_tmp, rec_off, rec_seg, keep, kidx, ncw, seqb, qualb, cig_at, seq_at, qual_at, geo, voff,
-        voff_end, crc_shift;
+        voff_end, crc_shift, lane_tables;
     std::vector<uint32_t> h_status;
     uint64_t n_host_blocks = 0;
     ~Scratch() {
         DevBuf* all[] = {&comp, &inflated, &blocks, &status, &segs, &counts, &rec_base, &first_seg, &small, &scan_tmp, &rec_off, &rec_seg, &keep, &kidx, &ncw,
-                         &seqb, &qualb, &cig_at, &seq_at, &qual_at, &geo, &voff, &voff_end, &crc_shift};
+                         &seqb, &qualb, &cig_at, &seq_at, &qual_at, &geo, &voff, &voff_end, &crc_shift, &lane_tables};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -507,6 +522,16 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
     uint64_t* d_tot = reinterpret_cast<uint64_t*>(W.small.as<uint8_t>() + 64);   // scan totals
     uint64_t n_rec = 0;
     if (n_blocks) {
+        // which decoder: a lane per block when the batch has blocks enough to fill the chip with lanes (np_inflate_lane.h), else a
+        // wave per block (np_inflate_dev.h).  NP1_INFLATE=lanes | wave forces one.
+        static const int mode = [] { const char* e = getenv("NP1_INFLATE"); return !e ? 0 : strcmp(e, "lanes") == 0 ? 1 : strcmp(e, "wave") == 0 ? 2 : 0; }();
+        static const uint32_t max_lanes = getenv("NP1_INFLATE_LANES") ? (uint32_t)atoi(getenv("NP1_INFLATE_LANES")) : 131072u;
+        if (mode == 1 || (mode == 0 && n_blocks >= 4096u)) {
+            const uint32_t lanes = std::min<uint32_t>((n_blocks + 63u) & ~63u, max_lanes);
+            if (W.lane_tables.ensure((size_t)lanes * nplane::LANE_TABLE_WORDS * 4)) return -1;
+            k_inflate_lanes<<<lanes / 64, 64, 0, q>>>(W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(),
+                                                       W.lane_tables.as<uint32_t>());
+        } else
         k_inflate<<<nblk(n_blocks, 4), 256, 0, q>>>(W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>());
         static const bool check_crc = getenv("NP_BGZF_NO_CRC") == nullptr;      // the same switch as the host reader's (np_bgzf.cpp)
         if (check_crc) {
@@ -682,7 +707,13 @@ extern "C" int64_t np1_debug_inflate_device_prof(int device, const uint8_t* bgzf
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, nullptr);
-    if (!blocks.empty()) {
+    static const bool use_lanes = getenv("NP1_INFLATE") && strcmp(getenv("NP1_INFLATE"), "lanes") == 0;
+    DevBuf dt;
+    if (use_lanes && !prof && dt.ensure((size_t)((blocks.size() + 63) & ~63ull) * nplane::LANE_TABLE_WORDS * 4)) return -1;
+    if (!blocks.empty() && use_lanes && !prof) {
+        const uint32_t lanes = (uint32_t)((blocks.size() + 63) & ~63ull);
+        k_inflate_lanes<<<lanes / 64, 64>>>(dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>(), dt.as<uint32_t>());
+    } else if (!blocks.empty()) {
         if (prof) k_inflate_prof<<<nblk(blocks.size(), 4), 256>>>(dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>(), dp.as<unsigned long long>());
         else k_inflate<<<nblk(blocks.size(), 4), 256>>>(dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>());
     }
@@ -694,6 +725,6 @@ extern "C" int64_t np1_debug_inflate_device_prof(int device, const uint8_t* bgzf
     dp.release();
     if (u) HIPCHK(hipMemcpy(out, du.p, u, hipMemcpyDeviceToHost));
     if (!blocks.empty()) HIPCHK(hipMemcpy(status, ds.p, 4 * blocks.size(), hipMemcpyDeviceToHost));
-    dc.release(); du.release(); db.release(); ds.release();
+    dc.release(); du.release(); db.release(); ds.release(); dt.release();
     return (int64_t)blocks.size();
 }

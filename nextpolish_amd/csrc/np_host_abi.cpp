@@ -8,6 +8,7 @@
 #include "np1_priv.h"
 #include "np_synth.h"
 #include "np_inflate.h"
+#include "np_inflate_lane.h"
 #include "np_crc32.h"
 
 
@@ -168,6 +169,11 @@ int np1_stream_synth_diploid(const np1_diploid_params* p, const char* prefix, np
 /* test hook: the BGZF block decoder on a raw DEFLATE stream (1 = accepted and dst filled) */
 int np1_debug_inflate(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) {
     return np::inflate_raw(src, (size_t)src_len, dst, (size_t)dst_len) ? 1 : 0;
+}
+/* test hook: the lane-per-block decoder of the device-side ingest (np_inflate_lane.h), run on the host: 1 = accepted and dst filled */
+int np1_debug_inflate_lane(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) {
+    std::vector<uint32_t> tab(nplane::LANE_TABLE_WORDS);
+    return nplane::inflate_block(src, (uint32_t)src_len, dst, (uint32_t)dst_len, tab.data()) == 0 ? 1 : 0;
 }
 /* test hook: the CRC-32 the BGZF reader / writer compute per block (np_crc32.h: carry-less-multiply folding) */
 uint32_t np1_debug_crc32(const uint8_t* src, uint64_t len) { return np::crc32_block(src, (size_t)len); }

@@ -11,12 +11,16 @@ import pytest
 from nextpolish_amd import _native as nat
 
 
+DECODER = "np1_debug_inflate"      # the host decoder; the tests below run a second time on np1_debug_inflate_lane
+
+
 def _inflate(raw, n):
     L = nat.lib()
-    L.np1_debug_inflate.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
-    L.np1_debug_inflate.restype = C.c_int
-    out = C.create_string_buffer(max(1, n))
-    ok = L.np1_debug_inflate(raw, len(raw), out, n)
+    fn = getattr(L, DECODER)
+    fn.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
+    fn.restype = C.c_int
+    out = C.create_string_buffer(max(1, n) + 16)
+    ok = fn(raw, len(raw), out, n)
     return bool(ok), out.raw[:n]
 
 
@@ -106,3 +110,20 @@ def test_block_crc32_equals_zlib():
         n = min(n, len(blob) - off)
         piece = blob[off:off + n]
         assert L.np1_debug_crc32(piece, n) == (zlib.crc32(piece) & 0xffffffff), n
+
+
+@pytest.fixture
+def lane_decoder(monkeypatch):
+    """the lane-per-block decoder of the device-side ingest (nextpolish_amd/csrc/np_inflate_lane.h: the same C++ the GPU lanes run)"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "DECODER", "np1_debug_inflate_lane")
+
+
+@pytest.mark.parametrize("level", [0, 1, 4, 6, 9])
+def test_lane_decoder_matches_zlib_on_every_block_kind(level, lane_decoder):
+    test_matches_zlib_on_every_block_kind(level)
+
+
+def test_lane_decoder_multi_block_streams_and_damage(lane_decoder):
+    test_multi_block_streams_and_flushes()
+    test_damaged_or_mismatched_streams_are_never_wrong()

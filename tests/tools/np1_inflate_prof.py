@@ -9,8 +9,11 @@ TAKE = int(float(sys.argv[2]) * 1e6) if len(sys.argv) > 2 else 64000000
 src = sys.argv[3] if len(sys.argv) > 3 else None
 if src is None:
     d = tempfile.mkdtemp(prefix="np1inf_")
-    st = nat.Stream.synth([2500000] * 4, depth=30.0, seed=5, with_qual=WQ)
-    st.write_files(os.path.join(d, "g.fa"), os.path.join(d, "r.bam"))
+    st = nat.Stream.synth([2500000] * int(os.environ.get("NP1_PROF_CONTIGS", "4")), depth=30.0, seed=5, with_qual=1 if WQ == 1 else 0)
+    L0 = nat.lib()
+    L0.np1_streams_write_files_q.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    arr = (C.c_void_p * 1)(st.handle)
+    L0.np1_streams_write_files_q(arr, 1, os.path.join(d, "g.fa").encode(), os.path.join(d, "r.bam").encode(), 1, 1 if WQ == 2 else 0)   # WQ 2: binned qualities
     src = os.path.join(d, "r.bam")
 buf = open(src, "rb").read()
 # whole blocks only
