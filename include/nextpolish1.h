@@ -111,7 +111,7 @@ typedef struct {
     const int32_t* pos;
     const uint32_t* ctg;
     const uint16_t* flag;
-    const uint16_t* n_cigar;
+    const uint32_t* n_cigar;
     const int32_t* l_qseq;
     const uint64_t* cigar_off;
     const uint64_t* seq_off;

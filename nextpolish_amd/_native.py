@@ -238,7 +238,7 @@ class Stream(object):
         self.pos = _arr(v.pos, nr, np.int32)
         self.ctg = _arr(v.ctg, nr, np.uint32)
         self.flag = _arr(v.flag, nr, np.uint16)
-        self.n_cigar = _arr(v.n_cigar, nr, np.uint16)
+        self.n_cigar = _arr(v.n_cigar, nr, np.uint32)
         self.l_qseq = _arr(v.l_qseq, nr, np.int32)
         self.cigar_off = _arr(v.cigar_off, nr, np.uint64)
         self.seq_off = _arr(v.seq_off, nr, np.uint64)
@@ -317,7 +317,7 @@ class Stream(object):
             ctg_len=ctg_len, ctg_off=ctg_off, read_begin=read_begin, draft=np.frombuffer(draft, dtype=np.uint8),
             pos=np.array([r["pos"] for r in reads], dtype=np.int32), ctg=np.array([r["ctg"] for r in reads], dtype=np.uint32),
             flag=np.array([r.get("flag", 0) for r in reads], dtype=np.uint16),
-            n_cigar=np.array([len(r["cigar"]) for r in reads], dtype=np.uint16),
+            n_cigar=np.array([len(r["cigar"]) for r in reads], dtype=np.uint32),
             l_qseq=np.array([len(r["seq"]) for r in reads], dtype=np.int32),
             cigar_off=np.array(cigar_off, dtype=np.uint64), seq_off=np.array(seq_off, dtype=np.uint64),
             mapq=np.array([r.get("mapq", 60) for r in reads], dtype=np.uint8),

@@ -69,7 +69,7 @@ struct np1_batch {
     uint64_t G = 0;
     int64_t n_reads = 0;
     // inputs
-    np1dev::DevBuf draft, ctg_off, pos, ctg, flag, ncig, lq, cigoff, seqoff, cigar, seq;
+    np1dev::DevBuf draft, ctg_off, pos, ctg, flag, ncig, ncig16, lq, cigoff, seqoff, cigar, seq;
     // work
     np1dev::DevBuf desc, ovf_desc, slot_g, dbg, dpack, dirty;
     // kmer_count inputs (uploaded only when the stream carries qualities) and work buffers
@@ -100,7 +100,7 @@ struct np1_batch {
     bool has_qual = false;
     std::vector<uint64_t> h_read_begin;
     np1dev::DevBuf qs, qe, span, ins, soff, slot_info, rbase, capb, rowoff, rows, meta, chunk_first, chunk_last, slot_res,
-        slot_rec, pool, heads, redo, redo2, counters, opos, out, bounds, scan_tmp, totals;
+        slot_rec, pool, heads, redo, redo2, redo3, ctx_lists, counters, opos, out, bounds, scan_tmp, totals;
     size_t input_bytes = 0;
     uint32_t max_lq = 0;   // longest record of the batch (bases)
     uint32_t last_counters[np1k::CNT_WORDS] = {0};
@@ -124,14 +124,14 @@ struct np1_batch {
                                   &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg, &kc_pt_se, &kc_pt_len, &kc_woff,
                                   &kc_wpool, &kc_haswin, &sv_failse, &sv_failcnt, &sv_vsz, &sv_voff, &sv_val, &sv_p2ctg, &sv_p2se, &sv_p2len, &sv_woff2,
                                   &sv_haswin2, &sv_range, &qs, &qe, &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
-                                  &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out, &bounds, &scan_tmp, &totals};
+                                  &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &redo3, &ctx_lists, &counters, &opos, &out, &bounds, &scan_tmp, &totals};
         np1dev::DevBuf* theirs[] = {&o.desc, &o.ovf_desc, &o.slot_g, &o.dbg, &o.dpack, &o.dirty, &o.kc_level, &o.kc_endpos, &o.kc_code, &o.kc_flag, &o.kc_fpos, &o.kc_flagged,
                                     &o.kc_work, &o.kc_nd_ctg, &o.kc_nd_se, &o.kc_kr_ctg, &o.kc_kr_se, &o.kc_cnt, &o.kc_sbase, &o.kc_sflag, &o.kc_srefk,
                                     &o.kc_scount, &o.kc_lhead, &o.kc_lpool, &o.kc_stsc, &o.kc_stkm, &o.kc_strk, &o.kc_hpool, &o.kc_workoff, &o.kc_nparts,
                                     &o.kc_partoff, &o.kc_pt_ctg, &o.kc_pt_se, &o.kc_pt_len, &o.kc_woff, &o.kc_wpool, &o.kc_haswin, &o.sv_failse,
                                     &o.sv_failcnt, &o.sv_vsz, &o.sv_voff, &o.sv_val, &o.sv_p2ctg, &o.sv_p2se, &o.sv_p2len, &o.sv_woff2, &o.sv_haswin2,
                                     &o.sv_range, &o.qs, &o.qe, &o.span, &o.ins, &o.soff, &o.slot_info, &o.rbase, &o.capb, &o.rowoff, &o.rows, &o.meta,
-                                    &o.chunk_first, &o.chunk_last, &o.slot_res, &o.slot_rec, &o.pool, &o.heads, &o.redo, &o.redo2, &o.counters, &o.opos,
+                                    &o.chunk_first, &o.chunk_last, &o.slot_res, &o.slot_rec, &o.pool, &o.heads, &o.redo, &o.redo2, &o.redo3, &o.ctx_lists, &o.counters, &o.opos,
                                     &o.out, &o.bounds, &o.scan_tmp, &o.totals};
         static_assert(sizeof(mine) == sizeof(theirs), "work buffer lists differ");
         for (size_t i = 0; i < sizeof(mine) / sizeof(mine[0]); ++i) {
@@ -143,9 +143,9 @@ struct np1_batch {
         out_pinned = false;
     }
     size_t device_bytes() const {
-        const np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
+        const np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &ncig16, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
                                &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
-                               &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out,
+                               &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &redo3, &ctx_lists, &counters, &opos, &out,
                                &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &dpack, &dirty, &mapq, &isize, &qualoff, &qual, &read_begin,
                                &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg, &kc_nd_se,
                                &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool,
@@ -158,9 +158,9 @@ struct np1_batch {
         return t;
     }
     void release_all() {
-        np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
+        np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &ncig16, &lq, &cigoff, &seqoff, &cigar, &seq, &qs, &qe,
                          &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
-                         &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &counters, &opos, &out,
+                         &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &redo3, &ctx_lists, &counters, &opos, &out,
                          &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &dpack, &dirty, &mapq, &isize, &qualoff, &qual, &read_begin,
                          &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg, &kc_nd_se,
                          &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool,

@@ -22,7 +22,7 @@ struct ReadsDev {
     const int32_t* pos;
     const uint32_t* ctg;
     const uint16_t* flag;
-    const uint16_t* n_cigar;
+    const uint32_t* n_cigar;
     const int32_t* l_qseq;
     const uint64_t* cigar_off;
     const uint64_t* seq_off;
@@ -34,13 +34,15 @@ struct ReadsDev {
 constexpr uint32_t SI_INSERT = 0x10, SI_LOWER = 0x20, SI_LAST = 0x40, SI_FIRST = 0x80;
 // k_vote geometry: a wave owns 62 consecutive slots; lanes 0,1 are left-context halo
 constexpr uint32_t VOTE_CH = 62;
+// context lists: 16 / 64 / 160 entries per slot in LDS, then every possible one (3 symbols of 4 bits) in an HBM scratch list
+constexpr int VOTE_E_ALL = 4096;
 // DP record: [slot][n<<16|total][refk | hdr<<16][n x (kmer<<16|count)][8 words state kmers][fmax base | mask<<8]
 constexpr uint32_t FLAG_ALL_RECORDS = 0x100;   // or-ed into the tile kernel's flag_single argument: every slot spills a DP record
 constexpr uint32_t REC_SINGLE = 1, REC_CTG_LAST = 2, REC_CTG_FIRST = 4;   // hdr bits; hdr bits 4..7 = previous slot's draft symbol
 constexpr uint32_t REC_FIXED_WORDS = 12;
 enum { CNT_POOL = 0, CNT_HEADS = 1, CNT_REDO = 2, CNT_ERR = 3, CNT_REDO2 = 4, CNT_OVFDESC = 5,
        CNT_STAT_EVENTS = 6, CNT_STAT_FALLBACK = 7,   // statistics of the event kernels
-       CNT_POOL_S0 = 8, CNT_HEADS_S0 = 16, CNT_WORDS = 24 };   // fused pipeline: pool / run-head counters sharded 8 ways
+       CNT_POOL_S0 = 8, CNT_HEADS_S0 = 16, CNT_REDO3 = 24, CNT_WORDS = 32 };   // fused pipeline: pool / run-head counters sharded 8 ways
 constexpr uint32_t POOL_SHARDS = 8;
 constexpr uint32_t ERR_DOUBLE_INS = 1, ERR_BAD_RECORD = 2, ERR_CTX_OVERFLOW = 4, ERR_POOL_OVERFLOW = 8,
                    ERR_DP_INCONSISTENT = 16, ERR_DESC_OVERFLOW = 32;

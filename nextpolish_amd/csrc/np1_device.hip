@@ -94,13 +94,14 @@ static void stream_facts(np1_stream* st) {
     if (st->facts) return;
     const np::ReadStream& s = st->s;
     const size_t n = s.n_reads();
-    uint32_t mx = 0;
+    uint32_t mx = 0, mx_ops = 0;
     bool dense = s.read_begin.size() == s.n_contigs() + 1 && (n == 0 || (s.cigar_off[0] == 0 && s.seq_off[0] == 0));
     uint64_t c_at = 0, s_at = 0;
     size_t ct = 0;
     for (size_t i = 0; i < n; ++i) {
         const int32_t l = s.l_qseq[i];
         if (l > 0 && (uint32_t)l > mx) mx = (uint32_t)l;
+        if (s.n_cigar[i] > mx_ops) mx_ops = s.n_cigar[i];
         if (dense) {
             while (ct + 1 < s.read_begin.size() && s.read_begin[ct + 1] <= i) ++ct;
             dense = s.cigar_off[i] == c_at && s.seq_off[i] == s_at && s.ctg[i] == ct && l >= 0;
@@ -109,6 +110,11 @@ static void stream_facts(np1_stream* st) {
         }
     }
     st->max_lq = mx;
+    st->ncig16.clear();
+    if (mx_ops <= 0xffffu && n > 0) {
+        st->ncig16.resize(n);
+        for (size_t i = 0; i < n; ++i) st->ncig16[i] = (uint16_t)s.n_cigar[i];
+    }
     st->facts = dense ? 1 : 2;
 }
 
@@ -139,7 +145,13 @@ static int fill_batch(np1_batch* b, const np1_stream* st_, bool sync) {
     rc |= upload(b->ctg_off, s.ctg_off.data(), 4 * s.ctg_off.size(), q);
     rc |= upload(b->pos, s.pos.data(), 4 * n, q);
     rc |= upload(b->flag, s.flag.data(), 2 * n, q);
-    rc |= upload(b->ncig, s.n_cigar.data(), 2 * n, q);
+    if (!st->ncig16.empty()) {   // the usual case: 2 bytes per record cross PCIe, the device widens them
+        rc |= upload(b->ncig16, st->ncig16.data(), 2 * n, q);
+        if (b->ncig.ensure(4 * n)) return -1;
+        if (rc == 0) launch_widen_u16(q, b->ncig16.as<uint16_t>(), b->ncig.as<uint32_t>(), (uint64_t)n);
+    } else {
+        rc |= upload(b->ncig, s.n_cigar.data(), 4 * n, q);
+    }
     rc |= upload(b->lq, s.l_qseq.data(), 4 * n, q);
     rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);
     rc |= upload(b->seq, s.seq.data(), s.seq.size(), q);
@@ -152,7 +164,7 @@ static int fill_batch(np1_batch* b, const np1_stream* st_, bool sync) {
             b->scan_tmp.ensure(8 * (scan_tmp_words((uint64_t)n + 1) + 8)) || b->totals.ensure(256))
             return -1;
         if (rc == 0)
-            launch_record_offsets(q, b->ncig.as<uint16_t>(), b->lq.as<int32_t>(), b->read_begin.as<uint64_t>(), b->nc, (uint64_t)n, b->cigoff.as<uint64_t>(),
+            launch_record_offsets(q, b->ncig.as<uint32_t>(), b->lq.as<int32_t>(), b->read_begin.as<uint64_t>(), b->nc, (uint64_t)n, b->cigoff.as<uint64_t>(),
                                   b->seqoff.as<uint64_t>(), b->ctg.as<uint32_t>(), b->scan_tmp.as<uint64_t>(), b->totals.as<uint64_t>() + 24);
     } else {
         rc |= upload(b->ctg, s.ctg.data(), 4 * n, q);
@@ -196,13 +208,14 @@ int np1_batch_reload(np1_batch* b, const np1_stream* st) {
 int np1_stream_pin(np1_stream* st) {
     if (!st) return -1;
     if (st->pinned) return 0;
+    stream_facts(st);
     np::ReadStream& s = st->s;
     auto reg = [](const void* p, size_t bytes) {
         if (!p || !bytes) return true;
         return hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess;
     };
     bool ok = reg(s.draft.data(), s.draft.size()) && reg(s.pos.data(), 4 * s.pos.size()) && reg(s.ctg.data(), 4 * s.ctg.size()) &&
-              reg(s.flag.data(), 2 * s.flag.size()) && reg(s.n_cigar.data(), 2 * s.n_cigar.size()) && reg(s.l_qseq.data(), 4 * s.l_qseq.size()) &&
+              reg(s.flag.data(), 2 * s.flag.size()) && reg(s.n_cigar.data(), 4 * s.n_cigar.size()) && reg(st->ncig16.data(), 2 * st->ncig16.size()) && reg(s.l_qseq.data(), 4 * s.l_qseq.size()) &&
               reg(s.cigar_off.data(), 8 * s.cigar_off.size()) && reg(s.seq_off.data(), 8 * s.seq_off.size()) &&
               reg(s.cigar.data(), 4 * s.cigar.size()) && reg(s.seq.data(), s.seq.size()) && reg(s.mapq.data(), s.mapq.size()) &&
               reg(s.isize.data(), 4 * s.isize.size()) && reg(s.qual_off.data(), 8 * s.qual_off.size()) && reg(s.qual.data(), s.qual.size());
@@ -251,7 +264,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     const uint32_t nc = b->nc;
     if (nc == 0) { b->h_bounds.assign(1, 0); b->S = 0; b->ran = true; return 0; }
 
-    ReadsDev R{b->pos.as<int32_t>(), b->ctg.as<uint32_t>(), b->flag.as<uint16_t>(), b->ncig.as<uint16_t>(),
+    ReadsDev R{b->pos.as<int32_t>(), b->ctg.as<uint32_t>(), b->flag.as<uint16_t>(), b->ncig.as<uint32_t>(),
                b->lq.as<int32_t>(), b->cigoff.as<uint64_t>(), b->seqoff.as<uint64_t>(), b->cigar.as<uint32_t>(),
                b->seq.as<uint8_t>()};
     const uint32_t* ctg_off = b->ctg_off.as<uint32_t>();
@@ -345,12 +358,28 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                 HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
                 HIPCHK(hipStreamSynchronize(q));
                 if (hc[CNT_REDO2]) {
+                    if (b->redo3.ensure(4 * (size_t)n_chunks)) return -1;
                     launch_vote(q, 160, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
                                 b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->redo2.as<uint32_t>(),
                                 hc[CNT_REDO2], b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(),
-                                pool_cap, counters, b->heads.as<uint32_t>(), nullptr, CNT_REDO2, flag_single);
+                                pool_cap, counters, b->heads.as<uint32_t>(), b->redo3.as<uint32_t>(), CNT_REDO3, flag_single);
                     HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
                     HIPCHK(hipStreamSynchronize(q));
+                    // slots with more than 160 distinct contexts (very deep pileups with ambiguity codes): every possible context gets
+                    // its own list entry, in HBM -- a slice of the list at a time, 1 MiB of scratch per chunk
+                    for (uint32_t at = 0; at < hc[CNT_REDO3];) {
+                        const uint32_t slice = std::min<uint32_t>(hc[CNT_REDO3] - at, 1024u);
+                        if (b->ctx_lists.ensure(4 * vote_hbm_list_words() * (size_t)slice)) return -1;
+                        launch_vote(q, VOTE_E_ALL, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
+                                    b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->redo3.as<uint32_t>() + at, slice,
+                                    b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
+                                    b->heads.as<uint32_t>(), nullptr, CNT_REDO3, flag_single, b->ctx_lists.as<uint32_t>());
+                        at += slice;
+                    }
+                    if (hc[CNT_REDO3]) {
+                        HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+                        HIPCHK(hipStreamSynchronize(q));
+                    }
                 }
             }
             if (hc[CNT_ERR] & ERR_POOL_OVERFLOW) {
@@ -387,9 +416,12 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
             HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
             HIPCHK(hipStreamSynchronize(q));
             if (!(hc[CNT_ERR] & ERR_DESC_OVERFLOW)) break;
-            if (hc[CNT_OVFDESC] <= ovf_cap || attempt >= 2) {   // not a capacity problem: a record is too long for 16-bit query indices
-                np1_set_error("record too long for the short-read descriptors (long reads belong to nextpolish2)");
-                return -1;
+            if (hc[CNT_OVFDESC] <= ovf_cap || attempt >= 2) {
+                // not a capacity problem: a record is too long for the descriptors' 16-bit query indices.  The staged launch sequence
+                // (symbol rows in HBM) has no such bound; this batch takes it from the start.
+                if (fp_rate) { np1_set_error("record too long for the short-read descriptors, which a general indel_balance_factor_sgs needs"); return -1; }
+                b->force_staged = true;
+                return np1_batch_score_chain(b, cfg, stage_ms);
             }
             if (b->ovf_desc.ensure(4 * (size_t)DESC_WORDS * ((size_t)hc[CNT_OVFDESC] + 1024))) return -1;
             uint32_t zero = hc[CNT_ERR] & ~ERR_DESC_OVERFLOW;
@@ -453,9 +485,10 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                 fprintf(stderr, "[k_tile6 cycles/tile] setup %.0f  records %.0f (clean %.0f, exact %.0f)  sort %.0f  tally %.0f  epilogue %.0f  tiles %llu\n",
                         h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n, h[7]);
             }
-            if (rc5 != 0) {
-                np1_set_error("records are too long for the LDS-staged path (long reads belong to nextpolish2)");
-                return -1;
+            if (rc5 != 0) {   // the longest record's bases do not fit the tile's LDS plan: the staged sequence reads them from HBM rows
+                if (fp_rate) { np1_set_error("records are too long for the LDS-staged path, which a general indel_balance_factor_sgs needs"); return -1; }
+                b->force_staged = true;
+                return np1_batch_score_chain(b, cfg, stage_ms);
             }
             t1(5);
             HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
@@ -468,6 +501,12 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                     if (tile(2, b->redo2.as<uint32_t>(), hc[CNT_REDO2], nullptr, CNT_REDO2) != 0) { np1_set_error("LDS plan failed (level 2)"); return -1; }
                     HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
                     HIPCHK(hipStreamSynchronize(q));
+                    if ((hc[CNT_ERR] & ERR_CTX_OVERFLOW) && !fp_rate) {
+                        // more than 160 distinct contexts in a slot: the staged sequence keeps such slots' lists in HBM; this batch takes
+                        // it from the start (a pileup this deep and this ambiguous is not a throughput case)
+                        b->force_staged = true;
+                        return np1_batch_score_chain(b, cfg, stage_ms);
+                    }
                 }
             }
             if (hc[CNT_ERR] & ERR_POOL_OVERFLOW) {
@@ -491,7 +530,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     }
     if (hc[CNT_ERR] & ERR_DOUBLE_INS) { np1_set_error("unsupported CIGAR: two insertion ops at one reference position"); return -1; }
     if (hc[CNT_ERR] & ERR_BAD_RECORD) { np1_set_error("alignment record extends beyond its contig"); return -1; }
-    if (hc[CNT_ERR] & ERR_CTX_OVERFLOW) { np1_set_error("a slot holds more than 160 distinct 3-base contexts"); return -1; }
+    if (hc[CNT_ERR] & ERR_CTX_OVERFLOW) { np1_set_error("a slot holds more than 160 distinct 3-base contexts, which a general indel_balance_factor_sgs cannot take"); return -1; }
     // ---- stage 6: chain DP over multi-state runs
     t0(6);
     {
@@ -715,7 +754,7 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
 
     KcCtx c;
     memset(&c, 0, sizeof(c));
-    c.R = ReadsDev{b->pos.as<int32_t>(), b->ctg.as<uint32_t>(), b->flag.as<uint16_t>(), b->ncig.as<uint16_t>(), b->lq.as<int32_t>(),
+    c.R = ReadsDev{b->pos.as<int32_t>(), b->ctg.as<uint32_t>(), b->flag.as<uint16_t>(), b->ncig.as<uint32_t>(), b->lq.as<int32_t>(),
                    b->cigoff.as<uint64_t>(), b->seqoff.as<uint64_t>(), b->cigar.as<uint32_t>(), b->seq.as<uint8_t>()};
     c.mapq = b->mapq.as<uint8_t>(); c.isize = b->isize.as<int32_t>(); c.qual_off = b->qualoff.as<uint64_t>(); c.qual = b->qual.as<uint8_t>();
     c.level = b->kc_level.as<uint8_t>(); c.endpos = b->kc_endpos.as<int32_t>();
@@ -979,7 +1018,7 @@ int64_t np1_batch_device_bytes(np1_batch* b) { return b ? (int64_t)b->device_byt
 void np1_stream_unpin(np1_stream* st) {
     if (!st || !st->pinned) return;
     np::ReadStream& s = st->s;
-    const void* ptrs[] = {s.draft.data(), s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), s.l_qseq.data(), s.cigar_off.data(),
+    const void* ptrs[] = {s.draft.data(), s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), st->ncig16.data(), s.l_qseq.data(), s.cigar_off.data(),
                           s.seq_off.data(), s.cigar.data(), s.seq.data(), s.mapq.data(), s.isize.data(), s.qual_off.data(), s.qual.data()};
     for (const void* p : ptrs)
         if (p) (void)hipHostUnregister(const_cast<void*>(p));   // fails harmlessly for arrays that were empty / never registered

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_rec_measure(const uint8_t* __restrict__
 }
 
 struct ScatterOut {
-    int32_t* pos; uint32_t* ctg; uint16_t* flag; uint16_t* ncig; int32_t* lq; uint64_t* cigoff; uint64_t* seqoff;
+    int32_t* pos; uint32_t* ctg; uint16_t* flag; uint32_t* ncig; int32_t* lq; uint64_t* cigoff; uint64_t* seqoff;
     uint32_t* cigar; uint8_t* seq; uint8_t* mapq; int32_t* isize; uint64_t* qualoff; uint8_t* qual;
 };
 
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_rec_scatter(const uint8_t* __restrict__
     o.pos[j] = (int32_t)ld32(p + 8);
     o.ctg[j] = segs[rec_seg[r]].ctg;
     o.flag[j] = ld16(p + 18);
-    o.ncig[j] = (uint16_t)n_cigar;
+    o.ncig[j] = n_cigar;
     o.lq[j] = l_seq;
     const uint64_t ca = cig_at[r], sa = seq_at[r];
     o.cigoff[j] = ca;
@@ -611,13 +611,13 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
     b->n_reads = (int64_t)n;
     b->max_lq = h_small[1];
     const size_t nn = n ? n : 1;
-    if (b->pos.ensure(4 * nn) || b->ctg.ensure(4 * nn) || b->flag.ensure(2 * nn) || b->ncig.ensure(2 * nn) || b->lq.ensure(4 * nn) || b->cigoff.ensure(8 * nn) ||
+    if (b->pos.ensure(4 * nn) || b->ctg.ensure(4 * nn) || b->flag.ensure(2 * nn) || b->ncig.ensure(4 * nn) || b->lq.ensure(4 * nn) || b->cigoff.ensure(8 * nn) ||
         b->seqoff.ensure(8 * nn) || b->cigar.ensure(4 * (size_t)totals[1] + 64) || b->seq.ensure((size_t)totals[2] + 64))
         return -1;
     b->has_qual = with_qual;
     if (with_qual && (b->mapq.ensure(nn) || b->isize.ensure(4 * nn) || b->qualoff.ensure(8 * nn) || b->qual.ensure((size_t)totals[3] + 64))) return -1;
     if (n_rec) {
-        ScatterOut o{b->pos.as<int32_t>(), b->ctg.as<uint32_t>(), b->flag.as<uint16_t>(), b->ncig.as<uint16_t>(), b->lq.as<int32_t>(), b->cigoff.as<uint64_t>(),
+        ScatterOut o{b->pos.as<int32_t>(), b->ctg.as<uint32_t>(), b->flag.as<uint16_t>(), b->ncig.as<uint32_t>(), b->lq.as<int32_t>(), b->cigoff.as<uint64_t>(),
                      b->seqoff.as<uint64_t>(), b->cigar.as<uint32_t>(), b->seq.as<uint8_t>(), b->mapq.as<uint8_t>(), b->isize.as<int32_t>(),
                      b->qualoff.as<uint64_t>(), b->qual.as<uint8_t>()};
         k_rec_scatter<<<nblk(n_rec, 256), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.rec_off.as<uint64_t>(), W.rec_seg.as<uint32_t>(), W.segs.as<Segment>(), n_rec,

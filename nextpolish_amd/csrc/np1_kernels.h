@@ -22,15 +22,17 @@ void launch_rowcap(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uin
 void launch_rows(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
                  const int32_t* qs, const int32_t* qe, const uint32_t* rbase, const uint64_t* rowoff, uint8_t* rows,
                  uint4* meta, uint32_t* chunk_first, uint32_t* chunk_last, unsigned long long* votes);
+inline size_t vote_hbm_list_words() { return (size_t)(np1k::VOTE_E_ALL - 2) * 64; }   // per chunk, for launch_vote with E > 160
 void launch_vote(hipStream_t st, int E, const uint4* meta, const uint8_t* rows, const uint8_t* slot_info, uint32_t S,
                  const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint32_t* redo_in,
                  uint32_t n_redo_in, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap,
-                 uint32_t* counters, uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single);
+                 uint32_t* counters, uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, uint32_t* hbm_lists = nullptr);
 void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
                  const int32_t* qs, const int32_t* qe, uint32_t* desc, uint32_t* ovf_pool, uint32_t ovf_cap,
                  uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters, const uint8_t* dpack = nullptr, uint32_t* dirty = nullptr);
 // cigar_off / seq_off / ctg of a dense record stream on the device (cigoff and seqoff get n + 1 entries)
-void launch_record_offsets(hipStream_t st, const uint16_t* ncig, const int32_t* lq, const uint64_t* read_begin, uint32_t nc, uint64_t n, uint64_t* cigoff,
+void launch_widen_u16(hipStream_t st, const uint16_t* src, uint32_t* dst, uint64_t n);   // the 16-bit upload form of the CIGAR operation counts
+void launch_record_offsets(hipStream_t st, const uint32_t* ncig, const int32_t* lq, const uint64_t* read_begin, uint32_t nc, uint64_t n, uint64_t* cigoff,
                            uint64_t* seqoff, uint32_t* ctg, uint64_t* tmp, uint64_t* total);
 // the draft as packed 4-bit codes (the layout of the reads' bases): what k_desc compares the records with for their dirty hulls
 void launch_dpack(hipStream_t st, const uint8_t* draft, uint32_t G, uint8_t* dpack);

@@ -1709,7 +1709,8 @@ __global__ __launch_bounds__(256) void k_vote(const uint4* __restrict__ meta, co
                                               uint16_t* __restrict__ slot_res, uint32_t* __restrict__ slot_rec,
                                               uint32_t* __restrict__ pool, uint32_t pool_cap,
                                               uint32_t* __restrict__ counters, uint32_t* __restrict__ heads,
-                                              uint32_t* __restrict__ redo_out, uint32_t redo_ci, uint32_t flag_single) {
+                                              uint32_t* __restrict__ redo_out, uint32_t redo_ci, uint32_t flag_single,
+                                              uint32_t* __restrict__ hbm_lists) {
     extern __shared__ uint32_t lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t ci = blockIdx.x * 4 + wave;
@@ -1721,7 +1722,8 @@ __global__ __launch_bounds__(256) void k_vote(const uint4* __restrict__ meta, co
         c = ci;
         if (c >= n_chunks) return;
     }
-    uint32_t* L = lds + wave * (E - 2) * 64;
+    // the wave's context lists: LDS, or (E = every possible context) its stretch of the HBM scratch
+    uint32_t* L = hbm_lists ? hbm_lists + (size_t)ci * (E - 2) * 64 : lds + wave * (E - 2) * 64;
     const int64_t s64 = (int64_t)c * VOTE_CH - 2 + lane;
     const bool valid = s64 >= 0 && s64 < (int64_t)S;
     const uint32_t s = (uint32_t)s64;
@@ -1856,7 +1858,7 @@ void launch_scan_u8(hipStream_t st, const uint8_t* v, uint64_t n, uint32_t* out,
 // the per-record arrays of a dense record stream rebuilt on the device instead of uploaded (np1_device.hip:fill_batch): pool offsets
 // as running sums of the CIGAR lengths / packed base bytes, and the contig of every record from the contigs' record ranges
 struct LoadNcig {
-    const uint16_t* p;
+    const uint32_t* p;
     __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
 };
 struct LoadSeqBytes {
@@ -1873,7 +1875,14 @@ __global__ __launch_bounds__(256) void k_record_contig(const uint64_t* __restric
     }
     ctg[r] = lo;
 }
-void launch_record_offsets(hipStream_t st, const uint16_t* ncig, const int32_t* lq, const uint64_t* read_begin, uint32_t nc, uint64_t n, uint64_t* cigoff,
+__global__ __launch_bounds__(256) void k_widen_u16(const uint16_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+void launch_widen_u16(hipStream_t st, const uint16_t* src, uint32_t* dst, uint64_t n) {
+    if (n) k_widen_u16<<<nblk(n, 256), 256, 0, st>>>(src, dst, n);
+}
+void launch_record_offsets(hipStream_t st, const uint32_t* ncig, const int32_t* lq, const uint64_t* read_begin, uint32_t nc, uint64_t n, uint64_t* cigoff,
                            uint64_t* seqoff, uint32_t* ctg, uint64_t* tmp, uint64_t* total) {
     if (n == 0) return;
     scan_impl<LoadNcig, uint64_t>(st, LoadNcig{ncig}, n, cigoff, tmp, total);
@@ -1908,14 +1917,19 @@ void launch_rows(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint3
 void launch_vote(hipStream_t st, int E, const uint4* meta, const uint8_t* rows, const uint8_t* slot_info, uint32_t S,
                  const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint32_t* redo_in,
                  uint32_t n_redo_in, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap,
-                 uint32_t* counters, uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single) {
+                 uint32_t* counters, uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, uint32_t* hbm_lists) {
     uint32_t work = redo_in ? n_redo_in : n_chunks;
     if (work == 0) return;
     unsigned blocks = nblk(work, 4);
+    if (E > 160) {   // hbm_lists: vote_hbm_list_words() words per chunk of the redo list
+        k_vote<VOTE_E_ALL><<<blocks, 256, 0, st>>>(meta, rows, slot_info, S, chunk_first, chunk_last, n_chunks, redo_in, n_redo_in, slot_res, slot_rec, pool,
+                                                  pool_cap, counters, heads, redo_out, redo_ci, flag_single, hbm_lists);
+        return;
+    }
 #define NP1_VOTE(EE)                                                                                              \
     k_vote<EE><<<blocks, 256, 4 * ((EE)-2) * 64 * sizeof(uint32_t), st>>>(                                        \
         meta, rows, slot_info, S, chunk_first, chunk_last, n_chunks, redo_in, n_redo_in, slot_res, slot_rec, pool, \
-        pool_cap, counters, heads, redo_out, redo_ci, flag_single)
+        pool_cap, counters, heads, redo_out, redo_ci, flag_single, nullptr)
     if (E <= 16) NP1_VOTE(16);
     else if (E <= 64) NP1_VOTE(64);
     else NP1_VOTE(160);

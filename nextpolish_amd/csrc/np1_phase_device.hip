@@ -370,7 +370,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
     auto make_ctx = [&](np1_batch* x) {
         KcCtx c;
         memset(&c, 0, sizeof(c));
-        c.R = ReadsDev{x->pos.as<int32_t>(), x->ctg.as<uint32_t>(), x->flag.as<uint16_t>(), x->ncig.as<uint16_t>(), x->lq.as<int32_t>(),
+        c.R = ReadsDev{x->pos.as<int32_t>(), x->ctg.as<uint32_t>(), x->flag.as<uint16_t>(), x->ncig.as<uint32_t>(), x->lq.as<int32_t>(),
                        x->cigoff.as<uint64_t>(), x->seqoff.as<uint64_t>(), x->cigar.as<uint32_t>(), x->seq.as<uint8_t>()};
         c.mapq = x->mapq.as<uint8_t>(); c.isize = x->isize.as<int32_t>(); c.qual_off = x->qualoff.as<uint64_t>(); c.qual = x->qual.as<uint8_t>();
         c.level = x->kc_level.as<uint8_t>(); c.endpos = x->kc_endpos.as<int32_t>();

@@ -12,6 +12,9 @@ struct np1_stream {
     // record's place in read_begin) -- then 20 of the 32 fixed bytes per record need not cross PCIe
     int facts = 0;         // 0 not looked at yet, 1 dense, 2 not dense
     uint32_t max_lq = 0;
+    // CIGAR operation counts in the 16 bits the BAM record gives them, for the upload (the device widens them): only a CG-tag CIGAR
+    // needs more, and a stream that holds one uploads its 32-bit counts as they are.  Empty: not made / does not apply.
+    std::vector<uint16_t> ncig16;
 };
 
 void np1_set_error(const std::string& e);   // np_host_abi.cpp

@@ -265,6 +265,23 @@ void BamWriter::index_record(int32_t tid, int32_t beg, int32_t end, voff_t v0, v
 bool BamWriter::write(int32_t tid, int32_t pos, uint8_t mapq, uint16_t flag, int32_t mtid, int32_t mpos,
                       int32_t isize, const std::string& qname, const uint32_t* cigar, uint32_t n_cigar,
                       const uint8_t* seq4, const uint8_t* qual, int32_t l_qseq, const uint8_t* aux, size_t aux_len) {
+    if (n_cigar > 0xffffu) {
+        // SAMv1 4.2.2: the 16-bit count cannot hold this CIGAR -- the record carries the placeholder "<l_qseq>S<reference length>N"
+        // and the operations go into the tag CG:B:I (what htslib's bam_write1 does; readers swap them back)
+        int64_t ref_len = 0;
+        for (uint32_t i = 0; i < n_cigar; ++i) {
+            const uint32_t op = cigar[i] & 0xf;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += cigar[i] >> 4;
+        }
+        const uint32_t fake[2] = {(uint32_t)l_qseq << 4 | 4u, (uint32_t)ref_len << 4 | 3u};
+        std::vector<uint8_t> aux2(aux_len + 8 + 4 * (size_t)n_cigar);
+        if (aux_len) memcpy(aux2.data(), aux, aux_len);
+        uint8_t* t = aux2.data() + aux_len;
+        memcpy(t, "CGBI", 4);
+        memcpy(t + 4, &n_cigar, 4);
+        memcpy(t + 8, cigar, 4 * (size_t)n_cigar);
+        return write(tid, pos, mapq, flag, mtid, mpos, isize, qname, fake, 2, seq4, qual, l_qseq, aux2.data(), aux2.size());
+    }
     int32_t rl = 0;
     for (uint32_t i = 0; i < n_cigar; ++i) {
         uint32_t op = cigar[i] & 0xf;

@@ -26,7 +26,7 @@ static void append_record(const BamRec& r, uint32_t c, bool with_qual, ReadStrea
     s->pos.push_back(r.pos);
     s->ctg.push_back(c);
     s->flag.push_back(r.flag);
-    s->n_cigar.push_back((uint16_t)r.n_cigar);
+    s->n_cigar.push_back(r.n_cigar);
     s->l_qseq.push_back(r.l_qseq);
     s->mapq.push_back(r.mapq);
     s->isize.push_back(r.isize);
@@ -114,10 +114,6 @@ bool load_stream(const std::string& fasta, const std::string& bam, const std::ve
             if (r.tid < tid) continue;
             if (r.pos >= L) { pending = true; break; }                  // iterator stop: beg >= end
             if (r.pos < 0 || r.endpos() <= 0) continue;
-            if (r.n_cigar > 0xffffu) {   // a CG-tag CIGAR swapped in by the reader: the short-read stream keeps 16-bit operation counts
-                *err = "alignment with more than 65535 CIGAR operations in " + bam + " (long reads belong to nextpolish2)";
-                return false;
-            }
             append_record(r, (uint32_t)c, with_qual, out, rec_v0, rec_v1);
         }
         if (r.tid < 0 && pending) { /* unplaced reads follow: nothing more for any contig */ }

@@ -26,7 +26,7 @@ struct ReadStream {
     std::vector<int32_t> pos;           // 0-based leftmost draft coordinate inside the contig
     std::vector<uint32_t> ctg;          // contig index inside this batch
     std::vector<uint16_t> flag;
-    std::vector<uint16_t> n_cigar;
+    std::vector<uint32_t> n_cigar;   // 32 bits: a CIGAR swapped in from a CG tag has more than 65 535 operations (htslib: bam1_core_t.n_cigar is 32-bit too)
     std::vector<int32_t> l_qseq;
     std::vector<uint64_t> cigar_off;    // index of the first op in `cigar`
     std::vector<uint64_t> seq_off;      // byte offset of the first base pair in `seq`

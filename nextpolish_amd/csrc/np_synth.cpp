@@ -397,7 +397,7 @@ void synth_contig_segmented(const np_synth_params& p, int c, const std::string& 
                 out->pos[ri] = r.pos;
                 out->ctg[ri] = (uint32_t)c;
                 out->flag[ri] = r.flag;
-                out->n_cigar[ri] = (uint16_t)r.cig_n;
+                out->n_cigar[ri] = (uint32_t)r.cig_n;
                 out->l_qseq[ri] = (int32_t)r.l_qseq;
                 out->mapq[ri] = r.mapq;
                 out->isize[ri] = r.isize;
@@ -505,7 +505,7 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
             out->pos.push_back(r.pos);
             out->ctg.push_back((uint32_t)c);
             out->flag.push_back(r.flag);
-            out->n_cigar.push_back((uint16_t)r.cig_n);
+            out->n_cigar.push_back((uint32_t)r.cig_n);
             out->l_qseq.push_back((int32_t)r.l_qseq);
             out->mapq.push_back(r.mapq);
             out->isize.push_back(r.isize);
@@ -594,7 +594,7 @@ bool synth_long_stream(const np_synth_long_params& p, const std::string& prefix,
             out->pos.push_back(st);
             out->ctg.push_back((uint32_t)c);
             out->flag.push_back((uint16_t)(rng.chance(0.5) ? 16 : 0));
-            out->n_cigar.push_back((uint16_t)cig.size());
+            out->n_cigar.push_back((uint32_t)cig.size());
             out->l_qseq.push_back((int32_t)seq.size());
             out->mapq.push_back(60);
             out->isize.push_back(0);
@@ -899,7 +899,7 @@ void append_read(np::ReadStream* out, uint32_t c, const DRead& r, uint16_t flag,
     out->pos.push_back(r.pos);
     out->ctg.push_back(c);
     out->flag.push_back(flag);
-    out->n_cigar.push_back((uint16_t)r.cig.size());
+    out->n_cigar.push_back((uint32_t)r.cig.size());
     out->l_qseq.push_back((int32_t)r.seq.size());
     out->mapq.push_back(mapq);
     out->isize.push_back(isize);

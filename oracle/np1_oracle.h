@@ -51,7 +51,7 @@ typedef struct {
     int64_t n_reads;
     const int32_t* pos;
     const uint16_t* flag;
-    const uint16_t* n_cigar;
+    const uint32_t* n_cigar;
     const int32_t* l_qseq;
     const uint8_t* mapq;
     const int32_t* isize;

@@ -96,3 +96,58 @@ def random_case(seed, n_contigs=2, max_len=160, max_reads=40, letters="ACGT", od
         rs.sort(key=lambda r: r["pos"])
         reads += rs
     return contigs, reads
+
+
+# ---- inputs beyond the bounds of the fast launch sequence (tests of the lifted limits) -----------------------------------------
+def long_record_case(seed, n_ops=70000, plain_bases=70000):
+    """one contig; a record of more than 65 535 CIGAR operations (what a CG tag carries), one of more than 65 535 bases in a single
+    match, and a shallow layer of ordinary reads over the same stretch"""
+    import random
+    rng = random.Random(seed)
+    L = 2 * n_ops + plain_bases + 3000
+    draft = "".join(rng.choice("ACGT") for _ in range(L))
+    reads = []
+    # (a) alternating 1M / 1I / 1M / 1D ... : n_ops operations
+    cig, seq, g = [], [], 500
+    pos_a = g
+    for k in range(n_ops // 4):
+        cig += [("M", 2), ("I", 1), ("M", 1), ("D", 1)]
+        seq += [draft[g], draft[g + 1], rng.choice("ACGT"), draft[g + 2]]
+        g += 4
+    cig.append(("M", 40))
+    seq += list(draft[g:g + 40])
+    reads.append(dict(ctg=0, pos=pos_a, cigar=cig, seq="".join(seq)))
+    # (b) one long match with a few substitutions
+    pos_b = pos_a + 1000
+    sb = list(draft[pos_b:pos_b + plain_bases])
+    for _ in range(50):
+        sb[rng.randrange(len(sb))] = rng.choice("ACGT")
+    reads.append(dict(ctg=0, pos=pos_b, cigar=[("M", plain_bases)], seq="".join(sb)))
+    # (c) ordinary reads
+    for _ in range(L // 30):
+        p = rng.randrange(0, L - 150)
+        s = list(draft[p:p + 150])
+        if rng.random() < 0.3:
+            s[rng.randrange(150)] = rng.choice("ACGT")
+        reads.append(dict(ctg=0, pos=p, cigar=[("M", 150)], seq="".join(s)))
+    reads.sort(key=lambda r: r["pos"])
+    return [("long", draft)], reads
+
+
+def crowded_context_case(seed, depth=900, L=400):
+    """a pileup whose reads carry every nt16 code at random: far more than 160 distinct 3-symbol contexts in a slot"""
+    import random
+    rng = random.Random(seed)
+    draft = "".join(rng.choice("ACGT") for _ in range(L))
+    codes = "=ACMGRSVTWYHKDBN"
+    reads = []
+    for _ in range(depth):
+        p = rng.randrange(0, L - 100)
+        s = "".join(rng.choice(codes) for _ in range(100))
+        if rng.random() < 0.3:
+            k = rng.randrange(10, 90)
+            reads.append(dict(ctg=0, pos=p, cigar=[("M", k), ("I", 2), ("M", 98 - k)], seq=s))
+        else:
+            reads.append(dict(ctg=0, pos=p, cigar=[("M", 100)], seq=s))
+    reads.sort(key=lambda r: r["pos"])
+    return [("crowd", draft)], reads

@@ -326,7 +326,22 @@ int np1m_fused = 0;   // 0: staged sequence (rows in memory), 1: descriptors (k_
 
 // Returns 0 on success; *out is malloc'd concatenation of the polished contigs, bounds[n_contigs+1].
 // stats (optional, 4 words): slots, dp heads, pool words, max context list length escalations
+static int score_chain_once(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds, uint64_t* stats);
+int np1m_restarts = 0, np1m_deep_chunks = 0;   // what the last call needed: staged restarts, chunks voted with HBM-sized context lists
 int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds, uint64_t* stats) {
+    np1m_restarts = 0;
+    np1m_deep_chunks = 0;
+    int rc = score_chain_once(v, cfg, out, bounds, stats);
+    if ((rc == -5 || rc == -3) && np1m_fused) {   // np1_device.hip: force_staged
+        const int keep = np1m_fused;
+        np1m_fused = 0;
+        ++np1m_restarts;
+        rc = score_chain_once(v, cfg, out, bounds, stats);
+        np1m_fused = keep;
+    }
+    return rc;
+}
+static int score_chain_once(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds, uint64_t* stats) {
     const uint32_t nc = (uint32_t)v->n_contigs;
     const int64_t n = v->n_reads;
     const uint64_t G = (uint64_t)v->draft_len;
@@ -359,6 +374,7 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
     std::vector<uint16_t> slot_res(S + 64, 0xffff);
     std::vector<uint32_t> slot_rec(S + 64, 0xffffffffu), pool, heads;
     uint64_t escal = 0;
+    int& deep = np1m_deep_chunks;
     if (np1m_fused) {
         std::vector<uint32_t> desc((size_t)(n ? n : 1) * DESC_WORDS, 0xdeadbeefu);
         const uint32_t ovf_cap = (uint32_t)(v->cigar_len + 16);
@@ -438,7 +454,9 @@ int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out,
             if (vote_chunk<16>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
             ++escal;
             if (vote_chunk<64>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
-            if (!vote_chunk<160>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) return -3;
+            if (vote_chunk<160>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
+            ++deep;   // every possible context in its own entry (the device keeps these lists in HBM)
+            if (!vote_chunk<VOTE_E_ALL>(c, meta, rows, slot_info, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) return -3;
         }
 
     }

@@ -48,7 +48,9 @@ def score_chain(stream, cfg=None, want_stats=False, fused=False):
     lib().np1m_free(out)
     res = [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)]
     if want_stats:
-        return res, dict(slots=stats[0], heads=stats[1], pool_words=stats[2], escalations=stats[3])
+        return res, dict(slots=stats[0], heads=stats[1], pool_words=stats[2], escalations=stats[3],
+                         restarts=C.c_int.in_dll(lib(), "np1m_restarts").value,        # staged restarts (a record beyond the descriptors, > 160 contexts)
+                         deep_chunks=C.c_int.in_dll(lib(), "np1m_deep_chunks").value)   # chunks voted with one list entry per possible context
     return res
 
 

@@ -341,3 +341,66 @@ def test_streamed_pipe_matches_oracle_and_direct_path(tmp_path):
     w = ob.from_files("kmer_count", fa, bam, ob.default_config(read_tlen=1500))
     assert [s for _, s in out] == [w[big.names[i]] for i in (3, 1)]
     pipe.close()
+
+
+def test_records_beyond_16_bit_counts_take_the_staged_sequence(ctx):
+    """more than 65 535 CIGAR operations (a CG-tag CIGAR) and more than 65 535 bases in one record: the reference walks any record
+    (contig.c:247-331); the descriptors index the query with 16 bits, so the batch re-runs on symbol rows -- and a second, ordinary
+    batch on the same batch object is back on the descriptors"""
+    from fuzzgen import long_record_case
+    contigs, reads = long_record_case(3)
+    st = nat.Stream.from_reads(contigs, reads)
+    assert int(st.n_cigar.max()) > 65535 and int(st.l_qseq.max()) > 65535
+    _check(ctx, st)
+    _check(ctx, nat.Stream.synth([30000], depth=30, seed=9))
+
+
+def test_more_than_160_contexts_in_a_slot(ctx):
+    """base.c:60-71: the reference's context list of a slot grows without bound; the fourth vote level keeps every possible context
+    (3 symbols of 4 bits) in an HBM list"""
+    from fuzzgen import crowded_context_case
+    contigs, reads = crowded_context_case(11)
+    _check(ctx, nat.Stream.from_reads(contigs, reads))
+    contigs, reads = crowded_context_case(12, depth=3000, L=2000)
+    _check(ctx, nat.Stream.from_reads(contigs, reads))
+
+
+def test_staged_sequence_matches_oracle():
+    """NP1_PIPELINE=staged: symbol rows in HBM + k_vote, the sequence batches with over-long records or over-crowded slots fall back to"""
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from nextpolish_amd import _native as nat\nfrom nextpolish_amd.device import Context\nimport oracle_binding as ob\n"
+            "from fuzzgen import random_case\n"
+            "c = Context(0)\n"
+            "sts = [nat.Stream.synth([20000, 3000, 700], depth=d, seed=40 + d, weird_rate=0.02, read_indel=0.002, softclip_rate=0.05) for d in (15, 60)]\n"
+            "sts += [nat.Stream.from_reads(*random_case(s)) for s in range(40)]\n"
+            "sts.append(nat.Stream.synth([4000], depth=300, seed=5, read_sub=0.08, read_indel=0.01))\n"
+            "for st in sts:\n"
+            "    got = c.score_chain(st)\n"
+            "    for i in range(st.n_contigs):\n"
+            "        assert got[i] == ob.score_chain(st, i)\n"
+            "print('staged ok', len(sts))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, NP1_PIPELINE="staged")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "staged ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_kmer_count_with_records_beyond_16_bit_counts(ctx, tmp_path):
+    """tasks 2 / 4 walk the records themselves (np1_kmer.h), no descriptors: a CG-tag CIGAR only needs the 32-bit operation count --
+    in memory, and from the files (device ingest meets the placeholder CIGAR and hands the file to the host loader)"""
+    from fuzzgen import long_record_case
+    contigs, reads = long_record_case(7, n_ops=66000, plain_bases=66000)
+    st = nat.Stream.from_reads(contigs, reads)
+    _check_kmer(ctx, st)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "g.bam")
+    st.write_files(fa, bam)
+    cfgp = nat.lib().config_init(fa.encode(), bam.encode(), None)
+    ocfg = ob.default_config(read_tlen=cfgp.contents.read_tlen, read_len=cfgp.contents.read_len)
+    nat.lib().config_destory(cfgp)
+    exe = os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1")
+    for cmd, task in (("kmercount", "kmer_count"), ("snpvalid", "snp_valid")):
+        out = subprocess.run([exe, cmd, fa, bam], stdout=subprocess.PIPE, timeout=600, check=True).stdout.decode()
+        assert parse_cli_fasta(out) == ob.from_files(task, fa, bam, ocfg), cmd
+    out = subprocess.run([exe, "scorechain", fa, bam], stdout=subprocess.PIPE, timeout=600, check=True).stdout.decode()
+    st2 = nat.Stream.load(fa, bam)
+    assert parse_cli_fasta(out)["long"] == ob.score_chain(st2, 0)

@@ -51,6 +51,30 @@ def test_model_crowded_slots_escalate():
     assert got[0] == ob.score_chain(st, 0)
 
 
+@pytest.mark.parametrize("fused", [0, 1])
+def test_model_records_beyond_16_bit_counts(fused):
+    """a CIGAR of more than 65 535 operations and a match of more than 65 535 bases (contig.c:247-331 walks any record): the
+    descriptor sequence hands the batch to the staged one"""
+    from fuzzgen import long_record_case
+    contigs, reads = long_record_case(3)
+    st = nat.Stream.from_reads(contigs, reads)
+    assert int(st.n_cigar.max()) > 65535 and int(st.l_qseq.max()) > 65535
+    got, stats = mb.score_chain(st, fused=fused, want_stats=True)
+    assert stats["restarts"] == (1 if fused else 0)
+    assert got[0] == ob.score_chain(st, 0)
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_model_more_than_160_contexts_in_a_slot(fused):
+    """base.c:60-71 grows a slot's context list without bound; here the fourth level keeps one entry per possible context"""
+    from fuzzgen import crowded_context_case
+    contigs, reads = crowded_context_case(11)
+    st = nat.Stream.from_reads(contigs, reads)
+    got, stats = mb.score_chain(st, fused=fused, want_stats=True)
+    assert stats["deep_chunks"] > 0 and stats["restarts"] == (1 if fused else 0)
+    assert got[0] == ob.score_chain(st, 0)
+
+
 # ---- kmer_count bodies (np1_kmer.h) against the oracle ----------------------------------------------------------
 def _lowercase_some(contigs, seed):
     import random

@@ -253,3 +253,29 @@ def test_oracle_kmer_count_equals_reference_library_for_general_indel_balance_fa
                 for i, n in enumerate(st.names):
                     r = L.kmer_count(n.encode(), cfg)
                     assert C.string_at(r.contents.contig).decode() == ob.kmer_count(st, i, ocfg), "rate %r contig %s seed %d" % (rate, n, seed)
+
+
+def test_cigar_in_a_cg_tag_reference_binary_agrees(tmp_path):
+    """a record of more than 65 535 CIGAR operations travels as the placeholder '<l_qseq>S<rlen>N' + tag CG:B:I (SAMv1 4.2.2); htslib
+    swaps the real CIGAR in while reading, so the reference votes with it -- pinned here on the reference binary itself: writer
+    (CG out), loader (CG in), oracle on the loaded stream == reference on the file, for score_chain and kmer_count"""
+    import numpy as np
+    import struct, gzip
+    from fuzzgen import long_record_case
+    contigs, reads = long_record_case(7, n_ops=66000, plain_bases=66000)
+    st = nat.Stream.from_reads(contigs, reads)
+    assert int(st.n_cigar.max()) > 65535
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "g.bam")
+    st.write_files(fa, bam)
+    raw = gzip.open(bam, "rb").read()
+    assert b"CGBI" + struct.pack("<I", int(st.n_cigar.max())) in raw        # the tag is really in the file
+    st2 = nat.Stream.load(fa, bam, with_qual=True)
+    for f in ["pos", "flag", "n_cigar", "l_qseq", "cigar", "seq"]:
+        assert np.array_equal(getattr(st, f), getattr(st2, f)), f
+    if ref_binary() is None:
+        pytest.skip("reference binary not built")
+    assert run_ref("scorechain", fa, bam)["long"] == ob.score_chain(st2, 0)
+    cfgp = nat.lib().config_init(fa.encode(), bam.encode(), None)
+    cfg = ob.default_config(read_tlen=cfgp.contents.read_tlen, read_len=cfgp.contents.read_len)
+    nat.lib().config_destory(cfgp)
+    assert run_ref("kmercount", fa, bam)["long"] == ob.from_files("kmer_count", fa, bam, cfg)["long"]

@@ -371,6 +371,48 @@ def test_gpu_matches_oracle_on_fuzzed_diploids(ctx):
     assert n > 20
 
 
+def ultra_long(seed=5):
+    """a 120 kb diploid contig whose few long reads each carry more than 65 535 CIGAR operations (what travels in a CG tag)"""
+    ctgs, srs, lrs = snpphase_gen.make_case(seed, lens=(120000,), sr_depth=12, lr_depth=5, lr_len=115000, lr_err=0.6, het=0.002)
+    s, l = nat.Stream.from_reads(ctgs, srs), nat.Stream.from_reads(ctgs, lrs)
+    assert int(l.n_cigar.max()) > 65535
+    return s, l
+
+
+@needs_ref
+def test_ultra_long_reads_with_cg_tag_cigars_vs_reference(tmp_path):
+    """snpphase.c reads the long-read BAM through htslib, which swaps a CG-tag CIGAR in (bam_tag2cigar): reference on the files ==
+    oracle == host model on the streams loaded back from them"""
+    fa, sr, lr = str(tmp_path / "s.fa"), str(tmp_path / "sr.bam"), str(tmp_path / "lr.bam")
+    s, l = ultra_long()
+    s.write_files(fa, sr)
+    l.write_files(str(tmp_path / "l.fa"), lr)
+    ref = run_ref3(fa, sr, lr)
+    cfgp = nat.lib().config_init(fa.encode(), sr.encode(), lr.encode())
+    tlen, rlen = cfgp.contents.read_tlen, cfgp.contents.read_len
+    nat.lib().config_destory(cfgp)
+    s2, l2 = nat.Stream.load(fa, sr, with_qual=True), nat.Stream.load(fa, lr, with_qual=True)
+    assert int(l2.n_cigar.max()) == int(l.n_cigar.max())
+    assert ob.snp_phase(s2, l2, 0, ob.default_config(read_tlen=tlen, read_len=rlen)) == ref["tig0"]
+    assert _model_case(s2, l2, tlen, rlen)
+
+
+@pytest.mark.gpu
+def test_gpu_ultra_long_reads_with_cg_tag_cigars(ctx, tmp_path):
+    """the same through the device, in memory and from the files (CLI: the long-read BAM goes through the host loader)"""
+    s, l = ultra_long()
+    assert _check(ctx, s, l)
+    fa, sr, lr = str(tmp_path / "s.fa"), str(tmp_path / "sr.bam"), str(tmp_path / "lr.bam")
+    s.write_files(fa, sr)
+    l.write_files(str(tmp_path / "l.fa"), lr)
+    cfgp = nat.lib().config_init(fa.encode(), sr.encode(), lr.encode())
+    ocfg = ob.default_config(read_tlen=cfgp.contents.read_tlen, read_len=cfgp.contents.read_len)
+    nat.lib().config_destory(cfgp)
+    s2, l2 = nat.Stream.load(fa, sr, with_qual=True), nat.Stream.load(fa, lr, with_qual=True)
+    out = subprocess.run([os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1"), "snpphase", fa, sr, lr], stdout=subprocess.PIPE, timeout=600, check=True).stdout.decode()
+    assert parse_cli_fasta(out)["tig0"] == ob.snp_phase(s2, l2, 0, ocfg)
+
+
 @pytest.mark.gpu
 def test_gpu_low_depth_regions_that_touch(ctx):
     for seed in range(12):
