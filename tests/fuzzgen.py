@@ -3,7 +3,9 @@
 import random
 
 
-def random_case(seed, n_contigs=2, max_len=160, max_reads=40, letters="ACGT", odd_letters=True, odd_cigars=True):
+def random_case(seed, n_contigs=2, max_len=160, max_reads=40, letters="ACGT", odd_letters=True, odd_cigars=True, double_ins=False):
+    """double_ins: insertion operations that meet at one reference position (I P I, I N I: the walk ignores P and N), which no aligner
+    writes but contig.c:299-320 votes on twice"""
     rng = random.Random(seed)
     contigs, reads = [], []
     for c in range(n_contigs):
@@ -63,7 +65,9 @@ def random_case(seed, n_contigs=2, max_len=160, max_reads=40, letters="ACGT", od
                     add("D", n); p += n; last_was_ins = False
                 elif x < 0.88:
                     if last_was_ins:
-                        continue
+                        if not double_ins or rng.random() < 0.3:
+                            continue
+                        add(rng.choice("PN"), 1)
                     n = rng.randint(1, 4)
                     add("I", n); seq += [rng.choice("ACGT") for _ in range(n)]; last_was_ins = True
                 elif odd_cigars and x < 0.92:

@@ -404,3 +404,14 @@ def test_kmer_count_with_records_beyond_16_bit_counts(ctx, tmp_path):
     out = subprocess.run([exe, "scorechain", fa, bam], stdout=subprocess.PIPE, timeout=600, check=True).stdout.decode()
     st2 = nat.Stream.load(fa, bam)
     assert parse_cli_fasta(out)["long"] == ob.score_chain(st2, 0)
+
+
+def test_two_insertions_at_one_position_are_refused_by_name(ctx):
+    """the reference dies on these (tests/test_oracle.py::test_reference_has_no_result_for_two_insertions_at_one_position): no result to match"""
+    contigs = [("t", "ACGTTGCAAGGCTTAACCGGTTACGATCGATTGCA" * 3)]
+    d = contigs[0][1]
+    reads = [dict(ctg=0, pos=5, cigar=[("M", 20), ("I", 2), ("P", 1), ("I", 1), ("M", 30)], seq=d[5:25] + "GG" + "T" + d[25:55])]
+    reads += [dict(ctg=0, pos=p, cigar=[("M", 60)], seq=d[p:p + 60]) for p in (0, 3, 8, 20)]
+    reads.sort(key=lambda r: r["pos"])
+    with pytest.raises(RuntimeError, match="two insertion"):
+        ctx.score_chain(nat.Stream.from_reads(contigs, reads))

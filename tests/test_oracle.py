@@ -4,6 +4,7 @@ the reference binary itself on fresh fuzzed inputs.  This is what pins the oracl
 import hashlib
 import json
 import os
+import subprocess
 
 import pytest
 
@@ -279,3 +280,38 @@ def test_cigar_in_a_cg_tag_reference_binary_agrees(tmp_path):
     cfg = ob.default_config(read_tlen=cfgp.contents.read_tlen, read_len=cfgp.contents.read_len)
     nat.lib().config_destory(cfgp)
     assert run_ref("kmercount", fa, bam)["long"] == ob.from_files("kmer_count", fa, bam, cfg)["long"]
+
+
+def _meets_twice(reads):
+    """does a record hold two insertion operations at one reference position (only M and D advance it: contig.c:262-326)?"""
+    for r in reads:
+        last = False
+        for o, _ in r["cigar"]:
+            if o == "I":
+                if last:
+                    return True
+                last = True
+            elif o in "MD":
+                last = False
+    return False
+
+
+@needs_ref
+def test_reference_has_no_result_for_two_insertions_at_one_position(tmp_path):
+    """'I P I' / 'I N I' (no aligner writes them; SAM allows them).  contig.c:299-320 votes on the insertion columns a second time with a
+    context whose predecessor is an insertion column, not the base before them; the chain (contig.c:424-496) then looks that predecessor
+    state up in the previous slot, finds none and dereferences NULL.  Pinned on the compiled reference: scorechain dies with SIGSEGV on
+    most such inputs -- there is no result to be identical to, which is why the product refuses these records by name (np1_core.h
+    ERR_DOUBLE_INS) instead of inventing one.  (kmercount only chains inside its flagged regions and mostly survives; the product's
+    region walk reports the same records as an inconsistent pileup.)"""
+    fa, bam = str(tmp_path / "d.fa"), str(tmp_path / "d.bam")
+    died = n = 0
+    for seed in range(60):
+        contigs, reads = random_case(seed, double_ins=True)
+        if not _meets_twice(reads):
+            continue
+        nat.Stream.from_reads(contigs, reads).write_files(fa, bam)
+        p = subprocess.run([ref_binary(), "scorechain", fa, bam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        n += 1
+        died += p.returncode == -11
+    assert n > 40 and died > n // 2, (died, n)
