@@ -10,6 +10,7 @@
 #include <cstring>
 #include <algorithm>
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #include "../../include/nextpolish1.h"
@@ -327,6 +328,9 @@ int np1m_fused = 0;   // 0: staged sequence (rows in memory), 1: descriptors (k_
 // Returns 0 on success; *out is malloc'd concatenation of the polished contigs, bounds[n_contigs+1].
 // stats (optional, 4 words): slots, dp heads, pool words, max context list length escalations
 static int score_chain_once(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds, uint64_t* stats);
+static bool g_keep_map = false;                       // score_chain_once leaves its slot geometry behind (tiling model below)
+static std::vector<uint32_t> g_soff, g_opos;          // slot of every draft base; output offset of every slot
+static std::vector<uint8_t> g_single;                 // slot had one state after the vote
 int np1m_restarts = 0, np1m_deep_chunks = 0;   // what the last call needed: staged restarts, chunks voted with HBM-sized context lists
 int np1m_score_chain(const np1_stream_view* v, const Configure* cfg, char** out, uint32_t* bounds, uint64_t* stats) {
     np1m_restarts = 0;
@@ -460,6 +464,10 @@ static int score_chain_once(const np1_stream_view* v, const Configure* cfg, char
         }
 
     }
+    if (g_keep_map) {   // tiling model: which slots came out of the vote with a single state (the chain restarts behind each of them)
+        g_single.assign(S + 1, 0);
+        for (uint32_t s = 0; s < S; ++s) g_single[s] = (slot_res[s] & 0xff) != 0xff;
+    }
     HostState st;
     for (uint32_t h : heads)
         if (!dp_run<false>(h, pool.data(), slot_rec.data(), slot_res.data(), K, Rfix, 0.0, cfg->min_count_ratio_skip, st)) return -4;
@@ -468,6 +476,7 @@ static int score_chain_once(const np1_stream_view* v, const Configure* cfg, char
     uint32_t o = 0;
     for (uint32_t s = 0; s < S; ++s) { opos[s] = o; o += (slot_res[s] & 0xff) != 3; }
     opos[S] = o;
+    if (g_keep_map) { g_soff.assign(soff.begin(), soff.begin() + G + 1); g_opos = opos; }
     char* buf = (char*)calloc(1, (size_t)o + 1);
     for (uint32_t s = 0; s < S; ++s) emit_slot(s, slot_res.data(), slot_info.data(), opos.data(), 3u, (uint8_t*)buf);
     for (uint32_t c = 0; c <= nc; ++c) bounds[c] = opos[soff[v->ctg_off[c]]];
@@ -755,6 +764,119 @@ int np1m_snp_valid_replay(const np1_stream_view* v, const Configure* cfg, const 
 }
 unsigned long long np1m_replay_revote_count() { return np1m_replay_revotes; }
 unsigned long long np1m_replay_break_count() { return np1m_replay_breaks; }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Intra-contig tiling: one contig cut into tiles of tile_bp draft bases that are polished independently
+// (one tile per GPU when a single contig is all there is) and joined.  What makes this exact without any exchange between tiles:
+//  * votes are local: what a slot receives depends on the records covering it, nothing else (contig.c:247-331);
+//  * the chain restarts behind every slot that came out of the vote with one state -- scores are exact integers and a single
+//    state is every path's predecessor at the same score (np1_core.h dp_run) -- so a tile needs no carried state, only to start
+//    and end its own computation at such slots.
+// A tile therefore computes [a - halo, b + halo) with every record that overlaps that stretch (the draft hull of those records, so
+// that none sticks out), checks that a single-state slot lies inside each halo among the slots whose votes are complete, and
+// contributes the output of its own bases [a, b) (with the insertion columns behind each).  No slot of that kind in a halo (a
+// multi-state run as long as the halo): the tile is recomputed with the halo doubled.  tstats: [0] tiles, [1] recomputations,
+// [2] records processed over all tiles.
+int np1m_score_chain_tiled(const np1_stream_view* v, const Configure* cfg, uint32_t tile_bp, uint32_t halo_bp, char** out, uint32_t* bounds, uint64_t* tstats) {
+    const uint32_t nc = (uint32_t)v->n_contigs;
+    std::string joined;
+    uint64_t n_tiles = 0, n_redo = 0, n_rec = 0;
+    std::vector<int32_t> endp((size_t)(v->n_reads ? v->n_reads : 1));
+    for (int64_t r = 0; r < v->n_reads; ++r) {      // reference end: only M and D advance the walk (contig.c:262-326)
+        int32_t e = v->pos[r];
+        const uint32_t* cg = v->cigar + v->cigar_off[r];
+        for (uint32_t i = 0; i < v->n_cigar[r]; ++i)
+            if ((cg[i] & 15u) == 0 || (cg[i] & 15u) == 2) e += (int32_t)(cg[i] >> 4);
+        endp[(size_t)r] = e;
+    }
+    g_keep_map = true;
+    int rc = 0;
+    for (uint32_t c = 0; c < nc && rc == 0; ++c) {
+        bounds[c] = (uint32_t)joined.size();
+        const int32_t L = (int32_t)(v->ctg_off[c + 1] - v->ctg_off[c]);
+        const int64_t r0 = (int64_t)v->read_begin[c], r1 = (int64_t)v->read_begin[c + 1];
+        for (int32_t a = 0; a < L && rc == 0; a += (int32_t)tile_bp) {
+            const int32_t b = std::min<int64_t>(L, (int64_t)a + tile_bp);
+            ++n_tiles;
+            for (uint32_t halo = halo_bp;; halo *= 2) {
+                const int32_t e_lo = std::max<int64_t>(0, (int64_t)a - halo), e_hi = std::min<int64_t>(L, (int64_t)b + halo);
+                std::vector<int64_t> pick;
+                int32_t lo = e_lo, hi = e_hi;
+                for (int64_t r = r0; r < r1; ++r) {
+                    const int32_t p = v->pos[r], e = endp[(size_t)r];
+                    // (<= / >=: a record that starts at e_hi with an insertion votes on the columns behind base e_hi - 1)
+                    if (p <= e_hi && e >= e_lo) {
+                        pick.push_back(r);
+                        lo = std::min(lo, std::max(p, 0));
+                        hi = std::max(hi, std::min(e, L));
+                    }
+                }
+                // one more base on each side: position 0 and the last base of a contig are special to the walk (an insertion before
+                // the first base shifts the query window instead of voting, contig.c:315-319; none is taken behind the last base),
+                // and no record of the tile may meet an artificial one
+                lo = std::max(0, lo - 1);
+                hi = std::min(L, hi + 1);
+                const size_t m = pick.size();
+                std::vector<int32_t> pos(m + 1), lq(m + 1), isz(m + 1);
+                std::vector<uint32_t> ctg(m + 1, 0), ncg(m + 1);
+                std::vector<uint16_t> flag(m + 1);
+                std::vector<uint64_t> coff(m + 1), soffv(m + 1), qoff(m + 1);
+                std::vector<uint8_t> mapq(m + 1);
+                for (size_t k = 0; k < m; ++k) {
+                    const int64_t r = pick[k];
+                    pos[k] = v->pos[r] - lo; lq[k] = v->l_qseq[r]; ncg[k] = v->n_cigar[r]; flag[k] = v->flag[r];
+                    coff[k] = v->cigar_off[r]; soffv[k] = v->seq_off[r];
+                    if (v->mapq) mapq[k] = v->mapq[r];
+                    if (v->isize) isz[k] = v->isize[r];
+                    if (v->qual_off) qoff[k] = v->qual_off[r];
+                }
+                np1_stream_view sub = *v;
+                const int32_t sub_len = hi - lo;
+                const uint32_t sub_off[2] = {0u, (uint32_t)sub_len};
+                const uint64_t sub_rb[2] = {0ull, (uint64_t)m};
+                sub.n_contigs = 1; sub.n_reads = (int64_t)m; sub.ctg_len = &sub_len; sub.ctg_off = sub_off; sub.read_begin = sub_rb;
+                sub.draft = v->draft + v->ctg_off[c] + lo; sub.draft_len = sub_len;
+                sub.pos = pos.data(); sub.ctg = ctg.data(); sub.flag = flag.data(); sub.n_cigar = ncg.data(); sub.l_qseq = lq.data();
+                sub.cigar_off = coff.data(); sub.seq_off = soffv.data(); sub.mapq = mapq.data(); sub.isize = isz.data(); sub.qual_off = qoff.data();
+                char* part = nullptr;
+                uint32_t pb[2] = {0, 0};
+                n_rec += m;
+                rc = np1m_score_chain(&sub, cfg, &part, pb, nullptr);
+                if (rc != 0) break;
+                // a single-state slot inside each halo, among the slots whose votes are complete (e_lo .. e_hi), clear of the two
+                // slots behind an artificial start whose draft context is cut short (contig.c:373-383)
+                bool left_ok = a == 0, right_ok = b == L;
+                if (!left_ok) {
+                    const uint32_t s_from = g_soff[(size_t)(e_lo - lo)] + (e_lo > 0 ? 2u : 0u), s_to = g_soff[(size_t)(a - lo)];
+                    for (uint32_t sl = s_from; sl < s_to && !left_ok; ++sl) left_ok = g_single[sl] != 0;
+                    if (e_lo == 0) left_ok = true;      // the halo reaches the real start of the contig
+                }
+                if (!right_ok) {
+                    const uint32_t s_from = g_soff[(size_t)(b - lo)], s_to = g_soff[(size_t)(e_hi - lo)];
+                    for (uint32_t sl = s_from; sl < s_to && !right_ok; ++sl) right_ok = g_single[sl] != 0;
+                    if (e_hi == L) right_ok = true;
+                }
+                if (left_ok && right_ok) {
+                    const uint32_t o0 = g_opos[g_soff[(size_t)(a - lo)]], o1 = b == L ? pb[1] : g_opos[g_soff[(size_t)(b - lo)]];
+                    joined.append(part + o0, part + o1);
+                    free(part);
+                    break;
+                }
+                free(part);
+                ++n_redo;
+                if (halo > (1u << 28)) { rc = -20; break; }
+            }
+        }
+    }
+    g_keep_map = false;
+    if (rc != 0) return rc;
+    bounds[nc] = (uint32_t)joined.size();
+    char* buf = (char*)calloc(1, joined.size() + 1);
+    memcpy(buf, joined.data(), joined.size());
+    *out = buf;
+    if (tstats) { tstats[0] = n_tiles; tstats[1] = n_redo; tstats[2] = n_rec; }
+    return 0;
+}
 
 void np1m_free(void* p) { free(p); }
 

@@ -54,6 +54,22 @@ def score_chain(stream, cfg=None, want_stats=False, fused=False):
     return res
 
 
+def score_chain_tiled(stream, tile_bp, halo_bp, cfg=None, fused=False):
+    """every contig cut into tiles of tile_bp bases, polished independently with a halo and joined (np1_model.cpp: the intra-contig
+    tiling of DESIGN.md 8); returns (contigs, dict(tiles, recomputed, records))"""
+    cfg = cfg or nat.default_config()
+    C.c_int.in_dll(lib(), "np1m_fused").value = int(fused)
+    out = C.c_void_p()
+    bounds = (C.c_uint32 * (stream.n_contigs + 1))()
+    ts = (C.c_uint64 * 3)()
+    rc = lib().np1m_score_chain_tiled(C.byref(stream.view), C.byref(cfg), C.c_uint32(tile_bp), C.c_uint32(halo_bp), C.byref(out), bounds, ts)
+    if rc != 0:
+        raise RuntimeError("tiled model failed rc=%d" % rc)
+    blob = C.string_at(out, bounds[stream.n_contigs])
+    lib().np1m_free(out)
+    return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)], dict(tiles=ts[0], recomputed=ts[1], records=ts[2])
+
+
 def kmer_count(stream, cfg):
     """kmer_count through the per-region bodies of np1_kmer.h (stream must carry qualities; cfg.read_tlen set)."""
     out = C.c_void_p()

@@ -75,6 +75,37 @@ def test_model_more_than_160_contexts_in_a_slot(fused):
     assert got[0] == ob.score_chain(st, 0)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_model_intra_contig_tiling_joins_to_the_untiled_result(seed):
+    """DESIGN.md 8 / SURVEY.md 8e: one contig polished as independent tiles (one per GPU when a single contig is all there is) ==
+    the untiled oracle.  No state travels between tiles: a tile computes its stretch plus a halo from the records overlapping it and
+    the chain restarts behind any single-state slot, which every halo must hold (else the tile is recomputed with a wider halo --
+    the tiny halos here force that)."""
+    st = nat.Stream.synth([6000 + 700 * seed, 1500], depth=[8, 30, 90][seed % 3], seed=300 + seed, weird_rate=0.02 if seed % 2 else 0.0,
+                          read_indel=0.004, read_sub=0.02 if seed % 4 == 0 else 0.004, softclip_rate=0.05, draft_lower=0.01)
+    want = [ob.score_chain(st, i) for i in range(st.n_contigs)]
+    redo = 0
+    for tile, halo in [(997, 64), (300, 8), (2048, 200), (150, 1), (5000, 150)]:
+        got, ts = mb.score_chain_tiled(st, tile, halo, fused=seed % 2)
+        assert got == want, (tile, halo)
+        assert ts["tiles"] >= sum((int(n) + tile - 1) // tile for n in st.ctg_len)
+        redo += ts["recomputed"]
+    assert redo > 0
+
+
+def test_model_intra_contig_tiling_micro_cases_and_crowded_runs():
+    """odd CIGAR shapes at tile edges (tiles of a few bases), and a pileup noisy enough for multi-state runs longer than a read"""
+    for seed in range(120):
+        contigs, reads = random_case(seed)
+        st = nat.Stream.from_reads(contigs, reads)
+        want = [ob.score_chain(st, i) for i in range(st.n_contigs)]
+        for tile, halo in [(7, 1), (23, 5), (64, 40)]:
+            assert mb.score_chain_tiled(st, tile, halo)[0] == want, (seed, tile, halo)
+    st = nat.Stream.synth([3000], depth=250, seed=5, read_sub=0.08, read_indel=0.01)
+    got, ts = mb.score_chain_tiled(st, 500, 150)
+    assert got[0] == ob.score_chain(st, 0)
+
+
 # ---- kmer_count bodies (np1_kmer.h) against the oracle ----------------------------------------------------------
 def _lowercase_some(contigs, seed):
     import random
