@@ -380,20 +380,47 @@ def phase_leg(device_index, mb, passes, procs, with_ref):
         b.close()
     finally:
         ctx.close()
-    # the same draft from files: FASTA + two sorted BAM files in the page cache -> polished FASTA, cold process of the CLI
+    # the same draft from files: FASTA + two sorted BAM files in the page cache -> polished contigs; both files go through the
+    # device-side ingest, contigs in batches of 4 Mb on two to four lanes (qualities as the generator made them, not binned: the
+    # resident measurement above and this one polish the same records)
     td = tempfile.mkdtemp(prefix="np1phase_e2e_")
     try:
         fa, s_bam, l_bam = os.path.join(td, "g.fa"), os.path.join(td, "sr.bam"), os.path.join(td, "lr.bam")
         sr.write_files(fa, s_bam, 1)
         lr.write_files(os.path.join(td, "l.fa"), l_bam, 1)
         exe = os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1")
-        env = dict(os.environ, NP1_DEVICE=str(device_index), NP_IO_THREADS=str(procs), NP1_BATCH_BP=str(int(mb * 1e6) + 1000000))
+        batch_bp = 4000000 + 1000
+        env = dict(os.environ, NP1_DEVICE=str(device_index), NP_IO_THREADS=str(procs), NP1_BATCH_BP=str(batch_bp))
         t0 = time.time()
         q = subprocess.run([exe, "snpphase", fa, s_bam, l_bam], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
         dt = time.time() - t0
-        out["e2e_from_files"] = ({"mbp_s": round(bp / 1e6 / dt, 2), "seconds": round(dt, 2), "bam_mb": round((os.path.getsize(s_bam) + os.path.getsize(l_bam)) / 1e6, 1),
-                                  "what": "nextpolish1 snpphase, cold process: short-read BAM through the device-side ingest, long-read BAM through the host loader (%d threads), one batch pair, FASTA out" % procs}
-                                 if q.returncode == 0 else {"error": q.stderr.decode()[-300:]})
+        if q.returncode != 0:
+            out["e2e_from_files"] = {"error": q.stderr.decode()[-300:]}
+        else:
+            e2e = {"mbp_s": None, "cold_process_mbp_s": round(bp / 1e6 / dt, 2), "cold_process_seconds": round(dt, 2),
+                   "bam_mb": round((os.path.getsize(s_bam) + os.path.getsize(l_bam)) / 1e6, 1)}
+            by_lanes = {}
+            n_out = [0]
+            for lanes in (2, 3, 4):
+                pipe = device.Pipe(device_index, lanes=lanes)
+                try:
+                    warm = []
+                    for _ in range(3):
+                        n_out[0] = 0
+                        t0 = time.perf_counter()
+                        pipe.run_phase_files(fa, s_bam, l_bam, batch_bp=batch_bp, cfg=cfg, sink=lambda name, seq: n_out.__setitem__(0, n_out[0] + len(seq)))
+                        warm.append(time.perf_counter() - t0)
+                    by_lanes[lanes] = min(warm)
+                finally:
+                    pipe.close()
+            best = min(by_lanes, key=by_lanes.get)
+            e2e.update({"mbp_s": round(bp / 1e6 / by_lanes[best], 2), "seconds": round(by_lanes[best], 3), "lanes": best,
+                        "mbp_s_by_lanes": {str(k): round(bp / 1e6 / v, 2) for k, v in by_lanes.items()}, "polished_bases_out": n_out[0],
+                        "what": "FASTA + short-read BAM + long-read BAM in the page cache (qualities as generated: uniformly random per base, the least compressible case) -> "
+                                "polished contigs at a sink: np1_pipe_run_phase_files in a warm process (best of 3 per lane count), both files through the device-side "
+                                "ingest, 4 Mb batches; cold_process = the `nextpolish1 snpphase` CLI started from nothing on the same files (HIP start-up and the "
+                                "first allocations included, FASTA written, 3 lanes)"})
+            out["e2e_from_files"] = e2e
     finally:
         shutil.rmtree(td, ignore_errors=True)
     sr.close()

@@ -72,11 +72,13 @@ int main(int argc, char* argv[]) {
         // records become two resident batches and one np1_batch_snp_phase pass (np1_phase_device.hip)
         if (!cfg->bamfn) { fprintf(stderr, "cannot access BAM %s\n", argv[3]); return 1; }
         if (!cfg->thirdbamfn) { fprintf(stderr, "cannot access BAM %s\n", argv[4]); return 1; }
-        int dev = 0;
-        long long batch_bp = 16000000;
+        int dev = 0, lanes = 3;
+        long long batch_bp = 4000000;     // small batches, several lanes: the blocks of one batch are copied and inflated under the kernels of the others
         if (const char* e = getenv("NP1_DEVICE")) dev = atoi(e);
         if (const char* e = getenv("NP1_BATCH_BP")) batch_bp = atoll(e);
-        np1_pipe* pipe = np1_pipe_open(dev, 1);
+        if (const char* e = getenv("NP1_LANES")) lanes = atoi(e);
+        if (lanes < 1) lanes = 1;
+        np1_pipe* pipe = np1_pipe_open(dev, lanes);
         if (!pipe) { fprintf(stderr, "%s\n", np1_last_error()); return 1; }
         struct Out { int step; } out{step};
         auto sink = [](void* user, const char* name, const char* seq, int64_t len) {

@@ -36,8 +36,9 @@ struct np1_pipe {
     uint64_t host_inflated_blocks = 0;             // last np1_pipe_run_files: BGZF blocks the device decoder handed back to the host
     // from-files mode: pinned staging buffers and per-lane HBM scratch live as long as the pipe (allocated on first use)
     std::vector<np1ingest::Staging*> staging;
+    std::vector<np1ingest::Staging*> staging_lr;   // np1_pipe_run_phase_files: the long-read file's compressed blocks
     std::vector<np1ingest::Scratch*> scratch;
-    np1_batch* phase_lr = nullptr;                 // np1_pipe_run_phase_files: the long-read batch, on lane 0's context
+    std::vector<np1_batch*> phase_lr;              // np1_pipe_run_phase_files: the long-read batch of every lane
 };
 
 namespace {
@@ -158,11 +159,12 @@ int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passe
 
 void np1_pipe_close(np1_pipe* p) {
     if (!p) return;
-    if (p->phase_lr) np1_batch_free(p->phase_lr);
+    for (np1_batch* b : p->phase_lr) if (b) np1_batch_free(b);
     for (np1_pipe::Blob& o : p->out) np1_host_free_pinned(o.p);
     drop_resident(p);
     for (np1ingest::Scratch* s : p->scratch) np1ingest::scratch_destroy(s);
     for (np1ingest::Staging* s : p->staging) delete s;
+    for (np1ingest::Staging* s : p->staging_lr) delete s;
     for (np1_pipe::Lane& ln : p->lanes) {
         if (ln.batch) np1_batch_free(ln.batch);
         if (ln.ctx) np1_ctx_destroy(ln.ctx);
@@ -401,9 +403,10 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
 
 // Task 3 from files (reference: one snp_phase(tigname, cfg) call per contig and worker, nextpolish1.py:95-96,181-189): contigs in
 // batches of batch_bp draft bases; per batch the short-read records come in as compressed BGZF blocks and are inflated and split
-// on the device (np1_ingest.hip; host loader where the index or the records do not allow it), the long-read records -- a few
-// per cent of the bytes -- are decoded by the host loader, both land in two batches of lane 0 and one np1_batch_snp_phase pass
-// runs over them.  A loader thread stages batch k + 1 while the device works on batch k.
+// on the device (np1_ingest.hip; host loader where the index or the records do not allow it), and so do the long-read records
+// (the host loader spent most of a batch's wall time on them: decode, then page-locking the decoded arrays; NP1_INGEST_LR=host
+// keeps it); both land in two batches of lane 0 and one np1_batch_snp_phase pass runs over them.  A loader thread stages batch
+// k + 1 while the device works on batch k.
 int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr, const char* bam_lr, const char* const* names, int n_names, int64_t batch_bp,
                              const Configure* cfg, np1_sink_fn sink, void* user) {
     if (!p || !fasta || !bam_sr || !bam_lr || !cfg) { np1_set_error("np1_pipe_run_phase_files: null argument"); return -1; }
@@ -411,6 +414,11 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
     {
         std::string e;
         if (!src.open(fasta, bam_sr, &e)) { np1_set_error(e); return -1; }
+    }
+    np1ingest::BamSource src_lr;
+    {
+        std::string e;
+        if (!src_lr.open(fasta, bam_lr, &e)) { np1_set_error(e); return -1; }
     }
     const np::Fai& fai = src.fai;
     std::vector<std::string> want;
@@ -430,12 +438,20 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
     const bool all_in_one = n == 1 && !(names && n_names > 0);   // every contig: sequential passes over the files, no index seeks
     const char* ing = getenv("NP1_INGEST");
     const bool device_ingest = src.have_bai && !(ing && strcmp(ing, "host") == 0);
-    np1_pipe::Lane& ln = p->lanes[0];
-    if (!p->phase_lr) p->phase_lr = np1_batch_create(ln.ctx);
-    if (!p->phase_lr) return -1;
-    while (device_ingest && p->staging.size() < 2) p->staging.push_back(new np1ingest::Staging());
+    const char* ing_lr = getenv("NP1_INGEST_LR");
+    const bool device_ingest_lr = src_lr.have_bai && !(ing && strcmp(ing, "host") == 0) && !(ing_lr && strcmp(ing_lr, "host") == 0);
+    // lanes: batch k runs on lane k % L (own stream, own pair of batch objects, own staging buffers and scratch) -- the staging of one
+    // batch and the copies of its blocks overlap the kernels of the other lane's batch; results leave in batch order
+    const size_t L = std::min<size_t>(std::max<size_t>(1, p->lanes.size()), 4);
+    p->phase_lr.resize(p->lanes.size(), nullptr);
+    for (size_t li = 0; li < L; ++li) {
+        if (!p->phase_lr[li]) p->phase_lr[li] = np1_batch_create(p->lanes[li].ctx);
+        if (!p->phase_lr[li]) return -1;
+    }
+    while (device_ingest && p->staging.size() < L) p->staging.push_back(new np1ingest::Staging());
+    while (device_ingest_lr && p->staging_lr.size() < L) p->staging_lr.push_back(new np1ingest::Staging());
     p->scratch.resize(p->lanes.size(), nullptr);
-    struct Item { np1ingest::Staging* staging = nullptr; np1_stream* sr = nullptr; np1_stream* lr = nullptr; std::string err; };
+    struct Item { np1ingest::Staging* staging = nullptr; np1ingest::Staging* staging_lr = nullptr; np1_stream* sr = nullptr; np1_stream* lr = nullptr; std::string err; };
     auto load_host = [&](int k, const char* bam) -> np1_stream* {
         std::vector<const char*> nm;
         for (const std::string& s : plan[(size_t)k]) nm.push_back(s.c_str());
@@ -447,9 +463,19 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
         Item it;
         const double t0 = now_ms();
         std::string lr_err;                // the long-read thread's own error string (merged after the join)
-        std::thread lr_thread([&] { it.lr = load_host(k, bam_lr); if (!it.lr) lr_err = np1_last_error(); });
+        std::thread lr_thread([&] {
+            if (device_ingest_lr) {
+                np1ingest::Staging* sg = p->staging_lr[(size_t)k % L];
+                std::string e;
+                const int rc = np1ingest::prepare(src_lr, plan[(size_t)k], sg, &e);
+                if (rc < 0) { lr_err = e; return; }
+                if (rc == 0) { it.staging_lr = sg; return; }
+            }
+            it.lr = load_host(k, bam_lr);
+            if (!it.lr) lr_err = np1_last_error();
+        });
         if (device_ingest) {
-            np1ingest::Staging* sg = p->staging[(size_t)k % 2];
+            np1ingest::Staging* sg = p->staging[(size_t)k % L];
             std::string e;
             const int rc = np1ingest::prepare(src, plan[(size_t)k], sg, &e);
             if (rc < 0) it.err = e;
@@ -461,48 +487,75 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
         }
         lr_thread.join();
         if (it.err.empty()) it.err = lr_err;
-        if (timing_on()) fprintf(stderr, "[np1 phase] batch %d staged on the host in %.1f ms (short reads: %s)\n", k, now_ms() - t0, it.staging ? "compressed blocks" : "host loader");
+        if (timing_on())
+            fprintf(stderr, "[np1 phase] batch %d staged on the host in %.1f ms (short reads: %s, long reads: %s)\n", k, now_ms() - t0, it.staging ? "compressed blocks" : "host loader",
+                    it.staging_lr ? "compressed blocks" : "host loader");
         return it;
     };
     auto drop = [](Item& it) { if (it.sr) np1_stream_free(it.sr); if (it.lr) np1_stream_free(it.lr); it.sr = it.lr = nullptr; };
-    Item cur = n > 0 ? stage(0) : Item();
-    int rc = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int next_emit = 0, rc_all = 0;
     std::string err;
-    for (int k = 0; k < n && rc == 0; ++k) {
-        Item next;
-        std::thread pre;
-        if (k + 1 < n) pre = std::thread([&, k] { next = stage(k + 1); });
-        std::vector<std::string> nm = plan[(size_t)k];
-        const double t0 = now_ms();
-        if (!cur.err.empty()) { err = cur.err; rc = -1; }
-        if (rc == 0 && cur.staging) {
-            if (!p->scratch[0]) p->scratch[0] = np1ingest::scratch_create();
-            rc = np1ingest::ingest(ln.batch, cur.staging, true, p->scratch[0]);
-            if (rc == 1) {   // records the device path does not take: the host loader decodes this batch
-                cur.sr = load_host(k, bam_sr);
-                rc = cur.sr ? 0 : -1;
-            } else if (rc == 0) {
-                nm = cur.staging->names();
+    auto lane_work = [&](size_t li) {
+        np1_pipe::Lane& ln = p->lanes[li];
+        np1_batch* lrb = p->phase_lr[li];
+        for (int k = (int)li; k < n; k += (int)L) {
+            { std::lock_guard<std::mutex> g(mu); if (rc_all != 0) return; }
+            Item cur = stage(k);
+            int rc = 0;
+            std::string e;
+            std::vector<std::string> nm = plan[(size_t)k];
+            const double t0 = now_ms();
+            if (!cur.err.empty()) { e = cur.err; rc = -1; }
+            if (rc == 0 && (cur.staging || cur.staging_lr) && !p->scratch[li]) p->scratch[li] = np1ingest::scratch_create();
+            if (rc == 0 && cur.staging) {
+                rc = np1ingest::ingest(ln.batch, cur.staging, true, p->scratch[li]);
+                if (rc == 1) {   // records the device path does not take: the host loader decodes this batch
+                    cur.sr = load_host(k, bam_sr);
+                    rc = cur.sr ? 0 : -1;
+                } else if (rc == 0) {
+                    nm = cur.staging->names();
+                }
             }
+            if (rc == 0 && cur.sr) rc = np1_batch_reload(ln.batch, cur.sr);
+            if (rc == 0 && cur.staging_lr) {
+                rc = np1ingest::ingest(lrb, cur.staging_lr, true, p->scratch[li]);
+                if (rc == 1) {   // a CIGAR in a CG tag (ultra-long reads): the host loader swaps it in
+                    cur.lr = load_host(k, bam_lr);
+                    rc = cur.lr ? 0 : -1;
+                }
+            }
+            if (rc == 0 && cur.lr) rc = np1_batch_reload(lrb, cur.lr);
+            const double t1 = now_ms();
+            if (rc == 0) rc = np1_batch_snp_phase(ln.batch, lrb, cfg);
+            const double t2 = now_ms();
+            if (rc == 0) rc = np1_batch_results_fetch(ln.batch);
+            if (rc != 0 && e.empty()) e = np1_last_error();
+            if (timing_on()) fprintf(stderr, "[np1 phase] batch %d (lane %zu): ingest %.1f ms, snp_phase %.1f ms, fetch %.1f ms\n", k, li, t1 - t0, t2 - t1, now_ms() - t2);
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return next_emit == k || rc_all != 0; });
+                if (rc != 0 && rc_all == 0) { rc_all = rc; err = e; }
+                if (rc_all == 0 && sink) {
+                    const uint32_t* b = np1_batch_results_bounds(ln.batch);
+                    const char* sq = np1_batch_results_ptr(ln.batch);
+                    for (size_t c = 0; c < nm.size(); ++c) sink(user, nm[c].c_str(), sq + b[c], (int64_t)b[c + 1] - (int64_t)b[c]);
+                }
+                next_emit = k + 1;
+                cv.notify_all();
+            }
+            drop(cur);
+            if (rc != 0) return;
         }
-        if (rc == 0 && cur.sr) rc = np1_batch_reload(ln.batch, cur.sr);
-        if (rc == 0) rc = np1_batch_reload(p->phase_lr, cur.lr);
-        const double t1 = now_ms();
-        if (rc == 0) rc = np1_batch_snp_phase(ln.batch, p->phase_lr, cfg);
-        const double t2 = now_ms();
-        if (rc == 0) rc = np1_batch_results_fetch(ln.batch);
-        if (rc != 0 && err.empty()) err = np1_last_error();
-        if (timing_on()) fprintf(stderr, "[np1 phase] batch %d: ingest %.1f ms, snp_phase %.1f ms, fetch %.1f ms\n", k, t1 - t0, t2 - t1, now_ms() - t2);
-        if (rc == 0 && sink) {
-            const uint32_t* b = np1_batch_results_bounds(ln.batch);
-            const char* s = np1_batch_results_ptr(ln.batch);
-            for (size_t c = 0; c < nm.size(); ++c) sink(user, nm[c].c_str(), s + b[c], (int64_t)b[c + 1] - (int64_t)b[c]);
-        }
-        drop(cur);
-        if (pre.joinable()) pre.join();
-        cur = next;
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t li = 1; li < L; ++li) th.emplace_back(lane_work, li);
+        lane_work(0);
+        for (std::thread& t : th) t.join();
     }
-    drop(cur);
+    const int rc = rc_all;
     if (rc != 0) { np1_set_error(err); return -1; }
     return 0;
 }
