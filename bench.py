@@ -671,7 +671,9 @@ def main():
         pipe.run(streams, cfg=cfg, fetch=False)
     sync_all()
     dt = max_over_ranks(time.perf_counter() - t0)
-    h2d_bytes = sum(alg_in)
+    L.np1_stream_upload_bytes.restype = C.c_uint64
+    L.np1_stream_upload_bytes.argtypes = [C.c_void_p]
+    h2d_bytes = sum(int(L.np1_stream_upload_bytes(s.handle)) for s in streams)   # what really crosses PCIe per pass (2-bit bases, 16-bit counts, no offsets)
     parity = parity_check(pipe, streams, int(args.parity_mb * 1e6)) if rank == 0 else None
     streamed_lengths = pipe.result_lengths(streams)
 
@@ -753,7 +755,7 @@ def main():
                        "slot_votes_per_step_rank0": updates // n_inst, "lanes": args.lanes,
                        "parallelism": "contigs dealt longest-first x%d (no collective)" % world,
                        "synth_seconds": round(t_gen, 1), "host_cores": ncpu, "host_threads_per_rank": per_rank,
-                       "h2d_gb_per_s_rank0": round(h2d_bytes * args.steps / dt / 1e9, 2)},
+                       "h2d_gb_per_s_rank0": round(h2d_bytes * args.steps / dt / 1e9, 2), "h2d_bytes_per_draft_bp": round(h2d_bytes / max(1, sum(int(x.ctg_len.sum()) for x in streams)), 2)},
             "resident": {"mbp_s": round(resident_v, 2), "ms_per_pass": round(dt_res / args.resident_passes * 1e3, 3), "passes": args.resident_passes,
                          "what": "the same pass with every batch already resident in HBM (no H2D / D2H inside), %d lanes: what the kernels alone sustain" % args.lanes},
             "parity": parity,

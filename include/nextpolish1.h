@@ -216,6 +216,8 @@ void np1_batch_free(np1_batch* b);
 np1_batch* np1_batch_create(np1_ctx* ctx);
 int np1_batch_reload(np1_batch* b, const np1_stream* s);
 int np1_stream_pin(np1_stream* s);
+/* bytes one np1_batch_reload of this stream moves over PCIe (bases as 2 bits + exceptions, operation counts as 16 bits, offsets rebuilt on the device) */
+uint64_t np1_stream_upload_bytes(np1_stream* s);
 int np1_batch_results_fetch(np1_batch* b);
 const char* np1_batch_results_ptr(np1_batch* b);
 const uint32_t* np1_batch_results_bounds(np1_batch* b);

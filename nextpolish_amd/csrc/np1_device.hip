@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/nextpolish1.h"
@@ -115,6 +116,61 @@ static void stream_facts(np1_stream* st) {
         st->ncig16.resize(n);
         for (size_t i = 0; i < n; ++i) st->ncig16[i] = (uint16_t)s.n_cigar[i];
     }
+    // ---- the 2-bit upload form of the bases
+    st->seq2.clear(); st->esc_at.clear(); st->esc_val.clear();
+    static const bool full = getenv("NP1_UPLOAD") && strcmp(getenv("NP1_UPLOAD"), "full") == 0;
+    const size_t nb = s.seq.size();
+    if (!full && nb >= 64) {
+        static const std::array<uint8_t, 256> lut = [] {      // byte of seq -> 4 bits of seq2, 0x80: an exception
+            std::array<uint8_t, 256> t{};
+            auto c2 = [](uint32_t nib) -> int { return nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : -1; };
+            for (uint32_t b = 0; b < 256; ++b) {
+                const int h = c2(b >> 4), l = c2(b & 15u);
+                t[b] = (h < 0 || l < 0) ? 0x80 : (uint8_t)(h << 2 | l);
+            }
+            return t;
+        }();
+        const size_t n2 = (nb + 1) / 2;
+        st->seq2.resize(n2);
+        const size_t grain = (size_t)1 << 20;                     // seq2 bytes per block
+        const size_t blocks = (n2 + grain - 1) / grain;
+        std::vector<std::vector<uint64_t>> e_at(blocks);
+        std::vector<std::vector<uint8_t>> e_val(blocks);
+        const uint8_t* src = s.seq.data();
+        uint8_t* dst = st->seq2.data();
+        np::parallel_for(blocks, 1, [&](size_t b0, size_t b1) {
+            for (size_t blk = b0; blk < b1; ++blk) {
+                const size_t j0 = blk * grain, j1 = std::min(n2, j0 + grain);
+                for (size_t j = j0; j < j1; ++j) {
+                    const uint8_t a = lut[src[2 * j]], c = 2 * j + 1 < nb ? lut[src[2 * j + 1]] : 0;
+                    if (a & 0x80) { e_at[blk].push_back(2 * j); e_val[blk].push_back(src[2 * j]); }
+                    if (c & 0x80) { e_at[blk].push_back(2 * j + 1); e_val[blk].push_back(src[2 * j + 1]); }
+                    dst[j] = (uint8_t)((a & 15u) << 4 | (c & 15u));
+                }
+            }
+        });
+        size_t n_esc = 0;
+        for (const auto& v : e_at) n_esc += v.size();
+        if (n_esc * 64 > nb) {                                    // not worth it: the plain array goes up
+            st->seq2.clear();
+            st->seq2.shrink_to_fit();
+        } else {
+            st->esc_at.reserve(n_esc); st->esc_val.reserve(n_esc);
+            for (size_t blk = 0; blk < blocks; ++blk) {
+                st->esc_at.insert(st->esc_at.end(), e_at[blk].begin(), e_at[blk].end());
+                st->esc_val.insert(st->esc_val.end(), e_val[blk].begin(), e_val[blk].end());
+            }
+        }
+    }
+    {
+        const bool slim_ok = !full && dense && n > 0;
+        uint64_t ub = s.draft.size() + 4 * s.ctg_off.size() + 4 * n + 2 * n + 4 * n + 4 * s.cigar.size() + 8 * s.read_begin.size();
+        ub += st->ncig16.empty() ? 4 * n : 2 * n;
+        ub += st->seq2.empty() ? nb : st->seq2.size() + 9 * st->esc_at.size();
+        if (!slim_ok) ub += 20 * n;
+        if (!s.qual.empty()) ub += 13 * n + s.qual.size();      // mapq, isize, quality offsets, qualities (tasks 2-4)
+        st->upload_bytes = ub;
+    }
     st->facts = dense ? 1 : 2;
 }
 
@@ -154,7 +210,15 @@ static int fill_batch(np1_batch* b, const np1_stream* st_, bool sync) {
     }
     rc |= upload(b->lq, s.l_qseq.data(), 4 * n, q);
     rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);
-    rc |= upload(b->seq, s.seq.data(), s.seq.size(), q);
+    if (!st->seq2.empty()) {   // 2 bits per base over PCIe; the device expands them and patches the exception bytes in
+        const size_t n2 = st->seq2.size(), ne = st->esc_at.size();
+        rc |= upload(b->seq2, st->seq2.data(), n2, q);
+        if (ne) { rc |= upload(b->esc_at, st->esc_at.data(), 8 * ne, q); rc |= upload(b->esc_val, st->esc_val.data(), ne, q); }
+        if (b->seq.ensure(2 * n2 + 16)) return -1;
+        if (rc == 0) launch_unpack_seq2(q, b->seq2.as<uint8_t>(), (uint64_t)n2, b->seq.as<uint8_t>(), b->esc_at.as<uint64_t>(), b->esc_val.as<uint8_t>(), (uint64_t)ne);
+    } else {
+        rc |= upload(b->seq, s.seq.data(), s.seq.size(), q);
+    }
     b->h_read_begin = s.read_begin;
     rc |= upload(b->read_begin, s.read_begin.data(), 8 * s.read_begin.size(), q);
     if (rebuild) {
@@ -205,6 +269,13 @@ int np1_batch_reload(np1_batch* b, const np1_stream* st) {
 
 // Registers the arrays of a host stream with the HIP runtime (page-locked): H2D copies from them run asynchronously at
 // full PCIe rate.  What an ingest stage that writes straight into pinned staging gets for free.
+// bytes one reload of this stream moves host -> device (what the streamed passes of bench.py divide by their time)
+uint64_t np1_stream_upload_bytes(np1_stream* st) {
+    if (!st) return 0;
+    stream_facts(st);
+    return st->upload_bytes;
+}
+
 int np1_stream_pin(np1_stream* st) {
     if (!st) return -1;
     if (st->pinned) return 0;
@@ -215,7 +286,8 @@ int np1_stream_pin(np1_stream* st) {
         return hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess;
     };
     bool ok = reg(s.draft.data(), s.draft.size()) && reg(s.pos.data(), 4 * s.pos.size()) && reg(s.ctg.data(), 4 * s.ctg.size()) &&
-              reg(s.flag.data(), 2 * s.flag.size()) && reg(s.n_cigar.data(), 4 * s.n_cigar.size()) && reg(st->ncig16.data(), 2 * st->ncig16.size()) && reg(s.l_qseq.data(), 4 * s.l_qseq.size()) &&
+              reg(s.flag.data(), 2 * s.flag.size()) && reg(s.n_cigar.data(), 4 * s.n_cigar.size()) && reg(st->ncig16.data(), 2 * st->ncig16.size()) && reg(st->seq2.data(), st->seq2.size()) &&
+              reg(st->esc_at.data(), 8 * st->esc_at.size()) && reg(st->esc_val.data(), st->esc_val.size()) && reg(s.l_qseq.data(), 4 * s.l_qseq.size()) &&
               reg(s.cigar_off.data(), 8 * s.cigar_off.size()) && reg(s.seq_off.data(), 8 * s.seq_off.size()) &&
               reg(s.cigar.data(), 4 * s.cigar.size()) && reg(s.seq.data(), s.seq.size()) && reg(s.mapq.data(), s.mapq.size()) &&
               reg(s.isize.data(), 4 * s.isize.size()) && reg(s.qual_off.data(), 8 * s.qual_off.size()) && reg(s.qual.data(), s.qual.size());
@@ -1018,7 +1090,7 @@ int64_t np1_batch_device_bytes(np1_batch* b) { return b ? (int64_t)b->device_byt
 void np1_stream_unpin(np1_stream* st) {
     if (!st || !st->pinned) return;
     np::ReadStream& s = st->s;
-    const void* ptrs[] = {s.draft.data(), s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), st->ncig16.data(), s.l_qseq.data(), s.cigar_off.data(),
+    const void* ptrs[] = {s.draft.data(), s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), st->ncig16.data(), st->seq2.data(), st->esc_at.data(), st->esc_val.data(), s.l_qseq.data(), s.cigar_off.data(),
                           s.seq_off.data(), s.cigar.data(), s.seq.data(), s.mapq.data(), s.isize.data(), s.qual_off.data(), s.qual.data()};
     for (const void* p : ptrs)
         if (p) (void)hipHostUnregister(const_cast<void*>(p));   // fails harmlessly for arrays that were empty / never registered

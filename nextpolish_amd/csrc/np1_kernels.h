@@ -31,7 +31,10 @@ void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint3
                  const int32_t* qs, const int32_t* qe, uint32_t* desc, uint32_t* ovf_pool, uint32_t ovf_cap,
                  uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters, const uint8_t* dpack = nullptr, uint32_t* dirty = nullptr);
 // cigar_off / seq_off / ctg of a dense record stream on the device (cigoff and seqoff get n + 1 entries)
-void launch_widen_u16(hipStream_t st, const uint16_t* src, uint32_t* dst, uint64_t n);   // the 16-bit upload form of the CIGAR operation counts
+void launch_widen_u16(hipStream_t st, const uint16_t* src, uint32_t* dst, uint64_t n);
+// the 2-bit upload form of the packed bases (np1_priv.h: np1_stream::seq2) expanded to the 4-bit codes the kernels read, then the
+// exception bytes put in place; seq must hold 2 * n2 bytes
+void launch_unpack_seq2(hipStream_t st, const uint8_t* seq2, uint64_t n2, uint8_t* seq, const uint64_t* esc_at, const uint8_t* esc_val, uint64_t n_esc);   // the 16-bit upload form of the CIGAR operation counts
 void launch_record_offsets(hipStream_t st, const uint32_t* ncig, const int32_t* lq, const uint64_t* read_begin, uint32_t nc, uint64_t n, uint64_t* cigoff,
                            uint64_t* seqoff, uint32_t* ctg, uint64_t* tmp, uint64_t* total);
 // the draft as packed 4-bit codes (the layout of the reads' bases): what k_desc compares the records with for their dirty hulls

@@ -1879,6 +1879,37 @@ __global__ __launch_bounds__(256) void k_widen_u16(const uint16_t* __restrict__ 
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i];
 }
+// 4 bytes of seq2 (16 bases) -> 8 bytes of seq per lane: coalesced 4-byte loads, 8-byte stores
+__global__ __launch_bounds__(256) void k_unpack_seq2(const uint8_t* __restrict__ seq2, uint64_t n2, uint8_t* __restrict__ seq) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;      // word of seq2
+    if (4 * w >= n2) return;
+    uint32_t v;
+    if (4 * w + 4 <= n2) v = reinterpret_cast<const uint32_t*>(seq2)[w];
+    else { v = 0; for (uint64_t k = 4 * w; k < n2; ++k) v |= (uint32_t)seq2[k] << (8 * (k - 4 * w)); }
+    uint32_t out[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t b = (v >> (16 * h + 8 * k)) & 0xffu;       // seq2 byte 4w + 2h + k: two bytes of seq
+            const uint32_t hi = ((1u << ((b >> 6) & 3u)) << 4) | (1u << ((b >> 4) & 3u));
+            const uint32_t lo = ((1u << ((b >> 2) & 3u)) << 4) | (1u << (b & 3u));
+            o |= (hi | lo << 8) << (16 * k);
+        }
+        out[h] = o;
+    }
+    uint2* dst = reinterpret_cast<uint2*>(seq) + w;                    // (the buffer holds 2 * n2 rounded up to 8 bytes)
+    *dst = make_uint2(out[0], out[1]);
+}
+__global__ __launch_bounds__(256) void k_patch_seq(const uint64_t* __restrict__ at, const uint8_t* __restrict__ val, uint64_t n, uint8_t* __restrict__ seq) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) seq[at[i]] = val[i];
+}
+void launch_unpack_seq2(hipStream_t st, const uint8_t* seq2, uint64_t n2, uint8_t* seq, const uint64_t* esc_at, const uint8_t* esc_val, uint64_t n_esc) {
+    if (n2) k_unpack_seq2<<<nblk((n2 + 3) / 4, 256), 256, 0, st>>>(seq2, n2, seq);
+    if (n_esc) k_patch_seq<<<nblk(n_esc, 256), 256, 0, st>>>(esc_at, esc_val, n_esc, seq);
+}
 void launch_widen_u16(hipStream_t st, const uint16_t* src, uint32_t* dst, uint64_t n) {
     if (n) k_widen_u16<<<nblk(n, 256), 256, 0, st>>>(src, dst, n);
 }

@@ -15,6 +15,15 @@ struct np1_stream {
     // CIGAR operation counts in the 16 bits the BAM record gives them, for the upload (the device widens them): only a CG-tag CIGAR
     // needs more, and a stream that holds one uploads its 32-bit counts as they are.  Empty: not made / does not apply.
     std::vector<uint16_t> ncig16;
+    // The packed bases in the form they cross PCIe in: 2 bits per base (A C G T; the 4-bit code is 1 << that), i.e. half the bytes of
+    // the largest array of a short-read batch -- the streamed pass is bound by the H2D copies (bench.py: h2d_gb_per_s).  Bytes of
+    // `seq` holding anything else (N, ambiguity codes, the pad nibble of an odd-length record) travel as (byte index, byte) pairs and
+    // are patched in after the device has expanded the rest.  seq2[j] = codes of seq[2j] (high 4 bits) and seq[2j + 1] (low 4 bits).
+    // Empty: not made, or more than 1 byte in 64 would be an exception (then `seq` is uploaded as it is).
+    std::vector<uint8_t> seq2;
+    std::vector<uint64_t> esc_at;
+    std::vector<uint8_t> esc_val;
+    uint64_t upload_bytes = 0;     // what a reload of this stream moves over PCIe (np1_stream_upload_bytes)
 };
 
 void np1_set_error(const std::string& e);   // np_host_abi.cpp

@@ -699,6 +699,13 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
         if (it.failed()) np2_die(err.c_str(), ref->n);
         in.recs.seq.resize(in.recs.seq.size() + 8, 0);
         lap("decode + merge");
+        if (timing) {
+            double ms[4];
+            uint64_t nw[2];
+            np::bgzf_prof_take(ms, nw);
+            fprintf(stderr, "[np2 host]   of which BGZF windows: read %.2f ms, block scan %.2f ms, device inflate %.2f ms (%llu windows), host inflate %.2f ms (%llu windows)\n", ms[0],
+                    ms[1], ms[2], (unsigned long long)nw[0], ms[3], (unsigned long long)nw[1]);
+        }
         // ---- spans of every candidate, then the order-dependent keep rules (ctg_cns.c:3540-3545)
         std::vector<np2::SpanOut> spans;
         if (!cfg->exec->compute_spans(in, 0, &spans, &err)) np2_die(err.c_str(), ref->n);

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <time.h>
 #include <thread>
 
 namespace np {
@@ -63,6 +64,14 @@ static unsigned io_threads() {
     return n;
 }
 
+// stage clocks of fill_window, summed over the process (NP2_TIMING prints them per polished window: np2_pipeline.cpp)
+static std::atomic<uint64_t> g_prof_ns[4];      // fread, block scan, batch (device) inflate, host inflate
+static std::atomic<uint64_t> g_prof_n[2];       // windows inflated by the batch hook / on the host
+static inline uint64_t prof_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
+void bgzf_prof_take(double ms[4], uint64_t n[2]) {
+    for (int i = 0; i < 4; ++i) ms[i] = g_prof_ns[i].exchange(0) * 1e-6;
+    for (int i = 0; i < 2; ++i) n[i] = g_prof_n[i].exchange(0);
+}
 static bgzf_batch_inflate_fn g_batch_fn = nullptr;
 static size_t g_batch_window = 0;
 void set_bgzf_batch_inflater(bgzf_batch_inflate_fn fn, size_t window_bytes) { g_batch_fn = fn; g_batch_window = window_bytes; }
@@ -81,7 +90,10 @@ bool BgzfReader::fill_window(uint64_t coff) {
     win_i_ = 0;
     if (fseeko(fp_, (off_t)coff, SEEK_SET) != 0) return false;
     cwin_.resize(kWindow + kMaxBlock + 64);
+    const uint64_t pt0 = prof_now();
     const size_t got = fread(cwin_.data(), 1, cwin_.size(), fp_);
+    const uint64_t pt1 = prof_now();
+    g_prof_ns[0] += pt1 - pt0;
     size_t p = 0, utotal = 0;
     while (p + 18 <= got) {
         const uint8_t* h = cwin_.data() + p;
@@ -109,6 +121,9 @@ bool BgzfReader::fill_window(uint64_t coff) {
     }
     if (win_.empty()) return got == 0 || got < 18 ? (got == 0) : false;   // clean EOF only when nothing is left
     uwin_.resize(utotal + 8);
+    const uint64_t pt2 = prof_now();
+    g_prof_ns[1] += pt2 - pt1;
+    struct Clock { uint64_t t0; int slot; ~Clock() { g_prof_ns[slot] += prof_now() - t0; ++g_prof_n[slot - 2]; } };
     if (g_batch_fn && win_.size() >= 64) {     // enough blocks to fill a device: one launch for the whole window (the hook checks the CRCs itself: np_bgzf_dev.hip)
         std::vector<BgzfBatchBlock> bb(win_.size());
         for (size_t i = 0; i < win_.size(); ++i) {
@@ -116,12 +131,14 @@ bool BgzfReader::fill_window(uint64_t coff) {
             bb[i] = BgzfBatchBlock{(uint64_t)b.cpos, (uint64_t)b.upos, (uint32_t)(b.total - (b.cpos - (size_t)(b.coff - coff)) - 8), b.isize};
         }
         batch_next_coff_ = win_.back().coff + win_.back().total;
+        Clock c{prof_now(), 2};
         if (g_batch_fn(cwin_.data(), got, bb.data(), bb.size(), uwin_.data(), utotal)) return true;
     } else if (g_batch_fn && !win_.empty()) {
         batch_next_coff_ = win_.back().coff + win_.back().total;
     }
     const unsigned nt = io_threads();
     static const bool check_crc = getenv("NP_BGZF_NO_CRC") == nullptr;   // on unless switched off
+    Clock c_host{prof_now(), 3};
     std::atomic<size_t> next(0);
     std::atomic<bool> ok(true);
     auto work = [&]() {

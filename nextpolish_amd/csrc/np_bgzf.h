@@ -100,4 +100,7 @@ void set_bgzf_batch_inflater(bgzf_batch_inflate_fn fn, size_t window_bytes);
 // Inflate one raw-deflate payload (used by the threaded whole-file loader).
 bool bgzf_inflate_block(const uint8_t* cdata, size_t clen, uint8_t* out, size_t out_len);
 
+// stage clocks of BgzfReader::fill_window summed since the last call (ms: read, block scan, batch inflate, host inflate; windows by inflater)
+void bgzf_prof_take(double ms[4], uint64_t n[2]);
+
 }  // namespace np
