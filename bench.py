@@ -568,6 +568,7 @@ def main():
     ap.add_argument("--parity-mb", type=float, default=8.0, help="draft bases compared with the CPU oracle inside the run")
     ap.add_argument("--workload", default="c5_3gb_30x", choices=sorted(WORKLOADS))
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight on the device")
+    ap.add_argument("--batch-mb", type=float, default=0.0, help="draft bases per batch (Mb); 0 = the workload's own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=3.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic = null)")
@@ -605,6 +606,8 @@ def main():
     from nextpolish_amd.shard import deal_contigs
 
     total, depth, lo, hi, batch_bp = WORKLOADS[args.workload]
+    if args.batch_mb > 0:
+        batch_bp = int(args.batch_mb * 1e6)
     lens = contig_lengths(total, lo, hi)
     names = ["c%04d" % i for i in range(len(lens))]
     lmap = dict(zip(names, lens))

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <array>
 #include <vector>
 
@@ -162,10 +163,55 @@ static void stream_facts(np1_stream* st) {
             }
         }
     }
+    // ---- the compact upload form of the per-record fields (np1_priv.h)
+    st->compact = np1_stream::Compact();
+    static const bool no_compact = getenv("NP1_UPLOAD") && strcmp(getenv("NP1_UPLOAD"), "seq2") == 0;      // NP1_UPLOAD=seq2: 2-bit bases only
+    // (small batches: the scans and kernels that undo it cost more than the bytes it saves -- measured on 13 Mb batches, 2.6 M records:
+    // 3650 -> 3300 Mbp/s; NP1_COMPACT_MIN = records from which on it is used)
+    static const size_t compact_min = getenv("NP1_COMPACT_MIN") ? (size_t)atoll(getenv("NP1_COMPACT_MIN")) : ((size_t)1 << 22);
+    if (!full && !no_compact && dense && n >= 64 && n >= compact_min) {
+        np1_stream::Compact& C = st->compact;
+        {   // the usual read length: the most frequent one among the first records
+            const size_t m = std::min<size_t>(n, 4096);
+            std::vector<int32_t> sample(s.l_qseq.begin(), s.l_qseq.begin() + m);
+            std::sort(sample.begin(), sample.end());
+            size_t best = 0, run = 0;
+            for (size_t i = 0; i < m; ++i) {
+                run = (i > 0 && sample[i] == sample[i - 1]) ? run + 1 : 1;
+                if (run > best && sample[i] > 0 && sample[i] < (1 << 28)) { best = run; C.common_lq = (uint32_t)sample[i]; }
+            }
+        }
+        C.plain.assign((n + 31) / 32, 0u);
+        C.dpos.resize(n);
+        const uint32_t plain_op = C.common_lq << 4;      // <common_lq>M
+        size_t ct = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t k = s.n_cigar[i];
+            const uint32_t* cg = s.cigar.data() + s.cigar_off[i];
+            if (C.common_lq && k == 1 && (uint32_t)s.l_qseq[i] == C.common_lq && cg[0] == plain_op) {
+                C.plain[i >> 5] |= 1u << (i & 31u);
+            } else {
+                C.x_lq.push_back(s.l_qseq[i]);
+                C.x_ncig.push_back(k);
+                C.x_cigar.insert(C.x_cigar.end(), cg, cg + k);
+            }
+            while (ct + 1 < s.read_begin.size() && s.read_begin[ct + 1] <= i) ++ct;
+            const int64_t d = i > 0 ? (int64_t)s.pos[i] - (int64_t)s.pos[i - 1] : -1;
+            if (i == 0 || i == s.read_begin[ct] || d < 0 || d >= 255) { C.dpos[i] = 255; C.x_pos.push_back(s.pos[i]); }
+            else C.dpos[i] = (uint8_t)d;
+        }
+        C.n_ops = s.cigar.size();
+        const uint64_t as_is = 4 * n + (st->ncig16.empty() ? 4 * n : 2 * n) + 4 * n + 4 * s.cigar.size();
+        const uint64_t packed = 4 * C.plain.size() + n + 4 * C.x_pos.size() + 8 * C.x_lq.size() + 4 * C.x_cigar.size();
+        C.on = packed * 10 < as_is * 9;
+        if (!C.on) st->compact = np1_stream::Compact();
+    }
     {
         const bool slim_ok = !full && dense && n > 0;
-        uint64_t ub = s.draft.size() + 4 * s.ctg_off.size() + 4 * n + 2 * n + 4 * n + 4 * s.cigar.size() + 8 * s.read_begin.size();
-        ub += st->ncig16.empty() ? 4 * n : 2 * n;
+        const np1_stream::Compact& C = st->compact;
+        uint64_t ub = s.draft.size() + 4 * s.ctg_off.size() + 2 * n + 8 * s.read_begin.size();
+        if (C.on) ub += 4 * C.plain.size() + n + 4 * C.x_pos.size() + 8 * C.x_lq.size() + 4 * C.x_cigar.size();
+        else ub += 4 * n + 4 * n + 4 * s.cigar.size() + (st->ncig16.empty() ? 4 * n : 2 * n);
         ub += st->seq2.empty() ? nb : st->seq2.size() + 9 * st->esc_at.size();
         if (!slim_ok) ub += 20 * n;
         if (!s.qual.empty()) ub += 13 * n + s.qual.size();      // mapq, isize, quality offsets, qualities (tasks 2-4)
@@ -199,17 +245,32 @@ static int fill_batch(np1_batch* b, const np1_stream* st_, bool sync) {
     const bool rebuild = slim && st->facts == 1 && n > 0;
     rc |= upload(b->draft, s.draft.data(), s.draft.size(), q);
     rc |= upload(b->ctg_off, s.ctg_off.data(), 4 * s.ctg_off.size(), q);
-    rc |= upload(b->pos, s.pos.data(), 4 * n, q);
+    const np1_stream::Compact& C = st->compact;
+    const bool compact = rebuild && C.on;
     rc |= upload(b->flag, s.flag.data(), 2 * n, q);
-    if (!st->ncig16.empty()) {   // the usual case: 2 bytes per record cross PCIe, the device widens them
+    if (compact) {   // one bit + one byte per record, and in full only what is not a plain read a few bases behind the last one
+        rc |= upload(b->up_plain, C.plain.data(), 4 * C.plain.size(), q);
+        rc |= upload(b->up_dpos, C.dpos.data(), n, q);
+        rc |= upload(b->up_xpos, C.x_pos.data(), 4 * C.x_pos.size(), q);
+        rc |= upload(b->up_xlq, C.x_lq.data(), 4 * C.x_lq.size(), q);
+        rc |= upload(b->up_xncig, C.x_ncig.data(), 4 * C.x_ncig.size(), q);
+        rc |= upload(b->up_xcigar, C.x_cigar.data(), 4 * C.x_cigar.size(), q);
+        if (b->pos.ensure(4 * n) || b->ncig.ensure(4 * n) || b->lq.ensure(4 * n) || b->cigar.ensure(4 * (size_t)C.n_ops + 16) ||
+            b->up_work.ensure(8 * (3 * (n + 1) + C.x_pos.size() + 8)))
+            return -1;
+    } else if (!st->ncig16.empty()) {
+        rc |= upload(b->pos, s.pos.data(), 4 * n, q);
+        rc |= upload(b->lq, s.l_qseq.data(), 4 * n, q);
+        rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);   // the usual case: 2 bytes per record cross PCIe, the device widens them
         rc |= upload(b->ncig16, st->ncig16.data(), 2 * n, q);
         if (b->ncig.ensure(4 * n)) return -1;
         if (rc == 0) launch_widen_u16(q, b->ncig16.as<uint16_t>(), b->ncig.as<uint32_t>(), (uint64_t)n);
     } else {
+        rc |= upload(b->pos, s.pos.data(), 4 * n, q);
+        rc |= upload(b->lq, s.l_qseq.data(), 4 * n, q);
+        rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);
         rc |= upload(b->ncig, s.n_cigar.data(), 4 * n, q);
     }
-    rc |= upload(b->lq, s.l_qseq.data(), 4 * n, q);
-    rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);
     if (!st->seq2.empty()) {   // 2 bits per base over PCIe; the device expands them and patches the exception bytes in
         const size_t n2 = st->seq2.size(), ne = st->esc_at.size();
         rc |= upload(b->seq2, st->seq2.data(), n2, q);
@@ -227,9 +288,17 @@ static int fill_batch(np1_batch* b, const np1_stream* st_, bool sync) {
         if (b->cigoff.ensure(8 * (n + 2)) || b->seqoff.ensure(8 * (n + 2)) || b->ctg.ensure(4 * n) ||
             b->scan_tmp.ensure(8 * (scan_tmp_words((uint64_t)n + 1) + 8)) || b->totals.ensure(256))
             return -1;
+        const CompactDev cd{b->up_plain.as<uint32_t>(), b->up_xlq.as<int32_t>(), b->up_xncig.as<uint32_t>(), b->up_xcigar.as<uint32_t>(), b->up_dpos.as<uint8_t>(),
+                            b->up_xpos.as<int32_t>(), C.common_lq, (uint64_t)n, (uint64_t)C.x_lq.size(), (uint64_t)C.x_pos.size()};
+        if (rc == 0 && compact)
+            launch_expand_records(q, cd, b->pos.as<int32_t>(), b->ncig.as<uint32_t>(), b->lq.as<int32_t>(), b->up_work.as<uint64_t>(), b->scan_tmp.as<uint64_t>(),
+                                  b->totals.as<uint64_t>() + 24);
         if (rc == 0)
             launch_record_offsets(q, b->ncig.as<uint32_t>(), b->lq.as<int32_t>(), b->read_begin.as<uint64_t>(), b->nc, (uint64_t)n, b->cigoff.as<uint64_t>(),
                                   b->seqoff.as<uint64_t>(), b->ctg.as<uint32_t>(), b->scan_tmp.as<uint64_t>(), b->totals.as<uint64_t>() + 24);
+        if (rc == 0 && compact)
+            launch_expand_cigars(q, cd, b->ncig.as<uint32_t>(), b->cigoff.as<uint64_t>(), b->cigar.as<uint32_t>(), b->up_work.as<uint64_t>(), b->scan_tmp.as<uint64_t>(),
+                                 b->totals.as<uint64_t>() + 24);
     } else {
         rc |= upload(b->ctg, s.ctg.data(), 4 * n, q);
         rc |= upload(b->cigoff, s.cigar_off.data(), 8 * n, q);
@@ -287,7 +356,10 @@ int np1_stream_pin(np1_stream* st) {
     };
     bool ok = reg(s.draft.data(), s.draft.size()) && reg(s.pos.data(), 4 * s.pos.size()) && reg(s.ctg.data(), 4 * s.ctg.size()) &&
               reg(s.flag.data(), 2 * s.flag.size()) && reg(s.n_cigar.data(), 4 * s.n_cigar.size()) && reg(st->ncig16.data(), 2 * st->ncig16.size()) && reg(st->seq2.data(), st->seq2.size()) &&
-              reg(st->esc_at.data(), 8 * st->esc_at.size()) && reg(st->esc_val.data(), st->esc_val.size()) && reg(s.l_qseq.data(), 4 * s.l_qseq.size()) &&
+              reg(st->esc_at.data(), 8 * st->esc_at.size()) && reg(st->esc_val.data(), st->esc_val.size()) && reg(st->compact.plain.data(), 4 * st->compact.plain.size()) &&
+              reg(st->compact.dpos.data(), st->compact.dpos.size()) && reg(st->compact.x_pos.data(), 4 * st->compact.x_pos.size()) &&
+              reg(st->compact.x_lq.data(), 4 * st->compact.x_lq.size()) && reg(st->compact.x_ncig.data(), 4 * st->compact.x_ncig.size()) &&
+              reg(st->compact.x_cigar.data(), 4 * st->compact.x_cigar.size()) && reg(s.l_qseq.data(), 4 * s.l_qseq.size()) &&
               reg(s.cigar_off.data(), 8 * s.cigar_off.size()) && reg(s.seq_off.data(), 8 * s.seq_off.size()) &&
               reg(s.cigar.data(), 4 * s.cigar.size()) && reg(s.seq.data(), s.seq.size()) && reg(s.mapq.data(), s.mapq.size()) &&
               reg(s.isize.data(), 4 * s.isize.size()) && reg(s.qual_off.data(), 8 * s.qual_off.size()) && reg(s.qual.data(), s.qual.size());
@@ -1090,7 +1162,8 @@ int64_t np1_batch_device_bytes(np1_batch* b) { return b ? (int64_t)b->device_byt
 void np1_stream_unpin(np1_stream* st) {
     if (!st || !st->pinned) return;
     np::ReadStream& s = st->s;
-    const void* ptrs[] = {s.draft.data(), s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), st->ncig16.data(), st->seq2.data(), st->esc_at.data(), st->esc_val.data(), s.l_qseq.data(), s.cigar_off.data(),
+    const void* ptrs[] = {s.draft.data(), s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), st->ncig16.data(), st->seq2.data(), st->esc_at.data(), st->esc_val.data(), st->compact.plain.data(), st->compact.dpos.data(), st->compact.x_pos.data(),
+                          st->compact.x_lq.data(), st->compact.x_ncig.data(), st->compact.x_cigar.data(), s.l_qseq.data(), s.cigar_off.data(),
                           s.seq_off.data(), s.cigar.data(), s.seq.data(), s.mapq.data(), s.isize.data(), s.qual_off.data(), s.qual.data()};
     for (const void* p : ptrs)
         if (p) (void)hipHostUnregister(const_cast<void*>(p));   // fails harmlessly for arrays that were empty / never registered

@@ -32,6 +32,14 @@ void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint3
                  uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters, const uint8_t* dpack = nullptr, uint32_t* dirty = nullptr);
 // cigar_off / seq_off / ctg of a dense record stream on the device (cigoff and seqoff get n + 1 entries)
 void launch_widen_u16(hipStream_t st, const uint16_t* src, uint32_t* dst, uint64_t n);
+// the compact upload form of the per-record fields (np1_priv.h: np1_stream::Compact) -> pos, n_cigar, l_qseq and the operation pool;
+// cigoff = the running sums of n_cigar (launch_record_offsets, between the two halves).  work: 3 * (n + 1) + nx + 2 words of 8 bytes.
+struct CompactDev {
+    const uint32_t* plain; const int32_t* x_lq; const uint32_t* x_ncig; const uint32_t* x_cigar; const uint8_t* dpos; const int32_t* x_pos;
+    uint32_t common_lq; uint64_t n, nx, n_xpos;
+};
+void launch_expand_records(hipStream_t st, const CompactDev& c, int32_t* pos, uint32_t* ncig, int32_t* lq, uint64_t* work, uint64_t* tmp, uint64_t* total);
+void launch_expand_cigars(hipStream_t st, const CompactDev& c, const uint32_t* ncig, const uint64_t* cigoff, uint32_t* cigar, uint64_t* work, uint64_t* tmp, uint64_t* total);
 // the 2-bit upload form of the packed bases (np1_priv.h: np1_stream::seq2) expanded to the 4-bit codes the kernels read, then the
 // exception bytes put in place; seq must hold 2 * n2 bytes
 void launch_unpack_seq2(hipStream_t st, const uint8_t* seq2, uint64_t n2, uint8_t* seq, const uint64_t* esc_at, const uint8_t* esc_val, uint64_t n_esc);   // the 16-bit upload form of the CIGAR operation counts

@@ -1910,6 +1910,66 @@ void launch_unpack_seq2(hipStream_t st, const uint8_t* seq2, uint64_t n2, uint8_
     if (n2) k_unpack_seq2<<<nblk((n2 + 3) / 4, 256), 256, 0, st>>>(seq2, n2, seq);
     if (n_esc) k_patch_seq<<<nblk(n_esc, 256), 256, 0, st>>>(esc_at, esc_val, n_esc, seq);
 }
+// ---- the compact upload form of the per-record fields, undone (np1_priv.h: np1_stream::Compact)
+struct LoadNotPlain {
+    const uint32_t* bits;
+    __device__ uint64_t operator()(uint64_t i) const { return ((bits[i >> 5] >> (i & 31u)) & 1u) ^ 1u; }
+};
+struct LoadPosEsc {
+    const uint8_t* d;
+    __device__ uint64_t operator()(uint64_t i) const { return d[i] == 255 ? 1ull : 0ull; }
+};
+struct LoadPosStep {
+    const uint8_t* d;
+    __device__ uint64_t operator()(uint64_t i) const { return d[i] == 255 ? 0ull : (uint64_t)d[i]; }
+};
+// work: xidx[n + 1] | pidx[n + 1] | steps[n + 1] | esc_rec[n_xpos] (8-byte words each; x_cigoff[nx + 1] reuses pidx.. later)
+__global__ __launch_bounds__(256) void k_expand_a(CompactDev c, const uint64_t* __restrict__ xidx, const uint64_t* __restrict__ pidx, uint32_t* __restrict__ ncig,
+                                                  int32_t* __restrict__ lq, uint64_t* __restrict__ esc_rec) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= c.n) return;
+    const bool plain = (c.plain[r >> 5] >> (r & 31u)) & 1u;
+    if (plain) { ncig[r] = 1u; lq[r] = (int32_t)c.common_lq; }
+    else { const uint64_t k = xidx[r]; ncig[r] = c.x_ncig[k]; lq[r] = c.x_lq[k]; }
+    if (c.dpos[r] == 255) esc_rec[pidx[r]] = r;
+}
+__global__ __launch_bounds__(256) void k_expand_pos(CompactDev c, const uint64_t* __restrict__ pidx, const uint64_t* __restrict__ steps, const uint64_t* __restrict__ esc_rec,
+                                                    int32_t* __restrict__ pos) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= c.n) return;
+    const bool esc = c.dpos[r] == 255;
+    const uint64_t k = pidx[r] + (esc ? 1u : 0u) - 1u;      // the last full position at or before r (record 0 carries one)
+    const uint64_t e = esc_rec[k];
+    // steps[] are exclusive sums, and a record with a full position contributes no step: the steps from e + 1 to r inclusive
+    const uint64_t upto_r = steps[r] + (esc ? 0ull : (uint64_t)c.dpos[r]);
+    pos[r] = c.x_pos[k] + (int32_t)(upto_r - steps[e]);
+}
+__global__ __launch_bounds__(256) void k_expand_cigar(CompactDev c, const uint64_t* __restrict__ xidx, const uint64_t* __restrict__ x_cigoff, const uint32_t* __restrict__ ncig,
+                                                      const uint64_t* __restrict__ cigoff, uint32_t* __restrict__ cigar) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= c.n) return;
+    const bool plain = (c.plain[r >> 5] >> (r & 31u)) & 1u;
+    uint32_t* dst = cigar + cigoff[r];
+    if (plain) { dst[0] = c.common_lq << 4; return; }
+    const uint32_t* src = c.x_cigar + x_cigoff[xidx[r]];
+    const uint32_t m = ncig[r];
+    for (uint32_t j = 0; j < m; ++j) dst[j] = src[j];
+}
+void launch_expand_records(hipStream_t st, const CompactDev& c, int32_t* pos, uint32_t* ncig, int32_t* lq, uint64_t* work, uint64_t* tmp, uint64_t* total) {
+    if (c.n == 0) return;
+    uint64_t* xidx = work, *pidx = work + (c.n + 1), *steps = work + 2 * (c.n + 1), *esc_rec = work + 3 * (c.n + 1);
+    scan_impl<LoadNotPlain, uint64_t>(st, LoadNotPlain{c.plain}, c.n, xidx, tmp, total);
+    scan_impl<LoadPosEsc, uint64_t>(st, LoadPosEsc{c.dpos}, c.n, pidx, tmp, total);
+    scan_impl<LoadPosStep, uint64_t>(st, LoadPosStep{c.dpos}, c.n, steps, tmp, total);
+    k_expand_a<<<nblk(c.n, 256), 256, 0, st>>>(c, xidx, pidx, ncig, lq, esc_rec);
+    k_expand_pos<<<nblk(c.n, 256), 256, 0, st>>>(c, pidx, steps, esc_rec, pos);
+}
+void launch_expand_cigars(hipStream_t st, const CompactDev& c, const uint32_t* ncig, const uint64_t* cigoff, uint32_t* cigar, uint64_t* work, uint64_t* tmp, uint64_t* total) {
+    if (c.n == 0) return;
+    uint64_t* xidx = work, *x_cigoff = work + (c.n + 1);      // (pidx is done with)
+    if (c.nx) scan_impl<LoadU32, uint64_t>(st, LoadU32{c.x_ncig}, c.nx, x_cigoff, tmp, total);
+    k_expand_cigar<<<nblk(c.n, 256), 256, 0, st>>>(c, xidx, x_cigoff, ncig, cigoff, cigar);
+}
 void launch_widen_u16(hipStream_t st, const uint16_t* src, uint32_t* dst, uint64_t n) {
     if (n) k_widen_u16<<<nblk(n, 256), 256, 0, st>>>(src, dst, n);
 }

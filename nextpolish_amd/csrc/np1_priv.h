@@ -23,6 +23,23 @@ struct np1_stream {
     std::vector<uint8_t> seq2;
     std::vector<uint64_t> esc_at;
     std::vector<uint8_t> esc_val;
+    // The per-record fields in the form they cross PCIe in (dense streams of at least a few records; np1_device.hip:stream_facts
+    // builds it, np1_kernels.hip:launch_expand_records undoes it).  Short-read records are alike: one match operation as long as the
+    // read, the read as long as all the others, a position a few bases behind the previous record's.  A record of that kind ("plain")
+    // sends one bit instead of n_cigar + l_qseq + its operation; every record sends its position as a one-byte step from the record
+    // before it.  What does not fit -- other CIGARs and lengths, steps of 255 or more, the first record of a contig -- travels in
+    // full, in record order, in the x_ arrays.
+    struct Compact {
+        bool on = false;
+        uint32_t common_lq = 0;
+        std::vector<uint32_t> plain;      // bit r: record r is plain
+        std::vector<int32_t> x_lq;        // the records that are not, in record order: l_qseq, n_cigar, operations
+        std::vector<uint32_t> x_ncig;
+        std::vector<uint32_t> x_cigar;
+        std::vector<uint8_t> dpos;        // pos[r] - pos[r - 1]; 255: the next entry of x_pos
+        std::vector<int32_t> x_pos;
+        uint64_t n_ops = 0;               // operations of all records (size of the rebuilt pool)
+    } compact;
     uint64_t upload_bytes = 0;     // what a reload of this stream moves over PCIe (np1_stream_upload_bytes)
 };
 
