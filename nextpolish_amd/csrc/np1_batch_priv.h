@@ -69,7 +69,7 @@ struct np1_batch {
     uint64_t G = 0;
     int64_t n_reads = 0;
     // inputs
-    np1dev::DevBuf draft, ctg_off, pos, ctg, flag, ncig, ncig16, lq, cigoff, seqoff, cigar, seq, seq2, esc_at, esc_val, up_plain, up_xlq, up_xncig, up_xcigar, up_dpos, up_xpos, up_work;
+    np1dev::DevBuf draft, ctg_off, pos, ctg, flag, ncig, ncig16, lq, cigoff, seqoff, cigar, seq, seq2, esc_at, esc_val, up_plain, up_xlq, up_xncig, up_xcigar, up_dpos, up_xpos, up_work, draft4, desc_at, desc_val;
     // work
     np1dev::DevBuf desc, ovf_desc, slot_g, dbg, dpack, dirty;
     // kmer_count inputs (uploaded only when the stream carries qualities) and work buffers
@@ -143,7 +143,7 @@ struct np1_batch {
         out_pinned = false;
     }
     size_t device_bytes() const {
-        const np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &ncig16, &lq, &cigoff, &seqoff, &cigar, &seq, &seq2, &esc_at, &esc_val, &up_plain, &up_xlq, &up_xncig, &up_xcigar, &up_dpos, &up_xpos, &up_work, &qs, &qe,
+        const np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &ncig16, &lq, &cigoff, &seqoff, &cigar, &seq, &seq2, &esc_at, &esc_val, &up_plain, &up_xlq, &up_xncig, &up_xcigar, &up_dpos, &up_xpos, &up_work, &draft4, &desc_at, &desc_val, &qs, &qe,
                                &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
                                &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &redo3, &ctx_lists, &counters, &opos, &out,
                                &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &dpack, &dirty, &mapq, &isize, &qualoff, &qual, &read_begin,
@@ -158,7 +158,7 @@ struct np1_batch {
         return t;
     }
     void release_all() {
-        np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &ncig16, &lq, &cigoff, &seqoff, &cigar, &seq, &seq2, &esc_at, &esc_val, &up_plain, &up_xlq, &up_xncig, &up_xcigar, &up_dpos, &up_xpos, &up_work, &qs, &qe,
+        np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &ncig16, &lq, &cigoff, &seqoff, &cigar, &seq, &seq2, &esc_at, &esc_val, &up_plain, &up_xlq, &up_xncig, &up_xcigar, &up_dpos, &up_xpos, &up_work, &draft4, &desc_at, &desc_val, &qs, &qe,
                          &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
                          &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &redo3, &ctx_lists, &counters, &opos, &out,
                          &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &dpack, &dirty, &mapq, &isize, &qualoff, &qual, &read_begin,

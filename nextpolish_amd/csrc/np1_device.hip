@@ -163,6 +163,45 @@ static void stream_facts(np1_stream* st) {
             }
         }
     }
+    // ---- the 4-bit upload form of the draft
+    st->draft4.clear(); st->desc_at.clear(); st->desc_val.clear();
+    const size_t G = s.draft.size();
+    if (!full && G >= 4096) {
+        const size_t g2 = (G + 1) / 2;
+        st->draft4.resize(g2);
+        auto code = [](uint8_t ch) -> int {      // 2-bit base | lower << 2, or -1
+            switch (ch) {
+                case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
+                case 'a': return 4; case 'c': return 5; case 'g': return 6; case 't': return 7;
+                default: return -1;
+            }
+        };
+        const size_t grain = (size_t)1 << 20, blocks = (g2 + grain - 1) / grain;
+        std::vector<std::vector<uint64_t>> e_at(blocks);
+        std::vector<std::vector<uint8_t>> e_val(blocks);
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(s.draft.data());
+        uint8_t* dst = st->draft4.data();
+        np::parallel_for(blocks, 1, [&](size_t b0, size_t b1) {
+            for (size_t blk = b0; blk < b1; ++blk)
+                for (size_t j = blk * grain, j1 = std::min(g2, (blk + 1) * grain); j < j1; ++j) {
+                    int a = code(src[2 * j]), c = 2 * j + 1 < G ? code(src[2 * j + 1]) : 0;
+                    if (a < 0) { e_at[blk].push_back(2 * j); e_val[blk].push_back(src[2 * j]); a = 0; }
+                    if (c < 0) { e_at[blk].push_back(2 * j + 1); e_val[blk].push_back(src[2 * j + 1]); c = 0; }
+                    dst[j] = (uint8_t)(a << 4 | c);
+                }
+        });
+        size_t n_esc = 0;
+        for (const auto& v : e_at) n_esc += v.size();
+        if (n_esc * 32 > G) {
+            st->draft4.clear();
+            st->draft4.shrink_to_fit();
+        } else {
+            for (size_t blk = 0; blk < blocks; ++blk) {
+                st->desc_at.insert(st->desc_at.end(), e_at[blk].begin(), e_at[blk].end());
+                st->desc_val.insert(st->desc_val.end(), e_val[blk].begin(), e_val[blk].end());
+            }
+        }
+    }
     // ---- the compact upload form of the per-record fields (np1_priv.h)
     st->compact = np1_stream::Compact();
     static const bool no_compact = getenv("NP1_UPLOAD") && strcmp(getenv("NP1_UPLOAD"), "seq2") == 0;      // NP1_UPLOAD=seq2: 2-bit bases only
@@ -209,7 +248,7 @@ static void stream_facts(np1_stream* st) {
     {
         const bool slim_ok = !full && dense && n > 0;
         const np1_stream::Compact& C = st->compact;
-        uint64_t ub = s.draft.size() + 4 * s.ctg_off.size() + 2 * n + 8 * s.read_begin.size();
+        uint64_t ub = (st->draft4.empty() ? s.draft.size() : st->draft4.size() + 9 * st->desc_at.size()) + 4 * s.ctg_off.size() + 2 * n + 8 * s.read_begin.size();
         if (C.on) ub += 4 * C.plain.size() + n + 4 * C.x_pos.size() + 8 * C.x_lq.size() + 4 * C.x_cigar.size();
         else ub += 4 * n + 4 * n + 4 * s.cigar.size() + (st->ncig16.empty() ? 4 * n : 2 * n);
         ub += st->seq2.empty() ? nb : st->seq2.size() + 9 * st->esc_at.size();
@@ -243,7 +282,15 @@ static int fill_batch(np1_batch* b, const np1_stream* st_, bool sync) {
     int rc = 0;
     static const bool slim = !(getenv("NP1_UPLOAD") && strcmp(getenv("NP1_UPLOAD"), "full") == 0);   // NP1_UPLOAD=full: every array as the host holds it
     const bool rebuild = slim && st->facts == 1 && n > 0;
-    rc |= upload(b->draft, s.draft.data(), s.draft.size(), q);
+    if (!st->draft4.empty()) {
+        const size_t ne = st->desc_at.size();
+        rc |= upload(b->draft4, st->draft4.data(), st->draft4.size(), q);
+        if (ne) { rc |= upload(b->desc_at, st->desc_at.data(), 8 * ne, q); rc |= upload(b->desc_val, st->desc_val.data(), ne, q); }
+        if (b->draft.ensure(s.draft.size() + 16)) return -1;
+        if (rc == 0) launch_unpack_draft4(q, b->draft4.as<uint8_t>(), (uint64_t)s.draft.size(), b->draft.as<uint8_t>(), b->desc_at.as<uint64_t>(), b->desc_val.as<uint8_t>(), (uint64_t)ne);
+    } else {
+        rc |= upload(b->draft, s.draft.data(), s.draft.size(), q);
+    }
     rc |= upload(b->ctg_off, s.ctg_off.data(), 4 * s.ctg_off.size(), q);
     const np1_stream::Compact& C = st->compact;
     const bool compact = rebuild && C.on;
@@ -356,7 +403,8 @@ int np1_stream_pin(np1_stream* st) {
     };
     bool ok = reg(s.draft.data(), s.draft.size()) && reg(s.pos.data(), 4 * s.pos.size()) && reg(s.ctg.data(), 4 * s.ctg.size()) &&
               reg(s.flag.data(), 2 * s.flag.size()) && reg(s.n_cigar.data(), 4 * s.n_cigar.size()) && reg(st->ncig16.data(), 2 * st->ncig16.size()) && reg(st->seq2.data(), st->seq2.size()) &&
-              reg(st->esc_at.data(), 8 * st->esc_at.size()) && reg(st->esc_val.data(), st->esc_val.size()) && reg(st->compact.plain.data(), 4 * st->compact.plain.size()) &&
+              reg(st->esc_at.data(), 8 * st->esc_at.size()) && reg(st->esc_val.data(), st->esc_val.size()) && reg(st->draft4.data(), st->draft4.size()) &&
+              reg(st->desc_at.data(), 8 * st->desc_at.size()) && reg(st->desc_val.data(), st->desc_val.size()) && reg(st->compact.plain.data(), 4 * st->compact.plain.size()) &&
               reg(st->compact.dpos.data(), st->compact.dpos.size()) && reg(st->compact.x_pos.data(), 4 * st->compact.x_pos.size()) &&
               reg(st->compact.x_lq.data(), 4 * st->compact.x_lq.size()) && reg(st->compact.x_ncig.data(), 4 * st->compact.x_ncig.size()) &&
               reg(st->compact.x_cigar.data(), 4 * st->compact.x_cigar.size()) && reg(s.l_qseq.data(), 4 * s.l_qseq.size()) &&
@@ -1162,7 +1210,7 @@ int64_t np1_batch_device_bytes(np1_batch* b) { return b ? (int64_t)b->device_byt
 void np1_stream_unpin(np1_stream* st) {
     if (!st || !st->pinned) return;
     np::ReadStream& s = st->s;
-    const void* ptrs[] = {s.draft.data(), s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), st->ncig16.data(), st->seq2.data(), st->esc_at.data(), st->esc_val.data(), st->compact.plain.data(), st->compact.dpos.data(), st->compact.x_pos.data(),
+    const void* ptrs[] = {s.draft.data(), s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), st->ncig16.data(), st->seq2.data(), st->esc_at.data(), st->esc_val.data(), st->draft4.data(), st->desc_at.data(), st->desc_val.data(), st->compact.plain.data(), st->compact.dpos.data(), st->compact.x_pos.data(),
                           st->compact.x_lq.data(), st->compact.x_ncig.data(), st->compact.x_cigar.data(), s.l_qseq.data(), s.cigar_off.data(),
                           s.seq_off.data(), s.cigar.data(), s.seq.data(), s.mapq.data(), s.isize.data(), s.qual_off.data(), s.qual.data()};
     for (const void* p : ptrs)

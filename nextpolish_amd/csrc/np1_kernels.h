@@ -34,6 +34,8 @@ void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint3
 void launch_widen_u16(hipStream_t st, const uint16_t* src, uint32_t* dst, uint64_t n);
 // the compact upload form of the per-record fields (np1_priv.h: np1_stream::Compact) -> pos, n_cigar, l_qseq and the operation pool;
 // cigoff = the running sums of n_cigar (launch_record_offsets, between the two halves).  work: 3 * (n + 1) + nx + 2 words of 8 bytes.
+// the 4-bit upload form of the draft (np1_priv.h: np1_stream::draft4) -> its characters; exceptions patched with launch_unpack_seq2's kernel
+void launch_unpack_draft4(hipStream_t st, const uint8_t* d4, uint64_t G, uint8_t* draft, const uint64_t* esc_at, const uint8_t* esc_val, uint64_t n_esc);
 struct CompactDev {
     const uint32_t* plain; const int32_t* x_lq; const uint32_t* x_ncig; const uint32_t* x_cigar; const uint8_t* dpos; const int32_t* x_pos;
     uint32_t common_lq; uint64_t n, nx, n_xpos;

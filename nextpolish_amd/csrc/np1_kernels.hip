@@ -1906,6 +1906,21 @@ __global__ __launch_bounds__(256) void k_patch_seq(const uint64_t* __restrict__ 
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) seq[at[i]] = val[i];
 }
+// one lane per byte of draft4 = two characters ("ACGT"[code] | 0x20 when lower)
+__global__ __launch_bounds__(256) void k_unpack_draft4(const uint8_t* __restrict__ d4, uint64_t G, uint8_t* __restrict__ draft) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (2 * j >= G) return;
+    const uint32_t v = d4[j];
+    const uint32_t lut = 0x54474341u;      // 'A' 'C' 'G' 'T'
+    const uint32_t a = ((lut >> (8 * ((v >> 4) & 3u))) & 0xffu) | ((v >> 6) & 1u) << 5;
+    const uint32_t b = ((lut >> (8 * (v & 3u))) & 0xffu) | ((v >> 2) & 1u) << 5;
+    draft[2 * j] = (uint8_t)a;
+    if (2 * j + 1 < G) draft[2 * j + 1] = (uint8_t)b;
+}
+void launch_unpack_draft4(hipStream_t st, const uint8_t* d4, uint64_t G, uint8_t* draft, const uint64_t* esc_at, const uint8_t* esc_val, uint64_t n_esc) {
+    if (G) k_unpack_draft4<<<nblk((G + 1) / 2, 256), 256, 0, st>>>(d4, G, draft);
+    if (n_esc) k_patch_seq<<<nblk(n_esc, 256), 256, 0, st>>>(esc_at, esc_val, n_esc, draft);
+}
 void launch_unpack_seq2(hipStream_t st, const uint8_t* seq2, uint64_t n2, uint8_t* seq, const uint64_t* esc_at, const uint8_t* esc_val, uint64_t n_esc) {
     if (n2) k_unpack_seq2<<<nblk((n2 + 3) / 4, 256), 256, 0, st>>>(seq2, n2, seq);
     if (n_esc) k_patch_seq<<<nblk(n_esc, 256), 256, 0, st>>>(esc_at, esc_val, n_esc, seq);

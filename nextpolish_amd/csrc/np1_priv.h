@@ -40,6 +40,11 @@ struct np1_stream {
         std::vector<int32_t> x_pos;
         uint64_t n_ops = 0;               // operations of all records (size of the rebuilt pool)
     } compact;
+    // the draft as it crosses PCIe: 4 bits per character (2-bit base, lower-case flag); every other character (N, ambiguity letters,
+    // anything else) is an exception (index, character) patched in on the device.  Empty: not made / too many exceptions.
+    std::vector<uint8_t> draft4;
+    std::vector<uint64_t> desc_at;
+    std::vector<uint8_t> desc_val;
     uint64_t upload_bytes = 0;     // what a reload of this stream moves over PCIe (np1_stream_upload_bytes)
 };
 
