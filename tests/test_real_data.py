@@ -131,7 +131,18 @@ def test_long_read_goldens_still_match_compiled_reference(tag, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", SR)
 def test_gpu_dropin_symbols_on_real_bwa_alignments(tag):
-    """config_init -> score_chain / kmer_count per contig exactly like source/lib/nextpolish1.py:181-189,219."""
+    """config_init -> score_chain / kmer_count per contig exactly like source/lib/nextpolish1.py:181-189,219 -- in a worker process of
+    its own, as the reference's caller runs them (nextpolish1.py:148-179 forks its workers before the library is touched).
+    (Known issue, DESIGN.md 12: a full `pytest -m gpu` run, one long-lived process, ended with SIGABRT in 3 of about 9 runs this round;
+    the one crash with a captured stack was inside this test's first drop-in call, when it still ran in that process.  Never seen in
+    30 runs of this file alone or of shorter prefixes of the suite, and host-side ASan runs of the loader on these files are clean.)"""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport test_real_data as t\nt.dropin_symbols_body(%r)\nprint('dropin ok')\n"
+            % (ROOT, HERE, tag))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "dropin ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def dropin_symbols_body(tag):
     g, fa, bam = sr_files(tag)
     L = nat.lib()
     cfg = L.config_init(fa.encode(), bam.encode(), None)
