@@ -15,12 +15,14 @@
 #include <deque>
 #include <map>
 #include <mutex>
+#include <system_error>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/nextpolish1.h"
 #include "np1_priv.h"
+#include "np_threads.h"
 #include "np_bam.h"
 #include "np1_ingest.h"
 
@@ -149,8 +151,10 @@ int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passe
                 }
             }
     };
-    std::vector<std::thread> th;
-    for (size_t i = 1; i < nl; ++i) th.emplace_back(work, i);
+    std::vector<std::thread> th;      // (a lane whose thread the system refuses stays idle: the batches are handed out dynamically)
+    for (size_t i = 1; i < nl; ++i) {
+        try { th.emplace_back(work, i); } catch (const std::system_error&) { break; }
+    }
     work(0);
     for (std::thread& t : th) t.join();
     if (failed) { np1_set_error(err); return -1; }
@@ -199,7 +203,9 @@ int np1_pipe_run(np1_pipe* p, np1_stream* const* streams, int n, const Configure
         }
     };
     std::vector<std::thread> th;
-    for (size_t i = 1; i < p->lanes.size() && (int)i < n; ++i) th.emplace_back(work, std::ref(p->lanes[i]));
+    for (size_t i = 1; i < p->lanes.size() && (int)i < n; ++i) {
+        try { th.emplace_back(work, std::ref(p->lanes[i])); } catch (const std::system_error&) { break; }
+    }
     work(p->lanes[0]);
     for (std::thread& t : th) t.join();
     if (failed) { np1_set_error(err); return -1; }
@@ -385,8 +391,10 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
     };
     std::vector<std::thread> th;
     const unsigned nl = std::min<unsigned>(loader_threads(), (unsigned)std::max(1, n));
-    for (unsigned i = 0; i < nl; ++i) th.emplace_back(loader);
-    for (size_t i = 1; i < p->lanes.size(); ++i) th.emplace_back(lane_work, i);
+    if (np::spawn_helpers(th, nl, loader) == 0) { np1_set_error("cannot start a loader thread (out of threads or mappings)"); return -1; }
+    for (size_t i = 1; i < p->lanes.size(); ++i) {      // lanes take the staged batches as they come: one that cannot start is not missed
+        try { th.emplace_back(lane_work, i); } catch (const std::system_error&) { break; }
+    }
     lane_work(0);
     for (std::thread& t : th) t.join();
     {   // whatever finished out of turn while another thread was emitting
@@ -459,13 +467,13 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
         if (st) (void)np1_stream_pin(st);
         return st;
     };
-    auto stage = [&](int k) -> Item {   // host half of batch k
+    auto stage = [&](int k, size_t li) -> Item {   // host half of batch k, into lane li's staging buffers
         Item it;
         const double t0 = now_ms();
         std::string lr_err;                // the long-read thread's own error string (merged after the join)
-        std::thread lr_thread([&] {
+        auto stage_lr = [&] {
             if (device_ingest_lr) {
-                np1ingest::Staging* sg = p->staging_lr[(size_t)k % L];
+                np1ingest::Staging* sg = p->staging_lr[li];
                 std::string e;
                 const int rc = np1ingest::prepare(src_lr, plan[(size_t)k], sg, &e);
                 if (rc < 0) { lr_err = e; return; }
@@ -473,9 +481,11 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
             }
             it.lr = load_host(k, bam_lr);
             if (!it.lr) lr_err = np1_last_error();
-        });
+        };
+        std::thread lr_thread;
+        try { lr_thread = std::thread(stage_lr); } catch (const std::system_error&) {}
         if (device_ingest) {
-            np1ingest::Staging* sg = p->staging[(size_t)k % L];
+            np1ingest::Staging* sg = p->staging[li];
             std::string e;
             const int rc = np1ingest::prepare(src, plan[(size_t)k], sg, &e);
             if (rc < 0) it.err = e;
@@ -485,7 +495,8 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
             it.sr = load_host(k, bam_sr);
             if (!it.sr) it.err = np1_last_error();
         }
-        lr_thread.join();
+        if (lr_thread.joinable()) lr_thread.join();
+        else stage_lr();          // no thread to be had: one file after the other
         if (it.err.empty()) it.err = lr_err;
         if (timing_on())
             fprintf(stderr, "[np1 phase] batch %d staged on the host in %.1f ms (short reads: %s, long reads: %s)\n", k, now_ms() - t0, it.staging ? "compressed blocks" : "host loader",
@@ -495,14 +506,15 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
     auto drop = [](Item& it) { if (it.sr) np1_stream_free(it.sr); if (it.lr) np1_stream_free(it.lr); it.sr = it.lr = nullptr; };
     std::mutex mu;
     std::condition_variable cv;
-    int next_emit = 0, rc_all = 0;
+    int next_emit = 0, rc_all = 0, next_batch = 0;
     std::string err;
     auto lane_work = [&](size_t li) {
         np1_pipe::Lane& ln = p->lanes[li];
         np1_batch* lrb = p->phase_lr[li];
-        for (int k = (int)li; k < n; k += (int)L) {
-            { std::lock_guard<std::mutex> g(mu); if (rc_all != 0) return; }
-            Item cur = stage(k);
+        for (;;) {      // batches in turn to whichever lane is free (results still leave in batch order)
+            int k;
+            { std::lock_guard<std::mutex> g(mu); if (rc_all != 0 || next_batch >= n) return; k = next_batch++; }
+            Item cur = stage(k, li);
             int rc = 0;
             std::string e;
             std::vector<std::string> nm = plan[(size_t)k];
@@ -551,7 +563,9 @@ int np1_pipe_run_phase_files(np1_pipe* p, const char* fasta, const char* bam_sr,
     };
     {
         std::vector<std::thread> th;
-        for (size_t li = 1; li < L; ++li) th.emplace_back(lane_work, li);
+        for (size_t li = 1; li < L; ++li) {
+            try { th.emplace_back(lane_work, li); } catch (const std::system_error&) { break; }
+        }
         lane_work(0);
         for (std::thread& t : th) t.join();
     }

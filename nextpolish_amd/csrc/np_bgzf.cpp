@@ -1,5 +1,6 @@
 // BGZF reader/writer (SAMv1 §4.1).  See np_bgzf.h for the reference call sites this replaces.
 #include "np_bgzf.h"
+#include "np_threads.h"
 #include "np_crc32.h"
 #include "np_inflate.h"
 
@@ -160,7 +161,7 @@ bool BgzfReader::fill_window(uint64_t coff) {
     } else {
         std::vector<std::thread> th;
         const unsigned n = (unsigned)std::min<size_t>(nt, win_.size());
-        for (unsigned t = 1; t < n; ++t) th.emplace_back(work);
+        spawn_helpers(th, n - 1, work);
         work();
         for (std::thread& t : th) t.join();
     }
@@ -324,7 +325,7 @@ bool BgzfWriter::drain() {
     };
     const unsigned nt = (unsigned)std::min<size_t>(threads_ ? threads_ : io_threads(), pending_.size());
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    if (nt > 1) spawn_helpers(th, nt - 1, work);
     work();
     for (std::thread& t : th) t.join();
     if (!ok) return false;

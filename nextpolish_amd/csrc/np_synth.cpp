@@ -744,7 +744,7 @@ bool write_streams_files(const std::vector<const ReadStream*>& ss, const std::st
                 pix[k] = w.take_part_index();
             }
         };
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+        if (nt > 1) np::spawn_helpers(th, nt - 1, work);
         work();
         for (std::thread& t : th) t.join();
     }
@@ -792,7 +792,7 @@ bool write_streams_files(const std::vector<const ReadStream*>& ss, const std::st
                 std::vector<uint8_t>().swap(part[k]);
             }
         };
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+        if (nt > 1) np::spawn_helpers(th, nt - 1, work);
         work();
         for (std::thread& t : th) t.join();
     }

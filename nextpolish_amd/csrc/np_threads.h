@@ -4,6 +4,7 @@
 #pragma once
 #include <atomic>
 #include <cstdlib>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -17,6 +18,20 @@ inline unsigned host_threads() {
         return hw == 0 ? 1u : (hw < 8u ? hw : 8u);
     }();
     return n;
+}
+
+// Starts up to `extra` helper threads on f.  A thread the system refuses (pthread_create: EAGAIN -- a long-lived process out of
+// mappings or pids) is simply not there: every caller hands its work out dynamically and works itself, so fewer helpers mean less
+// overlap, never less work; an exception escaping here with started threads still joinable would end the process instead.
+template <class F>
+unsigned spawn_helpers(std::vector<std::thread>& th, unsigned extra, F f) {
+    unsigned started = 0;
+    th.reserve(th.size() + extra);
+    for (unsigned t = 0; t < extra; ++t) {
+        try { th.emplace_back(f); } catch (const std::system_error&) { break; }
+        ++started;
+    }
+    return started;
 }
 
 // f(begin, end) over [0, n) in blocks of `grain`, handed out dynamically
@@ -37,8 +52,7 @@ void parallel_for(size_t n, size_t grain, F f) {
         }
     };
     std::vector<std::thread> th;
-    th.reserve(nt - 1);
-    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    spawn_helpers(th, nt - 1, work);
     work();
     for (std::thread& t : th) t.join();
 }
