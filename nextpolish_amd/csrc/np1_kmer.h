@@ -219,9 +219,11 @@ NP1_HD void kc_brim(const uint8_t* code, const uint8_t* flag, int32_t ext, bool 
     *end = *end <= bend - ext ? *end + ext : bend;
     if (!with_ext) return;
     int32_t p = *start + 1;                                       // contig_brim_with_extension
-    while (*start > bstart && (code[p] == code[p - 1] || (flag[p - 1] & KC_FLAG_ZERO) != 0)) { --*start; --p; }
-    p = *end - 1;
-    while (*end < bend && (code[p] == code[p + 1] || (flag[p + 1] & KC_FLAG_ZERO) != 0)) { ++*end; ++p; }
+    // (ext_len_edge = 0 and a region that starts on the last base: the reference reads data[L], contig.c:507-508 -- not here)
+    while (*start > bstart && p <= bend && (code[p] == code[p - 1] || (flag[p - 1] & KC_FLAG_ZERO) != 0)) { --*start; --p; }
+    p = *end - 1;      // (a region that ends at position 0 -- only possible with ext_len_edge = 0 -- makes the reference read data[-1],
+                       // contig.c:512-513: no defined result; no read in front of the array here)
+    while (*end < bend && p >= 0 && (code[p] == code[p + 1] || (flag[p + 1] & KC_FLAG_ZERO) != 0)) { ++*end; ++p; }
 }
 
 // returns the number of int32 values written to out (pairs), or -1 when out_cap is too small
