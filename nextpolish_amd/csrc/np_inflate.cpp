@@ -24,10 +24,19 @@ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3
 const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
-inline uint32_t reverse_bits(uint32_t code, int len) {
-    uint32_t r = 0;
-    for (int i = 0; i < len; ++i) { r = r << 1 | (code & 1); code >>= 1; }
-    return r;
+struct Rev8 {
+    uint8_t t[256];
+    Rev8() {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t r = 0;
+            for (int k = 0; k < 8; ++k) r |= ((i >> k) & 1u) << (7 - k);
+            t[i] = (uint8_t)r;
+        }
+    }
+};
+const Rev8 kRev8;
+inline uint32_t reverse_bits(uint32_t code, int len) {      // len <= 15
+    return (((uint32_t)kRev8.t[code & 0xffu] << 8) | kRev8.t[(code >> 8) & 0xffu]) >> (16 - len);
 }
 
 // canonical Huffman decode table from code lengths.  is_dist selects the symbol meaning.  Returns false for an
@@ -49,7 +58,8 @@ bool build_table(const uint8_t* lens, int n_sym, int table_bits, bool is_dist, u
         next_code[len] = code;
     }
     const uint32_t primary = 1u << table_bits;
-    for (uint32_t i = 0; i < primary; ++i) table[i] = mk(0, K_INVALID, 0, 1);
+    if (left != 0)      // an incomplete code leaves slots no symbol fills (a complete one writes every slot below)
+        for (uint32_t i = 0; i < primary; ++i) table[i] = mk(0, K_INVALID, 0, 1);
     // longest code below every primary slot that heads a second level
     uint8_t sub_max[1 << LIT_BITS];
     memset(sub_max, 0, primary);
@@ -136,6 +146,7 @@ struct Bits {
         buf >>= n;
         cnt -= n;
     }
+    inline void drop_fast(uint32_t n) { buf >>= n; cnt -= n; }      // only right behind a refill, for codes known to fit what it left
     inline uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
 };
 
@@ -228,59 +239,58 @@ bool inflate_raw(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_le
         } else {
             return false;
         }
-        // ---- symbols of a Huffman block.  After a refill the buffer holds >= 56 bits (or all that is left): enough for
-        // three literals (<= 15 bits each), or two literals and a length with its extra bits (<= 20); the distance
-        // (<= 28 bits) gets its own refill.
+        // ---- symbols of a Huffman block.  After a refill the buffer holds >= 56 bits (or all that is left).  BAM payloads are match
+        // dominated (4-bit bases and binned qualities repeat: a match every 5-9 bytes, tests/tools measured 12 M matches in 123 MB of
+        // long-read records), so the loop is laid out around the match: its test comes first, length + distance decode share one
+        // refill whenever the length code is the first token behind it (<= 20 + 28 bits), and short copies are two unconditional
+        // 16-byte moves.
         for (;;) {
             b.refill();
             uint32_t e = lit[b.peek(LIT_BITS)];
-            if (out_end - out >= 272) {   // room for 3 x 2 literals + the longest match + 8 bytes of copy slack
-                // up to three lookups of literals (one or two per slot, <= 15 bits each) on one refill
-                uint32_t kind = (e >> 12) & 15u;
+            uint32_t kind = (e >> 12) & 15u;
+            const bool roomy = out_end - out >= 272;     // room for 2 x 2 literals + the longest match + 16 bytes of copy slack
+            if (roomy && b.cnt >= 56 && (kind == K_LITERAL2 || kind == K_LITERAL)) {   // (cnt: a real refill, not the tail of the input)
+                // up to two lookups of literals (one or two per slot, <= 11 bits each: primary entries) on this refill
+                b.drop_fast(e & 0xffu);
+                out[0] = (uint8_t)(e >> 16);
+                out[1] = (uint8_t)(e >> 24);
+                out += kind == K_LITERAL2 ? 2 : 1;
+                e = lit[b.peek(LIT_BITS)];
+                kind = (e >> 12) & 15u;
                 if (kind == K_LITERAL2 || kind == K_LITERAL) {
-                    b.drop(e & 0xffu);
+                    b.drop_fast(e & 0xffu);
                     out[0] = (uint8_t)(e >> 16);
                     out[1] = (uint8_t)(e >> 24);
                     out += kind == K_LITERAL2 ? 2 : 1;
                     e = lit[b.peek(LIT_BITS)];
                     kind = (e >> 12) & 15u;
-                    if (kind == K_LITERAL2 || kind == K_LITERAL) {
-                        b.drop(e & 0xffu);
-                        out[0] = (uint8_t)(e >> 16);
-                        out[1] = (uint8_t)(e >> 24);
-                        out += kind == K_LITERAL2 ? 2 : 1;
-                        e = lit[b.peek(LIT_BITS)];
-                        kind = (e >> 12) & 15u;
-                        if (kind == K_LITERAL2 || kind == K_LITERAL) {
-                            b.drop(e & 0xffu);
-                            out[0] = (uint8_t)(e >> 16);
-                            out[1] = (uint8_t)(e >> 24);
-                            out += kind == K_LITERAL2 ? 2 : 1;
-                            continue;
-                        }
-                    }
+                    if (kind != K_LENGTH) continue;      // (whatever it is gets a fresh refill)
                 }
             }
-            if (((e >> 12) & 15u) == K_LITERAL2) {   // near the end of the output: one literal at a time
-                if (out_end - out < 2) return false;   // two more literals than the declared size has room for
-                b.drop(e & 0xffu);
-                *out++ = (uint8_t)(e >> 16);
-                *out++ = (uint8_t)(e >> 24);
-                continue;
+            if (kind != K_LENGTH) {
+                if (kind == K_LITERAL2) {   // near the end of the output: literals one slot at a time
+                    if (out_end - out < 2) return false;   // two more literals than the declared size has room for
+                    b.drop(e & 0xffu);
+                    *out++ = (uint8_t)(e >> 16);
+                    *out++ = (uint8_t)(e >> 24);
+                    continue;
+                }
+                if (kind == K_SUB) {
+                    e = lit[(e >> 16) + ((uint32_t)(b.buf >> LIT_BITS) & ((1u << ((e >> 8) & 15u)) - 1u))];
+                    kind = (e >> 12) & 15u;
+                }
+                if (kind == K_LITERAL) {
+                    if (out >= out_end) return false;
+                    b.drop(e & 0xffu);
+                    *out++ = (uint8_t)(e >> 16);
+                    continue;
+                }
+                if (kind == K_END) { b.drop(e & 0xffu); break; }
+                if (kind != K_LENGTH) return false;
             }
-            if (((e >> 12) & 15u) == K_SUB) e = lit[(e >> 16) + ((uint32_t)(b.buf >> LIT_BITS) & ((1u << ((e >> 8) & 15u)) - 1u))];
-            const uint32_t kind = (e >> 12) & 15u;
-            if (kind == K_LITERAL) {
-                if (out >= out_end) return false;
-                b.drop(e & 0xffu);
-                *out++ = (uint8_t)(e >> 16);
-                continue;
-            }
-            if (kind == K_END) { b.drop(e & 0xffu); break; }
-            if (kind != K_LENGTH) return false;
             b.drop(e & 0xffu);
             const uint32_t len = (e >> 16) + b.take((e >> 8) & 15u);
-            b.refill();
+            if (b.cnt < 32) b.refill();                  // distance code + extra bits: <= 28
             uint32_t d = dist[b.peek(DIST_BITS)];
             if (((d >> 12) & 15u) == K_SUB) d = dist[(d >> 16) + ((uint32_t)(b.buf >> DIST_BITS) & ((1u << ((d >> 8) & 15u)) - 1u))];
             if (((d >> 12) & 15u) != K_LENGTH) return false;
@@ -288,7 +298,24 @@ bool inflate_raw(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_le
             const uint32_t off = (d >> 16) + b.take((d >> 8) & 15u);
             if (b.overrun || off > (size_t)(out - dst) || len > (size_t)(out_end - out)) return false;
             const uint8_t* from = out - off;
-            if (off >= 8 && (size_t)(out_end - out) >= (size_t)len + 8) {   // whole words; the slack bytes are overwritten by what follows
+            if (off >= 16 && roomy) {   // whole 16-byte moves; the slack bytes are overwritten by what follows (roomy: 258 + 16 fit)
+                uint8_t* o = out;
+                memcpy(o, from, 16);
+                if (len > 16) {
+                    memcpy(o + 16, from + 16, 16);
+                    if (len > 32) {
+                        const uint8_t* const stop = out + len;
+                        o += 32;
+                        from += 32;
+                        do {
+                            memcpy(o, from, 16);
+                            from += 16;
+                            o += 16;
+                        } while (o < stop);
+                    }
+                }
+                out += len;
+            } else if (off >= 8 && (size_t)(out_end - out) >= (size_t)len + 8) {
                 uint8_t* o = out;
                 const uint8_t* const stop = out + len;
                 do {
