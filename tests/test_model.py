@@ -106,6 +106,23 @@ def test_model_intra_contig_tiling_micro_cases_and_crowded_runs():
     assert got[0] == ob.score_chain(st, 0)
 
 
+def test_model_kmer_count_and_snp_valid_take_two_insertions_at_one_position():
+    """'I P I' / 'I N I' records (tests/fuzzgen.py double_ins): score_chain has no result upstream (test_oracle.py pins the reference's
+    crash) and refuses them by name, but kmercount.c / snpvalid.c only chain inside their regions and do have one -- the region walk
+    of np1_kmer.h gives exactly that (oracle == compiled reference on such files: 198 of 200 live, the other two crash upstream)."""
+    n = 0
+    for seed in range(60):
+        contigs, reads = random_case(seed, double_ins=True)
+        st = nat.Stream.from_reads(contigs, reads)
+        cfg = nat.default_config()
+        cfg.read_tlen = 1500
+        ocfg = ob.default_config(read_tlen=1500)
+        assert mb.kmer_count(st, cfg) == [ob.kmer_count(st, i, ocfg) for i in range(st.n_contigs)], seed
+        assert mb.snp_valid(st, cfg) == [ob.snp_valid(st, i, ocfg) for i in range(st.n_contigs)], seed
+        n += 1
+    assert n == 60
+
+
 # ---- kmer_count bodies (np1_kmer.h) against the oracle ----------------------------------------------------------
 def _lowercase_some(contigs, seed):
     import random

@@ -302,8 +302,8 @@ def test_reference_has_no_result_for_two_insertions_at_one_position(tmp_path):
     context whose predecessor is an insertion column, not the base before them; the chain (contig.c:424-496) then looks that predecessor
     state up in the previous slot, finds none and dereferences NULL.  Pinned on the compiled reference: scorechain dies with SIGSEGV on
     most such inputs -- there is no result to be identical to, which is why the product refuses these records by name (np1_core.h
-    ERR_DOUBLE_INS) instead of inventing one.  (kmercount only chains inside its flagged regions and mostly survives; the product's
-    region walk reports the same records as an inconsistent pileup.)"""
+    ERR_DOUBLE_INS) instead of inventing one.  (kmercount / snpvalid only chain inside their flagged regions and mostly survive; the product's
+    region walk takes these records the same way: tests/test_model.py.)"""
     fa, bam = str(tmp_path / "d.fa"), str(tmp_path / "d.bam")
     died = n = 0
     for seed in range(60):
