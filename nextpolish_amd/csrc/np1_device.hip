@@ -19,6 +19,7 @@
 #include "np1_batch_priv.h"
 #include "np1_replay.h"
 #include "np_threads.h"
+#include "np1_upload.h"
 
 
 using namespace np1k;
@@ -117,133 +118,23 @@ static void stream_facts(np1_stream* st) {
         st->ncig16.resize(n);
         for (size_t i = 0; i < n; ++i) st->ncig16[i] = (uint16_t)s.n_cigar[i];
     }
-    // ---- the 2-bit upload form of the bases
-    st->seq2.clear(); st->esc_at.clear(); st->esc_val.clear();
+    // ---- the upload forms (np1_upload.h)
     static const bool full = getenv("NP1_UPLOAD") && strcmp(getenv("NP1_UPLOAD"), "full") == 0;
     const size_t nb = s.seq.size();
-    if (!full && nb >= 64) {
-        static const std::array<uint8_t, 256> lut = [] {      // byte of seq -> 4 bits of seq2, 0x80: an exception
-            std::array<uint8_t, 256> t{};
-            auto c2 = [](uint32_t nib) -> int { return nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : -1; };
-            for (uint32_t b = 0; b < 256; ++b) {
-                const int h = c2(b >> 4), l = c2(b & 15u);
-                t[b] = (h < 0 || l < 0) ? 0x80 : (uint8_t)(h << 2 | l);
-            }
-            return t;
-        }();
-        const size_t n2 = (nb + 1) / 2;
-        st->seq2.resize(n2);
-        const size_t grain = (size_t)1 << 20;                     // seq2 bytes per block
-        const size_t blocks = (n2 + grain - 1) / grain;
-        std::vector<std::vector<uint64_t>> e_at(blocks);
-        std::vector<std::vector<uint8_t>> e_val(blocks);
-        const uint8_t* src = s.seq.data();
-        uint8_t* dst = st->seq2.data();
-        np::parallel_for(blocks, 1, [&](size_t b0, size_t b1) {
-            for (size_t blk = b0; blk < b1; ++blk) {
-                const size_t j0 = blk * grain, j1 = std::min(n2, j0 + grain);
-                for (size_t j = j0; j < j1; ++j) {
-                    const uint8_t a = lut[src[2 * j]], c = 2 * j + 1 < nb ? lut[src[2 * j + 1]] : 0;
-                    if (a & 0x80) { e_at[blk].push_back(2 * j); e_val[blk].push_back(src[2 * j]); }
-                    if (c & 0x80) { e_at[blk].push_back(2 * j + 1); e_val[blk].push_back(src[2 * j + 1]); }
-                    dst[j] = (uint8_t)((a & 15u) << 4 | (c & 15u));
-                }
-            }
-        });
-        size_t n_esc = 0;
-        for (const auto& v : e_at) n_esc += v.size();
-        if (n_esc * 64 > nb) {                                    // not worth it: the plain array goes up
-            st->seq2.clear();
-            st->seq2.shrink_to_fit();
-        } else {
-            st->esc_at.reserve(n_esc); st->esc_val.reserve(n_esc);
-            for (size_t blk = 0; blk < blocks; ++blk) {
-                st->esc_at.insert(st->esc_at.end(), e_at[blk].begin(), e_at[blk].end());
-                st->esc_val.insert(st->esc_val.end(), e_val[blk].begin(), e_val[blk].end());
-            }
-        }
-    }
-    // ---- the 4-bit upload form of the draft
+    st->seq2.clear(); st->esc_at.clear(); st->esc_val.clear();
+    if (!full && nb >= 64) np1up::build_seq2(s.seq, &st->seq2, &st->esc_at, &st->esc_val);                    // 2 bits per base
     st->draft4.clear(); st->desc_at.clear(); st->desc_val.clear();
-    const size_t G = s.draft.size();
-    if (!full && G >= 4096) {
-        const size_t g2 = (G + 1) / 2;
-        st->draft4.resize(g2);
-        auto code = [](uint8_t ch) -> int {      // 2-bit base | lower << 2, or -1
-            switch (ch) {
-                case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
-                case 'a': return 4; case 'c': return 5; case 'g': return 6; case 't': return 7;
-                default: return -1;
-            }
-        };
-        const size_t grain = (size_t)1 << 20, blocks = (g2 + grain - 1) / grain;
-        std::vector<std::vector<uint64_t>> e_at(blocks);
-        std::vector<std::vector<uint8_t>> e_val(blocks);
-        const uint8_t* src = reinterpret_cast<const uint8_t*>(s.draft.data());
-        uint8_t* dst = st->draft4.data();
-        np::parallel_for(blocks, 1, [&](size_t b0, size_t b1) {
-            for (size_t blk = b0; blk < b1; ++blk)
-                for (size_t j = blk * grain, j1 = std::min(g2, (blk + 1) * grain); j < j1; ++j) {
-                    int a = code(src[2 * j]), c = 2 * j + 1 < G ? code(src[2 * j + 1]) : 0;
-                    if (a < 0) { e_at[blk].push_back(2 * j); e_val[blk].push_back(src[2 * j]); a = 0; }
-                    if (c < 0) { e_at[blk].push_back(2 * j + 1); e_val[blk].push_back(src[2 * j + 1]); c = 0; }
-                    dst[j] = (uint8_t)(a << 4 | c);
-                }
-        });
-        size_t n_esc = 0;
-        for (const auto& v : e_at) n_esc += v.size();
-        if (n_esc * 32 > G) {
-            st->draft4.clear();
-            st->draft4.shrink_to_fit();
-        } else {
-            for (size_t blk = 0; blk < blocks; ++blk) {
-                st->desc_at.insert(st->desc_at.end(), e_at[blk].begin(), e_at[blk].end());
-                st->desc_val.insert(st->desc_val.end(), e_val[blk].begin(), e_val[blk].end());
-            }
-        }
-    }
-    // ---- the compact upload form of the per-record fields (np1_priv.h)
+    if (!full && s.draft.size() >= 4096) np1up::build_draft4(s.draft, &st->draft4, &st->desc_at, &st->desc_val);   // 4 bits per draft character
     st->compact = np1_stream::Compact();
     static const bool no_compact = getenv("NP1_UPLOAD") && strcmp(getenv("NP1_UPLOAD"), "seq2") == 0;      // NP1_UPLOAD=seq2: 2-bit bases only
-    // (small batches: the scans and kernels that undo it cost more than the bytes it saves -- measured on 13 Mb batches, 2.6 M records:
-    // 3650 -> 3300 Mbp/s; NP1_COMPACT_MIN = records from which on it is used)
+    // (small batches: the scans and kernels that undo the compact record form cost more than the bytes it saves -- measured on 13 Mb
+    // batches, 2.6 M records: 3650 -> 3300 Mbp/s; NP1_COMPACT_MIN = records from which on it is used)
     static const size_t compact_min = getenv("NP1_COMPACT_MIN") ? (size_t)atoll(getenv("NP1_COMPACT_MIN")) : ((size_t)1 << 22);
     if (!full && !no_compact && dense && n >= 64 && n >= compact_min) {
-        np1_stream::Compact& C = st->compact;
-        {   // the usual read length: the most frequent one among the first records
-            const size_t m = std::min<size_t>(n, 4096);
-            std::vector<int32_t> sample(s.l_qseq.begin(), s.l_qseq.begin() + m);
-            std::sort(sample.begin(), sample.end());
-            size_t best = 0, run = 0;
-            for (size_t i = 0; i < m; ++i) {
-                run = (i > 0 && sample[i] == sample[i - 1]) ? run + 1 : 1;
-                if (run > best && sample[i] > 0 && sample[i] < (1 << 28)) { best = run; C.common_lq = (uint32_t)sample[i]; }
-            }
-        }
-        C.plain.assign((n + 31) / 32, 0u);
-        C.dpos.resize(n);
-        const uint32_t plain_op = C.common_lq << 4;      // <common_lq>M
-        size_t ct = 0;
-        for (size_t i = 0; i < n; ++i) {
-            const uint32_t k = s.n_cigar[i];
-            const uint32_t* cg = s.cigar.data() + s.cigar_off[i];
-            if (C.common_lq && k == 1 && (uint32_t)s.l_qseq[i] == C.common_lq && cg[0] == plain_op) {
-                C.plain[i >> 5] |= 1u << (i & 31u);
-            } else {
-                C.x_lq.push_back(s.l_qseq[i]);
-                C.x_ncig.push_back(k);
-                C.x_cigar.insert(C.x_cigar.end(), cg, cg + k);
-            }
-            while (ct + 1 < s.read_begin.size() && s.read_begin[ct + 1] <= i) ++ct;
-            const int64_t d = i > 0 ? (int64_t)s.pos[i] - (int64_t)s.pos[i - 1] : -1;
-            if (i == 0 || i == s.read_begin[ct] || d < 0 || d >= 255) { C.dpos[i] = 255; C.x_pos.push_back(s.pos[i]); }
-            else C.dpos[i] = (uint8_t)d;
-        }
-        C.n_ops = s.cigar.size();
+        np1up::build_compact(s, &st->compact);
         const uint64_t as_is = 4 * n + (st->ncig16.empty() ? 4 * n : 2 * n) + 4 * n + 4 * s.cigar.size();
-        const uint64_t packed = 4 * C.plain.size() + n + 4 * C.x_pos.size() + 8 * C.x_lq.size() + 4 * C.x_cigar.size();
-        C.on = packed * 10 < as_is * 9;
-        if (!C.on) st->compact = np1_stream::Compact();
+        st->compact.on = np1up::compact_bytes(st->compact, n) * 10 < as_is * 9;
+        if (!st->compact.on) st->compact = np1_stream::Compact();
     }
     {
         const bool slim_ok = !full && dense && n > 0;

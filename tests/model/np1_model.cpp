@@ -19,6 +19,7 @@
 #include "../../nextpolish_amd/csrc/np1_kmer.h"
 #include "../../nextpolish_amd/csrc/np1_events.h"
 #include "../../nextpolish_amd/csrc/np1_replay.h"
+#include "../../nextpolish_amd/csrc/np1_upload.h"
 
 using namespace np1k;
 
@@ -875,6 +876,58 @@ int np1m_score_chain_tiled(const np1_stream_view* v, const Configure* cfg, uint3
     memcpy(buf, joined.data(), joined.size());
     *out = buf;
     if (tstats) { tstats[0] = n_tiles; tstats[1] = n_redo; tstats[2] = n_rec; }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The upload forms of DESIGN.md section 4 (np1_upload.h): built by the product's own builders, undone by host restatements of the
+// device kernels; what comes back must be the stream's arrays.  The compact record form is built whatever the batch size (the
+// product uses it from 4 M records on).  Returns 0, or the number of the first form that does not round-trip (1 bases, 2 draft,
+// 3 positions, 4 operation counts, 5 read lengths, 6 operations); sizes (optional, 6 words): bytes of the bases as they are / in
+// 2-bit form with exceptions, of the per-record fields as they are / compact, plain records, full positions.
+int np1m_upload_roundtrip(const np1_stream_view* v, uint64_t* sizes) {
+    np::ReadStream s;
+    const size_t n = (size_t)v->n_reads, nc = (size_t)v->n_contigs;
+    s.names.resize(nc);
+    s.ctg_off.assign(v->ctg_off, v->ctg_off + nc + 1);
+    s.read_begin.assign(v->read_begin, v->read_begin + nc + 1);
+    s.draft.assign(v->draft, (size_t)v->draft_len);
+    s.pos.assign(v->pos, v->pos + n);
+    s.n_cigar.assign(v->n_cigar, v->n_cigar + n);
+    s.l_qseq.assign(v->l_qseq, v->l_qseq + n);
+    s.cigar_off.assign(v->cigar_off, v->cigar_off + n);
+    s.cigar.assign(v->cigar, v->cigar + v->cigar_len);
+    s.seq.assign(v->seq, v->seq + v->seq_len);
+    std::vector<uint8_t> seq2, esc_val, draft4, desc_val;
+    std::vector<uint64_t> esc_at, desc_at;
+    uint64_t sz[6] = {s.seq.size(), s.seq.size(), 0, 0, 0, 0};
+    if (np1up::build_seq2(s.seq, &seq2, &esc_at, &esc_val, 1)) {      // (ratio 1: kept however many exceptions there are)
+        std::vector<uint8_t> back;
+        np1up::undo_seq2(seq2, esc_at, esc_val, &back);
+        if (back.size() < s.seq.size() || memcmp(back.data(), s.seq.data(), s.seq.size()) != 0) return 1;
+        sz[1] = seq2.size() + 9 * esc_at.size();
+    }
+    if (np1up::build_draft4(s.draft, &draft4, &desc_at, &desc_val, 1)) {
+        std::string back;
+        np1up::undo_draft4(draft4, s.draft.size(), desc_at, desc_val, &back);
+        if (back != s.draft) return 2;
+    }
+    if (n) {
+        np1_stream::Compact C;
+        np1up::build_compact(s, &C);
+        std::vector<int32_t> pos, lq;
+        std::vector<uint32_t> ncig, cigar;
+        np1up::undo_compact(C, n, &pos, &ncig, &lq, &cigar);
+        if (pos != s.pos) return 3;
+        if (ncig != s.n_cigar) return 4;
+        if (lq != s.l_qseq) return 5;
+        if (cigar != s.cigar) return 6;
+        sz[2] = 12 * n + 4 * s.cigar.size();
+        sz[3] = np1up::compact_bytes(C, n);
+        for (size_t i = 0; i < n; ++i) sz[4] += (C.plain[i >> 5] >> (i & 31u)) & 1u;
+        sz[5] = C.x_pos.size();
+    }
+    if (sizes) memcpy(sizes, sz, sizeof(sz));
     return 0;
 }
 

@@ -70,6 +70,16 @@ def score_chain_tiled(stream, tile_bp, halo_bp, cfg=None, fused=False):
     return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)], dict(tiles=ts[0], recomputed=ts[1], records=ts[2])
 
 
+def upload_roundtrip(stream):
+    """the forms a stream crosses PCIe in (np1_upload.h), built by the product's builders and undone by host restatements of the device
+    kernels; returns dict(seq_bytes, seq2_bytes, fields_bytes, compact_bytes, plain, full_positions) or raises naming the form that differs"""
+    sizes = (C.c_uint64 * 6)()
+    rc = lib().np1m_upload_roundtrip(C.byref(stream.view), sizes)
+    if rc != 0:
+        raise RuntimeError("upload form %d does not round-trip" % rc)
+    return dict(seq_bytes=sizes[0], seq2_bytes=sizes[1], fields_bytes=sizes[2], compact_bytes=sizes[3], plain=sizes[4], full_positions=sizes[5])
+
+
 def kmer_count(stream, cfg):
     """kmer_count through the per-region bodies of np1_kmer.h (stream must carry qualities; cfg.read_tlen set)."""
     out = C.c_void_p()

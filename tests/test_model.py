@@ -123,6 +123,26 @@ def test_model_kmer_count_and_snp_valid_take_two_insertions_at_one_position():
     assert n == 60
 
 
+def test_upload_forms_round_trip():
+    """2-bit bases + exception bytes, 4-bit draft, plain-record bits + one-byte position steps -- the product's builders
+    (np1_upload.h) against host restatements of the kernels that undo them on the device: every array comes back as it was, on
+    PE150-like streams (where the forms pay), on micro-cases full of odd letters, odd lengths, clips and empty contigs, and on
+    records beyond the 16-bit counts"""
+    from fuzzgen import long_record_case, crowded_context_case
+    st = nat.Stream.synth([60000, 9000, 300], depth=30, seed=4)
+    z = mb.upload_roundtrip(st)
+    assert z["seq2_bytes"] * 100 < z["seq_bytes"] * 53 and z["compact_bytes"] * 3 < z["fields_bytes"] * 2 and z["plain"] * 10 > st.n_reads * 4 and z["full_positions"] == 3
+    z = mb.upload_roundtrip(nat.Stream.synth([20000, 700], depth=40, seed=5, weird_rate=0.05, softclip_rate=0.2, read_indel=0.004, draft_lower=0.05))
+    assert z["plain"] > 0
+    for seed in range(150):
+        mb.upload_roundtrip(nat.Stream.from_reads(*random_case(seed)))
+    mb.upload_roundtrip(nat.Stream.from_reads(*long_record_case(3)))
+    mb.upload_roundtrip(nat.Stream.from_reads(*crowded_context_case(11)))      # every nt16 code in the reads: all bytes are exceptions
+    sr, lr = nat.Stream.synth_diploid([30000, 8000], seed=3, sr_holes=1)
+    mb.upload_roundtrip(sr)
+    mb.upload_roundtrip(lr)
+
+
 # ---- kmer_count bodies (np1_kmer.h) against the oracle ----------------------------------------------------------
 def _lowercase_some(contigs, seed):
     import random
