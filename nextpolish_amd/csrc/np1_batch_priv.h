@@ -26,7 +26,9 @@ struct DevBuf {
     int ensure(size_t bytes, double slack = 1.0) {
         if (bytes <= cap && p) return 0;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = (size_t)((double)bytes * slack) + 256;
+        // 64 KiB behind every buffer: kernels that stage with wide loads read a few bytes past the last element (tile staging: up to 15,
+        // chase window: up to 8 KiB), and a buffer that ends a mapping has nothing mapped behind it
+        size_t want = (size_t)((double)bytes * slack) + 65536;
         if (!hip_ok(hipMalloc(&p, want), "hipMalloc")) { p = nullptr; return -1; }
         cap = want;
         return 0;
