@@ -46,6 +46,41 @@ np1_ctx* process_ctx() {
     return g_ctx;
 }
 
+// -debug (trace_polish_open): the list of changed bases the reference builds inside contig_get_contig (source/lib/contig.c:743-797),
+// which every task ends with (scorechain.c:12, kmercount.c:121, snpvalid.c:30, snpphase.c:129).  One walk over the contig's slots in
+// their final state: a dropped base is ('.', draft), an insertion column that survived (base, '.'), a substituted base (base, draft).
+// All four launch sequences leave that state in the batch's slot arrays (slot offsets + chosen base per slot).
+void fill_points(np1_batch* b, const np::ReadStream& s, PolishResult* res) {
+    std::vector<uint32_t> soff;
+    std::vector<uint16_t> sres;
+    if (np1_batch_download_slots(b, 0, &soff, &sres) != 0) die(np1_last_error());
+    const std::string& draft = s.draft;
+    std::vector<PolishPoint> pts;
+    const int32_t L = s.ctg_len[0];
+    static const char tbl[] = "=ACMGRSVTWYHKDBN";
+    for (int32_t i = 0; i < L; ++i) {
+        const uint32_t s0 = soff[i] - soff[0], s1 = soff[i + 1] - soff[0];
+        const char was = (char)toupper((unsigned char)draft[i]);
+        for (uint32_t t = s0; t < s1; ++t) {
+            const int j = (int)(t - s0);
+            const uint32_t base = sres[t] & 0xff;
+            PolishPoint p;
+            p.pos = i;
+            p.index = (int16_t)j;
+            if (base == 3) {
+                if (j == 0) { p.curbase = '.'; p.base = was; pts.push_back(p); }
+            } else {
+                p.curbase = tbl[base & 0xf];
+                if (j != 0) { p.base = '.'; pts.push_back(p); }
+                else if (p.curbase != was) { p.base = was; pts.push_back(p); }
+            }
+        }
+    }
+    res->datalength = (int32_t)pts.size();
+    res->data = (PolishPoint*)calloc(pts.size() ? pts.size() : 1, sizeof(PolishPoint));
+    if (!pts.empty()) memcpy(res->data, pts.data(), pts.size() * sizeof(PolishPoint));
+}
+
 }  // namespace
 
 extern "C" {
@@ -123,38 +158,7 @@ PolishResult* score_chain(const char* tigname, Configure* cfg) {
     res->contig = (char*)calloc(1, (size_t)len + 1);
     if (np1_batch_result_copy(b, 0, res->contig, len + 1) != 0) die(np1_last_error());
     res->length = (int32_t)len;
-    if (cfg->trace_polish_open) {   // -debug: list of changed bases (reference: source/lib/contig.c:743-797)
-        std::vector<uint32_t> soff;
-        std::vector<uint16_t> sres;
-        if (np1_batch_download_slots(b, 0, &soff, &sres) != 0) die(np1_last_error());
-        const std::string& draft = st.s.draft;
-        std::vector<PolishPoint> pts;
-        int32_t L = st.s.ctg_len[0];
-        static const char tbl[] = "=ACMGRSVTWYHKDBN";
-        for (int32_t i = 0; i < L; ++i) {
-            uint32_t s0 = soff[i] - soff[0], s1 = soff[i + 1] - soff[0];
-            for (uint32_t s = s0; s < s1; ++s) {
-                int j = (int)(s - s0);
-                uint32_t base = sres[s] & 0xff;
-                PolishPoint p;
-                p.pos = i;
-                p.index = (int16_t)j;
-                if (base == 3) {
-                    if (j == 0) { p.curbase = '.'; p.base = (char)toupper((unsigned char)draft[i]); pts.push_back(p); }
-                } else {
-                    p.curbase = tbl[base & 0xf];
-                    if (j != 0) { p.base = '.'; pts.push_back(p); }
-                    else if (p.curbase != (char)toupper((unsigned char)draft[i])) {
-                        p.base = (char)toupper((unsigned char)draft[i]);
-                        pts.push_back(p);
-                    }
-                }
-            }
-        }
-        res->datalength = (int32_t)pts.size();
-        res->data = (PolishPoint*)calloc(pts.size() ? pts.size() : 1, sizeof(PolishPoint));
-        if (!pts.empty()) memcpy(res->data, pts.data(), pts.size() * sizeof(PolishPoint));
-    }
+    if (cfg->trace_polish_open) fill_points(b, st.s, res);
     np1_batch_free(b);
     return res;
 }
@@ -179,10 +183,7 @@ static PolishResult* kmer_task(const char* tigname, Configure* cfg, bool snp_val
     res->contig = (char*)calloc(1, (size_t)len + 1);
     if (np1_batch_result_copy(b, 0, res->contig, len + 1) != 0) die(np1_last_error());
     res->length = (int32_t)len;
-    if (cfg->trace_polish_open) {   // the change list is not produced for tasks 2 and 4 yet: an empty list, like a run that changed nothing
-        res->data = (PolishPoint*)calloc(1, sizeof(PolishPoint));
-        res->datalength = 0;
-    }
+    if (cfg->trace_polish_open) fill_points(b, st.s, res);
     np1_batch_free(b);
     return res;
 }
@@ -209,10 +210,7 @@ PolishResult* snp_phase(const char* tigname, Configure* cfg) {
     res->contig = (char*)calloc(1, (size_t)len + 1);
     if (np1_batch_result_copy(b, 0, res->contig, len + 1) != 0) die(np1_last_error());
     res->length = (int32_t)len;
-    if (cfg->trace_polish_open) {   // the change list is not produced for tasks 2-4: an empty list, like a run that changed nothing
-        res->data = (PolishPoint*)calloc(1, sizeof(PolishPoint));
-        res->datalength = 0;
-    }
+    if (cfg->trace_polish_open) fill_points(b, ss.s, res);
     np1_batch_free(l);
     np1_batch_free(b);
     return res;

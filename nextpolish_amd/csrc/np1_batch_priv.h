@@ -10,6 +10,7 @@
 #include "np1_kernels.h"
 #include "np1_priv.h"
 #include "np_bam.h"
+#include "np_devalloc.h"
 
 namespace np1dev {
 
@@ -25,15 +26,16 @@ struct DevBuf {
     size_t cap = 0;
     int ensure(size_t bytes, double slack = 1.0) {
         if (bytes <= cap && p) return 0;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        // 64 KiB behind every buffer: kernels that stage with wide loads read a few bytes past the last element (tile staging: up to 15,
-        // chase window: up to 8 KiB), and a buffer that ends a mapping has nothing mapped behind it
-        size_t want = (size_t)((double)bytes * slack) + 65536;
-        if (!hip_ok(hipMalloc(&p, want), "hipMalloc")) { p = nullptr; return -1; }
+        if (p) { (void)npalloc::dev_free(p); p = nullptr; cap = 0; }
+        // No kernel reads past the bytes it was given (round 4: the wide staging loads and the chase window clamp at the logical end;
+        // NP_EFENCE=1 places every buffer against an unmapped page to prove it, np_devalloc.h).  The 64 KiB behind each buffer are
+        // defence in depth only; under NP_EFENCE there is no slack at all.
+        size_t want = npalloc::efence() ? bytes : (size_t)((double)bytes * slack) + 65536;
+        if (!hip_ok(npalloc::dev_malloc(&p, want), "hipMalloc")) { p = nullptr; return -1; }
         cap = want;
         return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)npalloc::dev_free(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 

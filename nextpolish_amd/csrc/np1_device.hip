@@ -81,8 +81,10 @@ const char* np1_stage_name(int i) {
     return use_staged() ? kStageNamesStaged[i] : kStageNamesFused[i];
 }
 
+// Every uploaded array carries 64 bytes of pad: the kernels stage pools with 16-byte loads from 16-byte aligned addresses, which reach
+// up to 15 bytes past the last element (the pad is part of the allocation, not slack the allocator happens to leave: NP_EFENCE=1)
 static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t st) {
-    if (b.ensure(bytes ? bytes : 4) != 0) return -1;
+    if (b.ensure(bytes + 64) != 0) return -1;
     if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
     return 0;
 }
@@ -213,7 +215,7 @@ static int fill_batch(np1_batch* b, const np1_stream* st_, bool sync) {
         const size_t n2 = st->seq2.size(), ne = st->esc_at.size();
         rc |= upload(b->seq2, st->seq2.data(), n2, q);
         if (ne) { rc |= upload(b->esc_at, st->esc_at.data(), 8 * ne, q); rc |= upload(b->esc_val, st->esc_val.data(), ne, q); }
-        if (b->seq.ensure(2 * n2 + 16)) return -1;
+        if (b->seq.ensure(2 * n2 + 64)) return -1;
         if (rc == 0) launch_unpack_seq2(q, b->seq2.as<uint8_t>(), (uint64_t)n2, b->seq.as<uint8_t>(), b->esc_at.as<uint64_t>(), b->esc_val.as<uint8_t>(), (uint64_t)ne);
     } else {
         rc |= upload(b->seq, s.seq.data(), s.seq.size(), q);

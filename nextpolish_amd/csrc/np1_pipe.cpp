@@ -135,23 +135,31 @@ int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passe
     std::string err;
     std::mutex err_mu;
     const size_t nl = p->lanes.size();
+    // (pass, batch) pairs are handed out through one counter: a lane whose thread the system refuses is simply not there, and the
+    // lanes that did start take its share (round 3 strode the batches by lane index, which left every nl-th batch undone in that case)
+    const size_t nb = p->resident.size();
+    const size_t n_items = nb * (size_t)(passes > 0 ? passes : 0);
+    std::atomic<size_t> next(0);
+    std::vector<std::mutex> busy(nb);                            // (a fast lane can reach batch k of the next pass while a slow one still holds it)
     auto work = [&](size_t lane) {
-        for (int pass = 0; pass < passes && !failed; ++pass)
-            for (size_t k = lane; k < p->resident.size(); k += nl) {
-                np1_batch* b = p->resident[k];
-                np1_batch* w = p->lanes[lane].batch;        // the lane's work buffers (slot arrays, descriptors, DP records ...)
-                np1_batch_swap_work(b, w);
-                const int rc = run_task(b, cfg, task);
-                np1_batch_swap_work(b, w);                           // the batch keeps only its inputs (and its host-side result bounds)
-                if (rc != 0) {
-                    std::lock_guard<std::mutex> g(err_mu);
-                    if (!failed) err = np1_last_error();
-                    failed = true;
-                    return;
-                }
+        for (;;) {
+            const size_t it = next.fetch_add(1);
+            if (it >= n_items || failed) return;
+            np1_batch* b = p->resident[it % nb];
+            std::lock_guard<std::mutex> hold(busy[it % nb]);
+            np1_batch* w = p->lanes[lane].batch;        // the lane's work buffers (slot arrays, descriptors, DP records ...)
+            np1_batch_swap_work(b, w);
+            const int rc = run_task(b, cfg, task);
+            np1_batch_swap_work(b, w);                           // the batch keeps only its inputs (and its host-side result bounds)
+            if (rc != 0) {
+                std::lock_guard<std::mutex> g(err_mu);
+                if (!failed) err = np1_last_error();
+                failed = true;
+                return;
             }
+        }
     };
-    std::vector<std::thread> th;      // (a lane whose thread the system refuses stays idle: the batches are handed out dynamically)
+    std::vector<std::thread> th;
     for (size_t i = 1; i < nl; ++i) {
         try { th.emplace_back(work, i); } catch (const std::system_error&) { break; }
     }

@@ -33,6 +33,7 @@
 #include "np2_poa_dev.h"
 #include "np2_lq.h"
 #include "np_threads.h"
+#include "np_devalloc.h"
 
 namespace np { void bgzf_device_inflate_enable(int device); }   // np_bgzf_dev.hip
 
@@ -52,13 +53,13 @@ struct DevBuf {
     size_t cap = 0;
     bool ensure(size_t bytes) {
         if (bytes <= cap && p) return true;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        const size_t want = bytes + bytes / 4 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+        if (p) { (void)npalloc::dev_free(p); p = nullptr; cap = 0; }
+        const size_t want = npalloc::efence() ? bytes : bytes + bytes / 4 + 256;      // NP_EFENCE=1: the buffer ends where its mapping ends (np_devalloc.h)
+        if (npalloc::dev_malloc(&p, want) != hipSuccess) { p = nullptr; return false; }
         cap = want;
         return true;
     }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) (void)npalloc::dev_free(p); }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 

@@ -14,6 +14,7 @@
 #include "np_inflate_dev.h"
 #include "np_crc_dev.h"
 #include "np_crc32.h"
+#include "np_devalloc.h"
 
 namespace {
 
@@ -46,11 +47,11 @@ struct DevInflater {
 
     bool grow(void** p, size_t* cap, size_t want, bool host) {
         if (want <= *cap) return true;
-        if (*p) { if (host) (void)hipHostFree(*p); else (void)hipFree(*p); }
+        if (*p) { if (host) (void)hipHostFree(*p); else (void)npalloc::dev_free(*p); }
         *p = nullptr;
         *cap = 0;
-        const size_t n = want + want / 4 + (1u << 20);
-        const hipError_t e = host ? hipHostMalloc(p, n, hipHostMallocPortable) : hipMalloc(p, n);
+        const size_t n = (!host && npalloc::efence()) ? want : want + want / 4 + (1u << 20);
+        const hipError_t e = host ? hipHostMalloc(p, n, hipHostMallocPortable) : npalloc::dev_malloc(p, n);
         if (e != hipSuccess) { *p = nullptr; return false; }
         *cap = n;
         return true;
@@ -64,10 +65,10 @@ struct DevInflater {
             !grow(&d_blocks, &cb, sizeof(npdev::BlockDesc) * n + 64, false))
             return false;
         if (cb != c_blocks || !d_status) {       // the status words follow the block table's size
-            if (d_status) (void)hipFree(d_status);
+            if (d_status) (void)npalloc::dev_free(d_status);
             d_status = nullptr;
             c_blocks = 0;                        // (stays 0 if the allocation fails: the next batch allocates again instead of launching on a null pointer)
-            if (hipMalloc(&d_status, cb / sizeof(npdev::BlockDesc) * 4 + 64) != hipSuccess) { d_status = nullptr; return false; }
+            if (npalloc::dev_malloc(&d_status, cb / sizeof(npdev::BlockDesc) * 4 + 64) != hipSuccess) { d_status = nullptr; return false; }
             c_blocks = cb;
         }
         static const bool check_crc = getenv("NP_BGZF_NO_CRC") == nullptr;

@@ -1,0 +1,87 @@
+// Device allocations of both libraries go through here.
+//
+// Default: hipMalloc / hipFree.
+//
+// NP_EFENCE=1 (debugging): every buffer is placed through the HIP virtual-memory API so that its LAST byte (rounded up to 16, the
+// widest vector access the kernels use) is the last mapped byte of its own address reservation, with an unmapped granule behind it.
+// A kernel that reads or writes past the end of a buffer then faults at the first such access, deterministically, instead of
+// touching whatever the allocator happened to place there (how the over-reads behind the round-3 abort were
+// found).  The mode costs one granule (2 MiB) of physical memory per buffer and a few hundred microseconds per allocation.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+
+namespace npalloc {
+
+inline bool efence() {
+    static const bool on = [] { const char* e = getenv("NP_EFENCE"); return e && e[0] && e[0] != '0'; }();
+    return on;
+}
+
+struct FenceRec { void* base; size_t reserved, mapped; hipMemGenericAllocationHandle_t handle; };
+struct FenceTable {
+    std::mutex mu;
+    std::unordered_map<void*, FenceRec> live;
+};
+inline FenceTable& fence_table() { static FenceTable t; return t; }
+
+inline hipError_t dev_malloc(void** p, size_t bytes) {
+    if (!efence()) return hipMalloc(p, bytes);
+    *p = nullptr;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (gran == 0) gran = (size_t)2 << 20;
+    const size_t need = (bytes + 15) & ~(size_t)15;
+    const size_t mapped = ((need ? need : 16) + gran - 1) / gran * gran;
+    FenceRec r{nullptr, mapped + gran, mapped, {}};
+    e = hipMemAddressReserve(&r.base, r.reserved, gran, nullptr, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemCreate(&r.handle, mapped, &prop, 0);
+    if (e != hipSuccess) { (void)hipMemAddressFree(r.base, r.reserved); return e; }
+    e = hipMemMap(r.base, mapped, 0, r.handle, 0);
+    if (e != hipSuccess) { (void)hipMemRelease(r.handle); (void)hipMemAddressFree(r.base, r.reserved); return e; }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess(r.base, mapped, &acc, 1);
+    if (e != hipSuccess) { (void)hipMemUnmap(r.base, mapped); (void)hipMemRelease(r.handle); (void)hipMemAddressFree(r.base, r.reserved); return e; }
+    void* user = static_cast<char*>(r.base) + (mapped - need);
+    {
+        FenceTable& t = fence_table();
+        std::lock_guard<std::mutex> g(t.mu);
+        t.live[user] = r;
+    }
+    *p = user;
+    return hipSuccess;
+}
+
+inline hipError_t dev_free(void* p) {
+    if (!p) return hipSuccess;
+    if (!efence()) return hipFree(p);
+    FenceRec r;
+    {
+        FenceTable& t = fence_table();
+        std::lock_guard<std::mutex> g(t.mu);
+        auto it = t.live.find(p);
+        if (it == t.live.end()) return hipFree(p);      // (allocated before the mode was read: cannot happen, the flag is read once)
+        r = it->second;
+        t.live.erase(it);
+    }
+    (void)hipDeviceSynchronize();                        // hipFree waits for work in flight; so does this
+    (void)hipMemUnmap(r.base, r.mapped);
+    (void)hipMemRelease(r.handle);
+    return hipMemAddressFree(r.base, r.reserved);
+}
+
+}  // namespace npalloc

@@ -16,6 +16,7 @@ import sys
 import pytest
 
 from nextpolish_amd import _native as nat
+from nextpolish_amd import device as npdev
 import oracle_binding as ob
 import model_binding as mb
 import ref2_binding as rb
@@ -131,15 +132,51 @@ def test_long_read_goldens_still_match_compiled_reference(tag, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", SR)
 def test_gpu_dropin_symbols_on_real_bwa_alignments(tag):
-    """config_init -> score_chain / kmer_count per contig exactly like source/lib/nextpolish1.py:181-189,219 -- in a worker process of
-    its own, as the reference's caller runs them (nextpolish1.py:148-179 forks its workers before the library is touched).
-    (Known issue, DESIGN.md 12: a full `pytest -m gpu` run, one long-lived process, ended with SIGABRT in 3 of about 9 runs this round;
-    the one crash with a captured stack was inside this test's first drop-in call, when it still ran in that process.  Never seen in
-    30 runs of this file alone or of shorter prefixes of the suite, and host-side ASan runs of the loader on these files are clean.)"""
+    """config_init -> score_chain / kmer_count per contig exactly like source/lib/nextpolish1.py:181-189,219, IN THIS PROCESS: a
+    long-lived worker calling the drop-in symbols contig after contig is how the reference's caller uses the library.  (Round 3 moved
+    this test into a subprocess after an intermittent SIGABRT of the one-process suite; round 4 found the cause -- DESIGN.md section
+    12 -- and it runs here again.)"""
+    dropin_symbols_body(tag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", SR[:1])
+def test_gpu_dropin_symbols_on_real_bwa_alignments_in_a_worker_process(tag):
+    """The same calls in a worker process of their own, as the reference's caller runs them (nextpolish1.py:148-179 forks its workers
+    before the library is touched)."""
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport test_real_data as t\nt.dropin_symbols_body(%r)\nprint('dropin ok')\n"
             % (ROOT, HERE, tag))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "dropin ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_gpu_soak_alternating_dropin_calls_with_large_batches_in_between():
+    """One process, 200 alternating score_chain / kmer_count drop-in calls (the call pattern of source/lib/nextpolish1.py:181-189,
+    219-224 in a long-lived worker) with a large batch allocated, (130 Mb, 26 M records) run and freed every 50 calls, so that the allocator hands the small
+    buffers of the next calls the address ranges the large ones just left."""
+    g, fa, bam = sr_files("r1.slice")
+    L = nat.lib()
+    cfg = L.config_init(fa.encode(), bam.encode(), None)
+    names = sorted(g["score_chain"])
+    big = nat.Stream.synth([100_000_000, 30_000_000], depth=30, seed=77)
+    ctx = npdev.Context()
+    for k in range(200):
+        n = names[k % len(names)]
+        if k % 2 == 0:
+            r = L.score_chain(n.encode(), cfg)
+            assert digest(C.string_at(r.contents.contig).decode()) == g["score_chain"][n], "call %d score_chain %s" % (k, n)
+        else:
+            r = L.kmer_count(n.encode(), cfg)
+            assert digest(C.string_at(r.contents.contig).decode()) == g["kmer_count"][n], "call %d kmer_count %s" % (k, n)
+        L.polishresult_destory(r)
+        if k % 50 == 49:
+            b = ctx.upload(big)
+            b.score_chain()
+            assert len(b.results()) == 2
+            b.close()
+    ctx.close()
+    L.config_destory(cfg)
 
 
 def dropin_symbols_body(tag):
