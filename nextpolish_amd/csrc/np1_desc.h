@@ -183,67 +183,6 @@ NP1_HD uint32_t desc_symbol(const uint32_t* d, uint32_t g, int32_t jj, Sq sq) {
     return 3u;   // an insertion column this record only passes through (or pads): DEL
 }
 
-// ---- where a record disagrees with the draft (k_tile8) ------------------------------------------------------------------------
-// Most votes repeat the draft: a record adds 1 to the count of the draft's own 3-base context on every slot it covers, and that is
-// all it does -- except around the places where it differs from the draft (a substituted base, a deletion, an insertion) and on the
-// first two slots of its run (whose contexts lack predecessors).  k_tile8 handles the plain stretches of a record with one masked add
-// per 64-slot chunk and evaluates symbols only inside the record's DIRTY HULL, computed here once per record: the slot interval from its
-// first disagreeing vote to two slots behind its last one (a vote at slot m enters the contexts of m, m + 1 and m + 2).  Conservative
-// by construction: anything not proven to agree is inside the hull (deletions, insertions, chained descriptors as a whole).
-// Packed comparison: the read's bases are 4-bit nt16 codes, two per byte, first base in the high nibble (BAM); `dpack` holds the
-// draft's codes (draft_code of the upper-cased letter = the base slot's symbol, slotinfo_base) in the same layout, so eight bases are
-// one XOR of two byte-swapped words.
-NP1_HD uint64_t nib16(const uint8_t* p, uint64_t n) {   // 16 nibbles from nibble index n on, first one in bits 63..60
-    const uint8_t* b = p + (n >> 1);
-    typedef uint64_t __attribute__((aligned(1))) u64u;
-    uint64_t v = __builtin_bswap64(*reinterpret_cast<const u64u*>(b));
-    if (n & 1) v = (v << 4) | (uint64_t)(b[8] >> 4);
-    return v;
-}
-constexpr uint32_t DIRTY_NONE = 0u;   // every vote of the record agrees with the draft
-// Result: bit j = the record has to be evaluated lane by lane in vote chunk (sfirst / VOTE_CH) + j, i.e. a disagreeing vote at slot m
-// marks the chunks of m .. m + 2 (a vote enters the contexts of its own slot and of the next two; chunk c votes on slots
-// 62 c .. 62 c + 61 and reads the two slots before them); bit 31 stands for every chunk from the 31st on.
-template <class So>
-NP1_HD uint32_t desc_dirty_chunks(const uint32_t* d, const uint8_t* seq, const uint8_t* dpack, So so) {
-    const uint32_t sfirst = d[0], slast = d[1], cnt = d[2];
-    if (cnt & DESC_CHAIN) return 0xffffffffu;                                      // more parts than this one: all of it
-    if ((int32_t)(slast - sfirst) < 0) return DIRTY_NONE;                          // votes on nothing
-    const uint32_t c0 = sfirst / VOTE_CH;
-    uint32_t mask = 0;
-    auto mark = [&](uint32_t a, uint32_t b) {       // disagreeing votes on slots a .. b (the part of them inside the record's run)
-        if (a < sfirst) a = sfirst;
-        if (b > slast) b = slast;
-        if (a > b) return;
-        uint32_t lo = a / VOTE_CH - c0, hi = (b + 2) / VOTE_CH - c0;
-        if (lo > 31) lo = 31;
-        if (hi > 31) hi = 31;
-        mask |= (hi >= 31 ? 0xffffffffu : (2u << hi) - 1u) & ~((1u << lo) - 1u);
-    };
-    const uint32_t nseg = cnt & 0xffu, nins = (cnt >> 8) & 0xffu;
-    for (uint32_t k = 0; k < nseg; ++k) {
-        const uint32_t g_lo = d[DESC_SEG0 + 2 * k], w = d[DESC_SEG0 + 2 * k + 1], len = w & 0xffffu, qc = w >> 16;
-        if (!len) continue;
-        if (qc == 0xffffu) { mark(so(g_lo), so(g_lo + len - 1)); continue; }       // a deletion votes DEL on base slots
-        for (uint32_t t = 0; t < len; t += 16) {
-            uint64_t x = nib16(seq, (uint64_t)qc + t) ^ nib16(dpack, (uint64_t)g_lo + t);
-            const uint32_t left = len - t;
-            if (left < 16) x &= ~0ull << (4 * (16 - left));
-            while (x) {                              // every disagreeing base of the group (they are few)
-                const uint32_t i = (uint32_t)__builtin_clzll(x) >> 2;
-                const uint32_t sl = so(g_lo + t + i);
-                mark(sl, sl);
-                x &= ~(0xfull << (60 - 4 * i));
-            }
-        }
-    }
-    for (uint32_t k = 0; k < nins; ++k) {           // bases in insertion columns (the draft's symbol there is DEL)
-        const uint32_t p = d[DESC_INS0 + 2 * k], len = d[DESC_INS0 + 2 * k + 1] & 0xffffu;
-        mark(so(p) + 1, so(p) + len);
-    }
-    return mask;
-}
-
 // k_desc body: descriptor (+ overflow parts) and the vote chunks the record's votes can touch
 // (d = where the record's head descriptor is built: its place in the descriptor array, or a staging slot in LDS that the kernel
 // writes out with coalesced stores afterwards)

@@ -483,9 +483,6 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     } else {
         // ---- stage 3 (fused): record descriptors (+ overflow parts) and the candidate record range of every vote chunk
         if (b->desc.ensure(4 * (size_t)DESC_WORDS * nn)) return -1;
-        static const int tile_kind_desc = getenv("NP1_TILE") ? atoi(getenv("NP1_TILE")) : 3;
-        const bool want_hulls = tile_kind_desc == 8 && !fp_rate;      // k_tile8 reads the records' dirty hulls
-        if (want_hulls && (b->dpack.ensure((size_t)G / 2 + 64) || b->dirty.ensure(4 * nn + 64))) return -1;
         if (b->ovf_desc.cap == 0 && b->ovf_desc.ensure(4 * (size_t)DESC_WORDS * (nn / 64 + 4096))) return -1;
         for (int attempt = 0;; ++attempt) {
             const uint32_t ovf_cap = (uint32_t)std::min<size_t>(b->ovf_desc.cap / (4 * DESC_WORDS), 0x7fffffffu);
@@ -493,10 +490,8 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
             HIPCHK(hipMemsetAsync(b->chunk_last.p, 0, 4 * (size_t)n_chunks, q));
             HIPCHK(hipMemsetAsync(&counters[CNT_OVFDESC], 0, 4, q));
             t0(3);
-            if (want_hulls) launch_dpack(q, b->draft.as<uint8_t>(), (uint32_t)G, b->dpack.as<uint8_t>());
             launch_desc(q, R, n, ctg_off, b->soff.as<uint32_t>(), b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->desc.as<uint32_t>(),
-                        b->ovf_desc.as<uint32_t>(), ovf_cap, b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), counters,
-                        want_hulls ? b->dpack.as<uint8_t>() : nullptr, want_hulls ? b->dirty.as<uint32_t>() : nullptr);
+                        b->ovf_desc.as<uint32_t>(), ovf_cap, b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), counters);
             t1(3);
             HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
             HIPCHK(hipStreamSynchronize(q));
@@ -527,49 +522,19 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
             };
             HIPCHK(hipMemsetAsync(&totals[8], 0, 8 * POOL_SHARDS, q));
             t0(5);
-            static const int tile_kind_env = getenv("NP1_TILE") ? atoi(getenv("NP1_TILE")) : 3;   // 3: per-vote kernel; 5, 6: event kernels
+            // NP1_TILE=3: k_tile3 for every chunk (A/B timing); default: k_tile9, k_tile3 for the chunks it hands back.  The general-rate
+            // fp64 path spills a record for every slot and stays with k_tile3.
+            static const int tile_kind_env = getenv("NP1_TILE") ? atoi(getenv("NP1_TILE")) : 9;
             const int tile_kind = fp_rate ? 3 : tile_kind_env;
-            static const bool phase_timing = getenv("NP1_PHASE_TIMING") != nullptr;            // k_tile6 phase cycles to stderr
             const uint32_t heads_cap5 = (uint32_t)std::min<size_t>(b->heads.cap / 4, 0xfffffff0u);
-            unsigned long long* dbg = nullptr;
-            if (phase_timing && tile_kind == 6) {
-                if (b->dbg.ensure(64)) return -1;
-                dbg = b->dbg.as<unsigned long long>();
-                HIPCHK(hipMemsetAsync(dbg, 0, 64, q));
-            }
             int rc5;
-            if (tile_kind == 6)
-                rc5 = launch_tile6(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
-                                   b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(),
-                                   b->slot_g.as<uint32_t>(), S, b->max_lq, b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(),
-                                   b->pool.as<uint32_t>(), pool_cap, counters, b->heads.as<uint32_t>(), heads_cap5,
-                                   b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes, dbg);
-            else if (tile_kind == 8)
-                rc5 = launch_tile8(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->dirty.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
-                                   b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(), b->slot_g.as<uint32_t>(), S,
-                                   b->max_lq, b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
-                                   b->heads.as<uint32_t>(), heads_cap5, b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes);
-            else if (tile_kind == 7)
-                rc5 = launch_tile7(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(), b->chunk_first.as<uint32_t>(),
+            if (tile_kind == 9)
+                rc5 = launch_tile9(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(), b->chunk_first.as<uint32_t>(),
                                    b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(), b->slot_g.as<uint32_t>(), S, b->max_lq,
                                    b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
                                    b->heads.as<uint32_t>(), heads_cap5, b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes);
-            else if (tile_kind == 5)
-                rc5 = launch_tile5(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(),
-                                   b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(),
-                                   b->slot_g.as<uint32_t>(), S, b->max_lq, b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(),
-                                   b->pool.as<uint32_t>(), pool_cap, counters, b->heads.as<uint32_t>(), heads_cap5,
-                                   b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes);
             else
                 rc5 = tile(0, nullptr, 0, b->redo.as<uint32_t>(), CNT_REDO);
-            if (dbg) {
-                unsigned long long h[8];
-                HIPCHK(hipMemcpyAsync(h, dbg, 64, hipMemcpyDeviceToHost, q));
-                HIPCHK(hipStreamSynchronize(q));
-                const double n = h[7] ? (double)h[7] : 1.0;
-                fprintf(stderr, "[k_tile6 cycles/tile] setup %.0f  records %.0f (clean %.0f, exact %.0f)  sort %.0f  tally %.0f  epilogue %.0f  tiles %llu\n",
-                        h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n, h[7]);
-            }
             if (rc5 != 0) {   // the longest record's bases do not fit the tile's LDS plan: the staged sequence reads them from HBM rows
                 if (fp_rate) { np1_set_error("records are too long for the LDS-staged path, which a general indel_balance_factor_sgs needs"); return -1; }
                 b->force_staged = true;

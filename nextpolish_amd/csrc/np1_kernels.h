@@ -29,7 +29,7 @@ void launch_vote(hipStream_t st, int E, const uint4* meta, const uint8_t* rows, 
                  uint32_t* counters, uint32_t* heads, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, uint32_t* hbm_lists = nullptr);
 void launch_desc(hipStream_t st, const ReadsDev& R, int64_t n_reads, const uint32_t* ctg_off, const uint32_t* soff,
                  const int32_t* qs, const int32_t* qe, uint32_t* desc, uint32_t* ovf_pool, uint32_t ovf_cap,
-                 uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters, const uint8_t* dpack = nullptr, uint32_t* dirty = nullptr);
+                 uint32_t* chunk_first, uint32_t* chunk_last, uint32_t* counters);
 // cigar_off / seq_off / ctg of a dense record stream on the device (cigoff and seqoff get n + 1 entries)
 void launch_widen_u16(hipStream_t st, const uint16_t* src, uint32_t* dst, uint64_t n);
 // the compact upload form of the per-record fields (np1_priv.h: np1_stream::Compact) -> pos, n_cigar, l_qseq and the operation pool;
@@ -47,13 +47,6 @@ void launch_expand_cigars(hipStream_t st, const CompactDev& c, const uint32_t* n
 void launch_unpack_seq2(hipStream_t st, const uint8_t* seq2, uint64_t n2, uint8_t* seq, const uint64_t* esc_at, const uint8_t* esc_val, uint64_t n_esc);   // the 16-bit upload form of the CIGAR operation counts
 void launch_record_offsets(hipStream_t st, const uint32_t* ncig, const int32_t* lq, const uint64_t* read_begin, uint32_t nc, uint64_t n, uint64_t* cigoff,
                            uint64_t* seqoff, uint32_t* ctg, uint64_t* tmp, uint64_t* total);
-// the draft as packed 4-bit codes (the layout of the reads' bases): what k_desc compares the records with for their dirty hulls
-void launch_dpack(hipStream_t st, const uint8_t* draft, uint32_t G, uint8_t* dpack);
-// k_tile8: plain (record, chunk) pairs as one masked add, per-lane evaluation only inside a record's dirty hull (np1_kernels.hip)
-int launch_tile8(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* dirty, const uint32_t* ovf_pool,
-                 const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S,
-                 uint32_t max_lq, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters, uint32_t* heads,
-                 uint32_t heads_cap, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes);
 // default fused kernel (descriptors + packed bases staged through LDS); levels as launch_tile
 int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc,
                  const uint32_t* ovf_pool, const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint32_t* redo_in,
@@ -61,22 +54,12 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
                  uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters,
                  uint32_t* heads, uint32_t heads_cap, uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single,
                  unsigned long long* votes);
-// event form of the fused kernel (default): chunks that overflow its event buffers land in redo_out for k_tile3
-// k_tile7: the per-vote kernel with the per-record bookkeeping on lane masks in scalar registers (np1_kernels.hip)
-int launch_tile7(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool, const uint32_t* chunk_first,
+// k_tile9 (default since round 4, np1_tile9.h): four slots per lane, agreeing records counted per window, the rest deferred and tallied in
+// record order; the vote chunks of a wave that runs out of room land in redo_out for launch_tile3(level 1)
+int launch_tile9(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool, const uint32_t* chunk_first,
                  const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S, uint32_t max_lq,
                  uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters, uint32_t* heads, uint32_t heads_cap,
                  uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes);
-int launch_tile5(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool,
-                 const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info,
-                 const uint32_t* slot_g, uint32_t S, uint32_t max_lq, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool,
-                 uint32_t pool_cap, uint32_t* counters, uint32_t* heads, uint32_t heads_cap, uint32_t* redo_out, uint32_t redo_ci,
-                 uint32_t flag_single, unsigned long long* votes);
-int launch_tile6(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool,
-                 const uint32_t* chunk_first, const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info,
-                 const uint32_t* slot_g, uint32_t S, uint32_t max_lq, uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool,
-                 uint32_t pool_cap, uint32_t* counters, uint32_t* heads, uint32_t heads_cap, uint32_t* redo_out, uint32_t redo_ci,
-                 uint32_t flag_single, unsigned long long* votes, unsigned long long* dbg);
 void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t cnt0, uint32_t n_shards,
                uint32_t heads_region, uint32_t* pool, const uint32_t* slot_rec, uint16_t* slot_res, int K, long long Rfix,
                double min_ratio, uint32_t grid, bool fp = false, double rate = 0.0);   // fp: general-rate path (doubles, whole-contig runs)

@@ -17,7 +17,7 @@
 #include "../../nextpolish_amd/csrc/np1_core.h"
 #include "../../nextpolish_amd/csrc/np1_desc.h"
 #include "../../nextpolish_amd/csrc/np1_kmer.h"
-#include "../../nextpolish_amd/csrc/np1_events.h"
+#include "../../nextpolish_amd/csrc/np1_tile9.h"
 #include "../../nextpolish_amd/csrc/np1_replay.h"
 #include "../../nextpolish_amd/csrc/np1_upload.h"
 
@@ -112,9 +112,6 @@ bool vote_chunk(uint32_t c, const std::vector<uint4>& meta, const std::vector<ui
     return true;
 }
 // fused sequence (k_desc + k_tile3): lanes evaluate record descriptors instead of reading symbol rows
-// k_tile8 emulation (np1m_fused == 4): the records' dirty hulls (np1_desc.h); plain (record, chunk) pairs take the masked-add path
-static const uint32_t* g_dirty = nullptr;
-
 template <int E>
 bool vote_chunk_desc(uint32_t c, const std::vector<uint32_t>& desc, const std::vector<uint32_t>& ovf, const ReadsDev& R, const std::vector<uint32_t>& soff,
                      const std::vector<uint8_t>& slot_info, const std::vector<uint32_t>& slot_g, uint32_t S,
@@ -150,26 +147,6 @@ bool vote_chunk_desc(uint32_t c, const std::vector<uint32_t>& desc, const std::v
     if (r0 != 0xffffffffu)
         for (uint32_t r = r0; r <= r1; ++r) {
             const uint32_t* d = desc.data() + (uint64_t)r * DESC_WORDS;
-            if (g_dirty && !(d[2] & DESC_CHAIN)) {     // what k_tile8 does with a pair whose chunk lies outside the record's dirty hull
-                const int32_t cs = (int32_t)((int64_t)c * VOTE_CH - 2);
-                if ((int32_t)(d[1] - d[0]) < 0) continue;
-                int32_t lo = (int32_t)d[0] - cs, hi = (int32_t)d[1] - cs;
-                lo = lo < 0 ? 0 : lo;
-                hi = hi > 63 ? 63 : hi;
-                if (lo > hi) continue;
-                const uint32_t dw = g_dirty[r];
-                const uint32_t cj = c - d[0] / VOTE_CH;
-                const bool isdirty = ((dw >> (cj < 31u ? cj : 31u)) & 1u) != 0;
-                if (!isdirty) {
-                    for (int l = lo < 2 ? 2 : lo; l <= hi; ++l) {
-                        const bool has1 = l - 1 >= lo, has2 = l - 2 >= lo;
-                        const bool full = (has1 || first[l]) && (has2 || first[l] || first[l - 1]);
-                        if (full) ++vl[l].c0;
-                        else vl[l].tally(has1 ? (d1eff[l] << 4 | dsym[l]) : dsym[l], L.data(), l);
-                    }
-                    continue;
-                }
-            }
             for (int l = 0; l < 64; ++l) sym[l] = 0;   // rsym: kept across the parts of a chained record
             for (;;) {
                 bool cov[64];
@@ -214,116 +191,98 @@ bool vote_chunk_desc(uint32_t c, const std::vector<uint32_t>& desc, const std::v
     }
     return true;
 }
-// event sequence (k_desc + k_tile5): agreeing votes are counted through the coverage, disagreeing ones as events
-struct ModelEvSink {
-    std::vector<std::vector<uint32_t>>* per_slot;   // window-relative
-    uint32_t w0;
-    void event(uint32_t slot, uint32_t ctx) { (*per_slot)[slot - w0].push_back(ctx); }
-};
-
+// k_tile9 (np1m_fused == 2): four slots per lane, agreeing records counted per window, everything else deferred (np1_tile9.h).
+// One call = one wave = T9_CH vote chunks.  Returns false when a bucket or a context list overflows (the device redoes the chunks with k_tile3).
 template <int E>
-bool vote_chunk_events(uint32_t c, const std::vector<uint32_t>& desc, const std::vector<uint32_t>& ovf, const ReadsDev& R,
-                       const uint8_t* seq_padded, const std::vector<uint32_t>& soff, const std::vector<uint8_t>& slot_info,
-                       const std::vector<uint32_t>& slot_g, uint32_t S, const std::vector<uint32_t>& chunk_first,
-                       const std::vector<uint32_t>& chunk_last, std::vector<uint16_t>& slot_res, std::vector<uint32_t>& slot_rec,
-                       std::vector<uint32_t>& pool, std::vector<uint32_t>& heads, uint32_t flag_single) {
-    const int64_t first64 = (int64_t)c * VOTE_CH - 2;
-    const uint32_t w0 = first64 < 0 ? 0u : (uint32_t)first64;
-    const uint32_t wend = std::min<uint64_t>((uint64_t)c * VOTE_CH + VOTE_CH, S);   // exclusive
-    if (w0 >= wend) return true;
-    const uint32_t n = wend - w0;
-    // window arrays
-    std::vector<uint8_t> sinfo(n);
-    std::vector<uint32_t> sg(n);
-    std::vector<uint16_t> k0(n);
-    for (uint32_t k = 0; k < n; ++k) { sinfo[k] = slot_info[w0 + k]; sg[k] = slot_g[w0 + k]; }
-    for (uint32_t k = 0; k < n; ++k) {   // draft context in slot space, restarted at contig starts (contig.c:373-383)
-        uint32_t d0 = sinfo[k] & 0xf, d1 = 0, d2 = 0;
-        if (!(sinfo[k] & SI_FIRST)) {
-            const uint32_t s = w0 + k;
-            d1 = slot_info[s - 1] & 0xf;
-            if (!(slot_info[s - 1] & SI_FIRST)) d2 = slot_info[s - 2] & 0xf;
+bool vote_tile9(uint32_t t, const std::vector<uint32_t>& desc, const std::vector<uint32_t>& ovf, const ReadsDev& R, const uint8_t* seq_padded,
+                const std::vector<uint32_t>& soff, const std::vector<uint8_t>& slot_info, const std::vector<uint32_t>& slot_g, uint32_t S,
+                const std::vector<uint32_t>& chunk_first, const std::vector<uint32_t>& chunk_last, uint32_t n_chunks, std::vector<uint16_t>& slot_res,
+                std::vector<uint32_t>& slot_rec, std::vector<uint32_t>& pool, std::vector<uint32_t>& heads, uint32_t flag_single, uint64_t* n_agree, uint64_t* n_entries,
+                uint64_t* n_general) {
+    const uint32_t tile_s0 = t * T9_SLOTS;
+    T9Win w[64];
+    uint32_t info[64][6];
+    VoteLane<E> vl[64][4];
+    uint32_t basemask[64][4], c_all[64];
+    std::vector<uint32_t> L(4 * (E - 2) * 64);
+    std::vector<std::vector<uint32_t>> bucket(64);
+    uint32_t wave_entries = 0;
+    for (int l = 0; l < 64; ++l) {
+        t9_window(tile_s0, l, S, slot_info.data(), slot_g.data(), &w[l], info[l]);
+        c_all[l] = 0;
+        for (int j = 0; j < 4; ++j) {
+            const int p = j + 2;
+            uint32_t d0 = info[l][p] & 0xf, d1 = info[l][p - 1] & 0xf, d2 = info[l][p - 2] & 0xf;
+            if (info[l][p] & SI_FIRST) { d1 = 0; d2 = 0; }
+            else if (info[l][p - 1] & SI_FIRST) d2 = 0;
+            vl[l][j].init(d2 << 8 | d1 << 4 | d0);
+            basemask[l][j] = 1u << d0;
         }
-        k0[k] = (uint16_t)(d2 << 8 | d1 << 4 | d0);
     }
-    const uint32_t dpk_g0 = sg[0] & ~1u;
-    const uint32_t g_last = sg[n - 1];
-    std::vector<uint8_t> dpk((g_last - dpk_g0) / 2 + 8, 0);
-    for (uint32_t k = 0; k < n; ++k)
-        if (!(sinfo[k] & SI_INSERT)) {
-            const uint32_t i = sg[k] - dpk_g0;
-            dpk[i >> 1] |= (uint8_t)((sinfo[k] & 0xf) << ((~i & 1) << 2));
-        }
-    EvWindow w{w0, n, (uint32_t)std::max<int64_t>(first64 + 2, 0), sinfo.data(), sg.data(), k0.data(), dpk.data(), dpk_g0, soff.data()};
-    std::vector<uint16_t> gins((n + EV_G - 1) / EV_G + 1);
-    for (uint32_t j = 0; j < gins.size(); ++j) gins[j] = (uint16_t)group_ins_mask(sinfo.data(), n, j);
-    const GroupWin gw{gins.data()};
-    std::vector<std::vector<uint32_t>> events(n);
-    std::vector<uint32_t> cover(n, 0);
-    ModelEvSink sink{&events, w0};
-    const uint32_t r0 = chunk_first[c], r1 = chunk_last[c];
+    uint32_t r0 = 0xffffffffu, r1 = 0;
+    for (uint32_t c = t * T9_CH; c < t * T9_CH + T9_CH && c < n_chunks; ++c)
+        if (chunk_first[c] != 0xffffffffu) { r0 = std::min(r0, chunk_first[c]); r1 = std::max(r1, chunk_last[c]); }
     if (r0 != 0xffffffffu)
         for (uint32_t r = r0; r <= r1; ++r) {
             const uint32_t* d = desc.data() + (uint64_t)r * DESC_WORDS;
-            if (d[0] > d[DESC_NEXT + 1]) continue;
-            for (uint32_t k = 0; k < n; ++k) cover[k] += (w0 + k >= d[0] && w0 + k <= d[DESC_NEXT + 1]);
-            if (np1m_fused == 3) record_groups(d, ovf.data(), seq_padded + R.seq_off[r], w, gw, sink);   // k_tile6's item form
-            else record_events<true>(d, ovf.data(), seq_padded + R.seq_off[r], w, sink);
+            for (int l = 0; l < 64; ++l) {
+                uint32_t e = 0;
+                const int k = t9_classify(d, seq_padded + R.seq_off[r], w[l], r, &e);
+                if (k == T9_AGREE) { ++c_all[l]; ++*n_agree; }
+                else if (k == T9_ENTRY) {
+                    if (++wave_entries > T9_DL) return false;     // the wave's deferred list is full: its chunks go to k_tile3
+                    bucket[l].push_back(e);
+                    ++*n_entries;
+                }
+            }
         }
-    // per-slot tally
-    std::vector<uint32_t> L((E - 2) * 64);
-    VoteLane<E> vl[64];
-    uint32_t basemask[64], total[64];
-    bool single[64], valid[64], first[64];
-    uint32_t dsym[64], info[64], sl[64], prev_dsym[64];
-    for (int l = 0; l < 64; ++l) {
-        const int64_t s64 = first64 + l;
-        valid[l] = s64 >= 0 && s64 < (int64_t)S;
-        sl[l] = (uint32_t)s64;
-        info[l] = valid[l] ? slot_info[sl[l]] : 0u;
-        dsym[l] = info[l] & 0xf;
-        first[l] = (info[l] & SI_FIRST) != 0;
-        prev_dsym[l] = (l >= 1) ? (info[l - 1] & 0xf) : 0;
-        basemask[l] = 1u << dsym[l];
-        total[l] = 0;
-        if (!valid[l]) { vl[l].init(0); continue; }
-        const uint32_t k = sl[l] - w0;
-        vl[l].init(k0[k]);
-        for (uint32_t ctx : events[k]) {
-            basemask[l] |= 1u << (ctx & 0xf);
-            if (l >= 2) vl[l].tally(ctx, L.data(), l);
-        }
-        vl[l].c0 += cover[k] - (uint32_t)events[k].size();   // every other covering vote is the draft's own context
-        total[l] = (1u + cover[k]) & 0xffffu;
-    }
     for (int l = 0; l < 64; ++l)
-        if (vl[l].ovf) return false;
-    for (int l = 0; l < 64; ++l) single[l] = __builtin_popcount(basemask[l]) == 1;
-    for (int l = 2; l < 64; ++l) {
-        if (!valid[l]) continue;
-        bool prev_is_single = first[l] || single[l - 1];
-        bool is_head = !single[l] && prev_is_single;
-        bool need_rec = !single[l] || !prev_is_single;
-        uint32_t res = 0xffu;
-        if (single[l]) res = dsym[l] | (((total[l] == 1 ? 1u : 0u) | flag_single) << 8);
-        slot_res[sl[l]] = (uint16_t)res;
-        uint32_t my_off = 0xffffffffu;
-        if (need_rec) {
-            my_off = (uint32_t)pool.size();
-            pool.resize(pool.size() + vl[l].n + REC_FIXED_WORDS, 0xdeadbeefu);
-            uint32_t hdr = (single[l] ? REC_SINGLE : 0u) | ((info[l] & SI_LAST) ? REC_CTG_LAST : 0u) |
-                           (first[l] ? REC_CTG_FIRST : 0u) | (prev_dsym[l] << 4);
-            vl[l].write_record(pool.data() + my_off, sl[l], total[l], hdr, L.data(), l);
+        for (uint32_t e : bucket[l]) {
+            if (e & T9_GENERAL) {
+                const uint32_t r = e & 0x7fffffffu;
+                e = t9_general(desc.data() + (uint64_t)r * DESC_WORDS, ovf.data(), seq_padded + R.seq_off[r], w[l], SoGlobal{soff.data()});
+                ++*n_general;
+            }
+            t9_tally<E>(e, vl[l], basemask[l], L.data(), l);
         }
-        slot_rec[sl[l]] = my_off;
-        if (is_head) heads.push_back(my_off);
-    }
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 4; ++j) {
+            vl[l][j].c0 += c_all[l];
+            if (vl[l][j].ovf) return false;
+        }
+    for (int l = 1; l <= 62; ++l)
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t s = w[l].s0 + (uint32_t)j;
+            if (!w[l].active || s >= S) continue;
+            const uint32_t inf = info[l][j + 2], dsym = inf & 0xf;
+            const bool first = (inf & SI_FIRST) != 0;
+            const bool single = __builtin_popcount(basemask[l][j]) == 1;
+            const bool psingle = j > 0 ? __builtin_popcount(basemask[l][j - 1]) == 1 : __builtin_popcount(basemask[l - 1][3]) == 1;
+            const uint32_t* Lj = L.data() + j * (E - 2) * 64;
+            const uint32_t total = vl[l][j].total(Lj, l);
+            const bool prev_is_single = first || psingle;
+            const bool is_head = !single && prev_is_single;
+            const bool need_rec = !single || !prev_is_single;
+            uint32_t res = 0xffu;
+            if (single) res = dsym | (((total == 1 ? 1u : 0u) | flag_single) << 8);
+            slot_res[s] = (uint16_t)res;
+            uint32_t my_off = 0xffffffffu;
+            if (need_rec) {
+                my_off = (uint32_t)pool.size();
+                pool.resize(pool.size() + vl[l][j].n + REC_FIXED_WORDS, 0xdeadbeefu);
+                const uint32_t hdr = (single ? REC_SINGLE : 0u) | ((inf & SI_LAST) ? REC_CTG_LAST : 0u) | (first ? REC_CTG_FIRST : 0u) | ((info[l][j + 1] & 0xf) << 4);
+                vl[l][j].write_record(pool.data() + my_off, s, total, hdr, Lj, l);
+            }
+            slot_rec[s] = my_off;
+            if (is_head) heads.push_back(my_off);
+        }
     return true;
 }
 }  // namespace
 
 extern "C" {
-int np1m_fused = 0;   // 0: staged sequence (rows in memory), 1: descriptors (k_tile3), 2: events (k_tile5), 3: event groups (k_tile6)
+int np1m_fused = 0;   // 0: staged sequence (rows in memory), 1: descriptors (k_tile3), 2: four slots per lane with deferred entries (k_tile9; k_tile3 for what it hands back)
+unsigned long long np1m_t9_stats[4] = {0, 0, 0, 0};   // last call in mode 2: agreeing (record, window) pairs, deferred entries, index entries among them, waves handed back
 
 
 // Returns 0 on success; *out is malloc'd concatenation of the polished contigs, bounds[n_contigs+1].
@@ -396,45 +355,23 @@ static int score_chain_once(const np1_stream_view* v, const Configure* cfg, char
         if (stats) stats[3] = counters[CNT_OVFDESC];
         std::vector<uint8_t> seq_padded((size_t)v->seq_len + 16, 0);
         if (v->seq_len) memcpy(seq_padded.data(), v->seq, (size_t)v->seq_len);
-        for (uint32_t c = 0; np1m_fused >= 2 && c < n_chunks; ++c) {
-            if (vote_chunk_events<8>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
-            if (vote_chunk_events<64>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
-            if (!vote_chunk_events<160>(c, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) return -3;
-        }
-        std::vector<uint32_t> dirty_v;
-        g_dirty = nullptr;
-        if (np1m_fused == 4) {
-            std::vector<uint8_t> dpack((size_t)G / 2 + 64, 0);
-            for (uint64_t i = 0; 2 * i < G; ++i) {
-                uint32_t a = (uint8_t)v->draft[2 * i], b2 = 2 * i + 1 < G ? (uint8_t)v->draft[2 * i + 1] : (uint32_t)'=';
-                if (a >= 97 && a <= 122) a -= 32;
-                if (b2 >= 97 && b2 <= 122) b2 -= 32;
-                dpack[i] = (uint8_t)(draft_code(a) << 4 | draft_code(b2));
+        std::vector<uint8_t> redo_chunk(n_chunks, np1m_fused == 1 ? 1 : 0);
+        if (np1m_fused == 2) {
+            uint64_t na = 0, ne = 0, ng = 0, nr = 0;
+            for (uint32_t t = 0; t * T9_CH < n_chunks; ++t) {
+                const size_t pool_at = pool.size(), heads_at = heads.size();
+                if (vote_tile9<8>(t, desc, ovf, R, seq_padded.data(), soff, slot_info, slot_g, S, chunk_first, chunk_last, n_chunks, slot_res, slot_rec, pool, heads,
+                                  flag_single, &na, &ne, &ng))
+                    continue;
+                pool.resize(pool_at);          // (the device writes nothing for a wave it hands back)
+                heads.resize(heads_at);
+                ++nr;
+                for (uint32_t c = t * T9_CH; c < t * T9_CH + T9_CH && c < n_chunks; ++c) redo_chunk[c] = 1;
             }
-            dirty_v.assign((size_t)(n ? n : 1), DIRTY_NONE);
-            for (int64_t r = 0; r < n; ++r)
-                dirty_v[(size_t)r] = desc_dirty_chunks(desc.data() + (uint64_t)r * DESC_WORDS, seq_padded.data() + R.seq_off[r], dpack.data(), SoGlobal{soff.data()});
-            g_dirty = dirty_v.data();
-            if (getenv("NP1M_CHECK_DIRTY")) {      // brute force: every disagreeing vote must lie in a marked chunk
-                for (int64_t r = 0; r < n; ++r) {
-                    const uint32_t* d = desc.data() + (uint64_t)r * DESC_WORDS;
-                    if ((d[2] & DESC_CHAIN) || (int32_t)(d[1] - d[0]) < 0) continue;
-                    for (uint32_t sl = d[0]; sl <= d[1]; ++sl) {
-                        const uint32_t gg = slot_g[sl];
-                        const int32_t jj = (slot_info[sl] & SI_INSERT) ? (int32_t)(sl - soff[gg]) - 1 : -1;
-                        const uint32_t sym = desc_symbol(d, gg, jj, SeqBytes{R.seq + R.seq_off[r]});
-                        if (sym == (slot_info[sl] & 0xfu)) continue;
-                        for (uint32_t t = sl; t <= sl + 2; ++t) {
-                            const uint32_t cj = t / VOTE_CH - d[0] / VOTE_CH;
-                            if (!((dirty_v[(size_t)r] >> (cj < 31u ? cj : 31u)) & 1u))
-                                fprintf(stderr, "record %lld slot %u (g %u jj %d) sym %u != dsym %u: chunk of slot %u not marked (mask %08x, sfirst %u slast %u cnt %x)\n",
-                                        (long long)r, sl, gg, jj, sym, slot_info[sl] & 0xfu, t, dirty_v[(size_t)r], d[0], d[1], d[2]);
-                        }
-                    }
-                }
-            }
+            np1m_t9_stats[0] = na; np1m_t9_stats[1] = ne; np1m_t9_stats[2] = ng; np1m_t9_stats[3] = nr;
         }
-        for (uint32_t c = 0; (np1m_fused == 1 || np1m_fused == 4) && c < n_chunks; ++c) {
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            if (!redo_chunk[c]) continue;
             if (vote_chunk_desc<8>(c, desc, ovf, R, soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;
             ++escal;
             if (vote_chunk_desc<64>(c, desc, ovf, R, soff, slot_info, slot_g, S, chunk_first, chunk_last, slot_res, slot_rec, pool, heads, flag_single)) continue;

@@ -35,9 +35,10 @@ def lib():
 
 
 def score_chain(stream, cfg=None, want_stats=False, fused=False):
-    """fused=False: staged launch sequence (symbol rows); fused=True: descriptor-based sequence (k_desc + k_tile3)."""
+    """fused=0: staged launch sequence (symbol rows); 1: descriptor-based sequence (k_desc + k_tile3); 2: k_desc + k_tile9 (np1_tile9.h),
+    k_tile3 for the waves it hands back.  want_stats adds t9 = (agreeing pairs, deferred entries, index entries, waves handed back)."""
     cfg = cfg or nat.default_config()
-    C.c_int.in_dll(lib(), "np1m_fused").value = int(fused)   # 0 staged, 1 descriptors (k_tile3), 2 events (k_tile5)
+    C.c_int.in_dll(lib(), "np1m_fused").value = int(fused)   # 0 staged, 1 k_tile3, 2 k_tile9
     out = C.c_void_p()
     bounds = (C.c_uint32 * (stream.n_contigs + 1))()
     stats = (C.c_uint64 * 4)()
@@ -50,7 +51,8 @@ def score_chain(stream, cfg=None, want_stats=False, fused=False):
     if want_stats:
         return res, dict(slots=stats[0], heads=stats[1], pool_words=stats[2], escalations=stats[3],
                          restarts=C.c_int.in_dll(lib(), "np1m_restarts").value,        # staged restarts (a record beyond the descriptors, > 160 contexts)
-                         deep_chunks=C.c_int.in_dll(lib(), "np1m_deep_chunks").value)   # chunks voted with one list entry per possible context
+                         deep_chunks=C.c_int.in_dll(lib(), "np1m_deep_chunks").value,   # chunks voted with one list entry per possible context
+                         t9=tuple((C.c_ulonglong * 4).in_dll(lib(), "np1m_t9_stats")))
     return res
 
 
