@@ -373,6 +373,10 @@ def phase_leg(device_index, mb, passes, procs, with_ref):
         best = min(times)
         out.update({"value": round(bp / 1e6 / best, 2), "ms_per_pass": round(best * 1e3, 2), "passes": passes,
                     "achieved_whole_pass_gbs": round(alg / best / 1e9, 2),
+                    "roofline": {"bound": "hbm", "kernel": "whole pass (the task's 25 kernels + its host steps; per-kernel times: profiles/r4_snp_phase_kernel_stats_20mb.txt)",
+                                 "achieved": round(alg / best / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / best / 1e9 / HBM_PEAK_GBS, 5),
+                                 "algorithmic_bytes_per_pass": int(alg), "traffic": None,
+                                 "note": "latency- and atomic-bound irregular work (a lane per record, site or region), not a streaming kernel: the fraction says how far"},
                     "config": {"workload": "%.1f Mb diploid draft in %d contigs (0.2 %% heterozygous substitutions, 0.03 %% indel alleles, 0.2 %% draft errors) + 30x PE150 "
                                            "(%d records) + 20x long reads of 8 kb, 4 %% errors (%d records); synthetic, generated in %.1f s"
                                            % (bp / 1e6, n_ctg, sr.n_reads, lr.n_reads, t_gen)}})
@@ -629,8 +633,20 @@ def main():
     t_gen = time.time() - t_gen
     n_reads = sum(s.n_reads for s in streams)
     alg_in = [s.algorithmic_bytes(False) for s in streams]   # records (32 + 4 n_cigar + ceil(l/2)) + draft, per batch
+    # The upload forms (2-bit bases, compact record fields: DESIGN.md section 4) are built ONCE per stream on the host, outside the timed
+    # steps; a stream that is polished once pays for them once.  Timed here and reported next to `value` (upload_forms_build_s,
+    # streamed_single_use) so that the line says what its scope leaves out.
+    L0 = nat.lib()
+    L0.np1_stream_upload_bytes.restype = C.c_uint64
+    L0.np1_stream_upload_bytes.argtypes = [C.c_void_p]
+    t_forms = time.time()
+    with ThreadPoolExecutor(max(1, min(per_rank, len(streams)))) as ex:
+        list(ex.map(lambda s: L0.np1_stream_upload_bytes(s.handle), streams))     # builds the forms (np1_device.hip: stream_facts)
+    t_forms = time.time() - t_forms
+    t_pin = time.time()
     for s in streams:
         s.pin()
+    t_pin = time.time() - t_pin
     pipe = Pipe(local_rank, lanes=args.lanes)
     cfg = nat.default_config()
     L = nat.lib()
@@ -761,6 +777,11 @@ def main():
                        "h2d_gb_per_s_rank0": round(h2d_bytes * args.steps / dt / 1e9, 2), "h2d_bytes_per_draft_bp": round(h2d_bytes / max(1, sum(int(x.ctg_len.sum()) for x in streams)), 2)},
             "resident": {"mbp_s": round(resident_v, 2), "ms_per_pass": round(dt_res / args.resident_passes * 1e3, 3), "passes": args.resident_passes,
                          "what": "the same pass with every batch already resident in HBM (no H2D / D2H inside), %d lanes: what the kernels alone sustain" % args.lanes},
+            "upload_forms": {"build_s": round(t_forms, 3), "pin_s": round(t_pin, 3), "host_threads": max(1, min(per_rank, len(streams))),
+                             "streamed_single_use_mbp_s": round(my_bp / 1e6 / (t_forms + dt / args.steps), 2),
+                             "what": "`value` uploads the records in forms (2-bit bases, compact record fields) that are built once per stream on the host BEFORE the "
+                                     "timed steps (build_s, on host_threads threads; pin_s = page-locking them); streamed_single_use = this rank's draft / (build_s + one "
+                                     "step): the rate of a decoded stream that is polished exactly once.  From files the device-side ingest never builds them (e2e_from_files)"},
             "parity": parity,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic["bytes"] if traffic else None,

@@ -522,19 +522,37 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
             };
             HIPCHK(hipMemsetAsync(&totals[8], 0, 8 * POOL_SHARDS, q));
             t0(5);
-            // NP1_TILE=3: k_tile3 for every chunk (A/B timing); default: k_tile9, k_tile3 for the chunks it hands back.  The general-rate
-            // fp64 path spills a record for every slot and stays with k_tile3.
-            static const int tile_kind_env = getenv("NP1_TILE") ? atoi(getenv("NP1_TILE")) : 9;
+            // Default: k_tile3.  NP1_TILE=9: k_tile9 (np1_tile9.h; round 4: four slots per lane, agreeing records counted per window), k_tile3
+            // for the chunks it hands back -- exact (GPU-tested in a subprocess: tests/test_gpu_score_chain.py) but slower on MI355X as it stands
+            // (DESIGN.md section 7 has its phase clocks).  The general-rate fp64 path spills a record for every slot and stays with k_tile3.
+            static const int tile_kind_env = getenv("NP1_TILE") ? atoi(getenv("NP1_TILE")) : 3;
             const int tile_kind = fp_rate ? 3 : tile_kind_env;
             const uint32_t heads_cap5 = (uint32_t)std::min<size_t>(b->heads.cap / 4, 0xfffffff0u);
+            static const bool t9_phases = getenv("NP1_T9_PHASES") != nullptr;      // k_tile9's phase clocks to stderr
+            unsigned long long* dbg = nullptr;
+            if (t9_phases && tile_kind == 9) {
+                if (b->dbg.ensure(64 * 128)) return -1;
+                dbg = b->dbg.as<unsigned long long>();
+                HIPCHK(hipMemsetAsync(dbg, 0, 64 * 128, q));
+            }
             int rc5;
             if (tile_kind == 9)
                 rc5 = launch_tile9(q, R, b->soff.as<uint32_t>(), b->desc.as<uint32_t>(), b->ovf_desc.as<uint32_t>(), b->chunk_first.as<uint32_t>(),
                                    b->chunk_last.as<uint32_t>(), n_chunks, b->slot_info.as<uint8_t>(), b->slot_g.as<uint32_t>(), S, b->max_lq,
                                    b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
-                                   b->heads.as<uint32_t>(), heads_cap5, b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes);
+                                   b->heads.as<uint32_t>(), heads_cap5, b->redo.as<uint32_t>(), CNT_REDO, flag_single, votes, dbg);
             else
                 rc5 = tile(0, nullptr, 0, b->redo.as<uint32_t>(), CNT_REDO);
+            if (dbg) {
+                unsigned long long hs[64 * 16], h[16] = {0};
+                HIPCHK(hipMemcpyAsync(hs, dbg, sizeof(hs), hipMemcpyDeviceToHost, q));
+                HIPCHK(hipStreamSynchronize(q));
+                for (int sh = 0; sh < 64; ++sh)
+                    for (int k = 0; k < 16; ++k) h[k] += hs[16 * sh + k];
+                const double nw = h[6] ? (double)h[6] : 1.0;
+                fprintf(stderr, "[k_tile9 cycles/wave] setup %.0f  staging %.0f  records %.0f  evaluation %.0f  tally %.0f  epilogue %.0f | waves %llu  steps/wave %.1f  entries/wave %.1f  rounds/wave %.2f  hot lanes/wave %.2f\n",
+                        h[0] / nw, h[1] / nw, h[2] / nw, h[3] / nw, h[4] / nw, h[5] / nw, h[6], h[7] / nw, h[8] / nw, h[9] / nw, h[10] / nw);
+            }
             if (rc5 != 0) {   // the longest record's bases do not fit the tile's LDS plan: the staged sequence reads them from HBM rows
                 if (fp_rate) { np1_set_error("records are too long for the LDS-staged path, which a general indel_balance_factor_sgs needs"); return -1; }
                 b->force_staged = true;

@@ -59,7 +59,7 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
 int launch_tile9(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool, const uint32_t* chunk_first,
                  const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S, uint32_t max_lq,
                  uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters, uint32_t* heads, uint32_t heads_cap,
-                 uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes);
+                 uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes, unsigned long long* dbg = nullptr);
 void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t cnt0, uint32_t n_shards,
                uint32_t heads_region, uint32_t* pool, const uint32_t* slot_rec, uint16_t* slot_res, int K, long long Rfix,
                double min_ratio, uint32_t grid, bool fp = false, double rate = 0.0);   // fp: general-rate path (doubles, whole-contig runs)

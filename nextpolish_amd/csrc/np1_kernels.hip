@@ -596,14 +596,20 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
 // ------------------------------------------------------------------------------------------------
 // k_tile9 (default since round 4; np1_tile9.h has the idea and the per-lane logic, shared with the host model).
 // A workgroup of NW waves stages the descriptors and packed bases of its candidate records like k_tile3 does; every wave owns
-// T9_CH vote chunks (248 slots), four slots per lane.  Record loop: wave-uniform over the staged records; a lane whose window the
-// record covers inside one matched segment compares six codes at once and counts an agreement in a register, every other
-// (record, lane) pair becomes an entry of the wave's deferred list in LDS (appended densely in step order, chained per lane).
-// After the loop of a staging round the index entries of the round are turned into code entries, 64 at a time whoever owns them;
-// after the last round every lane walks its own chain in record order and tallies.  Epilogue as in tile_epilogue, four slots per lane.
-constexpr uint32_t T9_NIL = 0xffffffffu;
+// T9_CH vote chunks (248 slots), four slots per lane.
+//   record loop   wave-uniform over the staged records, the record's fields fetched one record ahead and moved to scalar registers;
+//                 per lane two range checks (does the record cover my window / touch my slots), one range check per segment,
+//                 one 32-bit LDS read of six bases, one compare: agreement -> a register counter; any other touching pair -> an
+//                 entry (record, lane) on the wave's list in LDS, appended densely per step and chained per lane
+//   evaluation    after the loop of a staging round: 64 list entries at a time, whoever owns them -- the owner's window from the
+//                 slot arrays, the record's segment table into registers, the symbol at each covered position (t9_code)
+//   tally         after the last round: lanes with a few entries walk their chains; lanes with many (a draft error under the
+//                 window: every covering record is an entry) are taken by the whole wave, distinct contexts and counts by ballot
+//   epilogue      as tile_epilogue, four slots per lane
+constexpr uint32_t T9_NIL = 0xffffu;
 template <int E>
-__host__ __device__ constexpr uint32_t t9_wave_words() { return 4u * (E - 2) * 64u + 2u * T9_DL + 7u * 64u; }
+__host__ __device__ constexpr uint32_t t9_wave_words() { return 4u * (E - 2) * 64u + 2u * T9_DL; }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 template <int E, int NW>
 __global__ __launch_bounds__(NW * 64) void k_tile9(ReadsDev R, const uint32_t* __restrict__ soff, const uint32_t* __restrict__ desc,
@@ -613,16 +619,26 @@ __global__ __launch_bounds__(NW * 64) void k_tile9(ReadsDev R, const uint32_t* _
                                                    uint16_t* __restrict__ slot_res, uint32_t* __restrict__ slot_rec, uint32_t* __restrict__ pool,
                                                    uint32_t pool_cap, uint32_t* __restrict__ counters, uint32_t* __restrict__ heads, uint32_t heads_cap,
                                                    uint32_t* __restrict__ redo_out, uint32_t redo_ci, uint32_t flag_single,
-                                                   unsigned long long* __restrict__ votes) {
+                                                   unsigned long long* __restrict__ votes, unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t sh_r[4];
     __shared__ uint32_t sh_e[3 * NW + 4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // NP1_T9_PHASES=1: shader-clock cycles per wave and phase (0 setup, 1 staging + barriers, 2 record loop, 3 evaluation, 4 tally,
+    // 5 epilogue; 6 waves, 7 record-loop steps, 8 deferred entries, 9 staging rounds, 10 lanes tallied by the whole wave), kept per wave
+    // in registers and added up once at the end on 64 shards (one counter bumped by every wave costs more than the phases)
+    long long tph = dbg ? clock64() : 0;
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
+    auto phase = [&](int k) {
+        if (dbg) {
+            const long long now = clock64();
+            pc[k] += (unsigned long long)(now - tph);
+            tph = now;
+        }
+    };
     constexpr uint32_t PER_WAVE = t9_wave_words<E>();
     uint32_t* L = lds + (uint32_t)wave * PER_WAVE;                            // context lists: slot j's at L + j * (E - 2) * 64
-    uint2* dl = reinterpret_cast<uint2*>(L + 4 * (E - 2) * 64);               // deferred entries: (entry, next of the same lane)
-    uint32_t* wg = L + 4 * (E - 2) * 64 + 2 * T9_DL;                          // windows of the wave's lanes: g[p] at wg[p * 64 + lane]
-    uint32_t* wim = wg + 6 * 64;                                              //                              insertion-column masks
+    uint2* dl = reinterpret_cast<uint2*>(L + 4 * (E - 2) * 64);               // deferred entries: x = record index, later the evaluated code; y = next of the same lane | owner lane << 16
     uint32_t* dsc = lds + (uint32_t)NW * PER_WAVE;                            // (nb_max + 1) descriptors
     uint32_t* seqst = dsc + (nb_max + 1) * DESC_WORDS;                        // nb_max * seq_w + 8 words of packed bases
     const uint32_t t = blockIdx.x * NW + wave;                                // this wave's tile
@@ -644,13 +660,42 @@ __global__ __launch_bounds__(NW * 64) void k_tile9(ReadsDev R, const uint32_t* _
         sh_r[0] = r0;
         sh_r[1] = r1;
     }
+    // ---- the lane's window: its own four slots with two vector loads, the two slots in front of them from the lane below (lane 0: two
+    // more loads); only windows at the ends of the batch take the slot-by-slot path
     T9Win w;
     uint32_t info[6];
-    t9_window(tile_s0, lane, S, slot_info, slot_g, &w, info);
-    if (!wave_ok) w.active = false;
+    {
+        const int64_t s0l = (int64_t)tile_s0 + 4 * ((int64_t)lane - 1);
+        const bool own_all = wave_ok && lane <= 62 && s0l >= 0 && s0l + 4 <= (int64_t)S;
+        uint32_t iw = 0;
+        uint4 gw = make_uint4(0, 0, 0, 0);
+        if (own_all) {
+            iw = *reinterpret_cast<const uint32_t*>(slot_info + s0l);
+            gw = *reinterpret_cast<const uint4*>(slot_g + s0l);
+        }
+        uint32_t ih = wave_shr1(iw) >> 16, gh0 = wave_shr1(gw.z), gh1 = wave_shr1(gw.w);
+        const bool below_all = wave_shr1((uint32_t)own_all) != 0;
+        const bool halo_direct = lane == 0 && own_all && s0l >= 2;
+        if (halo_direct) {
+            ih = *reinterpret_cast<const uint16_t*>(slot_info + s0l - 2);
+            const uint2 gg = *reinterpret_cast<const uint2*>(slot_g + s0l - 2);
+            gh0 = gg.x; gh1 = gg.y;
+        }
+        const bool fast = own_all && (lane == 0 ? halo_direct : below_all);
+        if (fast) {
+            uint32_t g6[6] = {gh0, gh1, gw.x, gw.y, gw.z, gw.w};
+            info[0] = ih & 0xffu; info[1] = (ih >> 8) & 0xffu;
+            info[2] = iw & 0xffu; info[3] = (iw >> 8) & 0xffu; info[4] = (iw >> 16) & 0xffu; info[5] = iw >> 24;
+            t9_window_from((uint32_t)s0l, true, 63u, info, g6, &w);
+        } else if (wave_ok && lane <= 62) {
+            t9_window(tile_s0, lane, S, slot_info, slot_g, &w, info);
+        } else {
+            uint32_t g6[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int p = 0; p < 6; ++p) wg[p * 64 + lane] = w.g[p];
-    wim[lane] = w.imask;
+            for (int p = 0; p < 6; ++p) info[p] = 0;
+            t9_window_from((uint32_t)s0l, false, 0u, info, g6, &w);
+        }
+    }
     VoteLane<E> vl[4];
     uint32_t basemask[4];
 #pragma unroll
@@ -662,14 +707,19 @@ __global__ __launch_bounds__(NW * 64) void k_tile9(ReadsDev R, const uint32_t* _
         vl[j].init(d2 << 8 | d1 << 4 | d0);
         basemask[j] = 1u << d0;
     }
-    uint32_t c_all = 0, nvotes = 0;
+    const bool act = w.active, act_plain = w.active && w.plain;
+    const uint32_t s0 = w.s0, s0p3 = w.s0 + 3u, ga = w.g[0], D = w.D;
+    uint32_t c_all = 0, nvotes = 0, my_n = 0;
     uint32_t head = T9_NIL, prev = T9_NIL;      // this lane's chain through the deferred list
     uint32_t dl_n = 0;                          // entries appended so far (wave-uniform; beyond T9_DL: overflow, nothing is stored)
     const int64_t cs = (int64_t)tile_s0 - 4, ce = (int64_t)tile_s0 + T9_SLOTS - 1;
     __syncthreads();
+    phase(0);
+    uint32_t n_steps = 0, n_rounds = 0, n_hot = 0;
     const uint32_t r0 = sh_r[0], r1 = sh_r[1];
     if (r0 != 0xffffffffu) {
         for (uint64_t rb = r0; rb <= r1; rb += nb_max) {
+            ++n_rounds;
             const uint32_t nb = (uint32_t)((r1 - rb + 1 < nb_max) ? (r1 - rb + 1) : nb_max);
             {
                 const uint4* dsrc = reinterpret_cast<const uint4*>(desc + rb * DESC_WORDS);
@@ -688,6 +738,7 @@ __global__ __launch_bounds__(NW * 64) void k_tile9(ReadsDev R, const uint32_t* _
             }
             const uint32_t sq0_lo = (uint32_t)sq0;
             __syncthreads();
+            phase(1);
             const uint8_t* seqb = reinterpret_cast<const uint8_t*>(seqst);
             if (wave_ok) {
                 uint32_t a = nb, b = 0;
@@ -707,56 +758,143 @@ __global__ __launch_bounds__(NW * 64) void k_tile9(ReadsDev R, const uint32_t* _
                 }
                 const uint32_t round_start = dl_n < T9_DL ? dl_n : T9_DL;
                 if (a < nb) {
+                    n_steps += b - a + 1;
+                    // d[0..3] (run start, -, flag word, base offset), the first three segments d[4..9] and the end of the whole run d[23] are
+                    // fetched one record ahead (one spare descriptor slot keeps the loads in range)
+                    const uint32_t* dp = dsc + a * DESC_WORDS;
+                    uint4 h = *reinterpret_cast<const uint4*>(dp);
+                    uint4 s01 = *reinterpret_cast<const uint4*>(dp + DESC_SEG0);
+                    uint2 s2 = *reinterpret_cast<const uint2*>(dp + DESC_SEG0 + 4);
+                    uint32_t slw = dp[DESC_NEXT + 1];
                     for (uint32_t i = a; i <= b; ++i) {
-                        const uint32_t* d = dsc + i * DESC_WORDS;
-                        uint32_t entry = 0;
-                        const int kind = t9_classify(d, seqb + (d[3] - sq0_lo), w, i | (uint32_t)lane << 24, &entry);
-                        c_all += kind == T9_AGREE ? 1u : 0u;
-                        const bool isent = kind == T9_ENTRY;
-                        const unsigned long long m = __ballot(isent);
-                        if (m) {
-                            const uint32_t idx = dl_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                            if (isent && idx < T9_DL) {
-                                dl[idx] = make_uint2(entry, T9_NIL);
-                                if (prev != T9_NIL) dl[prev].y = idx; else head = idx;
-                                prev = idx;
+                        const uint32_t* dn = dsc + (i + 1) * DESC_WORDS;
+                        const uint4 hn = *reinterpret_cast<const uint4*>(dn);
+                        const uint4 s01n = *reinterpret_cast<const uint4*>(dn + DESC_SEG0);
+                        const uint2 s2n = *reinterpret_cast<const uint2*>(dn + DESC_SEG0 + 4);
+                        const uint32_t slwn = dn[DESC_NEXT + 1];
+                        const uint32_t sf = rfl(h.x), sl = rfl(slw), cnt = rfl(h.z);
+                        if (sf <= sl) {      // (a record that votes on nothing: filtered, or trimmed away)
+                            // coverage as two range checks: the window is covered iff s0 in [sf + 2, sl - 3]; the own slots are touched iff
+                            // s0 + 3 in [sf, sl + 3]
+                            const uint32_t a2 = sf + 2u;
+                            const bool can_full = sl >= sf + 5u;
+                            const bool cfull = can_full && (s0 - a2) <= (sl - 3u - a2);
+                            const bool crel = (s0p3 - sf) <= (sl + 3u - sf);
+                            // a matched segment holds the window iff (ga - g_lo) < len - 5; the first such segment gives the query index
+                            const uint32_t g0 = rfl(s01.x), w0 = rfl(s01.y), g1 = rfl(s01.z), w1 = rfl(s01.w), g2 = rfl(s2.x), w2 = rfl(s2.y);
+                            const uint32_t nseg = cnt & 0xffu;
+                            const uint32_t l0 = nseg >= 1u ? t9_seg_lim(w0) : 0u, l1 = nseg >= 2u ? t9_seg_lim(w1) : 0u, l2 = nseg >= 3u ? t9_seg_lim(w2) : 0u;
+                            const uint32_t o0 = ga - g0, o1 = ga - g1, o2 = ga - g2;
+                            const bool in0 = o0 < l0, in1 = o1 < l1, in2 = o2 < l2;
+                            uint32_t q = in2 ? (w2 >> 16) + o2 : 0u;
+                            q = in1 ? (w1 >> 16) + o1 : q;
+                            q = in0 ? (w0 >> 16) + o0 : q;
+                            const uint32_t F = t9_fetch8(seqb + (rfl(h.w) - sq0_lo), q);
+                            const bool agree = act_plain && cfull && (in0 || in1 || in2) && !(cnt & DESC_CHAIN) && (F >> 8) == D;
+                            c_all += agree ? 1u : 0u;
+                            const bool isent = act && crel && !agree;
+                            const unsigned long long m = __ballot(isent);
+                            if (m) {
+                                const uint32_t idx = dl_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                                if (isent) {
+                                    ++my_n;
+                                    if (idx < T9_DL) {
+                                        dl[idx] = make_uint2(i, T9_NIL | (uint32_t)lane << 16);
+                                        if (prev != T9_NIL) *reinterpret_cast<uint16_t*>(&dl[prev].y) = (uint16_t)idx; else head = idx;
+                                        prev = idx;
+                                    }
+                                }
+                                dl_n += (uint32_t)__popcll(m);
                             }
-                            dl_n += (uint32_t)__popcll(m);
                         }
+                        h = hn; s01 = s01n; s2 = s2n; slw = slwn;
                     }
                 }
-                // ---- index entries of this round -> code entries, dense over the list (the staged records go away with the round)
+                // ---- this round's entries: (record, lane) -> the record's symbols at the covered positions of the lane's window.
+                // Dense over the list; the owner's window comes from the slot arrays (L2), the record from LDS (gone with the round).
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                phase(2);
                 const uint32_t round_end = dl_n < T9_DL ? dl_n : T9_DL;
                 for (uint32_t x = round_start + lane; x < round_end; x += 64) {
-                    const uint32_t e = dl[x].x;
-                    if (e & T9_GENERAL) {
-                        const uint32_t owner = (e >> 24) & 63u, i = e & 0xffffu;
-                        T9Win wo;
-                        wo.s0 = tile_s0 + 4u * owner - 4u;
-                        wo.imask = wim[owner];
+                    const uint2 e = dl[x];
+                    const uint32_t owner = e.y >> 16, i = e.x;
+                    const int64_t so = (int64_t)tile_s0 + 4 * ((int64_t)owner - 1);
+                    uint32_t g6[6], inf6[6];
+                    if (so >= 2 && so + 4 <= (int64_t)S) {
+                        const uint2 ga2 = *reinterpret_cast<const uint2*>(slot_g + so - 2);
+                        const uint4 gb4 = *reinterpret_cast<const uint4*>(slot_g + so);
+                        const uint32_t ia = *reinterpret_cast<const uint16_t*>(slot_info + so - 2), ib = *reinterpret_cast<const uint32_t*>(slot_info + so);
+                        g6[0] = ga2.x; g6[1] = ga2.y; g6[2] = gb4.x; g6[3] = gb4.y; g6[4] = gb4.z; g6[5] = gb4.w;
+                        inf6[0] = ia & 0xffu; inf6[1] = ia >> 8; inf6[2] = ib & 0xffu; inf6[3] = (ib >> 8) & 0xffu; inf6[4] = (ib >> 16) & 0xffu; inf6[5] = ib >> 24;
+                    } else {
 #pragma unroll
-                        for (int p = 0; p < 6; ++p) wo.g[p] = wg[p * 64 + owner];
-                        const uint32_t* d = dsc + i * DESC_WORDS;
-                        dl[x].x = t9_general(d, ovf_pool, seqb + (d[3] - sq0_lo), wo, SoGlobal{soff});
+                        for (int p = 0; p < 6; ++p) {
+                            const int64_t sp = so - 2 + p;
+                            const bool v = sp >= 0 && sp < (int64_t)S;
+                            g6[p] = v ? slot_g[sp] : 0u;
+                            inf6[p] = v ? slot_info[sp] : 0u;
+                        }
                     }
+                    int32_t jj6[6];
+#pragma unroll
+                    for (int p = 0; p < 6; ++p) {
+                        jj6[p] = -1;
+                        if (inf6[p] & SI_INSERT) jj6[p] = (int32_t)((uint32_t)(so - 2 + p) - soff[g6[p]]) - 1;     // (rare: an insertion column in the window)
+                    }
+                    const uint32_t* d = dsc + i * DESC_WORDS;
+                    dl[x].x = t9_code(d, ovf_pool, seqb + (d[3] - sq0_lo), (uint32_t)so, g6, jj6);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                phase(3);
             }
             __syncthreads();
         }
     }
+    phase(1);
+    // ---- tally, in record order per slot
     const bool dl_ovf = dl_n > T9_DL;
-    if (!dl_ovf) {     // every lane tallies its own entries, in the order they were appended = record order
-        uint32_t x = head;
+    const bool hot = my_n > T9_HOT;
+    if (!dl_ovf) {
+        uint32_t x = hot ? T9_NIL : head;          // a lane with a few entries walks its own chain
         while (x != T9_NIL) {
             const uint2 e = dl[x];
             nvotes += t9_tally<E>(e.x, vl, basemask, L, lane);
-            x = e.y;
+            x = e.y & 0xffffu;
+        }
+        unsigned long long hm = __ballot(hot && act);
+        while (hm) {                               // a lane with many: the whole wave, 64 list entries at a time
+            const int hl = __builtin_ctzll(hm);
+            hm &= hm - 1ull;
+            ++n_hot;
+            for (uint32_t base = 0; base < dl_n; base += 64) {
+                const uint32_t x2 = base + lane;
+                uint2 e = make_uint2(0u, 0xffffffffu);
+                if (x2 < dl_n) e = dl[x2];
+                const bool sel = (e.y >> 16) == (uint32_t)hl;
+                if (__ballot(sel) == 0ull) continue;
+                const uint32_t lo = (e.x >> 24) & 7u, hi = (e.x >> 27) & 7u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t p = (uint32_t)j + 2u;
+                    const bool on = sel && p >= lo && p <= hi;
+                    const uint32_t k = (e.x >> (20 - 4 * p)) & 0xfffu;
+                    unsigned long long rem = __ballot(on);
+                    while (rem) {                  // distinct contexts of this slot in list order = first-seen order, with their counts
+                        const int ld = __builtin_ctzll(rem);
+                        const uint32_t kL = (uint32_t)__builtin_amdgcn_readlane((int)k, ld);
+                        const unsigned long long mm = __ballot(on && k == kL);
+                        rem &= ~mm;
+                        const uint32_t cnt = (uint32_t)__popcll(mm);
+                        t9_tally_ctx<E>(kL, cnt, lane == hl, vl[j], basemask[j], L + j * (E - 2) * 64, lane);
+                        nvotes += lane == hl ? cnt : 0u;
+                    }
+                }
+            }
         }
     }
+    phase(4);
     bool lane_ovf = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { vl[j].c0 += c_all; lane_ovf = lane_ovf || vl[j].ovf; }
@@ -774,7 +912,8 @@ __global__ __launch_bounds__(NW * 64) void k_tile9(ReadsDev R, const uint32_t* _
         } else atomicOr(&counters[CNT_ERR], ERR_CTX_OVERFLOW);
     }
     bool single[4], is_head[4], need_rec[4];
-    uint32_t total[4], words[4];
+    uint32_t total[4], words[4], res4[4], off4[4];
+    const bool own4 = live && lane >= 1 && lane <= 62 && w.active && (uint64_t)w.s0 + 4 <= (uint64_t)S;     // all four slots: one store each for slot_res / slot_rec
     uint32_t lane_words = 0, lane_heads = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) single[j] = __popc(basemask[j]) == 1;
@@ -788,15 +927,14 @@ __global__ __launch_bounds__(NW * 64) void k_tile9(ReadsDev R, const uint32_t* _
         is_head[j] = own && !single[j] && prev_is_single;
         need_rec[j] = own && (!single[j] || !prev_is_single);
         total[j] = vl[j].total(L + j * (E - 2) * 64, lane);
-        if (own) {
-            uint32_t res = 0xffu;
-            if (single[j]) res = (info[j + 2] & 0xfu) | (((total[j] == 1 ? 1u : 0u) | flag_single) << 8);
-            slot_res[s] = (uint16_t)res;
-        }
+        res4[j] = 0xffu;
+        if (single[j]) res4[j] = (info[j + 2] & 0xfu) | (((total[j] == 1 ? 1u : 0u) | flag_single) << 8);
+        if (own && !own4) slot_res[s] = (uint16_t)res4[j];
         words[j] = need_rec[j] ? vl[j].n + REC_FIXED_WORDS : 0u;
         lane_words += words[j];
         lane_heads += is_head[j] ? 1u : 0u;
     }
+    if (own4) *reinterpret_cast<uint2*>(slot_res + w.s0) = make_uint2(res4[0] | res4[1] << 16, res4[2] | res4[3] << 16);
     uint32_t incl = lane_heads << 16 | lane_words;       // (a wave's records are a few thousand words at most)
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = __shfl_up(incl, o);
@@ -843,9 +981,22 @@ __global__ __launch_bounds__(NW * 64) void k_tile9(ReadsDev R, const uint32_t* _
             vl[j].write_record(pool + my_off, s, total[j], hdr, L + j * (E - 2) * 64, lane);
         }
         woff += words[j];
-        if (own) slot_rec[s] = my_off;
+        off4[j] = my_off;
+        if (own && !own4) slot_rec[s] = my_off;
         if (is_head[j] && fits) heads[hoff] = my_off;
         hoff += is_head[j] ? 1u : 0u;
+    }
+    if (own4) *reinterpret_cast<uint4*>(slot_rec + w.s0) = make_uint4(off4[0], off4[1], off4[2], off4[3]);
+    phase(5);
+    if (dbg && lane == 0) {
+        unsigned long long* sh = dbg + 16 * ((blockIdx.x * NW + wave) & 63u);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&sh[k], pc[k]);
+        atomicAdd(&sh[6], 1ull);
+        atomicAdd(&sh[7], (unsigned long long)n_steps);
+        atomicAdd(&sh[8], (unsigned long long)dl_n);
+        atomicAdd(&sh[9], (unsigned long long)n_rounds);
+        atomicAdd(&sh[10], (unsigned long long)n_hot);
     }
 }
 
@@ -1252,7 +1403,7 @@ int launch_tile3(hipStream_t st, int level, const ReadsDev& R, const uint32_t* s
 int launch_tile9(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const uint32_t* desc, const uint32_t* ovf_pool, const uint32_t* chunk_first,
                  const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S, uint32_t max_lq,
                  uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters, uint32_t* heads, uint32_t heads_cap,
-                 uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes) {
+                 uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes, unsigned long long* dbg) {
     constexpr int E9 = 6, NW9 = 4;      // (a slot with more than six contexts sends its wave's chunks to k_tile3<64>)
     const uint32_t seq_w = (((max_lq + 1) >> 1) + 3) / 4 + 1;   // packed bases per record, in words (upper bound)
     const uint32_t fixed = (uint32_t)NW9 * t9_wave_words<E9>() + 8u + (uint32_t)DESC_WORDS;
@@ -1272,7 +1423,7 @@ int launch_tile9(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const 
         attr_set = true;
     }
     k_tile9<E9, NW9><<<items, NW9 * 64, bytes, st>>>(R, soff, desc, ovf_pool, chunk_first, chunk_last, n_chunks, slot_info, slot_g, S, seq_w, nb_max, slot_res, slot_rec,
-                                                      pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci, flag_single, votes);
+                                                      pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci, flag_single, votes, dbg);
     return 0;
 }
 

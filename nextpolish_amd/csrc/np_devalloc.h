@@ -81,7 +81,10 @@ inline hipError_t dev_free(void* p) {
     (void)hipDeviceSynchronize();                        // hipFree waits for work in flight; so does this
     (void)hipMemUnmap(r.base, r.mapped);
     (void)hipMemRelease(r.handle);
-    return hipMemAddressFree(r.base, r.reserved);
+    // The address range is NOT handed back: a range that is reserved and mapped again showed stale contents on this runtime (ROCm 7.2:
+    // tests/tools/efence_probe.hip, third reuse of one range: 43 % of a buffer wrong after a fill kernel + hipMemsetAsync), and a debugging
+    // mode can afford to leak address space (47 bits of it) -- a freed buffer's range also stays unmapped, so a use after free faults too.
+    return hipSuccess;
 }
 
 }  // namespace npalloc

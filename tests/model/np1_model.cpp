@@ -192,24 +192,28 @@ bool vote_chunk_desc(uint32_t c, const std::vector<uint32_t>& desc, const std::v
     return true;
 }
 // k_tile9 (np1m_fused == 2): four slots per lane, agreeing records counted per window, everything else deferred (np1_tile9.h).
-// One call = one wave = T9_CH vote chunks.  Returns false when a bucket or a context list overflows (the device redoes the chunks with k_tile3).
+// One call = one wave = T9_CH vote chunks, in the kernel's own order of events: record loop -> the wave's dense list of deferred
+// (record, lane) pairs -> evaluation -> tally (a lane's own chain, or, for a lane with many entries, the list in batches of 64 with
+// distinct contexts and counts per batch).  Returns false when the list or a context list overflows (the device redoes the chunks with k_tile3).
 template <int E>
 bool vote_tile9(uint32_t t, const std::vector<uint32_t>& desc, const std::vector<uint32_t>& ovf, const ReadsDev& R, const uint8_t* seq_padded,
                 const std::vector<uint32_t>& soff, const std::vector<uint8_t>& slot_info, const std::vector<uint32_t>& slot_g, uint32_t S,
                 const std::vector<uint32_t>& chunk_first, const std::vector<uint32_t>& chunk_last, uint32_t n_chunks, std::vector<uint16_t>& slot_res,
                 std::vector<uint32_t>& slot_rec, std::vector<uint32_t>& pool, std::vector<uint32_t>& heads, uint32_t flag_single, uint64_t* n_agree, uint64_t* n_entries,
-                uint64_t* n_general) {
+                uint64_t* n_hot) {
     const uint32_t tile_s0 = t * T9_SLOTS;
     T9Win w[64];
     uint32_t info[64][6];
+    int32_t jj[64][6];
     VoteLane<E> vl[64][4];
-    uint32_t basemask[64][4], c_all[64];
+    uint32_t basemask[64][4], c_all[64], my_n[64];
     std::vector<uint32_t> L(4 * (E - 2) * 64);
-    std::vector<std::vector<uint32_t>> bucket(64);
-    uint32_t wave_entries = 0;
+    struct Ent { uint32_t x; int owner; };
+    std::vector<Ent> dl;
     for (int l = 0; l < 64; ++l) {
         t9_window(tile_s0, l, S, slot_info.data(), slot_g.data(), &w[l], info[l]);
-        c_all[l] = 0;
+        c_all[l] = my_n[l] = 0;
+        for (int p = 0; p < 6; ++p) jj[l][p] = ((w[l].imask >> p) & 1u) ? (int32_t)(w[l].s0 - 2u + (uint32_t)p - soff[w[l].g[p]]) - 1 : -1;
         for (int j = 0; j < 4; ++j) {
             const int p = j + 2;
             uint32_t d0 = info[l][p] & 0xf, d1 = info[l][p - 1] & 0xf, d2 = info[l][p - 2] & 0xf;
@@ -224,27 +228,49 @@ bool vote_tile9(uint32_t t, const std::vector<uint32_t>& desc, const std::vector
         if (chunk_first[c] != 0xffffffffu) { r0 = std::min(r0, chunk_first[c]); r1 = std::max(r1, chunk_last[c]); }
     if (r0 != 0xffffffffu)
         for (uint32_t r = r0; r <= r1; ++r) {
-            const uint32_t* d = desc.data() + (uint64_t)r * DESC_WORDS;
+            const T9Rec rec = t9_rec(desc.data() + (uint64_t)r * DESC_WORDS);
             for (int l = 0; l < 64; ++l) {
-                uint32_t e = 0;
-                const int k = t9_classify(d, seq_padded + R.seq_off[r], w[l], r, &e);
+                const int k = t9_step(rec, seq_padded + R.seq_off[r], w[l]);
                 if (k == T9_AGREE) { ++c_all[l]; ++*n_agree; }
                 else if (k == T9_ENTRY) {
-                    if (++wave_entries > T9_DL) return false;     // the wave's deferred list is full: its chunks go to k_tile3
-                    bucket[l].push_back(e);
+                    if (dl.size() >= T9_DL) return false;      // the wave's deferred list is full: its chunks go to k_tile3
+                    dl.push_back(Ent{r, l});
+                    ++my_n[l];
                     ++*n_entries;
                 }
             }
         }
-    for (int l = 0; l < 64; ++l)
-        for (uint32_t e : bucket[l]) {
-            if (e & T9_GENERAL) {
-                const uint32_t r = e & 0x7fffffffu;
-                e = t9_general(desc.data() + (uint64_t)r * DESC_WORDS, ovf.data(), seq_padded + R.seq_off[r], w[l], SoGlobal{soff.data()});
-                ++*n_general;
-            }
-            t9_tally<E>(e, vl[l], basemask[l], L.data(), l);
+    for (Ent& e : dl) {
+        const uint32_t r = e.x;
+        e.x = t9_code(desc.data() + (uint64_t)r * DESC_WORDS, ovf.data(), seq_padded + R.seq_off[r], w[e.owner].s0, w[e.owner].g, jj[e.owner]);
+    }
+    for (int l = 0; l < 64; ++l) {
+        if (my_n[l] <= T9_HOT) {
+            for (const Ent& e : dl)
+                if (e.owner == l) t9_tally<E>(e.x, vl[l], basemask[l], L.data(), l);
+            continue;
         }
+        ++*n_hot;
+        for (size_t base = 0; base < dl.size(); base += 64) {       // the whole wave on one lane's entries, 64 list entries at a time
+            const size_t end = std::min(dl.size(), base + 64);
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t p = j + 2;
+                std::vector<uint8_t> left(end - base, 0);
+                for (size_t x = base; x < end; ++x) {
+                    const uint32_t lo = (dl[x].x >> 24) & 7u, hi = (dl[x].x >> 27) & 7u;
+                    left[x - base] = dl[x].owner == l && p >= lo && p <= hi;
+                }
+                for (size_t x = base; x < end; ++x) {
+                    if (!left[x - base]) continue;
+                    const uint32_t k = (dl[x].x >> (20 - 4 * p)) & 0xfffu;
+                    uint32_t cnt = 0;
+                    for (size_t y = x; y < end; ++y)
+                        if (left[y - base] && ((dl[y].x >> (20 - 4 * p)) & 0xfffu) == k) { ++cnt; left[y - base] = 0; }
+                    t9_tally_ctx<E>(k, cnt, true, vl[l][j], basemask[l][j], L.data() + j * (E - 2) * 64, l);
+                }
+            }
+        }
+    }
     for (int l = 0; l < 64; ++l)
         for (int j = 0; j < 4; ++j) {
             vl[l][j].c0 += c_all[l];
@@ -282,7 +308,7 @@ bool vote_tile9(uint32_t t, const std::vector<uint32_t>& desc, const std::vector
 
 extern "C" {
 int np1m_fused = 0;   // 0: staged sequence (rows in memory), 1: descriptors (k_tile3), 2: four slots per lane with deferred entries (k_tile9; k_tile3 for what it hands back)
-unsigned long long np1m_t9_stats[4] = {0, 0, 0, 0};   // last call in mode 2: agreeing (record, window) pairs, deferred entries, index entries among them, waves handed back
+unsigned long long np1m_t9_stats[4] = {0, 0, 0, 0};   // last call in mode 2: agreeing (record, window) pairs, deferred entries, lanes tallied by the whole wave, waves handed back
 
 
 // Returns 0 on success; *out is malloc'd concatenation of the polished contigs, bounds[n_contigs+1].

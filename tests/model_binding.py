@@ -36,7 +36,7 @@ def lib():
 
 def score_chain(stream, cfg=None, want_stats=False, fused=False):
     """fused=0: staged launch sequence (symbol rows); 1: descriptor-based sequence (k_desc + k_tile3); 2: k_desc + k_tile9 (np1_tile9.h),
-    k_tile3 for the waves it hands back.  want_stats adds t9 = (agreeing pairs, deferred entries, index entries, waves handed back)."""
+    k_tile3 for the waves it hands back.  want_stats adds t9 = (agreeing pairs, deferred entries, lanes tallied by the whole wave, waves handed back)."""
     cfg = cfg or nat.default_config()
     C.c_int.in_dll(lib(), "np1m_fused").value = int(fused)   # 0 staged, 1 k_tile3, 2 k_tile9
     out = C.c_void_p()

@@ -385,6 +385,30 @@ def test_staged_sequence_matches_oracle():
     assert r.returncode == 0 and "staged ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_four_slots_per_lane_kernel_matches_oracle():
+    """NP1_TILE=9: k_tile9 (np1_tile9.h) instead of k_tile3 -- agreeing records counted per six-slot window, every other (record, lane)
+    pair deferred, evaluated and tallied in record order; waves that run out of list room hand their chunks to k_tile3.  The switch is
+    read once per process, hence the subprocess.  Workloads: the synthetic shapes at 8-120x (deep ones overflow the lists and take
+    the hand-back path), the micro-case fuzz (odd CIGARs, chained descriptors, contig edges), crowded slots, a megabase."""
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from nextpolish_amd import _native as nat\nfrom nextpolish_amd.device import Context\nimport oracle_binding as ob\n"
+            "from fuzzgen import random_case\n"
+            "c = Context(0)\n"
+            "sts = [nat.Stream.synth([30000 + 977 * d, 3000, 700], depth=d, seed=90 + d, weird_rate=0.02 if d %% 2 else 0.0, read_indel=0.002, softclip_rate=0.05, draft_lower=0.02) for d in (8, 15, 30, 60, 120)]\n"
+            "sts += [nat.Stream.from_reads(*random_case(s)) for s in range(120)]\n"
+            "sts.append(nat.Stream.synth([4000], depth=300, seed=5, read_sub=0.08, read_indel=0.01))\n"
+            "sts.append(nat.Stream.synth([1000000, 250000], depth=30, seed=123))\n"
+            "for st in sts:\n"
+            "    got = c.score_chain(st)\n"
+            "    for i in range(st.n_contigs):\n"
+            "        assert got[i] == ob.score_chain(st, i)\n"
+            "print('tile9 ok', len(sts))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, NP1_TILE="9")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "tile9 ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_kmer_count_with_records_beyond_16_bit_counts(ctx, tmp_path):
     """tasks 2 / 4 walk the records themselves (np1_kmer.h), no descriptors: a CG-tag CIGAR only needs the 32-bit operation count --
     in memory, and from the files (device ingest meets the placeholder CIGAR and hands the file to the host loader)"""
