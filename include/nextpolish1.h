@@ -281,6 +281,26 @@ int np1_batch_snp_valid(np1_batch* b, const Configure* cfg, float* stage_ms);
  * same context.  cfg->read_len / read_tlen as config_init sets them.  The result lands in `sr` (np1_batch_result_*).  Inputs for
  * which the reference itself reads through a null or unset pointer fail with an error message instead of a result. */
 int np1_batch_snp_phase(np1_batch* sr, np1_batch* lr, const Configure* cfg);
+/* Intra-contig tiling (np1_tile.cpp): one contig of any length polished as independent tiles of tile_bp draft bases with
+ * a halo of halo_bp on each side, each tile reading its own region of the BAM through the index; the join is exact (a tile is redone
+ * with a doubled halo when a halo holds no slot the chain restarts behind).  The reference takes contigs up to 2^31 bases
+ * (source/nextPolish:101-102) in one score_chain call (source/lib/scorechain.c:3-15); this is that call for contigs beyond one HBM batch.
+ * first_tile / tile_stride: this call polishes tiles first_tile, first_tile + tile_stride, ... (0, 1: all of them; rank r of n ranks:
+ * r, n -- the pieces of the ranks are concatenated tile by tile by the caller).  *out: malloc'd, NUL-terminated (np1_free_string).
+ * stats (optional, 4 words): tiles, tiles recomputed with a wider halo, records read, records of the largest tile.
+ * Pieces: np1_batch_keep_single (before the run) makes a one-contig batch remember which slots left the vote with one state;
+ * np1_batch_tile_join gives {left halo has such a slot, right halo has one, output offset of the tile's first own base, of the first base
+ * behind it}; np1_batch_result_range copies polished characters [o0, o1) out. */
+int np1_score_chain_tiled(np1_ctx* ctx, const char* fasta, const char* bam, const char* name, const Configure* cfg, int64_t tile_bp, int64_t halo_bp,
+                          int64_t first_tile, int64_t tile_stride, char** out, int64_t* out_len, uint64_t* stats);
+void np1_free_string(char* s);
+/* score_chain over a whole FASTA index with tiling on: contigs longer than tile_bp tile by tile, the others through the pipe in batches;
+ * every contig reaches `sink` in index order (what `nextpolish1 scorechain` does when NP1_TILE_BP is set) */
+int np1_run_files_tiled(np1_pipe* pipe, int device, const char* fasta, const char* bam, int64_t batch_bp, int64_t tile_bp, int64_t halo_bp,
+                        const Configure* cfg, np1_sink_fn sink, void* user);
+int np1_batch_keep_single(np1_batch* b, int on);
+int np1_batch_tile_join(np1_batch* b, uint32_t i_elo, uint32_t i_a, uint32_t i_b, uint32_t i_ehi, uint32_t skip, uint32_t out[4]);
+int np1_batch_result_range(np1_batch* b, uint32_t o0, uint32_t o1, char* dst);
 /* Blocks until the batch's work is complete. */
 int np1_batch_sync(np1_batch* b);
 /* Polished length of contig i (valid after a completed run), and copy-out of its NUL-terminated string. */

@@ -62,7 +62,13 @@ int main(int argc, char* argv[]) {
             fwrite(seq, 1, (size_t)len, stdout);
             fputc('\n', stdout);
         };
-        if (np1_pipe_run_files(pipe, cfg->fastafn, cfg->bamfn, nullptr, 0, batch_bp, cfg, step, sink, &out) != 0) {
+        // NP1_TILE_BP (score_chain): contigs longer than this are polished as independent tiles with NP1_TILE_HALO bases of halo (default
+        // 1000) and joined exactly -- a contig need not fit one HBM batch (np1_tile.cpp; the reference takes contigs up to 2^31 bases)
+        const long long tile_bp = (step == 1 && getenv("NP1_TILE_BP")) ? atoll(getenv("NP1_TILE_BP")) : 0;
+        const long long halo_bp = getenv("NP1_TILE_HALO") ? atoll(getenv("NP1_TILE_HALO")) : 1000;
+        const int rc = tile_bp > 0 ? np1_run_files_tiled(pipe, dev, cfg->fastafn, cfg->bamfn, batch_bp, tile_bp, halo_bp, cfg, sink, &out)
+                                   : np1_pipe_run_files(pipe, cfg->fastafn, cfg->bamfn, nullptr, 0, batch_bp, cfg, step, sink, &out);
+        if (rc != 0) {
             fprintf(stderr, "%s\n", np1_last_error());
             return 1;
         }

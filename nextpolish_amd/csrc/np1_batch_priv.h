@@ -75,7 +75,8 @@ struct np1_batch {
     // inputs
     np1dev::DevBuf draft, ctg_off, pos, ctg, flag, ncig, ncig16, lq, cigoff, seqoff, cigar, seq, seq2, esc_at, esc_val, up_plain, up_xlq, up_xncig, up_xcigar, up_dpos, up_xpos, up_work, draft4, desc_at, desc_val;
     // work
-    np1dev::DevBuf desc, ovf_desc, slot_g, dbg;
+    np1dev::DevBuf desc, ovf_desc, slot_g, dbg, single_map, join_out;
+    bool keep_single = false;   // intra-contig tiling: keep which slots left the vote with one state (np1_batch_tile_join)
     // kmer_count inputs (uploaded only when the stream carries qualities) and work buffers
     np1dev::DevBuf mapq, isize, qualoff, qual, read_begin;
     np1dev::DevBuf kc_level, kc_endpos, kc_code, kc_flag, kc_fpos, kc_flagged, kc_work, kc_nd_ctg, kc_nd_se, kc_kr_ctg, kc_kr_se, kc_cnt,
@@ -123,13 +124,13 @@ struct np1_batch {
     // buffers of another batch: resident batches keep only their inputs in HBM and borrow the work set of the lane they run on
     // (np1_pipe_run_resident), so a draft of any size stays resident with two work sets instead of one per batch.
     void swap_work(np1_batch& o) {
-        np1dev::DevBuf* mine[] = {&desc, &ovf_desc, &slot_g, &dbg, &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg,
+        np1dev::DevBuf* mine[] = {&desc, &ovf_desc, &slot_g, &dbg, &single_map, &join_out, &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg,
                                   &kc_nd_se, &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool, &kc_stsc,
                                   &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg, &kc_pt_se, &kc_pt_len, &kc_woff,
                                   &kc_wpool, &kc_haswin, &sv_failse, &sv_failcnt, &sv_vsz, &sv_voff, &sv_val, &sv_p2ctg, &sv_p2se, &sv_p2len, &sv_woff2,
                                   &sv_haswin2, &sv_range, &qs, &qe, &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
                                   &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &redo3, &ctx_lists, &counters, &opos, &out, &bounds, &scan_tmp, &totals};
-        np1dev::DevBuf* theirs[] = {&o.desc, &o.ovf_desc, &o.slot_g, &o.dbg, &o.kc_level, &o.kc_endpos, &o.kc_code, &o.kc_flag, &o.kc_fpos, &o.kc_flagged,
+        np1dev::DevBuf* theirs[] = {&o.desc, &o.ovf_desc, &o.slot_g, &o.dbg, &o.single_map, &o.join_out, &o.kc_level, &o.kc_endpos, &o.kc_code, &o.kc_flag, &o.kc_fpos, &o.kc_flagged,
                                     &o.kc_work, &o.kc_nd_ctg, &o.kc_nd_se, &o.kc_kr_ctg, &o.kc_kr_se, &o.kc_cnt, &o.kc_sbase, &o.kc_sflag, &o.kc_srefk,
                                     &o.kc_scount, &o.kc_lhead, &o.kc_lpool, &o.kc_stsc, &o.kc_stkm, &o.kc_strk, &o.kc_hpool, &o.kc_workoff, &o.kc_nparts,
                                     &o.kc_partoff, &o.kc_pt_ctg, &o.kc_pt_se, &o.kc_pt_len, &o.kc_woff, &o.kc_wpool, &o.kc_haswin, &o.sv_failse,
@@ -150,7 +151,7 @@ struct np1_batch {
         const np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &ncig16, &lq, &cigoff, &seqoff, &cigar, &seq, &seq2, &esc_at, &esc_val, &up_plain, &up_xlq, &up_xncig, &up_xcigar, &up_dpos, &up_xpos, &up_work, &draft4, &desc_at, &desc_val, &qs, &qe,
                                &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
                                &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &redo3, &ctx_lists, &counters, &opos, &out,
-                               &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &dbg, &mapq, &isize, &qualoff, &qual, &read_begin,
+                               &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &dbg, &single_map, &join_out, &mapq, &isize, &qualoff, &qual, &read_begin,
                                &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg, &kc_nd_se,
                                &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool,
                                &kc_stsc, &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg,
@@ -165,7 +166,7 @@ struct np1_batch {
         np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &ncig16, &lq, &cigoff, &seqoff, &cigar, &seq, &seq2, &esc_at, &esc_val, &up_plain, &up_xlq, &up_xncig, &up_xcigar, &up_dpos, &up_xpos, &up_work, &draft4, &desc_at, &desc_val, &qs, &qe,
                          &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
                          &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &redo3, &ctx_lists, &counters, &opos, &out,
-                         &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &dbg, &mapq, &isize, &qualoff, &qual, &read_begin,
+                         &bounds, &scan_tmp, &totals, &desc, &ovf_desc, &slot_g, &dbg, &single_map, &join_out, &mapq, &isize, &qualoff, &qual, &read_begin,
                          &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg, &kc_nd_se,
                          &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool,
                          &kc_stsc, &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg, &kc_pt_se,

@@ -2,6 +2,8 @@
 // (include/nextpolish1.h, Part 2: np1_ctx_*, np1_batch_*).  Kernels: np1_kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <sys/stat.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +11,7 @@
 #include <string>
 #include <algorithm>
 #include <array>
+#include <mutex>
 #include <vector>
 
 #include "../../include/nextpolish1.h"
@@ -96,6 +99,7 @@ static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t st) {
 // Longest record, and whether cigar_off / seq_off / ctg are exactly what a device rebuilds from n_cigar, l_qseq and read_begin (true
 // for every stream this library makes: loaders and generators append to the pools in record order).  Found once per stream.
 static void stream_facts(np1_stream* st) {
+    std::lock_guard<std::mutex> hold(st->facts_mu);      // (two lanes reloading one stream, pin + reload: the const API invites it)
     if (st->facts) return;
     const np::ReadStream& s = st->s;
     const size_t n = s.n_reads();
@@ -599,6 +603,10 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     if (hc[CNT_ERR] & ERR_DOUBLE_INS) { np1_set_error("unsupported CIGAR: two insertion ops at one reference position"); return -1; }
     if (hc[CNT_ERR] & ERR_BAD_RECORD) { np1_set_error("alignment record extends beyond its contig"); return -1; }
     if (hc[CNT_ERR] & ERR_CTX_OVERFLOW) { np1_set_error("a slot holds more than 160 distinct 3-base contexts, which a general indel_balance_factor_sgs cannot take"); return -1; }
+    if (b->keep_single) {      // intra-contig tiling: the single-state slots of the vote, before the chain overwrites the others
+        if (b->single_map.ensure((size_t)S + 64)) return -1;
+        launch_single_map(q, b->slot_res.as<uint16_t>(), S, b->single_map.as<uint8_t>());
+    }
     // ---- stage 6: chain DP over multi-state runs
     t0(6);
     {
@@ -1062,6 +1070,33 @@ int np1_batch_result_copy(np1_batch* b, int64_t c, char* dst, int64_t cap) {
     return 0;
 }
 
+// ---- intra-contig tiling (np1_tile.cpp) -------------------------------------------------------------------------
+extern "C" int np1_batch_keep_single(np1_batch* b, int on) {
+    if (!b) { np1_set_error("np1_batch_keep_single: null batch"); return -1; }
+    b->keep_single = on != 0;
+    return 0;
+}
+// Join facts of a one-contig batch that holds a tile: i_* are indices into the tile's own draft (e_lo, a, b, e_hi minus the hull's start),
+// skip = 2 when the halo does not start at the contig's first base (the two slots behind an artificial start have a cut context).
+extern "C" int np1_batch_tile_join(np1_batch* b, uint32_t i_elo, uint32_t i_a, uint32_t i_b, uint32_t i_ehi, uint32_t skip, uint32_t out[4]) {
+    if (!b || !b->ran || !b->keep_single || b->nc != 1) { np1_set_error("np1_batch_tile_join: needs a completed score_chain run of a one-contig batch with keep_single"); return -1; }
+    if (!(i_elo <= i_a && i_a <= i_b && i_b <= i_ehi && i_ehi <= b->G)) { np1_set_error("np1_batch_tile_join: bad tile indices"); return -1; }
+    (void)hipSetDevice(b->ctx->device);
+    hipStream_t q = b->ctx->stream;
+    if (b->join_out.ensure(16)) return -1;
+    launch_join_info(q, b->soff.as<uint32_t>(), b->single_map.as<uint8_t>(), b->opos.as<uint32_t>(), i_elo, i_a, i_b, i_ehi, skip, b->join_out.as<uint32_t>());
+    HIPCHK(hipMemcpyAsync(out, b->join_out.p, 16, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipStreamSynchronize(q));
+    return 0;
+}
+// polished characters [o0, o1) of the batch's output
+extern "C" int np1_batch_result_range(np1_batch* b, uint32_t o0, uint32_t o1, char* dst) {
+    if (!b || !b->ran || o0 > o1 || o1 > b->h_bounds[b->nc]) { np1_set_error("np1_batch_result_range: bad range"); return -1; }
+    (void)hipSetDevice(b->ctx->device);
+    if (o1 > o0) HIPCHK(hipMemcpy(dst, b->out.as<uint8_t>() + o0, (size_t)(o1 - o0), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int np1_batch_debug_counters(np1_batch* b, uint32_t* out, int n) {
     if (!b) return -1;
     for (int i = 0; i < n && i < (int)CNT_WORDS; ++i) out[i] = b->last_counters[i];
@@ -1138,11 +1173,18 @@ extern "C" int np1_batch_enable_replay(np1_batch* b, const np1_stream* st, const
     }
     np1_batch::Replay& R = b->replay;
     R.on = false;
+    // the parsed index is kept across passes of one batch object, keyed on what the file IS, not only on its name: an index regenerated
+    // at the same path between two passes (iterative polishing rounds, tests reusing temporary names) is read again
     const std::string bai_path = std::string(bam) + ".bai";
-    if (R.own_bai_path != bai_path) {
+    struct stat sb;
+    if (stat(bai_path.c_str(), &sb) != 0) { np1_set_error("cannot load BAM index: " + bai_path); return -1; }
+    const std::string key = bai_path + "|" + std::to_string((long long)sb.st_ino) + "|" + std::to_string((long long)sb.st_size) + "|" +
+                            std::to_string((long long)sb.st_mtim.tv_sec) + "." + std::to_string((long long)sb.st_mtim.tv_nsec);
+    if (R.own_bai_path != key) {
         R.own_bai_path.clear();
+        R.own_bai = np::BaiIndex();
         if (!R.own_bai.load(bai_path)) { np1_set_error("cannot load BAM index: " + bai_path); return -1; }
-        R.own_bai_path = bai_path;
+        R.own_bai_path = key;
     }
     R.bai = &R.own_bai;
     np::BamReader rd;

@@ -525,7 +525,13 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         // which decoder: a lane per block when the batch has blocks enough to fill the chip with lanes (np_inflate_lane.h), else a
         // wave per block (np_inflate_dev.h).  NP1_INFLATE=lanes | wave forces one.
         static const int mode = [] { const char* e = getenv("NP1_INFLATE"); return !e ? 0 : strcmp(e, "lanes") == 0 ? 1 : strcmp(e, "wave") == 0 ? 2 : 0; }();
-        static const uint32_t max_lanes = getenv("NP1_INFLATE_LANES") ? (uint32_t)atoi(getenv("NP1_INFLATE_LANES")) : 131072u;
+        // lanes in flight: a multiple of the wave, at least one wave, at most 2^18 (their tables are ~15 KB each in HBM)
+        static const uint32_t max_lanes = [] {
+            long v = getenv("NP1_INFLATE_LANES") ? atol(getenv("NP1_INFLATE_LANES")) : 131072;
+            if (v < 64) v = 64;
+            if (v > 262144) v = 262144;
+            return (uint32_t)((v + 63) / 64 * 64);
+        }();
         if (mode == 1 || (mode == 0 && n_blocks >= 4096u)) {
             const uint32_t lanes = std::min<uint32_t>((n_blocks + 63u) & ~63u, max_lanes);
             if (W.lane_tables.ensure((size_t)lanes * nplane::LANE_TABLE_WORDS * 4)) return -1;

@@ -60,6 +60,11 @@ int launch_tile9(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const 
                  const uint32_t* chunk_last, uint32_t n_chunks, const uint8_t* slot_info, const uint32_t* slot_g, uint32_t S, uint32_t max_lq,
                  uint16_t* slot_res, uint32_t* slot_rec, uint32_t* pool, uint32_t pool_cap, uint32_t* counters, uint32_t* heads, uint32_t heads_cap,
                  uint32_t* redo_out, uint32_t redo_ci, uint32_t flag_single, unsigned long long* votes, unsigned long long* dbg = nullptr);
+// intra-contig tiling: single-state map of the vote, and a tile's join facts (out[4]: left halo has a single-state slot, right halo has one,
+// output offset of the tile's first own base, of the first base behind it)
+void launch_single_map(hipStream_t st, const uint16_t* slot_res, uint32_t S, uint8_t* single);
+void launch_join_info(hipStream_t st, const uint32_t* soff, const uint8_t* single, const uint32_t* opos, uint32_t i_elo, uint32_t i_a, uint32_t i_b, uint32_t i_ehi,
+                      uint32_t skip, uint32_t* out);
 void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t cnt0, uint32_t n_shards,
                uint32_t heads_region, uint32_t* pool, const uint32_t* slot_rec, uint16_t* slot_res, int K, long long Rfix,
                double min_ratio, uint32_t grid, bool fp = false, double rate = 0.0);   // fp: general-rate path (doubles, whole-contig runs)

@@ -1427,6 +1427,34 @@ int launch_tile9(hipStream_t st, const ReadsDev& R, const uint32_t* soff, const 
     return 0;
 }
 
+// ---- intra-contig tiling: which slots left the vote with one state (the chain restarts behind each of them), and
+// what a tile needs to know to be joined: is there such a slot in each halo, and where do its own bases start / end in the output
+__global__ __launch_bounds__(256) void k_single_map(const uint16_t* __restrict__ slot_res, uint32_t S, uint8_t* __restrict__ single) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) single[s] = (slot_res[s] & 0xffu) != 0xffu ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_join_info(const uint32_t* __restrict__ soff, const uint8_t* __restrict__ single, const uint32_t* __restrict__ opos,
+                                                   uint32_t i_elo, uint32_t i_a, uint32_t i_b, uint32_t i_ehi, uint32_t skip, uint32_t* __restrict__ out) {
+    __shared__ uint32_t any[2];
+    if (threadIdx.x < 2) any[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t l0 = soff[i_elo] + skip, l1 = soff[i_a], r0 = soff[i_b], r1 = soff[i_ehi];
+    bool a = false, b = false;
+    for (uint32_t s = l0 + threadIdx.x; s < l1; s += 256) a = a || single[s] != 0;
+    for (uint32_t s = r0 + threadIdx.x; s < r1; s += 256) b = b || single[s] != 0;
+    if (a) any[0] = 1;
+    if (b) any[1] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = any[0]; out[1] = any[1]; out[2] = opos[soff[i_a]]; out[3] = opos[soff[i_b]]; }
+}
+void launch_single_map(hipStream_t st, const uint16_t* slot_res, uint32_t S, uint8_t* single) {
+    if (S) k_single_map<<<nblk(S, 256), 256, 0, st>>>(slot_res, S, single);
+}
+void launch_join_info(hipStream_t st, const uint32_t* soff, const uint8_t* single, const uint32_t* opos, uint32_t i_elo, uint32_t i_a, uint32_t i_b, uint32_t i_ehi,
+                      uint32_t skip, uint32_t* out) {
+    k_join_info<<<1, 256, 0, st>>>(soff, single, opos, i_elo, i_a, i_b, i_ehi, skip, out);
+}
+
 void launch_dp(hipStream_t st, const uint32_t* heads, uint32_t* counters, uint32_t cnt0, uint32_t n_shards,
                uint32_t heads_region, uint32_t* pool, const uint32_t* slot_rec, uint16_t* slot_res, int K, long long Rfix,
                double min_ratio, uint32_t grid, bool fp, double rate) {

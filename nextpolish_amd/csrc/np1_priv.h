@@ -1,5 +1,6 @@
 // Definitions shared by the translation units behind include/nextpolish1.h, Part 2 (not part of the ABI).
 #pragma once
+#include <mutex>
 #include <string>
 
 #include "np_stream.h"
@@ -11,6 +12,7 @@ struct np1_stream {
     // per-record arrays a device can rebuild itself really are what it would rebuild (pool offsets = running sums, contig = the
     // record's place in read_begin) -- then 20 of the 32 fixed bytes per record need not cross PCIe
     int facts = 0;         // 0 not looked at yet, 1 dense, 2 not dense
+    std::mutex facts_mu;   // the facts and the upload forms are built lazily, by whichever lane or thread asks first (np1_device.hip:stream_facts)
     uint32_t max_lq = 0;
     // CIGAR operation counts in the 16 bits the BAM record gives them, for the upload (the device widens them): only a CG-tag CIGAR
     // needs more, and a stream that holds one uploads its 32-bit counts as they are.  Empty: not made / does not apply.

@@ -122,6 +122,60 @@ bool load_stream(const std::string& fasta, const std::string& bam, const std::ve
     return true;
 }
 
+bool load_stream_region(const std::string& bam, const BaiIndex& bai, const std::string& name, const std::string& draft_whole, int32_t e_lo, int32_t e_hi,
+                        ReadStream* out, int32_t* lo_out, int32_t* hi_out, std::string* err) {
+    out->clear();
+    BamReader rd;
+    if (!rd.open(bam)) { *err = "cannot open BAM: " + bam; return false; }
+    const int tid = rd.header().name2id(name);
+    const int32_t L = (int32_t)draft_whole.size();
+    // the records come sorted by position: the first one that is kept has the smallest start, which fixes the hull's left end
+    int32_t lo = e_lo > 0 ? e_lo - 1 : 0, hi = e_hi;
+    bool first = true;
+    out->names.push_back(name);
+    out->read_begin.assign(2, 0);
+    voff_t v;
+    // (one base earlier than the interval: a record whose last base is e_lo - 1 still pads the columns behind it)
+    if (tid >= 0 && bai.region_start(tid, e_lo > 0 ? e_lo - 1 : 0, e_hi < L ? e_hi + 1 : L, &v)) {
+        if (!rd.seek(v)) { *err = "BAM seek failed"; return false; }
+        BamRec r;
+        for (;;) {
+            const voff_t v0 = rd.tell();
+            const int st = rd.next(r);
+            const voff_t v1 = rd.tell();
+            if (st < 0) { *err = "corrupt BAM record in " + bam; return false; }
+            if (st == 0) break;
+            if (r.tid >= 0 && r.tid < tid) continue;
+            if (r.tid != tid) break;
+            if (r.pos > e_hi || r.pos >= L) break;                                   // nothing further touches the tile
+            if (r.pos < 0 || r.endpos() <= 0) continue;                              // (what the whole-contig iterator drops)
+            int32_t e = r.pos;
+            const uint32_t* cg = r.cigar();
+            for (uint32_t i = 0; i < r.n_cigar; ++i)
+                if ((cg[i] & 15u) == 0 || (cg[i] & 15u) == 2) e += (int32_t)(cg[i] >> 4);
+            if (e < e_lo) continue;
+            if (first) {
+                first = false;
+                const int32_t m = r.pos < e_lo ? r.pos : e_lo;
+                lo = m > 0 ? m - 1 : 0;
+            }
+            if (e > hi) hi = e;
+            r.pos -= lo;
+            append_record(r, 0u, false, out, v0, v1);
+        }
+    }
+    hi = hi < L ? hi + 1 : L;
+    if (hi > L) hi = L;
+    out->ctg_len.push_back(hi - lo);
+    out->draft.assign(draft_whole, (size_t)lo, (size_t)(hi - lo));
+    out->ctg_off.push_back(0);
+    out->ctg_off.push_back((uint32_t)out->draft.size());
+    out->read_begin[1] = out->n_reads();
+    *lo_out = lo;
+    *hi_out = hi;
+    return true;
+}
+
 bool bam_insert_probe(const std::string& bam, uint32_t count_read_ins, uint32_t max_ins_len, uint32_t* mean_out,
                       int32_t* read_len_out) {
     BamReader rd;

@@ -58,6 +58,14 @@ bool load_stream(const std::string& fasta, const std::string& bam, const std::ve
 
 // Mean-insert-size probe of config_init (reference: source/lib/config.c:80-101): scans the first
 // records of the BAM; returns sum/count with count starting at 1, and the first qualifying l_qseq.
+struct BaiIndex;
+// One TILE of one contig (intra-contig tiling): the records of `name` that touch draft bases [e_lo, e_hi] -- as the
+// reference's walk sees them: a record ends where its M and D operations end, contig.c:262-326 -- read through the index, in file order, as
+// a stream of ONE contig whose draft is the hull [*lo, *hi) of those records and of the interval itself, widened by one base on each side
+// (position 0 and the last base of a contig are special to the walk, and no record of the tile may meet an artificial one).  Record
+// positions are relative to *lo.  draft_whole: the contig's draft (fetched once by the caller); *n_seen = records read to find them.
+bool load_stream_region(const std::string& bam, const BaiIndex& bai, const std::string& name, const std::string& draft_whole, int32_t e_lo, int32_t e_hi,
+                        ReadStream* out, int32_t* lo, int32_t* hi, std::string* err);
 bool bam_insert_probe(const std::string& bam, uint32_t count_read_ins, uint32_t max_ins_len, uint32_t* mean_out,
                       int32_t* read_len_out);
 

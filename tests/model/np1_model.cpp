@@ -20,6 +20,8 @@
 #include "../../nextpolish_amd/csrc/np1_tile9.h"
 #include "../../nextpolish_amd/csrc/np1_replay.h"
 #include "../../nextpolish_amd/csrc/np1_upload.h"
+#include "../../nextpolish_amd/csrc/np_bam.h"
+#include "../../nextpolish_amd/csrc/np_stream.h"
 
 using namespace np1k;
 
@@ -838,6 +840,70 @@ int np1m_score_chain_tiled(const np1_stream_view* v, const Configure* cfg, uint3
     char* buf = (char*)calloc(1, joined.size() + 1);
     memcpy(buf, joined.data(), joined.size());
     *out = buf;
+    if (tstats) { tstats[0] = n_tiles; tstats[1] = n_redo; tstats[2] = n_rec; }
+    return 0;
+}
+
+// The product's tiling driver (nextpolish_amd/csrc/np1_tile.cpp) with the model in place of the device: tiles read from the FILES through
+// the index (np_stream.cpp: load_stream_region), joined with the same index arithmetic.  CPU check of the region loader and of the join.
+int np1m_score_chain_tiled_files(const char* fasta, const char* bam, const char* name, const Configure* cfg, int64_t tile_bp, int64_t halo_bp, char** out,
+                                 int64_t* out_len, uint64_t* tstats) {
+    np::Fai fai;
+    if (!fai.load(fasta)) return -30;
+    const int id = fai.find(name);
+    if (id < 0) return -31;
+    std::string draft;
+    if (!fai.fetch(id, &draft)) return -32;
+    np::BaiIndex bai;
+    if (!bai.load(std::string(bam) + ".bai")) return -33;
+    const int64_t L = (int64_t)draft.size();
+    std::string joined;
+    uint64_t n_tiles = 0, n_redo = 0, n_rec = 0;
+    g_keep_map = true;
+    int rc = 0;
+    for (int64_t a = 0; a < L && rc == 0; a += tile_bp) {
+        const int64_t b = a + tile_bp < L ? a + tile_bp : L;
+        ++n_tiles;
+        for (int64_t halo = halo_bp;; halo *= 2) {
+            const int32_t e_lo = (int32_t)(a - halo > 0 ? a - halo : 0), e_hi = (int32_t)(b + halo < L ? b + halo : L);
+            np::ReadStream rs;
+            std::string err;
+            int32_t lo = 0, hi = 0;
+            if (!np::load_stream_region(bam, bai, name, draft, e_lo, e_hi, &rs, &lo, &hi, &err)) { rc = -34; break; }
+            n_rec += rs.n_reads();
+            np1_stream_view v;
+            memset(&v, 0, sizeof(v));
+            v.n_contigs = 1; v.n_reads = (int64_t)rs.n_reads(); v.draft_len = (int64_t)rs.draft.size(); v.draft = rs.draft.data();
+            v.ctg_len = rs.ctg_len.data(); v.ctg_off = rs.ctg_off.data(); v.read_begin = rs.read_begin.data();
+            v.pos = rs.pos.data(); v.ctg = rs.ctg.data(); v.flag = rs.flag.data(); v.n_cigar = rs.n_cigar.data(); v.l_qseq = rs.l_qseq.data();
+            v.cigar_off = rs.cigar_off.data(); v.seq_off = rs.seq_off.data(); v.cigar = rs.cigar.data(); v.seq = rs.seq.data();
+            v.cigar_len = (int64_t)rs.cigar.size(); v.seq_len = (int64_t)rs.seq.size();
+            v.mapq = rs.mapq.data(); v.isize = rs.isize.data(); v.qual_off = rs.qual_off.data();
+            char* part = nullptr;
+            uint32_t pb[2] = {0, 0};
+            rc = np1m_score_chain(&v, cfg, &part, pb, nullptr);
+            if (rc != 0) break;
+            const uint32_t i_elo = (uint32_t)(e_lo - lo), i_a = (uint32_t)(a - lo), i_b = (uint32_t)(b - lo), i_ehi = (uint32_t)(e_hi - lo);
+            bool left_any = false, right_any = false;
+            for (uint32_t sl = g_soff[i_elo] + (e_lo > 0 ? 2u : 0u); sl < g_soff[i_a]; ++sl) left_any = left_any || g_single[sl] != 0;
+            for (uint32_t sl = g_soff[i_b]; sl < g_soff[i_ehi]; ++sl) right_any = right_any || g_single[sl] != 0;
+            const bool left_ok = a == 0 || e_lo == 0 || left_any, right_ok = b == L || e_hi == L || right_any;
+            if (left_ok && right_ok) {
+                joined.append(part + g_opos[g_soff[i_a]], part + g_opos[g_soff[i_b]]);
+                free(part);
+                break;
+            }
+            free(part);
+            ++n_redo;
+            if (halo > ((int64_t)1 << 30)) { rc = -20; break; }
+        }
+    }
+    g_keep_map = false;
+    if (rc != 0) return rc;
+    char* buf = (char*)calloc(1, joined.size() + 1);
+    memcpy(buf, joined.data(), joined.size());
+    *out = buf;
+    *out_len = (int64_t)joined.size();
     if (tstats) { tstats[0] = n_tiles; tstats[1] = n_redo; tstats[2] = n_rec; }
     return 0;
 }

@@ -241,3 +241,22 @@ def test_corrupt_block_is_rejected_like_htslib_does(tmp_path):
             assert "CRC" in r.stderr, r.stderr
     r = subprocess.run([exe, "scorechain", fa, bam], capture_output=True, text=True, env=dict(env, NP_BGZF_NO_CRC="1"))
     assert r.returncode == 0 or "CRC" not in r.stderr      # without the check the damaged byte is just a base or a quality (or a broken record chain)
+
+
+def test_lane_per_block_decoder_and_compact_upload_form_in_processes_of_their_own():
+    """Two device paths that only big inputs take by default: the lane-per-block DEFLATE decoder (k_inflate_lanes: from 4 096 blocks per
+    ingest) and the compact per-record upload form (k_expand_*: from 2^22 records per stream).  Both switches are read once per process,
+    so the ingest / score_chain / kmer_count / snp_valid parity tests run again in child processes with NP1_INFLATE=lanes (and a lane
+    count that is not a multiple of 64: it is rounded) and with NP1_COMPACT_MIN=64."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    runs = [(dict(NP1_INFLATE="lanes", NP1_INFLATE_LANES="1000"),
+             ["tests/test_gpu_ingest.py", "-k", "equals_host_loader or real_bwa or samtools_written or corrupt_block or rejects_damaged"]),
+            (dict(NP1_COMPACT_MIN="64"),
+             ["tests/test_gpu_score_chain.py", "tests/test_snp_valid.py", "-k",
+              "synth_matches_oracle or micro_cases or empty_and_ragged or kmer_count_synth or one_round or many_contigs or adversarial"])]
+    for env_add, args in runs:
+        p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"] + args, cwd=os.path.dirname(here),
+                           env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=1200)
+        assert p.returncode == 0 and " passed" in p.stdout, "%r\n%s\n%s" % (env_add, p.stdout[-3000:], p.stderr[-2000:])

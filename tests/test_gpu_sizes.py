@@ -39,3 +39,17 @@ def test_config5_scale_chromosome_contig_and_multibatch_from_files_match_oracle(
     info = run_tool("check_config5.py")
     assert info["mismatches"] == 0 and info["big"]["draft_bp"] >= 249000000 and info["big"]["records"] >= 49000000
     assert info["slice"]["batches"] >= 4 and info["slice"]["draft_bp"] >= 112000000
+
+
+def test_config5_scale_kmer_count_round_on_a_chromosome_contig_from_files_in_replay_mode():
+    """Task 2 at the scale of the metric's draft: a 250 Mb contig at 30x with qualities from a sorted BAM through `nextpolish1 kmercount`
+    (device ingest, iterator replay) identical to the oracle run on the same files with the iterator replayed."""
+    info = run_tool("check_config5_kmer.py")
+    assert info["mismatches"] == 0 and info["draft_bp"] >= 249000000 and info["records"] >= 49000000 and info["lower_case_out"] >= 0
+
+
+def test_config5_scale_long_read_leg_chromosome_contig_of_52_windows_matches_reference_golden():
+    """The long-read leg at chromosome scale: one 210 Mb contig = 52 overlapping windows stitched by link_consensus, 20x ONT-like reads,
+    identical (md5 + length of every piece) to what the compiled reference produced for the same files."""
+    info = run_tool("check_config5_lgs.py")
+    assert info["mismatches"] == 0 and info["missing"] == 0 and info["windows"] >= 50 and info["draft_bp"] >= 200000000

@@ -1,0 +1,71 @@
+"""Intra-contig tiling in the product (nextpolish_amd/csrc/np1_tile.cpp): a contig polished as independent tiles, each
+reading its own region of the BAM through the index, joins to exactly what the untiled pass gives -- and to the CPU oracle.  The reference
+polishes a contig of any length up to 2^31 in one score_chain call (source/lib/scorechain.c:3-15, source/nextPolish:101-102); the scheme's
+proof by fuzz is the host model's (tests/test_model.py::test_model_intra_contig_tiling_*)."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+from nextpolish_amd import _native as nat
+from nextpolish_amd.device import Context
+import oracle_binding as ob
+from conftest import ROOT, parse_cli_fasta
+
+pytestmark = pytest.mark.gpu
+
+
+def tiled(ctx, fa, bam, name, tile_bp, halo_bp, first=0, stride=1):
+    L = nat.lib()
+    L.np1_score_chain_tiled.restype = C.c_int
+    L.np1_score_chain_tiled.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(nat.Configure), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+    L.np1_free_string.argtypes = [C.c_void_p]
+    cfg = nat.default_config()
+    out, n, st = C.c_void_p(), C.c_int64(0), (C.c_uint64 * 4)()
+    rc = L.np1_score_chain_tiled(ctx.handle, fa.encode(), bam.encode(), name.encode(), C.byref(cfg), tile_bp, halo_bp, first, stride, C.byref(out), C.byref(n), st)
+    assert rc == 0, nat.last_error()
+    s = C.string_at(out, n.value).decode()
+    L.np1_free_string(out)
+    return s, dict(tiles=st[0], recomputed=st[1], records=st[2], largest=st[3])
+
+
+def test_tiles_of_every_size_join_to_the_oracle(tmp_path):
+    """tiles from a few hundred bases to a fraction of the contig, halos from one base up (a halo without a single-state slot makes the
+    tile run again with twice the halo), indel-rich reads, soft clips, lower case: always the oracle's string"""
+    st = nat.Stream.synth([60000, 9000], depth=25, seed=4242, read_indel=0.004, softclip_rate=0.05, draft_lower=0.02, weird_rate=0.01)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "r.bam")
+    st.write_files(fa, bam)
+    want = [ob.score_chain(st, i) for i in range(st.n_contigs)]
+    ctx = Context(0)
+    redo = 0
+    for tile, halo in ((700, 1), (5000, 40), (20000, 300), (59999, 150), (100000, 50)):
+        for i, n in enumerate(st.names):
+            got, info = tiled(ctx, fa, bam, n, tile, halo)
+            assert got == want[i], (tile, halo, n, info)
+            assert info["tiles"] == -(-int(st.ctg_len[i]) // tile)
+            redo += info["recomputed"]
+    assert redo > 0          # the one-base halos really were too small somewhere
+    # tiles dealt over two ranks: the pieces of the ranks, concatenated tile by tile, are the contig
+    tile = 8000
+    a, ia = tiled(ctx, fa, bam, st.names[0], tile, 200, 0, 2)
+    b, ib = tiled(ctx, fa, bam, st.names[0], tile, 200, 1, 2)
+    assert ia["tiles"] + ib["tiles"] == -(-int(st.ctg_len[0]) // tile) and len(a) + len(b) == len(want[0])
+    ctx.close()
+
+
+def test_cli_with_tiling_equals_cli_without(tmp_path):
+    """`nextpolish1 scorechain` with NP1_TILE_BP: a 24 Mb contig in 8 tiles of 3 Mb between short contigs that take the batched pipe, output
+    identical to the untiled run, byte for byte, in index order"""
+    st = nat.Stream.synth([300000, 24000000, 150000, 2000000], depth=30, seed=4243)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "r.bam")
+    st.write_files(fa, bam)
+    exe = os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1")
+    plain = subprocess.run([exe, "scorechain", fa, bam], capture_output=True, text=True)
+    assert plain.returncode == 0, plain.stderr[-800:]
+    t = subprocess.run([exe, "scorechain", fa, bam], capture_output=True, text=True, env=dict(os.environ, NP1_TILE_BP="3000000", NP1_TIMING="1"))
+    assert t.returncode == 0, t.stderr[-800:]
+    assert "in 8 tiles" in t.stderr and t.stderr.count("[np1 tiles]") == 1, t.stderr[-800:]
+    assert t.stdout == plain.stdout
+    assert list(parse_cli_fasta(t.stdout)) == list(st.names)

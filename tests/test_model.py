@@ -237,3 +237,20 @@ def test_model_kmer_count_general_indel_balance_factor(rate):
         got = mb.kmer_count(st, cfg)
         for i in range(st.n_contigs):
             assert got[i] == ob.kmer_count(st, i, ob.default_config(read_tlen=1500, indel_balance_factor_sgs=rate)), "seed %d" % seed
+
+
+def test_model_intra_contig_tiling_from_files_through_the_index(tmp_path):
+    """np1_tile.cpp's driver with the model as the device: every tile reads its own region of the BAM through the index
+    (load_stream_region), the join uses the driver's index arithmetic -- equal to the untiled oracle for tiles of 300 bases to a whole
+    contig and halos from one base up, on indel-rich reads with soft clips and odd CIGAR shapes"""
+    st = nat.Stream.synth([30000, 4000, 700], depth=20, seed=991, read_indel=0.005, softclip_rate=0.06, draft_lower=0.02, weird_rate=0.02)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "r.bam")
+    st.write_files(fa, bam)
+    want = [ob.score_chain(st, i) for i in range(st.n_contigs)]
+    redo = 0
+    for tile, halo in ((300, 1), (1700, 25), (9000, 200), (29999, 100), (50000, 10)):
+        for i, n in enumerate(st.names):
+            got, info = mb.score_chain_tiled_files(fa, bam, n, tile, halo, fused=(tile // 100) % 3)
+            assert got == want[i], (tile, halo, n, info)
+            redo += info["recomputed"]
+    assert redo > 0
