@@ -278,7 +278,7 @@ def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref, with_pmc):
         f.write(bam + "\n")
     go = os.path.join(d, "go")
     env = dict(os.environ, NP2_DEVICE=str(local_rank))
-    wt = os.environ.get("NP2_WORKER_THREADS", "4")   # several workers share the host cores of one GPU
+    wt = os.environ.get("NP2_WORKER_THREADS", "2")   # many workers share the host cores of one GPU (round-3 sweep: 24 x 2 > 16 x 4 > 12 x 4)
     env["NP_HOST_THREADS"] = wt
     env["NP_IO_THREADS"] = wt
     lib2 = os.path.join(ROOT, "nextpolish_amd", "lib", "nextpolish2.so")
@@ -580,9 +580,10 @@ def main():
     ap.add_argument("--pmc-batches", type=int, default=4, help="batches of the workload the two rocprofv3 --pmc child runs polish (generating all 600 M records twice more is most of a full-size run)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the from-files leg")
     ap.add_argument("--no-lgs", action="store_true", help="skip the long-read (nextpolish2) leg")
-    ap.add_argument("--lgs-workers", type=int, default=12, help="worker processes per GPU of the long-read leg")
+    ap.add_argument("--lgs-workers", type=int, default=24, help="worker processes per GPU of the long-read leg (x NP2_WORKER_THREADS host threads each, default 2)")
     ap.add_argument("--lgs-mb", type=float, default=5.0, help="contig length (Mb) each long-read worker polishes")
     ap.add_argument("--lgs-calls", type=int, default=4)
+    ap.add_argument("--no-lgs-config4", action="store_true", help="skip the 100 Mb / 67-contig long-read run (BASELINE configs[3] at its stated size)")
     ap.add_argument("--no-phase", action="store_true", help="skip the snp_phase (task 3) leg")
     ap.add_argument("--phase-mb", type=float, default=20.0, help="draft length (Mb) of the snp_phase leg")
     args = ap.parse_args()
@@ -749,6 +750,20 @@ def main():
         lgs_workers = args.lgs_workers if world == 1 else max(2, min(args.lgs_workers, (ncpu * 3 // 4) // world))   # the ranks share the host cores
         lgs = lgs_leg(rank, local_rank, lgs_workers, args.lgs_mb, args.lgs_calls,
                       rank == 0 and world == 1 and not args.no_cpu_baseline, rank == 0 and world == 1 and not args.no_pmc)
+        if world == 1 and rank == 0 and "error" not in lgs and not args.no_lgs_config4:
+            # BASELINE configs[3] at its stated size: ~100 Mb in 67 contigs (four of them two or three windows), 20x ONT-like reads, the contigs
+            # in 8 groups (one FASTA + BAM each) taken by worker processes like the reference's -p model: from cold processes to the last
+            # consensus, every contig compared with the md5 the compiled reference produced (tests/tools/check_config4.py, tests/golden/)
+            env4 = dict(os.environ, NP2_DEVICE=str(local_rank), NP_HOST_THREADS=os.environ.get("NP2_WORKER_THREADS", "2"), NP_IO_THREADS=os.environ.get("NP2_WORKER_THREADS", "2"))
+            q = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "check_config4.py"), "--procs", "8"], capture_output=True, text=True, env=env4)
+            try:
+                c4 = json.loads(q.stdout.strip().splitlines()[-1])
+                lgs["config4"] = {"mbp_s": c4.get("mbp_s"), "draft_bp": c4.get("draft_bp"), "contigs": c4.get("contigs"), "groups": c4.get("groups"), "procs": c4.get("procs"),
+                                  "polish_s": c4.get("polish_s"), "mismatches_vs_reference_golden": c4.get("mismatches"), "missing": c4.get("missing"),
+                                  "what": "100 Mb / 67 contigs / 20x ONT-like (BASELINE configs[3]), 8 cold worker processes sharing the GPU, process start and "
+                                          "first allocations included; every contig's md5 against the compiled reference's"}
+            except Exception as e:      # noqa: BLE001
+                lgs["config4"] = {"error": (q.stderr or str(e))[-300:]}
         if world > 1:   # whole job: bp of all ranks over the slowest rank's span
             tt = torch.tensor([float(lgs.get("bp", 0)), float(lgs.get("seconds", 0)), 1.0 if "error" in lgs else 0.0], device="cuda", dtype=torch.float64)
             bp_sum = tt.clone()
@@ -801,9 +816,9 @@ def main():
                 out["lgs"] = {"metric": "polished Mbp/s (ctg_cns_core, long reads, sorted BAM in the page cache -> consensus, warm workers)",
                               "value": round(lgs["bp"] / 1e6 / lgs["seconds"], 3), "unit": "Mbp/s", "n_gpus": world,
                               "config": {"workload": "%.1f Mb synthetic contig + 20x ONT-like reads (8 kb, 7%% errors) per worker, %d worker processes per GPU, "
-                                                     "%d calls each, %s host threads per worker" % (args.lgs_mb, lgs["workers"], args.lgs_calls, os.environ.get("NP2_WORKER_THREADS", "4"))},
+                                                     "%d calls each, %s host threads per worker" % (args.lgs_mb, lgs["workers"], args.lgs_calls, os.environ.get("NP2_WORKER_THREADS", "2"))},
                               "s_per_call": lgs["s_per_call"], "host_cpu_s_per_mbp": lgs["cpu_s_per_mbp"]}
-                for k in ("roofline", "cpu_baseline"):
+                for k in ("roofline", "cpu_baseline", "config4"):
                     if k in lgs:
                         out["lgs"][k] = lgs[k]
         if world == 1 and not args.no_cpu_baseline:

@@ -32,6 +32,8 @@
 #include "np_inflate_lane.h"
 #include "np_crc_dev.h"
 #include "np_crc32.h"
+#include "np_threads.h"
+#include <atomic>
 
 using namespace np1dev;
 
@@ -327,6 +329,10 @@ uint64_t Staging::compressed_bytes() const { return impl->comp_bytes; }
 // Host half: FASTA strings, the compressed extents of the batch's contigs into pinned memory, the block table, the anchors.
 // Returns 1 when this batch cannot take the device path (index without the per-contig offsets), 0 on success, -1 on error.
 int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, std::string* err) {
+    static const bool timing = getenv("NP1_TIMING") != nullptr;
+    auto now_ms = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_begin = now_ms();
+    double t_draft = 0, t_alloc = 0, t_read = 0;
     Staging::Impl& S = *st->impl;
     S.names = names;
     S.blocks.clear(); S.block_coff.clear(); S.block_size.clear(); S.segs.clear(); S.first_seg.clear(); S.ctg_off.assign(1, 0); S.ctg_len.clear();
@@ -341,7 +347,8 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
         tid[c] = src.hdr.name2id(names[c]);
     }
     if (draft_total >= 0xfff00000ull) { *err = "batch too large: draft must stay below 2^32 slots"; return -1; }
-    if (!S.draft.ensure(draft_total + 64)) { *err = "hipHostMalloc failed"; return -1; }
+    { const double t0 = now_ms(); if (!S.draft.ensure(draft_total + 64)) { *err = "hipHostMalloc failed"; return -1; } t_alloc += now_ms() - t0; }
+    const double t_d0 = now_ms();
     std::string seq;
     size_t at = 0;
     for (size_t c = 0; c < nc; ++c) {
@@ -351,6 +358,7 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
         S.ctg_len.push_back((int32_t)seq.size());
         S.ctg_off.push_back((uint32_t)at);
     }
+    t_draft = now_ms() - t_d0;
     // ---- compressed extents: [block of the contig's first record, block of the end of its last record]
     std::vector<std::pair<np::voff_t, np::voff_t>> vr(nc, {0, 0});
     for (size_t c = 0; c < nc; ++c) {
@@ -387,15 +395,30 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
     }
     uint64_t comp_at = 0, u_at = 0;
     for (Run& r : runs) { r.comp_at = comp_at; comp_at += r.bytes; }
-    if (!S.comp.ensure(comp_at + 4096)) { *err = "hipHostMalloc failed"; return -1; }
-    for (const Run& r : runs) {
-        uint64_t done = 0;
-        while (done < r.bytes) {
-            const ssize_t g = pread(src.fd, (char*)S.comp.p + r.comp_at + done, r.bytes - done, (off_t)(r.coff + done));
-            if (g <= 0) { *err = "BAM read failed"; return -1; }
-            done += (uint64_t)g;
-        }
+    { const double t0 = now_ms(); if (!S.comp.ensure(comp_at + 4096)) { *err = "hipHostMalloc failed"; return -1; } t_alloc += now_ms() - t0; }
+    const double t_r0 = now_ms();
+    {   // the file bytes in pieces of 16 MiB on the host threads: one thread's pread() moves ~2.6 GB/s out of the page cache, which made this
+        // function, not the device, the slowest stage of the from-files pipeline (round 4: 2.45 s of staging against 0.74 s of device work
+        // for a 250 Mb batch, profiles/r4_e2e_300mb_cli.txt)
+        struct Piece { uint64_t at, coff, bytes; };
+        std::vector<Piece> pieces;
+        for (const Run& r : runs)
+            for (uint64_t done = 0; done < r.bytes; done += (uint64_t)16 << 20)
+                pieces.push_back(Piece{r.comp_at + done, r.coff + done, std::min<uint64_t>((uint64_t)16 << 20, r.bytes - done)});
+        std::atomic<bool> ok{true};
+        np::parallel_for(pieces.size(), 1, [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi && ok; ++k) {
+                uint64_t done = 0;
+                while (done < pieces[k].bytes) {
+                    const ssize_t g = pread(src.fd, (char*)S.comp.p + pieces[k].at + done, pieces[k].bytes - done, (off_t)(pieces[k].coff + done));
+                    if (g <= 0) { ok = false; return; }
+                    done += (uint64_t)g;
+                }
+            }
+        });
+        if (!ok) { *err = "BAM read failed"; return -1; }
     }
+    t_read = now_ms() - t_r0;
     memset((char*)S.comp.p + comp_at, 0, 4096);
     for (const Run& r : runs) {
         uint64_t p = 0;
@@ -479,6 +502,9 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
             S.segs.push_back(Segment{anchors[a], a + 1 < anchors.size() ? anchors[a + 1] : ue, (uint32_t)c, (int32_t)tid[c], S.ctg_len[c], 0});
     }
     S.first_seg[nc] = (uint32_t)S.segs.size();
+    if (timing)
+        fprintf(stderr, "[np1 staging] %zu contigs, %.1f MB of draft, %.1f MB compressed | ms: pinned allocations %.1f  draft fetch %.1f  file reads %.1f  block table + segments %.1f\n",
+                nc, draft_total / 1e6, S.comp_bytes / 1e6, t_alloc, t_draft, t_read, now_ms() - t_begin - t_alloc - t_draft - t_read);
     return 0;
 }
 

@@ -66,6 +66,8 @@ def test_cli_with_tiling_equals_cli_without(tmp_path):
     assert plain.returncode == 0, plain.stderr[-800:]
     t = subprocess.run([exe, "scorechain", fa, bam], capture_output=True, text=True, env=dict(os.environ, NP1_TILE_BP="3000000", NP1_TIMING="1"))
     assert t.returncode == 0, t.stderr[-800:]
-    assert "in 8 tiles" in t.stderr and t.stderr.count("[np1 tiles]") == 1, t.stderr[-800:]
+    import re
+    m = re.findall(r"\[np1 tiles\] (\S+): (\d+) bases in (\d+) tiles", t.stderr)
+    assert len(m) == 1 and m[0][0] == st.names[1] and int(m[0][2]) == -(-int(m[0][1]) // 3000000) >= 8, t.stderr[-800:]
     assert t.stdout == plain.stdout
     assert list(parse_cli_fasta(t.stdout)) == list(st.names)

@@ -88,6 +88,38 @@ def test_fasta_with_odd_line_lengths(tmp_path):
     assert [st.contig_draft(i) for i in range(3)] == [b"ACGTACGT", b"ACG", b"TTTTTTTTTT"]
 
 
+def test_fasta_fetch_by_line_layout_and_its_fallback(tmp_path):
+    """Fai::fetch copies line by line on the host threads when the index's line layout holds (np_bam.cpp) and falls back to the
+    byte-by-byte walk when it does not: CRLF line ends, a last line that is full / partial / missing its newline, lines with blanks
+    inside (the index counts them, fai_fetch drops them), a contig of many jobs -- always what the plain reading gives"""
+    import random
+    rng = random.Random(5)
+    seqs = {"unix60": "".join(rng.choice("ACGTNacgtRYKM") for _ in range(60 * 41 + 17)),
+            "crlf70": "".join(rng.choice("ACGT") for _ in range(70 * 9)),
+            "one_line": "".join(rng.choice("ACGT") for _ in range(501)),
+            "blanks": "".join(rng.choice("ACGT") for _ in range(50 * 7 + 3)),
+            "big": "".join(rng.choice("ACGT") for _ in range(100 * 90000 + 55))}
+    fa = tmp_path / "layout.fa"
+    with open(fa, "wb") as f:
+        def lines(s, w):
+            return [s[i:i + w] for i in range(0, len(s), w)]
+        f.write(b">unix60\n" + "\n".join(lines(seqs["unix60"], 60)).encode() + b"\n")
+        f.write(b">crlf70 x\r\n" + "\r\n".join(lines(seqs["crlf70"], 70)).encode() + b"\r\n")
+        f.write(b">one_line\n" + seqs["one_line"].encode() + b"\n")
+        bl = lines(seqs["blanks"], 50)
+        bl[2] = bl[2][:20] + " " + bl[2][20:]              # a blank inside a line: same byte width as the others would have with 51
+        f.write(b">blanks\n" + "\n".join(bl).encode() + b"\n")
+        f.write(b">big\n" + "\n".join(lines(seqs["big"], 100)).encode())     # no newline at the end of the file
+    names = list(seqs)
+    if "blanks" in names:
+        pass
+    bam = str(tmp_path / "e.bam")
+    nat.Stream.from_reads([(n, seqs[n]) for n in names], []).write_files(str(tmp_path / "tmp.fa"), bam)
+    st = nat.Stream.load(str(fa), bam)
+    for i, n in enumerate(names):
+        assert st.contig_draft(i) == seqs[n].encode(), n
+
+
 def test_config_init_defaults_and_insert_probe(tmp_path):
     st = nat.Stream.synth([20000], depth=30, seed=23, with_qual=1)
     fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "g.bam")
