@@ -508,7 +508,7 @@ def e2e_from_files(streams, draft_bp, threads, n_records):
     from nextpolish_amd.device import Pipe
     d = tempfile.mkdtemp(prefix="np1e2e_")
     out = {}
-    pipe = Pipe(int(os.environ.get("LOCAL_RANK", "0")), lanes=int(os.environ.get("NP1_E2E_LANES", "2")))
+    pipe = Pipe(int(os.environ.get("LOCAL_RANK", "0")), lanes=int(os.environ.get("NP1_E2E_LANES", "3")))      # round-4 sweep (tests/tools/r4_e2e_lanes.py): 3 > 2 > 4
     try:
         fa, bam = os.path.join(d, "g.fa"), os.path.join(d, "r.bam")
         t_write = _write_files(streams, fa, bam, 1)
@@ -538,29 +538,46 @@ def e2e_from_files(streams, draft_bp, threads, n_records):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def parity_check(pipe, streams, budget_bp):
-    """Polished strings of this run (the last streamed pass) against the CPU oracle, shortest contigs first up to budget_bp."""
+def parity_check(pipe, streams, budget_bp, per_batch_cap_bp=40000000):
+    """Polished strings of this run (the last streamed pass) against the CPU oracle: the shortest contigs of the draft up to budget_bp AND
+    the shortest contig of EVERY batch (so that each batch of the pass is represented; a batch whose shortest contig exceeds
+    per_batch_cap_bp is listed as unchecked).  The oracle calls run side by side on the host cores."""
     import ctypes as C
     import hashlib
     from nextpolish_amd import _native as nat
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     cand = sorted((int(st.ctg_len[c]), k, c) for k, st in enumerate(streams) for c in range(st.n_contigs))
-    n, bp, bad = 0, 0, []
-    t0 = time.time()
-    ln = C.c_int64(0)
+    chosen, bp = [], 0
     for L, k, c in cand:
-        if n >= 1 and bp + L > budget_bp:
+        if chosen and bp + L > budget_bp:
             break
+        chosen.append((L, k, c))
+        bp += L
+    unchecked = []
+    for k, st in enumerate(streams):
+        if any(kk == k for _, kk, _ in chosen) or st.n_contigs == 0:
+            continue
+        L, c = min((int(st.ctg_len[c]), c) for c in range(st.n_contigs))
+        if L <= per_batch_cap_bp:
+            chosen.append((L, k, c))
+        else:
+            unchecked.append(k)
+    t0 = time.time()
+
+    def one(item):
+        L, k, c = item
+        ln = C.c_int64(0)
         p = nat.lib().np1_pipe_result(pipe.handle, k, c, C.byref(ln))
         got = C.string_at(p, ln.value)
         want = ob.score_chain(streams[k], c).encode()
-        if hashlib.md5(got).digest() != hashlib.md5(want).digest():
-            bad.append(streams[k].names[c])
-        n += 1
-        bp += L
-    return {"contigs": n, "draft_bp": bp, "identical": not bad, "differing": bad, "oracle_seconds": round(time.time() - t0, 1),
-            "what": "md5 of the polished strings of the timed streamed passes vs oracle/np1_oracle (CPU restatement), shortest contigs of the draft"}
+        return None if hashlib.md5(got).digest() == hashlib.md5(want).digest() else streams[k].names[c]
+    with ThreadPoolExecutor(max(1, min(host_cores(), len(chosen)))) as ex:
+        bad = [x for x in ex.map(one, sorted(chosen, reverse=True)) if x is not None]
+    return {"contigs": len(chosen), "draft_bp": sum(x[0] for x in chosen), "batches_represented": len({k for _, k, _ in chosen}), "batches": len(streams),
+            "batches_unchecked": unchecked, "identical": not bad, "differing": bad, "oracle_seconds": round(time.time() - t0, 1),
+            "what": "md5 of the polished strings of the timed streamed passes vs oracle/np1_oracle (CPU restatement): the shortest contigs of the draft and "
+                    "the shortest contig of every batch (up to %d Mb each)" % (per_batch_cap_bp // 1000000)}
 
 
 def main():

@@ -3,7 +3,7 @@
 //   nextpolish1 <scorechain|kmercount|snpphase|snpvalid|lgspolish> fasta bam [bam3]
 // prints ">name_<step>\nseq" per contig in FASTA-index order.  Unlike the reference, which loops
 // score_chain contig by contig, the contigs travel to the GPU in batches of NP1_BATCH_BP draft bases (default 16 M) on
-// NP1_LANES device lanes (default 2) while host threads inflate and split the records of the next batches (np1_pipe.cpp).
+// NP1_LANES device lanes (default 3) while host threads inflate and split the records of the next batches (np1_pipe.cpp).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,7 +47,7 @@ int main(int argc, char* argv[]) {
     if (step == 1 || step == 2) {
         if (!cfg->bamfn) { fprintf(stderr, "cannot access BAM %s\n", argv[3]); return 1; }
         // contigs flow through the device in batches (FASTA-index order), loaders and lanes overlapped: np1_pipe.cpp
-        int dev = 0, lanes = 2;
+        int dev = 0, lanes = 3;      // (from files the device ingest of one batch runs under the kernels of the others: 3 lanes > 2 > 4, tests/tools/r4_e2e_lanes.py)
         long long batch_bp = 16000000;
         if (const char* e = getenv("NP1_DEVICE")) dev = atoi(e);
         if (const char* e = getenv("NP1_LANES")) lanes = atoi(e);
