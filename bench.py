@@ -312,7 +312,7 @@ def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref, with_pmc):
         files = []
 
         def make(k):
-            s1 = nat.Stream.synth_long([1000000], depth=20.0, seed=4242 + k)
+            s1 = nat.Stream.synth_long([2000000], depth=20.0, seed=4242 + k)
             fa1, bam1, fofn1 = os.path.join(d, "g1_%d.fa" % k), os.path.join(d, "r1_%d.bam" % k), os.path.join(d, "bam1_%d.fofn" % k)
             s1.write_files(fa1, bam1)
             s1.close()
@@ -338,7 +338,7 @@ def lgs_leg(rank, local_rank, workers, contig_mb, calls, with_ref, with_pmc):
         allc, one = run_ref(range(ncore)), run_ref([0])
         if allc and one:
             res["cpu_baseline"] = {"value": round(allc[0], 4), "unit": "Mbp/s", "cores": ncore, "kind": "reference", "one_core": round(one[0], 4),
-                                   "sample": "%d processes x 1 Mb synthetic contig, 20x ONT-like reads, ctg_cns_core of oracle/_ref/nextpolish2.so, %.1f s; "
+                                   "sample": "%d processes x 2 Mb synthetic contig, 20x ONT-like reads, ctg_cns_core of oracle/_ref/nextpolish2.so, %.1f s; "
                                              "one process alone %.1f s" % (ncore, allc[1], one[1])}
     shutil.rmtree(d, ignore_errors=True)
     return res
@@ -599,7 +599,7 @@ def main():
     ap.add_argument("--no-lgs", action="store_true", help="skip the long-read (nextpolish2) leg")
     ap.add_argument("--lgs-workers", type=int, default=24, help="worker processes per GPU of the long-read leg (x NP2_WORKER_THREADS host threads each, default 2)")
     ap.add_argument("--lgs-mb", type=float, default=5.0, help="contig length (Mb) each long-read worker polishes")
-    ap.add_argument("--lgs-calls", type=int, default=4)
+    ap.add_argument("--lgs-calls", type=int, default=8, help="timed calls per long-read worker (the rate is bp over the span from the common start to the last end: few calls leave the stragglers idle)")
     ap.add_argument("--no-lgs-config4", action="store_true", help="skip the 100 Mb / 67-contig long-read run (BASELINE configs[3] at its stated size)")
     ap.add_argument("--no-phase", action="store_true", help="skip the snp_phase (task 3) leg")
     ap.add_argument("--phase-mb", type=float, default=20.0, help="draft length (Mb) of the snp_phase leg")

@@ -56,6 +56,9 @@ struct WindowInput {
     RecordSet recs;                     // candidate records in merge order
     RecordSet sup;                      // supplementary alignments (read bases of the primary, CIGAR of the supplementary record)
     bool want_tags = false;             // copy the tag streams back to the host too (only the structural layer reads them there)
+    // > 0: the executor may also mark where the low-quality scans of the window consensus have anything to look at (WindowOutput::
+    // trig_del / trig_ins, ctg_cns.c:1562-1725 loop heads) with this gap_min_ratio1; the scans then visit those positions only
+    float lq_ratio1 = 0.f;
     std::vector<StreamRef> streams;     // the streams to pile up, in order (the seed -- the window against itself -- comes first, implicitly)
 };
 
@@ -68,6 +71,10 @@ struct WindowOutput {
     std::vector<uint32_t> aln_t_s, aln_t_e;
     std::vector<uint8_t> tags;
     std::vector<ConsBase> cons;                   // main-line consensus, window order (before the LQ stage)
+    // Optional (empty = not computed: the scans test every position themselves).  Bit i of word i / 64:
+    //   trig_del  consensus base i (i >= 1) passes the loop head of get_l_del_regions: NOT (l_del < coverage * 0.3 and pos < previous pos + 20)
+    //   trig_ins  consensus base i passes the loop head of the insertion scan: NOT ((float) l_ins < (float) coverage * gap_min_ratio1)
+    std::vector<uint64_t> trig_del, trig_ins;
 };
 
 // the concatenated low-quality regions of a window: up to 30 gapped string pairs over one target coordinate space

@@ -774,6 +774,23 @@ __global__ __launch_bounds__(256) void k2_match(MsaView mv, const uint32_t* __re
     }
     match[g] = mt;
 }
+// Where the low-quality scans of the window consensus have anything to look at (ctg_cns.c:1562-1725: the loop heads of get_l_del_regions
+// and of the insertion scan), one bit per consensus base, written a 64-bit word per wave.  The comparisons are the reference's own:
+// int against double for the deletion rule, float against float for the insertion rule (no contraction: -ffp-contract=off).
+__global__ __launch_bounds__(256) void k2_lq_triggers(const ConsBase* __restrict__ cb, uint32_t len, const ColStat* __restrict__ st, float ratio1,
+                                                      unsigned long long* __restrict__ trig_del, unsigned long long* __restrict__ trig_ins) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool del = false, ins = false;
+    if (i < len) {
+        const uint32_t pos = cb[i].pos;
+        const ColStat c = st[pos];
+        if (i >= 1) del = !((double)c.l_del < (double)c.coverage * 0.3 && pos < cb[i - 1].pos + 20u);
+        ins = !((float)c.l_ins < (float)c.coverage * ratio1);
+    }
+    const unsigned long long md = __ballot(del), mi = __ballot(ins);
+    if ((threadIdx.x & 63) == 0 && i < ((len + 63u) & ~63u)) { trig_del[i >> 6] = md; trig_ins[i >> 6] = mi; }
+}
+
 
 __global__ void k2_pack_stat(const uint32_t* coverage, const uint32_t* max_size, const uint32_t* l_ins, const uint32_t* l_del,
                              uint32_t n, ColStat* st, uint32_t seed_len, const uint32_t* cov_pre, const uint32_t* cov_diff, uint32_t* col_cnt) {
@@ -1906,7 +1923,7 @@ class HipExec : public Exec {
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
     DevBuf runsz_, runoff_, live_, ematch_, xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
     DevBuf tilecnt_, tileoff_, tilecur_, tilelist_, tilectr_, ntags_, colne_, runflag_, runlist_, runctr_, tileredo_;
-    DevBuf poapool_, poaoff_, poalen_, poajobs_, poatabs_, poatabf_, poaout_, poaolen_, poastat_;
+    DevBuf poapool_, poaoff_, poalen_, poajobs_, poatabs_, poatabf_, poaout_, poaolen_, poastat_, trig_;
     bool graph_compact_ = false;   // the graph in HBM was built by tiles: columns are contiguous, every entry slot is live
     DevBuf ondpool_, ondregs_, ondcoff_, ondclen_, ondpairof_, ondpairs_, ondres_, ondout_, ondv_, ondlo_, ondch_, ondplen_, ondpkind_, ondppos_, ondtot_;
     PinBuf pin_;
@@ -2062,6 +2079,17 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     // consensus + column statistics (8 B per draft base each) come back through a pinned staging buffer (DMA at link
     // speed) and are copied out by the host thread pool; pageable targets would cost ~4x the time on one core
     const size_t cons_bytes = sizeof(ConsBase) * (size_t)cons_len, stat_bytes = sizeof(ColStat) * (size_t)n_cols;
+    static const bool lq_triggers = !(getenv("NP2_LQ_TRIGGERS") && getenv("NP2_LQ_TRIGGERS")[0] == '0');
+    const size_t trig_words = (in.lq_ratio1 > 0.f && lq_triggers && cons_len) ? ((size_t)cons_len + 63) / 64 : 0;
+    out->trig_del.assign(trig_words, 0);
+    out->trig_ins.assign(trig_words, 0);
+    if (trig_words) {      // the loop heads of the low-quality scans, evaluated for every consensus base where the data lies
+        if (!trig_.ensure(16 * trig_words + 64)) { *err = "out of device memory (low-quality triggers)"; return false; }
+        k2_lq_triggers<<<nblk((cons_len + 63u) & ~63u, 256), 256, 0, q>>>(cons_.as<ConsBase>(), cons_len, stat_.as<ColStat>(), in.lq_ratio1,
+                                                                          trig_.as<unsigned long long>(), trig_.as<unsigned long long>() + trig_words);
+        HIPOK(hipMemcpyAsync(out->trig_del.data(), trig_.p, 8 * trig_words, hipMemcpyDeviceToHost, q));
+        HIPOK(hipMemcpyAsync(out->trig_ins.data(), trig_.as<unsigned long long>() + trig_words, 8 * trig_words, hipMemcpyDeviceToHost, q));
+    }
     if (!pin_.ensure(cons_bytes + stat_bytes + 64)) { *err = "out of pinned host memory (window download)"; return false; }
     uint8_t* pin = static_cast<uint8_t*>(pin_.p);
     if (cons_len) HIPOK(hipMemcpyAsync(pin, cons_.p, cons_bytes, hipMemcpyDeviceToHost, q));

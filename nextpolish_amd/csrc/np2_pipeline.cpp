@@ -228,7 +228,28 @@ struct LqCtx {
     int reads_type;
     float gap_min_ratio1;
     const std::vector<np2::LqCluster>* clusters;
+    // where the two scans have anything to look at, marked by the executor (np2_exec.h: WindowOutput::trig_*); null: test every position
+    const std::vector<uint64_t>* trig_del = nullptr;
+    const std::vector<uint64_t>* trig_ins = nullptr;
 };
+
+// next set bit at or above i (ascending scans) / at or below i (descending scans) of a bitmap over [0, len); len / -1 when there is none
+inline int next_bit_up(const std::vector<uint64_t>& m, int i, int len) {
+    while (i < len) {
+        const uint64_t w = m[(size_t)i >> 6] >> (i & 63);
+        if (w) { i += __builtin_ctzll(w); return i < len ? i : len; }
+        i = (i | 63) + 1;
+    }
+    return len;
+}
+inline int next_bit_down(const std::vector<uint64_t>& m, int i) {
+    while (i >= 0) {
+        const uint64_t w = m[(size_t)i >> 6] << (63 - (i & 63));
+        if (w) return i - __builtin_clzll(w);
+        i = (i & ~63) - 1;
+    }
+    return -1;
+}
 
 int cal_del_pos(const std::vector<ColStat>& m, int s, int e) {
     int validy = 0;
@@ -244,8 +265,12 @@ std::vector<Del> l_del_regions(const LqCtx& x) {
     std::vector<Del> dels;
     int ps = 0, pe = 0;
     auto st = [&](int i) -> const ColStat& { return msa[(size_t)cb[(size_t)i].pos]; };
+    const bool marked = x.trig_del && x.trig_del->size() * 64 >= (size_t)len;
     for (int i = 1; i < len; ++i) {
-        if (st(i).l_del < st(i).coverage * 0.3 && cb[(size_t)i].pos < cb[(size_t)i - 1].pos + 20) continue;
+        if (marked) {      // (the executor evaluated the loop head for every position; only the marked ones are visited)
+            i = next_bit_up(*x.trig_del, i, len);
+            if (i >= len) break;
+        } else if (st(i).l_del < st(i).coverage * 0.3 && cb[(size_t)i].pos < cb[(size_t)i - 1].pos + 20) continue;
         if (i >= ps && i <= pe) continue;
         int s = i - 1;
         while (s > 0 && st(s).l_del > st(s).coverage * 0.3) --s;
@@ -327,8 +352,12 @@ std::vector<LqReg> lq_regions(const LqCtx& x) {
     const std::vector<np2::LqCluster>& clusters = *x.clusters;
     int clusters_i = (int)clusters.size();
     auto st = [&](int i) -> const ColStat& { return msa[(size_t)cb[(size_t)i].pos]; };
+    const bool marked = x.trig_ins && x.trig_ins->size() * 64 >= (size_t)len;
     for (int i = len - 1; i >= 0; --i) {
-        if ((float)st(i).l_ins < (float)st(i).coverage * x.gap_min_ratio1) continue;
+        if (marked) {
+            i = next_bit_down(*x.trig_ins, i);
+            if (i < 0) break;
+        } else if ((float)st(i).l_ins < (float)st(i).coverage * x.gap_min_ratio1) continue;
         if (st(i).l_ins < st(i).coverage * 0.1) {
             const int s0 = (int)cb[(size_t)i].pos - 10;
             const int e0 = (int)cb[(size_t)i].pos + 10;
@@ -811,6 +840,7 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
         }
         lap("keep rules + structural");
         in.want_tags = sv.brk_g != 0;   // generate_gapseqs walks the split reads' streams on the host
+        in.lq_ratio1 = reads_type == np2k::READS_HIFI ? 0.f : gap_min_ratio1;   // the executor marks where the low-quality scans have to look (NP2_LQ_TRIGGERS=0: off)
         if (!cfg->exec->run_window(in, &out, &err)) np2_die(err.c_str(), ref->n);
         lap("window (executor)");
         std::vector<np2::LqCluster> clusters;
@@ -844,7 +874,7 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
         if (reads_type == np2k::READS_HIFI) {
             regs = hifi_regions(&out.cons, out.stat, clusters);   // also applies the HiFi case rule (qv > 80)
         } else {
-            LqCtx lx{&out.stat, &out.cons, reads_type, gap_min_ratio1, &clusters};
+            LqCtx lx{&out.stat, &out.cons, reads_type, gap_min_ratio1, &clusters, out.trig_del.empty() ? nullptr : &out.trig_del, out.trig_ins.empty() ? nullptr : &out.trig_ins};
             for (const LqReg& q : lq_regions(lx)) regs.push_back(np2::LqRegionIn{q.start, q.end, q.l});
         }
         lap("lq regions");

@@ -201,6 +201,21 @@ class HostExec : public Exec {
             if (key_tpos(cur) == -1) break;
         }
         std::reverse(out->cons.begin(), out->cons.end());
+        // where the low-quality scans have anything to look at (the HIP executor's k2_lq_triggers, restated): NP2_LQ_TRIGGERS=0 leaves
+        // the lists empty and the scans test every position themselves, as they did before round 4
+        out->trig_del.clear();
+        out->trig_ins.clear();
+        if (in.lq_ratio1 > 0.f && !(getenv("NP2_LQ_TRIGGERS") && getenv("NP2_LQ_TRIGGERS")[0] == '0') && !out->cons.empty()) {
+            const size_t len = out->cons.size();
+            out->trig_del.assign((len + 63) / 64, 0);
+            out->trig_ins.assign((len + 63) / 64, 0);
+            for (size_t i = 0; i < len; ++i) {
+                const uint32_t pos = out->cons[i].pos;
+                const ColStat c = out->stat[pos];
+                if (i >= 1 && !((double)c.l_del < (double)c.coverage * 0.3 && pos < out->cons[i - 1].pos + 20u)) out->trig_del[i >> 6] |= 1ull << (i & 63);
+                if (!((float)c.l_ins < (float)c.coverage * in.lq_ratio1)) out->trig_ins[i >> 6] |= 1ull << (i & 63);
+            }
+        }
         win_tags_ = out->tags;
         win_tag_off_ = out->tag_off;
         win_ts_ = out->aln_t_s;
