@@ -8,6 +8,7 @@
  */
 #include "np1_oracle.h"
 
+#include <ctype.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
@@ -513,17 +514,40 @@ static void score_correct(octg* c, int32_t start, int32_t end, int32_t flag, dou
     }
 }
 
-/* contig_get_contig without the trace list (reference: source/lib/contig.c:736-799) */
+/* contig_get_contig (reference: source/lib/contig.c:736-799).  With cfg->trace_polish_open the change list (PolishPoint: pos, index,
+ * curbase, base -- contig.c:743-797) of the call is kept per thread and read back with np1o_last_points; every task ends here. */
+static __thread int32_t* g_points = NULL;      /* 4 words per point: pos, index, curbase, base */
+static __thread int32_t g_npoints = 0, g_cappoints = 0;
+static void point_add(int32_t pos, int32_t index, char cur, char was) {
+    if (g_npoints == g_cappoints) {
+        g_cappoints = g_cappoints ? 2 * g_cappoints : 1024;
+        g_points = (int32_t*)realloc(g_points, (size_t)g_cappoints * 4 * sizeof(int32_t));
+    }
+    int32_t* p = g_points + 4 * (size_t)g_npoints++;
+    p[0] = pos; p[1] = index; p[2] = (uint8_t)cur; p[3] = (uint8_t)was;
+}
+int32_t np1o_last_points(const int32_t** out) {
+    *out = g_points;
+    return g_npoints;
+}
 static char* get_contig(octg* c, int32_t start, int32_t end, uint8_t flag, int32_t* out_len) {
     int32_t i = start, j = 0, length = 0;
     char* result = (char*)calloc(1, (size_t)c->L + (size_t)c->inslength + 1), *q = result;
     oslot* p = &c->b[start].m;
     uint8_t sign = 0;
+    const int trace = c->cfg->trace_polish_open != 0;
+    g_npoints = 0;
     while (IN_RANGE(i, j, end)) {
+        const char was = (char)toupper((unsigned char)c->in->draft[i]);
         if (p->base == 3) {
             if ((p->flag & flag) != 0) sign = 1;
+            if (trace && j == 0) point_add(i, j, '.', was);
         } else {
             *q = basetostr[p->base];
+            if (trace) {
+                if (j != 0) point_add(i, j, *q, '.');
+                else if (*q != was) point_add(i, j, *q, was);
+            }
             if (sign || (p->flag & flag) != 0) { *q += 32; sign = 0; }
             q++;
             length++;

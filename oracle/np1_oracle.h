@@ -83,6 +83,9 @@ char* np1o_snp_valid(const np1o_contig* c, const np1o_configure* cfg, int32_t* o
  * qualities).  NULL with *out_len = -1 where the reference's own result rests on a null / uninitialised read. */
 char* np1o_snp_phase(const np1o_contig* sr, const np1o_contig* lr, const np1o_configure* cfg, int32_t* out_len);
 void np1o_snp_phase_stats(int64_t out[10]);   /* what the stages of the last np1o_snp_phase call did (np1_oracle.c: g_sp_stats) */
+/* the change list of the calling thread's last task call made with cfg->trace_polish_open set (reference: source/lib/contig.c:743-797):
+ * 4 words per point (pos, index, curbase, base); returns the number of points; the array stays the oracle's */
+int32_t np1o_last_points(const int32_t** out);
 void np1o_free(void* p);
 
 /* Algorithmic update count of score_chain's pileup (one per slot vote), for throughput reports. */

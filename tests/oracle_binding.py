@@ -235,3 +235,13 @@ def snp_phase_stats():
     a = (C.c_int64 * 10)()
     lib().np1o_snp_phase_stats(a)
     return list(a)
+
+
+def last_points():
+    """the change list (PolishPoint: [pos, index, curbase, base]) of this thread's last oracle call made with trace_polish_open = 1"""
+    p = C.POINTER(C.c_int32)()
+    f = lib().np1o_last_points
+    f.restype = C.c_int32
+    f.argtypes = [C.POINTER(C.POINTER(C.c_int32))]
+    n = f(C.byref(p))
+    return [[p[4 * k], p[4 * k + 1], chr(p[4 * k + 2]), chr(p[4 * k + 3])] for k in range(n)]

@@ -65,6 +65,52 @@ def test_golden_file_covers_all_three_tasks_with_nonempty_lists():
     assert all(v > 50 for v in n.values()), n
 
 
+@pytest.mark.parametrize("k", range(len(GOLD["synth"])))
+def test_oracle_change_lists_equal_the_compiled_reference_on_synthetic_workloads(k):
+    """(CPU) the oracle's restatement of the list (np1_oracle.c: get_contig) against the goldens of the compiled reference, tasks 2 and 4"""
+    import oracle_binding as ob
+    e = GOLD["synth"][k]
+    kw = dict(e["params"])
+    lens = kw.pop("lens")
+    st = nat.Stream.synth(lens, **kw)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fa, bam = os.path.join(td, "s.fa"), os.path.join(td, "s.bam")
+        st.write_files(fa, bam)
+        cp = nat.lib().config_init(fa.encode(), bam.encode(), None)
+        ocfg = ob.default_config(read_tlen=cp.contents.read_tlen, read_len=cp.contents.read_len, trace_polish_open=1)
+        nat.lib().config_destory(cp)
+        for task, fn in (("kmer_count", ob.kmer_count), ("snp_valid", ob.snp_valid)):
+            for i, n in enumerate(st.names):          # contig by contig from the files, the iterator replayed like the reference on files
+                st2 = nat.Stream.load(fa, bam, names=[n], with_qual=True)
+                seq = fn(st2, 0, ocfg, ob.Geometry(st2, bam))
+                got = digest_points(ob.last_points())      # the list of this thread's last call
+                st2.close()
+                assert hashlib.md5(seq.encode()).hexdigest() == e[task][i]["seq_md5"]
+                assert (got["n"], got["md5"]) == (e[task][i]["n"], e[task][i]["md5"]), (task, n, got["head"], e[task][i]["head"])
+
+
+@pytest.mark.parametrize("k", range(len(GOLD["synth3"])))
+def test_oracle_change_lists_of_snp_phase_equal_the_compiled_reference(k):
+    """(CPU) task 3: the oracle's list against the reference's on the seeded diploid workloads"""
+    import oracle_binding as ob
+    import tempfile
+    e = GOLD["synth3"][k]
+    ctgs, srs, lrs = snpphase_gen.make_case(**e["params"])
+    s, l = nat.Stream.from_reads(ctgs, srs), nat.Stream.from_reads(ctgs, lrs)
+    with tempfile.TemporaryDirectory() as td:
+        fa, bam = os.path.join(td, "s.fa"), os.path.join(td, "s.bam")
+        s.write_files(fa, bam)
+        cp = nat.lib().config_init(fa.encode(), bam.encode(), None)
+        ocfg = ob.default_config(read_tlen=cp.contents.read_tlen, read_len=cp.contents.read_len, trace_polish_open=1)
+        nat.lib().config_destory(cp)
+    for i in range(len(ctgs)):
+        seq = ob.snp_phase(s, l, i, ocfg)
+        got = digest_points(ob.last_points())
+        assert hashlib.md5(seq.encode()).hexdigest() == e["snp_phase"][i]["seq_md5"]
+        assert (got["n"], got["md5"]) == (e["snp_phase"][i]["n"], e["snp_phase"][i]["md5"]), (i, got["head"], e["snp_phase"][i]["head"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", sorted(GOLD["real"]))
 def test_gpu_dropin_symbols_give_the_reference_change_lists_on_real_alignments(tag):
