@@ -169,6 +169,10 @@ int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passe
     return 0;
 }
 
+// BGZF blocks the device-side ingest handed back to the host since the pipe was opened (a block its decoder does not accept, or one whose
+// CRC it found wrong: the host inflates and checks it again); 0 on well-formed files
+uint64_t np1_pipe_host_inflated_blocks(np1_pipe* p) { return p ? p->host_inflated_blocks : 0; }
+
 void np1_pipe_close(np1_pipe* p) {
     if (!p) return;
     for (np1_batch* b : p->phase_lr) if (b) np1_batch_free(b);

@@ -36,14 +36,28 @@ inline void crc_shift_table(uint32_t* out) {
     for (int i = 0; i < 64; ++i) { out[i] = v; v = crc_mulmod(v, x8k); }
 }
 
-// 256-entry byte table into LDS by the first 256 threads of a workgroup (call before a barrier)
+// Four 256-entry tables into LDS by the first 256 threads of a workgroup (slicing by four: tab[k * 256 + b] = the CRC state a byte b
+// leaves k bytes further on).  Contains the barriers it needs; every thread of the workgroup has to call it.
+// Round 4: the byte-wise loop was one chain of dependent LDS lookups per byte (1 024 of them per lane and block, ~100 cycles each: the
+// kernel was bound by that latency, 7 % of the device time of the from-files pipeline); with four tables a word is four INDEPENDENT
+// lookups, the chain is one lookup per word.
 __device__ __forceinline__ void crc_table_build(uint32_t* tab) {
+    uint32_t c = 0;
     if (threadIdx.x < 256) {
-        uint32_t c = threadIdx.x;
+        c = threadIdx.x;
 #pragma unroll
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
         tab[threadIdx.x] = c;
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        if (threadIdx.x < 256) {
+            c = (c >> 8) ^ tab[c & 0xffu];
+            tab[k * 256 + threadIdx.x] = c;
+        }
+    }
+    __syncthreads();
 }
 
 // CRC-32 (zlib's crc32) of p[0 .. len), len <= 65536, computed by one wave; the result is the same in every lane
@@ -56,10 +70,7 @@ __device__ __forceinline__ uint32_t crc_block_wave(const uint8_t* __restrict__ p
     for (; i < hi && ((uintptr_t)(p + i) & 3u); ++i) c = tab[(c ^ p[i]) & 0xffu] ^ (c >> 8);
     for (; i + 4 <= hi; i += 4) {
         c ^= *reinterpret_cast<const uint32_t*>(p + i);
-        c = tab[c & 0xffu] ^ (c >> 8);
-        c = tab[c & 0xffu] ^ (c >> 8);
-        c = tab[c & 0xffu] ^ (c >> 8);
-        c = tab[c & 0xffu] ^ (c >> 8);
+        c = tab[768 + (c & 0xffu)] ^ tab[512 + ((c >> 8) & 0xffu)] ^ tab[256 + ((c >> 16) & 0xffu)] ^ tab[c >> 24];
     }
     for (; i < hi; ++i) c = tab[(c ^ p[i]) & 0xffu] ^ (c >> 8);
     c = hi > lo ? ~c : 0u;                            // an empty piece contributes nothing
@@ -76,9 +87,8 @@ constexpr uint32_t CRC_MISMATCH = 0x43524321u;
 template <class Desc>
 __device__ __forceinline__ void crc_check_body(const uint8_t* __restrict__ comp, const Desc* __restrict__ blocks, uint32_t n_blocks, const uint8_t* __restrict__ out,
                                                uint32_t* __restrict__ status, const uint32_t* __restrict__ shift) {
-    __shared__ uint32_t tab[256];
+    __shared__ uint32_t tab[1024];
     crc_table_build(tab);
-    __syncthreads();
     const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= n_blocks) return;
     const Desc d = blocks[b];

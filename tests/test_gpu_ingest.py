@@ -260,3 +260,24 @@ def test_lane_per_block_decoder_and_compact_upload_form_in_processes_of_their_ow
         p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"] + args, cwd=os.path.dirname(here),
                            env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=1200)
         assert p.returncode == 0 and " passed" in p.stdout, "%r\n%s\n%s" % (env_add, p.stdout[-3000:], p.stderr[-2000:])
+
+
+def test_device_crc_accepts_every_block_of_well_formed_files(tmp_path):
+    """the device-side CRC-32 (np_crc_dev.h: four tables, a word per step, 64 pieces per block joined by carry-less multiplication) agrees
+    with the gzip trailers of every block: no block of a samtools-written BAM or of this library's writer goes back to the host decoder"""
+    from nextpolish_amd.device import Pipe
+    L = nat.lib()
+    L.np1_pipe_host_inflated_blocks.restype = C.c_uint64
+    L.np1_pipe_host_inflated_blocks.argtypes = [C.c_void_p]
+    st = nat.Stream.synth([400000, 90000, 1500], depth=30, seed=81, with_qual=1)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "r.bam")
+    st.write_files(fa, bam)
+    real = os.path.join(ROOT, "tests", "golden", "real")
+    pipe = Pipe(0, lanes=2)
+    try:
+        out = pipe.run_files(fa, bam, batch_bp=200000)
+        assert [n for n, _ in out] == list(st.names)
+        pipe.run_files(os.path.join(real, "g.fa"), os.path.join(real, "sgs.sort.bam"))
+        assert L.np1_pipe_host_inflated_blocks(pipe.handle) == 0
+    finally:
+        pipe.close()
