@@ -156,12 +156,49 @@ def polish_batched(args, cfg, names, device, emit):
     names = [n for n in names if n in lengths]
     if not names:
         return
+    # --tile_bp (task 1): a contig longer than that is polished as independent tiles with a halo and joined exactly (np1_tile.cpp;
+    # the reference takes contigs up to 2^31 bases in one score_chain call, source/nextPolish:101-102) -- it need not fit an HBM batch.
+    # The runs of shorter contigs between such contigs go through the pipe as before, so the output keeps the order of `names`.
+    tile_bp = args.tile_bp if args.task == 1 else 0
     pipe = Pipe(device, args.lanes)
+    ctx = None
     try:
-        pipe.run_files(args.genome, args.bam_sgs, names=names, batch_bp=args.batch_bp, cfg=cfg.contents, task=args.task,
-                       sink=lambda name, seq: emit(name, seq, []))
+        run = []
+
+        def flush():
+            if run:
+                pipe.run_files(args.genome, args.bam_sgs, names=run, batch_bp=args.batch_bp, cfg=cfg.contents, task=args.task,
+                               sink=lambda name, seq: emit(name, seq, []))
+                del run[:]
+        for n in names:
+            if tile_bp <= 0 or lengths[n] <= tile_bp:
+                run.append(n)
+                continue
+            flush()
+            if ctx is None:
+                from nextpolish_amd.device import Context
+                ctx = Context(device)
+            emit(n, score_chain_tiled(ctx, args.genome, args.bam_sgs, n, cfg, tile_bp, args.tile_halo), [])
+        flush()
     finally:
+        if ctx is not None:
+            ctx.close()
         pipe.close()
+
+
+def score_chain_tiled(ctx, fasta, bam, name, cfg, tile_bp, halo_bp):
+    """np1_score_chain_tiled (include/nextpolish1.h): one contig, every tile, on this process's GPU"""
+    L = nat.lib()
+    L.np1_score_chain_tiled.restype = C.c_int
+    L.np1_score_chain_tiled.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(nat.Configure), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+    L.np1_free_string.argtypes = [C.c_void_p]
+    out, n = C.c_void_p(), C.c_int64(0)
+    if L.np1_score_chain_tiled(ctx.handle, fasta.encode(), bam.encode(), name.encode(), cfg, tile_bp, halo_bp, 0, 1, C.byref(out), C.byref(n), None) != 0:
+        raise SystemExit("np1_score_chain_tiled: " + nat.last_error())
+    seq = C.string_at(out, n.value).decode()
+    L.np1_free_string(out)
+    return seq
 
 
 def polish_phase_batched(args, cfg, names, device, emit):
@@ -287,6 +324,9 @@ def build_parser():
     gpu.add_argument("--batch_bp", type=parse_num_unit, default=parse_num_unit("16m"),
                      help="draft bases per HBM-resident batch (a longer contig is a batch of its own)")
     gpu.add_argument("--lanes", type=int, default=2, help="batches in flight on the device (HIP stream + host thread each)")
+    gpu.add_argument("--tile_bp", type=parse_num_unit, default=0,
+                     help="task 1: polish contigs longer than this many bases as independent tiles of that size, joined exactly (0 = off)")
+    gpu.add_argument("--tile_halo", type=parse_num_unit, default=1000, help="bases of halo on each side of a tile (doubled when too small)")
     return p
 
 

@@ -71,3 +71,19 @@ def test_cli_with_tiling_equals_cli_without(tmp_path):
     assert len(m) == 1 and m[0][0] == st.names[1] and int(m[0][2]) == -(-int(m[0][1]) // 3000000) >= 8, t.stderr[-800:]
     assert t.stdout == plain.stdout
     assert list(parse_cli_fasta(t.stdout)) == list(st.names)
+
+
+def test_python_caller_with_tile_bp_equals_the_untiled_caller(tmp_path):
+    """nextpolish1.py -t 1 --tile_bp: the long contig in tiles, the short ones through the batched pipe, same FASTA as without the option"""
+    import sys
+    st = nat.Stream.synth([200000, 6000000, 90000], depth=30, seed=4244)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "r.bam")
+    st.write_files(fa, bam)
+    outs = []
+    for extra in ([], ["--tile_bp", "900k", "--tile_halo", "500"]):
+        out = str(tmp_path / ("o%d.fa" % len(outs)))
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "nextpolish_amd", "nextpolish1.py"), "-g", fa, "-t", "1", "-s", bam, "-o", out] + extra,
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-800:]
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and outs[0].count(">") == 3
