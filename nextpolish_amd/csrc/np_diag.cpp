@@ -1,0 +1,85 @@
+// Abort diagnostics, off unless NP_ABORT_TRACE is set (tests/conftest.py sets it).
+//
+// A process that dies of SIGABRT inside native code says nothing about where: Python's faulthandler prints the Python frames, glibc and
+// libstdc++ print one line, the HIP runtime sometimes none.  With NP_ABORT_TRACE set, loading either library installs
+//   * a std::terminate handler that prints the type and what() of the exception in flight, and
+//   * a SIGABRT handler that prints the native frames of the aborting thread (backtrace_symbols_fd: no allocation),
+// to stderr and, when the variable's value is a path, appended to that file as well.  Both then hand over to whatever was installed before
+// them (faulthandler's dump, the default action), so the process ends exactly as it would have.
+#include <cxxabi.h>
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <unistd.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <typeinfo>
+
+namespace {
+
+int g_fd = -1;                       // the file copy (or -1), opened at the first line written: open(2) is async-signal-safe
+char g_path[512];
+struct sigaction g_prev;             // what handled SIGABRT before us
+std::terminate_handler g_prev_term = nullptr;
+
+void put(const char* s) {
+    size_t n = strlen(s);
+    if (g_fd < 0 && g_path[0]) g_fd = open(g_path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    (void)!write(2, s, n);
+    if (g_fd >= 0) (void)!write(g_fd, s, n);
+}
+
+void frames() {
+    void* pc[96];
+    int n = backtrace(pc, 96);
+    backtrace_symbols_fd(pc, n, 2);
+    if (g_fd >= 0) backtrace_symbols_fd(pc, n, g_fd);
+}
+
+void on_abort(int sig) {
+    put("[np abort] SIGABRT; native frames of the aborting thread:\n");
+    frames();
+    sigaction(SIGABRT, &g_prev, nullptr);     // faulthandler's (or the default): the signal is raised again below and handled there
+    raise(sig);
+}
+
+void on_terminate() {
+    put("[np abort] std::terminate");
+    if (std::type_info* t = abi::__cxa_current_exception_type()) {
+        put(" with an exception in flight: ");
+        put(t->name());
+        try {
+            throw;
+        } catch (const std::exception& e) {
+            put(": ");
+            put(e.what());
+        } catch (...) {
+        }
+    }
+    put("\n");
+    if (g_prev_term && g_prev_term != on_terminate) g_prev_term();
+    abort();
+}
+
+struct Install {
+    Install() {
+        const char* v = getenv("NP_ABORT_TRACE");
+        if (!v || !*v || !strcmp(v, "0")) return;
+        if (getenv("NP_ABORT_TRACE_ON")) return;     // the other library of the pair was first (each holds its own copy of this unit)
+        setenv("NP_ABORT_TRACE_ON", "1", 1);
+        if (strchr(v, '/') && strlen(v) < sizeof g_path) strcpy(g_path, v);
+        void* warm[4];
+        backtrace(warm, 4);                   // loads libgcc's unwinder now, not inside the handler
+        struct sigaction sa;
+        memset(&sa, 0, sizeof sa);
+        sa.sa_handler = on_abort;
+        sigemptyset(&sa.sa_mask);
+        sa.sa_flags = SA_NODEFER;
+        sigaction(SIGABRT, &sa, &g_prev);
+        g_prev_term = std::set_terminate(on_terminate);
+    }
+} g_install;
+
+}  // namespace

@@ -12,16 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # a fatal signal inside native code (ours, the HIP runtime's) leaves the Python stacks of all threads in gpurun_out/fault.log as well
-    # as on stderr, so that a crash on the GPU box can be read afterwards
-    try:
-        import faulthandler
-        d = os.path.join(ROOT, "gpurun_out")
-        os.makedirs(d, exist_ok=True)
-        config._np_fault_log = open(os.path.join(d, "fault.log"), "a")
-        faulthandler.enable(file=config._np_fault_log, all_threads=True)
-    except Exception:
-        pass
+    # a fatal signal inside native code (ours, the HIP runtime's) must leave enough behind to be read afterwards
+    # (pytest's own faulthandler plugin prints them on stderr; the libraries add the native frames of the aborting thread and the exception
+    # behind a std::terminate when NP_ABORT_TRACE is set: csrc/np_diag.cpp)
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    os.environ.setdefault("NP_ABORT_TRACE", os.path.join(d, "abort_%d.txt" % os.getpid()))
 
 
 @pytest.fixture(scope="session", autouse=True)
