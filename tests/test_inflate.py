@@ -127,3 +127,19 @@ def test_lane_decoder_matches_zlib_on_every_block_kind(level, lane_decoder):
 def test_lane_decoder_multi_block_streams_and_damage(lane_decoder):
     test_multi_block_streams_and_flushes()
     test_damaged_or_mismatched_streams_are_never_wrong()
+
+
+@pytest.mark.parametrize("decoder", ["host", "lane"])
+def test_decoders_never_touch_a_byte_outside_their_buffers(decoder):
+    """tests/model/inflate_fuzz.cpp under AddressSanitizer + UBSan: streams decoded from / into heap buffers of exactly their size, intact
+    and damaged; includes the constructed case (1-4 literals, then a 258-byte far match ending 10-13 bytes before the end of the block) on
+    which the host decoder used to write up to 4 bytes into the neighbouring block of a BGZF window (found in round 4)."""
+    import os
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "model")
+    b = subprocess.run(["make", "-C", d, "inflate_fuzz"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-1500:]
+    for seed in (1, 2, 3):
+        p = subprocess.run([os.path.join(d, "inflate_fuzz"), decoder, "1200", str(seed)], capture_output=True, text=True,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert p.returncode == 0 and " 0 failures" in p.stdout, (p.stdout[-300:], p.stderr[-2500:])
