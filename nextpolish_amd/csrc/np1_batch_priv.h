@@ -49,6 +49,7 @@ struct PinBuf {
         p = nullptr; cap = 0;
         const size_t want = bytes + bytes / 4 + 4096;
         if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) { p = nullptr; return false; }
+        if (npalloc::poison() >= 0) memset(p, npalloc::poison(), want);      // (debugging: a D2H target read before it was written shows)
         cap = want;
         return true;
     }
@@ -123,29 +124,40 @@ struct np1_batch {
     // Everything a pass allocates besides the uploaded inputs (record arrays, draft, qualities) changes places with the same
     // buffers of another batch: resident batches keep only their inputs in HBM and borrow the work set of the lane they run on
     // (np1_pipe_run_resident), so a draft of any size stays resident with two work sets instead of one per batch.
+    // the buffers a run computes into (everything but the uploaded records and their forms): what two lanes of the pipe swap, and what the
+    // debugging poison fills before every run
+    template <class F> static void for_each_work(F f) {
+        static np1dev::DevBuf np1_batch::* const list[] = {&np1_batch::desc, &np1_batch::ovf_desc, &np1_batch::slot_g, &np1_batch::dbg,
+            &np1_batch::single_map, &np1_batch::join_out, &np1_batch::kc_level, &np1_batch::kc_endpos, &np1_batch::kc_code, &np1_batch::kc_flag,
+            &np1_batch::kc_fpos, &np1_batch::kc_flagged, &np1_batch::kc_work, &np1_batch::kc_nd_ctg, &np1_batch::kc_nd_se, &np1_batch::kc_kr_ctg,
+            &np1_batch::kc_kr_se, &np1_batch::kc_cnt, &np1_batch::kc_sbase, &np1_batch::kc_sflag, &np1_batch::kc_srefk, &np1_batch::kc_scount,
+            &np1_batch::kc_lhead, &np1_batch::kc_lpool, &np1_batch::kc_stsc, &np1_batch::kc_stkm, &np1_batch::kc_strk, &np1_batch::kc_hpool,
+            &np1_batch::kc_workoff, &np1_batch::kc_nparts, &np1_batch::kc_partoff, &np1_batch::kc_pt_ctg, &np1_batch::kc_pt_se,
+            &np1_batch::kc_pt_len, &np1_batch::kc_woff, &np1_batch::kc_wpool, &np1_batch::kc_haswin, &np1_batch::sv_failse, &np1_batch::sv_failcnt,
+            &np1_batch::sv_vsz, &np1_batch::sv_voff, &np1_batch::sv_val, &np1_batch::sv_p2ctg, &np1_batch::sv_p2se, &np1_batch::sv_p2len,
+            &np1_batch::sv_woff2, &np1_batch::sv_haswin2, &np1_batch::sv_range, &np1_batch::qs, &np1_batch::qe, &np1_batch::span, &np1_batch::ins,
+            &np1_batch::soff, &np1_batch::slot_info, &np1_batch::rbase, &np1_batch::capb, &np1_batch::rowoff, &np1_batch::rows, &np1_batch::meta,
+            &np1_batch::chunk_first, &np1_batch::chunk_last, &np1_batch::slot_res, &np1_batch::slot_rec, &np1_batch::pool, &np1_batch::heads,
+            &np1_batch::redo, &np1_batch::redo2, &np1_batch::redo3, &np1_batch::ctx_lists, &np1_batch::counters, &np1_batch::opos, &np1_batch::out,
+            &np1_batch::bounds, &np1_batch::scan_tmp, &np1_batch::totals};
+        for (np1dev::DevBuf np1_batch::* m : list) f(m);
+    }
     void swap_work(np1_batch& o) {
-        np1dev::DevBuf* mine[] = {&desc, &ovf_desc, &slot_g, &dbg, &single_map, &join_out, &kc_level, &kc_endpos, &kc_code, &kc_flag, &kc_fpos, &kc_flagged, &kc_work, &kc_nd_ctg,
-                                  &kc_nd_se, &kc_kr_ctg, &kc_kr_se, &kc_cnt, &kc_sbase, &kc_sflag, &kc_srefk, &kc_scount, &kc_lhead, &kc_lpool, &kc_stsc,
-                                  &kc_stkm, &kc_strk, &kc_hpool, &kc_workoff, &kc_nparts, &kc_partoff, &kc_pt_ctg, &kc_pt_se, &kc_pt_len, &kc_woff,
-                                  &kc_wpool, &kc_haswin, &sv_failse, &sv_failcnt, &sv_vsz, &sv_voff, &sv_val, &sv_p2ctg, &sv_p2se, &sv_p2len, &sv_woff2,
-                                  &sv_haswin2, &sv_range, &qs, &qe, &span, &ins, &soff, &slot_info, &rbase, &capb, &rowoff, &rows, &meta, &chunk_first,
-                                  &chunk_last, &slot_res, &slot_rec, &pool, &heads, &redo, &redo2, &redo3, &ctx_lists, &counters, &opos, &out, &bounds, &scan_tmp, &totals};
-        np1dev::DevBuf* theirs[] = {&o.desc, &o.ovf_desc, &o.slot_g, &o.dbg, &o.single_map, &o.join_out, &o.kc_level, &o.kc_endpos, &o.kc_code, &o.kc_flag, &o.kc_fpos, &o.kc_flagged,
-                                    &o.kc_work, &o.kc_nd_ctg, &o.kc_nd_se, &o.kc_kr_ctg, &o.kc_kr_se, &o.kc_cnt, &o.kc_sbase, &o.kc_sflag, &o.kc_srefk,
-                                    &o.kc_scount, &o.kc_lhead, &o.kc_lpool, &o.kc_stsc, &o.kc_stkm, &o.kc_strk, &o.kc_hpool, &o.kc_workoff, &o.kc_nparts,
-                                    &o.kc_partoff, &o.kc_pt_ctg, &o.kc_pt_se, &o.kc_pt_len, &o.kc_woff, &o.kc_wpool, &o.kc_haswin, &o.sv_failse,
-                                    &o.sv_failcnt, &o.sv_vsz, &o.sv_voff, &o.sv_val, &o.sv_p2ctg, &o.sv_p2se, &o.sv_p2len, &o.sv_woff2, &o.sv_haswin2,
-                                    &o.sv_range, &o.qs, &o.qe, &o.span, &o.ins, &o.soff, &o.slot_info, &o.rbase, &o.capb, &o.rowoff, &o.rows, &o.meta,
-                                    &o.chunk_first, &o.chunk_last, &o.slot_res, &o.slot_rec, &o.pool, &o.heads, &o.redo, &o.redo2, &o.redo3, &o.ctx_lists, &o.counters, &o.opos,
-                                    &o.out, &o.bounds, &o.scan_tmp, &o.totals};
-        static_assert(sizeof(mine) == sizeof(theirs), "work buffer lists differ");
-        for (size_t i = 0; i < sizeof(mine) / sizeof(mine[0]); ++i) {
-            np1dev::DevBuf t = *mine[i];
-            *mine[i] = *theirs[i];
-            *theirs[i] = t;
-        }
+        for_each_work([&](np1dev::DevBuf np1_batch::* m) {
+            np1dev::DevBuf t = this->*m;
+            this->*m = o.*m;
+            o.*m = t;
+        });
         out_cached = false;
         out_pinned = false;
+    }
+    // NP_DEVPOISON (np_devalloc.h) set to 2..: besides new allocations, every work buffer is filled with a5 at the start of every run, so a
+    // kernel that reads what an EARLIER run left in a buffer -- the other thing a long-lived process has and a fresh one has not -- shows
+    void poison_work(hipStream_t q) {
+        for_each_work([&](np1dev::DevBuf np1_batch::* m) {
+            np1dev::DevBuf& d = this->*m;
+            if (d.p && d.cap) (void)hipMemsetAsync(d.p, 0xa5, d.cap, q);
+        });
     }
     size_t device_bytes() const {
         const np1dev::DevBuf* all[] = {&draft, &ctg_off, &pos, &ctg, &flag, &ncig, &ncig16, &lq, &cigoff, &seqoff, &cigar, &seq, &seq2, &esc_at, &esc_val, &up_plain, &up_xlq, &up_xncig, &up_xcigar, &up_dpos, &up_xpos, &up_work, &draft4, &desc_at, &desc_val, &qs, &qe,

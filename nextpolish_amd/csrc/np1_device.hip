@@ -340,6 +340,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     b->ran = false;
     b->out_cached = false;
     b->out_pinned = false;
+    if (npalloc::poison_runs()) b->poison_work(q);
     int K = 0;
     long long Rfix = 0;
     // rate = R / 2^K (the default 0.5, 0.25, 0.75 ...): exact integer scores, multi-state runs are independent (fast path).
@@ -806,6 +807,7 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
     b->out_cached = false;
     b->out_pinned = false;
     b->replay.have_pos = false;
+    if (npalloc::poison_runs()) b->poison_work(q);
     int K = 0;
     long long Rfix = 0;
     if (!rate_fixed_point(cfg->indel_balance_factor_sgs, &K, &Rfix)) {   // general rate: the region DP keeps doubles (np1_kmer.h)

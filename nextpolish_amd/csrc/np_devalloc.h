@@ -7,10 +7,17 @@
 // A kernel that reads or writes past the end of a buffer then faults at the first such access, deterministically, instead of
 // touching whatever the allocator happened to place there (how the over-reads behind the round-3 abort were
 // found).  The mode costs one granule (2 MiB) of physical memory per buffer and a few hundred microseconds per allocation.
+//
+// NP_DEVPOISON=1 (debugging; or a hex byte, e.g. NP_DEVPOISON=ff): every new device buffer is filled with that byte (default a5) before it
+// is handed out.  hipMalloc hands a long-lived process the bytes of whatever it freed before -- a fresh process mostly sees zeros -- so a
+// kernel that reads memory nobody wrote behaves differently in the one-process test suite than in any single test; with the poison it
+// misbehaves the same way everywhere.  NP_DEVPOISON=2 also fills the work buffers of a short-read batch before
+// every run (what an earlier run left in a reused buffer is the other thing only a long-lived process has).  Works with and without NP_EFENCE.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
 
@@ -28,7 +35,32 @@ struct FenceTable {
 };
 inline FenceTable& fence_table() { static FenceTable t; return t; }
 
+inline int poison() {      // -1: off
+    static const int v = [] {
+        const char* e = getenv("NP_DEVPOISON");
+        if (!e || !e[0] || !strcmp(e, "0")) return -1;
+        if (!strcmp(e, "1") || !strcmp(e, "2")) return 0xa5;
+        return (int)(strtol(e, nullptr, 16) & 0xff);
+    }();
+    return v;
+}
+
+inline bool poison_runs() {      // NP_DEVPOISON=2: also the work buffers of a batch before every run (np1_batch::poison_work)
+    static const bool on = [] { const char* e = getenv("NP_DEVPOISON"); return poison() >= 0 && e && !strcmp(e, "2"); }();
+    return on;
+}
+
+inline hipError_t dev_malloc_raw(void** p, size_t bytes);
 inline hipError_t dev_malloc(void** p, size_t bytes) {
+    const hipError_t e = dev_malloc_raw(p, bytes);
+    if (e == hipSuccess && poison() >= 0 && bytes) {
+        (void)hipMemset(*p, poison(), bytes);
+        (void)hipDeviceSynchronize();
+    }
+    return e;
+}
+
+inline hipError_t dev_malloc_raw(void** p, size_t bytes) {
     if (!efence()) return hipMalloc(p, bytes);
     *p = nullptr;
     int dev = 0;
