@@ -287,8 +287,11 @@ int np1_batch_snp_phase(np1_batch* sr, np1_batch* lr, const Configure* cfg);
  * a halo of halo_bp on each side, each tile reading its own region of the BAM through the index; the join is exact (a tile is redone
  * with a doubled halo when a halo holds no slot the chain restarts behind).  The reference takes contigs up to 2^31 bases
  * (source/nextPolish:101-102) in one score_chain call (source/lib/scorechain.c:3-15); this is that call for contigs beyond one HBM batch.
- * first_tile / tile_stride: this call polishes tiles first_tile, first_tile + tile_stride, ... (0, 1: all of them; rank r of n ranks:
- * r, n -- the pieces of the ranks are concatenated tile by tile by the caller).  *out: malloc'd, NUL-terminated (np1_free_string).
+ * first_tile / tile_stride: this call polishes tiles first_tile, first_tile + tile_stride, ... and returns their pieces concatenated in
+ * tile order (0, 1: all of them = the polished contig).  Tiles are independent, so the tiles of one dominant contig can be dealt over
+ * ranks: a call with first_tile = k and a stride of at least the number of tiles returns the piece of tile k alone, and the pieces of all
+ * tiles in tile order are the polished contig (the callers of this repository still deal whole contigs over ranks: DESIGN.md section 11).
+ * *out: malloc'd, NUL-terminated (np1_free_string).
  * stats (optional, 4 words): tiles, tiles recomputed with a wider halo, records read, records of the largest tile.
  * Pieces: np1_batch_keep_single (before the run) makes a one-contig batch remember which slots left the vote with one state;
  * np1_batch_tile_join gives {left halo has such a slot, right halo has one, output offset of the tile's first own base, of the first base
