@@ -599,7 +599,7 @@ def main():
     ap.add_argument("--no-lgs", action="store_true", help="skip the long-read (nextpolish2) leg")
     ap.add_argument("--lgs-workers", type=int, default=24, help="worker processes per GPU of the long-read leg (x NP2_WORKER_THREADS host threads each, default 2)")
     ap.add_argument("--lgs-mb", type=float, default=5.0, help="contig length (Mb) each long-read worker polishes")
-    ap.add_argument("--lgs-calls", type=int, default=8, help="timed calls per long-read worker (the rate is bp over the span from the common start to the last end: few calls leave the stragglers idle)")
+    ap.add_argument("--lgs-calls", type=int, default=24, help="timed calls per long-read worker (the rate is bp over the span from the common start to the last end; measured: 0.63 s of ramp and stragglers + 0.70 s per round of calls, so 4 / 8 calls read 140 / 154 Mbp/s of a steady state of 171: a worker of a real run polishes hundreds of windows)")
     ap.add_argument("--no-lgs-config4", action="store_true", help="skip the 100 Mb / 67-contig long-read run (BASELINE configs[3] at its stated size)")
     ap.add_argument("--no-phase", action="store_true", help="skip the snp_phase (task 3) leg")
     ap.add_argument("--phase-mb", type=float, default=20.0, help="draft length (Mb) of the snp_phase leg")
