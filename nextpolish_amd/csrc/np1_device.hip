@@ -294,8 +294,10 @@ int np1_stream_pin(np1_stream* st) {
     if (st->pinned) return 0;
     stream_facts(st);
     np::ReadStream& s = st->s;
+    // (arrays below 64 KiB stay pageable: the runtime stages such a copy through its own pinned buffer at once, and page-locking a few
+    // hundred bytes of heap locks -- and maps into the GPU's address space -- whole pages that other allocations of the process share)
     auto reg = [](const void* p, size_t bytes) {
-        if (!p || !bytes) return true;
+        if (!p || bytes < 65536) return true;
         return hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess;
     };
     bool ok = reg(s.draft.data(), s.draft.size()) && reg(s.pos.data(), 4 * s.pos.size()) && reg(s.ctg.data(), 4 * s.ctg.size()) &&
