@@ -110,7 +110,7 @@ void check_indel(Gap* g, int32_t rlen, const Pos* rfp1, const Pos* rdp1, const P
 // SA:Z value of a record (SAMv1 4.2.4 aux layout), nullptr when absent
 const char* find_sa(const np::BamRec& r) {
     const uint8_t* p = r.qual() + r.l_qseq;
-    const uint8_t* end = r.data.data() + r.data.size();
+    const uint8_t* end = r.end();
     while (p + 3 <= end) {
         const char t0 = (char)p[0], t1 = (char)p[1], ty = (char)p[2];
         p += 3;
@@ -159,6 +159,10 @@ class MergeIter {
             files_[i].reset(new FileIter());
             FileIter& f = *files_[i];
             if (!f.rd.open(paths[i])) { *err = "fail to open \"" + paths[i] + "\""; return false; }
+            // records are consumed before the next one of their file is asked for (next() advances the file of the record handed out
+            // last), so they may point into the reader's window: one copy of every record less (NP2_ZERO_COPY=0: owned copies)
+            static const bool zero_copy = !(getenv("NP2_ZERO_COPY") && getenv("NP2_ZERO_COPY")[0] == '0');
+            f.rd.set_zero_copy(zero_copy);
             f.tid = f.rd.header().name2id(ctg);
             np::BaiIndex bai;
             if (!bai.load(paths[i] + ".bai")) { *err = "failed to load index for " + paths[i]; return false; }

@@ -94,6 +94,7 @@ int BamReader::next(BamRec& r) {
         if (r.n_cigar) memcpy(&c0, view + 32 + r.l_qname, 4);
         if (!(r.n_cigar && (c0 & 0xfu) == 4 && (int64_t)(c0 >> 4) == (int64_t)r.l_qseq)) {   // (a CG placeholder takes the copying path)
             r.ext = view + 32;
+            r.ext_len = rest;
             return 1;
         }
     }

@@ -33,6 +33,8 @@ struct BamRec {
     uint8_t l_qname = 0;
     std::vector<uint8_t> data;   // qname | cigar | seq | qual | aux   (as stored in BAM)
     const uint8_t* ext = nullptr;   // zero-copy readers: the same bytes inside the BGZF window (valid until the next record)
+    size_t ext_len = 0;             // ... and how many there are (the record without its 32 fixed bytes)
+    const uint8_t* end() const { return ext ? ext + ext_len : data.data() + data.size(); }   // behind the optional fields (an owned copy: + 8 zero bytes of pad)
     const uint8_t* base() const { return ext ? ext : data.data(); }
     const char* qname() const { return reinterpret_cast<const char*>(base()); }
     const uint32_t* cigar() const { return reinterpret_cast<const uint32_t*>(base() + l_qname); }
