@@ -83,6 +83,19 @@ void fill_points(np1_batch* b, const np::ReadStream& s, PolishResult* res) {
 
 }  // namespace
 
+// A C++ exception must not leave through the C boundary (the caller is ctypes: there is no frame that could catch it, the process would
+// end in std::terminate without a word): it becomes the same kind of exit as every other failure of these entry points.
+template <class F>
+PolishResult* guarded(const char* what, F f) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        die(std::string(what) + ": " + e.what());
+    } catch (...) {
+        die(std::string(what) + ": unknown exception");
+    }
+}
+
 extern "C" {
 
 Configure* config_init(const char* fastafn, const char* bamfn, const char* thirdbamfn) {
@@ -143,7 +156,7 @@ void polishresult_destory(PolishResult* p) {
     free(p);
 }
 
-PolishResult* score_chain(const char* tigname, Configure* cfg) {
+static PolishResult* score_chain_task(const char* tigname, Configure* cfg) {
     if (!cfg || !cfg->fastafn) die("score_chain: configuration without a FASTA");
     if (!cfg->bamfn) die("score_chain: short-read BAM missing or unreadable");
     np1_stream st;
@@ -187,11 +200,13 @@ static PolishResult* kmer_task(const char* tigname, Configure* cfg, bool snp_val
     np1_batch_free(b);
     return res;
 }
-PolishResult* kmer_count(const char* tigname, Configure* cfg) { return kmer_task(tigname, cfg, false); }
+/* task 1 (reference: source/lib/scorechain.c:3-15) */
+PolishResult* score_chain(const char* tigname, Configure* cfg) { return guarded("score_chain", [&] { return score_chain_task(tigname, cfg); }); }
+PolishResult* kmer_count(const char* tigname, Configure* cfg) { return guarded("kmer_count", [&] { return kmer_task(tigname, cfg, false); }); }
 /* task 4 (reference: source/lib/snpvalid.c:3-36) */
-PolishResult* snp_valid(const char* tigname, Configure* cfg) { return kmer_task(tigname, cfg, true); }
+PolishResult* snp_valid(const char* tigname, Configure* cfg) { return guarded("snp_valid", [&] { return kmer_task(tigname, cfg, true); }); }
 /* task 3 (reference: source/lib/snpphase.c:87-134): short reads from cfg->bamfn, long reads from cfg->thirdbamfn */
-PolishResult* snp_phase(const char* tigname, Configure* cfg) {
+static PolishResult* snp_phase_task(const char* tigname, Configure* cfg) {
     if (!cfg || !cfg->fastafn) die("snp_phase: configuration without a FASTA");
     if (!cfg->bamfn) die("snp_phase: short-read BAM missing or unreadable");
     if (!cfg->thirdbamfn) die("snp_phase: long-read BAM missing or unreadable (the reference dereferences a null index here)");
@@ -215,6 +230,7 @@ PolishResult* snp_phase(const char* tigname, Configure* cfg) {
     np1_batch_free(b);
     return res;
 }
+PolishResult* snp_phase(const char* tigname, Configure* cfg) { return guarded("snp_phase", [&] { return snp_phase_task(tigname, cfg); }); }
 PolishResult* lgspolish(const char* tigname, Configure* cfg) {
     (void)tigname; (void)cfg;
     die("lgspolish (task 5) is disabled by the reference's own caller; use the long-read path");

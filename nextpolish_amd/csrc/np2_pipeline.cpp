@@ -593,7 +593,7 @@ static void np2_die(const char* what, const char* ctg) {
     exit(1);
 }
 
-extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char* bam_list) {
+static consensus_trimed_data* ctg_cns_core_task(ctg_cns_cfg* cfg, ref_* ref, char* bam_list) {
     g_err.clear();
     if (!cfg->exec || cfg->exec_pid != (int)getpid()) {   // lazily, per process: the caller forks after ctg_cns_init
         // one executor per process, shared by every configuration and kept until the process ends: its buffers in HBM
@@ -901,4 +901,16 @@ extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char
     consensus_trimed_data* result = link_windows(windows, sv.split_ps, (int)ref->length, 50, cfg->split, cfg->s);
     if (!windows.empty()) out.cons.swap(windows.back().b);   // keep the buffer (its capacity) for the next contig's window
     return result;
+}
+
+// A C++ exception must not leave through the C boundary (the caller is ctypes): it ends the worker like every other failure here does.
+extern "C" consensus_trimed_data* ctg_cns_core(ctg_cns_cfg* cfg, ref_* ref, char* bam_list) {
+    try {
+        return ctg_cns_core_task(cfg, ref, bam_list);
+    } catch (const std::exception& e) {
+        np2_die(e.what(), ref && ref->n ? ref->n : "?");
+    } catch (...) {
+        np2_die("unknown exception", ref && ref->n ? ref->n : "?");
+    }
+    return nullptr;
 }
