@@ -6,6 +6,7 @@
 // mismatch); the caller then falls back to zlib, so a false negative costs time, never correctness.
 #include "np_inflate.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace np {
@@ -503,7 +504,7 @@ __attribute__((target("bmi,bmi2"))) bool inflate_bmi2(const uint8_t* src, size_t
 }  // namespace
 
 bool inflate_raw(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len) {
-    static const bool bmi2 = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi");
+    static const bool bmi2 = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi") && !getenv("NP_INFLATE_PLAIN");   // (the variable: the tests run both builds)
     return bmi2 ? inflate_bmi2(src, src_len, dst, dst_len) : inflate_plain(src, src_len, dst, dst_len);
 }
 
