@@ -148,14 +148,31 @@ def rank_share(all_names, lengths, world, rank, polished_seqs, filter_polished):
     return out
 
 
-def polish_batched(args, cfg, names, device, emit):
+def polish_batched(args, cfg, names, device, emit, shared=(), polished_seqs=()):
     """Tasks 1, 2 and 4 without -debug: the rank's contigs flow through the device in batches of --batch_bp draft bases on
-    --lanes device lanes while host threads inflate and split the records of the next batches (np1_pipe_run_files)."""
-    from nextpolish_amd.device import Pipe
+    --lanes device lanes while host threads inflate and split the records of the next batches (np1_pipe_run_files).
+    shared: contigs longer than --tile_bp whose tiles all ranks share (main); this rank writes its pieces first, polishes its own
+    contigs, and joins the shared contigs it is the joiner of at the end."""
     lengths = fasta_lengths(args.genome)
     names = [n for n in names if n in lengths]
-    if not names:
-        return
+    if shared:
+        from nextpolish_amd.device import Context
+        sctx = Context(device)
+        try:
+            piece = device_tile_piece(sctx, args.genome, args.bam_sgs, cfg, args.tile_bp, args.tile_halo)
+            for n in shared:
+                write_tile_pieces(piece, args.tile_dir, n, lengths[n], args.tile_bp, args.world, args.rank)
+        finally:
+            sctx.close()
+    if names:
+        polish_own_batched(args, cfg, names, lengths, device, emit)
+    for i, n in enumerate(shared):
+        if i % args.world == args.rank and not (args.block_index != "all" and n.split("_np")[0] in polished_seqs):      # (the filter of rank_share)
+            emit(n, join_tile_pieces(args.tile_dir, n, lengths[n], args.tile_bp, args.tile_wait), [])
+
+
+def polish_own_batched(args, cfg, names, lengths, device, emit):
+    from nextpolish_amd.device import Pipe
     # --tile_bp (task 1): a contig longer than that is polished as independent tiles with a halo and joined exactly (np1_tile.cpp;
     # the reference takes contigs up to 2^31 bases in one score_chain call, source/nextPolish:101-102) -- it need not fit an HBM batch.
     # The runs of shorter contigs between such contigs go through the pipe as before, so the output keeps the order of `names`.
@@ -199,6 +216,77 @@ def score_chain_tiled(ctx, fasta, bam, name, cfg, tile_bp, halo_bp):
     seq = C.string_at(out, n.value).decode()
     L.np1_free_string(out)
     return seq
+
+
+# ---- the tiles of one dominant contig over the ranks of a node (--world > 1 with --tile_bp) ------------------------
+# Tiles are independent (np1_tile.cpp), so rank r polishes tiles r, r + world, ... of every contig longer than --tile_bp and leaves each
+# piece as a file in --tile_dir (a directory all ranks see); the contig's joiner -- rank (its position among such contigs) mod world --
+# concatenates the pieces in tile order and writes the record into its own -o part.  No collective, no process group: files, written
+# under a temporary name and renamed.  Every rank writes ALL its pieces before any rank waits, so nobody waits for a rank that waits.
+
+def tile_count(length, tile_bp):
+    return (length + tile_bp - 1) // tile_bp
+
+
+def tile_piece_dir(tile_dir, name):
+    import hashlib
+    return os.path.join(tile_dir, hashlib.md5(name.encode()).hexdigest())
+
+
+def device_tile_piece(ctx, fasta, bam, cfg, tile_bp, halo_bp):
+    """piece(name, k, n_tiles): tile k of a contig alone -- np1_score_chain_tiled with first_tile = k and a stride no other tile meets"""
+    L = nat.lib()
+    L.np1_score_chain_tiled.restype = C.c_int
+    L.np1_score_chain_tiled.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(nat.Configure), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+    L.np1_free_string.argtypes = [C.c_void_p]
+
+    def piece(name, k, n_tiles):
+        out, n = C.c_void_p(), C.c_int64(0)
+        if L.np1_score_chain_tiled(ctx.handle, fasta.encode(), bam.encode(), name.encode(), cfg, tile_bp, halo_bp, k, max(n_tiles, 1), C.byref(out), C.byref(n), None) != 0:
+            raise SystemExit("np1_score_chain_tiled: " + nat.last_error())
+        seq = C.string_at(out, n.value).decode()
+        L.np1_free_string(out)
+        return seq
+    return piece
+
+
+def write_tile_pieces(piece, tile_dir, name, length, tile_bp, world, rank):
+    """this rank's tiles of one contig, each left as <tile_dir>/<md5 of the name>/<k>.seq"""
+    n = tile_count(length, tile_bp)
+    d = tile_piece_dir(tile_dir, name)
+    os.makedirs(d, exist_ok=True)
+    for k in range(rank, n, world):
+        seq = piece(name, k, n)
+        tmp = os.path.join(d, "%d.tmp.%d" % (k, os.getpid()))
+        with open(tmp, "w") as f:
+            f.write(seq)
+        os.replace(tmp, os.path.join(d, "%d.seq" % k))
+
+
+def join_tile_pieces(tile_dir, name, length, tile_bp, wait_s, poll_s=0.2):
+    """the polished contig from the pieces of all ranks, in tile order; waits up to wait_s seconds for each missing piece"""
+    import shutil
+    import time
+    n = tile_count(length, tile_bp)
+    d = tile_piece_dir(tile_dir, name)
+    parts = []
+    for k in range(n):
+        path = os.path.join(d, "%d.seq" % k)
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > wait_s:
+                raise SystemExit("tile %d of %s did not arrive in %s within %d s (is every rank of --world running with the same --tile_dir?)" % (k, name, d, wait_s))
+            time.sleep(poll_s)
+        with open(path) as f:
+            parts.append(f.read())
+    shutil.rmtree(d, ignore_errors=True)
+    return "".join(parts)
+
+
+def shared_tile_contigs(all_names, lengths, tile_bp):
+    """contigs of the block every rank takes tiles of, in block order"""
+    return [n for n in all_names if lengths.get(n, 0) > tile_bp]
 
 
 def polish_phase_batched(args, cfg, names, device, emit):
@@ -247,6 +335,14 @@ def main(args):
         args.block_index = "all"
         blockfile = args.genome
     all_names = read_unpolished_seqs(blockfile, args.block_index, polished_seqs, keep_polished=True)
+    shared = []
+    if args.world > 1 and args.task == 1 and args.tile_bp > 0 and not args.debug:      # tiles of dominant contigs are shared by all ranks
+        lens_all = fasta_lengths(args.genome)
+        shared = shared_tile_contigs(all_names, lens_all, args.tile_bp)
+        if shared and not args.tile_dir:
+            args.tile_dir = args.genome + ".np1_tiles"
+        held = set(shared)
+        all_names = [n for n in all_names if n not in held]
     names = rank_share(all_names, fasta_lengths(args.genome) if args.world > 1 else {}, args.world, args.rank, polished_seqs,
                        args.block_index != "all")
 
@@ -265,7 +361,7 @@ def main(args):
     fun = {1: L.score_chain, 2: L.kmer_count, 3: L.snp_phase, 4: L.snp_valid, 5: L.lgspolish}[args.task]
     if args.task in (1, 2, 4) and not args.debug:
         device = args.device if args.device >= 0 else args.rank
-        polish_batched(args, cfg, names, device, emit)
+        polish_batched(args, cfg, names, device, emit, shared, polished_seqs)
     elif args.task == 3 and not args.debug:
         polish_phase_batched(args, cfg, names, args.device if args.device >= 0 else args.rank, emit)
     else:
@@ -327,6 +423,9 @@ def build_parser():
     gpu.add_argument("--tile_bp", type=parse_num_unit, default=0,
                      help="task 1: polish contigs longer than this many bases as independent tiles of that size, joined exactly (0 = off)")
     gpu.add_argument("--tile_halo", type=parse_num_unit, default=1000, help="bases of halo on each side of a tile (doubled when too small)")
+    gpu.add_argument("--tile_dir", type=str, default="",
+                     help="--world > 1 with --tile_bp: directory all ranks see, where the pieces of contigs longer than --tile_bp meet (default: <genome>.np1_tiles)")
+    gpu.add_argument("--tile_wait", type=int, default=86400, help="seconds the joiner of such a contig waits for a piece of another rank")
     return p
 
 

@@ -846,8 +846,8 @@ int np1m_score_chain_tiled(const np1_stream_view* v, const Configure* cfg, uint3
 
 // The product's tiling driver (nextpolish_amd/csrc/np1_tile.cpp) with the model in place of the device: tiles read from the FILES through
 // the index (np_stream.cpp: load_stream_region), joined with the same index arithmetic.  CPU check of the region loader and of the join.
-int np1m_score_chain_tiled_files(const char* fasta, const char* bam, const char* name, const Configure* cfg, int64_t tile_bp, int64_t halo_bp, char** out,
-                                 int64_t* out_len, uint64_t* tstats) {
+int np1m_score_chain_tiled_files(const char* fasta, const char* bam, const char* name, const Configure* cfg, int64_t tile_bp, int64_t halo_bp, int64_t first_tile,
+                                 int64_t tile_stride, char** out, int64_t* out_len, uint64_t* tstats) {
     np::Fai fai;
     if (!fai.load(fasta)) return -30;
     const int id = fai.find(name);
@@ -861,7 +861,9 @@ int np1m_score_chain_tiled_files(const char* fasta, const char* bam, const char*
     uint64_t n_tiles = 0, n_redo = 0, n_rec = 0;
     g_keep_map = true;
     int rc = 0;
-    for (int64_t a = 0; a < L && rc == 0; a += tile_bp) {
+    int64_t tile_no = 0;
+    for (int64_t a = 0; a < L && rc == 0; a += tile_bp, ++tile_no) {
+        if (tile_no < first_tile || (tile_no - first_tile) % tile_stride != 0) continue;     // (np1_tile.cpp: this call's tiles)
         const int64_t b = a + tile_bp < L ? a + tile_bp : L;
         ++n_tiles;
         for (int64_t halo = halo_bp;; halo *= 2) {

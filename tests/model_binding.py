@@ -162,7 +162,7 @@ def kmer_count_replay(stream, cfg, bam, fn="np1m_kmer_count_replay"):
     return [blob[bounds[i]:bounds[i + 1]].decode() for i in range(stream.n_contigs)]
 
 
-def score_chain_tiled_files(fasta, bam, name, tile_bp, halo_bp, cfg=None, fused=1):
+def score_chain_tiled_files(fasta, bam, name, tile_bp, halo_bp, cfg=None, fused=1, first_tile=0, tile_stride=1):
     """the product's tiling driver (np1_tile.cpp) with the model in place of the device: tiles read from the files through the index
     (np_stream.cpp: load_stream_region); returns (string, dict(tiles, recomputed, records))"""
     cfg = cfg or nat.default_config()
@@ -170,8 +170,9 @@ def score_chain_tiled_files(fasta, bam, name, tile_bp, halo_bp, cfg=None, fused=
     out, n, ts = C.c_void_p(), C.c_int64(0), (C.c_uint64 * 3)()
     f = lib().np1m_score_chain_tiled_files
     f.restype = C.c_int
-    f.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(nat.Configure), C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
-    rc = f(fasta.encode(), bam.encode(), name.encode(), C.byref(cfg), tile_bp, halo_bp, C.byref(out), C.byref(n), ts)
+    f.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(nat.Configure), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                  C.POINTER(C.c_uint64)]
+    rc = f(fasta.encode(), bam.encode(), name.encode(), C.byref(cfg), tile_bp, halo_bp, first_tile, tile_stride, C.byref(out), C.byref(n), ts)
     if rc != 0:
         raise RuntimeError("tiled model (files) failed rc=%d" % rc)
     s = C.string_at(out, n.value).decode()
