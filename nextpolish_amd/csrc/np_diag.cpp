@@ -39,6 +39,7 @@ void frames() {
 }
 
 void on_abort(int sig) {
+    alarm(20);      // (should the unwinder block on a lock the aborting thread holds, SIGALRM ends the process instead of a hang)
     put("[np abort] SIGABRT; native frames of the aborting thread:\n");
     frames();
     sigaction(SIGABRT, &g_prev, nullptr);     // faulthandler's (or the default): the signal is raised again below and handled there
