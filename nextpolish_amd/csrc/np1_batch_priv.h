@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -17,6 +18,9 @@ namespace np1dev {
 inline bool hip_ok(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
     np1_set_error(std::string(what) + ": " + hipGetErrorString(e));
+    // the caller returns now, and most callers have asynchronous copies into or out of their own locals in flight: nothing of this
+    // process may still be moving when those locals go away
+    (void)hipDeviceSynchronize();
     return false;
 }
 #define HIPCHK(x) do { if (!hip_ok((x), #x)) return -1; } while (0)
@@ -45,15 +49,15 @@ struct PinBuf {
     size_t cap = 0;
     bool ensure(size_t bytes) {
         if (bytes <= cap && p) return true;
-        if (p) (void)hipHostFree(p);
+        if (p) (void)npalloc::host_free(p);
         p = nullptr; cap = 0;
         const size_t want = bytes + bytes / 4 + 4096;
-        if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) { p = nullptr; return false; }
+        if (npalloc::host_malloc(&p, want, hipHostMallocPortable) != hipSuccess) { p = nullptr; return false; }
         if (npalloc::poison() >= 0) memset(p, npalloc::poison(), want);      // (debugging: a D2H target read before it was written shows)
         cap = want;
         return true;
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)npalloc::host_free(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -62,11 +66,17 @@ constexpr int kStages = 8;
 }  // namespace np1dev
 
 
+// A context is shared by its owner (np1_ctx_create ... np1_ctx_destroy) and by every batch made on it: the stream and the events live
+// until the last of them lets go, so a batch that is freed after its context was destroyed (a Python Batch waiting for the garbage
+// collector behind an explicit Context.close()) still finds the stream it has to wait on.
 struct np1_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0[np1dev::kStages], ev1[np1dev::kStages];
+    std::atomic<int> refs{1};
 };
+void np1_ctx_retain(np1_ctx* c);      // np1_device.hip
+void np1_ctx_release(np1_ctx* c);
 
 struct np1_batch {
     np1_ctx* ctx = nullptr;

@@ -47,6 +47,16 @@ bool use_staged() {
 
 }  // namespace
 
+void np1_ctx_retain(np1_ctx* c) { c->refs.fetch_add(1); }
+void np1_ctx_release(np1_ctx* c) {
+    if (c->refs.fetch_sub(1) != 1) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < kStages; ++i) { (void)hipEventDestroy(c->ev0[i]); (void)hipEventDestroy(c->ev1[i]); }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
 extern "C" {
 
 int np1_device_count(void) {
@@ -73,9 +83,8 @@ np1_ctx* np1_ctx_create(int device) {
 void np1_ctx_destroy(np1_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (int i = 0; i < kStages; ++i) { (void)hipEventDestroy(c->ev0[i]); (void)hipEventDestroy(c->ev1[i]); }
-    (void)hipStreamDestroy(c->stream);
-    delete c;
+    (void)hipStreamSynchronize(c->stream);
+    np1_ctx_release(c);      // batches that are still alive keep the stream and the events until they are freed
 }
 
 int np1_stage_count(void) { return kStages; }
@@ -264,7 +273,8 @@ np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* st) {
     if (!ctx || !st) { np1_set_error("np1_batch_upload: null argument"); return nullptr; }
     np1_batch* b = new np1_batch();
     b->ctx = ctx;
-    if (fill_batch(b, st, true) != 0) { b->release_all(); delete b; return nullptr; }
+    np1_ctx_retain(ctx);
+    if (fill_batch(b, st, true) != 0) { np1_batch_free(b); return nullptr; }
     return b;
 }
 
@@ -272,6 +282,7 @@ np1_batch* np1_batch_create(np1_ctx* ctx) {
     if (!ctx) { np1_set_error("np1_batch_create: null context"); return nullptr; }
     np1_batch* b = new np1_batch();
     b->ctx = ctx;
+    np1_ctx_retain(ctx);
     return b;
 }
 
@@ -296,9 +307,11 @@ int np1_stream_pin(np1_stream* st) {
     np::ReadStream& s = st->s;
     // (arrays below 64 KiB stay pageable: the runtime stages such a copy through its own pinned buffer at once, and page-locking a few
     // hundred bytes of heap locks -- and maps into the GPU's address space -- whole pages that other allocations of the process share)
-    auto reg = [](const void* p, size_t bytes) {
+    auto reg = [st](const void* p, size_t bytes) {
         if (!p || bytes < 65536) return true;
-        return hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess;
+        if (npalloc::host_register(const_cast<void*>(p), bytes) != hipSuccess) return false;
+        st->registered.push_back(const_cast<void*>(p));
+        return true;
     };
     bool ok = reg(s.draft.data(), s.draft.size()) && reg(s.pos.data(), 4 * s.pos.size()) && reg(s.ctg.data(), 4 * s.ctg.size()) &&
               reg(s.flag.data(), 2 * s.flag.size()) && reg(s.n_cigar.data(), 4 * s.n_cigar.size()) && reg(st->ncig16.data(), 2 * st->ncig16.size()) && reg(st->seq2.data(), st->seq2.size()) &&
@@ -320,7 +333,8 @@ void np1_batch_free(np1_batch* b) {
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     b->release_all();
-    if (b->h_pin) (void)hipHostFree(b->h_pin);
+    if (b->h_pin) (void)npalloc::host_free(b->h_pin);
+    np1_ctx_release(b->ctx);
     delete b;
 }
 
@@ -1041,10 +1055,10 @@ int np1_batch_results_fetch(np1_batch* b) {
     (void)hipSetDevice(b->ctx->device);
     const size_t total = b->h_bounds[b->nc];
     if (total + 1 > b->h_pin_cap) {
-        if (b->h_pin) (void)hipHostFree(b->h_pin);
+        if (b->h_pin) (void)npalloc::host_free(b->h_pin);
         b->h_pin = nullptr;
         b->h_pin_cap = total + total / 8 + 4096;
-        if (!hip_ok(hipHostMalloc((void**)&b->h_pin, b->h_pin_cap, hipHostMallocDefault), "hipHostMalloc")) { b->h_pin_cap = 0; return -1; }
+        if (!hip_ok(npalloc::host_malloc((void**)&b->h_pin, b->h_pin_cap, hipHostMallocDefault), "hipHostMalloc")) { b->h_pin_cap = 0; return -1; }
     }
     if (total) HIPCHK(hipMemcpyAsync(b->h_pin, b->out.p, total, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
@@ -1124,12 +1138,10 @@ int64_t np1_batch_device_bytes(np1_batch* b) { return b ? (int64_t)b->device_byt
 
 void np1_stream_unpin(np1_stream* st) {
     if (!st || !st->pinned) return;
-    np::ReadStream& s = st->s;
-    const void* ptrs[] = {s.draft.data(), s.pos.data(), s.ctg.data(), s.flag.data(), s.n_cigar.data(), st->ncig16.data(), st->seq2.data(), st->esc_at.data(), st->esc_val.data(), st->draft4.data(), st->desc_at.data(), st->desc_val.data(), st->compact.plain.data(), st->compact.dpos.data(), st->compact.x_pos.data(),
-                          st->compact.x_lq.data(), st->compact.x_ncig.data(), st->compact.x_cigar.data(), s.l_qseq.data(), s.cigar_off.data(),
-                          s.seq_off.data(), s.cigar.data(), s.seq.data(), s.mapq.data(), s.isize.data(), s.qual_off.data(), s.qual.data()};
-    for (const void* p : ptrs)
-        if (p) (void)hipHostUnregister(const_cast<void*>(p));   // fails harmlessly for arrays that were empty / never registered
+    // (hipHostUnregister waits for copies in flight from the range; only what np1_stream_pin registered is handed to it -- a failing
+    // call would leave its error behind for whoever asks hipGetLastError next)
+    for (void* p : st->registered) (void)npalloc::host_unregister(p);
+    st->registered.clear();
     st->pinned = false;
 }
 
@@ -1160,10 +1172,10 @@ int np1_batch_results_fetch_to(np1_batch* b, char* dst, size_t cap) {
 size_t np1_batch_results_total(np1_batch* b) { return (b && b->ran) ? (size_t)b->h_bounds[b->nc] : 0; }
 void* np1_host_alloc_pinned(size_t bytes) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+    if (npalloc::host_malloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
     return p;
 }
-void np1_host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+void np1_host_free_pinned(void* p) { if (p) (void)npalloc::host_free(p); }
 void np1_batch_swap_work(np1_batch* a, np1_batch* b) { if (a && b && a != b) a->swap_work(*b); }
 
 // Makes np1_batch_kmer_count / np1_batch_snp_valid of this batch replay the reference's region iterator (np1_replay.h).  `st` is the stream

@@ -295,15 +295,15 @@ struct HostPin {
     size_t cap = 0;
     bool ensure(size_t bytes) {
         if (bytes <= cap) return true;
-        if (p) (void)hipHostFree(p);
+        if (p) (void)npalloc::host_free(p);
         p = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 4 + (1u << 20);
-        if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) { p = nullptr; return false; }
+        if (npalloc::host_malloc(&p, want, hipHostMallocPortable) != hipSuccess) { p = nullptr; return false; }
         cap = want;
         return true;
     }
-    ~HostPin() { if (p) (void)hipHostFree(p); }
+    ~HostPin() { if (p) (void)npalloc::host_free(p); }
 };
 
 struct Staging::Impl {

@@ -8,6 +8,7 @@
 struct np1_stream {
     np::ReadStream s;
     bool pinned = false;   // the arrays are registered with the HIP runtime (np1_stream_pin): H2D copies from them are asynchronous
+    std::vector<void*> registered;   // exactly the ranges np1_stream_pin registered (np1_stream_unpin releases these and nothing else)
     // facts about the record arrays an upload needs, found once (np1_device.hip:stream_facts): the longest record, and whether the
     // per-record arrays a device can rebuild itself really are what it would rebuild (pool offsets = running sums, contig = the
     // record's place in read_begin) -- then 20 of the 32 fixed bytes per record need not cross PCIe

@@ -68,13 +68,13 @@ struct PinBuf {   // pinned host staging, grow-only
     size_t cap = 0;
     bool ensure(size_t bytes) {
         if (bytes <= cap && p) return true;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        if (p) { (void)npalloc::host_free(p); p = nullptr; cap = 0; }
         const size_t want = bytes + bytes / 4 + 256;
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        if (npalloc::host_malloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
         cap = want;
         return true;
     }
-    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    ~PinBuf() { if (p) (void)npalloc::host_free(p); }
 };
 
 struct DevStat {   // column statistics as 32-bit device counters (packed to the reference's 16-bit fields afterwards)
@@ -2325,13 +2325,13 @@ int HipExec::build_graph_tiles(const std::vector<uint32_t>& n_tags, uint32_t n_c
     if (getenv("NP2_TILE_PROF")) {     // phase clocks of the tile kernel (cycles summed over the tiles)
         unsigned long long* d_prof = nullptr;
         unsigned long long h[12];
-        (void)hipMalloc(&d_prof, 96);
+        (void)npalloc::dev_malloc((void**)&d_prof, 96);
         (void)hipMemsetAsync(d_prof, 0, 96, q);
         k2_tile_graph<true, 768, 64><<<n_tiles, 64, 0, q>>>(A1, d_prof);
         k2_tile_graph<true, 2048, 128><<<n_tiles, 64, 0, q>>>(A2, d_prof + 6);
         (void)hipMemcpyAsync(h, d_prof, 96, hipMemcpyDeviceToHost, q);
         (void)hipStreamSynchronize(q);
-        (void)hipFree(d_prof);
+        (void)npalloc::dev_free(d_prof);
         fprintf(stderr, "[np2 tile prof] %u tiles; cycles per tile: setup %.0f, stream state %.0f, lookup %.0f, insert %.0f, finish %.0f; large pool (all its tiles) %.0f\n", n_tiles,
                 (double)h[0] / n_tiles, (double)h[1] / n_tiles, (double)h[2] / n_tiles, (double)h[3] / n_tiles, (double)h[4] / n_tiles,
                 (double)(h[6] + h[7] + h[8] + h[9] + h[10]));

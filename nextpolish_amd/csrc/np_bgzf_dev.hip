@@ -47,11 +47,11 @@ struct DevInflater {
 
     bool grow(void** p, size_t* cap, size_t want, bool host) {
         if (want <= *cap) return true;
-        if (*p) { if (host) (void)hipHostFree(*p); else (void)npalloc::dev_free(*p); }
+        if (*p) { if (host) (void)npalloc::host_free(*p); else (void)npalloc::dev_free(*p); }
         *p = nullptr;
         *cap = 0;
         const size_t n = (!host && npalloc::efence()) ? want : want + want / 4 + (1u << 20);
-        const hipError_t e = host ? hipHostMalloc(p, n, hipHostMallocPortable) : npalloc::dev_malloc(p, n);
+        const hipError_t e = host ? npalloc::host_malloc(p, n, hipHostMallocPortable) : npalloc::dev_malloc(p, n);
         if (e != hipSuccess) { *p = nullptr; return false; }
         *cap = n;
         return true;
@@ -75,7 +75,7 @@ struct DevInflater {
         if (check_crc && !d_shift) {
             uint32_t t[64];
             npdev::crc_shift_table(t);
-            if (hipMalloc(&d_shift, sizeof(t)) != hipSuccess) { d_shift = nullptr; return false; }
+            if (npalloc::dev_malloc(&d_shift, sizeof(t)) != hipSuccess) { d_shift = nullptr; return false; }
             if (hipMemcpy(d_shift, t, sizeof(t), hipMemcpyHostToDevice) != hipSuccess) return false;
         }
         static thread_local std::vector<npdev::BlockDesc> desc;

@@ -16,12 +16,64 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
 
 namespace npalloc {
+
+// NP_ALLOCLOG=<path> (debugging): every device allocation, pinned host allocation and host registration of both libraries, and every
+// release, is appended to <path>.<pid> as one line "<ms> <tid> <op> <address> <bytes>" (ops D+ D- device, H+ H- hipHostMalloc, R+ R-
+// hipHostRegister), written with one write(2) each so that the file is complete when the runtime ends the process on a GPU memory fault:
+// the address in the runtime's "Memory access fault by GPU ... on address" line is then looked up among the ranges that were live, or had
+// just been released, at that moment (tests/tools/r5_fault_lookup.py).
+inline int alloc_log_fd() {
+    static const int fd = [] {
+        const char* e = getenv("NP_ALLOCLOG");
+        if (!e || !e[0]) return -1;
+        char path[600];
+        snprintf(path, sizeof path, "%.500s.%d", e, (int)getpid());
+        return open(path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    }();
+    return fd;
+}
+inline void alloc_log(const char* op, const void* p, size_t bytes) {
+    const int fd = alloc_log_fd();
+    if (fd < 0) return;
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    char line[160];
+    const int n = snprintf(line, sizeof line, "%lld.%03ld %ld %s %p %zu\n", (long long)ts.tv_sec, ts.tv_nsec / 1000000, (long)syscall(SYS_gettid), op, p, bytes);
+    if (n > 0) (void)!write(fd, line, (size_t)n);
+}
+
+// pinned host memory and host registrations of both libraries go through here too (so that the log above sees them)
+inline hipError_t host_malloc(void** p, size_t bytes, unsigned flags) {
+    const hipError_t e = hipHostMalloc(p, bytes, flags);
+    if (e == hipSuccess) alloc_log("H+", *p, bytes);
+    return e;
+}
+inline hipError_t host_free(void* p) {
+    if (!p) return hipSuccess;
+    alloc_log("H-", p, 0);
+    return hipHostFree(p);
+}
+inline hipError_t host_register(void* p, size_t bytes) {
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    alloc_log(e == hipSuccess ? "R+" : "R!", p, bytes);
+    return e;
+}
+inline hipError_t host_unregister(void* p) {
+    alloc_log("R-", p, 0);
+    return hipHostUnregister(p);
+}
 
 inline bool efence() {
     static const bool on = [] { const char* e = getenv("NP_EFENCE"); return e && e[0] && e[0] != '0'; }();
@@ -53,6 +105,7 @@ inline bool poison_runs() {      // NP_DEVPOISON=2: also the work buffers of a b
 inline hipError_t dev_malloc_raw(void** p, size_t bytes);
 inline hipError_t dev_malloc(void** p, size_t bytes) {
     const hipError_t e = dev_malloc_raw(p, bytes);
+    if (e == hipSuccess) alloc_log("D+", *p, bytes);
     if (e == hipSuccess && poison() >= 0 && bytes) {
         (void)hipMemset(*p, poison(), bytes);
         (void)hipDeviceSynchronize();
@@ -100,6 +153,7 @@ inline hipError_t dev_malloc_raw(void** p, size_t bytes) {
 
 inline hipError_t dev_free(void* p) {
     if (!p) return hipSuccess;
+    alloc_log("D-", p, 0);
     if (!efence()) return hipFree(p);
     FenceRec r;
     {

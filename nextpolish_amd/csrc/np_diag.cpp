@@ -12,6 +12,7 @@
 #include <signal.h>
 #include <unistd.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -68,9 +69,18 @@ struct Install {
     Install() {
         const char* v = getenv("NP_ABORT_TRACE");
         if (!v || !*v || !strcmp(v, "0")) return;
-        if (getenv("NP_ABORT_TRACE_ON")) return;     // the other library of the pair was first (each holds its own copy of this unit)
-        setenv("NP_ABORT_TRACE_ON", "1", 1);
-        if (strchr(v, '/') && strlen(v) < sizeof g_path) strcpy(g_path, v);
+        // the other library of the pair was first in THIS process (each holds its own copy of this unit).  The marker carries the pid: a
+        // child process inherits the environment and must still install its own handlers
+        char me[32];
+        snprintf(me, sizeof me, "%d", (int)getpid());
+        const char* on = getenv("NP_ABORT_TRACE_ON");
+        if (on && !strcmp(on, me)) return;
+        setenv("NP_ABORT_TRACE_ON", me, 1);
+        // a path ending in a pid that is not ours (inherited from the parent) gets ours appended, so every process writes its own file
+        if (strchr(v, '/') && strlen(v) + 16 < sizeof g_path) {
+            strcpy(g_path, v);
+            if (!strstr(v, me)) { strcat(g_path, "."); strcat(g_path, me); }
+        }
         void* warm[4];
         backtrace(warm, 4);                   // loads libgcc's unwinder now, not inside the handler
         struct sigaction sa;
