@@ -12,6 +12,7 @@
 #include "np1_priv.h"
 #include "np_bam.h"
 #include "np_devalloc.h"
+#include "np_hostcopy.h"
 
 namespace np1dev {
 

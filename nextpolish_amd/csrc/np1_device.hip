@@ -97,7 +97,7 @@ const char* np1_stage_name(int i) {
 // up to 15 bytes past the last element (the pad is part of the allocation, not slack the allocator happens to leave: NP_EFENCE=1)
 static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t st) {
     if (b.ensure(bytes + 64) != 0) return -1;
-    if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+    if (bytes) HIPCHK(npcopy::h2d(b.p, src, bytes, st));
     return 0;
 }
 
@@ -184,57 +184,58 @@ static int fill_batch(np1_batch* b, const np1_stream* st_, bool sync) {
     b->out_pinned = false;
     b->max_lq = st->max_lq;
     hipStream_t q = ctx->stream;
+    auto up = [&](DevBuf& d, const void* src, size_t bytes, hipStream_t qq) { return upload(d, st->up(src), bytes, qq); };
     size_t n = s.n_reads();
     int rc = 0;
     static const bool slim = !(getenv("NP1_UPLOAD") && strcmp(getenv("NP1_UPLOAD"), "full") == 0);   // NP1_UPLOAD=full: every array as the host holds it
     const bool rebuild = slim && st->facts == 1 && n > 0;
     if (!st->draft4.empty()) {
         const size_t ne = st->desc_at.size();
-        rc |= upload(b->draft4, st->draft4.data(), st->draft4.size(), q);
-        if (ne) { rc |= upload(b->desc_at, st->desc_at.data(), 8 * ne, q); rc |= upload(b->desc_val, st->desc_val.data(), ne, q); }
+        rc |= up(b->draft4, st->draft4.data(), st->draft4.size(), q);
+        if (ne) { rc |= up(b->desc_at, st->desc_at.data(), 8 * ne, q); rc |= up(b->desc_val, st->desc_val.data(), ne, q); }
         if (b->draft.ensure(s.draft.size() + 16)) return -1;
         if (rc == 0) launch_unpack_draft4(q, b->draft4.as<uint8_t>(), (uint64_t)s.draft.size(), b->draft.as<uint8_t>(), b->desc_at.as<uint64_t>(), b->desc_val.as<uint8_t>(), (uint64_t)ne);
     } else {
-        rc |= upload(b->draft, s.draft.data(), s.draft.size(), q);
+        rc |= up(b->draft, s.draft.data(), s.draft.size(), q);
     }
-    rc |= upload(b->ctg_off, s.ctg_off.data(), 4 * s.ctg_off.size(), q);
+    rc |= up(b->ctg_off, s.ctg_off.data(), 4 * s.ctg_off.size(), q);
     const np1_stream::Compact& C = st->compact;
     const bool compact = rebuild && C.on;
-    rc |= upload(b->flag, s.flag.data(), 2 * n, q);
+    rc |= up(b->flag, s.flag.data(), 2 * n, q);
     if (compact) {   // one bit + one byte per record, and in full only what is not a plain read a few bases behind the last one
-        rc |= upload(b->up_plain, C.plain.data(), 4 * C.plain.size(), q);
-        rc |= upload(b->up_dpos, C.dpos.data(), n, q);
-        rc |= upload(b->up_xpos, C.x_pos.data(), 4 * C.x_pos.size(), q);
-        rc |= upload(b->up_xlq, C.x_lq.data(), 4 * C.x_lq.size(), q);
-        rc |= upload(b->up_xncig, C.x_ncig.data(), 4 * C.x_ncig.size(), q);
-        rc |= upload(b->up_xcigar, C.x_cigar.data(), 4 * C.x_cigar.size(), q);
+        rc |= up(b->up_plain, C.plain.data(), 4 * C.plain.size(), q);
+        rc |= up(b->up_dpos, C.dpos.data(), n, q);
+        rc |= up(b->up_xpos, C.x_pos.data(), 4 * C.x_pos.size(), q);
+        rc |= up(b->up_xlq, C.x_lq.data(), 4 * C.x_lq.size(), q);
+        rc |= up(b->up_xncig, C.x_ncig.data(), 4 * C.x_ncig.size(), q);
+        rc |= up(b->up_xcigar, C.x_cigar.data(), 4 * C.x_cigar.size(), q);
         if (b->pos.ensure(4 * n) || b->ncig.ensure(4 * n) || b->lq.ensure(4 * n) || b->cigar.ensure(4 * (size_t)C.n_ops + 16) ||
             b->up_work.ensure(8 * (3 * (n + 1) + C.x_pos.size() + 8)))
             return -1;
     } else if (!st->ncig16.empty()) {
-        rc |= upload(b->pos, s.pos.data(), 4 * n, q);
-        rc |= upload(b->lq, s.l_qseq.data(), 4 * n, q);
-        rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);   // the usual case: 2 bytes per record cross PCIe, the device widens them
-        rc |= upload(b->ncig16, st->ncig16.data(), 2 * n, q);
+        rc |= up(b->pos, s.pos.data(), 4 * n, q);
+        rc |= up(b->lq, s.l_qseq.data(), 4 * n, q);
+        rc |= up(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);   // the usual case: 2 bytes per record cross PCIe, the device widens them
+        rc |= up(b->ncig16, st->ncig16.data(), 2 * n, q);
         if (b->ncig.ensure(4 * n)) return -1;
         if (rc == 0) launch_widen_u16(q, b->ncig16.as<uint16_t>(), b->ncig.as<uint32_t>(), (uint64_t)n);
     } else {
-        rc |= upload(b->pos, s.pos.data(), 4 * n, q);
-        rc |= upload(b->lq, s.l_qseq.data(), 4 * n, q);
-        rc |= upload(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);
-        rc |= upload(b->ncig, s.n_cigar.data(), 4 * n, q);
+        rc |= up(b->pos, s.pos.data(), 4 * n, q);
+        rc |= up(b->lq, s.l_qseq.data(), 4 * n, q);
+        rc |= up(b->cigar, s.cigar.data(), 4 * s.cigar.size(), q);
+        rc |= up(b->ncig, s.n_cigar.data(), 4 * n, q);
     }
     if (!st->seq2.empty()) {   // 2 bits per base over PCIe; the device expands them and patches the exception bytes in
         const size_t n2 = st->seq2.size(), ne = st->esc_at.size();
-        rc |= upload(b->seq2, st->seq2.data(), n2, q);
-        if (ne) { rc |= upload(b->esc_at, st->esc_at.data(), 8 * ne, q); rc |= upload(b->esc_val, st->esc_val.data(), ne, q); }
+        rc |= up(b->seq2, st->seq2.data(), n2, q);
+        if (ne) { rc |= up(b->esc_at, st->esc_at.data(), 8 * ne, q); rc |= up(b->esc_val, st->esc_val.data(), ne, q); }
         if (b->seq.ensure(2 * n2 + 64)) return -1;
         if (rc == 0) launch_unpack_seq2(q, b->seq2.as<uint8_t>(), (uint64_t)n2, b->seq.as<uint8_t>(), b->esc_at.as<uint64_t>(), b->esc_val.as<uint8_t>(), (uint64_t)ne);
     } else {
-        rc |= upload(b->seq, s.seq.data(), s.seq.size(), q);
+        rc |= up(b->seq, s.seq.data(), s.seq.size(), q);
     }
     b->h_read_begin = s.read_begin;
-    rc |= upload(b->read_begin, s.read_begin.data(), 8 * s.read_begin.size(), q);
+    rc |= up(b->read_begin, s.read_begin.data(), 8 * s.read_begin.size(), q);
     if (rebuild) {
         // 20 of the 32 fixed bytes per record are functions of the rest: pool offsets = running sums, contig = the record's place in
         // read_begin.  The device rebuilds them (two scans and a search per record) instead of taking them over PCIe.
@@ -253,16 +254,16 @@ static int fill_batch(np1_batch* b, const np1_stream* st_, bool sync) {
             launch_expand_cigars(q, cd, b->ncig.as<uint32_t>(), b->cigoff.as<uint64_t>(), b->cigar.as<uint32_t>(), b->up_work.as<uint64_t>(), b->scan_tmp.as<uint64_t>(),
                                  b->totals.as<uint64_t>() + 24);
     } else {
-        rc |= upload(b->ctg, s.ctg.data(), 4 * n, q);
-        rc |= upload(b->cigoff, s.cigar_off.data(), 8 * n, q);
-        rc |= upload(b->seqoff, s.seq_off.data(), 8 * n, q);
+        rc |= up(b->ctg, s.ctg.data(), 4 * n, q);
+        rc |= up(b->cigoff, s.cigar_off.data(), 8 * n, q);
+        rc |= up(b->seqoff, s.seq_off.data(), 8 * n, q);
     }
     b->has_qual = !s.qual.empty() || n == 0;
     if (b->has_qual) {   // kmer_count needs mapq / isize / base qualities too (kmercount.c:365-465, contig.c:648-665)
-        rc |= upload(b->mapq, s.mapq.data(), n, q);
-        rc |= upload(b->isize, s.isize.data(), 4 * n, q);
-        rc |= upload(b->qualoff, s.qual_off.data(), 8 * n, q);
-        rc |= upload(b->qual, s.qual.data(), s.qual.size(), q);
+        rc |= up(b->mapq, s.mapq.data(), n, q);
+        rc |= up(b->isize, s.isize.data(), 4 * n, q);
+        rc |= up(b->qualoff, s.qual_off.data(), 8 * n, q);
+        rc |= up(b->qual, s.qual.data(), s.qual.size(), q);
     }
     if (rc == 0 && sync && hipStreamSynchronize(q) != hipSuccess) { np1_set_error("upload failed"); rc = -1; }
     b->input_bytes = s.draft.size() + 32 * n + 4 * s.cigar.size() + s.seq.size();
@@ -305,26 +306,53 @@ int np1_stream_pin(np1_stream* st) {
     if (st->pinned) return 0;
     stream_facts(st);
     np::ReadStream& s = st->s;
-    // (arrays below 64 KiB stay pageable: the runtime stages such a copy through its own pinned buffer at once, and page-locking a few
-    // hundred bytes of heap locks -- and maps into the GPU's address space -- whole pages that other allocations of the process share)
-    auto reg = [st](const void* p, size_t bytes) {
-        if (!p || bytes < 65536) return true;
-        if (npalloc::host_register(const_cast<void*>(p), bytes) != hipSuccess) return false;
-        st->registered.push_back(const_cast<void*>(p));
-        return true;
+    // every array fill_batch may upload; what is small enough for the runtime's own staging stays where it is (np_hostcopy.h)
+    std::vector<std::pair<const void*, size_t>> arrays;
+    auto add = [&](const void* p, size_t bytes) { if (p && bytes > npcopy::kDirectMax) arrays.emplace_back(p, bytes); };
+    add(s.draft.data(), s.draft.size()); add(s.pos.data(), 4 * s.pos.size()); add(s.ctg.data(), 4 * s.ctg.size());
+    add(s.flag.data(), 2 * s.flag.size()); add(s.n_cigar.data(), 4 * s.n_cigar.size()); add(st->ncig16.data(), 2 * st->ncig16.size()); add(st->seq2.data(), st->seq2.size());
+    add(st->esc_at.data(), 8 * st->esc_at.size()); add(st->esc_val.data(), st->esc_val.size()); add(st->draft4.data(), st->draft4.size());
+    add(st->desc_at.data(), 8 * st->desc_at.size()); add(st->desc_val.data(), st->desc_val.size()); add(st->compact.plain.data(), 4 * st->compact.plain.size());
+    add(st->compact.dpos.data(), st->compact.dpos.size()); add(st->compact.x_pos.data(), 4 * st->compact.x_pos.size());
+    add(st->compact.x_lq.data(), 4 * st->compact.x_lq.size()); add(st->compact.x_ncig.data(), 4 * st->compact.x_ncig.size());
+    add(st->compact.x_cigar.data(), 4 * st->compact.x_cigar.size()); add(s.l_qseq.data(), 4 * s.l_qseq.size());
+    add(s.cigar_off.data(), 8 * s.cigar_off.size()); add(s.seq_off.data(), 8 * s.seq_off.size());
+    add(s.cigar.data(), 4 * s.cigar.size()); add(s.seq.data(), s.seq.size()); add(s.mapq.data(), s.mapq.size());
+    add(s.isize.data(), 4 * s.isize.size()); add(s.qual_off.data(), 8 * s.qual_off.size()); add(s.qual.data(), s.qual.size());
+    add(s.read_begin.data(), 8 * s.read_begin.size()); add(s.ctg_off.data(), 4 * s.ctg_off.size());
+    // (an upload that does not use a form -- seq when seq2 exists, the per-record arrays when the compact form is on -- never asks for it)
+    const bool slim = !(getenv("NP1_UPLOAD") && strcmp(getenv("NP1_UPLOAD"), "full") == 0);
+    const bool rebuild = slim && st->facts == 1 && s.n_reads() > 0;
+    auto unused = [&](const void* p) {
+        if (!st->seq2.empty() && p == s.seq.data()) return true;
+        if (!st->draft4.empty() && p == s.draft.data()) return true;
+        if (rebuild && (p == s.ctg.data() || p == s.cigar_off.data() || p == s.seq_off.data())) return true;
+        if (rebuild && st->compact.on && (p == s.pos.data() || p == s.l_qseq.data() || p == s.cigar.data() || p == s.n_cigar.data() || p == st->ncig16.data())) return true;
+        if (!(rebuild && st->compact.on) && !st->ncig16.empty() && p == s.n_cigar.data()) return true;
+        return false;
     };
-    bool ok = reg(s.draft.data(), s.draft.size()) && reg(s.pos.data(), 4 * s.pos.size()) && reg(s.ctg.data(), 4 * s.ctg.size()) &&
-              reg(s.flag.data(), 2 * s.flag.size()) && reg(s.n_cigar.data(), 4 * s.n_cigar.size()) && reg(st->ncig16.data(), 2 * st->ncig16.size()) && reg(st->seq2.data(), st->seq2.size()) &&
-              reg(st->esc_at.data(), 8 * st->esc_at.size()) && reg(st->esc_val.data(), st->esc_val.size()) && reg(st->draft4.data(), st->draft4.size()) &&
-              reg(st->desc_at.data(), 8 * st->desc_at.size()) && reg(st->desc_val.data(), st->desc_val.size()) && reg(st->compact.plain.data(), 4 * st->compact.plain.size()) &&
-              reg(st->compact.dpos.data(), st->compact.dpos.size()) && reg(st->compact.x_pos.data(), 4 * st->compact.x_pos.size()) &&
-              reg(st->compact.x_lq.data(), 4 * st->compact.x_lq.size()) && reg(st->compact.x_ncig.data(), 4 * st->compact.x_ncig.size()) &&
-              reg(st->compact.x_cigar.data(), 4 * st->compact.x_cigar.size()) && reg(s.l_qseq.data(), 4 * s.l_qseq.size()) &&
-              reg(s.cigar_off.data(), 8 * s.cigar_off.size()) && reg(s.seq_off.data(), 8 * s.seq_off.size()) &&
-              reg(s.cigar.data(), 4 * s.cigar.size()) && reg(s.seq.data(), s.seq.size()) && reg(s.mapq.data(), s.mapq.size()) &&
-              reg(s.isize.data(), 4 * s.isize.size()) && reg(s.qual_off.data(), 8 * s.qual_off.size()) && reg(s.qual.data(), s.qual.size());
-    st->pinned = true;   // also after a partial failure: unpin releases what was registered
-    if (!ok) { np1_stream_unpin(st); np1_set_error("hipHostRegister failed"); return -1; }
+    size_t total = 0;
+    for (auto& a : arrays) if (!unused(a.first)) total += (a.second + 63) & ~(size_t)63;
+    st->arena_map.clear();
+    if (total) {
+        if (npalloc::host_malloc(&st->arena, total, hipHostMallocPortable) != hipSuccess) { st->arena = nullptr; np1_set_error("hipHostMalloc failed (pinned upload arena)"); return -1; }
+        st->arena_bytes = total;
+        size_t at = 0;
+        for (auto& a : arrays) {
+            if (unused(a.first)) continue;
+            st->arena_map.emplace_back(a.first, static_cast<char*>(st->arena) + at);
+            at += (a.second + 63) & ~(size_t)63;
+        }
+        np::parallel_for(st->arena_map.size(), 1, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                size_t bytes = 0;
+                for (auto& a : arrays) if (a.first == st->arena_map[i].first) bytes = a.second;
+                memcpy(const_cast<void*>(st->arena_map[i].second), st->arena_map[i].first, bytes);
+            }
+        });
+        std::sort(st->arena_map.begin(), st->arena_map.end());
+    }
+    st->pinned = true;
     return 0;
 }
 
@@ -402,7 +430,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     launch_scan_slots(q, b->ins.as<uint32_t>(), G, b->soff.as<uint32_t>(), scan_tmp, &totals[0]);
     t1(1);
     uint64_t S64 = 0;
-    HIPCHK(hipMemcpyAsync(&S64, &totals[0], 8, hipMemcpyDeviceToHost, q));
+    HIPCHK(npcopy::d2h(&S64, &totals[0], 8, q));
     HIPCHK(hipStreamSynchronize(q));
     if (S64 >= 0xfffffff0ull) { np1_set_error("batch too large: more than 2^32 slots"); return -1; }
     const uint32_t S = (uint32_t)S64;
@@ -433,7 +461,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
         launch_scan_rows(q, b->capb.as<uint32_t>(), (uint64_t)(n > 0 ? n : 0), b->rowoff.as<uint64_t>(), scan_tmp, &totals[1]);
         t1(3);
         uint64_t row_bytes = 0;
-        HIPCHK(hipMemcpyAsync(&row_bytes, &totals[1], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(&row_bytes, &totals[1], 8, q));
         HIPCHK(hipStreamSynchronize(q));
         if ((row_bytes >> 2) >= 0xffffffffull) { np1_set_error("batch too large: symbol rows exceed 16 GiB"); return -1; }
         if (b->rows.ensure(row_bytes + 64, 1.02)) return -1;
@@ -454,14 +482,14 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                         b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(), pool_cap, counters,
                         b->heads.as<uint32_t>(), b->redo.as<uint32_t>(), CNT_REDO, flag_single);
             t1(5);
-            HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(hc, counters, sizeof(hc), q));
             HIPCHK(hipStreamSynchronize(q));
             if (hc[CNT_REDO]) {
                 launch_vote(q, 64, b->meta.as<uint4>(), b->rows.as<uint8_t>(), b->slot_info.as<uint8_t>(), S,
                             b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->redo.as<uint32_t>(),
                             hc[CNT_REDO], b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(),
                             pool_cap, counters, b->heads.as<uint32_t>(), b->redo2.as<uint32_t>(), CNT_REDO2, flag_single);
-                HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+                HIPCHK(npcopy::d2h(hc, counters, sizeof(hc), q));
                 HIPCHK(hipStreamSynchronize(q));
                 if (hc[CNT_REDO2]) {
                     if (b->redo3.ensure(4 * (size_t)n_chunks)) return -1;
@@ -469,7 +497,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                                 b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), n_chunks, b->redo2.as<uint32_t>(),
                                 hc[CNT_REDO2], b->slot_res.as<uint16_t>(), b->slot_rec.as<uint32_t>(), b->pool.as<uint32_t>(),
                                 pool_cap, counters, b->heads.as<uint32_t>(), b->redo3.as<uint32_t>(), CNT_REDO3, flag_single);
-                    HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+                    HIPCHK(npcopy::d2h(hc, counters, sizeof(hc), q));
                     HIPCHK(hipStreamSynchronize(q));
                     // slots with more than 160 distinct contexts (very deep pileups with ambiguity codes): every possible context gets
                     // its own list entry, in HBM -- a slice of the list at a time, 1 MiB of scratch per chunk
@@ -483,7 +511,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                         at += slice;
                     }
                     if (hc[CNT_REDO3]) {
-                        HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+                        HIPCHK(npcopy::d2h(hc, counters, sizeof(hc), q));
                         HIPCHK(hipStreamSynchronize(q));
                     }
                 }
@@ -494,7 +522,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                 if (b->pool.ensure(need + need / 4 + (1u << 20))) return -1;
                 uint32_t zero[CNT_WORDS] = {0};
                 zero[CNT_ERR] = hc[CNT_ERR] & ~ERR_POOL_OVERFLOW;
-                HIPCHK(hipMemcpyAsync(counters, zero, sizeof(zero), hipMemcpyHostToDevice, q));
+                HIPCHK(npcopy::h2d(counters, zero, sizeof(zero), q));
                 HIPCHK(hipStreamSynchronize(q));
                 continue;
             }
@@ -514,7 +542,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
             launch_desc(q, R, n, ctg_off, b->soff.as<uint32_t>(), b->qs.as<int32_t>(), b->qe.as<int32_t>(), b->desc.as<uint32_t>(),
                         b->ovf_desc.as<uint32_t>(), ovf_cap, b->chunk_first.as<uint32_t>(), b->chunk_last.as<uint32_t>(), counters);
             t1(3);
-            HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(hc, counters, sizeof(hc), q));
             HIPCHK(hipStreamSynchronize(q));
             if (!(hc[CNT_ERR] & ERR_DESC_OVERFLOW)) break;
             if (hc[CNT_OVFDESC] <= ovf_cap || attempt >= 2) {
@@ -526,7 +554,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
             }
             if (b->ovf_desc.ensure(4 * (size_t)DESC_WORDS * ((size_t)hc[CNT_OVFDESC] + 1024))) return -1;
             uint32_t zero = hc[CNT_ERR] & ~ERR_DESC_OVERFLOW;
-            HIPCHK(hipMemcpyAsync(&counters[CNT_ERR], &zero, 4, hipMemcpyHostToDevice, q));
+            HIPCHK(npcopy::h2d(&counters[CNT_ERR], &zero, 4, q));
         }
         // ---- stage 5 (fused): votes through LDS (+ escalation for crowded slots, + pool growth)
         for (int attempt = 0;; ++attempt) {
@@ -566,7 +594,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                 rc5 = tile(0, nullptr, 0, b->redo.as<uint32_t>(), CNT_REDO);
             if (dbg) {
                 unsigned long long hs[64 * 16], h[16] = {0};
-                HIPCHK(hipMemcpyAsync(hs, dbg, sizeof(hs), hipMemcpyDeviceToHost, q));
+                HIPCHK(npcopy::d2h(hs, dbg, sizeof(hs), q));
                 HIPCHK(hipStreamSynchronize(q));
                 for (int sh = 0; sh < 64; ++sh)
                     for (int k = 0; k < 16; ++k) h[k] += hs[16 * sh + k];
@@ -580,15 +608,15 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                 return np1_batch_score_chain(b, cfg, stage_ms);
             }
             t1(5);
-            HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(hc, counters, sizeof(hc), q));
             HIPCHK(hipStreamSynchronize(q));
             if (hc[CNT_REDO]) {
                 if (tile(1, b->redo.as<uint32_t>(), hc[CNT_REDO], b->redo2.as<uint32_t>(), CNT_REDO2) != 0) { np1_set_error("LDS plan failed (level 1)"); return -1; }
-                HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+                HIPCHK(npcopy::d2h(hc, counters, sizeof(hc), q));
                 HIPCHK(hipStreamSynchronize(q));
                 if (hc[CNT_REDO2]) {
                     if (tile(2, b->redo2.as<uint32_t>(), hc[CNT_REDO2], nullptr, CNT_REDO2) != 0) { np1_set_error("LDS plan failed (level 2)"); return -1; }
-                    HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+                    HIPCHK(npcopy::d2h(hc, counters, sizeof(hc), q));
                     HIPCHK(hipStreamSynchronize(q));
                     if ((hc[CNT_ERR] & ERR_CTX_OVERFLOW) && !fp_rate) {
                         // more than 160 distinct contexts in a slot: the staged sequence keeps such slots' lists in HBM; this batch takes
@@ -610,7 +638,7 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
                 if (b->pool.ensure(need + need / 4 + (1u << 20))) return -1;
                 uint32_t zero[CNT_WORDS] = {0};
                 zero[CNT_ERR] = hc[CNT_ERR] & ~ERR_POOL_OVERFLOW;
-                HIPCHK(hipMemcpyAsync(counters, zero, sizeof(zero), hipMemcpyHostToDevice, q));
+                HIPCHK(npcopy::h2d(counters, zero, sizeof(zero), q));
                 HIPCHK(hipStreamSynchronize(q));
                 continue;
             }
@@ -649,11 +677,11 @@ int np1_batch_score_chain(np1_batch* b, const Configure* cfg, float* stage_ms) {
     launch_contig_bounds(q, ctg_off, nc, b->soff.as<uint32_t>(), b->opos.as<uint32_t>(), b->bounds.as<uint32_t>());
     t1(7);
     b->h_bounds.resize((size_t)nc + 1);
-    HIPCHK(hipMemcpyAsync(b->h_bounds.data(), b->bounds.p, 4 * ((size_t)nc + 1), hipMemcpyDeviceToHost, q));
+    HIPCHK(npcopy::d2h(b->h_bounds.data(), b->bounds.p, 4 * ((size_t)nc + 1), q));
     uint64_t h_votes[1 + POOL_SHARDS];
-    HIPCHK(hipMemcpyAsync(&h_votes[0], &totals[3], 8, hipMemcpyDeviceToHost, q));
-    HIPCHK(hipMemcpyAsync(&h_votes[1], &totals[8], 8 * POOL_SHARDS, hipMemcpyDeviceToHost, q));
-    HIPCHK(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, q));
+    HIPCHK(npcopy::d2h(&h_votes[0], &totals[3], 8, q));
+    HIPCHK(npcopy::d2h(&h_votes[1], &totals[8], 8 * POOL_SHARDS, q));
+    HIPCHK(npcopy::d2h(hc, counters, sizeof(hc), q));
     HIPCHK(hipStreamSynchronize(q));
     b->votes = 0;
     for (uint32_t i = 0; i < 1 + POOL_SHARDS; ++i) b->votes += h_votes[i];
@@ -687,15 +715,15 @@ static int replay_votes(np1_batch* b, const KcCtx& c, const uint32_t* d_ctg, con
     if (!R.have_pos) {     // once per pass: positions and end positions of the records as the kernels see them
         if (!R.pos.ensure(4 * (size_t)(n_all + 1)) || !R.endpos.ensure(4 * (size_t)(n_all + 1))) { np1_set_error("hipHostMalloc failed"); return -1; }
         if (n_all) {
-            HIPCHK(hipMemcpyAsync(R.pos.p, b->pos.p, 4 * (size_t)n_all, hipMemcpyDeviceToHost, q));
-            HIPCHK(hipMemcpyAsync(R.endpos.p, b->kc_endpos.p, 4 * (size_t)n_all, hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(R.pos.p, b->pos.p, 4 * (size_t)n_all, q));
+            HIPCHK(npcopy::d2h(R.endpos.p, b->kc_endpos.p, 4 * (size_t)n_all, q));
         }
         R.have_pos = true;
     }
     std::vector<uint32_t> pt_ctg(n_parts);
     std::vector<int32_t> pt_se(2 * (size_t)n_parts);
-    HIPCHK(hipMemcpyAsync(pt_ctg.data(), d_ctg, 4 * (size_t)n_parts, hipMemcpyDeviceToHost, q));
-    HIPCHK(hipMemcpyAsync(pt_se.data(), d_se, 8 * (size_t)n_parts, hipMemcpyDeviceToHost, q));
+    HIPCHK(npcopy::d2h(pt_ctg.data(), d_ctg, 4 * (size_t)n_parts, q));
+    HIPCHK(npcopy::d2h(pt_se.data(), d_se, 8 * (size_t)n_parts, q));
     HIPCHK(hipStreamSynchronize(q));
     struct Run { uint32_t ct, p0, p1; };
     std::vector<Run> runs;
@@ -752,15 +780,15 @@ static int replay_votes(np1_batch* b, const KcCtx& c, const uint32_t* d_ctg, con
     if (R.first.ensure(4 * ((size_t)n_parts + 2)) || R.stale.ensure(8 * ((size_t)n_parts + 1)) || R.n2.ensure(4 * ((size_t)n_parts + 1)) || R.brk.ensure(4 * ((size_t)n_parts + 1))) return -1;
     auto vote = [&](const Lists& L, const int32_t* d_n2) -> int {
         if (R.list.ensure(4 * (L.list.size() + 2))) return -1;
-        HIPCHK(hipMemcpyAsync(R.first.p, L.first.data(), 4 * ((size_t)n_parts + 1), hipMemcpyHostToDevice, q));
-        if (!L.list.empty()) HIPCHK(hipMemcpyAsync(R.list.p, L.list.data(), 4 * L.list.size(), hipMemcpyHostToDevice, q));
-        HIPCHK(hipMemcpyAsync(R.stale.p, L.stale.data(), 8 * (size_t)n_parts, hipMemcpyHostToDevice, q));
+        HIPCHK(npcopy::h2d(R.first.p, L.first.data(), 4 * ((size_t)n_parts + 1), q));
+        if (!L.list.empty()) HIPCHK(npcopy::h2d(R.list.p, L.list.data(), 4 * L.list.size(), q));
+        HIPCHK(npcopy::h2d(R.stale.p, L.stale.data(), 8 * (size_t)n_parts, q));
         HIPCHK(hipMemsetAsync(c.hcount, 0, 4, q));     // every launch takes the haplotype pool from its start
         kc_launch_winner_replay(q, c, d_ctg, d_se, d_len, d_woff, n_parts, n_all, d_wpool, d_haswin, R.first.as<uint32_t>(), R.list.as<uint32_t>(), R.stale.as<long long>(), d_n2,
                                 d_n2 ? nullptr : R.brk.as<uint32_t>());
         if (!d_n2) {
-            HIPCHK(hipMemcpyAsync(state.data(), d_haswin, n_parts, hipMemcpyDeviceToHost, q));
-            HIPCHK(hipMemcpyAsync(brk.data(), R.brk.p, 4 * (size_t)n_parts, hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(state.data(), d_haswin, n_parts, q));
+            HIPCHK(npcopy::d2h(brk.data(), R.brk.p, 4 * (size_t)n_parts, q));
         }
         HIPCHK(hipStreamSynchronize(q));   // (the host vectors are the source of the copies above)
         return 0;
@@ -808,7 +836,7 @@ static int replay_votes(np1_batch* b, const KcCtx& c, const uint32_t* d_ctg, con
             for (uint32_t p = r.p0; p < r.p1; ++p) n2[p] = (int32_t)k[p - r.p0];
         }
     });
-    HIPCHK(hipMemcpyAsync(R.n2.p, n2.data(), 4 * (size_t)n_parts, hipMemcpyHostToDevice, q));
+    HIPCHK(npcopy::h2d(R.n2.p, n2.data(), 4 * (size_t)n_parts, q));
     return vote(cur, R.n2.as<int32_t>());
 }
 
@@ -871,7 +899,7 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
         kc_launch_draft(q, b->draft.as<uint8_t>(), (uint32_t)G, b->kc_code.as<uint8_t>(), b->kc_flag.as<uint8_t>());
         launch_scan_u8(q, b->kc_flag.as<uint8_t>(), G, b->kc_fpos.as<uint32_t>(), scan_tmp, &totals[0]);
         uint64_t M = 0;
-        HIPCHK(hipMemcpyAsync(&M, &totals[0], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(&M, &totals[0], 8, q));
         HIPCHK(hipStreamSynchronize(q));
         const uint32_t reg_cap = (uint32_t)(M + nc + 16);
         if (b->kc_flagged.ensure(4 * (M + 4)) || b->kc_work.ensure(4 * (12 * M + 4ull * nc + 64)) || b->kc_nd_ctg.ensure(4ull * reg_cap) ||
@@ -881,7 +909,7 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
         kc_launch_regions(q, c, nc, b->kc_fpos.as<uint32_t>(), b->kc_flagged.as<uint32_t>(), b->kc_work.as<int32_t>(),
                           b->kc_nd_ctg.as<uint32_t>(), b->kc_nd_se.as<int32_t>(), b->kc_kr_ctg.as<uint32_t>(), b->kc_kr_se.as<int32_t>(),
                           reg_cap, kcnt);
-        HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(hk, kcnt, sizeof(hk), q));
         HIPCHK(hipStreamSynchronize(q));
         if (hk[KCC_ERR]) { np1_set_error(std::string(task) + ": region discovery failed"); return -1; }
         const uint32_t n_nd = snp_valid ? 0u : hk[KCC_NODEPTH], n_kr = hk[KCC_KREG];   // snp_valid has no no-depth regions
@@ -894,7 +922,7 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
                           b->kc_nd_se.as<int32_t>(), n_nd, b->ins.as<uint32_t>());
         launch_scan_slots(q, b->ins.as<uint32_t>(), G, b->soff.as<uint32_t>(), scan_tmp, &totals[1]);
         uint64_t S64 = 0;
-        HIPCHK(hipMemcpyAsync(&S64, &totals[1], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(&S64, &totals[1], 8, q));
         HIPCHK(hipStreamSynchronize(q));
         if (S64 >= 0xfffffff0ull) { np1_set_error("batch too large: more than 2^32 slots"); return -1; }
         const uint32_t S = (uint32_t)S64;
@@ -923,19 +951,19 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
         uint64_t W = 0;
         if (n_kr) {
             std::vector<int32_t> se(2 * (size_t)n_kr);
-            HIPCHK(hipMemcpyAsync(se.data(), b->kc_kr_se.p, 8 * (size_t)n_kr, hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(se.data(), b->kc_kr_se.p, 8 * (size_t)n_kr, q));
             HIPCHK(hipStreamSynchronize(q));
             std::vector<uint32_t> woff((size_t)n_kr + 1, 0);
             for (uint32_t i = 0; i < n_kr; ++i) woff[i + 1] = woff[i] + (uint32_t)(se[2 * i + 1] - se[2 * i]) + 8u;
             if (b->kc_workoff.ensure(4 * ((size_t)n_kr + 1)) || b->kc_work.ensure(4 * ((size_t)woff[n_kr] + 16)) ||
                 b->kc_nparts.ensure(4 * ((size_t)n_kr + 2)) || b->kc_partoff.ensure(4 * ((size_t)n_kr + 2)))
                 return -1;
-            HIPCHK(hipMemcpyAsync(b->kc_workoff.p, woff.data(), 4 * ((size_t)n_kr + 1), hipMemcpyHostToDevice, q));
+            HIPCHK(npcopy::h2d(b->kc_workoff.p, woff.data(), 4 * ((size_t)n_kr + 1), q));
             kc_launch_split(q, c, b->kc_kr_ctg.as<uint32_t>(), b->kc_kr_se.as<int32_t>(), n_kr, b->kc_work.as<int32_t>(),
                             b->kc_workoff.as<uint32_t>(), b->kc_nparts.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
             launch_scan_u32(q, b->kc_nparts.as<uint32_t>(), n_kr, b->kc_partoff.as<uint32_t>(), scan_tmp, &totals[2]);
             uint64_t np64 = 0;
-            HIPCHK(hipMemcpyAsync(&np64, &totals[2], 8, hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(&np64, &totals[2], 8, q));
             HIPCHK(hipStreamSynchronize(q));   // also keeps woff alive until the copy above is done
             n_parts = (uint32_t)np64;
             if (b->kc_pt_ctg.ensure(4 * ((size_t)n_parts + 1)) || b->kc_pt_se.ensure(8 * ((size_t)n_parts + 1)) ||
@@ -946,7 +974,7 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
                             b->kc_workoff.as<uint32_t>(), b->kc_nparts.as<uint32_t>(), b->kc_partoff.as<uint32_t>(),
                             b->kc_pt_ctg.as<uint32_t>(), b->kc_pt_se.as<int32_t>(), b->kc_pt_len.as<uint32_t>());
             launch_scan_u32(q, b->kc_pt_len.as<uint32_t>(), n_parts, b->kc_woff.as<uint32_t>(), scan_tmp, &totals[3]);
-            HIPCHK(hipMemcpyAsync(&W, &totals[3], 8, hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(&W, &totals[3], 8, q));
             HIPCHK(hipStreamSynchronize(q));
             const size_t hcap = std::min<size_t>(((size_t)8192 * n_parts + ((size_t)64 << 20)) * scale, (size_t)0xfffffff0u);
             if (b->kc_wpool.ensure(W + 64) || b->kc_hpool.ensure(hcap)) return -1;
@@ -974,7 +1002,7 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
                 sv_launch_val_sizes(q, b->kc_pt_len.as<uint32_t>(), n_parts, b->sv_vsz.as<uint32_t>());
                 launch_scan_u32(q, b->sv_vsz.as<uint32_t>(), n_parts, b->sv_voff.as<uint32_t>(), scan_tmp, &totals[5]);
                 uint64_t V = 0;
-                HIPCHK(hipMemcpyAsync(&V, &totals[5], 8, hipMemcpyDeviceToHost, q));
+                HIPCHK(npcopy::d2h(&V, &totals[5], 8, q));
                 HIPCHK(hipStreamSynchronize(q));
                 if (b->sv_val.ensure(4 * (V + 4)) || b->sv_p2ctg.ensure(4 * (V + 4)) || b->sv_p2se.ensure(8 * (V + 4)) || b->sv_p2len.ensure(4 * (V + 4)) ||
                     b->sv_woff2.ensure(4 * (V + 4)) || b->sv_haswin2.ensure(V + 4))
@@ -987,7 +1015,7 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
                                        b->sv_p2se.as<int32_t>(), b->sv_p2len.as<uint32_t>());
                 launch_scan_u32(q, b->sv_p2len.as<uint32_t>(), V, b->sv_woff2.as<uint32_t>(), scan_tmp, &totals[6]);
                 uint64_t W2 = 0;
-                HIPCHK(hipMemcpyAsync(&W2, &totals[6], 8, hipMemcpyDeviceToHost, q));
+                HIPCHK(npcopy::d2h(&W2, &totals[6], 8, q));
                 HIPCHK(hipStreamSynchronize(q));
                 if (b->kc_wpool.ensure(W2 + 64)) return -1;     // round 1's winners are in the slots by now
                 if (b->replay.on) {
@@ -1010,8 +1038,8 @@ static int kmer_pipeline(np1_batch* b, const Configure* cfg, bool snp_valid) {
         launch_emit(q, b->slot_res.as<uint16_t>(), b->slot_info.as<uint8_t>(), b->opos.as<uint32_t>(), S, 1u, b->out.as<uint8_t>());
         launch_contig_bounds(q, ctg_off, nc, b->soff.as<uint32_t>(), b->opos.as<uint32_t>(), b->bounds.as<uint32_t>());
         b->h_bounds.resize((size_t)nc + 1);
-        HIPCHK(hipMemcpyAsync(b->h_bounds.data(), b->bounds.p, 4 * ((size_t)nc + 1), hipMemcpyDeviceToHost, q));
-        HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(b->h_bounds.data(), b->bounds.p, 4 * ((size_t)nc + 1), q));
+        HIPCHK(npcopy::d2h(hk, kcnt, sizeof(hk), q));
         HIPCHK(hipStreamSynchronize(q));
         if (hk[KCC_ERR] & ERR_KC_POOL) continue;   // a scratch pool ran out: rerun with larger pools
         if (hk[KCC_ERR] & ERR_KC_UNDEFINED) {
@@ -1060,7 +1088,7 @@ int np1_batch_results_fetch(np1_batch* b) {
         b->h_pin_cap = total + total / 8 + 4096;
         if (!hip_ok(npalloc::host_malloc((void**)&b->h_pin, b->h_pin_cap, hipHostMallocDefault), "hipHostMalloc")) { b->h_pin_cap = 0; return -1; }
     }
-    if (total) HIPCHK(hipMemcpyAsync(b->h_pin, b->out.p, total, hipMemcpyDeviceToHost, b->ctx->stream));
+    if (total) HIPCHK(npcopy::d2h(b->h_pin, b->out.p, total, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     b->out_pinned = true;
     return 0;
@@ -1080,7 +1108,7 @@ int np1_batch_result_copy(np1_batch* b, int64_t c, char* dst, int64_t cap) {
     if (!b->out_cached) {
         size_t total = b->h_bounds[b->nc];
         b->h_out.resize(total + 1);
-        if (total) HIPCHK(hipMemcpy(b->h_out.data(), b->out.p, total, hipMemcpyDeviceToHost));
+        if (total) HIPCHK(npcopy::d2h_sync(b->h_out.data(), b->out.p, total));
         b->out_cached = true;
     }
     memcpy(dst, b->h_out.data() + b->h_bounds[(size_t)c], (size_t)len);
@@ -1103,7 +1131,7 @@ extern "C" int np1_batch_tile_join(np1_batch* b, uint32_t i_elo, uint32_t i_a, u
     hipStream_t q = b->ctx->stream;
     if (b->join_out.ensure(16)) return -1;
     launch_join_info(q, b->soff.as<uint32_t>(), b->single_map.as<uint8_t>(), b->opos.as<uint32_t>(), i_elo, i_a, i_b, i_ehi, skip, b->join_out.as<uint32_t>());
-    HIPCHK(hipMemcpyAsync(out, b->join_out.p, 16, hipMemcpyDeviceToHost, q));
+    HIPCHK(npcopy::d2h(out, b->join_out.p, 16, q));
     HIPCHK(hipStreamSynchronize(q));
     return 0;
 }
@@ -1111,7 +1139,7 @@ extern "C" int np1_batch_tile_join(np1_batch* b, uint32_t i_elo, uint32_t i_a, u
 extern "C" int np1_batch_result_range(np1_batch* b, uint32_t o0, uint32_t o1, char* dst) {
     if (!b || !b->ran || o0 > o1 || o1 > b->h_bounds[b->nc]) { np1_set_error("np1_batch_result_range: bad range"); return -1; }
     (void)hipSetDevice(b->ctx->device);
-    if (o1 > o0) HIPCHK(hipMemcpy(dst, b->out.as<uint8_t>() + o0, (size_t)(o1 - o0), hipMemcpyDeviceToHost));
+    if (o1 > o0) HIPCHK(npcopy::d2h_sync(dst, b->out.as<uint8_t>() + o0, (size_t)(o1 - o0)));
     return 0;
 }
 
@@ -1128,7 +1156,7 @@ int64_t np1_batch_debug_slots(np1_batch* b, int kind, void* out, int64_t n) {
     const size_t m = (size_t)std::min<int64_t>(n, (int64_t)b->S);
     const void* src = kind == 0 ? b->slot_info.p : kind == 1 ? b->slot_res.p : b->slot_rec.p;
     const size_t w = kind == 0 ? 1 : kind == 1 ? 2 : 4;
-    if (m && hipMemcpy(out, src, m * w, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (m && npcopy::d2h_sync(out, src, m * w) != hipSuccess) return -1;
     return (int64_t)b->S;
 }
 int64_t np1_batch_update_count(np1_batch* b) { return b && b->ran ? (int64_t)b->votes : -1; }
@@ -1138,10 +1166,11 @@ int64_t np1_batch_device_bytes(np1_batch* b) { return b ? (int64_t)b->device_byt
 
 void np1_stream_unpin(np1_stream* st) {
     if (!st || !st->pinned) return;
-    // (hipHostUnregister waits for copies in flight from the range; only what np1_stream_pin registered is handed to it -- a failing
-    // call would leave its error behind for whoever asks hipGetLastError next)
-    for (void* p : st->registered) (void)npalloc::host_unregister(p);
-    st->registered.clear();
+    (void)hipDeviceSynchronize();      // copies out of the arena may still be in flight on any lane's stream
+    if (st->arena) (void)npalloc::host_free(st->arena);
+    st->arena = nullptr;
+    st->arena_bytes = 0;
+    st->arena_map.clear();
     st->pinned = false;
 }
 
@@ -1151,10 +1180,10 @@ int np1_batch_download_slots(np1_batch* b, int64_t c, std::vector<uint32_t>* sof
     (void)hipSetDevice(b->ctx->device);
     uint32_t g0 = b->h_ctg_off[(size_t)c], g1 = b->h_ctg_off[(size_t)c + 1];
     soff->resize((size_t)(g1 - g0) + 1);
-    HIPCHK(hipMemcpy(soff->data(), b->soff.as<uint32_t>() + g0, 4 * soff->size(), hipMemcpyDeviceToHost));
+    HIPCHK(npcopy::d2h_sync(soff->data(), b->soff.as<uint32_t>() + g0, 4 * soff->size()));
     uint32_t s0 = (*soff)[0], s1 = soff->back();
     res->resize(s1 - s0);
-    if (s1 > s0) HIPCHK(hipMemcpy(res->data(), b->slot_res.as<uint16_t>() + s0, 2 * (size_t)(s1 - s0), hipMemcpyDeviceToHost));
+    if (s1 > s0) HIPCHK(npcopy::d2h_sync(res->data(), b->slot_res.as<uint16_t>() + s0, 2 * (size_t)(s1 - s0)));
     return 0;
 }
 
@@ -1165,7 +1194,7 @@ int np1_batch_results_fetch_to(np1_batch* b, char* dst, size_t cap) {
     (void)hipSetDevice(b->ctx->device);
     const size_t total = b->h_bounds[b->nc];
     if (total > cap) { np1_set_error("np1_batch_results_fetch_to: buffer too small"); return -1; }
-    if (total) HIPCHK(hipMemcpyAsync(dst, b->out.p, total, hipMemcpyDeviceToHost, b->ctx->stream));
+    if (total) HIPCHK(npcopy::d2h(dst, b->out.p, total, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     return 0;
 }

@@ -537,12 +537,12 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         W.rec_base.ensure(8 * (size_t)(n_segs + 2)) || W.first_seg.ensure(4 * (size_t)(nc + 2)) || W.small.ensure(256) ||
         W.scan_tmp.ensure(8 * (np1k::scan_tmp_words((uint64_t)n_segs + 1) + 8)))
         return -1;
-    if (b->G) HIPCHK(hipMemcpyAsync(b->draft.p, S.draft.p, b->G, hipMemcpyHostToDevice, q));
-    HIPCHK(hipMemcpyAsync(b->ctg_off.p, S.ctg_off.data(), 4 * (size_t)(nc + 1), hipMemcpyHostToDevice, q));
-    if (S.comp_bytes) HIPCHK(hipMemcpyAsync(W.comp.p, S.comp.p, S.comp_bytes + 4096, hipMemcpyHostToDevice, q));
-    if (n_blocks) HIPCHK(hipMemcpyAsync(W.blocks.p, S.blocks.data(), sizeof(npdev::BlockDesc) * (size_t)n_blocks, hipMemcpyHostToDevice, q));
-    if (n_segs) HIPCHK(hipMemcpyAsync(W.segs.p, S.segs.data(), sizeof(Segment) * (size_t)n_segs, hipMemcpyHostToDevice, q));
-    HIPCHK(hipMemcpyAsync(W.first_seg.p, S.first_seg.data(), 4 * (size_t)(nc + 1), hipMemcpyHostToDevice, q));
+    if (b->G) HIPCHK(npcopy::h2d(b->draft.p, S.draft.p, b->G, q));
+    HIPCHK(npcopy::h2d(b->ctg_off.p, S.ctg_off.data(), 4 * (size_t)(nc + 1), q));
+    if (S.comp_bytes) HIPCHK(npcopy::h2d(W.comp.p, S.comp.p, S.comp_bytes + 4096, q));
+    if (n_blocks) HIPCHK(npcopy::h2d(W.blocks.p, S.blocks.data(), sizeof(npdev::BlockDesc) * (size_t)n_blocks, q));
+    if (n_segs) HIPCHK(npcopy::h2d(W.segs.p, S.segs.data(), sizeof(Segment) * (size_t)n_segs, q));
+    HIPCHK(npcopy::h2d(W.first_seg.p, S.first_seg.data(), 4 * (size_t)(nc + 1), q));
     HIPCHK(hipMemsetAsync(W.small.p, 0, 256, q));
     uint32_t* d_err = W.small.as<uint32_t>();           // [0] error bits, [1] max l_qseq
     uint64_t* d_tot = reinterpret_cast<uint64_t*>(W.small.as<uint8_t>() + 64);   // scan totals
@@ -571,18 +571,18 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
                 uint32_t t[64];
                 npdev::crc_shift_table(t);
                 if (W.crc_shift.ensure(sizeof(t))) return -1;
-                HIPCHK(hipMemcpy(W.crc_shift.p, t, sizeof(t), hipMemcpyHostToDevice));
+                HIPCHK(npcopy::h2d_sync(W.crc_shift.p, t, sizeof(t)));
             }
             k_crc_check<<<nblk(n_blocks, 4), 256, 0, q>>>(W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(),
                                                          W.crc_shift.as<uint32_t>());
         }
         W.h_status.resize(n_blocks);
-        HIPCHK(hipMemcpyAsync(W.h_status.data(), W.status.p, 4 * (size_t)n_blocks, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(W.h_status.data(), W.status.p, 4 * (size_t)n_blocks, q));
     }
     if (n_segs) {
         k_chase<false><<<nblk(n_segs, 4), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, W.counts.as<uint32_t>(), nullptr, nullptr, nullptr, d_err);
         np1k::launch_scan_rows(q, W.counts.as<uint32_t>(), n_segs, W.rec_base.as<uint64_t>(), W.scan_tmp.as<uint64_t>(), &d_tot[0]);
-        HIPCHK(hipMemcpyAsync(&n_rec, &d_tot[0], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(&n_rec, &d_tot[0], 8, q));
     } else {
         HIPCHK(hipMemsetAsync(W.rec_base.p, 0, 16, q));
     }
@@ -600,7 +600,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
             memcpy(&want, (const uint8_t*)S.comp.p + d.in_off + d.in_len, 4);
             if (np::crc32_block(tmp.data(), d.out_len) != want) { np1_set_error("corrupt BGZF block in the BAM (CRC mismatch)"); return -1; }
         }
-        HIPCHK(hipMemcpy(W.inflated.as<uint8_t>() + d.out_off, tmp.data(), d.out_len, hipMemcpyHostToDevice));
+        HIPCHK(npcopy::h2d_sync(W.inflated.as<uint8_t>() + d.out_off, tmp.data(), d.out_len));
         patched = true;
         ++W.n_host_blocks;
     }
@@ -608,7 +608,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         HIPCHK(hipMemsetAsync(d_err, 0, 4, q));
         k_chase<false><<<nblk(n_segs, 4), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.segs.as<Segment>(), n_segs, W.counts.as<uint32_t>(), nullptr, nullptr, nullptr, d_err);
         np1k::launch_scan_rows(q, W.counts.as<uint32_t>(), n_segs, W.rec_base.as<uint64_t>(), W.scan_tmp.as<uint64_t>(), &d_tot[0]);
-        HIPCHK(hipMemcpyAsync(&n_rec, &d_tot[0], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(&n_rec, &d_tot[0], 8, q));
         HIPCHK(hipStreamSynchronize(q));
     }
     if (n_rec >= 0xfffffff0ull) { np1_set_error("batch too large: more than 2^32 records"); return -1; }
@@ -630,11 +630,11 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         np1k::launch_scan_rows(q, W.ncw.as<uint32_t>(), n_rec, W.cig_at.as<uint64_t>(), tmp, &d_tot[2]);
         np1k::launch_scan_rows(q, W.seqb.as<uint32_t>(), n_rec, W.seq_at.as<uint64_t>(), tmp, &d_tot[3]);
         if (with_qual) np1k::launch_scan_rows(q, W.qualb.as<uint32_t>(), n_rec, W.qual_at.as<uint64_t>(), tmp, &d_tot[4]);
-        HIPCHK(hipMemcpyAsync(totals, &d_tot[1], with_qual ? 32 : 24, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(totals, &d_tot[1], with_qual ? 32 : 24, q));
     } else {
         HIPCHK(hipMemsetAsync(W.kidx.p, 0, 8, q));
     }
-    HIPCHK(hipMemcpyAsync(h_small, d_err, 8, hipMemcpyDeviceToHost, q));
+    HIPCHK(npcopy::d2h(h_small, d_err, 8, q));
     HIPCHK(hipStreamSynchronize(q));
     if (timing) t_2 = now_ms();
     if (h_small[0] & IG_ERR_CGTAG) return 1;
@@ -658,17 +658,17 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
     }
     k_read_begin<<<nblk(nc + 1, 64), 64, 0, q>>>(W.first_seg.as<uint32_t>(), nc, W.rec_base.as<uint64_t>(), W.kidx.as<uint32_t>(), n_rec, b->read_begin.as<uint64_t>());
     b->h_read_begin.resize((size_t)nc + 1);
-    HIPCHK(hipMemcpyAsync(b->h_read_begin.data(), b->read_begin.p, 8 * (size_t)(nc + 1), hipMemcpyDeviceToHost, q));
+    HIPCHK(npcopy::d2h(b->h_read_begin.data(), b->read_begin.p, 8 * (size_t)(nc + 1), q));
     if (replay_bai) {   // kmer_count / snp_valid replay the reference's region iterator: the records' virtual offsets come down with the batch
         np1_batch::Replay& R = b->replay;
         if (W.geo.ensure(8 * (S.block_geo.size() + 3)) || W.voff.ensure(8 * nn) || W.voff_end.ensure(8 * nn)) return -1;
         if (!R.own_voff.ensure(8 * nn) || !R.own_voff_end.ensure(8 * nn)) { np1_set_error("hipHostMalloc failed"); return -1; }
         if (n_rec) {
-            HIPCHK(hipMemcpyAsync(W.geo.p, S.block_geo.data(), 8 * S.block_geo.size(), hipMemcpyHostToDevice, q));
+            HIPCHK(npcopy::h2d(W.geo.p, S.block_geo.data(), 8 * S.block_geo.size(), q));
             k_rec_voff<<<nblk(n_rec, 256), 256, 0, q>>>(W.inflated.as<uint8_t>(), W.rec_off.as<uint64_t>(), n_rec, W.keep.as<uint32_t>(), W.kidx.as<uint32_t>(),
                                                        W.blocks.as<npdev::BlockDesc>(), W.geo.as<uint64_t>(), n_blocks, W.voff.as<uint64_t>(), W.voff_end.as<uint64_t>());
-            HIPCHK(hipMemcpyAsync(R.own_voff.p, W.voff.p, 8 * n, hipMemcpyDeviceToHost, q));
-            HIPCHK(hipMemcpyAsync(R.own_voff_end.p, W.voff_end.p, 8 * n, hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(R.own_voff.p, W.voff.p, 8 * n, q));
+            HIPCHK(npcopy::d2h(R.own_voff_end.p, W.voff_end.p, 8 * n, q));
         }
     }
     HIPCHK(hipStreamSynchronize(q));
@@ -730,8 +730,8 @@ extern "C" int64_t np1_debug_inflate_device_prof(int device, const uint8_t* bgzf
     DevBuf dc, du, db, ds;
     if (dc.ensure(n + 4096) || du.ensure(u + 64) || db.ensure(sizeof(npdev::BlockDesc) * (blocks.size() + 1)) || ds.ensure(4 * (blocks.size() + 1))) return -1;
     HIPCHK(hipMemset(dc.p, 0, n + 4096));
-    HIPCHK(hipMemcpy(dc.p, bgzf, n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(db.p, blocks.data(), sizeof(npdev::BlockDesc) * blocks.size(), hipMemcpyHostToDevice));
+    HIPCHK(npcopy::h2d_sync(dc.p, bgzf, n));
+    HIPCHK(npcopy::h2d_sync(db.p, blocks.data(), sizeof(npdev::BlockDesc) * blocks.size()));
     HIPCHK(hipMemset(du.p, 0xEE, u + 64));
     DevBuf dp;
     if (dp.ensure(64)) return -1;
@@ -753,10 +753,10 @@ extern "C" int64_t np1_debug_inflate_device_prof(int device, const uint8_t* bgzf
     HIPCHK(hipDeviceSynchronize());
     if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (prof) HIPCHK(hipMemcpy(prof, dp.p, 64, hipMemcpyDeviceToHost));
+    if (prof) HIPCHK(npcopy::d2h_sync(prof, dp.p, 64));
     dp.release();
-    if (u) HIPCHK(hipMemcpy(out, du.p, u, hipMemcpyDeviceToHost));
-    if (!blocks.empty()) HIPCHK(hipMemcpy(status, ds.p, 4 * blocks.size(), hipMemcpyDeviceToHost));
+    if (u) HIPCHK(npcopy::d2h_sync(out, du.p, u));
+    if (!blocks.empty()) HIPCHK(npcopy::d2h_sync(status, ds.p, 4 * blocks.size()));
     dc.release(); du.release(); db.release(); ds.release(); dt.release();
     return (int64_t)blocks.size();
 }

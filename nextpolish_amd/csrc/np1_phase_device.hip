@@ -315,13 +315,13 @@ __global__ __launch_bounds__(256) void k_sp_apply(uint32_t n, const uint32_t* __
 template <class T>
 int upload_vec(DevBuf& b, const std::vector<T>& v, hipStream_t q) {
     if (b.ensure(sizeof(T) * (v.size() + 1))) return -1;
-    if (!v.empty()) HIPCHK(hipMemcpyAsync(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, q));
+    if (!v.empty()) HIPCHK(npcopy::h2d(b.p, v.data(), sizeof(T) * v.size(), q));
     return 0;
 }
 template <class T>
 int download_vec(std::vector<T>& v, const void* p, size_t n, hipStream_t q) {
     v.resize(n);
-    if (n) HIPCHK(hipMemcpyAsync(v.data(), p, sizeof(T) * n, hipMemcpyDeviceToHost, q));
+    if (n) HIPCHK(npcopy::d2h(v.data(), p, sizeof(T) * n, q));
     HIPCHK(hipStreamSynchronize(q));
     return 0;
 }
@@ -403,9 +403,9 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
         launch_scan_slots(q, b->ins.as<uint32_t>(), G, W[W_SOFF1].as<uint32_t>(), scan_tmp, &totals[1]);
         uint64_t S64 = 0;
         uint32_t lr_span = 0;
-        HIPCHK(hipMemcpyAsync(&S64, &totals[1], 8, hipMemcpyDeviceToHost, q));
-        HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
-        HIPCHK(hipMemcpyAsync(&lr_span, W[W_LR_CNT].p, 4, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(&S64, &totals[1], 8, q));
+        HIPCHK(npcopy::d2h(hk, kcnt, sizeof(hk), q));
+        HIPCHK(npcopy::d2h(&lr_span, W[W_LR_CNT].p, 4, q));
         HIPCHK(hipStreamSynchronize(q));
         if (S64 >= 0x0ffffff0ull) { np1_set_error("snp_phase: batch too large (more than 2^28 slots; the histogram is 128 bytes per slot)"); return -1; }
         const uint32_t S1 = (uint32_t)S64;
@@ -432,7 +432,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
                                                 W[W_DIRTY].as<uint8_t>(), W[W_ALLE].as<uint8_t>());
         launch_scan_u8(q, W[W_DIRTY].as<uint8_t>(), G, W[W_DPOS].as<uint32_t>(), scan_tmp, &totals[2]);
         uint64_t NS64 = 0;
-        HIPCHK(hipMemcpyAsync(&NS64, &totals[2], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(&NS64, &totals[2], 8, q));
         HIPCHK(hipStreamSynchronize(q));
         const uint32_t NS = (uint32_t)NS64;
         const size_t ns1 = (size_t)NS + 1;
@@ -449,7 +449,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
         k_sp_depthmark<<<nblk(S1, 256), 256, 0, q>>>(S1, W[W_SFLAG1].as<uint8_t>(), W[W_MARK].as<uint8_t>());
         launch_scan_u8(q, W[W_MARK].as<uint8_t>(), S1, W[W_MPOS].as<uint32_t>(), scan_tmp, &totals[3]);
         uint64_t M = 0;
-        HIPCHK(hipMemcpyAsync(&M, &totals[3], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(&M, &totals[3], 8, q));
         HIPCHK(hipStreamSynchronize(q));
         HIPCHK(hipMemcpyAsync(W[W_MPOS].as<uint32_t>() + S1, &totals[3], 4, hipMemcpyDeviceToDevice, q));   // mpos[S1] = M
         if (W[W_F].ensure(4 * (M + 4)) || W[W_DOUT].ensure(8 * (M + (size_t)nc + 4))) return -1;
@@ -459,7 +459,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
         std::vector<uint32_t> dcnt;
         if (download_vec(dcnt, W[W_DCNT].p, 2 * (size_t)nc, q)) return -1;
         b->h_ctg_off.resize((size_t)nc + 1);
-        HIPCHK(hipMemcpyAsync(b->h_ctg_off.data(), b->ctg_off.p, 4 * ((size_t)nc + 1), hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(b->h_ctg_off.data(), b->ctg_off.p, 4 * ((size_t)nc + 1), q));
         HIPCHK(hipStreamSynchronize(q));
         std::vector<uint32_t> reg_ctg;
         std::vector<int32_t> reg_se;
@@ -467,7 +467,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
             if (!dcnt[ct]) continue;
             const size_t at = reg_se.size();
             reg_se.resize(at + dcnt[ct]);
-            HIPCHK(hipMemcpyAsync(reg_se.data() + at, W[W_DOUT].as<int32_t>() + 2ull * ((uint64_t)dcnt[nc + ct] + ct), 4ull * dcnt[ct], hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(reg_se.data() + at, W[W_DOUT].as<int32_t>() + 2ull * ((uint64_t)dcnt[nc + ct] + ct), 4ull * dcnt[ct], q));
             for (uint32_t i = 0; i + 1 < dcnt[ct]; i += 2) reg_ctg.push_back(ct);
         }
         HIPCHK(hipStreamSynchronize(q));
@@ -481,7 +481,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
         k_sp_insert<<<nblk((uint64_t)nnl, 256), 256, 0, q>>>(cl.R, nl, l->kc_level.as<uint8_t>(), ctg_off, b->ins.as<uint32_t>(), F_INSERT | F_SNP, W[W_SOFF1].as<uint32_t>(),
                                                              W[W_SFLAG1].as<uint8_t>());
         launch_scan_slots(q, b->ins.as<uint32_t>(), G, b->soff.as<uint32_t>(), scan_tmp, &totals[4]);
-        HIPCHK(hipMemcpyAsync(&S64, &totals[4], 8, hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(&S64, &totals[4], 8, q));
         HIPCHK(hipStreamSynchronize(q));
         if (S64 >= 0xfffffff0ull) { np1_set_error("batch too large: more than 2^32 slots"); return -1; }
         const uint32_t S = (uint32_t)S64;
@@ -502,7 +502,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
             HIPCHK(hipMemsetAsync(&totals[5], 0, 8, q));
             k_sp_region_slots<<<nblk(n_reg, 256), 256, 0, q>>>(n_reg, W[W_REG_CTG].as<uint32_t>(), W[W_REG_SE].as<int32_t>(), ctg_off, b->soff.as<uint32_t>(),
                                                                reinterpret_cast<unsigned long long*>(&totals[5]));
-            HIPCHK(hipMemcpyAsync(&nd_slots, &totals[5], 8, hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(&nd_slots, &totals[5], 8, q));
             HIPCHK(hipStreamSynchronize(q));
         }
         const size_t lcap = std::min<size_t>(((size_t)64 * nd_slots + ((size_t)1 << 20)) * scale, (size_t)0x7ffffff0u);
@@ -525,7 +525,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
             k_sp_site_stride<<<nblk(NS, 256), 256, 0, q>>>(NS, W[W_SITE_G].as<uint32_t>(), b->soff.as<uint32_t>(), W[W_RSTRIDE].as<uint32_t>(), W[W_RBYTES].as<uint32_t>(),
                                                            W[W_SITE_LEN].as<int32_t>(), W[W_KEEP].as<uint8_t>());
             launch_scan_u32(q, W[W_RBYTES].as<uint32_t>(), NS, W[W_ROFF].as<uint32_t>(), scan_tmp, &totals[6]);
-            HIPCHK(hipMemcpyAsync(&RB, &totals[6], 8, hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(&RB, &totals[6], 8, q));
             HIPCHK(hipStreamSynchronize(q));
             if (RB >= 0xfffffff0ull) { np1_set_error("snp_phase: allele strings of the sites exceed 4 GB"); return -1; }
             if (W[W_RPOOL].ensure(RB + 64)) return -1;
@@ -538,7 +538,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
         }
         // ---- P9: low-depth regions, both streams
         if (n_reg) k_sp_lowdepth<<<nblk(n_grp, site_lanes), 64, 0, q>>>(cs, cl, n_grp, site_lanes, W[W_GRP].as<uint32_t>(), W[W_REG_CTG].as<uint32_t>(), W[W_REG_SE].as<int32_t>());
-        HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(hk, kcnt, sizeof(hk), q));
         HIPCHK(hipStreamSynchronize(q));
         if (hk[KCC_ERR] & (ERR_KC_POOL | ERR_SP_POOL)) continue;
         // ---- kept sites (host lays out the list), links
@@ -629,7 +629,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
                                                                 W[W_LREG_NREC].as<uint32_t>(), W[W_LREG_NCH].as<uint32_t>());
                 launch_scan_u32(q, W[W_LREG_NCH].as<uint32_t>(), nlr, W[W_LREG_CHOFF].as<uint32_t>(), scan_tmp, &totals[5]);
                 uint64_t n_chunks = 0;
-                HIPCHK(hipMemcpyAsync(&n_chunks, &totals[5], 8, hipMemcpyDeviceToHost, q));
+                HIPCHK(npcopy::d2h(&n_chunks, &totals[5], 8, q));
                 HIPCHK(hipStreamSynchronize(q));
                 if (!n_chunks) return 0;
                 const uint32_t blocks = (uint32_t)std::min<uint64_t>(n_chunks, phase == 0 ? 1024u : 512u);
@@ -653,7 +653,7 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
                                                                     b->kc_sflag.as<uint8_t>());
             }
             if (fetch_flags() || run_links(cl, 1) || fetch_links()) return -1;
-            HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
+            HIPCHK(npcopy::d2h(hk, kcnt, sizeof(hk), q));
             HIPCHK(hipStreamSynchronize(q));
             undefined = undefined || (hk[KCC_ERR] & ERR_SP_UNDEFINED) != 0;
             // ---- the chain over the sites of every contig, then the writes
@@ -680,8 +680,8 @@ extern "C" int np1_batch_snp_phase(np1_batch* b, np1_batch* l, const Configure* 
         launch_emit(q, b->slot_res.as<uint16_t>(), b->slot_info.as<uint8_t>(), b->opos.as<uint32_t>(), S, F_THIRD, b->out.as<uint8_t>());
         launch_contig_bounds(q, ctg_off, nc, b->soff.as<uint32_t>(), b->opos.as<uint32_t>(), b->bounds.as<uint32_t>());
         b->h_bounds.resize((size_t)nc + 1);
-        HIPCHK(hipMemcpyAsync(b->h_bounds.data(), b->bounds.p, 4 * ((size_t)nc + 1), hipMemcpyDeviceToHost, q));
-        HIPCHK(hipMemcpyAsync(hk, kcnt, sizeof(hk), hipMemcpyDeviceToHost, q));
+        HIPCHK(npcopy::d2h(b->h_bounds.data(), b->bounds.p, 4 * ((size_t)nc + 1), q));
+        HIPCHK(npcopy::d2h(hk, kcnt, sizeof(hk), q));
         HIPCHK(hipStreamSynchronize(q));
         if (hk[KCC_ERR] & (ERR_KC_POOL | ERR_SP_POOL)) continue;
         if (hk[KCC_ERR] & ERR_SP_DEPTH) { np1_set_error("snp_phase: more than 65535 votes on one slot (the reference's 16-bit counters wrap there)"); return -1; }

@@ -2,13 +2,26 @@
 #pragma once
 #include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "np_stream.h"
 
 struct np1_stream {
     np::ReadStream s;
-    bool pinned = false;   // the arrays are registered with the HIP runtime (np1_stream_pin): H2D copies from them are asynchronous
-    std::vector<void*> registered;   // exactly the ranges np1_stream_pin registered (np1_stream_unpin releases these and nothing else)
+    // np1_stream_pin: every array an upload moves (above the size the runtime stages itself) has a copy in ONE page-locked arena from
+    // hipHostMalloc, and uploads read from there -- asynchronous at full PCIe rate.  (Rounds 2-4 registered the std::vector storage
+    // itself with hipHostRegister; round 5 found the GPU faulting on heap addresses and took the GPU off the heap: DESIGN.md section 12.)
+    bool pinned = false;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    std::vector<std::pair<const void*, const void*>> arena_map;   // (array, its copy in the arena), sorted by array address
+    const void* up(const void* p) const {      // where an upload of array p reads from
+        if (!pinned || arena_map.empty()) return p;
+        size_t lo = 0, hi = arena_map.size();
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (arena_map[mid].first < p) lo = mid + 1; else hi = mid; }
+        return (lo < arena_map.size() && arena_map[lo].first == p) ? arena_map[lo].second : p;
+    }
     // facts about the record arrays an upload needs, found once (np1_device.hip:stream_facts): the longest record, and whether the
     // per-record arrays a device can rebuild itself really are what it would rebuild (pool offsets = running sums, contig = the
     // record's place in read_begin) -- then 20 of the 32 fixed bytes per record need not cross PCIe

@@ -34,6 +34,7 @@
 #include "np2_lq.h"
 #include "np_threads.h"
 #include "np_devalloc.h"
+#include "np_hostcopy.h"
 
 namespace np { void bgzf_device_inflate_enable(int device); }   // np_bgzf_dev.hip
 
@@ -1938,7 +1939,7 @@ bool HipExec::upload_contig(const WindowInput& in, std::string* err) {
     const size_t clen = strlen(in.contig_seq);
     if (contig_serial_ != in.contig_serial || contig_len_ != clen) {
         if (!contig_.ensure(clen + 16)) { *err = "out of device memory (contig)"; return false; }
-        HIPOK(hipMemcpyAsync(contig_.p, in.contig_seq, clen + 1, hipMemcpyHostToDevice, stream_));
+        HIPOK(npcopy::h2d(contig_.p, in.contig_seq, clen + 1, stream_));
         contig_serial_ = in.contig_serial;
         contig_len_ = clen;
     }
@@ -1951,7 +1952,7 @@ bool HipExec::upload_set(const RecordSet& rs, int set, std::string* err) {
     DevBuf* b = rb_[set];
     auto up = [&](DevBuf& d, const void* src, size_t bytes) -> bool {
         if (!d.ensure(bytes + 16)) return false;
-        return bytes == 0 || hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, q) == hipSuccess;
+        return bytes == 0 || npcopy::h2d(d.p, src, bytes, q) == hipSuccess;
     };
     if (!up(b[0], rs.pos.data(), 4 * n) || !up(b[1], rs.n_cigar.data(), 4 * n) || !up(b[2], rs.q0.data(), 4 * n) ||
         !up(b[3], rs.cigar_off.data(), 8 * n) || !up(b[4], rs.seq_off.data(), 8 * n) || !up(b[5], rs.cigar.data(), 4 * rs.cigar.size()) ||
@@ -1970,7 +1971,7 @@ bool HipExec::compute_spans(const WindowInput& in, int set, std::vector<SpanOut>
     if (n) {
         if (!spans_.ensure(sizeof(SpanOut) * (size_t)n)) { *err = "out of device memory (spans)"; return false; }
         k2_span<<<nblk(n, SERIAL_LANES), 64, 0, q>>>(dev_set(set), n, contig_.as<char>(), in.s, in.e, spans_.as<SpanOut>());
-        HIPOK(hipMemcpyAsync(spans->data(), spans_.p, sizeof(SpanOut) * (size_t)n, hipMemcpyDeviceToHost, q));
+        HIPOK(npcopy::d2h(spans->data(), spans_.p, sizeof(SpanOut) * (size_t)n, q));
     }
     HIPOK(hipStreamSynchronize(q));
     return true;
@@ -2017,7 +2018,7 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     HIPOK(hipMemsetAsync(covdiff_.p, 0, 4ull * (n_cols + 4), q));
     k2_seed_tags<<<nblk(((uint64_t)l + 1) / 2 + 1, 256), 256, 0, q>>>(contig_.as<char>(), s, (uint32_t)l, tags_.as<uint8_t>());
     if (!sd.empty()) {
-        HIPOK(hipMemcpyAsync(sd_.p, sd.data(), sizeof(StreamDesc) * sd.size(), hipMemcpyHostToDevice, q));
+        HIPOK(npcopy::h2d(sd_.p, sd.data(), sizeof(StreamDesc) * sd.size(), q));
         // chunk list (host, O(records)); empty streams still need their terminator and end position
         std::vector<TagChunk> tcs;
         std::vector<uint32_t> choff(sd.size());
@@ -2035,12 +2036,12 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
             if (sd[k].aln_len == 0) {
                 const uint8_t ff = 0xff;
                 const uint32_t te = sd[k].aln_t_s - (uint32_t)s;
-                HIPOK(hipMemcpyAsync(tags_.as<uint8_t>() + sd[k].tag_off, &ff, 1, hipMemcpyHostToDevice, q));
-                HIPOK(hipMemcpyAsync(te_.as<uint32_t>() + 1 + k, &te, 4, hipMemcpyHostToDevice, q));
+                HIPOK(npcopy::h2d(tags_.as<uint8_t>() + sd[k].tag_off, &ff, 1, q));
+                HIPOK(npcopy::h2d(te_.as<uint32_t>() + 1 + k, &te, 4, q));
             }
         if (n_tchunks) {
-            HIPOK(hipMemcpyAsync(tchunks_.p, tcs.data(), sizeof(TagChunk) * (size_t)n_tchunks, hipMemcpyHostToDevice, q));
-            HIPOK(hipMemcpyAsync(tchoff_.p, choff.data(), 4ull * sd.size(), hipMemcpyHostToDevice, q));
+            HIPOK(npcopy::h2d(tchunks_.p, tcs.data(), sizeof(TagChunk) * (size_t)n_tchunks, q));
+            HIPOK(npcopy::h2d(tchoff_.p, choff.data(), 4ull * sd.size(), q));
             k2_tag_ckpt<<<nblk(sd.size(), SERIAL_LANES), 64, 0, q>>>(sd_.as<StreamDesc>(), (uint32_t)sd.size(), tchoff_.as<uint32_t>(), dev_set(0), dev_set(1), s,
                                                            tckpt_.as<TagCkpt>());
             k2_tags_chunk<<<nblk(n_tchunks, 64), 64, 0, q>>>(tchunks_.as<TagChunk>(), n_tchunks, tckpt_.as<TagCkpt>(), sd_.as<StreamDesc>(), dev_set(0), dev_set(1),
@@ -2057,8 +2058,8 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
     }
     k2_pack_stat<<<nblk(n_cols, 256), 256, 0, q>>>(st.coverage, st.max_size, st.l_ins, st.l_del, n_cols, stat_.as<ColStat>(), (uint32_t)l, covpre_.as<uint32_t>(),
                                                     covdiff_.as<uint32_t>(), colcnt_.as<uint32_t>());
-    HIPOK(hipMemcpyAsync(tagoff_.p, out->tag_off.data(), 8ull * n_streams, hipMemcpyHostToDevice, q));
-    HIPOK(hipMemcpyAsync(alnts_.p, out->aln_t_s.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
+    HIPOK(npcopy::h2d(tagoff_.p, out->tag_off.data(), 8ull * n_streams, q));
+    HIPOK(npcopy::h2d(alnts_.p, out->aln_t_s.data(), 4ull * n_streams, q));
     clk.mark("tags");
     uint32_t total = 0;
     std::vector<uint32_t> n_tags;
@@ -2087,15 +2088,15 @@ bool HipExec::run_window(const WindowInput& in, WindowOutput* out, std::string* 
         if (!trig_.ensure(16 * trig_words + 64)) { *err = "out of device memory (low-quality triggers)"; return false; }
         k2_lq_triggers<<<nblk((cons_len + 63u) & ~63u, 256), 256, 0, q>>>(cons_.as<ConsBase>(), cons_len, stat_.as<ColStat>(), in.lq_ratio1,
                                                                           trig_.as<unsigned long long>(), trig_.as<unsigned long long>() + trig_words);
-        HIPOK(hipMemcpyAsync(out->trig_del.data(), trig_.p, 8 * trig_words, hipMemcpyDeviceToHost, q));
-        HIPOK(hipMemcpyAsync(out->trig_ins.data(), trig_.as<unsigned long long>() + trig_words, 8 * trig_words, hipMemcpyDeviceToHost, q));
+        HIPOK(npcopy::d2h(out->trig_del.data(), trig_.p, 8 * trig_words, q));
+        HIPOK(npcopy::d2h(out->trig_ins.data(), trig_.as<unsigned long long>() + trig_words, 8 * trig_words, q));
     }
     if (!pin_.ensure(cons_bytes + stat_bytes + 64)) { *err = "out of pinned host memory (window download)"; return false; }
     uint8_t* pin = static_cast<uint8_t*>(pin_.p);
-    if (cons_len) HIPOK(hipMemcpyAsync(pin, cons_.p, cons_bytes, hipMemcpyDeviceToHost, q));
-    HIPOK(hipMemcpyAsync(pin + cons_bytes, stat_.p, stat_bytes, hipMemcpyDeviceToHost, q));
-    if (in.want_tags) HIPOK(hipMemcpyAsync(out->tags.data(), tags_.p, tag_bytes, hipMemcpyDeviceToHost, q));
-    if (n_streams > 1) HIPOK(hipMemcpyAsync(out->aln_t_e.data() + 1, te_.as<uint32_t>() + 1, 4ull * (n_streams - 1), hipMemcpyDeviceToHost, q));
+    if (cons_len) HIPOK(npcopy::d2h(pin, cons_.p, cons_bytes, q));
+    HIPOK(npcopy::d2h(pin + cons_bytes, stat_.p, stat_bytes, q));
+    if (in.want_tags) HIPOK(npcopy::d2h(out->tags.data(), tags_.p, tag_bytes, q));
+    if (n_streams > 1) HIPOK(npcopy::d2h(out->aln_t_e.data() + 1, te_.as<uint32_t>() + 1, 4ull * (n_streams - 1), q));
     HIPOK(hipStreamSynchronize(q));
     {
         uint8_t* dst_c = reinterpret_cast<uint8_t*>(out->cons.data());
@@ -2140,7 +2141,7 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
         k2_scan_sums<<<nsb2, SCAN_T, 0, q>>>(cutflag_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>());
         k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb2);
         k2_scan_final<<<nsb2, SCAN_T, 0, q>>>(cutflag_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), cutpos_.as<uint32_t>());
-        HIPOK(hipMemcpyAsync(&n_cuts, cutpos_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
+        HIPOK(npcopy::d2h(&n_cuts, cutpos_.as<uint32_t>() + n_cols, 4, q));
         HIPOK(hipStreamSynchronize(q));
         if (K == CUT_K_LARGE || (uint64_t)n_cuts * 3 >= (uint64_t)(n_cols / CUT_BLOCK) * 2 || getenv("NP2_CUT_K")) break;
         K = CUT_K_LARGE;
@@ -2148,14 +2149,14 @@ bool HipExec::solve(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t tota
     if (clk) clk->mark("dp.cutscan");
     k2_cut_list<<<nblk(n_cols, 256), 256, 0, q>>>(cutflag_.as<uint32_t>(), cutpos_.as<uint32_t>(), n_cols, cuts_.as<uint32_t>());
     uint32_t last_cut = 0xffffffffu;
-    if (n_cuts) HIPOK(hipMemcpyAsync(&last_cut, cuts_.as<uint32_t>() + (n_cuts - 1), 4, hipMemcpyDeviceToHost, q));
+    if (n_cuts) HIPOK(npcopy::d2h(&last_cut, cuts_.as<uint32_t>() + (n_cuts - 1), 4, q));
     HIPOK(hipStreamSynchronize(q));
     if (clk) clk->mark("dp.cutlist");
     // a window ending on a cut column has no open run behind it
     const uint32_t n_runs = (n_cuts && (int32_t)last_cut == l - 1) ? n_cuts : n_cuts + 1;
     if (clk && clk->on) {
         std::vector<uint32_t> hc(n_cuts);
-        if (n_cuts) (void)hipMemcpy(hc.data(), cuts_.p, 4ull * n_cuts, hipMemcpyDeviceToHost);
+        if (n_cuts) (void)npcopy::d2h_sync(hc.data(), cuts_.p, 4ull * n_cuts);
         uint32_t mx = n_cuts ? hc[0] + 1 : (uint32_t)l, over1k = 0;
         for (uint32_t i = 1; i < n_cuts; ++i) { mx = std::max(mx, hc[i] - hc[i - 1]); over1k += hc[i] - hc[i - 1] > 1000; }
         fprintf(stderr, "[np2 dp] cut width %u: %u cuts, %u runs over %d columns; longest run %u columns, %u runs > 1000\n", K, n_cuts, n_runs, l, mx, over1k);
@@ -2187,7 +2188,7 @@ bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t
         k2_scan_final<<<nsr, SCAN_T, 0, q>>>(runsz_.as<uint32_t>(), n_runs + 1, sums2_.as<uint32_t>(), runoff_.as<uint32_t>());
     }
     uint32_t ring_units = 0;
-    HIPOK(hipMemcpyAsync(&ring_units, runoff_.as<uint32_t>() + n_runs, 4, hipMemcpyDeviceToHost, q));
+    HIPOK(npcopy::d2h(&ring_units, runoff_.as<uint32_t>() + n_runs, 4, q));
     HIPOK(hipStreamSynchronize(q));
     if (!eav_.ensure(8ull * (K + 1) * (size_t)ring_units + 64)) { *err = "out of device memory (dp runs)"; return false; }
     if (clk) clk->mark("dp.cuts");
@@ -2211,7 +2212,7 @@ bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t
                                                 runlist_.as<uint32_t>(), runctr_.as<uint32_t>(), status);
         if (clk && clk->on) {
             uint32_t c[3] = {0, 0, 0};
-            (void)hipMemcpyAsync(c, runctr_.p, 12, hipMemcpyDeviceToHost, q);
+            (void)npcopy::d2h(c, runctr_.p, 12, q);
             (void)hipStreamSynchronize(q);
             fprintf(stderr, "[np2 dp] %u of %u runs left to the kernels that walk HBM (a column over %u entries)\n", c[0], n_runs, RL_COLMAX);
         }
@@ -2276,8 +2277,8 @@ bool HipExec::solve_runs(const MsaView& mv, int32_t l, uint32_t n_cols, uint32_t
     else k2_bt_runs<false, true><<<nblk(n_runs, rpw_bt1), 64, 0, q>>>(mv, cuts_.as<uint32_t>(), n_cuts, n_runs, l, res_.as<DpResult>(), nullptr, btpick_.as<BtPick>(), cons_.as<ConsBase>(), nullptr, status, K, rpw_bt1);
     DpResult res;
     uint32_t st2[2] = {0, 0};
-    HIPOK(hipMemcpyAsync(&res, res_.p, sizeof(res), hipMemcpyDeviceToHost, q));
-    HIPOK(hipMemcpyAsync(st2, status, 8, hipMemcpyDeviceToHost, q));
+    HIPOK(npcopy::d2h(&res, res_.p, sizeof(res), q));
+    HIPOK(npcopy::d2h(st2, status, 8, q));
     HIPOK(hipStreamSynchronize(q));
     if (clk) clk->mark("backtrace");
     if (st2[0] == 4) { *err = "a link reaches further back than the previous column"; return false; }
@@ -2302,7 +2303,7 @@ int HipExec::build_graph_tiles(const std::vector<uint32_t>& n_tags, uint32_t n_c
         *err = "out of device memory (link graph)";
         return 0;
     }
-    TILEOK(hipMemcpyAsync(ntags_.p, n_tags.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
+    TILEOK(npcopy::h2d(ntags_.p, n_tags.data(), 4ull * n_streams, q));
     TILEOK(hipMemsetAsync(tilecnt_.p, 0, 4ull * (n_tiles + 2), q));
     TILEOK(hipMemsetAsync(tilecur_.p, 0, 4ull * (n_tiles + 2), q));
     TILEOK(hipMemsetAsync(tilectr_.p, 0, 64, q));
@@ -2329,7 +2330,7 @@ int HipExec::build_graph_tiles(const std::vector<uint32_t>& n_tags, uint32_t n_c
         (void)hipMemsetAsync(d_prof, 0, 96, q);
         k2_tile_graph<true, 768, 64><<<n_tiles, 64, 0, q>>>(A1, d_prof);
         k2_tile_graph<true, 2048, 128><<<n_tiles, 64, 0, q>>>(A2, d_prof + 6);
-        (void)hipMemcpyAsync(h, d_prof, 96, hipMemcpyDeviceToHost, q);
+        (void)npcopy::d2h(h, d_prof, 96, q);
         (void)hipStreamSynchronize(q);
         (void)npalloc::dev_free(d_prof);
         fprintf(stderr, "[np2 tile prof] %u tiles; cycles per tile: setup %.0f, stream state %.0f, lookup %.0f, insert %.0f, finish %.0f; large pool (all its tiles) %.0f\n", n_tiles,
@@ -2340,7 +2341,7 @@ int HipExec::build_graph_tiles(const std::vector<uint32_t>& n_tags, uint32_t n_c
         k2_tile_graph<false, 2048, 128><<<n_tiles, 64, 0, q>>>(A2, nullptr);
     }
     uint32_t ctr[3] = {0, 0, 0};
-    TILEOK(hipMemcpyAsync(ctr, tilectr_.p, 12, hipMemcpyDeviceToHost, q));
+    TILEOK(npcopy::d2h(ctr, tilectr_.p, 12, q));
     TILEOK(hipStreamSynchronize(q));
     if (clk && clk->on && ctr[2]) fprintf(stderr, "[np2 graph] %u of %u tiles took the large pool\n", ctr[2], n_tiles);
     if (clk) clk->mark("tiles.graph");
@@ -2375,7 +2376,7 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
     if (!chunks_.ensure(sizeof(ChunkDesc) * (size_t)n_chunks + 64) || !chcnt_.ensure(4ull * (n_chunks + 2)) || !chpre_.ensure(4ull * (n_chunks + 2)) ||
         !sums2_.ensure(4ull * (nblk(n_chunks + 1, SCAN_TILE) + 2))) { *err = "out of device memory (chunks)"; return false; }
     if (n_chunks) {
-        HIPOK(hipMemcpyAsync(chunks_.p, cd.data(), sizeof(ChunkDesc) * (size_t)n_chunks, hipMemcpyHostToDevice, q));
+        HIPOK(npcopy::h2d(chunks_.p, cd.data(), sizeof(ChunkDesc) * (size_t)n_chunks, q));
         HIPOK(hipMemsetAsync(chcnt_.as<uint32_t>() + n_chunks, 0, 4, q));
         k2_chunk_count<<<nblk(n_chunks, 4), 256, 0, q>>>(chunks_.as<ChunkDesc>(), n_chunks, tagoff_.as<uint64_t>(), tags_.as<uint8_t>(), chcnt_.as<uint32_t>());
         const uint32_t nsc = nblk(n_chunks + 1, SCAN_TILE);
@@ -2401,8 +2402,8 @@ bool HipExec::build_graph(const std::vector<uint32_t>& n_tags, uint32_t n_cols, 
         k2_scan_top<<<1, 1, 0, q>>>(sums_.as<uint32_t>(), nsb);
         k2_scan_final<<<nsb, SCAN_T, 0, q>>>(colcnt_.as<uint32_t>(), n_cols + 1, sums_.as<uint32_t>(), coloff_.as<uint32_t>());
         uint32_t flag = 0;
-        HIPOK(hipMemcpyAsync(&total, coloff_.as<uint32_t>() + n_cols, 4, hipMemcpyDeviceToHost, q));
-        if (m_seen && pass == 0) HIPOK(hipMemcpyAsync(&flag, m_seen, 4, hipMemcpyDeviceToHost, q));
+        HIPOK(npcopy::d2h(&total, coloff_.as<uint32_t>() + n_cols, 4, q));
+        if (m_seen && pass == 0) HIPOK(npcopy::d2h(&flag, m_seen, 4, q));
         HIPOK(hipStreamSynchronize(q));
         if (!flag) break;
         // a read carries the base code M: count the observations exactly (rare)
@@ -2452,14 +2453,14 @@ bool HipExec::extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off
     const uint32_t nsb = nblk(n + 1, SCAN_TILE);
     if (!xreq_.ensure(sizeof(SubReqDev) * (size_t)n) || !xfirst_.ensure(4ull * n) || !xlen_.ensure(4ull * (n + 2)) || !xoff_.ensure(4ull * (n + 2)) ||
         !sums2_.ensure(4ull * (nsb + 2))) { *err = "out of device memory (candidates)"; return false; }
-    HIPOK(hipMemcpyAsync(xreq_.p, rd.data(), sizeof(SubReqDev) * (size_t)n, hipMemcpyHostToDevice, q));
+    HIPOK(npcopy::h2d(xreq_.p, rd.data(), sizeof(SubReqDev) * (size_t)n, q));
     HIPOK(hipMemsetAsync(xlen_.as<uint32_t>() + n, 0, 4, q));
     k2_extract<false><<<nblk(n, 64), 64, 0, q>>>(xreq_.as<SubReqDev>(), n, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), tags_.as<uint8_t>(),
                                                   xfirst_.as<uint32_t>(), xlen_.as<uint32_t>(), nullptr, nullptr);
     k2_scan_sums<<<nsb, SCAN_T, 0, q>>>(xlen_.as<uint32_t>(), n + 1, sums2_.as<uint32_t>());
     k2_scan_top<<<1, 1, 0, q>>>(sums2_.as<uint32_t>(), nsb);
     k2_scan_final<<<nsb, SCAN_T, 0, q>>>(xlen_.as<uint32_t>(), n + 1, sums2_.as<uint32_t>(), xoff_.as<uint32_t>());
-    HIPOK(hipMemcpyAsync(off->data(), xoff_.p, 4ull * (n + 1), hipMemcpyDeviceToHost, q));
+    HIPOK(npcopy::d2h(off->data(), xoff_.p, 4ull * (n + 1), q));
     HIPOK(hipStreamSynchronize(q));
     const uint32_t total = (*off)[n];
     if (total) {
@@ -2467,7 +2468,7 @@ bool HipExec::extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off
         k2_extract<true><<<nblk(n, 64), 64, 0, q>>>(xreq_.as<SubReqDev>(), n, chpre_.as<uint32_t>(), tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), tags_.as<uint8_t>(),
                                                      xfirst_.as<uint32_t>(), nullptr, xoff_.as<uint32_t>(), xout_.as<char>());
         bases->resize(total);
-        HIPOK(hipMemcpyAsync(&(*bases)[0], xout_.p, total, hipMemcpyDeviceToHost, q));
+        HIPOK(npcopy::d2h(&(*bases)[0], xout_.p, total, q));
         HIPOK(hipStreamSynchronize(q));
     }
     return true;
@@ -2490,8 +2491,8 @@ bool HipExec::run_lq(const LqInput& in, std::string* cons_rev, std::string* err)
         str_len.push_back((uint32_t)in.t[i].size());
     }
     if (!strpool_.ensure(pool.size() + 16) || !stroff_.ensure(8ull * str_off.size() + 16)) { *err = "out of device memory (low-quality regions)"; return false; }
-    HIPOK(hipMemcpyAsync(strpool_.p, pool.data(), pool.size(), hipMemcpyHostToDevice, q));
-    HIPOK(hipMemcpyAsync(stroff_.p, str_off.data(), 8ull * str_off.size(), hipMemcpyHostToDevice, q));
+    HIPOK(npcopy::h2d(strpool_.p, pool.data(), pool.size(), q));
+    HIPOK(npcopy::h2d(stroff_.p, str_off.data(), 8ull * str_off.size(), q));
     HIPOK(hipStreamSynchronize(q));   // pool / str_off are locals
     return lq_from_pool(str_len, in.t_len, in.gap_min_len, in.hifi, cons_rev, err);
 }
@@ -2537,12 +2538,12 @@ bool HipExec::run_lq_aligned(const LqAlignInput& in, std::string* cons_rev, std:
         *err = "out of device memory (low-quality alignments)";
         return false;
     }
-    HIPOK(hipMemcpyAsync(ondpool_.p, in.chars.data(), in.chars.size(), hipMemcpyHostToDevice, q));
-    HIPOK(hipMemcpyAsync(ondregs_.p, regs.data(), sizeof(OndRegion) * (size_t)n_regs, hipMemcpyHostToDevice, q));
-    HIPOK(hipMemcpyAsync(ondcoff_.p, coff.data(), 8ull * coff.size(), hipMemcpyHostToDevice, q));
-    HIPOK(hipMemcpyAsync(ondclen_.p, in.cand_len.data(), 4ull * in.cand_len.size(), hipMemcpyHostToDevice, q));
-    HIPOK(hipMemcpyAsync(ondpairof_.p, pair_of.data(), 4ull * pair_of.size(), hipMemcpyHostToDevice, q));
-    if (n_pairs) HIPOK(hipMemcpyAsync(ondpairs_.p, pairs.data(), sizeof(np2ond::Pair) * (size_t)n_pairs, hipMemcpyHostToDevice, q));
+    HIPOK(npcopy::h2d(ondpool_.p, in.chars.data(), in.chars.size(), q));
+    HIPOK(npcopy::h2d(ondregs_.p, regs.data(), sizeof(OndRegion) * (size_t)n_regs, q));
+    HIPOK(npcopy::h2d(ondcoff_.p, coff.data(), 8ull * coff.size(), q));
+    HIPOK(npcopy::h2d(ondclen_.p, in.cand_len.data(), 4ull * in.cand_len.size(), q));
+    HIPOK(npcopy::h2d(ondpairof_.p, pair_of.data(), 4ull * pair_of.size(), q));
+    if (n_pairs) HIPOK(npcopy::h2d(ondpairs_.p, pairs.data(), sizeof(np2ond::Pair) * (size_t)n_pairs, q));
     if (n_pairs)
         k2_ond_align<<<grid, 256, 0, q>>>(ondpool_.as<uint8_t>(), ondpairs_.as<np2ond::Pair>(), n_pairs, ondout_.as<uint8_t>(), ondres_.as<np2ond::PairResult>(),
                                          ondv_.as<int32_t>(), ondlo_.as<int32_t>(), ondch_.as<uint64_t>(), max_d_cap, row_words);
@@ -2550,7 +2551,7 @@ bool HipExec::run_lq_aligned(const LqAlignInput& in, std::string* cons_rev, std:
                                                  ondres_.as<np2ond::PairResult>(), ondplen_.as<uint32_t>(), ondpkind_.as<uint8_t>());
     k2_ond_scan<<<LQ_ROUNDS, 256, 0, q>>>(ondplen_.as<uint32_t>(), n_regs, ondppos_.as<uint32_t>(), ondtot_.as<uint32_t>());
     std::vector<uint32_t> str_len(LQ_ROUNDS);
-    HIPOK(hipMemcpyAsync(str_len.data(), ondtot_.p, 4ull * LQ_ROUNDS, hipMemcpyDeviceToHost, q));
+    HIPOK(npcopy::d2h(str_len.data(), ondtot_.p, 4ull * LQ_ROUNDS, q));
     HIPOK(hipStreamSynchronize(q));
     std::vector<uint64_t> str_off;
     uint64_t at = 0;
@@ -2559,7 +2560,7 @@ bool HipExec::run_lq_aligned(const LqAlignInput& in, std::string* cons_rev, std:
         str_off.push_back(at); at += (uint64_t)str_len[(size_t)i] + 1;
     }
     if (!strpool_.ensure(at + 16)) { *err = "out of device memory (low-quality regions)"; return false; }
-    HIPOK(hipMemcpyAsync(stroff_.p, str_off.data(), 8ull * str_off.size(), hipMemcpyHostToDevice, q));
+    HIPOK(npcopy::h2d(stroff_.p, str_off.data(), 8ull * str_off.size(), q));
     k2_ond_emit<<<nblk((uint64_t)LQ_ROUNDS * n_regs, 4), 256, 0, q>>>(ondregs_.as<OndRegion>(), n_regs, ondpool_.as<uint8_t>(), ondcoff_.as<uint64_t>(),
                                                                      ondclen_.as<uint32_t>(), ondpairof_.as<int32_t>(), ondpairs_.as<np2ond::Pair>(),
                                                                      ondres_.as<np2ond::PairResult>(), ondout_.as<uint8_t>(), ondplen_.as<uint32_t>(),
@@ -2593,9 +2594,9 @@ bool HipExec::lq_from_pool(const std::vector<uint32_t>& str_len, uint32_t t_len,
         *err = "out of device memory (low-quality regions)";
         return false;
     }
-    HIPOK(hipMemcpyAsync(strlen_.p, str_len.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
-    HIPOK(hipMemcpyAsync(tagoff_.p, tag_off.data(), 8ull * n_streams, hipMemcpyHostToDevice, q));
-    HIPOK(hipMemcpyAsync(alnts_.p, zeros.data(), 4ull * n_streams, hipMemcpyHostToDevice, q));
+    HIPOK(npcopy::h2d(strlen_.p, str_len.data(), 4ull * n_streams, q));
+    HIPOK(npcopy::h2d(tagoff_.p, tag_off.data(), 8ull * n_streams, q));
+    HIPOK(npcopy::h2d(alnts_.p, zeros.data(), 4ull * n_streams, q));
     HIPOK(hipMemsetAsync(tags_.p, 0, tag_bytes + 16, q));
     HIPOK(hipMemsetAsync(cnt4_.p, 0, 16ull * n_cols + 64, q));
     HIPOK(hipMemsetAsync(colcnt_.p, 0, 4ull * (n_cols + 2), q));
@@ -2612,7 +2613,7 @@ bool HipExec::lq_from_pool(const std::vector<uint32_t>& str_len, uint32_t t_len,
         const uint32_t nsc = (uint32_t)scs.size();
         if (!tchunks_.ensure(sizeof(StrChunk) * (size_t)nsc + 64) || !chcnt_.ensure(4ull * (nsc + 2)) || !chpre_.ensure(4ull * (nsc + 2)) ||
             !sums2_.ensure(4ull * (nblk(nsc + 1, SCAN_TILE) + 2))) { *err = "out of device memory (low-quality chunks)"; return false; }
-        HIPOK(hipMemcpyAsync(tchunks_.p, scs.data(), sizeof(StrChunk) * (size_t)nsc, hipMemcpyHostToDevice, q));
+        HIPOK(npcopy::h2d(tchunks_.p, scs.data(), sizeof(StrChunk) * (size_t)nsc, q));
         HIPOK(hipMemsetAsync(chcnt_.as<uint32_t>() + nsc, 0, 4, q));
         k2_str_count<<<nblk(nsc, 64), 64, 0, q>>>(tchunks_.as<StrChunk>(), nsc, strpool_.as<char>(), stroff_.as<uint64_t>(), chcnt_.as<uint32_t>());
         const uint32_t nss = nblk(nsc + 1, SCAN_TILE);
@@ -2630,7 +2631,7 @@ bool HipExec::lq_from_pool(const std::vector<uint32_t>& str_len, uint32_t t_len,
     uint32_t cons_len = 0;
     if (!solve(mv, (int32_t)t_len, n_cols, total, hifi ? RULE_LQ_HIFI : RULE_LQ, &cons_len, nullptr, err)) return false;
     std::string fwd(cons_len, '\0');
-    if (cons_len) HIPOK(hipMemcpyAsync(&fwd[0], cons_.p, cons_len, hipMemcpyDeviceToHost, q));
+    if (cons_len) HIPOK(npcopy::d2h(&fwd[0], cons_.p, cons_len, q));
     HIPOK(hipStreamSynchronize(q));
     cons_rev->assign(fwd.rbegin(), fwd.rend());   // the reference leaves this string in backtrace order
     return true;
@@ -2664,16 +2665,16 @@ bool HipExec::run_poa(const PoaBatch& in, std::vector<std::string>* out, std::st
             !poajobs_.ensure(sizeof(np2poa::Job) * (size_t)n_jobs + 64) || !poatabs_.ensure(4ull * TAB_CAP * slots + 64) ||
             !poatabf_.ensure(4ull * TAB_CAP * slots + 64) || !poaout_.ensure(out_total + 64) || !poaolen_.ensure(4ull * n_jobs + 64) ||
             !poastat_.ensure(4ull * n_jobs + 64)) { *err = "out of device memory (pseudo-seeds)"; return false; }
-        HIPOK(hipMemcpyAsync(poapool_.p, in.chars.data(), in.chars.size(), hipMemcpyHostToDevice, q));
-        HIPOK(hipMemcpyAsync(poaoff_.p, in.str_off.data(), 4ull * n_str, hipMemcpyHostToDevice, q));
-        HIPOK(hipMemcpyAsync(poalen_.p, in.str_len.data(), 4ull * n_str, hipMemcpyHostToDevice, q));
-        HIPOK(hipMemcpyAsync(poajobs_.p, jobs.data(), sizeof(np2poa::Job) * (size_t)n_jobs, hipMemcpyHostToDevice, q));
+        HIPOK(npcopy::h2d(poapool_.p, in.chars.data(), in.chars.size(), q));
+        HIPOK(npcopy::h2d(poaoff_.p, in.str_off.data(), 4ull * n_str, q));
+        HIPOK(npcopy::h2d(poalen_.p, in.str_len.data(), 4ull * n_str, q));
+        HIPOK(npcopy::h2d(poajobs_.p, jobs.data(), sizeof(np2poa::Job) * (size_t)n_jobs, q));
         k2_poa<<<slots, 64, 0, q>>>(poapool_.as<char>(), poaoff_.as<uint32_t>(), poalen_.as<uint32_t>(), poajobs_.as<np2poa::Job>(), n_jobs, poatabs_.as<int32_t>(),
                                     poatabf_.as<uint32_t>(), TAB_CAP, poaout_.as<char>(), poaolen_.as<uint32_t>(), poastat_.as<uint32_t>());
         obuf.resize(out_total);
-        HIPOK(hipMemcpyAsync(&obuf[0], poaout_.p, out_total, hipMemcpyDeviceToHost, q));
-        HIPOK(hipMemcpyAsync(olen.data(), poaolen_.p, 4ull * n_jobs, hipMemcpyDeviceToHost, q));
-        HIPOK(hipMemcpyAsync(status.data(), poastat_.p, 4ull * n_jobs, hipMemcpyDeviceToHost, q));
+        HIPOK(npcopy::d2h(&obuf[0], poaout_.p, out_total, q));
+        HIPOK(npcopy::d2h(olen.data(), poaolen_.p, 4ull * n_jobs, q));
+        HIPOK(npcopy::d2h(status.data(), poastat_.p, 4ull * n_jobs, q));
         HIPOK(hipStreamSynchronize(q));
     }
     std::vector<uint32_t> todo;

@@ -15,6 +15,7 @@
 #include "np_crc_dev.h"
 #include "np_crc32.h"
 #include "np_devalloc.h"
+#include "np_hostcopy.h"
 
 namespace {
 
@@ -76,7 +77,7 @@ struct DevInflater {
             uint32_t t[64];
             npdev::crc_shift_table(t);
             if (npalloc::dev_malloc(&d_shift, sizeof(t)) != hipSuccess) { d_shift = nullptr; return false; }
-            if (hipMemcpy(d_shift, t, sizeof(t), hipMemcpyHostToDevice) != hipSuccess) return false;
+            if (npcopy::h2d_sync(d_shift, t, sizeof(t)) != hipSuccess) return false;
         }
         static thread_local std::vector<npdev::BlockDesc> desc;
         desc.resize(n);
@@ -85,9 +86,9 @@ struct DevInflater {
         // straight from / into the reader's own (pageable) windows: the runtime stages them, no copy of ours in between.  Once anything
         // is enqueued every way out waits for the stream first: the caller inflates into the same `out` window on its host threads
         // when this returns false
-        bool ok = hipMemcpyAsync(d_comp, comp, comp_len, hipMemcpyHostToDevice, q) == hipSuccess &&
+        bool ok = npcopy::h2d(d_comp, comp, comp_len, q) == hipSuccess &&
                   hipMemsetAsync((char*)d_comp + comp_len, 0, 4096, q) == hipSuccess &&
-                  hipMemcpyAsync(d_blocks, desc.data(), sizeof(npdev::BlockDesc) * n, hipMemcpyHostToDevice, q) == hipSuccess;
+                  npcopy::h2d(d_blocks, desc.data(), sizeof(npdev::BlockDesc) * n, q) == hipSuccess;
         if (ok) {
             k_bgzf_inflate<<<(unsigned)((n + 3) / 4), 256, 0, q>>>((const uint8_t*)d_comp, (const npdev::BlockDesc*)d_blocks, (uint32_t)n, (uint8_t*)d_out, (uint32_t*)d_status);
             ok = hipGetLastError() == hipSuccess;
@@ -97,8 +98,8 @@ struct DevInflater {
                                                                (const uint32_t*)d_shift);
             ok = hipGetLastError() == hipSuccess;
         }
-        ok = ok && hipMemcpyAsync(out, d_out, out_len, hipMemcpyDeviceToHost, q) == hipSuccess;
-        ok = ok && hipMemcpyAsync(status.data(), d_status, 4 * n, hipMemcpyDeviceToHost, q) == hipSuccess;
+        ok = ok && npcopy::d2h(out, d_out, out_len, q) == hipSuccess;
+        ok = ok && npcopy::d2h(status.data(), d_status, 4 * n, q) == hipSuccess;
         const bool synced = hipStreamSynchronize(q) == hipSuccess;
         if (!ok || !synced) return false;
         ++n_batches;

@@ -23,15 +23,17 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 
 namespace npalloc {
 
 // NP_ALLOCLOG=<path> (debugging): every device allocation, pinned host allocation and host registration of both libraries, and every
-// release, is appended to <path>.<pid> as one line "<ms> <tid> <op> <address> <bytes>" (ops D+ D- device, H+ H- hipHostMalloc, R+ R-
-// hipHostRegister), written with one write(2) each so that the file is complete when the runtime ends the process on a GPU memory fault:
+// release, is appended to <path>.<pid> as one line "<ms> <tid> <op> <address> <bytes>" (ops D+ D- device, H+ H- hipHostMalloc; round 5's hunt also logged R+ R- hipHostRegister,
+// which the libraries no longer use), written with one write(2) each so that the file is complete when the runtime ends the process on a GPU memory fault:
 // the address in the runtime's "Memory access fault by GPU ... on address" line is then looked up among the ranges that were live, or had
 // just been released, at that moment (tests/tools/r5_fault_lookup.py).
 inline int alloc_log_fd() {
@@ -54,25 +56,42 @@ inline void alloc_log(const char* op, const void* p, size_t bytes) {
     if (n > 0) (void)!write(fd, line, (size_t)n);
 }
 
-// pinned host memory and host registrations of both libraries go through here too (so that the log above sees them)
+// Page-locked host memory of both libraries comes from here: hipHostMalloc, and a list of the ranges handed out -- np_hostcopy.h lets
+// the DMA engines touch host memory only when it lies in one of them (never the user's pageable pages, never a hipHostRegister of heap
+// memory: DESIGN.md section 12).
+struct PinnedRanges {
+    std::mutex mu;
+    std::map<uintptr_t, size_t> live;      // start -> bytes
+};
+inline PinnedRanges& pinned_ranges() { static PinnedRanges* r = new PinnedRanges(); return *r; }
+inline bool is_pinned(const void* p, size_t bytes) {
+    PinnedRanges& R = pinned_ranges();
+    const uintptr_t a = (uintptr_t)p;
+    std::lock_guard<std::mutex> g(R.mu);
+    auto it = R.live.upper_bound(a);
+    if (it == R.live.begin()) return false;
+    --it;
+    return a >= it->first && a + bytes <= it->first + it->second;
+}
 inline hipError_t host_malloc(void** p, size_t bytes, unsigned flags) {
     const hipError_t e = hipHostMalloc(p, bytes, flags);
-    if (e == hipSuccess) alloc_log("H+", *p, bytes);
+    if (e == hipSuccess) {
+        alloc_log("H+", *p, bytes);
+        PinnedRanges& R = pinned_ranges();
+        std::lock_guard<std::mutex> g(R.mu);
+        R.live[(uintptr_t)*p] = bytes;
+    }
     return e;
 }
 inline hipError_t host_free(void* p) {
     if (!p) return hipSuccess;
     alloc_log("H-", p, 0);
+    {
+        PinnedRanges& R = pinned_ranges();
+        std::lock_guard<std::mutex> g(R.mu);
+        R.live.erase((uintptr_t)p);
+    }
     return hipHostFree(p);
-}
-inline hipError_t host_register(void* p, size_t bytes) {
-    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
-    alloc_log(e == hipSuccess ? "R+" : "R!", p, bytes);
-    return e;
-}
-inline hipError_t host_unregister(void* p) {
-    alloc_log("R-", p, 0);
-    return hipHostUnregister(p);
 }
 
 inline bool efence() {

@@ -1,0 +1,151 @@
+// Host <-> device copies of both libraries go through here.
+//
+// Why (round 5): on this runtime (ROCm 7.2) hipMemcpy / hipMemcpyAsync with PAGEABLE host memory is served three ways,
+// by size (tests/tools/r5_stale_pin_probe.hip `thresh` under AMD_LOG_LEVEL=4, profiles/r5_fault_hunt.txt):
+//   <= 1 MiB          staged through the runtime's own pinned buffer: the bytes are taken (H2D) while the call runs;
+//   1 MiB .. 32 MiB   the USER's pages are locked in place ("Locking to pool", a userptr registration with the kernel driver), the DMA engine
+//                     reads / writes them directly and the call RETURNS WITHOUT WAITING -- the copy is really asynchronous;
+//   > 32 MiB          the same in chunks of 32 MiB, and the call waits for the last chunk.
+// The middle class is what ended the one-process GPU suite: "Memory access fault by GPU ... on address 0x58a0ab503000" is an address of the
+// brk heap, hit during the H2D copy of a 3.25 MB std::vector (np1_batch_upload).  A vector freed before its stream is synchronised -- legal
+// under the "pageable copies are synchronous" assumption this code was written on -- is read by the DMA engine after the heap has given the
+// pages back; and a userptr registration of heap pages is only as good as the kernel driver's tracking of every trim, growth and migration
+// of those pages underneath it.
+//
+// So: the GPU never touches memory it did not get from hipHostMalloc.  Copies whose host side is page-locked memory of ours (allocated through
+// npalloc::host_malloc, which keeps the list) go straight to hipMemcpyAsync and are asynchronous.  Everything else:
+//   H2D  the bytes are taken at the time of the call (small: by the runtime's staging; above 256 KiB: through a ring of our own pinned
+//        slots, the host memcpy of chunk k + 1 overlapping the DMA of chunk k) -- the source may be freed as soon as the call returns;
+//   D2H  small: the runtime's staging (the bytes arrive with the next synchronisation of the stream, as before); above 256 KiB: through the
+//        ring, complete when the call returns.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+
+#include "np_devalloc.h"
+
+namespace npcopy {
+
+constexpr size_t kDirectMax = 256 << 10;      // pageable copies up to this size are left to the runtime's own staging
+constexpr size_t kSlotBytes = 8 << 20;
+constexpr int kSlots = 6;
+
+struct Slot { void* p = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
+
+class Ring {      // one per device and library, made at the first large pageable copy
+public:
+    bool acquire(Slot* out) {
+        std::unique_lock<std::mutex> g(mu_);
+        if (made_ < kSlots && (free_.empty() || free_.front().pending)) {
+            Slot s;
+            if (npalloc::host_malloc(&s.p, kSlotBytes, hipHostMallocPortable) != hipSuccess) { s.p = nullptr; }
+            else if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { (void)npalloc::host_free(s.p); s.p = nullptr; }
+            if (s.p) { ++made_; *out = s; return true; }
+            if (made_ < 2 && free_.empty()) return false;      // no pinned memory to be had: the caller reports the failure
+        }
+        cv_.wait(g, [&] { return !free_.empty(); });
+        *out = free_.front();
+        free_.pop_front();
+        g.unlock();
+        if (out->pending) { (void)hipEventSynchronize(out->ev); out->pending = false; }
+        return true;
+    }
+    void release(const Slot& s) {
+        { std::lock_guard<std::mutex> g(mu_); free_.push_back(s); }
+        cv_.notify_one();
+    }
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Slot> free_;
+    int made_ = 0;
+};
+
+inline Ring& ring() {
+    static std::mutex mu;
+    static std::map<int, Ring*> rings;      // (never destroyed: the runtime may already be gone when static destructors run)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    Ring*& r = rings[dev];
+    if (!r) r = new Ring();
+    return *r;
+}
+
+inline hipError_t h2d(void* dst, const void* src, size_t bytes, hipStream_t q) {
+    if (!bytes) return hipSuccess;
+    if (bytes <= kDirectMax || npalloc::is_pinned(src, bytes)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, q);
+    Ring& R = ring();
+    for (size_t off = 0; off < bytes;) {
+        const size_t n = bytes - off < kSlotBytes ? bytes - off : kSlotBytes;
+        Slot s;
+        if (!R.acquire(&s)) return hipErrorOutOfMemory;
+        memcpy(s.p, static_cast<const char*>(src) + off, n);
+        hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + off, s.p, n, hipMemcpyHostToDevice, q);
+        if (e == hipSuccess) e = hipEventRecord(s.ev, q);
+        s.pending = e == hipSuccess;
+        if (e != hipSuccess) (void)hipStreamSynchronize(q);
+        R.release(s);
+        if (e != hipSuccess) return e;
+        off += n;
+    }
+    return hipSuccess;
+}
+
+// (large pageable destination: complete on return; two slots in flight so that the memcpy out of one overlaps the DMA into the other)
+inline hipError_t d2h(void* dst, const void* src, size_t bytes, hipStream_t q) {
+    if (!bytes) return hipSuccess;
+    if (bytes <= kDirectMax || npalloc::is_pinned(dst, bytes)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, q);
+    Ring& R = ring();
+    Slot cur, nxt;
+    size_t cur_off = 0, cur_n = 0;
+    bool have_cur = false;
+    hipError_t err = hipSuccess;
+    for (size_t off = 0; off < bytes || have_cur;) {
+        bool have_nxt = false;
+        size_t nxt_off = 0, nxt_n = 0;
+        if (off < bytes && err == hipSuccess) {
+            nxt_n = bytes - off < kSlotBytes ? bytes - off : kSlotBytes;
+            nxt_off = off;
+            if (!R.acquire(&nxt)) { err = hipErrorOutOfMemory; }
+            else {
+                hipError_t e = hipMemcpyAsync(nxt.p, static_cast<const char*>(src) + off, nxt_n, hipMemcpyDeviceToHost, q);
+                if (e == hipSuccess) e = hipEventRecord(nxt.ev, q);
+                if (e != hipSuccess) { (void)hipStreamSynchronize(q); R.release(nxt); err = e; }
+                else { have_nxt = true; off += nxt_n; }
+            }
+        }
+        if (have_cur) {
+            const hipError_t e = hipEventSynchronize(cur.ev);
+            if (e == hipSuccess) memcpy(static_cast<char*>(dst) + cur_off, cur.p, cur_n);
+            else if (err == hipSuccess) err = e;
+            cur.pending = false;
+            R.release(cur);
+            have_cur = false;
+        }
+        if (have_nxt) { cur = nxt; cur_off = nxt_off; cur_n = nxt_n; have_cur = true; }
+        else if (err != hipSuccess) break;
+    }
+    return err;
+}
+
+// the synchronous forms (hipMemcpy): on the null stream, complete on return
+inline hipError_t h2d_sync(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    if (bytes <= kDirectMax || npalloc::is_pinned(src, bytes)) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    const hipError_t e = h2d(dst, src, bytes, nullptr);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+inline hipError_t d2h_sync(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    if (bytes <= kDirectMax || npalloc::is_pinned(dst, bytes)) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    return d2h(dst, src, bytes, nullptr);
+}
+
+}  // namespace npcopy
