@@ -299,6 +299,16 @@ int np1_batch_snp_phase(np1_batch* sr, np1_batch* lr, const Configure* cfg);
 int np1_score_chain_tiled(np1_ctx* ctx, const char* fasta, const char* bam, const char* name, const Configure* cfg, int64_t tile_bp, int64_t halo_bp,
                           int64_t first_tile, int64_t tile_stride, char** out, int64_t* out_len, uint64_t* stats);
 void np1_free_string(char* s);
+/* The same with the contig opened ONCE: np1_tiler_open reads the FASTA index entry, the contig's draft and the BAM index; np1_tiler_run
+ * polishes tiles first_tile, first_tile + tile_stride, ... (the records of tile t + 1 are read while the device runs tile t) and returns their
+ * pieces joined in tile order, piece_len[i] (optional; room for every tile of the call) = the length of the i-th piece -- what a rank that
+ * takes every world-th tile of a dominant contig calls once (nextpolish_amd/nextpolish1.py: write_tile_pieces). */
+typedef struct np1_tiler np1_tiler;
+np1_tiler* np1_tiler_open(const char* fasta, const char* bam, const char* name);
+int64_t np1_tiler_length(const np1_tiler* t);
+int np1_tiler_run(np1_tiler* t, np1_ctx* ctx, const Configure* cfg, int64_t tile_bp, int64_t halo_bp, int64_t first_tile, int64_t tile_stride,
+                  char** out, int64_t* out_len, int64_t* piece_len, uint64_t* stats);
+void np1_tiler_close(np1_tiler* t);
 /* score_chain over a whole FASTA index with tiling on: contigs longer than tile_bp tile by tile, the others through the pipe in batches;
  * every contig reaches `sink` in index order (what `nextpolish1 scorechain` does when NP1_TILE_BP is set) */
 int np1_run_files_tiled(np1_pipe* pipe, int device, const char* fasta, const char* bam, int64_t batch_bp, int64_t tile_bp, int64_t halo_bp,

