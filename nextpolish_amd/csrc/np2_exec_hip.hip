@@ -1661,15 +1661,29 @@ __global__ void k2_bt_place(const BtWalk* walks, uint32_t n_runs, const BtGroupP
 
 
 // ---- pseudo-seeds of the low-quality regions: one resident wave per job slot (np2_poa_dev.h) --------------------------------
+// Jobs come off ONE atomic counter (round 4 dealt them in a fixed stride: a slot that drew the long regions finished last with the others
+// idle).  Two launches: the Small class (graph indices in bytes, score table in LDS, 9 waves a CU) takes every job the host did not rule
+// out; what it gives back (status 1: graph or table outgrew the class) runs in the Big class (table in a slice of HBM scratch); what
+// that gives back goes to the host version.
+template <class C>
 __global__ __launch_bounds__(64) void k2_poa(const char* __restrict__ pool, const uint32_t* __restrict__ str_off, const uint32_t* __restrict__ str_len,
                                              const np2poa::Job* __restrict__ jobs, uint32_t n_jobs, int32_t* tabS, uint32_t* tabF, uint32_t tab_cap,
-                                             char* out_pool, uint32_t* out_len, uint32_t* status) {
-    __shared__ np2poa::PoaLds L;
-    int32_t* TS = tabS + (size_t)blockIdx.x * tab_cap;
-    uint32_t* TF = tabF + (size_t)blockIdx.x * tab_cap;
-    for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) {
+                                             char* out_pool, uint32_t* out_len, uint32_t* status, uint32_t* queue) {
+    __shared__ np2poa::PoaLdsT<C> L;
+    int32_t* TS = C::TAB_LDS ? nullptr : tabS + (size_t)blockIdx.x * tab_cap;
+    uint32_t* TF = C::TAB_LDS ? nullptr : tabF + (size_t)blockIdx.x * tab_cap;
+    for (;;) {
+        uint32_t j = 0;
+        if (threadIdx.x == 0) j = atomicAdd(queue, 1u);
+        j = np2poa::uni(j);
+        if (j >= n_jobs) break;
         const np2poa::Job J = jobs[j];
-        const bool ok = np2poa::poa_region(pool, str_off, str_len, J, TS, TF, tab_cap, out_pool, &out_len[j], &L);
+        if (C::TAB_LDS) {      // first launch: every job gets its status here
+            if (!J.small) { if (threadIdx.x == 0) status[j] = 1u; continue; }
+        } else if (status[j] == 0) {
+            continue;          // second launch: done by the first one
+        }
+        const bool ok = np2poa::poa_region<C>(pool, str_off, str_len, J, TS, TF, tab_cap, out_pool, &out_len[j], &L);
         if (threadIdx.x == 0) status[j] = ok ? 0u : 1u;
         np2poa::lds_sync();
     }
@@ -2653,10 +2667,16 @@ bool HipExec::run_poa(const PoaBatch& in, std::vector<std::string>* out, std::st
     std::string obuf;
     if (!host_only) {
         uint64_t out_total = 0;
+        static const bool no_small = getenv("NP2_POA_BIG_ONLY") != nullptr;      // test hook: every job in the first version's class
+        uint32_t n_small = 0;
         for (uint32_t j = 0; j < n_jobs; ++j) {
             uint32_t cap = 0;
             for (uint32_t k = 0; k < in.job_n[j]; ++k) cap += in.str_len[in.job_first[j] + k] + 1;
-            jobs[j] = np2poa::Job{in.job_first[j], in.job_n[j], out_total, cap, 0};
+            uint32_t longest = 0;
+            for (uint32_t k = 0; k < in.job_n[j]; ++k) longest = std::max(longest, in.str_len[in.job_first[j] + k]);
+            const bool small = !no_small && in.job_n[j] <= np2poa::Small::MAXSTR && longest <= np2poa::Small::MAXLEN;
+            jobs[j] = np2poa::Job{in.job_first[j], in.job_n[j], out_total, cap, small ? 1u : 0u};
+            n_small += small;
             out_total += cap;
         }
         const uint32_t slots = std::min<uint32_t>(n_jobs, 1792u);        // resident waves (7 per CU by their LDS), each with its slice of table scratch
@@ -2664,13 +2684,19 @@ bool HipExec::run_poa(const PoaBatch& in, std::vector<std::string>* out, std::st
         if (!poapool_.ensure(in.chars.size() + 64) || !poaoff_.ensure(4ull * n_str + 64) || !poalen_.ensure(4ull * n_str + 64) ||
             !poajobs_.ensure(sizeof(np2poa::Job) * (size_t)n_jobs + 64) || !poatabs_.ensure(4ull * TAB_CAP * slots + 64) ||
             !poatabf_.ensure(4ull * TAB_CAP * slots + 64) || !poaout_.ensure(out_total + 64) || !poaolen_.ensure(4ull * n_jobs + 64) ||
-            !poastat_.ensure(4ull * n_jobs + 64)) { *err = "out of device memory (pseudo-seeds)"; return false; }
+            !poastat_.ensure(4ull * n_jobs + 64 + 64)) { *err = "out of device memory (pseudo-seeds)"; return false; }
+        uint32_t* queue = poastat_.as<uint32_t>() + n_jobs + 4;      // two job counters behind the status words
+        HIPOK(hipMemsetAsync(queue, 0, 8, q));
         HIPOK(npcopy::h2d(poapool_.p, in.chars.data(), in.chars.size(), q));
         HIPOK(npcopy::h2d(poaoff_.p, in.str_off.data(), 4ull * n_str, q));
         HIPOK(npcopy::h2d(poalen_.p, in.str_len.data(), 4ull * n_str, q));
         HIPOK(npcopy::h2d(poajobs_.p, jobs.data(), sizeof(np2poa::Job) * (size_t)n_jobs, q));
-        k2_poa<<<slots, 64, 0, q>>>(poapool_.as<char>(), poaoff_.as<uint32_t>(), poalen_.as<uint32_t>(), poajobs_.as<np2poa::Job>(), n_jobs, poatabs_.as<int32_t>(),
-                                    poatabf_.as<uint32_t>(), TAB_CAP, poaout_.as<char>(), poaolen_.as<uint32_t>(), poastat_.as<uint32_t>());
+        const uint32_t small_slots = std::min<uint32_t>(n_jobs, 256u * 9u);      // 16.9 KB of LDS a wave: 9 a CU
+        k2_poa<np2poa::Small><<<small_slots, 64, 0, q>>>(poapool_.as<char>(), poaoff_.as<uint32_t>(), poalen_.as<uint32_t>(), poajobs_.as<np2poa::Job>(), n_jobs, nullptr,
+                                                         nullptr, 0u, poaout_.as<char>(), poaolen_.as<uint32_t>(), poastat_.as<uint32_t>(), queue);
+        k2_poa<np2poa::Big><<<slots, 64, 0, q>>>(poapool_.as<char>(), poaoff_.as<uint32_t>(), poalen_.as<uint32_t>(), poajobs_.as<np2poa::Job>(), n_jobs, poatabs_.as<int32_t>(),
+                                                 poatabf_.as<uint32_t>(), TAB_CAP, poaout_.as<char>(), poaolen_.as<uint32_t>(), poastat_.as<uint32_t>(), queue + 1);
+        if (getenv("NP2_TIMING")) fprintf(stderr, "[np2 poa] %u jobs, %u of them offered to the Small class\n", n_jobs, n_small);
         obuf.resize(out_total);
         HIPOK(npcopy::d2h(&obuf[0], poaout_.p, out_total, q));
         HIPOK(npcopy::d2h(olen.data(), poaolen_.p, 4ull * n_jobs, q));

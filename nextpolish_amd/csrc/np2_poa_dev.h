@@ -20,25 +20,46 @@
 
 namespace np2poa {
 
-constexpr uint32_t MAXN = 256, MAXE = 512, MAXLEN = 255, MAXP = MAXN + MAXLEN + 1, MAXS = 1024, NONE16 = 0xffffu;   // 21 KB of LDS: 7 regions per CU
 constexpr int32_t W_MATCH = 1, W_MISMATCH = -2, W_GAP = -2;
 
-struct PoaLds {
-    uint8_t base[MAXN];
-    uint16_t in_head[MAXN], in_tail[MAXN], out_head[MAXN], out_tail[MAXN];   // edge lists in attachment order (linked through the edges)
-    uint16_t col_of[MAXN], col_next[MAXN];          // aligned group ("column") of a node, next member in joining order
-    uint16_t col_head[MAXN], col_tail[MAXN];        // per group: first (= lowest-numbered) and last member
-    uint16_t order[MAXN], rank[MAXN];
-    uint16_t e_src[MAXE], e_dst[MAXE], e_nin[MAXE], e_nout[MAXE];
-    unsigned long long e_sup[MAXE];                 // bit q: string q runs along this edge
-    int16_t path_node[MAXP], path_chr[MAXP];        // the alignment columns in walk-back order
-    uint16_t stack[MAXS];
-    uint8_t finished[MAXN], open[MAXN];
-    double best_at[MAXN];
-    int16_t came_from[MAXN];
+// Two size classes of one algorithm (round 5).  A job = the best six candidates of a region at most (np2_lq.cpp: rank_and_seed), typically
+// 35-45 characters each, so its graph has a few dozen nodes and its score table a few thousand cells:
+//   Small  indices in one byte (127 nodes, 254 edges, strings up to 126 characters, 8 strings), the SCORE TABLE IN LDS as 16-bit scores +
+//          16-bit back pointers (3072 cells): 16.9 KB of LDS a wave, 9 regions a CU, and a row of the table costs LDS round trips where the
+//          first version (one class, table in a slice of HBM scratch) paid three dependent global round trips and a fence per row;
+//   Big    the first version as it was (255 nodes, 511 edges, 255 characters, 64 strings, table in HBM scratch): what a Small wave gives
+//          back (graph or table too large) runs here, what this one gives back goes to the host version.
+// Scores fit 16 bits: |score| <= 2 (rows + columns) <= 2 (128 + 127); the weights of the heaviest path are multiples of 0.5 below 2^11,
+// exact in a float; so both classes compute the same numbers and take the same decisions.
+struct Big {
+    using ix = uint16_t; using sup_t = unsigned long long; using best_t = double; using path_t = int16_t; using ts_t = int32_t; using tf_t = uint32_t;
+    static constexpr uint32_t MAXN = 256, MAXE = 512, MAXLEN = 255, MAXP = MAXN + MAXLEN + 1, MAXS = 1024, NONE = 0xffffu, TAB_LDS = 0, FSHIFT = 16, MAXSTR = 64;
+};
+struct Small {
+    using ix = uint8_t; using sup_t = uint8_t; using best_t = float; using path_t = int8_t; using ts_t = int16_t; using tf_t = uint16_t;
+    static constexpr uint32_t MAXN = 127, MAXE = 254, MAXLEN = 126, MAXP = MAXN + MAXLEN + 1, MAXS = 512, NONE = 0xffu, TAB_LDS = 3072, FSHIFT = 8, MAXSTR = 8;
 };
 
-struct Job { uint32_t first_str, n_str; unsigned long long out_off; uint32_t out_cap, pad; };
+template <class C> struct PoaLdsT {
+    using ix = typename C::ix;
+    uint8_t base[C::MAXN];
+    ix in_head[C::MAXN], in_tail[C::MAXN], out_head[C::MAXN], out_tail[C::MAXN];   // edge lists in attachment order (linked through the edges)
+    ix col_of[C::MAXN], col_next[C::MAXN];          // aligned group ("column") of a node, next member in joining order
+    ix col_head[C::MAXN], col_tail[C::MAXN];        // per group: first (= lowest-numbered) and last member
+    ix order[C::MAXN], rank[C::MAXN];
+    ix e_src[C::MAXE], e_dst[C::MAXE], e_nin[C::MAXE], e_nout[C::MAXE];
+    typename C::sup_t e_sup[C::MAXE];               // bit q: string q runs along this edge
+    typename C::path_t path_node[C::MAXP], path_chr[C::MAXP];        // the alignment columns in walk-back order
+    ix stack[C::MAXS];
+    uint8_t finished[C::MAXN], open[C::MAXN];
+    typename C::best_t best_at[C::MAXN];
+    typename C::path_t came_from[C::MAXN];
+    typename C::ts_t ts[C::TAB_LDS ? C::TAB_LDS : 1];      // Small: the score table and its back pointers
+    typename C::tf_t tf[C::TAB_LDS ? C::TAB_LDS : 1];
+};
+using PoaLds = PoaLdsT<Big>;
+
+struct Job { uint32_t first_str, n_str; unsigned long long out_off; uint32_t out_cap, small; };      // small: 1 = the host found nothing that rules the Small class out
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void lds_sync() {
@@ -50,40 +71,43 @@ __device__ __forceinline__ void glb_sync() {      // the wave's own table rows: 
     __builtin_amdgcn_wave_barrier();
 }
 
-struct Graph {          // wave-uniform counters; the arrays are in LDS
-    PoaLds* L;
+template <class C> struct Graph {          // wave-uniform counters; the arrays are in LDS
+    static constexpr uint32_t MAXN = C::MAXN, MAXE = C::MAXE, MAXS = C::MAXS, NONE16 = C::NONE;
+    using ix_t = typename C::ix;
+    using sup_t = typename C::sup_t;
+    PoaLdsT<C>* L;
     uint32_t n, ne, ncols;
     bool fail;
     __device__ __forceinline__ uint32_t new_node(uint32_t b, uint32_t col) {      // col == NONE16: a group of its own
         if (n >= MAXN) { fail = true; return 0; }
         const uint32_t v = n++;
         L->base[v] = (uint8_t)b;
-        L->in_head[v] = L->in_tail[v] = L->out_head[v] = L->out_tail[v] = (uint16_t)NONE16;
-        L->col_next[v] = (uint16_t)NONE16;
+        L->in_head[v] = L->in_tail[v] = L->out_head[v] = L->out_tail[v] = (ix_t)NONE16;
+        L->col_next[v] = (ix_t)NONE16;
         if (col == NONE16) {
             col = ncols++;
-            L->col_head[col] = L->col_tail[col] = (uint16_t)v;
+            L->col_head[col] = L->col_tail[col] = (ix_t)v;
         } else {
             const uint32_t t = uni(L->col_tail[col]);
-            L->col_next[t] = (uint16_t)v;
-            L->col_tail[col] = (uint16_t)v;
+            L->col_next[t] = (ix_t)v;
+            L->col_tail[col] = (ix_t)v;
         }
-        L->col_of[v] = (uint16_t)col;
+        L->col_of[v] = (ix_t)col;
         lds_sync();
         return v;
     }
     __device__ __forceinline__ void connect(uint32_t a, uint32_t b, uint32_t q) {
         if (ne >= MAXE) { fail = true; return; }
         const uint32_t e = ne++;
-        L->e_src[e] = (uint16_t)a; L->e_dst[e] = (uint16_t)b; L->e_sup[e] = 1ull << q;
-        L->e_nin[e] = L->e_nout[e] = (uint16_t)NONE16;
+        L->e_src[e] = (ix_t)a; L->e_dst[e] = (ix_t)b; L->e_sup[e] = (sup_t)(1ull << q);
+        L->e_nin[e] = L->e_nout[e] = (ix_t)NONE16;
         const uint32_t ot = uni(L->out_tail[a]);
-        if (ot == NONE16) L->out_head[a] = (uint16_t)e; else L->e_nout[ot] = (uint16_t)e;
-        L->out_tail[a] = (uint16_t)e;
+        if (ot == NONE16) L->out_head[a] = (ix_t)e; else L->e_nout[ot] = (ix_t)e;
+        L->out_tail[a] = (ix_t)e;
         lds_sync();          // a == b cannot happen, but in-list and out-list updates may touch the same edge record
         const uint32_t it = uni(L->in_tail[b]);
-        if (it == NONE16) L->in_head[b] = (uint16_t)e; else L->e_nin[it] = (uint16_t)e;
-        L->in_tail[b] = (uint16_t)e;
+        if (it == NONE16) L->in_head[b] = (ix_t)e; else L->e_nin[it] = (ix_t)e;
+        L->in_tail[b] = (ix_t)e;
         lds_sync();
     }
     // a run of fresh nodes for characters that align with nothing
@@ -117,7 +141,7 @@ struct Graph {          // wave-uniform counters; the arrays are in LDS
             for (uint32_t g = lane; g < ncols; g += 64) L->open[g] = 0;
             lds_sync();
             uint32_t sp = 0;
-            L->stack[sp++] = (uint16_t)start;
+            L->stack[sp++] = (ix_t)start;
             lds_sync();
             while (sp) {
                 const uint32_t g = uni(L->stack[--sp]);
@@ -128,14 +152,14 @@ struct Graph {          // wave-uniform counters; the arrays are in LDS
                     L->open[g] = 0;
                     for (uint32_t p = v; p != NONE16; p = uni(L->col_next[p])) {
                         if (slot < 0) { fail = true; break; }
-                        L->order[slot--] = (uint16_t)p;
+                        L->order[slot--] = (ix_t)p;
                     }
                     lds_sync();
                     continue;
                 }
                 L->open[g] = 1;
                 if (sp >= MAXS) { fail = true; break; }
-                L->stack[sp++] = (uint16_t)g;
+                L->stack[sp++] = (ix_t)g;
                 for (uint32_t p = v; p != NONE16 && !fail; p = uni(L->col_next[p]))
                     for (uint32_t e = uni(L->out_head[p]); e != NONE16; e = uni(L->e_nout[e])) {
                         if (sp >= MAXS) { fail = true; break; }
@@ -144,26 +168,50 @@ struct Graph {          // wave-uniform counters; the arrays are in LDS
                 lds_sync();
             }
         }
-        for (uint32_t i = lane; i < n; i += 64) L->rank[L->order[i]] = (uint16_t)i;
+        for (uint32_t i = lane; i < n; i += 64) L->rank[L->order[i]] = (ix_t)i;
         lds_sync();
     }
 };
 
+// signed wave-uniform broadcast (path and came_from entries are -1 or an index)
+__device__ __forceinline__ int32_t unis(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// The score table of one string against the graph, (nodes + 1) rows x (length + 1) columns, a score and a back pointer (row << FSHIFT |
+// column) per cell.  Big: a slice of HBM scratch owned by the resident wave; Small: the wave's LDS.
+template <class C> struct Table {
+    PoaLdsT<C>* L;
+    int32_t* TS;
+    uint32_t* TF;
+    uint32_t cap;
+    __device__ __forceinline__ uint32_t capacity() const { if constexpr (C::TAB_LDS > 0) return C::TAB_LDS; else return cap; }
+    __device__ __forceinline__ int32_t score(uint32_t i) const { if constexpr (C::TAB_LDS > 0) return (int32_t)L->ts[i]; else return TS[i]; }
+    __device__ __forceinline__ uint32_t from(uint32_t i) const { if constexpr (C::TAB_LDS > 0) return (uint32_t)L->tf[i]; else return TF[i]; }
+    __device__ __forceinline__ void set(uint32_t i, int32_t sc, uint32_t fr) const {
+        if constexpr (C::TAB_LDS > 0) { L->ts[i] = (typename C::ts_t)sc; L->tf[i] = (typename C::tf_t)fr; }
+        else { TS[i] = sc; TF[i] = fr; }
+    }
+    __device__ __forceinline__ void sync() const {      // the wave's own rows: written by some lanes, read by others later
+        if constexpr (C::TAB_LDS > 0) lds_sync(); else glb_sync();
+    }
+};
+
 // one string against the graph, then through it (np2_poa.cpp add_string)
-__device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, int32_t* TS, uint32_t* TF, uint32_t tab_cap) {
-    PoaLds* L = G.L;
+template <class C> __device__ void add_string(Graph<C>& G, uint32_t q, const char* s, uint32_t len, const Table<C>& T) {
+    constexpr uint32_t NONE16 = C::NONE, MAXP = C::MAXP, FS = C::FSHIFT, FMASK = (1u << C::FSHIFT) - 1u;
+    using path_t = typename C::path_t;
+    using sup_t = typename C::sup_t;
+    PoaLdsT<C>* L = G.L;
     const uint32_t lane = __lane_id();
     const uint32_t n = G.n, width = len + 1;
-    if ((unsigned long long)(n + 1) * width > tab_cap) { G.fail = true; return; }
-    for (uint32_t c = lane; c < width; c += 64) { TS[c] = (int32_t)c * W_GAP; TF[c] = 0; }
-    glb_sync();
+    if ((unsigned long long)(n + 1) * width > T.capacity()) { G.fail = true; return; }
+    for (uint32_t c = lane; c < width; c += 64) T.set(c, (int32_t)c * W_GAP, 0u);
+    T.sync();
     // rows in emission order
     for (uint32_t r = 0; r < n; ++r) {
         const uint32_t v = uni(L->order[r]);
         const char vb = (char)uni(L->base[v]);
         const uint32_t row = r + 1;
-        int32_t* RS = TS + (size_t)row * width;
-        uint32_t* RF = TF + (size_t)row * width;
+        const uint32_t R0 = row * width;
         // left border: the best predecessor's border value plus a gap (sources start from 0)
         const uint32_t e0 = uni(L->in_head[v]);
         int32_t border = 0;
@@ -171,12 +219,12 @@ __device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, in
             bool any = false;
             for (uint32_t e = e0; e != NONE16; e = uni(L->e_nin[e])) {
                 const uint32_t pr = uni(L->rank[uni(L->e_src[e])]) + 1u;
-                const int32_t x = (int32_t)uni((uint32_t)TS[(size_t)pr * width]);
+                const int32_t x = unis(T.score(pr * width));
                 if (!any || x > border) { border = x; any = true; }
             }
             border += W_GAP;
         }
-        if (lane == 0) { RS[0] = border; RF[0] = 0; }
+        if (lane == 0) T.set(R0, border, 0u);
         int32_t run = border;                     // max over k < j of (H(k) + 2 k) = of A(k); A(0) = H(0)
         for (uint32_t cb = 0; cb < len; cb += 64) {
             const uint32_t c = cb + lane;         // string position; the cell is column j = c + 1
@@ -187,11 +235,11 @@ __device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, in
                 const int32_t w = s[c] == vb ? W_MATCH : W_MISMATCH;
                 bool first = true;
                 auto offer = [&](uint32_t pr) {
-                    const int32_t* P = TS + (size_t)pr * width;
-                    const int32_t skip = P[c + 1] + W_GAP, pair = P[c] + w;
+                    const uint32_t P0 = pr * width;
+                    const int32_t skip = T.score(P0 + c + 1) + W_GAP, pair = T.score(P0 + c) + w;
                     const bool sk = skip >= pair;
                     const int32_t cand = sk ? skip : pair;
-                    if (first || cand > O) { O = cand; F = pr << 16 | (c + (sk ? 1u : 0u)); }
+                    if (first || cand > O) { O = cand; F = pr << FS | (c + (sk ? 1u : 0u)); }
                     first = false;
                 };
                 if (e0 == NONE16) offer(0);
@@ -206,13 +254,12 @@ __device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, in
             if (valid) {
                 const bool take = A > exc;
                 const int32_t M = take ? A : exc;
-                RS[j] = M + W_GAP * j;
-                RF[j] = take ? F : (row << 16 | (uint32_t)(j - 1));
+                T.set(R0 + (uint32_t)j, M + W_GAP * j, take ? F : (row << FS | (uint32_t)(j - 1)));
             }
             const int32_t last = __shfl(inc, 63, 64);      // invalid lanes carry INT32_MIN: the maximum of the valid ones
             if (last > run) run = last;
         }
-        glb_sync();
+        T.sync();
     }
     // the alignment ends in a sink: the first one in order with the best full-length score
     uint32_t row = 0;
@@ -222,7 +269,7 @@ __device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, in
         for (uint32_t rb = 0; rb < n; rb += 64) {
             const uint32_t r = rb + lane;
             const bool cand = r < n && L->out_head[L->order[r]] == NONE16;
-            const int32_t x = cand ? TS[(size_t)(r + 1) * width + len] : INT32_MIN;
+            const int32_t x = cand ? T.score((r + 1) * width + len) : INT32_MIN;
             int32_t m = x;
             for (int o = 32; o > 0; o >>= 1) { const int32_t y = __shfl_xor(m, o, 64); m = y > m ? y : m; }
             const unsigned long long hit = __ballot(cand && x == m);
@@ -233,8 +280,8 @@ __device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, in
     uint32_t np = 0;
     int32_t lowest_chr = -1, highest_chr = -1;
     for (uint32_t col = len; row != 0 || col != 0;) {
-        const uint32_t from = uni(TF[(size_t)row * width + col]);
-        const uint32_t from_row = from >> 16, from_col = from & 0xffffu;
+        const uint32_t from = uni(T.from(row * width + col));
+        const uint32_t from_row = from >> FS, from_col = from & FMASK;
         int32_t node = -1, chr = -1;
         if (from_row != row) node = (int32_t)uni(L->order[row - 1]);
         if (from_col != col) {
@@ -243,8 +290,8 @@ __device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, in
             if (highest_chr == -1) highest_chr = chr;
         }
         if (np >= MAXP) { G.fail = true; return; }
-        L->path_node[np] = (int16_t)node;
-        L->path_chr[np] = (int16_t)chr;
+        L->path_node[np] = (path_t)node;
+        L->path_chr[np] = (path_t)chr;
         ++np;
         row = from_row;
         col = from_col;
@@ -257,9 +304,9 @@ __device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, in
     if (highest_chr < (int32_t)len - 1)                                                         // and behind the last one (the run takes the
         G.chain(q, s + highest_chr + 1, (uint32_t)((int32_t)len - highest_chr), &tail_first, &cur);   // terminator along, like the reference)
     for (uint32_t k = np; k-- > 0 && !G.fail;) {
-        const int32_t chr = (int16_t)uni((uint32_t)(uint16_t)L->path_chr[k]);
+        const int32_t chr = unis((int32_t)L->path_chr[k]);
         if (chr == -1) continue;
-        const int32_t node = (int16_t)uni((uint32_t)(uint16_t)L->path_node[k]);
+        const int32_t node = unis((int32_t)L->path_node[k]);
         cur_is_new = false;
         const uint8_t b = (uint8_t)s[chr];
         if (node == -1) { cur = (int32_t)G.new_node(b, NONE16); cur_is_new = true; }
@@ -276,7 +323,7 @@ __device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, in
             bool joined = false;
             if (!cur_is_new && !prev_is_new)
                 for (uint32_t e = uni(L->out_head[prev]); e != NONE16; e = uni(L->e_nout[e]))
-                    if (uni(L->e_dst[e]) == (uint32_t)cur) { L->e_sup[e] |= 1ull << q; joined = true; }
+                    if (uni(L->e_dst[e]) == (uint32_t)cur) { L->e_sup[e] |= (sup_t)(1ull << q); joined = true; }
             if (joined) lds_sync();
             else G.connect((uint32_t)prev, (uint32_t)cur, q);
         }
@@ -289,29 +336,36 @@ __device__ void add_string(Graph& G, uint32_t q, const char* s, uint32_t len, in
 }
 
 // the whole job: strings of one region -> consensus characters; returns false when the region has to go to the host version
-__device__ bool poa_region(const char* pool, const uint32_t* __restrict__ str_off, const uint32_t* __restrict__ str_len, const Job& J, int32_t* TS, uint32_t* TF,
-                           uint32_t tab_cap, char* out_pool, uint32_t* out_len, PoaLds* L) {
+template <class C> __device__ bool poa_region(const char* pool, const uint32_t* __restrict__ str_off, const uint32_t* __restrict__ str_len, const Job& J, int32_t* TS, uint32_t* TF,
+                                              uint32_t tab_cap, char* out_pool, uint32_t* out_len, PoaLdsT<C>* L) {
+    constexpr uint32_t NONE16 = C::NONE, MAXLEN = C::MAXLEN, MAXN = C::MAXN;
+    using ix_t = typename C::ix;
+    using path_t = typename C::path_t;
+    using sup_t = typename C::sup_t;
+    using best_t = typename C::best_t;
     const uint32_t lane = __lane_id();
-    Graph G{L, 0u, 0u, 0u, false};
+    if (J.n_str > C::MAXSTR) return false;
+    Graph<C> G{L, 0u, 0u, 0u, false};
+    const Table<C> T{L, TS, TF, tab_cap};
     // the first string is the graph: a chain, every node a group of its own, emission order = string order
     const uint32_t len0 = str_len[J.first_str];
     const char* s0 = pool + str_off[J.first_str];
     if (len0 == 0 || len0 > MAXLEN || len0 > MAXN) return false;
     for (uint32_t i = lane; i < len0; i += 64) {
         L->base[i] = (uint8_t)s0[i];
-        L->in_head[i] = L->in_tail[i] = (uint16_t)(i > 0 ? i - 1 : NONE16);
-        L->out_head[i] = L->out_tail[i] = (uint16_t)(i + 1 < len0 ? i : NONE16);
-        L->col_of[i] = (uint16_t)i; L->col_next[i] = (uint16_t)NONE16;
-        L->col_head[i] = L->col_tail[i] = (uint16_t)i;
-        L->order[i] = L->rank[i] = (uint16_t)i;
-        if (i + 1 < len0) { L->e_src[i] = (uint16_t)i; L->e_dst[i] = (uint16_t)(i + 1); L->e_nin[i] = L->e_nout[i] = (uint16_t)NONE16; L->e_sup[i] = 1ull; }
+        L->in_head[i] = L->in_tail[i] = (ix_t)(i > 0 ? i - 1 : NONE16);
+        L->out_head[i] = L->out_tail[i] = (ix_t)(i + 1 < len0 ? i : NONE16);
+        L->col_of[i] = (ix_t)i; L->col_next[i] = (ix_t)NONE16;
+        L->col_head[i] = L->col_tail[i] = (ix_t)i;
+        L->order[i] = L->rank[i] = (ix_t)i;
+        if (i + 1 < len0) { L->e_src[i] = (ix_t)i; L->e_dst[i] = (ix_t)(i + 1); L->e_nin[i] = L->e_nout[i] = (ix_t)NONE16; L->e_sup[i] = (sup_t)1; }
     }
     G.n = len0; G.ne = len0 - 1; G.ncols = len0;
     lds_sync();
     for (uint32_t q = 1; q < J.n_str && !G.fail; ++q) {
         const uint32_t len = str_len[J.first_str + q];
         if (len == 0 || len > MAXLEN) return false;
-        add_string(G, q, pool + str_off[J.first_str + q], len, TS, TF, tab_cap);
+        add_string<C>(G, q, pool + str_off[J.first_str + q], len, T);
     }
     if (G.fail) return false;
     // heaviest path: weight of entering a node over an edge = strings on the edge - half the node's indegree (as uint8); the
@@ -328,26 +382,26 @@ __device__ bool poa_region(const char* pool, const uint32_t* __restrict__ str_of
             const double toll = 0.5 * (double)(uint8_t)indeg;
             for (uint32_t e = e0; e != NONE16; e = uni(L->e_nin[e])) {
                 const uint32_t src = uni(L->e_src[e]);
-                const unsigned long long sup = L->e_sup[e];
-                const double x = L->best_at[src] + (double)__popcll(sup) - toll;
+                const unsigned long long sup = (unsigned long long)L->e_sup[e];
+                const double x = (double)L->best_at[src] + (double)__popcll(sup) - toll;
                 if (x > carried || from == -1) { carried = x; from = (int32_t)src; }
             }
         } else {
             carried = 0;
         }
-        L->best_at[v] = carried;
-        L->came_from[v] = (int16_t)from;
+        L->best_at[v] = (best_t)carried;
+        L->came_from[v] = (path_t)from;
         lds_sync();
         if (carried > top_score) { top_score = carried; top = (int32_t)v; }
     }
     // characters from the end of the path backwards, then turned over; an embedded terminator (a tail node built from the NUL of
     // a candidate) ends the string
     uint32_t m = 0;
-    for (int32_t v = top; v != -1; v = (int16_t)uni((uint32_t)(uint16_t)L->came_from[v])) ++m;
+    for (int32_t v = top; v != -1; v = unis((int32_t)L->came_from[v])) ++m;
     if (m > J.out_cap) return false;
     char* out = out_pool + J.out_off;
     uint32_t k = m;
-    for (int32_t v = top; v != -1; v = (int16_t)uni((uint32_t)(uint16_t)L->came_from[v])) {
+    for (int32_t v = top; v != -1; v = unis((int32_t)L->came_from[v])) {
         --k;
         if (lane == 0) out[k] = (char)L->base[v];
     }
