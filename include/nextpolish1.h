@@ -245,6 +245,9 @@ np1_batch* np1_pipe_resident_batch(np1_pipe* p, int k);
 void np1_pipe_close(np1_pipe* p);
 /* BGZF blocks the device-side ingest of np1_pipe_run_files / _phase_files handed back to the host decoder since the pipe was opened (0 on well-formed files) */
 uint64_t np1_pipe_host_inflated_blocks(np1_pipe* p);
+/* device-side ingest since the pipe was opened (or the last call with reset != 0): out = {BGZF block decoder ms, CRC pass ms, compressed bytes in,
+ * inflated bytes out, launches}, HIP-event times on the lanes' streams summed over the lanes */
+void np1_pipe_ingest_stats(np1_pipe* p, double out[5], int reset);
 /* From files: contigs of the FASTA index (all when names == NULL) are packed in index order into batches of at most
  * batch_bp draft bases; host threads load batch k+1.. (BGZF inflate + record split) while the lanes polish batch k.
  * Every finished contig is handed to `sink` in index order (user, name, sequence, length).  Returns 0 on success. */

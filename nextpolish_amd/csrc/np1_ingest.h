@@ -38,6 +38,8 @@ struct Scratch;   // HBM scratch of one device lane (compressed + inflated bytes
 Scratch* scratch_create();
 void scratch_destroy(Scratch* s);
 uint64_t scratch_host_blocks(const Scratch* s);   // blocks the device decoder handed back to the host so far
+void scratch_stats(const Scratch* s, double out[5]);      // += {decoder ms, CRC ms, compressed bytes in, inflated bytes out, launches} (HIP events)
+void scratch_stats_reset(Scratch* s);
 
 // 0 = staged; 1 = this batch has to take the host loader (index without per-contig offsets); -1 = error (*err set)
 int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, std::string* err);

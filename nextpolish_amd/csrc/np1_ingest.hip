@@ -280,7 +280,13 @@ struct Scratch {
         voff_end, crc_shift, lane_tables;
     std::vector<uint32_t> h_status;
     uint64_t n_host_blocks = 0;
+    // HIP-event times of the block decoder and the CRC pass and the bytes they moved, summed over the batches of this lane (bench.py's
+    // roofline of the from-files leg: np1_pipe_ingest_stats)
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    double inflate_ms = 0, crc_ms = 0;
+    uint64_t comp_bytes = 0, inflated_bytes = 0, launches = 0;
     ~Scratch() {
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
         DevBuf* all[] = {&comp, &inflated, &blocks, &status, &segs, &counts, &rec_base, &first_seg, &small, &scan_tmp, &rec_off, &rec_seg, &keep, &kidx, &ncw,
                          &seqb, &qualb, &cig_at, &seq_at, &qual_at, &geo, &voff, &voff_end, &crc_shift, &lane_tables};
         for (DevBuf* b : all) b->release();
@@ -289,6 +295,11 @@ struct Scratch {
 Scratch* scratch_create() { return new Scratch(); }
 void scratch_destroy(Scratch* s) { delete s; }
 uint64_t scratch_host_blocks(const Scratch* s) { return s ? s->n_host_blocks : 0; }
+void scratch_stats(const Scratch* s, double out[5]) {
+    if (!s) return;
+    out[0] += s->inflate_ms; out[1] += s->crc_ms; out[2] += (double)s->comp_bytes; out[3] += (double)s->inflated_bytes; out[4] += (double)s->launches;
+}
+void scratch_stats_reset(Scratch* s) { if (s) { s->inflate_ms = s->crc_ms = 0; s->comp_bytes = s->inflated_bytes = s->launches = 0; } }
 
 struct HostPin {
     void* p = nullptr;
@@ -558,6 +569,8 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
             if (v > 262144) v = 262144;
             return (uint32_t)((v + 63) / 64 * 64);
         }();
+        for (hipEvent_t& e : W.ev) if (!e) (void)hipEventCreate(&e);
+        (void)hipEventRecord(W.ev[0], q);
         if (mode == 1 || (mode == 0 && n_blocks >= 4096u)) {
             const uint32_t lanes = std::min<uint32_t>((n_blocks + 63u) & ~63u, max_lanes);
             if (W.lane_tables.ensure((size_t)lanes * nplane::LANE_TABLE_WORDS * 4)) return -1;
@@ -565,6 +578,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
                                                        W.lane_tables.as<uint32_t>());
         } else
         k_inflate<<<nblk(n_blocks, 4), 256, 0, q>>>(W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>());
+        (void)hipEventRecord(W.ev[1], q);
         static const bool check_crc = getenv("NP_BGZF_NO_CRC") == nullptr;      // the same switch as the host reader's (np_bgzf.cpp)
         if (check_crc) {
             if (!W.crc_shift.p) {
@@ -576,6 +590,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
             k_crc_check<<<nblk(n_blocks, 4), 256, 0, q>>>(W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(),
                                                          W.crc_shift.as<uint32_t>());
         }
+        (void)hipEventRecord(W.ev[2], q);
         W.h_status.resize(n_blocks);
         HIPCHK(npcopy::d2h(W.h_status.data(), W.status.p, 4 * (size_t)n_blocks, q));
     }
@@ -588,6 +603,12 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
     }
     HIPCHK(hipStreamSynchronize(q));
     if (timing) t_1 = now_ms();
+    if (n_blocks) {
+        float a = 0, c = 0;
+        if (hipEventElapsedTime(&a, W.ev[0], W.ev[1]) == hipSuccess && hipEventElapsedTime(&c, W.ev[1], W.ev[2]) == hipSuccess) {
+            W.inflate_ms += a; W.crc_ms += c; W.comp_bytes += S.comp_bytes; W.inflated_bytes += S.inflated_bytes; ++W.launches;
+        }
+    }
     // blocks the device decoder did not accept: inflate them on the host and patch them in, then redo the count
     bool patched = false;
     for (uint32_t i = 0; i < n_blocks; ++i) {

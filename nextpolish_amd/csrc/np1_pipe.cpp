@@ -172,6 +172,13 @@ int np1_pipe_run_resident(np1_pipe* p, const Configure* cfg, int task, int passe
 // BGZF blocks the device-side ingest handed back to the host since the pipe was opened (a block its decoder does not accept, or one whose
 // CRC it found wrong: the host inflates and checks it again); 0 on well-formed files
 uint64_t np1_pipe_host_inflated_blocks(np1_pipe* p) { return p ? p->host_inflated_blocks : 0; }
+// {block decoder ms, CRC ms, compressed bytes in, inflated bytes out, launches} of the device-side ingest, summed over the lanes, since the
+// pipe was opened or the last reset (HIP events on the lanes' streams)
+void np1_pipe_ingest_stats(np1_pipe* p, double out[5], int reset) {
+    for (int i = 0; i < 5; ++i) out[i] = 0;
+    if (!p) return;
+    for (np1ingest::Scratch* s : p->scratch) { np1ingest::scratch_stats(s, out); if (reset) np1ingest::scratch_stats_reset(s); }
+}
 
 void np1_pipe_close(np1_pipe* p) {
     if (!p) return;

@@ -1661,30 +1661,36 @@ __global__ void k2_bt_place(const BtWalk* walks, uint32_t n_runs, const BtGroupP
 
 
 // ---- pseudo-seeds of the low-quality regions: one resident wave per job slot (np2_poa_dev.h) --------------------------------
-// Jobs come off ONE atomic counter (round 4 dealt them in a fixed stride: a slot that drew the long regions finished last with the others
-// idle).  Two launches: the Small class (graph indices in bytes, score table in LDS, 9 waves a CU) takes every job the host did not rule
-// out; what it gives back (status 1: graph or table outgrew the class) runs in the Big class (table in a slice of HBM scratch); what
-// that gives back goes to the host version.
+// A launch works through a list of job numbers (`order`, longest first) that its waves take off ONE atomic counter (round 4 dealt jobs in a
+// fixed stride: the slot that drew the long regions finished last with the others idle).  Three launches per window: the Small class (graph
+// indices in bytes, score table in LDS, 9 waves a CU) on the jobs the host expects to fit it, at the same time the Big class (table in HBM
+// scratch, the last two rows in LDS) on the rest, then the Big class again on what the Small one gave back (redo_only: status 1); what Big
+// gives back goes to the host version.
 template <class C>
 __global__ __launch_bounds__(64) void k2_poa(const char* __restrict__ pool, const uint32_t* __restrict__ str_off, const uint32_t* __restrict__ str_len,
-                                             const np2poa::Job* __restrict__ jobs, uint32_t n_jobs, int32_t* tabS, uint32_t* tabF, uint32_t tab_cap,
-                                             char* out_pool, uint32_t* out_len, uint32_t* status, uint32_t* queue) {
+                                             const np2poa::Job* __restrict__ jobs, const uint32_t* __restrict__ order, uint32_t n_order, uint32_t redo_only,
+                                             int32_t* tabS, uint32_t* tabF, uint32_t tab_cap, char* out_pool, uint32_t* out_len, uint32_t* status, uint32_t* queue, uint32_t* dbg) {
     __shared__ np2poa::PoaLdsT<C> L;
+    if (dbg) dbg += 4 * blockIdx.x;
     int32_t* TS = C::TAB_LDS ? nullptr : tabS + (size_t)blockIdx.x * tab_cap;
     uint32_t* TF = C::TAB_LDS ? nullptr : tabF + (size_t)blockIdx.x * tab_cap;
     for (;;) {
-        uint32_t j = 0;
-        if (threadIdx.x == 0) j = atomicAdd(queue, 1u);
-        j = np2poa::uni(j);
-        if (j >= n_jobs) break;
+        uint32_t at = 0;
+        if (threadIdx.x == 0) at = atomicAdd(queue, 1u);
+        at = np2poa::uni(at);
+        if (at >= n_order) break;
+        const uint32_t j = order[at];
+        if (dbg && threadIdx.x == 0) { __atomic_store_n(dbg + 2, j, __ATOMIC_RELAXED); __atomic_store_n(dbg, 0u, __ATOMIC_RELAXED); }
         const np2poa::Job J = jobs[j];
-        if (C::TAB_LDS) {      // first launch: every job gets its status here
-            if (!J.small) { if (threadIdx.x == 0) status[j] = 1u; continue; }
-        } else if (status[j] == 0) {
-            continue;          // second launch: done by the first one
-        }
-        const bool ok = np2poa::poa_region<C>(pool, str_off, str_len, J, TS, TF, tab_cap, out_pool, &out_len[j], &L);
-        if (threadIdx.x == 0) status[j] = ok ? 0u : 1u;
+        // Every path through the body ends in the same lane-0 store + wave barrier: a `continue` behind a store of lane 0 alone let the
+        // compiler run the other 63 lanes ahead into the next iteration, where readfirstlane then broadcast THEIR counter value (0)
+        // instead of lane 0's fresh one -- an endless loop (round 5, found with NP2_POA_DEBUG; the wave-uniform idiom needs the wave to
+        // reconverge before the back edge).
+        const bool run = redo_only ? status[j] != 0 : true;
+        bool ok = false;
+        if (run) ok = np2poa::poa_region<C>(pool, str_off, str_len, J, TS, TF, tab_cap, out_pool, &out_len[j], &L, dbg);
+        if (threadIdx.x == 0 && run) status[j] = ok ? 0u : 1u;
+        if (dbg && threadIdx.x == 0) __atomic_store_n(dbg, ok ? 100u : 101u, __ATOMIC_RELAXED);
         np2poa::lds_sync();
     }
 }
@@ -1898,7 +1904,13 @@ int pick_device(std::string* err) {
 class HipExec : public Exec {
   public:
     explicit HipExec(int device) : device_(device) {}
-    ~HipExec() override { if (stream_) (void)hipStreamDestroy(stream_); }
+    ~HipExec() override {
+        if (stream_) (void)hipStreamSynchronize(stream_);
+        if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }
+        if (ev_up_) (void)hipEventDestroy(ev_up_);
+        if (ev_big_) (void)hipEventDestroy(ev_big_);
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
     bool init(std::string* err) {
         HIPOK(hipSetDevice(device_));
         // workers share the host cores of a GPU (the reference's -p model): waiting for the GPU must not spin on one
@@ -1938,7 +1950,9 @@ class HipExec : public Exec {
         coloff_, cursor_, sums_, obs_, entries_, nodes_, colnn_, res_, cons_, strpool_, stroff_, strlen_, flag_, tchunks_, tckpt_, tchoff_, chunks_, chcnt_, chpre_, sums2_, cutflag_, cutpos_, cuts_, eav_, runt_, grpt_, grpx_, grpn_, btwalk_, btpick_, btgrp_, btgpick_;
     DevBuf runsz_, runoff_, live_, ematch_, xreq_, xfirst_, xlen_, xoff_, xout_, obscol_, obsaux_, grpt2_, grpx2_, grpn2_, covdiff_, covpre_;
     DevBuf tilecnt_, tileoff_, tilecur_, tilelist_, tilectr_, ntags_, colne_, runflag_, runlist_, runctr_, tileredo_;
-    DevBuf poapool_, poaoff_, poalen_, poajobs_, poatabs_, poatabf_, poaout_, poaolen_, poastat_, trig_;
+    DevBuf poapool_, poaoff_, poalen_, poajobs_, poatabs_, poatabf_, poaout_, poaolen_, poastat_, poadbg_, poaord_, trig_;
+    hipStream_t stream2_ = nullptr;      // the Big class of the pseudo-seed jobs runs beside the Small one (run_poa)
+    hipEvent_t ev_up_ = nullptr, ev_big_ = nullptr;
     bool graph_compact_ = false;   // the graph in HBM was built by tiles: columns are contiguous, every entry slot is live
     DevBuf ondpool_, ondregs_, ondcoff_, ondclen_, ondpairof_, ondpairs_, ondres_, ondout_, ondv_, ondlo_, ondch_, ondplen_, ondpkind_, ondppos_, ondtot_;
     PinBuf pin_;
@@ -2667,36 +2681,98 @@ bool HipExec::run_poa(const PoaBatch& in, std::vector<std::string>* out, std::st
     std::string obuf;
     if (!host_only) {
         uint64_t out_total = 0;
-        static const bool no_small = getenv("NP2_POA_BIG_ONLY") != nullptr;      // test hook: every job in the first version's class
-        uint32_t n_small = 0;
+        static const bool no_small = getenv("NP2_POA_BIG_ONLY") != nullptr;      // test hooks: every job in the first version's class /
+        static const bool small_only = getenv("NP2_POA_SMALL_ONLY") != nullptr;  // what the Small class gives back goes straight to the host version
+        std::vector<std::pair<uint64_t, uint32_t>> list_small, list_big;          // (work, job): longest first
         for (uint32_t j = 0; j < n_jobs; ++j) {
-            uint32_t cap = 0;
-            for (uint32_t k = 0; k < in.job_n[j]; ++k) cap += in.str_len[in.job_first[j] + k] + 1;
-            uint32_t longest = 0;
-            for (uint32_t k = 0; k < in.job_n[j]; ++k) longest = std::max(longest, in.str_len[in.job_first[j] + k]);
-            const bool small = !no_small && in.job_n[j] <= np2poa::Small::MAXSTR && longest <= np2poa::Small::MAXLEN;
+            uint32_t cap = 0, longest = 0;
+            for (uint32_t k = 0; k < in.job_n[j]; ++k) { const uint32_t l = in.str_len[in.job_first[j] + k]; cap += l + 1; longest = std::max(longest, l); }
+            // the Small class holds 3072 table cells: (nodes + 1) x (length + 1), and a graph of six ~L-character candidates ends with ~1.4 L
+            // nodes (measured on the test windows: 6 x 50 characters -> 70 nodes).  A job expected not to fit starts in the Big class at once
+            // instead of after the Small one has given it back.
+            const bool small = !no_small && in.job_n[j] <= np2poa::Small::MAXSTR && longest <= np2poa::Small::MAXLEN &&
+                               (uint64_t)(longest * 3 / 2 + 2) * (longest + 1) <= np2poa::Small::TAB_LDS;
             jobs[j] = np2poa::Job{in.job_first[j], in.job_n[j], out_total, cap, small ? 1u : 0u};
-            n_small += small;
+            (small ? list_small : list_big).emplace_back((uint64_t)cap * (longest + 1), j);
             out_total += cap;
         }
-        const uint32_t slots = std::min<uint32_t>(n_jobs, 1792u);        // resident waves (7 per CU by their LDS), each with its slice of table scratch
-        constexpr uint32_t TAB_CAP = 1u << 16;          // cells of score table per resident wave (rows x columns)
+        std::vector<uint32_t> order;
+        for (auto* l : {&list_small, &list_big}) {
+            std::sort(l->begin(), l->end(), [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+            for (auto& e : *l) order.push_back(e.second);
+        }
+        const uint32_t n_small = (uint32_t)list_small.size(), n_big = (uint32_t)list_big.size();
+        const uint32_t slots = std::min<uint32_t>(std::max<uint32_t>(n_big, std::min<uint32_t>(n_small, 256u)), 1792u);   // resident Big waves (7 per CU by their LDS), each with its slice of table scratch
+        constexpr uint32_t TAB_CAP = 1u << 16;          // cells of score table per resident Big wave (rows x columns)
         if (!poapool_.ensure(in.chars.size() + 64) || !poaoff_.ensure(4ull * n_str + 64) || !poalen_.ensure(4ull * n_str + 64) ||
             !poajobs_.ensure(sizeof(np2poa::Job) * (size_t)n_jobs + 64) || !poatabs_.ensure(4ull * TAB_CAP * slots + 64) ||
             !poatabf_.ensure(4ull * TAB_CAP * slots + 64) || !poaout_.ensure(out_total + 64) || !poaolen_.ensure(4ull * n_jobs + 64) ||
-            !poastat_.ensure(4ull * n_jobs + 64 + 64)) { *err = "out of device memory (pseudo-seeds)"; return false; }
-        uint32_t* queue = poastat_.as<uint32_t>() + n_jobs + 4;      // two job counters behind the status words
-        HIPOK(hipMemsetAsync(queue, 0, 8, q));
+            !poastat_.ensure(4ull * n_jobs + 64 + 64) || !poaord_.ensure(4ull * n_jobs + 64)) { *err = "out of device memory (pseudo-seeds)"; return false; }
+        uint32_t* queue = poastat_.as<uint32_t>() + n_jobs + 4;      // three job counters behind the status words
+        if (!stream2_) { HIPOK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking)); HIPOK(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming)); HIPOK(hipEventCreateWithFlags(&ev_big_, hipEventDisableTiming)); }
+        HIPOK(hipMemsetAsync(queue, 0, 12, q));
+        HIPOK(hipMemsetAsync(poastat_.p, 0xff, 4ull * n_jobs, q));      // (a job no launch reaches reads as "not done")
         HIPOK(npcopy::h2d(poapool_.p, in.chars.data(), in.chars.size(), q));
         HIPOK(npcopy::h2d(poaoff_.p, in.str_off.data(), 4ull * n_str, q));
         HIPOK(npcopy::h2d(poalen_.p, in.str_len.data(), 4ull * n_str, q));
         HIPOK(npcopy::h2d(poajobs_.p, jobs.data(), sizeof(np2poa::Job) * (size_t)n_jobs, q));
-        const uint32_t small_slots = std::min<uint32_t>(n_jobs, 256u * 9u);      // 16.9 KB of LDS a wave: 9 a CU
-        k2_poa<np2poa::Small><<<small_slots, 64, 0, q>>>(poapool_.as<char>(), poaoff_.as<uint32_t>(), poalen_.as<uint32_t>(), poajobs_.as<np2poa::Job>(), n_jobs, nullptr,
-                                                         nullptr, 0u, poaout_.as<char>(), poaolen_.as<uint32_t>(), poastat_.as<uint32_t>(), queue);
-        k2_poa<np2poa::Big><<<slots, 64, 0, q>>>(poapool_.as<char>(), poaoff_.as<uint32_t>(), poalen_.as<uint32_t>(), poajobs_.as<np2poa::Job>(), n_jobs, poatabs_.as<int32_t>(),
-                                                 poatabf_.as<uint32_t>(), TAB_CAP, poaout_.as<char>(), poaolen_.as<uint32_t>(), poastat_.as<uint32_t>(), queue + 1);
+        HIPOK(npcopy::h2d(poaord_.p, order.data(), 4ull * n_jobs, q));
+        HIPOK(hipEventRecord(ev_up_, q));
+        const uint32_t small_slots = std::min<uint32_t>(std::max<uint32_t>(n_small, 1u), 256u * 9u);      // 16.9 KB of LDS a wave: 9 a CU
+        // NP2_POA_DEBUG=1: every wave keeps {stage, counter, job} in a device array the host reads over another stream when the kernels have
+        // not finished after five seconds (how round 5 found where a wave was spinning)
+        static const bool debug = getenv("NP2_POA_DEBUG") != nullptr;
+        uint32_t *dbg_small = nullptr, *dbg_big = nullptr;
+        if (debug) {
+            if (!poadbg_.ensure(16ull * (small_slots + slots) + 64)) { *err = "out of device memory (pseudo-seed debug)"; return false; }
+            HIPOK(hipMemsetAsync(poadbg_.p, 0xff, 16ull * (small_slots + slots), q));
+            HIPOK(hipEventRecord(ev_up_, q));
+            dbg_small = poadbg_.as<uint32_t>();
+            dbg_big = dbg_small + 4 * small_slots;
+        }
+        const uint32_t* ord = poaord_.as<uint32_t>();
+        if (n_big) {      // the jobs that start in the Big class, on the second stream, while the Small class works on the others
+            HIPOK(hipStreamWaitEvent(stream2_, ev_up_, 0));
+            k2_poa<np2poa::Big><<<std::min<uint32_t>(n_big, slots), 64, 0, stream2_>>>(poapool_.as<char>(), poaoff_.as<uint32_t>(), poalen_.as<uint32_t>(), poajobs_.as<np2poa::Job>(), ord + n_small,
+                                                                                       n_big, 0u, poatabs_.as<int32_t>(), poatabf_.as<uint32_t>(), TAB_CAP, poaout_.as<char>(),
+                                                                                       poaolen_.as<uint32_t>(), poastat_.as<uint32_t>(), queue + 1, dbg_big);
+            HIPOK(hipEventRecord(ev_big_, stream2_));
+        }
+        if (n_small)
+            k2_poa<np2poa::Small><<<small_slots, 64, 0, q>>>(poapool_.as<char>(), poaoff_.as<uint32_t>(), poalen_.as<uint32_t>(), poajobs_.as<np2poa::Job>(), ord, n_small, 0u, nullptr,
+                                                             nullptr, 0u, poaout_.as<char>(), poaolen_.as<uint32_t>(), poastat_.as<uint32_t>(), queue, dbg_small);
+        if (n_big) HIPOK(hipStreamWaitEvent(q, ev_big_, 0));      // (the third launch reuses the Big slots' table scratch)
+        if (n_small && !small_only)
+            k2_poa<np2poa::Big><<<std::min<uint32_t>(n_small, slots), 64, 0, q>>>(poapool_.as<char>(), poaoff_.as<uint32_t>(), poalen_.as<uint32_t>(), poajobs_.as<np2poa::Job>(), ord, n_small, 1u,
+                                                                                  poatabs_.as<int32_t>(), poatabf_.as<uint32_t>(), TAB_CAP, poaout_.as<char>(), poaolen_.as<uint32_t>(),
+                                                                                  poastat_.as<uint32_t>(), queue + 2, dbg_big);
         if (getenv("NP2_TIMING")) fprintf(stderr, "[np2 poa] %u jobs, %u of them offered to the Small class\n", n_jobs, n_small);
+        if (debug) {
+            timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (;;) {
+                if (hipStreamQuery(q) == hipSuccess) break;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 5.0) {
+                    hipStream_t q3;
+                    std::vector<uint32_t> h(4 * (size_t)(small_slots + slots));
+                    if (hipStreamCreateWithFlags(&q3, hipStreamNonBlocking) == hipSuccess && hipMemcpyAsync(h.data(), poadbg_.p, 4 * h.size(), hipMemcpyDeviceToHost, q3) == hipSuccess &&
+                        hipStreamSynchronize(q3) == hipSuccess) {
+                        for (uint32_t b = 0; b < small_slots + slots; ++b) {
+                            const uint32_t* w = &h[4 * (size_t)b];
+                            if (w[0] == 0xffffffffu || w[0] == 100u || w[0] == 101u) continue;
+                            const uint32_t j = w[2];
+                            fprintf(stderr, "[np2 poa debug] %s wave %u: stage %u counter %#x job %u", b < small_slots ? "Small" : "Big", b < small_slots ? b : b - small_slots, w[0], w[1], j);
+                            if (j < n_jobs) { fprintf(stderr, " strings:"); for (uint32_t k = 0; k < in.job_n[j]; ++k) fprintf(stderr, " %u", in.str_len[in.job_first[j] + k]); }
+                            fprintf(stderr, "\n");
+                        }
+                    }
+                    fprintf(stderr, "[np2 poa debug] the pseudo-seed kernels did not finish within 5 s\n");
+                    _exit(3);
+                }
+                usleep(1000);
+            }
+        }
         obuf.resize(out_total);
         HIPOK(npcopy::d2h(&obuf[0], poaout_.p, out_total, q));
         HIPOK(npcopy::d2h(olen.data(), poaolen_.p, 4ull * n_jobs, q));

@@ -15,7 +15,9 @@
 // The score table (rows x columns, 8 bytes a cell) lives in a slice of HBM scratch owned by the resident wave.
 // A region whose graph does not fit the LDS arrays is flagged and done by the host version.
 #pragma once
+#ifndef NP2_POA_HOST_EMU      // tests/model/np2_poa_emu.cpp runs this header on 64 host threads in lockstep and supplies the wave intrinsics itself
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace np2poa {
@@ -56,11 +58,17 @@ template <class C> struct PoaLdsT {
     typename C::path_t came_from[C::MAXN];
     typename C::ts_t ts[C::TAB_LDS ? C::TAB_LDS : 1];      // Small: the score table and its back pointers
     typename C::tf_t tf[C::TAB_LDS ? C::TAB_LDS : 1];
+    // Big: the scores of the last two rows.  Graphs are mostly chains, so the row a new row reads is nearly always the one just made: it is
+    // read here, and the wave waits for its stores to HBM only when a row further back is needed (and once before walking back)
+    int32_t prev[2][C::TAB_LDS ? 1 : C::MAXLEN + 2];
 };
 using PoaLds = PoaLdsT<Big>;
 
 struct Job { uint32_t first_str, n_str; unsigned long long out_off; uint32_t out_cap, small; };      // small: 1 = the host found nothing that rules the Small class out
 
+// wave-uniform broadcast of a value every lane has just read from LDS (one scalar copy instead of 64).  EVERY read of wave-uniform LDS
+// state goes through uni() / unis(), and always from wave-uniform control flow: that is what lets the host emulation
+// (tests/model/np2_poa_emu.cpp) keep its 64 threads in step -- there it is a barrier behind the read.
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
@@ -183,6 +191,10 @@ template <class C> struct Table {
     int32_t* TS;
     uint32_t* TF;
     uint32_t cap;
+    uint32_t* dbg;      // debugging (NP2_POA_DEBUG): where this wave is -- {stage, counter} -- readable from the host while the kernel runs
+    __device__ __forceinline__ void mark(uint32_t stage, uint32_t v) const {
+        if (dbg && __lane_id() == 0) { __atomic_store_n(dbg, stage, __ATOMIC_RELAXED); __atomic_store_n(dbg + 1, v, __ATOMIC_RELAXED); }
+    }
     __device__ __forceinline__ uint32_t capacity() const { if constexpr (C::TAB_LDS > 0) return C::TAB_LDS; else return cap; }
     __device__ __forceinline__ int32_t score(uint32_t i) const { if constexpr (C::TAB_LDS > 0) return (int32_t)L->ts[i]; else return TS[i]; }
     __device__ __forceinline__ uint32_t from(uint32_t i) const { if constexpr (C::TAB_LDS > 0) return (uint32_t)L->tf[i]; else return TF[i]; }
@@ -204,46 +216,80 @@ template <class C> __device__ void add_string(Graph<C>& G, uint32_t q, const cha
     const uint32_t lane = __lane_id();
     const uint32_t n = G.n, width = len + 1;
     if ((unsigned long long)(n + 1) * width > T.capacity()) { G.fail = true; return; }
-    for (uint32_t c = lane; c < width; c += 64) T.set(c, (int32_t)c * W_GAP, 0u);
-    T.sync();
+    constexpr bool BIGC = C::TAB_LDS == 0;
+    for (uint32_t c = lane; c < width; c += 64) {
+        T.set(c, (int32_t)c * W_GAP, 0u);
+        if constexpr (BIGC) L->prev[0][c] = (int32_t)c * W_GAP;
+    }
+    if constexpr (BIGC) lds_sync(); else T.sync();
     // rows in emission order
     for (uint32_t r = 0; r < n; ++r) {
+        T.mark(3, q << 16 | r);
         const uint32_t v = uni(L->order[r]);
         const char vb = (char)uni(L->base[v]);
         const uint32_t row = r + 1;
         const uint32_t R0 = row * width;
-        // left border: the best predecessor's border value plus a gap (sources start from 0)
         const uint32_t e0 = uni(L->in_head[v]);
-        int32_t border = 0;
-        {
-            bool any = false;
-            for (uint32_t e = e0; e != NONE16; e = uni(L->e_nin[e])) {
-                const uint32_t pr = uni(L->rank[uni(L->e_src[e])]) + 1u;
-                const int32_t x = unis(T.score(pr * width));
-                if (!any || x > border) { border = x; any = true; }
-            }
-            border += W_GAP;
+        // The rows this row reads (its predecessors' rows; a source reads row 0), found ONCE per row and kept in scalars -- the border,
+        // the "anything but the row just made?" test and every 64-column chunk below go over them (round 5: each of those walked the edge
+        // list through LDS again, three dependent reads per edge and chunk).  More than four predecessors: the walk is repeated as before.
+        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, n_pred = 0;
+        if (e0 == NONE16) { n_pred = 1; }
+        else for (uint32_t e = e0; e != NONE16; e = uni(L->e_nin[e])) {
+            const uint32_t pr = uni(L->rank[uni(L->e_src[e])]) + 1u;
+            if (n_pred == 0) p0 = pr; else if (n_pred == 1) p1 = pr; else if (n_pred == 2) p2 = pr; else if (n_pred == 3) p3 = pr;
+            ++n_pred;
         }
-        if (lane == 0) T.set(R0, border, 0u);
+        auto for_each_pred = [&](auto&& f) {
+            if (n_pred <= 4) {
+                f(p0);
+                if (n_pred > 1) f(p1);
+                if (n_pred > 2) f(p2);
+                if (n_pred > 3) f(p3);
+            } else {
+                for (uint32_t e = e0; e != NONE16; e = uni(L->e_nin[e])) f(uni(L->rank[uni(L->e_src[e])]) + 1u);
+            }
+        };
+        if constexpr (BIGC) {      // does this row read anything but the row just made?  then the earlier rows' stores have to have landed
+            bool far = false;
+            for_each_pred([&](uint32_t pr) { if (pr != row - 1u) far = true; });
+            if (far) glb_sync();
+        }
+        auto rd = [&](uint32_t pr, uint32_t col) -> int32_t {      // (pr is wave-uniform)
+            if constexpr (BIGC) { if (pr == row - 1u) return L->prev[(row - 1u) & 1u][col]; }
+            return T.score(pr * width + col);
+        };
+        // left border: the best predecessor's border value plus a gap (sources start from 0)
+        int32_t border = 0;
+        if (e0 != NONE16) {
+            bool any = false;
+            for_each_pred([&](uint32_t pr) {
+                const int32_t x = unis(rd(pr, 0));
+                if (!any || x > border) { border = x; any = true; }
+            });
+        }
+        border += W_GAP;
+        if (lane == 0) {
+            T.set(R0, border, 0u);
+            if constexpr (BIGC) L->prev[row & 1u][0] = border;
+        }
         int32_t run = border;                     // max over k < j of (H(k) + 2 k) = of A(k); A(0) = H(0)
         for (uint32_t cb = 0; cb < len; cb += 64) {
             const uint32_t c = cb + lane;         // string position; the cell is column j = c + 1
             const bool valid = c < len;
             int32_t O = INT32_MIN;
             uint32_t F = 0;
-            if (valid) {
-                const int32_t w = s[c] == vb ? W_MATCH : W_MISMATCH;
+            {
+                const int32_t w = (valid && s[c] == vb) ? W_MATCH : W_MISMATCH;
                 bool first = true;
-                auto offer = [&](uint32_t pr) {
-                    const uint32_t P0 = pr * width;
-                    const int32_t skip = T.score(P0 + c + 1) + W_GAP, pair = T.score(P0 + c) + w;
+                for_each_pred([&](uint32_t pr) {
+                    if (!valid) return;
+                    const int32_t skip = rd(pr, c + 1) + W_GAP, pair = rd(pr, c) + w;
                     const bool sk = skip >= pair;
                     const int32_t cand = sk ? skip : pair;
                     if (first || cand > O) { O = cand; F = pr << FS | (c + (sk ? 1u : 0u)); }
                     first = false;
-                };
-                if (e0 == NONE16) offer(0);
-                for (uint32_t e = e0; e != NONE16; e = uni(L->e_nin[e])) offer(uni(L->rank[uni(L->e_src[e])]) + 1u);
+                });
             }
             const int32_t j = (int32_t)c + 1;
             const int32_t A = valid ? O - W_GAP * j : INT32_MIN;
@@ -255,12 +301,14 @@ template <class C> __device__ void add_string(Graph<C>& G, uint32_t q, const cha
                 const bool take = A > exc;
                 const int32_t M = take ? A : exc;
                 T.set(R0 + (uint32_t)j, M + W_GAP * j, take ? F : (row << FS | (uint32_t)(j - 1)));
+                if constexpr (BIGC) L->prev[row & 1u][j] = M + W_GAP * j;
             }
             const int32_t last = __shfl(inc, 63, 64);      // invalid lanes carry INT32_MIN: the maximum of the valid ones
             if (last > run) run = last;
         }
-        T.sync();
+        if constexpr (BIGC) lds_sync(); else T.sync();
     }
+    if constexpr (BIGC) glb_sync();      // the sinks' last cells and the back pointers are read from HBM below
     // the alignment ends in a sink: the first one in order with the best full-length score
     uint32_t row = 0;
     {
@@ -280,6 +328,7 @@ template <class C> __device__ void add_string(Graph<C>& G, uint32_t q, const cha
     uint32_t np = 0;
     int32_t lowest_chr = -1, highest_chr = -1;
     for (uint32_t col = len; row != 0 || col != 0;) {
+        T.mark(4, row << 16 | col);
         const uint32_t from = uni(T.from(row * width + col));
         const uint32_t from_row = from >> FS, from_col = from & FMASK;
         int32_t node = -1, chr = -1;
@@ -304,6 +353,7 @@ template <class C> __device__ void add_string(Graph<C>& G, uint32_t q, const cha
     if (highest_chr < (int32_t)len - 1)                                                         // and behind the last one (the run takes the
         G.chain(q, s + highest_chr + 1, (uint32_t)((int32_t)len - highest_chr), &tail_first, &cur);   // terminator along, like the reference)
     for (uint32_t k = np; k-- > 0 && !G.fail;) {
+        T.mark(5, q << 16 | k);
         const int32_t chr = unis((int32_t)L->path_chr[k]);
         if (chr == -1) continue;
         const int32_t node = unis((int32_t)L->path_node[k]);
@@ -332,12 +382,14 @@ template <class C> __device__ void add_string(Graph<C>& G, uint32_t q, const cha
         if (first == -1) first = prev;
     }
     if (tail_first != -1 && !G.fail) G.connect((uint32_t)prev, (uint32_t)tail_first, q);
+    T.mark(6, q << 16 | G.n);
     if (!G.fail) G.reorder();
+    T.mark(7, q);
 }
 
 // the whole job: strings of one region -> consensus characters; returns false when the region has to go to the host version
 template <class C> __device__ bool poa_region(const char* pool, const uint32_t* __restrict__ str_off, const uint32_t* __restrict__ str_len, const Job& J, int32_t* TS, uint32_t* TF,
-                                              uint32_t tab_cap, char* out_pool, uint32_t* out_len, PoaLdsT<C>* L) {
+                                              uint32_t tab_cap, char* out_pool, uint32_t* out_len, PoaLdsT<C>* L, uint32_t* dbg = nullptr) {
     constexpr uint32_t NONE16 = C::NONE, MAXLEN = C::MAXLEN, MAXN = C::MAXN;
     using ix_t = typename C::ix;
     using path_t = typename C::path_t;
@@ -346,7 +398,8 @@ template <class C> __device__ bool poa_region(const char* pool, const uint32_t* 
     const uint32_t lane = __lane_id();
     if (J.n_str > C::MAXSTR) return false;
     Graph<C> G{L, 0u, 0u, 0u, false};
-    const Table<C> T{L, TS, TF, tab_cap};
+    const Table<C> T{L, TS, TF, tab_cap, dbg};
+    T.mark(1, J.first_str);
     // the first string is the graph: a chain, every node a group of its own, emission order = string order
     const uint32_t len0 = str_len[J.first_str];
     const char* s0 = pool + str_off[J.first_str];
@@ -373,6 +426,7 @@ template <class C> __device__ bool poa_region(const char* pool, const uint32_t* 
     int32_t top = -1;
     double carried = -1, top_score = -1;
     for (uint32_t r = 0; r < G.n; ++r) {
+        T.mark(8, r);
         const uint32_t v = uni(L->order[r]);
         int32_t from = -1;
         const uint32_t e0 = uni(L->in_head[v]);
@@ -397,7 +451,9 @@ template <class C> __device__ bool poa_region(const char* pool, const uint32_t* 
     // characters from the end of the path backwards, then turned over; an embedded terminator (a tail node built from the NUL of
     // a candidate) ends the string
     uint32_t m = 0;
+    T.mark(9, (uint32_t)top);
     for (int32_t v = top; v != -1; v = unis((int32_t)L->came_from[v])) ++m;
+    T.mark(10, m);
     if (m > J.out_cap) return false;
     char* out = out_pool + J.out_off;
     uint32_t k = m;
@@ -412,6 +468,7 @@ template <class C> __device__ bool poa_region(const char* pool, const uint32_t* 
         if (nul) { z = cb + (uint32_t)__ffsll((long long)nul) - 1u; break; }
     }
     if (lane == 0) *out_len = z;
+    T.mark(11, z);
     return true;
 }
 

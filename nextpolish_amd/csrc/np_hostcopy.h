@@ -56,6 +56,25 @@ public:
         if (out->pending) { (void)hipEventSynchronize(out->ev); out->pending = false; }
         return true;
     }
+    // a slot only if one can be had without waiting for another thread to give one back (a thread that already holds a slot must not
+    // block here: with as many such threads as slots nobody could ever release)
+    bool try_acquire(Slot* out) {
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            if (made_ < kSlots && (free_.empty() || free_.front().pending)) {
+                Slot s;
+                if (npalloc::host_malloc(&s.p, kSlotBytes, hipHostMallocPortable) == hipSuccess) {
+                    if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) == hipSuccess) { ++made_; *out = s; return true; }
+                    (void)npalloc::host_free(s.p);
+                }
+            }
+            if (free_.empty()) return false;
+            *out = free_.front();
+            free_.pop_front();
+        }
+        if (out->pending) { (void)hipEventSynchronize(out->ev); out->pending = false; }
+        return true;
+    }
     void release(const Slot& s) {
         { std::lock_guard<std::mutex> g(mu_); free_.push_back(s); }
         cv_.notify_one();
@@ -113,8 +132,11 @@ inline hipError_t d2h(void* dst, const void* src, size_t bytes, hipStream_t q) {
         if (off < bytes && err == hipSuccess) {
             nxt_n = bytes - off < kSlotBytes ? bytes - off : kSlotBytes;
             nxt_off = off;
-            if (!R.acquire(&nxt)) { err = hipErrorOutOfMemory; }
-            else {
+            // the first slot may be waited for; a second one (to overlap the memcpy out of the first with the next DMA) only if it is free
+            const bool got = have_cur ? R.try_acquire(&nxt) : R.acquire(&nxt);
+            if (!got) {
+                if (!have_cur) err = hipErrorOutOfMemory;
+            } else {
                 hipError_t e = hipMemcpyAsync(nxt.p, static_cast<const char*>(src) + off, nxt_n, hipMemcpyDeviceToHost, q);
                 if (e == hipSuccess) e = hipEventRecord(nxt.ev, q);
                 if (e != hipSuccess) { (void)hipStreamSynchronize(q); R.release(nxt); err = e; }

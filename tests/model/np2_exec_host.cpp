@@ -1,6 +1,7 @@
 // Host lockstep executor of the long-read window pipeline -- TEST INFRASTRUCTURE (tests/model): runs the same
 // per-lane bodies the HIP kernels compile (nextpolish_amd/csrc/np2_core.h) in plain loops, so the algorithm can be
 // validated against the compiled reference on the CPU.  Never linked into the product library.
+#include <cstdio>
 #include <algorithm>
 #include <cstring>
 
@@ -227,11 +228,17 @@ class HostExec : public Exec {
         (void)err;
         out->assign(in.job_first.size(), std::string());
         std::vector<std::string> v;
+        FILE* dump = getenv("NP2_POA_DUMP") ? fopen(getenv("NP2_POA_DUMP"), "a") : nullptr;      // test hook: the jobs as text, one line each (tab-separated strings)
         for (size_t j = 0; j < in.job_first.size(); ++j) {
             v.clear();
             for (uint32_t k = 0; k < in.job_n[j]; ++k) v.emplace_back(in.chars.data() + in.str_off[in.job_first[j] + k], in.str_len[in.job_first[j] + k]);
             (*out)[j] = poa_consensus(v);
+            if (dump) {
+                for (size_t k = 0; k < v.size(); ++k) fprintf(dump, "%s%s", k ? "\t" : "", v[k].c_str());
+                fprintf(dump, "\n");
+            }
         }
+        if (dump) fclose(dump);
         return true;
     }
     bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) override {
