@@ -5,6 +5,8 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <cstdlib>
+#include <new>
 #include <vector>
 
 #include "np2_core.h"
@@ -18,13 +20,42 @@ struct ConsBase {   // consensus_base, ctg_cns.h:103-107
 };
 
 // alignment records handed to the executor: BAM core fields of the path (position, CIGAR, packed bases)
+// Storage of the two big host arrays that cross PCIe with every window (CIGAR operations and packed bases: ~170 MB of a 5 Mb / 20x
+// window).  It comes from a pair of hooks so that the HIP executor can make it page-locked memory of its own (np2_exec_hip.hip,
+// NP2_PINNED_RECORDS=1): np_hostcopy.h then lets the DMA engine read the arrays where they are, instead of copying them through its pinned
+// ring first (measured: no gain on the long-read leg, so it is opt-in).  Default and host model: malloc.  A block remembers what it was made by.
+struct BigMem {
+    static void* (*make)(size_t bytes);      // returns page-locked memory or nullptr
+    static void (*drop)(void* p);
+};
+template <class T> struct BigAlloc {
+    using value_type = T;
+    BigAlloc() = default;
+    template <class U> BigAlloc(const BigAlloc<U>&) {}
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T) + 64;
+        char* p = BigMem::make ? static_cast<char*>(BigMem::make(bytes)) : nullptr;
+        const bool hooked = p != nullptr;
+        if (!p) p = static_cast<char*>(malloc(bytes));
+        if (!p) throw std::bad_alloc();
+        p[0] = hooked ? 1 : 0;
+        return reinterpret_cast<T*>(p + 64);
+    }
+    void deallocate(T* q, size_t) {
+        char* p = reinterpret_cast<char*>(q) - 64;
+        if (p[0]) BigMem::drop(p); else free(p);
+    }
+    template <class U> bool operator==(const BigAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const BigAlloc<U>&) const { return false; }
+};
+
 struct RecordSet {
     std::vector<int32_t> pos;
     std::vector<uint32_t> n_cigar;
     std::vector<uint32_t> q0;           // leading clip length = query coordinate of the first aligned base
     std::vector<uint64_t> cigar_off, seq_off;
-    std::vector<uint32_t> cigar;
-    std::vector<uint8_t> seq;
+    std::vector<uint32_t, BigAlloc<uint32_t>> cigar;
+    std::vector<uint8_t, BigAlloc<uint8_t>> seq;
     size_t size() const { return pos.size(); }
     void clear() { pos.clear(); n_cigar.clear(); q0.clear(); cigar_off.clear(); seq_off.clear(); cigar.clear(); seq.clear(); }
     void add(int32_t p, const uint32_t* cg, uint32_t nc, const uint8_t* sq, size_t seq_bytes, uint32_t q_start) {

@@ -2812,6 +2812,23 @@ bool HipExec::run_poa(const PoaBatch& in, std::vector<std::string>* out, std::st
 
 }  // namespace
 
+// NP2_PINNED_RECORDS=1: the big record arrays of the pipeline live in page-locked memory of this library (np2_exec.h: BigMem), installed
+// when the library is loaded, before the first window builds them; np_hostcopy.h then copies them with no host-side staging.  Opt-in:
+// measured on the long-read leg (24 workers x 12 calls of a 5 Mb window, tests/tools/r4_lgs_quick.py) 157.4 Mbp/s and 0.0859 host CPU-s per
+// Mbp with it against 159.2 and 0.0867 through the ring -- the staging copy is not what the leg's host time is made of.
+static void* big_make(size_t bytes) {
+    std::string e;
+    const int d = pick_device(&e);
+    if (d < 0 || hipSetDevice(d) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (npalloc::host_malloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
+    return p;
+}
+static void big_drop(void* p) { (void)npalloc::host_free(p); }
+static struct BigMemInstall {
+    BigMemInstall() { if (getenv("NP2_PINNED_RECORDS")) { BigMem::make = big_make; BigMem::drop = big_drop; } }
+} g_big_mem_install;
+
 Exec* make_exec(std::string* err) {
     const int d = pick_device(err);
     if (d < 0) return nullptr;

@@ -29,6 +29,10 @@
 #include "np2_sv.h"
 #include "np_bam.h"
 
+// storage hooks of the big record arrays (np2_exec.h): malloc unless an executor installs its own
+void* (*np2::BigMem::make)(size_t) = nullptr;
+void (*np2::BigMem::drop)(void*) = nullptr;
+
 namespace {
 
 thread_local std::string g_err;
