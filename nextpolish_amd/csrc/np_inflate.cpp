@@ -499,13 +499,18 @@ __attribute__((always_inline)) inline bool inflate_body(const uint8_t* src, size
 }
 
 bool inflate_plain(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len) { return inflate_body(src, src_len, dst, dst_len); }
+#if defined(__x86_64__)      // (the second build and its run-time dispatch exist on x86 only: ADVICE r4)
 __attribute__((target("bmi,bmi2"))) bool inflate_bmi2(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len) { return inflate_body(src, src_len, dst, dst_len); }
+#endif
 
 }  // namespace
 
 bool inflate_raw(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len) {
+#if defined(__x86_64__)
     static const bool bmi2 = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi") && !getenv("NP_INFLATE_PLAIN");   // (the variable: the tests run both builds)
-    return bmi2 ? inflate_bmi2(src, src_len, dst, dst_len) : inflate_plain(src, src_len, dst, dst_len);
+    if (bmi2) return inflate_bmi2(src, src_len, dst, dst_len);
+#endif
+    return inflate_plain(src, src_len, dst, dst_len);
 }
 
 }  // namespace np
