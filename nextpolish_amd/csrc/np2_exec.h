@@ -145,6 +145,7 @@ struct PoaBatch {
 // "the bases of stream `stream` at window positions [start, end]" (inclusive; gap tags dropped): one candidate string
 // of a low-quality region (generate_lqseqs_from_tags, ctg_cns.c:822-870)
 struct SubReq { uint32_t stream, start, end; };
+struct CoordReq { uint32_t stream, col, through_col; };
 
 class Exec {
   public:
@@ -163,6 +164,11 @@ class Exec {
     virtual bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) = 0;
     // one consensus string per job of the batch
     virtual bool run_poa(const PoaBatch& in, std::vector<std::string>* out, std::string* err) = 0;
+    // "how many bases of its read has stream `stream` used up when it reaches window column `col`" on the tag streams of the LAST
+    // run_window call: bases carried by the tags in front of the column's own (first) tag, plus that tag's base when through_col is set
+    // (the structural layer's cut of a split read across a gap cluster: generate_gapseqs, ctg_cns.c:2898-2971).  col must lie inside
+    // the stream's span.
+    virtual bool read_coords(const std::vector<CoordReq>& req, std::vector<uint32_t>* bases, std::string* err) = 0;
 };
 
 // provided by whichever executor is linked (HIP in the product library)

@@ -875,6 +875,40 @@ __global__ void k2_extract(const SubReqDev* rq, uint32_t n, const uint32_t* pre,
     if (!kWrite) len[i] = n_out;
 }
 
+// read coordinate of a stream at a window column (Exec::read_coords): a lane per request walks its stream's tag nibbles from the front --
+// eight at a time while the column lies beyond the word -- counting the tags that carry a base; the column's own tag is its need-th
+// non-insertion tag.  A few hundred requests per window with split reads; replaces the download of every tag stream of the window
+// (~40 MB) that the host walk needed (round 5).
+struct CoordReqDev { uint32_t stream, col, through_col, pad; };
+__global__ void k2_read_coord(const CoordReqDev* rq, uint32_t n, const uint64_t* tag_off, const uint32_t* aln_t_s, const uint8_t* tags, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const CoordReqDev r = rq[i];
+    const uint8_t* tg = tags + tag_off[r.stream];
+    const uint32_t need = r.col - aln_t_s[r.stream] + 1;      // the column's first tag is the need-th non-insertion tag of the stream
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(tg);   // streams start 4-byte aligned
+    uint32_t have = 0, q = 0, j = 0;
+    for (;;) {      // whole words while the target lies beyond them (a terminator nibble has bit 3 set: it never counts as a column)
+        const uint32_t x = *w;
+        const uint32_t cols = 8u - (uint32_t)__popc(x & 0x88888888u);
+        if (have + cols >= need) break;
+        if (x & (x >> 1) & (x >> 2) & (x >> 3) & 0x11111111u) break;      // the stream's terminator (15) is in this word: a column behind the
+                                                                           // stream's last one was asked for -- everything up to the end counts
+        const uint32_t y = (x & 0x77777777u) ^ 0x44444444u;      // a nibble is zero where the tag's base code is 4 (a gap)
+        q += (uint32_t)__popc((y | (y >> 1) | (y >> 2)) & 0x11111111u);
+        have += cols;
+        ++w;
+        j += 8;
+    }
+    for (;; ++j) {
+        const uint32_t nb = tag_nib(tg, j);
+        if (nb == 15u) break;                                     // (a column behind the stream's last one: the walk ends with the stream, like the host's)
+        if (!(nb & 8u) && ++have == need) { if (r.through_col && (nb & 7u) != 4u) ++q; break; }
+        if ((nb & 7u) != 4u) ++q;
+    }
+    out[i] = q;
+}
+
 struct StrChunk { uint32_t stream, c0, n, first_chunk_of_stream, last, pad0, pad1, pad2; };
 __global__ void k2_str_count(const StrChunk* sc, uint32_t n_chunks, const char* pool, const uint64_t* str_off, uint32_t* cnt) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1925,6 +1959,7 @@ class HipExec : public Exec {
     bool run_lq_aligned(const LqAlignInput& in, std::string* cons_rev, std::string* err) override;
     bool extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off, std::string* bases, std::string* err) override;
     bool run_poa(const PoaBatch& in, std::vector<std::string>* out, std::string* err) override;
+    bool read_coords(const std::vector<CoordReq>& req, std::vector<uint32_t>* bases, std::string* err) override;
 
   private:
     bool lq_from_pool(const std::vector<uint32_t>& str_len, uint32_t t_len, uint32_t gap_min_len, bool hifi, std::string* cons_rev, std::string* err);
@@ -2499,6 +2534,26 @@ bool HipExec::extract(const std::vector<SubReq>& req, std::vector<uint32_t>* off
         HIPOK(npcopy::d2h(&(*bases)[0], xout_.p, total, q));
         HIPOK(hipStreamSynchronize(q));
     }
+    return true;
+}
+
+bool HipExec::read_coords(const std::vector<CoordReq>& req, std::vector<uint32_t>* bases, std::string* err) {
+    HIPOK(hipSetDevice(device_));
+    hipStream_t q = stream_;
+    const uint32_t n = (uint32_t)req.size();
+    bases->assign(n, 0);
+    if (!n) return true;
+    if (!win_tags_live_) { *err = "read_coords without a window in HBM"; return false; }
+    std::vector<CoordReqDev> rd(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (req[i].stream >= win_n_chunks_.size() || !win_n_chunks_[req[i].stream]) { *err = "read_coords: bad stream"; return false; }
+        rd[i] = CoordReqDev{req[i].stream, req[i].col, req[i].through_col, 0u};
+    }
+    if (!xreq_.ensure(sizeof(CoordReqDev) * (size_t)n) || !xlen_.ensure(4ull * (n + 2))) { *err = "out of device memory (read coordinates)"; return false; }
+    HIPOK(npcopy::h2d(xreq_.p, rd.data(), sizeof(CoordReqDev) * (size_t)n, q));
+    k2_read_coord<<<nblk(n, 64), 64, 0, q>>>(xreq_.as<CoordReqDev>(), n, tagoff_.as<uint64_t>(), alnts_.as<uint32_t>(), tags_.as<uint8_t>(), xlen_.as<uint32_t>());
+    HIPOK(npcopy::d2h(bases->data(), xlen_.p, 4ull * n, q));
+    HIPOK(hipStreamSynchronize(q));
     return true;
 }
 

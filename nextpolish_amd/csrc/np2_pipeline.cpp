@@ -847,13 +847,13 @@ static consensus_trimed_data* ctg_cns_core_task(ctg_cns_cfg* cfg, ref_* ref, cha
             if (getenv("NP2_SV_LOG")) { FILE* lg2 = fopen(getenv("NP2_SV_LOG"), "a"); if (lg2) { fprintf(lg2, "update_align_tags streams %u -> %u\n", sc0, seq_count); fclose(lg2); } }
         }
         lap("keep rules + structural");
-        in.want_tags = sv.brk_g != 0;   // generate_gapseqs walks the split reads' streams on the host
+        in.want_tags = false;           // (round 5: generate_gapseqs asks the executor for the read coordinates it needs instead of walking the streams here)
         in.lq_ratio1 = reads_type == np2k::READS_HIFI ? 0.f : gap_min_ratio1;   // the executor marks where the low-quality scans have to look (NP2_LQ_TRIGGERS=0: off)
         if (!cfg->exec->run_window(in, &out, &err)) np2_die(err.c_str(), ref->n);
         lap("window (executor)");
         std::vector<np2::LqCluster> clusters;
         if (sv.brk_g) {
-            np2::sv_generate_gapseqs(&svw, out, s);
+            if (!np2::sv_generate_gapseqs(&svw, out, s, cfg->exec, &err)) np2_die(err.c_str(), ref->n);
             FILE* lg = getenv("NP2_SV_LOG") ? fopen(getenv("NP2_SV_LOG"), "a") : nullptr;
             if (lg) {
                 for (size_t i = 0; i < svw.clusters.size(); ++i) {

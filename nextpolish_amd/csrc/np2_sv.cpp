@@ -285,12 +285,18 @@ uint32_t sv_update_align_tags(SvWindow* w, const std::vector<SpanOut>& sup_span,
 
 namespace {
 
-// One cluster's search for the draft interval its split reads bridge, and the piece of every read that lies across it.
+// One cluster's search for the draft interval its split reads bridge, and the piece of every read that lies across it.  The search is
+// a small state machine so that ALL clusters of a window advance together: what needs the tag streams -- "which base of its read has
+// stream s reached at column c" -- is asked of the executor for every cluster at once (Exec::read_coords, a lane per question on the
+// device; round 4 downloaded every tag stream of the window, ~40 MB, and walked them here).
 struct GapBridge {
     SvWindow* w;
     SvCluster& clu;
     const WindowOutput& wo;
     uint32_t win_s;
+    uint32_t radius = 10;
+    bool done = false;
+    std::vector<uint32_t> asked;      // members whose two coordinates are in flight, in request order
     uint32_t first_col(uint32_t stream) const { return wo.aln_t_s[stream]; }
     uint32_t last_col(uint32_t stream) const { return wo.aln_t_e[stream] - 1; }     // inclusive, like align_tags_t.aln_t_e
 
@@ -308,62 +314,69 @@ struct GapBridge {
         }
         return n;
     }
-    // read coordinate a stream has reached at draft column `col` (bases of the read consumed up to there; counting starts at q0)
-    uint32_t read_coord(uint32_t stream, uint32_t q0, uint32_t col, bool count_col) const {
-        np2k::Tag tag{0, 0, 0};
-        uint32_t cursor = 0, q = q0;
-        const uint8_t* tg = wo.tags.data() + wo.tag_off[stream];
-        while (np2k::next_tag(tg, first_col(stream), &cursor, &tag)) {
-            if (count_col) { if (tag.q_base != 4) ++q; if ((uint32_t)tag.t_pos == col) break; }
-            else { if ((uint32_t)tag.t_pos == col) break; if (tag.q_base != 4) ++q; }
+    // generate_gapseqs for this cluster (ctg_cns.c:2898-2971): widen the interval around the breakpoint estimate in steps of ten
+    // while that wins bridging members (or until half of them bridge), keep the last interval that won some; then every member's
+    // read substring across it is wanted: the questions go to `req`
+    void widen_and_ask(std::vector<CoordReq>* req) {
+        if (radius == 10) clu.r.s = clu.r.e = 0;
+        uint32_t now = 0, before = 0, idle = 0;
+        while (radius < 30000 && before < clu.i_m - idle && (now >= before || before < clu.i_m / 2)) {
+            const uint32_t from = clu.median > radius ? clu.median - radius - win_s : 0, to = clu.median + radius - win_s;
+            before = now;
+            now = bridging(from, to, &idle);
+            if (now > before) { clu.r.s = from; clu.r.e = to; }
+            radius += 10;
         }
-        return q;
-    }
-    // with the interval fixed: every member's read substring across it; returns how many are usable (longer than ten bases) and
-    // the shortest substring length seen (the step by which the search widens if too few are)
-    uint32_t measure(uint32_t* shortest) {
-        uint32_t usable = 0;
-        *shortest = UINT32_MAX;
+        last_before = before;
+        asked.clear();
         for (uint32_t j = 0; j < clu.i_m; ++j) {
             SvGapRead& g = w->gaps[clu.gap[j]];
             if (!g.l) continue;
             const uint32_t a = g.p_id, b = g.s_id;
             if (first_col(a) > clu.r.s || last_col(a) < clu.r.s || first_col(b) > clu.r.e || last_col(b) < clu.r.e) { g.l = 1; continue; }
-            g.gap.s = read_coord(a, g.p_s - 1, clu.r.s, true);
-            g.gap.e = read_coord(b, g.s_s, clu.r.e + 1, false);
+            asked.push_back(j);
+            req->push_back(CoordReq{a, clu.r.s, 1u});             // bases of the primary's read used up through column r.s ...
+            req->push_back(CoordReq{b, clu.r.e + 1, 0u});         // ... and of the supplementary's before column r.e + 1
+        }
+    }
+    uint32_t last_before = 0;
+    // with the answers: every member's substring; usable = longer than ten bases; if too few are, the search widens further by half
+    // the shortest piece + 20 and asks again
+    void take(const uint32_t* ans) {
+        uint32_t usable = 0, shortest = UINT32_MAX;
+        for (size_t k = 0; k < asked.size(); ++k) {
+            SvGapRead& g = w->gaps[clu.gap[asked[k]]];
+            g.gap.s = g.p_s - 1 + ans[2 * k];
+            g.gap.e = g.s_s + ans[2 * k + 1];
             g.l = g.gap.e > g.gap.s + 10 ? 2 : 1;
             usable += g.l == 2;
-            *shortest = std::min(*shortest, mabs(g.gap.s, g.gap.e));
+            shortest = std::min(shortest, mabs(g.gap.s, g.gap.e));
         }
-        return usable;
-    }
-    // generate_gapseqs for this cluster (ctg_cns.c:2898-2971): widen the interval around the breakpoint estimate in steps of ten
-    // while that wins bridging members (or until half of them bridge), keep the last interval that won some; cut the reads; if too
-    // few pieces are usable, widen further by half the shortest piece + 20 and try again.
-    void run() {
-        uint32_t radius = 10;
-        clu.r.s = clu.r.e = 0;
-        for (;;) {
-            uint32_t now = 0, before = 0, idle = 0;
-            while (radius < 30000 && before < clu.i_m - idle && (now >= before || before < clu.i_m / 2)) {
-                const uint32_t from = clu.median > radius ? clu.median - radius - win_s : 0, to = clu.median + radius - win_s;
-                before = now;
-                now = bridging(from, to, &idle);
-                if (now > before) { clu.r.s = from; clu.r.e = to; }
-                radius += 10;
-            }
-            uint32_t shortest;
-            const uint32_t usable = measure(&shortest);
-            if (usable >= before / 2 || usable >= 10) return;
-            radius += shortest / 2 + 20;
-        }
+        if (usable >= last_before / 2 || usable >= 10) { done = true; return; }
+        radius += shortest / 2 + 20;
     }
 };
 
 }  // namespace
 
-void sv_generate_gapseqs(SvWindow* w, const WindowOutput& wo, int32_t s_) {
-    for (SvCluster& clu : w->clusters) GapBridge{w, clu, wo, (uint32_t)s_}.run();
+bool sv_generate_gapseqs(SvWindow* w, const WindowOutput& wo, int32_t s_, Exec* exec, std::string* err) {
+    std::vector<GapBridge> br;
+    br.reserve(w->clusters.size());
+    for (SvCluster& clu : w->clusters) br.push_back(GapBridge{w, clu, wo, (uint32_t)s_});
+    std::vector<CoordReq> req;
+    std::vector<uint32_t> ans;
+    for (;;) {
+        req.clear();
+        std::vector<std::pair<size_t, size_t>> part;      // (cluster, first request)
+        for (size_t i = 0; i < br.size(); ++i) {
+            if (br[i].done) continue;
+            part.emplace_back(i, req.size());
+            br[i].widen_and_ask(&req);
+        }
+        if (part.empty()) break;
+        if (!exec->read_coords(req, &ans, err)) return false;
+        for (auto& pr : part) br[pr.first].take(ans.data() + pr.second);
+    }
     // of two neighbouring clusters whose intervals come within 500 bases, the one with fewer members in play goes (ctg_cns.c:2973-2996)
     auto in_play = [&](const SvCluster& c) { int n = 0; for (uint32_t j = 0; j < c.i_m; ++j) n += w->gaps[c.gap[j]].l ? 1 : 0; return n; };
     for (size_t i = 0; i + 1 < w->clusters.size(); ++i) {
@@ -373,6 +386,7 @@ void sv_generate_gapseqs(SvWindow* w, const WindowOutput& wo, int32_t s_) {
         if (in_play(next) > in_play(here)) here.i_m = 0;
         else next.i_m = 0;
     }
+    return true;
 }
 
 // Where the contig is cut (update_split_p, ctg_cns.c:2999-3051): a low-depth region away from the window's ends that no cluster

@@ -62,8 +62,9 @@ int sv_update_gap_cluster(SvWindow* w, int rw, int d, int32_t ref_s);
 // alignment against the window (computed for every gap up front).  Appends StreamRefs (set 1, rec = gap index) and
 // returns the new stream count.
 uint32_t sv_update_align_tags(SvWindow* w, const std::vector<SpanOut>& sup_span, uint32_t seq_count, int32_t ref_s, std::vector<StreamRef>* streams);
-// generate_gapseqs: needs the finished tag streams
-void sv_generate_gapseqs(SvWindow* w, const WindowOutput& wo, int32_t s_);
+// generate_gapseqs: the window's tag streams stay with the executor; the read coordinates at the cluster's ends are asked of it
+// (Exec::read_coords), for all clusters of the window at once
+bool sv_generate_gapseqs(SvWindow* w, const WindowOutput& wo, int32_t s_, Exec* exec, std::string* err);
 void sv_update_split_p(std::vector<SvPos>* split_ps, const SvWindow& w, int32_t s, int32_t l, const ref_* ref);
 // clusters as the low-quality stage sees them (ascending position)
 std::vector<LqCluster> sv_lq_clusters(const SvWindow& w);

@@ -269,6 +269,24 @@ class HostExec : public Exec {
         return true;
     }
 
+    // the host walk the reference does (ctg_cns.c:2898-2971, get_qpos-style loops over the stream's tags)
+    bool read_coords(const std::vector<CoordReq>& req, std::vector<uint32_t>* bases, std::string* err) override {
+        bases->assign(req.size(), 0);
+        for (size_t i = 0; i < req.size(); ++i) {
+            const uint32_t st = req[i].stream;
+            if (st >= win_tag_off_.size()) { *err = "read_coords: bad stream"; return false; }
+            Tag tag{0, 0, 0};
+            uint32_t p = 0, q = 0;
+            const uint8_t* tg = win_tags_.data() + win_tag_off_[st];
+            while (next_tag(tg, win_ts_[st], &p, &tag)) {
+                if (req[i].through_col) { if (tag.q_base != 4) ++q; if ((uint32_t)tag.t_pos == req[i].col) break; }
+                else { if ((uint32_t)tag.t_pos == req[i].col) break; if (tag.q_base != 4) ++q; }
+            }
+            (*bases)[i] = q;
+        }
+        return true;
+    }
+
   private:
     std::vector<uint8_t> win_tags_;
     std::vector<uint64_t> win_tag_off_;
