@@ -209,9 +209,11 @@ typedef struct np1_batch np1_batch;
 np1_batch* np1_batch_upload(np1_ctx* ctx, const np1_stream* s);
 void np1_batch_free(np1_batch* b);
 /* Streaming use: an empty batch object bound to a context, (re)filled from successive host streams.  Its HBM buffers only
- * grow, so nothing is allocated in steady state; np1_batch_reload leaves the H2D copies in flight on the context's stream
- * (the stream's arrays must stay alive until the pass is complete; pin them with np1_stream_pin for full-rate asynchronous
- * copies).  np1_batch_results_fetch moves the polished strings of the whole batch into a pinned host buffer with one D2H
+ * grow, so nothing is allocated in steady state; np1_batch_reload leaves the H2D copies in flight on the context's stream.
+ * Round 5: the bytes of an UNPINNED stream are taken while the call runs (through the library's own pinned ring: the stream may be freed
+ * right after); np1_stream_pin copies the arrays an upload moves into one page-locked arena of the stream, from which the copies run
+ * asynchronously at full PCIe rate (the stream must then outlive the pass; np1_stream_free waits for the device).  The GPU never reads
+ * the caller's pageable memory in place (csrc/np_hostcopy.h).  np1_batch_results_fetch moves the polished strings of the whole batch into a pinned host buffer with one D2H
  * copy on the same stream and waits for it; np1_batch_results_ptr()[bounds[c] .. bounds[c+1]) is contig c. */
 np1_batch* np1_batch_create(np1_ctx* ctx);
 int np1_batch_reload(np1_batch* b, const np1_stream* s);
