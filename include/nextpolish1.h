@@ -305,7 +305,7 @@ int np1_score_chain_tiled(np1_ctx* ctx, const char* fasta, const char* bam, cons
                           int64_t first_tile, int64_t tile_stride, char** out, int64_t* out_len, uint64_t* stats);
 void np1_free_string(char* s);
 /* The same with the contig opened ONCE: np1_tiler_open reads the FASTA index entry, the contig's draft and the BAM index; np1_tiler_run
- * polishes tiles first_tile, first_tile + tile_stride, ... (the records of tile t + 1 are read while the device runs tile t) and returns their
+ * polishes tiles first_tile, first_tile + tile_stride, ... (NP1_TILE_PREFETCH=1: the records of tile t + 1 are read while the device runs tile t) and returns their
  * pieces joined in tile order, piece_len[i] (optional; room for every tile of the call) = the length of the i-th piece -- what a rank that
  * takes every world-th tile of a dominant contig calls once (nextpolish_amd/nextpolish1.py: write_tile_pieces). */
 typedef struct np1_tiler np1_tiler;
