@@ -335,6 +335,13 @@ int np1_batch_debug_counters(np1_batch* b, uint32_t* out, int n);
  * copies min(n, slots) elements and returns the slot count */
 int64_t np1_batch_debug_slots(np1_batch* b, int kind, void* out, int64_t n);
 
+/* Device memory of both libraries comes from a caching allocator in front of hipMalloc / hipFree (csrc/np_devalloc.h; NP_DEVCACHE_MB, NP_PINCACHE_MB):
+ * np1_alloc_stats: {hits, misses, runtime frees, blocks fenced at release, idle bytes, bytes handed out, peak idle bytes, bound} of the device cache;
+ * np1_alloc_trim: every idle block back to the runtime; np1_diag_report: the library's streams with their state and the cache counters, to `fd`. */
+void np1_alloc_stats(uint64_t out[8]);
+void np1_alloc_trim(void);
+void np1_diag_report(int fd);
+
 /* calgs (reference: source/lib/calgs.c:8-24): sum of sequence lengths of a FASTA/FASTQ (gz aware) */
 uint64_t calgs(const char* file);
 

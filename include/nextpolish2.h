@@ -82,6 +82,8 @@ void free_consensus_trimed_data(consensus_trimed_data* d);   /* ctg_cns.c:2150-2
 const char* np2_last_error(void);
 /* device index the process will use / uses (pid mod device count, or NP2_DEVICE) */
 int np2_device_index(void);
+/* diagnostics: this library's streams with their state and the allocator caches' counters, written to `fd` */
+void np2_diag_report(int fd);
 
 #ifdef __cplusplus
 }

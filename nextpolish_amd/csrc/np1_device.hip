@@ -53,7 +53,7 @@ void np1_ctx_release(np1_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < kStages; ++i) { (void)hipEventDestroy(c->ev0[i]); (void)hipEventDestroy(c->ev1[i]); }
-    (void)hipStreamDestroy(c->stream);
+    (void)npalloc::stream_destroy(c->stream);
     delete c;
 }
 
@@ -72,7 +72,7 @@ np1_ctx* np1_ctx_create(int device) {
     if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
     np1_ctx* c = new np1_ctx();
     c->device = device;
-    if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
+    if (!hip_ok(npalloc::stream_create(&c->stream), "hipStreamCreate")) { delete c; return nullptr; }
     for (int i = 0; i < kStages; ++i) {
         (void)hipEventCreate(&c->ev0[i]);
         (void)hipEventCreate(&c->ev1[i]);
@@ -86,6 +86,17 @@ void np1_ctx_destroy(np1_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     np1_ctx_release(c);      // batches that are still alive keep the stream and the events until they are freed
 }
+
+// diagnostics: streams of this library with their state and the allocator caches' counters, written to `fd` (np_devalloc.h: report)
+void np1_diag_report(int fd) { npalloc::report(fd, "nextpolish1.so"); }
+// cache counters for tests and bench.py: {hits, misses, runtime frees, fenced, idle bytes, live bytes, peak idle bytes, bound} of the device cache
+void np1_alloc_stats(uint64_t out[8]) {
+    const npalloc::CacheStats st = npalloc::dev_cache().stats();
+    out[0] = st.hits; out[1] = st.misses; out[2] = st.raw_frees; out[3] = st.fenced; out[4] = st.cached; out[5] = st.live; out[6] = st.peak_cached;
+    out[7] = npalloc::dev_cache().cap();
+}
+// every idle block of both caches back to the runtime (a worker that shares its GPU and is about to sit idle)
+void np1_alloc_trim(void) { npalloc::dev_cache().flush(-1); npalloc::host_cache().flush(-1); }
 
 int np1_stage_count(void) { return kStages; }
 const char* np1_stage_name(int i) {

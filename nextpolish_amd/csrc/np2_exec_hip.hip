@@ -46,7 +46,8 @@ using namespace np2k;
 #define HIPOK(x)                                                                                        \
     do {                                                                                                \
         hipError_t e_ = (x);                                                                            \
-        if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); return false; }  \
+        /* (nothing of this process may still be moving when the caller's locals go away: a second stream may be running) */ \
+        if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); (void)hipDeviceSynchronize(); return false; }  \
     } while (0)
 
 struct DevBuf {
@@ -1708,7 +1709,9 @@ __global__ __launch_bounds__(64) void k2_poa(const char* __restrict__ pool, cons
     if (dbg) dbg += 4 * blockIdx.x;
     int32_t* TS = C::TAB_LDS ? nullptr : tabS + (size_t)blockIdx.x * tab_cap;
     uint32_t* TF = C::TAB_LDS ? nullptr : tabF + (size_t)blockIdx.x * tab_cap;
-    for (;;) {
+    // (a wave takes n_order jobs at most, plus the one fetch that tells it the list is empty: the bound costs nothing and makes the loop end
+    // whatever a future compiler does with the wave-uniform idiom below -- a job nobody reached keeps status "not done" and goes to the host)
+    for (uint32_t taken = 0; taken <= n_order; ++taken) {
         uint32_t at = 0;
         if (threadIdx.x == 0) at = atomicAdd(queue, 1u);
         at = np2poa::uni(at);
@@ -1940,16 +1943,16 @@ class HipExec : public Exec {
     explicit HipExec(int device) : device_(device) {}
     ~HipExec() override {
         if (stream_) (void)hipStreamSynchronize(stream_);
-        if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)hipStreamDestroy(stream2_); }
+        if (stream2_) { (void)hipStreamSynchronize(stream2_); (void)npalloc::stream_destroy(stream2_); }
         if (ev_up_) (void)hipEventDestroy(ev_up_);
         if (ev_big_) (void)hipEventDestroy(ev_big_);
-        if (stream_) (void)hipStreamDestroy(stream_);
+        if (stream_) (void)npalloc::stream_destroy(stream_);
     }
     bool init(std::string* err) {
         HIPOK(hipSetDevice(device_));
         // workers share the host cores of a GPU (the reference's -p model): waiting for the GPU must not spin on one
         if (!getenv("NP2_SPIN_SYNC")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
-        HIPOK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        HIPOK(npalloc::stream_create(&stream_));
         np::bgzf_device_inflate_enable(device_);   // the worker's BAM readers inflate their windows on the device from now on
         return true;
     }
@@ -2764,7 +2767,7 @@ bool HipExec::run_poa(const PoaBatch& in, std::vector<std::string>* out, std::st
             !poatabf_.ensure(4ull * TAB_CAP * slots + 64) || !poaout_.ensure(out_total + 64) || !poaolen_.ensure(4ull * n_jobs + 64) ||
             !poastat_.ensure(4ull * n_jobs + 64 + 64) || !poaord_.ensure(4ull * n_jobs + 64)) { *err = "out of device memory (pseudo-seeds)"; return false; }
         uint32_t* queue = poastat_.as<uint32_t>() + n_jobs + 4;      // three job counters behind the status words
-        if (!stream2_) { HIPOK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking)); HIPOK(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming)); HIPOK(hipEventCreateWithFlags(&ev_big_, hipEventDisableTiming)); }
+        if (!stream2_) { HIPOK(npalloc::stream_create(&stream2_)); HIPOK(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming)); HIPOK(hipEventCreateWithFlags(&ev_big_, hipEventDisableTiming)); }
         HIPOK(hipMemsetAsync(queue, 0, 12, q));
         HIPOK(hipMemsetAsync(poastat_.p, 0xff, 4ull * n_jobs, q));      // (a job no launch reaches reads as "not done")
         HIPOK(npcopy::h2d(poapool_.p, in.chars.data(), in.chars.size(), q));
@@ -2811,7 +2814,7 @@ bool HipExec::run_poa(const PoaBatch& in, std::vector<std::string>* out, std::st
                 if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 5.0) {
                     hipStream_t q3;
                     std::vector<uint32_t> h(4 * (size_t)(small_slots + slots));
-                    if (hipStreamCreateWithFlags(&q3, hipStreamNonBlocking) == hipSuccess && hipMemcpyAsync(h.data(), poadbg_.p, 4 * h.size(), hipMemcpyDeviceToHost, q3) == hipSuccess &&
+                    if (npalloc::stream_create(&q3) == hipSuccess && hipMemcpyAsync(h.data(), poadbg_.p, 4 * h.size(), hipMemcpyDeviceToHost, q3) == hipSuccess &&
                         hipStreamSynchronize(q3) == hipSuccess) {
                         for (uint32_t b = 0; b < small_slots + slots; ++b) {
                             const uint32_t* w = &h[4 * (size_t)b];
@@ -2894,6 +2897,7 @@ Exec* make_exec(std::string* err) {
 
 }  // namespace np2
 
+extern "C" void np2_diag_report(int fd) { npalloc::report(fd, "nextpolish2.so"); }
 extern "C" int np2_device_index(void) {
     std::string err;
     return np2::pick_device(&err);

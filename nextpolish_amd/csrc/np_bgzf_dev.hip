@@ -60,7 +60,7 @@ struct DevInflater {
     bool run(const uint8_t* comp, size_t comp_len, const np::BgzfBatchBlock* bl, size_t n, uint8_t* out, size_t out_len) {
         std::lock_guard<std::mutex> g(mu);
         if (hipSetDevice(device) != hipSuccess) return false;
-        if (!q && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return false;
+        if (!q && npalloc::stream_create(&q) != hipSuccess) return false;
         size_t cb = c_blocks;
         if (!grow(&d_comp, &c_comp, comp_len + 4096, false) || !grow(&d_out, &c_out, out_len + 4096, false) ||
             !grow(&d_blocks, &cb, sizeof(npdev::BlockDesc) * n + 64, false))

@@ -1,6 +1,17 @@
 // Device allocations of both libraries go through here.
 //
-// Default: hipMalloc / hipFree.
+// Default (round 6): a caching allocator in front of hipMalloc / hipFree (BlockCache below).  Why: on this runtime every hipFree first
+// waits for EVERY stream of the process (hip::Stream::SyncAllStreams; profiles/r5_fault_hunt.txt section 3 measured it), and a drop-in
+// call or a tile allocates and frees ~110 buffers -- a long-lived worker (the reference's caller: one process, contig after contig,
+// source/lib/nextpolish1.py:181-189,219-224) made ~65 000 such device-wide waits per test-suite run, and the one-process suite stopped
+// inside one of them in rounds 4 and 5.  With the cache a released buffer goes to a per-device free list and the
+// next request of a similar size takes it from there: no runtime call on either side in steady state.  The guarantee hipFree gave --
+// nothing in flight still touches the block when somebody else gets it -- is kept without waiting: at release time every stream either
+// library created (stream_create below keeps the registry) is asked with hipStreamQuery; for each one that is busy an event is
+// recorded and kept with the block, and the block is handed out again only once those events have completed (asked with
+// hipEventQuery at the time of the request; a block that is not ready is skipped, the request falls through to hipMalloc).
+// NP_DEVCACHE_MB=<n> bounds the bytes kept per device (default 16384; 0 = no cache: plain hipMalloc / hipFree as before); blocks
+// larger than half the bound go straight to hipFree, and when hipMalloc runs out of memory the cache is emptied and the request retried.
 //
 // NP_EFENCE=1 (debugging): every buffer is placed through the HIP virtual-memory API so that its LAST byte (rounded up to 16, the
 // widest vector access the kernels use) is the last mapped byte of its own address reservation, with an unmapped granule behind it.
@@ -28,6 +39,7 @@
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 namespace npalloc {
 
@@ -73,8 +85,233 @@ inline bool is_pinned(const void* p, size_t bytes) {
     --it;
     return a >= it->first && a + bytes <= it->first + it->second;
 }
-inline hipError_t host_malloc(void** p, size_t bytes, unsigned flags) {
-    const hipError_t e = hipHostMalloc(p, bytes, flags);
+// (round 6: pinned host memory goes through a BlockCache of its own, defined below -- hipHostFree waits for the device like hipFree does)
+inline hipError_t host_malloc(void** p, size_t bytes, unsigned flags);
+inline hipError_t host_free(void* p);
+
+// ----------------------------------------------------------------------------------------------- stream registry
+// Streams of both libraries are created and destroyed through here, so that a released block can be fenced against everything in flight
+// (BlockCache) and a stopped process can say which stream is busy (np_busy_streams, used by the tests' watchdog).
+struct StreamRegistry {
+    std::mutex mu;
+    std::map<hipStream_t, int> live;      // stream -> device
+};
+inline StreamRegistry& stream_registry() { static StreamRegistry* r = new StreamRegistry(); return *r; }
+inline hipError_t stream_create(hipStream_t* q) {
+    const hipError_t e = hipStreamCreateWithFlags(q, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        StreamRegistry& R = stream_registry();
+        std::lock_guard<std::mutex> g(R.mu);
+        R.live[*q] = dev;
+    }
+    return e;
+}
+// (hooks run before a stream goes away: the pinned copy ring settles the events it recorded on it, np_hostcopy.h)
+typedef void (*StreamDestroyHook)(hipStream_t);
+inline StreamDestroyHook& stream_destroy_hook() { static StreamDestroyHook h = nullptr; return h; }
+inline hipError_t stream_destroy(hipStream_t q) {
+    if (!q) return hipSuccess;
+    (void)hipStreamSynchronize(q);
+    if (StreamDestroyHook h = stream_destroy_hook()) h(q);
+    {
+        StreamRegistry& R = stream_registry();
+        std::lock_guard<std::mutex> g(R.mu);
+        R.live.erase(q);
+    }
+    return hipStreamDestroy(q);
+}
+// streams of `dev` (plus the null stream) that still have work in flight
+inline void busy_streams(int dev, std::vector<hipStream_t>* out) {
+    out->clear();
+    std::vector<hipStream_t> all;
+    {
+        StreamRegistry& R = stream_registry();
+        std::lock_guard<std::mutex> g(R.mu);
+        for (auto& kv : R.live) if (kv.second == dev) all.push_back(kv.first);
+    }
+    all.push_back(nullptr);
+    for (hipStream_t q : all) if (hipStreamQuery(q) == hipErrorNotReady) out->push_back(q);
+}
+
+// ----------------------------------------------------------------------------------------------- block cache
+struct CacheStats { uint64_t hits = 0, misses = 0, raw_frees = 0, fenced = 0, not_ready = 0, flushes = 0; size_t cached = 0, live = 0, peak_cached = 0; };
+
+class BlockCache {
+public:
+    typedef hipError_t (*RawAlloc)(void**, size_t);
+    typedef hipError_t (*RawFree)(void*);
+    BlockCache(RawAlloc a, RawFree f, size_t cap_bytes) : alloc_(a), free_(f), cap_(cap_bytes) {}
+
+    // size classes with three mantissa bits (at most 12.5 % above the request), 4 KiB at least
+    static size_t size_class(size_t bytes) {
+        if (bytes <= 4096) return 4096;
+        int top = 63 - __builtin_clzll((unsigned long long)bytes);
+        const size_t step = (size_t)1 << (top - 3);
+        return (bytes + step - 1) & ~(step - 1);
+    }
+
+    hipError_t get(void** p, size_t bytes) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const size_t want = size_class(bytes);
+        if (cap_) {
+            Block hit{};
+            bool found = false;
+            std::vector<hipEvent_t> done;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                auto& fl = free_list_[dev];
+                // a block of up to 1.5x the class (small ones: up to 4x, nothing is lost with them)
+                const size_t most = want < ((size_t)1 << 20) ? want * 4 : want + want / 2;
+                int looked = 0;
+                for (auto it = fl.lower_bound(want); it != fl.end() && it->first <= most && looked < 8; ++it, ++looked) {
+                    bool ready = true;
+                    for (hipEvent_t e : it->second.waits) if (hipEventQuery(e) != hipSuccess) { ready = false; break; }
+                    if (!ready) { ++st_.not_ready; continue; }
+                    hit = it->second;
+                    fl.erase(it);
+                    found = true;
+                    break;
+                }
+                if (found) {
+                    st_.cached -= hit.bytes;
+                    st_.live += hit.bytes;
+                    ++st_.hits;
+                    live_[hit.p] = Live{hit.bytes, dev};
+                    for (hipEvent_t e : hit.waits) spare_events_.push_back(e);
+                }
+            }
+            if (found) { *p = hit.p; return hipSuccess; }
+        }
+        hipError_t e = alloc_(p, cap_ ? want : bytes);
+        if (e != hipSuccess && cap_) {
+            (void)hipGetLastError();
+            flush(dev);                      // out of memory with blocks of our own lying idle: give them back and ask again
+            e = alloc_(p, want);
+        }
+        if (e == hipSuccess && cap_) {
+            std::lock_guard<std::mutex> g(mu_);
+            ++st_.misses;
+            st_.live += want;
+            live_[*p] = Live{want, dev};
+        }
+        return e;
+    }
+
+    hipError_t put(void* p) {
+        if (!p) return hipSuccess;
+        Live l{};
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto it = live_.find(p);
+            if (it == live_.end()) { ++st_.raw_frees; l.bytes = 0; }
+            else { l = it->second; live_.erase(it); st_.live -= l.bytes; }
+        }
+        if (!cap_ || l.bytes == 0 || l.bytes > cap_ / 2) {
+            if (cap_ && l.bytes) { std::lock_guard<std::mutex> g(mu_); ++st_.raw_frees; }
+            return free_(p);
+        }
+        // fence the block against whatever is in flight on any stream of ours (what hipFree did by waiting)
+        Block b{p, l.bytes, {}};
+        std::vector<hipStream_t> busy;
+        busy_streams(l.dev, &busy);
+        for (hipStream_t q : busy) {
+            hipEvent_t e = take_event();
+            if (!e || hipEventRecord(e, q) != hipSuccess) {      // cannot fence: wait like hipFree would have
+                if (e) give_event(e);
+                (void)hipStreamSynchronize(q);
+                continue;
+            }
+            b.waits.push_back(e);
+        }
+        std::vector<Block> evict;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!b.waits.empty()) ++st_.fenced;
+            free_list_[l.dev].emplace(b.bytes, b);
+            st_.cached += b.bytes;
+            if (st_.cached > st_.peak_cached) st_.peak_cached = st_.cached;
+            // over the bound: the largest idle blocks of this device go back to the runtime
+            auto& fl = free_list_[l.dev];
+            while (st_.cached > cap_ && !fl.empty()) {
+                auto last = std::prev(fl.end());
+                evict.push_back(last->second);
+                st_.cached -= last->second.bytes;
+                fl.erase(last);
+            }
+        }
+        for (Block& v : evict) release_block(v);
+        return hipSuccess;
+    }
+
+    // every idle block of the device back to the runtime (dev < 0: of every device)
+    void flush(int dev) {
+        std::vector<Block> all;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            ++st_.flushes;
+            for (auto& kv : free_list_) {
+                if (dev >= 0 && kv.first != dev) continue;
+                for (auto& b : kv.second) { all.push_back(b.second); st_.cached -= b.second.bytes; }
+                kv.second.clear();
+            }
+        }
+        for (Block& v : all) release_block(v);
+    }
+    CacheStats stats() { std::lock_guard<std::mutex> g(mu_); return st_; }
+    size_t cap() const { return cap_; }
+
+private:
+    struct Block { void* p; size_t bytes; std::vector<hipEvent_t> waits; };
+    struct Live { size_t bytes; int dev; };
+    void release_block(Block& v) {
+        for (hipEvent_t e : v.waits) { (void)hipEventSynchronize(e); give_event(e); }
+        { std::lock_guard<std::mutex> g(mu_); ++st_.raw_frees; }
+        (void)free_(v.p);
+    }
+    hipEvent_t take_event() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!spare_events_.empty()) { hipEvent_t e = spare_events_.back(); spare_events_.pop_back(); return e; }
+        }
+        hipEvent_t e = nullptr;
+        return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? e : nullptr;
+    }
+    void give_event(hipEvent_t e) { std::lock_guard<std::mutex> g(mu_); spare_events_.push_back(e); }
+
+    RawAlloc alloc_;
+    RawFree free_;
+    size_t cap_;
+    std::mutex mu_;
+    std::map<int, std::multimap<size_t, Block>> free_list_;
+    std::unordered_map<void*, Live> live_;
+    std::vector<hipEvent_t> spare_events_;
+    CacheStats st_;
+};
+
+inline size_t env_mb(const char* name, size_t dflt_mb) {
+    const char* e = getenv(name);
+    if (!e || !e[0]) return dflt_mb << 20;
+    return (size_t)strtoull(e, nullptr, 10) << 20;
+}
+inline hipError_t raw_dev_alloc(void** p, size_t n) { return hipMalloc(p, n); }
+inline hipError_t raw_dev_free(void* p) { return hipFree(p); }
+inline BlockCache& dev_cache() {      // (never destroyed: the runtime may already be gone when static destructors run)
+    static BlockCache* c = new BlockCache(raw_dev_alloc, raw_dev_free, env_mb("NP_DEVCACHE_MB", 16384));
+    return *c;
+}
+
+
+inline hipError_t raw_host_alloc(void** p, size_t n) { return hipHostMalloc(p, n, hipHostMallocPortable); }
+inline hipError_t raw_host_free(void* p) { return hipHostFree(p); }
+inline BlockCache& host_cache() {
+    static BlockCache* c = new BlockCache(raw_host_alloc, raw_host_free, env_mb("NP_PINCACHE_MB", 2048));
+    return *c;
+}
+inline hipError_t host_malloc(void** p, size_t bytes, unsigned /*flags: every block is hipHostMallocPortable*/) {
+    const hipError_t e = host_cache().get(p, bytes ? bytes : 1);
     if (e == hipSuccess) {
         alloc_log("H+", *p, bytes);
         PinnedRanges& R = pinned_ranges();
@@ -91,7 +328,33 @@ inline hipError_t host_free(void* p) {
         std::lock_guard<std::mutex> g(R.mu);
         R.live.erase((uintptr_t)p);
     }
-    return hipHostFree(p);
+    return host_cache().put(p);
+}
+// What a stopped process can say about itself (tests/conftest.py's watchdog calls np1_diag_report / np2_diag_report from a helper thread):
+// every stream of the registry with hipStreamQuery's answer, and the cache counters.  A stream that answers "ready" while another thread sits
+// in a runtime wait is a wake-up the runtime lost; one that answers "not ready" on an idle GPU is work the runtime never finished.
+inline void report(int fd, const char* who) {
+    std::vector<std::pair<hipStream_t, int>> all;
+    {
+        StreamRegistry& R = stream_registry();
+        std::lock_guard<std::mutex> g(R.mu);
+        for (auto& kv : R.live) all.emplace_back(kv.first, kv.second);
+    }
+    all.emplace_back(nullptr, -1);
+    dprintf(fd, "[np diag] %s: %zu stream(s) in the registry (+ the null stream)\n", who, all.size() - 1);
+    for (auto& kv : all) {
+        const hipError_t e = hipStreamQuery(kv.first);
+        dprintf(fd, "[np diag]   stream %p device %d: %s\n", (void*)kv.first, kv.second, e == hipSuccess ? "ready" : e == hipErrorNotReady ? "NOT READY" : hipGetErrorString(e));
+    }
+    (void)hipGetLastError();
+    for (int k = 0; k < 2; ++k) {
+        BlockCache& c = k ? host_cache() : dev_cache();
+        const CacheStats st = c.stats();
+        dprintf(fd, "[np diag]   %s cache (bound %zu MiB): %llu hits, %llu misses, %llu runtime frees, %llu blocks fenced at release, %llu skipped not ready, %llu flushes; "
+                    "%zu MiB idle now (peak %zu), %zu MiB handed out\n",
+                k ? "pinned-host" : "device", c.cap() >> 20, (unsigned long long)st.hits, (unsigned long long)st.misses, (unsigned long long)st.raw_frees,
+                (unsigned long long)st.fenced, (unsigned long long)st.not_ready, (unsigned long long)st.flushes, st.cached >> 20, st.peak_cached >> 20, st.live >> 20);
+    }
 }
 
 inline bool efence() {
@@ -133,7 +396,7 @@ inline hipError_t dev_malloc(void** p, size_t bytes) {
 }
 
 inline hipError_t dev_malloc_raw(void** p, size_t bytes) {
-    if (!efence()) return hipMalloc(p, bytes);
+    if (!efence()) return dev_cache().get(p, bytes);
     *p = nullptr;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -173,7 +436,7 @@ inline hipError_t dev_malloc_raw(void** p, size_t bytes) {
 inline hipError_t dev_free(void* p) {
     if (!p) return hipSuccess;
     alloc_log("D-", p, 0);
-    if (!efence()) return hipFree(p);
+    if (!efence()) return dev_cache().put(p);
     FenceRec r;
     {
         FenceTable& t = fence_table();

@@ -27,6 +27,7 @@
 #include <deque>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "np_devalloc.h"
 
@@ -40,60 +41,76 @@ struct Slot { void* p = nullptr; hipEvent_t ev = nullptr; bool pending = false; 
 
 class Ring {      // one per device and library, made at the first large pageable copy
 public:
-    bool acquire(Slot* out) {
+    // A slot to fill.  Blocks only while all kSlots exist and other threads hold them.  (Round 6: a new slot is allocated OUTSIDE the lock --
+    // hipHostMalloc can take milliseconds and used to stall every release() behind it; and a failed allocation only fails the call when
+    // there is no slot at all to wait for.)
+    bool acquire(Slot* out) { return take(out, true); }
+    // a slot only if one can be had without waiting for another thread to give one back (a thread that already holds a slot must not
+    // block here: with as many such threads as slots nobody could ever release)
+    bool try_acquire(Slot* out) { return take(out, false); }
+    void release(const Slot& s) {
+        { std::lock_guard<std::mutex> g(mu_); free_.push_back(s); }
+        cv_.notify_one();
+    }
+    // Before a stream is destroyed: every event this ring recorded on ANY stream is waited for now, so that no slot is left with an event
+    // whose stream no longer exists (slots in other threads' hands are theirs to settle: they synchronise their own stream).
+    void settle() {
+        std::deque<Slot> mine;
+        { std::lock_guard<std::mutex> g(mu_); mine.swap(free_); }
+        for (Slot& s : mine) if (s.pending) { (void)hipEventSynchronize(s.ev); s.pending = false; }
+        { std::lock_guard<std::mutex> g(mu_); for (Slot& s : mine) free_.push_back(s); }
+        cv_.notify_all();
+    }
+private:
+    bool take(Slot* out, bool may_wait) {
         std::unique_lock<std::mutex> g(mu_);
-        if (made_ < kSlots && (free_.empty() || free_.front().pending)) {
-            Slot s;
-            if (npalloc::host_malloc(&s.p, kSlotBytes, hipHostMallocPortable) != hipSuccess) { s.p = nullptr; }
-            else if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { (void)npalloc::host_free(s.p); s.p = nullptr; }
-            if (s.p) { ++made_; *out = s; return true; }
-            if (made_ < 2 && free_.empty()) return false;      // no pinned memory to be had: the caller reports the failure
+        for (;;) {
+            if (!free_.empty() && !free_.front().pending) break;                 // an idle slot: take it
+            if (made_ + making_ < kSlots && !alloc_failed_) {                     // room for one more: make it, unlocked
+                ++making_;
+                g.unlock();
+                Slot s;
+                bool ok = npalloc::host_malloc(&s.p, kSlotBytes, hipHostMallocPortable) == hipSuccess;
+                if (ok && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { (void)npalloc::host_free(s.p); ok = false; }
+                g.lock();
+                --making_;
+                if (ok) { ++made_; *out = s; return true; }
+                alloc_failed_ = true;                                             // (no second attempt while slots exist: wait for one instead)
+                cv_.notify_all();
+                continue;
+            }
+            if (!free_.empty()) break;                                            // a slot whose last copy is still in flight: its event is waited for below
+            if (made_ + making_ == 0) { alloc_failed_ = false; return false; }    // no pinned memory to be had at all: the caller reports it
+            if (!may_wait) return false;
+            cv_.wait(g, [&] { return !free_.empty() || made_ + making_ == 0; });
         }
-        cv_.wait(g, [&] { return !free_.empty(); });
         *out = free_.front();
         free_.pop_front();
         g.unlock();
         if (out->pending) { (void)hipEventSynchronize(out->ev); out->pending = false; }
         return true;
     }
-    // a slot only if one can be had without waiting for another thread to give one back (a thread that already holds a slot must not
-    // block here: with as many such threads as slots nobody could ever release)
-    bool try_acquire(Slot* out) {
-        {
-            std::unique_lock<std::mutex> g(mu_);
-            if (made_ < kSlots && (free_.empty() || free_.front().pending)) {
-                Slot s;
-                if (npalloc::host_malloc(&s.p, kSlotBytes, hipHostMallocPortable) == hipSuccess) {
-                    if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) == hipSuccess) { ++made_; *out = s; return true; }
-                    (void)npalloc::host_free(s.p);
-                }
-            }
-            if (free_.empty()) return false;
-            *out = free_.front();
-            free_.pop_front();
-        }
-        if (out->pending) { (void)hipEventSynchronize(out->ev); out->pending = false; }
-        return true;
-    }
-    void release(const Slot& s) {
-        { std::lock_guard<std::mutex> g(mu_); free_.push_back(s); }
-        cv_.notify_one();
-    }
-private:
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<Slot> free_;
-    int made_ = 0;
+    int made_ = 0, making_ = 0;
+    bool alloc_failed_ = false;
 };
 
+struct Rings { std::mutex mu; std::map<int, Ring*> of; };      // (never destroyed: the runtime may already be gone when static destructors run)
+inline Rings& rings() { static Rings* r = new Rings(); return *r; }
+inline void settle_all(hipStream_t) {
+    std::vector<Ring*> all;
+    { Rings& R = rings(); std::lock_guard<std::mutex> g(R.mu); for (auto& kv : R.of) all.push_back(kv.second); }
+    for (Ring* r : all) r->settle();
+}
 inline Ring& ring() {
-    static std::mutex mu;
-    static std::map<int, Ring*> rings;      // (never destroyed: the runtime may already be gone when static destructors run)
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> g(mu);
-    Ring*& r = rings[dev];
-    if (!r) r = new Ring();
+    Rings& R = rings();
+    std::lock_guard<std::mutex> g(R.mu);
+    Ring*& r = R.of[dev];
+    if (!r) { r = new Ring(); npalloc::stream_destroy_hook() = settle_all; }
     return *r;
 }
 

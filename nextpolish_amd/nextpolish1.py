@@ -29,6 +29,7 @@ import sys
 if __package__ in (None, ""):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.realpath(__file__))))
 from nextpolish_amd import _native as nat  # noqa: E402
+from nextpolish_amd import resume  # noqa: E402
 from nextpolish_amd.shard import deal_contigs, fasta_lengths  # noqa: E402
 
 
@@ -42,22 +43,9 @@ def parse_num_unit(s):
 
 
 def read_polished_seqs(infile, polished_seqs):
-    """Resume support (reference: nextpolish1.py:163-179): names already written to the output; the last
-    record may be truncated, so it is dropped and its file offset returned for the rewrite."""
-    last_seq = ""
-    cur_seq_offset = last_seq_position = 0
-    with open(infile) as IN:
-        for line in IN:
-            if line.startswith(">"):
-                last_seq_position += cur_seq_offset
-                cur_seq_offset = len(line)
-                last_seq = seq_name = line.split()[0].split("_np")[0][1:]
-                polished_seqs.add(seq_name)
-            else:
-                cur_seq_offset += len(line)
-    if last_seq:
-        polished_seqs.remove(last_seq)
-    return last_seq_position
+    """Resume support (reference: nextpolish1.py:163-179): adds the contigs `infile` already holds to `polished_seqs`, except the last
+    one (its record may be cut off); returns that record's offset for the rewrite (nextpolish_amd/resume.py)."""
+    return resume.finished_contigs(infile, resume.polished_record, polished_seqs)
 
 
 def read_unpolished_seqs(infile, index, polished_seqs, keep_polished=False):

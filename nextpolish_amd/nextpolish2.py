@@ -20,6 +20,9 @@ import sys
 from multiprocessing import Pool
 
 HERE = os.path.dirname(os.path.realpath(__file__))
+if __package__ in (None, ""):      # run as a script (the way the reference's workflow starts its callers)
+    sys.path.insert(0, os.path.dirname(HERE))
+from nextpolish_amd import resume  # noqa: E402
 
 
 class ConsensusTrimed(C.Structure):   # reference: nextpolish2.py:21-26
@@ -62,26 +65,9 @@ def parse_num_unit(s):
 
 
 def read_corrected_seqs(infile, corrected_seqs):
-    """Resume support (nextpolish2.py:117-137): names already in the output; the last contig may be incomplete, so it
-    is dropped and the file offset of its first record returned."""
-    last_seq = ""
-    cur_seq_offset = last_seq_position = 0
-    with open(infile) as IN:
-        for line in IN:
-            if line.startswith(">"):
-                lines = line.split()[0].split("_s")
-                last_seq = seq_name = lines[0][1:]
-                if len(lines) == 1 or lines[1] == "0":
-                    last_seq_position += cur_seq_offset
-                    cur_seq_offset = len(line)
-                else:
-                    cur_seq_offset += len(line)
-                corrected_seqs.add(seq_name)
-            else:
-                cur_seq_offset += len(line)
-    if last_seq:
-        corrected_seqs.remove(last_seq)
-    return last_seq_position
+    """Resume support (nextpolish2.py:116-137): adds the contigs `infile` already holds to `corrected_seqs`, except the one the file ends
+    in (it may be incomplete); returns the offset of that contig's first record (nextpolish_amd/resume.py)."""
+    return resume.finished_contigs(infile, resume.corrected_piece, corrected_seqs)
 
 
 def read_uncorrected_seqs(infile, index, corrected_seqs, keep_corrected=False):
@@ -103,18 +89,11 @@ def read_uncorrected_seqs(infile, index, corrected_seqs, keep_corrected=False):
 
 
 def set_window_process(args):
-    """nextpolish2.py:67-90 (host RAM bound of the reference; the device path needs ~60 B per alignment column of a
-    window in HBM, so the 288 GB of an MI355X are not the limit at the default 5 Mb window)."""
+    """nextpolish2.py:67-79 (host RAM bound of the reference; the device path needs ~60 B per alignment column of a window in HBM, so the
+    288 GB of an MI355X are not the limit at the default 5 Mb window).  Unlike the reference this never leaves zero workers."""
     import psutil
-    max_mem = psutil.virtual_memory().available / 1536
-    max_cpu = psutil.cpu_count()
-    if args.process > max_cpu:
-        args.process = max_cpu
-    if args.window < 5000000 or args.process * args.window > max_mem:
-        args.window = 5000000
-    process = int(max_mem / args.window)
-    if args.process > process:
-        args.process = max(1, process)
+    args.window, workers = resume.fit_workers(args.window, args.process, psutil.virtual_memory().available, psutil.cpu_count())
+    args.process = max(1, workers)
 
 
 _P = _CFG = _REFS = None

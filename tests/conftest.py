@@ -78,6 +78,36 @@ def _debugger_dump(path):
     return txt if len(txt) < (4 << 20) else txt[: 3 << 20] + "\n[... cut ...]\n" + txt[-(1 << 20):]
 
 
+def _library_report(path):
+    """np1_diag_report / np2_diag_report of whichever library this process has loaded (streams with hipStreamQuery's answer, allocator cache
+    counters), asked from a helper thread of its own: the call goes into the HIP runtime, which the stopped thread may hold a lock of."""
+    import ctypes
+    import threading
+    loaded = open("/proc/self/maps").read()
+
+    def ask():
+        with open(path + ".streams", "w") as f:
+            for lib, fn in (("nextpolish1.so", "np1_diag_report"), ("nextpolish2.so", "np2_diag_report")):
+                full = os.path.join(ROOT, "nextpolish_amd", "lib", lib)
+                if full not in loaded and os.path.realpath(full) not in loaded:
+                    continue
+                f.write("[np watchdog] %s:\n" % fn)
+                f.flush()
+                try:
+                    getattr(ctypes.CDLL(full), fn)(f.fileno())
+                except Exception as e:      # noqa: BLE001
+                    f.write("  failed: %r\n" % (e,))
+
+    t = threading.Thread(target=ask, daemon=True)
+    t.start()
+    t.join(20.0)
+    try:
+        txt = open(path + ".streams").read()
+    except OSError:
+        txt = ""
+    return txt + ("[np watchdog] (the report itself did not return within 20 s)\n" if t.is_alive() else "")
+
+
 def _watchdog(limit, outdir):
     import faulthandler
     import signal
@@ -97,6 +127,7 @@ def _watchdog(limit, outdir):
                 os.write(2, s.encode("utf-8", "replace"))      # (fd 2 itself: sys.stderr is pytest's capture object)
             say("\n[np watchdog] %s has been running for %.0f s (limit %d s): collecting the state of process %d\n" % (name, time.time() - t0, limit, os.getpid()))
             say("[np watchdog] threads (tid comm wchan state syscall):\n" + _thread_states() + "\n")
+            say("[np watchdog] the libraries' streams and allocator caches:\n" + _library_report(path) + "\n")
             say("[np watchdog] debugger:\n" + _debugger_dump(path) + "\n")
             say("[np watchdog] threads after the debugger let go:\n" + _thread_states() + "\n")
             say("[np watchdog] Python frames:\n")

@@ -19,7 +19,10 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_short_read_and_long_read_legs_back_to_back_in_one_process(tmp_path):
+# NP_STRESS_REPS=<n> repeats the test n times in the process (tests/tools/r6_hang_hunt.sh: the body makes a few thousand device allocations and
+# releases per pass with both libraries' streams alive -- the pattern in which the one-process suite stopped inside hipFree)
+@pytest.mark.parametrize("rep", range(int(os.environ.get("NP_STRESS_REPS", "1"))))
+def test_short_read_and_long_read_legs_back_to_back_in_one_process(rep, tmp_path):
     gold2 = json.load(open(os.path.join(HERE, "golden", "np2_golden.json")))["cases"]
     L2 = rb.bind(os.path.join(ROOT, "nextpolish_amd", "lib", "nextpolish2.so"))
     st = nat.Stream.synth([2500000, 900000, 40000], depth=30, seed=515)
