@@ -165,6 +165,12 @@ def lib():
     L.np1_batch_update_count.restype = C.c_int64
     L.np1_batch_device_bytes.argtypes = [C.c_void_p]
     L.np1_batch_device_bytes.restype = C.c_int64
+    L.np1_alloc_stats.argtypes = [C.POINTER(C.c_uint64)]
+    L.np1_alloc_stats.restype = None
+    L.np1_alloc_trim.argtypes = []
+    L.np1_alloc_trim.restype = None
+    L.np1_diag_report.argtypes = [C.c_int]
+    L.np1_diag_report.restype = None
     L.calgs.argtypes = [C.c_char_p]
     L.calgs.restype = C.c_uint64
     L.np1_stream_pin.argtypes = [C.c_void_p]

@@ -750,13 +750,13 @@ extern "C" int64_t np1_debug_inflate_device_prof(int device, const uint8_t* bgzf
     if (u > out_cap || (int64_t)blocks.size() > status_cap) { np1_set_error("output buffers too small"); return -1; }
     DevBuf dc, du, db, ds;
     if (dc.ensure(n + 4096) || du.ensure(u + 64) || db.ensure(sizeof(npdev::BlockDesc) * (blocks.size() + 1)) || ds.ensure(4 * (blocks.size() + 1))) return -1;
-    HIPCHK(hipMemset(dc.p, 0, n + 4096));
+    HIPCHK(hipMemsetAsync(dc.p, 0, n + 4096, nullptr));
     HIPCHK(npcopy::h2d_sync(dc.p, bgzf, n));
     HIPCHK(npcopy::h2d_sync(db.p, blocks.data(), sizeof(npdev::BlockDesc) * blocks.size()));
-    HIPCHK(hipMemset(du.p, 0xEE, u + 64));
+    HIPCHK(hipMemsetAsync(du.p, 0xEE, u + 64, nullptr));
     DevBuf dp;
     if (dp.ensure(64)) return -1;
-    HIPCHK(hipMemset(dp.p, 0, 64));
+    HIPCHK(hipMemsetAsync(dp.p, 0, 64, nullptr));
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, nullptr);

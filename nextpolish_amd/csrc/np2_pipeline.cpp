@@ -10,6 +10,7 @@
 // Low-quality regions go through np2_lq.cpp (candidates, POA pseudo-seed, O(ND) alignment on the host; the graph
 // consensus of the concatenated regions in the executor).
 // The split-read structural layer (depth track, gap clusters, supplementary streams, split points) is in np2_sv.cpp.  See DESIGN.md section "path B".
+#include <algorithm>
 #include <cassert>
 #include <cctype>
 #include <climits>
@@ -66,49 +67,55 @@ int32_t full_query_len(const np::BamRec& r) {   // cal_l_qseq / cal_l_qseq_from_
     if ((last & 0xf) == 5) rlen += (int32_t)(last >> 4);
     return rlen;
 }
-uint32_t cigarstr_clip(const char* s, int end) {   // cigarstr2ul
-    if (end) {
-        int index = 0;
-        while (*(s + 1) != '\0') {
-            if (*s >= '0' && *s <= '9') ++index; else index = 0;
-            ++s;
-        }
-        s -= index;
+// What the split-read logic needs from the CIGAR text of an SA:Z entry, found in one pass over its <length><op> pairs: the clip (H or S)
+// the text opens with, the clip it ends in, and the contig bases it covers.  Counted like the reference counts them (cigarstr2ul /
+// cigarstr2rlen, ctg_cns.c:2368-2401): only M and D advance on the contig (N, = and X do not), and a text that ends in digits without an
+// operation has no closing clip.
+struct SaCigar { uint32_t lead_clip = 0, tail_clip = 0, ref_span = 0; };
+SaCigar read_sa_cigar(const char* text) {
+    SaCigar c;
+    uint32_t len = 0, last_len = 0;
+    char last_op = 0;
+    bool first = true;
+    for (const char* p = text; *p; ++p) {
+        if (*p >= '0' && *p <= '9') { len = len * 10 + (uint32_t)(*p - '0'); last_op = 0; continue; }
+        if (*p == 'M' || *p == 'D') c.ref_span += len;
+        if (first && (*p == 'H' || *p == 'S')) c.lead_clip = len;
+        first = false;
+        last_op = *p;
+        last_len = len;
+        len = 0;
     }
-    uint32_t result = 0;
-    while (*s >= '0' && *s <= '9') { result = result * 10 + (uint32_t)(*s - '0'); ++s; }
-    if (*s != 'H' && *s != 'S') result = 0;
-    return result;
+    if (last_op == 'H' || last_op == 'S') c.tail_clip = last_len;
+    return c;
 }
-int32_t cigarstr_rlen(const char* s) {   // cigarstr2rlen
-    uint32_t rlen = 0, clen = 0;
-    while (*s != '\0') {
-        if (*s >= '0' && *s <= '9') clen = clen * 10 + (uint32_t)(*s - '0');
-        else { if (*s == 'M' || *s == 'D') rlen += clen; clen = 0; }
-        ++s;
-    }
-    return (int32_t)rlen;
-}
-inline uint32_t mabs(uint32_t x, uint32_t y) { return x > y ? x - y : y - x; }
-void check_indel(Gap* g, int32_t rlen, const Pos* rfp1, const Pos* rdp1, const Pos* rfp2, const Pos* rdp2) {   // ctg_cns.c:2463-2492
-    int l = 0;
-    const int32_t mclen = (int32_t)(rlen * 0.1);
-    if (rfp1->s > rfp2->s) {
-        l = 1;
-        const Pos* t = rfp1; rfp1 = rfp2; rfp2 = t;
-        t = rdp1; rdp1 = rdp2; rdp2 = t;
-    }
-    if (rfp2->e > rfp1->e && rdp2->e > rdp1->e && (int64_t)rdp1->s < mclen && (int64_t)rdp2->e > (int64_t)rlen - mclen &&
-        mabs(rfp2->s, rfp1->e) < 30000 && mabs(rdp2->s, rdp1->e) < 30000 && rfp1->s != rfp2->s) {
-        const uint32_t score = rdp1->s + (uint32_t)rlen - rdp2->e + mabs(rfp2->s, rfp1->e) + mabs(rdp2->s, rdp1->e);
-        if (score < g->score || !g->score) {
-            g->score = score;
-            g->ds = l ? rdp1->s : rdp2->s;
-            g->fs = l ? rfp1->s : rfp2->s;
-            if (rfp1->e < rfp2->s) { g->gap.s = rfp1->e; g->gap.e = rfp2->s; }
-            else { g->gap.s = rfp2->s; g->gap.e = rfp1->e; }
-        }
-    }
+
+// One aligned piece of a read: where it lies on the contig and which part of the (unclipped) read it covers.
+struct Piece { Pos ref, read; };
+inline uint32_t span_between(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
+
+// Does the pair (this record, one same-strand SA entry on the same contig) look like ONE read torn apart by an insertion or deletion
+// (ctg_cns.c:2463-2492)?  With `a` the piece that starts first on the contig and `b` the other: b must end later than a on the contig and
+// on the read, the two together must reach both ends of the read to within a tenth of its length, and the jump between them must stay
+// under 30 kb on both axes.  The cost of the pairing is what is left uncovered plus both jumps; the cheapest pairing of a record wins, and
+// the gap it brackets on the contig lies between a's end and b's start (whichever comes first).
+void consider_split(Gap* best, int32_t read_len, const Piece& self, const Piece& other) {
+    const bool other_first = self.ref.s > other.ref.s;
+    const Piece& a = other_first ? other : self;
+    const Piece& b = other_first ? self : other;
+    if (a.ref.s == b.ref.s) return;
+    if (!(b.ref.e > a.ref.e && b.read.e > a.read.e)) return;
+    const int32_t edge = (int32_t)(read_len * 0.1);
+    if (!(a.read.s < (uint32_t)edge && b.read.e > (uint32_t)(read_len - edge))) return;
+    const uint32_t ref_jump = span_between(b.ref.s, a.ref.e), read_jump = span_between(b.read.s, a.read.e);
+    if (ref_jump >= 30000 || read_jump >= 30000) return;
+    const uint32_t cost = a.read.s + (uint32_t)read_len - b.read.e + ref_jump + read_jump;
+    if (best->score && cost >= best->score) return;
+    best->score = cost;
+    best->ds = other.read.s;      // (the reference keeps the starts of the piece the SA entry describes)
+    best->fs = other.ref.s;
+    best->gap.s = std::min(a.ref.e, b.ref.s);
+    best->gap.e = std::max(a.ref.e, b.ref.s);
 }
 
 // SA:Z value of a record (SAMv1 4.2.4 aux layout), nullptr when absent
@@ -698,9 +705,9 @@ static consensus_trimed_data* ctg_cns_core_task(ctg_cns_cfg* cfg, ref_* ref, cha
                     if (f.size() < 4) break;
                     if (f[0] == ref->n && ((f[2][0] == '+') ? 0 : 1) == strand) {
                         const uint32_t sp = (uint32_t)(atoll(f[1].c_str()) - 1);
-                        const Pos rfp2{sp, sp + (uint32_t)cigarstr_rlen(f[3].c_str())};
-                        const Pos rdp2{cigarstr_clip(f[3].c_str(), 0), (uint32_t)l_qseq - cigarstr_clip(f[3].c_str(), 1)};
-                        check_indel(&g, l_qseq, &rfp1, &rdp1, &rfp2, &rdp2);
+                        const SaCigar sc = read_sa_cigar(f[3].c_str());
+                        const Piece other{Pos{sp, sp + sc.ref_span}, Pos{sc.lead_clip, (uint32_t)l_qseq - sc.tail_clip}};
+                        consider_split(&g, l_qseq, Piece{rfp1, rdp1}, other);
                     }
                 }
             }

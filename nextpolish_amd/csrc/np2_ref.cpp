@@ -97,42 +97,58 @@ const uint8_t kNt[128] = {   // A/a 0, C/c 1, G/g 2, T/t/U/u 3, everything else 
     4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
     4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4};
 
-bool starts_with(const char* pre, const char* s) {
-    size_t a = strlen(pre), b = strlen(s);
-    return b < a ? false : memcmp(pre, s, a) == 0;
-}
-
-// ctg_cns.c:2233-2267: "node=<n>" style token -> qv_l = atoi(token + 7); "qv" token -> hex words separated by ':'.
-// `s` is tokenised in place exactly like the reference does (the buffer persists between records there).
-void parse_ref_qv(char* s, ref_* r) {
-    char *token, *qv = nullptr, sep[2] = " ";
+// The per-base quality summary a previous long-read round left in the FASTA comment (read back by ctg_cns.c:2233-2267): among the
+// blank-separated words of the comment, the last one beginning with "node" carries the number of entries from its 8th character on, the last
+// one beginning with "qv" carries the entries from its 6th character on: ':'-separated hexadecimal words of 64 bits = position (32 bits),
+// identity, and two rates (10 bits each).  Words are read with strtoull like the reference reads them (so "0x" prefixes and trailing junk
+// behave the same); entries the comment does not supply stay zero, and entries beyond the announced count are ignored (the reference writes
+// them past the end of its array).
+// The comment is not modified.  The reference splits its reader's buffer in place, and a later record WITHOUT a comment is parsed from what
+// is left visible of that buffer -- the text up to the end of its first word, or up to the end of the first hexadecimal entry when that first
+// word is the "qv" one that was read.  The return value is that visible length; read_ref cuts its copy of the buffer there.
+size_t parse_ref_qv(const char* comment, ref_* r) {
     r->qv_l = 0;
-    if (s) {
-        token = strtok(s, sep);
-        while (token != nullptr) {
-            if (starts_with("node", token)) r->qv_l = (uint32_t)atoi(token + 7);
-            if (starts_with("qv", token)) qv = token + 5;
-            token = strtok(nullptr, sep);
-        }
+    r->qv = nullptr;
+    if (!comment) return 0;
+    const char *count_word = nullptr, *qv_word = nullptr, *qv_end = nullptr, *first_end = nullptr;
+    for (const char* w = comment; *w;) {
+        while (*w == ' ') ++w;
+        const char* e = w;
+        while (*e && *e != ' ') ++e;
+        const size_t n = (size_t)(e - w);
+        if (n && !first_end) first_end = e;
+        if (n >= 4 && memcmp(w, "node", 4) == 0) count_word = n > 7 ? w + 7 : "";
+        if (n >= 2 && memcmp(w, "qv", 2) == 0) { qv_word = n > 5 ? w + 5 : e; qv_end = e; }
+        w = e;
     }
-    if (r->qv_l && qv) {
-        uint64_t i = 0;
-        sep[0] = ':';
-        r->qv = (ref_qv*)malloc(r->qv_l * sizeof(ref_qv));
-        token = strtok(qv, sep);
-        while (token != nullptr && i < r->qv_l) {   // the reference writes past its array when the header lists more words than node=<n> (ctg_cns.c:2259); stop at n
-            ref_qv* q = &r->qv[i++];
-            const uint64_t t = strtoull(token, nullptr, 16);
-            q->p = (uint32_t)(t >> 32);
-            q->ide = t >> 20 & 0x3ff;
-            q->ort = t >> 10 & 0x3ff;
-            q->irt = t & 0x3ff;
-            token = strtok(nullptr, sep);
-        }
-    } else {
-        r->qv_l = 0;
-        r->qv = nullptr;
+    size_t visible = first_end ? (size_t)(first_end - comment) : strlen(comment);
+    const uint32_t announced = count_word ? (uint32_t)atoi(count_word) : 0;      // (atoi stops at the blank that ends the word)
+    if (!announced || !qv_word) return visible;
+    if (qv_end == first_end) {      // the entries are part of the first word: the reference's split ends the visible text behind the first entry
+        const char* p = qv_word;
+        while (p < qv_end && *p == ':') ++p;
+        while (p < qv_end && *p != ':') ++p;
+        if (p < qv_end && p > qv_word) visible = (size_t)(p - comment);
     }
+    r->qv_l = announced;
+    r->qv = (ref_qv*)calloc(announced, sizeof(ref_qv));
+    uint32_t filled = 0;
+    std::string word;
+    for (const char* p = qv_word; p < qv_end && filled < announced;) {
+        while (p < qv_end && *p == ':') ++p;
+        const char* e = p;
+        while (e < qv_end && *e != ':') ++e;
+        if (e == p) break;
+        word.assign(p, e);
+        const uint64_t bits = strtoull(word.c_str(), nullptr, 16);
+        ref_qv& q = r->qv[filled++];
+        q.p = (uint32_t)(bits >> 32);
+        q.ide = (bits >> 20) & 0x3ff;
+        q.ort = (bits >> 10) & 0x3ff;
+        q.irt = bits & 0x3ff;
+        p = e;
+    }
+    return visible;
 }
 
 int str_cmp(const void* a, const void* b) { return strcmp(*(char* const*)a, *(char* const*)b); }
@@ -219,7 +235,8 @@ refs_* read_ref(char* fasta, char** accept_names, int n) {
         r->length = (uint32_t)seq.size();
         r->s = (uint32_t*)malloc(sizeof(uint32_t) * (r->length / 16 + 1));
         seq2bit1(r->s, r->length, seq.empty() ? (char*)"" : &seq[0]);
-        parse_ref_qv(have_cbuf ? cbuf.data() : nullptr, r);
+        const size_t visible = parse_ref_qv(have_cbuf ? cbuf.data() : nullptr, r);
+        if (have_cbuf) { cbuf.resize(visible); cbuf.push_back('\0'); }
         if (++refs->i >= refs->i_m) {
             refs->i_m += 100;
             refs->ref = (ref_*)realloc(refs->ref, refs->i_m * sizeof(ref_));

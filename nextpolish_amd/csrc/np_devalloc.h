@@ -10,8 +10,9 @@
 // library created (stream_create below keeps the registry) is asked with hipStreamQuery; for each one that is busy an event is
 // recorded and kept with the block, and the block is handed out again only once those events have completed (asked with
 // hipEventQuery at the time of the request; a block that is not ready is skipped, the request falls through to hipMalloc).
-// NP_DEVCACHE_MB=<n> bounds the bytes kept per device (default 16384; 0 = no cache: plain hipMalloc / hipFree as before); blocks
-// larger than half the bound go straight to hipFree, and when hipMalloc runs out of memory the cache is emptied and the request retried.
+// NP_DEVCACHE_MB=<n> bounds the idle bytes kept per device (default 16384; 0 = no cache: every release is a hipFree as before); over the
+// bound the largest idle blocks go back to the runtime, and when hipMalloc runs out of memory the cache is emptied and the request retried.
+// Whenever memory does go back to the runtime, every stream is synchronised with hipStreamSynchronize first (quiesce below, and why).
 //
 // NP_EFENCE=1 (debugging): every buffer is placed through the HIP virtual-memory API so that its LAST byte (rounded up to 16, the
 // widest vector access the kernels use) is the last mapped byte of its own address reservation, with an unmapped granule behind it.
@@ -135,6 +136,25 @@ inline void busy_streams(int dev, std::vector<hipStream_t>* out) {
     for (hipStream_t q : all) if (hipStreamQuery(q) == hipErrorNotReady) out->push_back(q);
 }
 
+// Before memory really goes back to the runtime.  hipFree and hipHostFree first wait for every stream of the process, and they wait the
+// fragile way: HostQueue::finish(cpu_wait = true) -> Command::awaitCompletion(), i.e. the calling thread sleeps on a condition variable until
+// the runtime's signal-handler thread marks the stream's last command complete -- and that wake-up sometimes never comes (round 6: three
+// stops of the test process, all inside hipFree, every queue idle and hipStreamQuery answering "ready" for every stream; DESIGN.md section
+// 12, profiles/r6_hang_hunt.txt).  hipStreamSynchronize waits on the hardware signal itself and, once it returns, the stream has no "last
+// command" left for hipFree to wait for.  So every stream of the registry and the null stream are synchronised that way first, under one
+// lock so that two releasing threads do not interleave; hipFree then finds nothing to wait for.
+inline std::mutex& raw_free_mutex() { static std::mutex* m = new std::mutex(); return *m; }
+inline void quiesce() {
+    std::vector<hipStream_t> all;
+    {
+        StreamRegistry& R = stream_registry();
+        std::lock_guard<std::mutex> g(R.mu);
+        for (auto& kv : R.live) all.push_back(kv.first);
+    }
+    for (hipStream_t q : all) (void)hipStreamSynchronize(q);
+    (void)hipStreamSynchronize(nullptr);
+}
+
 // ----------------------------------------------------------------------------------------------- block cache
 struct CacheStats { uint64_t hits = 0, misses = 0, raw_frees = 0, fenced = 0, not_ready = 0, flushes = 0; size_t cached = 0, live = 0, peak_cached = 0; };
 
@@ -209,8 +229,10 @@ public:
             if (it == live_.end()) { ++st_.raw_frees; l.bytes = 0; }
             else { l = it->second; live_.erase(it); st_.live -= l.bytes; }
         }
-        if (!cap_ || l.bytes == 0 || l.bytes > cap_ / 2) {
+        if (!cap_ || l.bytes == 0 || l.bytes > cap_) {
             if (cap_ && l.bytes) { std::lock_guard<std::mutex> g(mu_); ++st_.raw_frees; }
+            std::lock_guard<std::mutex> g(raw_free_mutex());
+            quiesce();
             return free_(p);
         }
         // fence the block against whatever is in flight on any stream of ours (what hipFree did by waiting)
@@ -269,6 +291,8 @@ private:
     void release_block(Block& v) {
         for (hipEvent_t e : v.waits) { (void)hipEventSynchronize(e); give_event(e); }
         { std::lock_guard<std::mutex> g(mu_); ++st_.raw_frees; }
+        std::lock_guard<std::mutex> g(raw_free_mutex());
+        quiesce();
         (void)free_(v.p);
     }
     hipEvent_t take_event() {
@@ -389,8 +413,8 @@ inline hipError_t dev_malloc(void** p, size_t bytes) {
     const hipError_t e = dev_malloc_raw(p, bytes);
     if (e == hipSuccess) alloc_log("D+", *p, bytes);
     if (e == hipSuccess && poison() >= 0 && bytes) {
-        (void)hipMemset(*p, poison(), bytes);
-        (void)hipDeviceSynchronize();
+        (void)hipMemsetAsync(*p, poison(), bytes, nullptr);
+        (void)hipStreamSynchronize(nullptr);
     }
     return e;
 }

@@ -174,17 +174,18 @@ inline hipError_t d2h(void* dst, const void* src, size_t bytes, hipStream_t q) {
     return err;
 }
 
-// the synchronous forms (hipMemcpy): on the null stream, complete on return
+// the synchronous forms: on the null stream, complete on return.  (Not hipMemcpy: the synchronous API waits through
+// Command::awaitCompletion, the wake-up by the runtime's handler thread that hipFree was seen to lose -- np_devalloc.h, quiesce;
+// hipMemcpyAsync + hipStreamSynchronize waits on the hardware signal.)
 inline hipError_t h2d_sync(void* dst, const void* src, size_t bytes) {
     if (!bytes) return hipSuccess;
-    if (bytes <= kDirectMax || npalloc::is_pinned(src, bytes)) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
     const hipError_t e = h2d(dst, src, bytes, nullptr);
     return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
 }
 inline hipError_t d2h_sync(void* dst, const void* src, size_t bytes) {
     if (!bytes) return hipSuccess;
-    if (bytes <= kDirectMax || npalloc::is_pinned(dst, bytes)) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
-    return d2h(dst, src, bytes, nullptr);
+    const hipError_t e = d2h(dst, src, bytes, nullptr);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
 }
 
 }  // namespace npcopy

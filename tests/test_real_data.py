@@ -150,35 +150,6 @@ def test_gpu_dropin_symbols_on_real_bwa_alignments_in_a_worker_process(tag):
     assert p.returncode == 0 and "dropin ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.gpu
-def test_gpu_soak_alternating_dropin_calls_with_large_batches_in_between():
-    """One process, 200 alternating score_chain / kmer_count drop-in calls (the call pattern of source/lib/nextpolish1.py:181-189,
-    219-224 in a long-lived worker) with a large batch allocated, (130 Mb, 26 M records) run and freed every 50 calls, so that the allocator hands the small
-    buffers of the next calls the address ranges the large ones just left."""
-    g, fa, bam = sr_files("r1.slice")
-    L = nat.lib()
-    cfg = L.config_init(fa.encode(), bam.encode(), None)
-    names = sorted(g["score_chain"])
-    big = nat.Stream.synth([100_000_000, 30_000_000], depth=30, seed=77)
-    ctx = npdev.Context()
-    for k in range(200):
-        n = names[k % len(names)]
-        if k % 2 == 0:
-            r = L.score_chain(n.encode(), cfg)
-            assert digest(C.string_at(r.contents.contig).decode()) == g["score_chain"][n], "call %d score_chain %s" % (k, n)
-        else:
-            r = L.kmer_count(n.encode(), cfg)
-            assert digest(C.string_at(r.contents.contig).decode()) == g["kmer_count"][n], "call %d kmer_count %s" % (k, n)
-        L.polishresult_destory(r)
-        if k % 50 == 49:
-            b = ctx.upload(big)
-            b.score_chain()
-            assert len(b.results()) == 2
-            b.close()
-    ctx.close()
-    L.config_destory(cfg)
-
-
 def dropin_symbols_body(tag):
     g, fa, bam = sr_files(tag)
     L = nat.lib()
