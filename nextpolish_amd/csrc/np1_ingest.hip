@@ -30,6 +30,7 @@
 #include "np_bgzf.h"
 #include "np_inflate_dev.h"
 #include "np_inflate_lane.h"
+#include "np_inflate_lds.h"
 #include "np_crc_dev.h"
 #include "np_crc32.h"
 #include "np_threads.h"
@@ -76,6 +77,45 @@ __global__ __launch_bounds__(64, 4) void k_inflate_lanes(const uint8_t* __restri
         if (d.out_len) rc = nplane::inflate_block(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, tab);
         status[b] = (uint32_t)rc;
     }
+}
+
+// Lane-per-block decoder with its primary tables in LDS (np_inflate_lds.h; round 6): a workgroup is one wave, every lane inflates blocks of
+// its own (lane, lane + lanes, ...); 2^LB + 2^DB 16-bit slots per lane, [slot][lane], fill the LDS of a CU with one wave (10 / 8 bits:
+// exactly 160 KiB) or two (9 / 6 bits: 72 KiB each).  The grid is as many waves as the chip holds at once.
+struct LdsTab {
+    uint16_t* col;      // this lane's column of the [slot][lane] array
+    __device__ __forceinline__ uint16_t rd(uint32_t i) const { return col[i << 6]; }
+    __device__ __forceinline__ void wr(uint32_t i, uint16_t v) { col[i << 6] = v; }
+};
+template <int LB, int DB>
+__global__ __launch_bounds__(64) void k_inflate_lds(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks, uint8_t* out,
+                                                    uint32_t* __restrict__ status, nplds::Scratch* __restrict__ scratch) {
+    __shared__ uint16_t slots[64u * ((1u << LB) + (1u << DB))];
+    const uint32_t lanes = gridDim.x * 64u, me = blockIdx.x * 64u + threadIdx.x;
+    LdsTab tab{slots + threadIdx.x};
+    nplds::Scratch* sc = scratch + me;
+    for (uint32_t b = me; b < n_blocks; b += lanes) {
+        const npdev::BlockDesc d = blocks[b];
+        int rc = 0;
+        if (d.out_len) rc = nplds::inflate_block<LB, DB>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, tab, sc);
+        status[b] = (uint32_t)rc;
+    }
+}
+// waves the chip holds of the kernel at once (by its LDS), and the launch
+template <int LB, int DB>
+int launch_inflate_lds(hipStream_t q, const uint8_t* comp, const npdev::BlockDesc* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* status, DevBuf& scratch) {
+    static const uint32_t cus = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return (uint32_t)n;
+    }();
+    constexpr uint32_t lds_bytes = 64u * ((1u << LB) + (1u << DB)) * 2u;
+    const uint32_t per_cu = std::max<uint32_t>(1u, 163840u / lds_bytes);
+    const uint32_t waves = std::min<uint32_t>(cus * per_cu, (n_blocks + 63u) / 64u);
+    if (scratch.ensure((size_t)waves * 64u * sizeof(nplds::Scratch))) return -1;
+    k_inflate_lds<LB, DB><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
+    return 0;
 }
 
 // gzip trailer CRC of every block the decoder accepted (np_crc_dev.h; the reference's htslib rejects a block whose CRC differs)
@@ -561,7 +601,11 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
     if (n_blocks) {
         // which decoder: a lane per block when the batch has blocks enough to fill the chip with lanes (np_inflate_lane.h), else a
         // wave per block (np_inflate_dev.h).  NP1_INFLATE=lanes | wave forces one.
-        static const int mode = [] { const char* e = getenv("NP1_INFLATE"); return !e ? 0 : strcmp(e, "lanes") == 0 ? 1 : strcmp(e, "wave") == 0 ? 2 : 0; }();
+        // NP1_INFLATE=lds | lds96: the lane decoder with its tables in LDS (np_inflate_lds.h), 10 / 8-bit or 9 / 6-bit primaries.
+        static const int mode = [] {
+            const char* e = getenv("NP1_INFLATE");
+            return !e ? 0 : strcmp(e, "lanes") == 0 ? 1 : strcmp(e, "wave") == 0 ? 2 : strcmp(e, "lds") == 0 ? 3 : strcmp(e, "lds96") == 0 ? 4 : 0;
+        }();
         // lanes in flight: a multiple of the wave, at least one wave, at most 2^18 (their tables are ~15 KB each in HBM)
         static const uint32_t max_lanes = [] {
             long v = getenv("NP1_INFLATE_LANES") ? atol(getenv("NP1_INFLATE_LANES")) : 131072;
@@ -571,7 +615,11 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         }();
         for (hipEvent_t& e : W.ev) if (!e) (void)hipEventCreate(&e);
         (void)hipEventRecord(W.ev[0], q);
-        if (mode == 1 || (mode == 0 && n_blocks >= 4096u)) {
+        if (mode == 3) {
+            if (launch_inflate_lds<10, 8>(q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(), W.lane_tables)) return -1;
+        } else if (mode == 4) {
+            if (launch_inflate_lds<9, 6>(q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(), W.lane_tables)) return -1;
+        } else if (mode == 1 || (mode == 0 && n_blocks >= 4096u)) {
             const uint32_t lanes = std::min<uint32_t>((n_blocks + 63u) & ~63u, max_lanes);
             if (W.lane_tables.ensure((size_t)lanes * nplane::LANE_TABLE_WORDS * 4)) return -1;
             k_inflate_lanes<<<lanes / 64, 64, 0, q>>>(W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(),
@@ -761,9 +809,14 @@ extern "C" int64_t np1_debug_inflate_device_prof(int device, const uint8_t* bgzf
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, nullptr);
     static const bool use_lanes = getenv("NP1_INFLATE") && strcmp(getenv("NP1_INFLATE"), "lanes") == 0;
+    static const int use_lds = !getenv("NP1_INFLATE") ? 0 : strcmp(getenv("NP1_INFLATE"), "lds") == 0 ? 1 : strcmp(getenv("NP1_INFLATE"), "lds96") == 0 ? 2 : 0;
     DevBuf dt;
     if (use_lanes && !prof && dt.ensure((size_t)((blocks.size() + 63) & ~63ull) * nplane::LANE_TABLE_WORDS * 4)) return -1;
-    if (!blocks.empty() && use_lanes && !prof) {
+    if (!blocks.empty() && use_lds && !prof) {
+        const int rc = use_lds == 1 ? launch_inflate_lds<10, 8>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>(), dt)
+                                    : launch_inflate_lds<9, 6>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>(), dt);
+        if (rc) return -1;
+    } else if (!blocks.empty() && use_lanes && !prof) {
         const uint32_t lanes = (uint32_t)((blocks.size() + 63) & ~63ull);
         k_inflate_lanes<<<lanes / 64, 64>>>(dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>(), dt.as<uint32_t>());
     } else if (!blocks.empty()) {

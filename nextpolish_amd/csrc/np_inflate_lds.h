@@ -1,0 +1,311 @@
+// Raw DEFLATE (RFC 1951) decoder for whole BGZF blocks, ONE LANE PER BLOCK, DECODE TABLES IN LDS (round 6).
+//
+// np_inflate_lane.h gave every lane a 12 KB table slice in HBM and counted on the number of lanes in flight: with 40 000 blocks per
+// launch the hot entries of all lanes (~5 KB each) are 200 MB -- beyond every cache -- so each symbol costs a dependent trip to MALL or
+// HBM (measured: 77 ms for 40 k blocks, ~7 000 cycles per symbol and lane, 40 GB/s).  Here the tables a symbol
+// normally needs are small enough to live in LDS:
+//   * one 16-bit entry per primary slot (symbol << 4 | code length), 2^LB slots for literals / lengths and 2^DB for distances, laid
+//     out [slot][lane] so that the 64 lanes of a wave, each reading a slot of its own table, meet different banks (two lanes per
+//     dword: at most a two-way conflict);
+//   * codes longer than the primary index are decoded canonically from two short per-length arrays (upper code bound, offset into the
+//     symbols sorted by code) and the sorted symbols, kept in a 1.3 KB per-lane slice of HBM scratch that stays in L2: with a wave or two
+//     per CU there are only 16-32 k lanes in flight, ~40 MB of scratch in total of which a lane touches a few lines;
+//   * the bit buffer is refilled from a word loaded one refill ahead (the load's latency is off the symbol chain), literals are
+//     gathered in a register and leave as 8-byte stores.
+// A symbol then costs one LDS lookup plus ~40 instructions instead of a trip to HBM.  The code is ordinary C++ over a table policy
+// (`Tab`: rd / wr of a 16-bit slot): the device instantiates it over LDS, the host over a plain array -- tests/test_inflate.py runs the
+// host build against zlib over every block type, level and strategy and over damaged streams, and under AddressSanitizer with buffers
+// of exactly the streams' sizes (no byte outside [src, src + src_len) is read, none outside [dst, dst + dst_len) written).
+// Returns 0 when exactly dst_len bytes came out of the stream, else an error code (the caller inflates refused blocks on the host).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NPD_HD __host__ __device__ __forceinline__
+#define NPD_HD_CALL __host__ __device__ __noinline__
+#else
+#define NPD_HD inline
+#define NPD_HD_CALL inline
+#endif
+
+namespace nplds {
+
+typedef uint64_t __attribute__((aligned(1))) u64u;
+
+// per-lane HBM scratch: code lengths while the tables are built, the symbols of both alphabets sorted by code, and for every code length the
+// exclusive upper bound of its codes (15-bit, left-justified, in the order the bits arrive) and what to add to a code to index `sorted`
+struct Scratch {
+    uint8_t lens[320];
+    uint16_t sorted_lit[288];
+    uint16_t sorted_dist[32];
+    uint16_t lim_lit[16], ofs_lit[16], lim_dist[16], ofs_dist[16];
+};
+
+NPD_HD uint32_t len_base(uint32_t i) {      // RFC 1951 3.2.5, computed
+    if (i < 8) return 3 + i;
+    if (i == 28) return 258;
+    const uint32_t xb = (i - 4) >> 2;
+    return 3 + ((4 + ((i - 4) & 3)) << xb);
+}
+NPD_HD uint32_t len_extra(uint32_t i) { return i < 8 || i == 28 ? 0 : (i - 4) >> 2; }
+NPD_HD uint32_t dist_base(uint32_t i) {
+    if (i < 4) return 1 + i;
+    const uint32_t xb = (i - 2) >> 1;
+    return 1 + ((2 + (i & 1)) << xb);
+}
+NPD_HD uint32_t dist_extra(uint32_t i) { return i < 4 ? 0 : (i - 2) >> 1; }
+
+NPD_HD uint32_t rev32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v);
+#else
+    v = (v >> 16) | (v << 16);
+    v = ((v & 0xff00ff00u) >> 8) | ((v & 0x00ff00ffu) << 8);
+    v = ((v & 0xf0f0f0f0u) >> 4) | ((v & 0x0f0f0f0fu) << 4);
+    v = ((v & 0xccccccccu) >> 2) | ((v & 0x33333333u) << 2);
+    v = ((v & 0xaaaaaaaau) >> 1) | ((v & 0x55555555u) << 1);
+    return v;
+#endif
+}
+
+// Canonical code from lens[0 .. n_sym): primary slots [base, base + 2^bits) of `tab` for the codes of up to `bits` bits, the per-length
+// arrays and the sorted symbols for the others.  false: over-subscribed code.
+template <class Tab>
+NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& tab, uint32_t base, uint16_t* sorted, uint16_t* lim, uint16_t* ofs) {
+    uint32_t count[16];
+    for (int i = 0; i < 16; ++i) count[i] = 0;
+    for (uint32_t s = 0; s < n_sym; ++s) ++count[lens[s] & 15u];
+    count[0] = 0;
+    int left = 1;
+    for (int len = 1; len <= 15; ++len) {
+        left = (left << 1) - (int)count[len];
+        if (left < 0) return false;
+    }
+    uint32_t next_code[16], next_index[16];
+    uint32_t code = 0, index = 0;
+    next_code[0] = next_index[0] = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code = (code + count[len - 1]) << 1;
+        next_code[len] = code;
+        next_index[len] = index;
+        // codes of this length, as their first 15 bits arrive: [code << (15 - len), (code + count) << (15 - len))
+        lim[len] = (uint16_t)((code + count[len]) << (15 - len));      // (<= 32768)
+        ofs[len] = (uint16_t)(index - code);
+        index += count[len];
+    }
+    const uint32_t slots = 1u << bits;
+    for (uint32_t i = 0; i < slots; ++i) tab.wr(base + i, 0);
+    for (uint32_t s = 0; s < n_sym; ++s) {
+        const uint32_t len = lens[s] & 15u;
+        if (!len) continue;
+        const uint32_t c = next_code[len]++;
+        sorted[next_index[len]++] = (uint16_t)s;
+        if (len <= bits) {
+            const uint32_t r = rev32(c) >> (32 - len);
+            const uint16_t e = (uint16_t)(s << 4 | len);
+            for (uint32_t i = r; i < slots; i += 1u << len) tab.wr(base + i, e);
+        }
+    }
+    return true;
+}
+
+// A code longer than the primary index: `peek` = the next 15 bits of the stream.  Returns symbol << 4 | length, or 0 when no code matches.
+NPD_HD uint32_t decode_long(uint32_t peek, uint32_t bits, const uint16_t* sorted, const uint16_t* lim, const uint16_t* ofs) {
+    const uint32_t v = rev32(peek) >> 17;      // the 15 bits in the order they arrived, first bit on top
+    for (uint32_t len = bits + 1; len <= 15; ++len)
+        if (v < lim[len]) return (uint32_t)sorted[(uint16_t)(ofs[len] + (v >> (15 - len)))] << 4 | len;
+    return 0;
+}
+
+struct Bits {
+    const uint8_t* in;       // next byte not yet in `buf` or `next`... see refill
+    const uint8_t* end;
+    uint64_t buf, next;      // next = the 8 bytes at `in` (zero-extended near the end), loaded one refill ahead
+    uint32_t cnt;
+    uint32_t taken;          // bits consumed so far (to tell a stream that ran past its end)
+    NPD_HD uint64_t load(const uint8_t* p) const {
+        if (end - p >= 8) return *reinterpret_cast<const u64u*>(p);
+        uint64_t v = 0;
+        for (int i = 0; p + i < end; ++i) v |= (uint64_t)p[i] << (8 * i);
+        return v;
+    }
+    NPD_HD void start(const uint8_t* s, uint32_t n) { in = s; end = s + n; buf = 0; cnt = 0; taken = 0; next = load(in); }
+    // tops the buffer up to >= 56 bits.  Bytes behind the end of the stream read as zero (the caller checks `taken` against the stream's length).
+    NPD_HD void refill() {
+        buf |= next << cnt;
+        const uint32_t k = (63 - cnt) >> 3;
+        in = (size_t)(end - in) > k ? in + k : end;
+        cnt |= 56;
+        next = load(in);
+    }
+    NPD_HD uint32_t peek(uint32_t n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
+    NPD_HD void drop(uint32_t n) { buf >>= n; cnt -= n; taken += n; }
+    NPD_HD uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+
+// src[0 .. src_len): raw DEFLATE stream; dst[0 .. dst_len): its output; tab: 2^LB + 2^DB 16-bit slots; sc: the lane's scratch.
+template <int LB, int DB, class Tab>
+NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uint32_t dst_len, Tab& tab, Scratch* sc) {
+    constexpr uint32_t LIT0 = 0, DIST0 = 1u << LB;
+    Bits b;
+    b.start(src, src_len);
+    uint8_t* out = dst;                    // everything below `out` is in memory
+    uint8_t* const out_end = dst + dst_len;
+    uint64_t pend = 0;                     // literals not yet stored: bytes out[0 .. npend)
+    uint32_t npend = 0;
+    const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t* const lens = sc->lens;
+    // the pending literals to memory (an 8-byte store when that stays inside the block: the bytes above the pending ones are this lane's
+    // own future output, written again later)
+    auto flush = [&]() {
+        if (!npend) return;
+        if ((size_t)(out_end - out) >= 8) *reinterpret_cast<u64u*>(out) = pend;
+        else for (uint32_t i = 0; i < npend; ++i) out[i] = (uint8_t)(pend >> (8 * i));
+        out += npend;
+        pend = 0;
+        npend = 0;
+    };
+    for (;;) {
+        b.refill();
+        const uint32_t final_block = b.take(1), type = b.take(2);
+        if (type == 0) {   // stored: skip to the byte boundary, LEN / NLEN, bytes
+            b.drop(b.cnt & 7u);
+            b.refill();
+            const uint32_t len = b.take(16), nlen = b.take(16);
+            if ((len ^ 0xffffu) != nlen) return 2;
+            if (b.taken > 8u * src_len) return 17;
+            flush();
+            const uint8_t* p = src + (b.taken >> 3);      // (byte aligned here)
+            if ((size_t)(b.end - p) < len || (size_t)(out_end - out) < len) return 3;
+            for (uint32_t i = 0; i < len; ++i) out[i] = p[i];
+            out += len;
+            const uint32_t done = b.taken + 8u * len;
+            b.start(p + len, (uint32_t)(b.end - (p + len)));
+            b.taken = done;
+            if (final_block) break;
+            continue;
+        } else if (type == 1) {
+            for (int i = 0; i < 144; ++i) lens[i] = 8;
+            for (int i = 144; i < 256; ++i) lens[i] = 9;
+            for (int i = 256; i < 280; ++i) lens[i] = 7;
+            for (int i = 280; i < 288; ++i) lens[i] = 8;
+            if (!build(lens, 288, LB, tab, LIT0, sc->sorted_lit, sc->lim_lit, sc->ofs_lit)) return 11;
+            for (int i = 0; i < 32; ++i) lens[i] = 5;
+            if (!build(lens, 32, DB, tab, DIST0, sc->sorted_dist, sc->lim_dist, sc->ofs_dist)) return 12;
+        } else if (type == 2) {
+            const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
+            if (hlit > 286 || hdist > 30) return 5;
+            uint8_t* const cl = lens + 300;      // 19 code-length code lengths, behind the 286 + 30 lengths they describe
+            for (int i = 0; i < 19; ++i) cl[i] = 0;
+            for (uint32_t i = 0; i < hclen; ++i) {
+                if (b.cnt < 3) b.refill();
+                cl[kClOrder[i]] = (uint8_t)b.take(3);
+            }
+            // the code-length alphabet (codes of up to 7 bits) borrows the head of the literal table and the distance alphabet's arrays
+            if (!build(cl, 19, 7 <= LB ? 7 : LB, tab, LIT0, sc->sorted_dist, sc->lim_dist, sc->ofs_dist)) return 6;
+            uint32_t n = 0;
+            while (n < hlit + hdist) {
+                if (b.cnt < 32) b.refill();
+                uint32_t e = tab.rd(LIT0 + b.peek(7 <= LB ? 7 : LB));
+                if (!(e & 15u)) e = decode_long(b.peek(15), 7 <= LB ? 7 : LB, sc->sorted_dist, sc->lim_dist, sc->ofs_dist);
+                if (!(e & 15u)) return 7;
+                b.drop(e & 15u);
+                const uint32_t sym = e >> 4;
+                if (sym < 16) { lens[n++] = (uint8_t)sym; continue; }
+                uint32_t rep, val = 0;
+                if (sym == 16) { if (!n) return 8; val = lens[n - 1]; rep = 3 + b.take(2); }
+                else if (sym == 17) rep = 3 + b.take(3);
+                else rep = 11 + b.take(7);
+                if (n + rep > hlit + hdist) return 9;
+                for (uint32_t i = 0; i < rep; ++i) lens[n + i] = (uint8_t)val;
+                n += rep;
+            }
+            if (b.taken > 8u * src_len || lens[256] == 0) return 10;
+            if (!build(lens + hlit, hdist, DB, tab, DIST0, sc->sorted_dist, sc->lim_dist, sc->ofs_dist)) return 12;
+            if (!build(lens, hlit, LB, tab, LIT0, sc->sorted_lit, sc->lim_lit, sc->ofs_lit)) return 11;
+        } else {
+            return 4;
+        }
+        // ---- the symbols of the block.  With >= 32 bits in the buffer a literal / length code and its extra bits (<= 20) or a distance
+        // code and its extra bits (<= 28) can be taken without looking at the count again.
+        for (;;) {
+            if (b.cnt < 32) b.refill();
+            uint32_t e = tab.rd(LIT0 + b.peek(LB));
+            if (!(e & 15u)) {
+                e = decode_long(b.peek(15), LB, sc->sorted_lit, sc->lim_lit, sc->ofs_lit);
+                if (!(e & 15u)) return 14;
+            }
+            b.drop(e & 15u);
+            const uint32_t sym = e >> 4;
+            if (sym < 256) {
+                if ((size_t)(out_end - out) <= npend) return 13;
+                pend |= (uint64_t)sym << (8 * npend);
+                if (++npend == 8) { *reinterpret_cast<u64u*>(out) = pend; out += 8; pend = 0; npend = 0; }
+                continue;
+            }
+            if (sym == 256) break;
+            if (sym > 285) return 14;
+            const uint32_t len = len_base(sym - 257) + b.take(len_extra(sym - 257));
+            if (b.cnt < 32) b.refill();
+            uint32_t d = tab.rd(DIST0 + b.peek(DB));
+            if (!(d & 15u)) {
+                d = decode_long(b.peek(15), DB, sc->sorted_dist, sc->lim_dist, sc->ofs_dist);
+                if (!(d & 15u)) return 15;
+            }
+            b.drop(d & 15u);
+            if ((d >> 4) > 29) return 15;
+            const uint32_t off = dist_base(d >> 4) + b.take(dist_extra(d >> 4));
+            flush();
+            if (off > (size_t)(out - dst) || len > (size_t)(out_end - out)) return 16;
+            const uint8_t* from = out - off;
+            // The copy (as in np_inflate_lane.h): every load that may alias an earlier store of the lane waits for the memory round trip, so
+            // sources far enough away are taken four words at a time, a short period (offset < 8) is loaded ONCE and written out as stores.
+            const size_t room = (size_t)(out_end - out);
+            if (off >= 32 && room >= (size_t)len + 32) {
+                uint8_t* o = out;
+                const uint8_t* const stop = out + len;
+                do {
+                    const uint64_t w0 = *reinterpret_cast<const u64u*>(from), w1 = *reinterpret_cast<const u64u*>(from + 8);
+                    const uint64_t w2 = *reinterpret_cast<const u64u*>(from + 16), w3 = *reinterpret_cast<const u64u*>(from + 24);
+                    *reinterpret_cast<u64u*>(o) = w0; *reinterpret_cast<u64u*>(o + 8) = w1;
+                    *reinterpret_cast<u64u*>(o + 16) = w2; *reinterpret_cast<u64u*>(o + 24) = w3;
+                    from += 32;
+                    o += 32;
+                } while (o < stop);
+            } else if (off >= 8 && room >= (size_t)len + 8) {   // whole words; the slack bytes are overwritten by what follows
+                uint8_t* o = out;
+                const uint8_t* const stop = out + len;
+                do {
+                    *reinterpret_cast<u64u*>(o) = *reinterpret_cast<const u64u*>(from);
+                    from += 8;
+                    o += 8;
+                } while (o < stop);
+            } else if (off < 8 && (size_t)(out - dst) >= 8) {   // a period of 1 .. 7 bytes: the last eight bytes hold at least one whole period
+                const uint64_t tail = *reinterpret_cast<const u64u*>(out - 8);
+                const uint32_t first = 8u - off;              // byte of `tail` that is from[0]
+                uint32_t k = 0;
+                for (uint32_t i = 0; i < len; ++i) {
+                    out[i] = (uint8_t)(tail >> (8u * (first + k)));
+                    if (++k == off) k = 0;
+                }
+            } else {
+                for (uint32_t i = 0; i < len; ++i) out[i] = from[i];   // near the start or the end of the output: forward, byte by byte
+            }
+            out += len;
+        }
+        if (b.taken > 8u * src_len) return 17;
+        if (final_block) break;
+    }
+    flush();
+    return (b.taken <= 8u * src_len && out == out_end) ? 0 : 19;
+}
+
+// the host's table policy (tests; the device's lives in np1_ingest.hip: LDS, [slot][lane])
+struct ArrayTab {
+    uint16_t* t;
+    NPD_HD uint16_t rd(uint32_t i) const { return t[i]; }
+    NPD_HD void wr(uint32_t i, uint16_t v) { t[i] = v; }
+};
+
+}  // namespace nplds

@@ -1,5 +1,5 @@
 // Memory-safety fuzz of the two block decoders that run on the host (test infrastructure only): the host decoder of the BGZF reader
-// (csrc/np_inflate.cpp) and the host build of the lane-per-block decoder of the device ingest (csrc/np_inflate_lane.h).  Built with
+// (csrc/np_inflate.cpp) and the host builds of the lane-per-block decoders of the device ingest (csrc/np_inflate_lane.h, csrc/np_inflate_lds.h).  Built with
 // -fsanitize=address,undefined (tests/model/Makefile: inflate_fuzz) and run by tests/test_inflate.py.
 //   * streams of seven kinds of data (incompressible, 2-bit literals, short near matches, long far matches, binned qualities, runs, a
 //     period of 300 bytes with rare substitutions = maximum-length matches with literals between them up to the last byte) x zlib
@@ -7,7 +7,7 @@
 //     write one byte outside either is an AddressSanitizer report (blocks of a BGZF window lie back to back and are decoded by different
 //     threads: a write past a block's end lands in its neighbour);
 //   * the same streams damaged (bit flips, truncation) must be refused or decoded, never touch a byte outside.
-// usage: inflate_fuzz <host|lane> <iterations> <seed>      exit code 0 = every intact stream decoded to its data
+// usage: inflate_fuzz <host|lane|lds|lds96|lds64> <iterations> <seed>      exit code 0 = every intact stream decoded to its data
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,10 +17,18 @@
 
 #include "np_inflate.h"
 #include "np_inflate_lane.h"
+#include "np_inflate_lds.h"
 
 static bool decode_lane(const uint8_t* s, size_t sl, uint8_t* d, size_t dl) {
     static std::vector<uint32_t> tab(nplane::LANE_TABLE_WORDS);
     return nplane::inflate_block(s, (uint32_t)sl, d, (uint32_t)dl, tab.data()) == 0;
+}
+
+template <int LB, int DB> static bool decode_lds(const uint8_t* s, size_t sl, uint8_t* d, size_t dl) {
+    static std::vector<uint16_t> slots((1u << LB) + (1u << DB));
+    nplds::ArrayTab tab{slots.data()};
+    static nplds::Scratch sc;
+    return nplds::inflate_block<LB, DB>(s, (uint32_t)sl, d, (uint32_t)dl, tab, &sc) == 0;
 }
 
 static std::vector<uint8_t> raw_deflate(const std::vector<uint8_t>& d, int level, int strategy) {
@@ -40,7 +48,8 @@ static std::vector<uint8_t> raw_deflate(const std::vector<uint8_t>& d, int level
 
 int main(int argc, char** argv) {
     if (argc < 4) { fprintf(stderr, "usage: inflate_fuzz <host|lane> <iterations> <seed>\n"); return 2; }
-    bool (*decode)(const uint8_t*, size_t, uint8_t*, size_t) = strcmp(argv[1], "lane") == 0 ? decode_lane : np::inflate_raw;
+    bool (*decode)(const uint8_t*, size_t, uint8_t*, size_t) = strcmp(argv[1], "lane") == 0 ? decode_lane : strcmp(argv[1], "lds") == 0 ? decode_lds<10, 8>
+                                                               : strcmp(argv[1], "lds96") == 0 ? decode_lds<9, 6> : strcmp(argv[1], "lds64") == 0 ? decode_lds<6, 4> : np::inflate_raw;
     const int iters = atoi(argv[2]);
     std::mt19937_64 rng((uint64_t)atoll(argv[3]));
     static const int strategies[5] = {Z_DEFAULT_STRATEGY, Z_FILTERED, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED};
