@@ -111,7 +111,9 @@ int launch_inflate_lds(hipStream_t q, const uint8_t* comp, const npdev::BlockDes
         return (uint32_t)n;
     }();
     constexpr uint32_t lds_bytes = 64u * ((1u << LB) + (1u << DB)) * 2u;
-    const uint32_t per_cu = std::max<uint32_t>(1u, 163840u / lds_bytes);
+    // (NP1_LDS_WAVES_PER_CU: fewer than the LDS allows, for measurements)
+    static const uint32_t cap_per_cu = getenv("NP1_LDS_WAVES_PER_CU") ? (uint32_t)atoi(getenv("NP1_LDS_WAVES_PER_CU")) : 64u;
+    const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(cap_per_cu, 163840u / lds_bytes));
     const uint32_t waves = std::min<uint32_t>(cus * per_cu, (n_blocks + 63u) / 64u);
     if (scratch.ensure((size_t)waves * 64u * sizeof(nplds::Scratch))) return -1;
     k_inflate_lds<LB, DB><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
@@ -604,7 +606,8 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         // NP1_INFLATE=lds | lds96: the lane decoder with its tables in LDS (np_inflate_lds.h), 10 / 8-bit or 9 / 6-bit primaries.
         static const int mode = [] {
             const char* e = getenv("NP1_INFLATE");
-            return !e ? 0 : strcmp(e, "lanes") == 0 ? 1 : strcmp(e, "wave") == 0 ? 2 : strcmp(e, "lds") == 0 ? 3 : strcmp(e, "lds96") == 0 ? 4 : 0;
+            return !e ? 0 : strcmp(e, "lanes") == 0 ? 1 : strcmp(e, "wave") == 0 ? 2 : strcmp(e, "lds") == 0 ? 3 : strcmp(e, "lds96") == 0 ? 4 : strcmp(e, "lds85") == 0 ? 5 :
+                   strcmp(e, "lds75") == 0 ? 6 : 0;
         }();
         // lanes in flight: a multiple of the wave, at least one wave, at most 2^18 (their tables are ~15 KB each in HBM)
         static const uint32_t max_lanes = [] {
@@ -619,6 +622,10 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
             if (launch_inflate_lds<10, 8>(q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(), W.lane_tables)) return -1;
         } else if (mode == 4) {
             if (launch_inflate_lds<9, 6>(q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(), W.lane_tables)) return -1;
+        } else if (mode == 5) {
+            if (launch_inflate_lds<8, 5>(q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(), W.lane_tables)) return -1;
+        } else if (mode == 6) {
+            if (launch_inflate_lds<7, 5>(q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(), W.lane_tables)) return -1;
         } else if (mode == 1 || (mode == 0 && n_blocks >= 4096u)) {
             const uint32_t lanes = std::min<uint32_t>((n_blocks + 63u) & ~63u, max_lanes);
             if (W.lane_tables.ensure((size_t)lanes * nplane::LANE_TABLE_WORDS * 4)) return -1;
@@ -809,12 +816,16 @@ extern "C" int64_t np1_debug_inflate_device_prof(int device, const uint8_t* bgzf
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, nullptr);
     static const bool use_lanes = getenv("NP1_INFLATE") && strcmp(getenv("NP1_INFLATE"), "lanes") == 0;
-    static const int use_lds = !getenv("NP1_INFLATE") ? 0 : strcmp(getenv("NP1_INFLATE"), "lds") == 0 ? 1 : strcmp(getenv("NP1_INFLATE"), "lds96") == 0 ? 2 : 0;
+    static const int use_lds = !getenv("NP1_INFLATE") ? 0 : strcmp(getenv("NP1_INFLATE"), "lds") == 0 ? 1 : strcmp(getenv("NP1_INFLATE"), "lds96") == 0 ? 2 :
+                               strcmp(getenv("NP1_INFLATE"), "lds85") == 0 ? 3 : strcmp(getenv("NP1_INFLATE"), "lds75") == 0 ? 4 : 0;
     DevBuf dt;
     if (use_lanes && !prof && dt.ensure((size_t)((blocks.size() + 63) & ~63ull) * nplane::LANE_TABLE_WORDS * 4)) return -1;
     if (!blocks.empty() && use_lds && !prof) {
-        const int rc = use_lds == 1 ? launch_inflate_lds<10, 8>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>(), dt)
-                                    : launch_inflate_lds<9, 6>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>(), dt);
+        const uint32_t nb = (uint32_t)blocks.size();
+        const int rc = use_lds == 1 ? launch_inflate_lds<10, 8>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), nb, du.as<uint8_t>(), ds.as<uint32_t>(), dt)
+                     : use_lds == 2 ? launch_inflate_lds<9, 6>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), nb, du.as<uint8_t>(), ds.as<uint32_t>(), dt)
+                     : use_lds == 3 ? launch_inflate_lds<8, 5>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), nb, du.as<uint8_t>(), ds.as<uint32_t>(), dt)
+                                    : launch_inflate_lds<7, 5>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), nb, du.as<uint8_t>(), ds.as<uint32_t>(), dt);
         if (rc) return -1;
     } else if (!blocks.empty() && use_lanes && !prof) {
         const uint32_t lanes = (uint32_t)((blocks.size() + 63) & ~63ull);

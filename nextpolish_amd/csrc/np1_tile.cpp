@@ -92,13 +92,12 @@ int np1_tiler_run(np1_tiler* t, np1_ctx* ctx, const Configure* cfg, int64_t tile
     Loaded next;
     bool next_ready = false;
     std::thread loader;
-    // NP1_TILE_PREFETCH=1 / NP1_TILE_REUSE=1 (both off by default): read tile t + 1 on a helper thread while the device runs tile t / keep one
-    // batch object for every tile instead of uploading into a fresh one.  Both were the default for a day of round 5: alone and under the
-    // memory fence the GPU tests passed, but ONE of three one-process runs of the whole GPU suite stopped for good inside the first tiling
-    // test (no stack: the run was ended by its time limit; the GPU answered the next process at once).  The round's GPU time was spent, so
-    // the form that has never hung -- read, upload into a fresh batch, run, free, tile after tile -- is what runs unless asked otherwise.
-    static const bool prefetch = getenv("NP1_TILE_PREFETCH") != nullptr;
-    static const bool reuse = getenv("NP1_TILE_REUSE") != nullptr;
+    // While the device runs tile t a helper thread reads tile t + 1 (NP1_TILE_PREFETCH=0 switches that off: read, upload, run, release, tile
+    // after tile on one thread).  History: round 5 had this and a reused batch object as defaults for a day, then switched both off on suspicion
+    // after a one-process run of the GPU suite stopped inside a tiling test.  Round 6 found the stop: hipFree itself, in any long-lived process
+    //  -- the read-ahead thread makes no HIP call at all.  Since the allocator cache of np_devalloc.h a fresh batch per
+    // tile costs no runtime call in steady state, so the reused batch object is gone and the read-ahead is the default again.
+    static const bool prefetch = !(getenv("NP1_TILE_PREFETCH") && strcmp(getenv("NP1_TILE_PREFETCH"), "0") == 0);
     auto start_load = [&](size_t k) {
         next_ready = false;
         if (!prefetch) return;
@@ -127,8 +126,7 @@ int np1_tiler_run(np1_tiler* t, np1_ctx* ctx, const Configure* cfg, int64_t tile
         return load_tile(t, jobs[k].a, jobs[k].b, halo_bp);
     };
     int rc_all = 0;
-    np1_batch* bt = reuse ? np1_batch_create(ctx) : nullptr;      // NP1_TILE_REUSE: one batch object for every tile, its HBM buffers only grow
-    if (reuse && !bt) return -1;
+    np1_batch* bt = nullptr;
     if (!jobs.empty()) start_load(0);
     for (size_t k = 0; k < jobs.size() && rc_all == 0; ++k) {
         const int64_t a = jobs[k].a, b = jobs[k].b;
@@ -141,15 +139,15 @@ int np1_tiler_run(np1_tiler* t, np1_ctx* ctx, const Configure* cfg, int64_t tile
             n_rec += cur.st->s.n_reads();
             if (cur.st->s.n_reads() > max_tile_records) max_tile_records = cur.st->s.n_reads();
             int rc = 0;
-            if (reuse) rc = np1_batch_reload(bt, cur.st);      // (the copies take their bytes during the call: np_hostcopy.h)
-            else { bt = np1_batch_upload(ctx, cur.st); rc = bt ? 0 : -1; }
+            bt = np1_batch_upload(ctx, cur.st);      // (complete on return: the stream may go)
+            rc = bt ? 0 : -1;
             delete cur.st;
             cur.st = nullptr;
             if (rc == 0) rc = np1_batch_keep_single(bt, 1);
             if (rc == 0) rc = np1_batch_score_chain(bt, cfg, nullptr);
             uint32_t j[4] = {0, 0, 0, 0};
             if (rc == 0) rc = np1_batch_tile_join(bt, (uint32_t)(e_lo - lo), (uint32_t)(a - lo), (uint32_t)(b - lo), (uint32_t)(e_hi - lo), e_lo > 0 ? 2u : 0u, j);
-            if (rc != 0) { if (!reuse && bt) { np1_batch_free(bt); bt = nullptr; } rc_all = -1; break; }
+            if (rc != 0) { if (bt) { np1_batch_free(bt); bt = nullptr; } rc_all = -1; break; }
             // a single-state slot inside each halo, among the slots whose votes are complete (e_lo .. e_hi), clear of the two slots behind
             // an artificial start whose draft context is cut short (contig.c:373-383); a halo that reaches the contig's end needs none
             const bool left_ok = a == 0 || e_lo == 0 || j[0] != 0, right_ok = b == L || e_hi == L || j[1] != 0;
@@ -158,11 +156,13 @@ int np1_tiler_run(np1_tiler* t, np1_ctx* ctx, const Configure* cfg, int64_t tile
                 piece = (size_t)(j[3] - j[2]);
                 joined.resize(at + piece);
                 rc = np1_batch_result_range(bt, j[2], j[3], &joined[at]);
-                if (!reuse) { np1_batch_free(bt); bt = nullptr; }
+                np1_batch_free(bt);
+                bt = nullptr;
                 if (rc != 0) rc_all = -1;
                 break;
             }
-            if (!reuse) { np1_batch_free(bt); bt = nullptr; }
+            np1_batch_free(bt);
+            bt = nullptr;
             ++n_redo;
             if (halo > ((int64_t)1 << 30)) { np1_set_error("np1_tiler_run: no single-state slot found in a halo of 2^30 bases"); rc_all = -1; break; }
             cur = load_tile(t, a, b, halo * 2);

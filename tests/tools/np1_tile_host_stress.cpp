@@ -1,9 +1,9 @@
 // The product's tiling driver (np1_tile.cpp) over a FAKE device, on real files through the real host readers: a host-only stress of its
-// read-ahead thread and batch reuse (NP1_TILE_PREFETCH=1 NP1_TILE_REUSE=1), written after a one-process GPU suite run stopped inside the first
+// read-ahead thread (and, in round 5, of a batch-reuse branch that round 6 deleted), written after a one-process GPU suite run stopped inside the first
 // tiling test.  Build and run (files: any FASTA + sorted, indexed BAM made by nat.Stream.write_files with contigs ctg0001, ctg0002):
 //   C=nextpolish_amd/csrc; g++ -O1 -g -std=c++17 -fsanitize=thread -I$C -o /tmp/tile_stress tests/tools/np1_tile_host_stress.cpp $C/np1_tile.cpp \
 //       $C/np_stream.cpp $C/np_bam.cpp $C/np_bgzf.cpp $C/np_inflate.cpp -lz -lpthread
-//   NP1_TILE_PREFETCH=1 NP1_TILE_REUSE=1 /tmp/tile_stress 6      (expects /tmp/tsan/g.fa, /tmp/tsan/r.bam)
+//   /tmp/tile_stress 6      (expects /tmp/tsan/g.fa, /tmp/tsan/r.bam)
 // Round 5: ThreadSanitizer reports nothing over 6 rounds (2 contigs x tiles of 700 / 5 000 / 20 000 bases, halo 1: hundreds of retries racing the
 // read-ahead); 300 rounds of the plain build: no stop.  The host side of the driver is not where that run stopped.
 #include <atomic>
