@@ -87,17 +87,17 @@ struct LdsTab {
     __device__ __forceinline__ uint16_t rd(uint32_t i) const { return col[i << 6]; }
     __device__ __forceinline__ void wr(uint32_t i, uint16_t v) { col[i << 6] = v; }
 };
-template <int LB, int DB>
+template <int LB, int DB, int DBG = 0>
 __global__ __launch_bounds__(64) void k_inflate_lds(const uint8_t* __restrict__ comp, const npdev::BlockDesc* __restrict__ blocks, uint32_t n_blocks, uint8_t* out,
                                                     uint32_t* __restrict__ status, nplds::Scratch* __restrict__ scratch) {
-    __shared__ uint16_t slots[64u * ((1u << LB) + (1u << DB))];
+    __shared__ uint16_t slots[64u * nplds::Layout<LB, DB>::SLOTS];
     const uint32_t lanes = gridDim.x * 64u, me = blockIdx.x * 64u + threadIdx.x;
     LdsTab tab{slots + threadIdx.x};
     nplds::Scratch* sc = scratch + me;
     for (uint32_t b = me; b < n_blocks; b += lanes) {
         const npdev::BlockDesc d = blocks[b];
         int rc = 0;
-        if (d.out_len) rc = nplds::inflate_block<LB, DB>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, tab, sc);
+        if (d.out_len) rc = nplds::inflate_block<LB, DB, LdsTab, DBG>(comp + d.in_off, d.in_len, out + d.out_off, d.out_len, tab, sc);
         status[b] = (uint32_t)rc;
     }
 }
@@ -110,14 +110,37 @@ int launch_inflate_lds(hipStream_t q, const uint8_t* comp, const npdev::BlockDes
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return (uint32_t)n;
     }();
-    constexpr uint32_t lds_bytes = 64u * ((1u << LB) + (1u << DB)) * 2u;
+    constexpr uint32_t lds_bytes = 64u * nplds::Layout<LB, DB>::SLOTS * 2u;
     // (NP1_LDS_WAVES_PER_CU: fewer than the LDS allows, for measurements)
     static const uint32_t cap_per_cu = getenv("NP1_LDS_WAVES_PER_CU") ? (uint32_t)atoi(getenv("NP1_LDS_WAVES_PER_CU")) : 64u;
     const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(cap_per_cu, 163840u / lds_bytes));
     const uint32_t waves = std::min<uint32_t>(cus * per_cu, (n_blocks + 63u) / 64u);
     if (scratch.ensure((size_t)waves * 64u * sizeof(nplds::Scratch))) return -1;
-    k_inflate_lds<LB, DB><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
+    // NP1_LDS_DBG=<bits>: timing experiments with parts of the work left out (np_inflate_lds.h; the output is wrong)
+    static const int dbg = getenv("NP1_LDS_DBG") ? atoi(getenv("NP1_LDS_DBG")) : 0;
+    if (LB == 8 && dbg == 1) k_inflate_lds<LB, DB, 1><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
+    else if (LB == 8 && dbg == 2) k_inflate_lds<LB, DB, 2><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
+    else if (LB == 8 && dbg == 3) k_inflate_lds<LB, DB, 3><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
+    else k_inflate_lds<LB, DB><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
     return 0;
+}
+
+// NP1_INFLATE=lds<LB><DB> (lds96, lds86, lds85, lds76, lds75, lds65; "lds" = the default of the family): which table sizes
+int lds_variant(const char* e) {
+    if (!e || strncmp(e, "lds", 3) != 0) return 0;
+    if (!e[3]) return 85;
+    const int v = atoi(e + 3);
+    return v == 96 || v == 86 || v == 85 || v == 76 || v == 75 || v == 65 ? v : 0;
+}
+int launch_inflate_lds_variant(int v, hipStream_t q, const uint8_t* comp, const npdev::BlockDesc* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* status, DevBuf& scratch) {
+    switch (v) {
+        case 96: return launch_inflate_lds<9, 6>(q, comp, blocks, n_blocks, out, status, scratch);
+        case 86: return launch_inflate_lds<8, 6>(q, comp, blocks, n_blocks, out, status, scratch);
+        case 76: return launch_inflate_lds<7, 6>(q, comp, blocks, n_blocks, out, status, scratch);
+        case 75: return launch_inflate_lds<7, 5>(q, comp, blocks, n_blocks, out, status, scratch);
+        case 65: return launch_inflate_lds<6, 5>(q, comp, blocks, n_blocks, out, status, scratch);
+        default: return launch_inflate_lds<8, 5>(q, comp, blocks, n_blocks, out, status, scratch);
+    }
 }
 
 // gzip trailer CRC of every block the decoder accepted (np_crc_dev.h; the reference's htslib rejects a block whose CRC differs)
@@ -606,8 +629,7 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         // NP1_INFLATE=lds | lds96: the lane decoder with its tables in LDS (np_inflate_lds.h), 10 / 8-bit or 9 / 6-bit primaries.
         static const int mode = [] {
             const char* e = getenv("NP1_INFLATE");
-            return !e ? 0 : strcmp(e, "lanes") == 0 ? 1 : strcmp(e, "wave") == 0 ? 2 : strcmp(e, "lds") == 0 ? 3 : strcmp(e, "lds96") == 0 ? 4 : strcmp(e, "lds85") == 0 ? 5 :
-                   strcmp(e, "lds75") == 0 ? 6 : 0;
+            return !e ? 0 : strcmp(e, "lanes") == 0 ? 1 : strcmp(e, "wave") == 0 ? 2 : lds_variant(e) ? 3 : 0;
         }();
         // lanes in flight: a multiple of the wave, at least one wave, at most 2^18 (their tables are ~15 KB each in HBM)
         static const uint32_t max_lanes = [] {
@@ -619,13 +641,8 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         for (hipEvent_t& e : W.ev) if (!e) (void)hipEventCreate(&e);
         (void)hipEventRecord(W.ev[0], q);
         if (mode == 3) {
-            if (launch_inflate_lds<10, 8>(q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(), W.lane_tables)) return -1;
-        } else if (mode == 4) {
-            if (launch_inflate_lds<9, 6>(q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(), W.lane_tables)) return -1;
-        } else if (mode == 5) {
-            if (launch_inflate_lds<8, 5>(q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(), W.lane_tables)) return -1;
-        } else if (mode == 6) {
-            if (launch_inflate_lds<7, 5>(q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(), W.lane_tables)) return -1;
+            if (launch_inflate_lds_variant(lds_variant(getenv("NP1_INFLATE")), q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(),
+                                           W.status.as<uint32_t>(), W.lane_tables)) return -1;
         } else if (mode == 1 || (mode == 0 && n_blocks >= 4096u)) {
             const uint32_t lanes = std::min<uint32_t>((n_blocks + 63u) & ~63u, max_lanes);
             if (W.lane_tables.ensure((size_t)lanes * nplane::LANE_TABLE_WORDS * 4)) return -1;
@@ -816,16 +833,11 @@ extern "C" int64_t np1_debug_inflate_device_prof(int device, const uint8_t* bgzf
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, nullptr);
     static const bool use_lanes = getenv("NP1_INFLATE") && strcmp(getenv("NP1_INFLATE"), "lanes") == 0;
-    static const int use_lds = !getenv("NP1_INFLATE") ? 0 : strcmp(getenv("NP1_INFLATE"), "lds") == 0 ? 1 : strcmp(getenv("NP1_INFLATE"), "lds96") == 0 ? 2 :
-                               strcmp(getenv("NP1_INFLATE"), "lds85") == 0 ? 3 : strcmp(getenv("NP1_INFLATE"), "lds75") == 0 ? 4 : 0;
+    static const int use_lds = lds_variant(getenv("NP1_INFLATE"));
     DevBuf dt;
     if (use_lanes && !prof && dt.ensure((size_t)((blocks.size() + 63) & ~63ull) * nplane::LANE_TABLE_WORDS * 4)) return -1;
     if (!blocks.empty() && use_lds && !prof) {
-        const uint32_t nb = (uint32_t)blocks.size();
-        const int rc = use_lds == 1 ? launch_inflate_lds<10, 8>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), nb, du.as<uint8_t>(), ds.as<uint32_t>(), dt)
-                     : use_lds == 2 ? launch_inflate_lds<9, 6>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), nb, du.as<uint8_t>(), ds.as<uint32_t>(), dt)
-                     : use_lds == 3 ? launch_inflate_lds<8, 5>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), nb, du.as<uint8_t>(), ds.as<uint32_t>(), dt)
-                                    : launch_inflate_lds<7, 5>(nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), nb, du.as<uint8_t>(), ds.as<uint32_t>(), dt);
+        const int rc = launch_inflate_lds_variant(use_lds, nullptr, dc.as<uint8_t>(), db.as<npdev::BlockDesc>(), (uint32_t)blocks.size(), du.as<uint8_t>(), ds.as<uint32_t>(), dt);
         if (rc) return -1;
     } else if (!blocks.empty() && use_lanes && !prof) {
         const uint32_t lanes = (uint32_t)((blocks.size() + 63) & ~63ull);

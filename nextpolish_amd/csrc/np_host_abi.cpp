@@ -19,7 +19,7 @@ void np1_set_error(const std::string& e) { g_err = e; }
 
 // (np1_debug_inflate_lds* below)
 template <int LB, int DB> static int debug_inflate_lds(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) {
-    std::vector<uint16_t> slots((1u << LB) + (1u << DB));
+    std::vector<uint16_t> slots(nplds::Layout<LB, DB>::SLOTS);
     nplds::ArrayTab tab{slots.data()};
     nplds::Scratch sc;
     return nplds::inflate_block<LB, DB>(src, (uint32_t)src_len, dst, (uint32_t)dst_len, tab, &sc) == 0 ? 1 : 0;
@@ -187,6 +187,7 @@ int np1_debug_inflate_lane(const uint8_t* src, uint64_t src_len, uint8_t* dst, u
 /* test hooks: the LDS-table decoder of the device-side ingest (np_inflate_lds.h), run on the host over a plain array, in the table sizes the
  * device kernels are built in and in a tiny one (6 / 4 bits) that sends most codes down the long-code path: 1 = accepted and dst filled */
 int np1_debug_inflate_lds(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) { return debug_inflate_lds<10, 8>(src, src_len, dst, dst_len); }
+int np1_debug_inflate_lds85(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) { return debug_inflate_lds<8, 5>(src, src_len, dst, dst_len); }
 int np1_debug_inflate_lds96(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) { return debug_inflate_lds<9, 6>(src, src_len, dst, dst_len); }
 int np1_debug_inflate_lds64(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) { return debug_inflate_lds<6, 4>(src, src_len, dst, dst_len); }
 /* test hook: the CRC-32 the BGZF reader / writer compute per block (np_crc32.h: carry-less-multiply folding) */

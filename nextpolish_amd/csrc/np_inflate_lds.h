@@ -7,11 +7,13 @@
 //   * one 16-bit entry per primary slot (symbol << 4 | code length), 2^LB slots for literals / lengths and 2^DB for distances, laid
 //     out [slot][lane] so that the 64 lanes of a wave, each reading a slot of its own table, meet different banks (two lanes per
 //     dword: at most a two-way conflict);
-//   * codes longer than the primary index are decoded canonically from two short per-length arrays (upper code bound, offset into the
-//     symbols sorted by code) and the sorted symbols, kept in a 1.3 KB per-lane slice of HBM scratch that stays in L2: with a wave or two
-//     per CU there are only 16-32 k lanes in flight, ~40 MB of scratch in total of which a lane touches a few lines;
-//   * the bit buffer is refilled from a word loaded one refill ahead (the load's latency is off the symbol chain), literals are
-//     gathered in a register and leave as 8-byte stores.
+//   * codes longer than the primary index are decoded canonically: per code length the upper bound of its codes and an offset (a few
+//     more LDS slots of the lane, read in one go), then the symbol from the symbols sorted by code, in a 1 KB per-lane slice of HBM
+//     scratch that stays in L2 (a few waves per CU: tens of thousands of lanes in flight, of whose slices a lane touches a few lines);
+//   * the bit buffer is refilled from a word loaded one refill ahead, literals are gathered in a register and leave as 8-byte stores;
+//   * the last eight output bytes are kept in a register, and a match at a distance of 1 .. 7 -- the runs base qualities consist of -- is
+//     written from there: measured (profiles/r6_inflate_lds.txt), copies that read back what the lane had just stored were 60 % of the
+//     decoder's time, each one a trip to L2 and back behind the stores before it.
 // A symbol then costs one LDS lookup plus ~40 instructions instead of a trip to HBM.  The code is ordinary C++ over a table policy
 // (`Tab`: rd / wr of a 16-bit slot): the device instantiates it over LDS, the host over a plain array -- tests/test_inflate.py runs the
 // host build against zlib over every block type, level and strategy and over damaged streams, and under AddressSanitizer with buffers
@@ -24,7 +26,9 @@
 #if defined(__HIPCC__)
 #define NPD_HD __host__ __device__ __forceinline__
 #define NPD_HD_CALL __host__ __device__ __noinline__
+#define NPD_UNROLL _Pragma("unroll")
 #else
+#define NPD_UNROLL
 #define NPD_HD inline
 #define NPD_HD_CALL inline
 #endif
@@ -33,13 +37,20 @@ namespace nplds {
 
 typedef uint64_t __attribute__((aligned(1))) u64u;
 
-// per-lane HBM scratch: code lengths while the tables are built, the symbols of both alphabets sorted by code, and for every code length the
-// exclusive upper bound of its codes (15-bit, left-justified, in the order the bits arrive) and what to add to a code to index `sorted`
+// per-lane HBM scratch: code lengths while the tables are built, and the symbols of both alphabets sorted by code (read only for codes
+// longer than the primary index)
 struct Scratch {
     uint8_t lens[320];
     uint16_t sorted_lit[288];
     uint16_t sorted_dist[32];
-    uint16_t lim_lit[16], ofs_lit[16], lim_dist[16], ofs_dist[16];
+};
+
+// 16-bit slots of a lane's table: [0, 2^LB) literal / length primaries, [2^LB, 2^LB + 2^DB) distance primaries, then for every code length
+// above the primary index the exclusive upper bound of its codes (15-bit, left-justified, in the order the bits arrive) and what to add
+// to a code to index `sorted` -- literals / lengths first, then distances
+template <int LB, int DB> struct Layout {
+    static constexpr uint32_t LIT0 = 0, DIST0 = 1u << LB, NL = 15 - LB, ND = 15 - DB;
+    static constexpr uint32_t LIM_LIT = DIST0 + (1u << DB), OFS_LIT = LIM_LIT + NL, LIM_DIST = OFS_LIT + NL, OFS_DIST = LIM_DIST + ND, SLOTS = OFS_DIST + ND;
 };
 
 NPD_HD uint32_t len_base(uint32_t i) {      // RFC 1951 3.2.5, computed
@@ -69,10 +80,11 @@ NPD_HD uint32_t rev32(uint32_t v) {
 #endif
 }
 
-// Canonical code from lens[0 .. n_sym): primary slots [base, base + 2^bits) of `tab` for the codes of up to `bits` bits, the per-length
-// arrays and the sorted symbols for the others.  false: over-subscribed code.
+// Canonical code from lens[0 .. n_sym): primary slots [base, base + 2^bits) of `tab` for the codes of up to `bits` bits; for the lengths
+// above aux_bits (the width of the region's own primary index; bits <= aux_bits) the bound and offset slots at lim0 / ofs0; the sorted
+// symbols.  false: over-subscribed code.
 template <class Tab>
-NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& tab, uint32_t base, uint16_t* sorted, uint16_t* lim, uint16_t* ofs) {
+NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& tab, uint32_t base, uint16_t* sorted, uint32_t aux_bits, uint32_t lim0, uint32_t ofs0) {
     uint32_t count[16];
     for (int i = 0; i < 16; ++i) count[i] = 0;
     for (uint32_t s = 0; s < n_sym; ++s) ++count[lens[s] & 15u];
@@ -85,13 +97,15 @@ NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& 
     uint32_t next_code[16], next_index[16];
     uint32_t code = 0, index = 0;
     next_code[0] = next_index[0] = 0;
-    for (int len = 1; len <= 15; ++len) {
+    for (uint32_t len = 1; len <= 15; ++len) {
         code = (code + count[len - 1]) << 1;
         next_code[len] = code;
         next_index[len] = index;
-        // codes of this length, as their first 15 bits arrive: [code << (15 - len), (code + count) << (15 - len))
-        lim[len] = (uint16_t)((code + count[len]) << (15 - len));      // (<= 32768)
-        ofs[len] = (uint16_t)(index - code);
+        if (len > aux_bits) {
+            // codes of this length, as their first 15 bits arrive: [code << (15 - len), (code + count) << (15 - len))
+            tab.wr(lim0 + (len - aux_bits - 1), (uint16_t)((code + count[len]) << (15 - len)));      // (<= 32768)
+            tab.wr(ofs0 + (len - aux_bits - 1), (uint16_t)(index - code));
+        }
         index += count[len];
     }
     const uint32_t slots = 1u << bits;
@@ -110,28 +124,43 @@ NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& 
     return true;
 }
 
-// A code longer than the primary index: `peek` = the next 15 bits of the stream.  Returns symbol << 4 | length, or 0 when no code matches.
-NPD_HD uint32_t decode_long(uint32_t peek, uint32_t bits, const uint16_t* sorted, const uint16_t* lim, const uint16_t* ofs) {
+// A code longer than the primary index of BITS bits: `peek` = the next 15 bits of the stream.  Returns symbol << 4 | length, or 0 when no
+// code matches.  The bounds are read in one go (independent reads of the lane's slots), the symbol comes from the lane's scratch.
+template <int BITS, class Tab>
+NPD_HD uint32_t decode_long(uint32_t peek, const Tab& tab, uint32_t lim0, uint32_t ofs0, const uint16_t* sorted) {
     const uint32_t v = rev32(peek) >> 17;      // the 15 bits in the order they arrived, first bit on top
-    for (uint32_t len = bits + 1; len <= 15; ++len)
-        if (v < lim[len]) return (uint32_t)sorted[(uint16_t)(ofs[len] + (v >> (15 - len)))] << 4 | len;
-    return 0;
+    uint32_t lim[15 - BITS];
+NPD_UNROLL
+    for (int k = 0; k < 15 - BITS; ++k) lim[k] = tab.rd(lim0 + k);
+    uint32_t k = 0;                             // number of lengths whose codes all lie below v
+NPD_UNROLL
+    for (int j = 0; j < 15 - BITS; ++j) k += v >= lim[j] ? 1u : 0u;      // (the bounds never decrease with the length)
+    if (k >= 15u - BITS) return 0;
+    const uint32_t len = BITS + 1 + k;
+    return (uint32_t)sorted[(uint16_t)(tab.rd(ofs0 + k) + (v >> (15 - len)))] << 4 | len;
 }
 
 struct Bits {
-    const uint8_t* in;       // next byte not yet in `buf` or `next`... see refill
+    const uint8_t* in;       // where `next` was loaded from
     const uint8_t* end;
-    uint64_t buf, next;      // next = the 8 bytes at `in` (zero-extended near the end), loaded one refill ahead
+    uint64_t buf, next;      // next = the 8 bytes at `in`, loaded one refill ahead
     uint32_t cnt;
     uint32_t taken;          // bits consumed so far (to tell a stream that ran past its end)
+    // On the device the 8 bytes at any address up to `end` are readable (the compressed blocks of a launch lie in one buffer with a pad behind
+    // the last; what is read behind a stream's end is never used by a stream that is intact, and `taken` convicts one that is not); on the
+    // host (tests: buffers of exactly the stream's size) bytes behind the end read as zero.
     NPD_HD uint64_t load(const uint8_t* p) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return *reinterpret_cast<const u64u*>(p);
+#else
         if (end - p >= 8) return *reinterpret_cast<const u64u*>(p);
         uint64_t v = 0;
         for (int i = 0; p + i < end; ++i) v |= (uint64_t)p[i] << (8 * i);
         return v;
+#endif
     }
     NPD_HD void start(const uint8_t* s, uint32_t n) { in = s; end = s + n; buf = 0; cnt = 0; taken = 0; next = load(in); }
-    // tops the buffer up to >= 56 bits.  Bytes behind the end of the stream read as zero (the caller checks `taken` against the stream's length).
+    // tops the buffer up to >= 56 bits
     NPD_HD void refill() {
         buf |= next << cnt;
         const uint32_t k = (63 - cnt) >> 3;
@@ -144,24 +173,45 @@ struct Bits {
     NPD_HD uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
 };
 
-// src[0 .. src_len): raw DEFLATE stream; dst[0 .. dst_len): its output; tab: 2^LB + 2^DB 16-bit slots; sc: the lane's scratch.
-template <int LB, int DB, class Tab>
+// eight bytes of the endless repetition of the low `period` bytes of p (1 <= period < 8), starting `phase` bytes into it (phase < period)
+NPD_HD uint64_t periodic(uint64_t p, uint32_t period, uint32_t phase) {
+    uint64_t w = 0;
+    uint32_t k = phase;
+NPD_UNROLL
+    for (int j = 0; j < 8; ++j) {
+        w |= ((p >> (8 * k)) & 0xffull) << (8 * j);
+        if (++k == period) k = 0;
+    }
+    return w;
+}
+
+// src[0 .. src_len): raw DEFLATE stream; dst[0 .. dst_len): its output; tab: Layout<LB, DB>::SLOTS 16-bit slots; sc: the lane's scratch.
+// (DBG: timing experiments only -- bit 0 drops the literal stores, bit 1 the match copies: wrong output)
+template <int LB, int DB, class Tab, int DBG = 0>
 NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uint32_t dst_len, Tab& tab, Scratch* sc) {
-    constexpr uint32_t LIT0 = 0, DIST0 = 1u << LB;
+    typedef Layout<LB, DB> Y;
+    constexpr int CLB = 7 <= LB ? 7 : LB;      // primary bits of the code-length alphabet (its codes have up to 7 bits)
     Bits b;
     b.start(src, src_len);
     uint8_t* out = dst;                    // everything below `out` is in memory
     uint8_t* const out_end = dst + dst_len;
     uint64_t pend = 0;                     // literals not yet stored: bytes out[0 .. npend)
     uint32_t npend = 0;
+    // The last bytes of the output so far, pending ones included, newest on top; the top `nvalid` bytes are known.  A match at a distance
+    // of 1 .. 7 -- the runs base qualities are made of -- is written from here: no load from memory that was stored a moment ago (on the
+    // device such a load waits for the stores before it, a trip to L2 and back per match).
+    uint64_t last8 = 0;
+    uint32_t nvalid = 0;
     const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     uint8_t* const lens = sc->lens;
     // the pending literals to memory (an 8-byte store when that stays inside the block: the bytes above the pending ones are this lane's
     // own future output, written again later)
     auto flush = [&]() {
         if (!npend) return;
-        if ((size_t)(out_end - out) >= 8) *reinterpret_cast<u64u*>(out) = pend;
-        else for (uint32_t i = 0; i < npend; ++i) out[i] = (uint8_t)(pend >> (8 * i));
+        if (!(DBG & 1)) {
+            if ((size_t)(out_end - out) >= 8) *reinterpret_cast<u64u*>(out) = pend;
+            else for (uint32_t i = 0; i < npend; ++i) out[i] = (uint8_t)(pend >> (8 * i));
+        }
         out += npend;
         pend = 0;
         npend = 0;
@@ -180,6 +230,7 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
             if ((size_t)(b.end - p) < len || (size_t)(out_end - out) < len) return 3;
             for (uint32_t i = 0; i < len; ++i) out[i] = p[i];
             out += len;
+            if (len) nvalid = 0;
             const uint32_t done = b.taken + 8u * len;
             b.start(p + len, (uint32_t)(b.end - (p + len)));
             b.taken = done;
@@ -190,9 +241,9 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
             for (int i = 144; i < 256; ++i) lens[i] = 9;
             for (int i = 256; i < 280; ++i) lens[i] = 7;
             for (int i = 280; i < 288; ++i) lens[i] = 8;
-            if (!build(lens, 288, LB, tab, LIT0, sc->sorted_lit, sc->lim_lit, sc->ofs_lit)) return 11;
+            if (!build(lens, 288, LB, tab, Y::LIT0, sc->sorted_lit, LB, Y::LIM_LIT, Y::OFS_LIT)) return 11;
             for (int i = 0; i < 32; ++i) lens[i] = 5;
-            if (!build(lens, 32, DB, tab, DIST0, sc->sorted_dist, sc->lim_dist, sc->ofs_dist)) return 12;
+            if (!build(lens, 32, DB, tab, Y::DIST0, sc->sorted_dist, DB, Y::LIM_DIST, Y::OFS_DIST)) return 12;
         } else if (type == 2) {
             const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
             if (hlit > 286 || hdist > 30) return 5;
@@ -202,13 +253,14 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
                 if (b.cnt < 3) b.refill();
                 cl[kClOrder[i]] = (uint8_t)b.take(3);
             }
-            // the code-length alphabet (codes of up to 7 bits) borrows the head of the literal table and the distance alphabet's arrays
-            if (!build(cl, 19, 7 <= LB ? 7 : LB, tab, LIT0, sc->sorted_dist, sc->lim_dist, sc->ofs_dist)) return 6;
+            // the code-length alphabet borrows the head of the literal table, the literal alphabet's bound / offset slots and the distance
+            // alphabet's sorted symbols (all three are built afterwards)
+            if (!build(cl, 19, CLB, tab, Y::LIT0, sc->sorted_dist, LB, Y::LIM_LIT, Y::OFS_LIT)) return 6;
             uint32_t n = 0;
             while (n < hlit + hdist) {
                 if (b.cnt < 32) b.refill();
-                uint32_t e = tab.rd(LIT0 + b.peek(7 <= LB ? 7 : LB));
-                if (!(e & 15u)) e = decode_long(b.peek(15), 7 <= LB ? 7 : LB, sc->sorted_dist, sc->lim_dist, sc->ofs_dist);
+                uint32_t e = tab.rd(Y::LIT0 + b.peek(CLB));
+                if (!(e & 15u) && CLB < 7) e = decode_long<LB>(b.peek(15), tab, Y::LIM_LIT, Y::OFS_LIT, sc->sorted_dist);
                 if (!(e & 15u)) return 7;
                 b.drop(e & 15u);
                 const uint32_t sym = e >> 4;
@@ -222,8 +274,8 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
                 n += rep;
             }
             if (b.taken > 8u * src_len || lens[256] == 0) return 10;
-            if (!build(lens + hlit, hdist, DB, tab, DIST0, sc->sorted_dist, sc->lim_dist, sc->ofs_dist)) return 12;
-            if (!build(lens, hlit, LB, tab, LIT0, sc->sorted_lit, sc->lim_lit, sc->ofs_lit)) return 11;
+            if (!build(lens + hlit, hdist, DB, tab, Y::DIST0, sc->sorted_dist, DB, Y::LIM_DIST, Y::OFS_DIST)) return 12;
+            if (!build(lens, hlit, LB, tab, Y::LIT0, sc->sorted_lit, LB, Y::LIM_LIT, Y::OFS_LIT)) return 11;
         } else {
             return 4;
         }
@@ -231,9 +283,9 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
         // code and its extra bits (<= 28) can be taken without looking at the count again.
         for (;;) {
             if (b.cnt < 32) b.refill();
-            uint32_t e = tab.rd(LIT0 + b.peek(LB));
+            uint32_t e = tab.rd(Y::LIT0 + b.peek(LB));
             if (!(e & 15u)) {
-                e = decode_long(b.peek(15), LB, sc->sorted_lit, sc->lim_lit, sc->ofs_lit);
+                e = decode_long<LB>(b.peek(15), tab, Y::LIM_LIT, Y::OFS_LIT, sc->sorted_lit);
                 if (!(e & 15u)) return 14;
             }
             b.drop(e & 15u);
@@ -241,28 +293,76 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
             if (sym < 256) {
                 if ((size_t)(out_end - out) <= npend) return 13;
                 pend |= (uint64_t)sym << (8 * npend);
-                if (++npend == 8) { *reinterpret_cast<u64u*>(out) = pend; out += 8; pend = 0; npend = 0; }
+                last8 = last8 >> 8 | (uint64_t)sym << 56;
+                nvalid = nvalid < 8 ? nvalid + 1 : 8;
+                if (++npend == 8) { if (!(DBG & 1)) *reinterpret_cast<u64u*>(out) = pend; out += 8; pend = 0; npend = 0; }
                 continue;
             }
             if (sym == 256) break;
             if (sym > 285) return 14;
             const uint32_t len = len_base(sym - 257) + b.take(len_extra(sym - 257));
             if (b.cnt < 32) b.refill();
-            uint32_t d = tab.rd(DIST0 + b.peek(DB));
+            uint32_t d = tab.rd(Y::DIST0 + b.peek(DB));
             if (!(d & 15u)) {
-                d = decode_long(b.peek(15), DB, sc->sorted_dist, sc->lim_dist, sc->ofs_dist);
+                d = decode_long<DB>(b.peek(15), tab, Y::LIM_DIST, Y::OFS_DIST, sc->sorted_dist);
                 if (!(d & 15u)) return 15;
             }
             b.drop(d & 15u);
             if ((d >> 4) > 29) return 15;
             const uint32_t off = dist_base(d >> 4) + b.take(dist_extra(d >> 4));
+            if (off > (size_t)(out - dst) + npend || len > (size_t)(out_end - out) - npend) return 16;
+            if (off <= nvalid && off < 8) {
+                // ---- a run: the period is the top `off` bytes of last8
+                flush();
+                const uint64_t x = off == 1 ? (last8 >> 56) * 0x0101010101010101ull : periodic(last8 >> (8 * (8 - off)), off, 0);
+                if (!(DBG & 2)) {
+                    // whole words, each starting at the head of a period; what a word writes beyond the run is this lane's own future output
+                    const uint32_t step = off == 3 || off == 6 ? 6u : off == 5 ? 5u : off == 7 ? 7u : 8u;
+                    uint32_t done = 0;
+                    for (; done < len && (size_t)(out_end - (out + done)) >= 8; done += step) *reinterpret_cast<u64u*>(out + done) = x;
+                    if (done < len) {      // the end of the block: byte by byte
+                        uint32_t k = done % off;
+                        for (uint32_t i = done; i < len; ++i) { out[i] = (uint8_t)(x >> (8 * k)); if (++k == off) k = 0; }
+                    }
+                }
+                out += len;
+                if (len >= 8) { last8 = off == 1 ? x : periodic(x, off, (len - 8) % off); nvalid = 8; }
+                else { last8 = last8 >> (8 * len) | x << (8 * (8 - len)); nvalid = nvalid + len < 8 ? nvalid + len : 8; }
+                continue;
+            }
+            nvalid = 0;
+            // ---- a copy from memory (as in np_inflate_lane.h: every load that may alias an earlier store of the lane waits for the memory round
+            // trip, so sources far enough away are taken four words at a time).  When the first 32 source bytes lie wholly below the pending
+            // literals they are loaded BEFORE those are stored, so that the load does not queue behind that store.
+            if (off >= 40 && (size_t)(out_end - out) - npend >= (size_t)len + 32) {
+                const uint8_t* from = out + npend - off;
+                const uint64_t w0 = *reinterpret_cast<const u64u*>(from), w1 = *reinterpret_cast<const u64u*>(from + 8);
+                const uint64_t w2 = *reinterpret_cast<const u64u*>(from + 16), w3 = *reinterpret_cast<const u64u*>(from + 24);
+                flush();
+                if (!(DBG & 2)) {
+                    uint8_t* o = out;
+                    const uint8_t* const stop = out + len;
+                    *reinterpret_cast<u64u*>(o) = w0; *reinterpret_cast<u64u*>(o + 8) = w1;
+                    *reinterpret_cast<u64u*>(o + 16) = w2; *reinterpret_cast<u64u*>(o + 24) = w3;
+                    from += 32;
+                    o += 32;
+                    while (o < stop) {
+                        const uint64_t v0 = *reinterpret_cast<const u64u*>(from), v1 = *reinterpret_cast<const u64u*>(from + 8);
+                        const uint64_t v2 = *reinterpret_cast<const u64u*>(from + 16), v3 = *reinterpret_cast<const u64u*>(from + 24);
+                        *reinterpret_cast<u64u*>(o) = v0; *reinterpret_cast<u64u*>(o + 8) = v1;
+                        *reinterpret_cast<u64u*>(o + 16) = v2; *reinterpret_cast<u64u*>(o + 24) = v3;
+                        from += 32;
+                        o += 32;
+                    }
+                }
+                out += len;
+                continue;
+            }
             flush();
-            if (off > (size_t)(out - dst) || len > (size_t)(out_end - out)) return 16;
             const uint8_t* from = out - off;
-            // The copy (as in np_inflate_lane.h): every load that may alias an earlier store of the lane waits for the memory round trip, so
-            // sources far enough away are taken four words at a time, a short period (offset < 8) is loaded ONCE and written out as stores.
             const size_t room = (size_t)(out_end - out);
-            if (off >= 32 && room >= (size_t)len + 32) {
+            if (DBG & 2) {
+            } else if (off >= 32 && room >= (size_t)len + 32) {
                 uint8_t* o = out;
                 const uint8_t* const stop = out + len;
                 do {
@@ -281,7 +381,7 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
                     from += 8;
                     o += 8;
                 } while (o < stop);
-            } else if (off < 8 && (size_t)(out - dst) >= 8) {   // a period of 1 .. 7 bytes: the last eight bytes hold at least one whole period
+            } else if (off < 8 && (size_t)(out - dst) >= 8) {   // a period of 1 .. 7 bytes whose bytes are not in last8: the last eight bytes in memory hold it
                 const uint64_t tail = *reinterpret_cast<const u64u*>(out - 8);
                 const uint32_t first = 8u - off;              // byte of `tail` that is from[0]
                 uint32_t k = 0;

@@ -253,10 +253,10 @@ def test_lane_per_block_decoder_and_compact_upload_form_in_processes_of_their_ow
     here = os.path.dirname(os.path.abspath(__file__))
     runs = [(dict(NP1_INFLATE="lanes", NP1_INFLATE_LANES="1000"),
              ["tests/test_gpu_ingest.py", "-k", "equals_host_loader or real_bwa or samtools_written or corrupt_block or rejects_damaged"]),
-            # the lane decoder with its tables in LDS (np_inflate_lds.h, round 6) in both table sizes, on every kind of block too
-            (dict(NP1_INFLATE="lds"),
+            # the lane decoder with its tables in LDS (np_inflate_lds.h, round 6) in two table sizes (8 / 5 bits: the default of the family; 6 / 5 bits: most codes take the long-code path), on every kind of block too
+            (dict(NP1_INFLATE="lds85"),
              ["tests/test_gpu_ingest.py", "-k", "every_block_type or equals_host_loader or real_bwa or samtools_written or corrupt_block or rejects_damaged"]),
-            (dict(NP1_INFLATE="lds96"),
+            (dict(NP1_INFLATE="lds65"),
              ["tests/test_gpu_ingest.py", "-k", "every_block_type or equals_host_loader or real_bwa or samtools_written or corrupt_block or rejects_damaged"]),
             (dict(NP1_COMPACT_MIN="64"),
              ["tests/test_gpu_score_chain.py", "tests/test_snp_valid.py", "-k",

@@ -53,8 +53,8 @@ def run(path):
             bad += want != out[at:at + isz].tobytes()
         at += isz
     md5 = hashlib.md5(out[:nout].tobytes()).hexdigest() if not rej else "-"
-    print("%-6s %d blocks, %.1f MB -> %.1f MB in %.2f ms = %.1f GB/s out, %.1f GB/s in+out; rejected %d; sample vs zlib: %d differ; md5 %s"
-          % (os.environ.get("NP1_INFLATE", "auto"), nb, len(buf) / 1e6, nout / 1e6, best, nout / best / 1e6, (nout + len(buf)) / best / 1e6, rej, bad, md5), flush=True)
+    print("%-6s dbg=%s %d blocks, %.1f MB -> %.1f MB in %.2f ms = %.1f GB/s out, %.1f GB/s in+out; rejected %d; sample vs zlib: %d differ; md5 %s"
+          % (os.environ.get("NP1_INFLATE", "auto"), os.environ.get("NP1_LDS_DBG", "0"), nb, len(buf) / 1e6, nout / 1e6, best, nout / best / 1e6, (nout + len(buf)) / best / 1e6, rej, bad, md5), flush=True)
 
 
 if __name__ == "__main__":
@@ -66,5 +66,6 @@ if __name__ == "__main__":
     modes = (sys.argv[3] if len(sys.argv) > 3 else "lanes,lds,lds96,wave").split(",")
     path = make_bam(wq, contigs)
     print("qualities mode %d, %d contigs of 2.5 Mb at 30x: %s, %.1f MB" % (wq, contigs, path, os.path.getsize(path) / 1e6), flush=True)
-    for m in modes:
-        subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path], env=dict(os.environ, NP1_INFLATE=m), check=False)
+    for m in modes:      # "lds85:3" = NP1_INFLATE=lds85 with NP1_LDS_DBG=3 (timing experiments: parts of the work left out, wrong output)
+        mm, _, dbg = m.partition(":")
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path], env=dict(os.environ, NP1_INFLATE=mm, NP1_LDS_DBG=dbg or "0"), check=False)
