@@ -140,33 +140,54 @@ NPD_UNROLL
     return (uint32_t)sorted[(uint16_t)(tab.rd(ofs0 + k) + (v >> (15 - len)))] << 4 | len;
 }
 
+// The bit reader.  The stream's bytes come through a WINDOW OF REGISTERS: five 8-byte words w0..w4 = the stream's bytes [base, base + 40) and
+// the four words behind them (n0..n3), loaded one window ahead.  A refill takes its eight bytes out of the window with shifts and selects --
+// no memory access -- and only every 32 bytes of input does the window slide (w0 = w4, w1..w4 = n0..n3, four new loads issued).  Why: on
+// this hardware a wait for a load is also a wait for every store issued before it (one in-order counter), so the refill of round 6's first
+// versions -- one load per ~3 symbols -- queued behind the output stores again and again (profiles/r6_inflate_lds.txt).
 struct Bits {
-    const uint8_t* in;       // where `next` was loaded from
-    const uint8_t* end;
-    uint64_t buf, next;      // next = the 8 bytes at `in`, loaded one refill ahead
+    const uint8_t* src;      // the stream
+    uint32_t len;            // its length
+    uint32_t base;           // offset of w0 in the stream
+    uint32_t pos;            // offset from `base` of the next byte that is not yet in `buf` (< 32 between refills)
+    uint64_t w0, w1, w2, w3, w4, n0, n1, n2, n3;
+    uint64_t buf;
     uint32_t cnt;
     uint32_t taken;          // bits consumed so far (to tell a stream that ran past its end)
-    // On the device the 8 bytes at any address up to `end` are readable (the compressed blocks of a launch lie in one buffer with a pad behind
-    // the last; what is read behind a stream's end is never used by a stream that is intact, and `taken` convicts one that is not); on the
-    // host (tests: buffers of exactly the stream's size) bytes behind the end read as zero.
-    NPD_HD uint64_t load(const uint8_t* p) const {
+    // The 8 bytes at offset `at` (clamped to the stream's end).  On the device the 8 bytes at any address up to the end are readable (the
+    // compressed blocks of a launch lie in one buffer with a pad behind the last; what is read behind a stream's end is never used by a stream
+    // that is intact, and `taken` convicts one that is not); on the host (tests: buffers of exactly the stream's size) they read as zero.
+    NPD_HD uint64_t load(uint32_t at) const {
+        if (at > len) at = len;
 #if defined(__HIP_DEVICE_COMPILE__)
-        return *reinterpret_cast<const u64u*>(p);
+        return *reinterpret_cast<const u64u*>(src + at);
 #else
-        if (end - p >= 8) return *reinterpret_cast<const u64u*>(p);
+        if (len - at >= 8) return *reinterpret_cast<const u64u*>(src + at);
         uint64_t v = 0;
-        for (int i = 0; p + i < end; ++i) v |= (uint64_t)p[i] << (8 * i);
+        for (uint32_t i = 0; at + i < len; ++i) v |= (uint64_t)src[at + i] << (8 * i);
         return v;
 #endif
     }
-    NPD_HD void start(const uint8_t* s, uint32_t n) { in = s; end = s + n; buf = 0; cnt = 0; taken = 0; next = load(in); }
+    NPD_HD void start(const uint8_t* s, uint32_t n) {
+        src = s; len = n; base = 0; pos = 0; buf = 0; cnt = 0; taken = 0;
+        w0 = load(0); w1 = load(8); w2 = load(16); w3 = load(24); w4 = load(32);
+        n0 = load(40); n1 = load(48); n2 = load(56); n3 = load(64);
+    }
     // tops the buffer up to >= 56 bits
     NPD_HD void refill() {
-        buf |= next << cnt;
-        const uint32_t k = (63 - cnt) >> 3;
-        in = (size_t)(end - in) > k ? in + k : end;
+        const uint32_t i = pos >> 3, sh = (pos & 7u) * 8u;
+        const uint64_t lo = i == 0 ? w0 : i == 1 ? w1 : i == 2 ? w2 : w3;
+        const uint64_t hi = i == 0 ? w1 : i == 1 ? w2 : i == 2 ? w3 : w4;
+        const uint64_t v = sh ? lo >> sh | hi << (64u - sh) : lo;
+        buf |= v << cnt;
+        pos += (63 - cnt) >> 3;
         cnt |= 56;
-        next = load(in);
+        if (pos >= 32) {      // slide: the words loaded a window ago become the window, the next four are asked for
+            w0 = w4; w1 = n0; w2 = n1; w3 = n2; w4 = n3;
+            base += 32;
+            pos -= 32;
+            n0 = load(base + 40); n1 = load(base + 48); n2 = load(base + 56); n3 = load(base + 64);
+        }
     }
     NPD_HD uint32_t peek(uint32_t n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
     NPD_HD void drop(uint32_t n) { buf >>= n; cnt -= n; taken += n; }
@@ -216,6 +237,28 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
         pend = 0;
         npend = 0;
     };
+    // Copies whose source bytes have been asked for but not yet stored (at most two).  A match that reads memory costs a trip to L2 or HBM
+    // and back, and 3 800 of the 5 800 symbols of a BAM block are such matches (profiles/r6_inflate_lds.txt): instead of waiting for each, the
+    // loads of a short match are issued and the decoder goes on; when a second one has been issued, or something needs the bytes (a match that
+    // reads them, the end of the block), ONE wait brings both in and they are stored -- exactly their bytes, because what lies behind them
+    // may already be in memory.
+    uint8_t *pc0_d = nullptr, *pc1_d = nullptr;
+    uint32_t pc0_n = 0, pc1_n = 0, npc = 0;
+    uint64_t pc0_a = 0, pc0_b = 0, pc0_c = 0, pc0_e = 0, pc1_a = 0, pc1_b = 0, pc1_c = 0, pc1_e = 0;
+    auto store_exact = [&](uint8_t* d, uint32_t n, uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3) {
+        if (DBG & 2) return;
+        uint64_t tail = a0;
+        if (n >= 8) { *reinterpret_cast<u64u*>(d) = a0; d += 8; n -= 8; tail = a1; }
+        if (n >= 8) { *reinterpret_cast<u64u*>(d) = a1; d += 8; n -= 8; tail = a2; }
+        if (n >= 8) { *reinterpret_cast<u64u*>(d) = a2; d += 8; n -= 8; tail = a3; }
+        if (n >= 8) { *reinterpret_cast<u64u*>(d) = a3; d += 8; n -= 8; tail = 0; }
+        for (uint32_t i = 0; i < n; ++i) d[i] = (uint8_t)(tail >> (8 * i));
+    };
+    auto drain = [&]() {
+        if (npc >= 1) store_exact(pc0_d, pc0_n, pc0_a, pc0_b, pc0_c, pc0_e);
+        if (npc >= 2) store_exact(pc1_d, pc1_n, pc1_a, pc1_b, pc1_c, pc1_e);
+        npc = 0;
+    };
     for (;;) {
         b.refill();
         const uint32_t final_block = b.take(1), type = b.take(2);
@@ -225,14 +268,15 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
             const uint32_t len = b.take(16), nlen = b.take(16);
             if ((len ^ 0xffffu) != nlen) return 2;
             if (b.taken > 8u * src_len) return 17;
+            drain();
             flush();
-            const uint8_t* p = src + (b.taken >> 3);      // (byte aligned here)
-            if ((size_t)(b.end - p) < len || (size_t)(out_end - out) < len) return 3;
-            for (uint32_t i = 0; i < len; ++i) out[i] = p[i];
+            const uint32_t at = b.taken >> 3;      // (byte aligned here)
+            if (src_len - at < len || (size_t)(out_end - out) < len) return 3;
+            for (uint32_t i = 0; i < len; ++i) out[i] = src[at + i];
             out += len;
             if (len) nvalid = 0;
             const uint32_t done = b.taken + 8u * len;
-            b.start(p + len, (uint32_t)(b.end - (p + len)));
+            b.start(src + at + len, src_len - at - len);
             b.taken = done;
             if (final_block) break;
             continue;
@@ -331,33 +375,30 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
                 continue;
             }
             nvalid = 0;
-            // ---- a copy from memory (as in np_inflate_lane.h: every load that may alias an earlier store of the lane waits for the memory round
-            // trip, so sources far enough away are taken four words at a time).  When the first 32 source bytes lie wholly below the pending
-            // literals they are loaded BEFORE those are stored, so that the load does not queue behind that store.
-            if (off >= 40 && (size_t)(out_end - out) - npend >= (size_t)len + 32) {
+            // ---- a copy from memory.  Short, not overlapping itself, its 32 source bytes inside the block: deferred (see above).
+            {
                 const uint8_t* from = out + npend - off;
-                const uint64_t w0 = *reinterpret_cast<const u64u*>(from), w1 = *reinterpret_cast<const u64u*>(from + 8);
-                const uint64_t w2 = *reinterpret_cast<const u64u*>(from + 16), w3 = *reinterpret_cast<const u64u*>(from + 24);
-                flush();
-                if (!(DBG & 2)) {
-                    uint8_t* o = out;
-                    const uint8_t* const stop = out + len;
-                    *reinterpret_cast<u64u*>(o) = w0; *reinterpret_cast<u64u*>(o + 8) = w1;
-                    *reinterpret_cast<u64u*>(o + 16) = w2; *reinterpret_cast<u64u*>(o + 24) = w3;
-                    from += 32;
-                    o += 32;
-                    while (o < stop) {
-                        const uint64_t v0 = *reinterpret_cast<const u64u*>(from), v1 = *reinterpret_cast<const u64u*>(from + 8);
-                        const uint64_t v2 = *reinterpret_cast<const u64u*>(from + 16), v3 = *reinterpret_cast<const u64u*>(from + 24);
-                        *reinterpret_cast<u64u*>(o) = v0; *reinterpret_cast<u64u*>(o + 8) = v1;
-                        *reinterpret_cast<u64u*>(o + 16) = v2; *reinterpret_cast<u64u*>(o + 24) = v3;
-                        from += 32;
-                        o += 32;
+                if (len <= 32 && off >= len && (size_t)(out_end - from) >= 32) {
+                    bool dep = false;      // does it read bytes of a pending copy?
+                    if (npc >= 1) dep = dep || (from < pc0_d + pc0_n && from + len > pc0_d);
+                    if (npc >= 2) dep = dep || (from < pc1_d + pc1_n && from + len > pc1_d);
+                    if (dep || npc == 2) drain();
+                    if (from + len > out) flush();      // it reads pending literals: they go to memory first
+                    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    if (!(DBG & 2)) {
+                        a0 = *reinterpret_cast<const u64u*>(from); a1 = *reinterpret_cast<const u64u*>(from + 8);
+                        a2 = *reinterpret_cast<const u64u*>(from + 16); a3 = *reinterpret_cast<const u64u*>(from + 24);
                     }
+                    flush();                              // (behind the loads: they do not queue behind this store)
+                    if (npc == 0) { pc0_d = out; pc0_n = len; pc0_a = a0; pc0_b = a1; pc0_c = a2; pc0_e = a3; }
+                    else { pc1_d = out; pc1_n = len; pc1_a = a0; pc1_b = a1; pc1_c = a2; pc1_e = a3; }
+                    ++npc;
+                    out += len;
+                    continue;
                 }
-                out += len;
-                continue;
             }
+            // ---- every other copy from memory, at once (as in np_inflate_lane.h: sources far enough away four words at a time)
+            drain();
             flush();
             const uint8_t* from = out - off;
             const size_t room = (size_t)(out_end - out);
@@ -397,6 +438,7 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
         if (b.taken > 8u * src_len) return 17;
         if (final_block) break;
     }
+    drain();
     flush();
     return (b.taken <= 8u * src_len && out == out_end) ? 0 : 19;
 }
