@@ -1,24 +1,25 @@
-// Raw DEFLATE (RFC 1951) decoder for whole BGZF blocks, ONE LANE PER BLOCK, DECODE TABLES IN LDS (round 6).
+// Raw DEFLATE (RFC 1951) decoder for whole BGZF blocks, ONE LANE PER BLOCK, written for a machine whose lanes run in lockstep (round 6).
 //
-// np_inflate_lane.h gave every lane a 12 KB table slice in HBM and counted on the number of lanes in flight: with 40 000 blocks per
-// launch the hot entries of all lanes (~5 KB each) are 200 MB -- beyond every cache -- so each symbol costs a dependent trip to MALL or
-// HBM (measured: 77 ms for 40 k blocks, ~7 000 cycles per symbol and lane, 40 GB/s).  Here the tables a symbol
-// normally needs are small enough to live in LDS:
-//   * one 16-bit entry per primary slot (symbol << 4 | code length), 2^LB slots for literals / lengths and 2^DB for distances, laid
-//     out [slot][lane] so that the 64 lanes of a wave, each reading a slot of its own table, meet different banks (two lanes per
-//     dword: at most a two-way conflict);
-//   * codes longer than the primary index are decoded canonically: per code length the upper bound of its codes and an offset (a few
-//     more LDS slots of the lane, read in one go), then the symbol from the symbols sorted by code, in a 1 KB per-lane slice of HBM
-//     scratch that stays in L2 (a few waves per CU: tens of thousands of lanes in flight, of whose slices a lane touches a few lines);
-//   * the bit buffer is refilled from a word loaded one refill ahead, literals are gathered in a register and leave as 8-byte stores;
-//   * the last eight output bytes are kept in a register, and a match at a distance of 1 .. 7 -- the runs base qualities consist of -- is
-//     written from there: measured (profiles/r6_inflate_lds.txt), copies that read back what the lane had just stored were 60 % of the
-//     decoder's time, each one a trip to L2 and back behind the stores before it.
-// A symbol then costs one LDS lookup plus ~40 instructions instead of a trip to HBM.  The code is ordinary C++ over a table policy
-// (`Tab`: rd / wr of a 16-bit slot): the device instantiates it over LDS, the host over a plain array -- tests/test_inflate.py runs the
-// host build against zlib over every block type, level and strategy and over damaged streams, and under AddressSanitizer with buffers
-// of exactly the streams' sizes (no byte outside [src, src + src_len) is read, none outside [dst, dst + dst_len) written).
-// Returns 0 when exactly dst_len bytes came out of the stream, else an error code (the caller inflates refused blocks on the host).
+// np_inflate_lane.h is a sequential decoder per lane: tables in a 12 KB slice of HBM per lane, one load per table lookup and refill, every
+// match copied at once.  Measured (profiles/r6_inflate_lds.txt): with 40 000 blocks per launch a launch takes as long as ONE lane needs for
+// ONE 64 KiB block, ~42 ms, i.e. ~7 us per symbol -- because the 64 lanes of a wave are each at a different kind of symbol, the wave runs
+// the union of all paths in every iteration, and every path that waits for memory (table lookup, refill, each of the copy loops: 3 800 of the
+// 5 800 symbols of a BAM block are matches that read back what the lane wrote) stalls all 64 lanes.  Moving the tables to LDS alone changed
+// nothing, deferring copies on top of the old structure made it slower (more paths).  So the symbol loop here has a fixed shape with ONE
+// place where it waits for memory:
+//     (a) a lane with bytes of a match still to copy asks for the next <= 32 of them (loads, no wait);
+//     (b) a lane that has no more bytes to ask for decodes its next symbol -- registers and LDS only: the primary tables are 16-bit slots in
+//         LDS laid out [slot][lane] (two lanes per dword: at most a two-way bank conflict), codes longer than the primary index are decoded
+//         canonically from per-length bounds and the first symbols of the sorted order, also in LDS; the stream's bytes come out of a window
+//         of registers; a literal goes into a register that leaves as an 8-byte store when full (a store is not waited for); a match at a
+//         distance of 1 .. 7 whose period is known is written from a register copy of the last eight bytes;
+//     (c) the wait: the bytes asked for in (a) arrive -- while (b) ran -- and are stored, exactly their count (what follows them may already
+//         be in memory); the input window slides when 16 of its bytes are used (the words it takes in were asked for an iteration ago).
+// The code is ordinary C++ over a table policy (`Tab`: rd / wr of a 16-bit slot): the device instantiates it over LDS, the host over a plain
+// array -- tests/test_inflate.py runs the host build against zlib over every block type, level and strategy and over damaged streams, and
+// under AddressSanitizer with buffers of exactly the streams' sizes (no byte outside [src, src + src_len) is read, none outside
+// [dst, dst + dst_len) written).  Returns 0 when exactly dst_len bytes came out of the stream, else an error code (the caller inflates
+// refused blocks on the host: a refusal costs time, never correctness).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -37,21 +38,27 @@ namespace nplds {
 
 typedef uint64_t __attribute__((aligned(1))) u64u;
 
-// per-lane HBM scratch: code lengths while the tables are built, and the symbols of both alphabets sorted by code (read only for codes
-// longer than the primary index)
+// per-lane HBM scratch: code lengths while the tables are built, and the symbols of both alphabets sorted by code (read only for the rare
+// long code whose symbol is not among the first ones kept in LDS)
 struct Scratch {
     uint8_t lens[320];
     uint16_t sorted_lit[288];
     uint16_t sorted_dist[32];
 };
 
-// 16-bit slots of a lane's table: [0, 2^LB) literal / length primaries, [2^LB, 2^LB + 2^DB) distance primaries, then for every code length
-// above the primary index the exclusive upper bound of its codes (15-bit, left-justified, in the order the bits arrive) and what to add
-// to a code to index `sorted` -- literals / lengths first, then distances
-template <int LB, int DB> struct Layout {
-    static constexpr uint32_t LIT0 = 0, DIST0 = 1u << LB, NL = 15 - LB, ND = 15 - DB;
-    static constexpr uint32_t LIM_LIT = DIST0 + (1u << DB), OFS_LIT = LIM_LIT + NL, LIM_DIST = OFS_LIT + NL, OFS_DIST = LIM_DIST + ND, SLOTS = OFS_DIST + ND;
+// 16-bit slots of a lane's table.  Per alphabet: 2^bits primaries (symbol << 4 | code length, 0 = no code this short), for every code
+// length above `bits` the exclusive upper bound of its codes (15-bit, left-justified, in the order the bits arrive) and what to add to a
+// code to index the symbols sorted by code, the index of the first long symbol in that order, and the first NS long symbols themselves.
+template <int LB, int DB, int NSL = 64, int NSD = 24> struct Layout {
+    static constexpr uint32_t NL = 15 - LB, ND = 15 - DB;
+    static constexpr uint32_t LIT0 = 0, DIST0 = 1u << LB;
+    static constexpr uint32_t LIM_LIT = DIST0 + (1u << DB), OFS_LIT = LIM_LIT + NL, LONG0_LIT = OFS_LIT + NL, SORT_LIT = LONG0_LIT + 1;
+    static constexpr uint32_t LIM_DIST = SORT_LIT + NSL, OFS_DIST = LIM_DIST + ND, LONG0_DIST = OFS_DIST + ND, SORT_DIST = LONG0_DIST + 1;
+    static constexpr uint32_t SLOTS = SORT_DIST + NSD;
+    static constexpr uint32_t NS_LIT = NSL, NS_DIST = NSD;
 };
+// one alphabet's places in the table
+struct Alpha { uint32_t base, bits, lim, ofs, long0, sort, ns; };
 
 NPD_HD uint32_t len_base(uint32_t i) {      // RFC 1951 3.2.5, computed
     if (i < 8) return 3 + i;
@@ -80,11 +87,11 @@ NPD_HD uint32_t rev32(uint32_t v) {
 #endif
 }
 
-// Canonical code from lens[0 .. n_sym): primary slots [base, base + 2^bits) of `tab` for the codes of up to `bits` bits; for the lengths
-// above aux_bits (the width of the region's own primary index; bits <= aux_bits) the bound and offset slots at lim0 / ofs0; the sorted
-// symbols.  false: over-subscribed code.
+// Canonical code from lens[0 .. n_sym) into the alphabet's places: primaries for the codes of up to `bits` bits (bits <= A.bits: the code-length
+// alphabet borrows the literal alphabet's places with 7 bits), bounds and offsets for the lengths above A.bits, the first A.ns long symbols,
+// and all symbols sorted by code in `sorted`.  false: over-subscribed code.
 template <class Tab>
-NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& tab, uint32_t base, uint16_t* sorted, uint32_t aux_bits, uint32_t lim0, uint32_t ofs0) {
+NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& tab, const Alpha A, uint16_t* sorted) {
     uint32_t count[16];
     for (int i = 0; i < 16; ++i) count[i] = 0;
     for (uint32_t s = 0; s < n_sym; ++s) ++count[lens[s] & 15u];
@@ -95,62 +102,67 @@ NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& 
         if (left < 0) return false;
     }
     uint32_t next_code[16], next_index[16];
-    uint32_t code = 0, index = 0;
+    uint32_t code = 0, index = 0, long0 = 0;
     next_code[0] = next_index[0] = 0;
     for (uint32_t len = 1; len <= 15; ++len) {
         code = (code + count[len - 1]) << 1;
         next_code[len] = code;
         next_index[len] = index;
-        if (len > aux_bits) {
+        if (len == A.bits + 1) long0 = index;
+        if (len > A.bits) {
             // codes of this length, as their first 15 bits arrive: [code << (15 - len), (code + count) << (15 - len))
-            tab.wr(lim0 + (len - aux_bits - 1), (uint16_t)((code + count[len]) << (15 - len)));      // (<= 32768)
-            tab.wr(ofs0 + (len - aux_bits - 1), (uint16_t)(index - code));
+            tab.wr(A.lim + (len - A.bits - 1), (uint16_t)((code + count[len]) << (15 - len)));      // (<= 32768)
+            tab.wr(A.ofs + (len - A.bits - 1), (uint16_t)(index - code));
         }
         index += count[len];
     }
+    tab.wr(A.long0, (uint16_t)long0);
     const uint32_t slots = 1u << bits;
-    for (uint32_t i = 0; i < slots; ++i) tab.wr(base + i, 0);
+    for (uint32_t i = 0; i < slots; ++i) tab.wr(A.base + i, 0);
     for (uint32_t s = 0; s < n_sym; ++s) {
         const uint32_t len = lens[s] & 15u;
         if (!len) continue;
         const uint32_t c = next_code[len]++;
-        sorted[next_index[len]++] = (uint16_t)s;
+        const uint32_t at = next_index[len]++;
+        sorted[at] = (uint16_t)s;
+        if (len > A.bits && at - long0 < A.ns) tab.wr(A.sort + (at - long0), (uint16_t)s);
         if (len <= bits) {
             const uint32_t r = rev32(c) >> (32 - len);
             const uint16_t e = (uint16_t)(s << 4 | len);
-            for (uint32_t i = r; i < slots; i += 1u << len) tab.wr(base + i, e);
+            for (uint32_t i = r; i < slots; i += 1u << len) tab.wr(A.base + i, e);
         }
     }
     return true;
 }
 
 // A code longer than the primary index of BITS bits: `peek` = the next 15 bits of the stream.  Returns symbol << 4 | length, or 0 when no
-// code matches.  The bounds are read in one go (independent reads of the lane's slots), the symbol comes from the lane's scratch.
+// code matches.  All of it LDS (the bounds are read in one go), except a symbol beyond the first A.ns long ones.
 template <int BITS, class Tab>
-NPD_HD uint32_t decode_long(uint32_t peek, const Tab& tab, uint32_t lim0, uint32_t ofs0, const uint16_t* sorted) {
+NPD_HD uint32_t decode_long(uint32_t peek, const Tab& tab, const Alpha A, const uint16_t* sorted) {
     const uint32_t v = rev32(peek) >> 17;      // the 15 bits in the order they arrived, first bit on top
     uint32_t lim[15 - BITS];
 NPD_UNROLL
-    for (int k = 0; k < 15 - BITS; ++k) lim[k] = tab.rd(lim0 + k);
+    for (int k = 0; k < 15 - BITS; ++k) lim[k] = tab.rd(A.lim + k);
     uint32_t k = 0;                             // number of lengths whose codes all lie below v
 NPD_UNROLL
     for (int j = 0; j < 15 - BITS; ++j) k += v >= lim[j] ? 1u : 0u;      // (the bounds never decrease with the length)
     if (k >= 15u - BITS) return 0;
     const uint32_t len = BITS + 1 + k;
-    return (uint32_t)sorted[(uint16_t)(tab.rd(ofs0 + k) + (v >> (15 - len)))] << 4 | len;
+    const uint32_t at = (uint16_t)(tab.rd(A.ofs + k) + (v >> (15 - len)));
+    const uint32_t rel = at - tab.rd(A.long0);
+    const uint32_t sym = rel < A.ns ? tab.rd(A.sort + rel) : sorted[at];
+    return sym << 4 | len;
 }
 
-// The bit reader.  The stream's bytes come through a WINDOW OF REGISTERS: five 8-byte words w0..w4 = the stream's bytes [base, base + 40) and
-// the four words behind them (n0..n3), loaded one window ahead.  A refill takes its eight bytes out of the window with shifts and selects --
-// no memory access -- and only every 32 bytes of input does the window slide (w0 = w4, w1..w4 = n0..n3, four new loads issued).  Why: on
-// this hardware a wait for a load is also a wait for every store issued before it (one in-order counter), so the refill of round 6's first
-// versions -- one load per ~3 symbols -- queued behind the output stores again and again (profiles/r6_inflate_lds.txt).
+// The bit reader.  The stream's bytes come through a WINDOW OF REGISTERS: w0..w4 = the stream's bytes [base, base + 40), n0 n1 = the 16
+// behind them.  A refill takes its eight bytes out of the window with shifts and selects -- no memory access; the window slides by 16 bytes
+// (slide(), called where the symbol loop waits for memory anyway) and then asks for the next 16.
 struct Bits {
     const uint8_t* src;      // the stream
     uint32_t len;            // its length
     uint32_t base;           // offset of w0 in the stream
-    uint32_t pos;            // offset from `base` of the next byte that is not yet in `buf` (< 32 between refills)
-    uint64_t w0, w1, w2, w3, w4, n0, n1, n2, n3;
+    uint32_t pos;            // offset from `base` of the next byte that is not yet in `buf` (< 32 whenever refill runs)
+    uint64_t w0, w1, w2, w3, w4, n0, n1;
     uint64_t buf;
     uint32_t cnt;
     uint32_t taken;          // bits consumed so far (to tell a stream that ran past its end)
@@ -171,24 +183,36 @@ struct Bits {
     NPD_HD void start(const uint8_t* s, uint32_t n) {
         src = s; len = n; base = 0; pos = 0; buf = 0; cnt = 0; taken = 0;
         w0 = load(0); w1 = load(8); w2 = load(16); w3 = load(24); w4 = load(32);
-        n0 = load(40); n1 = load(48); n2 = load(56); n3 = load(64);
+        n0 = load(40); n1 = load(48);
     }
-    // tops the buffer up to >= 56 bits
+    // tops the buffer up to >= 56 bits (pos < 32 on entry; it grows by at most 7)
     NPD_HD void refill() {
+        // (the word is picked with masks, not with a chain of selects: a compiler that sees "select among five variables" turns the window
+        // into an indexed array in scratch memory -- and every refill into a load the wave has to wait for)
         const uint32_t i = pos >> 3, sh = (pos & 7u) * 8u;
-        const uint64_t lo = i == 0 ? w0 : i == 1 ? w1 : i == 2 ? w2 : w3;
-        const uint64_t hi = i == 0 ? w1 : i == 1 ? w2 : i == 2 ? w3 : w4;
-        const uint64_t v = sh ? lo >> sh | hi << (64u - sh) : lo;
+        const uint64_t m0 = 0ull - (uint64_t)(i == 0), m1 = 0ull - (uint64_t)(i == 1), m2 = 0ull - (uint64_t)(i == 2), m3 = 0ull - (uint64_t)(i >= 3);
+        const uint64_t lo = (w0 & m0) | (w1 & m1) | (w2 & m2) | (w3 & m3);
+        const uint64_t hi = (w1 & m0) | (w2 & m1) | (w3 & m2) | (w4 & m3);
+        const uint64_t v = lo >> sh | (hi << 1) << (63u - sh);
         buf |= v << cnt;
         pos += (63 - cnt) >> 3;
         cnt |= 56;
-        if (pos >= 32) {      // slide: the words loaded a window ago become the window, the next four are asked for
-            w0 = w4; w1 = n0; w2 = n1; w3 = n2; w4 = n3;
-            base += 32;
-            pos -= 32;
-            n0 = load(base + 40); n1 = load(base + 48); n2 = load(base + 56); n3 = load(base + 64);
+    }
+    // once pos >= 16: two words out, the two asked for at the previous slide in, the next two asked for.  Between two calls at most 16
+    // bytes may be consumed (a symbol with its extra bits and a distance with its: <= 6 bytes, two refills of <= 7).
+    // (The two words behind the window are asked for on EVERY call, slid or not -- the same addresses again when not: a load under a
+    // condition has to be merged with the old value of its register, and the compiler does that with a wait right behind the load.)
+    // In the symbol loop the two halves are called apart: take() right where the wave has waited for memory (it reads n0 n1), ask() behind the
+    // stores of that place (a load waits for nothing, but whoever next waits for it also waits for the stores issued before it).
+    NPD_HD void slide_take() {
+        if (pos >= 16) {
+            w0 = w2; w1 = w3; w2 = w4; w3 = n0; w4 = n1;
+            base += 16;
+            pos -= 16;
         }
     }
+    NPD_HD void slide_ask() { n0 = load(base + 40); n1 = load(base + 48); }
+    NPD_HD void slide() { slide_take(); slide_ask(); }
     NPD_HD uint32_t peek(uint32_t n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
     NPD_HD void drop(uint32_t n) { buf >>= n; cnt -= n; taken += n; }
     NPD_HD uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
@@ -206,21 +230,35 @@ NPD_UNROLL
     return w;
 }
 
+// 32 bytes at p, of which the caller uses the first n <= 32.  On the device the output buffer has slack behind its last block, so the four
+// words are read whatever n is; the host build never reads at or beyond `limit`.
+NPD_HD void load32(const uint8_t* p, const uint8_t* limit, uint64_t* a0, uint64_t* a1, uint64_t* a2, uint64_t* a3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)limit;
+    *a0 = *reinterpret_cast<const u64u*>(p); *a1 = *reinterpret_cast<const u64u*>(p + 8);
+    *a2 = *reinterpret_cast<const u64u*>(p + 16); *a3 = *reinterpret_cast<const u64u*>(p + 24);
+#else
+    uint64_t w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 32 && p + i < limit; ++i) w[i >> 3] |= (uint64_t)p[i] << (8 * (i & 7));
+    *a0 = w[0]; *a1 = w[1]; *a2 = w[2]; *a3 = w[3];
+#endif
+}
+
 // src[0 .. src_len): raw DEFLATE stream; dst[0 .. dst_len): its output; tab: Layout<LB, DB>::SLOTS 16-bit slots; sc: the lane's scratch.
 // (DBG: timing experiments only -- bit 0 drops the literal stores, bit 1 the match copies: wrong output)
 template <int LB, int DB, class Tab, int DBG = 0>
 NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uint32_t dst_len, Tab& tab, Scratch* sc) {
     typedef Layout<LB, DB> Y;
     constexpr int CLB = 7 <= LB ? 7 : LB;      // primary bits of the code-length alphabet (its codes have up to 7 bits)
+    const Alpha AL{Y::LIT0, (uint32_t)LB, Y::LIM_LIT, Y::OFS_LIT, Y::LONG0_LIT, Y::SORT_LIT, Y::NS_LIT};
+    const Alpha AD{Y::DIST0, (uint32_t)DB, Y::LIM_DIST, Y::OFS_DIST, Y::LONG0_DIST, Y::SORT_DIST, Y::NS_DIST};
     Bits b;
     b.start(src, src_len);
-    uint8_t* out = dst;                    // everything below `out` is in memory
+    uint8_t* out = dst;                    // where the next decoded byte goes, less the pending literals
     uint8_t* const out_end = dst + dst_len;
     uint64_t pend = 0;                     // literals not yet stored: bytes out[0 .. npend)
     uint32_t npend = 0;
-    // The last bytes of the output so far, pending ones included, newest on top; the top `nvalid` bytes are known.  A match at a distance
-    // of 1 .. 7 -- the runs base qualities are made of -- is written from here: no load from memory that was stored a moment ago (on the
-    // device such a load waits for the stores before it, a trip to L2 and back per match).
+    // The last bytes of the output so far, pending ones included, newest on top; the top `nvalid` bytes are known.
     uint64_t last8 = 0;
     uint32_t nvalid = 0;
     const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -237,28 +275,6 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
         pend = 0;
         npend = 0;
     };
-    // Copies whose source bytes have been asked for but not yet stored (at most two).  A match that reads memory costs a trip to L2 or HBM
-    // and back, and 3 800 of the 5 800 symbols of a BAM block are such matches (profiles/r6_inflate_lds.txt): instead of waiting for each, the
-    // loads of a short match are issued and the decoder goes on; when a second one has been issued, or something needs the bytes (a match that
-    // reads them, the end of the block), ONE wait brings both in and they are stored -- exactly their bytes, because what lies behind them
-    // may already be in memory.
-    uint8_t *pc0_d = nullptr, *pc1_d = nullptr;
-    uint32_t pc0_n = 0, pc1_n = 0, npc = 0;
-    uint64_t pc0_a = 0, pc0_b = 0, pc0_c = 0, pc0_e = 0, pc1_a = 0, pc1_b = 0, pc1_c = 0, pc1_e = 0;
-    auto store_exact = [&](uint8_t* d, uint32_t n, uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3) {
-        if (DBG & 2) return;
-        uint64_t tail = a0;
-        if (n >= 8) { *reinterpret_cast<u64u*>(d) = a0; d += 8; n -= 8; tail = a1; }
-        if (n >= 8) { *reinterpret_cast<u64u*>(d) = a1; d += 8; n -= 8; tail = a2; }
-        if (n >= 8) { *reinterpret_cast<u64u*>(d) = a2; d += 8; n -= 8; tail = a3; }
-        if (n >= 8) { *reinterpret_cast<u64u*>(d) = a3; d += 8; n -= 8; tail = 0; }
-        for (uint32_t i = 0; i < n; ++i) d[i] = (uint8_t)(tail >> (8 * i));
-    };
-    auto drain = [&]() {
-        if (npc >= 1) store_exact(pc0_d, pc0_n, pc0_a, pc0_b, pc0_c, pc0_e);
-        if (npc >= 2) store_exact(pc1_d, pc1_n, pc1_a, pc1_b, pc1_c, pc1_e);
-        npc = 0;
-    };
     for (;;) {
         b.refill();
         const uint32_t final_block = b.take(1), type = b.take(2);
@@ -268,7 +284,6 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
             const uint32_t len = b.take(16), nlen = b.take(16);
             if ((len ^ 0xffffu) != nlen) return 2;
             if (b.taken > 8u * src_len) return 17;
-            drain();
             flush();
             const uint32_t at = b.taken >> 3;      // (byte aligned here)
             if (src_len - at < len || (size_t)(out_end - out) < len) return 3;
@@ -285,26 +300,26 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
             for (int i = 144; i < 256; ++i) lens[i] = 9;
             for (int i = 256; i < 280; ++i) lens[i] = 7;
             for (int i = 280; i < 288; ++i) lens[i] = 8;
-            if (!build(lens, 288, LB, tab, Y::LIT0, sc->sorted_lit, LB, Y::LIM_LIT, Y::OFS_LIT)) return 11;
+            if (!build(lens, 288, LB, tab, AL, sc->sorted_lit)) return 11;
             for (int i = 0; i < 32; ++i) lens[i] = 5;
-            if (!build(lens, 32, DB, tab, Y::DIST0, sc->sorted_dist, DB, Y::LIM_DIST, Y::OFS_DIST)) return 12;
+            if (!build(lens, 32, DB, tab, AD, sc->sorted_dist)) return 12;
         } else if (type == 2) {
+            b.slide();
             const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
             if (hlit > 286 || hdist > 30) return 5;
             uint8_t* const cl = lens + 300;      // 19 code-length code lengths, behind the 286 + 30 lengths they describe
             for (int i = 0; i < 19; ++i) cl[i] = 0;
             for (uint32_t i = 0; i < hclen; ++i) {
-                if (b.cnt < 3) b.refill();
+                if (b.cnt < 3) { b.refill(); b.slide(); }
                 cl[kClOrder[i]] = (uint8_t)b.take(3);
             }
-            // the code-length alphabet borrows the head of the literal table, the literal alphabet's bound / offset slots and the distance
-            // alphabet's sorted symbols (all three are built afterwards)
-            if (!build(cl, 19, CLB, tab, Y::LIT0, sc->sorted_dist, LB, Y::LIM_LIT, Y::OFS_LIT)) return 6;
+            // the code-length alphabet borrows the literal alphabet's places and the distance alphabet's sorted symbols (both built afterwards)
+            if (!build(cl, 19, CLB, tab, AL, sc->sorted_dist)) return 6;
             uint32_t n = 0;
             while (n < hlit + hdist) {
-                if (b.cnt < 32) b.refill();
+                if (b.cnt < 32) { b.refill(); b.slide(); }
                 uint32_t e = tab.rd(Y::LIT0 + b.peek(CLB));
-                if (!(e & 15u) && CLB < 7) e = decode_long<LB>(b.peek(15), tab, Y::LIM_LIT, Y::OFS_LIT, sc->sorted_dist);
+                if (!(e & 15u) && CLB < 7) e = decode_long<LB>(b.peek(15), tab, AL, sc->sorted_dist);
                 if (!(e & 15u)) return 7;
                 b.drop(e & 15u);
                 const uint32_t sym = e >> 4;
@@ -318,127 +333,106 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
                 n += rep;
             }
             if (b.taken > 8u * src_len || lens[256] == 0) return 10;
-            if (!build(lens + hlit, hdist, DB, tab, Y::DIST0, sc->sorted_dist, DB, Y::LIM_DIST, Y::OFS_DIST)) return 12;
-            if (!build(lens, hlit, LB, tab, Y::LIT0, sc->sorted_lit, LB, Y::LIM_LIT, Y::OFS_LIT)) return 11;
+            if (!build(lens + hlit, hdist, DB, tab, AD, sc->sorted_dist)) return 12;
+            if (!build(lens, hlit, LB, tab, AL, sc->sorted_lit)) return 11;
         } else {
             return 4;
         }
-        // ---- the symbols of the block.  With >= 32 bits in the buffer a literal / length code and its extra bits (<= 20) or a distance
-        // code and its extra bits (<= 28) can be taken without looking at the count again.
+        b.slide();
+        // ---- the symbols of the block: (a) ask, (b) decode, (c) wait and store -- see the head of this file.
+        // c_*: the match being copied (bytes not yet asked for); f_*: the piece asked for in (a), stored in (c).
+        uint32_t c_rem = 0, c_off = 0, f_n = 0;
+        uint8_t *c_dst = nullptr, *f_d = nullptr;
+        uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        bool ended = false;
+        int err = 0;
         for (;;) {
-            if (b.cnt < 32) b.refill();
-            uint32_t e = tab.rd(Y::LIT0 + b.peek(LB));
-            if (!(e & 15u)) {
-                e = decode_long<LB>(b.peek(15), tab, Y::LIM_LIT, Y::OFS_LIT, sc->sorted_lit);
-                if (!(e & 15u)) return 14;
+            // (a) the next piece of the match in hand: at most 32 bytes, and no more than the distance (the source of a piece must be in
+            // memory when it is asked for: everything below c_dst is, after the (c) of the iteration before)
+            if (c_rem) {
+                uint32_t piece = c_rem < 32 ? c_rem : 32;
+                if (c_off < piece) piece = c_off;
+                if (!(DBG & 2)) load32(c_dst - c_off, out_end, &a0, &a1, &a2, &a3);
+                f_n = piece;
+                f_d = c_dst;
+                c_dst += piece;
+                c_rem -= piece;
             }
-            b.drop(e & 15u);
-            const uint32_t sym = e >> 4;
-            if (sym < 256) {
-                if ((size_t)(out_end - out) <= npend) return 13;
-                pend |= (uint64_t)sym << (8 * npend);
-                last8 = last8 >> 8 | (uint64_t)sym << 56;
-                nvalid = nvalid < 8 ? nvalid + 1 : 8;
-                if (++npend == 8) { if (!(DBG & 1)) *reinterpret_cast<u64u*>(out) = pend; out += 8; pend = 0; npend = 0; }
-                continue;
-            }
-            if (sym == 256) break;
-            if (sym > 285) return 14;
-            const uint32_t len = len_base(sym - 257) + b.take(len_extra(sym - 257));
-            if (b.cnt < 32) b.refill();
-            uint32_t d = tab.rd(Y::DIST0 + b.peek(DB));
-            if (!(d & 15u)) {
-                d = decode_long<DB>(b.peek(15), tab, Y::LIM_DIST, Y::OFS_DIST, sc->sorted_dist);
-                if (!(d & 15u)) return 15;
-            }
-            b.drop(d & 15u);
-            if ((d >> 4) > 29) return 15;
-            const uint32_t off = dist_base(d >> 4) + b.take(dist_extra(d >> 4));
-            if (off > (size_t)(out - dst) + npend || len > (size_t)(out_end - out) - npend) return 16;
-            if (off <= nvalid && off < 8) {
-                // ---- a run: the period is the top `off` bytes of last8
-                flush();
-                const uint64_t x = off == 1 ? (last8 >> 56) * 0x0101010101010101ull : periodic(last8 >> (8 * (8 - off)), off, 0);
-                if (!(DBG & 2)) {
-                    // whole words, each starting at the head of a period; what a word writes beyond the run is this lane's own future output
-                    const uint32_t step = off == 3 || off == 6 ? 6u : off == 5 ? 5u : off == 7 ? 7u : 8u;
-                    uint32_t done = 0;
-                    for (; done < len && (size_t)(out_end - (out + done)) >= 8; done += step) *reinterpret_cast<u64u*>(out + done) = x;
-                    if (done < len) {      // the end of the block: byte by byte
-                        uint32_t k = done % off;
-                        for (uint32_t i = done; i < len; ++i) { out[i] = (uint8_t)(x >> (8 * k)); if (++k == off) k = 0; }
+            // (b) the next symbol, for a lane that has nothing left to ask for
+            if (!c_rem && !ended) {
+                if (b.cnt < 32) b.refill();
+                uint32_t e = tab.rd(Y::LIT0 + b.peek(LB));
+                if (!(e & 15u)) e = decode_long<LB>(b.peek(15), tab, AL, sc->sorted_lit);
+                if (!(e & 15u)) { err = 14; break; }
+                b.drop(e & 15u);
+                const uint32_t sym = e >> 4;
+                if (sym < 256) {
+                    if ((size_t)(out_end - out) <= npend) { err = 13; break; }
+                    pend |= (uint64_t)sym << (8 * npend);
+                    last8 = last8 >> 8 | (uint64_t)sym << 56;
+                    nvalid = nvalid < 8 ? nvalid + 1 : 8;
+                    if (++npend == 8) { if (!(DBG & 1)) *reinterpret_cast<u64u*>(out) = pend; out += 8; pend = 0; npend = 0; }
+                } else if (sym == 256) {
+                    ended = true;
+                } else {
+                    if (sym > 285) { err = 14; break; }
+                    const uint32_t len = len_base(sym - 257) + b.take(len_extra(sym - 257));
+                    if (b.cnt < 32) b.refill();
+                    uint32_t d = tab.rd(Y::DIST0 + b.peek(DB));
+                    if (!(d & 15u)) d = decode_long<DB>(b.peek(15), tab, AD, sc->sorted_dist);
+                    if (!(d & 15u) || (d >> 4) > 29) { err = 15; break; }
+                    b.drop(d & 15u);
+                    const uint32_t off = dist_base(d >> 4) + b.take(dist_extra(d >> 4));
+                    if (off > (size_t)(out - dst) + npend || len > (size_t)(out_end - out) - npend) { err = 16; break; }
+                    flush();
+                    if (off <= nvalid && off < 8) {
+                        // a run: the period is the top `off` bytes of last8; whole words, each starting at the head of a period (what a word
+                        // writes beyond the run is this lane's own future output), the end of the block byte by byte
+                        const uint64_t x = off == 1 ? (last8 >> 56) * 0x0101010101010101ull : periodic(last8 >> (8 * (8 - off)), off, 0);
+                        if (!(DBG & 2)) {
+                            const uint32_t step = off == 3 || off == 6 ? 6u : off == 5 ? 5u : off == 7 ? 7u : 8u;
+                            uint32_t done = 0;
+                            for (; done < len && (size_t)(out_end - (out + done)) >= 8; done += step) *reinterpret_cast<u64u*>(out + done) = x;
+                            if (done < len) {
+                                uint32_t k = done % off;
+                                for (uint32_t i = done; i < len; ++i) { out[i] = (uint8_t)(x >> (8 * k)); if (++k == off) k = 0; }
+                            }
+                        }
+                        if (len >= 8) { last8 = off == 1 ? x : periodic(x, off, (len - 8) % off); nvalid = 8; }
+                        else { last8 = last8 >> (8 * len) | x << (8 * (8 - len)); nvalid = nvalid + len < 8 ? nvalid + len : 8; }
+                    } else {
+                        // a copy from memory: from the next (a) on
+                        c_rem = len;
+                        c_off = off;
+                        c_dst = out;
+                        nvalid = 0;
                     }
-                }
-                out += len;
-                if (len >= 8) { last8 = off == 1 ? x : periodic(x, off, (len - 8) % off); nvalid = 8; }
-                else { last8 = last8 >> (8 * len) | x << (8 * (8 - len)); nvalid = nvalid + len < 8 ? nvalid + len : 8; }
-                continue;
-            }
-            nvalid = 0;
-            // ---- a copy from memory.  Short, not overlapping itself, its 32 source bytes inside the block: deferred (see above).
-            {
-                const uint8_t* from = out + npend - off;
-                if (len <= 32 && off >= len && (size_t)(out_end - from) >= 32) {
-                    bool dep = false;      // does it read bytes of a pending copy?
-                    if (npc >= 1) dep = dep || (from < pc0_d + pc0_n && from + len > pc0_d);
-                    if (npc >= 2) dep = dep || (from < pc1_d + pc1_n && from + len > pc1_d);
-                    if (dep || npc == 2) drain();
-                    if (from + len > out) flush();      // it reads pending literals: they go to memory first
-                    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-                    if (!(DBG & 2)) {
-                        a0 = *reinterpret_cast<const u64u*>(from); a1 = *reinterpret_cast<const u64u*>(from + 8);
-                        a2 = *reinterpret_cast<const u64u*>(from + 16); a3 = *reinterpret_cast<const u64u*>(from + 24);
-                    }
-                    flush();                              // (behind the loads: they do not queue behind this store)
-                    if (npc == 0) { pc0_d = out; pc0_n = len; pc0_a = a0; pc0_b = a1; pc0_c = a2; pc0_e = a3; }
-                    else { pc1_d = out; pc1_n = len; pc1_a = a0; pc1_b = a1; pc1_c = a2; pc1_e = a3; }
-                    ++npc;
                     out += len;
-                    continue;
                 }
             }
-            // ---- every other copy from memory, at once (as in np_inflate_lane.h: sources far enough away four words at a time)
-            drain();
-            flush();
-            const uint8_t* from = out - off;
-            const size_t room = (size_t)(out_end - out);
-            if (DBG & 2) {
-            } else if (off >= 32 && room >= (size_t)len + 32) {
-                uint8_t* o = out;
-                const uint8_t* const stop = out + len;
-                do {
-                    const uint64_t w0 = *reinterpret_cast<const u64u*>(from), w1 = *reinterpret_cast<const u64u*>(from + 8);
-                    const uint64_t w2 = *reinterpret_cast<const u64u*>(from + 16), w3 = *reinterpret_cast<const u64u*>(from + 24);
-                    *reinterpret_cast<u64u*>(o) = w0; *reinterpret_cast<u64u*>(o + 8) = w1;
-                    *reinterpret_cast<u64u*>(o + 16) = w2; *reinterpret_cast<u64u*>(o + 24) = w3;
-                    from += 32;
-                    o += 32;
-                } while (o < stop);
-            } else if (off >= 8 && room >= (size_t)len + 8) {   // whole words; the slack bytes are overwritten by what follows
-                uint8_t* o = out;
-                const uint8_t* const stop = out + len;
-                do {
-                    *reinterpret_cast<u64u*>(o) = *reinterpret_cast<const u64u*>(from);
-                    from += 8;
-                    o += 8;
-                } while (o < stop);
-            } else if (off < 8 && (size_t)(out - dst) >= 8) {   // a period of 1 .. 7 bytes whose bytes are not in last8: the last eight bytes in memory hold it
-                const uint64_t tail = *reinterpret_cast<const u64u*>(out - 8);
-                const uint32_t first = 8u - off;              // byte of `tail` that is from[0]
-                uint32_t k = 0;
-                for (uint32_t i = 0; i < len; ++i) {
-                    out[i] = (uint8_t)(tail >> (8u * (first + k)));
-                    if (++k == off) k = 0;
+            // (c) the one wait: the window slides (the words it takes in were asked for an iteration ago), the piece asked for in (a) is
+            // stored, exactly its bytes, and the window's next words are asked for
+            b.slide_take();
+            if (f_n) {
+                if (!(DBG & 2)) {
+                    uint8_t* d = f_d;
+                    uint32_t n = f_n;
+                    uint64_t tail = a0;
+                    if (n >= 8) { *reinterpret_cast<u64u*>(d) = a0; d += 8; n -= 8; tail = a1; }
+                    if (n >= 8) { *reinterpret_cast<u64u*>(d) = a1; d += 8; n -= 8; tail = a2; }
+                    if (n >= 8) { *reinterpret_cast<u64u*>(d) = a2; d += 8; n -= 8; tail = a3; }
+                    if (n >= 8) { *reinterpret_cast<u64u*>(d) = a3; d += 8; n -= 8; tail = 0; }
+                    for (uint32_t i = 0; i < n; ++i) d[i] = (uint8_t)(tail >> (8 * i));
                 }
-            } else {
-                for (uint32_t i = 0; i < len; ++i) out[i] = from[i];   // near the start or the end of the output: forward, byte by byte
+                f_n = 0;
             }
-            out += len;
+            b.slide_ask();
+            if (ended && !c_rem) break;
         }
+        if (err) return err;
         if (b.taken > 8u * src_len) return 17;
         if (final_block) break;
     }
-    drain();
     flush();
     return (b.taken <= 8u * src_len && out == out_end) ? 0 : 19;
 }
