@@ -128,7 +128,7 @@ int launch_inflate_lds(hipStream_t q, const uint8_t* comp, const npdev::BlockDes
 // NP1_INFLATE=lds<LB><DB> (lds96, lds86, lds85, lds76, lds75, lds65; "lds" = the default of the family): which table sizes
 int lds_variant(const char* e) {
     if (!e || strncmp(e, "lds", 3) != 0) return 0;
-    if (!e[3]) return 85;
+    if (!e[3]) return 75;
     const int v = atoi(e + 3);
     return v == 96 || v == 86 || v == 85 || v == 76 || v == 75 || v == 65 ? v : 0;
 }
@@ -624,13 +624,15 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
     uint64_t* d_tot = reinterpret_cast<uint64_t*>(W.small.as<uint8_t>() + 64);   // scan totals
     uint64_t n_rec = 0;
     if (n_blocks) {
-        // which decoder: a lane per block when the batch has blocks enough to fill the chip with lanes (np_inflate_lane.h), else a
-        // wave per block (np_inflate_dev.h).  NP1_INFLATE=lanes | wave forces one.
-        // NP1_INFLATE=lds | lds96: the lane decoder with its tables in LDS (np_inflate_lds.h), 10 / 8-bit or 9 / 6-bit primaries.
+        // which decoder: a lane per block with its tables in LDS (np_inflate_lds.h; round 6: 7 / 5-bit primaries, three waves per CU -- measured
+        // 14.4 ms for 34 k blocks, 45.5 ms for 138 k, against 42.6 / 94.8 ms of the round-4 lane decoder: profiles/r6_inflate_lds.txt) when the
+        // batch has blocks enough to fill the chip with lanes, else a wave per block (np_inflate_dev.h).
+        // NP1_INFLATE=lds<LB><DB> | lanes (np_inflate_lane.h, tables in HBM) | wave forces one.
         static const int mode = [] {
             const char* e = getenv("NP1_INFLATE");
             return !e ? 0 : strcmp(e, "lanes") == 0 ? 1 : strcmp(e, "wave") == 0 ? 2 : lds_variant(e) ? 3 : 0;
         }();
+        static const int variant = lds_variant(getenv("NP1_INFLATE")) ? lds_variant(getenv("NP1_INFLATE")) : 75;
         // lanes in flight: a multiple of the wave, at least one wave, at most 2^18 (their tables are ~15 KB each in HBM)
         static const uint32_t max_lanes = [] {
             long v = getenv("NP1_INFLATE_LANES") ? atol(getenv("NP1_INFLATE_LANES")) : 131072;
@@ -640,10 +642,10 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         }();
         for (hipEvent_t& e : W.ev) if (!e) (void)hipEventCreate(&e);
         (void)hipEventRecord(W.ev[0], q);
-        if (mode == 3) {
-            if (launch_inflate_lds_variant(lds_variant(getenv("NP1_INFLATE")), q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(),
+        if (mode == 3 || (mode == 0 && n_blocks >= 4096u)) {
+            if (launch_inflate_lds_variant(variant, q, W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(),
                                            W.status.as<uint32_t>(), W.lane_tables)) return -1;
-        } else if (mode == 1 || (mode == 0 && n_blocks >= 4096u)) {
+        } else if (mode == 1) {
             const uint32_t lanes = std::min<uint32_t>((n_blocks + 63u) & ~63u, max_lanes);
             if (W.lane_tables.ensure((size_t)lanes * nplane::LANE_TABLE_WORDS * 4)) return -1;
             k_inflate_lanes<<<lanes / 64, 64, 0, q>>>(W.comp.as<uint8_t>(), W.blocks.as<npdev::BlockDesc>(), n_blocks, W.inflated.as<uint8_t>(), W.status.as<uint32_t>(),

@@ -10,7 +10,7 @@
 //     (a) a lane with bytes of a match still to copy asks for the next <= 32 of them (loads, no wait);
 //     (b) a lane that has no more bytes to ask for decodes its next symbol -- registers and LDS only: the primary tables are 16-bit slots in
 //         LDS laid out [slot][lane] (two lanes per dword: at most a two-way bank conflict), codes longer than the primary index are decoded
-//         canonically from per-length bounds and the first symbols of the sorted order, also in LDS; the stream's bytes come out of a window
+//         canonically from per-length bounds and the symbols sorted by code, all of them in LDS as bytes; the stream's bytes come out of a window
 //         of registers; a literal goes into a register that leaves as an 8-byte store when full (a store is not waited for); a match at a
 //         distance of 1 .. 7 whose period is known is written from a register copy of the last eight bytes;
 //     (c) the wait: the bytes asked for in (a) arrive -- while (b) ran -- and are stored, exactly their count (what follows them may already
@@ -38,27 +38,26 @@ namespace nplds {
 
 typedef uint64_t __attribute__((aligned(1))) u64u;
 
-// per-lane HBM scratch: code lengths while the tables are built, and the symbols of both alphabets sorted by code (read only for the rare
-// long code whose symbol is not among the first ones kept in LDS)
+// per-lane HBM scratch: code lengths while the tables of a block are built (never touched by the symbol loop)
 struct Scratch {
     uint8_t lens[320];
-    uint16_t sorted_lit[288];
-    uint16_t sorted_dist[32];
 };
 
-// 16-bit slots of a lane's table.  Per alphabet: 2^bits primaries (symbol << 4 | code length, 0 = no code this short), for every code
-// length above `bits` the exclusive upper bound of its codes (15-bit, left-justified, in the order the bits arrive) and what to add to a
-// code to index the symbols sorted by code, the index of the first long symbol in that order, and the first NS long symbols themselves.
-template <int LB, int DB, int NSL = 64, int NSD = 24> struct Layout {
+// 16-bit slots of a lane's table.  Per alphabet: 2^bits primaries (symbol << 4 | code length, 0 = no code this short); for every code
+// length above `bits` the exclusive upper bound of its codes (15-bit, left-justified, in the order the bits arrive), what to add to a code
+// to index the symbols sorted by code, and (literal/length alphabet) the index in that order from which the symbols of this length are
+// >= 256; and ALL symbols sorted by code, their low eight bits, two to a slot.  (Round 6, third version: only the first 64 long symbols were
+// in LDS, the rest in HBM scratch -- and with 64 lanes in lockstep some lane needed one of the rest in most iterations, a trip to HBM for
+// the whole wave.  The symbol loop now reads nothing but LDS.)
+template <int LB, int DB> struct Layout {
     static constexpr uint32_t NL = 15 - LB, ND = 15 - DB;
     static constexpr uint32_t LIT0 = 0, DIST0 = 1u << LB;
-    static constexpr uint32_t LIM_LIT = DIST0 + (1u << DB), OFS_LIT = LIM_LIT + NL, LONG0_LIT = OFS_LIT + NL, SORT_LIT = LONG0_LIT + 1;
-    static constexpr uint32_t LIM_DIST = SORT_LIT + NSL, OFS_DIST = LIM_DIST + ND, LONG0_DIST = OFS_DIST + ND, SORT_DIST = LONG0_DIST + 1;
-    static constexpr uint32_t SLOTS = SORT_DIST + NSD;
-    static constexpr uint32_t NS_LIT = NSL, NS_DIST = NSD;
+    static constexpr uint32_t LIM_LIT = DIST0 + (1u << DB), OFS_LIT = LIM_LIT + NL, HI_LIT = OFS_LIT + NL, SORT_LIT = HI_LIT + NL;
+    static constexpr uint32_t LIM_DIST = SORT_LIT + 144, OFS_DIST = LIM_DIST + ND, SORT_DIST = OFS_DIST + ND;
+    static constexpr uint32_t SLOTS = SORT_DIST + 16;
 };
-// one alphabet's places in the table
-struct Alpha { uint32_t base, bits, lim, ofs, long0, sort, ns; };
+// one alphabet's places in the table (hi = 0: no symbol of the alphabet is >= 256)
+struct Alpha { uint32_t base, bits, lim, ofs, hi, sort, nsort; };
 
 NPD_HD uint32_t len_base(uint32_t i) {      // RFC 1951 3.2.5, computed
     if (i < 8) return 3 + i;
@@ -88,10 +87,10 @@ NPD_HD uint32_t rev32(uint32_t v) {
 }
 
 // Canonical code from lens[0 .. n_sym) into the alphabet's places: primaries for the codes of up to `bits` bits (bits <= A.bits: the code-length
-// alphabet borrows the literal alphabet's places with 7 bits), bounds and offsets for the lengths above A.bits, the first A.ns long symbols,
-// and all symbols sorted by code in `sorted`.  false: over-subscribed code.
+// alphabet borrows the literal alphabet's places with 7 bits), bounds, offsets and >= 256 marks for the lengths above A.bits, and the low bytes
+// of all symbols sorted by code.  false: over-subscribed code.
 template <class Tab>
-NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& tab, const Alpha A, uint16_t* sorted) {
+NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& tab, const Alpha A) {
     uint32_t count[16];
     for (int i = 0; i < 16; ++i) count[i] = 0;
     for (uint32_t s = 0; s < n_sym; ++s) ++count[lens[s] & 15u];
@@ -102,30 +101,33 @@ NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& 
         if (left < 0) return false;
     }
     uint32_t next_code[16], next_index[16];
-    uint32_t code = 0, index = 0, long0 = 0;
+    uint32_t code = 0, index = 0;
     next_code[0] = next_index[0] = 0;
     for (uint32_t len = 1; len <= 15; ++len) {
         code = (code + count[len - 1]) << 1;
         next_code[len] = code;
         next_index[len] = index;
-        if (len == A.bits + 1) long0 = index;
         if (len > A.bits) {
             // codes of this length, as their first 15 bits arrive: [code << (15 - len), (code + count) << (15 - len))
             tab.wr(A.lim + (len - A.bits - 1), (uint16_t)((code + count[len]) << (15 - len)));      // (<= 32768)
             tab.wr(A.ofs + (len - A.bits - 1), (uint16_t)(index - code));
+            if (A.hi) tab.wr(A.hi + (len - A.bits - 1), (uint16_t)(index + count[len]));             // (until a symbol >= 256 of this length shows)
         }
         index += count[len];
     }
-    tab.wr(A.long0, (uint16_t)long0);
     const uint32_t slots = 1u << bits;
     for (uint32_t i = 0; i < slots; ++i) tab.wr(A.base + i, 0);
+    uint32_t marked = 0;      // lengths whose first symbol >= 256 has been seen
     for (uint32_t s = 0; s < n_sym; ++s) {
         const uint32_t len = lens[s] & 15u;
         if (!len) continue;
         const uint32_t c = next_code[len]++;
         const uint32_t at = next_index[len]++;
-        sorted[at] = (uint16_t)s;
-        if (len > A.bits && at - long0 < A.ns) tab.wr(A.sort + (at - long0), (uint16_t)s);
+        if (at < A.nsort) {      // (always, for a code that is not over-subscribed)
+            const uint32_t w = tab.rd(A.sort + (at >> 1));
+            tab.wr(A.sort + (at >> 1), (uint16_t)((at & 1u) ? (w & 0x00ffu) | (s & 0xffu) << 8 : (w & 0xff00u) | (s & 0xffu)));
+        }
+        if (A.hi && s >= 256 && len > A.bits && !(marked >> len & 1u)) { marked |= 1u << len; tab.wr(A.hi + (len - A.bits - 1), (uint16_t)at); }
         if (len <= bits) {
             const uint32_t r = rev32(c) >> (32 - len);
             const uint16_t e = (uint16_t)(s << 4 | len);
@@ -136,9 +138,9 @@ NPD_HD_CALL bool build(const uint8_t* lens, uint32_t n_sym, uint32_t bits, Tab& 
 }
 
 // A code longer than the primary index of BITS bits: `peek` = the next 15 bits of the stream.  Returns symbol << 4 | length, or 0 when no
-// code matches.  All of it LDS (the bounds are read in one go), except a symbol beyond the first A.ns long ones.
+// code matches.  All of it LDS (the bounds are read in one go).
 template <int BITS, class Tab>
-NPD_HD uint32_t decode_long(uint32_t peek, const Tab& tab, const Alpha A, const uint16_t* sorted) {
+NPD_HD uint32_t decode_long(uint32_t peek, const Tab& tab, const Alpha A) {
     const uint32_t v = rev32(peek) >> 17;      // the 15 bits in the order they arrived, first bit on top
     uint32_t lim[15 - BITS];
 NPD_UNROLL
@@ -149,8 +151,10 @@ NPD_UNROLL
     if (k >= 15u - BITS) return 0;
     const uint32_t len = BITS + 1 + k;
     const uint32_t at = (uint16_t)(tab.rd(A.ofs + k) + (v >> (15 - len)));
-    const uint32_t rel = at - tab.rd(A.long0);
-    const uint32_t sym = rel < A.ns ? tab.rd(A.sort + rel) : sorted[at];
+    if (at >= A.nsort) return 0;
+    const uint32_t w = tab.rd(A.sort + (at >> 1));
+    uint32_t sym = (at & 1u) ? w >> 8 : w & 0xffu;
+    if (A.hi && at >= tab.rd(A.hi + k)) sym |= 256u;
     return sym << 4 | len;
 }
 
@@ -250,8 +254,8 @@ template <int LB, int DB, class Tab, int DBG = 0>
 NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uint32_t dst_len, Tab& tab, Scratch* sc) {
     typedef Layout<LB, DB> Y;
     constexpr int CLB = 7 <= LB ? 7 : LB;      // primary bits of the code-length alphabet (its codes have up to 7 bits)
-    const Alpha AL{Y::LIT0, (uint32_t)LB, Y::LIM_LIT, Y::OFS_LIT, Y::LONG0_LIT, Y::SORT_LIT, Y::NS_LIT};
-    const Alpha AD{Y::DIST0, (uint32_t)DB, Y::LIM_DIST, Y::OFS_DIST, Y::LONG0_DIST, Y::SORT_DIST, Y::NS_DIST};
+    const Alpha AL{Y::LIT0, (uint32_t)LB, Y::LIM_LIT, Y::OFS_LIT, Y::HI_LIT, Y::SORT_LIT, 288};
+    const Alpha AD{Y::DIST0, (uint32_t)DB, Y::LIM_DIST, Y::OFS_DIST, 0, Y::SORT_DIST, 32};
     Bits b;
     b.start(src, src_len);
     uint8_t* out = dst;                    // where the next decoded byte goes, less the pending literals
@@ -300,9 +304,9 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
             for (int i = 144; i < 256; ++i) lens[i] = 9;
             for (int i = 256; i < 280; ++i) lens[i] = 7;
             for (int i = 280; i < 288; ++i) lens[i] = 8;
-            if (!build(lens, 288, LB, tab, AL, sc->sorted_lit)) return 11;
+            if (!build(lens, 288, LB, tab, AL)) return 11;
             for (int i = 0; i < 32; ++i) lens[i] = 5;
-            if (!build(lens, 32, DB, tab, AD, sc->sorted_dist)) return 12;
+            if (!build(lens, 32, DB, tab, AD)) return 12;
         } else if (type == 2) {
             b.slide();
             const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
@@ -313,13 +317,13 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
                 if (b.cnt < 3) { b.refill(); b.slide(); }
                 cl[kClOrder[i]] = (uint8_t)b.take(3);
             }
-            // the code-length alphabet borrows the literal alphabet's places and the distance alphabet's sorted symbols (both built afterwards)
-            if (!build(cl, 19, CLB, tab, AL, sc->sorted_dist)) return 6;
+            // the code-length alphabet borrows the literal alphabet's places (built afterwards)
+            if (!build(cl, 19, CLB, tab, AL)) return 6;
             uint32_t n = 0;
             while (n < hlit + hdist) {
                 if (b.cnt < 32) { b.refill(); b.slide(); }
                 uint32_t e = tab.rd(Y::LIT0 + b.peek(CLB));
-                if (!(e & 15u) && CLB < 7) e = decode_long<LB>(b.peek(15), tab, AL, sc->sorted_dist);
+                if (!(e & 15u) && CLB < 7) e = decode_long<LB>(b.peek(15), tab, AL);
                 if (!(e & 15u)) return 7;
                 b.drop(e & 15u);
                 const uint32_t sym = e >> 4;
@@ -333,8 +337,8 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
                 n += rep;
             }
             if (b.taken > 8u * src_len || lens[256] == 0) return 10;
-            if (!build(lens + hlit, hdist, DB, tab, AD, sc->sorted_dist)) return 12;
-            if (!build(lens, hlit, LB, tab, AL, sc->sorted_lit)) return 11;
+            if (!build(lens + hlit, hdist, DB, tab, AD)) return 12;
+            if (!build(lens, hlit, LB, tab, AL)) return 11;
         } else {
             return 4;
         }
@@ -362,7 +366,7 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
             if (!c_rem && !ended) {
                 if (b.cnt < 32) b.refill();
                 uint32_t e = tab.rd(Y::LIT0 + b.peek(LB));
-                if (!(e & 15u)) e = decode_long<LB>(b.peek(15), tab, AL, sc->sorted_lit);
+                if (!(e & 15u)) e = decode_long<LB>(b.peek(15), tab, AL);
                 if (!(e & 15u)) { err = 14; break; }
                 b.drop(e & 15u);
                 const uint32_t sym = e >> 4;
@@ -379,7 +383,7 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
                     const uint32_t len = len_base(sym - 257) + b.take(len_extra(sym - 257));
                     if (b.cnt < 32) b.refill();
                     uint32_t d = tab.rd(Y::DIST0 + b.peek(DB));
-                    if (!(d & 15u)) d = decode_long<DB>(b.peek(15), tab, AD, sc->sorted_dist);
+                    if (!(d & 15u)) d = decode_long<DB>(b.peek(15), tab, AD);
                     if (!(d & 15u) || (d >> 4) > 29) { err = 15; break; }
                     b.drop(d & 15u);
                     const uint32_t off = dist_base(d >> 4) + b.take(dist_extra(d >> 4));
