@@ -178,6 +178,9 @@ typedef struct {
     double clip_rate;
 } np1_synth_long_params;
 np1_stream* np1_stream_synth_long(const np1_synth_long_params* p, const char* contig_name_prefix);
+/* Either workload over contigs that are handed in (names, sequences, lengths; p = np1_synth_params for long_reads = 0, np1_synth_long_params for 1;
+ * their n_contigs / contig_len are not used): the reads of the next step of a multi-step run, aligned to the assembly the step before wrote. */
+np1_stream* np1_stream_synth_on(const void* p, int long_reads, const char* const* names, const char* const* seqs, const int64_t* lens, int n);
 /* Diploid workload of task 3 (snp_phase): per contig one draft with its own errors, short read pairs and long reads drawn from two
  * haplotypes that differ by substitutions (het_sub per base) and small indels (het_indel); sr_holes = stretches per contig no short
  * fragment touches.  Both streams carry qualities.  Returns 0 and the two streams (same contigs, same drafts). */

@@ -285,6 +285,35 @@ class Stream(object):
         return cls(lib().np1_stream_synth_long(C.byref(p), prefix.encode()))
 
     @classmethod
+    def synth_on(cls, contigs, long_reads=False, depth=None, seed=20250117, **kw):
+        """The synthetic short-read (or long-read) workload over contigs that are handed in -- [(name, sequence)], e.g. the FASTA a
+        polishing step wrote: the "re-mapped" reads of the next step of a multi-step run, aligned by construction (np_synth.h)."""
+        L = lib()
+        L.np1_stream_synth_on.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int]
+        L.np1_stream_synth_on.restype = C.c_void_p
+        if long_reads:
+            p = SynthLongParams()
+            p.seed, p.depth, p.mean_len = seed, 20.0 if depth is None else depth, 8000.0
+            p.sub, p.ins, p.dele, p.max_indel, p.clip_rate = 0.03, 0.02, 0.02, 4, 0.2
+        else:
+            p = SynthParams()
+            L.np1_synth_defaults(C.byref(p))
+            p.seed, p.depth = seed, 30.0 if depth is None else depth
+        for k, val in kw.items():
+            if not hasattr(p, k):
+                raise TypeError("unknown synth parameter " + k)
+            setattr(p, k, val)
+        n = len(contigs)
+        seqs = [s.encode() if isinstance(s, str) else bytes(s) for _, s in contigs]
+        names = (C.c_char_p * n)(*[nm.encode() for nm, _ in contigs])
+        sq = (C.c_char_p * n)(*seqs)
+        lens = (C.c_int64 * n)(*[len(x) for x in seqs])
+        h = L.np1_stream_synth_on(C.byref(p), 1 if long_reads else 0, names, sq, lens, n)
+        if not h:
+            raise RuntimeError("np1_stream_synth_on: " + last_error())
+        return cls(h)
+
+    @classmethod
     def synth_diploid(cls, contig_len, sr_depth=30.0, lr_depth=20.0, seed=7, read_len=150, frag_mean=400.0, lr_len=8000.0, het_sub=0.002, het_indel=0.0003,
                       draft_err=0.002, sr_err=0.003, lr_err=0.04, sr_holes=0, prefix="ctg"):
         """(short-read stream, long-read stream) of the same diploid contigs: the workload of task 3 (np1_diploid_params)"""

@@ -162,6 +162,18 @@ np1_stream* np1_stream_synth_long(const np1_synth_long_params* p, const char* pr
     return st;
 }
 
+/* test / bench helpers: the synthetic short-read (long_reads = 0: p = np1_synth_params) or long-read (1: np1_synth_long_params) workload over the
+   contigs of a FASTA that is handed in -- the "re-mapped" reads of the next step of a multi-step run (np_synth.h) */
+np1_stream* np1_stream_synth_on(const void* p, int long_reads, const char* const* names, const char* const* seqs, const int64_t* lens, int n) {
+    std::vector<std::string> nm, sq;
+    for (int i = 0; i < n; ++i) { nm.emplace_back(names[i]); sq.emplace_back(seqs[i], (size_t)lens[i]); }
+    np1_stream* st = new np1_stream();
+    const bool ok = long_reads ? np::synth_long_stream_on(*static_cast<const np1_synth_long_params*>(p), nm, sq, &st->s)
+                               : np::synth_stream_on(*static_cast<const np1_synth_params*>(p), nm, sq, &st->s);
+    if (!ok) { g_err = "synthetic generation failed"; delete st; return nullptr; }
+    return st;
+}
+
 int np1_stream_synth_diploid(const np1_diploid_params* p, const char* prefix, np1_stream** sr, np1_stream** lr) {
     np1_stream *a = new np1_stream(), *b = new np1_stream();
     if (!np::synth_diploid_streams(*p, prefix ? prefix : "ctg", &a->s, &b->s)) {

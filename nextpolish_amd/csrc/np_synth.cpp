@@ -424,15 +424,25 @@ void synth_contig_segmented(const np_synth_params& p, int c, const std::string& 
 
 }  // namespace
 
-bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStream* out) {
-    out->clear();
-    out->ctg_off.push_back(0);
-    Rng rng(p.seed);
+namespace {
+// the reads of one contig (truth T, its map onto the draft D) appended to the stream, coordinate-sorted; shared by the generator that
+// invents truth and draft and the one that is handed the draft (synth_stream_on)
+struct ContigScratch {
     std::vector<TmpRead> reads;
     std::vector<uint32_t> cig_pool;
     std::vector<char> base_pool;
     std::vector<uint8_t> qual_pool;
     std::vector<Col> cols;
+};
+void synth_contig_reads(const np_synth_params& p, Rng& rng, int c, const std::string& name, const std::string& T, const std::vector<int32_t>& dpos,
+                        const std::vector<uint8_t>& dins, const std::string& D, ContigScratch& W, ReadStream* out);
+}  // namespace
+
+bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStream* out) {
+    out->clear();
+    out->ctg_off.push_back(0);
+    Rng rng(p.seed);
+    ContigScratch W;
     for (int c = 0; c < p.n_contigs; ++c) {
         const int32_t Lt = p.contig_len[c];
         if (Lt >= kSegmentedMin) {     // chromosome-sized: generated in parallel, segment by segment (own RNG streams; `rng` is not touched)
@@ -441,7 +451,6 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
             synth_contig_segmented(p, c, nm, out);
             continue;
         }
-        reads.clear(); cig_pool.clear(); base_pool.clear(); qual_pool.clear();
         // ---- truth
         std::string T(Lt, 'A');
         for (int32_t i = 0; i < Lt; ++i) T[i] = kBases[rng.below(4)];
@@ -477,6 +486,25 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
                     for (int k = 0; k < n && i + k < Ld; ++k) D[i + k] = (char)(D[i + k] + 32);
                     i += n;
                 }
+        char nm[64];
+        snprintf(nm, sizeof(nm), "%s%04d", prefix.c_str(), c + 1);
+        synth_contig_reads(p, rng, c, nm, T, dpos, dins, D, W, out);
+    }
+    out->read_begin.push_back(out->n_reads());
+    return true;
+}
+
+namespace {
+void synth_contig_reads(const np_synth_params& p, Rng& rng, int c, const std::string& name, const std::string& T, const std::vector<int32_t>& dpos,
+                        const std::vector<uint8_t>& dins, const std::string& D, ContigScratch& W, ReadStream* out) {
+    std::vector<TmpRead>& reads = W.reads;
+    std::vector<uint32_t>& cig_pool = W.cig_pool;
+    std::vector<char>& base_pool = W.base_pool;
+    std::vector<uint8_t>& qual_pool = W.qual_pool;
+    std::vector<Col>& cols = W.cols;
+    reads.clear(); cig_pool.clear(); base_pool.clear(); qual_pool.clear();
+    const int32_t Lt = (int32_t)T.size(), Ld = (int32_t)D.size();
+    {
         // ---- reads
         const int RL = p.read_len;
         PairGen gen{p, T, dpos, dins, Lt, RL, reads, cig_pool, base_pool, qual_pool, cols};
@@ -493,9 +521,7 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
         std::vector<uint32_t> order(reads.size());
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return reads[a].pos < reads[b].pos; });
-        char nm[64];
-        snprintf(nm, sizeof(nm), "%s%04d", prefix.c_str(), c + 1);
-        out->names.push_back(nm);
+        out->names.push_back(name);
         out->ctg_len.push_back(Ld);
         out->draft += D;
         out->ctg_off.push_back((uint32_t)out->draft.size());
@@ -521,6 +547,52 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
             if (p.with_qual)
                 out->qual.insert(out->qual.end(), qual_pool.begin() + r.seq_beg, qual_pool.begin() + r.seq_beg + r.l_qseq);
         }
+        }
+}
+}  // namespace
+
+// The short-read workload over contigs that are HANDED IN (the assembly a polishing step left): a truth is derived from each draft by the
+// same edit process run the other way (substitutions; runs of 1-3 bases the truth has and the draft lacks; runs the draft has and the
+// truth lacks), then reads are sampled from the truth and aligned through the known edit script -- the "re-mapped reads" of the next
+// step of a multi-step run, without a mapper (tests/tools/check_config5_chain.py).  p.n_contigs / p.contig_len are not used.
+bool synth_stream_on(const np_synth_params& p, const std::vector<std::string>& names, const std::vector<std::string>& drafts, ReadStream* out) {
+    out->clear();
+    out->ctg_off.push_back(0);
+    Rng rng(p.seed);
+    ContigScratch W;
+    for (size_t c = 0; c < drafts.size(); ++c) {
+        const std::string& D = drafts[c];
+        const int32_t Ld = (int32_t)D.size();
+        std::string T;
+        std::vector<int32_t> dpos;
+        std::vector<uint8_t> dins;
+        T.reserve((size_t)Ld + (size_t)Ld / 100);
+        uint32_t pending = 0;      // draft-only bases since the last truth base that has a place in the draft
+        for (int32_t d = 0; d < Ld;) {
+            if (d > 0 && rng.chance(p.draft_indel * 0.5)) {      // bases the draft lacks
+                const int n = 1 + (int)rng.below(3);
+                const bool hp = rng.chance(0.5);
+                for (int k = 0; k < n; ++k) { T.push_back(hp ? T.back() : kBases[rng.below(4)]); dpos.push_back(-1); dins.push_back(0); }
+            }
+            if (d > 0 && rng.chance(p.draft_indel * 0.5)) {      // bases only the draft has (never its last one)
+                const int n = 1 + (int)rng.below(3);
+                int k = 0;
+                for (; k < n && d < Ld - 1 && pending < 200; ++k) { ++d; ++pending; }
+                if (k) continue;
+            }
+            char b = (char)(D[(size_t)d] & ~32);
+            if (b != 'A' && b != 'C' && b != 'G' && b != 'T') b = 'A';
+            if (rng.chance(p.draft_sub)) b = kBases[(std::find(kBases, kBases + 4, b) - kBases + 1 + rng.below(3)) & 3];
+            // (a truth base without a place in the draft cannot carry the draft-only bases: they go to the next one that has a place)
+            T.push_back(b);
+            dpos.push_back(d);
+            dins.push_back((uint8_t)pending);
+            pending = 0;
+            ++d;
+        }
+        dpos.push_back(-1);
+        dins.push_back(0);
+        synth_contig_reads(p, rng, (int)c, names[c], T, dpos, dins, D, W, out);
     }
     out->read_begin.push_back(out->n_reads());
     return true;
@@ -530,7 +602,18 @@ bool synth_stream(const np_synth_params& p, const std::string& prefix, ReadStrea
 // log-normal lengths whose CIGAR against the draft follows from the error process (substitution / insertion /
 // deletion per draft base, indel lengths uniform in 1..max_indel, first and last column always a match, optional
 // soft clips).  Reads come out sorted by position.
-bool synth_long_stream(const np_synth_long_params& p, const std::string& prefix, ReadStream* out) {
+namespace {
+bool synth_long_impl(const np_synth_long_params& p_in, const std::string& prefix, const std::vector<std::string>* given_names, const std::vector<std::string>* given, ReadStream* out);
+}
+bool synth_long_stream(const np_synth_long_params& p, const std::string& prefix, ReadStream* out) { return synth_long_impl(p, prefix, nullptr, nullptr, out); }
+// the same reads over contigs that are handed in (the assembly a polishing step left: "re-mapped" reads of the next step)
+bool synth_long_stream_on(const np_synth_long_params& p, const std::vector<std::string>& names, const std::vector<std::string>& drafts, ReadStream* out) {
+    return synth_long_impl(p, "", &names, &drafts, out);
+}
+namespace {
+bool synth_long_impl(const np_synth_long_params& p_in, const std::string& prefix, const std::vector<std::string>* given_names, const std::vector<std::string>* given, ReadStream* out) {
+    np_synth_long_params p = p_in;
+    if (given) p.n_contigs = (int32_t)given->size();
     out->clear();
     out->ctg_off.push_back(0);
     Rng rng(p.seed);
@@ -538,14 +621,21 @@ bool synth_long_stream(const np_synth_long_params& p, const std::string& prefix,
     std::vector<char> seq;
     std::vector<uint32_t> cig;
     for (int c = 0; c < p.n_contigs; ++c) {
-        const int32_t L = p.contig_len[c];
+        const int32_t L = given ? (int32_t)(*given)[(size_t)c].size() : p.contig_len[c];
         std::string D((size_t)L, 'A');
-        for (int32_t i = 0; i < L; ++i) D[(size_t)i] = B[rng.below(4)];
+        if (given) {      // the reads are copies of the draft with errors: the draft's own letters, upper case (a polished FASTA marks changes in lower case)
+            for (int32_t i = 0; i < L; ++i) {
+                const char u = (char)((*given)[(size_t)c][(size_t)i] & ~32);
+                D[(size_t)i] = u == 'A' || u == 'C' || u == 'G' || u == 'T' ? u : 'A';
+            }
+        } else {
+            for (int32_t i = 0; i < L; ++i) D[(size_t)i] = B[rng.below(4)];
+        }
         char nm[64];
         snprintf(nm, sizeof(nm), "%s%d", prefix.c_str(), c);
-        out->names.push_back(nm);
+        out->names.push_back(given_names ? (*given_names)[(size_t)c] : std::string(nm));
         out->ctg_len.push_back(L);
-        out->draft += D;
+        out->draft += given ? (*given)[(size_t)c] : D;
         out->ctg_off.push_back((uint32_t)out->draft.size());
         out->read_begin.push_back(out->n_reads());
         const uint32_t n_reads = std::max<uint32_t>(1, (uint32_t)(p.depth * L / p.mean_len));
@@ -611,6 +701,7 @@ bool synth_long_stream(const np_synth_long_params& p, const std::string& prefix,
     out->read_begin.push_back(out->n_reads());
     return true;
 }
+}  // namespace
 
 // Base qualities as a current Illumina instrument reports them (four bins: 2, 12, 23, 37), for BAM files written from streams that
 // carry none: mostly 37, short runs of lower bins that get more frequent towards the 3' end of the read, a few reads bad from some

@@ -26,6 +26,10 @@ bool synth_long_stream(const np_synth_long_params& p, const std::string& contig_
 void synth_default_params(np_synth_params* p);
 // Generates the batch.  `contig_name_prefix` + index names the contigs.
 bool synth_stream(const np_synth_params& p, const std::string& contig_name_prefix, ReadStream* out);
+// The same workloads over contigs that are handed in (names + sequences: the assembly a polishing step wrote) -- the re-mapped reads of
+// the next step of a multi-step run, by construction instead of by a mapper (np_synth.cpp).
+bool synth_stream_on(const np_synth_params& p, const std::vector<std::string>& names, const std::vector<std::string>& drafts, ReadStream* out);
+bool synth_long_stream_on(const np_synth_long_params& p, const std::vector<std::string>& names, const std::vector<std::string>& drafts, ReadStream* out);
 // Serialises a stream (needs qualities loaded unless write_qual_ff) to fasta(+.fai) and bam(+.bai).
 bool write_stream_files(const ReadStream& s, const std::string& fasta, const std::string& bam, int bgzf_level,
                         std::string* err, const uint8_t* aux_pool = nullptr,
