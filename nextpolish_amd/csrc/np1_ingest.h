@@ -17,12 +17,13 @@ struct BamSource {
     bool have_bai = false;
     int fd = -1;
     uint64_t file_size = 0;
+    const uint8_t* map = nullptr;      // the BAM mapped read-only (null: mapping failed, the batches take the host loader)
     bool open(const std::string& fasta, const std::string& bam, std::string* err);
     ~BamSource();
 };
 
-// Host half of one batch, in pinned memory: draft strings, the compressed BGZF blocks of the batch's contigs, the block
-// table and the record anchors taken from the index.  Reused from batch to batch (its buffers only grow).
+// Host half of one batch: draft strings, where the compressed BGZF blocks of the batch's contigs lie in the file (runs of bytes + the block
+// table, from a walk over the headers in the mapped file) and the record anchors taken from the index.  Reused from batch to batch.
 struct Staging {
     struct Impl;
     Impl* impl;

@@ -28,6 +28,8 @@
 #include "np1_ingest.h"
 #include "np1_kmer_kernels.h"
 #include "np_bgzf.h"
+#include <sys/mman.h>
+
 #include "np_inflate_dev.h"
 #include "np_inflate_lane.h"
 #include "np_inflate_lds.h"
@@ -366,24 +368,34 @@ void scratch_stats(const Scratch* s, double out[5]) {
 }
 void scratch_stats_reset(Scratch* s) { if (s) { s->inflate_ms = s->crc_ms = 0; s->comp_bytes = s->inflated_bytes = s->launches = 0; } }
 
-struct HostPin {
+// pageable host memory that only grows (the draft strings of a batch: they leave through npcopy::h2d, which takes the bytes at call time)
+struct HostBuf {
     void* p = nullptr;
     size_t cap = 0;
     bool ensure(size_t bytes) {
         if (bytes <= cap) return true;
-        if (p) (void)npalloc::host_free(p);
-        p = nullptr;
+        free(p);
         cap = 0;
-        const size_t want = bytes + bytes / 4 + (1u << 20);
-        if (npalloc::host_malloc(&p, want, hipHostMallocPortable) != hipSuccess) { p = nullptr; return false; }
-        cap = want;
+        p = malloc(bytes + bytes / 4 + 4096);
+        if (!p) return false;
+        cap = bytes + bytes / 4 + 4096;
         return true;
     }
-    ~HostPin() { if (p) (void)npalloc::host_free(p); }
+    ~HostBuf() { free(p); }
 };
 
+// a run of file bytes the batch needs: [coff, coff + bytes) of the BAM lands at [comp_at, comp_at + bytes) of the device's compressed buffer
+struct FileRun { uint64_t coff, bytes, comp_at, last_block; };   // last_block: highest file offset at which a needed block may start
+
 struct Staging::Impl {
-    HostPin comp, draft;
+    // Round 6: the compressed bytes of a batch are no longer copied into pinned memory of the staging object.  The cold start of the
+    // from-files CLI was page-locking: a staging object grew to the compressed size of the largest batch it met (2.2 GB for a 250 Mb contig
+    // at 30x) at ~1.6 GB/s of hipHostMalloc, every loader thread its own, every growth from scratch -- 5 of the 8 s of a 3 Gb run.  Now
+    // prepare() walks the BGZF headers in the mapped file (no bulk read), and ingest() sends the runs to the device through the small ring
+    // of pinned slots every large pageable copy already uses (np_hostcopy.h): pread() straight into a slot on the helper threads, DMA out.
+    const BamSource* src = nullptr;
+    std::vector<FileRun> runs;
+    HostBuf draft;
     std::vector<npdev::BlockDesc> blocks;
     std::vector<uint64_t> block_coff;          // file offset of every block, ascending
     std::vector<uint32_t> block_size;          // its size in the file
@@ -423,7 +435,7 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
         tid[c] = src.hdr.name2id(names[c]);
     }
     if (draft_total >= 0xfff00000ull) { *err = "batch too large: draft must stay below 2^32 slots"; return -1; }
-    { const double t0 = now_ms(); if (!S.draft.ensure(draft_total + 64)) { *err = "hipHostMalloc failed"; return -1; } t_alloc += now_ms() - t0; }
+    { const double t0 = now_ms(); if (!S.draft.ensure(draft_total + 64)) { *err = "out of host memory"; return -1; } t_alloc += now_ms() - t0; }
     const double t_d0 = now_ms();
     std::string seq;
     size_t at = 0;
@@ -453,8 +465,11 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
     std::vector<size_t> order;
     for (size_t c = 0; c < nc; ++c) if (vr[c].second > vr[c].first) order.push_back(c);
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return vr[a].first < vr[b].first; });
-    struct Run { uint64_t coff, bytes, comp_at, last_block; };   // last_block: highest file offset at which a needed block may start
-    std::vector<Run> runs;
+    typedef FileRun Run;
+    std::vector<Run>& runs = S.runs;
+    runs.clear();
+    S.src = &src;
+    if (!src.map) return 1;      // (the file could not be mapped: host loader)
     for (size_t c : order) {
         const uint64_t c0 = vr[c].first >> 16;
         const bool partial = (vr[c].second & 0xffffu) != 0;
@@ -471,36 +486,12 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
     }
     uint64_t comp_at = 0, u_at = 0;
     for (Run& r : runs) { r.comp_at = comp_at; comp_at += r.bytes; }
-    { const double t0 = now_ms(); if (!S.comp.ensure(comp_at + 4096)) { *err = "hipHostMalloc failed"; return -1; } t_alloc += now_ms() - t0; }
     const double t_r0 = now_ms();
-    {   // the file bytes in pieces of 16 MiB on the host threads: one thread's pread() moves ~2.6 GB/s out of the page cache, which made this
-        // function, not the device, the slowest stage of the from-files pipeline (round 4: 2.45 s of staging against 0.74 s of device work
-        // for a 250 Mb batch, profiles/r4_e2e_300mb_cli.txt)
-        struct Piece { uint64_t at, coff, bytes; };
-        std::vector<Piece> pieces;
-        for (const Run& r : runs)
-            for (uint64_t done = 0; done < r.bytes; done += (uint64_t)16 << 20)
-                pieces.push_back(Piece{r.comp_at + done, r.coff + done, std::min<uint64_t>((uint64_t)16 << 20, r.bytes - done)});
-        std::atomic<bool> ok{true};
-        np::parallel_for(pieces.size(), 1, [&](size_t lo, size_t hi) {
-            for (size_t k = lo; k < hi && ok; ++k) {
-                uint64_t done = 0;
-                while (done < pieces[k].bytes) {
-                    const ssize_t g = pread(src.fd, (char*)S.comp.p + pieces[k].at + done, pieces[k].bytes - done, (off_t)(pieces[k].coff + done));
-                    if (g <= 0) { ok = false; return; }
-                    done += (uint64_t)g;
-                }
-            }
-        });
-        if (!ok) { *err = "BAM read failed"; return -1; }
-    }
-    t_read = now_ms() - t_r0;
-    memset((char*)S.comp.p + comp_at, 0, 4096);
     for (const Run& r : runs) {
         uint64_t p = 0;
         while (r.coff + p <= r.last_block) {
             if (p + 18 > r.bytes) { *err = "BAM truncated inside the indexed range"; return -1; }
-            const uint8_t* h = (const uint8_t*)S.comp.p + r.comp_at + p;
+            const uint8_t* h = src.map + r.coff + p;      // (the header walk touches two pages of the mapped file per block)
             if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { *err = "not a BGZF block where the index points"; return -1; }
             const uint32_t xlen = h[10] | (h[11] << 8);
             if (p + 12 + xlen > r.bytes) { *err = "BAM truncated inside the indexed range"; return -1; }
@@ -527,6 +518,7 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
             p += bsize;
         }
     }
+    t_read = now_ms() - t_r0;
     S.comp_bytes = comp_at;
     S.inflated_bytes = u_at;
     S.tid.assign(tid.begin(), tid.end());
@@ -579,8 +571,53 @@ int prepare(BamSource& src, const std::vector<std::string>& names, Staging* st, 
     }
     S.first_seg[nc] = (uint32_t)S.segs.size();
     if (timing)
-        fprintf(stderr, "[np1 staging] %zu contigs, %.1f MB of draft, %.1f MB compressed | ms: pinned allocations %.1f  draft fetch %.1f  file reads %.1f  block table + segments %.1f\n",
+        fprintf(stderr, "[np1 staging] %zu contigs, %.1f MB of draft, %.1f MB compressed | ms: allocations %.1f  draft fetch %.1f  header walk %.1f  segments %.1f\n",
                 nc, draft_total / 1e6, S.comp_bytes / 1e6, t_alloc, t_draft, t_read, now_ms() - t_begin - t_alloc - t_draft - t_read);
+    return 0;
+}
+
+// The runs' bytes of the file -> the device buffer, through the ring of pinned slots (np_hostcopy.h): rounds of up to kWave pieces of one slot
+// each, every piece read by pread() on a helper thread STRAIGHT INTO ITS SLOT (one host copy, the kernel's), then this thread -- the lane's,
+// the only one that talks to the runtime -- enqueues the DMA of each slot on q and gives it back with its event.  The ring holds twice a
+// round's slots, so the DMA of round k overlaps the reads of round k + 1.
+static int stream_runs_to_device(int fd, const std::vector<FileRun>& runs, uint8_t* dst, hipStream_t q) {
+    struct Piece { uint64_t at, coff; size_t bytes; };
+    std::vector<Piece> pieces;
+    for (const FileRun& r : runs)
+        for (uint64_t done = 0; done < r.bytes; done += npcopy::kSlotBytes)
+            pieces.push_back(Piece{r.comp_at + done, r.coff + done, (size_t)std::min<uint64_t>(npcopy::kSlotBytes, r.bytes - done)});
+    npcopy::Ring& R = npcopy::ring();
+    const size_t kWave = std::max<size_t>(1, std::min<size_t>(npcopy::kSlots / 2, np::host_threads()));
+    std::vector<npcopy::Slot> slot(kWave);
+    for (size_t p0 = 0; p0 < pieces.size();) {
+        const size_t n = std::min(kWave, pieces.size() - p0);
+        size_t have = 0;
+        for (; have < n; ++have)      // (the first of a round may be waited for; further ones only if they can be had without waiting for other threads)
+            if (!(have == 0 ? R.acquire(&slot[have]) : R.try_acquire(&slot[have]))) break;
+        if (have == 0) return -1;
+        std::atomic<bool> ok{true};
+        np::parallel_for(have, 1, [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; ++k) {
+                const Piece& pc = pieces[p0 + k];
+                size_t done = 0;
+                while (done < pc.bytes) {
+                    const ssize_t g = pread(fd, (char*)slot[k].p + done, pc.bytes - done, (off_t)(pc.coff + done));
+                    if (g <= 0) { ok = false; break; }
+                    done += (size_t)g;
+                }
+            }
+        });
+        hipError_t e = ok ? hipSuccess : hipErrorUnknown;
+        for (size_t k = 0; k < have; ++k) {
+            if (e == hipSuccess) e = hipMemcpyAsync(dst + pieces[p0 + k].at, slot[k].p, pieces[p0 + k].bytes, hipMemcpyHostToDevice, q);
+            if (e == hipSuccess) e = hipEventRecord(slot[k].ev, q);
+            slot[k].pending = e == hipSuccess;
+        }
+        if (e != hipSuccess) (void)hipStreamSynchronize(q);
+        for (size_t k = 0; k < have; ++k) R.release(slot[k]);
+        if (e != hipSuccess) return -1;
+        p0 += have;      // (fewer slots than pieces this round: the rest next time)
+    }
     return 0;
 }
 
@@ -615,7 +652,10 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         return -1;
     if (b->G) HIPCHK(npcopy::h2d(b->draft.p, S.draft.p, b->G, q));
     HIPCHK(npcopy::h2d(b->ctg_off.p, S.ctg_off.data(), 4 * (size_t)(nc + 1), q));
-    if (S.comp_bytes) HIPCHK(npcopy::h2d(W.comp.p, S.comp.p, S.comp_bytes + 4096, q));
+    if (S.comp_bytes) {
+        if (stream_runs_to_device(S.src->fd, S.runs, W.comp.as<uint8_t>(), q) != 0) { np1_set_error("BAM read failed"); return -1; }
+        HIPCHK(hipMemsetAsync(W.comp.as<uint8_t>() + S.comp_bytes, 0, 4096, q));
+    }
     if (n_blocks) HIPCHK(npcopy::h2d(W.blocks.p, S.blocks.data(), sizeof(npdev::BlockDesc) * (size_t)n_blocks, q));
     if (n_segs) HIPCHK(npcopy::h2d(W.segs.p, S.segs.data(), sizeof(Segment) * (size_t)n_segs, q));
     HIPCHK(npcopy::h2d(W.first_seg.p, S.first_seg.data(), 4 * (size_t)(nc + 1), q));
@@ -689,10 +729,11 @@ int ingest(np1_batch* b, Staging* st, bool with_qual, Scratch* scr, const np::Ba
         if (!W.h_status[i]) continue;
         const npdev::BlockDesc& d = S.blocks[i];
         std::vector<uint8_t> tmp(d.out_len ? d.out_len : 1);
-        if (!np::bgzf_inflate_block((const uint8_t*)S.comp.p + d.in_off, d.in_len, tmp.data(), d.out_len)) { np1_set_error("corrupt BGZF block in the BAM"); return -1; }
+        const uint8_t* payload = S.src->map + S.block_coff[i] + (S.block_size[i] - d.in_len - 8u);      // (in the mapped file: header, payload, CRC + ISIZE)
+        if (!np::bgzf_inflate_block(payload, d.in_len, tmp.data(), d.out_len)) { np1_set_error("corrupt BGZF block in the BAM"); return -1; }
         if (getenv("NP_BGZF_NO_CRC") == nullptr && d.out_len) {     // blocks that come back to the host are checked here (the device checked the others)
             uint32_t want;
-            memcpy(&want, (const uint8_t*)S.comp.p + d.in_off + d.in_len, 4);
+            memcpy(&want, payload + d.in_len, 4);
             if (np::crc32_block(tmp.data(), d.out_len) != want) { np1_set_error("corrupt BGZF block in the BAM (CRC mismatch)"); return -1; }
         }
         HIPCHK(npcopy::h2d_sync(W.inflated.as<uint8_t>() + d.out_off, tmp.data(), d.out_len));
@@ -785,9 +826,16 @@ bool BamSource::open(const std::string& fasta, const std::string& bam, std::stri
     if (fd < 0) { *err = "cannot open BAM: " + bam; return false; }
     const off_t sz = lseek(fd, 0, SEEK_END);
     file_size = sz > 0 ? (uint64_t)sz : 0;
+    if (file_size) {      // read-only view of the file for the BGZF header walk and the few blocks the host inflates itself (a failure only costs the device path)
+        void* m = mmap(nullptr, (size_t)file_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) { map = static_cast<const uint8_t*>(m); (void)madvise(m, (size_t)file_size, MADV_RANDOM); }
+    }
     return true;
 }
-BamSource::~BamSource() { if (fd >= 0) ::close(fd); }
+BamSource::~BamSource() {
+    if (map) (void)munmap(const_cast<uint8_t*>(map), (size_t)file_size);
+    if (fd >= 0) ::close(fd);
+}
 
 }  // namespace np1ingest
 
