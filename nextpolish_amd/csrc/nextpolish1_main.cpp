@@ -4,6 +4,10 @@
 // prints ">name_<step>\nseq" per contig in FASTA-index order.  Unlike the reference, which loops
 // score_chain contig by contig, the contigs travel to the GPU in batches of NP1_BATCH_BP draft bases (default 16 M) on
 // NP1_LANES device lanes (default 3) while host threads inflate and split the records of the next batches (np1_pipe.cpp).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +47,12 @@ int main(int argc, char* argv[]) {
         return 0;
     }
     time_t t_start = time(nullptr);
+#if defined(F_SETPIPE_SZ)
+    {   // stdout into a pipe (the usual `> output.fa` is a file): the largest pipe the system gives, so that a contig's text leaves in a few writes
+        struct stat so;
+        if (fstat(1, &so) == 0 && S_ISFIFO(so.st_mode)) (void)fcntl(1, F_SETPIPE_SZ, 1 << 20);
+    }
+#endif
     Configure* cfg = (step == 5) ? config_init(argv[2], nullptr, argv[3]) : config_init(argv[2], argv[3], argc > 4 ? argv[4] : nullptr);
     if (step == 1 || step == 2) {
         if (!cfg->bamfn) { fprintf(stderr, "cannot access BAM %s\n", argv[3]); return 1; }

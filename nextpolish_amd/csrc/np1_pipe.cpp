@@ -287,7 +287,7 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
     struct Done { std::vector<std::string> names; std::vector<char> out; std::vector<uint32_t> bounds; };
     std::map<int, Done> done;              // polished batches waiting for their turn at the sink
     int next_load = 0, next_polish = 0, next_emit = 0, in_memory = 0;
-    bool failed = false, emitting = false;
+    bool failed = false;
     std::string err;
     auto fail = [&](const std::string& e) {
         std::lock_guard<std::mutex> g(mu);
@@ -400,12 +400,17 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
             d.out.assign(s, s + b[d.names.size()]);     // strings are not NUL-terminated inside the blob: the sink gets (pointer, length)
             std::unique_lock<std::mutex> g(mu);
             done[k] = std::move(d);
-            if (!emitting) {          // one thread at a time drains the in-order queue
-                emitting = true;
-                emit_ready(g);
-                emitting = false;
-            }
-            cv.notify_all();
+            cv.notify_all();          // (the emitter thread below hands the batches to the sink, in order)
+        }
+    };
+    // Round 6: the sink runs on a thread of its own.  It used to run on whichever lane finished a batch while nobody else was emitting -- and
+    // the CLI's sink writes the FASTA text into a pipe: 3 GB at the pace of the reader held one of three lanes half of the time.
+    auto emitter = [&]() {
+        std::unique_lock<std::mutex> g(mu);
+        for (;;) {
+            cv.wait(g, [&] { return failed || next_emit >= n || done.count(next_emit); });
+            if (failed || next_emit >= n) return;
+            emit_ready(g);
         }
     };
     std::vector<std::thread> th;
@@ -414,9 +419,16 @@ int np1_pipe_run_files(np1_pipe* p, const char* fasta, const char* bam, const ch
     for (size_t i = 1; i < p->lanes.size(); ++i) {      // lanes take the staged batches as they come: one that cannot start is not missed
         try { th.emplace_back(lane_work, i); } catch (const std::system_error&) { break; }
     }
+    bool have_emitter = true;
+    try { th.emplace_back(emitter); } catch (const std::system_error&) { have_emitter = false; }
     lane_work(0);
+    if (!have_emitter) {      // (no thread to be had: everything at the end, in order)
+        std::unique_lock<std::mutex> g(mu);
+        if (!failed) emit_ready(g);
+        next_emit = n;
+    }
     for (std::thread& t : th) t.join();
-    {   // whatever finished out of turn while another thread was emitting
+    {   // (nothing is left here unless the run failed)
         std::unique_lock<std::mutex> g(mu);
         if (!failed) emit_ready(g);
         for (auto& kv : ready) if (kv.second.stream) np1_stream_free(kv.second.stream);
