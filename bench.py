@@ -6,10 +6,11 @@ MI355X): a FIXED synthetic draft (contig lengths log-uniform) + 30
 The contigs are dealt longest-first over the N ranks (contigs are independent units: strong scaling of one fixed draft, no
 data-path collective; reference: source/lib/nextpolish1.py:181-189,223-224) and packed into batches of <= 260 Mb.
 
-One "step" = one full score_chain pass over the WHOLE draft in SURVEY.md 8d's timing scope 1: the decoded record stream in pinned
-host memory -> async H2D -> every kernel of np1_device.hip's launch sequence -> D2H of the polished strings, double-buffered on
-the device lanes, all inside the timed region (`value`).  Beside it, in the same JSON line:
-  resident          the same pass with the batches already resident in HBM (no PCIe inside): what the kernels alone sustain
+One "step" = one full score_chain pass over the WHOLE draft with every record batch RESIDENT IN HBM when the timed region starts
+(SURVEY.md 8d's timing scope 1; since round 6 -- rounds 1-5 timed the PCIe-inclusive pass and reported the resident one beside it):
+every kernel of np1_device.hip's launch sequence over all batches on the device lanes (`value`).  Beside it, in the same JSON line:
+  streamed          the PCIe-inclusive rate of the same pass: decoded records in pinned host memory -> async H2D -> kernels -> D2H of the
+                    polished strings, double-buffered on the lanes (bound by the H2D of the record stream; never `value`)
   e2e_from_files    FASTA + sorted BAM on disk (page cache) -> polished FASTA at the full size, on a BAM with Illumina-like binned
                     base qualities: cold process of the CLI and a warm process (scope 2); the BAM's bytes per record; on a one-batch
                     slice the same with no qualities (9:1) and with incompressible ones
@@ -629,7 +630,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--resident-passes", type=int, default=5, help="timed passes of the resident (no PCIe) sub-measurement")
+    ap.add_argument("--streamed-passes", type=int, default=3, help="timed passes of the PCIe-inclusive sub-measurement (inputs in pinned host memory)")
     ap.add_argument("--parity-mb", type=float, default=8.0, help="draft bases compared with the CPU oracle inside the run")
     ap.add_argument("--parity-big-seconds", type=float, default=180.0, help="a batch whose shortest contig is longer than 40 Mb is still checked when the oracle (one core, ~2 Mbp/s) walks that contig within this many seconds")
     ap.add_argument("--workload", default="c5_3gb_30x", choices=sorted(WORKLOADS))
@@ -744,30 +745,30 @@ def main():
         pipe.close()
         return
 
-    # ---- the timed steps (SURVEY 8d scope 1): pinned host -> H2D -> kernels -> D2H, double-buffered on the lanes, all inside
-    for _ in range(args.warmup):
-        pipe.run(streams, cfg=cfg, fetch=False)          # warm: lane batches grow to their final size
+    # ---- PCIe-inclusive passes (reported beside `value`, never as it): pinned host -> H2D -> kernels -> D2H, double-buffered on the lanes
+    pipe.run(streams, cfg=cfg, fetch=False)              # warm: lane batches grow to their final size
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.streamed_passes):
         pipe.run(streams, cfg=cfg, fetch=False)
     sync_all()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    dt_str = max_over_ranks(time.perf_counter() - t0)
     L.np1_stream_upload_bytes.restype = C.c_uint64
     L.np1_stream_upload_bytes.argtypes = [C.c_void_p]
     h2d_bytes = sum(int(L.np1_stream_upload_bytes(s.handle)) for s in streams)   # what really crosses PCIe per pass (2-bit bases, 16-bit counts, no offsets)
     parity = parity_check(pipe, streams, int(args.parity_mb * 1e6), big_seconds=args.parity_big_seconds) if rank == 0 else None
     streamed_lengths = pipe.result_lengths(streams)
 
-    # ---- the same pass with the batches resident in HBM (no PCIe inside the timed region)
+    # ---- the timed steps (SURVEY 8d scope 1): every batch of the rank's share of the draft resident in HBM when the clock starts; a step = one
+    # score_chain pass over all of them on the lanes (no H2D / D2H inside).  W untimed steps, then exactly K between two barriers.
     if L.np1_pipe_upload(pipe.handle, harr, len(streams)) != 0:
         raise SystemExit("upload: " + nat.last_error())
-    resident(1)
+    resident(args.warmup)
     sync_all()
     t0 = time.perf_counter()
-    resident(args.resident_passes)
+    resident(args.steps)
     sync_all()
-    dt_res = max_over_ranks(time.perf_counter() - t0)
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     # ---- per-stage HIP-event timing on the pipeline's own stream (separate instrumented passes, one lane, batch by batch)
     stage_acc, launches, polished, updates = {}, 0, [], 0
@@ -848,34 +849,36 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = draft_bp_total / 1e6 / (dt / args.steps)
-        resident_v = draft_bp_total / 1e6 / (dt_res / args.resident_passes)
+        streamed_v = draft_bp_total / 1e6 / (dt_str / args.streamed_passes)
         out = {
-            "metric": "polished Mbp/s (score_chain, 30x short reads, one fixed draft; decoded records in pinned host memory -> H2D -> kernels -> D2H)",
+            "metric": "polished Mbp/s (score_chain, 30x short reads, one fixed draft; record batches resident in HBM -> kernels -> polished strings in HBM)",
             "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8/int64", "data": "synthetic",
             "config": {"workload": "%s: %.1f Mb synthetic draft in %d contigs (log-uniform %g-%g bp) + %.0fx simulated 2x150 bp PE reads "
                                    "(%d records on rank 0), dealt longest-first over %d GPU(s), %d batches of <= %.0f Mb on rank 0; "
-                                   "one step = one score_chain pass over the whole draft, inputs in pinned host memory, H2D and D2H inside the timed region"
+                                   "one step = one score_chain pass over the whole draft, every batch resident in HBM when the timed region starts"
                                    % (args.workload, draft_bp_total / 1e6, len(lens), lo, hi, depth, n_reads, world, len(batches), batch_bp / 1e6),
                        "slot_votes_per_step_rank0": updates // n_inst, "lanes": args.lanes,
                        "parallelism": "contigs dealt longest-first x%d (no collective)" % world,
                        "synth_seconds": round(t_gen, 1), "host_cores": ncpu, "host_threads_per_rank": per_rank,
-                       "h2d_gb_per_s_rank0": round(h2d_bytes * args.steps / dt / 1e9, 2), "h2d_bytes_per_draft_bp": round(h2d_bytes / max(1, sum(int(x.ctg_len.sum()) for x in streams)), 2)},
-            "resident": {"mbp_s": round(resident_v, 2), "ms_per_pass": round(dt_res / args.resident_passes * 1e3, 3), "passes": args.resident_passes,
-                         "what": "the same pass with every batch already resident in HBM (no H2D / D2H inside), %d lanes: what the kernels alone sustain" % args.lanes},
+                       },
+            "streamed": {"mbp_s": round(streamed_v, 2), "ms_per_pass": round(dt_str / args.streamed_passes * 1e3, 3), "passes": args.streamed_passes,
+                         "h2d_gb_per_s_rank0": round(h2d_bytes * args.streamed_passes / dt_str / 1e9, 2), "h2d_bytes_per_draft_bp": round(h2d_bytes / max(1, sum(int(x.ctg_len.sum()) for x in streams)), 2),
+                         "what": "the PCIe-inclusive rate of the same pass (never `value`): decoded records in pinned host memory -> H2D -> kernels -> D2H of the polished strings, "
+                                 "double-buffered on %d lanes; bound by the H2D of the record stream" % args.lanes},
             "upload_forms": {"build_s": round(t_forms, 3), "pin_s": round(t_pin, 3), "host_threads": max(1, min(per_rank, len(streams))),
-                             "streamed_single_use_mbp_s": round(my_bp / 1e6 / (t_forms + dt / args.steps), 2),
-                             "what": "`value` uploads the records in forms (2-bit bases, compact record fields) that are built once per stream on the host BEFORE the "
-                                     "timed steps (build_s, on host_threads threads; pin_s = page-locking them); streamed_single_use = this rank's draft / (build_s + one "
-                                     "step): the rate of a decoded stream that is polished exactly once.  From files the device-side ingest never builds them (e2e_from_files)"},
+                             "streamed_single_use_mbp_s": round(my_bp / 1e6 / (t_forms + dt_str / args.streamed_passes), 2),
+                             "what": "the streamed passes upload the records in forms (2-bit bases, compact record fields) that are built once per stream on the host BEFORE the "
+                                     "timed passes (build_s, on host_threads threads; pin_s = page-locking them); streamed_single_use = this rank's draft / (build_s + one "
+                                     "streamed pass): the rate of a decoded stream that is polished exactly once.  From files the device-side ingest never builds them (e2e_from_files)"},
             "parity": {k: v for k, v in parity.items() if k != "oracle_md5"} if parity else parity,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic["bytes"] if traffic else None,
                          "traffic_detail": traffic if traffic else traffic_note,
                          "algorithmic_bytes_per_launch": int(alg_per_launch), "kernel_ms": round(stage_ms[dom], 4),
                          "launches_averaged": launches, "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-                         "achieved_whole_pass_gbs": round((sum(alg_in) + sum(polished)) / (dt_res / args.resident_passes) / 1e9, 2)},
+                         "achieved_whole_pass_gbs": round((sum(alg_in) + sum(polished)) / (dt / args.steps) / 1e9, 2)},
         }
         if parity is not None and not parity["identical"] and not os.environ.get("NP1_ABLATE"):   # (NP1_ABLATE: timing experiments with wrong results)
             raise SystemExit("bench: the polished strings differ from the oracle: %r" % (parity,))
