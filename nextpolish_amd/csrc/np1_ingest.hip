@@ -120,10 +120,12 @@ int launch_inflate_lds(hipStream_t q, const uint8_t* comp, const npdev::BlockDes
     if (scratch.ensure((size_t)waves * 64u * sizeof(nplds::Scratch))) return -1;
     // NP1_LDS_DBG=<bits>: timing experiments with parts of the work left out (np_inflate_lds.h; the output is wrong)
     static const int dbg = getenv("NP1_LDS_DBG") ? atoi(getenv("NP1_LDS_DBG")) : 0;
-    if (LB == 8 && dbg == 1) k_inflate_lds<LB, DB, 1><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
-    else if (LB == 8 && dbg == 2) k_inflate_lds<LB, DB, 2><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
-    else if (LB == 8 && dbg == 3) k_inflate_lds<LB, DB, 3><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
-    else k_inflate_lds<LB, DB><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
+    if constexpr (LB == 7 && DB == 5) {      // (the experiment builds exist for the default table sizes only)
+        if (dbg == 1) { k_inflate_lds<LB, DB, 1><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>()); return 0; }
+        if (dbg == 2) { k_inflate_lds<LB, DB, 2><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>()); return 0; }
+        if (dbg == 3) { k_inflate_lds<LB, DB, 3><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>()); return 0; }
+    }
+    k_inflate_lds<LB, DB><<<waves, 64, 0, q>>>(comp, blocks, n_blocks, out, status, scratch.as<nplds::Scratch>());
     return 0;
 }
 
