@@ -830,7 +830,7 @@ bool BamSource::open(const std::string& fasta, const std::string& bam, std::stri
     file_size = sz > 0 ? (uint64_t)sz : 0;
     if (file_size) {      // read-only view of the file for the BGZF header walk and the few blocks the host inflates itself (a failure only costs the device path)
         void* m = mmap(nullptr, (size_t)file_size, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m != MAP_FAILED) { map = static_cast<const uint8_t*>(m); (void)madvise(m, (size_t)file_size, MADV_RANDOM); }
+        if (m != MAP_FAILED) map = static_cast<const uint8_t*>(m);      // (default read-around: a fault brings the next header's page along)
     }
     return true;
 }

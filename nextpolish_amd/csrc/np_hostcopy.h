@@ -35,7 +35,8 @@ namespace npcopy {
 
 constexpr size_t kDirectMax = 256 << 10;      // pageable copies up to this size are left to the runtime's own staging
 constexpr size_t kSlotBytes = 8 << 20;
-constexpr int kSlots = 16;      // (round 6: 6 -> 16: the from-files ingest reads half of them full in parallel while the other half is on its way to the device)
+constexpr int kSlots = 16;      // (round 6: 6 -> 16: the from-files ingest reads half of them full in parallel while the other half is on its way to the device;
+                                // 32 x 4 MiB was measured too: no faster)
 
 struct Slot { void* p = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
 
