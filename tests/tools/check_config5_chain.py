@@ -71,7 +71,9 @@ def write_step(nat, contigs, task, k, d):
     return fa, bam, n
 
 
-def run(size, make_golden=False, workdir=None):
+def run(size, make_golden=False, workdir=None, engine="gpu"):
+    """engine "gpu": the product (nextpolish2.so, nextpolish1.so's file pipe); "model": the host models of both launch sequences
+    (tests/model/libnp2_model.so, libnp1_model.so) -- the same chain on the CPU, for the suite that runs without a GPU"""
     from nextpolish_amd import _native as nat
     from conftest import parse_cli_fasta
     import ref2_binding as rb
@@ -81,7 +83,10 @@ def run(size, make_golden=False, workdir=None):
     contigs = first_assembly(S["lens"])
     info = {"size": size, "draft_bp": sum(S["lens"]), "steps": [], "identical": True}
     pipe = L2 = None
-    if not make_golden:
+    if not make_golden and engine == "model":
+        import model_binding as mb
+        L2 = rb.bind(os.path.join(TESTS, "model", "libnp2_model.so"))
+    elif not make_golden:
         from nextpolish_amd.device import Pipe
         pipe = Pipe(0, lanes=2)
         L2 = rb.bind(os.path.join(ROOT, "nextpolish_amd", "lib", "nextpolish2.so"))
@@ -108,6 +113,11 @@ def run(size, make_golden=False, workdir=None):
                     out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "nextpolish1"), cmd, fa, bam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                                          check=True).stdout.decode()
                     got = parse_cli_fasta(out)
+                elif engine == "model":
+                    st = nat.Stream.load(fa, bam, with_qual=(task == 2))
+                    res1 = mb.score_chain(st, fused=1) if task == 1 else mb.kmer_count_replay(st, nat.default_config(), bam)
+                    got = dict(zip(st.names, res1))
+                    st.close()
                 else:
                     got = dict(pipe.run_files(fa, bam, batch_bp=S["batch_bp"], task=task))
                 nxt = [(n, got[n]) for n in order]
