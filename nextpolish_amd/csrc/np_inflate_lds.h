@@ -37,6 +37,8 @@
 namespace nplds {
 
 typedef uint64_t __attribute__((aligned(1))) u64u;
+typedef uint32_t __attribute__((aligned(1))) u32u;
+typedef uint16_t __attribute__((aligned(1))) u16u;
 
 // per-lane HBM scratch: code lengths while the tables of a block are built (never touched by the symbol loop)
 struct Scratch {
@@ -234,14 +236,18 @@ NPD_UNROLL
     return w;
 }
 
-// 32 bytes at p, of which the caller uses the first n <= 32.  On the device the output buffer has slack behind its last block, so the four
-// words are read whatever n is; the host build never reads at or beyond `limit`.
-NPD_HD void load32(const uint8_t* p, const uint8_t* limit, uint64_t* a0, uint64_t* a1, uint64_t* a2, uint64_t* a3) {
+struct __attribute__((packed, aligned(1))) Pair64 { uint64_t a, b; };
+NPD_HD void store16(uint8_t* p, uint64_t a, uint64_t b) { *reinterpret_cast<Pair64*>(p) = Pair64{a, b}; }
+
+// 32 bytes at p, of which the caller uses the first n <= 32.  On the device the output buffer has slack behind its last block, so whole
+// words are read whatever n is (the second pair only when n > 16); the host build never reads at or beyond `limit`.
+NPD_HD void load32(const uint8_t* p, const uint8_t* limit, uint32_t n, uint64_t* a0, uint64_t* a1, uint64_t* a2, uint64_t* a3) {
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)limit;
     *a0 = *reinterpret_cast<const u64u*>(p); *a1 = *reinterpret_cast<const u64u*>(p + 8);
-    *a2 = *reinterpret_cast<const u64u*>(p + 16); *a3 = *reinterpret_cast<const u64u*>(p + 24);
+    if (n > 16u) { *a2 = *reinterpret_cast<const u64u*>(p + 16); *a3 = *reinterpret_cast<const u64u*>(p + 24); }      // (a transaction per lane that asks)
 #else
+    (void)n;
     uint64_t w[4] = {0, 0, 0, 0};
     for (int i = 0; i < 32 && p + i < limit; ++i) w[i >> 3] |= (uint64_t)p[i] << (8 * (i & 7));
     *a0 = w[0]; *a1 = w[1]; *a2 = w[2]; *a3 = w[3];
@@ -356,7 +362,7 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
             if (c_rem) {
                 uint32_t piece = c_rem < 32 ? c_rem : 32;
                 if (c_off < piece) piece = c_off;
-                if (!(DBG & 2)) load32(c_dst - c_off, out_end, &a0, &a1, &a2, &a3);
+                if (!(DBG & 2)) load32(c_dst - c_off, out_end, piece, &a0, &a1, &a2, &a3);
                 f_n = piece;
                 f_d = c_dst;
                 c_dst += piece;
@@ -419,14 +425,20 @@ NPD_HD int inflate_block(const uint8_t* src, uint32_t src_len, uint8_t* dst, uin
             b.slide_take();
             if (f_n) {
                 if (!(DBG & 2)) {
+                    // exactly f_n <= 32 bytes in as few stores as their count has bits (16 + 8 + 4 + 2 + 1): every store instruction is a transaction
+                    // per lane, and the decoder runs at about half of L2's transaction rate (profiles/r6_inflate_lds.txt item 10); byte by byte the
+                    // last n < 8 bytes alone were up to seven
                     uint8_t* d = f_d;
-                    uint32_t n = f_n;
-                    uint64_t tail = a0;
-                    if (n >= 8) { *reinterpret_cast<u64u*>(d) = a0; d += 8; n -= 8; tail = a1; }
-                    if (n >= 8) { *reinterpret_cast<u64u*>(d) = a1; d += 8; n -= 8; tail = a2; }
-                    if (n >= 8) { *reinterpret_cast<u64u*>(d) = a2; d += 8; n -= 8; tail = a3; }
-                    if (n >= 8) { *reinterpret_cast<u64u*>(d) = a3; d += 8; n -= 8; tail = 0; }
-                    for (uint32_t i = 0; i < n; ++i) d[i] = (uint8_t)(tail >> (8 * i));
+                    const uint32_t n = f_n;
+                    uint64_t w0 = a0, w1 = a1, w2 = a2, w3 = a3;
+                    if (n >= 16u) { store16(d, w0, w1); d += 16; w0 = w2; w1 = w3; }
+                    if (n == 32u) { store16(d, w0, w1); }
+                    else {
+                        if (n & 8u) { *reinterpret_cast<u64u*>(d) = w0; d += 8; w0 = w1; }
+                        if (n & 4u) { *reinterpret_cast<u32u*>(d) = (uint32_t)w0; d += 4; w0 >>= 32; }
+                        if (n & 2u) { *reinterpret_cast<u16u*>(d) = (uint16_t)w0; d += 2; w0 >>= 16; }
+                        if (n & 1u) *d = (uint8_t)w0;
+                    }
                 }
                 f_n = 0;
             }
