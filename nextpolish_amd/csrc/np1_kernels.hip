@@ -396,13 +396,13 @@ __device__ __forceinline__ void tile_epilogue(const VoteLane<E>& vl, const uint3
 template <int E>
 __device__ __forceinline__ void vote_part(const uint32_t* d, const SeqLds& sq, bool valid, uint32_t s, uint32_t g,
                                           int32_t jj, int lane, uint32_t& rsym, uint32_t& basemask, VoteLane<E>& vl,
-                                          uint32_t* L, uint32_t& nvotes, uint32_t ablate = 0) {
+                                          uint32_t* L, uint32_t ablate = 0) {
     const bool cov = valid && s >= d[0] && s <= d[1];
     if (cov) rsym = (ablate & 8u) ? (g & 0xfu) : desc_symbol(d, g, jj, sq);
     const uint32_t p1 = wave_shr1(rsym), p2 = wave_shr1(p1);
     if (cov) {
         basemask |= 1u << rsym;
-        if (lane >= 2 && !(ablate & 4u)) { vl.tally(p2 << 8 | p1 << 4 | rsym, L, lane); ++nvotes; }
+        if (lane >= 2 && !(ablate & 4u)) vl.tally(p2 << 8 | p1 << 4 | rsym, L, lane);
     }
 }
 
@@ -467,7 +467,6 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
     VoteLane<E> vl;
     vl.init(d2 << 8 | d1 << 4 | dsym);
     uint32_t basemask = 1u << dsym;
-    uint32_t nvotes = 0;
     const uint32_t sv = valid ? s : 0xffffffffu;   // slot for coverage tests (never covered when invalid)
     const int64_t cs = (int64_t)c * VOTE_CH - 2, ce = (int64_t)c * VOTE_CH + VOTE_CH - 1;
     __syncthreads();
@@ -556,7 +555,6 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
                             const bool m0 = vote && k == vl.k0, m1 = vote && k == vl.k1;
                             vl.c0 += m0 ? 1u : 0u;
                             vl.c1 += m1 ? 1u : 0u;
-                            nvotes += vote ? 1u : 0u;
                             const bool rest = vote && !m0 && !m1;
                             if (__ballot(rest) != 0ull) {
                                 if (rest) vl.tally(k, L, lane);   // a context seen for the first time, or one kept in the LDS list
@@ -565,11 +563,11 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
                             const uint32_t* d = dsc + i * DESC_WORDS;   // LDS: every access below is a ds_read broadcast
                             const SeqLds sq{seqb + (h.w - sq0_lo)};
                             uint32_t rsym = 0;   // this record's symbol at my slot (kept across the parts of a chained record)
-                            vote_part<E>(d, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nvotes);
+                            vote_part<E>(d, sq, valid, s, g, jj, lane, rsym, basemask, vl, L);
                             uint32_t nx = d[DESC_NEXT];
                             while (nx) {   // rare: record with more indel operations than one descriptor holds; parts live in HBM
                                 const uint32_t* dg = ovf_pool + (uint64_t)(nx - 1) * DESC_WORDS;
-                                vote_part<E>(dg, sq, valid, s, g, jj, lane, rsym, basemask, vl, L, nvotes);
+                                vote_part<E>(dg, sq, valid, s, g, jj, lane, rsym, basemask, vl, L);
                                 nx = dg[DESC_NEXT];
                             }
                         }
@@ -581,6 +579,11 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
             __syncthreads();
         }
     }
+    // the vote statistic: every vote went into exactly one counter of its lane, and the draft's own context opened c0 with 1 (round 6: it
+    // used to be counted vote by vote inside the record loop)
+    uint32_t tsum = vl.c0 + vl.c1;
+    for (uint32_t e = 2; e < vl.n; ++e) tsum += L[(e - 2) * 64 + lane] & 0xffffu;
+    uint32_t nvotes = tsum - 1u;
     for (int o = 32; o > 0; o >>= 1) nvotes += __shfl_down(nvotes, o);
     const bool ovf_any = chunk_ok && __ballot(vl.ovf) != 0ull;
     const bool single = __popc(basemask) == 1;
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(NW * 64) void k_tile3(ReadsDev R, const uint32_t* _
     const bool prev_is_single = first || psingle != 0;
     // flag_single bit 8 (FLAG_ALL_RECORDS): general-rate path, every slot spills a record (np1_core.h:dp_run<true>)
     tile_epilogue<E, NW>(vl, L, tid, c, chunk_ok && !ovf_any, ovf_any, valid, s, info, dsym, first, prev_dsym, single, prev_is_single,
-                         vl.total(L, lane), slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci,
+                         tsum & 0xffffu, slot_res, slot_rec, pool, pool_cap, counters, heads, heads_cap, redo_out, redo_ci,
                          flag_single & 0xffu, nvotes, votes, (flag_single & FLAG_ALL_RECORDS) != 0);
 }
 
