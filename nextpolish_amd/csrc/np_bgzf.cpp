@@ -122,6 +122,7 @@ bool BgzfReader::fill_window(uint64_t coff) {
     }
     if (win_.empty()) return got == 0 || got < 18 ? (got == 0) : false;   // clean EOF only when nothing is left
     uwin_.resize(utotal + 8);
+    memset(uwin_.data() + utotal, 0, 8);      // (the slack behind the last block reads as zero, as it did when the storage was a vector)
     const uint64_t pt2 = prof_now();
     g_prof_ns[1] += pt2 - pt1;
     struct Clock { uint64_t t0; int slot; ~Clock() { g_prof_ns[slot] += prof_now() - t0; ++g_prof_n[slot - 2]; } };

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <cstdlib>
+#include <new>
 #include <vector>
 
 namespace np {
@@ -41,8 +43,30 @@ private:
     bool load_block();                 // make the block at file offset next_coff_ current
     bool fill_window(uint64_t coff);   // read + inflate the blocks starting at coff
     FILE* fp_ = nullptr;
-    std::vector<uint8_t> cwin_;        // compressed window
-    std::vector<uint8_t> uwin_;        // inflated window
+    // a window's bytes: storage that only grows and is NOT cleared (a std::vector zero-fills what resize() adds: with the batch inflater's
+    // 48 MB windows that was ~40 ms per 5 Mb window of a long-read worker, more than the header walk it sat in)
+    struct RawBuf {
+        uint8_t* p = nullptr;
+        size_t n = 0, cap = 0;
+        RawBuf() = default;
+        RawBuf(const RawBuf&) = delete;
+        RawBuf& operator=(const RawBuf&) = delete;
+        ~RawBuf() { free(p); }
+        uint8_t* data() { return p; }
+        const uint8_t* data() const { return p; }
+        size_t size() const { return n; }
+        void resize(size_t want) {
+            if (want > cap) {
+                free(p);
+                cap = want + want / 8 + 4096;
+                p = static_cast<uint8_t*>(malloc(cap));
+                if (!p) { cap = 0; throw std::bad_alloc(); }
+            }
+            n = want;
+        }
+    };
+    RawBuf cwin_;        // compressed window
+    RawBuf uwin_;        // inflated window
     std::vector<WinBlock> win_;
     size_t win_i_ = 0;                 // current block inside win_
     const uint8_t* ubuf_ = nullptr;    // inflated current block (<= 64 KiB)

@@ -121,6 +121,28 @@ def test_gpu_megabase_window_matches_reference_golden(tmp_path):
     assert [hashlib.md5(p[0].encode()).hexdigest() for p in got["ctg0"]] == want["md5"]
 
 
+def test_gpu_reader_windows_inflated_on_the_device_give_the_same_consensus(tmp_path):
+    """NP2_INFLATE=device (opt-in): the BAM reader's windows of BGZF blocks go to the wave-per-block decoder on the device (np_bgzf_dev.hip), CRC
+    checked there; the 1.2 Mb golden window again, and the reader's own statistics say that windows really went to the device.  (Round 6 also
+    tried the lane-per-block decoder of the short-read ingest here: correct, but a long-read block is ~25 k tokens of nearly incompressible bases
+    and takes a lane ~35 ms -- 147 ms of inflate per 5 Mb window against 69 with a wave per block and 120 on two host threads.)"""
+    import hashlib
+    from nextpolish_amd import _native as nat
+    st = nat.Stream.synth_long([1200000], depth=20.0, seed=31)
+    fa, bam, fofn = str(tmp_path / "g.fa"), str(tmp_path / "r.bam"), str(tmp_path / "bam.fofn")
+    st.write_files(fa, bam)
+    st.close()
+    open(fofn, "w").write(bam + "\n")
+    got, err = run_polish(PRODUCT_SO, fa, fofn, 1, env={"NP2_INFLATE": "device", "NP2_TIMING": "1"})
+    assert got is not None, err
+    want = GOLD["mb_window"]
+    assert [p[1] for p in got["ctg0"]] == want["lens"]
+    assert [hashlib.md5(p[0].encode()).hexdigest() for p in got["ctg0"]] == want["md5"]
+    import re
+    m = re.search(r"device inflate [0-9.]+ ms \((\d+) windows\)", err)
+    assert m and int(m.group(1)) > 0, err[-600:]
+
+
 def test_gpu_deep_pileup_matches_reference_golden(tmp_path):
     """100x: few columns with <= 8 live entries, so the run decomposition switches to cuts of width 32."""
     import hashlib
