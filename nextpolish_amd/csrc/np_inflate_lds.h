@@ -160,6 +160,9 @@ NPD_UNROLL
     return sym << 4 | len;
 }
 
+struct __attribute__((packed, aligned(1))) Pair64 { uint64_t a, b; };
+NPD_HD void store16(uint8_t* p, uint64_t a, uint64_t b) { *reinterpret_cast<Pair64*>(p) = Pair64{a, b}; }
+
 // The bit reader.  The stream's bytes come through a WINDOW OF REGISTERS: w0..w4 = the stream's bytes [base, base + 40), n0 n1 = the 16
 // behind them.  A refill takes its eight bytes out of the window with shifts and selects -- no memory access; the window slides by 16 bytes
 // (slide(), called where the symbol loop waits for memory anyway) and then asks for the next 16.
@@ -217,7 +220,19 @@ struct Bits {
             pos -= 16;
         }
     }
-    NPD_HD void slide_ask() { n0 = load(base + 40); n1 = load(base + 48); }
+    NPD_HD void slide_ask() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // one 16-byte load (one transaction per lane) instead of two of eight with a clamp each; what lies behind the stream's end is never consumed
+        uint32_t at = base + 40;
+        if (at > len) at = len;
+        const Pair64 v = *reinterpret_cast<const Pair64*>(src + at);
+        n0 = v.a;
+        n1 = v.b;
+#else
+        n0 = load(base + 40);
+        n1 = load(base + 48);
+#endif
+    }
     NPD_HD void slide() { slide_take(); slide_ask(); }
     NPD_HD uint32_t peek(uint32_t n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
     NPD_HD void drop(uint32_t n) { buf >>= n; cnt -= n; taken += n; }
@@ -235,9 +250,6 @@ NPD_UNROLL
     }
     return w;
 }
-
-struct __attribute__((packed, aligned(1))) Pair64 { uint64_t a, b; };
-NPD_HD void store16(uint8_t* p, uint64_t a, uint64_t b) { *reinterpret_cast<Pair64*>(p) = Pair64{a, b}; }
 
 // 32 bytes at p, of which the caller uses the first n <= 32.  On the device the output buffer has slack behind its last block, so whole
 // words are read whatever n is (the second pair only when n > 16); the host build never reads at or beyond `limit`.
