@@ -201,6 +201,7 @@ int np1_debug_inflate_lane(const uint8_t* src, uint64_t src_len, uint8_t* dst, u
 int np1_debug_inflate_lds(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) { return debug_inflate_lds<10, 8>(src, src_len, dst, dst_len); }
 int np1_debug_inflate_lds85(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) { return debug_inflate_lds<8, 5>(src, src_len, dst, dst_len); }
 int np1_debug_inflate_lds96(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) { return debug_inflate_lds<9, 6>(src, src_len, dst, dst_len); }
+int np1_debug_inflate_lds75(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) { return debug_inflate_lds<7, 5>(src, src_len, dst, dst_len); }      /* the kernel's default sizes */
 int np1_debug_inflate_lds64(const uint8_t* src, uint64_t src_len, uint8_t* dst, uint64_t dst_len) { return debug_inflate_lds<6, 4>(src, src_len, dst, dst_len); }
 /* test hook: the CRC-32 the BGZF reader / writer compute per block (np_crc32.h: carry-less-multiply folding) */
 uint32_t np1_debug_crc32(const uint8_t* src, uint64_t len) { return np::crc32_block(src, (size_t)len); }

@@ -7,7 +7,7 @@
 //     write one byte outside either is an AddressSanitizer report (blocks of a BGZF window lie back to back and are decoded by different
 //     threads: a write past a block's end lands in its neighbour);
 //   * the same streams damaged (bit flips, truncation) must be refused or decoded, never touch a byte outside.
-// usage: inflate_fuzz <host|lane|lds|lds96|lds85|lds64> <iterations> <seed>      exit code 0 = every intact stream decoded to its data
+// usage: inflate_fuzz <host|lane|lds|lds96|lds85|lds75|lds64> <iterations> <seed>      exit code 0 = every intact stream decoded to its data
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,7 +49,7 @@ static std::vector<uint8_t> raw_deflate(const std::vector<uint8_t>& d, int level
 int main(int argc, char** argv) {
     if (argc < 4) { fprintf(stderr, "usage: inflate_fuzz <host|lane> <iterations> <seed>\n"); return 2; }
     bool (*decode)(const uint8_t*, size_t, uint8_t*, size_t) = strcmp(argv[1], "lane") == 0 ? decode_lane : strcmp(argv[1], "lds") == 0 ? decode_lds<10, 8>
-                                                               : strcmp(argv[1], "lds96") == 0 ? decode_lds<9, 6> : strcmp(argv[1], "lds85") == 0 ? decode_lds<8, 5> : strcmp(argv[1], "lds64") == 0 ? decode_lds<6, 4> : np::inflate_raw;
+                                                               : strcmp(argv[1], "lds96") == 0 ? decode_lds<9, 6> : strcmp(argv[1], "lds75") == 0 ? decode_lds<7, 5> : strcmp(argv[1], "lds85") == 0 ? decode_lds<8, 5> : strcmp(argv[1], "lds64") == 0 ? decode_lds<6, 4> : np::inflate_raw;
     const int iters = atoi(argv[2]);
     std::mt19937_64 rng((uint64_t)atoll(argv[3]));
     static const int strategies[5] = {Z_DEFAULT_STRATEGY, Z_FILTERED, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED};

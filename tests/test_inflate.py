@@ -129,11 +129,11 @@ def test_lane_decoder_multi_block_streams_and_damage(lane_decoder):
     test_damaged_or_mismatched_streams_are_never_wrong()
 
 
-@pytest.fixture(params=["np1_debug_inflate_lds", "np1_debug_inflate_lds96", "np1_debug_inflate_lds85", "np1_debug_inflate_lds64"])
+@pytest.fixture(params=["np1_debug_inflate_lds", "np1_debug_inflate_lds75", "np1_debug_inflate_lds64"])
 def lds_decoder(request, monkeypatch):
     """the LDS-table lane decoder of the device-side ingest (nextpolish_amd/csrc/np_inflate_lds.h: the same C++ the GPU lanes run, over a plain
-    array here) with 10 / 8-bit, 9 / 6-bit and 8 / 5-bit primary tables (the latter two are kernels' sizes) and with 6 / 4-bit ones, which send most codes down the
-    canonical long-code path"""
+    array here) with 10 / 8-bit primary tables, with the 7 / 5-bit ones the kernel runs with by default, and with 6 / 4-bit ones, which send most codes down
+    the canonical long-code path"""
     import sys
     monkeypatch.setattr(sys.modules[__name__], "DECODER", request.param)
 
@@ -148,7 +148,7 @@ def test_lds_decoder_multi_block_streams_and_damage(lds_decoder):
     test_damaged_or_mismatched_streams_are_never_wrong()
 
 
-@pytest.mark.parametrize("decoder", ["host", "host-plain", "lane", "lds", "lds96", "lds85", "lds64"])
+@pytest.mark.parametrize("decoder", ["host", "host-plain", "lane", "lds", "lds75", "lds64"])
 def test_decoders_never_touch_a_byte_outside_their_buffers(decoder):
     """tests/model/inflate_fuzz.cpp under AddressSanitizer + UBSan: streams decoded from / into heap buffers of exactly their size, intact
     and damaged; includes the constructed case (1-4 literals, then a 258-byte far match ending 10-13 bytes before the end of the block) on
