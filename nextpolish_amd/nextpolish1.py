@@ -145,7 +145,7 @@ def polish_batched(args, cfg, names, device, emit, shared=(), polished_seqs=()):
     names = [n for n in names if n in lengths]
     if shared:
         from nextpolish_amd.device import Context
-        token = tile_run_token(args.genome, args.bam_sgs, cfg, args.tile_bp, args.tile_halo, args.world)
+        token = tile_run_token(args.genome, args.bam_sgs, cfg, args.tile_bp, args.tile_halo, args.world, getattr(args, "launch_id", ""))
         stale = os.path.join(args.tile_dir, "FAILED.%d" % args.rank)
         if os.path.exists(stale):
             os.remove(stale)
@@ -267,7 +267,7 @@ def device_tile_pieces(ctx, fasta, bam, cfg, tile_bp, halo_bp):
     return pieces
 
 
-def tile_run_token(genome, bam, cfg, tile_bp, halo_bp, world):
+def tile_run_token(genome, bam, cfg, tile_bp, halo_bp, world, launch_id=""):
     """what the pieces of one launch have in common and the leftovers of another launch have not: the input files as they are now (size,
     mtime), every parameter of the task and the tiling.  Pieces carry it in their first line; the joiner takes no piece without it (a
     directory left by a killed run on other inputs or parameters is not stitched into this run's output: ADVICE r4)."""
@@ -282,6 +282,10 @@ def tile_run_token(genome, bam, cfg, tile_bp, halo_bp, world):
         if isinstance(v, (int, float)):
             h.update(("%s=%r;" % (f, v)).encode())
     h.update(("%d:%d:%d" % (tile_bp, halo_bp, world)).encode())
+    # --launch_id: what the ranks of ONE launch share and a re-run of the same command does not (the token above is a pure function
+    # of inputs and parameters, so a rank of the re-run that reaches the join before its slower peer has restarted would take the peer's
+    # FAILED marker -- or a piece -- of the failed launch for this launch's)
+    h.update(("|" + str(launch_id)).encode())
     return h.hexdigest()
 
 
@@ -493,6 +497,8 @@ def build_parser():
     gpu.add_argument("--tile_halo", type=parse_num_unit, default=1000, help="bases of halo on each side of a tile (doubled when too small)")
     gpu.add_argument("--tile_dir", type=str, default="",
                      help="--world > 1 with --tile_bp: directory all ranks see, where the pieces of contigs longer than --tile_bp meet (default: <genome>.np1_tiles)")
+    gpu.add_argument("--launch_id", default="", help="any string all ranks of ONE launch share (e.g. the scheduler's job id): pieces and failure markers of another "
+                                                      "launch in --tile_dir, even of the same command run again, are then never taken for this launch's")
     gpu.add_argument("--tile_wait", type=int, default=7200,
                      help="seconds the joiner of such a contig waits for a piece of another rank (a rank that fails says so and ends the wait at once)")
     return p

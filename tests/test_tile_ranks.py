@@ -98,6 +98,7 @@ def test_run_token_follows_inputs_and_parameters(tmp_path):
     cfg = nat.default_config()
     t1 = np1.tile_run_token(fa, bam, cfg, 1000, 50, 2)
     assert t1 == np1.tile_run_token(fa, bam, cfg, 1000, 50, 2)
+    assert t1 != np1.tile_run_token(fa, bam, cfg, 1000, 50, 2, launch_id="job-17")      # the same command launched again under another id
     assert t1 != np1.tile_run_token(fa, bam, cfg, 1000, 50, 3) and t1 != np1.tile_run_token(fa, bam, cfg, 2000, 50, 2)
     cfg.trim_len_edge = 3
     assert t1 != np1.tile_run_token(fa, bam, cfg, 1000, 50, 2)
