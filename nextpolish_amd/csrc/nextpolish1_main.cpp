@@ -123,5 +123,9 @@ int main(int argc, char* argv[]) {
     config_destory(cfg);
     stamp(stderr);
     fprintf(stderr, "total time:%ds\n", (int)(time(nullptr) - t_start));
-    return 0;
+    // Everything this process had to say is written; what is left is the HIP runtime taking itself apart and giving back device memory the
+    // driver reclaims anyway -- 0.16 s of a 0.9 s run of 400 Mb (tests/tools/r6_cli_timeline.py).  Leave without it.
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);
 }
