@@ -314,7 +314,8 @@ uint64_t np1_stream_upload_bytes(np1_stream* st) {
 
 int np1_stream_pin(np1_stream* st) {
     if (!st) return -1;
-    if (st->pinned) return 0;
+    std::lock_guard<std::mutex> one(st->pin_mu);
+    if (st->pinned.load(std::memory_order_acquire)) return 0;
     stream_facts(st);
     np::ReadStream& s = st->s;
     // every array fill_batch may upload; what is small enough for the runtime's own staging stays where it is (np_hostcopy.h)
@@ -368,7 +369,7 @@ int np1_stream_pin(np1_stream* st) {
         });
         std::sort(st->arena_map.begin(), st->arena_map.end());
     }
-    st->pinned = true;
+    st->pinned.store(true, std::memory_order_release);
     return 0;
 }
 
@@ -1181,13 +1182,17 @@ int64_t np1_batch_device_bytes(np1_batch* b) { return b ? (int64_t)b->device_byt
 }  // extern "C"
 
 void np1_stream_unpin(np1_stream* st) {
-    if (!st || !st->pinned) return;
-    (void)hipDeviceSynchronize();      // copies out of the arena may still be in flight on any lane's stream
+    if (!st) return;
+    std::lock_guard<std::mutex> one(st->pin_mu);
+    if (!st->pinned.load(std::memory_order_acquire)) return;
+    // copies out of the arena may still be in flight on any lane's stream, of any device this process uploads to: every stream of the
+    // library's registry is waited for (np_devalloc.h), not just the calling thread's current device
+    npalloc::quiesce();
     if (st->arena) (void)npalloc::host_free(st->arena);
     st->arena = nullptr;
     st->arena_bytes = 0;
     st->arena_map.clear();
-    st->pinned = false;
+    st->pinned.store(false, std::memory_order_release);
 }
 
 // ---- internal accessors used by the drop-in entry points (np1_abi.cpp) for the -debug trace list

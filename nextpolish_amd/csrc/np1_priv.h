@@ -5,6 +5,9 @@
 #include <utility>
 #include <vector>
 
+#include <atomic>
+#include <mutex>
+
 #include "np_stream.h"
 
 struct np1_stream {
@@ -12,12 +15,13 @@ struct np1_stream {
     // np1_stream_pin: every array an upload moves (above the size the runtime stages itself) has a copy in ONE page-locked arena from
     // hipHostMalloc, and uploads read from there -- asynchronous at full PCIe rate.  (Rounds 2-4 registered the std::vector storage
     // itself with hipHostRegister; round 5 found the GPU faulting on heap addresses and took the GPU off the heap: DESIGN.md section 12.)
-    bool pinned = false;
+    std::atomic<bool> pinned{false};      // set (release) once the arena and its map are complete, read (acquire) by every upload: ADVICE r5
+    std::mutex pin_mu;                    // one np1_stream_pin / np1_stream_unpin at a time
     void* arena = nullptr;
     size_t arena_bytes = 0;
     std::vector<std::pair<const void*, const void*>> arena_map;   // (array, its copy in the arena), sorted by array address
     const void* up(const void* p) const {      // where an upload of array p reads from
-        if (!pinned || arena_map.empty()) return p;
+        if (!pinned.load(std::memory_order_acquire) || arena_map.empty()) return p;
         size_t lo = 0, hi = arena_map.size();
         while (lo < hi) { const size_t mid = (lo + hi) / 2; if (arena_map[mid].first < p) lo = mid + 1; else hi = mid; }
         return (lo < arena_map.size() && arena_map[lo].first == p) ? arena_map[lo].second : p;

@@ -14,7 +14,7 @@
 //
 // So: the GPU never touches memory it did not get from hipHostMalloc.  Copies whose host side is page-locked memory of ours (allocated through
 // npalloc::host_malloc, which keeps the list) go straight to hipMemcpyAsync and are asynchronous.  Everything else:
-//   H2D  the bytes are taken at the time of the call (small: by the runtime's staging; above 256 KiB: through a ring of our own pinned
+//   H2D  the bytes are taken at the time of the call through rings of our own pinned slots (up to 256 KiB: one small slot; above: 8 MiB
 //        slots, the host memcpy of chunk k + 1 overlapping the DMA of chunk k) -- the source may be freed as soon as the call returns;
 //   D2H  small: the runtime's staging (the bytes arrive with the next synchronisation of the stream, as before); above 256 KiB: through the
 //        ring, complete when the call returns.
@@ -40,8 +40,10 @@ constexpr int kSlots = 16;      // (round 6: 6 -> 16: the from-files ingest read
 
 struct Slot { void* p = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
 
-class Ring {      // one per device and library, made at the first large pageable copy
+class Ring {      // one per device, library and slot size, made at the first pageable copy that needs it
 public:
+    Ring(size_t slot_bytes, int max_slots) : slot_bytes_(slot_bytes), max_slots_(max_slots) {}
+    size_t slot_bytes() const { return slot_bytes_; }
     // A slot to fill.  Blocks only while all kSlots exist and other threads hold them.  (Round 6: a new slot is allocated OUTSIDE the lock --
     // hipHostMalloc can take milliseconds and used to stall every release() behind it; and a failed allocation only fails the call when
     // there is no slot at all to wait for.)
@@ -67,11 +69,11 @@ private:
         std::unique_lock<std::mutex> g(mu_);
         for (;;) {
             if (!free_.empty() && !free_.front().pending) break;                 // an idle slot: take it
-            if (made_ + making_ < kSlots && !alloc_failed_) {                     // room for one more: make it, unlocked
+            if (made_ + making_ < max_slots_ && !alloc_failed_) {                     // room for one more: make it, unlocked
                 ++making_;
                 g.unlock();
                 Slot s;
-                bool ok = npalloc::host_malloc(&s.p, kSlotBytes, hipHostMallocPortable) == hipSuccess;
+                bool ok = npalloc::host_malloc(&s.p, slot_bytes_, hipHostMallocPortable) == hipSuccess;
                 if (ok && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { (void)npalloc::host_free(s.p); ok = false; }
                 g.lock();
                 --making_;
@@ -91,6 +93,8 @@ private:
         if (out->pending) { (void)hipEventSynchronize(out->ev); out->pending = false; }
         return true;
     }
+    const size_t slot_bytes_;
+    const int max_slots_;
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<Slot> free_;
@@ -98,6 +102,8 @@ private:
     bool alloc_failed_ = false;
 };
 
+constexpr size_t kSmallSlotBytes = kDirectMax;      // small pageable H2D copies (round 6): their own ring of small slots
+constexpr int kSmallSlots = 32;
 struct Rings { std::mutex mu; std::map<int, Ring*> of; };      // (never destroyed: the runtime may already be gone when static destructors run)
 inline Rings& rings() { static Rings* r = new Rings(); return *r; }
 inline void settle_all(hipStream_t) {
@@ -105,19 +111,37 @@ inline void settle_all(hipStream_t) {
     { Rings& R = rings(); std::lock_guard<std::mutex> g(R.mu); for (auto& kv : R.of) all.push_back(kv.second); }
     for (Ring* r : all) r->settle();
 }
-inline Ring& ring() {
+inline Ring& ring(bool small = false) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     Rings& R = rings();
     std::lock_guard<std::mutex> g(R.mu);
-    Ring*& r = R.of[dev];
-    if (!r) { r = new Ring(); npalloc::stream_destroy_hook() = settle_all; }
+    Ring*& r = R.of[2 * dev + (small ? 1 : 0)];
+    if (!r) { r = small ? new Ring(kSmallSlotBytes, kSmallSlots) : new Ring(kSlotBytes, kSlots); npalloc::stream_destroy_hook() = settle_all; }
     return *r;
 }
 
 inline hipError_t h2d(void* dst, const void* src, size_t bytes, hipStream_t q) {
     if (!bytes) return hipSuccess;
-    if (bytes <= kDirectMax || npalloc::is_pinned(src, bytes)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, q);
+    if (npalloc::is_pinned(src, bytes)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, q);
+    if (bytes <= kDirectMax) {
+        // Small and pageable.  ROCm 7.2 stages such a copy through a pinned buffer of its own while the call runs -- but where "small" ends is
+        // the runtime's business (and an environment variable's), and callers free the source as soon as this returns: the bytes go through a
+        // slot of ours, taken now.  Only without any pinned memory to be had is the copy left to the runtime, and waited for.
+        Ring& S = ring(true);
+        Slot s;
+        if (!S.acquire(&s)) {
+            const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, q);
+            return e != hipSuccess ? e : hipStreamSynchronize(q);
+        }
+        memcpy(s.p, src, bytes);
+        hipError_t e = hipMemcpyAsync(dst, s.p, bytes, hipMemcpyHostToDevice, q);
+        if (e == hipSuccess) e = hipEventRecord(s.ev, q);
+        s.pending = e == hipSuccess;
+        if (e != hipSuccess) (void)hipStreamSynchronize(q);
+        S.release(s);
+        return e;
+    }
     Ring& R = ring();
     for (size_t off = 0; off < bytes;) {
         const size_t n = bytes - off < kSlotBytes ? bytes - off : kSlotBytes;
