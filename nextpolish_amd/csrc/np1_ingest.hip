@@ -265,6 +265,21 @@ struct ScatterOut {
     uint32_t* cigar; uint8_t* seq; uint8_t* mapq; int32_t* isize; uint64_t* qualoff; uint8_t* qual;
 };
 
+// n bytes between two byte-aligned places, 16 at a time (round 6: word loads and BYTE stores before -- 75 store instructions per record, every one
+// a transaction per lane; global loads and stores of any width take any alignment on this device, as the block decoder's do)
+struct __attribute__((packed, aligned(1))) Bytes16 { uint64_t a, b; };
+__device__ __forceinline__ void copy_unaligned(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n) {
+    typedef uint64_t __attribute__((aligned(1))) u64u;
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    typedef uint16_t __attribute__((aligned(1))) u16u;
+    uint32_t i = 0;
+    for (; i + 16 <= n; i += 16) *reinterpret_cast<Bytes16*>(dst + i) = *reinterpret_cast<const Bytes16*>(src + i);
+    if (n & 8u) { *reinterpret_cast<u64u*>(dst + i) = *reinterpret_cast<const u64u*>(src + i); i += 8; }
+    if (n & 4u) { *reinterpret_cast<u32u*>(dst + i) = *reinterpret_cast<const u32u*>(src + i); i += 4; }
+    if (n & 2u) { *reinterpret_cast<u16u*>(dst + i) = *reinterpret_cast<const u16u*>(src + i); i += 2; }
+    if (n & 1u) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void k_rec_scatter(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ rec_seg,
                                                      const Segment* __restrict__ segs, uint64_t n_rec, const uint32_t* __restrict__ keep,
                                                      const uint32_t* __restrict__ kidx, const uint64_t* __restrict__ cig_at, const uint64_t* __restrict__ seq_at,
@@ -288,19 +303,14 @@ __global__ __launch_bounds__(256) void k_rec_scatter(const uint8_t* __restrict__
     for (uint32_t i = 0; i < n_cigar; ++i) o.cigar[ca + i] = ld32(c + 4 * i);
     const uint8_t* sq = c + 4 * n_cigar;
     const uint32_t sb = (uint32_t)((l_seq + 1) / 2);
-    uint32_t i = 0;
-    for (; i + 4 <= sb; i += 4) {   // the pool is only byte aligned per record: assemble words, store bytes
-        const uint32_t w = ld32(sq + i);
-        o.seq[sa + i] = (uint8_t)w; o.seq[sa + i + 1] = (uint8_t)(w >> 8); o.seq[sa + i + 2] = (uint8_t)(w >> 16); o.seq[sa + i + 3] = (uint8_t)(w >> 24);
-    }
-    for (; i < sb; ++i) o.seq[sa + i] = sq[i];
+    copy_unaligned(o.seq + sa, sq, sb);      // (the pool is only byte aligned per record)
     if (with_qual) {
         o.mapq[j] = p[13];
         o.isize[j] = (int32_t)ld32(p + 32);
         const uint64_t qa = qual_at[r];
         o.qualoff[j] = qa;
         const uint8_t* ql = sq + sb;
-        for (uint32_t t = 0; t < (uint32_t)l_seq; ++t) o.qual[qa + t] = ql[t];
+        copy_unaligned(o.qual + qa, ql, (uint32_t)l_seq);
     }
 }
 
