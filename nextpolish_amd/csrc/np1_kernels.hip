@@ -112,14 +112,23 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_final(F f, uint64_t n, const ui
                                                        OutT* __restrict__ out, const uint64_t* __restrict__ total) {
     __shared__ uint64_t sh[SCAN_T];
     uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
-    // thread t owns SCAN_ITEMS consecutive elements
+    // thread t owns SCAN_ITEMS consecutive elements; they come in COALESCED through a padded tile in LDS (round 6: read from its own 64 bytes,
+    // every load instruction of a wave touched 64 different lines; every element of every scan of this file is below 2^32)
+    __shared__ uint32_t tile[SCAN_TILE + SCAN_TILE / 32];
     uint64_t first = base + (uint64_t)threadIdx.x * SCAN_ITEMS;
     uint64_t v[SCAN_ITEMS];
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        uint64_t i = first + k;
-        v[k] = i < n ? f(i) : 0;
+        const uint32_t j = (uint32_t)k * SCAN_T + threadIdx.x;
+        const uint64_t i = base + j;
+        tile[j + (j >> 5)] = i < n ? (uint32_t)f(i) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t j = threadIdx.x * SCAN_ITEMS + k;
+        v[k] = tile[j + (j >> 5)];
         acc += v[k];
     }
     sh[threadIdx.x] = acc;
@@ -131,11 +140,29 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_final(F f, uint64_t n, const ui
         __syncthreads();
     }
     uint64_t run = tile_offs[blockIdx.x] + sh[threadIdx.x] - acc;
+    if constexpr (sizeof(OutT) == 4) {
+        // Round 6: the results leave COALESCED.  A thread owns 16 consecutive elements, so stored from its registers every store instruction of a
+        // wave wrote 4 bytes into each of 64 different lines; through a (padded) tile in LDS a wave writes 256 contiguous bytes per instruction.
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        uint64_t i = first + k;
-        if (i < n) out[i] = (OutT)run;
-        run += v[k];
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            const uint32_t j = threadIdx.x * SCAN_ITEMS + k;
+            tile[j + (j >> 5)] = (uint32_t)run;      // (everybody has read its inputs out of the tile: the barriers of the block scan lie between)
+            run += v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            const uint32_t j = (uint32_t)k * SCAN_T + threadIdx.x;
+            const uint64_t i = base + j;
+            if (i < n) out[i] = (OutT)tile[j + (j >> 5)];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            uint64_t i = first + k;
+            if (i < n) out[i] = (OutT)run;
+            run += v[k];
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (OutT)*total;
 }
